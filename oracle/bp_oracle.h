@@ -1,0 +1,95 @@
+/* ORACLE -- TEST INFRASTRUCTURE ONLY.
+ *
+ * CPU restatement (plain C) of the reference's range-proof verification path
+ * and of the arithmetic it calls.  It is the checker for the HIP engine and the
+ * "port" CPU baseline of bench.py.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load liboracle.so; the product
+ * (bulletproofs_amd / libbpgpu.so) never does.
+ *
+ * Pinning: checked against the reference's 16 golden proofs
+ * (/root/reference/tests/range_proof.rs:16-95 -> tests/golden/rangeproof_v1.json),
+ * the Merlin and generator known-answer values of SURVEY.md Appendix A, and an
+ * independent pure-Python twin (oracle/py/bp_twin.py).  The reference itself is
+ * Rust with un-vendored dependencies (curve25519-dalek ^2, merlin ^2, sha3 0.8:
+ * Cargo.toml:21-31) and cannot be built here, so there is no oracle/_ref.
+ *
+ * Error codes mirror ProofError (/root/reference/src/errors.rs:12-54).
+ */
+#ifndef BP_ORACLE_H
+#define BP_ORACLE_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORACLE_OK 0
+#define ORACLE_ERR_VERIFICATION 1
+#define ORACLE_ERR_FORMAT 2
+#define ORACLE_ERR_INVALID_BITSIZE 3
+#define ORACLE_ERR_INVALID_GENERATORS_LENGTH 4
+
+typedef struct oracle_gens oracle_gens;
+
+/* BulletproofGens::new (src/generators.rs:157-204) + PedersenGens::default (44-53) */
+oracle_gens *oracle_gens_new(size_t gens_capacity, size_t party_capacity);
+void oracle_gens_free(oracle_gens *g);
+/* compressed encodings, party-major: G[party*gens_capacity + i] */
+void oracle_gens_export(const oracle_gens *g, uint8_t *G_out, uint8_t *H_out, uint8_t B[32], uint8_t B_blinding[32]);
+
+/* group / hash primitives */
+int oracle_point_decompress_ok(const uint8_t in[32]);
+void oracle_from_uniform_bytes(const uint8_t in[64], uint8_t out[32]);
+void oracle_scalar_from_wide(const uint8_t in[64], uint8_t out[32]);
+void oracle_scalar_mul(const uint8_t a[32], const uint8_t b[32], uint8_t out[32]);
+void oracle_scalar_invert(const uint8_t a[32], uint8_t out[32]);
+void oracle_merlin_kat(const uint8_t *label, size_t label_len, const char *msg_label,
+                       const uint8_t *msg, size_t msg_len, const char *ch_label, uint8_t *out, size_t out_len);
+void oracle_shake256(const uint8_t *in, size_t n, uint8_t *out, size_t out_len);
+void oracle_sha3_512(const uint8_t *in, size_t n, uint8_t out[64]);
+
+/* vartime_multiscalar_mul on compressed inputs; out = compress(sum).
+ * returns 1 when some point fails to decode (the Option::None case), else 0.
+ * algo: 0 = reference split (Straus < 190 <= Pippenger), 1 = Straus, 2 = Pippenger. */
+int oracle_msm(size_t n, const uint8_t *scalars, const uint8_t *points, int algo, uint8_t out[32]);
+uint64_t oracle_last_msm_ops(void);
+
+/* verify_multiple_with_rng (src/range_proof/mod.rs:345-452).
+ * rng64: the 64 bytes the rng would yield to Scalar::random for the batching
+ * challenge c (mod.rs:396).  msm_out (optional) receives compress(mega_check).
+ * Returns ORACLE_OK or an ORACLE_ERR_* code. */
+int oracle_verify(const oracle_gens *g, const uint8_t *proof, size_t proof_len,
+                  const uint8_t *commitments, size_t m, size_t n,
+                  const uint8_t *label, size_t label_len, const uint8_t rng64[64],
+                  uint8_t msm_out[32]);
+/* same transcript replay + scalar assembly, but returns the MSM terms instead:
+ * scalars_out / points_out: N x 32 bytes, N = 2nm + 2lg(nm) + m + 6, order of mod.rs:422-443 */
+int oracle_verify_terms(const oracle_gens *g, const uint8_t *proof, size_t proof_len,
+                        const uint8_t *commitments, size_t m, size_t n,
+                        const uint8_t *label, size_t label_len, const uint8_t rng64[64],
+                        uint8_t *scalars_out, uint8_t *points_out, size_t *n_terms);
+
+/* Non-constant-time prover used only to synthesise inputs
+ * (prove_multiple_with_rng, src/range_proof/mod.rs:234-288; party.rs; dealer.rs;
+ * inner_product_proof.rs:38-193).  Randomness = SHAKE256(seed) stream.
+ * proof_out: 32*(9+2lg(nm)) bytes; commitments_out: m*32 bytes. */
+int oracle_prove(const oracle_gens *g, const uint64_t *values, const uint8_t *blindings, size_t m, size_t n,
+                 const uint8_t *label, size_t label_len, const uint8_t *seed, size_t seed_len,
+                 uint8_t *proof_out, uint8_t *commitments_out);
+
+/* Batch drivers (independent proofs, equal shape), `threads` worker threads.
+ * verdicts[i] = error code.  Returns wall seconds. */
+double oracle_verify_batch(const oracle_gens *g, size_t nbatch, const uint8_t *proofs, size_t proof_len,
+                           const uint8_t *commitments, size_t m, size_t n,
+                           const uint8_t *label, size_t label_len, const uint8_t *rng64s,
+                           uint8_t *verdicts, uint8_t *msm_outs, int threads);
+double oracle_prove_batch(const oracle_gens *g, size_t nbatch, const uint64_t *values, const uint8_t *blindings,
+                          size_t m, size_t n, const uint8_t *label, size_t label_len,
+                          const uint8_t *seed, size_t seed_len, uint8_t *proofs_out, uint8_t *commitments_out,
+                          int threads);
+double oracle_msm_batch(size_t nbatch, size_t n, const uint8_t *scalars, const uint8_t *points, int algo,
+                        uint8_t *outs, uint8_t *status, int threads);
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,159 @@
+"""ctypes loader for liboracle.so (the plain-C CPU restatement).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "liboracle.so")
+
+ERR_NAMES = {0: "Ok", 1: "VerificationError", 2: "FormatError", 3: "InvalidBitsize",
+             4: "InvalidGeneratorsLength", 5: "InvalidAggregation"}
+
+
+def build(force=False):
+    srcs = [os.path.join(_HERE, "c", f) for f in os.listdir(os.path.join(_HERE, "c"))] + \
+           [os.path.join(_HERE, "bp_oracle.h"), os.path.join(_HERE, "Makefile")]
+    stale = (not os.path.exists(_SO)) or any(os.path.getmtime(s) > os.path.getmtime(_SO) for s in srcs)
+    if force or stale:
+        subprocess.check_call(["make", "-C", _HERE, "-B", "liboracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        build()
+    L = C.CDLL(_SO)
+    u8p, sz, vp = C.c_char_p, C.c_size_t, C.c_void_p
+    L.oracle_gens_new.restype = vp
+    L.oracle_gens_new.argtypes = [sz, sz]
+    L.oracle_gens_free.argtypes = [vp]
+    L.oracle_gens_export.argtypes = [vp, u8p, u8p, u8p, u8p]
+    L.oracle_point_decompress_ok.argtypes = [u8p]
+    L.oracle_from_uniform_bytes.argtypes = [u8p, u8p]
+    L.oracle_scalar_from_wide.argtypes = [u8p, u8p]
+    L.oracle_scalar_mul.argtypes = [u8p, u8p, u8p]
+    L.oracle_scalar_invert.argtypes = [u8p, u8p]
+    L.oracle_merlin_kat.argtypes = [u8p, sz, u8p, u8p, sz, u8p, u8p, sz]
+    L.oracle_shake256.argtypes = [u8p, sz, u8p, sz]
+    L.oracle_sha3_512.argtypes = [u8p, sz, u8p]
+    L.oracle_msm.argtypes = [sz, u8p, u8p, C.c_int, u8p]
+    L.oracle_last_msm_ops.restype = C.c_uint64
+    L.oracle_verify.argtypes = [vp, u8p, sz, u8p, sz, sz, u8p, sz, u8p, u8p]
+    L.oracle_verify_terms.argtypes = [vp, u8p, sz, u8p, sz, sz, u8p, sz, u8p, u8p, u8p, C.POINTER(sz)]
+    L.oracle_prove.argtypes = [vp, C.POINTER(C.c_uint64), u8p, sz, sz, u8p, sz, u8p, sz, u8p, u8p]
+    L.oracle_verify_batch.restype = C.c_double
+    L.oracle_verify_batch.argtypes = [vp, sz, u8p, sz, u8p, sz, sz, u8p, sz, u8p, u8p, u8p, C.c_int]
+    L.oracle_prove_batch.restype = C.c_double
+    L.oracle_prove_batch.argtypes = [vp, sz, C.POINTER(C.c_uint64), u8p, sz, sz, u8p, sz, u8p, sz, u8p, u8p, C.c_int]
+    L.oracle_msm_batch.restype = C.c_double
+    L.oracle_msm_batch.argtypes = [sz, sz, u8p, u8p, C.c_int, u8p, u8p, C.c_int]
+    _lib = L
+    return L
+
+
+def proof_len(n, m):
+    return 32 * (9 + 2 * ((n * m).bit_length() - 1))
+
+
+def n_terms(n, m):
+    return 2 * n * m + 2 * ((n * m).bit_length() - 1) + m + 6
+
+
+class Gens:
+    """BulletproofGens::new(gens_capacity, party_capacity) + PedersenGens::default()."""
+
+    def __init__(self, gens_capacity, party_capacity):
+        self.gens_capacity, self.party_capacity = gens_capacity, party_capacity
+        self.h = lib().oracle_gens_new(gens_capacity, party_capacity)
+
+    def __del__(self):
+        try:
+            lib().oracle_gens_free(self.h)
+        except Exception:
+            pass
+
+    def export(self):
+        tot = self.gens_capacity * self.party_capacity
+        G = C.create_string_buffer(32 * tot)
+        H = C.create_string_buffer(32 * tot)
+        B = C.create_string_buffer(32)
+        Bb = C.create_string_buffer(32)
+        lib().oracle_gens_export(self.h, G, H, B, Bb)
+        return G.raw, H.raw, B.raw, Bb.raw
+
+
+def msm(scalars, points, algo=0):
+    """scalars/points: bytes of n*32 each. Returns (status, 32-byte result)."""
+    n = len(scalars) // 32
+    assert len(points) == 32 * n
+    out = C.create_string_buffer(32)
+    st = lib().oracle_msm(n, scalars, points, algo, out)
+    return st, out.raw
+
+
+def verify(gens, proof, commitments, n, label, rng64):
+    m = len(commitments) // 32
+    out = C.create_string_buffer(32)
+    rc = lib().oracle_verify(gens.h, proof, len(proof), commitments, m, n, label, len(label), rng64, out)
+    return rc, out.raw
+
+
+def verify_terms(gens, proof, commitments, n, label, rng64):
+    m = len(commitments) // 32
+    N = n_terms(n, m) if n * m > 0 else 0
+    sc = C.create_string_buffer(32 * max(N, 1))
+    pt = C.create_string_buffer(32 * max(N, 1))
+    nt = C.c_size_t(0)
+    rc = lib().oracle_verify_terms(gens.h, proof, len(proof), commitments, m, n, label, len(label), rng64,
+                                   sc, pt, C.byref(nt))
+    if rc:
+        return rc, b"", b""
+    return 0, sc.raw[:32 * nt.value], pt.raw[:32 * nt.value]
+
+
+def prove(gens, values, blindings, n, label, seed):
+    m = len(values)
+    vals = (C.c_uint64 * m)(*values)
+    proof = C.create_string_buffer(proof_len(n, m))
+    com = C.create_string_buffer(32 * m)
+    rc = lib().oracle_prove(gens.h, vals, blindings, m, n, label, len(label), seed, len(seed), proof, com)
+    if rc:
+        raise ValueError("oracle_prove failed: %s" % ERR_NAMES.get(rc, rc))
+    return proof.raw, com.raw
+
+
+def prove_batch(gens, values, blindings, m, n, label, seed, threads=1):
+    nb = len(values) // m
+    vals = (C.c_uint64 * len(values))(*values)
+    pl = proof_len(n, m)
+    proofs = C.create_string_buffer(pl * nb)
+    com = C.create_string_buffer(32 * m * nb)
+    lib().oracle_prove_batch(gens.h, nb, vals, blindings, m, n, label, len(label), seed, len(seed), proofs, com, threads)
+    return proofs.raw, com.raw
+
+
+def verify_batch(gens, proofs, commitments, m, n, label, rng64s, threads=1):
+    pl = proof_len(n, m)
+    nb = len(proofs) // pl
+    verdicts = C.create_string_buffer(nb)
+    outs = C.create_string_buffer(32 * nb)
+    secs = lib().oracle_verify_batch(gens.h, nb, proofs, pl, commitments, m, n, label, len(label), rng64s,
+                                     verdicts, outs, threads)
+    return secs, verdicts.raw, outs.raw
+
+
+def msm_batch(nbatch, n, scalars, points, algo=0, threads=1):
+    outs = C.create_string_buffer(32 * nbatch)
+    status = C.create_string_buffer(nbatch)
+    secs = lib().oracle_msm_batch(nbatch, n, scalars, points, algo, outs, status, threads)
+    return secs, outs.raw, status.raw

@@ -1,0 +1,178 @@
+"""CPU tests pinning the oracle (C restatement + Python twin) against the
+reference's golden vectors (/root/reference/tests/range_proof.rs:16-95, fixture
+tests/golden/rangeproof_v1.json) and the known-answer values of SURVEY.md
+Appendix A / C."""
+import ctypes as C
+import hashlib
+
+import pytest
+
+import bp_twin as T
+
+C_APPENDIX = 12345678901234567890123456789
+
+
+def test_constants_match_survey_appendix_a():
+    assert T.D == 37095705934669439343138083508754565189542113879843219016388785533085940283555
+    assert T.SQRT_M1 == 19681161376707505956807079304988542015446066515923890162744021073123829784752
+    assert T.INVSQRT_A_MINUS_D == 54469307008909316920995813868745141605393597292927456921205312896311721017578
+    assert T.SQRT_AD_MINUS_ONE == 25063068953384623474111414158702152701244531502492656460079210482610430750235
+    assert T.ONE_MINUS_D_SQ == 1159843021668779879193775521855586647937357759715417654439879720876111806838
+    assert T.D_MINUS_ONE_SQ == 40440834346308536858101042469323190826248399146238708352240133220865137265952
+    assert T.compress(T.BASEPOINT) == T.BASEPOINT_COMPRESSED
+
+
+def test_merlin_kat_twin_and_c(oracle):
+    t = T.Transcript(b"test protocol")
+    t.append_message(b"some label", b"some data")
+    want = "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    assert t.challenge_bytes(b"challenge", 32).hex() == want
+    out = C.create_string_buffer(32)
+    oracle.lib().oracle_merlin_kat(b"test protocol", 13, b"some label", b"some data", 9, b"challenge", out, 32)
+    assert out.raw.hex() == want
+
+
+def test_keccak_against_hashlib(oracle):
+    for n in (0, 1, 71, 72, 73, 135, 136, 137, 500):
+        msg = bytes(range(256)) * 2
+        msg = msg[:n]
+        o64 = C.create_string_buffer(64)
+        oracle.lib().oracle_sha3_512(msg, n, o64)
+        assert o64.raw == hashlib.sha3_512(msg).digest()
+        o = C.create_string_buffer(400)
+        oracle.lib().oracle_shake256(msg, n, o, 400)
+        assert o.raw == hashlib.shake_256(msg).digest(400)
+
+
+def test_pedersen_and_generators(oracle, oracle_gens_64_8):
+    G, H, B, Bb = oracle_gens_64_8.export()
+    assert B.hex() == "e2f2ae0a6abc4e71a884a961c500515f58e30b6aa582dd8db6a65945e08d2d76"
+    assert Bb.hex() == "8c9240b456a9e6dc65c377a1048d745f94a08cdb7f44cbcd7b46f34048871134"
+    bg = T.BulletproofGens(16, 3)
+    for p in range(3):
+        for i in range(16):
+            assert G[32 * (p * 64 + i):32 * (p * 64 + i) + 32] == T.compress(bg.G_vec[p][i])
+            assert H[32 * (p * 64 + i):32 * (p * 64 + i) + 32] == T.compress(bg.H_vec[p][i])
+
+
+def test_golden_proofs_verify_c_oracle(oracle, oracle_gens_64_8, golden):
+    """tests/range_proof.rs:81-93: every golden proof verifies; mega-check encodes to identity."""
+    for case in golden["cases"]:
+        n, m = case["n"], case["m"]
+        for seed in (b"rng-a", b"rng-b"):
+            rng64 = hashlib.shake_256(seed).digest(64)
+            rc, res = oracle.verify(oracle_gens_64_8, bytes.fromhex(case["proof"]), golden["vc_bytes"][:32 * m], n,
+                                    golden["label"], rng64)
+            assert rc == 0 and res == bytes(32), (n, m)
+
+
+def test_golden_proofs_verify_python_twin(golden):
+    bg, pg = T.BulletproofGens(64, 8), T.PedersenGens()
+    vc = [golden["vc_bytes"][32 * j:32 * j + 32] for j in range(8)]
+    for case in golden["cases"]:
+        n, m = case["n"], case["m"]
+        if n * m > 128:
+            continue  # keep the CPU suite quick; the C oracle covers all 16
+        pr = T.RangeProof.from_bytes(bytes.fromhex(case["proof"]))
+        assert T.verify_multiple(pr, bg, pg, T.Transcript(golden["label"]), vc[:m], n, c=C_APPENDIX) == bytes(32)
+
+
+def test_msm_terms_c_equals_twin(oracle, oracle_gens_64_8, golden):
+    bg, pg = T.BulletproofGens(64, 8), T.PedersenGens()
+    rng64 = hashlib.shake_256(b"terms").digest(64)
+    c = int.from_bytes(rng64, "little") % T.L
+    for case in golden["cases"]:
+        n, m = case["n"], case["m"]
+        pr = bytes.fromhex(case["proof"])
+        rc, sc, pt = oracle.verify_terms(oracle_gens_64_8, pr, golden["vc_bytes"][:32 * m], n, golden["label"], rng64)
+        assert rc == 0
+        vcs = [golden["vc_bytes"][32 * j:32 * j + 32] for j in range(m)]
+        ts, tp = T.verification_msm_terms(T.RangeProof.from_bytes(pr), bg, pg, T.Transcript(golden["label"]), vcs, n, c)
+        assert len(ts) == oracle.n_terms(n, m) == len(sc) // 32
+        for i, (s, p) in enumerate(zip(ts, tp)):
+            assert sc[32 * i:32 * i + 32] == s.to_bytes(32, "little")
+            assert pt[32 * i:32 * i + 32] == (p if isinstance(p, bytes) else T.compress(p))
+
+
+def test_survey_appendix_c_negative_vectors(oracle, oracle_gens_64_8, golden):
+    rng64 = C_APPENDIX.to_bytes(64, "little")
+    case = [c for c in golden["cases"] if c["n"] == 8 and c["m"] == 2][0]
+    proof = bytes.fromhex(case["proof"])
+    vc = golden["vc_bytes"]
+    bad = bytearray(proof)
+    bad[128] ^= 1
+    rc, res = oracle.verify(oracle_gens_64_8, bytes(bad), vc[:64], 8, golden["label"], rng64)
+    assert rc == 1 and res.hex() == "1830445a3fd1b8fe4b2d9980c062cd3f5ad9fc31236f5d6a3724a28a6856b429"
+    rc, res = oracle.verify(oracle_gens_64_8, proof, vc[32:64] + vc[:32], 8, golden["label"], rng64)
+    assert rc == 1 and res.hex() == "0a333ed0a6fa3e884490095548f6a8508a2cb44cdea2062e8d0ab36f87d86f21"
+    rc, res = oracle.verify(oracle_gens_64_8, proof, vc[:64], 8, b"other", rng64)
+    assert rc == 1 and res.hex() == "14bbd613d451719a7e0449b5c8bf67b8b1d0a83e25ada7868417a4df58c40f32"
+
+
+def test_error_codes_mirror_proof_error(oracle, oracle_gens_64_8, golden):
+    case = golden["cases"][0]
+    proof = bytes.fromhex(case["proof"])
+    vc = golden["vc_bytes"]
+    z = bytes(64)
+    assert oracle.verify(oracle_gens_64_8, proof[:-1], vc[:32], 8, b"x", z)[0] == 2      # len % 32
+    assert oracle.verify(oracle_gens_64_8, proof[:6 * 32], vc[:32], 8, b"x", z)[0] == 2  # < 7*32
+    assert oracle.verify(oracle_gens_64_8, proof[:-32], vc[:32], 8, b"x", z)[0] == 2     # odd ipp element count
+    nc = bytearray(proof)
+    nc[128:160] = b"\xff" * 32                                                            # non-canonical t_x
+    assert oracle.verify(oracle_gens_64_8, bytes(nc), vc[:32], 8, b"x", z)[0] == 2
+    assert oracle.verify(oracle_gens_64_8, proof, vc[:32], 12, b"x", z)[0] == 3
+    small = oracle.Gens(8, 1)
+    assert oracle.verify(small, proof, vc[:32], 16, b"x", z)[0] == 4
+    assert oracle.verify(small, proof, vc[:64], 8, b"x", z)[0] == 4
+    assert oracle.verify(oracle_gens_64_8, proof, vc[:32], 16, golden["label"], z)[0] == 1  # n*m != 2^lg
+    ident = bytearray(proof)
+    ident[0:32] = bytes(32)                                                               # A = identity encoding
+    assert oracle.verify(oracle_gens_64_8, bytes(ident), vc[:32], 8, golden["label"], z)[0] == 1
+    undec = bytearray(proof)
+    undec[32] |= 1                                                                        # S negative -> decode fails
+    assert oracle.verify(oracle_gens_64_8, bytes(undec), vc[:32], 8, golden["label"], z)[0] == 1
+
+
+def test_prover_c_equals_twin_and_roundtrips(oracle, oracle_gens_64_8):
+    bg, pg = T.BulletproofGens(8, 2), T.PedersenGens()
+    rng = T.ShakeRng(b"blind")
+    vals, bl = [5, 250], [rng.scalar(), rng.scalar()]
+    pr, Vs = T.prove_multiple(bg, pg, T.Transcript(b"x"), vals, bl, 8, T.ShakeRng(b"prover"))
+    cp, cv = oracle.prove(oracle_gens_64_8, vals, b"".join(b.to_bytes(32, "little") for b in bl), 8, b"x", b"prover")
+    assert cp == pr.to_bytes() and cv == b"".join(Vs)
+    rc, res = oracle.verify(oracle_gens_64_8, cp, cv, 8, b"x", hashlib.shake_256(b"c").digest(64))
+    assert rc == 0 and res == bytes(32)
+    # out-of-range value must not verify (reference: tests/r1cs.rs-style negative; here 2^8 in 8 bits)
+    cp2, cv2 = oracle.prove(oracle_gens_64_8, [256], (7).to_bytes(32, "little"), 8, b"x", b"prover")
+    # (needs c != 0: with the batching challenge c = 0 the t_x statement drops out of the mega-check)
+    assert oracle.verify(oracle_gens_64_8, cp2, cv2, 8, b"x", hashlib.shake_256(b"q").digest(64))[0] == 1
+    assert oracle.verify(oracle_gens_64_8, cp2, cv2, 8, b"x", bytes(64))[0] == 0
+
+
+@pytest.mark.parametrize("n,m", [(32, 1), (64, 1), (64, 4)])
+def test_prove_verify_roundtrip_sizes(oracle, oracle_gens_64_8, n, m):
+    """mirrors src/range_proof/mod.rs:633-724 (create -> serialize -> verify)."""
+    vals = [(0x0123456789ABCDEF * (j + 3)) % (1 << n) for j in range(m)]
+    bl = b"".join(hashlib.shake_256(b"bl%d" % j).digest(32)[:31] + b"\x00" for j in range(m))
+    proof, com = oracle.prove(oracle_gens_64_8, vals, bl, n, b"roundtrip", b"seed")
+    assert len(proof) == oracle.proof_len(n, m)
+    assert oracle.verify(oracle_gens_64_8, proof, com, n, b"roundtrip", hashlib.shake_256(b"r").digest(64)) == (0, bytes(32))
+    assert oracle.verify(oracle_gens_64_8, proof, com, n, b"other label", bytes(64))[0] == 1
+
+
+def test_msm_algorithms_agree_and_match_twin(oracle):
+    for n in (1, 2, 17, 189, 190, 520, 810):
+        pts = b"".join(T.compress(T.from_uniform_bytes(hashlib.shake_256(b"p%d" % i).digest(64))) for i in range(n))
+        scs = b"".join((int.from_bytes(hashlib.shake_256(b"s%d" % i).digest(64), "little") % T.L).to_bytes(32, "little")
+                       for i in range(n))
+        r = [oracle.msm(scs, pts, a) for a in (0, 1, 2)]
+        assert r[0] == r[1] == r[2] and r[0][0] == 0
+        if n <= 17:
+            tw = T.compress(T.msm([int.from_bytes(scs[32 * i:32 * i + 32], "little") for i in range(n)],
+                                  [T.decompress(pts[32 * i:32 * i + 32]) for i in range(n)]))
+            assert tw == r[0][1]
+    bad = bytearray(pts[:64])
+    bad[0] |= 1
+    assert oracle.msm(scs[:64], bytes(bad), 0)[0] == 1
+    # empty MSM = identity
+    assert oracle.msm(b"", b"", 0) == (0, bytes(32))
