@@ -1,0 +1,162 @@
+"""ctypes binding of libbpgpu.so (the C ABI declared in include/bpgpu.h).
+
+There is no CPU fallback: if the HIP library is missing or no GPU is usable,
+everything here raises.  Nothing under oracle/ is ever imported.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libbpgpu.so")
+
+_lib = None
+
+EXPORTS = [
+    "bpgpu_version", "bpgpu_ctx_create", "bpgpu_ctx_destroy", "bpgpu_last_error", "bpgpu_ctx_set_option",
+    "bpgpu_synchronize", "bpgpu_gens_create", "bpgpu_gens_load", "bpgpu_gens_export",
+    "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_msm_batch_shared", "bpgpu_msm_batch_shared_dev",
+    "bpgpu_rangeproof_verify_batch", "bpgpu_rangeproof_verify_batch_dev",
+    "bpgpu_profile_enable", "bpgpu_profile_reset", "bpgpu_profile_report",
+]
+
+
+class BpgpuError(RuntimeError):
+    pass
+
+
+def lib():
+    """Load libbpgpu.so (built by __graft_entry__.build()); raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise BpgpuError("libbpgpu.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` -- "
+                         "there is no CPU fallback" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, sz, u8p, i = C.c_void_p, C.c_size_t, C.c_char_p, C.c_int
+    L.bpgpu_version.restype = i
+    L.bpgpu_ctx_create.argtypes = [i, C.POINTER(vp)]
+    L.bpgpu_ctx_destroy.argtypes = [vp]
+    L.bpgpu_ctx_destroy.restype = None
+    L.bpgpu_last_error.argtypes = [vp]
+    L.bpgpu_last_error.restype = C.c_char_p
+    L.bpgpu_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.bpgpu_synchronize.argtypes = [vp]
+    missing = [n for n in EXPORTS if not hasattr(L, n)]
+    if missing:
+        raise BpgpuError("libbpgpu.so lacks symbols declared in include/bpgpu.h: %s" % missing)
+    L.bpgpu_gens_create.argtypes = [vp, sz, sz]
+    L.bpgpu_gens_load.argtypes = [vp, sz, sz, u8p, u8p, u8p, u8p]
+    L.bpgpu_gens_export.argtypes = [vp, u8p, u8p, u8p, u8p]
+    L.bpgpu_msm_batch.argtypes = [vp, sz, C.POINTER(C.c_uint32), u8p, u8p, u8p, u8p]
+    L.bpgpu_msm_batch_dev.argtypes = [vp, sz, C.POINTER(C.c_uint32), vp, vp, vp, vp, vp]
+    L.bpgpu_msm_batch_shared.argtypes = [vp, sz, sz, sz, sz, u8p, u8p, u8p, u8p, u8p]
+    L.bpgpu_msm_batch_shared_dev.argtypes = [vp, sz, sz, sz, sz, vp, vp, vp, vp, vp, vp]
+    L.bpgpu_rangeproof_verify_batch.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p]
+    L.bpgpu_rangeproof_verify_batch_dev.argtypes = [vp, sz, sz, sz, vp, sz, vp, u8p, sz, vp, vp, vp, vp]
+    L.bpgpu_profile_enable.argtypes = [vp, i]
+    L.bpgpu_profile_reset.argtypes = [vp]
+    L.bpgpu_profile_report.argtypes = [vp, C.c_char_p, sz]
+    _lib = L
+    return L
+
+
+ERR_NAMES = {0: "OK", -1: "INVALID_ARG", -2: "HIP", -3: "NO_GENS", -4: "NO_DEVICE", -5: "BAD_GENERATOR"}
+
+
+class Context:
+    """Owns one bpgpu_ctx (one GPU)."""
+
+    def __init__(self, device=0, fixed_window_bits=None, fixed_splits=None):
+        self._L = lib()
+        h = C.c_void_p()
+        rc = self._L.bpgpu_ctx_create(device, C.byref(h))
+        if rc != 0:
+            raise BpgpuError("bpgpu_ctx_create(device=%d) failed: %s (no CPU fallback)" % (device, ERR_NAMES.get(rc, rc)))
+        self.h = h
+        if fixed_window_bits is not None:
+            self.set_option("fixed_window_bits", fixed_window_bits)
+        if fixed_splits is not None:
+            self.set_option("fixed_splits", fixed_splits)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.bpgpu_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise BpgpuError("%s: %s" % (ERR_NAMES.get(rc, rc), self._L.bpgpu_last_error(self.h).decode()))
+
+    def set_option(self, key, value):
+        self._chk(self._L.bpgpu_ctx_set_option(self.h, key.encode(), int(value)))
+
+    def synchronize(self):
+        self._chk(self._L.bpgpu_synchronize(self.h))
+
+    # ---- generators ----
+    def gens_create(self, gens_capacity, party_capacity):
+        self._chk(self._L.bpgpu_gens_create(self.h, gens_capacity, party_capacity))
+        self.gens_capacity, self.party_capacity = gens_capacity, party_capacity
+
+    def gens_load(self, gens_capacity, party_capacity, G, H, B, B_blinding):
+        assert len(G) == len(H) == 32 * gens_capacity * party_capacity
+        self._chk(self._L.bpgpu_gens_load(self.h, gens_capacity, party_capacity, G, H, B, B_blinding))
+        self.gens_capacity, self.party_capacity = gens_capacity, party_capacity
+
+    def gens_export(self):
+        tot = self.gens_capacity * self.party_capacity
+        G, H = C.create_string_buffer(32 * tot), C.create_string_buffer(32 * tot)
+        B, Bb = C.create_string_buffer(32), C.create_string_buffer(32)
+        self._chk(self._L.bpgpu_gens_export(self.h, G, H, B, Bb))
+        return G.raw, H.raw, B.raw, Bb.raw
+
+    # ---- MSM ----
+    def msm_batch(self, n_terms, scalars, points):
+        nb = len(n_terms)
+        tot = sum(n_terms)
+        assert len(scalars) == len(points) == 32 * tot
+        nt = (C.c_uint32 * max(nb, 1))(*n_terms)
+        out, st = C.create_string_buffer(32 * max(nb, 1)), C.create_string_buffer(max(nb, 1))
+        self._chk(self._L.bpgpu_msm_batch(self.h, nb, nt, scalars, points, out, st))
+        return out.raw[:32 * nb], st.raw[:nb]
+
+    def msm_batch_shared(self, n, m, nbatch, n_unique, gen_scalars, uniq_scalars, uniq_points):
+        assert len(gen_scalars) == 32 * (2 * n * m + 2) * nbatch
+        assert len(uniq_scalars) == len(uniq_points) == 32 * n_unique * nbatch
+        out, st = C.create_string_buffer(32 * max(nbatch, 1)), C.create_string_buffer(max(nbatch, 1))
+        self._chk(self._L.bpgpu_msm_batch_shared(self.h, n, m, nbatch, n_unique, gen_scalars, uniq_scalars, uniq_points, out, st))
+        return out.raw[:32 * nbatch], st.raw[:nbatch]
+
+    # ---- range proofs ----
+    def rangeproof_verify_batch(self, n, m, proofs, proof_len, commitments, label, rng64=None, want_msm=False):
+        nb = len(proofs) // proof_len if proof_len else 0
+        assert len(proofs) == nb * proof_len and len(commitments) == 32 * m * nb
+        assert rng64 is None or len(rng64) == 64 * nb
+        verdict = C.create_string_buffer(max(nb, 1))
+        msm = C.create_string_buffer(32 * max(nb, 1)) if want_msm else None
+        self._chk(self._L.bpgpu_rangeproof_verify_batch(self.h, n, m, nb, proofs, proof_len, commitments, label, len(label),
+                                                        rng64, verdict, msm))
+        return (verdict.raw[:nb], msm.raw[:32 * nb]) if want_msm else verdict.raw[:nb]
+
+    # ---- instrumentation ----
+    def profile_enable(self, on=True):
+        self._chk(self._L.bpgpu_profile_enable(self.h, 1 if on else 0))
+
+    def profile_reset(self):
+        self._chk(self._L.bpgpu_profile_reset(self.h))
+
+    def profile_report(self):
+        buf = C.create_string_buffer(1 << 16)
+        self._chk(self._L.bpgpu_profile_report(self.h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, n, ms = line.split()
+            out[name] = (int(n), float(ms))
+        return out

@@ -1,0 +1,656 @@
+// libbpgpu.so: HIP kernels (gfx950) + host runtime + C ABI (include/bpgpu.h).
+// Kernels are thin __global__ wrappers around the per-lane bodies in msm_vb.h /
+// msm_fixed.h / rangeproof.h; the bodies are shared with the CPU test harness.
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/bpgpu.h"
+#include "msm_fixed.h"
+#include "msm_vb.h"
+#include "rangeproof.h"
+
+using namespace bp;
+
+// ============================================================================
+// kernels
+// ============================================================================
+#define BP_BLOCK 256
+
+__global__ void __launch_bounds__(BP_BLOCK) k_vb_prepare(uint32_t total, const vb_chunk *chunks, const uint32_t *term_chunk,
+                                                          const uint32_t *scalars, const uint32_t *points, ge_cached *tab,
+                                                          uint32_t *recoded, uint32_t *status) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < total) vb_prepare_thread(t, chunks, term_chunk, scalars, points, tab, recoded, status);
+}
+
+__global__ void __launch_bounds__(BP_BLOCK) k_vb_window(uint32_t nthreads, const vb_chunk *chunks, const ge_cached *tab,
+                                                         const uint32_t *recoded, ge_ext *part) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < nthreads) vb_window_thread(tid, chunks, tab, recoded, part);
+}
+
+__global__ void __launch_bounds__(BP_BLOCK) k_vb_colsum(uint32_t nthreads, const uint32_t *chunk_first, const ge_ext *part,
+                                                         ge_ext *col) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < nthreads) vb_colsum_thread(tid, chunk_first, part, col);
+}
+
+__global__ void __launch_bounds__(64) k_vb_horner(uint32_t nbatch, const ge_ext *col, const uint32_t *status, uint32_t *out) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < nbatch) vb_horner_thread(b, col, status, out, nullptr);
+}
+
+__global__ void __launch_bounds__(64) k_status_bytes(uint32_t n, const uint32_t *status, uint8_t *out) {
+    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b < n) out[b] = (uint8_t)status[b];
+}
+
+__global__ void __launch_bounds__(64) k_fb_base(fb_params prm, const uint32_t *gens, ge_ext *base, uint32_t *bad) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g < prm.n_gens) fb_base_thread(g, prm, gens, base, bad);
+}
+
+__global__ void __launch_bounds__(64) k_fb_fill(fb_params prm, const ge_ext *base, fb_entry *table) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < prm.n_gens * prm.nwin) fb_fill_thread(tid, prm, base, table);
+}
+
+__global__ void __launch_bounds__(BP_BLOCK) k_fb_recode(uint32_t nthreads, fb_params prm, uint32_t nproofs, uint32_t n_gen_terms,
+                                                         const uint32_t *gen_scalars, uint16_t *digits, uint32_t *status) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < nthreads) fb_recode_thread(tid, prm, nproofs, n_gen_terms, gen_scalars, digits, status);
+}
+
+// grid: 1-D, nblk_p * nsplit blocks of FB_BLOCK lanes (lane = proof).  Block L serves
+// split = (L % 8) + 8 * ((L / 8) / nblk_p) so that the blocks the dispatcher places on
+// one XCD (L % 8) share the same slices of the table in that XCD's L2.
+#define FB_BLOCK 64
+__global__ void __launch_bounds__(FB_BLOCK) k_fb_accum(fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit,
+                                                        uint32_t npairs, const uint32_t *gen_ids, const uint16_t *digits,
+                                                        const fb_entry *table, ge_ext *partial) {
+    const uint32_t L = blockIdx.x;
+    uint32_t split, pblk;
+    if ((nsplit & 7) == 0) {
+        const uint32_t r = L & 7, rest = L >> 3;
+        pblk = rest % nblk_p;
+        split = r + 8 * (rest / nblk_p);
+    } else {
+        pblk = L % nblk_p;
+        split = L / nblk_p;
+    }
+    const uint32_t p = pblk * FB_BLOCK + threadIdx.x;
+    const uint32_t per = (npairs + nsplit - 1) / nsplit;
+    const uint32_t q0 = split * per, q1 = (q0 + per < npairs) ? q0 + per : npairs;
+    if (p < nproofs) fb_accum_thread(p, split, q0 < npairs ? q0 : npairs, q1, prm, nproofs, gen_ids, digits, table, partial);
+}
+
+__global__ void __launch_bounds__(64) k_shared_finish(uint32_t nproofs, uint32_t nsplit, const ge_ext *col, int have_unique,
+                                                       const ge_ext *partial, const uint32_t *status, uint32_t *out_words,
+                                                       uint8_t *verdict) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < nproofs) shared_finish_thread(p, nproofs, nsplit, col, have_unique != 0, partial, status, out_words, verdict);
+}
+
+// ============================================================================
+// host runtime
+// ============================================================================
+struct kstat {
+    uint64_t launches = 0;
+    double ms = 0;
+};
+
+struct bpgpu_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::mutex mu;
+    std::string err;
+    // bump arena for per-call scratch
+    char *arena = nullptr;
+    size_t arena_cap = 0, arena_off = 0;
+    // options
+    uint32_t W = 8;
+    uint32_t splits = 0;
+    // generators
+    size_t gens_capacity = 0, party_capacity = 0;
+    uint32_t *d_gens = nullptr;       // [B_blinding, B, G..., H...] compressed, n_gens x 8 words
+    fb_entry *d_table = nullptr;
+    fb_params prm{};
+    std::vector<uint8_t> h_gens;      // host copy of the encodings
+    std::map<std::pair<size_t, size_t>, uint32_t *> gen_ids_cache;  // (n,m) -> device id list
+    // profiling
+    bool prof = false;
+    std::map<std::string, kstat> stats;
+    std::vector<std::tuple<std::string, hipEvent_t, hipEvent_t>> pending;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+static int fail(bpgpu_ctx *c, int code, const char *fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (c) c->err = buf;
+    return code;
+}
+#define HIPCHK(c, call)                                                                                    \
+    do {                                                                                                   \
+        hipError_t e_ = (call);                                                                            \
+        if (e_ != hipSuccess) return fail(c, BPGPU_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_)); \
+    } while (0)
+
+static hipEvent_t get_event(bpgpu_ctx *c) {
+    if (!c->ev_pool.empty()) {
+        hipEvent_t e = c->ev_pool.back();
+        c->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e;
+    hipEventCreate(&e);
+    return e;
+}
+
+struct launch_scope {
+    bpgpu_ctx *c;
+    hipStream_t s;
+    const char *name;
+    hipEvent_t a = nullptr, b = nullptr;
+    launch_scope(bpgpu_ctx *c_, hipStream_t s_, const char *n) : c(c_), s(s_), name(n) {
+        if (c->prof) {
+            a = get_event(c);
+            b = get_event(c);
+            hipEventRecord(a, s);
+        }
+    }
+    ~launch_scope() {
+        if (c->prof) {
+            hipEventRecord(b, s);
+            c->pending.emplace_back(name, a, b);
+        }
+    }
+};
+#define LAUNCH(c, s, name, kern, grid, block, ...)                        \
+    do {                                                                  \
+        launch_scope ls_(c, s, name);                                     \
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, __VA_ARGS__); \
+    } while (0)
+
+static void drain_profile(bpgpu_ctx *c) {
+    for (auto &t : c->pending) {
+        hipEventSynchronize(std::get<2>(t));
+        float ms = 0;
+        hipEventElapsedTime(&ms, std::get<1>(t), std::get<2>(t));
+        auto &st = c->stats[std::get<0>(t)];
+        st.launches++;
+        st.ms += ms;
+        c->ev_pool.push_back(std::get<1>(t));
+        c->ev_pool.push_back(std::get<2>(t));
+    }
+    c->pending.clear();
+}
+
+// arena: reset at the start of each API call; grows (with a device sync) when too small
+static int arena_reserve(bpgpu_ctx *c, size_t bytes) {
+    if (bytes <= c->arena_cap) return BPGPU_OK;
+    HIPCHK(c, hipDeviceSynchronize());
+    if (c->arena) HIPCHK(c, hipFree(c->arena));
+    c->arena = nullptr;
+    c->arena_cap = 0;
+    size_t cap = bytes + bytes / 4 + (1 << 20);
+    HIPCHK(c, hipMalloc((void **)&c->arena, cap));
+    c->arena_cap = cap;
+    return BPGPU_OK;
+}
+static size_t align_up(size_t x) { return (x + 255) & ~(size_t)255; }
+struct arena_plan {
+    size_t total = 0;
+    size_t add(size_t bytes) {
+        size_t off = total;
+        total += align_up(bytes);
+        return off;
+    }
+};
+
+extern "C" {
+
+int bpgpu_version(void) { return 100; }
+
+int bpgpu_ctx_create(int device, bpgpu_ctx **out) {
+    if (!out) return BPGPU_ERR_INVALID_ARG;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return BPGPU_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return BPGPU_ERR_NO_DEVICE;
+    bpgpu_ctx *c = new bpgpu_ctx();
+    c->device = device;
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return BPGPU_ERR_HIP;
+    }
+    *out = c;
+    return BPGPU_OK;
+}
+
+void bpgpu_ctx_destroy(bpgpu_ctx *c) {
+    if (!c) return;
+    hipSetDevice(c->device);
+    hipDeviceSynchronize();
+    drain_profile(c);
+    for (auto e : c->ev_pool) hipEventDestroy(e);
+    for (auto &kv : c->gen_ids_cache) hipFree(kv.second);
+    if (c->arena) hipFree(c->arena);
+    if (c->d_gens) hipFree(c->d_gens);
+    if (c->d_table) hipFree(c->d_table);
+    if (c->stream) hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char *bpgpu_last_error(bpgpu_ctx *c) { return c ? c->err.c_str() : "null context"; }
+
+int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
+    if (!c || !key) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!strcmp(key, "fixed_window_bits")) {
+        if (value < 2 || value > 16) return fail(c, BPGPU_ERR_INVALID_ARG, "fixed_window_bits must be in 2..16");
+        if (c->d_table) return fail(c, BPGPU_ERR_INVALID_ARG, "set fixed_window_bits before loading generators");
+        c->W = (uint32_t)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "fixed_splits")) {
+        if (value < 0 || value > 4096) return fail(c, BPGPU_ERR_INVALID_ARG, "fixed_splits out of range");
+        c->splits = (uint32_t)value;
+        return BPGPU_OK;
+    }
+    return fail(c, BPGPU_ERR_INVALID_ARG, "unknown option %s", key);
+}
+
+int bpgpu_synchronize(bpgpu_ctx *c) {
+    if (!c) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return BPGPU_OK;
+}
+
+int bpgpu_profile_enable(bpgpu_ctx *c, int on) {
+    if (!c) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->prof = on != 0;
+    return BPGPU_OK;
+}
+int bpgpu_profile_reset(bpgpu_ctx *c) {
+    if (!c) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    drain_profile(c);
+    c->stats.clear();
+    return BPGPU_OK;
+}
+int bpgpu_profile_report(bpgpu_ctx *c, char *buf, size_t cap) {
+    if (!c || !buf || cap == 0) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    drain_profile(c);
+    std::string s;
+    for (auto &kv : c->stats) {
+        char line[256];
+        snprintf(line, sizeof line, "%s %llu %.6f\n", kv.first.c_str(), (unsigned long long)kv.second.launches, kv.second.ms);
+        s += line;
+    }
+    snprintf(buf, cap, "%s", s.c_str());
+    return BPGPU_OK;
+}
+
+}  // extern "C"
+
+// ============================================================================
+// generators
+// ============================================================================
+static int build_tables(bpgpu_ctx *c) {
+    // c->d_gens holds n_gens compressed points
+    fb_params prm;
+    prm.W = c->W;
+    prm.nwin = fb_nwin(c->W);
+    prm.half = 1u << (c->W - 1);
+    prm.n_gens = (uint32_t)(2 + 2 * c->gens_capacity * c->party_capacity);
+    c->prm = prm;
+    if (c->d_table) HIPCHK(c, hipFree(c->d_table));
+    c->d_table = nullptr;
+    const size_t entries = (size_t)prm.n_gens * prm.nwin * prm.half;
+    HIPCHK(c, hipMalloc((void **)&c->d_table, entries * sizeof(fb_entry)));
+    ge_ext *d_base = nullptr;
+    uint32_t *d_bad = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_base, (size_t)prm.n_gens * prm.nwin * sizeof(ge_ext)));
+    HIPCHK(c, hipMalloc((void **)&d_bad, 4));
+    HIPCHK(c, hipMemsetAsync(d_bad, 0, 4, c->stream));
+    LAUNCH(c, c->stream, "fb_base", k_fb_base, (prm.n_gens + 63) / 64, 64, prm, c->d_gens, d_base, d_bad);
+    LAUNCH(c, c->stream, "fb_fill", k_fb_fill, (prm.n_gens * prm.nwin + 63) / 64, 64, prm, d_base, c->d_table);
+    uint32_t bad = 0;
+    HIPCHK(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipGetLastError());
+    hipFree(d_base);
+    hipFree(d_bad);
+    if (bad) return fail(c, BPGPU_ERR_BAD_GENERATOR, "a generator encoding does not decode");
+    for (auto &kv : c->gen_ids_cache) hipFree(kv.second);
+    c->gen_ids_cache.clear();
+    return BPGPU_OK;
+}
+
+static int load_gens_locked(bpgpu_ctx *c, size_t gens_capacity, size_t party_capacity, const uint8_t *G, const uint8_t *H,
+                            const uint8_t *B, const uint8_t *Bb) {
+    const size_t tot = gens_capacity * party_capacity;
+    c->gens_capacity = gens_capacity;
+    c->party_capacity = party_capacity;
+    c->h_gens.assign((2 + 2 * tot) * 32, 0);
+    memcpy(&c->h_gens[0], Bb, 32);
+    memcpy(&c->h_gens[32], B, 32);
+    memcpy(&c->h_gens[64], G, tot * 32);
+    memcpy(&c->h_gens[64 + tot * 32], H, tot * 32);
+    if (c->d_gens) HIPCHK(c, hipFree(c->d_gens));
+    c->d_gens = nullptr;
+    HIPCHK(c, hipMalloc((void **)&c->d_gens, c->h_gens.size()));
+    HIPCHK(c, hipMemcpy(c->d_gens, c->h_gens.data(), c->h_gens.size(), hipMemcpyHostToDevice));
+    return build_tables(c);
+}
+
+extern "C" int bpgpu_gens_load(bpgpu_ctx *c, size_t gens_capacity, size_t party_capacity, const uint8_t *G, const uint8_t *H,
+                               const uint8_t B[32], const uint8_t Bb[32]) {
+    if (!c || !G || !H || !B || !Bb || gens_capacity == 0 || party_capacity == 0) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return load_gens_locked(c, gens_capacity, party_capacity, G, H, B, Bb);
+}
+
+extern "C" int bpgpu_gens_export(bpgpu_ctx *c, uint8_t *G, uint8_t *H, uint8_t B[32], uint8_t Bb[32]) {
+    if (!c) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->h_gens.empty()) return fail(c, BPGPU_ERR_NO_GENS, "generators not loaded");
+    const size_t tot = c->gens_capacity * c->party_capacity;
+    if (Bb) memcpy(Bb, &c->h_gens[0], 32);
+    if (B) memcpy(B, &c->h_gens[32], 32);
+    if (G) memcpy(G, &c->h_gens[64], tot * 32);
+    if (H) memcpy(H, &c->h_gens[64 + tot * 32], tot * 32);
+    return BPGPU_OK;
+}
+
+// id list of the generator terms of an (n, m) proof in the reference's order
+// (B_blinding, B, G(n,m), H(n,m)); ids index the loaded table
+static int gen_ids_for(bpgpu_ctx *c, size_t n, size_t m, uint32_t **out) {
+    auto key = std::make_pair(n, m);
+    auto it = c->gen_ids_cache.find(key);
+    if (it != c->gen_ids_cache.end()) {
+        *out = it->second;
+        return BPGPU_OK;
+    }
+    std::vector<uint32_t> ids;
+    const size_t tot = c->gens_capacity * c->party_capacity;
+    ids.push_back(0);
+    ids.push_back(1);
+    for (size_t j = 0; j < m; j++)
+        for (size_t i = 0; i < n; i++) ids.push_back((uint32_t)(2 + j * c->gens_capacity + i));
+    for (size_t j = 0; j < m; j++)
+        for (size_t i = 0; i < n; i++) ids.push_back((uint32_t)(2 + tot + j * c->gens_capacity + i));
+    uint32_t *d = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, ids.size() * 4));
+    HIPCHK(c, hipMemcpy(d, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+    c->gen_ids_cache[key] = d;
+    *out = d;
+    return BPGPU_OK;
+}
+
+// ============================================================================
+// variable-base MSM
+// ============================================================================
+struct vb_plan {
+    std::vector<vb_chunk> chunks;
+    std::vector<uint32_t> chunk_first, term_chunk;
+    uint32_t total = 0;
+};
+static void make_vb_plan(vb_plan &pl, size_t nbatch, const uint32_t *n_terms) {
+    pl.chunk_first.resize(nbatch + 1);
+    uint32_t t0 = 0;
+    for (size_t b = 0; b < nbatch; b++) {
+        pl.chunk_first[b] = (uint32_t)pl.chunks.size();
+        for (uint32_t k = 0; k < n_terms[b]; k += BP_VB_CHUNK) {
+            vb_chunk ch;
+            ch.msm = (uint32_t)b;
+            ch.first = t0 + k;
+            ch.count = n_terms[b] - k < BP_VB_CHUNK ? n_terms[b] - k : BP_VB_CHUNK;
+            ch.pad = 0;
+            for (uint32_t i = 0; i < ch.count; i++) pl.term_chunk.push_back((uint32_t)pl.chunks.size());
+            pl.chunks.push_back(ch);
+        }
+        t0 += n_terms[b];
+    }
+    pl.chunk_first[nbatch] = (uint32_t)pl.chunks.size();
+    pl.total = t0;
+}
+
+// Enqueue the variable-base stages up to the per-MSM column sums.  Scratch comes from the
+// arena at [base + offsets].  Returns device pointers through the struct.
+struct vb_dev {
+    vb_chunk *chunks;
+    uint32_t *chunk_first, *term_chunk, *recoded;
+    ge_cached *tab;
+    ge_ext *part, *col;
+};
+static void plan_vb(arena_plan &ap, const vb_plan &pl, size_t nbatch, size_t off[7]) {
+    off[0] = ap.add(pl.chunks.size() * sizeof(vb_chunk) + 16);
+    off[1] = ap.add((nbatch + 1) * 4);
+    off[2] = ap.add((size_t)pl.total * 4 + 16);
+    off[3] = ap.add((size_t)pl.total * 32 + 16);
+    off[4] = ap.add((size_t)pl.total * 8 * sizeof(ge_cached) + 16);
+    off[5] = ap.add(pl.chunks.size() * 64 * sizeof(ge_ext) + 16);
+    off[6] = ap.add(nbatch * 64 * sizeof(ge_ext) + 16);
+}
+static int enqueue_vb(bpgpu_ctx *c, hipStream_t s, const vb_plan &pl, size_t nbatch, const size_t off[7],
+                      const uint32_t *d_scalars, const uint32_t *d_points, uint32_t *d_status, vb_dev &d) {
+    char *a = c->arena;
+    d.chunks = (vb_chunk *)(a + off[0]);
+    d.chunk_first = (uint32_t *)(a + off[1]);
+    d.term_chunk = (uint32_t *)(a + off[2]);
+    d.recoded = (uint32_t *)(a + off[3]);
+    d.tab = (ge_cached *)(a + off[4]);
+    d.part = (ge_ext *)(a + off[5]);
+    d.col = (ge_ext *)(a + off[6]);
+    if (!pl.chunks.empty()) {
+        HIPCHK(c, hipMemcpyAsync(d.chunks, pl.chunks.data(), pl.chunks.size() * sizeof(vb_chunk), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(d.term_chunk, pl.term_chunk.data(), (size_t)pl.total * 4, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(c, hipMemcpyAsync(d.chunk_first, pl.chunk_first.data(), (nbatch + 1) * 4, hipMemcpyHostToDevice, s));
+    if (pl.total) {
+        LAUNCH(c, s, "vb_prepare", k_vb_prepare, (pl.total + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, pl.total, d.chunks, d.term_chunk,
+               d_scalars, d_points, d.tab, d.recoded, d_status);
+        const uint32_t nt = (uint32_t)pl.chunks.size() * 64;
+        LAUNCH(c, s, "vb_window", k_vb_window, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, d.chunks, d.tab, d.recoded, d.part);
+    }
+    const uint32_t nc = (uint32_t)nbatch * 64;
+    LAUNCH(c, s, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, d.col);
+    return BPGPU_OK;
+}
+
+static int msm_batch_dev_locked(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_terms, const void *d_scalars, const void *d_points,
+                                void *d_out, void *d_status_bytes, hipStream_t s) {
+    if (nbatch == 0) return BPGPU_OK;
+    vb_plan pl;
+    make_vb_plan(pl, nbatch, n_terms);
+    arena_plan ap;
+    size_t off[7];
+    plan_vb(ap, pl, nbatch, off);
+    const size_t off_status = ap.add(nbatch * 4);
+    int rc = arena_reserve(c, ap.total);
+    if (rc) return rc;
+    uint32_t *d_status = (uint32_t *)(c->arena + off_status);
+    HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
+    vb_dev d;
+    rc = enqueue_vb(c, s, pl, nbatch, off, (const uint32_t *)d_scalars, (const uint32_t *)d_points, d_status, d);
+    if (rc) return rc;
+    LAUNCH(c, s, "vb_horner", k_vb_horner, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d.col, d_status, (uint32_t *)d_out);
+    LAUNCH(c, s, "status_bytes", k_status_bytes, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d_status, (uint8_t *)d_status_bytes);
+    HIPCHK(c, hipGetLastError());
+    return BPGPU_OK;
+}
+
+extern "C" int bpgpu_msm_batch_dev(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_terms, const void *d_scalars, const void *d_points,
+                                   void *d_out, void *d_status, void *stream) {
+    if (!c || (nbatch && (!n_terms || !d_out || !d_status))) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return msm_batch_dev_locked(c, nbatch, n_terms, d_scalars, d_points, d_out, d_status, stream ? (hipStream_t)stream : c->stream);
+}
+
+extern "C" int bpgpu_msm_batch(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, const uint8_t *points,
+                               uint8_t *out, uint8_t *status) {
+    if (!c || (nbatch && (!n_terms || !out || !status))) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0) return BPGPU_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    size_t total = 0;
+    for (size_t b = 0; b < nbatch; b++) total += n_terms[b];
+    if (total && (!scalars || !points)) return BPGPU_ERR_INVALID_ARG;
+    char *d_io = nullptr;
+    const size_t sz_terms = align_up(total * 32 + 16), sz_out = align_up(nbatch * 32), sz_st = align_up(nbatch);
+    HIPCHK(c, hipMalloc((void **)&d_io, 2 * sz_terms + sz_out + sz_st));
+    char *d_s = d_io, *d_p = d_io + sz_terms, *d_o = d_io + 2 * sz_terms, *d_t = d_o + sz_out;
+    hipStream_t s = c->stream;
+    int rc = BPGPU_OK;
+    do {
+        if (total) {
+            if (hipMemcpyAsync(d_s, scalars, total * 32, hipMemcpyHostToDevice, s) != hipSuccess ||
+                hipMemcpyAsync(d_p, points, total * 32, hipMemcpyHostToDevice, s) != hipSuccess) {
+                rc = fail(c, BPGPU_ERR_HIP, "H2D copy failed");
+                break;
+            }
+        }
+        rc = msm_batch_dev_locked(c, nbatch, n_terms, d_s, d_p, d_o, d_t, s);
+        if (rc) break;
+        if (hipMemcpyAsync(out, d_o, nbatch * 32, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(status, d_t, nbatch, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(c, BPGPU_ERR_HIP, "D2H copy / sync failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+    } while (0);
+    hipStreamSynchronize(s);
+    hipFree(d_io);
+    return rc;
+}
+
+// ============================================================================
+// shared-generator MSM
+// ============================================================================
+static uint32_t pick_splits(bpgpu_ctx *c, size_t nbatch, uint32_t npairs) {
+    if (c->splits) return c->splits;
+    // aim for >= 2048 wavefronts (2 per SIMD) but keep >= 16 pairs per lane
+    const uint32_t nblk = (uint32_t)((nbatch + FB_BLOCK - 1) / FB_BLOCK);
+    uint32_t s = (2048 + nblk - 1) / nblk;
+    s = (s + 7) & ~7u;
+    while (s > 8 && npairs / s < 16) s -= 8;
+    if (s < 8) s = 8;
+    if (s > npairs) s = 8;
+    return s;
+}
+
+static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, size_t n_unique, const void *d_gen_scalars,
+                                 const void *d_uniq_scalars, const void *d_uniq_points, void *d_out, void *d_status_bytes,
+                                 void *d_verdict, hipStream_t s) {
+    if (nbatch == 0) return BPGPU_OK;
+    if (!c->d_table) return fail(c, BPGPU_ERR_NO_GENS, "generators not loaded");
+    if (n == 0 || m == 0 || n > c->gens_capacity || m > c->party_capacity)
+        return fail(c, BPGPU_ERR_NO_GENS, "generators too small for n=%zu m=%zu", n, m);
+    const uint32_t n_gen_terms = (uint32_t)(2 * n * m + 2);
+    const fb_params prm = c->prm;
+    const uint32_t npairs = n_gen_terms * prm.nwin;
+    uint32_t *d_ids = nullptr;
+    int rc = gen_ids_for(c, n, m, &d_ids);
+    if (rc) return rc;
+    std::vector<uint32_t> nt(nbatch, (uint32_t)n_unique);
+    vb_plan pl;
+    make_vb_plan(pl, nbatch, nt.data());
+    const uint32_t nsplit = pick_splits(c, nbatch, npairs);
+    arena_plan ap;
+    size_t off[7];
+    plan_vb(ap, pl, nbatch, off);
+    const size_t off_status = ap.add(nbatch * 4);
+    const size_t off_digits = ap.add((size_t)npairs * nbatch * 2 + 16);
+    const size_t off_partial = ap.add((size_t)nsplit * nbatch * sizeof(ge_ext) + 16);
+    rc = arena_reserve(c, ap.total);
+    if (rc) return rc;
+    uint32_t *d_status = (uint32_t *)(c->arena + off_status);
+    uint16_t *d_digits = (uint16_t *)(c->arena + off_digits);
+    ge_ext *d_partial = (ge_ext *)(c->arena + off_partial);
+    HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
+    vb_dev d{};
+    if (n_unique) {
+        rc = enqueue_vb(c, s, pl, nbatch, off, (const uint32_t *)d_uniq_scalars, (const uint32_t *)d_uniq_points, d_status, d);
+        if (rc) return rc;
+    }
+    const uint32_t nrec = n_gen_terms * (uint32_t)nbatch;
+    LAUNCH(c, s, "fb_recode", k_fb_recode, (nrec + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nrec, prm, (uint32_t)nbatch, n_gen_terms,
+           (const uint32_t *)d_gen_scalars, d_digits, d_status);
+    const uint32_t nblk_p = (uint32_t)((nbatch + FB_BLOCK - 1) / FB_BLOCK);
+    LAUNCH(c, s, "fb_accum", k_fb_accum, nblk_p * nsplit, FB_BLOCK, prm, (uint32_t)nbatch, nblk_p, nsplit, npairs, d_ids, d_digits,
+           c->d_table, d_partial);
+    LAUNCH(c, s, "shared_finish", k_shared_finish, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, nsplit, d.col, n_unique ? 1 : 0,
+           d_partial, d_status, (uint32_t *)d_out, (uint8_t *)d_verdict);
+    if (d_status_bytes)
+        LAUNCH(c, s, "status_bytes", k_status_bytes, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d_status, (uint8_t *)d_status_bytes);
+    HIPCHK(c, hipGetLastError());
+    return BPGPU_OK;
+}
+
+extern "C" int bpgpu_msm_batch_shared_dev(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, size_t n_unique, const void *d_gen_scalars,
+                                          const void *d_uniq_scalars, const void *d_uniq_points, void *d_out, void *d_status,
+                                          void *stream) {
+    if (!c || (nbatch && (!d_gen_scalars || !d_out || !d_status))) return BPGPU_ERR_INVALID_ARG;
+    if (n_unique && (!d_uniq_scalars || !d_uniq_points)) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return msm_shared_dev_locked(c, n, m, nbatch, n_unique, d_gen_scalars, d_uniq_scalars, d_uniq_points, d_out, d_status, nullptr,
+                                 stream ? (hipStream_t)stream : c->stream);
+}
+
+extern "C" int bpgpu_msm_batch_shared(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, size_t n_unique, const uint8_t *gen_scalars,
+                                      const uint8_t *uniq_scalars, const uint8_t *uniq_points, uint8_t *out, uint8_t *status) {
+    if (!c || (nbatch && (!gen_scalars || !out || !status))) return BPGPU_ERR_INVALID_ARG;
+    if (n_unique && (!uniq_scalars || !uniq_points)) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0) return BPGPU_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t ng = (2 * n * m + 2) * nbatch * 32, nu = n_unique * nbatch * 32;
+    const size_t sz_g = align_up(ng + 16), sz_u = align_up(nu + 16), sz_out = align_up(nbatch * 32), sz_st = align_up(nbatch);
+    char *d_io = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_io, sz_g + 2 * sz_u + sz_out + sz_st));
+    char *d_g = d_io, *d_us = d_io + sz_g, *d_up = d_us + sz_u, *d_o = d_up + sz_u, *d_t = d_o + sz_out;
+    hipStream_t s = c->stream;
+    int rc = BPGPU_OK;
+    do {
+        if (hipMemcpyAsync(d_g, gen_scalars, ng, hipMemcpyHostToDevice, s) != hipSuccess ||
+            (nu && (hipMemcpyAsync(d_us, uniq_scalars, nu, hipMemcpyHostToDevice, s) != hipSuccess ||
+                    hipMemcpyAsync(d_up, uniq_points, nu, hipMemcpyHostToDevice, s) != hipSuccess))) {
+            rc = fail(c, BPGPU_ERR_HIP, "H2D copy failed");
+            break;
+        }
+        rc = msm_shared_dev_locked(c, n, m, nbatch, n_unique, d_g, d_us, d_up, d_o, d_t, nullptr, s);
+        if (rc) break;
+        if (hipMemcpyAsync(out, d_o, nbatch * 32, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            hipMemcpyAsync(status, d_t, nbatch, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(c, BPGPU_ERR_HIP, "D2H copy / sync failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+    } while (0);
+    hipStreamSynchronize(s);
+    hipFree(d_io);
+    return rc;
+}
+
+// TEMPORARY (first bring-up run only; replaced by the device transcript pipeline before commit)
+extern "C" int bpgpu_gens_create(bpgpu_ctx *c, size_t, size_t) { return fail(c, BPGPU_ERR_INVALID_ARG, "not built yet"); }
+extern "C" int bpgpu_rangeproof_verify_batch(bpgpu_ctx *c, size_t, size_t, size_t, const uint8_t *, size_t, const uint8_t *, const uint8_t *, size_t, const uint8_t *, uint8_t *, uint8_t *) { return fail(c, BPGPU_ERR_INVALID_ARG, "not built yet"); }
+extern "C" int bpgpu_rangeproof_verify_batch_dev(bpgpu_ctx *c, size_t, size_t, size_t, const void *, size_t, const void *, const uint8_t *, size_t, const void *, void *, void *, void *) { return fail(c, BPGPU_ERR_INVALID_ARG, "not built yet"); }

@@ -1,0 +1,170 @@
+// Fixed-base part of the verification MSM: the 2nm+2 generator terms
+// (B_blinding, B, G[0..nm), H[0..nm) -- src/range_proof/mod.rs:439-442 and
+// src/generators.rs:207-259 of the reference) are the same points for every
+// proof of a batch and for every batch, so they get precomputed window tables
+//     T[g][win][k] = (k+1) * 2^(W*win) * P_g ,  k < 2^(W-1),  affine Niels form
+// that live in HBM.  With them a generator term costs 256/W mixed additions
+// and no doublings at all (the reference's Straus/Pippenger spend ~256
+// doublings + 256/5..256/8 additions per term on them).
+//
+// Lane mapping of the accumulation kernel: lane = proof.  All 64 lanes of a
+// wavefront walk the same (generator, window) sequence, so the scalar digits
+// are read coalesced from a [generator][window][proof] array and all table
+// gathers of one step fall into one 2^(W-1)*128-byte sub-table (16 KiB at
+// W = 8) that stays in L1/L2.  No cross-lane reduction is needed; the pair
+// range is split across SPLIT workgroups to fill the chip and the SPLIT
+// partial points per proof are added in the finishing kernel.
+#ifndef BPGPU_MSM_FIXED_H
+#define BPGPU_MSM_FIXED_H
+#include "msm_vb.h"
+
+namespace bp {
+
+// one table entry: affine Niels point, 10-limb form, padded to a 128-byte line
+struct __attribute__((aligned(16))) fb_entry {
+    fe ypx, ymx, t2d;   // 120 bytes
+    uint32_t pad[2];
+};
+
+struct fb_params {
+    uint32_t W;        // window bits (1..16)
+    uint32_t nwin;     // ceil(256 / W)  (+1 when the recoding can carry out of the top window)
+    uint32_t half;     // 2^(W-1) = entries per (generator, window)
+    uint32_t n_gens;   // generators in the table
+};
+
+// Windows needed so that the recoded value s + sum_win half*2^(W*win) (s < 2^253, W >= 2)
+// stays below 2^(W*nwin): the added constant is < (2/3)*2^(W*nwin), so W*nwin >= 256 suffices.
+BP_HD uint32_t fb_nwin(uint32_t W) { return (256 + W - 1) / W; }
+
+// ---- table construction ------------------------------------------------------
+// thread g < n_gens : decode generator, emit base[g][win] = 2^(W*win) * P_g (extended)
+BP_HD void fb_base_thread(uint32_t g, fb_params prm, const uint32_t *gens_compressed, ge_ext *base, uint32_t *bad) {
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = gens_compressed[8 * (uint64_t)g + i];
+    ge_ext p;
+    if (!ristretto_decompress(p, w)) *bad = 1;
+    for (uint32_t win = 0; win < prm.nwin; win++) {
+        base[(uint64_t)g * prm.nwin + win] = p;
+        for (uint32_t k = 0; k < prm.W; k++) ge_dbl(p, p, k + 1 == prm.W);
+    }
+}
+
+BP_HD void fb_entry_from_ext(fb_entry &e, const ge_ext &p) {
+    const fe d2 = BP_FE_D2;
+    fe zinv, x, y, xy;
+    fe_invert(zinv, p.Z);
+    fe_mul(x, p.X, zinv);
+    fe_mul(y, p.Y, zinv);
+    fe_mul(xy, x, y);
+    fe_add(e.ypx, y, x);
+    fe_carry(e.ypx);
+    fe_sub(e.ymx, y, x);
+    fe_mul(e.t2d, xy, d2);
+    e.pad[0] = 0;
+    e.pad[1] = 0;
+}
+
+// thread = g * nwin + win : fill the 2^(W-1) multiples of base[g][win]
+BP_HD void fb_fill_thread(uint32_t tid, fb_params prm, const ge_ext *base, fb_entry *table) {
+    const ge_ext p = base[tid];
+    ge_cached pc;
+    ge_to_cached(pc, p);
+    ge_ext cur = p;
+    fb_entry *out = table + (uint64_t)tid * prm.half;
+    for (uint32_t k = 0; k < prm.half; k++) {
+        fb_entry e;
+        fb_entry_from_ext(e, cur);
+        out[k] = e;
+        ge_add_cached(cur, cur, pc, false);
+    }
+}
+
+// ---- scalar recoding -----------------------------------------------------------
+// Signed fixed-window recoding of a canonical scalar: add half at every window
+// position, then window value v in [0, 2^W) encodes digit d = v - half.
+BP_HD void fb_recode(uint16_t *digits /*stride*/, uint64_t stride, const uint32_t s[8], fb_params prm) {
+    // r = s + sum_win half << (W*win), computed in 9 words (288 bits)
+    uint32_t r[10];
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = s[i];
+    r[8] = 0;
+    r[9] = 0;
+    for (uint32_t win = 0; win < prm.nwin; win++) {
+        const uint32_t bit = win * prm.W + (prm.W - 1);
+        uint32_t idx = bit >> 5;
+        uint64_t t = (uint64_t)r[idx] + (1u << (bit & 31));
+        r[idx] = (uint32_t)t;
+        uint32_t carry = (uint32_t)(t >> 32);
+        while (carry && ++idx < 10) {
+            t = (uint64_t)r[idx] + carry;
+            r[idx] = (uint32_t)t;
+            carry = (uint32_t)(t >> 32);
+        }
+    }
+    for (uint32_t win = 0; win < prm.nwin; win++) {
+        const uint32_t bit = win * prm.W, idx = bit >> 5, sh = bit & 31;
+        uint64_t two = (uint64_t)r[idx] | ((uint64_t)r[idx + 1] << 32);
+        digits[(uint64_t)win * stride] = (uint16_t)((two >> sh) & ((1u << prm.W) - 1u));
+    }
+}
+
+// thread = g_local * nproofs + p : recode scalar of generator term g_local of proof p into
+// digits[(g_local*nwin + win) * nproofs + p]
+BP_HD void fb_recode_thread(uint32_t tid, fb_params prm, uint32_t nproofs, uint32_t n_gen_terms,
+                            const uint32_t *gen_scalars /*[p][g_local][8]*/, uint16_t *digits, uint32_t *status) {
+    const uint32_t g = tid / nproofs, p = tid % nproofs;
+    uint32_t s[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = gen_scalars[((uint64_t)p * n_gen_terms + g) * 8 + i];
+    if (!sc_is_canonical(s)) status[p] = BP_STATUS_BAD_SCALAR;
+    fb_recode(digits + ((uint64_t)g * prm.nwin) * nproofs + p, nproofs, s, prm);
+}
+
+// ---- accumulation -----------------------------------------------------------------
+// thread (split, p): partial[split*nproofs + p] = sum over pairs q in [q0, q1) of d(q,p) * 2^(W*win) * P_{gen_ids[g]}
+BP_HD void fb_accum_thread(uint32_t p, uint32_t split, uint32_t q0, uint32_t q1, fb_params prm, uint32_t nproofs,
+                           const uint32_t *gen_ids, const uint16_t *digits, const fb_entry *table, ge_ext *partial) {
+    ge_ext acc;
+    ge_identity(acc);
+    for (uint32_t q = q0; q < q1; q++) {
+        const uint32_t g = q / prm.nwin, win = q - g * prm.nwin;
+        const int d = (int)digits[(uint64_t)q * nproofs + p] - (int)prm.half;
+        if (d != 0) {
+            const uint32_t a = (uint32_t)(d < 0 ? -d : d);
+            const fb_entry *e = table + ((uint64_t)gen_ids[g] * prm.nwin + win) * prm.half + (a - 1);
+            ge_niels n;
+            n.ypx = e->ypx;
+            n.ymx = e->ymx;
+            n.t2d = e->t2d;
+            ge_madd(acc, acc, n, d < 0);
+        }
+    }
+    partial[(uint64_t)split * nproofs + p] = acc;
+}
+
+// ---- finish --------------------------------------------------------------------------
+// thread p: result = Horner(col[p]) (unique, variable-base terms) + sum_split partial[split][p]
+// mode bit0: write compressed result; verdict[p] = 0 identity / 1 not (or status != 0)
+BP_HD void shared_finish_thread(uint32_t p, uint32_t nproofs, uint32_t nsplit, const ge_ext *col, bool have_unique,
+                                const ge_ext *partial, const uint32_t *status, uint32_t *out_words, uint8_t *verdict) {
+    ge_ext acc;
+    if (have_unique) vb_horner_point(acc, col + (uint64_t)p * 64);
+    else ge_identity(acc);
+    for (uint32_t s = 0; s < nsplit; s++) {
+        const ge_ext q = partial[(uint64_t)s * nproofs + p];
+        ge_add(acc, acc, q);
+    }
+    const bool bad = status[p] != 0;
+    if (out_words) {
+        uint32_t w[8];
+        ristretto_compress(w, acc);
+#pragma unroll
+        for (int i = 0; i < 8; i++) out_words[8 * (uint64_t)p + i] = bad ? 0u : w[i];
+    }
+    if (verdict) verdict[p] = (bad || !ge_is_identity(acc)) ? 1 : 0;
+}
+
+}  // namespace bp
+#endif

@@ -1,0 +1,166 @@
+// Variable-base multiscalar multiplication, per-lane bodies.
+//
+// This is the engine behind bpgpu_msm_batch: the drop-in for
+// RistrettoPoint::vartime_multiscalar_mul / optional_multiscalar_mul
+// (callers: src/range_proof/mod.rs:421, src/inner_product_proof.rs:308,
+// src/r1cs/verifier.rs:459 of the reference) for arbitrary points.
+//
+// Decomposition (every stage is embarrassingly parallel; stages meet in HBM):
+//   vb_prepare : lane = term      decode point, build {1..8}P in projective
+//                                 Niels form, recode the scalar to signed
+//                                 radix-16 digits (s + 0x88..8 trick)
+//   vb_window  : lane = (chunk,w) Pippenger-style column sum with the bucket
+//                                 step replaced by the 8-entry table lookup:
+//                                 W[chunk][w] = sum_k d_{k,w} * P_k
+//   vb_colsum  : lane = (msm,w)   add the chunks' column sums
+//   vb_horner  : lane = msm       sum_w 16^w * W[w]  (252 doublings), encode
+//
+// The bodies are plain functions of (thread index, pointers) so the same code
+// runs under the CPU harness in tests/cpu_harness.
+#ifndef BPGPU_MSM_VB_H
+#define BPGPU_MSM_VB_H
+#include "ge25519.h"
+
+namespace bp {
+
+#define BP_VB_CHUNK 32      // terms per (chunk) work item
+#define BP_VB_WINDOWS 64    // signed radix-16 digits of a canonical scalar
+
+#define BP_STATUS_OK 0
+#define BP_STATUS_BAD_POINT 1
+#define BP_STATUS_BAD_SCALAR 2
+
+struct vb_chunk {
+    uint32_t msm;     // which MSM of the batch
+    uint32_t first;   // first global term index
+    uint32_t count;   // terms in this chunk (<= BP_VB_CHUNK)
+    uint32_t pad;
+};
+
+// l = 2^252 + 27742317777372353535851937790883648493, little-endian words
+#define BP_L_WORDS {0x5cf5d3edu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0u, 0u, 0u, 0x10000000u}
+
+BP_HD bool sc_is_canonical(const uint32_t s[8]) {
+    const uint32_t l[8] = BP_L_WORDS;
+    // s < l  <=>  borrow out of s - l
+    uint32_t borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t d = (uint64_t)s[i] - l[i] - borrow;
+        borrow = (uint32_t)(d >> 63);
+    }
+    return borrow != 0;
+}
+
+// signed radix-16 recoding: r = s + 0x8888...8; digit_w = nibble_w(r) - 8 in [-8, 7]
+BP_HD void sc_recode16(uint32_t r[8], const uint32_t s[8]) {
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t t = (uint64_t)s[i] + 0x88888888u + carry;
+        r[i] = (uint32_t)t;
+        carry = (uint32_t)(t >> 32);
+    }
+}
+BP_HD int sc_digit16(const uint32_t r[8], int w) {
+    return (int)((r[w >> 3] >> ((w & 7) * 4)) & 15u) - 8;
+}
+
+// ---- stage 1 ---------------------------------------------------------------
+// thread t < n_terms_total
+BP_HD void vb_prepare_thread(uint32_t t, const vb_chunk *chunks, const uint32_t *term_chunk,
+                             const uint32_t *scalars, const uint32_t *points,
+                             ge_cached *tab /*[t][8]*/, uint32_t *recoded /*[t][8]*/, uint32_t *status) {
+    uint32_t sw[8], pw[8], rw[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        sw[i] = scalars[8 * (uint64_t)t + i];
+        pw[i] = points[8 * (uint64_t)t + i];
+    }
+    const uint32_t msm = chunks[term_chunk[t]].msm;
+    ge_ext p;
+    const bool ok = ristretto_decompress(p, pw);
+    const bool canon = sc_is_canonical(sw);
+    if (!ok) status[msm] = BP_STATUS_BAD_POINT;          // benign race: same value from every lane
+    else if (!canon) status[msm] = BP_STATUS_BAD_SCALAR;
+    sc_recode16(rw, sw);
+#pragma unroll
+    for (int i = 0; i < 8; i++) recoded[8 * (uint64_t)t + i] = rw[i];
+    // multiples 1P .. 8P
+    ge_cached c1, ck;
+    ge_to_cached(c1, p);
+    ge_cached *out = tab + 8 * (uint64_t)t;
+    out[0] = c1;
+    ge_ext cur = p;
+    for (int k = 1; k < 8; k++) {
+        ge_add_cached(cur, cur, c1, false);
+        ge_to_cached(ck, cur);
+        out[k] = ck;
+    }
+}
+
+// ---- stage 2 ---------------------------------------------------------------
+// thread = chunk * 64 + w
+BP_HD void vb_window_thread(uint32_t tid, const vb_chunk *chunks, const ge_cached *tab,
+                            const uint32_t *recoded, ge_ext *part /*[chunk][64]*/) {
+    const uint32_t c = tid >> 6, w = tid & 63;
+    const vb_chunk ch = chunks[c];
+    ge_ext acc;
+    ge_identity(acc);
+    for (uint32_t k = 0; k < ch.count; k++) {
+        const uint64_t t = (uint64_t)ch.first + k;
+        const uint32_t word = recoded[8 * t + (w >> 3)];
+        const int d = (int)((word >> ((w & 7) * 4)) & 15u) - 8;
+        if (d != 0) {
+            const int a = d < 0 ? -d : d;
+            const ge_cached q = tab[8 * t + (a - 1)];
+            ge_add_cached(acc, acc, q, d < 0);
+        }
+    }
+    part[tid] = acc;
+}
+
+// ---- stage 3 ---------------------------------------------------------------
+// thread = msm * 64 + w ; chunks of one msm are contiguous: [chunk_first[msm], chunk_first[msm+1])
+BP_HD void vb_colsum_thread(uint32_t tid, const uint32_t *chunk_first, const ge_ext *part, ge_ext *col /*[msm][64]*/) {
+    const uint32_t b = tid >> 6, w = tid & 63;
+    const uint32_t c0 = chunk_first[b], c1 = chunk_first[b + 1];
+    ge_ext acc;
+    ge_identity(acc);
+    if (c1 > c0) acc = part[(uint64_t)c0 * 64 + w];
+    for (uint32_t c = c0 + 1; c < c1; c++) {
+        const ge_ext q = part[(uint64_t)c * 64 + w];
+        ge_add(acc, acc, q);
+    }
+    col[tid] = acc;
+}
+
+// ---- stage 4 ---------------------------------------------------------------
+// Horner over the 64 column sums of one MSM: acc = sum_w 16^w col[w]
+BP_HD void vb_horner_point(ge_ext &acc, const ge_ext *col /*64 entries*/) {
+    acc = col[BP_VB_WINDOWS - 1];
+    for (int w = BP_VB_WINDOWS - 2; w >= 0; w--) {
+        ge_dbl(acc, acc, false);
+        ge_dbl(acc, acc, false);
+        ge_dbl(acc, acc, false);
+        ge_dbl(acc, acc, true);
+        const ge_ext q = col[w];
+        ge_add(acc, acc, q);
+    }
+}
+
+// thread = msm
+BP_HD void vb_horner_thread(uint32_t b, const ge_ext *col, const uint32_t *status, uint32_t *out /*[msm][8]*/,
+                            ge_ext *out_ext /*optional [msm]*/) {
+    ge_ext acc;
+    vb_horner_point(acc, col + (uint64_t)b * 64);
+    uint32_t w[8];
+    ristretto_compress(w, acc);
+    const bool bad = status[b] != 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) out[8 * (uint64_t)b + i] = bad ? 0u : w[i];
+    if (out_ext) out_ext[b] = acc;
+}
+
+}  // namespace bp
+#endif

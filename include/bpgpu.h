@@ -1,0 +1,146 @@
+/* bpgpu.h -- C ABI of the MI355X-native Bulletproofs verification engine
+ * (libbpgpu.so).
+ *
+ * The reference (dalek-cryptography/bulletproofs, Rust) has no FFI layer: its
+ * verification hot path is one call into a dependency,
+ *     RistrettoPoint::optional_multiscalar_mul(scalars, points)
+ * made at src/range_proof/mod.rs:421-445 (range proofs),
+ * src/inner_product_proof.rs:308-319 (stand-alone inner-product proofs) and
+ * src/r1cs/verifier.rs:459-491 (R1CS).  This header is the boundary a Rust
+ * maintainer would bind with `extern "C"` to move that call -- and, one level
+ * up, whole batches of RangeProof::verify_multiple -- onto the GPU.  Every
+ * entry point below names the reference interface it replaces.  INTEGRATION.md
+ * shows the Rust-side binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; caller owns every buffer; nothing is
+ *     retained after a call returns (except what *_load / *_create upload).
+ *   - scalars : 32 bytes little-endian, canonical (< l), as Scalar::as_bytes().
+ *   - points  : 32 bytes, CompressedRistretto encodings (RFC 9496).
+ *   - return  : BPGPU_OK or a negative BPGPU_ERR_* code; per-item results in
+ *     status / verdict byte arrays.  The library never aborts the process.
+ *   - entry points without suffix take HOST pointers and do H2D/D2H themselves;
+ *     `_dev` twins take DEVICE pointers plus a hipStream_t (as void*; NULL =
+ *     the context's own stream), enqueue asynchronously and return.
+ *   - one context serves one device; calls on one context are serialised by an
+ *     internal mutex (the reference's calls are &self and re-entrant; use one
+ *     context per host thread for concurrency).
+ */
+#ifndef BPGPU_H
+#define BPGPU_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BPGPU_OK 0
+#define BPGPU_ERR_INVALID_ARG (-1)
+#define BPGPU_ERR_HIP (-2)         /* a HIP runtime call failed; see bpgpu_last_error */
+#define BPGPU_ERR_NO_GENS (-3)     /* generators not loaded, or too few for the request */
+#define BPGPU_ERR_NO_DEVICE (-4)
+#define BPGPU_ERR_BAD_GENERATOR (-5) /* a generator encoding passed to bpgpu_gens_load does not decode */
+
+/* per-MSM status (msm entry points) */
+#define BPGPU_MSM_OK 0
+#define BPGPU_MSM_BAD_POINT 1      /* some point failed to decode: optional_multiscalar_mul -> None */
+#define BPGPU_MSM_BAD_SCALAR 2     /* some scalar is not canonical */
+
+/* per-proof verdicts: ProofError of src/errors.rs:12-54 */
+#define BPGPU_VERDICT_OK 0
+#define BPGPU_VERDICT_VERIFICATION_ERROR 1
+#define BPGPU_VERDICT_FORMAT_ERROR 2
+#define BPGPU_VERDICT_INVALID_BITSIZE 3
+#define BPGPU_VERDICT_INVALID_GENERATORS_LENGTH 4
+
+typedef struct bpgpu_ctx bpgpu_ctx;
+
+/* ---- context ------------------------------------------------------------- */
+int bpgpu_version(void);
+/* device: HIP device ordinal.  Fails with BPGPU_ERR_NO_DEVICE when no GPU is usable
+ * (there is no CPU fallback). */
+int bpgpu_ctx_create(int device, bpgpu_ctx **out);
+void bpgpu_ctx_destroy(bpgpu_ctx *ctx);
+const char *bpgpu_last_error(bpgpu_ctx *ctx);
+/* Tunables (call before bpgpu_gens_*): "fixed_window_bits" (2..16, default 8),
+ * "fixed_splits" (0 = auto).  Returns BPGPU_ERR_INVALID_ARG for unknown keys. */
+int bpgpu_ctx_set_option(bpgpu_ctx *ctx, const char *key, int64_t value);
+int bpgpu_synchronize(bpgpu_ctx *ctx);
+
+/* ---- generators ------------------------------------------------------------
+ * Replace BulletproofGens::new(gens_capacity, party_capacity)
+ * (src/generators.rs:157-204) and PedersenGens::default() (generators.rs:44-53)
+ * as held by a verifier.  Both build the fixed-base window tables in HBM. */
+/* derive the generators on the device exactly as the reference does
+ * (SHAKE256("GeneratorsChain" || 'G'/'H' || u32le(party)) -> from_uniform_bytes;
+ *  B = basepoint, B_blinding = hash_from_bytes::<Sha3_512>(compress(B))). */
+int bpgpu_gens_create(bpgpu_ctx *ctx, size_t gens_capacity, size_t party_capacity);
+/* or load them from encodings the caller already has; G/H party-major:
+ * G[(party * gens_capacity + i) * 32], as BulletproofGens::G_vec[party][i]. */
+int bpgpu_gens_load(bpgpu_ctx *ctx, size_t gens_capacity, size_t party_capacity,
+                    const uint8_t *G, const uint8_t *H, const uint8_t B[32], const uint8_t B_blinding[32]);
+/* read back the encodings (any pointer may be NULL) */
+int bpgpu_gens_export(bpgpu_ctx *ctx, uint8_t *G, uint8_t *H, uint8_t B[32], uint8_t B_blinding[32]);
+
+/* ---- multiscalar multiplication ---------------------------------------------
+ * bpgpu_msm_batch: nbatch independent calls of
+ *   RistrettoPoint::optional_multiscalar_mul(scalars_b, points_b.decompress())
+ * (trait curve25519_dalek::traits::VartimeMultiscalarMul; call sites
+ * range_proof/mod.rs:421, inner_product_proof.rs:308, r1cs/verifier.rs:459).
+ *   n_terms[b]  : number of (scalar, point) pairs of MSM b (host array, may be 0)
+ *   scalars     : sum(n_terms) x 32 bytes, MSM after MSM
+ *   points      : sum(n_terms) x 32 bytes
+ *   out         : nbatch x 32 bytes = compress(sum_i scalars[i] * points[i]);
+ *                 all-zero when status[b] != 0
+ *   status      : nbatch bytes, BPGPU_MSM_* */
+int bpgpu_msm_batch(bpgpu_ctx *ctx, size_t nbatch, const uint32_t *n_terms,
+                    const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status);
+int bpgpu_msm_batch_dev(bpgpu_ctx *ctx, size_t nbatch, const uint32_t *n_terms_host,
+                        const void *d_scalars, const void *d_points, void *d_out, void *d_status, void *stream);
+
+/* bpgpu_msm_batch_shared: the verification "mega-check" shape
+ * (range_proof/mod.rs:421-443): every MSM of the batch is
+ *     sum_{g < 2nm+2} gen_scalars[b][g] * Gen_g  +  sum_{u < n_unique} uniq_scalars[b][u] * uniq_points[b][u]
+ * with Gen = (B_blinding, B, G(n,m)..., H(n,m)...) taken from the loaded
+ * generators in the reference's order (mod.rs:439-442).  The generator terms
+ * use the precomputed tables; results are bit-identical to bpgpu_msm_batch on
+ * the same terms.  Requires n <= gens_capacity, m <= party_capacity. */
+int bpgpu_msm_batch_shared(bpgpu_ctx *ctx, size_t n, size_t m, size_t nbatch, size_t n_unique,
+                           const uint8_t *gen_scalars, const uint8_t *uniq_scalars, const uint8_t *uniq_points,
+                           uint8_t *out, uint8_t *status);
+int bpgpu_msm_batch_shared_dev(bpgpu_ctx *ctx, size_t n, size_t m, size_t nbatch, size_t n_unique,
+                               const void *d_gen_scalars, const void *d_uniq_scalars, const void *d_uniq_points,
+                               void *d_out, void *d_status, void *stream);
+
+/* ---- range-proof verification ---------------------------------------------------
+ * nbatch independent calls of
+ *   RangeProof::from_bytes(proof)?.verify_multiple_with_rng(bp_gens, pc_gens,
+ *        &mut Transcript::new(label), &commitments, n, rng)
+ * (src/range_proof/mod.rs:345-452, 504-538) with all proofs of one shape (n, m).
+ *   proofs       : nbatch x proof_len bytes, proof_len = 32*(9 + 2*lg(n*m)) for valid input
+ *   commitments  : nbatch x m x 32 bytes (value commitments V_j)
+ *   label        : Merlin transcript label shared by the batch
+ *   rng64        : nbatch x 64 bytes = what the rng would hand Scalar::random for the
+ *                  batching challenge c (mod.rs:396); NULL = draw from the OS CSPRNG
+ *   verdict      : nbatch bytes, BPGPU_VERDICT_*  (Ok(()) == 0)
+ *   msm_out      : optional nbatch x 32 bytes, compress(mega_check) for parity tests */
+int bpgpu_rangeproof_verify_batch(bpgpu_ctx *ctx, size_t n, size_t m, size_t nbatch,
+                                  const uint8_t *proofs, size_t proof_len, const uint8_t *commitments,
+                                  const uint8_t *label, size_t label_len, const uint8_t *rng64,
+                                  uint8_t *verdict, uint8_t *msm_out);
+int bpgpu_rangeproof_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t m, size_t nbatch,
+                                      const void *d_proofs, size_t proof_len, const void *d_commitments,
+                                      const uint8_t *label, size_t label_len, const void *d_rng64,
+                                      void *d_verdict, void *d_msm_out, void *stream);
+
+/* ---- instrumentation -----------------------------------------------------------
+ * When enabled, every kernel launch is bracketed by HIP events on its stream;
+ * bpgpu_profile_report writes one line per kernel: "name launches total_ms". */
+int bpgpu_profile_enable(bpgpu_ctx *ctx, int on);
+int bpgpu_profile_reset(bpgpu_ctx *ctx);
+int bpgpu_profile_report(bpgpu_ctx *ctx, char *buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

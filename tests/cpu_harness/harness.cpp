@@ -1,0 +1,148 @@
+// CPU harness: compiles the device headers (bulletproofs_amd/csrc/*.h) with g++
+// and BP_FE_CHECK so the exact per-lane code of the HIP kernels is unit-tested
+// without a GPU.  TEST-ONLY: never part of libbpgpu.so, never a fallback.
+#define BP_FE_CHECK 1
+#include "../../bulletproofs_amd/csrc/fe25519.h"
+#include "../../bulletproofs_amd/csrc/ge25519.h"
+#include "../../bulletproofs_amd/csrc/msm_vb.h"
+#include "../../bulletproofs_amd/csrc/msm_fixed.h"
+#include <cstring>
+#include <vector>
+using namespace bp;
+
+static void load(fe &f, const uint8_t *b) { uint32_t w[8]; memcpy(w, b, 32); fe_from_words(f, w); }
+static void store(uint8_t *b, const fe &f) { uint32_t w[8]; fe_to_words(w, f); memcpy(b, w, 32); }
+
+extern "C" {
+// op: 0 mul 1 sq 2 add 3 sub 4 neg 5 invert 6 pow22523 7 carry-roundtrip 8 lazy-chain
+void h_fe_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+    fe x, y, r; load(x, a); load(y, b);
+    switch (op) {
+    case 0: fe_mul(r, x, y); break;
+    case 1: fe_sq(r, x); break;
+    case 2: fe_add(r, x, y); break;
+    case 3: fe_sub(r, x, y); break;
+    case 4: fe_neg(r, x); break;
+    case 5: fe_invert(r, x); break;
+    case 6: fe_pow22523(r, x); break;
+    case 7: r = x; fe_carry(r); break;
+    case 8: { fe t, u; fe_add(t, x, y); fe_add(t, t, x); fe_add(u, y, y); fe_add(u, u, x); fe_mul(r, t, u); fe_sq(t, t); fe_sub(r, r, t); } break;  // (2x+y)(x+2y)-(2x+y)^2
+    default: fe_0(r);
+    }
+    store(out, r);
+}
+int h_fe_flags(const uint8_t *a) { fe x; load(x, a); return (fe_isneg(x) ? 1 : 0) | (fe_iszero(x) ? 2 : 0); }
+
+int h_decompress(const uint8_t *in, uint8_t *xyzt /*4x32*/) {
+    uint32_t w[8]; memcpy(w, in, 32);
+    ge_ext p; bool ok = ristretto_decompress(p, w);
+    store(xyzt, p.X); store(xyzt + 32, p.Y); store(xyzt + 64, p.Z); store(xyzt + 96, p.T);
+    return ok ? 1 : 0;
+}
+void h_compress_xyzt(const uint8_t *xyzt, uint8_t *out) {
+    ge_ext p; load(p.X, xyzt); load(p.Y, xyzt + 32); load(p.Z, xyzt + 64); load(p.T, xyzt + 96);
+    uint32_t w[8]; ristretto_compress(w, p); memcpy(out, w, 32);
+}
+// op: 0 add 1 sub 2 dbl 3 madd(+) 4 madd(-) 5 roundtrip 6 dbl x4 (3 without T) 7 neg ; inputs compressed
+int h_point_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+    uint32_t wa[8], wb[8], wo[8]; memcpy(wa, a, 32); memcpy(wb, b, 32);
+    ge_ext p, q, r; if (!ristretto_decompress(p, wa)) return 0; if (!ristretto_decompress(q, wb)) return 0;
+    // de-normalise p so Z != 1 paths are exercised
+    ge_dbl(r, p); ge_cached pc; ge_to_cached(pc, p); ge_add_cached(p, r, pc, true);
+    ge_cached qc; ge_to_cached(qc, q);
+    ge_niels qn; qn.ypx = qc.YpX; qn.ymx = qc.YmX; qn.t2d = qc.T2d;   // q has Z = 1
+    switch (op) {
+    case 0: ge_add_cached(r, p, qc, false); break;
+    case 1: ge_add_cached(r, p, qc, true); break;
+    case 2: ge_dbl(r, p); break;
+    case 3: ge_madd(r, p, qn, false); break;
+    case 4: ge_madd(r, p, qn, true); break;
+    case 5: r = p; break;
+    case 6: r = p; ge_dbl(r, r, false); ge_dbl(r, r, false); ge_dbl(r, r, false); ge_dbl(r, r, true); ge_add_cached(r, r, qc, false); break;
+    case 7: ge_neg(r, p); break;
+    default: ge_identity(r);
+    }
+    ristretto_compress(wo, r); memcpy(out, wo, 32);
+    return (ge_is_identity(r) ? 2 : 0) | 1;
+}
+void h_from_uniform(const uint8_t *in64, uint8_t *out) {
+    uint32_t w[16], wo[8]; memcpy(w, in64, 64);
+    ge_ext r; ristretto_from_uniform(r, w); ristretto_compress(wo, r); memcpy(out, wo, 32);
+}
+
+// Emulates the 4-stage variable-base pipeline lane by lane (same bodies as the HIP kernels).
+void h_msm_vb(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, const uint8_t *points,
+              uint8_t *out, uint8_t *status_out) {
+    std::vector<vb_chunk> chunks; std::vector<uint32_t> chunk_first(nbatch + 1), term_chunk;
+    uint32_t t0 = 0;
+    for (uint32_t b = 0; b < nbatch; b++) {
+        chunk_first[b] = (uint32_t)chunks.size();
+        for (uint32_t k = 0; k < n_terms[b]; k += BP_VB_CHUNK) {
+            vb_chunk c; c.msm = b; c.first = t0 + k; c.count = n_terms[b] - k < BP_VB_CHUNK ? n_terms[b] - k : BP_VB_CHUNK; c.pad = 0;
+            for (uint32_t i = 0; i < c.count; i++) term_chunk.push_back((uint32_t)chunks.size());
+            chunks.push_back(c);
+        }
+        t0 += n_terms[b];
+    }
+    chunk_first[nbatch] = (uint32_t)chunks.size();
+    uint32_t total = t0;
+    std::vector<ge_cached> tab((size_t)total * 8 + 1);
+    std::vector<uint32_t> rec((size_t)total * 8 + 1), status(nbatch + 1, 0), outw((size_t)nbatch * 8 + 1);
+    std::vector<ge_ext> part(chunks.size() * 64 + 1), col((size_t)nbatch * 64 + 1);
+    for (uint32_t t = 0; t < total; t++)
+        vb_prepare_thread(t, chunks.data(), term_chunk.data(), (const uint32_t *)scalars, (const uint32_t *)points, tab.data(), rec.data(), status.data());
+    for (uint32_t tid = 0; tid < chunks.size() * 64; tid++) vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data());
+    for (uint32_t tid = 0; tid < nbatch * 64; tid++) vb_colsum_thread(tid, chunk_first.data(), part.data(), col.data());
+    for (uint32_t b = 0; b < nbatch; b++) vb_horner_thread(b, col.data(), status.data(), outw.data(), nullptr);
+    memcpy(out, outw.data(), (size_t)nbatch * 32);
+    for (uint32_t b = 0; b < nbatch; b++) status_out[b] = (uint8_t)status[b];
+}
+// Emulates the shared-generator pipeline (table build, recode, split accumulation, finish).
+// gens: n_gens_loaded compressed points in table order; gen_ids: n_gen_terms ids (the (n,m) subset).
+int h_msm_shared(uint32_t W, uint32_t nsplit, uint32_t n_gens_loaded, const uint8_t *gens, uint32_t n_gen_terms, const uint32_t *gen_ids,
+                 uint32_t nbatch, uint32_t n_unique, const uint8_t *gen_scalars, const uint8_t *uniq_scalars, const uint8_t *uniq_points,
+                 uint8_t *out, uint8_t *status_out, uint8_t *verdict_out) {
+    fb_params prm; prm.W = W; prm.nwin = fb_nwin(W); prm.half = 1u << (W - 1); prm.n_gens = n_gens_loaded;
+    std::vector<ge_ext> base((size_t)prm.n_gens * prm.nwin);
+    std::vector<fb_entry> table((size_t)prm.n_gens * prm.nwin * prm.half);
+    uint32_t bad = 0;
+    for (uint32_t g = 0; g < prm.n_gens; g++) fb_base_thread(g, prm, (const uint32_t *)gens, base.data(), &bad);
+    if (bad) return -5;
+    for (uint32_t t = 0; t < prm.n_gens * prm.nwin; t++) fb_fill_thread(t, prm, base.data(), table.data());
+    // unique part
+    std::vector<vb_chunk> chunks; std::vector<uint32_t> chunk_first(nbatch + 1), term_chunk;
+    uint32_t t0 = 0;
+    for (uint32_t b = 0; b < nbatch; b++) {
+        chunk_first[b] = (uint32_t)chunks.size();
+        for (uint32_t k = 0; k < n_unique; k += BP_VB_CHUNK) {
+            vb_chunk c; c.msm = b; c.first = t0 + k; c.count = n_unique - k < BP_VB_CHUNK ? n_unique - k : BP_VB_CHUNK; c.pad = 0;
+            for (uint32_t i = 0; i < c.count; i++) term_chunk.push_back((uint32_t)chunks.size());
+            chunks.push_back(c);
+        }
+        t0 += n_unique;
+    }
+    chunk_first[nbatch] = (uint32_t)chunks.size();
+    std::vector<ge_cached> tab((size_t)t0 * 8 + 1);
+    std::vector<uint32_t> rec((size_t)t0 * 8 + 1), status(nbatch + 1, 0), outw((size_t)nbatch * 8 + 1);
+    std::vector<ge_ext> part(chunks.size() * 64 + 1), col((size_t)nbatch * 64 + 1);
+    for (uint32_t t = 0; t < t0; t++)
+        vb_prepare_thread(t, chunks.data(), term_chunk.data(), (const uint32_t *)uniq_scalars, (const uint32_t *)uniq_points, tab.data(), rec.data(), status.data());
+    for (uint32_t tid = 0; tid < chunks.size() * 64; tid++) vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data());
+    for (uint32_t tid = 0; tid < nbatch * 64; tid++) vb_colsum_thread(tid, chunk_first.data(), part.data(), col.data());
+    // generator part
+    const uint32_t npairs = n_gen_terms * prm.nwin;
+    std::vector<uint16_t> digits((size_t)npairs * nbatch + 1);
+    for (uint32_t tid = 0; tid < n_gen_terms * nbatch; tid++) fb_recode_thread(tid, prm, nbatch, n_gen_terms, (const uint32_t *)gen_scalars, digits.data(), status.data());
+    std::vector<ge_ext> partial((size_t)nsplit * nbatch + 1);
+    const uint32_t per = (npairs + nsplit - 1) / nsplit;
+    for (uint32_t sp = 0; sp < nsplit; sp++) {
+        uint32_t q0 = sp * per, q1 = q0 + per < npairs ? q0 + per : npairs; if (q0 > npairs) q0 = npairs;
+        for (uint32_t p = 0; p < nbatch; p++) fb_accum_thread(p, sp, q0, q1, prm, nbatch, gen_ids, digits.data(), table.data(), partial.data());
+    }
+    std::vector<uint8_t> verdict(nbatch + 1);
+    for (uint32_t p = 0; p < nbatch; p++) shared_finish_thread(p, nbatch, nsplit, col.data(), n_unique != 0, partial.data(), status.data(), outw.data(), verdict.data());
+    memcpy(out, outw.data(), (size_t)nbatch * 32);
+    for (uint32_t b = 0; b < nbatch; b++) { status_out[b] = (uint8_t)status[b]; verdict_out[b] = verdict[b]; }
+    return 0;
+}
+}

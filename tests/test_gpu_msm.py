@@ -1,0 +1,124 @@
+"""GPU parity tests for the multiscalar-multiplication entry points (C ABI:
+bpgpu_msm_batch / bpgpu_msm_batch_shared) against the CPU oracle, on the same
+seeded inputs; bit-exact on the 32-byte ristretto encoding of every result."""
+import hashlib
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _scalar(tag):
+    L = 2**252 + 27742317777372353535851937790883648493
+    return (int.from_bytes(hashlib.shake_256(tag).digest(64), "little") % L).to_bytes(32, "little")
+
+
+def _points(oracle, seed, n):
+    import ctypes as C
+    out = C.create_string_buffer(32)
+    pts = []
+    for i in range(n):
+        oracle.lib().oracle_from_uniform_bytes(hashlib.shake_256(b"%s-p%d" % (seed, i)).digest(64), out)
+        pts.append(out.raw)
+    return b"".join(pts)
+
+
+def _rand_msm(oracle, seed, n):
+    return b"".join(_scalar(b"%s-s%d" % (seed, i)) for i in range(n)), _points(oracle, seed, n)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import bulletproofs_amd as bp
+    c = bp.Context(0)
+    yield c
+    c.close()
+
+
+def test_msm_batch_random_ragged(ctx, oracle):
+    sizes = [0, 1, 2, 31, 32, 33, 64, 147, 200, 1, 0, 700]
+    S, P = b"", b""
+    for k, n in enumerate(sizes):
+        s, p = _rand_msm(oracle, b"m%d" % k, n)
+        S += s
+        P += p
+    out, st = ctx.msm_batch(sizes, S, P)
+    off = 0
+    for k, n in enumerate(sizes):
+        exp = oracle.msm(S[off:off + 32 * n], P[off:off + 32 * n])
+        off += 32 * n
+        assert st[k] == 0 and out[32 * k:32 * k + 32] == exp[1], (k, n)
+
+
+def test_msm_batch_edge_scalars_and_bad_inputs(ctx, oracle):
+    L = 2**252 + 27742317777372353535851937790883648493
+    sp = [0, 1, L - 1, 8, int("8" * 63, 16) % L, 2**252, 7, 2**128]
+    s = b"".join(x.to_bytes(32, "little") for x in sp)
+    p = _points(oracle, b"edge", len(sp))
+    out, st = ctx.msm_batch([len(sp)], s, p)
+    assert st[0] == 0 and out == oracle.msm(s, p)[1]
+    # P + (-1)P = identity -> all-zero encoding
+    two_s = (1).to_bytes(32, "little") + (L - 1).to_bytes(32, "little")
+    out, st = ctx.msm_batch([2], two_s, p[:32] + p[:32])
+    assert st[0] == 0 and out == bytes(32)
+    # undecodable point -> status 1 (Option::None), zero output; other MSMs of the batch unaffected
+    bad = bytearray(p)
+    bad[0] |= 1
+    out, st = ctx.msm_batch([len(sp), len(sp)], s + s, bytes(bad) + p)
+    assert st[0] == 1 and out[:32] == bytes(32)
+    assert st[1] == 0 and out[32:] == oracle.msm(s, p)[1]
+    # non-canonical scalar -> status 2
+    s2 = bytearray(s)
+    s2[0:32] = L.to_bytes(32, "little")
+    out, st = ctx.msm_batch([len(sp)], bytes(s2), p)
+    assert st[0] == 2
+
+
+def test_golden_proofs_mega_check_is_identity_on_gpu(ctx, oracle, oracle_gens_64_8, golden):
+    """The 16 reference proofs (tests/range_proof.rs:16-95): the oracle expands the MSM terms
+    (mod.rs:421-443), the GPU evaluates them; every result must be the identity encoding."""
+    rng64 = hashlib.shake_256(b"golden-gpu").digest(64)
+    sizes, S, P = [], b"", b""
+    for case in golden["cases"]:
+        n, m = case["n"], case["m"]
+        rc, sc, pt = oracle.verify_terms(oracle_gens_64_8, bytes.fromhex(case["proof"]), golden["vc_bytes"][:32 * m], n,
+                                         golden["label"], rng64)
+        assert rc == 0
+        sizes.append(len(sc) // 32)
+        S += sc
+        P += pt
+    assert sizes == [29, 48, 84, 154, 47, 82, 150, 284, 81, 148, 280, 542, 147, 278, 538, 1056]
+    out, st = ctx.msm_batch(sizes, S, P)
+    assert st == bytes(16) and out == bytes(32 * 16)
+
+
+@pytest.mark.parametrize("W", [8, 5])
+def test_msm_batch_shared_matches_general_path_and_oracle(oracle, W):
+    import bulletproofs_amd as bp
+    c = bp.Context(0, fixed_window_bits=W)
+    g = oracle.Gens(16, 2)
+    G, H, B, Bb = g.export()
+    c.gens_load(16, 2, G, H, B, Bb)
+    n, m, nb, nu = 16, 2, 70, 9
+    ngen = 2 * n * m + 2
+    gen_pts = Bb + B + G[:32 * 16] + G[32 * 16:32 * 32] + H[:32 * 16] + H[32 * 16:32 * 32]
+    GS, US, UP = b"", b"", b""
+    for b in range(nb):
+        GS += b"".join(_scalar(b"g%d-%d" % (b, i)) for i in range(ngen))
+        s, p = _rand_msm(oracle, b"u%d" % b, nu)
+        US += s
+        UP += p
+    out, st = c.msm_batch_shared(n, m, nb, nu, GS, US, UP)
+    for b in range(nb):
+        scs = GS[32 * ngen * b:32 * ngen * (b + 1)] + US[32 * nu * b:32 * nu * (b + 1)]
+        pts = gen_pts + UP[32 * nu * b:32 * nu * (b + 1)]
+        exp = oracle.msm(scs, pts)
+        assert st[b] == 0 and out[32 * b:32 * b + 32] == exp[1], b
+    # smaller (n, m) than the loaded capacity selects the right generator subset (generators.rs:207-259)
+    n2, m2 = 8, 1
+    ngen2 = 2 * n2 * m2 + 2
+    gs = b"".join(_scalar(b"h%d" % i) for i in range(ngen2))
+    out, st = c.msm_batch_shared(n2, m2, 1, 0, gs, b"", b"")
+    pts = Bb + B + G[:32 * 8] + H[:32 * 8]
+    assert st[0] == 0 and out == oracle.msm(gs, pts)[1]
+    c.close()
