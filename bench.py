@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""bench.py -- 64-bit range-proof verifications/s on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one pass of the verification hot path (bpgpu_rangeproof_verify_batch_dev: proof bytes ->
+Merlin transcript replay -> scalar expansion -> multiscalar multiplication -> verdict, all on the GPU)
+over one batch of synthetic proofs per GPU.  Inputs are resident in HBM before the timed region; the
+region is bracketed by barrier + synchronize; the maximum over ranks is reported.  Proofs are independent
+units, so ranks share nothing during compute (weak scaling); the only collective is one all_gather of the
+verdict bytes at the end (RCCL).
+
+Prints ONE JSON line on rank 0 (fields per the driver contract, plus `roofline` and `cpu_baseline`).
+"""
+import argparse
+import ctypes
+import hashlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4"],
+                    help="BASELINE.json config; cfg2 (batch of 1024 single 64-bit proofs per GPU) is the metric's config")
+    ap.add_argument("--batch", type=int, default=0, help="override proofs per GPU per step")
+    ap.add_argument("--window-bits", type=int, default=0, help="fixed-base window (default: library default)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--events-outside", action="store_true",
+                    help="collect the per-kernel HIP-event timings in a second pass instead of inside the timed region")
+    return ap.parse_args()
+
+
+def cpu_baseline(fx, batch):
+    """The oracle (C restatement of the reference's algorithm: u64 5x51 field, Straus/Pippenger split) timed on
+    this box's host cores on a bounded sample of the same workload.  This is the ONLY place bench.py touches oracle/."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import pyoracle as O
+    from bulletproofs_amd.workload import tile_batch
+    cores = os.cpu_count() or 1
+    g = O.Gens(fx.n, fx.m)
+    # single-thread calibration (~0.3 s), then ~10-30 s of CPU work in total across all cores
+    cal = max(4, min(64, fx.count))
+    proofs, coms = tile_batch(fx, cal)
+    rng = hashlib.shake_256(b"cpu-baseline").digest(64 * cal)
+    t1, v, _ = O.verify_batch(g, proofs, coms, fx.m, fx.n, fx.label, rng, threads=1)
+    assert v == bytes(cal)
+    per_proof = t1 / cal
+    sample = int(max(cores * 4, min(20.0 / per_proof, 65536)))
+    proofs, coms = tile_batch(fx, sample)
+    rng = hashlib.shake_256(b"cpu-baseline2").digest(64 * sample)
+    tN, v, _ = O.verify_batch(g, proofs, coms, fx.m, fx.n, fx.label, rng, threads=cores)
+    assert v == bytes(sample)
+    return {"value": round(sample / tN, 1), "unit": "verifications/s", "cores": cores, "kind": "port",
+            "sample": "%d proofs (n=%d, m=%d) = %.1f s of CPU work on %d threads; single thread: %.1f verifications/s "
+                      "(C restatement of the reference algorithm, u64 5x51 field, Straus<190<=Pippenger; not the Rust crate)"
+                      % (sample, fx.n, fx.m, per_proof * sample, cores, 1.0 / per_proof)}
+
+
+def main():
+    a = parse_args()
+    import torch
+    import torch.distributed as dist
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if a.gpus > 1 and world != a.gpus:
+        raise SystemExit("--gpus %d needs torch.distributed.run with --nproc-per-node %d (WORLD_SIZE=%d)" % (a.gpus, a.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the engine has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    fx_name, default_batch = wl.CONFIGS[a.config]
+    fx = wl.load_fixture(fx_name)
+    batch = a.batch or default_batch
+    n, m = fx.n, fx.m
+    N_terms = wl.msm_terms(n, m)
+
+    ctx = bp.Context(local_rank, fixed_window_bits=a.window_bits or None)
+    ctx.gens_create(n, m)
+    L = bp.lib()
+
+    # this rank's shard of the global batch (weak scaling: `batch` proofs per GPU), resident in HBM
+    lo = rank * batch
+    proofs_b, coms_b = wl.tile_batch(fx, batch, first=lo)
+    rng_b = hashlib.shake_256(b"bench-rng-%d" % rank).digest(64 * batch)
+    d_proofs = torch.frombuffer(bytearray(proofs_b), dtype=torch.uint8).to(dev)
+    d_coms = torch.frombuffer(bytearray(coms_b), dtype=torch.uint8).to(dev)
+    d_rng = torch.frombuffer(bytearray(rng_b), dtype=torch.uint8).to(dev)
+    d_verdicts = torch.full((max(a.steps, 1), batch), 255, dtype=torch.uint8, device=dev)
+    stream = torch.cuda.current_stream()
+
+    def step(i):
+        rc = L.bpgpu_rangeproof_verify_batch_dev(ctx.h, n, m, batch, d_proofs.data_ptr(), fx.proof_len, d_coms.data_ptr(),
+                                                 fx.label, len(fx.label), d_rng.data_ptr(),
+                                                 d_verdicts[i % d_verdicts.shape[0]].data_ptr(), None, stream.cuda_stream)
+        if rc != 0:
+            raise RuntimeError("bpgpu_rangeproof_verify_batch_dev failed: %s" % L.bpgpu_last_error(ctx.h).decode())
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        step(i)
+    fence()
+    in_region_events = not a.events_outside
+    ctx.profile_reset()
+    ctx.profile_enable(in_region_events)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        step(i)
+    if world > 1:   # the final identity-check gather: every rank's verdict bytes, one collective
+        gathered = [torch.empty_like(d_verdicts) for _ in range(world)]
+        dist.all_gather(gathered, d_verdicts)
+    fence()
+    elapsed = time.perf_counter() - t0
+    ctx.profile_enable(False)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        all_v = torch.stack(gathered)
+    else:
+        all_v = d_verdicts.unsqueeze(0)
+    ok = bool((all_v[:, :min(a.steps, all_v.shape[1])] == 0).all().item()) if a.steps else True
+    if not ok:
+        raise SystemExit("verification verdicts are not all Ok -- result invalid")
+
+    if not in_region_events:   # second pass, same steps, only to time the kernels
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        for i in range(a.steps):
+            step(i)
+        fence()
+        ctx.profile_enable(False)
+    kern = ctx.profile_report()
+
+    if rank == 0:
+        value = world * batch * a.steps / elapsed
+        # dominant kernel and its roofline.  Algorithmic bytes per verification at the MSM boundary
+        # (SURVEY.md 8d): 32 N + 32 (4+2k+m) + 32; one launch processes `batch` verifications.
+        dom = max(kern.items(), key=lambda kv: kv[1][1])[0] if kern else None
+        roof = None
+        if dom:
+            cnt, ms = kern[dom]
+            avg_s = ms / cnt * 1e-3
+            alg_bytes = wl.algorithmic_bytes_per_verification(n, m) * batch
+            achieved = alg_bytes / avg_s / 1e9
+            traffic = None
+            tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % a.config)
+            if os.path.exists(tpath):   # HBM bytes/launch of this kernel from the committed rocprofv3 --pmc passes
+                with open(tpath) as f:
+                    traffic = json.load(f).get(dom)
+            roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
+                    "frac": achieved / 8000.0, "traffic": traffic,
+                    "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt,
+                    "algorithmic_bytes_per_launch": alg_bytes,
+                    "timing": "hip events on the launch stream, %s the timed region" % ("inside" if in_region_events else "second pass after"),
+                    # the binding resource is integer VALU issue, not HBM: also report it
+                    "valu": {"reference_point_ops_per_s": wl.reference_point_ops(N_terms) * value,
+                             "measured_peak_madd_per_s": 3.14e10,
+                             "note": "A(N)=%d point ops per MSM by the reference's own algorithm x verifications/s; "
+                                     "peak = ge_madd microbenchmark (profiles/r01_microbench_valu_rates.txt)" % wl.reference_point_ops(N_terms)},
+                    "kernels_us": {k: round(v[1] / v[0] * 1e3, 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}}
+        out = {
+            "metric": "64-bit rangeproof verifications/sec (batched)",
+            "value": round(value, 1),
+            "unit": "verifications/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(elapsed / max(a.steps, 1) * 1e3, 4),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32 limbs (10x25.5-bit GF(2^255-19), 8x32-bit scalars mod l), u64 accumulators",
+            "data": "synthetic (oracle-proved range proofs, bench_data/%s.bin, tiled to the batch; all verdicts checked Ok)" % fx_name,
+            "config": {"workload": "%s: batch of %d %s%d-bit range proofs per GPU, proof bytes -> verdict on device "
+                                   "(MSM of %d terms each)" % (a.config, batch, ("aggregated m=%d " % m) if m > 1 else "single ", n, N_terms),
+                       "n": n, "m": m, "batch_per_gpu": batch, "global_batch": batch * world, "msm_terms": N_terms,
+                       "fixed_window_bits": a.window_bits or 8, "parallelism": "independent proofs sharded, dp%d" % world},
+            "roofline": roof,
+        }
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(fx, batch)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()

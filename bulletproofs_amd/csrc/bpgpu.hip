@@ -98,6 +98,50 @@ __global__ void __launch_bounds__(64) k_shared_finish(uint32_t nproofs, uint32_t
     if (p < nproofs) shared_finish_thread(p, nproofs, nsplit, col, have_unique != 0, partial, status, out_words, verdict);
 }
 
+
+// ---- range-proof front end ----------------------------------------------------
+#define RP_BLOCK 64
+__global__ void __launch_bounds__(RP_BLOCK) k_rp_transcript(rp_shape sh, rp_strobe_init init, const uint8_t *proofs,
+                                                             const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields,
+                                                             uint32_t *uniq_points, uint32_t *status) {
+    __shared__ uint32_t lds[50 * RP_BLOCK];   // sponge states, word-major: word w of lane t at w*RP_BLOCK + t
+    const uint32_t p = blockIdx.x * RP_BLOCK + threadIdx.x;
+    kstate st;
+    st.w = lds + threadIdx.x;
+    st.stride = RP_BLOCK;
+    if (p < sh.nproofs) rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields, uniq_points, status);
+}
+
+__global__ void __launch_bounds__(64) k_rp_expand_a(rp_shape sh, fb_params prm, uint32_t lg_m, uint32_t *fields, uint32_t *uniq_scalars,
+                                                     uint16_t *digits, const uint32_t *status) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < sh.nproofs) rp_expand_a_thread(p, sh, prm, lg_m, fields, uniq_scalars, digits, status);
+}
+
+__global__ void __launch_bounds__(BP_BLOCK) k_rp_expand_b(uint32_t nthreads, rp_shape sh, fb_params prm, const uint32_t *fields,
+                                                           uint16_t *digits, const uint32_t *status) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < nthreads) rp_expand_b_thread(tid, sh, prm, fields, digits, status);
+}
+
+// verdict[p] = status (Format / shape / Verification) if set, else the identity test of the mega-check
+__global__ void __launch_bounds__(64) k_rp_verdict(uint32_t n, const uint32_t *status, const uint8_t *msm_verdict, uint8_t *out) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) out[p] = status[p] ? (uint8_t)status[p] : msm_verdict[p];
+}
+
+// generator derivation: 64 uniform bytes -> RistrettoPoint::from_uniform_bytes -> encoding
+__global__ void __launch_bounds__(64) k_from_uniform(uint32_t n, const uint32_t *uniform, uint32_t *out) {
+    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
+    if (g >= n) return;
+    uint32_t w[16], o[8];
+    for (int i = 0; i < 16; i++) w[i] = uniform[16 * (uint64_t)g + i];
+    ge_ext r;
+    ristretto_from_uniform(r, w);
+    ristretto_compress(o, r);
+    for (int i = 0; i < 8; i++) out[8 * (uint64_t)g + i] = o[i];
+}
+
 // ============================================================================
 // host runtime
 // ============================================================================
@@ -650,7 +694,253 @@ extern "C" int bpgpu_msm_batch_shared(bpgpu_ctx *c, size_t n, size_t m, size_t n
     return rc;
 }
 
-// TEMPORARY (first bring-up run only; replaced by the device transcript pipeline before commit)
-extern "C" int bpgpu_gens_create(bpgpu_ctx *c, size_t, size_t) { return fail(c, BPGPU_ERR_INVALID_ARG, "not built yet"); }
-extern "C" int bpgpu_rangeproof_verify_batch(bpgpu_ctx *c, size_t, size_t, size_t, const uint8_t *, size_t, const uint8_t *, const uint8_t *, size_t, const uint8_t *, uint8_t *, uint8_t *) { return fail(c, BPGPU_ERR_INVALID_ARG, "not built yet"); }
-extern "C" int bpgpu_rangeproof_verify_batch_dev(bpgpu_ctx *c, size_t, size_t, size_t, const void *, size_t, const void *, const uint8_t *, size_t, const void *, void *, void *, void *) { return fail(c, BPGPU_ERR_INVALID_ARG, "not built yet"); }
+// ============================================================================
+// generator derivation on the device (BulletproofGens::new, PedersenGens::default)
+// ============================================================================
+static void host_shake_chain(std::vector<uint8_t> &out, uint8_t tag, uint32_t party, size_t count) {
+    // GeneratorsChain::new(label): SHAKE256("GeneratorsChain" || tag || u32le(party))  (generators.rs:64-72,186-201)
+    uint32_t w[50];
+    kstate st;
+    st.w = w;
+    st.stride = 1;
+    sponge k;
+    sponge_init(k, st, BP_SHAKE256_RATE);
+    const uint8_t dom[15] = {'G', 'e', 'n', 'e', 'r', 'a', 't', 'o', 'r', 's', 'C', 'h', 'a', 'i', 'n'};
+    const uint8_t label[5] = {tag, (uint8_t)party, (uint8_t)(party >> 8), (uint8_t)(party >> 16), (uint8_t)(party >> 24)};
+    sponge_absorb(k, dom, 15);
+    sponge_absorb(k, label, 5);
+    sponge_finish(k, 0x1f);
+    const size_t off = out.size();
+    out.resize(off + 64 * count);
+    sponge_squeeze(k, out.data() + off, (uint32_t)(64 * count));
+}
+
+static const uint8_t BASEPOINT_COMPRESSED[32] = {0xe2, 0xf2, 0xae, 0x0a, 0x6a, 0xbc, 0x4e, 0x71, 0xa8, 0x84, 0xa9,
+                                                 0x61, 0xc5, 0x00, 0x51, 0x5f, 0x58, 0xe3, 0x0b, 0x6a, 0xa5, 0x82,
+                                                 0xdd, 0x8d, 0xb6, 0xa6, 0x59, 0x45, 0xe0, 0x8d, 0x2d, 0x76};
+
+extern "C" int bpgpu_gens_create(bpgpu_ctx *c, size_t gens_capacity, size_t party_capacity) {
+    if (!c || gens_capacity == 0 || party_capacity == 0) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t tot = gens_capacity * party_capacity;
+    // uniform bytes: [B_blinding seed][G party 0..][H party 0..]
+    std::vector<uint8_t> uni;
+    {
+        uint32_t w[50];
+        kstate st;
+        st.w = w;
+        st.stride = 1;
+        sponge k;
+        sponge_init(k, st, BP_SHA3_512_RATE);   // hash_from_bytes::<Sha3_512>(compress(B))  (generators.rs:48)
+        sponge_absorb(k, BASEPOINT_COMPRESSED, 32);
+        sponge_finish(k, 0x06);
+        uni.resize(64);
+        sponge_squeeze(k, uni.data(), 64);
+    }
+    for (size_t p = 0; p < party_capacity; p++) host_shake_chain(uni, 'G', (uint32_t)p, gens_capacity);
+    for (size_t p = 0; p < party_capacity; p++) host_shake_chain(uni, 'H', (uint32_t)p, gens_capacity);
+    const uint32_t cnt = (uint32_t)(1 + 2 * tot);
+    uint32_t *d_uni = nullptr, *d_out = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_uni, uni.size()));
+    HIPCHK(c, hipMalloc((void **)&d_out, (size_t)cnt * 32));
+    HIPCHK(c, hipMemcpyAsync(d_uni, uni.data(), uni.size(), hipMemcpyHostToDevice, c->stream));
+    LAUNCH(c, c->stream, "from_uniform", k_from_uniform, (cnt + 63) / 64, 64, cnt, d_uni, d_out);
+    std::vector<uint8_t> enc((size_t)cnt * 32);
+    HIPCHK(c, hipMemcpyAsync(enc.data(), d_out, enc.size(), hipMemcpyDeviceToHost, c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    hipFree(d_uni);
+    hipFree(d_out);
+    return load_gens_locked(c, gens_capacity, party_capacity, enc.data() + 32, enc.data() + 32 + tot * 32, BASEPOINT_COMPRESSED,
+                            enc.data());
+}
+
+// ============================================================================
+// range-proof verification
+// ============================================================================
+#include <sys/random.h>
+
+static void make_strobe_init(rp_strobe_init &init, const uint8_t *label, size_t label_len, uint64_t n, uint64_t m) {
+    // Transcript::new(label) followed by rangeproof_domain_sep(n, m) (transcript.rs:44-48): identical for
+    // every proof of the batch, so it is replayed once here and the kernel starts from this state
+    kstate st;
+    st.w = init.w;
+    st.stride = 1;
+    strobe t;
+    merlin_strobe_init(t, st);
+    const uint8_t dom[7] = {'d', 'o', 'm', '-', 's', 'e', 'p'};
+    const uint8_t rp[13] = {'r', 'a', 'n', 'g', 'e', 'p', 'r', 'o', 'o', 'f', ' ', 'v', '1'};
+    const uint8_t ln[1] = {'n'}, lm[1] = {'m'};
+    merlin_append_message(t, dom, 7, label, (uint32_t)label_len);
+    merlin_append_message(t, dom, 7, rp, 13);
+    merlin_append_u64(t, ln, 1, n);
+    merlin_append_u64(t, lm, 1, m);
+    init.pos = t.pos;
+    init.pos_begin = t.pos_begin;
+    init.cur_flags = t.cur_flags;
+}
+
+static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
+                                const void *d_commitments, const uint8_t *label, size_t label_len, const void *d_rng64, void *d_verdict,
+                                void *d_msm_out, hipStream_t s) {
+    if (nbatch == 0) return BPGPU_OK;
+    if (!c->d_table) return fail(c, BPGPU_ERR_NO_GENS, "generators not loaded");
+    if (nbatch > 0x7fffffffu / 64) return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large");
+    // ---- length-only part of RangeProof::from_bytes / InnerProductProof::from_bytes (mod.rs:505-510, ipp.rs:374-388)
+    uint32_t all_verdict = 0;
+    size_t k = 0;
+    if (proof_len % 32 != 0 || proof_len < 7 * 32) all_verdict = BPGPU_VERDICT_FORMAT_ERROR;
+    else {
+        const size_t ne = (proof_len - 7 * 32) / 32;
+        if (ne < 2 || (ne - 2) % 2 != 0) all_verdict = BPGPU_VERDICT_FORMAT_ERROR;
+        else {
+            k = (ne - 2) / 2;
+            if (k >= 32) all_verdict = BPGPU_VERDICT_FORMAT_ERROR;
+        }
+    }
+    if (all_verdict) {   // every proof of the batch has the same malformed length
+        HIPCHK(c, hipMemsetAsync(d_verdict, (int)all_verdict, nbatch, s));
+        if (d_msm_out) HIPCHK(c, hipMemsetAsync(d_msm_out, 0, nbatch * 32, s));
+        return BPGPU_OK;
+    }
+    // ---- parameter checks of verify_multiple_with_rng (mod.rs:358-366), reported per proof AFTER its format check
+    uint32_t shape_verdict = 0;
+    if (!(n == 8 || n == 16 || n == 32 || n == 64)) shape_verdict = BPGPU_VERDICT_INVALID_BITSIZE;
+    else if (c->gens_capacity < n || c->party_capacity < m) shape_verdict = BPGPU_VERDICT_INVALID_GENERATORS_LENGTH;
+    else if (m == 0 || n * m != ((size_t)1 << k)) shape_verdict = BPGPU_VERDICT_VERIFICATION_ERROR;   // ipp.rs:209
+    if (!shape_verdict && k > BP_RP_MAX_K) return fail(c, BPGPU_ERR_INVALID_ARG, "n*m > 2^%d not supported", BP_RP_MAX_K);
+
+    rp_shape sh;
+    sh.n = (uint32_t)n;
+    sh.m = (uint32_t)m;
+    sh.nm = (uint32_t)(n * m);
+    sh.k = (uint32_t)k;
+    sh.U = (uint32_t)(4 + 2 * k + m);
+    sh.proof_len = (uint32_t)proof_len;
+    sh.nproofs = (uint32_t)nbatch;
+    sh.shape_verdict = shape_verdict;
+    uint32_t lg_m = 0;
+    while (((size_t)1 << lg_m) < m) lg_m++;
+    const fb_params prm = c->prm;
+    const uint32_t n_gen_terms = shape_verdict ? 2 : (uint32_t)(2 * n * m + 2);
+    const uint32_t npairs = n_gen_terms * prm.nwin;
+    const rp_fields fl = rp_field_layout(sh.k, sh.m);
+    uint32_t *d_ids = nullptr;
+    int rc;
+    if (!shape_verdict) {
+        rc = gen_ids_for(c, n, m, &d_ids);
+        if (rc) return rc;
+    }
+    std::vector<uint32_t> nt(nbatch, shape_verdict ? 0u : sh.U);
+    vb_plan pl;
+    make_vb_plan(pl, nbatch, nt.data());
+    const uint32_t nsplit = pick_splits(c, nbatch, npairs);
+    arena_plan ap;
+    size_t off[7];
+    plan_vb(ap, pl, nbatch, off);
+    const size_t off_status = ap.add(nbatch * 4);
+    const size_t off_digits = ap.add((size_t)npairs * nbatch * 2 + 16);
+    const size_t off_partial = ap.add((size_t)nsplit * nbatch * sizeof(ge_ext) + 16);
+    const size_t off_fields = ap.add((size_t)fl.count * nbatch * 32 + 16);
+    const size_t off_upts = ap.add((size_t)sh.U * nbatch * 32 + 16);
+    const size_t off_usc = ap.add((size_t)sh.U * nbatch * 32 + 16);
+    const size_t off_mv = ap.add(nbatch);
+    const size_t off_rng = ap.add(nbatch * 64);
+    rc = arena_reserve(c, ap.total);
+    if (rc) return rc;
+    char *a = c->arena;
+    uint32_t *d_status = (uint32_t *)(a + off_status);
+    uint16_t *d_digits = (uint16_t *)(a + off_digits);
+    ge_ext *d_partial = (ge_ext *)(a + off_partial);
+    uint32_t *d_fields = (uint32_t *)(a + off_fields), *d_upts = (uint32_t *)(a + off_upts), *d_usc = (uint32_t *)(a + off_usc);
+    uint8_t *d_mv = (uint8_t *)(a + off_mv);
+    const uint8_t *rng_ptr = (const uint8_t *)d_rng64;
+    if (!rng_ptr) {   // thread_rng() stand-in: OS CSPRNG (verify_multiple, mod.rs:455-470)
+        std::vector<uint8_t> h(nbatch * 64);
+        size_t got = 0;
+        while (got < h.size()) {
+            const ssize_t r = getrandom(h.data() + got, h.size() - got, 0);
+            if (r <= 0) return fail(c, BPGPU_ERR_HIP, "getrandom failed");
+            got += (size_t)r;
+        }
+        HIPCHK(c, hipMemcpyAsync(a + off_rng, h.data(), h.size(), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));   // h goes out of scope
+        rng_ptr = (const uint8_t *)(a + off_rng);
+    }
+    HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
+    HIPCHK(c, hipMemsetAsync(d_upts, 0, (size_t)sh.U * nbatch * 32, s));   // rejected proofs contribute identity terms
+    HIPCHK(c, hipMemsetAsync(d_usc, 0, (size_t)sh.U * nbatch * 32, s));
+    rp_strobe_init init;
+    make_strobe_init(init, label, label_len, n, m);
+    const uint32_t nb32 = (uint32_t)nbatch;
+    LAUNCH(c, s, "rp_transcript", k_rp_transcript, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, init, (const uint8_t *)d_proofs,
+           (const uint8_t *)d_commitments, rng_ptr, d_fields, d_upts, d_status);
+    if (shape_verdict) {
+        HIPCHK(c, hipMemsetAsync(d_mv, 1, nbatch, s));
+        LAUNCH(c, s, "rp_verdict", k_rp_verdict, (nb32 + 63) / 64, 64, nb32, d_status, d_mv, (uint8_t *)d_verdict);
+        if (d_msm_out) HIPCHK(c, hipMemsetAsync(d_msm_out, 0, nbatch * 32, s));
+        HIPCHK(c, hipGetLastError());
+        return BPGPU_OK;
+    }
+    LAUNCH(c, s, "rp_expand_a", k_rp_expand_a, (nb32 + 63) / 64, 64, sh, prm, lg_m, d_fields, d_usc, d_digits, d_status);
+    const uint32_t nexp = sh.nm * nb32;
+    LAUNCH(c, s, "rp_expand_b", k_rp_expand_b, (nexp + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
+    vb_dev d{};
+    rc = enqueue_vb(c, s, pl, nbatch, off, d_usc, d_upts, d_status, d);
+    if (rc) return rc;
+    const uint32_t nblk_p = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
+    LAUNCH(c, s, "fb_accum", k_fb_accum, nblk_p * nsplit, FB_BLOCK, prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, c->d_table,
+           d_partial);
+    LAUNCH(c, s, "shared_finish", k_shared_finish, (nb32 + 63) / 64, 64, nb32, nsplit, d.col, 1, d_partial, d_status,
+           (uint32_t *)d_msm_out, d_mv);
+    LAUNCH(c, s, "rp_verdict", k_rp_verdict, (nb32 + 63) / 64, 64, nb32, d_status, d_mv, (uint8_t *)d_verdict);
+    HIPCHK(c, hipGetLastError());
+    return BPGPU_OK;
+}
+
+extern "C" int bpgpu_rangeproof_verify_batch_dev(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
+                                                 const void *d_commitments, const uint8_t *label, size_t label_len, const void *d_rng64,
+                                                 void *d_verdict, void *d_msm_out, void *stream) {
+    if (!c || (nbatch && (!d_proofs || !d_verdict || (m && !d_commitments))) || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
+    if (((uintptr_t)d_proofs | (uintptr_t)d_commitments | (uintptr_t)d_rng64) & 3)
+        return fail(c, BPGPU_ERR_INVALID_ARG, "device buffers must be 4-byte aligned");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return rp_verify_dev_locked(c, n, m, nbatch, d_proofs, proof_len, d_commitments, label, label_len, d_rng64, d_verdict, d_msm_out,
+                                stream ? (hipStream_t)stream : c->stream);
+}
+
+extern "C" int bpgpu_rangeproof_verify_batch(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len,
+                                             const uint8_t *commitments, const uint8_t *label, size_t label_len, const uint8_t *rng64,
+                                             uint8_t *verdict, uint8_t *msm_out) {
+    if (!c || (nbatch && (!proofs || !verdict || (m && !commitments))) || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0) return BPGPU_OK;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t sz_p = align_up(nbatch * proof_len + 64), sz_c = align_up(nbatch * m * 32 + 64), sz_r = align_up(nbatch * 64),
+                 sz_v = align_up(nbatch), sz_o = align_up(nbatch * 32);
+    char *d_io = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_io, sz_p + sz_c + sz_r + sz_v + sz_o));
+    char *d_p = d_io, *d_c = d_p + sz_p, *d_r = d_c + sz_c, *d_v = d_r + sz_r, *d_o = d_v + sz_v;
+    hipStream_t s = c->stream;
+    int rc = BPGPU_OK;
+    do {
+        if (hipMemcpyAsync(d_p, proofs, nbatch * proof_len, hipMemcpyHostToDevice, s) != hipSuccess ||
+            (m && hipMemcpyAsync(d_c, commitments, nbatch * m * 32, hipMemcpyHostToDevice, s) != hipSuccess) ||
+            (rng64 && hipMemcpyAsync(d_r, rng64, nbatch * 64, hipMemcpyHostToDevice, s) != hipSuccess)) {
+            rc = fail(c, BPGPU_ERR_HIP, "H2D copy failed");
+            break;
+        }
+        rc = rp_verify_dev_locked(c, n, m, nbatch, d_p, proof_len, d_c, label, label_len, rng64 ? d_r : nullptr, d_v, msm_out ? d_o : nullptr, s);
+        if (rc) break;
+        if (hipMemcpyAsync(verdict, d_v, nbatch, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            (msm_out && hipMemcpyAsync(msm_out, d_o, nbatch * 32, hipMemcpyDeviceToHost, s) != hipSuccess) ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(c, BPGPU_ERR_HIP, "D2H copy / sync failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+    } while (0);
+    hipStreamSynchronize(s);
+    hipFree(d_io);
+    return rc;
+}

@@ -1,0 +1,239 @@
+// Keccak-f[1600], SHAKE256 / SHA3-512 and the Merlin transcript (STROBE-128)
+// for host and device.
+//
+// Replaces, on the verification path, the reference's use of merlin ^2
+// (src/transcript.rs:43-95: append_message / append_u64 / challenge_bytes) and
+// of sha3 0.8 (src/generators.rs:48, 64-72).  The 200-byte sponge state is
+// accessed through `kstate`, an array of 50 u32 words with a stride: on the
+// device it points into LDS with stride = workgroup size (word w of lane t at
+// w*stride + t: conflict-free, and byte positions that are uniform across the
+// wavefront need no register indexing); on the host the stride is 1.
+#ifndef BPGPU_KECCAK_H
+#define BPGPU_KECCAK_H
+#include "fe25519.h"
+
+namespace bp {
+
+struct kstate {
+    uint32_t *w;       // word i at w[i * stride]
+    uint32_t stride;
+};
+
+BP_HD uint32_t ks_get32(const kstate &s, uint32_t i) { return s.w[i * s.stride]; }
+BP_HD void ks_set32(const kstate &s, uint32_t i, uint32_t v) { s.w[i * s.stride] = v; }
+BP_HD void ks_xor8(const kstate &s, uint32_t pos, uint32_t b) { s.w[(pos >> 2) * s.stride] ^= b << (8 * (pos & 3)); }
+BP_HD uint32_t ks_get8(const kstate &s, uint32_t pos) { return (s.w[(pos >> 2) * s.stride] >> (8 * (pos & 3))) & 0xffu; }
+BP_HD void ks_clear8(const kstate &s, uint32_t pos) { s.w[(pos >> 2) * s.stride] &= ~(0xffu << (8 * (pos & 3))); }
+BP_HD void ks_zero(const kstate &s) {
+    for (uint32_t i = 0; i < 50; i++) ks_set32(s, i, 0);
+}
+
+BP_HD uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+
+// 24 rounds on 25 lanes held in registers (all indices static after unrolling)
+BP_HD void keccak_f1600_lanes(uint64_t a[25]) {
+    const uint64_t RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    for (int r = 0; r < 24; r++) {
+        uint64_t c[5], d[5], b[25];
+#pragma unroll
+        for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+#pragma unroll
+        for (int x = 0; x < 5; x++) d[x] = c[(x + 4) % 5] ^ rotl64(c[(x + 1) % 5], 1);
+#pragma unroll
+        for (int i = 0; i < 25; i++) a[i] ^= d[i % 5];
+        // rho + pi : b[y, 2x+3y] = rot(a[x, y])
+        b[0] = a[0];
+        b[10] = rotl64(a[1], 1);   b[20] = rotl64(a[2], 62);  b[5] = rotl64(a[3], 28);   b[15] = rotl64(a[4], 27);
+        b[16] = rotl64(a[5], 36);  b[1] = rotl64(a[6], 44);   b[11] = rotl64(a[7], 6);   b[21] = rotl64(a[8], 55);
+        b[6] = rotl64(a[9], 20);   b[7] = rotl64(a[10], 3);   b[17] = rotl64(a[11], 10); b[2] = rotl64(a[12], 43);
+        b[12] = rotl64(a[13], 25); b[22] = rotl64(a[14], 39); b[23] = rotl64(a[15], 41); b[8] = rotl64(a[16], 45);
+        b[18] = rotl64(a[17], 15); b[3] = rotl64(a[18], 21);  b[13] = rotl64(a[19], 8);  b[14] = rotl64(a[20], 18);
+        b[24] = rotl64(a[21], 2);  b[9] = rotl64(a[22], 61);  b[19] = rotl64(a[23], 56); b[4] = rotl64(a[24], 14);
+#pragma unroll
+        for (int y = 0; y < 25; y += 5) {
+#pragma unroll
+            for (int x = 0; x < 5; x++) a[y + x] = b[y + x] ^ ((~b[y + (x + 1) % 5]) & b[y + (x + 2) % 5]);
+        }
+        a[0] ^= RC[r];
+    }
+}
+
+BP_HD void keccak_f1600(const kstate &s) {
+    uint64_t a[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) a[i] = (uint64_t)ks_get32(s, 2 * i) | ((uint64_t)ks_get32(s, 2 * i + 1) << 32);
+    keccak_f1600_lanes(a);
+#pragma unroll
+    for (int i = 0; i < 25; i++) {
+        ks_set32(s, 2 * i, (uint32_t)a[i]);
+        ks_set32(s, 2 * i + 1, (uint32_t)(a[i] >> 32));
+    }
+}
+
+// ---- plain sponges (generator derivation) -------------------------------------
+struct sponge {
+    kstate st;
+    uint32_t pos, rate;
+};
+BP_HD void sponge_init(sponge &k, kstate st, uint32_t rate) {
+    k.st = st;
+    k.pos = 0;
+    k.rate = rate;
+    ks_zero(st);
+}
+BP_HD void sponge_absorb(sponge &k, const uint8_t *in, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) {
+        ks_xor8(k.st, k.pos++, in[i]);
+        if (k.pos == k.rate) {
+            keccak_f1600(k.st);
+            k.pos = 0;
+        }
+    }
+}
+BP_HD void sponge_finish(sponge &k, uint32_t suffix) {
+    ks_xor8(k.st, k.pos, suffix);
+    ks_xor8(k.st, k.rate - 1, 0x80);
+    keccak_f1600(k.st);
+    k.pos = 0;
+}
+BP_HD void sponge_squeeze(sponge &k, uint8_t *out, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) {
+        if (k.pos == k.rate) {
+            keccak_f1600(k.st);
+            k.pos = 0;
+        }
+        out[i] = (uint8_t)ks_get8(k.st, k.pos++);
+    }
+}
+#define BP_SHAKE256_RATE 136
+#define BP_SHA3_512_RATE 72
+
+// ---- STROBE-128 as used by Merlin -------------------------------------------
+#define BP_STROBE_R 166
+#define BP_FLAG_I 1
+#define BP_FLAG_A 2
+#define BP_FLAG_C 4
+#define BP_FLAG_T 8
+#define BP_FLAG_M 16
+#define BP_FLAG_K 32
+
+struct strobe {
+    kstate st;
+    uint32_t pos, pos_begin, cur_flags;
+};
+
+BP_HD void strobe_run_f(strobe &t) {
+    ks_xor8(t.st, t.pos, t.pos_begin);
+    ks_xor8(t.st, t.pos + 1, 0x04);
+    ks_xor8(t.st, BP_STROBE_R + 1, 0x80);
+    keccak_f1600(t.st);
+    t.pos = 0;
+    t.pos_begin = 0;
+}
+BP_HD void strobe_absorb1(strobe &t, uint32_t b) {
+    ks_xor8(t.st, t.pos++, b);
+    if (t.pos == BP_STROBE_R) strobe_run_f(t);
+}
+BP_HD void strobe_absorb(strobe &t, const uint8_t *d, uint32_t n) {
+    for (uint32_t i = 0; i < n; i++) strobe_absorb1(t, d[i]);
+}
+// absorb n32 little-endian words (messages that already sit in registers)
+BP_HD void strobe_absorb_words(strobe &t, const uint32_t *w, uint32_t n32) {
+    for (uint32_t i = 0; i < n32; i++) {
+        const uint32_t x = w[i];
+        strobe_absorb1(t, x & 0xff);
+        strobe_absorb1(t, (x >> 8) & 0xff);
+        strobe_absorb1(t, (x >> 16) & 0xff);
+        strobe_absorb1(t, x >> 24);
+    }
+}
+BP_HD uint32_t strobe_squeeze1(strobe &t) {
+    const uint32_t b = ks_get8(t.st, t.pos);
+    ks_clear8(t.st, t.pos++);
+    if (t.pos == BP_STROBE_R) strobe_run_f(t);
+    return b;
+}
+BP_HD void strobe_begin_op(strobe &t, uint32_t flags, bool more) {
+    if (more) return;   // continuation of the current operation (flags must equal cur_flags)
+    const uint32_t old_begin = t.pos_begin;
+    t.pos_begin = t.pos + 1;
+    t.cur_flags = flags;
+    strobe_absorb1(t, old_begin);
+    strobe_absorb1(t, flags);
+    if ((flags & (BP_FLAG_C | BP_FLAG_K)) && t.pos != 0) strobe_run_f(t);
+}
+BP_HD void strobe_meta_ad(strobe &t, const uint8_t *d, uint32_t n, bool more) {
+    strobe_begin_op(t, BP_FLAG_M | BP_FLAG_A, more);
+    strobe_absorb(t, d, n);
+}
+BP_HD void strobe_ad(strobe &t, const uint8_t *d, uint32_t n, bool more) {
+    strobe_begin_op(t, BP_FLAG_A, more);
+    strobe_absorb(t, d, n);
+}
+BP_HD void strobe_meta_len(strobe &t, uint32_t n) {
+    strobe_begin_op(t, BP_FLAG_M | BP_FLAG_A, true);
+    strobe_absorb1(t, n & 0xff);
+    strobe_absorb1(t, (n >> 8) & 0xff);
+    strobe_absorb1(t, (n >> 16) & 0xff);
+    strobe_absorb1(t, n >> 24);
+}
+
+// Strobe128::new(b"Merlin v1.0")
+BP_HD void merlin_strobe_init(strobe &t, kstate st) {
+    t.st = st;
+    ks_zero(st);
+    const uint8_t hdr[18] = {1, BP_STROBE_R + 2, 1, 0, 1, 96, 'S', 'T', 'R', 'O', 'B', 'E', 'v', '1', '.', '0', '.', '2'};
+    for (uint32_t i = 0; i < 18; i++) ks_xor8(st, i, hdr[i]);
+    keccak_f1600(st);
+    t.pos = 0;
+    t.pos_begin = 0;
+    t.cur_flags = 0;
+    const uint8_t proto[11] = {'M', 'e', 'r', 'l', 'i', 'n', ' ', 'v', '1', '.', '0'};
+    strobe_meta_ad(t, proto, 11, false);
+}
+// Transcript::append_message(label, msg)
+BP_HD void merlin_append_message(strobe &t, const uint8_t *label, uint32_t label_len, const uint8_t *msg, uint32_t n) {
+    strobe_meta_ad(t, label, label_len, false);
+    strobe_meta_len(t, n);
+    strobe_ad(t, msg, n, false);
+}
+// append_message with a 32-byte message held as 8 LE words
+BP_HD void merlin_append_words8(strobe &t, const uint8_t *label, uint32_t label_len, const uint32_t w[8]) {
+    strobe_meta_ad(t, label, label_len, false);
+    strobe_meta_len(t, 32);
+    strobe_begin_op(t, BP_FLAG_A, false);
+    strobe_absorb_words(t, w, 8);
+}
+BP_HD void merlin_append_u64(strobe &t, const uint8_t *label, uint32_t label_len, uint64_t x) {
+    uint8_t b[8];
+    for (int i = 0; i < 8; i++) b[i] = (uint8_t)(x >> (8 * i));
+    merlin_append_message(t, label, label_len, b, 8);
+}
+// Transcript::challenge_bytes(label, 64) as 16 LE words
+BP_HD void merlin_challenge_words16(strobe &t, const uint8_t *label, uint32_t label_len, uint32_t out[16]) {
+    strobe_meta_ad(t, label, label_len, false);
+    strobe_meta_len(t, 64);
+    strobe_begin_op(t, BP_FLAG_I | BP_FLAG_A | BP_FLAG_C, false);
+    for (uint32_t i = 0; i < 16; i++) {
+        uint32_t x = strobe_squeeze1(t);
+        x |= strobe_squeeze1(t) << 8;
+        x |= strobe_squeeze1(t) << 16;
+        x |= strobe_squeeze1(t) << 24;
+        out[i] = x;
+    }
+}
+BP_HD void merlin_challenge_bytes(strobe &t, const uint8_t *label, uint32_t label_len, uint8_t *out, uint32_t n) {
+    strobe_meta_ad(t, label, label_len, false);
+    strobe_meta_len(t, n);
+    strobe_begin_op(t, BP_FLAG_I | BP_FLAG_A | BP_FLAG_C, false);
+    for (uint32_t i = 0; i < n; i++) out[i] = (uint8_t)strobe_squeeze1(t);
+}
+
+}  // namespace bp
+#endif

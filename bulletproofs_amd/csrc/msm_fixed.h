@@ -118,7 +118,7 @@ BP_HD void fb_recode_thread(uint32_t tid, fb_params prm, uint32_t nproofs, uint3
     uint32_t s[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) s[i] = gen_scalars[((uint64_t)p * n_gen_terms + g) * 8 + i];
-    if (!sc_is_canonical(s)) status[p] = BP_STATUS_BAD_SCALAR;
+    if (!sc_is_canonical(s)) status_raise(status + p, BP_STATUS_BAD_SCALAR);
     fb_recode(digits + ((uint64_t)g * prm.nwin) * nproofs + p, nproofs, s, prm);
 }
 
@@ -130,7 +130,8 @@ BP_HD void fb_accum_thread(uint32_t p, uint32_t split, uint32_t q0, uint32_t q1,
     ge_identity(acc);
     for (uint32_t q = q0; q < q1; q++) {
         const uint32_t g = q / prm.nwin, win = q - g * prm.nwin;
-        const int d = (int)digits[(uint64_t)q * nproofs + p] - (int)prm.half;
+        // (masked: rows of rejected proofs are never written, keep the gather in bounds)
+        const int d = (int)(digits[(uint64_t)q * nproofs + p] & (2u * prm.half - 1u)) - (int)prm.half;
         if (d != 0) {
             const uint32_t a = (uint32_t)(d < 0 ? -d : d);
             const fb_entry *e = table + ((uint64_t)gen_ids[g] * prm.nwin + win) * prm.half + (a - 1);

@@ -40,6 +40,15 @@ struct vb_chunk {
 // l = 2^252 + 27742317777372353535851937790883648493, little-endian words
 #define BP_L_WORDS {0x5cf5d3edu, 0x5812631au, 0xa2f79cd6u, 0x14def9deu, 0u, 0u, 0u, 0x10000000u}
 
+// raise a per-item status word to at least `code` (deterministic when lanes disagree: max wins)
+BP_HD void status_raise(uint32_t *status, uint32_t code) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    atomicMax(status, code);
+#else
+    if (*status < code) *status = code;
+#endif
+}
+
 BP_HD bool sc_is_canonical(const uint32_t s[8]) {
     const uint32_t l[8] = BP_L_WORDS;
     // s < l  <=>  borrow out of s - l
@@ -81,8 +90,8 @@ BP_HD void vb_prepare_thread(uint32_t t, const vb_chunk *chunks, const uint32_t 
     ge_ext p;
     const bool ok = ristretto_decompress(p, pw);
     const bool canon = sc_is_canonical(sw);
-    if (!ok) status[msm] = BP_STATUS_BAD_POINT;          // benign race: same value from every lane
-    else if (!canon) status[msm] = BP_STATUS_BAD_SCALAR;
+    if (!canon) status_raise(status + msm, BP_STATUS_BAD_SCALAR);
+    else if (!ok) status_raise(status + msm, BP_STATUS_BAD_POINT);
     sc_recode16(rw, sw);
 #pragma unroll
     for (int i = 0; i < 8; i++) recoded[8 * (uint64_t)t + i] = rw[i];

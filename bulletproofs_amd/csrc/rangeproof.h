@@ -1,4 +1,408 @@
+// Range-proof verification front end on the device: everything
+// RangeProof::verify_multiple_with_rng does before its multiscalar
+// multiplication (src/range_proof/mod.rs:345-420 of the reference):
+//   rp_transcript : lane = proof   parse (mod.rs:504-538, ipp.rs:373-407), replay the Merlin
+//                                  transcript (mod.rs:368-393, ipp.rs:213-222), derive y,z,x,w,u_i
+//   rp_expand_a   : lane = proof   batch inversion, u_i^2, u_i^-2, delta(y,z) (mod.rs:587-593),
+//                                  the 4+2k+m "unique" coefficients and the B / B_blinding ones
+//   rp_expand_b   : lane = (i, proof)  s_i, g_i = -z - a s_i, h_i = z + y^-i (z^2 z^j 2^i' - b s_i^-1)
+//                                  (ipp.rs:241-250, mod.rs:406-419), written straight as
+//                                  fixed-window digits for the generator tables
+// Per-proof intermediate scalars live in HBM, field-major ([field][proof][8 words]) so that the
+// 64 proofs of a wavefront read consecutive 32-byte records.
 #ifndef BPGPU_RANGEPROOF_H
 #define BPGPU_RANGEPROOF_H
+#include "keccak.h"
 #include "msm_fixed.h"
+#include "sc25519.h"
+
+namespace bp {
+
+#define BP_RP_MAX_K 16   // lg(n*m) supported by the device front end
+
+#define BP_VERDICT_OK 0
+#define BP_VERDICT_VERIFICATION 1
+#define BP_VERDICT_FORMAT 2
+
+struct rp_shape {
+    uint32_t n, m, nm, k;          // k = lg(nm)
+    uint32_t U;                    // unique points per proof: 4 + 2k + m
+    uint32_t proof_len;            // bytes, = 32*(9+2k)
+    uint32_t nproofs;
+    uint32_t shape_verdict;        // != 0: only parse, then report this verdict (InvalidBitsize, ...)
+};
+
+// Merlin state after Transcript::new(label) + rangeproof_domain_sep(n, m), computed once on the host
+struct rp_strobe_init {
+    uint32_t w[50];
+    uint32_t pos, pos_begin, cur_flags;
+};
+
+// field-major scalar store
+enum {
+    RPF_Y = 0, RPF_Z, RPF_X, RPF_W, RPF_C, RPF_TX, RPF_TXB, RPF_EB, RPF_A, RPF_B,
+    RPF_ZZ,            // z^2
+    RPF_MINUS_Z,
+    RPF_A_M, RPF_B_M, RPF_Z_M, RPF_ZZ_M,   // Montgomery forms used by expand_b
+    RPF_FIXED_COUNT
+};
+struct rp_fields {
+    uint32_t u;         // k challenges u_i (plain)
+    uint32_t u_m;       // k: u_i      (Montgomery)
+    uint32_t uinv_m;    // k: u_i^-1   (Montgomery)
+    uint32_t yinvp_m;   // k: y^-(2^b) (Montgomery)
+    uint32_t zzzj_m;    // m: z^2 * z^j (Montgomery)
+    uint32_t count;
+};
+BP_HD rp_fields rp_field_layout(uint32_t k, uint32_t m) {
+    rp_fields f;
+    f.u = RPF_FIXED_COUNT;
+    f.u_m = f.u + k;
+    f.uinv_m = f.u_m + k;
+    f.yinvp_m = f.uinv_m + k;
+    f.zzzj_m = f.yinvp_m + k;
+    f.count = f.zzzj_m + m;
+    return f;
+}
+BP_HD void rp_store(uint32_t *buf, uint32_t nproofs, uint32_t field, uint32_t p, const sc &s) {
+    uint32_t *d = buf + ((uint64_t)field * nproofs + p) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) d[i] = s.v[i];
+}
+BP_HD void rp_load(sc &s, const uint32_t *buf, uint32_t nproofs, uint32_t field, uint32_t p) {
+    const uint32_t *d = buf + ((uint64_t)field * nproofs + p) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s.v[i] = d[i];
+}
+
+// 32-byte record -> 8 LE words; all proof / commitment / rng buffers are 4-byte aligned
+// (bpgpu.h requires it of device pointers; the host entry points stage through hipMalloc memory)
+BP_HD void load_words8(uint32_t w[8], const uint8_t *src) {
+    const uint32_t *s4 = (const uint32_t *)src;
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = s4[i];
+}
+BP_HD bool words8_zero(const uint32_t w[8]) {
+    uint32_t r = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r |= w[i];
+    return r == 0;
+}
+
+BP_HD void rp_challenge_scalar(strobe &t, const uint8_t *label, uint32_t label_len, sc &out) {
+    uint32_t w[16];
+    merlin_challenge_words16(t, label, label_len, w);
+    sc_from_wide(out, w);
+}
+
+// ---- stage 1: parse + transcript ------------------------------------------------------
+// thread p.  `st` = this lane's 50-word sponge state (LDS on the device).
+// Outputs: fields (plain scalars), uniq_points[p][U] = A,S,T1,T2,L_0..L_{k-1},R_0..R_{k-1},V_0..V_{m-1}
+// (the order of the unique part of mod.rs:433-443), verdict[p] (0, VerificationError, FormatError).
+BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &init, kstate st, const uint8_t *proofs,
+                                const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields, uint32_t *uniq_points,
+                                uint32_t *status) {
+    const uint32_t B = sh.nproofs, k = sh.k;
+    const uint8_t *pr = proofs + (uint64_t)p * sh.proof_len;
+    const rp_fields fl = rp_field_layout(k, sh.m);
+    uint32_t w[8];
+    // --- from_bytes: the five scalars must be canonical (mod.rs:519-524, ipp.rs:401-404)
+    sc tx, txb, eb, a, b;
+    bool fmt_ok = true;
+    load_words8(tx.v, pr + 128);   fmt_ok = fmt_ok && sc_is_canonical_sc(tx);
+    load_words8(txb.v, pr + 160);  fmt_ok = fmt_ok && sc_is_canonical_sc(txb);
+    load_words8(eb.v, pr + 192);   fmt_ok = fmt_ok && sc_is_canonical_sc(eb);
+    load_words8(a.v, pr + 224 + 64 * k);       fmt_ok = fmt_ok && sc_is_canonical_sc(a);
+    load_words8(b.v, pr + 224 + 64 * k + 32);  fmt_ok = fmt_ok && sc_is_canonical_sc(b);
+    if (!fmt_ok) {
+        status[p] = BP_VERDICT_FORMAT;
+        return;
+    }
+    if (sh.shape_verdict) {
+        status[p] = sh.shape_verdict;
+        return;
+    }
+    rp_store(fields, B, RPF_TX, p, tx);
+    rp_store(fields, B, RPF_TXB, p, txb);
+    rp_store(fields, B, RPF_EB, p, eb);
+    rp_store(fields, B, RPF_A, p, a);
+    rp_store(fields, B, RPF_B, p, b);
+
+    strobe t;
+    t.st = st;
+    for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, init.w[i]);
+    t.pos = init.pos;
+    t.pos_begin = init.pos_begin;
+    t.cur_flags = init.cur_flags;
+
+    uint32_t *up = uniq_points + (uint64_t)p * sh.U * 8;
+    bool verr = false;
+    const uint8_t lV[1] = {'V'}, lA[1] = {'A'}, lS[1] = {'S'}, ly[1] = {'y'}, lz[1] = {'z'}, lx[1] = {'x'}, lw[1] = {'w'},
+                  lL[1] = {'L'}, lR[1] = {'R'}, lu[1] = {'u'}, ln[1] = {'n'};
+    const uint8_t lT1[3] = {'T', '_', '1'}, lT2[3] = {'T', '_', '2'}, ltx[3] = {'t', '_', 'x'};
+    const uint8_t ltxb[12] = {'t', '_', 'x', '_', 'b', 'l', 'i', 'n', 'd', 'i', 'n', 'g'};
+    const uint8_t leb[10] = {'e', '_', 'b', 'l', 'i', 'n', 'd', 'i', 'n', 'g'};
+    const uint8_t ldom[7] = {'d', 'o', 'm', '-', 's', 'e', 'p'};
+    const uint8_t lipp[6] = {'i', 'p', 'p', ' ', 'v', '1'};
+
+    // V_j: append_point, no identity check (mod.rs:370-374)
+    for (uint32_t j = 0; j < sh.m; j++) {
+        load_words8(w, commitments + ((uint64_t)p * sh.m + j) * 32);
+        merlin_append_words8(t, lV, 1, w);
+        for (int i = 0; i < 8; i++) up[(4 + 2 * k + j) * 8 + i] = w[i];
+    }
+    // A, S: validate_and_append_point (transcript.rs:75-87)
+    load_words8(w, pr + 0);
+    verr = verr || words8_zero(w);
+    merlin_append_words8(t, lA, 1, w);
+    for (int i = 0; i < 8; i++) up[0 * 8 + i] = w[i];
+    load_words8(w, pr + 32);
+    verr = verr || words8_zero(w);
+    merlin_append_words8(t, lS, 1, w);
+    for (int i = 0; i < 8; i++) up[1 * 8 + i] = w[i];
+    sc y, z, x, wch, c;
+    rp_challenge_scalar(t, ly, 1, y);
+    rp_challenge_scalar(t, lz, 1, z);
+    load_words8(w, pr + 64);
+    verr = verr || words8_zero(w);
+    merlin_append_words8(t, lT1, 3, w);
+    for (int i = 0; i < 8; i++) up[2 * 8 + i] = w[i];
+    load_words8(w, pr + 96);
+    verr = verr || words8_zero(w);
+    merlin_append_words8(t, lT2, 3, w);
+    for (int i = 0; i < 8; i++) up[3 * 8 + i] = w[i];
+    rp_challenge_scalar(t, lx, 1, x);
+    merlin_append_words8(t, ltx, 3, tx.v);
+    merlin_append_words8(t, ltxb, 12, txb.v);
+    merlin_append_words8(t, leb, 10, eb.v);
+    rp_challenge_scalar(t, lw, 1, wch);
+    // batching challenge c = Scalar::random(rng) (mod.rs:396): 64 rng bytes, wide-reduced
+    {
+        uint32_t cw[16];
+        const uint8_t *rs = rng64 + (uint64_t)p * 64;
+        load_words8(cw, rs);
+        load_words8(cw + 8, rs + 32);
+        sc_from_wide(c, cw);
+    }
+    rp_store(fields, B, RPF_Y, p, y);
+    rp_store(fields, B, RPF_Z, p, z);
+    rp_store(fields, B, RPF_X, p, x);
+    rp_store(fields, B, RPF_W, p, wch);
+    rp_store(fields, B, RPF_C, p, c);
+    // inner-product part (ipp.rs:213-222)
+    merlin_append_message(t, ldom, 7, lipp, 6);
+    merlin_append_u64(t, ln, 1, sh.nm);
+    for (uint32_t i = 0; i < k; i++) {
+        load_words8(w, pr + 224 + 64 * i);
+        verr = verr || words8_zero(w);
+        merlin_append_words8(t, lL, 1, w);
+        for (int q = 0; q < 8; q++) up[(4 + i) * 8 + q] = w[q];
+        load_words8(w, pr + 224 + 64 * i + 32);
+        verr = verr || words8_zero(w);
+        merlin_append_words8(t, lR, 1, w);
+        for (int q = 0; q < 8; q++) up[(4 + k + i) * 8 + q] = w[q];
+        sc u;
+        rp_challenge_scalar(t, lu, 1, u);
+        rp_store(fields, B, fl.u + i, p, u);
+    }
+    if (verr) status_raise(status + p, BP_VERDICT_VERIFICATION);
+}
+
+// sum_{i<2^lg} x^i by repeated doubling (src/util.rs:240-256); x plain
+BP_HD void rp_sum_of_powers_pow2(sc &r, const sc &x, uint32_t lg) {
+    sc one;
+    sc_from_u32(one, 1);
+    if (lg == 0) {
+        r = one;
+        return;
+    }
+    sc result, factor = x, t;
+    sc_add(result, one, x);
+    for (uint32_t i = 1; i < lg; i++) {
+        sc_mul(factor, factor, factor);
+        sc_mul(t, factor, result);
+        sc_add(result, result, t);
+    }
+    r = result;
+}
+
+// ---- stage 2: per-proof scalars -----------------------------------------------------------
+// thread p.  Writes uniq_scalars[p][U] in the order of uniq_points, the Montgomery-form tables for
+// stage 3, and the digits of the B_blinding (row 0) and B (row 1) coefficients.
+BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t lg_m, uint32_t *fields, uint32_t *uniq_scalars,
+                              uint16_t *digits, const uint32_t *status) {
+    if (status[p] != 0) return;   // digits/scalars of rejected proofs are never consumed (finish masks them)
+    const uint32_t B = sh.nproofs, k = sh.k;
+    const rp_fields fl = rp_field_layout(k, sh.m);
+    sc y, z, x, w, c, tx, txb, eb, a, b, one;
+    sc_from_u32(one, 1);
+    rp_load(y, fields, B, RPF_Y, p);
+    rp_load(z, fields, B, RPF_Z, p);
+    rp_load(x, fields, B, RPF_X, p);
+    rp_load(w, fields, B, RPF_W, p);
+    rp_load(c, fields, B, RPF_C, p);
+    rp_load(tx, fields, B, RPF_TX, p);
+    rp_load(txb, fields, B, RPF_TXB, p);
+    rp_load(eb, fields, B, RPF_EB, p);
+    rp_load(a, fields, B, RPF_A, p);
+    rp_load(b, fields, B, RPF_B, p);
+
+    // batch inversion of (y, u_0, .., u_{k-1}) (Scalar::batch_invert, ipp.rs:226-227; y.invert(), mod.rs:414)
+    // prefix products are parked in the u_m slots (overwritten below)
+    sc acc = y, u;
+    for (uint32_t i = 0; i < k; i++) {
+        rp_store(fields, B, fl.u_m + i, p, acc);        // prefix before u_i
+        rp_load(u, fields, B, fl.u + i, p);
+        sc_mul(acc, acc, u);
+    }
+    sc inv;
+    sc_invert(inv, acc);                                  // (y * prod u_i)^-1
+    uint32_t *us = uniq_scalars + (uint64_t)p * sh.U * 8;
+    for (uint32_t ii = k; ii-- > 0;) {
+        sc pre, ui, um, uim, t;
+        rp_load(pre, fields, B, fl.u_m + ii, p);
+        rp_load(u, fields, B, fl.u + ii, p);
+        sc_mul(ui, inv, pre);                             // u_ii^-1
+        sc_mul(inv, inv, u);                              // drop u_ii from the running inverse
+        sc_to_mont(um, u);
+        sc_to_mont(uim, ui);
+        rp_store(fields, B, fl.u_m + ii, p, um);
+        rp_store(fields, B, fl.uinv_m + ii, p, uim);
+        sc_mul(t, u, u);                                  // u_i^2   -> L_i coefficient
+        for (int q = 0; q < 8; q++) us[(4 + ii) * 8 + q] = t.v[q];
+        sc_mul(t, ui, ui);                                // u_i^-2  -> R_i coefficient
+        for (int q = 0; q < 8; q++) us[(4 + k + ii) * 8 + q] = t.v[q];
+    }
+    const sc y_inv = inv;                                 // what is left is y^-1
+    // y^-(2^b) table (Montgomery)
+    {
+        sc pw;
+        sc_to_mont(pw, y_inv);
+        for (uint32_t bb = 0; bb < k; bb++) {
+            rp_store(fields, B, fl.yinvp_m + bb, p, pw);
+            sc_montmul(pw, pw, pw);
+        }
+    }
+    sc zz, minus_z, t0, t1;
+    sc_mul(zz, z, z);
+    sc_neg(minus_z, z);
+    rp_store(fields, B, RPF_ZZ, p, zz);
+    rp_store(fields, B, RPF_MINUS_Z, p, minus_z);
+    sc_to_mont(t0, a);  rp_store(fields, B, RPF_A_M, p, t0);
+    sc_to_mont(t0, b);  rp_store(fields, B, RPF_B_M, p, t0);
+    sc_to_mont(t0, z);  rp_store(fields, B, RPF_Z_M, p, t0);
+    sc_to_mont(t0, zz); rp_store(fields, B, RPF_ZZ_M, p, t0);
+    // unique coefficients: 1, x, c x, c x^2 (A, S, T_1, T_2)
+    sc cx, cxx;
+    sc_mul(cx, c, x);
+    sc_mul(cxx, cx, x);
+    for (int q = 0; q < 8; q++) {
+        us[0 * 8 + q] = one.v[q];
+        us[1 * 8 + q] = x.v[q];
+        us[2 * 8 + q] = cx.v[q];
+        us[3 * 8 + q] = cxx.v[q];
+    }
+    // V_j coefficients c z^2 z^j, and the z^2 z^j table
+    {
+        sc czz, zj = one, zm, zzm, zjm;
+        sc_mul(czz, c, zz);
+        sc_to_mont(zm, z);
+        sc_to_mont(zzm, zz);
+        zjm = zzm;                                        // zz * z^0 in Montgomery form
+        for (uint32_t j = 0; j < sh.m; j++) {
+            sc_mul(t0, czz, zj);
+            for (int q = 0; q < 8; q++) us[(4 + 2 * k + j) * 8 + q] = t0.v[q];
+            rp_store(fields, B, fl.zzzj_m + j, p, zjm);
+            sc_mul(zj, zj, z);
+            sc_montmul(zjm, zjm, zm);
+        }
+    }
+    // B_blinding coefficient: -e_blinding - c t_x_blinding  (row 0)
+    sc_mul(t0, c, txb);
+    sc_add(t0, t0, eb);
+    sc_neg(t0, t0);
+    fb_recode(digits + ((uint64_t)0 * prm.nwin) * B + p, B, t0.v, prm);
+    // B coefficient: w (t_x - a b) + c (delta(y,z) - t_x)  (row 1)
+    sc ab, dl, sum_y, sum_2, sum_z;
+    sc_mul(ab, a, b);
+    sc_sub(t0, tx, ab);
+    sc_mul(t0, w, t0);
+    rp_sum_of_powers_pow2(sum_y, y, k);
+    rp_sum_of_powers_pow2(sum_z, z, lg_m);
+    {   // sum_{i<n} 2^i = 2^n - 1, n <= 64
+        sc_0(sum_2);
+        if (sh.n >= 64) { sum_2.v[0] = 0xffffffffu; sum_2.v[1] = 0xffffffffu; }
+        else if (sh.n >= 32) { sum_2.v[0] = 0xffffffffu; sum_2.v[1] = (sh.n == 32) ? 0u : ((1u << (sh.n - 32)) - 1u); }
+        else sum_2.v[0] = (1u << sh.n) - 1u;
+    }
+    sc_sub(t1, z, zz);
+    sc_mul(t1, t1, sum_y);                                // (z - z^2) <1, y^nm>
+    sc_mul(dl, zz, z);
+    sc_mul(dl, dl, sum_2);
+    sc_mul(dl, dl, sum_z);                                // z^3 <1,2^n> sum_j z^j
+    sc_sub(dl, t1, dl);
+    sc_sub(t1, dl, tx);
+    sc_mul(t1, c, t1);
+    sc_add(t0, t0, t1);
+    fb_recode(digits + ((uint64_t)1 * prm.nwin) * B + p, B, t0.v, prm);
+}
+
+// ---- stage 3: per-(generator, proof) scalars -------------------------------------------------
+// thread tid = i * nproofs + p, i < nm: digits of g_i (row 2 + i) and h_i (row 2 + nm + i)
+BP_HD void rp_expand_b_thread(uint32_t tid, rp_shape sh, fb_params prm, const uint32_t *fields, uint16_t *digits,
+                              const uint32_t *status) {
+    const uint32_t B = sh.nproofs, k = sh.k;
+    const uint32_t i = tid / B, p = tid - i * B;
+    if (status[p] != 0) return;
+    const rp_fields fl = rp_field_layout(k, sh.m);
+    const sc one_m = BP_SC_R;
+    // s_i = prod_b (bit_b(i) ? u : u^-1)[k-1-b]  (ipp.rs:241-250), and its inverse s_{nm-1-i}
+    sc s = one_m, sinv = one_m, yp = one_m, um, uim, t;
+    for (uint32_t bb = 0; bb < k; bb++) {
+        rp_load(um, fields, B, fl.u_m + (k - 1 - bb), p);
+        rp_load(uim, fields, B, fl.uinv_m + (k - 1 - bb), p);
+        const bool bit = (i >> bb) & 1;
+        sc f1, f2;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            f1.v[q] = bit ? um.v[q] : uim.v[q];
+            f2.v[q] = bit ? uim.v[q] : um.v[q];
+        }
+        sc_montmul(s, s, f1);
+        sc_montmul(sinv, sinv, f2);
+        if (bit) {
+            rp_load(t, fields, B, fl.yinvp_m + bb, p);
+            sc_montmul(yp, yp, t);                         // y^-i
+        }
+    }
+    sc a_m, b_m, z, minus_z, g, h, r;
+    rp_load(a_m, fields, B, RPF_A_M, p);
+    rp_load(b_m, fields, B, RPF_B_M, p);
+    rp_load(z, fields, B, RPF_Z, p);
+    rp_load(minus_z, fields, B, RPF_MINUS_Z, p);
+    // g_i = -z - a s_i   (mod.rs:415)
+    sc_montmul(t, a_m, s);           // a*s*R
+    sc_from_mont(t, t);
+    sc_sub(g, minus_z, t);
+    fb_recode(digits + ((uint64_t)(2 + i) * prm.nwin) * B + p, B, g.v, prm);
+    // h_i = z + y^-i (z^2 z^j 2^i' - b s_i^-1), j = i / n, i' = i % n   (mod.rs:416-419)
+    const uint32_t j = i / sh.n, ib = i - j * sh.n;
+    sc zzzj, two_i, two_m;
+    rp_load(zzzj, fields, B, fl.zzzj_m + j, p);
+    sc_0(two_i);
+    two_i.v[ib >> 5] = 1u << (ib & 31);
+    sc_to_mont(two_m, two_i);
+    sc_montmul(r, zzzj, two_m);      // z^2 z^j 2^i' (Montgomery)
+    sc_montmul(t, b_m, sinv);        // b / s_i     (Montgomery)
+    sc_from_mont(r, r);
+    sc_from_mont(t, t);
+    sc_sub(r, r, t);
+    sc_to_mont(r, r);
+    sc_montmul(r, r, yp);
+    sc_from_mont(r, r);
+    sc_add(h, z, r);
+    fb_recode(digits + ((uint64_t)(2 + sh.nm + i) * prm.nwin) * B + p, B, h.v, prm);
+}
+
+}  // namespace bp
 #endif

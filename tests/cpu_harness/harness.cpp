@@ -6,6 +6,7 @@
 #include "../../bulletproofs_amd/csrc/ge25519.h"
 #include "../../bulletproofs_amd/csrc/msm_vb.h"
 #include "../../bulletproofs_amd/csrc/msm_fixed.h"
+#include "../../bulletproofs_amd/csrc/rangeproof.h"
 #include <cstring>
 #include <vector>
 using namespace bp;
@@ -143,6 +144,110 @@ int h_msm_shared(uint32_t W, uint32_t nsplit, uint32_t n_gens_loaded, const uint
     for (uint32_t p = 0; p < nbatch; p++) shared_finish_thread(p, nbatch, nsplit, col.data(), n_unique != 0, partial.data(), status.data(), outw.data(), verdict.data());
     memcpy(out, outw.data(), (size_t)nbatch * 32);
     for (uint32_t b = 0; b < nbatch; b++) { status_out[b] = (uint8_t)status[b]; verdict_out[b] = verdict[b]; }
+    return 0;
+}
+// host-side Merlin prefix: Transcript::new(label) + rangeproof_domain_sep(n, m)  (same code the runtime uses)
+static void make_strobe_init(rp_strobe_init &init, const uint8_t *label, uint32_t label_len, uint64_t n, uint64_t m) {
+    kstate st; st.w = init.w; st.stride = 1;
+    strobe t; merlin_strobe_init(t, st);
+    const uint8_t dom[7] = {'d','o','m','-','s','e','p'}, rp[13] = {'r','a','n','g','e','p','r','o','o','f',' ','v','1'}, ln[1] = {'n'}, lm[1] = {'m'};
+    merlin_append_message(t, dom, 7, label, label_len);
+    merlin_append_message(t, dom, 7, rp, 13);
+    merlin_append_u64(t, ln, 1, n); merlin_append_u64(t, lm, 1, m);
+    init.pos = t.pos; init.pos_begin = t.pos_begin; init.cur_flags = t.cur_flags;
+}
+
+void h_merlin_kat(const uint8_t *label, uint32_t label_len, const uint8_t *mlabel, uint32_t mlabel_len, const uint8_t *msg, uint32_t msg_len,
+                  const uint8_t *clabel, uint32_t clabel_len, uint8_t *out, uint32_t out_len) {
+    uint32_t w[50]; kstate st; st.w = w; st.stride = 1;
+    strobe t; merlin_strobe_init(t, st);
+    const uint8_t dom[7] = {'d','o','m','-','s','e','p'};
+    merlin_append_message(t, dom, 7, label, label_len);
+    merlin_append_message(t, mlabel, mlabel_len, msg, msg_len);
+    merlin_challenge_bytes(t, clabel, clabel_len, out, out_len);
+}
+void h_shake256(const uint8_t *in, uint32_t n, uint8_t *out, uint32_t out_len) {
+    uint32_t w[50]; kstate st; st.w = w; st.stride = 1; sponge k; sponge_init(k, st, BP_SHAKE256_RATE);
+    sponge_absorb(k, in, n); sponge_finish(k, 0x1f); sponge_squeeze(k, out, out_len);
+}
+void h_sha3_512(const uint8_t *in, uint32_t n, uint8_t *out) {
+    uint32_t w[50]; kstate st; st.w = w; st.stride = 1; sponge k; sponge_init(k, st, BP_SHA3_512_RATE);
+    sponge_absorb(k, in, n); sponge_finish(k, 0x06); sponge_squeeze(k, out, 64);
+}
+// op: 0 mul 1 add 2 sub 3 neg 4 invert 5 from_wide(a||b) 6 montmul
+void h_sc_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
+    sc x, y, r; memcpy(x.v, a, 32); memcpy(y.v, b, 32);
+    switch (op) {
+    case 0: sc_mul(r, x, y); break;
+    case 1: sc_add(r, x, y); break;
+    case 2: sc_sub(r, x, y); break;
+    case 3: sc_neg(r, x); break;
+    case 4: sc_invert(r, x); break;
+    case 5: { uint32_t w[16]; memcpy(w, a, 32); memcpy(w + 8, b, 32); sc_from_wide(r, w); } break;
+    case 6: sc_montmul(r, x, y); break;
+    default: sc_0(r);
+    }
+    memcpy(out, r.v, 32);
+}
+
+// Whole verification pipeline, lane by lane, as the HIP runtime enqueues it.
+int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t party_capacity, const uint8_t *gens /*Bb,B,G..,H..*/,
+                uint32_t n, uint32_t m, uint32_t nbatch, const uint8_t *proofs, uint32_t proof_len, const uint8_t *commitments,
+                const uint8_t *label, uint32_t label_len, const uint8_t *rng64, uint8_t *verdict_out, uint8_t *msm_out) {
+    uint32_t k = 0; while ((1u << k) < n * m) k++;
+    uint32_t lg_m = 0; while ((1u << lg_m) < m) lg_m++;
+    rp_shape sh; sh.n = n; sh.m = m; sh.nm = n * m; sh.k = k; sh.U = 4 + 2 * k + m; sh.proof_len = proof_len; sh.nproofs = nbatch; sh.shape_verdict = 0;
+    if (proof_len != 32 * (9 + 2 * k)) return -1;
+    fb_params prm; prm.W = W; prm.nwin = fb_nwin(W); prm.half = 1u << (W - 1); prm.n_gens = 2 + 2 * gens_capacity * party_capacity;
+    std::vector<ge_ext> base((size_t)prm.n_gens * prm.nwin);
+    std::vector<fb_entry> table((size_t)prm.n_gens * prm.nwin * prm.half);
+    uint32_t bad = 0;
+    for (uint32_t g = 0; g < prm.n_gens; g++) fb_base_thread(g, prm, (const uint32_t *)gens, base.data(), &bad);
+    if (bad) return -5;
+    for (uint32_t t = 0; t < prm.n_gens * prm.nwin; t++) fb_fill_thread(t, prm, base.data(), table.data());
+    std::vector<uint32_t> ids; ids.push_back(0); ids.push_back(1);
+    const uint32_t tot = gens_capacity * party_capacity;
+    for (uint32_t j = 0; j < m; j++) for (uint32_t i = 0; i < n; i++) ids.push_back(2 + j * gens_capacity + i);
+    for (uint32_t j = 0; j < m; j++) for (uint32_t i = 0; i < n; i++) ids.push_back(2 + tot + j * gens_capacity + i);
+    const uint32_t n_gen_terms = 2 * n * m + 2, npairs = n_gen_terms * prm.nwin;
+
+    rp_strobe_init init; make_strobe_init(init, label, label_len, n, m);
+    const rp_fields fl = rp_field_layout(k, m);
+    std::vector<uint32_t> fields((size_t)fl.count * nbatch * 8 + 8), uniq_points((size_t)nbatch * sh.U * 8 + 8, 0), uniq_scalars((size_t)nbatch * sh.U * 8 + 8, 0), status(nbatch + 1, 0);
+    std::vector<uint16_t> digits((size_t)npairs * nbatch + 1, 0xffff);   // poison: unwritten rows must be masked
+    for (uint32_t p = 0; p < nbatch; p++) {
+        uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;
+        rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields.data(), uniq_points.data(), status.data());
+    }
+    for (uint32_t p = 0; p < nbatch; p++) rp_expand_a_thread(p, sh, prm, lg_m, fields.data(), uniq_scalars.data(), digits.data(), status.data());
+    for (uint32_t tid = 0; tid < sh.nm * nbatch; tid++) rp_expand_b_thread(tid, sh, prm, fields.data(), digits.data(), status.data());
+    // unique part through the variable-base stages
+    std::vector<vb_chunk> chunks; std::vector<uint32_t> chunk_first(nbatch + 1), term_chunk; uint32_t t0 = 0;
+    for (uint32_t b = 0; b < nbatch; b++) {
+        chunk_first[b] = (uint32_t)chunks.size();
+        for (uint32_t kk = 0; kk < sh.U; kk += BP_VB_CHUNK) {
+            vb_chunk c; c.msm = b; c.first = t0 + kk; c.count = sh.U - kk < BP_VB_CHUNK ? sh.U - kk : BP_VB_CHUNK; c.pad = 0;
+            for (uint32_t i = 0; i < c.count; i++) term_chunk.push_back((uint32_t)chunks.size());
+            chunks.push_back(c);
+        }
+        t0 += sh.U;
+    }
+    chunk_first[nbatch] = (uint32_t)chunks.size();
+    std::vector<ge_cached> tab((size_t)t0 * 8 + 1); std::vector<uint32_t> rec((size_t)t0 * 8 + 1), outw((size_t)nbatch * 8 + 1);
+    std::vector<ge_ext> part(chunks.size() * 64 + 1), col((size_t)nbatch * 64 + 1);
+    for (uint32_t t = 0; t < t0; t++) vb_prepare_thread(t, chunks.data(), term_chunk.data(), uniq_scalars.data(), uniq_points.data(), tab.data(), rec.data(), status.data());
+    for (uint32_t tid = 0; tid < chunks.size() * 64; tid++) vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data());
+    for (uint32_t tid = 0; tid < nbatch * 64; tid++) vb_colsum_thread(tid, chunk_first.data(), part.data(), col.data());
+    std::vector<ge_ext> partial((size_t)nsplit * nbatch + 1);
+    const uint32_t per = (npairs + nsplit - 1) / nsplit;
+    for (uint32_t sp = 0; sp < nsplit; sp++) {
+        uint32_t q0 = sp * per, q1 = q0 + per < npairs ? q0 + per : npairs; if (q0 > npairs) q0 = npairs;
+        for (uint32_t p = 0; p < nbatch; p++) fb_accum_thread(p, sp, q0, q1, prm, nbatch, ids.data(), digits.data(), table.data(), partial.data());
+    }
+    std::vector<uint8_t> verdict(nbatch + 1);
+    for (uint32_t p = 0; p < nbatch; p++) shared_finish_thread(p, nbatch, nsplit, col.data(), true, partial.data(), status.data(), outw.data(), verdict.data());
+    for (uint32_t p = 0; p < nbatch; p++) verdict_out[p] = status[p] ? (uint8_t)status[p] : verdict[p];
+    if (msm_out) memcpy(msm_out, outw.data(), (size_t)nbatch * 32);
     return 0;
 }
 }
