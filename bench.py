@@ -34,19 +34,24 @@ def parse_args():
                     help="BASELINE.json config; cfg2 (batch of 1024 single 64-bit proofs per GPU) is the metric's config")
     ap.add_argument("--batch", type=int, default=0, help="override proofs per GPU per step")
     ap.add_argument("--window-bits", type=int, default=0, help="fixed-base window (default: library default)")
+    ap.add_argument("--streams", type=int, default=4,
+                    help="independent (context, HIP stream) pairs the steps are issued on round-robin, so that "
+                         "consecutive batches overlap on the device (one context per stream, as bpgpu.h prescribes "
+                         "for concurrent callers)")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--events-outside", action="store_true",
                     help="collect the per-kernel HIP-event timings in a second pass instead of inside the timed region")
     return ap.parse_args()
 
 
-def cpu_baseline(fx, batch):
+def cpu_baseline(fx, batch, threads=0):
     """The oracle (C restatement of the reference's algorithm: u64 5x51 field, Straus/Pippenger split) timed on
     this box's host cores on a bounded sample of the same workload.  This is the ONLY place bench.py touches oracle/."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as O
     from bulletproofs_amd.workload import tile_batch
-    cores = os.cpu_count() or 1
+    cores = threads or os.cpu_count() or 1
     g = O.Gens(fx.n, fx.m)
     # single-thread calibration (~0.3 s), then ~10-30 s of CPU work in total across all cores
     cal = max(4, min(64, fx.count))
@@ -72,6 +77,7 @@ def main():
     import torch.distributed as dist
     import bulletproofs_amd as bp
     from bulletproofs_amd import workload as wl
+    from bulletproofs_amd import dist as bpdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -83,8 +89,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        bpdist.init("nccl", dev)
 
     fx_name, default_batch = wl.CONFIGS[a.config]
     fx = wl.load_fixture(fx_name)
@@ -92,8 +97,13 @@ def main():
     n, m = fx.n, fx.m
     N_terms = wl.msm_terms(n, m)
 
-    ctx = bp.Context(local_rank, fixed_window_bits=a.window_bits or None)
-    ctx.gens_create(n, m)
+    nstreams = max(1, a.streams)
+    ctxs = []
+    for _ in range(nstreams):
+        c_ = bp.Context(local_rank, fixed_window_bits=a.window_bits or None)
+        c_.gens_create(n, m)
+        ctxs.append(c_)
+    ctx = ctxs[0]
     L = bp.lib()
 
     # this rank's shard of the global batch (weak scaling: `batch` proofs per GPU), resident in HBM
@@ -104,14 +114,15 @@ def main():
     d_coms = torch.frombuffer(bytearray(coms_b), dtype=torch.uint8).to(dev)
     d_rng = torch.frombuffer(bytearray(rng_b), dtype=torch.uint8).to(dev)
     d_verdicts = torch.full((max(a.steps, 1), batch), 255, dtype=torch.uint8, device=dev)
-    stream = torch.cuda.current_stream()
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
 
     def step(i):
-        rc = L.bpgpu_rangeproof_verify_batch_dev(ctx.h, n, m, batch, d_proofs.data_ptr(), fx.proof_len, d_coms.data_ptr(),
+        k = i % nstreams
+        rc = L.bpgpu_rangeproof_verify_batch_dev(ctxs[k].h, n, m, batch, d_proofs.data_ptr(), fx.proof_len, d_coms.data_ptr(),
                                                  fx.label, len(fx.label), d_rng.data_ptr(),
-                                                 d_verdicts[i % d_verdicts.shape[0]].data_ptr(), None, stream.cuda_stream)
+                                                 d_verdicts[i % d_verdicts.shape[0]].data_ptr(), None, streams[k].cuda_stream)
         if rc != 0:
-            raise RuntimeError("bpgpu_rangeproof_verify_batch_dev failed: %s" % L.bpgpu_last_error(ctx.h).decode())
+            raise RuntimeError("bpgpu_rangeproof_verify_batch_dev failed: %s" % L.bpgpu_last_error(ctxs[k].h).decode())
 
     def fence():
         torch.cuda.synchronize()
@@ -123,37 +134,40 @@ def main():
         step(i)
     fence()
     in_region_events = not a.events_outside
-    ctx.profile_reset()
-    ctx.profile_enable(in_region_events)
+    for c_ in ctxs:
+        c_.profile_reset()
+        c_.profile_enable(in_region_events)
     fence()
     t0 = time.perf_counter()
     for i in range(a.steps):
         step(i)
-    if world > 1:   # the final identity-check gather: every rank's verdict bytes, one collective
-        gathered = [torch.empty_like(d_verdicts) for _ in range(world)]
-        dist.all_gather(gathered, d_verdicts)
+    t_enqueued = time.perf_counter() - t0
+    for s_ in streams[1:]:
+        streams[0].wait_stream(s_)                       # verdicts of every stream are complete before the gather
+    all_v = bpdist.gather_verdicts(d_verdicts, world)   # the final identity-check gather: one collective
     fence()
     elapsed = time.perf_counter() - t0
-    ctx.profile_enable(False)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        all_v = torch.stack(gathered)
-    else:
-        all_v = d_verdicts.unsqueeze(0)
+    for c_ in ctxs:
+        c_.profile_enable(False)
+    elapsed = bpdist.max_over_ranks(elapsed, world, dev)
     ok = bool((all_v[:, :min(a.steps, all_v.shape[1])] == 0).all().item()) if a.steps else True
     if not ok:
         raise SystemExit("verification verdicts are not all Ok -- result invalid")
 
     if not in_region_events:   # second pass, same steps, only to time the kernels
-        ctx.profile_reset()
-        ctx.profile_enable(True)
+        for c_ in ctxs:
+            c_.profile_reset()
+            c_.profile_enable(True)
         for i in range(a.steps):
             step(i)
         fence()
-        ctx.profile_enable(False)
-    kern = ctx.profile_report()
+        for c_ in ctxs:
+            c_.profile_enable(False)
+    kern = {}
+    for c_ in ctxs:
+        for name, (cnt, ms) in c_.profile_report().items():
+            o = kern.get(name, (0, 0.0))
+            kern[name] = (o[0] + cnt, o[1] + ms)
 
     if rank == 0:
         value = world * batch * a.steps / elapsed
@@ -190,6 +204,7 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": round(elapsed / max(a.steps, 1) * 1e3, 4),
+            "host_enqueue_ms_per_step": round(t_enqueued / max(a.steps, 1) * 1e3, 4),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -198,16 +213,18 @@ def main():
             "config": {"workload": "%s: batch of %d %s%d-bit range proofs per GPU, proof bytes -> verdict on device "
                                    "(MSM of %d terms each)" % (a.config, batch, ("aggregated m=%d " % m) if m > 1 else "single ", n, N_terms),
                        "n": n, "m": m, "batch_per_gpu": batch, "global_batch": batch * world, "msm_terms": N_terms,
-                       "fixed_window_bits": a.window_bits or 8, "parallelism": "independent proofs sharded, dp%d" % world},
+                       "fixed_window_bits": ctx.get_option("fixed_window_bits"), "fixed_table_bytes": ctx.get_option("fixed_table_bytes"),
+                       "streams": nstreams, "parallelism": "independent proofs sharded, dp%d" % world},
             "roofline": roof,
         }
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(fx, batch)
+            out["cpu_baseline"] = cpu_baseline(fx, batch, a.cpu_threads)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
-    ctx.close()
+    for c_ in ctxs:
+        c_.close()
 
 
 if __name__ == "__main__":

@@ -13,6 +13,7 @@ _lib = None
 
 EXPORTS = [
     "bpgpu_version", "bpgpu_ctx_create", "bpgpu_ctx_destroy", "bpgpu_last_error", "bpgpu_ctx_set_option",
+    "bpgpu_ctx_get_option",
     "bpgpu_synchronize", "bpgpu_gens_create", "bpgpu_gens_load", "bpgpu_gens_export",
     "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_msm_batch_shared", "bpgpu_msm_batch_shared_dev",
     "bpgpu_rangeproof_verify_batch", "bpgpu_rangeproof_verify_batch_dev",
@@ -41,6 +42,7 @@ def lib():
     L.bpgpu_last_error.argtypes = [vp]
     L.bpgpu_last_error.restype = C.c_char_p
     L.bpgpu_ctx_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.bpgpu_ctx_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
     L.bpgpu_synchronize.argtypes = [vp]
     missing = [n for n in EXPORTS if not hasattr(L, n)]
     if missing:
@@ -67,7 +69,7 @@ ERR_NAMES = {0: "OK", -1: "INVALID_ARG", -2: "HIP", -3: "NO_GENS", -4: "NO_DEVIC
 class Context:
     """Owns one bpgpu_ctx (one GPU)."""
 
-    def __init__(self, device=0, fixed_window_bits=None, fixed_splits=None):
+    def __init__(self, device=0, fixed_window_bits=None, fixed_splits=None, fixed_table_max_bytes=None):
         self._L = lib()
         h = C.c_void_p()
         rc = self._L.bpgpu_ctx_create(device, C.byref(h))
@@ -78,6 +80,8 @@ class Context:
             self.set_option("fixed_window_bits", fixed_window_bits)
         if fixed_splits is not None:
             self.set_option("fixed_splits", fixed_splits)
+        if fixed_table_max_bytes is not None:
+            self.set_option("fixed_table_max_bytes", fixed_table_max_bytes)
 
     def close(self):
         if getattr(self, "h", None):
@@ -96,6 +100,11 @@ class Context:
 
     def set_option(self, key, value):
         self._chk(self._L.bpgpu_ctx_set_option(self.h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int64(0)
+        self._chk(self._L.bpgpu_ctx_get_option(self.h, key.encode(), C.byref(v)))
+        return v.value
 
     def synchronize(self):
         self._chk(self._L.bpgpu_synchronize(self.h))

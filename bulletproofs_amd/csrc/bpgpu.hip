@@ -62,6 +62,11 @@ __global__ void __launch_bounds__(64) k_fb_fill(fb_params prm, const ge_ext *bas
     if (tid < prm.n_gens * prm.nwin) fb_fill_thread(tid, prm, base, table);
 }
 
+__global__ void __launch_bounds__(64) k_fb_norm(uint64_t n_groups, uint64_t n_entries, fb_entry *table) {
+    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (gid < n_groups) fb_norm_thread(gid, n_entries, table);
+}
+
 __global__ void __launch_bounds__(BP_BLOCK) k_fb_recode(uint32_t nthreads, fb_params prm, uint32_t nproofs, uint32_t n_gen_terms,
                                                          const uint32_t *gen_scalars, uint16_t *digits, uint32_t *status) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
@@ -89,6 +94,12 @@ __global__ void __launch_bounds__(FB_BLOCK) k_fb_accum(fb_params prm, uint32_t n
     const uint32_t per = (npairs + nsplit - 1) / nsplit;
     const uint32_t q0 = split * per, q1 = (q0 + per < npairs) ? q0 + per : npairs;
     if (p < nproofs) fb_accum_thread(p, split, q0 < npairs ? q0 : npairs, q1, prm, nproofs, gen_ids, digits, table, partial);
+}
+
+__global__ void __launch_bounds__(BP_BLOCK) k_fb_reduce(uint32_t nthreads, uint32_t nproofs, uint32_t nsplit, uint32_t group,
+                                                         const ge_ext *partial, ge_ext *out) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < nthreads) fb_reduce_thread(tid, nproofs, nsplit, group, partial, out);
 }
 
 __global__ void __launch_bounds__(64) k_shared_finish(uint32_t nproofs, uint32_t nsplit, const ge_ext *col, int have_unique,
@@ -150,6 +161,18 @@ struct kstat {
     double ms = 0;
 };
 
+// Generator tables are read-only and depend only on (device, generator encodings, W): contexts of
+// one process share them (a service runs one context per host thread / stream).
+struct shared_table {
+    int device;
+    uint32_t W;
+    std::vector<uint8_t> gens;
+    fb_entry *d_table;
+    int refs;
+};
+static std::mutex g_tab_mu;
+static std::vector<shared_table *> g_tables;
+
 struct bpgpu_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
@@ -159,8 +182,10 @@ struct bpgpu_ctx {
     char *arena = nullptr;
     size_t arena_cap = 0, arena_off = 0;
     // options
-    uint32_t W = 8;
+    uint32_t W = 0;                          // fixed-base window bits; 0 = largest that fits table_budget
+    uint64_t table_budget = 12ull << 30;     // bytes of HBM the generator tables may take
     uint32_t splits = 0;
+    struct shared_table *tab_ref = nullptr;  // refcounted, shared by the contexts of one device
     // generators
     size_t gens_capacity = 0, party_capacity = 0;
     uint32_t *d_gens = nullptr;       // [B_blinding, B, G..., H...] compressed, n_gens x 8 words
@@ -168,12 +193,34 @@ struct bpgpu_ctx {
     fb_params prm{};
     std::vector<uint8_t> h_gens;      // host copy of the encodings
     std::map<std::pair<size_t, size_t>, uint32_t *> gen_ids_cache;  // (n,m) -> device id list
+    // device-resident work decomposition of the uniform (nbatch, terms-per-MSM) variable-base plans
+    struct plan_dev {
+        char *mem = nullptr;
+        size_t n_chunks = 0;
+        uint32_t total = 0;
+    };
+    std::map<std::pair<size_t, size_t>, plan_dev> plan_cache;
     // profiling
     bool prof = false;
     std::map<std::string, kstat> stats;
     std::vector<std::tuple<std::string, hipEvent_t, hipEvent_t>> pending;
     std::vector<hipEvent_t> ev_pool;
 };
+
+static void release_table(bpgpu_ctx *c) {
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    if (c->tab_ref && --c->tab_ref->refs == 0) {
+        hipFree(c->tab_ref->d_table);
+        for (size_t i = 0; i < g_tables.size(); i++)
+            if (g_tables[i] == c->tab_ref) {
+                g_tables.erase(g_tables.begin() + i);
+                break;
+            }
+        delete c->tab_ref;
+    }
+    c->tab_ref = nullptr;
+    c->d_table = nullptr;
+}
 
 static int fail(bpgpu_ctx *c, int code, const char *fmt, ...) {
     char buf[512];
@@ -262,6 +309,8 @@ struct arena_plan {
     }
 };
 
+static uint64_t table_bytes(uint32_t n_gens, uint32_t W);
+
 extern "C" {
 
 int bpgpu_version(void) { return 100; }
@@ -289,9 +338,10 @@ void bpgpu_ctx_destroy(bpgpu_ctx *c) {
     drain_profile(c);
     for (auto e : c->ev_pool) hipEventDestroy(e);
     for (auto &kv : c->gen_ids_cache) hipFree(kv.second);
+    for (auto &kv : c->plan_cache) hipFree(kv.second.mem);
     if (c->arena) hipFree(c->arena);
     if (c->d_gens) hipFree(c->d_gens);
-    if (c->d_table) hipFree(c->d_table);
+    release_table(c);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
 }
@@ -302,9 +352,15 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return BPGPU_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     if (!strcmp(key, "fixed_window_bits")) {
-        if (value < 2 || value > 16) return fail(c, BPGPU_ERR_INVALID_ARG, "fixed_window_bits must be in 2..16");
+        if (value != 0 && (value < 2 || value > 16)) return fail(c, BPGPU_ERR_INVALID_ARG, "fixed_window_bits must be 0 (auto) or 2..16");
         if (c->d_table) return fail(c, BPGPU_ERR_INVALID_ARG, "set fixed_window_bits before loading generators");
         c->W = (uint32_t)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "fixed_table_max_bytes")) {
+        if (value < (1 << 20)) return fail(c, BPGPU_ERR_INVALID_ARG, "fixed_table_max_bytes too small");
+        if (c->d_table) return fail(c, BPGPU_ERR_INVALID_ARG, "set fixed_table_max_bytes before loading generators");
+        c->table_budget = (uint64_t)value;
         return BPGPU_OK;
     }
     if (!strcmp(key, "fixed_splits")) {
@@ -313,6 +369,17 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
         return BPGPU_OK;
     }
     return fail(c, BPGPU_ERR_INVALID_ARG, "unknown option %s", key);
+}
+
+int bpgpu_ctx_get_option(bpgpu_ctx *c, const char *key, int64_t *value) {
+    if (!c || !key || !value) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (!strcmp(key, "fixed_window_bits")) *value = c->d_table ? c->prm.W : c->W;          // effective once tables exist
+    else if (!strcmp(key, "fixed_table_bytes")) *value = c->d_table ? (int64_t)table_bytes(c->prm.n_gens, c->prm.W) : 0;
+    else if (!strcmp(key, "fixed_table_max_bytes")) *value = (int64_t)c->table_budget;
+    else if (!strcmp(key, "fixed_splits")) *value = c->splits;
+    else return fail(c, BPGPU_ERR_INVALID_ARG, "unknown option %s", key);
+    return BPGPU_OK;
 }
 
 int bpgpu_synchronize(bpgpu_ctx *c) {
@@ -355,34 +422,66 @@ int bpgpu_profile_report(bpgpu_ctx *c, char *buf, size_t cap) {
 // ============================================================================
 // generators
 // ============================================================================
+static uint64_t table_bytes(uint32_t n_gens, uint32_t W) { return (uint64_t)n_gens * fb_nwin(W) * (1ull << (W - 1)) * sizeof(fb_entry); }
+
 static int build_tables(bpgpu_ctx *c) {
-    // c->d_gens holds n_gens compressed points
+    // c->d_gens / c->h_gens hold n_gens compressed points
     fb_params prm;
-    prm.W = c->W;
-    prm.nwin = fb_nwin(c->W);
-    prm.half = 1u << (c->W - 1);
     prm.n_gens = (uint32_t)(2 + 2 * c->gens_capacity * c->party_capacity);
+    uint32_t W = c->W;
+    if (W == 0) {   // largest window whose table fits the budget (256/W additions per generator term)
+        W = 4;
+        for (uint32_t w = 5; w <= 16; w++)
+            if (table_bytes(prm.n_gens, w) <= c->table_budget) W = w;
+    }
+    prm.W = W;
+    prm.nwin = fb_nwin(W);
+    prm.half = 1u << (W - 1);
     c->prm = prm;
-    if (c->d_table) HIPCHK(c, hipFree(c->d_table));
-    c->d_table = nullptr;
-    const size_t entries = (size_t)prm.n_gens * prm.nwin * prm.half;
-    HIPCHK(c, hipMalloc((void **)&c->d_table, entries * sizeof(fb_entry)));
-    ge_ext *d_base = nullptr;
-    uint32_t *d_bad = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_base, (size_t)prm.n_gens * prm.nwin * sizeof(ge_ext)));
-    HIPCHK(c, hipMalloc((void **)&d_bad, 4));
-    HIPCHK(c, hipMemsetAsync(d_bad, 0, 4, c->stream));
-    LAUNCH(c, c->stream, "fb_base", k_fb_base, (prm.n_gens + 63) / 64, 64, prm, c->d_gens, d_base, d_bad);
-    LAUNCH(c, c->stream, "fb_fill", k_fb_fill, (prm.n_gens * prm.nwin + 63) / 64, 64, prm, d_base, c->d_table);
-    uint32_t bad = 0;
-    HIPCHK(c, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream));
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    HIPCHK(c, hipGetLastError());
-    hipFree(d_base);
-    hipFree(d_bad);
-    if (bad) return fail(c, BPGPU_ERR_BAD_GENERATOR, "a generator encoding does not decode");
+    release_table(c);
     for (auto &kv : c->gen_ids_cache) hipFree(kv.second);
     c->gen_ids_cache.clear();
+    std::lock_guard<std::mutex> lk(g_tab_mu);
+    for (shared_table *t : g_tables)
+        if (t->device == c->device && t->W == W && t->gens == c->h_gens) {
+            t->refs++;
+            c->tab_ref = t;
+            c->d_table = t->d_table;
+            return BPGPU_OK;
+        }
+    const size_t entries = (size_t)prm.n_gens * prm.nwin * prm.half;
+    fb_entry *d_table = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_table, entries * sizeof(fb_entry)));
+    ge_ext *d_base = nullptr;
+    uint32_t *d_bad = nullptr;
+    if (hipMalloc((void **)&d_base, (size_t)prm.n_gens * prm.nwin * sizeof(ge_ext)) != hipSuccess ||
+        hipMalloc((void **)&d_bad, 4) != hipSuccess) {
+        hipFree(d_table);
+        return fail(c, BPGPU_ERR_HIP, "hipMalloc of table scratch failed");
+    }
+    hipMemsetAsync(d_bad, 0, 4, c->stream);
+    LAUNCH(c, c->stream, "fb_base", k_fb_base, (prm.n_gens + 63) / 64, 64, prm, c->d_gens, d_base, d_bad);
+    LAUNCH(c, c->stream, "fb_fill", k_fb_fill, (prm.n_gens * prm.nwin + 63) / 64, 64, prm, d_base, d_table);
+    const uint64_t n_groups = (entries + BP_FB_NORM_GROUP - 1) / BP_FB_NORM_GROUP;
+    LAUNCH(c, c->stream, "fb_norm", k_fb_norm, (uint32_t)((n_groups + 63) / 64), 64, n_groups, (uint64_t)entries, d_table);
+    uint32_t bad = 0;
+    hipError_t e1 = hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, c->stream);
+    hipError_t e2 = hipStreamSynchronize(c->stream);
+    hipError_t e3 = hipGetLastError();
+    hipFree(d_base);
+    hipFree(d_bad);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess) {
+        hipFree(d_table);
+        return fail(c, BPGPU_ERR_HIP, "table construction failed: %s", hipGetErrorString(e2 != hipSuccess ? e2 : (e1 != hipSuccess ? e1 : e3)));
+    }
+    if (bad) {
+        hipFree(d_table);
+        return fail(c, BPGPU_ERR_BAD_GENERATOR, "a generator encoding does not decode");
+    }
+    shared_table *t = new shared_table{c->device, W, c->h_gens, d_table, 1};
+    g_tables.push_back(t);
+    c->tab_ref = t;
+    c->d_table = d_table;
     return BPGPU_OK;
 }
 
@@ -493,8 +592,7 @@ static void plan_vb(arena_plan &ap, const vb_plan &pl, size_t nbatch, size_t off
     off[5] = ap.add(pl.chunks.size() * 64 * sizeof(ge_ext) + 16);
     off[6] = ap.add(nbatch * 64 * sizeof(ge_ext) + 16);
 }
-static int enqueue_vb(bpgpu_ctx *c, hipStream_t s, const vb_plan &pl, size_t nbatch, const size_t off[7],
-                      const uint32_t *d_scalars, const uint32_t *d_points, uint32_t *d_status, vb_dev &d) {
+static void vb_bind(bpgpu_ctx *c, const size_t off[7], vb_dev &d) {
     char *a = c->arena;
     d.chunks = (vb_chunk *)(a + off[0]);
     d.chunk_first = (uint32_t *)(a + off[1]);
@@ -503,20 +601,73 @@ static int enqueue_vb(bpgpu_ctx *c, hipStream_t s, const vb_plan &pl, size_t nba
     d.tab = (ge_cached *)(a + off[4]);
     d.part = (ge_ext *)(a + off[5]);
     d.col = (ge_ext *)(a + off[6]);
-    if (!pl.chunks.empty()) {
-        HIPCHK(c, hipMemcpyAsync(d.chunks, pl.chunks.data(), pl.chunks.size() * sizeof(vb_chunk), hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(d.term_chunk, pl.term_chunk.data(), (size_t)pl.total * 4, hipMemcpyHostToDevice, s));
-    }
-    HIPCHK(c, hipMemcpyAsync(d.chunk_first, pl.chunk_first.data(), (nbatch + 1) * 4, hipMemcpyHostToDevice, s));
-    if (pl.total) {
-        LAUNCH(c, s, "vb_prepare", k_vb_prepare, (pl.total + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, pl.total, d.chunks, d.term_chunk,
-               d_scalars, d_points, d.tab, d.recoded, d_status);
-        const uint32_t nt = (uint32_t)pl.chunks.size() * 64;
+}
+static int vb_launch(bpgpu_ctx *c, hipStream_t s, uint32_t total, uint32_t n_chunks, size_t nbatch, const uint32_t *d_scalars,
+                     const uint32_t *d_points, uint32_t *d_status, vb_dev &d) {
+    if (total) {
+        LAUNCH(c, s, "vb_prepare", k_vb_prepare, (total + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, total, d.chunks, d.term_chunk, d_scalars,
+               d_points, d.tab, d.recoded, d_status);
+        const uint32_t nt = n_chunks * 64;
         LAUNCH(c, s, "vb_window", k_vb_window, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, d.chunks, d.tab, d.recoded, d.part);
     }
     const uint32_t nc = (uint32_t)nbatch * 64;
     LAUNCH(c, s, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, d.col);
     return BPGPU_OK;
+}
+// ragged plans: upload the decomposition into the arena every call
+static int enqueue_vb(bpgpu_ctx *c, hipStream_t s, const vb_plan &pl, size_t nbatch, const size_t off[7],
+                      const uint32_t *d_scalars, const uint32_t *d_points, uint32_t *d_status, vb_dev &d) {
+    vb_bind(c, off, d);
+    if (!pl.chunks.empty()) {
+        HIPCHK(c, hipMemcpyAsync(d.chunks, pl.chunks.data(), pl.chunks.size() * sizeof(vb_chunk), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(d.term_chunk, pl.term_chunk.data(), (size_t)pl.total * 4, hipMemcpyHostToDevice, s));
+    }
+    HIPCHK(c, hipMemcpyAsync(d.chunk_first, pl.chunk_first.data(), (nbatch + 1) * 4, hipMemcpyHostToDevice, s));
+    return vb_launch(c, s, pl.total, (uint32_t)pl.chunks.size(), nbatch, d_scalars, d_points, d_status, d);
+}
+// uniform plans (every MSM of the batch has `per` variable-base terms): decomposition cached on the device
+static int uniform_plan(bpgpu_ctx *c, size_t nbatch, size_t per, bpgpu_ctx::plan_dev **out) {
+    auto key = std::make_pair(nbatch, per);
+    auto it = c->plan_cache.find(key);
+    if (it == c->plan_cache.end()) {
+        std::vector<uint32_t> nt(nbatch, (uint32_t)per);
+        vb_plan pl;
+        make_vb_plan(pl, nbatch, nt.data());
+        bpgpu_ctx::plan_dev pd;
+        pd.n_chunks = pl.chunks.size();
+        pd.total = pl.total;
+        const size_t o1 = align_up(pl.chunks.size() * sizeof(vb_chunk) + 16), o2 = o1 + align_up((nbatch + 1) * 4);
+        const size_t tot = o2 + align_up((size_t)pl.total * 4 + 16);
+        HIPCHK(c, hipMalloc((void **)&pd.mem, tot));
+        if (!pl.chunks.empty()) {
+            HIPCHK(c, hipMemcpy(pd.mem, pl.chunks.data(), pl.chunks.size() * sizeof(vb_chunk), hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(pd.mem + o2, pl.term_chunk.data(), (size_t)pl.total * 4, hipMemcpyHostToDevice));
+        }
+        HIPCHK(c, hipMemcpy(pd.mem + o1, pl.chunk_first.data(), (nbatch + 1) * 4, hipMemcpyHostToDevice));
+        it = c->plan_cache.emplace(key, pd).first;
+    }
+    *out = &it->second;
+    return BPGPU_OK;
+}
+static void plan_vb_uniform(arena_plan &ap, size_t nbatch, size_t per, size_t off[7]) {
+    const size_t n_chunks = nbatch * ((per + BP_VB_CHUNK - 1) / BP_VB_CHUNK), total = nbatch * per;
+    off[0] = off[1] = off[2] = 0;   // decomposition lives in the plan cache
+    off[3] = ap.add(total * 32 + 16);
+    off[4] = ap.add(total * 8 * sizeof(ge_cached) + 16);
+    off[5] = ap.add(n_chunks * 64 * sizeof(ge_ext) + 16);
+    off[6] = ap.add(nbatch * 64 * sizeof(ge_ext) + 16);
+}
+static int enqueue_vb_uniform(bpgpu_ctx *c, hipStream_t s, size_t nbatch, size_t per, const size_t off[7], const uint32_t *d_scalars,
+                              const uint32_t *d_points, uint32_t *d_status, vb_dev &d) {
+    bpgpu_ctx::plan_dev *pd = nullptr;
+    int rc = uniform_plan(c, nbatch, per, &pd);
+    if (rc) return rc;
+    vb_bind(c, off, d);
+    const size_t o1 = align_up(pd->n_chunks * sizeof(vb_chunk) + 16), o2 = o1 + align_up((nbatch + 1) * 4);
+    d.chunks = (vb_chunk *)pd->mem;
+    d.chunk_first = (uint32_t *)(pd->mem + o1);
+    d.term_chunk = (uint32_t *)(pd->mem + o2);
+    return vb_launch(c, s, pd->total, (uint32_t)pd->n_chunks, nbatch, d_scalars, d_points, d_status, d);
 }
 
 static int msm_batch_dev_locked(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_terms, const void *d_scalars, const void *d_points,
@@ -601,6 +752,25 @@ static uint32_t pick_splits(bpgpu_ctx *c, size_t nbatch, uint32_t npairs) {
     return s;
 }
 
+// Tree-reduce the per-split partial points (8-way per level) until at most 8 remain per proof.
+// `buf` must hold nsplit*nbatch + ceil(nsplit/8)*nbatch (+ ...) points: callers reserve 2*nsplit*nbatch.
+#define FB_REDUCE_GROUP 8
+static void enqueue_fb_reduce(bpgpu_ctx *c, hipStream_t s, uint32_t nbatch, uint32_t nsplit, ge_ext *buf, ge_ext **out, uint32_t *nout) {
+    ge_ext *cur = buf;
+    uint32_t n = nsplit;
+    ge_ext *next = buf + (size_t)nsplit * nbatch;
+    while (n > FB_REDUCE_GROUP) {
+        const uint32_t ng = (n + FB_REDUCE_GROUP - 1) / FB_REDUCE_GROUP;
+        const uint32_t nt = ng * nbatch;
+        LAUNCH(c, s, "fb_reduce", k_fb_reduce, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, nbatch, n, (uint32_t)FB_REDUCE_GROUP, cur, next);
+        cur = next;
+        next = next + (size_t)ng * nbatch;
+        n = ng;
+    }
+    *out = cur;
+    *nout = n;
+}
+
 static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, size_t n_unique, const void *d_gen_scalars,
                                  const void *d_uniq_scalars, const void *d_uniq_points, void *d_out, void *d_status_bytes,
                                  void *d_verdict, hipStream_t s) {
@@ -614,16 +784,13 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
     uint32_t *d_ids = nullptr;
     int rc = gen_ids_for(c, n, m, &d_ids);
     if (rc) return rc;
-    std::vector<uint32_t> nt(nbatch, (uint32_t)n_unique);
-    vb_plan pl;
-    make_vb_plan(pl, nbatch, nt.data());
     const uint32_t nsplit = pick_splits(c, nbatch, npairs);
     arena_plan ap;
     size_t off[7];
-    plan_vb(ap, pl, nbatch, off);
+    plan_vb_uniform(ap, nbatch, n_unique, off);
     const size_t off_status = ap.add(nbatch * 4);
     const size_t off_digits = ap.add((size_t)npairs * nbatch * 2 + 16);
-    const size_t off_partial = ap.add((size_t)nsplit * nbatch * sizeof(ge_ext) + 16);
+    const size_t off_partial = ap.add((size_t)2 * nsplit * nbatch * sizeof(ge_ext) + 16);
     rc = arena_reserve(c, ap.total);
     if (rc) return rc;
     uint32_t *d_status = (uint32_t *)(c->arena + off_status);
@@ -632,7 +799,7 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
     HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
     vb_dev d{};
     if (n_unique) {
-        rc = enqueue_vb(c, s, pl, nbatch, off, (const uint32_t *)d_uniq_scalars, (const uint32_t *)d_uniq_points, d_status, d);
+        rc = enqueue_vb_uniform(c, s, nbatch, n_unique, off, (const uint32_t *)d_uniq_scalars, (const uint32_t *)d_uniq_points, d_status, d);
         if (rc) return rc;
     }
     const uint32_t nrec = n_gen_terms * (uint32_t)nbatch;
@@ -641,8 +808,11 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
     const uint32_t nblk_p = (uint32_t)((nbatch + FB_BLOCK - 1) / FB_BLOCK);
     LAUNCH(c, s, "fb_accum", k_fb_accum, nblk_p * nsplit, FB_BLOCK, prm, (uint32_t)nbatch, nblk_p, nsplit, npairs, d_ids, d_digits,
            c->d_table, d_partial);
-    LAUNCH(c, s, "shared_finish", k_shared_finish, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, nsplit, d.col, n_unique ? 1 : 0,
-           d_partial, d_status, (uint32_t *)d_out, (uint8_t *)d_verdict);
+    ge_ext *d_red = nullptr;
+    uint32_t nred = 0;
+    enqueue_fb_reduce(c, s, (uint32_t)nbatch, nsplit, d_partial, &d_red, &nred);
+    LAUNCH(c, s, "shared_finish", k_shared_finish, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, nred, d.col, n_unique ? 1 : 0,
+           d_red, d_status, (uint32_t *)d_out, (uint8_t *)d_verdict);
     if (d_status_bytes)
         LAUNCH(c, s, "status_bytes", k_status_bytes, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d_status, (uint8_t *)d_status_bytes);
     HIPCHK(c, hipGetLastError());
@@ -831,16 +1001,13 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         rc = gen_ids_for(c, n, m, &d_ids);
         if (rc) return rc;
     }
-    std::vector<uint32_t> nt(nbatch, shape_verdict ? 0u : sh.U);
-    vb_plan pl;
-    make_vb_plan(pl, nbatch, nt.data());
     const uint32_t nsplit = pick_splits(c, nbatch, npairs);
     arena_plan ap;
     size_t off[7];
-    plan_vb(ap, pl, nbatch, off);
+    plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off);
     const size_t off_status = ap.add(nbatch * 4);
     const size_t off_digits = ap.add((size_t)npairs * nbatch * 2 + 16);
-    const size_t off_partial = ap.add((size_t)nsplit * nbatch * sizeof(ge_ext) + 16);
+    const size_t off_partial = ap.add((size_t)2 * nsplit * nbatch * sizeof(ge_ext) + 16);
     const size_t off_fields = ap.add((size_t)fl.count * nbatch * 32 + 16);
     const size_t off_upts = ap.add((size_t)sh.U * nbatch * 32 + 16);
     const size_t off_usc = ap.add((size_t)sh.U * nbatch * 32 + 16);
@@ -886,14 +1053,16 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const uint32_t nexp = sh.nm * nb32;
     LAUNCH(c, s, "rp_expand_b", k_rp_expand_b, (nexp + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
     vb_dev d{};
-    rc = enqueue_vb(c, s, pl, nbatch, off, d_usc, d_upts, d_status, d);
+    rc = enqueue_vb_uniform(c, s, nbatch, sh.U, off, d_usc, d_upts, d_status, d);
     if (rc) return rc;
     const uint32_t nblk_p = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
     LAUNCH(c, s, "fb_accum", k_fb_accum, nblk_p * nsplit, FB_BLOCK, prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, c->d_table,
            d_partial);
-    LAUNCH(c, s, "shared_finish", k_shared_finish, (nb32 + 63) / 64, 64, nb32, nsplit, d.col, 1, d_partial, d_status,
-           (uint32_t *)d_msm_out, d_mv);
-    LAUNCH(c, s, "rp_verdict", k_rp_verdict, (nb32 + 63) / 64, 64, nb32, d_status, d_mv, (uint8_t *)d_verdict);
+    ge_ext *d_red = nullptr;
+    uint32_t nred = 0;
+    enqueue_fb_reduce(c, s, nb32, nsplit, d_partial, &d_red, &nred);
+    LAUNCH(c, s, "shared_finish", k_shared_finish, (nb32 + 63) / 64, 64, nb32, nred, d.col, 1, d_red, d_status,
+           (uint32_t *)d_msm_out, (uint8_t *)d_verdict);
     HIPCHK(c, hipGetLastError());
     return BPGPU_OK;
 }

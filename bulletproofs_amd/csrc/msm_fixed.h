@@ -51,22 +51,12 @@ BP_HD void fb_base_thread(uint32_t g, fb_params prm, const uint32_t *gens_compre
     }
 }
 
-BP_HD void fb_entry_from_ext(fb_entry &e, const ge_ext &p) {
-    const fe d2 = BP_FE_D2;
-    fe zinv, x, y, xy;
-    fe_invert(zinv, p.Z);
-    fe_mul(x, p.X, zinv);
-    fe_mul(y, p.Y, zinv);
-    fe_mul(xy, x, y);
-    fe_add(e.ypx, y, x);
-    fe_carry(e.ypx);
-    fe_sub(e.ymx, y, x);
-    fe_mul(e.t2d, xy, d2);
-    e.pad[0] = 0;
-    e.pad[1] = 0;
-}
+// Table construction runs in two passes so that the field inversions of the projective -> affine
+// normalisation are shared (Montgomery's trick, 8 entries per inversion):
+//   fb_fill : thread = g * nwin + win   writes the 2^(W-1) multiples of base[g][win] as raw (X, Y, Z)
+//   fb_norm : thread = group of 8 consecutive entries   (X,Y,Z) -> (y+x, y-x, 2d*x*y)
+#define BP_FB_NORM_GROUP 8
 
-// thread = g * nwin + win : fill the 2^(W-1) multiples of base[g][win]
 BP_HD void fb_fill_thread(uint32_t tid, fb_params prm, const ge_ext *base, fb_entry *table) {
     const ge_ext p = base[tid];
     ge_cached pc;
@@ -75,9 +65,52 @@ BP_HD void fb_fill_thread(uint32_t tid, fb_params prm, const ge_ext *base, fb_en
     fb_entry *out = table + (uint64_t)tid * prm.half;
     for (uint32_t k = 0; k < prm.half; k++) {
         fb_entry e;
-        fb_entry_from_ext(e, cur);
+        e.ypx = cur.X;   // raw projective coordinates, normalised by fb_norm
+        e.ymx = cur.Y;
+        e.t2d = cur.Z;
+        e.pad[0] = 0;
+        e.pad[1] = 0;
         out[k] = e;
         ge_add_cached(cur, cur, pc, false);
+    }
+}
+
+BP_HD void fb_norm_thread(uint64_t gid, uint64_t n_entries, fb_entry *table) {
+    const fe d2 = BP_FE_D2;
+    fb_entry *e = table + gid * BP_FB_NORM_GROUP;
+    const uint32_t cnt = (gid * BP_FB_NORM_GROUP + BP_FB_NORM_GROUP <= n_entries) ? BP_FB_NORM_GROUP
+                                                                                   : (uint32_t)(n_entries - gid * BP_FB_NORM_GROUP);
+    fe pre[BP_FB_NORM_GROUP];   // pre[i] = Z_0 * ... * Z_i
+    pre[0] = e[0].t2d;
+#pragma unroll
+    for (uint32_t i = 1; i < BP_FB_NORM_GROUP; i++) {
+        if (i < cnt) fe_mul(pre[i], pre[i - 1], e[i].t2d);
+        else pre[i] = pre[i - 1];
+    }
+    fe inv;
+    fe_invert(inv, pre[BP_FB_NORM_GROUP - 1]);
+#pragma unroll
+    for (uint32_t ii = BP_FB_NORM_GROUP; ii-- > 0;) {
+        if (ii >= cnt) continue;
+        fe zinv, x, y, xy;
+        const fe Z = e[ii].t2d;
+        if (ii > 0) {
+            fe_mul(zinv, inv, pre[ii - 1]);
+            fe_mul(inv, inv, Z);
+        } else {
+            zinv = inv;
+        }
+        fe_mul(x, e[ii].ypx, zinv);
+        fe_mul(y, e[ii].ymx, zinv);
+        fe_mul(xy, x, y);
+        fb_entry o;
+        fe_add(o.ypx, y, x);
+        fe_carry(o.ypx);
+        fe_sub(o.ymx, y, x);
+        fe_mul(o.t2d, xy, d2);
+        o.pad[0] = 0;
+        o.pad[1] = 0;
+        e[ii] = o;
     }
 }
 
@@ -145,9 +178,22 @@ BP_HD void fb_accum_thread(uint32_t p, uint32_t split, uint32_t q0, uint32_t q1,
     partial[(uint64_t)split * nproofs + p] = acc;
 }
 
+// ---- partial reduction -------------------------------------------------------------------
+// thread tid = g * nproofs + p: out[g][p] = sum_{r < group} partial[g*group + r][p]  (r bounded by nsplit)
+BP_HD void fb_reduce_thread(uint32_t tid, uint32_t nproofs, uint32_t nsplit, uint32_t group, const ge_ext *partial, ge_ext *out) {
+    const uint32_t g = tid / nproofs, p = tid - g * nproofs;
+    const uint32_t s0 = g * group, s1 = (s0 + group < nsplit) ? s0 + group : nsplit;
+    ge_ext acc = partial[(uint64_t)s0 * nproofs + p];
+    for (uint32_t s = s0 + 1; s < s1; s++) {
+        const ge_ext q = partial[(uint64_t)s * nproofs + p];
+        ge_add(acc, acc, q);
+    }
+    out[tid] = acc;
+}
+
 // ---- finish --------------------------------------------------------------------------
 // thread p: result = Horner(col[p]) (unique, variable-base terms) + sum_split partial[split][p]
-// mode bit0: write compressed result; verdict[p] = 0 identity / 1 not (or status != 0)
+// out_words (optional): compressed result; verdict (optional): status[p] if set, else 0 identity / 1 not
 BP_HD void shared_finish_thread(uint32_t p, uint32_t nproofs, uint32_t nsplit, const ge_ext *col, bool have_unique,
                                 const ge_ext *partial, const uint32_t *status, uint32_t *out_words, uint8_t *verdict) {
     ge_ext acc;
@@ -164,7 +210,7 @@ BP_HD void shared_finish_thread(uint32_t p, uint32_t nproofs, uint32_t nsplit, c
 #pragma unroll
         for (int i = 0; i < 8; i++) out_words[8 * (uint64_t)p + i] = bad ? 0u : w[i];
     }
-    if (verdict) verdict[p] = (bad || !ge_is_identity(acc)) ? 1 : 0;
+    if (verdict) verdict[p] = bad ? (uint8_t)status[p] : (ge_is_identity(acc) ? 0 : 1);
 }
 
 }  // namespace bp

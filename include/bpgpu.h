@@ -62,9 +62,15 @@ int bpgpu_version(void);
 int bpgpu_ctx_create(int device, bpgpu_ctx **out);
 void bpgpu_ctx_destroy(bpgpu_ctx *ctx);
 const char *bpgpu_last_error(bpgpu_ctx *ctx);
-/* Tunables (call before bpgpu_gens_*): "fixed_window_bits" (2..16, default 8),
- * "fixed_splits" (0 = auto).  Returns BPGPU_ERR_INVALID_ARG for unknown keys. */
+/* Tunables (set before bpgpu_gens_*):
+ *   "fixed_window_bits"     window W of the generator tables, 2..16; 0 (default) = the largest W whose
+ *                           table (n_gens * ceil(256/W) * 2^(W-1) * 128 bytes) fits fixed_table_max_bytes
+ *   "fixed_table_max_bytes" HBM budget of the tables (default 12 GiB; the MI355X has 288 GB)
+ *   "fixed_splits"          workgroups the generator terms of one proof block are split over (0 = auto)
+ * get_option additionally answers "fixed_table_bytes" and the effective "fixed_window_bits".
+ * Returns BPGPU_ERR_INVALID_ARG for unknown keys. */
 int bpgpu_ctx_set_option(bpgpu_ctx *ctx, const char *key, int64_t value);
+int bpgpu_ctx_get_option(bpgpu_ctx *ctx, const char *key, int64_t *value);
 int bpgpu_synchronize(bpgpu_ctx *ctx);
 
 /* ---- generators ------------------------------------------------------------

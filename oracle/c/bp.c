@@ -13,6 +13,7 @@
 #include <stdlib.h>
 #include <pthread.h>
 #include <time.h>
+#include <malloc.h>
 
 struct oracle_gens {
     size_t gens_capacity, party_capacity;
@@ -42,6 +43,12 @@ static void generators_chain(ge_p3 *out, uint8_t *outc, uint8_t tag, uint32_t pa
 
 oracle_gens *oracle_gens_new(size_t gens_capacity, size_t party_capacity) {
     ge_init();
+    /* keep the per-verification scratch (up to a few MB) on the per-thread heaps: with the default
+       128 KiB mmap threshold every verification mmap()s/munmap()s and the batch drivers serialise on
+       the kernel's address-space lock beyond ~32 threads */
+    mallopt(M_MMAP_THRESHOLD, 16 << 20);   /* (glibc caps this at 32 MiB) */
+    mallopt(M_TRIM_THRESHOLD, 512 << 20);
+    mallopt(M_ARENA_MAX, 512);
     oracle_gens *g = calloc(1, sizeof *g);
     g->gens_capacity = gens_capacity; g->party_capacity = party_capacity;
     size_t tot = gens_capacity * party_capacity;

@@ -110,6 +110,7 @@ int h_msm_shared(uint32_t W, uint32_t nsplit, uint32_t n_gens_loaded, const uint
     for (uint32_t g = 0; g < prm.n_gens; g++) fb_base_thread(g, prm, (const uint32_t *)gens, base.data(), &bad);
     if (bad) return -5;
     for (uint32_t t = 0; t < prm.n_gens * prm.nwin; t++) fb_fill_thread(t, prm, base.data(), table.data());
+    for (uint64_t gq = 0; gq < (table.size() + BP_FB_NORM_GROUP - 1) / BP_FB_NORM_GROUP; gq++) fb_norm_thread(gq, table.size(), table.data());
     // unique part
     std::vector<vb_chunk> chunks; std::vector<uint32_t> chunk_first(nbatch + 1), term_chunk;
     uint32_t t0 = 0;
@@ -205,6 +206,7 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
     for (uint32_t g = 0; g < prm.n_gens; g++) fb_base_thread(g, prm, (const uint32_t *)gens, base.data(), &bad);
     if (bad) return -5;
     for (uint32_t t = 0; t < prm.n_gens * prm.nwin; t++) fb_fill_thread(t, prm, base.data(), table.data());
+    for (uint64_t gq = 0; gq < (table.size() + BP_FB_NORM_GROUP - 1) / BP_FB_NORM_GROUP; gq++) fb_norm_thread(gq, table.size(), table.data());
     std::vector<uint32_t> ids; ids.push_back(0); ids.push_back(1);
     const uint32_t tot = gens_capacity * party_capacity;
     for (uint32_t j = 0; j < m; j++) for (uint32_t i = 0; i < n; i++) ids.push_back(2 + j * gens_capacity + i);
@@ -246,7 +248,7 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
     }
     std::vector<uint8_t> verdict(nbatch + 1);
     for (uint32_t p = 0; p < nbatch; p++) shared_finish_thread(p, nbatch, nsplit, col.data(), true, partial.data(), status.data(), outw.data(), verdict.data());
-    for (uint32_t p = 0; p < nbatch; p++) verdict_out[p] = status[p] ? (uint8_t)status[p] : verdict[p];
+    for (uint32_t p = 0; p < nbatch; p++) verdict_out[p] = verdict[p];
     if (msm_out) memcpy(msm_out, outw.data(), (size_t)nbatch * 32);
     return 0;
 }

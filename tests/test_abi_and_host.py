@@ -1,0 +1,82 @@
+"""Host-side checks that need no GPU: the C-ABI library loads and exports every symbol declared in
+include/bpgpu.h, refuses to run without a device (no CPU fallback), and the product package never
+touches oracle/."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def built():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as ge
+    ge.build()
+    import bulletproofs_amd as bp
+    return bp
+
+
+def test_library_exports_every_declared_symbol(built):
+    hdr = open(os.path.join(ROOT, "include", "bpgpu.h")).read()
+    declared = sorted(set(re.findall(r"\b(bpgpu_[a-z0-9_]+)\s*\(", hdr)))
+    assert len(declared) >= 18
+    L = C.CDLL(built.LIB_PATH)
+    for name in declared:
+        assert hasattr(L, name), name
+    from bulletproofs_amd import _lib
+    assert sorted(_lib.EXPORTS) == declared
+    assert built.lib().bpgpu_version() >= 100
+
+
+def test_no_cpu_fallback(built):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    with pytest.raises(built.BpgpuError, match="NO_DEVICE"):
+        built.Context(0)
+
+
+def test_product_never_imports_oracle():
+    pkg = os.path.join(ROOT, "bulletproofs_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".h", ".hip", ".cpp")):
+                txt = open(os.path.join(dirpath, f)).read()
+                assert "pyoracle" not in txt and "liboracle" not in txt and "bp_twin" not in txt, f
+                assert not re.search(r'#include\s+"[^"]*oracle', txt), f
+    out = subprocess.check_output(["ldd", os.path.join(pkg, "csrc", "libbpgpu.so")]).decode()
+    assert "liboracle" not in out
+
+
+def test_workload_fixtures_and_figures():
+    sys.path.insert(0, ROOT)
+    from bulletproofs_amd import workload as wl
+    fx = wl.load_fixture("cfg2_n64_m1")
+    assert (fx.n, fx.m, fx.count, fx.proof_len) == (64, 1, 1024, 672) and fx.label == b"AggregateRangeProofBenchmark"
+    p, c = wl.tile_batch(fx, 1030, first=1020)
+    assert len(p) == 1030 * 672 and p[4 * 672:5 * 672] == fx.proofs[:672] and len(c) == 1030 * 32
+    # SURVEY.md Appendix B / section 8d figures
+    assert [wl.msm_terms(*s) for s in ((32, 1), (64, 1), (64, 16), (64, 32))] == [81, 147, 2090, 4156]
+    assert [wl.reference_point_ops(N) for N in (147, 2090, 4156, 6179)] == [7704, 77608, 145786, 212545]
+    assert [wl.algorithmic_bytes_per_verification(*s) for s in ((64, 1), (64, 16), (64, 32))] == [5280, 68192, 134880]
+    for total, world in ((4096, 8), (10, 4), (3, 8)):
+        r = [wl.shard_range(total, world, k) for k in range(world)]
+        assert r[0][0] == 0 and r[-1][1] == total and all(r[i][1] == r[i + 1][0] for i in range(world - 1))
+        assert max(h - l for l, h in r) - min(h - l for l, h in r) <= 1
+
+
+def test_fixture_proofs_verify_with_oracle(oracle):
+    sys.path.insert(0, ROOT)
+    from bulletproofs_amd import workload as wl
+    for name in ("cfg1_n32_m1", "cfg3_n64_m16", "cfg4_n64_m32"):
+        fx = wl.load_fixture(name)
+        g = oracle.Gens(fx.n, fx.m)
+        cnt = min(fx.count, 4)
+        _, v, _ = oracle.verify_batch(g, fx.proofs[:cnt * fx.proof_len], fx.commitments[:cnt * 32 * fx.m], fx.m, fx.n, fx.label,
+                                      bytes(range(64)) * cnt, threads=2)
+        assert v == bytes(cnt)

@@ -1,0 +1,213 @@
+"""The per-lane bodies of the HIP kernels (bulletproofs_amd/csrc/*.h) compiled for the host with
+bounds checks (tests/cpu_harness) and compared with the oracle / Python twin.  Covers the exact
+device arithmetic and pipeline logic without a GPU; the `-m gpu` tests then only have to show that
+the same code behaves identically when launched as kernels."""
+import ctypes as C
+import hashlib
+import random
+
+import pytest
+
+import bp_twin as T
+import harness_lib
+
+
+@pytest.fixture(scope="module")
+def H():
+    return harness_lib.lib()
+
+
+def _b(x):
+    return (x % T.P).to_bytes(32, "little")
+
+
+def _feop(H, op, x, y=0):
+    out = C.create_string_buffer(32)
+    H.h_fe_op(op, _b(x), _b(y), out)
+    return int.from_bytes(out.raw, "little")
+
+
+def test_field_arithmetic_matches_big_ints(H):
+    P = T.P
+    random.seed(7)
+    vals = [0, 1, 2, P - 1, P - 2, 19, 2**255 - 20, 2**26 - 1, 2**51] + [random.randrange(P) for _ in range(200)]
+    for i, x in enumerate(vals):
+        y = vals[(i * 7 + 3) % len(vals)]
+        assert _feop(H, 0, x, y) == x * y % P
+        assert _feop(H, 1, x) == x * x % P
+        assert _feop(H, 2, x, y) == (x + y) % P
+        assert _feop(H, 3, x, y) == (x - y) % P
+        assert _feop(H, 4, x) == (-x) % P
+        assert _feop(H, 8, x, y) == ((2 * x + y) * (x + 2 * y) - (2 * x + y) ** 2) % P   # lazy-limb chain
+        if i < 24:
+            assert _feop(H, 5, x) == pow(x, P - 2, P)
+            assert _feop(H, 6, x) == pow(x, (P - 5) // 8, P)
+        fl = H.h_fe_flags(_b(x))
+        assert (fl & 1) == (x % P & 1) and bool(fl & 2) == (x % P == 0)
+    out = C.create_string_buffer(32)   # non-canonical input bytes are reduced implicitly
+    H.h_fe_op(7, (P + 5).to_bytes(32, "little"), _b(0), out)
+    assert int.from_bytes(out.raw, "little") == 5
+
+
+def test_group_ops_and_ristretto_codec(H):
+    pts = [T.from_uniform_bytes(hashlib.shake_256(b"p%d" % i).digest(64)) for i in range(24)]
+    enc = [T.compress(p) for p in pts]
+    o = C.create_string_buffer(32)
+    for i in range(24):
+        a, b = enc[i], enc[(i + 1) % 24]
+        pa, pb = pts[i], pts[(i + 1) % 24]
+        xy = C.create_string_buffer(128)
+        assert H.h_decompress(a, xy) == 1
+        d = T.decompress(a)
+        assert [int.from_bytes(xy.raw[32 * k:32 * k + 32], "little") for k in range(4)] == list(d)
+        H.h_compress_xyzt(xy, o)
+        assert o.raw == a
+        exp = {0: T.pt_add(pa, pb), 1: T.pt_add(pa, T.pt_neg(pb)), 2: T.pt_dbl(pa), 3: T.pt_add(pa, pb),
+               4: T.pt_add(pa, T.pt_neg(pb)), 5: pa, 6: T.pt_add(T.pt_mul(16, pa), pb), 7: T.pt_neg(pa)}
+        for op, e in exp.items():
+            assert H.h_point_op(op, a, b, o) & 1 and o.raw == T.compress(e), (op, i)
+        assert H.h_point_op(1, a, a, o) == 3 and o.raw == bytes(32)      # P - P: identity flag + zero encoding
+        u = hashlib.shake_256(b"u%d" % i).digest(64)
+        H.h_from_uniform(u, o)
+        assert o.raw == T.compress(T.from_uniform_bytes(u))
+    P = T.P
+    for e in [bytes([1]) + bytes(31), P.to_bytes(32, "little"), (P + 2).to_bytes(32, "little"), b"\xff" * 32, (2).to_bytes(32, "little")]:
+        assert (H.h_decompress(e, C.create_string_buffer(128)) == 1) == (T.decompress(e) is not None)
+    for i in range(200):   # random byte strings: validity decision must agree with RFC 9496 decoding
+        e = hashlib.shake_256(b"e%d" % i).digest(32)
+        e = bytes([e[0] & 0xfe]) + e[1:31] + bytes([e[31] & 0x7f])
+        assert (H.h_decompress(e, C.create_string_buffer(128)) == 1) == (T.decompress(e) is not None)
+    assert H.h_decompress(bytes(32), C.create_string_buffer(128)) == 1
+
+
+def test_scalar_field_keccak_merlin(H):
+    L = T.L
+    random.seed(3)
+
+    def scop(op, x, y=0):
+        o = C.create_string_buffer(32)
+        H.h_sc_op(op, x.to_bytes(32, "little"), y.to_bytes(32, "little"), o)
+        return int.from_bytes(o.raw, "little")
+    vals = [0, 1, 2, L - 1, L - 2, 2**252, 2**128] + [random.randrange(L) for _ in range(60)]
+    for i, x in enumerate(vals):
+        y = vals[(3 * i + 1) % len(vals)]
+        assert scop(0, x, y) == x * y % L and scop(1, x, y) == (x + y) % L
+        assert scop(2, x, y) == (x - y) % L and scop(3, x) == (-x) % L
+        if i < 8 and x:
+            assert scop(4, x) == pow(x, L - 2, L)
+        lo, hi = random.randrange(2**256), random.randrange(2**256)
+        assert scop(5, lo, hi) == (lo + (hi << 256)) % L
+    assert scop(5, 2**256 - 1, 2**256 - 1) == (2**512 - 1) % L
+    out = C.create_string_buffer(32)
+    H.h_merlin_kat(b"test protocol", 13, b"some label", 10, b"some data", 9, b"challenge", 9, out, 32)
+    assert out.raw.hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    for n in (0, 1, 71, 72, 135, 136, 137, 300):
+        msg = (bytes(range(256)) * 2)[:n]
+        o = C.create_string_buffer(300)
+        H.h_shake256(msg, n, o, 300)
+        assert o.raw == hashlib.shake_256(msg).digest(300)
+        o = C.create_string_buffer(64)
+        H.h_sha3_512(msg, n, o)
+        assert o.raw == hashlib.sha3_512(msg).digest()
+
+
+def _sc(tag):
+    return (int.from_bytes(hashlib.shake_256(tag).digest(64), "little") % T.L).to_bytes(32, "little")
+
+
+def _pt(oracle, tag):
+    o = C.create_string_buffer(32)
+    oracle.lib().oracle_from_uniform_bytes(hashlib.shake_256(tag).digest(64), o)
+    return o.raw
+
+
+def test_variable_base_pipeline_lane_by_lane(H, oracle):
+    sizes = [0, 1, 2, 31, 32, 33, 70]
+    S = P = b""
+    for k, n in enumerate(sizes):
+        S += b"".join(_sc(b"m%d-s%d" % (k, i)) for i in range(n))
+        P += b"".join(_pt(oracle, b"m%d-p%d" % (k, i)) for i in range(n))
+    nt = (C.c_uint32 * len(sizes))(*sizes)
+    out, st = C.create_string_buffer(32 * len(sizes)), C.create_string_buffer(len(sizes))
+    H.h_msm_vb(len(sizes), nt, S, P, out, st)
+    off = 0
+    for k, n in enumerate(sizes):
+        assert st.raw[k] == 0 and out.raw[32 * k:32 * k + 32] == oracle.msm(S[off:off + 32 * n], P[off:off + 32 * n])[1]
+        off += 32 * n
+    sp = [0, 1, T.L - 1, 8, int("8" * 63, 16) % T.L, 2**252]
+    s = b"".join(x.to_bytes(32, "little") for x in sp)
+    p = b"".join(_pt(oracle, b"sp%d" % i) for i in range(len(sp)))
+    nt = (C.c_uint32 * 1)(len(sp))
+    H.h_msm_vb(1, nt, s, p, out, st)
+    assert out.raw[:32] == oracle.msm(s, p)[1] and st.raw[0] == 0
+    bad = bytearray(p)
+    bad[0] |= 1
+    H.h_msm_vb(1, nt, s, bytes(bad), out, st)
+    assert st.raw[0] == 1 and out.raw[:32] == bytes(32)
+    s2 = bytearray(s)
+    s2[0:32] = T.L.to_bytes(32, "little")
+    H.h_msm_vb(1, nt, bytes(s2), p, out, st)
+    assert st.raw[0] == 2
+
+
+@pytest.mark.parametrize("W,nsplit", [(4, 3), (5, 8), (7, 1)])
+def test_shared_generator_pipeline_lane_by_lane(H, oracle, W, nsplit):
+    g = oracle.Gens(8, 2)
+    G, Hh, B, Bb = g.export()
+    gens = Bb + B + G + Hh
+    n, m = 8, 2
+    ngen = 2 * n * m + 2
+    ids = [0, 1] + [2 + j * 8 + i for j in range(m) for i in range(n)] + [2 + 16 + j * 8 + i for j in range(m) for i in range(n)]
+    nb, nu = 4, 35
+    GS = b"".join(_sc(b"g%d-%d-%d" % (W, b, i)) for b in range(nb) for i in range(ngen))
+    edge = [0, 1, T.L - 1, 1 << (W - 1), (1 << W) - 1, 2**252]
+    GS = b"".join(x.to_bytes(32, "little") for x in edge) + GS[32 * len(edge):]
+    US = b"".join(_sc(b"us%d-%d" % (b, i)) for b in range(nb) for i in range(nu))
+    UP = b"".join(_pt(oracle, b"up%d-%d" % (b, i)) for b in range(nb) for i in range(nu))
+    out, st, vd = C.create_string_buffer(32 * nb), C.create_string_buffer(nb), C.create_string_buffer(nb)
+    assert H.h_msm_shared(W, nsplit, 34, gens, ngen, (C.c_uint32 * ngen)(*ids), nb, nu, GS, US, UP, out, st, vd) == 0
+    gp = b"".join(gens[32 * i:32 * i + 32] for i in ids)
+    for b in range(nb):
+        exp = oracle.msm(GS[32 * ngen * b:32 * ngen * (b + 1)] + US[32 * nu * b:32 * nu * (b + 1)], gp + UP[32 * nu * b:32 * nu * (b + 1)])
+        assert st.raw[b] == 0 and out.raw[32 * b:32 * b + 32] == exp[1] and vd.raw[b] == 1
+    assert H.h_msm_shared(W, nsplit, 34, gens, ngen, (C.c_uint32 * ngen)(*ids), 1, 0, bytes(32 * ngen), b"", b"", out, st, vd) == 0
+    assert vd.raw[0] == 0 and out.raw[:32] == bytes(32)
+
+
+def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, golden):
+    """rp_transcript -> rp_expand_a/b -> vb_* / fb_* -> finish, emulated lane by lane, on the reference's
+    golden proofs (small shapes; the GPU tests cover all 16) plus tampered copies."""
+    label = golden["label"]
+    vc = golden["vc_bytes"]
+    for case in golden["cases"]:
+        n, m = case["n"], case["m"]
+        if n * m > 32:
+            continue
+        pr = bytes.fromhex(case["proof"])
+        bad = bytearray(pr)
+        bad[128] ^= 1
+        proofs = pr + bytes(bad) + pr
+        coms = vc[:32 * m] + vc[:32 * m] + ((vc[32:32 * m] + vc[:32]) if m > 1 else vc[32:64])
+        rng = hashlib.shake_256(b"h%d%d" % (n, m)).digest(64 * 3)
+        gg = oracle.Gens(n, m)
+        G2, H2, B2, Bb2 = gg.export()
+        vd, mo = C.create_string_buffer(3), C.create_string_buffer(96)
+        assert H.h_rp_verify(4, 3, n, m, Bb2 + B2 + G2 + H2, n, m, 3, proofs, len(pr), coms, label, len(label), rng, vd, mo) == 0
+        for b in range(3):
+            erc, emsm = oracle.verify(gg, proofs[len(pr) * b:len(pr) * (b + 1)], coms[32 * m * b:32 * m * (b + 1)], n, label, rng[64 * b:64 * b + 64])
+            assert vd.raw[b] == erc and mo.raw[32 * b:32 * b + 32] == emsm, (n, m, b)
+        assert list(vd.raw) == [0, 1, 1]
+    pr = bytes.fromhex(golden["cases"][0]["proof"])
+    nc = bytearray(pr)
+    nc[128:160] = b"\xff" * 32
+    ia = bytearray(pr)
+    ia[0:32] = bytes(32)
+    us = bytearray(pr)
+    us[32] |= 1
+    gg = oracle.Gens(8, 1)
+    G2, H2, B2, Bb2 = gg.export()
+    vd, mo = C.create_string_buffer(4), C.create_string_buffer(128)
+    rng = hashlib.shake_256(b"zz").digest(256)
+    assert H.h_rp_verify(4, 2, 8, 1, Bb2 + B2 + G2 + H2, 8, 1, 4, bytes(nc) + bytes(ia) + bytes(us) + pr, len(pr), vc[:32] * 4, label,
+                         len(label), rng, vd, mo) == 0
+    assert list(vd.raw) == [2, 1, 1, 0]
