@@ -23,6 +23,9 @@ import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+# The ROCm runtime maps HIP streams onto at most GPU_MAX_HW_QUEUES hardware queues (default 4); batches
+# issued on different streams only overlap on the device when they sit on different hardware queues.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 
 def parse_args():
@@ -34,7 +37,7 @@ def parse_args():
                     help="BASELINE.json config; cfg2 (batch of 1024 single 64-bit proofs per GPU) is the metric's config")
     ap.add_argument("--batch", type=int, default=0, help="override proofs per GPU per step")
     ap.add_argument("--window-bits", type=int, default=0, help="fixed-base window (default: library default)")
-    ap.add_argument("--streams", type=int, default=4,
+    ap.add_argument("--streams", type=int, default=8,
                     help="independent (context, HIP stream) pairs the steps are issued on round-robin, so that "
                          "consecutive batches overlap on the device (one context per stream, as bpgpu.h prescribes "
                          "for concurrent callers)")

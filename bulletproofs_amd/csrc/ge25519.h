@@ -51,24 +51,25 @@ BP_HD void ge_to_cached(ge_cached &r, const ge_ext &p) {
 }
 
 // r = p + q (neg: r = p - q).  8M.  All stored operands are reduced.
+// -q swaps (Y+X, Y-X) and negates T2d; the negation is folded into which of D-C / D+C plays F and G.
 BP_HD void ge_add_cached(ge_ext &r, const ge_ext &p, const ge_cached &q, bool neg) {
-    fe ypx, ymx, a, b, c, d, qa, qb, qt;
-    fe_select(qa, q.YmX, q.YpX, neg);   // -q swaps (Y+X, Y-X) and negates T2d
+    fe ypx, ymx, a, b, c, d, qa, qb;
+    fe_select(qa, q.YmX, q.YpX, neg);
     fe_select(qb, q.YpX, q.YmX, neg);
-    qt = q.T2d;
-    fe_cneg(qt, neg);
     fe_add(ypx, p.Y, p.X);              // lazy
     fe_sub(ymx, p.Y, p.X);
     fe_mul(a, ymx, qa);
     fe_mul(b, ypx, qb);
-    fe_mul(c, p.T, qt);
+    fe_mul(c, p.T, q.T2d);
     fe_mul(d, p.Z, q.Z);
     fe_add(d, d, d);                    // lazy (2x)
-    fe e, f, g, h;
+    fe e, f, g, h, dmc, dpc;
     fe_sub(e, b, a);
     fe_add(h, b, a);                    // lazy (2x)
-    fe_sub(f, d, c);
-    fe_add(g, d, c);                    // lazy (3x)
+    fe_sub(dmc, d, c);
+    fe_add(dpc, d, c);                  // lazy (3x)
+    fe_select(f, dmc, dpc, neg);
+    fe_select(g, dpc, dmc, neg);
     fe_mul(r.X, e, f);
     fe_mul(r.Y, g, h);
     fe_mul(r.Z, f, g);
@@ -77,22 +78,22 @@ BP_HD void ge_add_cached(ge_ext &r, const ge_ext &p, const ge_cached &q, bool ne
 
 // mixed addition with an affine Niels point: 7M
 BP_HD void ge_madd(ge_ext &r, const ge_ext &p, const ge_niels &q, bool neg) {
-    fe ypx, ymx, a, b, c, d, qa, qb, qt;
+    fe ypx, ymx, a, b, c, d, qa, qb;
     fe_select(qa, q.ymx, q.ypx, neg);
     fe_select(qb, q.ypx, q.ymx, neg);
-    qt = q.t2d;
-    fe_cneg(qt, neg);
     fe_add(ypx, p.Y, p.X);
     fe_sub(ymx, p.Y, p.X);
     fe_mul(a, ymx, qa);
     fe_mul(b, ypx, qb);
-    fe_mul(c, p.T, qt);
+    fe_mul(c, p.T, q.t2d);
     fe_add(d, p.Z, p.Z);
-    fe e, f, g, h;
+    fe e, f, g, h, dmc, dpc;
     fe_sub(e, b, a);
     fe_add(h, b, a);
-    fe_sub(f, d, c);
-    fe_add(g, d, c);
+    fe_sub(dmc, d, c);
+    fe_add(dpc, d, c);
+    fe_select(f, dmc, dpc, neg);
+    fe_select(g, dpc, dmc, neg);
     fe_mul(r.X, e, f);
     fe_mul(r.Y, g, h);
     fe_mul(r.Z, f, g);

@@ -157,22 +157,51 @@ BP_HD void fb_recode_thread(uint32_t tid, fb_params prm, uint32_t nproofs, uint3
 
 // ---- accumulation -----------------------------------------------------------------
 // thread (split, p): partial[split*nproofs + p] = sum over pairs q in [q0, q1) of d(q,p) * 2^(W*win) * P_{gen_ids[g]}
+// Software-pipelined: the table line of pair q+1 and the digit of pair q+2 are in flight while the
+// seven field multiplications of pair q execute, so the random 128-byte gathers never stall the lane.
+struct fb_line {
+    uint32_t w[30];   // ypx, ymx, t2d as 3 x 10 limbs (the payload of one fb_entry)
+};
+BP_HD void fb_load_line(fb_line &l, const fb_entry *e) {
+    const uint32_t *src = (const uint32_t *)e;
+#pragma unroll
+    for (int i = 0; i < 30; i++) l.w[i] = src[i];
+}
+BP_HD const fb_entry *fb_entry_addr(const fb_entry *table, const uint32_t *gen_ids, fb_params prm, uint32_t q, uint32_t v) {
+    const uint32_t g = q / prm.nwin, win = q - g * prm.nwin;
+    const int d = (int)(v & (2u * prm.half - 1u)) - (int)prm.half;   // masked: rows of rejected proofs are never written
+    const uint32_t a = (uint32_t)(d < 0 ? -d : d);
+    return table + ((uint64_t)gen_ids[g] * prm.nwin + win) * prm.half + (a ? a - 1 : 0);
+}
 BP_HD void fb_accum_thread(uint32_t p, uint32_t split, uint32_t q0, uint32_t q1, fb_params prm, uint32_t nproofs,
                            const uint32_t *gen_ids, const uint16_t *digits, const fb_entry *table, ge_ext *partial) {
     ge_ext acc;
     ge_identity(acc);
-    for (uint32_t q = q0; q < q1; q++) {
-        const uint32_t g = q / prm.nwin, win = q - g * prm.nwin;
-        // (masked: rows of rejected proofs are never written, keep the gather in bounds)
-        const int d = (int)(digits[(uint64_t)q * nproofs + p] & (2u * prm.half - 1u)) - (int)prm.half;
-        if (d != 0) {
-            const uint32_t a = (uint32_t)(d < 0 ? -d : d);
-            const fb_entry *e = table + ((uint64_t)gen_ids[g] * prm.nwin + win) * prm.half + (a - 1);
-            ge_niels n;
-            n.ypx = e->ypx;
-            n.ymx = e->ymx;
-            n.t2d = e->t2d;
-            ge_madd(acc, acc, n, d < 0);
+    if (q0 < q1) {
+        uint32_t v_cur = digits[(uint64_t)q0 * nproofs + p];
+        uint32_t v_next = (q0 + 1 < q1) ? digits[(uint64_t)(q0 + 1) * nproofs + p] : prm.half;
+        fb_line line_cur;
+        fb_load_line(line_cur, fb_entry_addr(table, gen_ids, prm, q0, v_cur));
+        for (uint32_t q = q0; q < q1; q++) {
+            // issue the loads of the following iterations first
+            fb_line line_next = line_cur;
+            uint32_t v_next2 = prm.half;
+            if (q + 1 < q1) fb_load_line(line_next, fb_entry_addr(table, gen_ids, prm, q + 1, v_next));
+            if (q + 2 < q1) v_next2 = digits[(uint64_t)(q + 2) * nproofs + p];
+            const int d = (int)(v_cur & (2u * prm.half - 1u)) - (int)prm.half;
+            if (d != 0) {
+                ge_niels n;
+#pragma unroll
+                for (int i = 0; i < 10; i++) {
+                    n.ypx.v[i] = line_cur.w[i];
+                    n.ymx.v[i] = line_cur.w[10 + i];
+                    n.t2d.v[i] = line_cur.w[20 + i];
+                }
+                ge_madd(acc, acc, n, d < 0);
+            }
+            line_cur = line_next;
+            v_cur = v_next;
+            v_next = v_next2;
         }
     }
     partial[(uint64_t)split * nproofs + p] = acc;

@@ -8,8 +8,9 @@
 //   rp_expand_b   : lane = (i, proof)  s_i, g_i = -z - a s_i, h_i = z + y^-i (z^2 z^j 2^i' - b s_i^-1)
 //                                  (ipp.rs:241-250, mod.rs:406-419), written straight as
 //                                  fixed-window digits for the generator tables
-// Per-proof intermediate scalars live in HBM, field-major ([field][proof][8 words]) so that the
-// 64 proofs of a wavefront read consecutive 32-byte records.
+// Per-proof intermediate scalars live in HBM, field-major ([field][proof][10 words]) so that the
+// 64 proofs of a wavefront read consecutive 40-byte records (8 words: canonical scalar; 10 words:
+// lazy 28-bit-limb Montgomery form, sc25519.h).
 #ifndef BPGPU_RANGEPROOF_H
 #define BPGPU_RANGEPROOF_H
 #include "keccak.h"
@@ -64,15 +65,26 @@ BP_HD rp_fields rp_field_layout(uint32_t k, uint32_t m) {
     f.count = f.zzzj_m + m;
     return f;
 }
+#define BP_RP_REC 10   // words per record
 BP_HD void rp_store(uint32_t *buf, uint32_t nproofs, uint32_t field, uint32_t p, const sc &s) {
-    uint32_t *d = buf + ((uint64_t)field * nproofs + p) * 8;
+    uint32_t *d = buf + ((uint64_t)field * nproofs + p) * BP_RP_REC;
 #pragma unroll
     for (int i = 0; i < 8; i++) d[i] = s.v[i];
 }
 BP_HD void rp_load(sc &s, const uint32_t *buf, uint32_t nproofs, uint32_t field, uint32_t p) {
-    const uint32_t *d = buf + ((uint64_t)field * nproofs + p) * 8;
+    const uint32_t *d = buf + ((uint64_t)field * nproofs + p) * BP_RP_REC;
 #pragma unroll
     for (int i = 0; i < 8; i++) s.v[i] = d[i];
+}
+BP_HD void rp_store28(uint32_t *buf, uint32_t nproofs, uint32_t field, uint32_t p, const sc28 &s) {
+    uint32_t *d = buf + ((uint64_t)field * nproofs + p) * BP_RP_REC;
+#pragma unroll
+    for (int i = 0; i < 10; i++) d[i] = s.v[i];
+}
+BP_HD void rp_load28(sc28 &s, const uint32_t *buf, uint32_t nproofs, uint32_t field, uint32_t p) {
+    const uint32_t *d = buf + ((uint64_t)field * nproofs + p) * BP_RP_REC;
+#pragma unroll
+    for (int i = 0; i < 10; i++) s.v[i] = d[i];
 }
 
 // 32-byte record -> 8 LE words; all proof / commitment / rng buffers are 4-byte aligned
@@ -208,22 +220,35 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
     if (verr) status_raise(status + p, BP_VERDICT_VERIFICATION);
 }
 
-// sum_{i<2^lg} x^i by repeated doubling (src/util.rs:240-256); x plain
-BP_HD void rp_sum_of_powers_pow2(sc &r, const sc &x, uint32_t lg) {
-    sc one;
-    sc_from_u32(one, 1);
+// sum_{i<2^lg} x^i by repeated doubling (src/util.rs:240-256); Montgomery form in and out
+BP_HD void rp_sum_of_powers_pow2(sc28 &r, const sc28 &xm, uint32_t lg) {
+    sc28 one_m;
+    sc28_one_mont(one_m);
     if (lg == 0) {
-        r = one;
+        r = one_m;
         return;
     }
-    sc result, factor = x, t;
-    sc_add(result, one, x);
+    // result = 1 + x (lazy limb-wise add: both < 2^254 -> renormalise through a multiplication by 1)
+    sc a, b, sum;
+    sc_from_sc28(a, one_m);
+    sc_from_sc28(b, xm);
+    sc_add(sum, a, b);
+    sc28 result, factor = xm, t;
+    sc28_from_sc(result, sum);
     for (uint32_t i = 1; i < lg; i++) {
-        sc_mul(factor, factor, factor);
-        sc_mul(t, factor, result);
-        sc_add(result, result, t);
+        sc28_montmul(factor, factor, factor);
+        sc28_montmul(t, factor, result);
+        sc_from_sc28(a, t);
+        sc_from_sc28(b, result);
+        sc_add(sum, a, b);
+        sc28_from_sc(result, sum);
     }
     r = result;
+}
+
+BP_HD void store_words8(uint32_t *dst, const sc &s) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) dst[q] = s.v[q];
 }
 
 // ---- stage 2: per-proof scalars -----------------------------------------------------------
@@ -234,7 +259,7 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
     if (status[p] != 0) return;   // digits/scalars of rejected proofs are never consumed (finish masks them)
     const uint32_t B = sh.nproofs, k = sh.k;
     const rp_fields fl = rp_field_layout(k, sh.m);
-    sc y, z, x, w, c, tx, txb, eb, a, b, one;
+    sc y, z, x, w, c, tx, txb, eb, a, b, one, t0, t1;
     sc_from_u32(one, 1);
     rp_load(y, fields, B, RPF_Y, p);
     rp_load(z, fields, B, RPF_Z, p);
@@ -246,105 +271,132 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
     rp_load(eb, fields, B, RPF_EB, p);
     rp_load(a, fields, B, RPF_A, p);
     rp_load(b, fields, B, RPF_B, p);
+    sc28 ym, zm, xm, wm, cm, txm, txbm, am, bm;
+    sc_to_mont28(ym, y);
+    sc_to_mont28(zm, z);
+    sc_to_mont28(xm, x);
+    sc_to_mont28(wm, w);
+    sc_to_mont28(cm, c);
+    sc_to_mont28(txm, tx);
+    sc_to_mont28(txbm, txb);
+    sc_to_mont28(am, a);
+    sc_to_mont28(bm, b);
 
-    // batch inversion of (y, u_0, .., u_{k-1}) (Scalar::batch_invert, ipp.rs:226-227; y.invert(), mod.rs:414)
-    // prefix products are parked in the u_m slots (overwritten below)
-    sc acc = y, u;
+    // batch inversion of (y, u_0, .., u_{k-1}) (Scalar::batch_invert, ipp.rs:226-227; y.invert(), mod.rs:414),
+    // everything in Montgomery form; prefix products are parked in the uinv_m slots (overwritten below)
+    sc28 acc = ym, um;
+    sc u;
     for (uint32_t i = 0; i < k; i++) {
-        rp_store(fields, B, fl.u_m + i, p, acc);        // prefix before u_i
+        rp_store28(fields, B, fl.uinv_m + i, p, acc);     // prefix before u_i
         rp_load(u, fields, B, fl.u + i, p);
-        sc_mul(acc, acc, u);
+        sc_to_mont28(um, u);
+        rp_store28(fields, B, fl.u_m + i, p, um);
+        sc28_montmul(acc, acc, um);
     }
-    sc inv;
-    sc_invert(inv, acc);                                  // (y * prod u_i)^-1
+    sc28 inv;
+    sc28_invert_mont(inv, acc);                           // (y * prod u_i)^-1
     uint32_t *us = uniq_scalars + (uint64_t)p * sh.U * 8;
     for (uint32_t ii = k; ii-- > 0;) {
-        sc pre, ui, um, uim, t;
-        rp_load(pre, fields, B, fl.u_m + ii, p);
-        rp_load(u, fields, B, fl.u + ii, p);
-        sc_mul(ui, inv, pre);                             // u_ii^-1
-        sc_mul(inv, inv, u);                              // drop u_ii from the running inverse
-        sc_to_mont(um, u);
-        sc_to_mont(uim, ui);
-        rp_store(fields, B, fl.u_m + ii, p, um);
-        rp_store(fields, B, fl.uinv_m + ii, p, uim);
-        sc_mul(t, u, u);                                  // u_i^2   -> L_i coefficient
-        for (int q = 0; q < 8; q++) us[(4 + ii) * 8 + q] = t.v[q];
-        sc_mul(t, ui, ui);                                // u_i^-2  -> R_i coefficient
-        for (int q = 0; q < 8; q++) us[(4 + k + ii) * 8 + q] = t.v[q];
+        sc28 pre, uim, sq;
+        rp_load28(pre, fields, B, fl.uinv_m + ii, p);
+        rp_load28(um, fields, B, fl.u_m + ii, p);
+        sc28_montmul(uim, inv, pre);                      // u_ii^-1
+        sc28_montmul(inv, inv, um);                       // drop u_ii from the running inverse
+        rp_store28(fields, B, fl.uinv_m + ii, p, uim);
+        sc28_montmul(sq, um, um);                         // u_i^2   -> L_i coefficient
+        sc_from_mont28(t0, sq);
+        store_words8(us + (4 + ii) * 8, t0);
+        sc28_montmul(sq, uim, uim);                       // u_i^-2  -> R_i coefficient
+        sc_from_mont28(t0, sq);
+        store_words8(us + (4 + k + ii) * 8, t0);
     }
-    const sc y_inv = inv;                                 // what is left is y^-1
-    // y^-(2^b) table (Montgomery)
+    // what is left in inv is y^-1: table of y^-(2^b)
     {
-        sc pw;
-        sc_to_mont(pw, y_inv);
+        sc28 pw = inv;
         for (uint32_t bb = 0; bb < k; bb++) {
-            rp_store(fields, B, fl.yinvp_m + bb, p, pw);
-            sc_montmul(pw, pw, pw);
+            rp_store28(fields, B, fl.yinvp_m + bb, p, pw);
+            sc28_montmul(pw, pw, pw);
         }
     }
-    sc zz, minus_z, t0, t1;
-    sc_mul(zz, z, z);
+    sc28 zzm;
+    sc28_montmul(zzm, zm, zm);
+    sc zz, minus_z;
+    sc_from_mont28(zz, zzm);
     sc_neg(minus_z, z);
     rp_store(fields, B, RPF_ZZ, p, zz);
     rp_store(fields, B, RPF_MINUS_Z, p, minus_z);
-    sc_to_mont(t0, a);  rp_store(fields, B, RPF_A_M, p, t0);
-    sc_to_mont(t0, b);  rp_store(fields, B, RPF_B_M, p, t0);
-    sc_to_mont(t0, z);  rp_store(fields, B, RPF_Z_M, p, t0);
-    sc_to_mont(t0, zz); rp_store(fields, B, RPF_ZZ_M, p, t0);
+    rp_store28(fields, B, RPF_A_M, p, am);
+    rp_store28(fields, B, RPF_B_M, p, bm);
+    rp_store28(fields, B, RPF_Z_M, p, zm);
+    rp_store28(fields, B, RPF_ZZ_M, p, zzm);
     // unique coefficients: 1, x, c x, c x^2 (A, S, T_1, T_2)
-    sc cx, cxx;
-    sc_mul(cx, c, x);
-    sc_mul(cxx, cx, x);
-    for (int q = 0; q < 8; q++) {
-        us[0 * 8 + q] = one.v[q];
-        us[1 * 8 + q] = x.v[q];
-        us[2 * 8 + q] = cx.v[q];
-        us[3 * 8 + q] = cxx.v[q];
-    }
+    sc28 cxm, cxxm;
+    sc28_montmul(cxm, cm, xm);
+    sc28_montmul(cxxm, cxm, xm);
+    store_words8(us + 0 * 8, one);
+    store_words8(us + 1 * 8, x);
+    sc_from_mont28(t0, cxm);
+    store_words8(us + 2 * 8, t0);
+    sc_from_mont28(t0, cxxm);
+    store_words8(us + 3 * 8, t0);
     // V_j coefficients c z^2 z^j, and the z^2 z^j table
     {
-        sc czz, zj = one, zm, zzm, zjm;
-        sc_mul(czz, c, zz);
-        sc_to_mont(zm, z);
-        sc_to_mont(zzm, zz);
-        zjm = zzm;                                        // zz * z^0 in Montgomery form
+        sc28 czzj, zzj = zzm;
+        sc28_montmul(czzj, cm, zzm);
         for (uint32_t j = 0; j < sh.m; j++) {
-            sc_mul(t0, czz, zj);
-            for (int q = 0; q < 8; q++) us[(4 + 2 * k + j) * 8 + q] = t0.v[q];
-            rp_store(fields, B, fl.zzzj_m + j, p, zjm);
-            sc_mul(zj, zj, z);
-            sc_montmul(zjm, zjm, zm);
+            sc_from_mont28(t0, czzj);
+            store_words8(us + (4 + 2 * k + j) * 8, t0);
+            rp_store28(fields, B, fl.zzzj_m + j, p, zzj);
+            sc28_montmul(czzj, czzj, zm);
+            sc28_montmul(zzj, zzj, zm);
         }
     }
     // B_blinding coefficient: -e_blinding - c t_x_blinding  (row 0)
-    sc_mul(t0, c, txb);
-    sc_add(t0, t0, eb);
-    sc_neg(t0, t0);
-    fb_recode(digits + ((uint64_t)0 * prm.nwin) * B + p, B, t0.v, prm);
-    // B coefficient: w (t_x - a b) + c (delta(y,z) - t_x)  (row 1)
-    sc ab, dl, sum_y, sum_2, sum_z;
-    sc_mul(ab, a, b);
-    sc_sub(t0, tx, ab);
-    sc_mul(t0, w, t0);
-    rp_sum_of_powers_pow2(sum_y, y, k);
-    rp_sum_of_powers_pow2(sum_z, z, lg_m);
-    {   // sum_{i<n} 2^i = 2^n - 1, n <= 64
-        sc_0(sum_2);
-        if (sh.n >= 64) { sum_2.v[0] = 0xffffffffu; sum_2.v[1] = 0xffffffffu; }
-        else if (sh.n >= 32) { sum_2.v[0] = 0xffffffffu; sum_2.v[1] = (sh.n == 32) ? 0u : ((1u << (sh.n - 32)) - 1u); }
-        else sum_2.v[0] = (1u << sh.n) - 1u;
+    {
+        sc28 pm;
+        sc28_montmul(pm, cm, txbm);
+        sc_from_mont28(t0, pm);
+        sc_add(t0, t0, eb);
+        sc_neg(t0, t0);
+        fb_recode(digits + ((uint64_t)0 * prm.nwin) * B + p, B, t0.v, prm);
     }
-    sc_sub(t1, z, zz);
-    sc_mul(t1, t1, sum_y);                                // (z - z^2) <1, y^nm>
-    sc_mul(dl, zz, z);
-    sc_mul(dl, dl, sum_2);
-    sc_mul(dl, dl, sum_z);                                // z^3 <1,2^n> sum_j z^j
-    sc_sub(dl, t1, dl);
-    sc_sub(t1, dl, tx);
-    sc_mul(t1, c, t1);
-    sc_add(t0, t0, t1);
-    fb_recode(digits + ((uint64_t)1 * prm.nwin) * B + p, B, t0.v, prm);
+    // B coefficient: w (t_x - a b) + c (delta(y,z) - t_x)  (row 1)
+    {
+        sc28 abm, pm, sum_ym, sum_zm, dm;
+        sc ab, dl, sum_2;
+        sc28_montmul(abm, am, bm);
+        sc_from_mont28(ab, abm);
+        sc_sub(t0, tx, ab);
+        sc_to_mont28(pm, t0);
+        sc28_montmul(pm, wm, pm);
+        sc_from_mont28(t0, pm);                               // w (t_x - a b)
+        rp_sum_of_powers_pow2(sum_ym, ym, k);
+        rp_sum_of_powers_pow2(sum_zm, zm, lg_m);
+        {   // sum_{i<n} 2^i = 2^n - 1, n <= 64
+            sc_0(sum_2);
+            if (sh.n >= 64) { sum_2.v[0] = 0xffffffffu; sum_2.v[1] = 0xffffffffu; }
+            else if (sh.n >= 32) { sum_2.v[0] = 0xffffffffu; sum_2.v[1] = (sh.n == 32) ? 0u : ((1u << (sh.n - 32)) - 1u); }
+            else sum_2.v[0] = (1u << sh.n) - 1u;
+        }
+        // delta = (z - z^2) <1, y^nm> - z^3 <1, 2^n> sum_j z^j        (mod.rs:587-593)
+        sc_sub(t1, z, zz);
+        sc_to_mont28(dm, t1);
+        sc28_montmul(dm, dm, sum_ym);
+        sc_from_mont28(dl, dm);
+        sc28 z3m, s2m;
+        sc28_montmul(z3m, zzm, zm);
+        sc_to_mont28(s2m, sum_2);
+        sc28_montmul(z3m, z3m, s2m);
+        sc28_montmul(z3m, z3m, sum_zm);
+        sc_from_mont28(t1, z3m);
+        sc_sub(dl, dl, t1);
+        sc_sub(t1, dl, tx);
+        sc_to_mont28(pm, t1);
+        sc28_montmul(pm, cm, pm);
+        sc_from_mont28(t1, pm);                               // c (delta - t_x)
+        sc_add(t0, t0, t1);
+        fb_recode(digits + ((uint64_t)1 * prm.nwin) * B + p, B, t0.v, prm);
+    }
 }
 
 // ---- stage 3: per-(generator, proof) scalars -------------------------------------------------
@@ -355,52 +407,56 @@ BP_HD void rp_expand_b_thread(uint32_t tid, rp_shape sh, fb_params prm, const ui
     const uint32_t i = tid / B, p = tid - i * B;
     if (status[p] != 0) return;
     const rp_fields fl = rp_field_layout(k, sh.m);
-    const sc one_m = BP_SC_R;
     // s_i = prod_b (bit_b(i) ? u : u^-1)[k-1-b]  (ipp.rs:241-250), and its inverse s_{nm-1-i}
-    sc s = one_m, sinv = one_m, yp = one_m, um, uim, t;
+    sc28 s, sinv, yp, um, uim, t;
+    sc28_one_mont(s);
+    sinv = s;
+    yp = s;
     for (uint32_t bb = 0; bb < k; bb++) {
-        rp_load(um, fields, B, fl.u_m + (k - 1 - bb), p);
-        rp_load(uim, fields, B, fl.uinv_m + (k - 1 - bb), p);
+        rp_load28(um, fields, B, fl.u_m + (k - 1 - bb), p);
+        rp_load28(uim, fields, B, fl.uinv_m + (k - 1 - bb), p);
         const bool bit = (i >> bb) & 1;
-        sc f1, f2;
+        sc28 f1, f2;
 #pragma unroll
-        for (int q = 0; q < 8; q++) {
+        for (int q = 0; q < 10; q++) {
             f1.v[q] = bit ? um.v[q] : uim.v[q];
             f2.v[q] = bit ? uim.v[q] : um.v[q];
         }
-        sc_montmul(s, s, f1);
-        sc_montmul(sinv, sinv, f2);
+        sc28_montmul(s, s, f1);
+        sc28_montmul(sinv, sinv, f2);
         if (bit) {
-            rp_load(t, fields, B, fl.yinvp_m + bb, p);
-            sc_montmul(yp, yp, t);                         // y^-i
+            rp_load28(t, fields, B, fl.yinvp_m + bb, p);
+            sc28_montmul(yp, yp, t);                       // y^-i
         }
     }
-    sc a_m, b_m, z, minus_z, g, h, r;
-    rp_load(a_m, fields, B, RPF_A_M, p);
-    rp_load(b_m, fields, B, RPF_B_M, p);
+    sc28 a_m, b_m, r;
+    sc z, minus_z, g, h, v;
+    rp_load28(a_m, fields, B, RPF_A_M, p);
+    rp_load28(b_m, fields, B, RPF_B_M, p);
     rp_load(z, fields, B, RPF_Z, p);
     rp_load(minus_z, fields, B, RPF_MINUS_Z, p);
     // g_i = -z - a s_i   (mod.rs:415)
-    sc_montmul(t, a_m, s);           // a*s*R
-    sc_from_mont(t, t);
-    sc_sub(g, minus_z, t);
+    sc28_montmul(t, a_m, s);
+    sc_from_mont28(v, t);
+    sc_sub(g, minus_z, v);
     fb_recode(digits + ((uint64_t)(2 + i) * prm.nwin) * B + p, B, g.v, prm);
     // h_i = z + y^-i (z^2 z^j 2^i' - b s_i^-1), j = i / n, i' = i % n   (mod.rs:416-419)
     const uint32_t j = i / sh.n, ib = i - j * sh.n;
-    sc zzzj, two_i, two_m;
-    rp_load(zzzj, fields, B, fl.zzzj_m + j, p);
+    sc28 zzzj, two_m;
+    sc two_i, lhs, rhs;
+    rp_load28(zzzj, fields, B, fl.zzzj_m + j, p);
     sc_0(two_i);
     two_i.v[ib >> 5] = 1u << (ib & 31);
-    sc_to_mont(two_m, two_i);
-    sc_montmul(r, zzzj, two_m);      // z^2 z^j 2^i' (Montgomery)
-    sc_montmul(t, b_m, sinv);        // b / s_i     (Montgomery)
-    sc_from_mont(r, r);
-    sc_from_mont(t, t);
-    sc_sub(r, r, t);
-    sc_to_mont(r, r);
-    sc_montmul(r, r, yp);
-    sc_from_mont(r, r);
-    sc_add(h, z, r);
+    sc_to_mont28(two_m, two_i);
+    sc28_montmul(r, zzzj, two_m);    // z^2 z^j 2^i' (Montgomery)
+    sc28_montmul(t, b_m, sinv);      // b / s_i     (Montgomery)
+    sc_from_mont28(lhs, r);
+    sc_from_mont28(rhs, t);
+    sc_sub(lhs, lhs, rhs);
+    sc_to_mont28(r, lhs);
+    sc28_montmul(r, r, yp);
+    sc_from_mont28(v, r);
+    sc_add(h, z, v);
     fb_recode(digits + ((uint64_t)(2 + sh.nm + i) * prm.nwin) * B + p, B, h.v, prm);
 }
 

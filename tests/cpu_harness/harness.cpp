@@ -185,7 +185,7 @@ void h_sc_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
     case 3: sc_neg(r, x); break;
     case 4: sc_invert(r, x); break;
     case 5: { uint32_t w[16]; memcpy(w, a, 32); memcpy(w + 8, b, 32); sc_from_wide(r, w); } break;
-    case 6: sc_montmul(r, x, y); break;
+    case 6: { sc28 a28, b28, t28; sc28_from_sc(a28, x); sc28_from_sc(b28, y); sc28_montmul(t28, a28, b28); sc28_to_mont(t28, t28); sc28_to_mont(t28, t28); sc_from_mont28(r, t28); } break;  // lazy chain: ((xy/R)*R*R)/R = xy
     default: sc_0(r);
     }
     memcpy(out, r.v, 32);
@@ -215,7 +215,7 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
 
     rp_strobe_init init; make_strobe_init(init, label, label_len, n, m);
     const rp_fields fl = rp_field_layout(k, m);
-    std::vector<uint32_t> fields((size_t)fl.count * nbatch * 8 + 8), uniq_points((size_t)nbatch * sh.U * 8 + 8, 0), uniq_scalars((size_t)nbatch * sh.U * 8 + 8, 0), status(nbatch + 1, 0);
+    std::vector<uint32_t> fields((size_t)fl.count * nbatch * BP_RP_REC + 8), uniq_points((size_t)nbatch * sh.U * 8 + 8, 0), uniq_scalars((size_t)nbatch * sh.U * 8 + 8, 0), status(nbatch + 1, 0);
     std::vector<uint16_t> digits((size_t)npairs * nbatch + 1, 0xffff);   // poison: unwritten rows must be masked
     for (uint32_t p = 0; p < nbatch; p++) {
         uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;

@@ -13,6 +13,7 @@ ap.add_argument("--n", type=int, default=64); ap.add_argument("--m", type=int, d
 ap.add_argument("--batch", type=int, default=1024); ap.add_argument("--W", type=int, default=8)
 ap.add_argument("--splits", type=int, default=0); ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--check", type=int, default=2)
+ap.add_argument("--same-scalars", action="store_true", help="every proof uses the same generator scalars: all lanes gather the same table line")
 a = ap.parse_args()
 n, m, nb = a.n, a.m, a.batch
 k = (n * m).bit_length() - 1
@@ -33,6 +34,8 @@ for i in range(64):
     O.lib().oracle_from_uniform_bytes(hashlib.shake_256(b"u%d" % i).digest(64), out); upool.append(out.raw)
 UP = b"".join(upool[(b * 7 + u) % 64] for b in range(nb) for u in range(nu))
 GS, US = scalars(nb * ngen), scalars(nb * nu)
+if a.same_scalars:
+    GS = GS[:32 * ngen] * nb
 c.profile_enable(True)
 res, st = c.msm_batch_shared(n, m, nb, nu, GS, US, UP)   # warm-up (arena growth)
 c.profile_reset()
