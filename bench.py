@@ -31,8 +31,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4"],
                     help="BASELINE.json config; cfg2 (batch of 1024 single 64-bit proofs per GPU) is the metric's config")
     ap.add_argument("--batch", type=int, default=0, help="override proofs per GPU per step")
@@ -48,30 +48,44 @@ def parse_args():
     return ap.parse_args()
 
 
+def usable_cpus():
+    """Logical CPUs this process may actually use: affinity mask, capped by the cgroup CPU quota (cpu.max)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = max(1, min(n, int(int(quota) / int(period))))
+    except Exception:
+        pass
+    return n
+
+
 def cpu_baseline(fx, batch, threads=0):
     """The oracle (C restatement of the reference's algorithm: u64 5x51 field, Straus/Pippenger split) timed on
-    this box's host cores on a bounded sample of the same workload.  This is the ONLY place bench.py touches oracle/."""
+    this box's host cores on a bounded sample of the same workload, one proof per thread, as many threads as the
+    process may use (affinity and cgroup quota).  This is the ONLY place bench.py touches oracle/."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     import pyoracle as O
     from bulletproofs_amd.workload import tile_batch
-    cores = threads or os.cpu_count() or 1
+    th = threads or usable_cpus()
     g = O.Gens(fx.n, fx.m)
-    # single-thread calibration (~0.3 s), then ~10-30 s of CPU work in total across all cores
     cal = max(4, min(64, fx.count))
     proofs, coms = tile_batch(fx, cal)
     rng = hashlib.shake_256(b"cpu-baseline").digest(64 * cal)
-    t1, v, _ = O.verify_batch(g, proofs, coms, fx.m, fx.n, fx.label, rng, threads=1)
+    t1, v, _ = O.verify_batch(g, proofs, coms, fx.m, fx.n, fx.label, rng, threads=1)   # single-thread calibration
     assert v == bytes(cal)
     per_proof = t1 / cal
-    sample = int(max(cores * 4, min(20.0 / per_proof, 65536)))
+    sample = int(max(th * 8, min(20.0 / per_proof, 65536)))   # ~20 s of CPU work
     proofs, coms = tile_batch(fx, sample)
-    rng = hashlib.shake_256(b"cpu-baseline2").digest(64 * sample)
-    tN, v, _ = O.verify_batch(g, proofs, coms, fx.m, fx.n, fx.label, rng, threads=cores)
+    rng = hashlib.shake_256(b"cpu-baseline-%d" % th).digest(64 * sample)
+    O.verify_batch(g, proofs[:fx.proof_len * th], coms[:32 * fx.m * th], fx.m, fx.n, fx.label, rng[:64 * th], threads=th)  # warm-up
+    tN, v, _ = O.verify_batch(g, proofs, coms, fx.m, fx.n, fx.label, rng, threads=th)
     assert v == bytes(sample)
-    return {"value": round(sample / tN, 1), "unit": "verifications/s", "cores": cores, "kind": "port",
-            "sample": "%d proofs (n=%d, m=%d) = %.1f s of CPU work on %d threads; single thread: %.1f verifications/s "
-                      "(C restatement of the reference algorithm, u64 5x51 field, Straus<190<=Pippenger; not the Rust crate)"
-                      % (sample, fx.n, fx.m, per_proof * sample, cores, 1.0 / per_proof)}
+    return {"value": round(sample / tN, 1), "unit": "verifications/s", "cores": th, "kind": "port",
+            "sample": "%d proofs (n=%d, m=%d) = %.1f s of CPU work on %d threads (%d logical CPUs visible, %d usable under the "
+                      "cgroup quota); single thread: %.1f verifications/s (C restatement of the reference algorithm, u64 5x51 "
+                      "field, Straus<190<=Pippenger; not the Rust crate)"
+                      % (sample, fx.n, fx.m, per_proof * sample, th, os.cpu_count() or 1, usable_cpus(), 1.0 / per_proof)}
 
 
 def main():

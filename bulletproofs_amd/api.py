@@ -1,0 +1,115 @@
+"""Host-side mirror (Python) of the reference crate's verification API over the C ABI -- same names,
+argument meaning and error behaviour as src/lib.rs:34-45 exports for this path (RangeProof,
+BulletproofGens, PedersenGens, ProofError, Transcript).  The C++ twin is include/bulletproofs.hpp.
+No arithmetic happens here: parsing checks lengths / scalar canonicity, everything else is one call
+into libbpgpu.so.  There is no CPU fallback."""
+from ._lib import Context
+
+_L = 2**252 + 27742317777372353535851937790883648493
+
+
+class ProofError(Exception):
+    """src/errors.rs:12-54"""
+    code = None
+
+    def __eq__(self, other):
+        return isinstance(other, ProofError) and type(self) is type(other)
+
+    def __hash__(self):
+        return hash(type(self))
+
+
+class VerificationError(ProofError):
+    code = 1
+
+
+class FormatError(ProofError):
+    code = 2
+
+
+class InvalidBitsize(ProofError):
+    code = 3
+
+
+class InvalidGeneratorsLength(ProofError):
+    code = 4
+
+
+_BY_CODE = {c.code: c for c in (VerificationError, FormatError, InvalidBitsize, InvalidGeneratorsLength)}
+
+
+class PedersenGens:
+    """src/generators.rs:30-53; PedersenGens::default() as held by a BulletproofGens on the device."""
+
+    def __init__(self, B, B_blinding):
+        self.B, self.B_blinding = B, B_blinding
+
+
+class BulletproofGens:
+    """BulletproofGens::new(gens_capacity, party_capacity) (src/generators.rs:157-166), derived on the GPU."""
+
+    def __init__(self, gens_capacity, party_capacity, device=0, **ctx_options):
+        self.gens_capacity, self.party_capacity = gens_capacity, party_capacity
+        self.ctx = Context(device, **ctx_options)
+        self.ctx.gens_create(gens_capacity, party_capacity)
+
+    def pedersen(self):
+        _, _, B, Bb = self.ctx.gens_export()
+        return PedersenGens(B, Bb)
+
+
+class Transcript:
+    """merlin::Transcript::new(label): the engine replays the transcript from its label."""
+
+    def __init__(self, label):
+        self.label = bytes(label)
+
+
+class RangeProof:
+    def __init__(self, raw):
+        self._raw = raw
+
+    @staticmethod
+    def from_bytes(b):
+        """src/range_proof/mod.rs:504-538 + src/inner_product_proof.rs:373-407; raises FormatError."""
+        b = bytes(b)
+        if len(b) % 32 != 0 or len(b) < 7 * 32:
+            raise FormatError()
+        ne = (len(b) - 7 * 32) // 32
+        if ne < 2 or (ne - 2) % 2 != 0 or (ne - 2) // 2 >= 32:
+            raise FormatError()
+        for off in (128, 160, 192, len(b) - 64, len(b) - 32):
+            if int.from_bytes(b[off:off + 32], "little") >= _L:
+                raise FormatError()
+        return RangeProof(b)
+
+    def to_bytes(self):
+        return self._raw
+
+    def verify_multiple_with_rng(self, bp_gens, pc_gens, transcript, value_commitments, n, rng64):
+        """Ok(()) -> returns None; Err(e) -> raises e.  rng64 = the 64 bytes Scalar::random(rng) would draw (mod.rs:396);
+        None = thread_rng()."""
+        m = len(value_commitments)
+        v = bp_gens.ctx.rangeproof_verify_batch(n, m, self._raw, len(self._raw), b"".join(value_commitments), transcript.label, rng64)
+        if v[0] != 0:
+            raise _BY_CODE[v[0]]()
+
+    def verify_multiple(self, bp_gens, pc_gens, transcript, value_commitments, n):
+        return self.verify_multiple_with_rng(bp_gens, pc_gens, transcript, value_commitments, n, None)
+
+    def verify_single_with_rng(self, bp_gens, pc_gens, transcript, V, n, rng64):
+        return self.verify_multiple_with_rng(bp_gens, pc_gens, transcript, [V], n, rng64)
+
+    def verify_single(self, bp_gens, pc_gens, transcript, V, n):
+        return self.verify_multiple_with_rng(bp_gens, pc_gens, transcript, [V], n, None)
+
+    @staticmethod
+    def verify_batch(bp_gens, pc_gens, transcript, proofs, commitments, n, rng64=None):
+        """proofs[i].verify_multiple(..., &commitments[i], n) for all i in one GPU pass -> list of None / ProofError."""
+        if not proofs:
+            return []
+        raw = [p.to_bytes() if isinstance(p, RangeProof) else bytes(p) for p in proofs]
+        m, ln = len(commitments[0]), len(raw[0])
+        assert all(len(r) == ln for r in raw) and all(len(c) == m for c in commitments)
+        v = bp_gens.ctx.rangeproof_verify_batch(n, m, b"".join(raw), ln, b"".join(b"".join(c) for c in commitments), transcript.label, rng64)
+        return [None if x == 0 else _BY_CODE[x]() for x in v]

@@ -143,14 +143,24 @@ BP_HD void strobe_absorb1(strobe &t, uint32_t b) {
 BP_HD void strobe_absorb(strobe &t, const uint8_t *d, uint32_t n) {
     for (uint32_t i = 0; i < n; i++) strobe_absorb1(t, d[i]);
 }
-// absorb n32 little-endian words (messages that already sit in registers)
+// absorb n32 little-endian words (messages that already sit in registers).  A word that does not
+// straddle the rate boundary is XORed into (at most two) state words at once instead of four
+// byte-wide read-modify-writes; positions are uniform across the wavefront.
 BP_HD void strobe_absorb_words(strobe &t, const uint32_t *w, uint32_t n32) {
     for (uint32_t i = 0; i < n32; i++) {
         const uint32_t x = w[i];
-        strobe_absorb1(t, x & 0xff);
-        strobe_absorb1(t, (x >> 8) & 0xff);
-        strobe_absorb1(t, (x >> 16) & 0xff);
-        strobe_absorb1(t, x >> 24);
+        if (t.pos + 4 <= BP_STROBE_R) {
+            const uint32_t wi = t.pos >> 2, sh = (t.pos & 3) * 8;
+            t.st.w[wi * t.st.stride] ^= x << sh;
+            if (sh) t.st.w[(wi + 1) * t.st.stride] ^= x >> (32 - sh);
+            t.pos += 4;
+            if (t.pos == BP_STROBE_R) strobe_run_f(t);
+        } else {
+            strobe_absorb1(t, x & 0xff);
+            strobe_absorb1(t, (x >> 8) & 0xff);
+            strobe_absorb1(t, (x >> 16) & 0xff);
+            strobe_absorb1(t, x >> 24);
+        }
     }
 }
 BP_HD uint32_t strobe_squeeze1(strobe &t) {
@@ -158,6 +168,31 @@ BP_HD uint32_t strobe_squeeze1(strobe &t) {
     ks_clear8(t.st, t.pos++);
     if (t.pos == BP_STROBE_R) strobe_run_f(t);
     return b;
+}
+// squeeze one little-endian word (read, then zero the squeezed bytes, as STROBE's PRF does)
+BP_HD uint32_t strobe_squeeze_word(strobe &t) {
+    if (t.pos + 4 <= BP_STROBE_R) {
+        const uint32_t wi = t.pos >> 2, sh = (t.pos & 3) * 8;
+        uint32_t *w0 = &t.st.w[wi * t.st.stride];
+        uint32_t x;
+        if (sh) {
+            uint32_t *w1 = &t.st.w[(wi + 1) * t.st.stride];
+            x = (*w0 >> sh) | (*w1 << (32 - sh));
+            *w0 &= (1u << sh) - 1u;
+            *w1 &= 0xffffffffu << sh;
+        } else {
+            x = *w0;
+            *w0 = 0;
+        }
+        t.pos += 4;
+        if (t.pos == BP_STROBE_R) strobe_run_f(t);
+        return x;
+    }
+    uint32_t x = strobe_squeeze1(t);
+    x |= strobe_squeeze1(t) << 8;
+    x |= strobe_squeeze1(t) << 16;
+    x |= strobe_squeeze1(t) << 24;
+    return x;
 }
 BP_HD void strobe_begin_op(strobe &t, uint32_t flags, bool more) {
     if (more) return;   // continuation of the current operation (flags must equal cur_flags)
@@ -220,13 +255,7 @@ BP_HD void merlin_challenge_words16(strobe &t, const uint8_t *label, uint32_t la
     strobe_meta_ad(t, label, label_len, false);
     strobe_meta_len(t, 64);
     strobe_begin_op(t, BP_FLAG_I | BP_FLAG_A | BP_FLAG_C, false);
-    for (uint32_t i = 0; i < 16; i++) {
-        uint32_t x = strobe_squeeze1(t);
-        x |= strobe_squeeze1(t) << 8;
-        x |= strobe_squeeze1(t) << 16;
-        x |= strobe_squeeze1(t) << 24;
-        out[i] = x;
-    }
+    for (uint32_t i = 0; i < 16; i++) out[i] = strobe_squeeze_word(t);
 }
 BP_HD void merlin_challenge_bytes(strobe &t, const uint8_t *label, uint32_t label_len, uint8_t *out, uint32_t n) {
     strobe_meta_ad(t, label, label_len, false);

@@ -122,3 +122,35 @@ def test_msm_batch_shared_matches_general_path_and_oracle(oracle, W):
     pts = Bb + B + G[:32 * 8] + H[:32 * 8]
     assert st[0] == 0 and out == oracle.msm(gs, pts)[1]
     c.close()
+
+
+def test_r1cs_shape_msm_config5(oracle):
+    """BASELINE config 5 shape (r1cs/verifier.rs:459-491, k=1024 shuffle): one MSM of 6179 terms =
+    4098 generator terms (BulletproofGens::new(2048, 1) + Pedersen) + 2081 per-proof points; the reference
+    has no golden vector for it (feature disabled), so parity is GPU == oracle on seeded inputs.
+    Evaluated through both entry points."""
+    import bulletproofs_amd as bp
+    c = bp.Context(0)
+    c.gens_create(2048, 1)
+    g = oracle.Gens(2048, 1)
+    G, H, B, Bb = g.export()
+    assert c.gens_export() == (G, H, B, Bb)
+    n, m, nu, nb = 2048, 1, 2081, 2
+    ngen = 2 * n * m + 2
+    gen_pts = Bb + B + G + H
+    GS = b"".join(_scalar(b"r1cs-g%d" % i) for i in range(ngen * nb))
+    UP = _points(oracle, b"r1cs-u", nu) * nb
+    US = b"".join(_scalar(b"r1cs-u%d" % i) for i in range(nu * nb))
+    out, st = c.msm_batch_shared(n, m, nb, nu, GS, US, UP)
+    flat_s, flat_p = b"", b""
+    for b in range(nb):
+        scs = GS[32 * ngen * b:32 * ngen * (b + 1)] + US[32 * nu * b:32 * nu * (b + 1)]
+        pts = gen_pts + UP[32 * nu * b:32 * nu * (b + 1)]
+        assert len(scs) // 32 == 6179
+        exp = oracle.msm(scs, pts)
+        assert st[b] == 0 and out[32 * b:32 * b + 32] == exp[1], b
+        flat_s += scs
+        flat_p += pts
+    out2, st2 = c.msm_batch([6179, 6179], flat_s, flat_p)
+    assert st2 == bytes(2) and out2 == out
+    c.close()

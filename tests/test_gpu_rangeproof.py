@@ -160,3 +160,22 @@ def test_aggregated_m16_matches_oracle(oracle):
     secs, ev, em = oracle.verify_batch(g, bytes(pb), coms, m, n, b"agg", rng, threads=3)
     assert list(verdict) == [0, 1, 0] and verdict == ev and msm == em
     c.close()
+
+
+def test_aggregated_m32_config4_shape(oracle):
+    """BASELINE config 4 shape (n = 64, m = 32; N = 4156 terms, proof 992 B), fixture proofs + one corruption."""
+    import bulletproofs_amd as bp
+    from bulletproofs_amd.workload import load_fixture
+    fx = load_fixture("cfg4_n64_m32")
+    c = bp.Context(0)
+    c.gens_create(64, 32)
+    g = oracle.Gens(64, 32)
+    nb = 4
+    proofs = bytearray(fx.proofs[:nb * fx.proof_len])
+    proofs[2 * fx.proof_len + 500] ^= 0x10
+    coms = fx.commitments[:nb * 32 * 32]
+    rng = hashlib.shake_256(b"rng32").digest(64 * nb)
+    verdict, msm = c.rangeproof_verify_batch(64, 32, bytes(proofs), fx.proof_len, coms, fx.label, rng, want_msm=True)
+    secs, ev, em = oracle.verify_batch(g, bytes(proofs), coms, 32, 64, fx.label, rng, threads=4)
+    assert fx.proof_len == 992 and list(verdict) == [0, 0, 1, 0] and verdict == ev and msm == em
+    c.close()
