@@ -14,6 +14,7 @@
 #include "../../include/bpgpu.h"
 #include "msm_fixed.h"
 #include "msm_vb.h"
+#include "horner_wave.h"
 #include "rangeproof.h"
 
 using namespace bp;
@@ -37,14 +38,20 @@ __global__ void __launch_bounds__(BP_BLOCK) k_vb_window(uint32_t nthreads, const
 }
 
 __global__ void __launch_bounds__(BP_BLOCK) k_vb_colsum(uint32_t nthreads, const uint32_t *chunk_first, const ge_ext *part,
-                                                         ge_ext *col) {
+                                                         uint32_t *colq16) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < nthreads) vb_colsum_thread(tid, chunk_first, part, col);
+    if (tid < nthreads) vb_colsum_thread(tid, chunk_first, part, nullptr, colq16);
 }
 
-__global__ void __launch_bounds__(64) k_vb_horner(uint32_t nbatch, const ge_ext *col, const uint32_t *status, uint32_t *out) {
+// wavefront-cooperative Horner chain (horner_wave.h): one 64-lane workgroup = one wavefront = one MSM
+__global__ void __launch_bounds__(64) k_horner_wave(const uint32_t *colq16, ge_ext *hq) {
+    const uint32_t b = blockIdx.x;
+    hw_horner_msm((const uint16_t *)(colq16 + (uint64_t)b * 64 * 32), hq + b);
+}
+
+__global__ void __launch_bounds__(64) k_vb_horner(uint32_t nbatch, const ge_ext *hq, const uint32_t *status, uint32_t *out) {
     const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nbatch) vb_horner_thread(b, col, status, out, nullptr);
+    if (b < nbatch) vb_horner_thread(b, nullptr, hq, status, out, nullptr);
 }
 
 __global__ void __launch_bounds__(64) k_status_bytes(uint32_t n, const uint32_t *status, uint8_t *out) {
@@ -102,11 +109,11 @@ __global__ void __launch_bounds__(BP_BLOCK) k_fb_reduce(uint32_t nthreads, uint3
     if (tid < nthreads) fb_reduce_thread(tid, nproofs, nsplit, group, partial, out);
 }
 
-__global__ void __launch_bounds__(64) k_shared_finish(uint32_t nproofs, uint32_t nsplit, const ge_ext *col, int have_unique,
+__global__ void __launch_bounds__(64) k_shared_finish(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, int have_unique,
                                                        const ge_ext *partial, const uint32_t *status, uint32_t *out_words,
                                                        uint8_t *verdict) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < nproofs) shared_finish_thread(p, nproofs, nsplit, col, have_unique != 0, partial, status, out_words, verdict);
+    if (p < nproofs) shared_finish_thread(p, nproofs, nsplit, nullptr, have_unique != 0, hq, partial, status, out_words, verdict);
 }
 
 
@@ -581,7 +588,9 @@ struct vb_dev {
     vb_chunk *chunks;
     uint32_t *chunk_first, *term_chunk, *recoded;
     ge_cached *tab;
-    ge_ext *part, *col;
+    ge_ext *part;
+    uint32_t *colq16;   // [msm][64][4][8 words]: column sums as 16-bit limbs for the wavefront Horner
+    ge_ext *hq;         // [msm] Horner results
 };
 static void plan_vb(arena_plan &ap, const vb_plan &pl, size_t nbatch, size_t off[7]) {
     off[0] = ap.add(pl.chunks.size() * sizeof(vb_chunk) + 16);
@@ -590,7 +599,7 @@ static void plan_vb(arena_plan &ap, const vb_plan &pl, size_t nbatch, size_t off
     off[3] = ap.add((size_t)pl.total * 32 + 16);
     off[4] = ap.add((size_t)pl.total * 8 * sizeof(ge_cached) + 16);
     off[5] = ap.add(pl.chunks.size() * 64 * sizeof(ge_ext) + 16);
-    off[6] = ap.add(nbatch * 64 * sizeof(ge_ext) + 16);
+    off[6] = ap.add(nbatch * 64 * 128 + nbatch * sizeof(ge_ext) + 64);
 }
 static void vb_bind(bpgpu_ctx *c, const size_t off[7], vb_dev &d) {
     char *a = c->arena;
@@ -600,7 +609,8 @@ static void vb_bind(bpgpu_ctx *c, const size_t off[7], vb_dev &d) {
     d.recoded = (uint32_t *)(a + off[3]);
     d.tab = (ge_cached *)(a + off[4]);
     d.part = (ge_ext *)(a + off[5]);
-    d.col = (ge_ext *)(a + off[6]);
+    d.colq16 = (uint32_t *)(a + off[6]);
+    d.hq = nullptr;   // set by vb_launch (behind colq16)
 }
 static int vb_launch(bpgpu_ctx *c, hipStream_t s, uint32_t total, uint32_t n_chunks, size_t nbatch, const uint32_t *d_scalars,
                      const uint32_t *d_points, uint32_t *d_status, vb_dev &d) {
@@ -611,7 +621,9 @@ static int vb_launch(bpgpu_ctx *c, hipStream_t s, uint32_t total, uint32_t n_chu
         LAUNCH(c, s, "vb_window", k_vb_window, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, d.chunks, d.tab, d.recoded, d.part);
     }
     const uint32_t nc = (uint32_t)nbatch * 64;
-    LAUNCH(c, s, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, d.col);
+    d.hq = (ge_ext *)(d.colq16 + (size_t)nbatch * 64 * 32);
+    LAUNCH(c, s, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, d.colq16);
+    LAUNCH(c, s, "horner_wave", k_horner_wave, (uint32_t)nbatch, 64, d.colq16, d.hq);
     return BPGPU_OK;
 }
 // ragged plans: upload the decomposition into the arena every call
@@ -655,7 +667,7 @@ static void plan_vb_uniform(arena_plan &ap, size_t nbatch, size_t per, size_t of
     off[3] = ap.add(total * 32 + 16);
     off[4] = ap.add(total * 8 * sizeof(ge_cached) + 16);
     off[5] = ap.add(n_chunks * 64 * sizeof(ge_ext) + 16);
-    off[6] = ap.add(nbatch * 64 * sizeof(ge_ext) + 16);
+    off[6] = ap.add(nbatch * 64 * 128 + nbatch * sizeof(ge_ext) + 64);
 }
 static int enqueue_vb_uniform(bpgpu_ctx *c, hipStream_t s, size_t nbatch, size_t per, const size_t off[7], const uint32_t *d_scalars,
                               const uint32_t *d_points, uint32_t *d_status, vb_dev &d) {
@@ -686,7 +698,7 @@ static int msm_batch_dev_locked(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_t
     vb_dev d;
     rc = enqueue_vb(c, s, pl, nbatch, off, (const uint32_t *)d_scalars, (const uint32_t *)d_points, d_status, d);
     if (rc) return rc;
-    LAUNCH(c, s, "vb_horner", k_vb_horner, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d.col, d_status, (uint32_t *)d_out);
+    LAUNCH(c, s, "vb_horner", k_vb_horner, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d.hq, d_status, (uint32_t *)d_out);
     LAUNCH(c, s, "status_bytes", k_status_bytes, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d_status, (uint8_t *)d_status_bytes);
     HIPCHK(c, hipGetLastError());
     return BPGPU_OK;
@@ -811,7 +823,7 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
     ge_ext *d_red = nullptr;
     uint32_t nred = 0;
     enqueue_fb_reduce(c, s, (uint32_t)nbatch, nsplit, d_partial, &d_red, &nred);
-    LAUNCH(c, s, "shared_finish", k_shared_finish, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, nred, d.col, n_unique ? 1 : 0,
+    LAUNCH(c, s, "shared_finish", k_shared_finish, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, nred, d.hq, n_unique ? 1 : 0,
            d_red, d_status, (uint32_t *)d_out, (uint8_t *)d_verdict);
     if (d_status_bytes)
         LAUNCH(c, s, "status_bytes", k_status_bytes, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d_status, (uint8_t *)d_status_bytes);
@@ -1061,7 +1073,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     ge_ext *d_red = nullptr;
     uint32_t nred = 0;
     enqueue_fb_reduce(c, s, nb32, nsplit, d_partial, &d_red, &nred);
-    LAUNCH(c, s, "shared_finish", k_shared_finish, (nb32 + 63) / 64, 64, nb32, nred, d.col, 1, d_red, d_status,
+    LAUNCH(c, s, "shared_finish", k_shared_finish, (nb32 + 63) / 64, 64, nb32, nred, d.hq, 1, d_red, d_status,
            (uint32_t *)d_msm_out, (uint8_t *)d_verdict);
     HIPCHK(c, hipGetLastError());
     return BPGPU_OK;

@@ -1,0 +1,196 @@
+// Wavefront-cooperative Horner chain: ONE WAVEFRONT PER MSM, one 16-bit limb per lane.
+//
+// The last stage of every MSM,  R = sum_w 16^w C_w  over the 64 column sums of the variable-base
+// part, is 252 doublings + 64 additions that are sequential per MSM.  With one lane per MSM a batch
+// of 1024 proofs keeps 16 wavefronts busy for ~0.7 ms while 98 % of the chip idles, and because at
+// most ~4 kernels run concurrently on the device this chain bounds the batch-1024 throughput.
+//
+// Layout: the 64 lanes of a wavefront are 4 rows of 16 lanes; row r holds coordinate r of the running
+// point (X, Y, Z, T), lane k of a row holds limb k of that coordinate in radix 2^16
+// (2^256 = 38 mod p).  A field multiplication is 16 steps of {broadcast limb s of f inside the row
+// (through LDS: one store, four ds_read_b128), rotate g by s inside the row (DPP row_ror), multiply-accumulate into a 64-bit column
+// sum}; the carry normalisation is two rounds of {split, rotate by one lane, add} -- O(1) depth instead
+// of a 16-step carry chain.  The four field multiplications of a point operation run in the four rows
+// at once; coordinates move between rows with one LDS store + one ds_read_b128 (a field element is ONE VGPR
+// per lane).  A doubling costs 2 multiplication slots (~100 instructions each) instead of 8 x ~200.
+//
+// Written against wavevec.h, so the identical code runs lane-exact on the host (tests/cpu_harness).
+#ifndef BPGPU_HORNER_WAVE_H
+#define BPGPU_HORNER_WAVE_H
+#include "msm_vb.h"
+#include "wavevec.h"
+
+namespace bp {
+
+// ---- radix-2^16 field arithmetic, one limb per lane ---------------------------------------------
+// "small" = every limb <= 2^16 + 2^15 (output of hw_mul / hw_norm); hw_mul accepts limbs <= 2^21.
+
+// one carry round: limb k keeps its low 16 bits and receives the overflow of limb k-1
+// (limb 15's overflow re-enters limb 0 times 38).  In: limbs < 2^26.  Out: limbs <= 2^16 + 38 * 2^10.
+WV_FN wu32 hw_norm(const wu32 &l, const wu32 &k) {
+    const wu32 c = wv_row_ror<1>(l >> 16);
+    return (l & 0xffffu) + wv_select(k < 1u, c * 38u, c);
+}
+
+template <int S>
+struct hw_mul_steps {
+    static WV_FN void run(wu64 acc[4], const wu32 fl[16], const wu32 &g, const wu32 &g38, const wu32 &k) {
+        // limb (k-S) mod 16 of g, x38 when it wrapped: two zero-filling row shifts OR-ed together (no select)
+        const wu32 v = wv_row_shr0<S>(g) | wv_row_shl0<16 - S>(g38);
+        acc[S & 3] = wv_mad64(acc[S & 3], fl[S], v);                                          // four independent accumulation chains
+        hw_mul_steps<S + 1>::run(acc, fl, g, g38, k);
+    }
+};
+template <>
+struct hw_mul_steps<16> {
+    static WV_FN void run(wu64 *, const wu32 *, const wu32 &, const wu32 &, const wu32 &) {}
+};
+
+// column k = sum_{i+j=k} f_i g_j + 38 sum_{i+j=k+16} f_i g_j ; inputs <= 2^21 -> column < 2^52
+// The 16 limbs of f reach every lane of the row through LDS (wv_row_gather16); g is rotated with DPP.
+WV_FN wu32 hw_mul(const wv_ctx &cx, const wu32 &f, const wu32 &g, const wu32 &k) {
+    wu32 fl[16];
+    wv_row_gather16(cx, f, fl);
+    wu64 acc[4];
+    for (int i = 0; i < 4; i++) acc[i] = wv_widen(wv_splat(0));
+    hw_mul_steps<0>::run(acc, fl, g, g * 38u, k);
+    const wu64 sum = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    const wu32 lo = wv_lo32(sum), hi = wv_hi32(sum);          // hi < 2^20
+    const wu32 b1 = wv_row_ror<1>(lo >> 16), b2 = wv_row_ror<2>(hi);
+    const wu32 l = (lo & 0xffffu) + wv_select(k < 1u, b1 * 38u, b1) + wv_select(k < 2u, b2 * 38u, b2);   // < 2^26
+    return hw_norm(l, k);
+}
+
+// a - b + 8p, then one carry round.  b limbs must be <= 2^18 - 8; a limbs <= 2^21.
+WV_FN wu32 hw_sub(const wu32 &a, const wu32 &b, const wu32 &k) {
+    // 8p, limb-wise: 8 * (0xffed, 0xffff x 14, 0x7fff)
+    const wu32 bias = wv_select(k == 0u, wv_splat(0x7ff68u), wv_select(k == 15u, wv_splat(0x3fff8u), wv_splat(0x7fff8u)));
+    return hw_norm(a + bias - b, k);
+}
+
+// second half shared by doubling and addition: every row holds e, f, g, h; row r forms
+// X3 = e*f (r=0), Y3 = h*g (r=1), Z3 = g*f (r=2), T3 = e*h (r=3)
+WV_FN wu32 hw_point_finish(const wv_ctx &cx, const wu32 &e, const wu32 &f, const wu32 &g, const wu32 &h, const wu32 &row, const wu32 &k) {
+    const wu32 a = wv_select(row == 0u || row == 3u, e, wv_select(row == 1u, h, g));
+    const wu32 b = wv_select(row == 0u || row == 2u, f, wv_select(row == 1u, g, h));
+    return hw_mul(cx, a, b, k);
+}
+
+// c (small) <- 2 * point
+WV_FN wu32 hw_dbl(const wv_ctx &cx, const wu32 &c, const wu32 &row, const wu32 &k) {
+    wu32 r4[4];
+    wv_rows4(cx, c, r4);                                      // X, Y, Z, T limbs k in every row
+    const wu32 in = wv_select(row == 3u, r4[0] + r4[1], c);   // rows: X, Y, Z, X+Y
+    const wu32 sq = hw_mul(cx, in, in, k);                    // XX, YY, ZZ, (X+Y)^2
+    wv_rows4(cx, sq, r4);
+    const wu32 xx = r4[0], yy = r4[1], zz = r4[2], s = r4[3];
+    const wu32 h = yy + xx;                                   // <= 2^17.6
+    const wu32 g = hw_sub(yy, xx, k);
+    const wu32 e = hw_sub(s, h, k);
+    const wu32 f = hw_sub(zz + zz, g, k);
+    return hw_point_finish(cx, e, f, g, h, row, k);
+}
+
+// c (small) <- point + Q, q = this lane's limb of Q in cached row order (Y-X | Y+X | Z | 2dT), canonical limbs
+WV_FN wu32 hw_add_cached(const wv_ctx &cx, const wu32 &c, const wu32 &q, const wu32 &row, const wu32 &k) {
+    wu32 r4[4];
+    wv_rows4(cx, c, r4);
+    const wu32 x = r4[0], y = r4[1];
+    const wu32 in = wv_select(row == 0u, hw_sub(y, x, k), wv_select(row == 1u, y + x, c));
+    const wu32 m = hw_mul(cx, in, q, k);                      // A | B | Z1*Z2 | C
+    wv_rows4(cx, m, r4);
+    const wu32 a = r4[0], b = r4[1], cc = r4[3];
+    const wu32 d = r4[2] + r4[2];
+    const wu32 e = hw_sub(b, a, k);
+    const wu32 h = b + a;
+    const wu32 f = hw_sub(d, cc, k);
+    const wu32 g = d + cc;                                    // <= 2^18.2
+    return hw_point_finish(cx, e, f, g, h, row, k);
+}
+
+// The whole chain for one MSM.  colq16: this MSM's 64 column sums, [w][4][16] u16 limbs of the
+// canonical encodings of (Y-X, Y+X, Z, 2dT).  Returns the running point (row r = coordinate r).
+WV_FN wu32 hw_horner(const wv_ctx &cx, const uint16_t *colq16) {
+    const wu32 lane = wv_lane();
+    const wu32 k = lane & 15u, row = lane >> 4;
+    // identity (0 : 1 : 1 : 0)
+    wu32 c = wv_select((k == 0u) && (row == 1u || row == 2u), wv_splat(1), wv_splat(0));
+    for (int w = BP_VB_WINDOWS - 1; w >= 0; w--) {
+        if (w != BP_VB_WINDOWS - 1) {
+            c = hw_dbl(cx, c, row, k);
+            c = hw_dbl(cx, c, row, k);
+            c = hw_dbl(cx, c, row, k);
+            c = hw_dbl(cx, c, row, k);
+        }
+        const wu32 q = wv_load_u16(colq16, lane + (uint32_t)(w * 64));
+        c = hw_add_cached(cx, c, q, row, k);
+    }
+    return c;
+}
+
+// one lane's 16 lazy limbs (<= 2^17) -> 10 x 25.5-bit field element (lazy, limb 0 may exceed 2^26 by 19+38*small)
+BP_HD void hw_limbs_to_fe(fe &out, const uint32_t l[16]) {
+    uint32_t t[16], carry = 0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t s = l[i] + carry;
+        t[i] = s & 0xffffu;
+        carry = s >> 16;
+    }
+    // carry * 2^256 = carry * 38: fold into the low limbs (carry <= 2)
+    uint32_t s = t[0] + 38u * carry;
+    t[0] = s & 0xffffu;
+    carry = s >> 16;
+#pragma unroll
+    for (int i = 1; i < 16; i++) {
+        const uint32_t u = t[i] + carry;
+        t[i] = u & 0xffffu;
+        carry = u >> 16;
+    }
+    // (a second overflow is impossible: the value is now < 2^256)
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = t[2 * i] | (t[2 * i + 1] << 16);
+    const uint32_t top = w[7] >> 31;        // 2^255 = 19
+    w[7] &= 0x7fffffffu;
+    fe_from_words(out, w);
+    out.v[0] += 19u * top;
+}
+
+// Driver for one MSM (= one wavefront on the device, one lockstep emulation on the host):
+// runs the chain and writes the result as an extended point (4 field elements, lazy limbs).
+#if defined(__HIPCC__) && !defined(__HIP_DEVICE_COMPILE__)
+__device__ void hw_horner_msm(const uint16_t *colq16, ge_ext *out);   // host pass of hipcc: declaration only
+#elif defined(__HIP_DEVICE_COMPILE__)
+__device__ __forceinline__ void hw_horner_msm(const uint16_t *colq16, ge_ext *out) {
+    __shared__ __attribute__((aligned(16))) uint32_t hw_lds[128];
+    wv_ctx cx;
+    cx.lds = hw_lds;
+    const wu32 c = hw_horner(cx, colq16);
+    const uint32_t lane = wv_lane();
+    uint32_t limbs[16];
+    wv_row_gather16(cx, c, limbs);
+    if ((lane & 15u) == 0) {
+        fe r;
+        hw_limbs_to_fe(r, limbs);
+        ((fe *)out)[lane >> 4] = r;
+    }
+}
+#else
+inline void hw_horner_msm(const uint16_t *colq16, ge_ext *out) {
+    wv_ctx cx{0};
+    const wu32 c = hw_horner(cx, colq16);
+    wu32 limbs[16];
+    wv_row_gather16(cx, c, limbs);
+    for (int row = 0; row < 4; row++) {
+        uint32_t l[16];
+        for (int i = 0; i < 16; i++) l[i] = limbs[i].l[row * 16];
+        fe r;
+        hw_limbs_to_fe(r, l);
+        ((fe *)out)[row] = r;
+    }
+}
+#endif
+
+}  // namespace bp
+#endif

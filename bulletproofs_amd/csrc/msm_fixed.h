@@ -223,10 +223,13 @@ BP_HD void fb_reduce_thread(uint32_t tid, uint32_t nproofs, uint32_t nsplit, uin
 // ---- finish --------------------------------------------------------------------------
 // thread p: result = Horner(col[p]) (unique, variable-base terms) + sum_split partial[split][p]
 // out_words (optional): compressed result; verdict (optional): status[p] if set, else 0 identity / 1 not
+// horner_pre (optional): Horner results already computed by the wavefront-cooperative kernel (horner_wave.h)
 BP_HD void shared_finish_thread(uint32_t p, uint32_t nproofs, uint32_t nsplit, const ge_ext *col, bool have_unique,
-                                const ge_ext *partial, const uint32_t *status, uint32_t *out_words, uint8_t *verdict) {
+                                const ge_ext *horner_pre, const ge_ext *partial, const uint32_t *status, uint32_t *out_words,
+                                uint8_t *verdict) {
     ge_ext acc;
-    if (have_unique) vb_horner_point(acc, col + (uint64_t)p * 64);
+    if (have_unique && horner_pre) acc = horner_pre[p];
+    else if (have_unique) vb_horner_point(acc, col + (uint64_t)p * 64);
     else ge_identity(acc);
     for (uint32_t s = 0; s < nsplit; s++) {
         const ge_ext q = partial[(uint64_t)s * nproofs + p];

@@ -131,7 +131,10 @@ BP_HD void vb_window_thread(uint32_t tid, const vb_chunk *chunks, const ge_cache
 
 // ---- stage 3 ---------------------------------------------------------------
 // thread = msm * 64 + w ; chunks of one msm are contiguous: [chunk_first[msm], chunk_first[msm+1])
-BP_HD void vb_colsum_thread(uint32_t tid, const uint32_t *chunk_first, const ge_ext *part, ge_ext *col /*[msm][64]*/) {
+// col    (optional): the column sum as an extended point (input of the one-lane Horner chain)
+// colq16 (optional): the same point for the wavefront-cooperative chain (horner_wave.h):
+//                    [msm][w][4][8 words] = canonical encodings of (Y-X, Y+X, Z, 2dT), i.e. 16 u16 limbs each
+BP_HD void vb_colsum_thread(uint32_t tid, const uint32_t *chunk_first, const ge_ext *part, ge_ext *col, uint32_t *colq16) {
     const uint32_t b = tid >> 6, w = tid & 63;
     const uint32_t c0 = chunk_first[b], c1 = chunk_first[b + 1];
     ge_ext acc;
@@ -141,7 +144,16 @@ BP_HD void vb_colsum_thread(uint32_t tid, const uint32_t *chunk_first, const ge_
         const ge_ext q = part[(uint64_t)c * 64 + w];
         ge_add(acc, acc, q);
     }
-    col[tid] = acc;
+    if (col) col[tid] = acc;
+    if (colq16) {
+        ge_cached cc;
+        ge_to_cached(cc, acc);
+        uint32_t *o = colq16 + (uint64_t)tid * 32;
+        fe_to_words(o, cc.YmX);
+        fe_to_words(o + 8, cc.YpX);
+        fe_to_words(o + 16, cc.Z);
+        fe_to_words(o + 24, cc.T2d);
+    }
 }
 
 // ---- stage 4 ---------------------------------------------------------------
@@ -159,10 +171,12 @@ BP_HD void vb_horner_point(ge_ext &acc, const ge_ext *col /*64 entries*/) {
 }
 
 // thread = msm
-BP_HD void vb_horner_thread(uint32_t b, const ge_ext *col, const uint32_t *status, uint32_t *out /*[msm][8]*/,
+// `pre` (optional): Horner results already computed by the wavefront-cooperative kernel
+BP_HD void vb_horner_thread(uint32_t b, const ge_ext *col, const ge_ext *pre, const uint32_t *status, uint32_t *out /*[msm][8]*/,
                             ge_ext *out_ext /*optional [msm]*/) {
     ge_ext acc;
-    vb_horner_point(acc, col + (uint64_t)b * 64);
+    if (pre) acc = pre[b];
+    else vb_horner_point(acc, col + (uint64_t)b * 64);
     uint32_t w[8];
     ristretto_compress(w, acc);
     const bool bad = status[b] != 0;

@@ -7,12 +7,27 @@
 #include "../../bulletproofs_amd/csrc/msm_vb.h"
 #include "../../bulletproofs_amd/csrc/msm_fixed.h"
 #include "../../bulletproofs_amd/csrc/rangeproof.h"
+#include "../../bulletproofs_amd/csrc/horner_wave.h"
+#include <cstdio>
 #include <cstring>
 #include <vector>
 using namespace bp;
 
 static void load(fe &f, const uint8_t *b) { uint32_t w[8]; memcpy(w, b, 32); fe_from_words(f, w); }
 static void store(uint8_t *b, const fe &f) { uint32_t w[8]; fe_to_words(w, f); memcpy(b, w, 32); }
+
+// column sums -> Horner results through the wavefront-cooperative chain (lockstep emulation of the 64 lanes),
+// cross-checked against the one-lane chain on the ristretto encoding
+static int horner_all(uint32_t nbatch, const std::vector<ge_ext> &col, const std::vector<uint32_t> &colq16, std::vector<ge_ext> &hq) {
+    hq.resize(nbatch + 1);
+    for (uint32_t b = 0; b < nbatch; b++) {
+        hw_horner_msm((const uint16_t *)(colq16.data() + (size_t)b * 64 * 32), &hq[b]);
+        ge_ext ref; vb_horner_point(ref, col.data() + (size_t)b * 64);
+        uint32_t e1[8], e2[8]; ristretto_compress(e1, hq[b]); ristretto_compress(e2, ref);
+        if (memcmp(e1, e2, 32) != 0) { std::fprintf(stderr, "horner_wave mismatch at msm %u\n", b); return -99; }
+    }
+    return 0;
+}
 
 extern "C" {
 // op: 0 mul 1 sq 2 add 3 sub 4 neg 5 invert 6 pow22523 7 carry-roundtrip 8 lazy-chain
@@ -89,12 +104,14 @@ void h_msm_vb(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, 
     uint32_t total = t0;
     std::vector<ge_cached> tab((size_t)total * 8 + 1);
     std::vector<uint32_t> rec((size_t)total * 8 + 1), status(nbatch + 1, 0), outw((size_t)nbatch * 8 + 1);
-    std::vector<ge_ext> part(chunks.size() * 64 + 1), col((size_t)nbatch * 64 + 1);
+    std::vector<ge_ext> part(chunks.size() * 64 + 1), col((size_t)nbatch * 64 + 1), hq;
+    std::vector<uint32_t> colq16((size_t)nbatch * 64 * 32 + 1);
     for (uint32_t t = 0; t < total; t++)
         vb_prepare_thread(t, chunks.data(), term_chunk.data(), (const uint32_t *)scalars, (const uint32_t *)points, tab.data(), rec.data(), status.data());
     for (uint32_t tid = 0; tid < chunks.size() * 64; tid++) vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data());
-    for (uint32_t tid = 0; tid < nbatch * 64; tid++) vb_colsum_thread(tid, chunk_first.data(), part.data(), col.data());
-    for (uint32_t b = 0; b < nbatch; b++) vb_horner_thread(b, col.data(), status.data(), outw.data(), nullptr);
+    for (uint32_t tid = 0; tid < nbatch * 64; tid++) vb_colsum_thread(tid, chunk_first.data(), part.data(), col.data(), colq16.data());
+    if (horner_all(nbatch, col, colq16, hq)) { memset(out, 0xee, (size_t)nbatch * 32); return; }
+    for (uint32_t b = 0; b < nbatch; b++) vb_horner_thread(b, nullptr, hq.data(), status.data(), outw.data(), nullptr);
     memcpy(out, outw.data(), (size_t)nbatch * 32);
     for (uint32_t b = 0; b < nbatch; b++) status_out[b] = (uint8_t)status[b];
 }
@@ -126,11 +143,13 @@ int h_msm_shared(uint32_t W, uint32_t nsplit, uint32_t n_gens_loaded, const uint
     chunk_first[nbatch] = (uint32_t)chunks.size();
     std::vector<ge_cached> tab((size_t)t0 * 8 + 1);
     std::vector<uint32_t> rec((size_t)t0 * 8 + 1), status(nbatch + 1, 0), outw((size_t)nbatch * 8 + 1);
-    std::vector<ge_ext> part(chunks.size() * 64 + 1), col((size_t)nbatch * 64 + 1);
+    std::vector<ge_ext> part(chunks.size() * 64 + 1), col((size_t)nbatch * 64 + 1), hq;
+    std::vector<uint32_t> colq16((size_t)nbatch * 64 * 32 + 1);
     for (uint32_t t = 0; t < t0; t++)
         vb_prepare_thread(t, chunks.data(), term_chunk.data(), (const uint32_t *)uniq_scalars, (const uint32_t *)uniq_points, tab.data(), rec.data(), status.data());
     for (uint32_t tid = 0; tid < chunks.size() * 64; tid++) vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data());
-    for (uint32_t tid = 0; tid < nbatch * 64; tid++) vb_colsum_thread(tid, chunk_first.data(), part.data(), col.data());
+    for (uint32_t tid = 0; tid < nbatch * 64; tid++) vb_colsum_thread(tid, chunk_first.data(), part.data(), col.data(), colq16.data());
+    if (horner_all(nbatch, col, colq16, hq)) return -99;
     // generator part
     const uint32_t npairs = n_gen_terms * prm.nwin;
     std::vector<uint16_t> digits((size_t)npairs * nbatch + 1);
@@ -142,7 +161,7 @@ int h_msm_shared(uint32_t W, uint32_t nsplit, uint32_t n_gens_loaded, const uint
         for (uint32_t p = 0; p < nbatch; p++) fb_accum_thread(p, sp, q0, q1, prm, nbatch, gen_ids, digits.data(), table.data(), partial.data());
     }
     std::vector<uint8_t> verdict(nbatch + 1);
-    for (uint32_t p = 0; p < nbatch; p++) shared_finish_thread(p, nbatch, nsplit, col.data(), n_unique != 0, partial.data(), status.data(), outw.data(), verdict.data());
+    for (uint32_t p = 0; p < nbatch; p++) shared_finish_thread(p, nbatch, nsplit, nullptr, n_unique != 0, hq.data(), partial.data(), status.data(), outw.data(), verdict.data());
     memcpy(out, outw.data(), (size_t)nbatch * 32);
     for (uint32_t b = 0; b < nbatch; b++) { status_out[b] = (uint8_t)status[b]; verdict_out[b] = verdict[b]; }
     return 0;
@@ -236,10 +255,12 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
     }
     chunk_first[nbatch] = (uint32_t)chunks.size();
     std::vector<ge_cached> tab((size_t)t0 * 8 + 1); std::vector<uint32_t> rec((size_t)t0 * 8 + 1), outw((size_t)nbatch * 8 + 1);
-    std::vector<ge_ext> part(chunks.size() * 64 + 1), col((size_t)nbatch * 64 + 1);
+    std::vector<ge_ext> part(chunks.size() * 64 + 1), col((size_t)nbatch * 64 + 1), hq;
+    std::vector<uint32_t> colq16((size_t)nbatch * 64 * 32 + 1);
     for (uint32_t t = 0; t < t0; t++) vb_prepare_thread(t, chunks.data(), term_chunk.data(), uniq_scalars.data(), uniq_points.data(), tab.data(), rec.data(), status.data());
     for (uint32_t tid = 0; tid < chunks.size() * 64; tid++) vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data());
-    for (uint32_t tid = 0; tid < nbatch * 64; tid++) vb_colsum_thread(tid, chunk_first.data(), part.data(), col.data());
+    for (uint32_t tid = 0; tid < nbatch * 64; tid++) vb_colsum_thread(tid, chunk_first.data(), part.data(), col.data(), colq16.data());
+    if (horner_all(nbatch, col, colq16, hq)) return -99;
     std::vector<ge_ext> partial((size_t)nsplit * nbatch + 1);
     const uint32_t per = (npairs + nsplit - 1) / nsplit;
     for (uint32_t sp = 0; sp < nsplit; sp++) {
@@ -247,7 +268,7 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
         for (uint32_t p = 0; p < nbatch; p++) fb_accum_thread(p, sp, q0, q1, prm, nbatch, ids.data(), digits.data(), table.data(), partial.data());
     }
     std::vector<uint8_t> verdict(nbatch + 1);
-    for (uint32_t p = 0; p < nbatch; p++) shared_finish_thread(p, nbatch, nsplit, col.data(), true, partial.data(), status.data(), outw.data(), verdict.data());
+    for (uint32_t p = 0; p < nbatch; p++) shared_finish_thread(p, nbatch, nsplit, nullptr, true, hq.data(), partial.data(), status.data(), outw.data(), verdict.data());
     for (uint32_t p = 0; p < nbatch; p++) verdict_out[p] = verdict[p];
     if (msm_out) memcpy(msm_out, outw.data(), (size_t)nbatch * 32);
     return 0;
