@@ -23,9 +23,10 @@
 
 #if defined(__HIPCC__)
 #define BP_HD __host__ __device__ __forceinline__
-#define BP_DEV_CONST __device__ __constant__
+#define BP_HD_NOINLINE __host__ __device__ __attribute__((noinline))   // one copy of a big body (I-cache)
 #else
 #define BP_HD inline
+#define BP_HD_NOINLINE inline
 #endif
 
 #ifdef BP_FE_CHECK

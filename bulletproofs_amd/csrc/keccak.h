@@ -28,7 +28,21 @@ BP_HD void ks_zero(const kstate &s) {
     for (uint32_t i = 0; i < 50; i++) ks_set32(s, i, 0);
 }
 
-BP_HD uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
+// 64-bit rotate by a compile-time amount, written on 32-bit halves: each half is one funnel shift
+// (v_alignbit_b32, full rate) instead of two quarter-rate 64-bit shifts and an OR
+BP_HD uint64_t rotl64(uint64_t x, int n) {
+    uint32_t lo = (uint32_t)x, hi = (uint32_t)(x >> 32);
+    if (n >= 32) {
+        const uint32_t t = lo;
+        lo = hi;
+        hi = t;
+        n -= 32;
+    }
+    if (n == 0) return ((uint64_t)hi << 32) | lo;
+    const uint32_t nlo = (lo << n) | (hi >> (32 - n));
+    const uint32_t nhi = (hi << n) | (lo >> (32 - n));
+    return ((uint64_t)nhi << 32) | nlo;
+}
 
 // 24 rounds on 25 lanes held in registers (all indices static after unrolling)
 BP_HD void keccak_f1600_lanes(uint64_t a[25]) {

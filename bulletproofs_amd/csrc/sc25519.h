@@ -149,6 +149,8 @@ BP_HD void sc_from_sc28(sc &r, const sc28 &a) {
     for (int i = 0; i < 8; i++) r.v[i] = w[i];
 }
 
+BP_HD void sc28_montreduce(sc28 &r, uint64_t t[20]);
+
 // r = a * b * 2^-280 mod l, lazy in, lazy out.
 // Bounds: limbs <= 2^28+4 -> products < 2^56.01, schoolbook columns < 10 * 2^56.01 < 2^59.4; the reduction
 // adds < 5 * 2^56 + 2^28 + 2^32 per column -> every column stays < 2^60.  Value: (a*b + m*l) / 2^280
@@ -162,7 +164,10 @@ BP_HD void sc28_montmul(sc28 &r, const sc28 &a, const sc28 &b) {
 #pragma unroll
         for (int j = 0; j < 10; j++) t[i + j] += (uint64_t)a.v[i] * b.v[j];
     }
-    // Montgomery reduction, one 28-bit limb per step: m = t_i * (-l^-1) mod 2^28, t += m * l * 2^(28 i)
+    sc28_montreduce(r, t);
+}
+// shared tail of the Montgomery product: reduce the 20 column sums and normalise (see sc28_montmul)
+BP_HD void sc28_montreduce(sc28 &r, uint64_t t[20]) {
 #pragma unroll
     for (int i = 0; i < 10; i++) {
         const uint32_t m = ((uint32_t)t[i] * BP_SC28_LFACTOR) & BP_M28;
@@ -172,21 +177,34 @@ BP_HD void sc28_montmul(sc28 &r, const sc28 &a, const sc28 &b) {
         t[i + 3] += (uint64_t)m * BP_SC28_C3;
         t[i + 4] += (uint64_t)m * BP_SC28_C4;
         t[i + 9] += m;
-        t[i + 1] += t[i] >> 28;   // low 28 bits of t[i] are now zero
+        t[i + 1] += t[i] >> 28;
     }
-    // result columns t[10..19]; two parallel normalisation rounds
     uint32_t u[10];
 #pragma unroll
     for (int k = 0; k < 10; k++) {
         uint64_t x = t[10 + k] & BP_M28;
         if (k >= 1) x += (t[10 + k - 1] >> 28) & BP_M28;
         if (k >= 2) x += t[10 + k - 2] >> 56;
-        u[k] = (uint32_t)x;   // < 2^29 + 16
+        u[k] = (uint32_t)x;
     }
-    // (t[19] >> 28 and t[18] >> 56 would land above limb 9: zero because the value is < 2^254)
 #pragma unroll
     for (int k = 0; k < 10; k++) r.v[k] = (u[k] & BP_M28) + (k >= 1 ? (u[k - 1] >> 28) : 0u);
-    r.v[9] += (u[9] >> 28) << 28;   // keep a (never expected) top carry inside limb 9
+}
+// r = a^2 * 2^-280 mod l: 55 limb products instead of 100 (off-diagonal ones doubled)
+BP_HD void sc28_montsq(sc28 &r, const sc28 &a) {
+    uint64_t t[20];
+#pragma unroll
+    for (int k = 0; k < 20; k++) t[k] = 0;
+    uint32_t a2[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) a2[i] = a.v[i] << 1;   // <= 2^29 + 8
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        t[2 * i] += (uint64_t)a.v[i] * a.v[i];
+#pragma unroll
+        for (int j = i + 1; j < 10; j++) t[i + j] += (uint64_t)a2[i] * a.v[j];
+    }
+    sc28_montreduce(r, t);
 }
 BP_HD void sc28_to_mont(sc28 &r, const sc28 &a) {
     const sc28 rr = BP_SC28_RR;
@@ -202,18 +220,25 @@ BP_HD void sc28_one_mont(sc28 &r) {
     const sc28 R = BP_SC28_R;
     r = R;
 }
-// Montgomery form in, Montgomery form out: a^(l-2)
+// Montgomery form in, Montgomery form out: a^(l-2).  l - 2 = 2^252 + (c - 2): after the leading 1 come
+// 127 zero bits (squarings only) and a 125-bit tail, walked in 4-bit windows against a table of
+// a^0..a^15 (the exponent is a public constant, so the walk is the same for every lane).
 BP_HD void sc28_invert_mont(sc28 &r, const sc28 &am) {
-    const sc l = BP_SC_L;
-    uint32_t e[8];
-#pragma unroll
-    for (int i = 0; i < 8; i++) e[i] = l.v[i];
-    e[0] -= 2;
-    sc28 acc;
-    sc28_one_mont(acc);
-    for (int i = 252; i >= 0; i--) {
-        sc28_montmul(acc, acc, acc);
-        if ((e[i >> 5] >> (i & 31)) & 1) sc28_montmul(acc, acc, am);
+    // nibbles of (c - 2) = 0x14def9dea2f79cd65812631a5cf5d3eb, most significant first (32 nibbles = 128 bits)
+    const uint8_t nib[32] = {0x1, 0x4, 0xd, 0xe, 0xf, 0x9, 0xd, 0xe, 0xa, 0x2, 0xf, 0x7, 0x9, 0xc, 0xd, 0x6,
+                             0x5, 0x8, 0x1, 0x2, 0x6, 0x3, 0x1, 0xa, 0x5, 0xc, 0xf, 0x5, 0xd, 0x3, 0xe, 0xb};
+    sc28 tab[16];
+    sc28_one_mont(tab[0]);
+    tab[1] = am;
+    for (int i = 2; i < 16; i++) sc28_montmul(tab[i], tab[i - 1], am);
+    sc28 acc = am;                                      // the leading bit (2^252)
+    for (int i = 0; i < 252 - 128; i++) sc28_montsq(acc, acc);
+    for (int i = 0; i < 32; i++) {
+        sc28_montsq(acc, acc);
+        sc28_montsq(acc, acc);
+        sc28_montsq(acc, acc);
+        sc28_montsq(acc, acc);
+        sc28_montmul(acc, acc, tab[nib[i]]);            // (nibble 0 multiplies by one: keeps the lanes uniform)
     }
     r = acc;
 }
