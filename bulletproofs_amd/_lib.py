@@ -30,6 +30,13 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm wheels bundle their own libamdhip64; if libbpgpu.so pulled in /opt/rocm's copy first, a
+    # later `import torch` in the same process would bring up a second HIP runtime and find no GPU.  Loading
+    # torch first makes both share one runtime (torch is plumbing here: device buffers, streams, RCCL).
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise BpgpuError("libbpgpu.so not built (%s); run `python -c 'import __graft_entry__ as g; g.build()'` -- "
                          "there is no CPU fallback" % LIB_PATH)

@@ -154,3 +154,54 @@ def test_r1cs_shape_msm_config5(oracle):
     out2, st2 = c.msm_batch([6179, 6179], flat_s, flat_p)
     assert st2 == bytes(2) and out2 == out
     c.close()
+
+
+def test_device_pointer_entry_points_with_torch_streams(oracle):
+    """The *_dev twins: device pointers (torch tensors) + a caller-owned HIP stream; results stay on the device
+    and are ordered on that stream."""
+    import ctypes as C
+    import torch
+    import bulletproofs_amd as bp
+    L = bp.lib()
+    dev = torch.device("cuda", 0)
+    c = bp.Context(0, fixed_window_bits=8)
+    g = oracle.Gens(8, 1)
+    G, H, B, Bb = g.export()
+    c.gens_load(8, 1, G, H, B, Bb)
+    n, m, nb, nu = 8, 1, 5, 3
+    ngen = 2 * n * m + 2
+    GS = b"".join(_scalar(b"dg%d" % i) for i in range(ngen * nb))
+    US = b"".join(_scalar(b"du%d" % i) for i in range(nu * nb))
+    UP = _points(oracle, b"dp", nu * nb)
+    to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_gs, d_us, d_up = to_dev(GS), to_dev(US), to_dev(UP)
+    d_out = torch.zeros(32 * nb, dtype=torch.uint8, device=dev)
+    d_st = torch.full((nb,), 9, dtype=torch.uint8, device=dev)
+    s = torch.cuda.Stream(device=dev)
+    s.wait_stream(torch.cuda.current_stream())
+    rc = L.bpgpu_msm_batch_shared_dev(c.h, n, m, nb, nu, d_gs.data_ptr(), d_us.data_ptr(), d_up.data_ptr(), d_out.data_ptr(),
+                                      d_st.data_ptr(), s.cuda_stream)
+    assert rc == 0, L.bpgpu_last_error(c.h)
+    # general entry point on the same stream, ragged
+    flat_s = GS[:32 * ngen] + US[:32 * nu]
+    flat_p = Bb + B + G + H + UP[:32 * nu]
+    nt = (C.c_uint32 * 2)(ngen + nu, 2)
+    d_s2, d_p2 = to_dev(flat_s + US[:64]), to_dev(flat_p + UP[:64])
+    d_out2 = torch.zeros(64, dtype=torch.uint8, device=dev)
+    d_st2 = torch.full((2,), 9, dtype=torch.uint8, device=dev)
+    rc = L.bpgpu_msm_batch_dev(c.h, 2, nt, d_s2.data_ptr(), d_p2.data_ptr(), d_out2.data_ptr(), d_st2.data_ptr(), s.cuda_stream)
+    assert rc == 0, L.bpgpu_last_error(c.h)
+    s.synchronize()
+    out, st = bytes(d_out.cpu().numpy()), bytes(d_st.cpu().numpy())
+    gp = Bb + B + G + H
+    for b in range(nb):
+        exp = oracle.msm(GS[32 * ngen * b:32 * ngen * (b + 1)] + US[32 * nu * b:32 * nu * (b + 1)], gp + UP[32 * nu * b:32 * nu * (b + 1)])
+        assert st[b] == 0 and out[32 * b:32 * b + 32] == exp[1]
+    out2 = bytes(d_out2.cpu().numpy())
+    assert bytes(d_st2.cpu().numpy()) == bytes(2)
+    assert out2[:32] == out[:32] and out2[32:] == oracle.msm(US[:64], UP[:64])[1]
+    # misaligned device pointer is rejected by the range-proof entry point (bpgpu.h: 4-byte alignment)
+    d_misc = torch.zeros(4096, dtype=torch.uint8, device=dev)
+    rc = L.bpgpu_rangeproof_verify_batch_dev(c.h, 8, 1, 1, d_misc.data_ptr() + 1, 480, d_misc.data_ptr(), b"x", 1, None, d_st.data_ptr(), None, None)
+    assert rc == -1
+    c.close()

@@ -179,3 +179,58 @@ def test_aggregated_m32_config4_shape(oracle):
     secs, ev, em = oracle.verify_batch(g, bytes(proofs), coms, 32, 64, fx.label, rng, threads=4)
     assert fx.proof_len == 992 and list(verdict) == [0, 0, 1, 0] and verdict == ev and msm == em
     c.close()
+
+
+def test_differential_fuzz_against_oracle(ctx64x8, oracle, oracle_gens_64_8, golden):
+    """Seeded random single-bit / byte mutations anywhere in the proof or the commitments, several shapes:
+    every verdict (incl. FormatError vs VerificationError) and every decodable mega-check encoding must equal
+    the oracle's.  Covers non-canonical scalars, undecodable and identity points, wrong challenges."""
+    import random
+    rnd = random.Random(20260923)
+    for case in (golden["cases"][0], golden["cases"][5], golden["cases"][10], golden["cases"][12]):
+        n, m = case["n"], case["m"]
+        pr = bytes.fromhex(case["proof"])
+        pl = len(pr)
+        nb = 96
+        proofs, coms = bytearray(), bytearray()
+        for i in range(nb):
+            p, c = bytearray(pr), bytearray(golden["vc_bytes"][:32 * m])
+            kind = i % 6
+            if kind == 1:
+                p[rnd.randrange(pl)] ^= 1 << rnd.randrange(8)
+            elif kind == 2:
+                c[rnd.randrange(len(c))] ^= 1 << rnd.randrange(8)
+            elif kind == 3:
+                off = 32 * rnd.randrange(pl // 32)
+                p[off:off + 32] = bytes(rnd.randrange(256) for _ in range(32))
+            elif kind == 4:
+                off = 32 * rnd.randrange(pl // 32)
+                p[off:off + 32] = bytes(32)
+            elif kind == 5:
+                p[32 * rnd.randrange(pl // 32) + 31] |= 0x80
+            proofs += p
+            coms += c
+        rng = hashlib.shake_256(b"fuzz%d-%d" % (n, m)).digest(64 * nb)
+        verdict, msm = ctx64x8.rangeproof_verify_batch(n, m, bytes(proofs), pl, bytes(coms), golden["label"], rng, want_msm=True)
+        _, ev, em = oracle.verify_batch(oracle_gens_64_8, bytes(proofs), bytes(coms), m, n, golden["label"], rng, threads=os.cpu_count() or 1)
+        assert verdict == ev, (n, m, [i for i in range(nb) if verdict[i] != ev[i]][:5])
+        assert {0, 1, 2} <= set(verdict)
+        for b in range(nb):
+            if em[32 * b:32 * b + 32] != b"\xff" * 32 and ev[b] != 2:
+                assert msm[32 * b:32 * b + 32] == em[32 * b:32 * b + 32], (n, m, b)
+
+
+def test_zero_commitments_and_odd_batches(ctx64x8, oracle, oracle_gens_64_8, golden):
+    pr = bytes.fromhex(golden["cases"][0]["proof"])
+    rng = hashlib.shake_256(b"odd").digest(64 * 67)
+    # m = 0: n*m = 0 is not 2^lg(L_vec) -> VerificationError for every well-formed proof (ipp.rs:209)
+    assert list(ctx64x8.rangeproof_verify_batch(8, 0, pr * 3, len(pr), b"", golden["label"], rng[:192])) == [1, 1, 1]
+    # m = 3 is not a power of two -> VerificationError
+    assert list(ctx64x8.rangeproof_verify_batch(8, 3, pr, len(pr), golden["vc_bytes"][:96], golden["label"], rng[:64])) == [1]
+    # batch sizes around the wavefront width
+    for nb in (1, 63, 64, 65, 67):
+        v = ctx64x8.rangeproof_verify_batch(8, 1, pr * nb, len(pr), golden["vc_bytes"][:32] * nb, golden["label"], rng[:64 * nb])
+        assert v == bytes(nb), nb
+    # empty transcript label
+    rc, _ = oracle.verify(oracle_gens_64_8, pr, golden["vc_bytes"][:32], 8, b"", rng[:64])
+    assert list(ctx64x8.rangeproof_verify_batch(8, 1, pr, len(pr), golden["vc_bytes"][:32], b"", rng[:64])) == [rc] == [1]
