@@ -16,7 +16,7 @@ EXPORTS = [
     "bpgpu_ctx_get_option",
     "bpgpu_synchronize", "bpgpu_gens_create", "bpgpu_gens_load", "bpgpu_gens_export",
     "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_msm_batch_shared", "bpgpu_msm_batch_shared_dev",
-    "bpgpu_rangeproof_verify_batch", "bpgpu_rangeproof_verify_batch_dev",
+    "bpgpu_rangeproof_verify_batch", "bpgpu_rangeproof_verify_batch_dev", "bpgpu_ipp_verify_batch",
     "bpgpu_profile_enable", "bpgpu_profile_reset", "bpgpu_profile_report",
 ]
 
@@ -63,6 +63,7 @@ def lib():
     L.bpgpu_msm_batch_shared_dev.argtypes = [vp, sz, sz, sz, sz, vp, vp, vp, vp, vp, vp]
     L.bpgpu_rangeproof_verify_batch.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p]
     L.bpgpu_rangeproof_verify_batch_dev.argtypes = [vp, sz, sz, sz, vp, sz, vp, u8p, sz, vp, vp, vp, vp]
+    L.bpgpu_ipp_verify_batch.argtypes = [vp, sz, sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.bpgpu_profile_enable.argtypes = [vp, i]
     L.bpgpu_profile_reset.argtypes = [vp]
     L.bpgpu_profile_report.argtypes = [vp, C.c_char_p, sz]
@@ -159,6 +160,15 @@ class Context:
         msm = C.create_string_buffer(32 * max(nb, 1)) if want_msm else None
         self._chk(self._L.bpgpu_rangeproof_verify_batch(self.h, n, m, nb, proofs, proof_len, commitments, label, len(label),
                                                         rng64, verdict, msm))
+        return (verdict.raw[:nb], msm.raw[:32 * nb]) if want_msm else verdict.raw[:nb]
+
+    # ---- stand-alone inner-product proofs ----
+    def ipp_verify_batch(self, n, proofs, proof_len, label, Gf, Hf, P, Q, G, H, want_msm=False):
+        nb = len(proofs) // proof_len if proof_len else 0
+        assert len(Gf) == len(Hf) == len(G) == len(H) == 32 * n * nb and len(P) == len(Q) == 32 * nb
+        verdict = C.create_string_buffer(max(nb, 1))
+        msm = C.create_string_buffer(32 * max(nb, 1)) if want_msm else None
+        self._chk(self._L.bpgpu_ipp_verify_batch(self.h, n, nb, proofs, proof_len, label, len(label), Gf, Hf, P, Q, G, H, verdict, msm))
         return (verdict.raw[:nb], msm.raw[:32 * nb]) if want_msm else verdict.raw[:nb]
 
     # ---- instrumentation ----

@@ -16,6 +16,7 @@
 #include "msm_vb.h"
 #include "horner_wave.h"
 #include "rangeproof.h"
+#include "ipp.h"
 
 using namespace bp;
 
@@ -146,6 +147,23 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rp_expand_b(uint32_t nthreads, rp_
 __global__ void __launch_bounds__(64) k_rp_verdict(uint32_t n, const uint32_t *status, const uint8_t *msm_verdict, uint8_t *out) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p < n) out[p] = status[p] ? (uint8_t)status[p] : msm_verdict[p];
+}
+
+__global__ void __launch_bounds__(RP_BLOCK) k_ipp_prepare(ipp_shape sh, rp_strobe_init init, const uint8_t *proofs, const uint8_t *Gf,
+                                                           const uint8_t *Hf, const uint8_t *P, const uint8_t *Q, const uint8_t *G,
+                                                           const uint8_t *H, uint32_t *scalars, uint32_t *points, uint32_t *status) {
+    __shared__ uint32_t lds[50 * RP_BLOCK];
+    const uint32_t p = blockIdx.x * RP_BLOCK + threadIdx.x;
+    kstate st;
+    st.w = lds + threadIdx.x;
+    st.stride = RP_BLOCK;
+    if (p < sh.nproofs) ipp_prepare_thread(p, sh, init, st, proofs, Gf, Hf, P, Q, G, H, scalars, points, status);
+}
+
+__global__ void __launch_bounds__(64) k_ipp_verdict(uint32_t n, const uint32_t *status, const uint8_t *msm_status, const uint32_t *msm_out,
+                                                     uint8_t *verdict) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) ipp_verdict_thread(p, status, msm_status, msm_out, verdict);
 }
 
 // generator derivation: 64 uniform bytes -> RistrettoPoint::from_uniform_bytes -> encoding
@@ -1123,5 +1141,106 @@ extern "C" int bpgpu_rangeproof_verify_batch(bpgpu_ctx *c, size_t n, size_t m, s
     } while (0);
     hipStreamSynchronize(s);
     hipFree(d_io);
+    return rc;
+}
+
+// ============================================================================
+// stand-alone inner-product proofs
+// ============================================================================
+extern "C" int bpgpu_ipp_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, const uint8_t *proofs, size_t proof_len, const uint8_t *label,
+                                      size_t label_len, const uint8_t *G_factors, const uint8_t *H_factors, const uint8_t *P,
+                                      const uint8_t *Q, const uint8_t *G, const uint8_t *H, uint8_t *verdict, uint8_t *msm_out) {
+    if (!c || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0) return BPGPU_OK;
+    if (!proofs || !verdict || !P || !Q || (n && (!G_factors || !H_factors || !G || !H))) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    // InnerProductProof::from_bytes, length part (ipp.rs:374-388)
+    size_t k = 0;
+    bool fmt = false;
+    if (proof_len % 32 != 0) fmt = true;
+    else {
+        const size_t ne = proof_len / 32;
+        if (ne < 2 || (ne - 2) % 2 != 0) fmt = true;
+        else {
+            k = (ne - 2) / 2;
+            if (k >= 32) fmt = true;
+        }
+    }
+    if (fmt) {
+        memset(verdict, BPGPU_VERDICT_FORMAT_ERROR, nbatch);
+        if (msm_out) memset(msm_out, 0, nbatch * 32);
+        return BPGPU_OK;
+    }
+    ipp_shape sh;
+    sh.n = (uint32_t)n;
+    sh.k = (uint32_t)k;
+    sh.proof_len = (uint32_t)proof_len;
+    sh.nproofs = (uint32_t)nbatch;
+    if (n == ((size_t)1 << k) && k > BP_RP_MAX_K) return fail(c, BPGPU_ERR_INVALID_ARG, "n > 2^%d not supported", BP_RP_MAX_K);
+    sh.shape_verdict = (n == ((size_t)1 << k)) ? 0 : BPGPU_VERDICT_VERIFICATION_ERROR;   // ipp.rs:203-211
+    const size_t n_eff = sh.shape_verdict ? 0 : n;
+    sh.N = (uint32_t)(2 * n_eff + 2 * (sh.shape_verdict ? 0 : k) + 2);
+    if (sh.shape_verdict) {
+        sh.n = 0;   // only the canonical-scalar check runs
+    }
+    const size_t N = sh.N;
+    // staging (host pointers in; everything else lives in one allocation)
+    const size_t sz_pr = align_up(nbatch * proof_len + 64), sz_f = align_up(nbatch * n * 32 + 64), sz_pq = align_up(nbatch * 32 + 64);
+    const size_t sz_terms = align_up(nbatch * N * 32 + 64), sz_st = align_up(nbatch * 4), sz_b = align_up(nbatch + 64), sz_o = align_up(nbatch * 32 + 64);
+    char *d = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, sz_pr + 4 * sz_f + 2 * sz_pq + 2 * sz_terms + sz_st + 2 * sz_b + sz_o));
+    char *d_pr = d, *d_gf = d_pr + sz_pr, *d_hf = d_gf + sz_f, *d_g = d_hf + sz_f, *d_h = d_g + sz_f, *d_p = d_h + sz_f, *d_q = d_p + sz_pq;
+    char *d_sc = d_q + sz_pq, *d_pt = d_sc + sz_terms, *d_stat = d_pt + sz_terms, *d_mst = d_stat + sz_st, *d_ver = d_mst + sz_b, *d_out = d_ver + sz_b;
+    hipStream_t s = c->stream;
+    int rc = BPGPU_OK;
+    do {
+        bool ok = hipMemcpyAsync(d_pr, proofs, nbatch * proof_len, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(d_p, P, nbatch * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
+                  hipMemcpyAsync(d_q, Q, nbatch * 32, hipMemcpyHostToDevice, s) == hipSuccess;
+        if (n) {
+            ok = ok && hipMemcpyAsync(d_gf, G_factors, nbatch * n * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(d_hf, H_factors, nbatch * n * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(d_g, G, nbatch * n * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
+                 hipMemcpyAsync(d_h, H, nbatch * n * 32, hipMemcpyHostToDevice, s) == hipSuccess;
+        }
+        ok = ok && hipMemsetAsync(d_sc, 0, 2 * sz_terms + sz_st, s) == hipSuccess;   // scalars, points, status
+        if (!ok) {
+            rc = fail(c, BPGPU_ERR_HIP, "H2D copy failed");
+            break;
+        }
+        rp_strobe_init init;
+        {   // Transcript::new(label) + innerproduct_domain_sep(n) (transcript.rs:50-53), once for the batch
+            kstate st;
+            st.w = init.w;
+            st.stride = 1;
+            strobe t;
+            merlin_strobe_init(t, st);
+            const uint8_t dom[7] = {'d', 'o', 'm', '-', 's', 'e', 'p'}, ipp[6] = {'i', 'p', 'p', ' ', 'v', '1'}, ln[1] = {'n'};
+            merlin_append_message(t, dom, 7, label, (uint32_t)label_len);
+            merlin_append_message(t, dom, 7, ipp, 6);
+            merlin_append_u64(t, ln, 1, n);
+            init.pos = t.pos;
+            init.pos_begin = t.pos_begin;
+            init.cur_flags = t.cur_flags;
+        }
+        const uint32_t nb32 = (uint32_t)nbatch;
+        LAUNCH(c, s, "ipp_prepare", k_ipp_prepare, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, init, (const uint8_t *)d_pr, (const uint8_t *)d_gf,
+               (const uint8_t *)d_hf, (const uint8_t *)d_p, (const uint8_t *)d_q, (const uint8_t *)d_g, (const uint8_t *)d_h, (uint32_t *)d_sc,
+               (uint32_t *)d_pt, (uint32_t *)d_stat);
+        std::vector<uint32_t> nt(nbatch, (uint32_t)N);
+        rc = msm_batch_dev_locked(c, nbatch, nt.data(), d_sc, d_pt, d_out, d_mst, s);
+        if (rc) break;
+        LAUNCH(c, s, "ipp_verdict", k_ipp_verdict, (nb32 + 63) / 64, 64, nb32, (const uint32_t *)d_stat, (const uint8_t *)d_mst, (const uint32_t *)d_out,
+               (uint8_t *)d_ver);
+        if (hipMemcpyAsync(verdict, d_ver, nbatch, hipMemcpyDeviceToHost, s) != hipSuccess ||
+            (msm_out && hipMemcpyAsync(msm_out, d_out, nbatch * 32, hipMemcpyDeviceToHost, s) != hipSuccess) ||
+            hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(c, BPGPU_ERR_HIP, "D2H copy / sync failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+    } while (0);
+    hipStreamSynchronize(s);
+    hipFree(d);
     return rc;
 }

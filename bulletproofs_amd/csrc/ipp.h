@@ -1,0 +1,144 @@
+// Stand-alone inner-product-proof verification front end (device):
+// InnerProductProof::from_bytes (src/inner_product_proof.rs:373-407) + verify (ipp.rs:260-326) up to the
+// multiscalar multiplication.  Lane = proof: replay the transcript (L_i, R_i -> u_i), batch-invert the
+// challenges, and emit the 2n + 2k + 2 (scalar, point) terms of
+//     a*b * Q + sum_i (a s_i g_i) G_i + sum_i (b s_i^-1 h_i) H_i - sum_j u_j^2 L_j - sum_j u_j^-2 R_j - P
+// whose sum is the identity iff expect_P == P (ipp.rs:308-325).  The MSM itself is bpgpu_msm_batch's.
+#ifndef BPGPU_IPP_H
+#define BPGPU_IPP_H
+#include "rangeproof.h"
+
+namespace bp {
+
+struct ipp_shape {
+    uint32_t n, k;              // k = lg(n) as implied by the proof length
+    uint32_t N;                 // terms: 2n + 2k + 2
+    uint32_t proof_len, nproofs;
+    uint32_t shape_verdict;     // != 0: n != 2^k (VerificationError, ipp.rs:203-211): only parse
+};
+
+// thread p.  Outputs are pre-zeroed by the host, so rejected proofs contribute identity terms.
+BP_HD void ipp_prepare_thread(uint32_t p, ipp_shape sh, const rp_strobe_init &init, kstate st, const uint8_t *proofs,
+                              const uint8_t *Gf, const uint8_t *Hf, const uint8_t *P, const uint8_t *Q, const uint8_t *G,
+                              const uint8_t *H, uint32_t *scalars, uint32_t *points, uint32_t *status) {
+    const uint32_t n = sh.n, k = sh.k;
+    const uint8_t *pr = proofs + (uint64_t)p * sh.proof_len;
+    sc a, b;
+    load_words8(a.v, pr + 64 * k);
+    load_words8(b.v, pr + 64 * k + 32);
+    if (!sc_is_canonical_sc(a) || !sc_is_canonical_sc(b)) {
+        status[p] = BP_VERDICT_FORMAT;
+        return;
+    }
+    if (sh.shape_verdict) {
+        status[p] = sh.shape_verdict;
+        return;
+    }
+    strobe t;
+    t.st = st;
+    for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, init.w[i]);
+    t.pos = init.pos;
+    t.pos_begin = init.pos_begin;
+    t.cur_flags = init.cur_flags;
+    uint32_t *sc_out = scalars + (uint64_t)p * sh.N * 8, *pt_out = points + (uint64_t)p * sh.N * 8;
+    const uint8_t lL[1] = {'L'}, lR[1] = {'R'}, lu[1] = {'u'};
+    sc28 um[BP_RP_MAX_K], uim[BP_RP_MAX_K], acc, inv;
+    sc28_one_mont(acc);
+    uint32_t w[8];
+    bool verr = false;
+    for (uint32_t i = 0; i < k; i++) {
+        load_words8(w, pr + 64 * i);
+        verr = verr || words8_zero(w);
+        merlin_append_words8(t, lL, 1, w);
+        for (int q = 0; q < 8; q++) pt_out[(1 + 2 * n + i) * 8 + q] = w[q];
+        load_words8(w, pr + 64 * i + 32);
+        verr = verr || words8_zero(w);
+        merlin_append_words8(t, lR, 1, w);
+        for (int q = 0; q < 8; q++) pt_out[(1 + 2 * n + k + i) * 8 + q] = w[q];
+        sc u;
+        rp_challenge_scalar(t, lu, 1, u);
+        sc_to_mont28(um[i], u);
+        uim[i] = acc;                                   // prefix product before u_i
+        sc28_montmul(acc, acc, um[i]);
+    }
+    if (verr) {
+        status_raise(status + p, BP_VERDICT_VERIFICATION);
+        return;
+    }
+    sc28_invert_mont(inv, acc);
+    for (uint32_t ii = k; ii-- > 0;) {
+        sc28 ui;
+        sc28_montmul(ui, inv, uim[ii]);
+        sc28_montmul(inv, inv, um[ii]);
+        uim[ii] = ui;
+        sc28 sq;
+        sc t0;
+        sc28_montsq(sq, um[ii]);
+        sc_from_mont28(t0, sq);
+        sc_neg(t0, t0);                                 // -u_i^2 on L_i
+        store_words8(sc_out + (1 + 2 * n + ii) * 8, t0);
+        sc28_montsq(sq, ui);
+        sc_from_mont28(t0, sq);
+        sc_neg(t0, t0);                                 // -u_i^-2 on R_i
+        store_words8(sc_out + (1 + 2 * n + k + ii) * 8, t0);
+    }
+    sc28 am, bm, abm;
+    sc t0;
+    sc_to_mont28(am, a);
+    sc_to_mont28(bm, b);
+    sc28_montmul(abm, am, bm);
+    sc_from_mont28(t0, abm);                            // a*b on Q
+    store_words8(sc_out, t0);
+    load_words8(w, Q + (uint64_t)p * 32);
+    for (int q = 0; q < 8; q++) pt_out[q] = w[q];
+    for (uint32_t i = 0; i < n; i++) {
+        // s_i = prod_b (bit_b(i) ? u : u^-1)[k-1-b]; its inverse has the factors swapped (ipp.rs:241-250, 283)
+        sc28 s, sinv;
+        sc28_one_mont(s);
+        sinv = s;
+        for (uint32_t bb = 0; bb < k; bb++) {
+            const bool bit = (i >> bb) & 1;
+            sc28_montmul(s, s, bit ? um[k - 1 - bb] : uim[k - 1 - bb]);
+            sc28_montmul(sinv, sinv, bit ? uim[k - 1 - bb] : um[k - 1 - bb]);
+        }
+        sc f;
+        sc28 fm, r;
+        load_words8(f.v, Gf + ((uint64_t)p * n + i) * 32);
+        sc_to_mont28(fm, f);
+        sc28_montmul(r, am, s);
+        sc28_montmul(r, r, fm);
+        sc_from_mont28(t0, r);                          // (a s_i) g_i on G_i
+        store_words8(sc_out + (1 + i) * 8, t0);
+        load_words8(f.v, Hf + ((uint64_t)p * n + i) * 32);
+        sc_to_mont28(fm, f);
+        sc28_montmul(r, bm, sinv);
+        sc28_montmul(r, r, fm);
+        sc_from_mont28(t0, r);                          // (b / s_i) h_i on H_i
+        store_words8(sc_out + (1 + n + i) * 8, t0);
+        load_words8(w, G + ((uint64_t)p * n + i) * 32);
+        for (int q = 0; q < 8; q++) pt_out[(1 + i) * 8 + q] = w[q];
+        load_words8(w, H + ((uint64_t)p * n + i) * 32);
+        for (int q = 0; q < 8; q++) pt_out[(1 + n + i) * 8 + q] = w[q];
+    }
+    // - P
+    {
+        sc one, m1;
+        sc_from_u32(one, 1);
+        sc_neg(m1, one);
+        store_words8(sc_out + (1 + 2 * n + 2 * k) * 8, m1);
+        load_words8(w, P + (uint64_t)p * 32);
+        for (int q = 0; q < 8; q++) pt_out[(1 + 2 * n + 2 * k) * 8 + q] = w[q];
+    }
+}
+
+// thread p: verdict = front-end status if set, else VerificationError when a point failed to decode or the
+// difference expect_P - P is not the identity
+BP_HD void ipp_verdict_thread(uint32_t p, const uint32_t *status, const uint8_t *msm_status, const uint32_t *msm_out, uint8_t *verdict) {
+    uint32_t nz = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) nz |= msm_out[8 * (uint64_t)p + i];
+    verdict[p] = status[p] ? (uint8_t)status[p] : ((msm_status[p] != 0 || nz != 0) ? BP_VERDICT_VERIFICATION : BP_VERDICT_OK);
+}
+
+}  // namespace bp
+#endif

@@ -139,6 +139,20 @@ int bpgpu_rangeproof_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t m, size_t
                                       const uint8_t *label, size_t label_len, const void *d_rng64,
                                       void *d_verdict, void *d_msm_out, void *stream);
 
+/* ---- stand-alone inner-product proofs -------------------------------------------
+ * nbatch independent calls of
+ *   InnerProductProof::from_bytes(proof)?.verify(n, &mut Transcript::new(label), G_factors, H_factors, &P, &Q, &G, &H)
+ * (src/inner_product_proof.rs:260-326, 373-407), all of one size n.
+ *   proofs     : nbatch x proof_len bytes, proof_len = 32*(2*lg(n) + 2) for valid input
+ *   G_factors, H_factors : nbatch x n x 32 bytes (the iterators of verify())
+ *   P, Q       : nbatch x 32 bytes; G, H : nbatch x n x 32 bytes (compressed points)
+ *   verdict    : nbatch bytes, BPGPU_VERDICT_* (an undecodable point counts as VerificationError)
+ *   msm_out    : optional nbatch x 32 bytes, compress(expect_P - P) for parity tests */
+int bpgpu_ipp_verify_batch(bpgpu_ctx *ctx, size_t n, size_t nbatch, const uint8_t *proofs, size_t proof_len,
+                           const uint8_t *label, size_t label_len, const uint8_t *G_factors, const uint8_t *H_factors,
+                           const uint8_t *P, const uint8_t *Q, const uint8_t *G, const uint8_t *H,
+                           uint8_t *verdict, uint8_t *msm_out);
+
 /* ---- instrumentation -----------------------------------------------------------
  * When enabled, every kernel launch is bracketed by HIP events on its stream;
  * bpgpu_profile_report writes one line per kernel: "name launches total_ms". */

@@ -77,6 +77,19 @@ int oracle_prove(const oracle_gens *g, const uint64_t *values, const uint8_t *bl
                  const uint8_t *label, size_t label_len, const uint8_t *seed, size_t seed_len,
                  uint8_t *proof_out, uint8_t *commitments_out);
 
+/* Stand-alone inner-product proof (src/inner_product_proof.rs).
+ * oracle_ipp_verify = InnerProductProof::from_bytes(proof)?.verify(n, &mut Transcript::new(label), G_factors,
+ * H_factors, &P, &Q, &G, &H) (ipp.rs:260-326, 373-407); points compressed, scalars 32-byte canonical;
+ * msm_out (optional) = compress(expect_P - P).  Returns ORACLE_OK / ORACLE_ERR_*.
+ * oracle_ipp_test_instance = the reference's own test_helper_create(n) (ipp.rs:433-497) with a SHAKE256(seed)
+ * rng: fills proof (32*(2 lg n + 2) bytes), P, Q, G[n], H[n], G_factors[n] (= 1), H_factors[n] (= y^-i). */
+int oracle_ipp_verify(size_t n, const uint8_t *proof, size_t proof_len, const uint8_t *label, size_t label_len,
+                      const uint8_t *G_factors, const uint8_t *H_factors, const uint8_t P[32], const uint8_t Q[32],
+                      const uint8_t *G, const uint8_t *H, uint8_t msm_out[32]);
+int oracle_ipp_test_instance(size_t n, const uint8_t *label, size_t label_len, const uint8_t *seed, size_t seed_len,
+                             uint8_t *proof_out, uint8_t P_out[32], uint8_t Q_out[32], uint8_t *G_out, uint8_t *H_out,
+                             uint8_t *Gf_out, uint8_t *Hf_out);
+
 /* Batch drivers (independent proofs, equal shape), `threads` worker threads.
  * verdicts[i] = error code.  Returns wall seconds. */
 double oracle_verify_batch(const oracle_gens *g, size_t nbatch, const uint8_t *proofs, size_t proof_len,

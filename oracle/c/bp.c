@@ -506,6 +506,97 @@ int oracle_prove(const oracle_gens *g, const uint64_t *values, const uint8_t *bl
     return 0;
 }
 
+/* ---------------- stand-alone inner-product proof (ipp.rs:260-326, 373-407, 433-497) ---------------- */
+int oracle_ipp_verify(size_t n, const uint8_t *proof, size_t proof_len, const uint8_t *label, size_t label_len,
+                      const uint8_t *G_factors, const uint8_t *H_factors, const uint8_t P[32], const uint8_t Q[32],
+                      const uint8_t *G, const uint8_t *H, uint8_t msm_out[32]) {
+    ge_init();
+    /* InnerProductProof::from_bytes */
+    if (proof_len % 32 != 0) return ORACLE_ERR_FORMAT;
+    size_t ne = proof_len / 32;
+    if (ne < 2 || (ne - 2) % 2 != 0) return ORACLE_ERR_FORMAT;
+    size_t lg_n = (ne - 2) / 2;
+    if (lg_n >= 32) return ORACLE_ERR_FORMAT;
+    sc a, b;
+    if (sc_from_canonical_bytes(&a, proof + 64 * lg_n)) return ORACLE_ERR_FORMAT;
+    if (sc_from_canonical_bytes(&b, proof + 64 * lg_n + 32)) return ORACLE_ERR_FORMAT;
+    /* verification_scalars */
+    if (n != ((size_t)1 << lg_n)) return ORACLE_ERR_VERIFICATION;
+    merlin_transcript t; merlin_init(&t, label, label_len);
+    merlin_append_message(&t, "dom-sep", (const uint8_t *)"ipp v1", 6);
+    merlin_append_u64(&t, "n", n);
+    sc u_sq[32], u_inv_sq[32], allinv; sc_from_u64(&allinv, 1);
+    for (size_t i = 0; i < lg_n; i++) {
+        if (validate_and_append_point(&t, "L", proof + 64 * i)) return ORACLE_ERR_VERIFICATION;
+        if (validate_and_append_point(&t, "R", proof + 64 * i + 32)) return ORACLE_ERR_VERIFICATION;
+        sc u, ui; challenge_scalar(&t, "u", &u); sc_invert(&ui, &u);
+        sc_mul(&allinv, &allinv, &ui); sc_mul(&u_sq[i], &u, &u); sc_mul(&u_inv_sq[i], &ui, &ui);
+    }
+    sc *s = malloc((n + 1) * sizeof(sc));
+    s[0] = allinv;
+    for (size_t i = 1; i < n; i++) {
+        size_t lg_i = 63 - (size_t)__builtin_clzll((unsigned long long)i);
+        sc_mul(&s[i], &s[i - ((size_t)1 << lg_i)], &u_sq[(lg_n - 1) - lg_i]);
+    }
+    size_t N = 2 * n + 2 * lg_n + 2;
+    sc *scal = malloc(N * sizeof(sc)); ge_p3 *pts = malloc(N * sizeof(ge_p3));
+    int bad = 0; size_t o = 0;
+    sc_mul(&scal[o], &a, &b); if (ristretto_decompress(&pts[o], Q)) bad = 1; o++;
+    for (size_t i = 0; i < n; i++) {
+        sc gf, t0; sc_from_bytes_mod_order(&gf, G_factors + 32 * i);
+        sc_mul(&t0, &a, &s[i]); sc_mul(&scal[o], &t0, &gf);
+        if (ristretto_decompress(&pts[o], G + 32 * i)) bad = 1; o++;
+    }
+    for (size_t i = 0; i < n; i++) {
+        sc hf, t0; sc_from_bytes_mod_order(&hf, H_factors + 32 * i);
+        sc_mul(&t0, &b, &s[n - 1 - i]); sc_mul(&scal[o], &t0, &hf);
+        if (ristretto_decompress(&pts[o], H + 32 * i)) bad = 1; o++;
+    }
+    for (size_t i = 0; i < lg_n; i++) { sc_neg(&scal[o], &u_sq[i]); if (ristretto_decompress(&pts[o], proof + 64 * i)) bad = 1; o++; }
+    for (size_t i = 0; i < lg_n; i++) { sc_neg(&scal[o], &u_inv_sq[i]); if (ristretto_decompress(&pts[o], proof + 64 * i + 32)) bad = 1; o++; }
+    { sc one; sc_from_u64(&one, 1); sc_neg(&scal[o], &one); if (ristretto_decompress(&pts[o], P)) bad = 1; o++; }   /* expect_P - P */
+    int rc;
+    if (bad) { rc = ORACLE_ERR_VERIFICATION; if (msm_out) memset(msm_out, 0xff, 32); }
+    else {
+        ge_p3 r; msm_dispatch(&r, N, scal, pts, 0);
+        if (msm_out) ristretto_compress(msm_out, &r);
+        rc = ge_is_identity(&r) ? ORACLE_OK : ORACLE_ERR_VERIFICATION;   /* expect_P == *P  (ristretto equality) */
+    }
+    free(s); free(scal); free(pts);
+    return rc;
+}
+
+int oracle_ipp_test_instance(size_t n, const uint8_t *label, size_t label_len, const uint8_t *seed, size_t seed_len,
+                             uint8_t *proof_out, uint8_t P_out[32], uint8_t Q_out[32], uint8_t *G_out, uint8_t *H_out,
+                             uint8_t *Gf_out, uint8_t *Hf_out) {
+    if (n == 0 || (n & (n - 1))) return 5;
+    oracle_gens *g = oracle_gens_new(n, 1);
+    keccak_sponge rng; shake256_init(&rng); sponge_absorb(&rng, seed, seed_len);
+    ge_p3 Q; { uint8_t h[64]; sha3_512(h, (const uint8_t *)"test point", 10); ristretto_from_uniform_bytes(&Q, h); }
+    sc *a = malloc(n * sizeof(sc)), *b = malloc(n * sizeof(sc)), *Hf = malloc(n * sizeof(sc));
+    sc *sv = malloc((2 * n + 1) * sizeof(sc)); ge_p3 *pv = malloc((2 * n + 1) * sizeof(ge_p3));
+    for (size_t i = 0; i < n; i++) rng_scalar(&rng, &a[i]);
+    for (size_t i = 0; i < n; i++) rng_scalar(&rng, &b[i]);
+    sc c; inner_product(&c, a, b, n);
+    sc y_inv, one; rng_scalar(&rng, &y_inv); sc_from_u64(&one, 1);
+    Hf[0] = one; for (size_t i = 1; i < n; i++) sc_mul(&Hf[i], &Hf[i - 1], &y_inv);
+    for (size_t i = 0; i < n; i++) { sv[i] = a[i]; pv[i] = g->G[i]; sc_mul(&sv[n + i], &b[i], &Hf[i]); pv[n + i] = g->H[i]; }
+    sv[2 * n] = c; pv[2 * n] = Q;
+    ge_p3 P; ge_msm_vartime(&P, 2 * n + 1, sv, pv);
+    ristretto_compress(P_out, &P); ristretto_compress(Q_out, &Q);
+    memcpy(G_out, g->Gc, 32 * n); memcpy(H_out, g->Hc, 32 * n);
+    for (size_t i = 0; i < n; i++) { sc_tobytes(Gf_out + 32 * i, &one); sc_tobytes(Hf_out + 32 * i, &Hf[i]); }
+    ge_p3 *Gv = malloc(n * sizeof(ge_p3)), *Hv = malloc(n * sizeof(ge_p3));
+    memcpy(Gv, g->G, n * sizeof(ge_p3)); memcpy(Hv, g->H, n * sizeof(ge_p3));
+    size_t lg_n = 0; while (((size_t)1 << lg_n) < n) lg_n++;
+    merlin_transcript t; merlin_init(&t, label, label_len);
+    sc a_fin, b_fin;
+    ipp_create(&t, &Q, Hf, Gv, Hv, a, b, n, proof_out, &a_fin, &b_fin);
+    sc_tobytes(proof_out + 64 * lg_n, &a_fin); sc_tobytes(proof_out + 64 * lg_n + 32, &b_fin);
+    free(a); free(b); free(Hf); free(sv); free(pv); free(Gv); free(Hv); oracle_gens_free(g);
+    return 0;
+}
+
 /* ---------------- threaded batch drivers ---------------- */
 typedef struct {
     int kind, tid, threads;

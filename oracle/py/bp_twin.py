@@ -759,3 +759,26 @@ def prove_multiple(bp_gens, pc_gens, transcript, values, blindings, n, rng):
     pr.t_x, pr.t_x_blinding, pr.e_blinding = t_x, t_x_blinding, e_blinding
     pr.L_vec, pr.R_vec, pr.a, pr.b = Lv, Rv, a, b
     return pr, Vs
+
+
+def ipp_verify(proof_bytes, n, transcript, G_factors, H_factors, P, Q, G, H):
+    """InnerProductProof::from_bytes + verify (src/inner_product_proof.rs:260-326, 373-407).
+    Points are extended tuples.  Returns compress(expect_P - P) (all-zero == Ok)."""
+    b = proof_bytes
+    if len(b) % 32 != 0 or len(b) // 32 < 2 or (len(b) // 32 - 2) % 2:
+        raise FormatError()
+    lg_n = (len(b) // 32 - 2) // 2
+    if lg_n >= 32:
+        raise FormatError()
+    pr = RangeProof()
+    pr.L_vec = [b[64 * i:64 * i + 32] for i in range(lg_n)]
+    pr.R_vec = [b[64 * i + 32:64 * i + 64] for i in range(lg_n)]
+    pr.a = _canonical_scalar(b[64 * lg_n:64 * lg_n + 32])
+    pr.b = _canonical_scalar(b[64 * lg_n + 32:64 * lg_n + 64])
+    u_sq, u_inv_sq, s = verification_scalars(pr, n, transcript)
+    scalars = [pr.a * pr.b % L] + [pr.a * s[i] % L * G_factors[i] % L for i in range(n)] + \
+              [pr.b * s[n - 1 - i] % L * H_factors[i] % L for i in range(n)] + [(-u) % L for u in u_sq] + [(-u) % L for u in u_inv_sq] + [L - 1]
+    Ls, Rs = [decompress(x) for x in pr.L_vec], [decompress(x) for x in pr.R_vec]
+    if any(p is None for p in Ls + Rs):
+        raise VerificationError()
+    return compress(msm(scalars, [Q] + list(G) + list(H) + Ls + Rs + [P]))

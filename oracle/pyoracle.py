@@ -55,6 +55,8 @@ def lib():
     L.oracle_verify_batch.argtypes = [vp, sz, u8p, sz, u8p, sz, sz, u8p, sz, u8p, u8p, u8p, C.c_int]
     L.oracle_prove_batch.restype = C.c_double
     L.oracle_prove_batch.argtypes = [vp, sz, C.POINTER(C.c_uint64), u8p, sz, sz, u8p, sz, u8p, sz, u8p, u8p, C.c_int]
+    L.oracle_ipp_verify.argtypes = [sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
+    L.oracle_ipp_test_instance.argtypes = [sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.oracle_msm_batch.restype = C.c_double
     L.oracle_msm_batch.argtypes = [sz, sz, u8p, u8p, C.c_int, u8p, u8p, C.c_int]
     _lib = L
@@ -157,3 +159,21 @@ def msm_batch(nbatch, n, scalars, points, algo=0, threads=1):
     status = C.create_string_buffer(nbatch)
     secs = lib().oracle_msm_batch(nbatch, n, scalars, points, algo, outs, status, threads)
     return secs, outs.raw, status.raw
+
+
+def ipp_test_instance(n, label, seed):
+    """The reference's test_helper_create(n) (inner_product_proof.rs:433-497): returns a dict of byte strings."""
+    lg = n.bit_length() - 1
+    bufs = dict(proof=C.create_string_buffer(32 * (2 * lg + 2)), P=C.create_string_buffer(32), Q=C.create_string_buffer(32),
+                G=C.create_string_buffer(32 * n), H=C.create_string_buffer(32 * n), Gf=C.create_string_buffer(32 * n),
+                Hf=C.create_string_buffer(32 * n))
+    rc = lib().oracle_ipp_test_instance(n, label, len(label), seed, len(seed), bufs["proof"], bufs["P"], bufs["Q"], bufs["G"],
+                                        bufs["H"], bufs["Gf"], bufs["Hf"])
+    assert rc == 0
+    return {k: v.raw for k, v in bufs.items()}
+
+
+def ipp_verify(n, proof, label, Gf, Hf, P, Q, G, H):
+    out = C.create_string_buffer(32)
+    rc = lib().oracle_ipp_verify(n, proof, len(proof), label, len(label), Gf, Hf, P, Q, G, H, out)
+    return rc, out.raw

@@ -8,6 +8,7 @@
 #include "../../bulletproofs_amd/csrc/msm_fixed.h"
 #include "../../bulletproofs_amd/csrc/rangeproof.h"
 #include "../../bulletproofs_amd/csrc/horner_wave.h"
+#include "../../bulletproofs_amd/csrc/ipp.h"
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -271,6 +272,36 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
     for (uint32_t p = 0; p < nbatch; p++) shared_finish_thread(p, nbatch, nsplit, nullptr, true, hq.data(), partial.data(), status.data(), outw.data(), verdict.data());
     for (uint32_t p = 0; p < nbatch; p++) verdict_out[p] = verdict[p];
     if (msm_out) memcpy(msm_out, outw.data(), (size_t)nbatch * 32);
+    return 0;
+}
+void h_msm_vb(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status_out);
+
+// Stand-alone IPP verification, lane by lane: ipp_prepare -> variable-base MSM pipeline -> verdict
+int h_ipp_verify(uint32_t n, uint32_t nbatch, const uint8_t *proofs, uint32_t proof_len, const uint8_t *label, uint32_t label_len,
+                 const uint8_t *Gf, const uint8_t *Hf, const uint8_t *P, const uint8_t *Q, const uint8_t *G, const uint8_t *H,
+                 uint8_t *verdict_out, uint8_t *msm_out) {
+    if (proof_len % 32 || proof_len / 32 < 2 || (proof_len / 32 - 2) % 2) return -1;
+    uint32_t k = (proof_len / 32 - 2) / 2;
+    ipp_shape sh; sh.n = n; sh.k = k; sh.proof_len = proof_len; sh.nproofs = nbatch;
+    sh.shape_verdict = (n == (1u << k)) ? 0 : BP_VERDICT_VERIFICATION;
+    if (sh.shape_verdict) sh.n = 0;
+    sh.N = 2 * sh.n + 2 * (sh.shape_verdict ? 0 : k) + 2;
+    rp_strobe_init init;
+    {
+        kstate st; st.w = init.w; st.stride = 1; strobe t; merlin_strobe_init(t, st);
+        const uint8_t dom[7] = {'d','o','m','-','s','e','p'}, ipp[6] = {'i','p','p',' ','v','1'}, ln[1] = {'n'};
+        merlin_append_message(t, dom, 7, label, label_len); merlin_append_message(t, dom, 7, ipp, 6); merlin_append_u64(t, ln, 1, n);
+        init.pos = t.pos; init.pos_begin = t.pos_begin; init.cur_flags = t.cur_flags;
+    }
+    std::vector<uint32_t> scal((size_t)nbatch * sh.N * 8 + 8, 0), pts((size_t)nbatch * sh.N * 8 + 8, 0), status(nbatch + 1, 0), nt(nbatch, sh.N);
+    for (uint32_t p = 0; p < nbatch; p++) {
+        uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;
+        ipp_prepare_thread(p, sh, init, st, proofs, Gf, Hf, P, Q, G, H, scal.data(), pts.data(), status.data());
+    }
+    std::vector<uint8_t> out((size_t)nbatch * 32 + 32), mst(nbatch + 1);
+    h_msm_vb(nbatch, nt.data(), (const uint8_t *)scal.data(), (const uint8_t *)pts.data(), out.data(), mst.data());
+    for (uint32_t p = 0; p < nbatch; p++) ipp_verdict_thread(p, status.data(), mst.data(), (const uint32_t *)out.data(), verdict_out);
+    if (msm_out) memcpy(msm_out, out.data(), (size_t)nbatch * 32);
     return 0;
 }
 }

@@ -211,3 +211,22 @@ def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, gol
     assert H.h_rp_verify(4, 2, 8, 1, Bb2 + B2 + G2 + H2, 8, 1, 4, bytes(nc) + bytes(ia) + bytes(us) + pr, len(pr), vc[:32] * 4, label,
                          len(label), rng, vd, mo) == 0
     assert list(vd.raw) == [2, 1, 1, 0]
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 32])
+def test_standalone_ipp_front_end_lane_by_lane(H, oracle, n):
+    """ipp_prepare (transcript, batch inversion, s_i products) + the variable-base pipeline against the oracle's
+    restatement of InnerProductProof::verify (ipp.rs:260-326) on the reference's own test shape."""
+    insts = [oracle.ipp_test_instance(n, b"innerproducttest", b"hipp-%d-%d" % (n, j)) for j in range(3)]
+    pl = len(insts[0]["proof"])
+    bad = bytearray(insts[1]["proof"])
+    bad[-40] ^= 1                                   # a tampered: still canonical with overwhelming probability
+    insts[1] = dict(insts[1], proof=bytes(bad))
+    insts[2] = dict(insts[2], P=insts[2]["Q"])      # wrong P
+    cat = lambda key: b"".join(i[key] for i in insts)
+    vd, mo = C.create_string_buffer(3), C.create_string_buffer(96)
+    assert H.h_ipp_verify(n, 3, cat("proof"), pl, b"innerproducttest", 16, cat("Gf"), cat("Hf"), cat("P"), cat("Q"), cat("G"), cat("H"), vd, mo) == 0
+    for j, inst in enumerate(insts):
+        rc, em = oracle.ipp_verify(n, inst["proof"], b"innerproducttest", inst["Gf"], inst["Hf"], inst["P"], inst["Q"], inst["G"], inst["H"])
+        assert vd.raw[j] == rc and mo.raw[32 * j:32 * j + 32] == em, (n, j)
+    assert list(vd.raw) == [0, 1, 1]

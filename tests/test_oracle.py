@@ -176,3 +176,24 @@ def test_msm_algorithms_agree_and_match_twin(oracle):
     assert oracle.msm(scs[:64], bytes(bad), 0)[0] == 1
     # empty MSM = identity
     assert oracle.msm(b"", b"", 0) == (0, bytes(32))
+
+
+@pytest.mark.parametrize("n", [1, 2, 4, 32])
+def test_standalone_ipp_reference_test_shape(oracle, n):
+    """src/inner_product_proof.rs:433-534 (test_helper_create): create -> verify -> to_bytes/from_bytes -> verify,
+    C oracle vs Python twin on the same instance."""
+    inst = oracle.ipp_test_instance(n, b"innerproducttest", b"ipp-seed-%d" % n)
+    rc, out = oracle.ipp_verify(n, inst["proof"], b"innerproducttest", inst["Gf"], inst["Hf"], inst["P"], inst["Q"], inst["G"], inst["H"])
+    assert rc == 0 and out == bytes(32)
+    dec = lambda blob: [T.decompress(blob[32 * i:32 * i + 32]) for i in range(len(blob) // 32)]
+    sc = lambda blob: [int.from_bytes(blob[32 * i:32 * i + 32], "little") for i in range(len(blob) // 32)]
+    tw = T.ipp_verify(inst["proof"], n, T.Transcript(b"innerproducttest"), sc(inst["Gf"]), sc(inst["Hf"]),
+                      T.decompress(inst["P"]), T.decompress(inst["Q"]), dec(inst["G"]), dec(inst["H"]))
+    assert tw == bytes(32)
+    # wrong P: both restatements agree on the non-identity encoding
+    rc, out = oracle.ipp_verify(n, inst["proof"], b"innerproducttest", inst["Gf"], inst["Hf"], inst["Q"], inst["Q"], inst["G"], inst["H"])
+    tw = T.ipp_verify(inst["proof"], n, T.Transcript(b"innerproducttest"), sc(inst["Gf"]), sc(inst["Hf"]),
+                      T.decompress(inst["Q"]), T.decompress(inst["Q"]), dec(inst["G"]), dec(inst["H"]))
+    assert rc == 1 and out == tw != bytes(32)
+    assert oracle.ipp_verify(2 * n, inst["proof"], b"innerproducttest", inst["Gf"] * 2, inst["Hf"] * 2, inst["P"], inst["Q"], inst["G"] * 2, inst["H"] * 2)[0] == 1
+    assert oracle.ipp_verify(n, inst["proof"][:-1], b"x", inst["Gf"], inst["Hf"], inst["P"], inst["Q"], inst["G"], inst["H"])[0] == 2
