@@ -119,28 +119,72 @@ __global__ void __launch_bounds__(64) k_shared_finish(uint32_t nproofs, uint32_t
 
 
 // ---- range-proof front end ----------------------------------------------------
+// The device overlaps at most a handful of kernels, so a chain of narrow launches leaves most CUs idle.
+// Stages that do not depend on each other therefore share ONE launch: the leading blocks of the grid take
+// one role, the rest the other ("role-fused" launches; the long-running role gets the low block indices so
+// the dispatcher starts it first).
 #define RP_BLOCK 64
-__global__ void __launch_bounds__(RP_BLOCK) k_rp_transcript(rp_shape sh, rp_strobe_init init, const uint8_t *proofs,
-                                                             const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields,
-                                                             uint32_t *uniq_points, uint32_t *status) {
+// launch 1: [0, n_tr) Fiat-Shamir transcript replay, lane = proof  ||  [n_tr, ..) decode the proof's and the
+// commitments' points straight from the input bytes and build their 8-entry tables, lane = point
+__global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs,
+                                                         const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields,
+                                                         ge_cached *tab, uint32_t *status) {
     __shared__ uint32_t lds[50 * RP_BLOCK];   // sponge states, word-major: word w of lane t at w*RP_BLOCK + t
-    const uint32_t p = blockIdx.x * RP_BLOCK + threadIdx.x;
-    kstate st;
-    st.w = lds + threadIdx.x;
-    st.stride = RP_BLOCK;
-    if (p < sh.nproofs) rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields, uniq_points, status);
+    if (blockIdx.x < n_tr) {
+        const uint32_t p = blockIdx.x * RP_BLOCK + threadIdx.x;
+        kstate st;
+        st.w = lds + threadIdx.x;
+        st.stride = RP_BLOCK;
+        if (p < sh.nproofs) rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields, status);
+    } else {
+        const uint32_t t = (blockIdx.x - n_tr) * RP_BLOCK + threadIdx.x;
+        if (t < sh.nproofs * sh.U) rp_points_thread(t, sh, proofs, commitments, tab, status);
+    }
 }
 
-__global__ void __launch_bounds__(64) k_rp_expand_a(rp_shape sh, fb_params prm, uint32_t lg_m, uint32_t *fields, uint32_t *uniq_scalars,
+__global__ void __launch_bounds__(64) k_rp_expand_a(rp_shape sh, fb_params prm, uint32_t lg_m, uint32_t *fields, uint32_t *recoded,
                                                      uint16_t *digits, const uint32_t *status) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < sh.nproofs) rp_expand_a_thread(p, sh, prm, lg_m, fields, uniq_scalars, digits, status);
+    if (p < sh.nproofs) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status);
 }
 
-__global__ void __launch_bounds__(BP_BLOCK) k_rp_expand_b(uint32_t nthreads, rp_shape sh, fb_params prm, const uint32_t *fields,
-                                                           uint16_t *digits, const uint32_t *status) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < nthreads) rp_expand_b_thread(tid, sh, prm, fields, digits, status);
+// launch 3: [0, n_win) per-chunk window sums of the proof-specific points  ||  the 2nm generator exponents
+__global__ void __launch_bounds__(BP_BLOCK) k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab,
+                                                         const uint32_t *recoded, ge_ext *part, uint32_t nthreads_exp, rp_shape sh,
+                                                         fb_params prm, const uint32_t *fields, uint16_t *digits, const uint32_t *status) {
+    if (blockIdx.x < n_win) {
+        const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
+        if (tid < nthreads_win) vb_window_thread(tid, chunks, tab, recoded, part);
+    } else {
+        const uint32_t tid = (blockIdx.x - n_win) * BP_BLOCK + threadIdx.x;
+        if (tid < nthreads_exp) rp_expand_b_thread(tid, sh, prm, fields, digits, status);
+    }
+}
+
+// launch 4: [0, nproofs) one wavefront per proof: column sums + Horner chain of the proof-specific terms  ||
+// the fixed-base table walk (block -> (split, proof block) as in k_fb_accum)
+__global__ void __launch_bounds__(FB_BLOCK) k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge_ext *part, ge_ext *hq,
+                                                         fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit, uint32_t npairs,
+                                                         const uint32_t *gen_ids, const uint16_t *digits, const fb_entry *table,
+                                                         ge_ext *partial) {
+    if (blockIdx.x < n_hw) {
+        hw_colsum_horner_msm(blockIdx.x, chunk_first, part, hq + blockIdx.x);
+        return;
+    }
+    const uint32_t L = blockIdx.x - n_hw;
+    uint32_t split, pblk;
+    if ((nsplit & 7) == 0) {
+        const uint32_t r = L & 7, rest = L >> 3;
+        pblk = rest % nblk_p;
+        split = r + 8 * (rest / nblk_p);
+    } else {
+        pblk = L % nblk_p;
+        split = L / nblk_p;
+    }
+    const uint32_t p = pblk * FB_BLOCK + threadIdx.x;
+    const uint32_t per = (npairs + nsplit - 1) / nsplit;
+    const uint32_t q0 = split * per, q1 = (q0 + per < npairs) ? q0 + per : npairs;
+    if (p < nproofs) fb_accum_thread(p, split, q0 < npairs ? q0 : npairs, q1, prm, nproofs, gen_ids, digits, table, partial);
 }
 
 // verdict[p] = status (Format / shape / Verification) if set, else the identity test of the mega-check
@@ -1039,8 +1083,6 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const size_t off_digits = ap.add((size_t)npairs * nbatch * 2 + 16);
     const size_t off_partial = ap.add((size_t)2 * nsplit * nbatch * sizeof(ge_ext) + 16);
     const size_t off_fields = ap.add((size_t)fl.count * nbatch * BP_RP_REC * 4 + 16);
-    const size_t off_upts = ap.add((size_t)sh.U * nbatch * 32 + 16);
-    const size_t off_usc = ap.add((size_t)sh.U * nbatch * 32 + 16);
     const size_t off_mv = ap.add(nbatch);
     const size_t off_rng = ap.add(nbatch * 64);
     rc = arena_reserve(c, ap.total);
@@ -1049,7 +1091,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     uint32_t *d_status = (uint32_t *)(a + off_status);
     uint16_t *d_digits = (uint16_t *)(a + off_digits);
     ge_ext *d_partial = (ge_ext *)(a + off_partial);
-    uint32_t *d_fields = (uint32_t *)(a + off_fields), *d_upts = (uint32_t *)(a + off_upts), *d_usc = (uint32_t *)(a + off_usc);
+    uint32_t *d_fields = (uint32_t *)(a + off_fields);
     uint8_t *d_mv = (uint8_t *)(a + off_mv);
     const uint8_t *rng_ptr = (const uint8_t *)d_rng64;
     if (!rng_ptr) {   // thread_rng() stand-in: OS CSPRNG (verify_multiple, mod.rs:455-470)
@@ -1065,13 +1107,25 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         rng_ptr = (const uint8_t *)(a + off_rng);
     }
     HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
-    HIPCHK(c, hipMemsetAsync(d_upts, 0, (size_t)sh.U * nbatch * 32, s));   // rejected proofs contribute identity terms
-    HIPCHK(c, hipMemsetAsync(d_usc, 0, (size_t)sh.U * nbatch * 32, s));
     rp_strobe_init init;
     make_strobe_init(init, label, label_len, n, m);
     const uint32_t nb32 = (uint32_t)nbatch;
-    LAUNCH(c, s, "rp_transcript", k_rp_transcript, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, init, (const uint8_t *)d_proofs,
-           (const uint8_t *)d_commitments, rng_ptr, d_fields, d_upts, d_status);
+    // the proof-specific ("variable-base") terms: decomposition into chunks of 32 is cached per (batch, U)
+    vb_dev d{};
+    bpgpu_ctx::plan_dev *pd = nullptr;
+    if (!shape_verdict) {
+        rc = uniform_plan(c, nbatch, sh.U, &pd);
+        if (rc) return rc;
+        vb_bind(c, off, d);
+        const size_t o1 = align_up(pd->n_chunks * sizeof(vb_chunk) + 16);
+        d.chunks = (vb_chunk *)pd->mem;
+        d.chunk_first = (uint32_t *)(pd->mem + o1);
+        d.hq = (ge_ext *)(d.colq16 + (size_t)nbatch * 64 * 32);
+    }
+    const uint32_t n_tr = (nb32 + RP_BLOCK - 1) / RP_BLOCK;
+    const uint32_t n_pt = shape_verdict ? 0 : (nb32 * sh.U + RP_BLOCK - 1) / RP_BLOCK;
+    LAUNCH(c, s, "rp_stage1", k_rp_stage1, n_tr + n_pt, RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
+           (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status);
     if (shape_verdict) {
         HIPCHK(c, hipMemsetAsync(d_mv, 1, nbatch, s));
         LAUNCH(c, s, "rp_verdict", k_rp_verdict, (nb32 + 63) / 64, 64, nb32, d_status, d_mv, (uint8_t *)d_verdict);
@@ -1079,15 +1133,14 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         HIPCHK(c, hipGetLastError());
         return BPGPU_OK;
     }
-    LAUNCH(c, s, "rp_expand_a", k_rp_expand_a, (nb32 + 63) / 64, 64, sh, prm, lg_m, d_fields, d_usc, d_digits, d_status);
-    const uint32_t nexp = sh.nm * nb32;
-    LAUNCH(c, s, "rp_expand_b", k_rp_expand_b, (nexp + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
-    vb_dev d{};
-    rc = enqueue_vb_uniform(c, s, nbatch, sh.U, off, d_usc, d_upts, d_status, d);
-    if (rc) return rc;
+    LAUNCH(c, s, "rp_expand_a", k_rp_expand_a, (nb32 + 63) / 64, 64, sh, prm, lg_m, d_fields, d.recoded, d_digits, d_status);
+    const uint32_t nexp = sh.nm * nb32, nwin = (uint32_t)pd->n_chunks * 64;
+    const uint32_t n_win = (nwin + BP_BLOCK - 1) / BP_BLOCK, n_exp = (nexp + BP_BLOCK - 1) / BP_BLOCK;
+    LAUNCH(c, s, "rp_stage3", k_rp_stage3, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part, nexp, sh, prm, d_fields,
+           d_digits, d_status);
     const uint32_t nblk_p = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
-    LAUNCH(c, s, "fb_accum", k_fb_accum, nblk_p * nsplit, FB_BLOCK, prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, c->d_table,
-           d_partial);
+    LAUNCH(c, s, "rp_stage4", k_rp_stage4, nb32 + nblk_p * nsplit, FB_BLOCK, nb32, d.chunk_first, d.part, d.hq, prm, nb32, nblk_p, nsplit,
+           npairs, d_ids, d_digits, c->d_table, d_partial);
     ge_ext *d_red = nullptr;
     uint32_t nred = 0;
     enqueue_fb_reduce(c, s, nb32, nsplit, d_partial, &d_red, &nred);

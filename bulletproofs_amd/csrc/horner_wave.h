@@ -160,7 +160,8 @@ BP_HD void hw_limbs_to_fe(fe &out, const uint32_t l[16]) {
 // Driver for one MSM (= one wavefront on the device, one lockstep emulation on the host):
 // runs the chain and writes the result as an extended point (4 field elements, lazy limbs).
 #if defined(__HIPCC__) && !defined(__HIP_DEVICE_COMPILE__)
-__device__ void hw_horner_msm(const uint16_t *colq16, ge_ext *out);   // host pass of hipcc: declaration only
+__device__ void hw_horner_msm(const uint16_t *colq16, ge_ext *out);   // host pass of hipcc: declarations only
+__device__ void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out);
 #elif defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void hw_horner_msm(const uint16_t *colq16, ge_ext *out) {
     __shared__ __attribute__((aligned(16))) uint32_t hw_lds[128];
@@ -176,7 +177,32 @@ __device__ __forceinline__ void hw_horner_msm(const uint16_t *colq16, ge_ext *ou
         ((fe *)out)[lane >> 4] = r;
     }
 }
+// Fused variant: the wavefront first forms its MSM's 64 column sums itself (lane w = window w: add the
+// chunks' partial sums, re-encode as 16-bit limbs into LDS) and then runs the chain from LDS -- one launch
+// and no [msm][64][128 B] round trip through HBM.
+__device__ __forceinline__ void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out) {
+    __shared__ __attribute__((aligned(16))) uint32_t hw_lds2[128];
+    __shared__ __attribute__((aligned(16))) uint32_t hw_colq[64 * 32];
+    const uint32_t lane = wv_lane();
+    {
+        ge_ext acc;
+        vb_colsum_acc(acc, b, lane, chunk_first, part);
+        vb_encode_colq16(hw_colq + lane * 32, acc);
+    }
+    WV_LDS_ORDER();
+    wv_ctx cx;
+    cx.lds = hw_lds2;
+    const wu32 c = hw_horner(cx, (const uint16_t *)hw_colq);
+    uint32_t limbs[16];
+    wv_row_gather16(cx, c, limbs);
+    if ((lane & 15u) == 0) {
+        fe r;
+        hw_limbs_to_fe(r, limbs);
+        ((fe *)out)[lane >> 4] = r;
+    }
+}
 #else
+inline void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out);
 inline void hw_horner_msm(const uint16_t *colq16, ge_ext *out) {
     wv_ctx cx{0};
     const wu32 c = hw_horner(cx, colq16);
@@ -189,6 +215,15 @@ inline void hw_horner_msm(const uint16_t *colq16, ge_ext *out) {
         hw_limbs_to_fe(r, l);
         ((fe *)out)[row] = r;
     }
+}
+inline void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out) {
+    uint32_t colq[64 * 32];
+    for (uint32_t w = 0; w < 64; w++) {
+        ge_ext acc;
+        vb_colsum_acc(acc, b, w, chunk_first, part);
+        vb_encode_colq16(colq + w * 32, acc);
+    }
+    hw_horner_msm((const uint16_t *)colq, out);
 }
 #endif
 

@@ -76,6 +76,19 @@ BP_HD int sc_digit16(const uint32_t r[8], int w) {
 }
 
 // ---- stage 1 ---------------------------------------------------------------
+// multiples 1P .. 8P of a decoded point, projective Niels form
+BP_HD void vb_build_table(ge_cached *out /*[8]*/, const ge_ext &p) {
+    ge_cached c1, ck;
+    ge_to_cached(c1, p);
+    out[0] = c1;
+    ge_ext cur = p;
+    for (int k = 1; k < 8; k++) {
+        ge_add_cached(cur, cur, c1, false);
+        ge_to_cached(ck, cur);
+        out[k] = ck;
+    }
+}
+
 // thread t < n_terms_total
 BP_HD void vb_prepare_thread(uint32_t t, const vb_chunk *chunks, const uint32_t *term_chunk,
                              const uint32_t *scalars, const uint32_t *points,
@@ -95,17 +108,7 @@ BP_HD void vb_prepare_thread(uint32_t t, const vb_chunk *chunks, const uint32_t 
     sc_recode16(rw, sw);
 #pragma unroll
     for (int i = 0; i < 8; i++) recoded[8 * (uint64_t)t + i] = rw[i];
-    // multiples 1P .. 8P
-    ge_cached c1, ck;
-    ge_to_cached(c1, p);
-    ge_cached *out = tab + 8 * (uint64_t)t;
-    out[0] = c1;
-    ge_ext cur = p;
-    for (int k = 1; k < 8; k++) {
-        ge_add_cached(cur, cur, c1, false);
-        ge_to_cached(ck, cur);
-        out[k] = ck;
-    }
+    vb_build_table(tab + 8 * (uint64_t)t, p);
 }
 
 // ---- stage 2 ---------------------------------------------------------------
@@ -134,26 +137,29 @@ BP_HD void vb_window_thread(uint32_t tid, const vb_chunk *chunks, const ge_cache
 // col    (optional): the column sum as an extended point (input of the one-lane Horner chain)
 // colq16 (optional): the same point for the wavefront-cooperative chain (horner_wave.h):
 //                    [msm][w][4][8 words] = canonical encodings of (Y-X, Y+X, Z, 2dT), i.e. 16 u16 limbs each
-BP_HD void vb_colsum_thread(uint32_t tid, const uint32_t *chunk_first, const ge_ext *part, ge_ext *col, uint32_t *colq16) {
-    const uint32_t b = tid >> 6, w = tid & 63;
+BP_HD void vb_colsum_acc(ge_ext &acc, uint32_t b, uint32_t w, const uint32_t *chunk_first, const ge_ext *part) {
     const uint32_t c0 = chunk_first[b], c1 = chunk_first[b + 1];
-    ge_ext acc;
     ge_identity(acc);
     if (c1 > c0) acc = part[(uint64_t)c0 * 64 + w];
     for (uint32_t c = c0 + 1; c < c1; c++) {
         const ge_ext q = part[(uint64_t)c * 64 + w];
         ge_add(acc, acc, q);
     }
+}
+// 32 words: canonical encodings of (Y-X, Y+X, Z, 2dT) = 4 x 16 u16 limbs for the wavefront Horner chain
+BP_HD void vb_encode_colq16(uint32_t *o, const ge_ext &acc) {
+    ge_cached cc;
+    ge_to_cached(cc, acc);
+    fe_to_words(o, cc.YmX);
+    fe_to_words(o + 8, cc.YpX);
+    fe_to_words(o + 16, cc.Z);
+    fe_to_words(o + 24, cc.T2d);
+}
+BP_HD void vb_colsum_thread(uint32_t tid, const uint32_t *chunk_first, const ge_ext *part, ge_ext *col, uint32_t *colq16) {
+    ge_ext acc;
+    vb_colsum_acc(acc, tid >> 6, tid & 63, chunk_first, part);
     if (col) col[tid] = acc;
-    if (colq16) {
-        ge_cached cc;
-        ge_to_cached(cc, acc);
-        uint32_t *o = colq16 + (uint64_t)tid * 32;
-        fe_to_words(o, cc.YmX);
-        fe_to_words(o + 8, cc.YpX);
-        fe_to_words(o + 16, cc.Z);
-        fe_to_words(o + 24, cc.T2d);
-    }
+    if (colq16) vb_encode_colq16(colq16 + (uint64_t)tid * 32, acc);
 }
 
 // ---- stage 4 ---------------------------------------------------------------

@@ -109,11 +109,11 @@ BP_HD void rp_challenge_scalar(strobe &t, const uint8_t *label, uint32_t label_l
 
 // ---- stage 1: parse + transcript ------------------------------------------------------
 // thread p.  `st` = this lane's 50-word sponge state (LDS on the device).
-// Outputs: fields (plain scalars), uniq_points[p][U] = A,S,T1,T2,L_0..L_{k-1},R_0..R_{k-1},V_0..V_{m-1}
-// (the order of the unique part of mod.rs:433-443), verdict[p] (0, VerificationError, FormatError).
+// Outputs: fields (plain scalars) and status[p] (0, VerificationError, FormatError).  The per-proof points
+// (A,S,T1,T2,L_*,R_*,V_*) are decoded straight from the proof bytes by rp_points_thread, which does not
+// depend on the transcript and therefore shares a launch with it.
 BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &init, kstate st, const uint8_t *proofs,
-                                const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields, uint32_t *uniq_points,
-                                uint32_t *status) {
+                                const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields, uint32_t *status) {
     const uint32_t B = sh.nproofs, k = sh.k;
     const uint8_t *pr = proofs + (uint64_t)p * sh.proof_len;
     const rp_fields fl = rp_field_layout(k, sh.m);
@@ -127,11 +127,11 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
     load_words8(a.v, pr + 224 + 64 * k);       fmt_ok = fmt_ok && sc_is_canonical_sc(a);
     load_words8(b.v, pr + 224 + 64 * k + 32);  fmt_ok = fmt_ok && sc_is_canonical_sc(b);
     if (!fmt_ok) {
-        status[p] = BP_VERDICT_FORMAT;
+        status_raise(status + p, BP_VERDICT_FORMAT);   // FormatError outranks whatever the point decoder reports
         return;
     }
     if (sh.shape_verdict) {
-        status[p] = sh.shape_verdict;
+        status_raise(status + p, sh.shape_verdict);
         return;
     }
     rp_store(fields, B, RPF_TX, p, tx);
@@ -147,7 +147,6 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
     t.pos_begin = init.pos_begin;
     t.cur_flags = init.cur_flags;
 
-    uint32_t *up = uniq_points + (uint64_t)p * sh.U * 8;
     bool verr = false;
     const uint8_t lV[1] = {'V'}, lA[1] = {'A'}, lS[1] = {'S'}, ly[1] = {'y'}, lz[1] = {'z'}, lx[1] = {'x'}, lw[1] = {'w'},
                   lL[1] = {'L'}, lR[1] = {'R'}, lu[1] = {'u'}, ln[1] = {'n'};
@@ -161,28 +160,23 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
     for (uint32_t j = 0; j < sh.m; j++) {
         load_words8(w, commitments + ((uint64_t)p * sh.m + j) * 32);
         merlin_append_words8(t, lV, 1, w);
-        for (int i = 0; i < 8; i++) up[(4 + 2 * k + j) * 8 + i] = w[i];
     }
     // A, S: validate_and_append_point (transcript.rs:75-87)
     load_words8(w, pr + 0);
     verr = verr || words8_zero(w);
     merlin_append_words8(t, lA, 1, w);
-    for (int i = 0; i < 8; i++) up[0 * 8 + i] = w[i];
     load_words8(w, pr + 32);
     verr = verr || words8_zero(w);
     merlin_append_words8(t, lS, 1, w);
-    for (int i = 0; i < 8; i++) up[1 * 8 + i] = w[i];
     sc y, z, x, wch, c;
     rp_challenge_scalar(t, ly, 1, y);
     rp_challenge_scalar(t, lz, 1, z);
     load_words8(w, pr + 64);
     verr = verr || words8_zero(w);
     merlin_append_words8(t, lT1, 3, w);
-    for (int i = 0; i < 8; i++) up[2 * 8 + i] = w[i];
     load_words8(w, pr + 96);
     verr = verr || words8_zero(w);
     merlin_append_words8(t, lT2, 3, w);
-    for (int i = 0; i < 8; i++) up[3 * 8 + i] = w[i];
     rp_challenge_scalar(t, lx, 1, x);
     merlin_append_words8(t, ltx, 3, tx.v);
     merlin_append_words8(t, ltxb, 12, txb.v);
@@ -208,16 +202,36 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
         load_words8(w, pr + 224 + 64 * i);
         verr = verr || words8_zero(w);
         merlin_append_words8(t, lL, 1, w);
-        for (int q = 0; q < 8; q++) up[(4 + i) * 8 + q] = w[q];
         load_words8(w, pr + 224 + 64 * i + 32);
         verr = verr || words8_zero(w);
         merlin_append_words8(t, lR, 1, w);
-        for (int q = 0; q < 8; q++) up[(4 + k + i) * 8 + q] = w[q];
         sc u;
         rp_challenge_scalar(t, lu, 1, u);
         rp_store(fields, B, fl.u + i, p, u);
     }
     if (verr) status_raise(status + p, BP_VERDICT_VERIFICATION);
+}
+
+// ---- stage 1b: per-proof points -----------------------------------------------------------
+// unique term u of proof p, in the order A, S, T_1, T_2, L_0..L_{k-1}, R_0..R_{k-1}, V_0..V_{m-1}
+// (the non-generator part of mod.rs:433-443)
+BP_HD const uint8_t *rp_unique_point_ptr(const rp_shape &sh, const uint8_t *proofs, const uint8_t *commitments, uint32_t p, uint32_t u) {
+    const uint8_t *pr = proofs + (uint64_t)p * sh.proof_len;
+    const uint32_t k = sh.k;
+    if (u < 4) return pr + 32 * u;
+    if (u < 4 + k) return pr + 224 + 64 * (u - 4);
+    if (u < 4 + 2 * k) return pr + 224 + 64 * (u - 4 - k) + 32;
+    return commitments + ((uint64_t)p * sh.m + (u - 4 - 2 * k)) * 32;
+}
+// thread t = p * U + u: decode the point (mod.rs:433-443 .decompress()) and build its {1..8}P table.
+// An undecodable point is the Option::None of optional_multiscalar_mul -> VerificationError (mod.rs:445).
+BP_HD void rp_points_thread(uint32_t t, rp_shape sh, const uint8_t *proofs, const uint8_t *commitments, ge_cached *tab, uint32_t *status) {
+    const uint32_t p = t / sh.U, u = t - p * sh.U;
+    uint32_t w[8];
+    load_words8(w, rp_unique_point_ptr(sh, proofs, commitments, p, u));
+    ge_ext pt;
+    if (!ristretto_decompress(pt, w)) status_raise(status + p, BP_VERDICT_VERIFICATION);
+    vb_build_table(tab + 8 * (uint64_t)t, pt);
 }
 
 // sum_{i<2^lg} x^i by repeated doubling (src/util.rs:240-256); Montgomery form in and out
@@ -250,11 +264,19 @@ BP_HD void store_words8(uint32_t *dst, const sc &s) {
 #pragma unroll
     for (int q = 0; q < 8; q++) dst[q] = s.v[q];
 }
+// a canonical coefficient of a per-proof point, stored as its signed radix-16 recoding (msm_vb.h)
+BP_HD void store_recoded(uint32_t *dst, const sc &s) {
+    uint32_t r[8];
+    sc_recode16(r, s.v);
+#pragma unroll
+    for (int q = 0; q < 8; q++) dst[q] = r[q];
+}
 
 // ---- stage 2: per-proof scalars -----------------------------------------------------------
-// thread p.  Writes uniq_scalars[p][U] in the order of uniq_points, the Montgomery-form tables for
-// stage 3, and the digits of the B_blinding (row 0) and B (row 1) coefficients.
-BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t lg_m, uint32_t *fields, uint32_t *uniq_scalars,
+// thread p.  Writes the radix-16 recodings of the U per-proof coefficients (recoded[p][U][8], order of
+// rp_unique_point_ptr), the Montgomery-form tables for stage 3, and the digits of the B_blinding (row 0) and
+// B (row 1) coefficients.
+BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t lg_m, uint32_t *fields, uint32_t *recoded,
                               uint16_t *digits, const uint32_t *status) {
     if (status[p] != 0) return;   // digits/scalars of rejected proofs are never consumed (finish masks them)
     const uint32_t B = sh.nproofs, k = sh.k;
@@ -295,7 +317,7 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
     }
     sc28 inv;
     sc28_invert_mont(inv, acc);                           // (y * prod u_i)^-1
-    uint32_t *us = uniq_scalars + (uint64_t)p * sh.U * 8;
+    uint32_t *us = recoded + (uint64_t)p * sh.U * 8;
     for (uint32_t ii = k; ii-- > 0;) {
         sc28 pre, uim, sq;
         rp_load28(pre, fields, B, fl.uinv_m + ii, p);
@@ -305,10 +327,10 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
         rp_store28(fields, B, fl.uinv_m + ii, p, uim);
         sc28_montmul(sq, um, um);                         // u_i^2   -> L_i coefficient
         sc_from_mont28(t0, sq);
-        store_words8(us + (4 + ii) * 8, t0);
+        store_recoded(us + (4 + ii) * 8, t0);
         sc28_montmul(sq, uim, uim);                       // u_i^-2  -> R_i coefficient
         sc_from_mont28(t0, sq);
-        store_words8(us + (4 + k + ii) * 8, t0);
+        store_recoded(us + (4 + k + ii) * 8, t0);
     }
     // what is left in inv is y^-1: table of y^-(2^b)
     {
@@ -333,19 +355,19 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
     sc28 cxm, cxxm;
     sc28_montmul(cxm, cm, xm);
     sc28_montmul(cxxm, cxm, xm);
-    store_words8(us + 0 * 8, one);
-    store_words8(us + 1 * 8, x);
+    store_recoded(us + 0 * 8, one);
+    store_recoded(us + 1 * 8, x);
     sc_from_mont28(t0, cxm);
-    store_words8(us + 2 * 8, t0);
+    store_recoded(us + 2 * 8, t0);
     sc_from_mont28(t0, cxxm);
-    store_words8(us + 3 * 8, t0);
+    store_recoded(us + 3 * 8, t0);
     // V_j coefficients c z^2 z^j, and the z^2 z^j table
     {
         sc28 czzj, zzj = zzm;
         sc28_montmul(czzj, cm, zzm);
         for (uint32_t j = 0; j < sh.m; j++) {
             sc_from_mont28(t0, czzj);
-            store_words8(us + (4 + 2 * k + j) * 8, t0);
+            store_recoded(us + (4 + 2 * k + j) * 8, t0);
             rp_store28(fields, B, fl.zzzj_m + j, p, zzj);
             sc28_montmul(czzj, czzj, zm);
             sc28_montmul(zzj, zzj, zm);

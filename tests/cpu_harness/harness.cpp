@@ -211,7 +211,10 @@ void h_sc_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
     memcpy(out, r.v, 32);
 }
 
-// Whole verification pipeline, lane by lane, as the HIP runtime enqueues it.
+// Whole verification pipeline, lane by lane, in the launch structure of the HIP runtime:
+//   launch 1: rp_transcript  ||  rp_points        launch 2: rp_expand_a
+//   launch 3: rp_expand_b    ||  vb_window        launch 4: fb_accum  ||  (column sums + wavefront Horner)
+//   then fb_reduce, shared_finish
 int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t party_capacity, const uint8_t *gens /*Bb,B,G..,H..*/,
                 uint32_t n, uint32_t m, uint32_t nbatch, const uint8_t *proofs, uint32_t proof_len, const uint8_t *commitments,
                 const uint8_t *label, uint32_t label_len, const uint8_t *rng64, uint8_t *verdict_out, uint8_t *msm_out) {
@@ -235,45 +238,47 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
 
     rp_strobe_init init; make_strobe_init(init, label, label_len, n, m);
     const rp_fields fl = rp_field_layout(k, m);
-    std::vector<uint32_t> fields((size_t)fl.count * nbatch * BP_RP_REC + 8), uniq_points((size_t)nbatch * sh.U * 8 + 8, 0), uniq_scalars((size_t)nbatch * sh.U * 8 + 8, 0), status(nbatch + 1, 0);
+    const uint32_t t0 = nbatch * sh.U;
+    std::vector<uint32_t> fields((size_t)fl.count * nbatch * BP_RP_REC + 8), rec((size_t)t0 * 8 + 8, 0xdeadbeefu), status(nbatch + 1, 0), outw((size_t)nbatch * 8 + 1);
     std::vector<uint16_t> digits((size_t)npairs * nbatch + 1, 0xffff);   // poison: unwritten rows must be masked
+    std::vector<ge_cached> tab((size_t)t0 * 8 + 1);
+    // launch 1
     for (uint32_t p = 0; p < nbatch; p++) {
         uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;
-        rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields.data(), uniq_points.data(), status.data());
+        rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields.data(), status.data());
     }
-    for (uint32_t p = 0; p < nbatch; p++) rp_expand_a_thread(p, sh, prm, lg_m, fields.data(), uniq_scalars.data(), digits.data(), status.data());
+    for (uint32_t t = 0; t < t0; t++) rp_points_thread(t, sh, proofs, commitments, tab.data(), status.data());
+    // launch 2
+    for (uint32_t p = 0; p < nbatch; p++) rp_expand_a_thread(p, sh, prm, lg_m, fields.data(), rec.data(), digits.data(), status.data());
+    // launch 3
     for (uint32_t tid = 0; tid < sh.nm * nbatch; tid++) rp_expand_b_thread(tid, sh, prm, fields.data(), digits.data(), status.data());
-    // unique part through the variable-base stages
-    std::vector<vb_chunk> chunks; std::vector<uint32_t> chunk_first(nbatch + 1), term_chunk; uint32_t t0 = 0;
+    std::vector<vb_chunk> chunks; std::vector<uint32_t> chunk_first(nbatch + 1); uint32_t tt = 0;
     for (uint32_t b = 0; b < nbatch; b++) {
         chunk_first[b] = (uint32_t)chunks.size();
         for (uint32_t kk = 0; kk < sh.U; kk += BP_VB_CHUNK) {
-            vb_chunk c; c.msm = b; c.first = t0 + kk; c.count = sh.U - kk < BP_VB_CHUNK ? sh.U - kk : BP_VB_CHUNK; c.pad = 0;
-            for (uint32_t i = 0; i < c.count; i++) term_chunk.push_back((uint32_t)chunks.size());
+            vb_chunk c; c.msm = b; c.first = tt + kk; c.count = sh.U - kk < BP_VB_CHUNK ? sh.U - kk : BP_VB_CHUNK; c.pad = 0;
             chunks.push_back(c);
         }
-        t0 += sh.U;
+        tt += sh.U;
     }
     chunk_first[nbatch] = (uint32_t)chunks.size();
-    std::vector<ge_cached> tab((size_t)t0 * 8 + 1); std::vector<uint32_t> rec((size_t)t0 * 8 + 1), outw((size_t)nbatch * 8 + 1);
-    std::vector<ge_ext> part(chunks.size() * 64 + 1), col((size_t)nbatch * 64 + 1), hq;
-    std::vector<uint32_t> colq16((size_t)nbatch * 64 * 32 + 1);
-    for (uint32_t t = 0; t < t0; t++) vb_prepare_thread(t, chunks.data(), term_chunk.data(), uniq_scalars.data(), uniq_points.data(), tab.data(), rec.data(), status.data());
+    std::vector<ge_ext> part(chunks.size() * 64 + 1), hq(nbatch + 1);
     for (uint32_t tid = 0; tid < chunks.size() * 64; tid++) vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data());
-    for (uint32_t tid = 0; tid < nbatch * 64; tid++) vb_colsum_thread(tid, chunk_first.data(), part.data(), col.data(), colq16.data());
-    if (horner_all(nbatch, col, colq16, hq)) return -99;
+    // launch 4
     std::vector<ge_ext> partial((size_t)nsplit * nbatch + 1);
     const uint32_t per = (npairs + nsplit - 1) / nsplit;
     for (uint32_t sp = 0; sp < nsplit; sp++) {
         uint32_t q0 = sp * per, q1 = q0 + per < npairs ? q0 + per : npairs; if (q0 > npairs) q0 = npairs;
         for (uint32_t p = 0; p < nbatch; p++) fb_accum_thread(p, sp, q0, q1, prm, nbatch, ids.data(), digits.data(), table.data(), partial.data());
     }
+    for (uint32_t b = 0; b < nbatch; b++) hw_colsum_horner_msm(b, chunk_first.data(), part.data(), &hq[b]);
     std::vector<uint8_t> verdict(nbatch + 1);
     for (uint32_t p = 0; p < nbatch; p++) shared_finish_thread(p, nbatch, nsplit, nullptr, true, hq.data(), partial.data(), status.data(), outw.data(), verdict.data());
     for (uint32_t p = 0; p < nbatch; p++) verdict_out[p] = verdict[p];
     if (msm_out) memcpy(msm_out, outw.data(), (size_t)nbatch * 32);
     return 0;
 }
+
 void h_msm_vb(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status_out);
 
 // Stand-alone IPP verification, lane by lane: ipp_prepare -> variable-base MSM pipeline -> verdict
