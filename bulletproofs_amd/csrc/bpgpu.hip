@@ -117,6 +117,33 @@ __global__ void __launch_bounds__(64) k_shared_finish(uint32_t nproofs, uint32_t
     if (p < nproofs) shared_finish_thread(p, nproofs, nsplit, nullptr, have_unique != 0, hq, partial, status, out_words, verdict);
 }
 
+// One launch for the whole tail: 8 lanes per proof add up the per-split partial sums (and the Horner result),
+// a 3-level exchange through LDS folds them, lane 0 tests / compresses.  Replaces two fb_reduce launches and
+// shared_finish; `reset_status` hands the status words back zeroed for the next call on this context.
+template <bool WITH_OUT>   // WITH_OUT = false: verdicts only (no compression code, a third of the registers)
+__global__ void __launch_bounds__(64) k_finish8(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, const ge_ext *partial, uint32_t *status,
+                                                 uint32_t *out_words, uint8_t *verdict, int reset_status) {
+    __shared__ ge_ext xch[64];
+    const uint32_t lane = threadIdx.x, j = lane & 7, p = blockIdx.x * 8 + (lane >> 3);
+    const bool live = p < nproofs;
+    ge_ext acc;
+    if (live) shared_finish8_gather(acc, p, j, nproofs, nsplit, hq, partial);
+    else ge_identity(acc);
+#pragma unroll 1
+    for (uint32_t step = 4; step >= 1; step >>= 1) {
+        xch[lane] = acc;
+        __syncthreads();
+        if (j < step) {
+            const ge_ext q = xch[lane + step];
+            ge_add(acc, acc, q);
+        }
+        __syncthreads();
+    }
+    if (live && j == 0) {
+        shared_finish_tail(p, acc, status, WITH_OUT ? out_words : nullptr, verdict);
+        if (reset_status) status[p] = 0;
+    }
+}
 
 // ---- range-proof front end ----------------------------------------------------
 // The device overlaps at most a handful of kernels, so a chain of narrow launches leaves most CUs idle.
@@ -124,28 +151,28 @@ __global__ void __launch_bounds__(64) k_shared_finish(uint32_t nproofs, uint32_t
 // one role, the rest the other ("role-fused" launches; the long-running role gets the low block indices so
 // the dispatcher starts it first).
 #define RP_BLOCK 64
-// launch 1: [0, n_tr) Fiat-Shamir transcript replay, lane = proof  ||  [n_tr, ..) decode the proof's and the
-// commitments' points straight from the input bytes and build their 8-entry tables, lane = point
+// launch 1: [0, n_tr) Fiat-Shamir transcript replay, then the per-proof scalars (one inversion by division
+// steps, the U coefficient recodings, the Montgomery tables for launch 2), lane = proof  ||  [n_tr, ..) decode
+// the proof's and the commitments' points straight from the input bytes and build their 8-entry tables,
+// lane = point
 __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs,
                                                          const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields,
-                                                         ge_cached *tab, uint32_t *status) {
+                                                         ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m,
+                                                         uint32_t *recoded, uint16_t *digits) {
     __shared__ uint32_t lds[50 * RP_BLOCK];   // sponge states, word-major: word w of lane t at w*RP_BLOCK + t
     if (blockIdx.x < n_tr) {
         const uint32_t p = blockIdx.x * RP_BLOCK + threadIdx.x;
         kstate st;
         st.w = lds + threadIdx.x;
         st.stride = RP_BLOCK;
-        if (p < sh.nproofs) rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields, status);
+        if (p < sh.nproofs) {
+            rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields, status);
+            if (!sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status);
+        }
     } else {
         const uint32_t t = (blockIdx.x - n_tr) * RP_BLOCK + threadIdx.x;
         if (t < sh.nproofs * sh.U) rp_points_thread(t, sh, proofs, commitments, tab, status);
     }
-}
-
-__global__ void __launch_bounds__(64) k_rp_expand_a(rp_shape sh, fb_params prm, uint32_t lg_m, uint32_t *fields, uint32_t *recoded,
-                                                     uint16_t *digits, const uint32_t *status) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < sh.nproofs) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status);
 }
 
 // launch 3: [0, n_win) per-chunk window sums of the proof-specific points  ||  the 2nm generator exponents
@@ -188,9 +215,12 @@ __global__ void __launch_bounds__(FB_BLOCK) k_rp_stage4(uint32_t n_hw, const uin
 }
 
 // verdict[p] = status (Format / shape / Verification) if set, else the identity test of the mega-check
-__global__ void __launch_bounds__(64) k_rp_verdict(uint32_t n, const uint32_t *status, const uint8_t *msm_verdict, uint8_t *out) {
+__global__ void __launch_bounds__(64) k_rp_verdict(uint32_t n, uint32_t *status, const uint8_t *msm_verdict, uint8_t *out) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) out[p] = status[p] ? (uint8_t)status[p] : msm_verdict[p];
+    if (p < n) {
+        out[p] = status[p] ? (uint8_t)status[p] : msm_verdict[p];
+        status[p] = 0;   // handed back clean (see bpgpu_ctx::rp_status)
+    }
 }
 
 __global__ void __launch_bounds__(RP_BLOCK) k_ipp_prepare(ipp_shape sh, rp_strobe_init init, const uint8_t *proofs, const uint8_t *Gf,
@@ -269,6 +299,11 @@ struct bpgpu_ctx {
         uint32_t total = 0;
     };
     std::map<std::pair<size_t, size_t>, plan_dev> plan_cache;
+    // per-proof status words of the range-proof path: zero between calls (the last kernel of a call resets the
+    // entries it used), so no memset launch is needed per call; `dirty` forces one after an aborted enqueue
+    uint32_t *rp_status = nullptr;
+    size_t rp_status_cap = 0;
+    bool rp_status_dirty = false;
     // profiling
     bool prof = false;
     std::map<std::string, kstat> stats;
@@ -409,6 +444,7 @@ void bpgpu_ctx_destroy(bpgpu_ctx *c) {
     for (auto &kv : c->gen_ids_cache) hipFree(kv.second);
     for (auto &kv : c->plan_cache) hipFree(kv.second.mem);
     if (c->arena) hipFree(c->arena);
+    if (c->rp_status) hipFree(c->rp_status);
     if (c->d_gens) hipFree(c->d_gens);
     release_table(c);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -826,14 +862,15 @@ static uint32_t pick_splits(bpgpu_ctx *c, size_t nbatch, uint32_t npairs) {
     return s;
 }
 
-// Tree-reduce the per-split partial points (8-way per level) until at most 8 remain per proof.
+// Tree-reduce the per-split partial points (8-way per level) until at most `until` remain per proof.
 // `buf` must hold nsplit*nbatch + ceil(nsplit/8)*nbatch (+ ...) points: callers reserve 2*nsplit*nbatch.
 #define FB_REDUCE_GROUP 8
-static void enqueue_fb_reduce(bpgpu_ctx *c, hipStream_t s, uint32_t nbatch, uint32_t nsplit, ge_ext *buf, ge_ext **out, uint32_t *nout) {
+static void enqueue_fb_reduce(bpgpu_ctx *c, hipStream_t s, uint32_t nbatch, uint32_t nsplit, ge_ext *buf, ge_ext **out, uint32_t *nout,
+                              uint32_t until = FB_REDUCE_GROUP) {
     ge_ext *cur = buf;
     uint32_t n = nsplit;
     ge_ext *next = buf + (size_t)nsplit * nbatch;
-    while (n > FB_REDUCE_GROUP) {
+    while (n > until) {
         const uint32_t ng = (n + FB_REDUCE_GROUP - 1) / FB_REDUCE_GROUP;
         const uint32_t nt = ng * nbatch;
         LAUNCH(c, s, "fb_reduce", k_fb_reduce, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, nbatch, n, (uint32_t)FB_REDUCE_GROUP, cur, next);
@@ -1079,7 +1116,6 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     arena_plan ap;
     size_t off[7];
     plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off);
-    const size_t off_status = ap.add(nbatch * 4);
     const size_t off_digits = ap.add((size_t)npairs * nbatch * 2 + 16);
     const size_t off_partial = ap.add((size_t)2 * nsplit * nbatch * sizeof(ge_ext) + 16);
     const size_t off_fields = ap.add((size_t)fl.count * nbatch * BP_RP_REC * 4 + 16);
@@ -1088,7 +1124,15 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     rc = arena_reserve(c, ap.total);
     if (rc) return rc;
     char *a = c->arena;
-    uint32_t *d_status = (uint32_t *)(a + off_status);
+    if (c->rp_status_cap < nbatch) {
+        if (c->rp_status) HIPCHK(c, hipFree(c->rp_status));
+        c->rp_status = nullptr;
+        c->rp_status_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->rp_status, nbatch * 4));
+        c->rp_status_cap = nbatch;
+        c->rp_status_dirty = true;
+    }
+    uint32_t *d_status = c->rp_status;
     uint16_t *d_digits = (uint16_t *)(a + off_digits);
     ge_ext *d_partial = (ge_ext *)(a + off_partial);
     uint32_t *d_fields = (uint32_t *)(a + off_fields);
@@ -1106,7 +1150,8 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         HIPCHK(c, hipStreamSynchronize(s));   // h goes out of scope
         rng_ptr = (const uint8_t *)(a + off_rng);
     }
-    HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
+    if (c->rp_status_dirty) HIPCHK(c, hipMemsetAsync(d_status, 0, c->rp_status_cap * 4, s));
+    c->rp_status_dirty = true;   // until the kernel that resets the words has been enqueued
     rp_strobe_init init;
     make_strobe_init(init, label, label_len, n, m);
     const uint32_t nb32 = (uint32_t)nbatch;
@@ -1125,15 +1170,15 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const uint32_t n_tr = (nb32 + RP_BLOCK - 1) / RP_BLOCK;
     const uint32_t n_pt = shape_verdict ? 0 : (nb32 * sh.U + RP_BLOCK - 1) / RP_BLOCK;
     LAUNCH(c, s, "rp_stage1", k_rp_stage1, n_tr + n_pt, RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
-           (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status);
+           (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, d.recoded, d_digits);
     if (shape_verdict) {
         HIPCHK(c, hipMemsetAsync(d_mv, 1, nbatch, s));
         LAUNCH(c, s, "rp_verdict", k_rp_verdict, (nb32 + 63) / 64, 64, nb32, d_status, d_mv, (uint8_t *)d_verdict);
         if (d_msm_out) HIPCHK(c, hipMemsetAsync(d_msm_out, 0, nbatch * 32, s));
         HIPCHK(c, hipGetLastError());
+        c->rp_status_dirty = false;
         return BPGPU_OK;
     }
-    LAUNCH(c, s, "rp_expand_a", k_rp_expand_a, (nb32 + 63) / 64, 64, sh, prm, lg_m, d_fields, d.recoded, d_digits, d_status);
     const uint32_t nexp = sh.nm * nb32, nwin = (uint32_t)pd->n_chunks * 64;
     const uint32_t n_win = (nwin + BP_BLOCK - 1) / BP_BLOCK, n_exp = (nexp + BP_BLOCK - 1) / BP_BLOCK;
     LAUNCH(c, s, "rp_stage3", k_rp_stage3, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part, nexp, sh, prm, d_fields,
@@ -1143,10 +1188,13 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
            npairs, d_ids, d_digits, c->d_table, d_partial);
     ge_ext *d_red = nullptr;
     uint32_t nred = 0;
-    enqueue_fb_reduce(c, s, nb32, nsplit, d_partial, &d_red, &nred);
-    LAUNCH(c, s, "shared_finish", k_shared_finish, (nb32 + 63) / 64, 64, nb32, nred, d.hq, 1, d_red, d_status,
-           (uint32_t *)d_msm_out, (uint8_t *)d_verdict);
+    enqueue_fb_reduce(c, s, nb32, nsplit, d_partial, &d_red, &nred, 64);   // 8 lanes x <= 8 partials each in finish8
+    if (d_msm_out)
+        LAUNCH(c, s, "finish8", k_finish8<true>, (nb32 + 7) / 8, 64, nb32, nred, d.hq, d_red, d_status, (uint32_t *)d_msm_out, (uint8_t *)d_verdict, 1);
+    else
+        LAUNCH(c, s, "finish8", k_finish8<false>, (nb32 + 7) / 8, 64, nb32, nred, d.hq, d_red, d_status, (uint32_t *)nullptr, (uint8_t *)d_verdict, 1);
     HIPCHK(c, hipGetLastError());
+    c->rp_status_dirty = false;
     return BPGPU_OK;
 }
 

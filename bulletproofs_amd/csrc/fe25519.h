@@ -38,7 +38,8 @@
 
 namespace bp {
 
-struct fe {
+// (8-byte aligned so that whole-element loads and stores can use 64/128-bit memory operations)
+struct __attribute__((aligned(8))) fe {
     uint32_t v[10];
 };
 

@@ -22,11 +22,11 @@ namespace bp {
 #define BP_FE_D_MINUS_ONE_SQ {{0x0ed4d20u, 0x156aa91u, 0x3332635u, 0x16580f0u, 0x34a7928u, 0x09b4eebu, 0x26997a9u, 0x048299bu, 0x3af66c2u, 0x165a2cdu}}
 
 // extended coordinates (X:Y:Z:T), x = X/Z, y = Y/Z, xy = T/Z
-struct ge_ext {
+struct __attribute__((aligned(16))) ge_ext {
     fe X, Y, Z, T;
 };
 // projective Niels form of a point, the addend format of variable-base tables
-struct ge_cached {
+struct __attribute__((aligned(16))) ge_cached {
     fe YpX, YmX, Z, T2d;
 };
 // affine Niels form (Z = 1), the entry format of the fixed-base generator tables

@@ -65,7 +65,7 @@ BP_HD void ipp_prepare_thread(uint32_t p, ipp_shape sh, const rp_strobe_init &in
         status_raise(status + p, BP_VERDICT_VERIFICATION);
         return;
     }
-    sc28_invert_mont(inv, acc);
+    sc28_invert_mont_safegcd(inv, acc);
     for (uint32_t ii = k; ii-- > 0;) {
         sc28 ui;
         sc28_montmul(ui, inv, uim[ii]);

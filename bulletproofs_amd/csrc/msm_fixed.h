@@ -221,6 +221,37 @@ BP_HD void fb_reduce_thread(uint32_t tid, uint32_t nproofs, uint32_t nsplit, uin
 }
 
 // ---- finish --------------------------------------------------------------------------
+// last step for proof p: compress / identity test of the accumulated point, masked by the front end's status
+BP_HD void shared_finish_tail(uint32_t p, const ge_ext &acc, const uint32_t *status, uint32_t *out_words, uint8_t *verdict) {
+    const bool bad = status[p] != 0;
+    if (out_words) {
+        uint32_t w[8];
+        ristretto_compress(w, acc);
+#pragma unroll
+        for (int i = 0; i < 8; i++) out_words[8 * (uint64_t)p + i] = bad ? 0u : w[i];
+    }
+    if (verdict) verdict[p] = bad ? (uint8_t)status[p] : (ge_is_identity(acc) ? 0 : 1);
+}
+// lane j (0..7) of proof p: its share of the partial sums, s = j, j+8, ...; lane 7 also takes the Horner result.
+// Returns false when the lane has nothing to add (acc is then the identity).
+BP_HD bool shared_finish8_gather(ge_ext &acc, uint32_t p, uint32_t j, uint32_t nproofs, uint32_t nsplit, const ge_ext *horner_pre,
+                                 const ge_ext *partial) {
+    bool have = false;
+    for (uint32_t s = j; s < nsplit; s += 8) {
+        const ge_ext q = partial[(uint64_t)s * nproofs + p];
+        if (have) ge_add(acc, acc, q);
+        else acc = q;
+        have = true;
+    }
+    if (j == 7 && horner_pre) {
+        const ge_ext q = horner_pre[p];
+        if (have) ge_add(acc, acc, q);
+        else acc = q;
+        have = true;
+    }
+    if (!have) ge_identity(acc);
+    return have;
+}
 // thread p: result = Horner(col[p]) (unique, variable-base terms) + sum_split partial[split][p]
 // out_words (optional): compressed result; verdict (optional): status[p] if set, else 0 identity / 1 not
 // horner_pre (optional): Horner results already computed by the wavefront-cooperative kernel (horner_wave.h)
@@ -235,14 +266,7 @@ BP_HD void shared_finish_thread(uint32_t p, uint32_t nproofs, uint32_t nsplit, c
         const ge_ext q = partial[(uint64_t)s * nproofs + p];
         ge_add(acc, acc, q);
     }
-    const bool bad = status[p] != 0;
-    if (out_words) {
-        uint32_t w[8];
-        ristretto_compress(w, acc);
-#pragma unroll
-        for (int i = 0; i < 8; i++) out_words[8 * (uint64_t)p + i] = bad ? 0u : w[i];
-    }
-    if (verdict) verdict[p] = bad ? (uint8_t)status[p] : (ge_is_identity(acc) ? 0 : 1);
+    shared_finish_tail(p, acc, status, out_words, verdict);
 }
 
 }  // namespace bp

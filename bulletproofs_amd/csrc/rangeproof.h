@@ -16,6 +16,7 @@
 #include "keccak.h"
 #include "msm_fixed.h"
 #include "sc25519.h"
+#include "scinv.h"
 
 namespace bp {
 
@@ -281,28 +282,14 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
     if (status[p] != 0) return;   // digits/scalars of rejected proofs are never consumed (finish masks them)
     const uint32_t B = sh.nproofs, k = sh.k;
     const rp_fields fl = rp_field_layout(k, sh.m);
-    sc y, z, x, w, c, tx, txb, eb, a, b, one, t0, t1;
+    sc one, t0, t1;
     sc_from_u32(one, 1);
-    rp_load(y, fields, B, RPF_Y, p);
-    rp_load(z, fields, B, RPF_Z, p);
-    rp_load(x, fields, B, RPF_X, p);
-    rp_load(w, fields, B, RPF_W, p);
-    rp_load(c, fields, B, RPF_C, p);
-    rp_load(tx, fields, B, RPF_TX, p);
-    rp_load(txb, fields, B, RPF_TXB, p);
-    rp_load(eb, fields, B, RPF_EB, p);
-    rp_load(a, fields, B, RPF_A, p);
-    rp_load(b, fields, B, RPF_B, p);
-    sc28 ym, zm, xm, wm, cm, txm, txbm, am, bm;
-    sc_to_mont28(ym, y);
-    sc_to_mont28(zm, z);
-    sc_to_mont28(xm, x);
-    sc_to_mont28(wm, w);
-    sc_to_mont28(cm, c);
-    sc_to_mont28(txm, tx);
-    sc_to_mont28(txbm, txb);
-    sc_to_mont28(am, a);
-    sc_to_mont28(bm, b);
+    sc28 ym;
+    {
+        sc y;
+        rp_load(y, fields, B, RPF_Y, p);
+        sc_to_mont28(ym, y);
+    }
 
     // batch inversion of (y, u_0, .., u_{k-1}) (Scalar::batch_invert, ipp.rs:226-227; y.invert(), mod.rs:414),
     // everything in Montgomery form; prefix products are parked in the uinv_m slots (overwritten below)
@@ -316,7 +303,7 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
         sc28_montmul(acc, acc, um);
     }
     sc28 inv;
-    sc28_invert_mont(inv, acc);                           // (y * prod u_i)^-1
+    sc28_invert_mont_safegcd(inv, acc);                   // (y * prod u_i)^-1
     uint32_t *us = recoded + (uint64_t)p * sh.U * 8;
     for (uint32_t ii = k; ii-- > 0;) {
         sc28 pre, uim, sq;
@@ -340,6 +327,25 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
             sc28_montmul(pw, pw, pw);
         }
     }
+    // (the remaining inputs are loaded only now: nothing but y and the u_i is live across the inversion)
+    sc z, x, w, c, tx, txb, eb, a, b;
+    rp_load(z, fields, B, RPF_Z, p);
+    rp_load(x, fields, B, RPF_X, p);
+    rp_load(w, fields, B, RPF_W, p);
+    rp_load(c, fields, B, RPF_C, p);
+    rp_load(tx, fields, B, RPF_TX, p);
+    rp_load(txb, fields, B, RPF_TXB, p);
+    rp_load(eb, fields, B, RPF_EB, p);
+    rp_load(a, fields, B, RPF_A, p);
+    rp_load(b, fields, B, RPF_B, p);
+    sc28 zm, xm, wm, cm, txbm, am, bm;
+    sc_to_mont28(zm, z);
+    sc_to_mont28(xm, x);
+    sc_to_mont28(wm, w);
+    sc_to_mont28(cm, c);
+    sc_to_mont28(txbm, txb);
+    sc_to_mont28(am, a);
+    sc_to_mont28(bm, b);
     sc28 zzm;
     sc28_montmul(zzm, zm, zm);
     sc zz, minus_z;

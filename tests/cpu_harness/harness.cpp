@@ -9,6 +9,7 @@
 #include "../../bulletproofs_amd/csrc/rangeproof.h"
 #include "../../bulletproofs_amd/csrc/horner_wave.h"
 #include "../../bulletproofs_amd/csrc/ipp.h"
+#include "../../bulletproofs_amd/csrc/scinv.h"
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -206,15 +207,18 @@ void h_sc_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
     case 4: sc_invert(r, x); break;
     case 5: { uint32_t w[16]; memcpy(w, a, 32); memcpy(w + 8, b, 32); sc_from_wide(r, w); } break;
     case 6: { sc28 a28, b28, t28; sc28_from_sc(a28, x); sc28_from_sc(b28, y); sc28_montmul(t28, a28, b28); sc28_to_mont(t28, t28); sc28_to_mont(t28, t28); sc_from_mont28(r, t28); } break;  // lazy chain: ((xy/R)*R*R)/R = xy
+    case 7: sc_invert_safegcd(r, x); break;
+    case 8: { sc28 m28, i28; sc_to_mont28(m28, x); sc28_invert_mont_safegcd(i28, m28); sc_from_mont28(r, i28); } break;
     default: sc_0(r);
     }
     memcpy(out, r.v, 32);
 }
 
 // Whole verification pipeline, lane by lane, in the launch structure of the HIP runtime:
-//   launch 1: rp_transcript  ||  rp_points        launch 2: rp_expand_a
-//   launch 3: rp_expand_b    ||  vb_window        launch 4: fb_accum  ||  (column sums + wavefront Horner)
-//   then fb_reduce, shared_finish
+//   launch 1: rp_transcript + rp_expand_a  ||  rp_points
+//   launch 2: rp_expand_b  ||  vb_window
+//   launch 3: fb_accum  ||  (column sums + wavefront Horner)
+//   launch 4: finish8
 int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t party_capacity, const uint8_t *gens /*Bb,B,G..,H..*/,
                 uint32_t n, uint32_t m, uint32_t nbatch, const uint8_t *proofs, uint32_t proof_len, const uint8_t *commitments,
                 const uint8_t *label, uint32_t label_len, const uint8_t *rng64, uint8_t *verdict_out, uint8_t *msm_out) {
@@ -246,11 +250,10 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
     for (uint32_t p = 0; p < nbatch; p++) {
         uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;
         rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields.data(), status.data());
+        rp_expand_a_thread(p, sh, prm, lg_m, fields.data(), rec.data(), digits.data(), status.data());
     }
     for (uint32_t t = 0; t < t0; t++) rp_points_thread(t, sh, proofs, commitments, tab.data(), status.data());
     // launch 2
-    for (uint32_t p = 0; p < nbatch; p++) rp_expand_a_thread(p, sh, prm, lg_m, fields.data(), rec.data(), digits.data(), status.data());
-    // launch 3
     for (uint32_t tid = 0; tid < sh.nm * nbatch; tid++) rp_expand_b_thread(tid, sh, prm, fields.data(), digits.data(), status.data());
     std::vector<vb_chunk> chunks; std::vector<uint32_t> chunk_first(nbatch + 1); uint32_t tt = 0;
     for (uint32_t b = 0; b < nbatch; b++) {
@@ -264,7 +267,7 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
     chunk_first[nbatch] = (uint32_t)chunks.size();
     std::vector<ge_ext> part(chunks.size() * 64 + 1), hq(nbatch + 1);
     for (uint32_t tid = 0; tid < chunks.size() * 64; tid++) vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data());
-    // launch 4
+    // launch 3
     std::vector<ge_ext> partial((size_t)nsplit * nbatch + 1);
     const uint32_t per = (npairs + nsplit - 1) / nsplit;
     for (uint32_t sp = 0; sp < nsplit; sp++) {
@@ -273,7 +276,14 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
     }
     for (uint32_t b = 0; b < nbatch; b++) hw_colsum_horner_msm(b, chunk_first.data(), part.data(), &hq[b]);
     std::vector<uint8_t> verdict(nbatch + 1);
-    for (uint32_t p = 0; p < nbatch; p++) shared_finish_thread(p, nbatch, nsplit, nullptr, true, hq.data(), partial.data(), status.data(), outw.data(), verdict.data());
+    // launch 4 (k_finish8): 8 lanes per proof gather, 3-level fold, lane 0 finishes
+    for (uint32_t p = 0; p < nbatch; p++) {
+        ge_ext x[8];
+        for (uint32_t j = 0; j < 8; j++) shared_finish8_gather(x[j], p, j, nbatch, nsplit, hq.data(), partial.data());
+        for (uint32_t step = 4; step >= 1; step >>= 1)
+            for (uint32_t j = 0; j < step; j++) { const ge_ext q = x[j + step]; ge_add(x[j], x[j], q); }
+        shared_finish_tail(p, x[0], status.data(), outw.data(), verdict.data());
+    }
     for (uint32_t p = 0; p < nbatch; p++) verdict_out[p] = verdict[p];
     if (msm_out) memcpy(msm_out, outw.data(), (size_t)nbatch * 32);
     return 0;
