@@ -77,7 +77,7 @@ ERR_NAMES = {0: "OK", -1: "INVALID_ARG", -2: "HIP", -3: "NO_GENS", -4: "NO_DEVIC
 class Context:
     """Owns one bpgpu_ctx (one GPU)."""
 
-    def __init__(self, device=0, fixed_window_bits=None, fixed_splits=None, fixed_table_max_bytes=None):
+    def __init__(self, device=0, fixed_window_bits=None, fixed_splits=None, fixed_table_max_bytes=None, horner_lanes=None):
         self._L = lib()
         h = C.c_void_p()
         rc = self._L.bpgpu_ctx_create(device, C.byref(h))
@@ -90,6 +90,8 @@ class Context:
             self.set_option("fixed_splits", fixed_splits)
         if fixed_table_max_bytes is not None:
             self.set_option("fixed_table_max_bytes", fixed_table_max_bytes)
+        if horner_lanes is not None:
+            self.set_option("horner_lanes", horner_lanes)
 
     def close(self):
         if getattr(self, "h", None):

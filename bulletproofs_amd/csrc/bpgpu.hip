@@ -15,6 +15,7 @@
 #include "msm_fixed.h"
 #include "msm_vb.h"
 #include "horner_wave.h"
+#include "horner_quad.h"
 #include "rangeproof.h"
 #include "ipp.h"
 
@@ -39,9 +40,9 @@ __global__ void __launch_bounds__(BP_BLOCK) k_vb_window(uint32_t nthreads, const
 }
 
 __global__ void __launch_bounds__(BP_BLOCK) k_vb_colsum(uint32_t nthreads, const uint32_t *chunk_first, const ge_ext *part,
-                                                         uint32_t *colq16) {
+                                                         uint32_t *colq16, ge_cached *colc) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < nthreads) vb_colsum_thread(tid, chunk_first, part, nullptr, colq16);
+    if (tid < nthreads) vb_colsum_thread(tid, chunk_first, part, nullptr, colq16, colc);
 }
 
 // wavefront-cooperative Horner chain (horner_wave.h): one 64-lane workgroup = one wavefront = one MSM
@@ -177,25 +178,30 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1(rp_shape sh, rp_strobe_i
 
 // launch 3: [0, n_win) per-chunk window sums of the proof-specific points  ||  the 2nm generator exponents
 __global__ void __launch_bounds__(BP_BLOCK) k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab,
-                                                         const uint32_t *recoded, ge_ext *part, uint32_t nthreads_exp, rp_shape sh,
-                                                         fb_params prm, const uint32_t *fields, uint16_t *digits, const uint32_t *status) {
+                                                         const uint32_t *recoded, ge_ext *part, ge_cached *colc, uint32_t nthreads_exp,
+                                                         rp_shape sh, fb_params prm, const uint32_t *fields, uint16_t *digits,
+                                                         const uint32_t *status) {
     if (blockIdx.x < n_win) {
         const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
-        if (tid < nthreads_win) vb_window_thread(tid, chunks, tab, recoded, part);
+        if (tid < nthreads_win) vb_window_thread(tid, chunks, tab, recoded, part, colc);
     } else {
         const uint32_t tid = (blockIdx.x - n_win) * BP_BLOCK + threadIdx.x;
         if (tid < nthreads_exp) rp_expand_b_thread(tid, sh, prm, fields, digits, status);
     }
 }
 
-// launch 4: [0, nproofs) one wavefront per proof: column sums + Horner chain of the proof-specific terms  ||
-// the fixed-base table walk (block -> (split, proof block) as in k_fb_accum)
-__global__ void __launch_bounds__(FB_BLOCK) k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge_ext *part, ge_ext *hq,
-                                                         fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit, uint32_t npairs,
-                                                         const uint32_t *gen_ids, const uint16_t *digits, const fb_entry *table,
-                                                         ge_ext *partial) {
+// launch 4: [0, n_hw) the Horner chains of the proof-specific terms -- QUAD: one quad of lanes per proof, 16
+// proofs per wavefront, from cached column sums (horner_quad.h); otherwise one wavefront per proof, which forms
+// its column sums itself (horner_wave.h)  ||  the fixed-base table walk (block -> (split, proof block) as in
+// k_fb_accum)
+template <bool QUAD>
+__global__ void __launch_bounds__(FB_BLOCK) k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge_ext *part, const ge_cached *colc,
+                                                         ge_ext *hq, fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit,
+                                                         uint32_t npairs, const uint32_t *gen_ids, const uint16_t *digits,
+                                                         const fb_entry *table, ge_ext *partial) {
     if (blockIdx.x < n_hw) {
-        hw_colsum_horner_msm(blockIdx.x, chunk_first, part, hq + blockIdx.x);
+        if (QUAD) hq_horner_msm(blockIdx.x * 16 + (threadIdx.x >> 2), nproofs, colc, hq);
+        else hw_colsum_horner_msm(blockIdx.x, chunk_first, part, hq + blockIdx.x);
         return;
     }
     const uint32_t L = blockIdx.x - n_hw;
@@ -284,6 +290,7 @@ struct bpgpu_ctx {
     uint32_t W = 0;                          // fixed-base window bits; 0 = largest that fits table_budget
     uint64_t table_budget = 12ull << 30;     // bytes of HBM the generator tables may take
     uint32_t splits = 0;
+    uint32_t horner_lanes = 0;               // lanes per Horner chain in the range-proof path: 4, 64, 0 = auto (4)
     struct shared_table *tab_ref = nullptr;  // refcounted, shared by the contexts of one device
     // generators
     size_t gens_capacity = 0, party_capacity = 0;
@@ -473,6 +480,11 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
         c->splits = (uint32_t)value;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "horner_lanes")) {
+        if (value != 0 && value != 4 && value != 64) return fail(c, BPGPU_ERR_INVALID_ARG, "horner_lanes must be 0 (auto), 4 or 64");
+        c->horner_lanes = (uint32_t)value;
+        return BPGPU_OK;
+    }
     return fail(c, BPGPU_ERR_INVALID_ARG, "unknown option %s", key);
 }
 
@@ -483,6 +495,7 @@ int bpgpu_ctx_get_option(bpgpu_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "fixed_table_bytes")) *value = c->d_table ? (int64_t)table_bytes(c->prm.n_gens, c->prm.W) : 0;
     else if (!strcmp(key, "fixed_table_max_bytes")) *value = (int64_t)c->table_budget;
     else if (!strcmp(key, "fixed_splits")) *value = c->splits;
+    else if (!strcmp(key, "horner_lanes")) *value = c->horner_lanes;
     else return fail(c, BPGPU_ERR_INVALID_ARG, "unknown option %s", key);
     return BPGPU_OK;
 }
@@ -697,7 +710,7 @@ static void plan_vb(arena_plan &ap, const vb_plan &pl, size_t nbatch, size_t off
     off[3] = ap.add((size_t)pl.total * 32 + 16);
     off[4] = ap.add((size_t)pl.total * 8 * sizeof(ge_cached) + 16);
     off[5] = ap.add(pl.chunks.size() * 64 * sizeof(ge_ext) + 16);
-    off[6] = ap.add(nbatch * 64 * 128 + nbatch * sizeof(ge_ext) + 64);
+    off[6] = ap.add(nbatch * 64 * sizeof(ge_cached) + nbatch * sizeof(ge_ext) + 64);   // colq16 (128 B) or colc (160 B) per column, then hq
 }
 static void vb_bind(bpgpu_ctx *c, const size_t off[7], vb_dev &d) {
     char *a = c->arena;
@@ -720,7 +733,7 @@ static int vb_launch(bpgpu_ctx *c, hipStream_t s, uint32_t total, uint32_t n_chu
     }
     const uint32_t nc = (uint32_t)nbatch * 64;
     d.hq = (ge_ext *)(d.colq16 + (size_t)nbatch * 64 * 32);
-    LAUNCH(c, s, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, d.colq16);
+    LAUNCH(c, s, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, d.colq16, (ge_cached *)nullptr);
     LAUNCH(c, s, "horner_wave", k_horner_wave, (uint32_t)nbatch, 64, d.colq16, d.hq);
     return BPGPU_OK;
 }
@@ -765,7 +778,7 @@ static void plan_vb_uniform(arena_plan &ap, size_t nbatch, size_t per, size_t of
     off[3] = ap.add(total * 32 + 16);
     off[4] = ap.add(total * 8 * sizeof(ge_cached) + 16);
     off[5] = ap.add(n_chunks * 64 * sizeof(ge_ext) + 16);
-    off[6] = ap.add(nbatch * 64 * 128 + nbatch * sizeof(ge_ext) + 64);
+    off[6] = ap.add(nbatch * 64 * sizeof(ge_cached) + nbatch * sizeof(ge_ext) + 64);   // colq16 (128 B) or colc (160 B) per column, then hq
 }
 static int enqueue_vb_uniform(bpgpu_ctx *c, hipStream_t s, size_t nbatch, size_t per, const size_t off[7], const uint32_t *d_scalars,
                               const uint32_t *d_points, uint32_t *d_status, vb_dev &d) {
@@ -1165,8 +1178,12 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         const size_t o1 = align_up(pd->n_chunks * sizeof(vb_chunk) + 16);
         d.chunks = (vb_chunk *)pd->mem;
         d.chunk_first = (uint32_t *)(pd->mem + o1);
-        d.hq = (ge_ext *)(d.colq16 + (size_t)nbatch * 64 * 32);
+        d.hq = (ge_ext *)((char *)d.colq16 + (size_t)nbatch * 64 * sizeof(ge_cached));
     }
+    // Horner layout: quads (16 chains per wavefront, least total work) unless the caller asked for the
+    // wavefront-per-chain variant (lowest latency of a single small batch)
+    const bool quad = c->horner_lanes != 64;
+    ge_cached *d_colc = quad ? (ge_cached *)d.colq16 : nullptr;
     const uint32_t n_tr = (nb32 + RP_BLOCK - 1) / RP_BLOCK;
     const uint32_t n_pt = shape_verdict ? 0 : (nb32 * sh.U + RP_BLOCK - 1) / RP_BLOCK;
     LAUNCH(c, s, "rp_stage1", k_rp_stage1, n_tr + n_pt, RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
@@ -1181,11 +1198,22 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     }
     const uint32_t nexp = sh.nm * nb32, nwin = (uint32_t)pd->n_chunks * 64;
     const uint32_t n_win = (nwin + BP_BLOCK - 1) / BP_BLOCK, n_exp = (nexp + BP_BLOCK - 1) / BP_BLOCK;
-    LAUNCH(c, s, "rp_stage3", k_rp_stage3, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part, nexp, sh, prm, d_fields,
-           d_digits, d_status);
+    const bool one_chunk = pd->n_chunks == nbatch;   // U <= 32: a chunk's window sums are the MSM's column sums
+    LAUNCH(c, s, "rp_stage3", k_rp_stage3, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part,
+           (quad && one_chunk) ? d_colc : (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits, d_status);
+    if (quad && !one_chunk) {
+        const uint32_t nc = nb32 * 64;
+        LAUNCH(c, s, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, (uint32_t *)nullptr, d_colc);
+    }
     const uint32_t nblk_p = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
-    LAUNCH(c, s, "rp_stage4", k_rp_stage4, nb32 + nblk_p * nsplit, FB_BLOCK, nb32, d.chunk_first, d.part, d.hq, prm, nb32, nblk_p, nsplit,
-           npairs, d_ids, d_digits, c->d_table, d_partial);
+    if (quad) {
+        const uint32_t n_hw = (nb32 + 15) / 16;
+        LAUNCH(c, s, "rp_stage4", k_rp_stage4<true>, n_hw + nblk_p * nsplit, FB_BLOCK, n_hw, d.chunk_first, d.part, d_colc, d.hq, prm, nb32, nblk_p,
+               nsplit, npairs, d_ids, d_digits, c->d_table, d_partial);
+    } else {
+        LAUNCH(c, s, "rp_stage4", k_rp_stage4<false>, nb32 + nblk_p * nsplit, FB_BLOCK, nb32, d.chunk_first, d.part, (const ge_cached *)nullptr, d.hq,
+               prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, c->d_table, d_partial);
+    }
     ge_ext *d_red = nullptr;
     uint32_t nred = 0;
     enqueue_fb_reduce(c, s, nb32, nsplit, d_partial, &d_red, &nred, 64);   // 8 lanes x <= 8 partials each in finish8

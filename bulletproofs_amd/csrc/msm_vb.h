@@ -113,8 +113,10 @@ BP_HD void vb_prepare_thread(uint32_t t, const vb_chunk *chunks, const uint32_t 
 
 // ---- stage 2 ---------------------------------------------------------------
 // thread = chunk * 64 + w
+// colc (optional, only when every MSM has exactly ONE chunk): the window sum IS the column sum; it is
+// written as a cached point to colc[msm][w] (input of the quad Horner chain, horner_quad.h) instead of part.
 BP_HD void vb_window_thread(uint32_t tid, const vb_chunk *chunks, const ge_cached *tab,
-                            const uint32_t *recoded, ge_ext *part /*[chunk][64]*/) {
+                            const uint32_t *recoded, ge_ext *part /*[chunk][64]*/, ge_cached *colc = nullptr) {
     const uint32_t c = tid >> 6, w = tid & 63;
     const vb_chunk ch = chunks[c];
     ge_ext acc;
@@ -129,7 +131,13 @@ BP_HD void vb_window_thread(uint32_t tid, const vb_chunk *chunks, const ge_cache
             ge_add_cached(acc, acc, q, d < 0);
         }
     }
-    part[tid] = acc;
+    if (colc) {
+        ge_cached cc;
+        ge_to_cached(cc, acc);
+        colc[(uint64_t)ch.msm * 64 + w] = cc;
+    } else {
+        part[tid] = acc;
+    }
 }
 
 // ---- stage 3 ---------------------------------------------------------------
@@ -155,11 +163,17 @@ BP_HD void vb_encode_colq16(uint32_t *o, const ge_ext &acc) {
     fe_to_words(o + 16, cc.Z);
     fe_to_words(o + 24, cc.T2d);
 }
-BP_HD void vb_colsum_thread(uint32_t tid, const uint32_t *chunk_first, const ge_ext *part, ge_ext *col, uint32_t *colq16) {
+BP_HD void vb_colsum_thread(uint32_t tid, const uint32_t *chunk_first, const ge_ext *part, ge_ext *col, uint32_t *colq16,
+                            ge_cached *colc = nullptr) {
     ge_ext acc;
     vb_colsum_acc(acc, tid >> 6, tid & 63, chunk_first, part);
     if (col) col[tid] = acc;
     if (colq16) vb_encode_colq16(colq16 + (uint64_t)tid * 32, acc);
+    if (colc) {
+        ge_cached cc;
+        ge_to_cached(cc, acc);
+        colc[tid] = cc;
+    }
 }
 
 // ---- stage 4 ---------------------------------------------------------------

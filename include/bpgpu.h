@@ -67,6 +67,9 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
  *                           table (n_gens * ceil(256/W) * 2^(W-1) * 128 bytes) fits fixed_table_max_bytes
  *   "fixed_table_max_bytes" HBM budget of the tables (default 12 GiB; the MI355X has 288 GB)
  *   "fixed_splits"          workgroups the generator terms of one proof block are split over (0 = auto)
+ *   "horner_lanes"          lanes per Horner chain of the proof-specific terms in the range-proof path:
+ *                           4 (16 chains per wavefront: least total work, best with several batches in flight),
+ *                           64 (one wavefront per chain: lowest latency of a single small batch), 0 = auto (4)
  * get_option additionally answers "fixed_table_bytes" and the effective "fixed_window_bits".
  * Returns BPGPU_ERR_INVALID_ARG for unknown keys. */
 int bpgpu_ctx_set_option(bpgpu_ctx *ctx, const char *key, int64_t value);

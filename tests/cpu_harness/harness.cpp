@@ -8,6 +8,7 @@
 #include "../../bulletproofs_amd/csrc/msm_fixed.h"
 #include "../../bulletproofs_amd/csrc/rangeproof.h"
 #include "../../bulletproofs_amd/csrc/horner_wave.h"
+#include "../../bulletproofs_amd/csrc/horner_quad.h"
 #include "../../bulletproofs_amd/csrc/ipp.h"
 #include "../../bulletproofs_amd/csrc/scinv.h"
 #include <cstdio>
@@ -27,6 +28,15 @@ static int horner_all(uint32_t nbatch, const std::vector<ge_ext> &col, const std
         ge_ext ref; vb_horner_point(ref, col.data() + (size_t)b * 64);
         uint32_t e1[8], e2[8]; ristretto_compress(e1, hq[b]); ristretto_compress(e2, ref);
         if (memcmp(e1, e2, 32) != 0) { std::fprintf(stderr, "horner_wave mismatch at msm %u\n", b); return -99; }
+    }
+    // and the four-lane chain (horner_quad.h) from the same column sums in cached form
+    std::vector<ge_cached> colc((size_t)nbatch * 64 + 1);
+    std::vector<ge_ext> hq4(nbatch + 1);
+    for (size_t i = 0; i < (size_t)nbatch * 64; i++) ge_to_cached(colc[i], col[i]);
+    for (uint32_t b = 0; b < nbatch; b++) {
+        hq_horner_msm(b, nbatch, colc.data(), hq4.data());
+        uint32_t e1[8], e2[8]; ristretto_compress(e1, hq[b]); ristretto_compress(e2, hq4[b]);
+        if (memcmp(e1, e2, 32) != 0) { std::fprintf(stderr, "horner_quad mismatch at msm %u\n", b); return -98; }
     }
     return 0;
 }
@@ -214,6 +224,9 @@ void h_sc_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
     memcpy(out, r.v, 32);
 }
 
+static int g_horner_lanes = 4;
+void h_set_horner_lanes(int lanes) { g_horner_lanes = lanes; }
+
 // Whole verification pipeline, lane by lane, in the launch structure of the HIP runtime:
 //   launch 1: rp_transcript + rp_expand_a  ||  rp_points
 //   launch 2: rp_expand_b  ||  vb_window
@@ -266,7 +279,13 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
     }
     chunk_first[nbatch] = (uint32_t)chunks.size();
     std::vector<ge_ext> part(chunks.size() * 64 + 1), hq(nbatch + 1);
-    for (uint32_t tid = 0; tid < chunks.size() * 64; tid++) vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data());
+    const bool quad = g_horner_lanes != 64;
+    const bool one_chunk = chunks.size() == nbatch;
+    std::vector<ge_cached> colc((size_t)nbatch * 64 + 1);
+    for (uint32_t tid = 0; tid < chunks.size() * 64; tid++)
+        vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data(), (quad && one_chunk) ? colc.data() : nullptr);
+    if (quad && !one_chunk)
+        for (uint32_t tid = 0; tid < nbatch * 64; tid++) vb_colsum_thread(tid, chunk_first.data(), part.data(), nullptr, nullptr, colc.data());
     // launch 3
     std::vector<ge_ext> partial((size_t)nsplit * nbatch + 1);
     const uint32_t per = (npairs + nsplit - 1) / nsplit;
@@ -274,7 +293,10 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
         uint32_t q0 = sp * per, q1 = q0 + per < npairs ? q0 + per : npairs; if (q0 > npairs) q0 = npairs;
         for (uint32_t p = 0; p < nbatch; p++) fb_accum_thread(p, sp, q0, q1, prm, nbatch, ids.data(), digits.data(), table.data(), partial.data());
     }
-    for (uint32_t b = 0; b < nbatch; b++) hw_colsum_horner_msm(b, chunk_first.data(), part.data(), &hq[b]);
+    for (uint32_t b = 0; b < nbatch; b++) {
+        if (quad) hq_horner_msm(b, nbatch, colc.data(), hq.data());
+        else hw_colsum_horner_msm(b, chunk_first.data(), part.data(), &hq[b]);
+    }
     std::vector<uint8_t> verdict(nbatch + 1);
     // launch 4 (k_finish8): 8 lanes per proof gather, 3-level fold, lane 0 finishes
     for (uint32_t p = 0; p < nbatch; p++) {

@@ -179,9 +179,12 @@ def test_shared_generator_pipeline_lane_by_lane(H, oracle, W, nsplit):
     assert vd.raw[0] == 0 and out.raw[:32] == bytes(32)
 
 
-def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, golden):
+@pytest.mark.parametrize("horner_lanes", [4, 64])
+def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, golden, horner_lanes):
     """rp_transcript -> rp_expand_a/b -> vb_* / fb_* -> finish, emulated lane by lane, on the reference's
-    golden proofs (small shapes; the GPU tests cover all 16) plus tampered copies."""
+    golden proofs (small shapes; the GPU tests cover all 16) plus tampered copies.  Both Horner layouts:
+    4 lanes per chain (horner_quad.h) and 64 (horner_wave.h)."""
+    H.h_set_horner_lanes(horner_lanes)
     label = golden["label"]
     vc = golden["vc_bytes"]
     for case in golden["cases"]:
