@@ -2,6 +2,7 @@
 // Kernels are thin __global__ wrappers around the per-lane bodies in msm_vb.h /
 // msm_fixed.h / rangeproof.h; the bodies are shared with the CPU test harness.
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <cstdarg>
 #include <cstdio>
@@ -359,29 +360,18 @@ static hipEvent_t get_event(bpgpu_ctx *c) {
     return e;
 }
 
-struct launch_scope {
-    bpgpu_ctx *c;
-    hipStream_t s;
-    const char *name;
-    hipEvent_t a = nullptr, b = nullptr;
-    launch_scope(bpgpu_ctx *c_, hipStream_t s_, const char *n) : c(c_), s(s_), name(n) {
-        if (c->prof) {
-            a = get_event(c);
-            b = get_event(c);
-            hipEventRecord(a, s);
-        }
-    }
-    ~launch_scope() {
-        if (c->prof) {
-            hipEventRecord(b, s);
-            c->pending.emplace_back(name, a, b);
-        }
-    }
-};
-#define LAUNCH(c, s, name, kern, grid, block, ...)                        \
-    do {                                                                  \
-        launch_scope ls_(c, s, name);                                     \
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, __VA_ARGS__); \
+// Kernel launch; with profiling on, a start/stop event pair is attached to the dispatch itself
+// (hipExtLaunchKernelGGL), so the elapsed time is the kernel's own begin..end -- the timestamps rocprofv3's
+// kernel trace reports -- and excludes time spent queued behind other streams' kernels.
+#define LAUNCH(c, s, name, kern, grid, block, ...)                                                          \
+    do {                                                                                                    \
+        if ((c)->prof) {                                                                                    \
+            hipEvent_t a_ = get_event(c), b_ = get_event(c);                                                \
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, a_, b_, 0, __VA_ARGS__);             \
+            (c)->pending.emplace_back(name, a_, b_);                                                        \
+        } else {                                                                                            \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, __VA_ARGS__);                           \
+        }                                                                                                   \
     } while (0)
 
 static void drain_profile(bpgpu_ctx *c) {
