@@ -17,6 +17,7 @@ EXPORTS = [
     "bpgpu_synchronize", "bpgpu_gens_create", "bpgpu_gens_load", "bpgpu_gens_export",
     "bpgpu_msm_batch", "bpgpu_msm_batch_dev", "bpgpu_msm_batch_shared", "bpgpu_msm_batch_shared_dev",
     "bpgpu_rangeproof_verify_batch", "bpgpu_rangeproof_verify_batch_dev", "bpgpu_ipp_verify_batch",
+    "bpgpu_rangeproof_verify_rlc", "bpgpu_rangeproof_verify_rlc_dev",
     "bpgpu_profile_enable", "bpgpu_profile_reset", "bpgpu_profile_report",
 ]
 
@@ -63,6 +64,8 @@ def lib():
     L.bpgpu_msm_batch_shared_dev.argtypes = [vp, sz, sz, sz, sz, vp, vp, vp, vp, vp, vp]
     L.bpgpu_rangeproof_verify_batch.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p]
     L.bpgpu_rangeproof_verify_batch_dev.argtypes = [vp, sz, sz, sz, vp, sz, vp, u8p, sz, vp, vp, vp, vp]
+    L.bpgpu_rangeproof_verify_rlc.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p, u8p]
+    L.bpgpu_rangeproof_verify_rlc_dev.argtypes = [vp, sz, sz, sz, vp, sz, vp, u8p, sz, vp, vp, vp, vp, vp]
     L.bpgpu_ipp_verify_batch.argtypes = [vp, sz, sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.bpgpu_profile_enable.argtypes = [vp, i]
     L.bpgpu_profile_reset.argtypes = [vp]
@@ -163,6 +166,19 @@ class Context:
         self._chk(self._L.bpgpu_rangeproof_verify_batch(self.h, n, m, nb, proofs, proof_len, commitments, label, len(label),
                                                         rng64, verdict, msm))
         return (verdict.raw[:nb], msm.raw[:32 * nb]) if want_msm else verdict.raw[:nb]
+
+    def rangeproof_verify_rlc(self, n, m, proofs, proof_len, commitments, label, rng64=None, weights64=None):
+        """Batch-combined verification (include/bpgpu.h): returns (verdict bytes, batch_ok, 32-byte encoding of the
+        combined point).  On a failing combination the verdicts come from the per-proof path (automatic fallback)."""
+        nb = len(proofs) // proof_len if proof_len else 0
+        assert len(proofs) == nb * proof_len and len(commitments) == 32 * m * nb
+        assert rng64 is None or len(rng64) == 64 * nb
+        assert weights64 is None or len(weights64) == 64 * nb
+        verdict = C.create_string_buffer(max(nb, 1))
+        bo = C.create_string_buffer(33)
+        self._chk(self._L.bpgpu_rangeproof_verify_rlc(self.h, n, m, nb, proofs, proof_len, commitments, label, len(label),
+                                                      rng64, weights64, verdict, bo))
+        return verdict.raw[:nb], bo.raw[0] == 0, bo.raw[1:33]
 
     # ---- stand-alone inner-product proofs ----
     def ipp_verify_batch(self, n, proofs, proof_len, label, Gf, Hf, P, Q, G, H, want_msm=False):

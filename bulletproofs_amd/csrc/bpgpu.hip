@@ -17,6 +17,7 @@
 #include "msm_vb.h"
 #include "horner_wave.h"
 #include "horner_quad.h"
+#include "rlc.h"
 #include "rangeproof.h"
 #include "ipp.h"
 
@@ -160,7 +161,7 @@ __global__ void __launch_bounds__(64) k_finish8(uint32_t nproofs, uint32_t nspli
 __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs,
                                                          const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields,
                                                          ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m,
-                                                         uint32_t *recoded, uint16_t *digits) {
+                                                         uint32_t *recoded, uint16_t *digits, const uint8_t *rho64) {
     __shared__ uint32_t lds[50 * RP_BLOCK];   // sponge states, word-major: word w of lane t at w*RP_BLOCK + t
     if (blockIdx.x < n_tr) {
         const uint32_t p = blockIdx.x * RP_BLOCK + threadIdx.x;
@@ -169,7 +170,7 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1(rp_shape sh, rp_strobe_i
         st.stride = RP_BLOCK;
         if (p < sh.nproofs) {
             rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields, status);
-            if (!sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status);
+            if (!sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64);
         }
     } else {
         const uint32_t t = (blockIdx.x - n_tr) * RP_BLOCK + threadIdx.x;
@@ -219,6 +220,150 @@ __global__ void __launch_bounds__(FB_BLOCK) k_rp_stage4(uint32_t n_hw, const uin
     const uint32_t per = (npairs + nsplit - 1) / nsplit;
     const uint32_t q0 = split * per, q1 = (q0 + per < npairs) ? q0 + per : npairs;
     if (p < nproofs) fb_accum_thread(p, split, q0 < npairs ? q0 : npairs, q1, prm, nproofs, gen_ids, digits, table, partial);
+}
+
+// ---- batch combination (rlc.h) --------------------------------------------------------------------------
+// sum over the wavefront of a value below 2^28 per lane: four DPP prefix steps inside each row of 16 lanes
+// (row sums < 2^32), then the four row totals are read to scalars and added in 64 bits
+__device__ __forceinline__ uint64_t wave_sum_u28(uint32_t x) {
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   // row_shr:1, zero fill
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   // row_shr:2
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   // row_shr:4
+    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   // row_shr:8
+    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)x, 15) + (uint32_t)__builtin_amdgcn_readlane((int)x, 31) +
+           (uint32_t)__builtin_amdgcn_readlane((int)x, 47) + (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+// add one scalar per lane into the batch accumulator of generator row `row` (ten 64-bit limb sums).
+// uniform: all 64 lanes of the wavefront hold contributions to the SAME row -> one atomic per limb per wavefront
+__device__ __forceinline__ void rlc_accumulate(unsigned long long *acc, uint32_t row, const sc &v, bool active, bool uniform) {
+    uint64_t l[10];
+    rlc_limbs(l, v);
+    if (uniform) {
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            const uint64_t t = wave_sum_u28(active ? (uint32_t)l[i] : 0u);
+            if (__lane_id() == 0) atomicAdd(acc + (uint64_t)row * 10 + i, (unsigned long long)t);
+        }
+    } else if (active) {
+#pragma unroll
+        for (int i = 0; i < 10; i++) atomicAdd(acc + (uint64_t)row * 10 + i, (unsigned long long)l[i]);
+    }
+}
+
+// launch 2 of the combined mode: [0, n_win) window sums of the proof-specific points (rejected proofs skipped)
+// ||  the weighted generator coefficients, summed over the batch into acc[row][10]
+__global__ void __launch_bounds__(BP_BLOCK) k_rlc_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab,
+                                                          const uint32_t *recoded, ge_ext *part, uint32_t nthreads_exp, rp_shape sh,
+                                                          fb_params prm, const uint32_t *fields, const uint32_t *status,
+                                                          unsigned long long *acc, int uniform) {
+    if (blockIdx.x < n_win) {
+        const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
+        if (tid < nthreads_win) vb_window_thread(tid, chunks, tab, recoded, part, nullptr, status);
+        return;
+    }
+    const uint32_t tid = (blockIdx.x - n_win) * BP_BLOCK + threadIdx.x;
+    const bool valid = tid < nthreads_exp;
+    const uint32_t B = sh.nproofs;
+    const uint32_t i = valid ? tid / B : 0, p = valid ? tid - i * B : 0;
+    sc g, h;
+    sc_0(g);
+    sc_0(h);
+    if (valid) rp_expand_b_thread(tid, sh, prm, fields, nullptr, status, &g, &h);
+    rlc_accumulate(acc, 2 + i, g, valid, uniform != 0);
+    rlc_accumulate(acc, 2 + sh.nm + i, h, valid, uniform != 0);
+    // the B_blinding (row 0) and B (row 1) coefficients were left in the ROW0/ROW1 fields by launch 1; the lanes
+    // of generator index 0 / 1 add them (a proof rejected since then contributes nothing)
+    const bool row_lane = valid && i < 2;
+    if (!uniform || i < 2) {   // uniform mode: i is the same in all 64 lanes, so whole wavefronts take this branch
+        sc r;
+        sc_0(r);
+        if (row_lane && status[p] == 0) rp_load(r, fields, B, RPF_ROW0 + i, p);
+        rlc_accumulate(acc, i, r, row_lane, uniform != 0);
+    }
+}
+
+// (k_rlc_colsum_scalars below runs this as the second role of the last column-sum launch)
+// lane g: reduce the accumulated coefficient of generator row g mod l, recode it for the table walk (batch of 1)
+// (lane 0 also initialises the small control block of the batch-of-one tail: verdict byte, a zero status word and
+// the chunk bounds {0, rows} of the final column sums)
+__device__ __forceinline__ void rlc_scalars_lane(uint32_t g, uint32_t n_rows, const unsigned long long *acc, uint16_t *digits, fb_params prm,
+                                                 uint32_t *ctl, uint32_t rows) {
+    if (g == 0) {
+        ctl[0] = 0;
+        ctl[1] = 0;
+        ctl[2] = 0;
+        ctl[3] = rows;
+    }
+    if (g >= n_rows) return;
+    uint64_t a[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) a[i] = acc[(uint64_t)g * 10 + i];
+    sc v;
+    rlc_acc_to_sc(v, a);
+    fb_recode(digits + (uint64_t)g * prm.nwin, 1, v.v, prm);
+}
+// one level of the column-sum tree (blocks [0, n_red))  ||  the combined generator coefficients
+__global__ void __launch_bounds__(BP_BLOCK) k_rlc_colsum_scalars(uint32_t n_red, uint32_t nthreads, uint32_t rows_in, uint32_t group,
+                                                                  const ge_ext *in, ge_ext *out, uint32_t n_rows, const unsigned long long *acc,
+                                                                  uint16_t *digits, fb_params prm, uint32_t *ctl, uint32_t rows_out) {
+    if (blockIdx.x < n_red) {
+        const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
+        if (tid < nthreads) fb_reduce_thread(tid, 64, rows_in, group, in, out);
+    } else {
+        rlc_scalars_lane((blockIdx.x - n_red) * BP_BLOCK + threadIdx.x, n_rows, acc, digits, prm, ctl, rows_out);
+    }
+}
+
+// Tail of the combined check, ONE wavefront: the 64 lanes add up the batch-of-one table walk's partial points
+// (and the Horner result), fold them through LDS, lane 0 tests the identity (WITH_OUT: and encodes R); then
+// every proof's verdict is written: the front end's status if set, else 0 when R is the identity, UNDECIDED
+// otherwise.  Status words are handed back zeroed.
+template <bool WITH_OUT>
+__global__ void __launch_bounds__(64) k_rlc_finish(uint32_t nsplit, const ge_ext *hq, const ge_ext *partial, uint32_t nproofs, uint32_t *status,
+                                                    uint8_t *verdict, uint8_t *batch_out) {
+    __shared__ ge_ext xch[64];
+    __shared__ uint32_t res[9];
+    const uint32_t lane = threadIdx.x;
+    ge_ext acc;
+    bool have = false;
+    for (uint32_t sp = lane; sp < nsplit; sp += 64) {
+        const ge_ext q = partial[sp];
+        if (have) ge_add(acc, acc, q);
+        else acc = q;
+        have = true;
+    }
+    if (lane == 63) {
+        const ge_ext q = hq[0];
+        if (have) ge_add(acc, acc, q);
+        else acc = q;
+        have = true;
+    }
+    if (!have) ge_identity(acc);
+#pragma unroll 1
+    for (uint32_t step = 32; step >= 1; step >>= 1) {
+        xch[lane] = acc;
+        __syncthreads();
+        if (lane < step) {
+            const ge_ext q = xch[lane + step];
+            ge_add(acc, acc, q);
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        const uint32_t zero = 0;
+        uint8_t bv = 0;
+        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        shared_finish_tail(0, acc, &zero, WITH_OUT ? w : nullptr, &bv);
+        res[8] = bv;
+        for (int i = 0; i < 8; i++) res[i] = w[i];
+    }
+    __syncthreads();
+    const uint8_t bv = (uint8_t)res[8];
+    for (uint32_t p = lane; p < nproofs; p += 64) {
+        verdict[p] = status[p] ? (uint8_t)status[p] : (bv ? (uint8_t)BP_VERDICT_UNDECIDED : (uint8_t)0);
+        status[p] = 0;
+    }
+    if (WITH_OUT && lane < 33) batch_out[lane] = lane == 0 ? bv : (uint8_t)(res[(lane - 1) >> 2] >> (8 * ((lane - 1) & 3)));
 }
 
 // verdict[p] = status (Format / shape / Verification) if set, else the identity test of the mega-check
@@ -1066,8 +1211,14 @@ static void make_strobe_init(rp_strobe_init &init, const uint8_t *label, size_t 
 
 static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
                                 const void *d_commitments, const uint8_t *label, size_t label_len, const void *d_rng64, void *d_verdict,
-                                void *d_msm_out, hipStream_t s) {
-    if (nbatch == 0) return BPGPU_OK;
+                                void *d_msm_out, hipStream_t s, bool rlc = false, const void *d_weights64 = nullptr,
+                                void *d_batch_out = nullptr) {
+    // rlc: batch-combination mode (bpgpu_rangeproof_verify_rlc[_dev]); d_msm_out is unused then, d_batch_out
+    // (33 bytes, optional) receives the batch verdict and the encoding of the combined point
+    if (nbatch == 0) {
+        if (rlc && d_batch_out) HIPCHK(c, hipMemsetAsync(d_batch_out, 0, 33, s));
+        return BPGPU_OK;
+    }
     if (!c->d_table) return fail(c, BPGPU_ERR_NO_GENS, "generators not loaded");
     if (nbatch > 0x7fffffffu / 64) return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large");
     // ---- length-only part of RangeProof::from_bytes / InnerProductProof::from_bytes (mod.rs:505-510, ipp.rs:374-388)
@@ -1085,6 +1236,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     if (all_verdict) {   // every proof of the batch has the same malformed length
         HIPCHK(c, hipMemsetAsync(d_verdict, (int)all_verdict, nbatch, s));
         if (d_msm_out) HIPCHK(c, hipMemsetAsync(d_msm_out, 0, nbatch * 32, s));
+        if (rlc && d_batch_out) HIPCHK(c, hipMemsetAsync(d_batch_out, 0, 33, s));   // nothing to combine
         return BPGPU_OK;
     }
     // ---- parameter checks of verify_multiple_with_rng (mod.rs:358-366), reported per proof AFTER its format check
@@ -1124,6 +1276,16 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const size_t off_fields = ap.add((size_t)fl.count * nbatch * BP_RP_REC * 4 + 16);
     const size_t off_mv = ap.add(nbatch);
     const size_t off_rng = ap.add(nbatch * 64);
+    // batch-combination mode: weights, coefficient accumulators, the column-sum reduction tree, and a batch-of-one
+    // table walk (digits, partial sums, result)
+    const uint32_t nsplit1 = rlc ? pick_splits(c, 1, npairs) : 0;
+    const size_t n_rows0 = shape_verdict ? 0 : nbatch * ((sh.U + BP_VB_CHUNK - 1) / BP_VB_CHUNK);
+    const size_t off_wts = rlc ? ap.add(nbatch * 64) : 0;
+    const size_t off_acc = rlc ? ap.add((size_t)n_gen_terms * 10 * 8) : 0;
+    const size_t off_tree = rlc ? ap.add((n_rows0 / 8 + 64) * 64 * sizeof(ge_ext)) : 0;
+    const size_t off_dig1 = rlc ? ap.add((size_t)npairs * 2 + 16) : 0;
+    const size_t off_part1 = rlc ? ap.add((size_t)2 * nsplit1 * sizeof(ge_ext) + 16) : 0;
+    const size_t off_res1 = rlc ? ap.add(sizeof(ge_ext) + 64) : 0;   // Horner result, then 8 result words, verdict byte, chunk bounds
     rc = arena_reserve(c, ap.total);
     if (rc) return rc;
     char *a = c->arena;
@@ -1153,6 +1315,19 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         HIPCHK(c, hipStreamSynchronize(s));   // h goes out of scope
         rng_ptr = (const uint8_t *)(a + off_rng);
     }
+    const uint8_t *wts_ptr = (const uint8_t *)d_weights64;
+    if (rlc && !wts_ptr) {   // the combination weights must be unpredictable to the prover: OS CSPRNG
+        std::vector<uint8_t> h(nbatch * 64);
+        size_t got = 0;
+        while (got < h.size()) {
+            const ssize_t r = getrandom(h.data() + got, h.size() - got, 0);
+            if (r <= 0) return fail(c, BPGPU_ERR_HIP, "getrandom failed");
+            got += (size_t)r;
+        }
+        HIPCHK(c, hipMemcpyAsync(a + off_wts, h.data(), h.size(), hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipStreamSynchronize(s));
+        wts_ptr = (const uint8_t *)(a + off_wts);
+    }
     if (c->rp_status_dirty) HIPCHK(c, hipMemsetAsync(d_status, 0, c->rp_status_cap * 4, s));
     c->rp_status_dirty = true;   // until the kernel that resets the words has been enqueued
     rp_strobe_init init;
@@ -1177,17 +1352,60 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const uint32_t n_tr = (nb32 + RP_BLOCK - 1) / RP_BLOCK;
     const uint32_t n_pt = shape_verdict ? 0 : (nb32 * sh.U + RP_BLOCK - 1) / RP_BLOCK;
     LAUNCH(c, s, "rp_stage1", k_rp_stage1, n_tr + n_pt, RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
-           (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, d.recoded, d_digits);
+           (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, d.recoded, d_digits,
+           rlc ? wts_ptr : (const uint8_t *)nullptr);
     if (shape_verdict) {
         HIPCHK(c, hipMemsetAsync(d_mv, 1, nbatch, s));
         LAUNCH(c, s, "rp_verdict", k_rp_verdict, (nb32 + 63) / 64, 64, nb32, d_status, d_mv, (uint8_t *)d_verdict);
         if (d_msm_out) HIPCHK(c, hipMemsetAsync(d_msm_out, 0, nbatch * 32, s));
+        if (rlc && d_batch_out) HIPCHK(c, hipMemsetAsync(d_batch_out, 0, 33, s));
         HIPCHK(c, hipGetLastError());
         c->rp_status_dirty = false;
         return BPGPU_OK;
     }
     const uint32_t nexp = sh.nm * nb32, nwin = (uint32_t)pd->n_chunks * 64;
     const uint32_t n_win = (nwin + BP_BLOCK - 1) / BP_BLOCK, n_exp = (nexp + BP_BLOCK - 1) / BP_BLOCK;
+    if (rlc) {
+        // ---- batch combination (rlc.h): R = sum_i rho_i MegaCheck_i ---------------------------------------
+        unsigned long long *d_acc = (unsigned long long *)(a + off_acc);
+        HIPCHK(c, hipMemsetAsync(d_acc, 0, (size_t)n_gen_terms * 10 * 8, s));
+        LAUNCH(c, s, "rlc_stage3", k_rlc_stage3, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part, nexp, sh, prm,
+               d_fields, d_status, d_acc, (nbatch % 64 == 0) ? 1 : 0);
+        // column sums over ALL chunks of ALL proofs: rows of 64 window sums, tree-added 16- then 8-way until <= 8 rows
+        // remain; the Horner wavefront adds those itself
+        uint16_t *d_dig1 = (uint16_t *)(a + off_dig1);
+        ge_ext *d_part1 = (ge_ext *)(a + off_part1), *d_hq1 = (ge_ext *)(a + off_res1);
+        uint32_t *d_ctl = (uint32_t *)(a + off_res1 + sizeof(ge_ext));   // [0] unused, [1] zero, [2..4) chunk bounds {0, rows}
+        ge_ext *cur = d.part, *next = (ge_ext *)(a + off_tree);
+        uint32_t rows = (uint32_t)pd->n_chunks;
+        bool scalars_done = false;
+        const uint32_t n_sc = (n_gen_terms + BP_BLOCK - 1) / BP_BLOCK;
+        while (rows > 8) {
+            const uint32_t group = rows > 64 ? 16 : 8, ng = (rows + group - 1) / group, nt = ng * 64;
+            if (ng <= 8) {   // last level: shares its launch with the coefficient reduction
+                LAUNCH(c, s, "rlc_colsum", k_rlc_colsum_scalars, (nt + BP_BLOCK - 1) / BP_BLOCK + n_sc, BP_BLOCK, (nt + BP_BLOCK - 1) / BP_BLOCK, nt, rows,
+                       group, (const ge_ext *)cur, next, n_gen_terms, (const unsigned long long *)d_acc, d_dig1, prm, d_ctl, ng);
+                scalars_done = true;
+            } else {
+                LAUNCH(c, s, "rlc_colsum", k_fb_reduce, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, 64u, rows, group, cur, next);
+            }
+            cur = next;
+            next = next + (size_t)ng * 64;
+            rows = ng;
+        }
+        if (!scalars_done)
+            LAUNCH(c, s, "rlc_colsum", k_rlc_colsum_scalars, n_sc, BP_BLOCK, 0u, 0u, 0u, 1u, (const ge_ext *)cur, next, n_gen_terms,
+                   (const unsigned long long *)d_acc, d_dig1, prm, d_ctl, rows);
+        LAUNCH(c, s, "rlc_stage4", k_rp_stage4<false>, 1 + nsplit1, FB_BLOCK, 1u, d_ctl + 2, cur, (const ge_cached *)nullptr, d_hq1, prm, 1u, 1u,
+               nsplit1, npairs, d_ids, d_dig1, c->d_table, d_part1);
+        if (d_batch_out)
+            LAUNCH(c, s, "rlc_finish", k_rlc_finish<true>, 1, 64, nsplit1, d_hq1, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)d_batch_out);
+        else
+            LAUNCH(c, s, "rlc_finish", k_rlc_finish<false>, 1, 64, nsplit1, d_hq1, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)nullptr);
+        HIPCHK(c, hipGetLastError());
+        c->rp_status_dirty = false;
+        return BPGPU_OK;
+    }
     const bool one_chunk = pd->n_chunks == nbatch;   // U <= 32: a chunk's window sums are the MSM's column sums
     LAUNCH(c, s, "rp_stage3", k_rp_stage3, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part,
            (quad && one_chunk) ? d_colc : (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits, d_status);
@@ -1257,6 +1475,67 @@ extern "C" int bpgpu_rangeproof_verify_batch(bpgpu_ctx *c, size_t n, size_t m, s
             rc = fail(c, BPGPU_ERR_HIP, "D2H copy / sync failed: %s", hipGetErrorString(hipGetLastError()));
             break;
         }
+    } while (0);
+    hipStreamSynchronize(s);
+    hipFree(d_io);
+    return rc;
+}
+
+// ---- batch combination entry points (rlc.h; SURVEY 8f-3, additional to the reference's API) ---------------
+extern "C" int bpgpu_rangeproof_verify_rlc_dev(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
+                                               const void *d_commitments, const uint8_t *label, size_t label_len, const void *d_rng64,
+                                               const void *d_weights64, void *d_verdict, void *d_batch_out, void *stream) {
+    if (!c || (nbatch && (!d_proofs || !d_verdict || (m && !d_commitments))) || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
+    if (((uintptr_t)d_proofs | (uintptr_t)d_commitments | (uintptr_t)d_rng64 | (uintptr_t)d_weights64) & 3)
+        return fail(c, BPGPU_ERR_INVALID_ARG, "device pointers must be 4-byte aligned");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return rp_verify_dev_locked(c, n, m, nbatch, d_proofs, proof_len, d_commitments, label, label_len, d_rng64, d_verdict, nullptr,
+                                stream ? (hipStream_t)stream : c->stream, true, d_weights64, d_batch_out);
+}
+
+extern "C" int bpgpu_rangeproof_verify_rlc(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len,
+                                           const uint8_t *commitments, const uint8_t *label, size_t label_len, const uint8_t *rng64,
+                                           const uint8_t *weights64, uint8_t *verdict, uint8_t *batch_out) {
+    if (!c || (nbatch && (!proofs || !verdict || (m && !commitments))) || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0) {
+        if (batch_out) memset(batch_out, 0, 33);
+        return BPGPU_OK;
+    }
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t sz_p = align_up(nbatch * proof_len + 64), sz_c = align_up(nbatch * m * 32 + 64), sz_r = align_up(nbatch * 64),
+                 sz_v = align_up(nbatch), sz_o = align_up(64);
+    char *d_io = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d_io, sz_p + sz_c + 2 * sz_r + sz_v + sz_o));
+    char *d_p = d_io, *d_c = d_p + sz_p, *d_r = d_c + sz_c, *d_w = d_r + sz_r, *d_v = d_w + sz_r, *d_o = d_v + sz_v;
+    hipStream_t s = c->stream;
+    int rc = BPGPU_OK;
+    uint8_t bo[33];
+    do {
+        if (hipMemcpyAsync(d_p, proofs, nbatch * proof_len, hipMemcpyHostToDevice, s) != hipSuccess ||
+            (m && hipMemcpyAsync(d_c, commitments, nbatch * m * 32, hipMemcpyHostToDevice, s) != hipSuccess) ||
+            (rng64 && hipMemcpyAsync(d_r, rng64, nbatch * 64, hipMemcpyHostToDevice, s) != hipSuccess) ||
+            (weights64 && hipMemcpyAsync(d_w, weights64, nbatch * 64, hipMemcpyHostToDevice, s) != hipSuccess)) {
+            rc = fail(c, BPGPU_ERR_HIP, "H2D copy failed");
+            break;
+        }
+        rc = rp_verify_dev_locked(c, n, m, nbatch, d_p, proof_len, d_c, label, label_len, rng64 ? d_r : nullptr, d_v, nullptr, s, true,
+                                  weights64 ? d_w : nullptr, d_o);
+        if (rc) break;
+        if (hipMemcpyAsync(bo, d_o, 33, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(c, BPGPU_ERR_HIP, "D2H copy / sync failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+        if (bo[0] != 0) {   // the combination is not the identity: some proof fails -- find out which, proof by proof
+            rc = rp_verify_dev_locked(c, n, m, nbatch, d_p, proof_len, d_c, label, label_len, rng64 ? d_r : nullptr, d_v, nullptr, s);
+            if (rc) break;
+        }
+        if (hipMemcpyAsync(verdict, d_v, nbatch, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
+            rc = fail(c, BPGPU_ERR_HIP, "D2H copy / sync failed: %s", hipGetErrorString(hipGetLastError()));
+            break;
+        }
+        if (batch_out) memcpy(batch_out, bo, 33);
     } while (0);
     hipStreamSynchronize(s);
     hipFree(d_io);

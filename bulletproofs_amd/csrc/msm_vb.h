@@ -115,13 +115,17 @@ BP_HD void vb_prepare_thread(uint32_t t, const vb_chunk *chunks, const uint32_t 
 // thread = chunk * 64 + w
 // colc (optional, only when every MSM has exactly ONE chunk): the window sum IS the column sum; it is
 // written as a cached point to colc[msm][w] (input of the quad Horner chain, horner_quad.h) instead of part.
+// skip_status (optional): MSMs whose status word is set contribute the identity (batch-combination mode,
+// where the window sums of all proofs are added together afterwards).
 BP_HD void vb_window_thread(uint32_t tid, const vb_chunk *chunks, const ge_cached *tab,
-                            const uint32_t *recoded, ge_ext *part /*[chunk][64]*/, ge_cached *colc = nullptr) {
+                            const uint32_t *recoded, ge_ext *part /*[chunk][64]*/, ge_cached *colc = nullptr,
+                            const uint32_t *skip_status = nullptr) {
     const uint32_t c = tid >> 6, w = tid & 63;
     const vb_chunk ch = chunks[c];
     ge_ext acc;
     ge_identity(acc);
-    for (uint32_t k = 0; k < ch.count; k++) {
+    const uint32_t count = (skip_status && skip_status[ch.msm] != 0) ? 0u : ch.count;
+    for (uint32_t k = 0; k < count; k++) {
         const uint64_t t = (uint64_t)ch.first + k;
         const uint32_t word = recoded[8 * t + (w >> 3)];
         const int d = (int)((word >> ((w & 7) * 4)) & 15u) - 8;

@@ -46,6 +46,7 @@ enum {
     RPF_ZZ,            // z^2
     RPF_MINUS_Z,
     RPF_A_M, RPF_B_M, RPF_Z_M, RPF_ZZ_M,   // Montgomery forms used by expand_b
+    RPF_ROW0, RPF_ROW1,                    // weighted B_blinding / B coefficients (batch-combination mode only)
     RPF_FIXED_COUNT
 };
 struct rp_fields {
@@ -273,17 +274,40 @@ BP_HD void store_recoded(uint32_t *dst, const sc &s) {
     for (int q = 0; q < 8; q++) dst[q] = r[q];
 }
 
+// a coefficient held in Montgomery form -> (times the proof's batch weight, if any) -> radix-16 recoding
+BP_HD void rp_emit_coeff(uint32_t *dst, const sc28 &vm, const sc28 *rho_m) {
+    sc28 t = vm;
+    if (rho_m) sc28_montmul(t, vm, *rho_m);
+    sc s;
+    sc_from_mont28(s, t);
+    store_recoded(dst, s);
+}
+
 // ---- stage 2: per-proof scalars -----------------------------------------------------------
 // thread p.  Writes the radix-16 recodings of the U per-proof coefficients (recoded[p][U][8], order of
 // rp_unique_point_ptr), the Montgomery-form tables for stage 3, and the digits of the B_blinding (row 0) and
 // B (row 1) coefficients.
+// rho64 (optional): batch-combination mode (bpgpu_rangeproof_verify_rlc): every coefficient of proof p is
+// multiplied by its weight rho_p = from_bytes_mod_order_wide(rho64[p]); the B_blinding / B coefficients go to
+// the ROW0 / ROW1 fields instead of `digits` (they are summed over the batch in the next launch).
 BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t lg_m, uint32_t *fields, uint32_t *recoded,
-                              uint16_t *digits, const uint32_t *status) {
+                              uint16_t *digits, const uint32_t *status, const uint8_t *rho64 = nullptr) {
     if (status[p] != 0) return;   // digits/scalars of rejected proofs are never consumed (finish masks them)
     const uint32_t B = sh.nproofs, k = sh.k;
     const rp_fields fl = rp_field_layout(k, sh.m);
-    sc one, t0, t1;
-    sc_from_u32(one, 1);
+    sc t0, t1;
+    sc28 rho_m;
+    const sc28 *rho = nullptr;
+    if (rho64) {
+        uint32_t w16[16];
+        const uint32_t *src = (const uint32_t *)(rho64 + 64 * (uint64_t)p);
+#pragma unroll
+        for (int i = 0; i < 16; i++) w16[i] = src[i];
+        sc r;
+        sc_from_wide(r, w16);
+        sc_to_mont28(rho_m, r);
+        rho = &rho_m;
+    }
     sc28 ym;
     {
         sc y;
@@ -313,11 +337,9 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
         sc28_montmul(inv, inv, um);                       // drop u_ii from the running inverse
         rp_store28(fields, B, fl.uinv_m + ii, p, uim);
         sc28_montmul(sq, um, um);                         // u_i^2   -> L_i coefficient
-        sc_from_mont28(t0, sq);
-        store_recoded(us + (4 + ii) * 8, t0);
+        rp_emit_coeff(us + (4 + ii) * 8, sq, rho);
         sc28_montmul(sq, uim, uim);                       // u_i^-2  -> R_i coefficient
-        sc_from_mont28(t0, sq);
-        store_recoded(us + (4 + k + ii) * 8, t0);
+        rp_emit_coeff(us + (4 + k + ii) * 8, sq, rho);
     }
     // what is left in inv is y^-1: table of y^-(2^b)
     {
@@ -352,29 +374,50 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
     sc_from_mont28(zz, zzm);
     sc_neg(minus_z, z);
     rp_store(fields, B, RPF_ZZ, p, zz);
-    rp_store(fields, B, RPF_MINUS_Z, p, minus_z);
-    rp_store28(fields, B, RPF_A_M, p, am);
-    rp_store28(fields, B, RPF_B_M, p, bm);
     rp_store28(fields, B, RPF_Z_M, p, zm);
     rp_store28(fields, B, RPF_ZZ_M, p, zzm);
+    if (rho) {   // what stage 3 reads (z, -z, a, b, z^2 z^j) carries the weight; g_i and h_i are linear in them
+        sc28 t;
+        sc zr;
+        sc28_montmul(t, zm, rho_m);
+        sc_from_mont28(zr, t);
+        sc_neg(minus_z, zr);
+        rp_store(fields, B, RPF_Z, p, zr);
+        rp_store(fields, B, RPF_MINUS_Z, p, minus_z);
+        sc28_montmul(t, am, rho_m);
+        rp_store28(fields, B, RPF_A_M, p, t);
+        sc28_montmul(t, bm, rho_m);
+        rp_store28(fields, B, RPF_B_M, p, t);
+    } else {
+        rp_store(fields, B, RPF_MINUS_Z, p, minus_z);
+        rp_store28(fields, B, RPF_A_M, p, am);
+        rp_store28(fields, B, RPF_B_M, p, bm);
+    }
     // unique coefficients: 1, x, c x, c x^2 (A, S, T_1, T_2)
     sc28 cxm, cxxm;
     sc28_montmul(cxm, cm, xm);
     sc28_montmul(cxxm, cxm, xm);
-    store_recoded(us + 0 * 8, one);
-    store_recoded(us + 1 * 8, x);
-    sc_from_mont28(t0, cxm);
-    store_recoded(us + 2 * 8, t0);
-    sc_from_mont28(t0, cxxm);
-    store_recoded(us + 3 * 8, t0);
+    {
+        sc28 one_m;
+        sc28_one_mont(one_m);
+        rp_emit_coeff(us + 0 * 8, one_m, rho);
+    }
+    rp_emit_coeff(us + 1 * 8, xm, rho);
+    rp_emit_coeff(us + 2 * 8, cxm, rho);
+    rp_emit_coeff(us + 3 * 8, cxxm, rho);
     // V_j coefficients c z^2 z^j, and the z^2 z^j table
     {
         sc28 czzj, zzj = zzm;
         sc28_montmul(czzj, cm, zzm);
         for (uint32_t j = 0; j < sh.m; j++) {
-            sc_from_mont28(t0, czzj);
-            store_recoded(us + (4 + 2 * k + j) * 8, t0);
-            rp_store28(fields, B, fl.zzzj_m + j, p, zzj);
+            rp_emit_coeff(us + (4 + 2 * k + j) * 8, czzj, rho);
+            if (rho) {
+                sc28 t;
+                sc28_montmul(t, zzj, rho_m);
+                rp_store28(fields, B, fl.zzzj_m + j, p, t);
+            } else {
+                rp_store28(fields, B, fl.zzzj_m + j, p, zzj);
+            }
             sc28_montmul(czzj, czzj, zm);
             sc28_montmul(zzj, zzj, zm);
         }
@@ -386,7 +429,15 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
         sc_from_mont28(t0, pm);
         sc_add(t0, t0, eb);
         sc_neg(t0, t0);
-        fb_recode(digits + ((uint64_t)0 * prm.nwin) * B + p, B, t0.v, prm);
+        if (rho) {
+            sc28 t;
+            sc_to_mont28(t, t0);
+            sc28_montmul(t, t, rho_m);
+            sc_from_mont28(t0, t);
+            rp_store(fields, B, RPF_ROW0, p, t0);
+        } else {
+            fb_recode(digits + ((uint64_t)0 * prm.nwin) * B + p, B, t0.v, prm);
+        }
     }
     // B coefficient: w (t_x - a b) + c (delta(y,z) - t_x)  (row 1)
     {
@@ -423,16 +474,30 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
         sc28_montmul(pm, cm, pm);
         sc_from_mont28(t1, pm);                               // c (delta - t_x)
         sc_add(t0, t0, t1);
-        fb_recode(digits + ((uint64_t)1 * prm.nwin) * B + p, B, t0.v, prm);
+        if (rho) {
+            sc28 t;
+            sc_to_mont28(t, t0);
+            sc28_montmul(t, t, rho_m);
+            sc_from_mont28(t0, t);
+            rp_store(fields, B, RPF_ROW1, p, t0);
+        } else {
+            fb_recode(digits + ((uint64_t)1 * prm.nwin) * B + p, B, t0.v, prm);
+        }
     }
 }
 
 // ---- stage 3: per-(generator, proof) scalars -------------------------------------------------
 // thread tid = i * nproofs + p, i < nm: digits of g_i (row 2 + i) and h_i (row 2 + nm + i)
+// g_out / h_out (optional, batch-combination mode): the two coefficients are returned (zero for a rejected
+// proof) instead of being recoded into `digits`.
 BP_HD void rp_expand_b_thread(uint32_t tid, rp_shape sh, fb_params prm, const uint32_t *fields, uint16_t *digits,
-                              const uint32_t *status) {
+                              const uint32_t *status, sc *g_out = nullptr, sc *h_out = nullptr) {
     const uint32_t B = sh.nproofs, k = sh.k;
     const uint32_t i = tid / B, p = tid - i * B;
+    if (g_out) {
+        sc_0(*g_out);
+        sc_0(*h_out);
+    }
     if (status[p] != 0) return;
     const rp_fields fl = rp_field_layout(k, sh.m);
     // s_i = prod_b (bit_b(i) ? u : u^-1)[k-1-b]  (ipp.rs:241-250), and its inverse s_{nm-1-i}
@@ -467,7 +532,8 @@ BP_HD void rp_expand_b_thread(uint32_t tid, rp_shape sh, fb_params prm, const ui
     sc28_montmul(t, a_m, s);
     sc_from_mont28(v, t);
     sc_sub(g, minus_z, v);
-    fb_recode(digits + ((uint64_t)(2 + i) * prm.nwin) * B + p, B, g.v, prm);
+    if (g_out) *g_out = g;
+    else fb_recode(digits + ((uint64_t)(2 + i) * prm.nwin) * B + p, B, g.v, prm);
     // h_i = z + y^-i (z^2 z^j 2^i' - b s_i^-1), j = i / n, i' = i % n   (mod.rs:416-419)
     const uint32_t j = i / sh.n, ib = i - j * sh.n;
     sc28 zzzj, two_m;
@@ -485,7 +551,8 @@ BP_HD void rp_expand_b_thread(uint32_t tid, rp_shape sh, fb_params prm, const ui
     sc28_montmul(r, r, yp);
     sc_from_mont28(v, r);
     sc_add(h, z, v);
-    fb_recode(digits + ((uint64_t)(2 + sh.nm + i) * prm.nwin) * B + p, B, h.v, prm);
+    if (h_out) *h_out = h;
+    else fb_recode(digits + ((uint64_t)(2 + sh.nm + i) * prm.nwin) * B + p, B, h.v, prm);
 }
 
 }  // namespace bp

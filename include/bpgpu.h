@@ -142,6 +142,30 @@ int bpgpu_rangeproof_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t m, size_t
                                       const uint8_t *label, size_t label_len, const void *d_rng64,
                                       void *d_verdict, void *d_msm_out, void *stream);
 
+/* ---- batch-combined verification (ADDITIONAL entry point; not a call of the reference) ---------------
+ * The reference verifies one proof per MSM (verify_multiple checks ONE aggregated proof: mod.rs:345-452).
+ * For a batch of independent proofs the standard next step is a random linear combination:
+ *     R = sum_i rho_i * MegaCheck_i ,  MegaCheck_i = the multiscalar multiplication of mod.rs:421-443 for proof i,
+ * with one weight rho_i = Scalar::from_bytes_mod_order_wide(weights64[i]) per proof.  The 2nm+2 generator
+ * coefficients of all proofs add up in the scalar field, so the table walk runs once per batch.  R is the
+ * identity when every combined proof verifies; if one does not, R != identity except with probability ~2^-252
+ * over the weights, which must be unpredictable to the provers (NULL = OS CSPRNG, as for rng64).
+ *   verdict   : nbatch bytes.  Proofs rejected by the parser / point decoder get their BPGPU_VERDICT_* code and
+ *               are left out of the combination.  The others get 0 when R is the identity.  Otherwise:
+ *               - bpgpu_rangeproof_verify_rlc re-verifies the batch proof by proof (same rng64) and returns
+ *                 exactly the verdicts of bpgpu_rangeproof_verify_batch;
+ *               - the asynchronous _dev variant marks them BPGPU_VERDICT_UNDECIDED and leaves that to the caller.
+ *   batch_out : optional 33 bytes: [0] = 0 if R is the identity else 1; [1..33) = compress(R) (parity tests) */
+#define BPGPU_VERDICT_UNDECIDED 5
+int bpgpu_rangeproof_verify_rlc(bpgpu_ctx *ctx, size_t n, size_t m, size_t nbatch,
+                                const uint8_t *proofs, size_t proof_len, const uint8_t *commitments,
+                                const uint8_t *label, size_t label_len, const uint8_t *rng64,
+                                const uint8_t *weights64, uint8_t *verdict, uint8_t *batch_out);
+int bpgpu_rangeproof_verify_rlc_dev(bpgpu_ctx *ctx, size_t n, size_t m, size_t nbatch,
+                                    const void *d_proofs, size_t proof_len, const void *d_commitments,
+                                    const uint8_t *label, size_t label_len, const void *d_rng64,
+                                    const void *d_weights64, void *d_verdict, void *d_batch_out, void *stream);
+
 /* ---- stand-alone inner-product proofs -------------------------------------------
  * nbatch independent calls of
  *   InnerProductProof::from_bytes(proof)?.verify(n, &mut Transcript::new(label), G_factors, H_factors, &P, &Q, &G, &H)

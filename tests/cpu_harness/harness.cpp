@@ -11,6 +11,7 @@
 #include "../../bulletproofs_amd/csrc/horner_quad.h"
 #include "../../bulletproofs_amd/csrc/ipp.h"
 #include "../../bulletproofs_amd/csrc/scinv.h"
+#include "../../bulletproofs_amd/csrc/rlc.h"
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -232,9 +233,12 @@ void h_set_horner_lanes(int lanes) { g_horner_lanes = lanes; }
 //   launch 2: rp_expand_b  ||  vb_window
 //   launch 3: fb_accum  ||  (column sums + wavefront Horner)
 //   launch 4: finish8
-int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t party_capacity, const uint8_t *gens /*Bb,B,G..,H..*/,
+// weights64 != nullptr: the batch-combination pipeline (rlc.h) -- verdict_out as bpgpu_rangeproof_verify_rlc_dev,
+// msm_out = 33 bytes (batch verdict, encoding of the combined point)
+static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t party_capacity, const uint8_t *gens /*Bb,B,G..,H..*/,
                 uint32_t n, uint32_t m, uint32_t nbatch, const uint8_t *proofs, uint32_t proof_len, const uint8_t *commitments,
-                const uint8_t *label, uint32_t label_len, const uint8_t *rng64, uint8_t *verdict_out, uint8_t *msm_out) {
+                const uint8_t *label, uint32_t label_len, const uint8_t *rng64, uint8_t *verdict_out, uint8_t *msm_out,
+                const uint8_t *weights64) {
     uint32_t k = 0; while ((1u << k) < n * m) k++;
     uint32_t lg_m = 0; while ((1u << lg_m) < m) lg_m++;
     rp_shape sh; sh.n = n; sh.m = m; sh.nm = n * m; sh.k = k; sh.U = 4 + 2 * k + m; sh.proof_len = proof_len; sh.nproofs = nbatch; sh.shape_verdict = 0;
@@ -263,11 +267,26 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
     for (uint32_t p = 0; p < nbatch; p++) {
         uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;
         rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields.data(), status.data());
-        rp_expand_a_thread(p, sh, prm, lg_m, fields.data(), rec.data(), digits.data(), status.data());
+        rp_expand_a_thread(p, sh, prm, lg_m, fields.data(), rec.data(), digits.data(), status.data(), weights64);
     }
     for (uint32_t t = 0; t < t0; t++) rp_points_thread(t, sh, proofs, commitments, tab.data(), status.data());
     // launch 2
-    for (uint32_t tid = 0; tid < sh.nm * nbatch; tid++) rp_expand_b_thread(tid, sh, prm, fields.data(), digits.data(), status.data());
+    std::vector<uint64_t> acc((size_t)n_gen_terms * 10, 0);
+    if (weights64) {
+        for (uint32_t tid = 0; tid < sh.nm * nbatch; tid++) {
+            const uint32_t i = tid / nbatch, p = tid - i * nbatch;
+            sc g, h; uint64_t l[10];
+            rp_expand_b_thread(tid, sh, prm, fields.data(), nullptr, status.data(), &g, &h);
+            rlc_limbs(l, g); for (int q = 0; q < 10; q++) acc[(size_t)(2 + i) * 10 + q] += l[q];
+            rlc_limbs(l, h); for (int q = 0; q < 10; q++) acc[(size_t)(2 + sh.nm + i) * 10 + q] += l[q];
+            if (i < 2 && status[p] == 0) {
+                sc r; rp_load(r, fields.data(), nbatch, RPF_ROW0 + i, p);
+                rlc_limbs(l, r); for (int q = 0; q < 10; q++) acc[(size_t)i * 10 + q] += l[q];
+            }
+        }
+    } else {
+        for (uint32_t tid = 0; tid < sh.nm * nbatch; tid++) rp_expand_b_thread(tid, sh, prm, fields.data(), digits.data(), status.data());
+    }
     std::vector<vb_chunk> chunks; std::vector<uint32_t> chunk_first(nbatch + 1); uint32_t tt = 0;
     for (uint32_t b = 0; b < nbatch; b++) {
         chunk_first[b] = (uint32_t)chunks.size();
@@ -282,6 +301,44 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
     const bool quad = g_horner_lanes != 64;
     const bool one_chunk = chunks.size() == nbatch;
     std::vector<ge_cached> colc((size_t)nbatch * 64 + 1);
+    if (weights64) {
+        // window sums with rejected proofs skipped, then one column sum over all chunks of all proofs (tree as on
+        // the device: 16-way while > 64 rows, then 8-way, the last <= 8 rows are added by the Horner wavefront)
+        for (uint32_t tid = 0; tid < chunks.size() * 64; tid++)
+            vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data(), nullptr, status.data());
+        std::vector<ge_ext> cur(part.begin(), part.begin() + chunks.size() * 64), nxt;
+        uint32_t rows = (uint32_t)chunks.size();
+        while (rows > 8) {
+            const uint32_t group = rows > 64 ? 16 : 8, ng = (rows + group - 1) / group;
+            nxt.assign((size_t)ng * 64, ge_ext());
+            for (uint32_t tid = 0; tid < ng * 64; tid++) fb_reduce_thread(tid, 64, rows, group, cur.data(), nxt.data());
+            cur.swap(nxt);
+            rows = ng;
+        }
+        // batch-of-one tail: coefficients mod l -> digits -> table walk -> Horner over the combined column sums -> finish
+        std::vector<uint16_t> dig1((size_t)npairs + 1);
+        for (uint32_t g = 0; g < n_gen_terms; g++) {
+            sc v; rlc_acc_to_sc(v, &acc[(size_t)g * 10]);
+            fb_recode(dig1.data() + (size_t)g * prm.nwin, 1, v.v, prm);
+        }
+        std::vector<ge_ext> partial1((size_t)nsplit + 1), hq1(2);
+        const uint32_t per1 = (npairs + nsplit - 1) / nsplit;
+        for (uint32_t sp = 0; sp < nsplit; sp++) {
+            uint32_t q0 = sp * per1, q1 = q0 + per1 < npairs ? q0 + per1 : npairs; if (q0 > npairs) q0 = npairs;
+            fb_accum_thread(0, sp, q0, q1, prm, 1, ids.data(), dig1.data(), table.data(), partial1.data());
+        }
+        const uint32_t cf[2] = {0, rows};
+        hw_colsum_horner_msm(0, cf, cur.data(), &hq1[0]);
+        ge_ext x[8];
+        for (uint32_t j = 0; j < 8; j++) shared_finish8_gather(x[j], 0, j, 1, nsplit, hq1.data(), partial1.data());
+        for (uint32_t step = 4; step >= 1; step >>= 1)
+            for (uint32_t j = 0; j < step; j++) { const ge_ext q = x[j + step]; ge_add(x[j], x[j], q); }
+        uint32_t zero_status = 0, rw[8]; uint8_t bv = 0;
+        shared_finish_tail(0, x[0], &zero_status, rw, &bv);
+        for (uint32_t p = 0; p < nbatch; p++) verdict_out[p] = status[p] ? (uint8_t)status[p] : (bv ? (uint8_t)BP_VERDICT_UNDECIDED : (uint8_t)0);
+        if (msm_out) { msm_out[0] = bv; memcpy(msm_out + 1, rw, 32); }
+        return 0;
+    }
     for (uint32_t tid = 0; tid < chunks.size() * 64; tid++)
         vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data(), (quad && one_chunk) ? colc.data() : nullptr);
     if (quad && !one_chunk)
@@ -309,6 +366,29 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
     for (uint32_t p = 0; p < nbatch; p++) verdict_out[p] = verdict[p];
     if (msm_out) memcpy(msm_out, outw.data(), (size_t)nbatch * 32);
     return 0;
+}
+int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t party_capacity, const uint8_t *gens, uint32_t n, uint32_t m,
+                uint32_t nbatch, const uint8_t *proofs, uint32_t proof_len, const uint8_t *commitments, const uint8_t *label,
+                uint32_t label_len, const uint8_t *rng64, uint8_t *verdict_out, uint8_t *msm_out) {
+    return rp_verify_impl(W, nsplit, gens_capacity, party_capacity, gens, n, m, nbatch, proofs, proof_len, commitments, label, label_len, rng64,
+                          verdict_out, msm_out, nullptr);
+}
+int h_rp_verify_rlc(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t party_capacity, const uint8_t *gens, uint32_t n, uint32_t m,
+                    uint32_t nbatch, const uint8_t *proofs, uint32_t proof_len, const uint8_t *commitments, const uint8_t *label,
+                    uint32_t label_len, const uint8_t *rng64, const uint8_t *weights64, uint8_t *verdict_out, uint8_t *batch_out) {
+    return rp_verify_impl(W, nsplit, gens_capacity, party_capacity, gens, n, m, nbatch, proofs, proof_len, commitments, label, label_len, rng64,
+                          verdict_out, batch_out, weights64);
+}
+// sum of `count` canonical scalars through the limb accumulator (rlc.h)
+void h_rlc_sum(uint32_t count, const uint8_t *scalars, uint8_t *out) {
+    uint64_t acc[10] = {0};
+    for (uint32_t i = 0; i < count; i++) {
+        sc v; memcpy(v.v, scalars + 32 * (size_t)i, 32);
+        uint64_t l[10]; rlc_limbs(l, v);
+        for (int q = 0; q < 10; q++) acc[q] += l[q];
+    }
+    sc r; rlc_acc_to_sc(r, acc);
+    memcpy(out, r.v, 32);
 }
 
 void h_msm_vb(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status_out);

@@ -221,6 +221,66 @@ def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, gol
     assert list(vd.raw) == [2, 1, 1, 0]
 
 
+def _rlc_expected(oracle, gg, n, m, label, proofs, plen, coms, rng, wts):
+    """R = sum_i rho_i * MegaCheck_i over the proofs the front end accepts, by one oracle MSM over all weighted terms."""
+    L = T.L
+    all_s, all_p, included = b"", b"", []
+    nb = len(proofs) // plen
+    for b in range(nb):
+        rc, sc_, pt_ = oracle.verify_terms(gg, proofs[plen * b:plen * (b + 1)], coms[32 * m * b:32 * m * (b + 1)], n, label, rng[64 * b:64 * b + 64])
+        ok = rc == 0 and all(oracle.lib().oracle_point_decompress_ok(pt_[32 * j:32 * j + 32]) for j in range(len(pt_) // 32))
+        included.append(ok)
+        if not ok:
+            continue
+        rho = int.from_bytes(wts[64 * b:64 * b + 64], "little") % L
+        for j in range(len(sc_) // 32):
+            all_s += (int.from_bytes(sc_[32 * j:32 * j + 32], "little") * rho % L).to_bytes(32, "little")
+        all_p += pt_
+    st, enc = oracle.msm(all_s, all_p) if all_s else (0, bytes(32))
+    assert st == 0
+    return included, enc
+
+
+def test_batch_combination_pipeline_lane_by_lane(H, oracle, golden):
+    """rlc.h: limb accumulator, and the combined pipeline R = sum rho_i MegaCheck_i against one oracle MSM."""
+    L = T.L
+    random.seed(11)
+    for vals in ([1], [L - 1] * 3, [random.randrange(L) for _ in range(1000)], [L - 1] * 5000):
+        o = C.create_string_buffer(32)
+        H.h_rlc_sum(len(vals), b"".join(v.to_bytes(32, "little") for v in vals), o)
+        assert int.from_bytes(o.raw, "little") == sum(vals) % L
+    label = golden["label"]
+    vc = golden["vc_bytes"]
+    for case in golden["cases"]:
+        n, m = case["n"], case["m"]
+        if n * m > 32:
+            continue
+        pr = bytes.fromhex(case["proof"])
+        gg = oracle.Gens(n, m)
+        G2, H2, B2, Bb2 = gg.export()
+        gens = Bb2 + B2 + G2 + H2
+        bad = bytearray(pr)
+        bad[128] ^= 1                 # t_x: parses, fails the check
+        fmt = bytearray(pr)
+        fmt[128:160] = b"\xff" * 32   # non-canonical scalar: FormatError, left out of the combination
+        und = bytearray(pr)
+        und[32] |= 1                  # S undecodable: VerificationError from the decoder, left out
+        for name, batch in (("valid", [pr, pr, pr]), ("mixed", [pr, bytes(bad), bytes(fmt), bytes(und), pr])):
+            nb = len(batch)
+            proofs, coms = b"".join(batch), vc[:32 * m] * nb
+            rng = hashlib.shake_256(b"r%d%d" % (n, m)).digest(64 * nb)
+            wts = hashlib.shake_256(b"w%d%d" % (n, m)).digest(64 * nb)
+            vd, bo = C.create_string_buffer(nb), C.create_string_buffer(33)
+            assert H.h_rp_verify_rlc(4, 3, n, m, gens, n, m, nb, proofs, len(pr), coms, label, len(label), rng, wts, vd, bo) == 0
+            included, enc = _rlc_expected(oracle, gg, n, m, label, proofs, len(pr), coms, rng, wts)
+            assert bo.raw[1:33] == enc, (n, m, name)
+            if name == "valid":
+                assert bo.raw[0] == 0 and enc == bytes(32) and list(vd.raw) == [0, 0, 0]
+            else:
+                assert included == [True, True, False, False, True] and bo.raw[0] == 1 and enc != bytes(32)
+                assert list(vd.raw) == [5, 5, 2, 1, 5]
+
+
 @pytest.mark.parametrize("n", [1, 2, 4, 32])
 def test_standalone_ipp_front_end_lane_by_lane(H, oracle, n):
     """ipp_prepare (transcript, batch inversion, s_i products) + the variable-base pipeline against the oracle's

@@ -1,0 +1,150 @@
+"""GPU parity tests of the batch-combination entry point bpgpu_rangeproof_verify_rlc[_dev] (include/bpgpu.h,
+csrc/rlc.h; SURVEY.md 8f-3 -- additional to the reference's API): the combined point
+    R = sum_i rho_i * MegaCheck_i     (MegaCheck_i = the MSM of src/range_proof/mod.rs:421-443 for proof i)
+must equal, bit for bit, ONE oracle multiscalar multiplication over all weighted terms of the proofs the front
+end accepts, and the verdicts must equal those of the per-proof entry point (automatic fallback)."""
+import ctypes as C
+import hashlib
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+L = 2**252 + 27742317777372353535851937790883648493
+
+
+@pytest.fixture(scope="module")
+def ctx64x8():
+    import bulletproofs_amd as bp
+    c = bp.Context(0)
+    c.gens_create(64, 8)
+    yield c
+    c.close()
+
+
+def expected_combination(oracle, gg, n, m, label, proofs, plen, coms, rng, wts):
+    all_s, all_p, included = [], [], []
+    nb = len(proofs) // plen
+    for b in range(nb):
+        rc, sc_, pt_ = oracle.verify_terms(gg, proofs[plen * b:plen * (b + 1)], coms[32 * m * b:32 * m * (b + 1)], n, label, rng[64 * b:64 * b + 64])
+        ok = rc == 0 and all(oracle.lib().oracle_point_decompress_ok(pt_[32 * j:32 * j + 32]) for j in range(len(pt_) // 32))
+        included.append(ok)
+        if not ok:
+            continue
+        rho = int.from_bytes(wts[64 * b:64 * b + 64], "little") % L
+        all_s.append(b"".join((int.from_bytes(sc_[32 * j:32 * j + 32], "little") * rho % L).to_bytes(32, "little") for j in range(len(sc_) // 32)))
+        all_p.append(pt_)
+    if not all_s:
+        return included, bytes(32)
+    st, enc = oracle.msm(b"".join(all_s), b"".join(all_p))
+    assert st == 0
+    return included, enc
+
+
+def test_golden_proofs_combined(ctx64x8, oracle, oracle_gens_64_8, golden):
+    """Every golden case of tests/range_proof.rs:16-95: a batch of valid copies combines to the identity; a batch
+    with a failing, a malformed and an undecodable member does not, R equals the oracle's combination, and the
+    host entry point falls back to the per-proof verdicts."""
+    label, vc = golden["label"], golden["vc_bytes"]
+    for case in golden["cases"]:
+        n, m = case["n"], case["m"]
+        pr = bytes.fromhex(case["proof"])
+        bad = bytearray(pr)
+        bad[128] ^= 1
+        fmt = bytearray(pr)
+        fmt[128:160] = b"\xff" * 32
+        und = bytearray(pr)
+        und[32] |= 1
+        for name, batch in (("valid", [pr] * 5), ("mixed", [pr, bytes(bad), bytes(fmt), bytes(und), pr, pr])):
+            nb = len(batch)
+            proofs, coms = b"".join(batch), vc[:32 * m] * nb
+            rng = hashlib.shake_256(b"r%d-%d" % (n, m)).digest(64 * nb)
+            wts = hashlib.shake_256(b"w%d-%d" % (n, m)).digest(64 * nb)
+            verdict, ok, enc = ctx64x8.rangeproof_verify_rlc(n, m, proofs, len(pr), coms, label, rng, wts)
+            included, exp = expected_combination(oracle, oracle_gens_64_8, n, m, label, proofs, len(pr), coms, rng, wts)
+            assert enc == exp, (n, m, name)
+            per_proof = ctx64x8.rangeproof_verify_batch(n, m, proofs, len(pr), coms, label, rng)
+            assert verdict == per_proof, (n, m, name)
+            if name == "valid":
+                assert ok and enc == bytes(32) and verdict == bytes(nb)
+            else:
+                assert not ok and included == [True, True, False, False, True, True] and list(verdict) == [0, 1, 2, 1, 0, 0]
+
+
+@pytest.mark.parametrize("nb", [64, 200, 1024])
+def test_synthetic_batches_combined(ctx64x8, oracle, oracle_gens_64_8, nb):
+    """BASELINE config 2 shape.  nb = 64 / 1024 take the one-atomic-per-wavefront accumulation, nb = 200 the per-lane
+    one; a clean batch gives the identity, one flipped byte gives the oracle's non-identity combination."""
+    n, m = 64, 1
+    vals = [int.from_bytes(hashlib.shake_256(b"v%d" % i).digest(8), "little") for i in range(nb)]
+    bl = b"".join(hashlib.shake_256(b"b%d" % i).digest(31) + b"\x00" for i in range(nb))
+    proofs, coms = oracle.prove_batch(oracle_gens_64_8, vals, bl, m, n, b"cfg2", b"seed", threads=os.cpu_count() or 1)
+    pl = oracle.proof_len(n, m)
+    rng = hashlib.shake_256(b"rng-rlc").digest(64 * nb)
+    wts = hashlib.shake_256(b"wts-rlc").digest(64 * nb)
+    verdict, ok, enc = ctx64x8.rangeproof_verify_rlc(n, m, proofs, pl, coms, b"cfg2", rng, wts)
+    assert ok and enc == bytes(32) and verdict == bytes(nb)
+    verdict, ok, enc = ctx64x8.rangeproof_verify_rlc(n, m, proofs, pl, coms, b"cfg2", rng, None)   # weights from the OS CSPRNG
+    assert ok and enc == bytes(32) and verdict == bytes(nb)
+    pb = bytearray(proofs)
+    pb[(nb // 3) * pl + 130] ^= 0x10          # t_x of one proof
+    verdict, ok, enc = ctx64x8.rangeproof_verify_rlc(n, m, bytes(pb), pl, coms, b"cfg2", rng, wts)
+    assert not ok and list(verdict) == [1 if i == nb // 3 else 0 for i in range(nb)]
+    if nb <= 200:
+        included, exp = expected_combination(oracle, oracle_gens_64_8, n, m, b"cfg2", bytes(pb), pl, coms, rng, wts)
+        assert all(included) and enc == exp
+
+
+def test_aggregated_m16_combined(oracle):
+    """BASELINE config 3 shape (n = 64, m = 16): 40 proof-specific points per proof = two chunks of window sums per
+    proof, all of them rows of the one column-sum tree."""
+    import bulletproofs_amd as bp
+    c = bp.Context(0)
+    c.gens_create(64, 16)
+    g = oracle.Gens(64, 16)
+    nb, n, m = 9, 64, 16
+    vals = [(i * 0x9E3779B97F4A7C15) % (1 << 64) for i in range(nb * m)]
+    bl = b"".join(hashlib.shake_256(b"bb%d" % i).digest(31) + b"\x00" for i in range(nb * m))
+    proofs, coms = oracle.prove_batch(g, vals, bl, m, n, b"agg", b"seed16", threads=os.cpu_count() or 1)
+    pl = oracle.proof_len(n, m)
+    rng = hashlib.shake_256(b"rng16").digest(64 * nb)
+    wts = hashlib.shake_256(b"wts16").digest(64 * nb)
+    verdict, ok, enc = c.rangeproof_verify_rlc(n, m, proofs, pl, coms, b"agg", rng, wts)
+    assert ok and enc == bytes(32) and verdict == bytes(nb)
+    pb = bytearray(proofs)
+    pb[4 * pl + 200] ^= 1
+    verdict, ok, enc = c.rangeproof_verify_rlc(n, m, bytes(pb), pl, coms, b"agg", rng, wts)
+    included, exp = expected_combination(oracle, g, n, m, b"agg", bytes(pb), pl, coms, rng, wts)
+    assert not ok and enc == exp and list(verdict) == [0, 0, 0, 0, 1, 0, 0, 0, 0]
+    c.close()
+
+
+def test_device_pointer_variant_marks_undecided(ctx64x8, golden):
+    """_dev: asynchronous, no fallback -- proofs of a failing combination are BPGPU_VERDICT_UNDECIDED (5)."""
+    import torch
+    import bulletproofs_amd as bp
+    L_ = bp.lib()
+    case = golden["cases"][12]   # n = 64, m = 1
+    pr = bytes.fromhex(case["proof"])
+    bad = bytearray(pr)
+    bad[128] ^= 1
+    fmt = bytearray(pr)
+    fmt[128:160] = b"\xff" * 32
+    for batch, exp_verdict, exp_bad in (([pr] * 4, [0, 0, 0, 0], 0), ([pr, bytes(bad), bytes(fmt), pr], [5, 5, 2, 5], 1)):
+        nb = len(batch)
+        dev = torch.device("cuda", 0)
+        d_p = torch.frombuffer(bytearray(b"".join(batch)), dtype=torch.uint8).to(dev)
+        d_c = torch.frombuffer(bytearray(golden["vc_bytes"][:32] * nb), dtype=torch.uint8).to(dev)
+        d_r = torch.frombuffer(bytearray(hashlib.shake_256(b"r").digest(64 * nb)), dtype=torch.uint8).to(dev)
+        d_w = torch.frombuffer(bytearray(hashlib.shake_256(b"w").digest(64 * nb)), dtype=torch.uint8).to(dev)
+        d_v = torch.full((nb,), 255, dtype=torch.uint8, device=dev)
+        d_o = torch.full((33,), 255, dtype=torch.uint8, device=dev)
+        rc = L_.bpgpu_rangeproof_verify_rlc_dev(ctx64x8.h, 64, 1, nb, d_p.data_ptr(), len(pr), d_c.data_ptr(), golden["label"],
+                                                len(golden["label"]), d_r.data_ptr(), d_w.data_ptr(), d_v.data_ptr(), d_o.data_ptr(),
+                                                torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        torch.cuda.synchronize()
+        assert d_v.cpu().tolist() == exp_verdict and d_o.cpu().tolist()[0] == exp_bad
+        # and the context is left clean for the per-proof path
+        assert ctx64x8.rangeproof_verify_batch(64, 1, pr * 2, len(pr), golden["vc_bytes"][:32] * 2, golden["label"], None) == bytes(2)
