@@ -31,14 +31,14 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=960)
+    ap.add_argument("--warmup", type=int, default=96)
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4"],
                     help="BASELINE.json config; cfg2 (batch of 1024 single 64-bit proofs per GPU) is the metric's config")
     ap.add_argument("--batch", type=int, default=0, help="override proofs per GPU per step")
     ap.add_argument("--window-bits", type=int, default=0, help="fixed-base window (default: library default)")
     ap.add_argument("--horner-lanes", type=int, default=0, choices=[0, 4, 64], help="lanes per Horner chain (default: library default)")
-    ap.add_argument("--streams", type=int, default=16,
+    ap.add_argument("--streams", type=int, default=48,
                     help="independent (context, HIP stream) pairs the steps are issued on round-robin, so that "
                          "consecutive batches overlap on the device (one context per stream, as bpgpu.h prescribes "
                          "for concurrent callers)")
@@ -157,6 +157,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # context set-up (not a warmup step): the first call on a context sizes its arena and caches the work
+    # decomposition, like gens_create above it allocates and synchronises
+    for k in range(nstreams):
+        step(k)
+    fence()
     for i in range(a.warmup):
         step(i)
     fence()
