@@ -434,7 +434,7 @@ struct bpgpu_ctx {
     size_t arena_cap = 0, arena_off = 0;
     // options
     uint32_t W = 0;                          // fixed-base window bits; 0 = largest that fits table_budget
-    uint64_t table_budget = 12ull << 30;     // bytes of HBM the generator tables may take
+    uint64_t table_budget = 48ull << 30;     // bytes of HBM the generator tables may take (a sixth of the MI355X's 288 GB)
     uint32_t splits = 0;
     uint32_t horner_lanes = 0;               // lanes per Horner chain in the range-proof path: 4, 64, 0 = auto (4)
     struct shared_table *tab_ref = nullptr;  // refcounted, shared by the contexts of one device

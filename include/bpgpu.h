@@ -65,7 +65,7 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
 /* Tunables (set before bpgpu_gens_*):
  *   "fixed_window_bits"     window W of the generator tables, 2..16; 0 (default) = the largest W whose
  *                           table (n_gens * ceil(256/W) * 2^(W-1) * 128 bytes) fits fixed_table_max_bytes
- *   "fixed_table_max_bytes" HBM budget of the tables (default 12 GiB; the MI355X has 288 GB)
+ *   "fixed_table_max_bytes" HBM budget of the tables (default 48 GiB; the MI355X has 288 GB)
  *   "fixed_splits"          workgroups the generator terms of one proof block are split over (0 = auto)
  *   "horner_lanes"          lanes per Horner chain of the proof-specific terms in the range-proof path:
  *                           4 (16 chains per wavefront: least total work, best with several batches in flight),
