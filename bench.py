@@ -47,6 +47,7 @@ def parse_args():
                          "(one combined identity check per batch, include/bpgpu.h) instead of the per-proof one")
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the informational batch-combined (rlc) figure")
     ap.add_argument("--events-outside", action="store_true",
                     help="collect the per-kernel HIP-event timings in a second pass instead of inside the timed region")
     return ap.parse_args()
@@ -135,12 +136,12 @@ def main():
     d_coms = torch.frombuffer(bytearray(coms_b), dtype=torch.uint8).to(dev)
     d_rng = torch.frombuffer(bytearray(rng_b), dtype=torch.uint8).to(dev)
     d_verdicts = torch.full((max(a.steps, 1), batch), 255, dtype=torch.uint8, device=dev)
-    d_wts = torch.frombuffer(bytearray(hashlib.shake_256(b"bench-wts-%d" % rank).digest(64 * batch)), dtype=torch.uint8).to(dev) if a.rlc else None
+    d_wts = torch.frombuffer(bytearray(hashlib.shake_256(b"bench-wts-%d" % rank).digest(64 * batch)), dtype=torch.uint8).to(dev)
     streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
 
-    def step(i):
+    def step(i, rlc=a.rlc):
         k = i % nstreams
-        if a.rlc:
+        if rlc:
             rc = L.bpgpu_rangeproof_verify_rlc_dev(ctxs[k].h, n, m, batch, d_proofs.data_ptr(), fx.proof_len, d_coms.data_ptr(),
                                                    fx.label, len(fx.label), d_rng.data_ptr(), d_wts.data_ptr(),
                                                    d_verdicts[i % d_verdicts.shape[0]].data_ptr(), None, streams[k].cuda_stream)
@@ -200,6 +201,25 @@ def main():
         fence()
         for c_ in ctxs:
             c_.profile_enable(False)
+    # informational second figure (single GPU, per-proof runs only): the same batches through the batch-combined entry
+    # point bpgpu_rangeproof_verify_rlc_dev (one identity check per batch; include/bpgpu.h) -- never `value`
+    extra = None
+    if world == 1 and not a.rlc and not a.no_extra and a.steps >= 8:
+        ksteps = max(nstreams, a.steps // 4)
+        for k in range(nstreams):
+            step(k, True)
+        fence()
+        d_verdicts.fill_(255)
+        t1 = time.perf_counter()
+        for i in range(ksteps):
+            step(i, True)
+        fence()
+        dt = time.perf_counter() - t1
+        if not bool((d_verdicts[:min(ksteps, d_verdicts.shape[0])] == 0).all().item()):
+            raise SystemExit("batch-combined verdicts are not all Ok -- result invalid")
+        extra = {"rlc_verifications_per_s": round(batch * ksteps / dt, 1), "rlc_steps": ksteps,
+                 "note": "bpgpu_rangeproof_verify_rlc_dev: one combined identity check per batch of %d (additional entry point, "
+                         "SURVEY 8f-3); not the headline mode" % batch}
     kern = {}
     for c_ in ctxs:
         for name, (cnt, ms) in c_.profile_report().items():
@@ -225,6 +245,19 @@ def main():
             if os.path.exists(tpath):   # HBM bytes/launch of this kernel from the committed rocprofv3 --pmc passes
                 with open(tpath) as f:
                     traffic = json.load(f).get(dom)
+            # VALU utilisation: wavefront-instructions per batch (SQ_INSTS_VALU of the committed --pmc pass, summed over
+            # the launches of one batch) x batches/s  /  (1024 SIMDs x one wave-instruction per 4 cycles at 2.4 GHz)
+            valu_util = {}
+            wpath = os.path.join(ROOT, "profiles", "valu_work_%s.json" % a.config)
+            if os.path.exists(wpath) and batch == default_batch and not a.rlc:
+                with open(wpath) as f:
+                    wk = json.load(f)
+                per_batch = sum(v for k, v in wk.items() if k in kern)
+                if per_batch:
+                    valu_util = {"wavefront_instructions_per_batch": per_batch,
+                                 "achieved_wavefront_instructions_per_s": per_batch * value / batch,
+                                 "peak_wavefront_instructions_per_s": 1024 * 2.4e9 / 4,
+                                 "utilisation": per_batch * value / batch / (1024 * 2.4e9 / 4)}
             roof = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
                     "frac": achieved / 8000.0, "traffic": traffic,
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt,
@@ -232,7 +265,8 @@ def main():
                     "timing": "start/stop events attached to the dispatches (hipExtLaunchKernelGGL) of every 4th stream, on their launch stream, %s the timed region; "
                               "kernel begin..end as in rocprofv3's kernel trace" % ("inside" if in_region_events else "second pass after"),
                     # the binding resource is integer VALU issue, not HBM: also report it
-                    "valu": {"reference_point_ops_per_s": wl.reference_point_ops(N_terms) * value,
+                    "valu": {**valu_util,
+                             "reference_point_ops_per_s": wl.reference_point_ops(N_terms) * value,
                              "measured_peak_madd_per_s": 3.14e10,
                              "note": "A(N)=%d point ops per MSM by the reference's own algorithm x verifications/s; "
                                      "peak = ge_madd microbenchmark (profiles/r01_microbench_valu_rates.txt)" % wl.reference_point_ops(N_terms)},
@@ -259,6 +293,8 @@ def main():
                        "streams": nstreams, "parallelism": "independent proofs sharded, dp%d" % world},
             "roofline": roof,
         }
+        if extra:
+            out["extra"] = extra
         if world == 1 and not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(fx, batch, a.cpu_threads)
         print(json.dumps(out))

@@ -16,6 +16,8 @@ grep '"metric"' /tmp/pf1.log > $OUT/bench_streams1_under_rocprof.json
 # counters in their own passes (kernel-trace only, no other trace domains)
 rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pm1 -o t --output-format csv -- python $REPO/bench.py --no-cpu-baseline --steps 8 --warmup 2 --streams 1 > /tmp/pm1.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pm2 -o t --output-format csv -- python $REPO/bench.py --no-cpu-baseline --steps 8 --warmup 2 --streams 1 > /tmp/pm2.log 2>&1
+# VALU instruction mix / work per launch (tools/pmc_insts.sh writes gpurun_out/pmc_insts/)
+$REPO/tools/pmc_insts.sh > $OUT/pmc_insts.log 2>&1; cp $REPO/gpurun_out/pmc_insts/insts.json $OUT/pmc_instruction_mix_streams1.json; cp $REPO/gpurun_out/pmc_insts/valu_work_cfg2.json $OUT/valu_work_cfg2.json
 python - <<PY
 import csv, collections, json, glob, re
 def short(name):

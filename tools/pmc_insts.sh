@@ -20,6 +20,17 @@ for d in glob.glob("/tmp/pi*/"):
             a[0] += 1; a[1] += float(r["Counter_Value"])
 out = {k: {c: v[1] / v[0] for c, v in cs.items()} for k, cs in acc.items()}
 json.dump(out, open("$OUT/insts.json", "w"), indent=1)
+# VALU work per launch, by short kernel name (what bench.py reads as profiles/valu_work_cfg2.json)
+import re
+def short(name):
+    n = re.sub(r"^void\s+", "", name.strip()); n = re.sub(r"<.*$", "", n)
+    return n[2:] if n.startswith("k_") else n
+work = {"_note": "SQ_INSTS_VALU per launch (wavefront-instructions) of bench.py --streams 1 at cfg2, batch 1024 "
+        "(rocprofv3 --pmc, tools/pmc_insts.sh); one batch = one launch of each rp_*/fb_reduce/finish8 kernel "
+        "(fb_reduce: its per-launch average x 1 launch)"}
+for k, cs in out.items():
+    if "SQ_INSTS_VALU" in cs: work[short(k)] = int(cs["SQ_INSTS_VALU"])
+json.dump(work, open("$OUT/valu_work_cfg2.json", "w"), indent=1)
 for k, cs in out.items():
     w = cs.get("SQ_WAVES", 0) or 1
     print("%-16s waves %6d  valu/wave %8.0f salu/wave %7.0f lds/wave %6.0f vmem/wave %5.0f  wave_cycles/wave %9.0f  gui_active %8.0f" % (
