@@ -37,6 +37,7 @@ def parse_args():
                     help="BASELINE.json config; cfg2 (batch of 1024 single 64-bit proofs per GPU) is the metric's config")
     ap.add_argument("--batch", type=int, default=0, help="override proofs per GPU per step")
     ap.add_argument("--window-bits", type=int, default=0, help="fixed-base window (default: library default)")
+    ap.add_argument("--splits", type=int, default=0, help="workgroups the generator terms of a proof block are split over (default: library default)")
     ap.add_argument("--horner-lanes", type=int, default=0, choices=[0, 4, 64], help="lanes per Horner chain (default: library default)")
     ap.add_argument("--streams", type=int, default=48,
                     help="independent (context, HIP stream) pairs the steps are issued on round-robin, so that "
@@ -122,7 +123,7 @@ def main():
     nstreams = max(1, a.streams)
     ctxs = []
     for _ in range(nstreams):
-        c_ = bp.Context(local_rank, fixed_window_bits=a.window_bits or None, horner_lanes=a.horner_lanes or None)
+        c_ = bp.Context(local_rank, fixed_window_bits=a.window_bits or None, horner_lanes=a.horner_lanes or None, fixed_splits=a.splits or None)
         c_.gens_create(n, m)
         ctxs.append(c_)
     ctx = ctxs[0]

@@ -1000,10 +1000,16 @@ extern "C" int bpgpu_msm_batch(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_te
 // ============================================================================
 static uint32_t pick_splits(bpgpu_ctx *c, size_t nbatch, uint32_t npairs) {
     if (c->splits) return c->splits;
-    // >= 4096 wavefronts (4 per SIMD: fewer leave VALU dependency stalls exposed -- measured 4.0 ms at 2048
-    // wavefronts vs 2.8 ms at 4096 for the same work), but keep >= 8 pairs per lane
+    // >= 1024 wavefronts (one per SIMD).  A lone table walk runs 1.45x faster with 4096 (4 per SIMD hide its VALU
+    // dependency stalls: 4.0 ms at 2048 wavefronts vs 2.8 ms at 4096, batch 16384), but it shares its launch with the
+    // longer Horner role, and with several batches in flight the device is work-bound: every split costs one
+    // more point addition per proof in the reduction (measured at 48 x 1024: 256 splits 4.35 M/s, 128: 4.5, 64:
+    // 4.57, 32: 4.45) and with <= 64 partial sums the finish kernel needs no separate reduction launch.
+    // Aggregated shapes (thousands of generator terms per proof, e.g. m = 16: 38950 pairs) are all table walk:
+    // they keep the 4096-wavefront target (cfg3: 478 k/s vs 443 k/s).
     const uint32_t nblk = (uint32_t)((nbatch + FB_BLOCK - 1) / FB_BLOCK);
-    uint32_t s = (4096 + nblk - 1) / nblk;
+    const uint32_t target = npairs > 8192 ? 4096 : 1024;
+    uint32_t s = (target + nblk - 1) / nblk;
     s = (s + 7) & ~7u;
     while (s > 8 && npairs / s < 8) s -= 8;
     if (s < 8) s = 8;
