@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rp_stage3(uint32_t n_win, uint32_t
         if (tid < nthreads_win) vb_window_thread(tid, chunks, tab, recoded, part, colc);
     } else {
         const uint32_t tid = (blockIdx.x - n_win) * BP_BLOCK + threadIdx.x;
-        if (tid < nthreads_exp) rp_expand_b_thread(tid, sh, prm, fields, digits, status);
+        if (tid < nthreads_exp) rp_expand_b4_thread(tid, sh, prm, fields, digits, status);
     }
 }
 
@@ -264,21 +264,29 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rlc_stage3(uint32_t n_win, uint32_
     const uint32_t tid = (blockIdx.x - n_win) * BP_BLOCK + threadIdx.x;
     const bool valid = tid < nthreads_exp;
     const uint32_t B = sh.nproofs;
-    const uint32_t i = valid ? tid / B : 0, p = valid ? tid - i * B : 0;
-    sc g, h;
-    sc_0(g);
-    sc_0(h);
-    if (valid) rp_expand_b_thread(tid, sh, prm, fields, nullptr, status, &g, &h);
-    rlc_accumulate(acc, 2 + i, g, valid, uniform != 0);
-    rlc_accumulate(acc, 2 + sh.nm + i, h, valid, uniform != 0);
+    const uint32_t t4 = valid ? tid / B : 0, p = valid ? tid - t4 * B : 0;
+    sc g[4], h[4];
+    for (int j = 0; j < 4; j++) {
+        sc_0(g[j]);
+        sc_0(h[j]);
+    }
+    if (valid) rp_expand_b4_thread(tid, sh, prm, fields, nullptr, status, g, h);
+#pragma unroll 1
+    for (uint32_t j = 0; j < 4; j++) {
+        rlc_accumulate(acc, 2 + 4 * t4 + j, g[j], valid, uniform != 0);
+        rlc_accumulate(acc, 2 + sh.nm + 4 * t4 + j, h[j], valid, uniform != 0);
+    }
     // the B_blinding (row 0) and B (row 1) coefficients were left in the ROW0/ROW1 fields by launch 1; the lanes
-    // of generator index 0 / 1 add them (a proof rejected since then contributes nothing)
-    const bool row_lane = valid && i < 2;
-    if (!uniform || i < 2) {   // uniform mode: i is the same in all 64 lanes, so whole wavefronts take this branch
-        sc r;
-        sc_0(r);
-        if (row_lane && status[p] == 0) rp_load(r, fields, B, RPF_ROW0 + i, p);
-        rlc_accumulate(acc, i, r, row_lane, uniform != 0);
+    // of the first index group add them (a proof rejected since then contributes nothing)
+    const bool row_lane = valid && t4 == 0;
+    if (!uniform || t4 == 0) {   // uniform mode: t4 is the same in all 64 lanes, so whole wavefronts take this branch
+#pragma unroll 1
+        for (uint32_t row = 0; row < 2; row++) {
+            sc r;
+            sc_0(r);
+            if (row_lane && status[p] == 0) rp_load(r, fields, B, RPF_ROW0 + row, p);
+            rlc_accumulate(acc, row, r, row_lane, uniform != 0);
+        }
     }
 }
 
@@ -1369,7 +1377,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         c->rp_status_dirty = false;
         return BPGPU_OK;
     }
-    const uint32_t nexp = sh.nm * nb32, nwin = (uint32_t)pd->n_chunks * 64;
+    const uint32_t nexp = (sh.nm / 4) * nb32, nwin = (uint32_t)pd->n_chunks * 64;   // four generator indices per lane
     const uint32_t n_win = (nwin + BP_BLOCK - 1) / BP_BLOCK, n_exp = (nexp + BP_BLOCK - 1) / BP_BLOCK;
     if (rlc) {
         // ---- batch combination (rlc.h): R = sum_i rho_i MegaCheck_i ---------------------------------------

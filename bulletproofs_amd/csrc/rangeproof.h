@@ -487,72 +487,180 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
 }
 
 // ---- stage 3: per-(generator, proof) scalars -------------------------------------------------
-// thread tid = i * nproofs + p, i < nm: digits of g_i (row 2 + i) and h_i (row 2 + nm + i)
-// g_out / h_out (optional, batch-combination mode): the two coefficients are returned (zero for a rejected
-// proof) instead of being recoded into `digits`.
-BP_HD void rp_expand_b_thread(uint32_t tid, rp_shape sh, fb_params prm, const uint32_t *fields, uint16_t *digits,
-                              const uint32_t *status, sc *g_out = nullptr, sc *h_out = nullptr) {
+// 2^i * R mod l (Montgomery form of 2^i), i < 64: the factor 2^(i mod n) of h_i without a multiplication by R^2
+BP_HD void rp_two_pow_mont(sc28 &r, uint32_t i) {
+    const sc28 T[64] = {
+    {{0xcf5d3edu, 0x4305db8u, 0x676a4b2u, 0x80113d7u, 0x0622aafu, 0xfffeb21u, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x73a89cbu, 0x550730cu, 0x0643d7fu, 0x0c44080u, 0xfffd642u, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0xd4ee1f1u, 0x3040fc0u, 0x12a90cfu, 0x1886c21u, 0xfffac84u, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x977923du, 0xe6b4929u, 0x2b7376eu, 0x310c363u, 0xfff5908u, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x1c8f2d5u, 0x539bbfbu, 0x5d084aeu, 0x62171e7u, 0xffeb210u, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x26bb405u, 0x2d6a19eu, 0xc031f2du, 0xc42ceefu, 0xffd6420u, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x3b13665u, 0xe106ce4u, 0x868542au, 0x8858900u, 0xffac841u, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x63c3b25u, 0x4840370u, 0x132be26u, 0x10afd22u, 0xff59083u, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0xb5244a5u, 0x16b3088u, 0x2c7921du, 0x215e565u, 0xfeb2106u, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x57e57a5u, 0xb398ab9u, 0x5f13a0au, 0x42bb5ebu, 0xfd6420cu, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x9d67da5u, 0xed63f1au, 0xc4489e5u, 0x85756f7u, 0xfac8418u, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x286c9a5u, 0x60fa7ddu, 0x8eb299cu, 0x0ae9910u, 0xf590831u, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x3e761a5u, 0x4827962u, 0x2386909u, 0x15d1d42u, 0xeb21062u, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x6a891a5u, 0x1681c6cu, 0x4d2e7e3u, 0x2ba25a5u, 0xd6420c4u, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0xc2af1a5u, 0xb336280u, 0xa07e596u, 0x574366bu, 0xac84188u, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x72fb1a5u, 0xec9eea9u, 0x471e0fdu, 0xae857f8u, 0x5908310u, 0xfffffffu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0xd3931a5u, 0x5f706fau, 0x945d7ccu, 0x5d09b11u, 0xb210621u, 0xffffffeu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x94c31a5u, 0x451379du, 0x2edc569u, 0xba12144u, 0x6420c42u, 0xffffffdu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x17231a5u, 0x10598e3u, 0x63da0a3u, 0x7422da9u, 0xc841885u, 0xffffffau, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x1be31a5u, 0xa6e5b6eu, 0xcdd5716u, 0xe844673u, 0x908310au, 0xffffff5u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x25631a5u, 0xd3fe084u, 0xa1cc3fdu, 0xd087808u, 0x2106215u, 0xfffffebu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x38631a5u, 0x2e2eab0u, 0x49b9dccu, 0xa10db32u, 0x420c42bu, 0xfffffd6u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x5e631a5u, 0xe28ff08u, 0x9995168u, 0x421a185u, 0x8418857u, 0xfffffacu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0xaa631a5u, 0x4b527b8u, 0x394b8a2u, 0x8432e2cu, 0x08310aeu, 0xfffff59u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x42631a5u, 0x1cd7919u, 0x78b8715u, 0x0864779u, 0x106215du, 0xffffeb2u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x72631a5u, 0xbfe1bdau, 0xf7923fau, 0x10c7a13u, 0x20c42bau, 0xffffd64u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0xd2631a5u, 0x05f615cu, 0xf545dc6u, 0x218df48u, 0x4188574u, 0xffffac8u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x92631a5u, 0x921ec61u, 0xf0ad15cu, 0x431a9b2u, 0x8310ae8u, 0xffff590u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0xaa7026bu, 0xe77b889u, 0x8633e86u, 0x06215d0u, 0xfffeb21u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0xdb12e7eu, 0xd5186e3u, 0x0c6682eu, 0x0c42ba1u, 0xfffd642u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x3c586a4u, 0xb052398u, 0x18cbb7eu, 0x1885742u, 0xfffac84u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0xfee36f0u, 0x66c5d00u, 0x319621eu, 0x310ae84u, 0xfff5908u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x83f9788u, 0xd3acfd2u, 0x632af5du, 0x6215d08u, 0xffeb210u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x8e258b8u, 0xad7b575u, 0xc6549dcu, 0xc42ba10u, 0xffd6420u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0xa27db18u, 0x61180bbu, 0x8ca7edau, 0x8857421u, 0xffac841u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0xcb2dfd8u, 0xc851747u, 0x194e8d5u, 0x10ae843u, 0xff59083u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x1c8e958u, 0x96c4460u, 0x329bcccu, 0x215d086u, 0xfeb2106u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0xbf4fc58u, 0x33a9e90u, 0x65364bau, 0x42ba10cu, 0xfd6420cu, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x04d2258u, 0x6d752f2u, 0xca6b495u, 0x8574218u, 0xfac8418u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x8fd6e58u, 0xe10bbb4u, 0x94d544bu, 0x0ae8431u, 0xf590831u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0xa5e0658u, 0xc838d39u, 0x29a93b8u, 0x15d0863u, 0xeb21062u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0xd1f3658u, 0x9693043u, 0x5351292u, 0x2ba10c6u, 0xd6420c4u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x2a19658u, 0x3347658u, 0xa6a1046u, 0x574218cu, 0xac84188u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0xda65658u, 0x6cb0280u, 0x4d40badu, 0xae84319u, 0x5908310u, 0xfffffffu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x3afd658u, 0xdf81ad2u, 0x9a8027bu, 0x5d08632u, 0xb210621u, 0xffffffeu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0xfc2d658u, 0xc524b74u, 0x34ff018u, 0xba10c65u, 0x6420c42u, 0xffffffdu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x7e8d658u, 0x906acbau, 0x69fcb52u, 0x74218cau, 0xc841885u, 0xffffffau, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x834d658u, 0x26f6f45u, 0xd3f81c6u, 0xe843194u, 0x908310au, 0xffffff5u, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x8ccd658u, 0x540f45bu, 0xa7eeeadu, 0xd086329u, 0x2106215u, 0xfffffebu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x9fcd658u, 0xae3fe87u, 0x4fdc87bu, 0xa10c653u, 0x420c42bu, 0xfffffd6u, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0xc5cd658u, 0x62a12dfu, 0x9fb7c18u, 0x4218ca6u, 0x8418857u, 0xfffffacu, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x11cd658u, 0xcb63b90u, 0x3f6e351u, 0x843194du, 0x08310aeu, 0xfffff59u, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0xa9cd658u, 0x9ce8cf0u, 0x7edb1c4u, 0x086329au, 0x106215du, 0xffffeb2u, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0xd9cd658u, 0x3ff2fb1u, 0xfdb4eaau, 0x10c6534u, 0x20c42bau, 0xffffd64u, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x39cd658u, 0x8607534u, 0xfb68875u, 0x218ca69u, 0x4188574u, 0xffffac8u, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0xf9cd658u, 0x1230038u, 0xf6cfc0cu, 0x43194d3u, 0x8310ae8u, 0xffff590u, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x79cd658u, 0x2a81642u, 0xed9e339u, 0x86329a7u, 0x06215d0u, 0xfffeb21u, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x79cd658u, 0x5b24255u, 0xdb3b193u, 0x0c6534fu, 0x0c42ba1u, 0xfffd642u, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x79cd658u, 0xbc69a7bu, 0xb674e47u, 0x18ca69fu, 0x1885742u, 0xfffac84u, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x79cd658u, 0x7ef4ac7u, 0x6ce87b0u, 0x3194d3fu, 0x310ae84u, 0xfff5908u, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x79cd658u, 0x040ab5fu, 0xd9cfa82u, 0x6329a7eu, 0x6215d08u, 0xffeb210u, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x79cd658u, 0x0e36c8fu, 0xb39e025u, 0xc6534fdu, 0xc42ba10u, 0xffd6420u, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x79cd658u, 0x228eeefu, 0x673ab6bu, 0x8ca69fbu, 0x8857421u, 0xffac841u, 0xfffffffu, 0x0000000u}},
+    {{0xcf5d3edu, 0x12631a5u, 0x79cd658u, 0x4b3f3afu, 0xce741f7u, 0x194d3f6u, 0x10ae843u, 0xff59083u, 0xfffffffu, 0x0000000u}}};
+    r = T[i & 63];
+}
+// r = a - b + 4l with normalised limbs (a, b lazy, < 2^254): stays in Montgomery form, costs ~40 instructions
+// instead of two conversions out of it, a canonical subtraction and a conversion back
+BP_HD void sc28_sub_lazy(sc28 &r, const sc28 &a, const sc28 &b) {
+    const uint32_t L4[10] = {0x3d74fb4u, 0x498c697u, 0xe735960u, 0xe77a8bdu, 0x000537bu, 0u, 0u, 0u, 0u, 0x4u};   // 4l
+    int32_t cy = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const int32_t t = (int32_t)a.v[i] - (int32_t)b.v[i] + (int32_t)L4[i] + cy;   // |t| < 2^30
+        if (i < 9) {
+            r.v[i] = (uint32_t)t & BP_M28;
+            cy = t >> 28;
+        } else {
+            r.v[i] = (uint32_t)t;   // a - b + 4l > 0: the top limb is non-negative
+        }
+    }
+}
+
+// FOUR consecutive generator indices per thread: tid = t * nproofs + p, t < nm/4, i = 4t .. 4t+3.
+// s_i = prod_b (bit_b(i) ? u : u^-1)[k-1-b]  (ipp.rs:241-250) and s_i^-1 = s_{nm-1-i}: the factors of bits >= 2
+// are shared by the four indices, the four products over bits 0, 1 serve s (index j) and s^-1 (index 3-j);
+// y^-i likewise.  g_i = -z - a s_i (mod.rs:415), h_i = z + y^-i (z^2 z^j 2^i' - b s_i^-1), j = i / n,
+// i' = i % n (mod.rs:416-419).  Writes the digits of rows 2+i and 2+nm+i, or -- g_out / h_out given (batch-
+// combination mode) -- returns the eight coefficients (zero for a rejected proof).
+BP_HD void rp_expand_b4_thread(uint32_t tid, rp_shape sh, fb_params prm, const uint32_t *fields, uint16_t *digits,
+                               const uint32_t *status, sc *g_out = nullptr, sc *h_out = nullptr) {
     const uint32_t B = sh.nproofs, k = sh.k;
-    const uint32_t i = tid / B, p = tid - i * B;
+    const uint32_t t4 = tid / B, p = tid - t4 * B, i0 = 4 * t4;
     if (g_out) {
-        sc_0(*g_out);
-        sc_0(*h_out);
+        for (int j = 0; j < 4; j++) {
+            sc_0(g_out[j]);
+            sc_0(h_out[j]);
+        }
     }
     if (status[p] != 0) return;
     const rp_fields fl = rp_field_layout(k, sh.m);
-    // s_i = prod_b (bit_b(i) ? u : u^-1)[k-1-b]  (ipp.rs:241-250), and its inverse s_{nm-1-i}
-    sc28 s, sinv, yp, um, uim, t;
-    sc28_one_mont(s);
-    sinv = s;
-    yp = s;
-    for (uint32_t bb = 0; bb < k; bb++) {
+    sc28 s_hi, sinv_hi, y_hi, um, uim, t;
+    sc28_one_mont(s_hi);
+    sinv_hi = s_hi;
+    y_hi = s_hi;
+    for (uint32_t bb = 2; bb < k; bb++) {
         rp_load28(um, fields, B, fl.u_m + (k - 1 - bb), p);
         rp_load28(uim, fields, B, fl.uinv_m + (k - 1 - bb), p);
-        const bool bit = (i >> bb) & 1;
+        const bool bit = (i0 >> bb) & 1;
         sc28 f1, f2;
 #pragma unroll
         for (int q = 0; q < 10; q++) {
             f1.v[q] = bit ? um.v[q] : uim.v[q];
             f2.v[q] = bit ? uim.v[q] : um.v[q];
         }
-        sc28_montmul(s, s, f1);
-        sc28_montmul(sinv, sinv, f2);
+        sc28_montmul(s_hi, s_hi, f1);
+        sc28_montmul(sinv_hi, sinv_hi, f2);
         if (bit) {
             rp_load28(t, fields, B, fl.yinvp_m + bb, p);
-            sc28_montmul(yp, yp, t);                       // y^-i
+            sc28_montmul(y_hi, y_hi, t);
         }
     }
-    sc28 a_m, b_m, r;
-    sc z, minus_z, g, h, v;
+    // bits 0 (challenge k-1) and 1 (challenge k-2): P[j] = (bit0(j) ? A : A^-1) (bit1(j) ? Bc : Bc^-1)
+    sc28 A, Ai, Bc, Bi, P[4];
+    rp_load28(A, fields, B, fl.u_m + (k - 1), p);
+    rp_load28(Ai, fields, B, fl.uinv_m + (k - 1), p);
+    rp_load28(Bc, fields, B, fl.u_m + (k - 2), p);
+    rp_load28(Bi, fields, B, fl.uinv_m + (k - 2), p);
+    sc28_montmul(P[0], Ai, Bi);
+    sc28_montmul(P[1], A, Bi);
+    sc28_montmul(P[2], Ai, Bc);
+    sc28_montmul(P[3], A, Bc);
+    sc28 y1, y2, y3;
+    rp_load28(y1, fields, B, fl.yinvp_m + 0, p);
+    rp_load28(y2, fields, B, fl.yinvp_m + 1, p);
+    sc28_montmul(y3, y1, y2);
+    sc28 a_m, b_m;
+    sc z, minus_z;
     rp_load28(a_m, fields, B, RPF_A_M, p);
     rp_load28(b_m, fields, B, RPF_B_M, p);
     rp_load(z, fields, B, RPF_Z, p);
     rp_load(minus_z, fields, B, RPF_MINUS_Z, p);
-    // g_i = -z - a s_i   (mod.rs:415)
-    sc28_montmul(t, a_m, s);
-    sc_from_mont28(v, t);
-    sc_sub(g, minus_z, v);
-    if (g_out) *g_out = g;
-    else fb_recode(digits + ((uint64_t)(2 + i) * prm.nwin) * B + p, B, g.v, prm);
-    // h_i = z + y^-i (z^2 z^j 2^i' - b s_i^-1), j = i / n, i' = i % n   (mod.rs:416-419)
-    const uint32_t j = i / sh.n, ib = i - j * sh.n;
-    sc28 zzzj, two_m;
-    sc two_i, lhs, rhs;
-    rp_load28(zzzj, fields, B, fl.zzzj_m + j, p);
-    sc_0(two_i);
-    two_i.v[ib >> 5] = 1u << (ib & 31);
-    sc_to_mont28(two_m, two_i);
-    sc28_montmul(r, zzzj, two_m);    // z^2 z^j 2^i' (Montgomery)
-    sc28_montmul(t, b_m, sinv);      // b / s_i     (Montgomery)
-    sc_from_mont28(lhs, r);
-    sc_from_mont28(rhs, t);
-    sc_sub(lhs, lhs, rhs);
-    sc_to_mont28(r, lhs);
-    sc28_montmul(r, r, yp);
-    sc_from_mont28(v, r);
-    sc_add(h, z, v);
-    if (h_out) *h_out = h;
-    else fb_recode(digits + ((uint64_t)(2 + sh.nm + i) * prm.nwin) * B + p, B, h.v, prm);
+#pragma unroll 1
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t i = i0 + j;
+        sc28 s, sinv, yp, r, two_m, zzzj;
+        sc g, h, v;
+        sc28_montmul(s, s_hi, P[j]);
+        sc28_montmul(sinv, sinv_hi, P[3 - j]);
+        if (j == 0) yp = y_hi;
+        else sc28_montmul(yp, y_hi, j == 1 ? y1 : (j == 2 ? y2 : y3));
+        sc28_montmul(t, a_m, s);
+        sc_from_mont28(v, t);
+        sc_sub(g, minus_z, v);
+        const uint32_t jj = i / sh.n, ib = i - jj * sh.n;
+        rp_load28(zzzj, fields, B, fl.zzzj_m + jj, p);
+        rp_two_pow_mont(two_m, ib);
+        sc28_montmul(r, zzzj, two_m);    // z^2 z^j 2^i'
+        sc28_montmul(t, b_m, sinv);      // b / s_i
+        sc28_sub_lazy(r, r, t);
+        sc28_montmul(r, r, yp);
+        sc_from_mont28(v, r);
+        sc_add(h, z, v);
+        if (g_out) {
+            g_out[j] = g;
+            h_out[j] = h;
+        } else {
+            fb_recode(digits + ((uint64_t)(2 + i) * prm.nwin) * B + p, B, g.v, prm);
+            fb_recode(digits + ((uint64_t)(2 + sh.nm + i) * prm.nwin) * B + p, B, h.v, prm);
+        }
+    }
 }
 
 }  // namespace bp

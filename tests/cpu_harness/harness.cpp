@@ -273,19 +273,23 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
     // launch 2
     std::vector<uint64_t> acc((size_t)n_gen_terms * 10, 0);
     if (weights64) {
-        for (uint32_t tid = 0; tid < sh.nm * nbatch; tid++) {
-            const uint32_t i = tid / nbatch, p = tid - i * nbatch;
-            sc g, h; uint64_t l[10];
-            rp_expand_b_thread(tid, sh, prm, fields.data(), nullptr, status.data(), &g, &h);
-            rlc_limbs(l, g); for (int q = 0; q < 10; q++) acc[(size_t)(2 + i) * 10 + q] += l[q];
-            rlc_limbs(l, h); for (int q = 0; q < 10; q++) acc[(size_t)(2 + sh.nm + i) * 10 + q] += l[q];
-            if (i < 2 && status[p] == 0) {
-                sc r; rp_load(r, fields.data(), nbatch, RPF_ROW0 + i, p);
-                rlc_limbs(l, r); for (int q = 0; q < 10; q++) acc[(size_t)i * 10 + q] += l[q];
+        for (uint32_t tid = 0; tid < (sh.nm / 4) * nbatch; tid++) {
+            const uint32_t t4 = tid / nbatch, p = tid - t4 * nbatch;
+            sc g[4], h[4]; uint64_t l[10];
+            rp_expand_b4_thread(tid, sh, prm, fields.data(), nullptr, status.data(), g, h);
+            for (uint32_t j = 0; j < 4; j++) {
+                rlc_limbs(l, g[j]); for (int q = 0; q < 10; q++) acc[(size_t)(2 + 4 * t4 + j) * 10 + q] += l[q];
+                rlc_limbs(l, h[j]); for (int q = 0; q < 10; q++) acc[(size_t)(2 + sh.nm + 4 * t4 + j) * 10 + q] += l[q];
+            }
+            if (t4 == 0 && status[p] == 0) {
+                for (uint32_t row = 0; row < 2; row++) {
+                    sc r; rp_load(r, fields.data(), nbatch, RPF_ROW0 + row, p);
+                    rlc_limbs(l, r); for (int q = 0; q < 10; q++) acc[(size_t)row * 10 + q] += l[q];
+                }
             }
         }
     } else {
-        for (uint32_t tid = 0; tid < sh.nm * nbatch; tid++) rp_expand_b_thread(tid, sh, prm, fields.data(), digits.data(), status.data());
+        for (uint32_t tid = 0; tid < (sh.nm / 4) * nbatch; tid++) rp_expand_b4_thread(tid, sh, prm, fields.data(), digits.data(), status.data());
     }
     std::vector<vb_chunk> chunks; std::vector<uint32_t> chunk_first(nbatch + 1); uint32_t tt = 0;
     for (uint32_t b = 0; b < nbatch; b++) {
