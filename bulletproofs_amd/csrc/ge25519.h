@@ -100,6 +100,24 @@ BP_HD void ge_madd(ge_ext &r, const ge_ext &p, const ge_niels &q, bool neg) {
     fe_mul(r.T, e, h);
 }
 
+// r = +-q for an affine Niels point: what ge_madd(identity, q, neg) computes, with its constant operands folded
+// (1 multiplication instead of 7): (X:Y:Z:T) = (2e : 2h : 4 : e h), e = x-part, h = y-part of q
+BP_HD void ge_from_niels(ge_ext &r, const ge_niels &q, bool neg) {
+    fe qa, qb, e, h;
+    fe_select(qa, q.ymx, q.ypx, neg);
+    fe_select(qb, q.ypx, q.ymx, neg);
+    fe_sub(e, qb, qa);                  // 2x (or -2x)
+    fe_add(h, qb, qa);                  // 2y
+    fe_carry(h);
+    fe_add(r.X, e, e);
+    fe_carry(r.X);                      // coordinates of an accumulator are kept reduced
+    fe_add(r.Y, h, h);
+    fe_carry(r.Y);
+    fe_0(r.Z);
+    r.Z.v[0] = 4;
+    fe_mul(r.T, e, h);
+}
+
 BP_HD void ge_add(ge_ext &r, const ge_ext &p, const ge_ext &q) {
     ge_cached c;
     ge_to_cached(c, q);

@@ -197,7 +197,8 @@ BP_HD void fb_accum_thread(uint32_t p, uint32_t split, uint32_t q0, uint32_t q1,
                     n.ymx.v[i] = line_cur.w[10 + i];
                     n.t2d.v[i] = line_cur.w[20 + i];
                 }
-                ge_madd(acc, acc, n, d < 0);
+                if (q == q0) ge_from_niels(acc, n, d < 0);   // the accumulator is still the identity: 1 multiplication, not 7
+                else ge_madd(acc, acc, n, d < 0);
             }
             line_cur = line_next;
             v_cur = v_next;
