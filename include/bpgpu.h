@@ -25,6 +25,11 @@
  *   - one context serves one device; calls on one context are serialised by an
  *     internal mutex (the reference's calls are &self and re-entrant; use one
  *     context per host thread for concurrency).
+ *   - throughput: a batch is a chain of a few dependent launches, several of them
+ *     narrow, so one stream cannot fill the device.  Keep many batches in flight:
+ *     one context per HIP stream (the generator tables are shared by the contexts
+ *     of a process), ~48 streams, and GPU_MAX_HW_QUEUES=16 in the environment
+ *     (ROCm's default of 4 hardware queues serialises the streams).
  */
 #ifndef BPGPU_H
 #define BPGPU_H
