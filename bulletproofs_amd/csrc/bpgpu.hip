@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(64) k_fb_norm(uint64_t n_groups, uint64_t n_en
 }
 
 __global__ void __launch_bounds__(BP_BLOCK) k_fb_recode(uint32_t nthreads, fb_params prm, uint32_t nproofs, uint32_t n_gen_terms,
-                                                         const uint32_t *gen_scalars, uint16_t *digits, uint32_t *status) {
+                                                         const uint32_t *gen_scalars, fb_digit *digits, uint32_t *status) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid < nthreads) fb_recode_thread(tid, prm, nproofs, n_gen_terms, gen_scalars, digits, status);
 }
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_fb_recode(uint32_t nthreads, fb_pa
 // one XCD (L % 8) share the same slices of the table in that XCD's L2.
 #define FB_BLOCK 64
 __global__ void __launch_bounds__(FB_BLOCK) k_fb_accum(fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit,
-                                                        uint32_t npairs, const uint32_t *gen_ids, const uint16_t *digits,
+                                                        uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits,
                                                         const fb_entry *table, ge_ext *partial) {
     const uint32_t L = blockIdx.x;
     uint32_t split, pblk;
@@ -161,7 +161,7 @@ __global__ void __launch_bounds__(64) k_finish8(uint32_t nproofs, uint32_t nspli
 __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs,
                                                          const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields,
                                                          ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m,
-                                                         uint32_t *recoded, uint16_t *digits, const uint8_t *rho64) {
+                                                         uint32_t *recoded, fb_digit *digits, const uint8_t *rho64) {
     __shared__ uint32_t lds[50 * RP_BLOCK];   // sponge states, word-major: word w of lane t at w*RP_BLOCK + t
     if (blockIdx.x < n_tr) {
         const uint32_t p = blockIdx.x * RP_BLOCK + threadIdx.x;
@@ -181,7 +181,7 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1(rp_shape sh, rp_strobe_i
 // launch 3: [0, n_win) per-chunk window sums of the proof-specific points  ||  the 2nm generator exponents
 __global__ void __launch_bounds__(BP_BLOCK) k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab,
                                                          const uint32_t *recoded, ge_ext *part, ge_cached *colc, uint32_t nthreads_exp,
-                                                         rp_shape sh, fb_params prm, const uint32_t *fields, uint16_t *digits,
+                                                         rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits,
                                                          const uint32_t *status) {
     if (blockIdx.x < n_win) {
         const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
@@ -199,7 +199,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rp_stage3(uint32_t n_win, uint32_t
 template <bool QUAD>
 __global__ void __launch_bounds__(FB_BLOCK) k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge_ext *part, const ge_cached *colc,
                                                          ge_ext *hq, fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit,
-                                                         uint32_t npairs, const uint32_t *gen_ids, const uint16_t *digits,
+                                                         uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits,
                                                          const fb_entry *table, ge_ext *partial) {
     if (blockIdx.x < n_hw) {
         if (QUAD) hq_horner_msm(blockIdx.x * 16 + (threadIdx.x >> 2), nproofs, colc, hq);
@@ -294,7 +294,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rlc_stage3(uint32_t n_win, uint32_
 // lane g: reduce the accumulated coefficient of generator row g mod l, recode it for the table walk (batch of 1)
 // (lane 0 also initialises the small control block of the batch-of-one tail: verdict byte, a zero status word and
 // the chunk bounds {0, rows} of the final column sums)
-__device__ __forceinline__ void rlc_scalars_lane(uint32_t g, uint32_t n_rows, const unsigned long long *acc, uint16_t *digits, fb_params prm,
+__device__ __forceinline__ void rlc_scalars_lane(uint32_t g, uint32_t n_rows, const unsigned long long *acc, fb_digit *digits, fb_params prm,
                                                  uint32_t *ctl, uint32_t rows) {
     if (g == 0) {
         ctl[0] = 0;
@@ -313,7 +313,7 @@ __device__ __forceinline__ void rlc_scalars_lane(uint32_t g, uint32_t n_rows, co
 // one level of the column-sum tree (blocks [0, n_red))  ||  the combined generator coefficients
 __global__ void __launch_bounds__(BP_BLOCK) k_rlc_colsum_scalars(uint32_t n_red, uint32_t nthreads, uint32_t rows_in, uint32_t group,
                                                                   const ge_ext *in, ge_ext *out, uint32_t n_rows, const unsigned long long *acc,
-                                                                  uint16_t *digits, fb_params prm, uint32_t *ctl, uint32_t rows_out) {
+                                                                  fb_digit *digits, fb_params prm, uint32_t *ctl, uint32_t rows_out) {
     if (blockIdx.x < n_red) {
         const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
         if (tid < nthreads) fb_reduce_thread(tid, 64, rows_in, group, in, out);
@@ -442,7 +442,7 @@ struct bpgpu_ctx {
     size_t arena_cap = 0, arena_off = 0;
     // options
     uint32_t W = 0;                          // fixed-base window bits; 0 = largest that fits table_budget
-    uint64_t table_budget = 48ull << 30;     // bytes of HBM the generator tables may take (a sixth of the MI355X's 288 GB)
+    uint64_t table_budget = 96ull << 30;     // bytes of HBM the generator tables may take (a third of the MI355X's 288 GB)
     uint32_t splits = 0;
     uint32_t horner_lanes = 0;               // lanes per Horner chain in the range-proof path: 4, 64, 0 = auto (4)
     struct shared_table *tab_ref = nullptr;  // refcounted, shared by the contexts of one device
@@ -607,7 +607,7 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
     if (!c || !key) return BPGPU_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     if (!strcmp(key, "fixed_window_bits")) {
-        if (value != 0 && (value < 2 || value > 16)) return fail(c, BPGPU_ERR_INVALID_ARG, "fixed_window_bits must be 0 (auto) or 2..16");
+        if (value != 0 && (value < 2 || value > 20)) return fail(c, BPGPU_ERR_INVALID_ARG, "fixed_window_bits must be 0 (auto) or 2..20");
         if (c->d_table) return fail(c, BPGPU_ERR_INVALID_ARG, "set fixed_window_bits before loading generators");
         c->W = (uint32_t)value;
         return BPGPU_OK;
@@ -690,10 +690,10 @@ static int build_tables(bpgpu_ctx *c) {
     fb_params prm;
     prm.n_gens = (uint32_t)(2 + 2 * c->gens_capacity * c->party_capacity);
     uint32_t W = c->W;
-    if (W == 0) {   // largest window whose table fits the budget (256/W additions per generator term)
+    if (W == 0) {   // the fewest windows (= additions per generator term) whose table fits the budget; ties: smaller table
         W = 4;
-        for (uint32_t w = 5; w <= 16; w++)
-            if (table_bytes(prm.n_gens, w) <= c->table_budget) W = w;
+        for (uint32_t w = 5; w <= 20; w++)
+            if (table_bytes(prm.n_gens, w) <= c->table_budget && fb_nwin(w) < fb_nwin(W)) W = w;
     }
     prm.W = W;
     prm.nwin = fb_nwin(W);
@@ -1062,12 +1062,12 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
     size_t off[7];
     plan_vb_uniform(ap, nbatch, n_unique, off);
     const size_t off_status = ap.add(nbatch * 4);
-    const size_t off_digits = ap.add((size_t)npairs * nbatch * 2 + 16);
+    const size_t off_digits = ap.add((size_t)npairs * nbatch * sizeof(fb_digit) + 16);
     const size_t off_partial = ap.add((size_t)2 * nsplit * nbatch * sizeof(ge_ext) + 16);
     rc = arena_reserve(c, ap.total);
     if (rc) return rc;
     uint32_t *d_status = (uint32_t *)(c->arena + off_status);
-    uint16_t *d_digits = (uint16_t *)(c->arena + off_digits);
+    fb_digit *d_digits = (fb_digit *)(c->arena + off_digits);
     ge_ext *d_partial = (ge_ext *)(c->arena + off_partial);
     HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
     vb_dev d{};
@@ -1285,7 +1285,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     arena_plan ap;
     size_t off[7];
     plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off);
-    const size_t off_digits = ap.add((size_t)npairs * nbatch * 2 + 16);
+    const size_t off_digits = ap.add((size_t)npairs * nbatch * sizeof(fb_digit) + 16);
     const size_t off_partial = ap.add((size_t)2 * nsplit * nbatch * sizeof(ge_ext) + 16);
     const size_t off_fields = ap.add((size_t)fl.count * nbatch * BP_RP_REC * 4 + 16);
     const size_t off_mv = ap.add(nbatch);
@@ -1297,7 +1297,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const size_t off_wts = rlc ? ap.add(nbatch * 64) : 0;
     const size_t off_acc = rlc ? ap.add((size_t)n_gen_terms * 10 * 8) : 0;
     const size_t off_tree = rlc ? ap.add((n_rows0 / 8 + 64) * 64 * sizeof(ge_ext)) : 0;
-    const size_t off_dig1 = rlc ? ap.add((size_t)npairs * 2 + 16) : 0;
+    const size_t off_dig1 = rlc ? ap.add((size_t)npairs * sizeof(fb_digit) + 16) : 0;
     const size_t off_part1 = rlc ? ap.add((size_t)2 * nsplit1 * sizeof(ge_ext) + 16) : 0;
     const size_t off_res1 = rlc ? ap.add(sizeof(ge_ext) + 64) : 0;   // Horner result, then 8 result words, verdict byte, chunk bounds
     rc = arena_reserve(c, ap.total);
@@ -1312,7 +1312,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         c->rp_status_dirty = true;
     }
     uint32_t *d_status = c->rp_status;
-    uint16_t *d_digits = (uint16_t *)(a + off_digits);
+    fb_digit *d_digits = (fb_digit *)(a + off_digits);
     ge_ext *d_partial = (ge_ext *)(a + off_partial);
     uint32_t *d_fields = (uint32_t *)(a + off_fields);
     uint8_t *d_mv = (uint8_t *)(a + off_mv);
@@ -1387,7 +1387,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
                d_fields, d_status, d_acc, (nbatch % 64 == 0) ? 1 : 0);
         // column sums over ALL chunks of ALL proofs: rows of 64 window sums, tree-added 16- then 8-way until <= 8 rows
         // remain; the Horner wavefront adds those itself
-        uint16_t *d_dig1 = (uint16_t *)(a + off_dig1);
+        fb_digit *d_dig1 = (fb_digit *)(a + off_dig1);
         ge_ext *d_part1 = (ge_ext *)(a + off_part1), *d_hq1 = (ge_ext *)(a + off_res1);
         uint32_t *d_ctl = (uint32_t *)(a + off_res1 + sizeof(ge_ext));   // [0] unused, [1] zero, [2..4) chunk bounds {0, rows}
         ge_ext *cur = d.part, *next = (ge_ext *)(a + off_tree);

@@ -3,7 +3,7 @@
 // src/generators.rs:207-259 of the reference) are the same points for every
 // proof of a batch and for every batch, so they get precomputed window tables
 //     T[g][win][k] = (k+1) * 2^(W*win) * P_g ,  k < 2^(W-1),  affine Niels form
-// that live in HBM.  With them a generator term costs 256/W mixed additions
+// that live in HBM.  With them a generator term costs ceil(255/W) mixed additions
 // and no doublings at all (the reference's Straus/Pippenger spend ~256
 // doublings + 256/5..256/8 additions per term on them).
 //
@@ -28,14 +28,17 @@ struct __attribute__((aligned(16))) fb_entry {
 
 struct fb_params {
     uint32_t W;        // window bits (1..16)
-    uint32_t nwin;     // ceil(256 / W)  (+1 when the recoding can carry out of the top window)
+    uint32_t nwin;     // fb_nwin(W) = ceil(255 / W)
     uint32_t half;     // 2^(W-1) = entries per (generator, window)
     uint32_t n_gens;   // generators in the table
 };
 
-// Windows needed so that the recoded value s + sum_win half*2^(W*win) (s < 2^253, W >= 2)
-// stays below 2^(W*nwin): the added constant is < (2/3)*2^(W*nwin), so W*nwin >= 256 suffices.
-BP_HD uint32_t fb_nwin(uint32_t W) { return (256 + W - 1) / W; }
+// one recoded window: the unsigned W-bit value digit + half (W <= 20)
+typedef uint32_t fb_digit;
+// Windows needed so that the recoded value s + sum_win half*2^(W*win) (s < 2^253, W >= 2) stays below
+// 2^(W*nwin): the added constant is < 2^(W*nwin-1) (1 + 1/(2^W-1)), so W*nwin >= 255 suffices
+// (2^253 <= 2^254 (2^W-2)/(2^W-1) for W >= 2).  W = 17 is the first window that saves one (15 instead of 16).
+BP_HD uint32_t fb_nwin(uint32_t W) { return (255 + W - 1) / W; }
 
 // ---- table construction ------------------------------------------------------
 // thread g < n_gens : decode generator, emit base[g][win] = 2^(W*win) * P_g (extended)
@@ -117,7 +120,7 @@ BP_HD void fb_norm_thread(uint64_t gid, uint64_t n_entries, fb_entry *table) {
 // ---- scalar recoding -----------------------------------------------------------
 // Signed fixed-window recoding of a canonical scalar: add half at every window
 // position, then window value v in [0, 2^W) encodes digit d = v - half.
-BP_HD void fb_recode(uint16_t *digits /*stride*/, uint64_t stride, const uint32_t s[8], fb_params prm) {
+BP_HD void fb_recode(fb_digit *digits /*stride*/, uint64_t stride, const uint32_t s[8], fb_params prm) {
     // r = s + sum_win half << (W*win), computed in 9 words (288 bits)
     uint32_t r[10];
 #pragma unroll
@@ -139,14 +142,14 @@ BP_HD void fb_recode(uint16_t *digits /*stride*/, uint64_t stride, const uint32_
     for (uint32_t win = 0; win < prm.nwin; win++) {
         const uint32_t bit = win * prm.W, idx = bit >> 5, sh = bit & 31;
         uint64_t two = (uint64_t)r[idx] | ((uint64_t)r[idx + 1] << 32);
-        digits[(uint64_t)win * stride] = (uint16_t)((two >> sh) & ((1u << prm.W) - 1u));
+        digits[(uint64_t)win * stride] = (fb_digit)((two >> sh) & ((1u << prm.W) - 1u));
     }
 }
 
 // thread = g_local * nproofs + p : recode scalar of generator term g_local of proof p into
 // digits[(g_local*nwin + win) * nproofs + p]
 BP_HD void fb_recode_thread(uint32_t tid, fb_params prm, uint32_t nproofs, uint32_t n_gen_terms,
-                            const uint32_t *gen_scalars /*[p][g_local][8]*/, uint16_t *digits, uint32_t *status) {
+                            const uint32_t *gen_scalars /*[p][g_local][8]*/, fb_digit *digits, uint32_t *status) {
     const uint32_t g = tid / nproofs, p = tid % nproofs;
     uint32_t s[8];
 #pragma unroll
@@ -174,7 +177,7 @@ BP_HD const fb_entry *fb_entry_addr(const fb_entry *table, const uint32_t *gen_i
     return table + ((uint64_t)gen_ids[g] * prm.nwin + win) * prm.half + (a ? a - 1 : 0);
 }
 BP_HD void fb_accum_thread(uint32_t p, uint32_t split, uint32_t q0, uint32_t q1, fb_params prm, uint32_t nproofs,
-                           const uint32_t *gen_ids, const uint16_t *digits, const fb_entry *table, ge_ext *partial) {
+                           const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial) {
     ge_ext acc;
     ge_identity(acc);
     if (q0 < q1) {

@@ -291,7 +291,7 @@ BP_HD void rp_emit_coeff(uint32_t *dst, const sc28 &vm, const sc28 *rho_m) {
 // multiplied by its weight rho_p = from_bytes_mod_order_wide(rho64[p]); the B_blinding / B coefficients go to
 // the ROW0 / ROW1 fields instead of `digits` (they are summed over the batch in the next launch).
 BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t lg_m, uint32_t *fields, uint32_t *recoded,
-                              uint16_t *digits, const uint32_t *status, const uint8_t *rho64 = nullptr) {
+                              fb_digit *digits, const uint32_t *status, const uint8_t *rho64 = nullptr) {
     if (status[p] != 0) return;   // digits/scalars of rejected proofs are never consumed (finish masks them)
     const uint32_t B = sh.nproofs, k = sh.k;
     const rp_fields fl = rp_field_layout(k, sh.m);
@@ -579,7 +579,7 @@ BP_HD void sc28_sub_lazy(sc28 &r, const sc28 &a, const sc28 &b) {
 // y^-i likewise.  g_i = -z - a s_i (mod.rs:415), h_i = z + y^-i (z^2 z^j 2^i' - b s_i^-1), j = i / n,
 // i' = i % n (mod.rs:416-419).  Writes the digits of rows 2+i and 2+nm+i, or -- g_out / h_out given (batch-
 // combination mode) -- returns the eight coefficients (zero for a rejected proof).
-BP_HD void rp_expand_b4_thread(uint32_t tid, rp_shape sh, fb_params prm, const uint32_t *fields, uint16_t *digits,
+BP_HD void rp_expand_b4_thread(uint32_t tid, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits,
                                const uint32_t *status, sc *g_out = nullptr, sc *h_out = nullptr) {
     const uint32_t B = sh.nproofs, k = sh.k;
     const uint32_t t4 = tid / B, p = tid - t4 * B, i0 = 4 * t4;

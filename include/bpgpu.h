@@ -68,9 +68,9 @@ int bpgpu_ctx_create(int device, bpgpu_ctx **out);
 void bpgpu_ctx_destroy(bpgpu_ctx *ctx);
 const char *bpgpu_last_error(bpgpu_ctx *ctx);
 /* Tunables (set before bpgpu_gens_*):
- *   "fixed_window_bits"     window W of the generator tables, 2..16; 0 (default) = the largest W whose
- *                           table (n_gens * ceil(256/W) * 2^(W-1) * 128 bytes) fits fixed_table_max_bytes
- *   "fixed_table_max_bytes" HBM budget of the tables (default 48 GiB; the MI355X has 288 GB)
+ *   "fixed_window_bits"     window W of the generator tables, 2..20; 0 (default) = the W with the fewest windows whose
+ *                           table (n_gens * ceil(255/W) * 2^(W-1) * 128 bytes) fits fixed_table_max_bytes
+ *   "fixed_table_max_bytes" HBM budget of the tables (default 96 GiB; the MI355X has 288 GB)
  *   "fixed_splits"          workgroups the generator terms of one proof block are split over (0 = auto)
  *   "horner_lanes"          lanes per Horner chain of the proof-specific terms in the range-proof path:
  *                           4 (16 chains per wavefront: least total work, best with several batches in flight),

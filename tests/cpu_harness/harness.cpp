@@ -165,7 +165,7 @@ int h_msm_shared(uint32_t W, uint32_t nsplit, uint32_t n_gens_loaded, const uint
     if (horner_all(nbatch, col, colq16, hq)) return -99;
     // generator part
     const uint32_t npairs = n_gen_terms * prm.nwin;
-    std::vector<uint16_t> digits((size_t)npairs * nbatch + 1);
+    std::vector<fb_digit> digits((size_t)npairs * nbatch + 1);
     for (uint32_t tid = 0; tid < n_gen_terms * nbatch; tid++) fb_recode_thread(tid, prm, nbatch, n_gen_terms, (const uint32_t *)gen_scalars, digits.data(), status.data());
     std::vector<ge_ext> partial((size_t)nsplit * nbatch + 1);
     const uint32_t per = (npairs + nsplit - 1) / nsplit;
@@ -261,7 +261,7 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
     const rp_fields fl = rp_field_layout(k, m);
     const uint32_t t0 = nbatch * sh.U;
     std::vector<uint32_t> fields((size_t)fl.count * nbatch * BP_RP_REC + 8), rec((size_t)t0 * 8 + 8, 0xdeadbeefu), status(nbatch + 1, 0), outw((size_t)nbatch * 8 + 1);
-    std::vector<uint16_t> digits((size_t)npairs * nbatch + 1, 0xffff);   // poison: unwritten rows must be masked
+    std::vector<fb_digit> digits((size_t)npairs * nbatch + 1, 0xffff);   // poison: unwritten rows must be masked
     std::vector<ge_cached> tab((size_t)t0 * 8 + 1);
     // launch 1
     for (uint32_t p = 0; p < nbatch; p++) {
@@ -320,7 +320,7 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
             rows = ng;
         }
         // batch-of-one tail: coefficients mod l -> digits -> table walk -> Horner over the combined column sums -> finish
-        std::vector<uint16_t> dig1((size_t)npairs + 1);
+        std::vector<fb_digit> dig1((size_t)npairs + 1);
         for (uint32_t g = 0; g < n_gen_terms; g++) {
             sc v; rlc_acc_to_sc(v, &acc[(size_t)g * 10]);
             fb_recode(dig1.data() + (size_t)g * prm.nwin, 1, v.v, prm);
