@@ -689,30 +689,37 @@ static int build_tables(bpgpu_ctx *c) {
     // c->d_gens / c->h_gens hold n_gens compressed points
     fb_params prm;
     prm.n_gens = (uint32_t)(2 + 2 * c->gens_capacity * c->party_capacity);
-    uint32_t W = c->W;
-    if (W == 0) {   // the fewest windows (= additions per generator term) whose table fits the budget; ties: smaller table
-        W = 4;
-        for (uint32_t w = 5; w <= 20; w++)
-            if (table_bytes(prm.n_gens, w) <= c->table_budget && fb_nwin(w) < fb_nwin(W)) W = w;
-    }
-    prm.W = W;
-    prm.nwin = fb_nwin(W);
-    prm.half = 1u << (W - 1);
-    c->prm = prm;
     release_table(c);
     for (auto &kv : c->gen_ids_cache) hipFree(kv.second);
     c->gen_ids_cache.clear();
     std::lock_guard<std::mutex> lk(g_tab_mu);
-    for (shared_table *t : g_tables)
-        if (t->device == c->device && t->W == W && t->gens == c->h_gens) {
-            t->refs++;
-            c->tab_ref = t;
-            c->d_table = t->d_table;
-            return BPGPU_OK;
-        }
-    const size_t entries = (size_t)prm.n_gens * prm.nwin * prm.half;
+    uint32_t W = c->W;
     fb_entry *d_table = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_table, entries * sizeof(fb_entry)));
+    size_t entries = 0;
+    for (uint64_t budget = c->table_budget;; budget /= 2) {
+        if (c->W == 0) {   // the fewest windows (= additions per generator term) whose table fits the budget; ties: smaller table
+            W = 4;
+            for (uint32_t w = 5; w <= 20; w++)
+                if (table_bytes(prm.n_gens, w) <= budget && fb_nwin(w) < fb_nwin(W)) W = w;
+        }
+        prm.W = W;
+        prm.nwin = fb_nwin(W);
+        prm.half = 1u << (W - 1);
+        c->prm = prm;
+        for (shared_table *t : g_tables)
+            if (t->device == c->device && t->W == W && t->gens == c->h_gens) {
+                t->refs++;
+                c->tab_ref = t;
+                c->d_table = t->d_table;
+                return BPGPU_OK;
+            }
+        entries = (size_t)prm.n_gens * prm.nwin * prm.half;
+        if (hipMalloc((void **)&d_table, entries * sizeof(fb_entry)) == hipSuccess) break;
+        (void)hipGetLastError();
+        d_table = nullptr;
+        // automatic window: the HBM may be shared with other tenants -- settle for a smaller table
+        if (c->W != 0 || W <= 8) return fail(c, BPGPU_ERR_HIP, "hipMalloc of %zu table bytes (W = %u) failed", entries * sizeof(fb_entry), W);
+    }
     ge_ext *d_base = nullptr;
     uint32_t *d_bad = nullptr;
     if (hipMalloc((void **)&d_base, (size_t)prm.n_gens * prm.nwin * sizeof(ge_ext)) != hipSuccess ||

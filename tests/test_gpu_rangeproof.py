@@ -234,3 +234,25 @@ def test_zero_commitments_and_odd_batches(ctx64x8, oracle, oracle_gens_64_8, gol
     # empty transcript label
     rc, _ = oracle.verify(oracle_gens_64_8, pr, golden["vc_bytes"][:32], 8, b"", rng[:64])
     assert list(ctx64x8.rangeproof_verify_batch(8, 1, pr, len(pr), golden["vc_bytes"][:32], b"", rng[:64])) == [rc] == [1]
+
+
+def test_tables_shrink_when_hbm_is_short(golden):
+    """Automatic window choice: when the preferred table does not fit the free HBM (another tenant on the device),
+    gens_create settles for a smaller window instead of failing; results are unchanged."""
+    import torch
+    import bulletproofs_amd as bp
+    free, total = torch.cuda.mem_get_info(0)
+    hog = torch.empty(max(0, free - (24 << 30)), dtype=torch.uint8, device="cuda:0")   # leave ~24 GiB
+    c = bp.Context(0)
+    c.gens_create(64, 1)                          # preferred: W = 19, 61 GB
+    w = c.get_option("fixed_window_bits")
+    assert 8 <= w < 19 and c.get_option("fixed_table_bytes") < (24 << 30)
+    case = golden["cases"][12]                    # n = 64, m = 1
+    pr = bytes.fromhex(case["proof"])
+    bad = bytearray(pr)
+    bad[128] ^= 1
+    v = c.rangeproof_verify_batch(64, 1, pr + bytes(bad), len(pr), golden["vc_bytes"][:32] * 2, golden["label"], None)
+    assert list(v) == [0, 1]
+    c.close()
+    del hog
+    torch.cuda.empty_cache()
