@@ -383,6 +383,15 @@ int h_rp_verify_rlc(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_
     return rp_verify_impl(W, nsplit, gens_capacity, party_capacity, gens, n, m, nbatch, proofs, proof_len, commitments, label, label_len, rng64,
                           verdict_out, batch_out, weights64);
 }
+// window recoding of one scalar: returns nwin, digits[win] = unsigned W-bit value (real digit + half)
+uint32_t h_fb_recode(uint32_t W, const uint8_t *scalar, uint32_t *digits_out) {
+    fb_params prm; prm.W = W; prm.nwin = fb_nwin(W); prm.half = 1u << (W - 1); prm.n_gens = 0;
+    uint32_t s[8]; memcpy(s, scalar, 32);
+    std::vector<fb_digit> d(prm.nwin);
+    fb_recode(d.data(), 1, s, prm);
+    for (uint32_t i = 0; i < prm.nwin; i++) digits_out[i] = d[i];
+    return prm.nwin;
+}
 // sum of `count` canonical scalars through the limb accumulator (rlc.h)
 void h_rlc_sum(uint32_t count, const uint8_t *scalars, uint8_t *out) {
     uint64_t acc[10] = {0};

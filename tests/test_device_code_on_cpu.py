@@ -221,6 +221,23 @@ def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, gol
     assert list(vd.raw) == [2, 1, 1, 0]
 
 
+def test_window_recoding_all_widths(H):
+    """fb_recode / fb_nwin (msm_fixed.h): for every window width 2..20 the signed digits reconstruct the scalar and
+    ceil(255 / W) windows suffice (W = 17 is the first width that saves a window: 15 instead of 16)."""
+    L = T.L
+    random.seed(5)
+    vals = [0, 1, L - 1, 2**252, 2**253 - 1 if 2**253 - 1 < L else L - 2, (L - 1) // 2] + [random.randrange(L) for _ in range(40)]
+    for W in range(2, 21):
+        half = 1 << (W - 1)
+        for v in vals:
+            d = (C.c_uint32 * 130)()
+            nwin = H.h_fb_recode(W, v.to_bytes(32, "little"), d)
+            assert nwin == (255 + W - 1) // W
+            assert all(0 <= d[i] < (1 << W) for i in range(nwin))
+            assert sum((d[i] - half) << (W * i) for i in range(nwin)) == v, (W, hex(v))
+    assert (255 + 16) // 17 == 15 and (255 + 15) // 16 == 16
+
+
 def _rlc_expected(oracle, gg, n, m, label, proofs, plen, coms, rng, wts):
     """R = sum_i rho_i * MegaCheck_i over the proofs the front end accepts, by one oracle MSM over all weighted terms."""
     L = T.L
