@@ -39,7 +39,7 @@ def parse_args():
     ap.add_argument("--window-bits", type=int, default=0, help="fixed-base window (default: library default)")
     ap.add_argument("--splits", type=int, default=0, help="workgroups the generator terms of a proof block are split over (default: library default)")
     ap.add_argument("--horner-lanes", type=int, default=0, choices=[0, 4, 64], help="lanes per Horner chain (default: library default)")
-    ap.add_argument("--streams", type=int, default=64,
+    ap.add_argument("--streams", type=int, default=128,
                     help="independent (context, HIP stream) pairs the steps are issued on round-robin, so that "
                          "consecutive batches overlap on the device (one context per stream, as bpgpu.h prescribes "
                          "for concurrent callers)")
