@@ -31,8 +31,8 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=1920)
-    ap.add_argument("--warmup", type=int, default=192)
+    ap.add_argument("--steps", type=int, default=3840)
+    ap.add_argument("--warmup", type=int, default=256)
     ap.add_argument("--config", default="cfg2", choices=["cfg1", "cfg2", "cfg3", "cfg4"],
                     help="BASELINE.json config; cfg2 (batch of 1024 single 64-bit proofs per GPU) is the metric's config")
     ap.add_argument("--batch", type=int, default=0, help="override proofs per GPU per step")
