@@ -168,9 +168,9 @@ def main():
         step(i)
     fence()
     in_region_events = not a.events_outside
-    # per-kernel timing inside the timed region samples every 4th (context, stream) pair: the start/stop events of a
+    # per-kernel timing inside the timed region samples every 8th (context, stream) pair: the start/stop events of a
     # dispatch are cheap but not free (~5 % of throughput when attached to every launch of every stream)
-    prof_ctxs = ctxs[::4] if in_region_events else ctxs
+    prof_ctxs = ctxs[::8] if in_region_events else ctxs
     for c_ in ctxs:
         c_.profile_reset()
     for c_ in prof_ctxs:
@@ -263,7 +263,7 @@ def main():
                     "frac": achieved / 8000.0, "traffic": traffic,
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt,
                     "algorithmic_bytes_per_launch": alg_bytes,
-                    "timing": "start/stop events attached to the dispatches (hipExtLaunchKernelGGL) of every 4th stream, on their launch stream, %s the timed region; "
+                    "timing": "start/stop events attached to the dispatches (hipExtLaunchKernelGGL) of every 8th stream, on their launch stream, %s the timed region; "
                               "kernel begin..end as in rocprofv3's kernel trace" % ("inside" if in_region_events else "second pass after"),
                     # the binding resource is integer VALU issue, not HBM: also report it
                     "valu": {**valu_util,
