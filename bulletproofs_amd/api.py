@@ -113,3 +113,16 @@ class RangeProof:
         assert all(len(r) == ln for r in raw) and all(len(c) == m for c in commitments)
         v = bp_gens.ctx.rangeproof_verify_batch(n, m, b"".join(raw), ln, b"".join(b"".join(c) for c in commitments), transcript.label, rng64)
         return [None if x == 0 else _BY_CODE[x]() for x in v]
+
+    @staticmethod
+    def verify_batch_combined(bp_gens, pc_gens, transcript, proofs, commitments, n, rng64=None, weights64=None):
+        """The same verdicts through the batch-combined check (bpgpu_rangeproof_verify_rlc; no counterpart in the crate): one
+        identity test per batch when every proof verifies, per-proof re-verification inside the call when not."""
+        if not proofs:
+            return []
+        raw = [p.to_bytes() if isinstance(p, RangeProof) else bytes(p) for p in proofs]
+        m, ln = len(commitments[0]), len(raw[0])
+        assert all(len(r) == ln for r in raw) and all(len(c) == m for c in commitments)
+        v, _, _ = bp_gens.ctx.rangeproof_verify_rlc(n, m, b"".join(raw), ln, b"".join(b"".join(c) for c in commitments), transcript.label, rng64,
+                                                    weights64)
+        return [None if x == 0 else _BY_CODE[x]() for x in v]

@@ -172,6 +172,30 @@ class RangeProof {
         return out;
     }
 
+    // Same verdicts through the batch-combined check (bpgpu_rangeproof_verify_rlc, no counterpart in the crate): one
+    // identity test for the whole batch when every proof verifies, per-proof re-verification inside the call when
+    // not.  weights64 = nullptr draws the combination weights from the OS CSPRNG.
+    static std::vector<Status> verify_batch_combined(const BulletproofGens &bp_gens, const PedersenGens &, const Transcript &transcript,
+                                                     const std::vector<std::vector<uint8_t>> &proofs,
+                                                     const std::vector<std::vector<CompressedRistretto>> &commitments, size_t n,
+                                                     const uint8_t *rng64 = nullptr, const uint8_t *weights64 = nullptr) {
+        const size_t nb = proofs.size();
+        std::vector<Status> out;
+        if (nb == 0) return out;
+        const size_t m = commitments.at(0).size(), len = proofs[0].size();
+        std::vector<uint8_t> flat(nb * len), vs(nb * m * 32), verdict(nb);
+        for (size_t i = 0; i < nb; i++) {
+            if (proofs[i].size() != len || commitments.at(i).size() != m) throw std::invalid_argument("verify_batch_combined: proofs of one call share (m, length)");
+            std::memcpy(&flat[i * len], proofs[i].data(), len);
+            for (size_t j = 0; j < m; j++) std::memcpy(&vs[(i * m + j) * 32], commitments[i][j].data(), 32);
+        }
+        const int rc = bpgpu_rangeproof_verify_rlc(bp_gens.ctx(), n, m, nb, flat.data(), len, vs.data(), transcript.label().data(),
+                                                   transcript.label().size(), rng64, weights64, verdict.data(), nullptr);
+        if (rc != BPGPU_OK) throw GpuError(bpgpu_last_error(bp_gens.ctx()));
+        for (size_t i = 0; i < nb; i++) out.push_back(verdict[i] == 0 ? Status::Ok() : Status::Err(static_cast<ProofError>(verdict[i])));
+        return out;
+    }
+
   private:
     std::vector<uint8_t> bytes_;
 };

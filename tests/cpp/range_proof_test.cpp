@@ -67,6 +67,12 @@ int main() {
     std::vector<std::vector<CompressedRistretto>> coms(5, std::vector<CompressedRistretto>{vc[0]});
     auto res = RangeProof::verify_batch(bp_gens, pc_gens, Transcript(GOLDEN_LABEL), proofs, coms, 64);
     for (int k = 0; k < 5; k++) CHECK(res[k] == (k == 2 ? Status::Err(ProofError::VerificationError) : Status::Ok()));
+    // the batch-combined entry point gives the same verdicts (per-proof fallback inside when the combination fails)
+    auto res2 = RangeProof::verify_batch_combined(bp_gens, pc_gens, Transcript(GOLDEN_LABEL), proofs, coms, 64);
+    for (int k = 0; k < 5; k++) CHECK(res2[k] == res[k]);
+    proofs[2][130] ^= 1;
+    auto res3 = RangeProof::verify_batch_combined(bp_gens, pc_gens, Transcript(GOLDEN_LABEL), proofs, coms, 64);
+    for (int k = 0; k < 5; k++) CHECK(res3[k] == Status::Ok());
     std::printf("deserialize_and_verify: ok\n");
     return 0;
 }

@@ -33,6 +33,13 @@ def test_deserialize_and_verify(golden):
     res = RangeProof.verify_batch(bp_gens, pc_gens, Transcript(b"Deserialize-And-Verify Test"),
                                   [bytes.fromhex(proofs[3][0])] * 3, [[vc[0]], [vc[1]], [vc[0]]], 64)
     assert res[0] is None and res[1] == VerificationError() and res[2] is None
+    # the batch-combined entry point returns the same verdicts (clean batch: one identity check; otherwise the fallback)
+    clean = RangeProof.verify_batch_combined(bp_gens, pc_gens, Transcript(b"Deserialize-And-Verify Test"),
+                                             [bytes.fromhex(proofs[3][0])] * 4, [[vc[0]]] * 4, 64)
+    assert clean == [None] * 4
+    res2 = RangeProof.verify_batch_combined(bp_gens, pc_gens, Transcript(b"Deserialize-And-Verify Test"),
+                                            [bytes.fromhex(proofs[3][0])] * 3, [[vc[0]], [vc[1]], [vc[0]]], 64)
+    assert res2[0] is None and res2[1] == VerificationError() and res2[2] is None
 
 
 def test_cpp_mirror_deserialize_and_verify(golden, tmp_path):
