@@ -1,6 +1,6 @@
-// libbpgpu.so: HIP kernels (gfx950) + host runtime + C ABI (include/bpgpu.h).
-// Kernels are thin __global__ wrappers around the per-lane bodies in msm_vb.h /
-// msm_fixed.h / rangeproof.h; the bodies are shared with the CPU test harness.
+// libbpgpu.so: host runtime + C ABI (include/bpgpu.h).  The kernels (gfx950) live in k_*.hip, thin __global__
+// wrappers around the per-lane bodies in msm_vb.h / msm_fixed.h / rangeproof.h; the bodies are shared with the
+// CPU test harness.
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
@@ -13,404 +13,9 @@
 #include <vector>
 
 #include "../../include/bpgpu.h"
-#include "msm_fixed.h"
-#include "msm_vb.h"
-#include "horner_wave.h"
-#include "horner_quad.h"
-#include "rlc.h"
-#include "rangeproof.h"
-#include "ipp.h"
+#include "kernels.h"
 
 using namespace bp;
-
-// ============================================================================
-// kernels
-// ============================================================================
-#define BP_BLOCK 64   // one wavefront per workgroup: under contention a CU rarely has room for four waves of one group at once (256: -8% at 48 streams)
-
-__global__ void __launch_bounds__(BP_BLOCK) k_vb_prepare(uint32_t total, const vb_chunk *chunks, const uint32_t *term_chunk,
-                                                          const uint32_t *scalars, const uint32_t *points, ge_cached *tab,
-                                                          uint32_t *recoded, uint32_t *status) {
-    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < total) vb_prepare_thread(t, chunks, term_chunk, scalars, points, tab, recoded, status);
-}
-
-__global__ void __launch_bounds__(BP_BLOCK) k_vb_window(uint32_t nthreads, const vb_chunk *chunks, const ge_cached *tab,
-                                                         const uint32_t *recoded, ge_ext *part) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < nthreads) vb_window_thread(tid, chunks, tab, recoded, part);
-}
-
-__global__ void __launch_bounds__(BP_BLOCK) k_vb_colsum(uint32_t nthreads, const uint32_t *chunk_first, const ge_ext *part,
-                                                         uint32_t *colq16, ge_cached *colc) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < nthreads) vb_colsum_thread(tid, chunk_first, part, nullptr, colq16, colc);
-}
-
-// wavefront-cooperative Horner chain (horner_wave.h): one 64-lane workgroup = one wavefront = one MSM
-__global__ void __launch_bounds__(64) k_horner_wave(const uint32_t *colq16, ge_ext *hq) {
-    const uint32_t b = blockIdx.x;
-    hw_horner_msm((const uint16_t *)(colq16 + (uint64_t)b * 64 * 32), hq + b);
-}
-
-__global__ void __launch_bounds__(64) k_vb_horner(uint32_t nbatch, const ge_ext *hq, const uint32_t *status, uint32_t *out) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < nbatch) vb_horner_thread(b, nullptr, hq, status, out, nullptr);
-}
-
-__global__ void __launch_bounds__(64) k_status_bytes(uint32_t n, const uint32_t *status, uint8_t *out) {
-    const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
-    if (b < n) out[b] = (uint8_t)status[b];
-}
-
-__global__ void __launch_bounds__(64) k_fb_base(fb_params prm, const uint32_t *gens, ge_ext *base, uint32_t *bad) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g < prm.n_gens) fb_base_thread(g, prm, gens, base, bad);
-}
-
-__global__ void __launch_bounds__(64) k_fb_fill(fb_params prm, const ge_ext *base, fb_entry *table) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < prm.n_gens * prm.nwin) fb_fill_thread(tid, prm, base, table);
-}
-
-__global__ void __launch_bounds__(64) k_fb_norm(uint64_t n_groups, uint64_t n_entries, fb_entry *table) {
-    const uint64_t gid = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (gid < n_groups) fb_norm_thread(gid, n_entries, table);
-}
-
-__global__ void __launch_bounds__(BP_BLOCK) k_fb_recode(uint32_t nthreads, fb_params prm, uint32_t nproofs, uint32_t n_gen_terms,
-                                                         const uint32_t *gen_scalars, fb_digit *digits, uint32_t *status) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < nthreads) fb_recode_thread(tid, prm, nproofs, n_gen_terms, gen_scalars, digits, status);
-}
-
-// grid: 1-D, nblk_p * nsplit blocks of FB_BLOCK lanes (lane = proof).  Block L serves
-// split = (L % 8) + 8 * ((L / 8) / nblk_p) so that the blocks the dispatcher places on
-// one XCD (L % 8) share the same slices of the table in that XCD's L2.
-#define FB_BLOCK 64
-__global__ void __launch_bounds__(FB_BLOCK) k_fb_accum(fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit,
-                                                        uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits,
-                                                        const fb_entry *table, ge_ext *partial) {
-    const uint32_t L = blockIdx.x;
-    uint32_t split, pblk;
-    if ((nsplit & 7) == 0) {
-        const uint32_t r = L & 7, rest = L >> 3;
-        pblk = rest % nblk_p;
-        split = r + 8 * (rest / nblk_p);
-    } else {
-        pblk = L % nblk_p;
-        split = L / nblk_p;
-    }
-    const uint32_t p = pblk * FB_BLOCK + threadIdx.x;
-    const uint32_t per = (npairs + nsplit - 1) / nsplit;
-    const uint32_t q0 = split * per, q1 = (q0 + per < npairs) ? q0 + per : npairs;
-    if (p < nproofs) fb_accum_thread(p, split, q0 < npairs ? q0 : npairs, q1, prm, nproofs, gen_ids, digits, table, partial);
-}
-
-__global__ void __launch_bounds__(BP_BLOCK) k_fb_reduce(uint32_t nthreads, uint32_t nproofs, uint32_t nsplit, uint32_t group,
-                                                         const ge_ext *partial, ge_ext *out) {
-    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < nthreads) fb_reduce_thread(tid, nproofs, nsplit, group, partial, out);
-}
-
-__global__ void __launch_bounds__(64) k_shared_finish(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, int have_unique,
-                                                       const ge_ext *partial, const uint32_t *status, uint32_t *out_words,
-                                                       uint8_t *verdict) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < nproofs) shared_finish_thread(p, nproofs, nsplit, nullptr, have_unique != 0, hq, partial, status, out_words, verdict);
-}
-
-// One launch for the whole tail: 8 lanes per proof add up the per-split partial sums (and the Horner result),
-// a 3-level exchange through LDS folds them, lane 0 tests / compresses.  Replaces two fb_reduce launches and
-// shared_finish; `reset_status` hands the status words back zeroed for the next call on this context.
-template <bool WITH_OUT>   // WITH_OUT = false: verdicts only (no compression code, a third of the registers)
-__global__ void __launch_bounds__(64) k_finish8(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, const ge_ext *partial, uint32_t *status,
-                                                 uint32_t *out_words, uint8_t *verdict, int reset_status) {
-    __shared__ ge_ext xch[64];
-    const uint32_t lane = threadIdx.x, j = lane & 7, p = blockIdx.x * 8 + (lane >> 3);
-    const bool live = p < nproofs;
-    ge_ext acc;
-    if (live) shared_finish8_gather(acc, p, j, nproofs, nsplit, hq, partial);
-    else ge_identity(acc);
-#pragma unroll 1
-    for (uint32_t step = 4; step >= 1; step >>= 1) {
-        xch[lane] = acc;
-        __syncthreads();
-        if (j < step) {
-            const ge_ext q = xch[lane + step];
-            ge_add(acc, acc, q);
-        }
-        __syncthreads();
-    }
-    if (live && j == 0) {
-        shared_finish_tail(p, acc, status, WITH_OUT ? out_words : nullptr, verdict);
-        if (reset_status) status[p] = 0;
-    }
-}
-
-// ---- range-proof front end ----------------------------------------------------
-// The device overlaps at most a handful of kernels, so a chain of narrow launches leaves most CUs idle.
-// Stages that do not depend on each other therefore share ONE launch: the leading blocks of the grid take
-// one role, the rest the other ("role-fused" launches; the long-running role gets the low block indices so
-// the dispatcher starts it first).
-#define RP_BLOCK 64
-// launch 1: [0, n_tr) Fiat-Shamir transcript replay, then the per-proof scalars (one inversion by division
-// steps, the U coefficient recodings, the Montgomery tables for launch 2), lane = proof  ||  [n_tr, ..) decode
-// the proof's and the commitments' points straight from the input bytes and build their 8-entry tables,
-// lane = point
-__global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs,
-                                                         const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields,
-                                                         ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m,
-                                                         uint32_t *recoded, fb_digit *digits, const uint8_t *rho64) {
-    __shared__ uint32_t lds[50 * RP_BLOCK];   // sponge states, word-major: word w of lane t at w*RP_BLOCK + t
-    if (blockIdx.x < n_tr) {
-        const uint32_t p = blockIdx.x * RP_BLOCK + threadIdx.x;
-        kstate st;
-        st.w = lds + threadIdx.x;
-        st.stride = RP_BLOCK;
-        if (p < sh.nproofs) {
-            rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields, status);
-            if (!sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64);
-        }
-    } else {
-        const uint32_t t = (blockIdx.x - n_tr) * RP_BLOCK + threadIdx.x;
-        if (t < sh.nproofs * sh.U) rp_points_thread(t, sh, proofs, commitments, tab, status);
-    }
-}
-
-// launch 3: [0, n_win) per-chunk window sums of the proof-specific points  ||  the 2nm generator exponents
-__global__ void __launch_bounds__(BP_BLOCK) k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab,
-                                                         const uint32_t *recoded, ge_ext *part, ge_cached *colc, uint32_t nthreads_exp,
-                                                         rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits,
-                                                         const uint32_t *status) {
-    if (blockIdx.x < n_win) {
-        const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
-        if (tid < nthreads_win) vb_window_thread(tid, chunks, tab, recoded, part, colc);
-    } else {
-        const uint32_t tid = (blockIdx.x - n_win) * BP_BLOCK + threadIdx.x;
-        if (tid < nthreads_exp) rp_expand_b4_thread(tid, sh, prm, fields, digits, status);
-    }
-}
-
-// launch 4: [0, n_hw) the Horner chains of the proof-specific terms -- QUAD: one quad of lanes per proof, 16
-// proofs per wavefront, from cached column sums (horner_quad.h); otherwise one wavefront per proof, which forms
-// its column sums itself (horner_wave.h)  ||  the fixed-base table walk (block -> (split, proof block) as in
-// k_fb_accum)
-template <bool QUAD>
-__global__ void __launch_bounds__(FB_BLOCK) k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge_ext *part, const ge_cached *colc,
-                                                         ge_ext *hq, fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit,
-                                                         uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits,
-                                                         const fb_entry *table, ge_ext *partial) {
-    if (blockIdx.x < n_hw) {
-        if (QUAD) hq_horner_msm(blockIdx.x * 16 + (threadIdx.x >> 2), nproofs, colc, hq);
-        else hw_colsum_horner_msm(blockIdx.x, chunk_first, part, hq + blockIdx.x);
-        return;
-    }
-    const uint32_t L = blockIdx.x - n_hw;
-    uint32_t split, pblk;
-    if ((nsplit & 7) == 0) {
-        const uint32_t r = L & 7, rest = L >> 3;
-        pblk = rest % nblk_p;
-        split = r + 8 * (rest / nblk_p);
-    } else {
-        pblk = L % nblk_p;
-        split = L / nblk_p;
-    }
-    const uint32_t p = pblk * FB_BLOCK + threadIdx.x;
-    const uint32_t per = (npairs + nsplit - 1) / nsplit;
-    const uint32_t q0 = split * per, q1 = (q0 + per < npairs) ? q0 + per : npairs;
-    if (p < nproofs) fb_accum_thread(p, split, q0 < npairs ? q0 : npairs, q1, prm, nproofs, gen_ids, digits, table, partial);
-}
-
-// ---- batch combination (rlc.h) --------------------------------------------------------------------------
-// sum over the wavefront of a value below 2^28 per lane: four DPP prefix steps inside each row of 16 lanes
-// (row sums < 2^32), then the four row totals are read to scalars and added in 64 bits
-__device__ __forceinline__ uint64_t wave_sum_u28(uint32_t x) {
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, true);   // row_shr:1, zero fill
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, true);   // row_shr:2
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, true);   // row_shr:4
-    x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, true);   // row_shr:8
-    return (uint64_t)(uint32_t)__builtin_amdgcn_readlane((int)x, 15) + (uint32_t)__builtin_amdgcn_readlane((int)x, 31) +
-           (uint32_t)__builtin_amdgcn_readlane((int)x, 47) + (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
-}
-// add one scalar per lane into the batch accumulator of generator row `row` (ten 64-bit limb sums).
-// uniform: all 64 lanes of the wavefront hold contributions to the SAME row -> one atomic per limb per wavefront
-__device__ __forceinline__ void rlc_accumulate(unsigned long long *acc, uint32_t row, const sc &v, bool active, bool uniform) {
-    uint64_t l[10];
-    rlc_limbs(l, v);
-    if (uniform) {
-#pragma unroll
-        for (int i = 0; i < 10; i++) {
-            const uint64_t t = wave_sum_u28(active ? (uint32_t)l[i] : 0u);
-            if (__lane_id() == 0) atomicAdd(acc + (uint64_t)row * 10 + i, (unsigned long long)t);
-        }
-    } else if (active) {
-#pragma unroll
-        for (int i = 0; i < 10; i++) atomicAdd(acc + (uint64_t)row * 10 + i, (unsigned long long)l[i]);
-    }
-}
-
-// launch 2 of the combined mode: [0, n_win) window sums of the proof-specific points (rejected proofs skipped)
-// ||  the weighted generator coefficients, summed over the batch into acc[row][10]
-__global__ void __launch_bounds__(BP_BLOCK) k_rlc_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab,
-                                                          const uint32_t *recoded, ge_ext *part, uint32_t nthreads_exp, rp_shape sh,
-                                                          fb_params prm, const uint32_t *fields, const uint32_t *status,
-                                                          unsigned long long *acc, int uniform) {
-    if (blockIdx.x < n_win) {
-        const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
-        if (tid < nthreads_win) vb_window_thread(tid, chunks, tab, recoded, part, nullptr, status);
-        return;
-    }
-    const uint32_t tid = (blockIdx.x - n_win) * BP_BLOCK + threadIdx.x;
-    const bool valid = tid < nthreads_exp;
-    const uint32_t B = sh.nproofs;
-    const uint32_t t4 = valid ? tid / B : 0, p = valid ? tid - t4 * B : 0;
-    sc g[4], h[4];
-    for (int j = 0; j < 4; j++) {
-        sc_0(g[j]);
-        sc_0(h[j]);
-    }
-    if (valid) rp_expand_b4_thread(tid, sh, prm, fields, nullptr, status, g, h);
-#pragma unroll 1
-    for (uint32_t j = 0; j < 4; j++) {
-        rlc_accumulate(acc, 2 + 4 * t4 + j, g[j], valid, uniform != 0);
-        rlc_accumulate(acc, 2 + sh.nm + 4 * t4 + j, h[j], valid, uniform != 0);
-    }
-    // the B_blinding (row 0) and B (row 1) coefficients were left in the ROW0/ROW1 fields by launch 1; the lanes
-    // of the first index group add them (a proof rejected since then contributes nothing)
-    const bool row_lane = valid && t4 == 0;
-    if (!uniform || t4 == 0) {   // uniform mode: t4 is the same in all 64 lanes, so whole wavefronts take this branch
-#pragma unroll 1
-        for (uint32_t row = 0; row < 2; row++) {
-            sc r;
-            sc_0(r);
-            if (row_lane && status[p] == 0) rp_load(r, fields, B, RPF_ROW0 + row, p);
-            rlc_accumulate(acc, row, r, row_lane, uniform != 0);
-        }
-    }
-}
-
-// (k_rlc_colsum_scalars below runs this as the second role of the last column-sum launch)
-// lane g: reduce the accumulated coefficient of generator row g mod l, recode it for the table walk (batch of 1)
-// (lane 0 also initialises the small control block of the batch-of-one tail: verdict byte, a zero status word and
-// the chunk bounds {0, rows} of the final column sums)
-__device__ __forceinline__ void rlc_scalars_lane(uint32_t g, uint32_t n_rows, const unsigned long long *acc, fb_digit *digits, fb_params prm,
-                                                 uint32_t *ctl, uint32_t rows) {
-    if (g == 0) {
-        ctl[0] = 0;
-        ctl[1] = 0;
-        ctl[2] = 0;
-        ctl[3] = rows;
-    }
-    if (g >= n_rows) return;
-    uint64_t a[10];
-#pragma unroll
-    for (int i = 0; i < 10; i++) a[i] = acc[(uint64_t)g * 10 + i];
-    sc v;
-    rlc_acc_to_sc(v, a);
-    fb_recode(digits + (uint64_t)g * prm.nwin, 1, v.v, prm);
-}
-// one level of the column-sum tree (blocks [0, n_red))  ||  the combined generator coefficients
-__global__ void __launch_bounds__(BP_BLOCK) k_rlc_colsum_scalars(uint32_t n_red, uint32_t nthreads, uint32_t rows_in, uint32_t group,
-                                                                  const ge_ext *in, ge_ext *out, uint32_t n_rows, const unsigned long long *acc,
-                                                                  fb_digit *digits, fb_params prm, uint32_t *ctl, uint32_t rows_out) {
-    if (blockIdx.x < n_red) {
-        const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
-        if (tid < nthreads) fb_reduce_thread(tid, 64, rows_in, group, in, out);
-    } else {
-        rlc_scalars_lane((blockIdx.x - n_red) * BP_BLOCK + threadIdx.x, n_rows, acc, digits, prm, ctl, rows_out);
-    }
-}
-
-// Tail of the combined check, ONE wavefront: the 64 lanes add up the batch-of-one table walk's partial points
-// (and the Horner result), fold them through LDS, lane 0 tests the identity (WITH_OUT: and encodes R); then
-// every proof's verdict is written: the front end's status if set, else 0 when R is the identity, UNDECIDED
-// otherwise.  Status words are handed back zeroed.
-template <bool WITH_OUT>
-__global__ void __launch_bounds__(64) k_rlc_finish(uint32_t nsplit, const ge_ext *hq, const ge_ext *partial, uint32_t nproofs, uint32_t *status,
-                                                    uint8_t *verdict, uint8_t *batch_out) {
-    __shared__ ge_ext xch[64];
-    __shared__ uint32_t res[9];
-    const uint32_t lane = threadIdx.x;
-    ge_ext acc;
-    bool have = false;
-    for (uint32_t sp = lane; sp < nsplit; sp += 64) {
-        const ge_ext q = partial[sp];
-        if (have) ge_add(acc, acc, q);
-        else acc = q;
-        have = true;
-    }
-    if (lane == 63) {
-        const ge_ext q = hq[0];
-        if (have) ge_add(acc, acc, q);
-        else acc = q;
-        have = true;
-    }
-    if (!have) ge_identity(acc);
-#pragma unroll 1
-    for (uint32_t step = 32; step >= 1; step >>= 1) {
-        xch[lane] = acc;
-        __syncthreads();
-        if (lane < step) {
-            const ge_ext q = xch[lane + step];
-            ge_add(acc, acc, q);
-        }
-        __syncthreads();
-    }
-    if (lane == 0) {
-        const uint32_t zero = 0;
-        uint8_t bv = 0;
-        uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        shared_finish_tail(0, acc, &zero, WITH_OUT ? w : nullptr, &bv);
-        res[8] = bv;
-        for (int i = 0; i < 8; i++) res[i] = w[i];
-    }
-    __syncthreads();
-    const uint8_t bv = (uint8_t)res[8];
-    for (uint32_t p = lane; p < nproofs; p += 64) {
-        verdict[p] = status[p] ? (uint8_t)status[p] : (bv ? (uint8_t)BP_VERDICT_UNDECIDED : (uint8_t)0);
-        status[p] = 0;
-    }
-    if (WITH_OUT && lane < 33) batch_out[lane] = lane == 0 ? bv : (uint8_t)(res[(lane - 1) >> 2] >> (8 * ((lane - 1) & 3)));
-}
-
-// verdict[p] = status (Format / shape / Verification) if set, else the identity test of the mega-check
-__global__ void __launch_bounds__(64) k_rp_verdict(uint32_t n, uint32_t *status, const uint8_t *msm_verdict, uint8_t *out) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) {
-        out[p] = status[p] ? (uint8_t)status[p] : msm_verdict[p];
-        status[p] = 0;   // handed back clean (see bpgpu_ctx::rp_status)
-    }
-}
-
-__global__ void __launch_bounds__(RP_BLOCK) k_ipp_prepare(ipp_shape sh, rp_strobe_init init, const uint8_t *proofs, const uint8_t *Gf,
-                                                           const uint8_t *Hf, const uint8_t *P, const uint8_t *Q, const uint8_t *G,
-                                                           const uint8_t *H, uint32_t *scalars, uint32_t *points, uint32_t *status) {
-    __shared__ uint32_t lds[50 * RP_BLOCK];
-    const uint32_t p = blockIdx.x * RP_BLOCK + threadIdx.x;
-    kstate st;
-    st.w = lds + threadIdx.x;
-    st.stride = RP_BLOCK;
-    if (p < sh.nproofs) ipp_prepare_thread(p, sh, init, st, proofs, Gf, Hf, P, Q, G, H, scalars, points, status);
-}
-
-__global__ void __launch_bounds__(64) k_ipp_verdict(uint32_t n, const uint32_t *status, const uint8_t *msm_status, const uint32_t *msm_out,
-                                                     uint8_t *verdict) {
-    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < n) ipp_verdict_thread(p, status, msm_status, msm_out, verdict);
-}
-
-// generator derivation: 64 uniform bytes -> RistrettoPoint::from_uniform_bytes -> encoding
-__global__ void __launch_bounds__(64) k_from_uniform(uint32_t n, const uint32_t *uniform, uint32_t *out) {
-    const uint32_t g = blockIdx.x * blockDim.x + threadIdx.x;
-    if (g >= n) return;
-    uint32_t w[16], o[8];
-    for (int i = 0; i < 16; i++) w[i] = uniform[16 * (uint64_t)g + i];
-    ge_ext r;
-    ristretto_from_uniform(r, w);
-    ristretto_compress(o, r);
-    for (int i = 0; i < 8; i++) out[8 * (uint64_t)g + i] = o[i];
-}
 
 // ============================================================================
 // host runtime

@@ -1,0 +1,22 @@
+// k_ipp.hip: HIP kernels of libbpgpu.so (gfx950); thin __global__ wrappers around the per-lane bodies in the headers.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+using namespace bp;
+
+__global__ void __launch_bounds__(RP_BLOCK) k_ipp_prepare(ipp_shape sh, rp_strobe_init init, const uint8_t *proofs, const uint8_t *Gf,
+                                                           const uint8_t *Hf, const uint8_t *P, const uint8_t *Q, const uint8_t *G,
+                                                           const uint8_t *H, uint32_t *scalars, uint32_t *points, uint32_t *status) {
+    __shared__ uint32_t lds[50 * RP_BLOCK];
+    const uint32_t p = blockIdx.x * RP_BLOCK + threadIdx.x;
+    kstate st;
+    st.w = lds + threadIdx.x;
+    st.stride = RP_BLOCK;
+    if (p < sh.nproofs) ipp_prepare_thread(p, sh, init, st, proofs, Gf, Hf, P, Q, G, H, scalars, points, status);
+}
+
+__global__ void __launch_bounds__(64) k_ipp_verdict(uint32_t n, const uint32_t *status, const uint8_t *msm_status, const uint32_t *msm_out,
+                                                     uint8_t *verdict) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) ipp_verdict_thread(p, status, msm_status, msm_out, verdict);
+}

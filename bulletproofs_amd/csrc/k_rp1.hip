@@ -1,0 +1,43 @@
+// k_rp1.hip: HIP kernels of libbpgpu.so (gfx950); thin __global__ wrappers around the per-lane bodies in the headers.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+using namespace bp;
+
+// ---- range-proof front end ----------------------------------------------------
+// The device overlaps at most a handful of kernels, so a chain of narrow launches leaves most CUs idle.
+// Stages that do not depend on each other therefore share ONE launch: the leading blocks of the grid take
+// one role, the rest the other ("role-fused" launches; the long-running role gets the low block indices so
+// the dispatcher starts it first).
+// launch 1: [0, n_tr) Fiat-Shamir transcript replay, then the per-proof scalars (one inversion by division
+// steps, the U coefficient recodings, the Montgomery tables for launch 2), lane = proof  ||  [n_tr, ..) decode
+// the proof's and the commitments' points straight from the input bytes and build their 8-entry tables,
+// lane = point
+__global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs,
+                                                         const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields,
+                                                         ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m,
+                                                         uint32_t *recoded, fb_digit *digits, const uint8_t *rho64) {
+    __shared__ uint32_t lds[50 * RP_BLOCK];   // sponge states, word-major: word w of lane t at w*RP_BLOCK + t
+    if (blockIdx.x < n_tr) {
+        const uint32_t p = blockIdx.x * RP_BLOCK + threadIdx.x;
+        kstate st;
+        st.w = lds + threadIdx.x;
+        st.stride = RP_BLOCK;
+        if (p < sh.nproofs) {
+            rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields, status);
+            if (!sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64);
+        }
+    } else {
+        const uint32_t t = (blockIdx.x - n_tr) * RP_BLOCK + threadIdx.x;
+        if (t < sh.nproofs * sh.U) rp_points_thread(t, sh, proofs, commitments, tab, status);
+    }
+}
+
+// verdict[p] = status (Format / shape / Verification) if set, else the identity test of the mega-check
+__global__ void __launch_bounds__(64) k_rp_verdict(uint32_t n, uint32_t *status, const uint8_t *msm_verdict, uint8_t *out) {
+    const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+    if (p < n) {
+        out[p] = status[p] ? (uint8_t)status[p] : msm_verdict[p];
+        status[p] = 0;   // handed back clean (see bpgpu_ctx::rp_status)
+    }
+}

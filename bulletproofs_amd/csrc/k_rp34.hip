@@ -1,0 +1,52 @@
+// k_rp34.hip: HIP kernels of libbpgpu.so (gfx950); thin __global__ wrappers around the per-lane bodies in the headers.
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+using namespace bp;
+
+// launch 3: [0, n_win) per-chunk window sums of the proof-specific points  ||  the 2nm generator exponents
+__global__ void __launch_bounds__(BP_BLOCK) k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab,
+                                                         const uint32_t *recoded, ge_ext *part, ge_cached *colc, uint32_t nthreads_exp,
+                                                         rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits,
+                                                         const uint32_t *status) {
+    if (blockIdx.x < n_win) {
+        const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
+        if (tid < nthreads_win) vb_window_thread(tid, chunks, tab, recoded, part, colc);
+    } else {
+        const uint32_t tid = (blockIdx.x - n_win) * BP_BLOCK + threadIdx.x;
+        if (tid < nthreads_exp) rp_expand_b4_thread(tid, sh, prm, fields, digits, status);
+    }
+}
+
+// launch 4: [0, n_hw) the Horner chains of the proof-specific terms -- QUAD: one quad of lanes per proof, 16
+// proofs per wavefront, from cached column sums (horner_quad.h); otherwise one wavefront per proof, which forms
+// its column sums itself (horner_wave.h)  ||  the fixed-base table walk (block -> (split, proof block) as in
+// k_fb_accum)
+template <bool QUAD>
+__global__ void __launch_bounds__(FB_BLOCK) k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge_ext *part, const ge_cached *colc,
+                                                         ge_ext *hq, fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit,
+                                                         uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits,
+                                                         const fb_entry *table, ge_ext *partial) {
+    if (blockIdx.x < n_hw) {
+        if (QUAD) hq_horner_msm(blockIdx.x * 16 + (threadIdx.x >> 2), nproofs, colc, hq);
+        else hw_colsum_horner_msm(blockIdx.x, chunk_first, part, hq + blockIdx.x);
+        return;
+    }
+    const uint32_t L = blockIdx.x - n_hw;
+    uint32_t split, pblk;
+    if ((nsplit & 7) == 0) {
+        const uint32_t r = L & 7, rest = L >> 3;
+        pblk = rest % nblk_p;
+        split = r + 8 * (rest / nblk_p);
+    } else {
+        pblk = L % nblk_p;
+        split = L / nblk_p;
+    }
+    const uint32_t p = pblk * FB_BLOCK + threadIdx.x;
+    const uint32_t per = (npairs + nsplit - 1) / nsplit;
+    const uint32_t q0 = split * per, q1 = (q0 + per < npairs) ? q0 + per : npairs;
+    if (p < nproofs) fb_accum_thread(p, split, q0 < npairs ? q0 : npairs, q1, prm, nproofs, gen_ids, digits, table, partial);
+}
+
+template __global__ void k_rp_stage4<true>(uint32_t, const uint32_t *, const ge_ext *, const ge_cached *, ge_ext *, fb_params, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, const fb_digit *, const fb_entry *, ge_ext *);
+template __global__ void k_rp_stage4<false>(uint32_t, const uint32_t *, const ge_ext *, const ge_cached *, ge_ext *, fb_params, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, const fb_digit *, const fb_entry *, ge_ext *);

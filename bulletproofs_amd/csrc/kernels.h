@@ -1,0 +1,48 @@
+// Prototypes of every kernel of libbpgpu.so.  The kernels are defined in k_*.hip (one translation unit per group so
+// the library builds in parallel); the host runtime (bpgpu.hip and friends) launches them through these declarations.
+#ifndef BPGPU_KERNELS_H
+#define BPGPU_KERNELS_H
+#include <hip/hip_runtime.h>
+#include "msm_fixed.h"
+#include "msm_vb.h"
+#include "horner_wave.h"
+#include "horner_quad.h"
+#include "rlc.h"
+#include "rangeproof.h"
+#include "ipp.h"
+
+#define BP_BLOCK 64   // one wavefront per workgroup: under contention a CU rarely has room for four waves of one group at once (256: -8% at 48 streams)
+#define FB_BLOCK 64
+#define RP_BLOCK 64
+
+using namespace bp;
+
+__global__ void k_vb_prepare(uint32_t total, const vb_chunk *chunks, const uint32_t *term_chunk, const uint32_t *scalars, const uint32_t *points, ge_cached *tab, uint32_t *recoded, uint32_t *status);
+__global__ void k_vb_window(uint32_t nthreads, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part);
+__global__ void k_vb_colsum(uint32_t nthreads, const uint32_t *chunk_first, const ge_ext *part, uint32_t *colq16, ge_cached *colc);
+__global__ void k_horner_wave(const uint32_t *colq16, ge_ext *hq);
+__global__ void k_vb_horner(uint32_t nbatch, const ge_ext *hq, const uint32_t *status, uint32_t *out);
+__global__ void k_status_bytes(uint32_t n, const uint32_t *status, uint8_t *out);
+__global__ void k_fb_base(fb_params prm, const uint32_t *gens, ge_ext *base, uint32_t *bad);
+__global__ void k_fb_fill(fb_params prm, const ge_ext *base, fb_entry *table);
+__global__ void k_fb_norm(uint64_t n_groups, uint64_t n_entries, fb_entry *table);
+__global__ void k_fb_recode(uint32_t nthreads, fb_params prm, uint32_t nproofs, uint32_t n_gen_terms, const uint32_t *gen_scalars, fb_digit *digits, uint32_t *status);
+__global__ void k_fb_accum(fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit, uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial);
+__global__ void k_fb_reduce(uint32_t nthreads, uint32_t nproofs, uint32_t nsplit, uint32_t group, const ge_ext *partial, ge_ext *out);
+__global__ void k_shared_finish(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, int have_unique, const ge_ext *partial, const uint32_t *status, uint32_t *out_words, uint8_t *verdict);
+template <bool WITH_OUT>
+__global__ void k_finish8(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, const ge_ext *partial, uint32_t *status, uint32_t *out_words, uint8_t *verdict, int reset_status);
+__global__ void k_rp_stage1(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs, const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields, ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m, uint32_t *recoded, fb_digit *digits, const uint8_t *rho64);
+__global__ void k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, ge_cached *colc, uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits, const uint32_t *status);
+template <bool QUAD>
+__global__ void k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge_ext *part, const ge_cached *colc, ge_ext *hq, fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit, uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial);
+__global__ void k_rlc_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, const uint32_t *status, unsigned long long *acc, int uniform);
+__global__ void k_rlc_colsum_scalars(uint32_t n_red, uint32_t nthreads, uint32_t rows_in, uint32_t group, const ge_ext *in, ge_ext *out, uint32_t n_rows, const unsigned long long *acc, fb_digit *digits, fb_params prm, uint32_t *ctl, uint32_t rows_out);
+template <bool WITH_OUT>
+__global__ void k_rlc_finish(uint32_t nsplit, const ge_ext *hq, const ge_ext *partial, uint32_t nproofs, uint32_t *status, uint8_t *verdict, uint8_t *batch_out);
+__global__ void k_rp_verdict(uint32_t n, uint32_t *status, const uint8_t *msm_verdict, uint8_t *out);
+__global__ void k_ipp_prepare(ipp_shape sh, rp_strobe_init init, const uint8_t *proofs, const uint8_t *Gf, const uint8_t *Hf, const uint8_t *P, const uint8_t *Q, const uint8_t *G, const uint8_t *H, uint32_t *scalars, uint32_t *points, uint32_t *status);
+__global__ void k_ipp_verdict(uint32_t n, const uint32_t *status, const uint8_t *msm_status, const uint32_t *msm_out, uint8_t *verdict);
+__global__ void k_from_uniform(uint32_t n, const uint32_t *uniform, uint32_t *out);
+
+#endif
