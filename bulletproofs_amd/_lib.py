@@ -19,7 +19,11 @@ EXPORTS = [
     "bpgpu_rangeproof_verify_batch", "bpgpu_rangeproof_verify_batch_dev", "bpgpu_ipp_verify_batch",
     "bpgpu_rangeproof_verify_rlc", "bpgpu_rangeproof_verify_rlc_dev",
     "bpgpu_profile_enable", "bpgpu_profile_reset", "bpgpu_profile_report",
+    "bpgpu_transcript_new", "bpgpu_transcript_append_message", "bpgpu_transcript_challenge_bytes",
+    "bpgpu_rangeproof_verify_batch_ts", "bpgpu_rangeproof_verify_batch_ts_dev", "bpgpu_ipp_verify_batch_dev",
 ]
+
+TRANSCRIPT_BYTES = 208
 
 
 class BpgpuError(RuntimeError):
@@ -67,11 +71,40 @@ def lib():
     L.bpgpu_rangeproof_verify_rlc.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p, u8p]
     L.bpgpu_rangeproof_verify_rlc_dev.argtypes = [vp, sz, sz, sz, vp, sz, vp, u8p, sz, vp, vp, vp, vp, vp]
     L.bpgpu_ipp_verify_batch.argtypes = [vp, sz, sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
+    L.bpgpu_transcript_new.argtypes = [u8p, sz, u8p]
+    L.bpgpu_transcript_append_message.argtypes = [u8p, u8p, sz, u8p, sz]
+    L.bpgpu_transcript_challenge_bytes.argtypes = [u8p, u8p, sz, u8p, sz]
+    L.bpgpu_rangeproof_verify_batch_ts.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p, u8p]
+    L.bpgpu_rangeproof_verify_batch_ts_dev.argtypes = [vp, sz, sz, sz, vp, sz, vp, u8p, vp, vp, vp, vp, vp, vp]
+    L.bpgpu_ipp_verify_batch_dev.argtypes = [vp, sz, sz, vp, sz, u8p, sz, u8p, vp, vp, vp, vp, vp, vp, i, vp, vp, vp]
     L.bpgpu_profile_enable.argtypes = [vp, i]
     L.bpgpu_profile_reset.argtypes = [vp]
     L.bpgpu_profile_report.argtypes = [vp, C.c_char_p, sz]
     _lib = L
     return L
+
+
+def transcript_new(label):
+    """merlin::Transcript::new(label) as its 208-byte state (host-side helper of the library; needs no GPU)."""
+    st = C.create_string_buffer(TRANSCRIPT_BYTES)
+    if lib().bpgpu_transcript_new(label, len(label), st) != 0:
+        raise BpgpuError("bpgpu_transcript_new failed")
+    return st.raw
+
+
+def transcript_append_message(state, label, msg):
+    st = C.create_string_buffer(bytes(state), TRANSCRIPT_BYTES)
+    if lib().bpgpu_transcript_append_message(st, label, len(label), msg, len(msg)) != 0:
+        raise BpgpuError("bpgpu_transcript_append_message failed (malformed state?)")
+    return st.raw
+
+
+def transcript_challenge_bytes(state, label, n):
+    st = C.create_string_buffer(bytes(state), TRANSCRIPT_BYTES)
+    out = C.create_string_buffer(max(n, 1))
+    if lib().bpgpu_transcript_challenge_bytes(st, label, len(label), out, n) != 0:
+        raise BpgpuError("bpgpu_transcript_challenge_bytes failed (malformed state?)")
+    return st.raw, out.raw[:n]
 
 
 ERR_NAMES = {0: "OK", -1: "INVALID_ARG", -2: "HIP", -3: "NO_GENS", -4: "NO_DEVICE", -5: "BAD_GENERATOR"}
@@ -166,6 +199,26 @@ class Context:
         self._chk(self._L.bpgpu_rangeproof_verify_batch(self.h, n, m, nb, proofs, proof_len, commitments, label, len(label),
                                                         rng64, verdict, msm))
         return (verdict.raw[:nb], msm.raw[:32 * nb]) if want_msm else verdict.raw[:nb]
+
+    def rangeproof_verify_batch_ts(self, n, m, proofs, proof_len, commitments, transcripts, rng64=None, want_msm=False,
+                                   want_transcripts=False):
+        """bpgpu_rangeproof_verify_batch_ts: `transcripts` is ONE 208-byte state shared by the batch, or nbatch of them.
+        Returns verdict bytes [, msm encodings] [, advanced states]."""
+        nb = len(proofs) // proof_len if proof_len else 0
+        assert len(proofs) == nb * proof_len and len(commitments) == 32 * m * nb
+        assert len(transcripts) in (TRANSCRIPT_BYTES, TRANSCRIPT_BYTES * nb)
+        stride = 0 if (len(transcripts) == TRANSCRIPT_BYTES and nb != 1) else TRANSCRIPT_BYTES
+        verdict = C.create_string_buffer(max(nb, 1))
+        msm = C.create_string_buffer(32 * max(nb, 1)) if want_msm else None
+        tso = C.create_string_buffer(TRANSCRIPT_BYTES * max(nb, 1)) if want_transcripts else None
+        self._chk(self._L.bpgpu_rangeproof_verify_batch_ts(self.h, n, m, nb, proofs, proof_len, commitments, transcripts, stride,
+                                                           rng64, verdict, msm, tso))
+        out = [verdict.raw[:nb]]
+        if want_msm:
+            out.append(msm.raw[:32 * nb])
+        if want_transcripts:
+            out.append(tso.raw[:TRANSCRIPT_BYTES * nb])
+        return out[0] if len(out) == 1 else tuple(out)
 
     def rangeproof_verify_rlc(self, n, m, proofs, proof_len, commitments, label, rng64=None, weights64=None):
         """Batch-combined verification (include/bpgpu.h): returns (verdict bytes, batch_ok, 32-byte encoding of the

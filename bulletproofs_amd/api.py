@@ -3,7 +3,7 @@ argument meaning and error behaviour as src/lib.rs:34-45 exports for this path (
 BulletproofGens, PedersenGens, ProofError, Transcript).  The C++ twin is include/bulletproofs.hpp.
 No arithmetic happens here: parsing checks lengths / scalar canonicity, everything else is one call
 into libbpgpu.so.  There is no CPU fallback."""
-from ._lib import Context
+from ._lib import Context, transcript_new, transcript_append_message, transcript_challenge_bytes
 
 _L = 2**252 + 27742317777372353535851937790883648493
 
@@ -57,12 +57,42 @@ class BulletproofGens:
         _, _, B, Bb = self.ctx.gens_export()
         return PedersenGens(B, Bb)
 
+    def _check_pedersen(self, pc_gens):
+        """The verifier multiplies by pc_gens.B / B_blinding (mod.rs:439-440); the device tables hold the bases this
+        BulletproofGens was created with.  A different PedersenGens must be loaded with Context.gens_load."""
+        if pc_gens is None:
+            return
+        if not hasattr(self, "_pc"):
+            self._pc = self.pedersen()
+        if (bytes(pc_gens.B), bytes(pc_gens.B_blinding)) != (self._pc.B, self._pc.B_blinding):
+            raise ValueError("pc_gens differs from the Pedersen bases held in the device tables (use Context.gens_load for custom bases)")
+
 
 class Transcript:
-    """merlin::Transcript::new(label): the engine replays the transcript from its label."""
+    """merlin::Transcript: held as its 208-byte STROBE state (include/bpgpu.h BPGPU_TRANSCRIPT_BYTES), so a transcript
+    that already absorbed application messages can be handed to the verifier, which leaves it advanced exactly as
+    verify_multiple_with_rng(&mut transcript, ...) does (mod.rs:345-353)."""
 
-    def __init__(self, label):
-        self.label = bytes(label)
+    def __init__(self, label, _state=None):
+        self.state = _state if _state is not None else transcript_new(bytes(label))
+        self.fresh_label = bytes(label) if _state is None else None   # set while the transcript is exactly Transcript::new(label)
+
+    def clone(self):
+        t = Transcript(None, self.state)
+        t.fresh_label = self.fresh_label
+        return t
+
+    def append_message(self, label, message):
+        self.state = transcript_append_message(self.state, bytes(label), bytes(message))
+        self.fresh_label = None
+
+    def append_u64(self, label, x):
+        self.append_message(label, int(x).to_bytes(8, "little"))
+
+    def challenge_bytes(self, label, n):
+        self.state, out = transcript_challenge_bytes(self.state, bytes(label), n)
+        self.fresh_label = None
+        return out
 
 
 class RangeProof:
@@ -90,7 +120,11 @@ class RangeProof:
         """Ok(()) -> returns None; Err(e) -> raises e.  rng64 = the 64 bytes Scalar::random(rng) would draw (mod.rs:396);
         None = thread_rng()."""
         m = len(value_commitments)
-        v = bp_gens.ctx.rangeproof_verify_batch(n, m, self._raw, len(self._raw), b"".join(value_commitments), transcript.label, rng64)
+        bp_gens._check_pedersen(pc_gens)
+        v, ts = bp_gens.ctx.rangeproof_verify_batch_ts(n, m, self._raw, len(self._raw), b"".join(value_commitments), transcript.state, rng64,
+                                                       want_transcripts=True)
+        transcript.state = ts   # &mut Transcript: left advanced
+        transcript.fresh_label = None
         if v[0] != 0:
             raise _BY_CODE[v[0]]()
 
@@ -105,24 +139,33 @@ class RangeProof:
 
     @staticmethod
     def verify_batch(bp_gens, pc_gens, transcript, proofs, commitments, n, rng64=None):
-        """proofs[i].verify_multiple(..., &commitments[i], n) for all i in one GPU pass -> list of None / ProofError."""
+        """proofs[i].verify_multiple(bp_gens, pc_gens, &mut transcript.clone(), &commitments[i], n) for all i in one GPU pass
+        -> list of None / ProofError.  `transcript` itself is not advanced."""
         if not proofs:
             return []
+        bp_gens._check_pedersen(pc_gens)
         raw = [p.to_bytes() if isinstance(p, RangeProof) else bytes(p) for p in proofs]
         m, ln = len(commitments[0]), len(raw[0])
         assert all(len(r) == ln for r in raw) and all(len(c) == m for c in commitments)
-        v = bp_gens.ctx.rangeproof_verify_batch(n, m, b"".join(raw), ln, b"".join(b"".join(c) for c in commitments), transcript.label, rng64)
+        v = bp_gens.ctx.rangeproof_verify_batch_ts(n, m, b"".join(raw), ln, b"".join(b"".join(c) for c in commitments), transcript.state, rng64)
+        if len(raw) == 1:
+            v = bytes(v)
         return [None if x == 0 else _BY_CODE[x]() for x in v]
 
     @staticmethod
     def verify_batch_combined(bp_gens, pc_gens, transcript, proofs, commitments, n, rng64=None, weights64=None):
         """The same verdicts through the batch-combined check (bpgpu_rangeproof_verify_rlc; no counterpart in the crate): one
-        identity test per batch when every proof verifies, per-proof re-verification inside the call when not."""
+        identity test per batch when every proof verifies, per-proof re-verification inside the call when not.  This entry
+        point replays each proof's transcript from its label: `transcript` must be a fresh Transcript(label)."""
         if not proofs:
             return []
+        bp_gens._check_pedersen(pc_gens)
+        label = transcript.fresh_label
+        if label is None:
+            raise ValueError("verify_batch_combined needs a fresh Transcript(label); use verify_batch for pre-bound transcripts")
         raw = [p.to_bytes() if isinstance(p, RangeProof) else bytes(p) for p in proofs]
         m, ln = len(commitments[0]), len(raw[0])
         assert all(len(r) == ln for r in raw) and all(len(c) == m for c in commitments)
-        v, _, _ = bp_gens.ctx.rangeproof_verify_rlc(n, m, b"".join(raw), ln, b"".join(b"".join(c) for c in commitments), transcript.label, rng64,
+        v, _, _ = bp_gens.ctx.rangeproof_verify_rlc(n, m, b"".join(raw), ln, b"".join(b"".join(c) for c in commitments), label, rng64,
                                                     weights64)
         return [None if x == 0 else _BY_CODE[x]() for x in v]

@@ -4,6 +4,8 @@
 #include <hip/hip_runtime.h>
 #include <hip/hip_ext.h>
 
+#include <sys/random.h>
+
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -63,13 +65,35 @@ struct bpgpu_ctx {
         char *mem = nullptr;
         size_t n_chunks = 0;
         uint32_t total = 0;
+        uint64_t last_use = 0;
     };
+    uint64_t plan_tick = 0;                  // plan_cache is bounded: least-recently-used entries are evicted
     std::map<std::pair<size_t, size_t>, plan_dev> plan_cache;
     // per-proof status words of the range-proof path: zero between calls (the last kernel of a call resets the
     // entries it used), so no memset launch is needed per call; `dirty` forces one after an aborted enqueue
     uint32_t *rp_status = nullptr;
     size_t rp_status_cap = 0;
     bool rp_status_dirty = false;
+    // A context has ONE arena / status buffer / plan cache, so the work of consecutive calls must not overlap on the
+    // device: every call records order_ev at its end, and a call that arrives on a different stream than its
+    // predecessor makes its stream wait for that event first (ctx_enter / ctx_leave).
+    hipEvent_t order_ev = nullptr;
+    hipStream_t last_stream = nullptr;
+    bool have_last = false;
+    // pinned host staging (ragged work decompositions, library-drawn randomness, the host-pointer entry points' IO):
+    // copies out of it are truly asynchronous; pin_ev guards its reuse by the next call
+    char *pin = nullptr;
+    size_t pin_cap = 0, pin_off = 0;
+    hipEvent_t pin_ev = nullptr;
+    bool pin_pending = false;
+    std::vector<char *> pin_retired;         // outgrown mid-call: still referenced by that call, freed at the next one
+    // persistent device-side IO buffer of the host-pointer entry points (no hipMalloc / hipFree per call)
+    char *io_dev = nullptr;
+    size_t io_cap = 0;
+    char *ipp_buf = nullptr;                 // term lists of the stand-alone inner-product verifier
+    size_t ipp_cap = 0;
+    bool sync_blocking = false;              // host entry points: sleep on a blocking event instead of spinning
+    hipEvent_t done_ev = nullptr;
     // profiling
     bool prof = false;
     std::map<std::string, kstat> stats;
@@ -170,6 +194,75 @@ struct arena_plan {
 
 static uint64_t table_bytes(uint32_t n_gens, uint32_t W);
 
+// ---- ordering of calls on one context (see bpgpu_ctx::order_ev) ----
+static int ctx_enter(bpgpu_ctx *c, hipStream_t s) {
+    c->pin_off = 0;
+    if (!c->pin_retired.empty()) {
+        if (c->pin_pending) HIPCHK(c, hipEventSynchronize(c->pin_ev));
+        c->pin_pending = false;
+        for (char *q : c->pin_retired) hipHostFree(q);
+        c->pin_retired.clear();
+    }
+    if (c->have_last && c->last_stream != s) HIPCHK(c, hipStreamWaitEvent(s, c->order_ev, 0));
+    return BPGPU_OK;
+}
+static int ctx_leave(bpgpu_ctx *c, hipStream_t s) {
+    HIPCHK(c, hipEventRecord(c->order_ev, s));
+    c->last_stream = s;
+    c->have_last = true;
+    if (c->pin_off) {   // staged bytes are in flight on s: the next call waits for them before overwriting
+        HIPCHK(c, hipEventRecord(c->pin_ev, s));
+        c->pin_pending = true;
+    }
+    return BPGPU_OK;
+}
+// bump allocation from the pinned staging buffer; the first allocation of a call waits until the previous
+// call's copies out of the buffer are done
+static int pin_alloc(bpgpu_ctx *c, hipStream_t /*s*/, size_t bytes, char **out) {
+    if (c->pin_pending) {
+        HIPCHK(c, hipEventSynchronize(c->pin_ev));
+        c->pin_pending = false;
+    }
+    const size_t need = c->pin_off + align_up(bytes);
+    if (need > c->pin_cap) {
+        if (c->pin && c->pin_off) c->pin_retired.push_back(c->pin);   // earlier pieces of this call stay valid
+        else if (c->pin) HIPCHK(c, hipHostFree(c->pin));
+        c->pin = nullptr;
+        c->pin_cap = 0;
+        const size_t cap = need + need / 2 + (64 << 10);
+        HIPCHK(c, hipHostMalloc((void **)&c->pin, cap, hipHostMallocDefault));
+        c->pin_cap = cap;
+        c->pin_off = 0;
+    }
+    *out = c->pin + c->pin_off;
+    c->pin_off += align_up(bytes);
+    return BPGPU_OK;
+}
+static int io_reserve(bpgpu_ctx *c, size_t bytes) {
+    if (bytes <= c->io_cap) return BPGPU_OK;
+    HIPCHK(c, hipDeviceSynchronize());
+    if (c->io_dev) HIPCHK(c, hipFree(c->io_dev));
+    c->io_dev = nullptr;
+    c->io_cap = 0;
+    const size_t cap = bytes + bytes / 2 + (64 << 10);
+    HIPCHK(c, hipMalloc((void **)&c->io_dev, cap));
+    c->io_cap = cap;
+    return BPGPU_OK;
+}
+// wait for everything enqueued on s (host-pointer entry points): spin, or sleep on a blocking event
+static int host_wait(bpgpu_ctx *c, hipStream_t s) {
+    if (c->sync_blocking) {
+        HIPCHK(c, hipEventRecord(c->done_ev, s));
+        HIPCHK(c, hipEventSynchronize(c->done_ev));
+    } else {
+        HIPCHK(c, hipStreamSynchronize(s));
+    }
+    c->pin_pending = false;
+    c->pin_off = 0;
+    return BPGPU_OK;
+}
+static int os_random(bpgpu_ctx *c, char *dst, size_t bytes);
+
 extern "C" {
 
 int bpgpu_version(void) { return 100; }
@@ -182,7 +275,10 @@ int bpgpu_ctx_create(int device, bpgpu_ctx **out) {
     if (hipSetDevice(device) != hipSuccess) return BPGPU_ERR_NO_DEVICE;
     bpgpu_ctx *c = new bpgpu_ctx();
     c->device = device;
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->pin_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) {
         delete c;
         return BPGPU_ERR_HIP;
     }
@@ -199,6 +295,13 @@ void bpgpu_ctx_destroy(bpgpu_ctx *c) {
     for (auto &kv : c->gen_ids_cache) hipFree(kv.second);
     for (auto &kv : c->plan_cache) hipFree(kv.second.mem);
     if (c->arena) hipFree(c->arena);
+    if (c->io_dev) hipFree(c->io_dev);
+    if (c->ipp_buf) hipFree(c->ipp_buf);
+    if (c->pin) hipHostFree(c->pin);
+    for (char *q : c->pin_retired) hipHostFree(q);
+    if (c->order_ev) hipEventDestroy(c->order_ev);
+    if (c->pin_ev) hipEventDestroy(c->pin_ev);
+    if (c->done_ev) hipEventDestroy(c->done_ev);
     if (c->rp_status) hipFree(c->rp_status);
     if (c->d_gens) hipFree(c->d_gens);
     release_table(c);
@@ -233,6 +336,10 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
         c->horner_lanes = (uint32_t)value;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "host_sync_blocking")) {
+        c->sync_blocking = value != 0;
+        return BPGPU_OK;
+    }
     return fail(c, BPGPU_ERR_INVALID_ARG, "unknown option %s", key);
 }
 
@@ -244,6 +351,7 @@ int bpgpu_ctx_get_option(bpgpu_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "fixed_table_max_bytes")) *value = (int64_t)c->table_budget;
     else if (!strcmp(key, "fixed_splits")) *value = c->splits;
     else if (!strcmp(key, "horner_lanes")) *value = c->horner_lanes;
+    else if (!strcmp(key, "host_sync_blocking")) *value = c->sync_blocking ? 1 : 0;
     else return fail(c, BPGPU_ERR_INVALID_ARG, "unknown option %s", key);
     return BPGPU_OK;
 }
@@ -496,11 +604,20 @@ static int vb_launch(bpgpu_ctx *c, hipStream_t s, uint32_t total, uint32_t n_chu
 static int enqueue_vb(bpgpu_ctx *c, hipStream_t s, const vb_plan &pl, size_t nbatch, const size_t off[7],
                       const uint32_t *d_scalars, const uint32_t *d_points, uint32_t *d_status, vb_dev &d) {
     vb_bind(c, off, d);
+    // the plan is a local of the caller: stage it in pinned memory, which outlives the asynchronous copies
+    const size_t b0 = pl.chunks.size() * sizeof(vb_chunk), b1 = (size_t)pl.total * 4, b2 = (nbatch + 1) * 4;
+    char *h = nullptr;
+    int rc = pin_alloc(c, s, align_up(b0) + align_up(b1) + align_up(b2), &h);
+    if (rc) return rc;
+    char *h0 = h, *h1 = h0 + align_up(b0), *h2 = h1 + align_up(b1);
     if (!pl.chunks.empty()) {
-        HIPCHK(c, hipMemcpyAsync(d.chunks, pl.chunks.data(), pl.chunks.size() * sizeof(vb_chunk), hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipMemcpyAsync(d.term_chunk, pl.term_chunk.data(), (size_t)pl.total * 4, hipMemcpyHostToDevice, s));
+        memcpy(h0, pl.chunks.data(), b0);
+        memcpy(h1, pl.term_chunk.data(), b1);
+        HIPCHK(c, hipMemcpyAsync(d.chunks, h0, b0, hipMemcpyHostToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(d.term_chunk, h1, b1, hipMemcpyHostToDevice, s));
     }
-    HIPCHK(c, hipMemcpyAsync(d.chunk_first, pl.chunk_first.data(), (nbatch + 1) * 4, hipMemcpyHostToDevice, s));
+    memcpy(h2, pl.chunk_first.data(), b2);
+    HIPCHK(c, hipMemcpyAsync(d.chunk_first, h2, b2, hipMemcpyHostToDevice, s));
     return vb_launch(c, s, pl.total, (uint32_t)pl.chunks.size(), nbatch, d_scalars, d_points, d_status, d);
 }
 // uniform plans (every MSM of the batch has `per` variable-base terms): decomposition cached on the device
@@ -508,6 +625,14 @@ static int uniform_plan(bpgpu_ctx *c, size_t nbatch, size_t per, bpgpu_ctx::plan
     auto key = std::make_pair(nbatch, per);
     auto it = c->plan_cache.find(key);
     if (it == c->plan_cache.end()) {
+        if (c->plan_cache.size() >= 32) {   // bounded: drop the least recently used decomposition
+            auto victim = c->plan_cache.begin();
+            for (auto jt = c->plan_cache.begin(); jt != c->plan_cache.end(); ++jt)
+                if (jt->second.last_use < victim->second.last_use) victim = jt;
+            HIPCHK(c, hipDeviceSynchronize());   // kernels of earlier calls may still read it
+            HIPCHK(c, hipFree(victim->second.mem));
+            c->plan_cache.erase(victim);
+        }
         std::vector<uint32_t> nt(nbatch, (uint32_t)per);
         vb_plan pl;
         make_vb_plan(pl, nbatch, nt.data());
@@ -524,6 +649,7 @@ static int uniform_plan(bpgpu_ctx *c, size_t nbatch, size_t per, bpgpu_ctx::plan
         HIPCHK(c, hipMemcpy(pd.mem + o1, pl.chunk_first.data(), (nbatch + 1) * 4, hipMemcpyHostToDevice));
         it = c->plan_cache.emplace(key, pd).first;
     }
+    it->second.last_use = ++c->plan_tick;
     *out = &it->second;
     return BPGPU_OK;
 }
@@ -575,7 +701,15 @@ extern "C" int bpgpu_msm_batch_dev(bpgpu_ctx *c, size_t nbatch, const uint32_t *
     if (!c || (nbatch && (!n_terms || !d_out || !d_status))) return BPGPU_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    return msm_batch_dev_locked(c, nbatch, n_terms, d_scalars, d_points, d_out, d_status, stream ? (hipStream_t)stream : c->stream);
+    uint64_t total = 0;
+    for (size_t b = 0; b < nbatch; b++) total += n_terms[b];
+    if (nbatch > 0x7fffffffu / 64 || total > 0x7fffffffu / 64) return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large");
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    rc = msm_batch_dev_locked(c, nbatch, n_terms, d_scalars, d_points, d_out, d_status, s);
+    const int rc2 = ctx_leave(c, s);
+    return rc ? rc : rc2;
 }
 
 extern "C" int bpgpu_msm_batch(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, const uint8_t *points,
@@ -584,35 +718,34 @@ extern "C" int bpgpu_msm_batch(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_te
     if (nbatch == 0) return BPGPU_OK;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    size_t total = 0;
+    uint64_t total = 0;
     for (size_t b = 0; b < nbatch; b++) total += n_terms[b];
     if (total && (!scalars || !points)) return BPGPU_ERR_INVALID_ARG;
-    char *d_io = nullptr;
+    if (nbatch > 0x7fffffffu / 64 || total > 0x7fffffffu / 64) return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large");
+    // persistent device IO buffer + pinned staging: no allocation in steady state, one wait at the end
     const size_t sz_terms = align_up(total * 32 + 16), sz_out = align_up(nbatch * 32), sz_st = align_up(nbatch);
-    HIPCHK(c, hipMalloc((void **)&d_io, 2 * sz_terms + sz_out + sz_st));
-    char *d_s = d_io, *d_p = d_io + sz_terms, *d_o = d_io + 2 * sz_terms, *d_t = d_o + sz_out;
     hipStream_t s = c->stream;
-    int rc = BPGPU_OK;
-    do {
-        if (total) {
-            if (hipMemcpyAsync(d_s, scalars, total * 32, hipMemcpyHostToDevice, s) != hipSuccess ||
-                hipMemcpyAsync(d_p, points, total * 32, hipMemcpyHostToDevice, s) != hipSuccess) {
-                rc = fail(c, BPGPU_ERR_HIP, "H2D copy failed");
-                break;
-            }
-        }
-        rc = msm_batch_dev_locked(c, nbatch, n_terms, d_s, d_p, d_o, d_t, s);
-        if (rc) break;
-        if (hipMemcpyAsync(out, d_o, nbatch * 32, hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipMemcpyAsync(status, d_t, nbatch, hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipStreamSynchronize(s) != hipSuccess) {
-            rc = fail(c, BPGPU_ERR_HIP, "D2H copy / sync failed: %s", hipGetErrorString(hipGetLastError()));
-            break;
-        }
-    } while (0);
-    hipStreamSynchronize(s);
-    hipFree(d_io);
-    return rc;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    rc = io_reserve(c, 2 * sz_terms + sz_out + sz_st);
+    if (rc) return rc;
+    char *h = nullptr;
+    rc = pin_alloc(c, s, 2 * sz_terms + sz_out + sz_st, &h);
+    if (rc) return rc;
+    char *d_s = c->io_dev, *d_p = d_s + sz_terms, *d_o = d_p + sz_terms;
+    char *h_o = h + 2 * sz_terms;
+    if (total) {
+        memcpy(h, scalars, total * 32);
+        memcpy(h + sz_terms, points, total * 32);
+        HIPCHK(c, hipMemcpyAsync(d_s, h, 2 * sz_terms, hipMemcpyHostToDevice, s));
+    }
+    rc = msm_batch_dev_locked(c, nbatch, n_terms, d_s, d_p, d_o, d_o + sz_out, s);
+    if (!rc && hipMemcpyAsync(h_o, d_o, sz_out + sz_st, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+    const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
+    if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
+    memcpy(out, h_o, nbatch * 32);
+    memcpy(status, h_o + sz_out, nbatch);
+    return BPGPU_OK;
 }
 
 // ============================================================================
@@ -666,6 +799,10 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
     const uint32_t n_gen_terms = (uint32_t)(2 * n * m + 2);
     const fb_params prm = c->prm;
     const uint32_t npairs = n_gen_terms * prm.nwin;
+    // thread / element counts are 32-bit in the kernels: refuse what does not fit (grids of <= 2^31 / 64 blocks)
+    if ((uint64_t)n_gen_terms * nbatch > 0x7fffffffull || (uint64_t)nbatch * ((n_unique + BP_VB_CHUNK - 1) / BP_VB_CHUNK) * 64 > 0x7fffffffull ||
+        (uint64_t)nbatch * n_unique > 0x7fffffffull / 64)
+        return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large for this shape");
     uint32_t *d_ids = nullptr;
     int rc = gen_ids_for(c, n, m, &d_ids);
     if (rc) return rc;
@@ -711,8 +848,12 @@ extern "C" int bpgpu_msm_batch_shared_dev(bpgpu_ctx *c, size_t n, size_t m, size
     if (n_unique && (!d_uniq_scalars || !d_uniq_points)) return BPGPU_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    return msm_shared_dev_locked(c, n, m, nbatch, n_unique, d_gen_scalars, d_uniq_scalars, d_uniq_points, d_out, d_status, nullptr,
-                                 stream ? (hipStream_t)stream : c->stream);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    rc = msm_shared_dev_locked(c, n, m, nbatch, n_unique, d_gen_scalars, d_uniq_scalars, d_uniq_points, d_out, d_status, nullptr, s);
+    const int rc2 = ctx_leave(c, s);
+    return rc ? rc : rc2;
 }
 
 extern "C" int bpgpu_msm_batch_shared(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, size_t n_unique, const uint8_t *gen_scalars,
@@ -724,29 +865,29 @@ extern "C" int bpgpu_msm_batch_shared(bpgpu_ctx *c, size_t n, size_t m, size_t n
     HIPCHK(c, hipSetDevice(c->device));
     const size_t ng = (2 * n * m + 2) * nbatch * 32, nu = n_unique * nbatch * 32;
     const size_t sz_g = align_up(ng + 16), sz_u = align_up(nu + 16), sz_out = align_up(nbatch * 32), sz_st = align_up(nbatch);
-    char *d_io = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_io, sz_g + 2 * sz_u + sz_out + sz_st));
-    char *d_g = d_io, *d_us = d_io + sz_g, *d_up = d_us + sz_u, *d_o = d_up + sz_u, *d_t = d_o + sz_out;
     hipStream_t s = c->stream;
-    int rc = BPGPU_OK;
-    do {
-        if (hipMemcpyAsync(d_g, gen_scalars, ng, hipMemcpyHostToDevice, s) != hipSuccess ||
-            (nu && (hipMemcpyAsync(d_us, uniq_scalars, nu, hipMemcpyHostToDevice, s) != hipSuccess ||
-                    hipMemcpyAsync(d_up, uniq_points, nu, hipMemcpyHostToDevice, s) != hipSuccess))) {
-            rc = fail(c, BPGPU_ERR_HIP, "H2D copy failed");
-            break;
-        }
-        rc = msm_shared_dev_locked(c, n, m, nbatch, n_unique, d_g, d_us, d_up, d_o, d_t, nullptr, s);
-        if (rc) break;
-        if (hipMemcpyAsync(out, d_o, nbatch * 32, hipMemcpyDeviceToHost, s) != hipSuccess ||
-            hipMemcpyAsync(status, d_t, nbatch, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-            rc = fail(c, BPGPU_ERR_HIP, "D2H copy / sync failed: %s", hipGetErrorString(hipGetLastError()));
-            break;
-        }
-    } while (0);
-    hipStreamSynchronize(s);
-    hipFree(d_io);
-    return rc;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    rc = io_reserve(c, sz_g + 2 * sz_u + sz_out + sz_st);
+    if (rc) return rc;
+    char *h = nullptr;
+    rc = pin_alloc(c, s, sz_g + 2 * sz_u + sz_out + sz_st, &h);
+    if (rc) return rc;
+    char *d_g = c->io_dev, *d_us = d_g + sz_g, *d_up = d_us + sz_u, *d_o = d_up + sz_u;
+    char *h_o = h + sz_g + 2 * sz_u;
+    memcpy(h, gen_scalars, ng);
+    if (nu) {
+        memcpy(h + sz_g, uniq_scalars, nu);
+        memcpy(h + sz_g + sz_u, uniq_points, nu);
+    }
+    HIPCHK(c, hipMemcpyAsync(d_g, h, sz_g + 2 * sz_u, hipMemcpyHostToDevice, s));
+    rc = msm_shared_dev_locked(c, n, m, nbatch, n_unique, d_g, d_us, d_up, d_o, d_o + sz_out, nullptr, s);
+    if (!rc && hipMemcpyAsync(h_o, d_o, sz_out + sz_st, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+    const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
+    if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
+    memcpy(out, h_o, nbatch * 32);
+    memcpy(status, h_o + sz_out, nbatch);
+    return BPGPU_OK;
 }
 
 // ============================================================================
@@ -813,7 +954,78 @@ extern "C" int bpgpu_gens_create(bpgpu_ctx *c, size_t gens_capacity, size_t part
 // ============================================================================
 // range-proof verification
 // ============================================================================
-#include <sys/random.h>
+
+// ---- Merlin transcripts on the host (Transcript::new / append_message / challenge_bytes on the 208-byte state) ----
+static void ts_to_strobe(strobe &t, uint32_t w[50], const uint8_t *state) {
+    memcpy(w, state, 200);
+    t.st.w = w;
+    t.st.stride = 1;
+    t.pos = state[200];
+    t.pos_begin = state[201];
+    t.cur_flags = state[202];
+}
+static void ts_from_strobe(uint8_t *state, const strobe &t) {
+    memset(state, 0, BPGPU_TRANSCRIPT_BYTES);
+    memcpy(state, t.st.w, 200);
+    state[200] = (uint8_t)t.pos;
+    state[201] = (uint8_t)t.pos_begin;
+    state[202] = (uint8_t)t.cur_flags;
+}
+static bool ts_state_ok(const uint8_t *state) { return state[200] < BP_STROBE_R && state[201] <= BP_STROBE_R; }
+static const uint8_t DOM_SEP[7] = {'d', 'o', 'm', '-', 's', 'e', 'p'};
+
+extern "C" int bpgpu_transcript_new(const uint8_t *label, size_t label_len, uint8_t state[BPGPU_TRANSCRIPT_BYTES]) {
+    if (!state || (label_len && !label) || label_len > 0xffffffffu) return BPGPU_ERR_INVALID_ARG;
+    uint32_t w[50];
+    kstate st;
+    st.w = w;
+    st.stride = 1;
+    strobe t;
+    merlin_strobe_init(t, st);
+    merlin_append_message(t, DOM_SEP, 7, label, (uint32_t)label_len);   // Transcript::new: append_message(b"dom-sep", label)
+    ts_from_strobe(state, t);
+    return BPGPU_OK;
+}
+extern "C" int bpgpu_transcript_append_message(uint8_t state[BPGPU_TRANSCRIPT_BYTES], const uint8_t *label, size_t label_len,
+                                               const uint8_t *msg, size_t msg_len) {
+    if (!state || (label_len && !label) || (msg_len && !msg) || label_len > 0xffffffffu || msg_len > 0xffffffffu || !ts_state_ok(state))
+        return BPGPU_ERR_INVALID_ARG;
+    uint32_t w[50];
+    strobe t;
+    ts_to_strobe(t, w, state);
+    merlin_append_message(t, label, (uint32_t)label_len, msg, (uint32_t)msg_len);
+    ts_from_strobe(state, t);
+    return BPGPU_OK;
+}
+extern "C" int bpgpu_transcript_challenge_bytes(uint8_t state[BPGPU_TRANSCRIPT_BYTES], const uint8_t *label, size_t label_len,
+                                                uint8_t *out, size_t out_len) {
+    if (!state || (label_len && !label) || (out_len && !out) || label_len > 0xffffffffu || out_len > 0xffffffffu || !ts_state_ok(state))
+        return BPGPU_ERR_INVALID_ARG;
+    uint32_t w[50];
+    strobe t;
+    ts_to_strobe(t, w, state);
+    merlin_challenge_bytes(t, label, (uint32_t)label_len, out, (uint32_t)out_len);
+    ts_from_strobe(state, t);
+    return BPGPU_OK;
+}
+
+static int os_random(bpgpu_ctx *c, char *dst, size_t bytes) {
+    size_t got = 0;
+    while (got < bytes) {
+        const ssize_t r = getrandom(dst + got, bytes - got, 0);
+        if (r <= 0) return fail(c, BPGPU_ERR_HIP, "getrandom failed");
+        got += (size_t)r;
+    }
+    return BPGPU_OK;
+}
+
+// the caller's transcript, not yet domain-separated: the kernel applies rangeproof_domain_sep(n, m) per proof
+static void strobe_init_from_state(rp_strobe_init &init, const uint8_t *state) {
+    memcpy(init.w, state, 200);
+    init.pos = state[200];
+    init.pos_begin = state[201];
+    init.cur_flags = state[202];
+}
 
 static void make_strobe_init(rp_strobe_init &init, const uint8_t *label, size_t label_len, uint64_t n, uint64_t m) {
     // Transcript::new(label) followed by rangeproof_domain_sep(n, m) (transcript.rs:44-48): identical for
@@ -835,8 +1047,18 @@ static void make_strobe_init(rp_strobe_init &init, const uint8_t *label, size_t 
     init.cur_flags = t.cur_flags;
 }
 
+// Where a call's transcripts start: Transcript::new(label) (label), or one caller-supplied state for the whole batch
+// (shared_ts, host, 208 bytes), or one state per proof (d_ts_in, device); d_ts_out (optional): the advanced states.
+struct rp_transcripts {
+    const uint8_t *label = nullptr;
+    size_t label_len = 0;
+    const uint8_t *shared_ts = nullptr;
+    const void *d_ts_in = nullptr;
+    void *d_ts_out = nullptr;
+};
+
 static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
-                                const void *d_commitments, const uint8_t *label, size_t label_len, const void *d_rng64, void *d_verdict,
+                                const void *d_commitments, const rp_transcripts &tr, const void *d_rng64, void *d_verdict,
                                 void *d_msm_out, hipStream_t s, bool rlc = false, const void *d_weights64 = nullptr,
                                 void *d_batch_out = nullptr) {
     // rlc: batch-combination mode (bpgpu_rangeproof_verify_rlc[_dev]); d_msm_out is unused then, d_batch_out
@@ -859,7 +1081,21 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
             if (k >= 32) all_verdict = BPGPU_VERDICT_FORMAT_ERROR;
         }
     }
+    if (tr.shared_ts && !ts_state_ok(tr.shared_ts)) return fail(c, BPGPU_ERR_INVALID_ARG, "malformed transcript state");
     if (all_verdict) {   // every proof of the batch has the same malformed length
+        if (tr.d_ts_out) {   // FormatError leaves the caller's transcript untouched
+            if (tr.d_ts_in) HIPCHK(c, hipMemcpyAsync(tr.d_ts_out, tr.d_ts_in, nbatch * BPGPU_TRANSCRIPT_BYTES, hipMemcpyDeviceToDevice, s));
+            else {
+                char *h = nullptr;
+                int rcp = pin_alloc(c, s, nbatch * BPGPU_TRANSCRIPT_BYTES, &h);
+                if (rcp) return rcp;
+                uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
+                if (tr.shared_ts) memcpy(st0, tr.shared_ts, BPGPU_TRANSCRIPT_BYTES);
+                else bpgpu_transcript_new(tr.label, tr.label_len, st0);
+                for (size_t b = 0; b < nbatch; b++) memcpy(h + b * BPGPU_TRANSCRIPT_BYTES, st0, BPGPU_TRANSCRIPT_BYTES);
+                HIPCHK(c, hipMemcpyAsync(tr.d_ts_out, h, nbatch * BPGPU_TRANSCRIPT_BYTES, hipMemcpyHostToDevice, s));
+            }
+        }
         HIPCHK(c, hipMemsetAsync(d_verdict, (int)all_verdict, nbatch, s));
         if (d_msm_out) HIPCHK(c, hipMemsetAsync(d_msm_out, 0, nbatch * 32, s));
         if (rlc && d_batch_out) HIPCHK(c, hipMemsetAsync(d_batch_out, 0, 33, s));   // nothing to combine
@@ -894,6 +1130,11 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         if (rc) return rc;
     }
     const uint32_t nsplit = pick_splits(c, nbatch, npairs);
+    // thread / element counts are 32-bit in the kernels: refuse what does not fit
+    if ((uint64_t)n_gen_terms * nbatch > 0x7fffffffull || (uint64_t)nbatch * sh.U > 0x7fffffffull / 64 ||
+        (uint64_t)nbatch * ((sh.U + BP_VB_CHUNK - 1) / BP_VB_CHUNK) * 64 > 0x7fffffffull || (uint64_t)(sh.nm / 4 + 1) * nbatch > 0x7fffffffull ||
+        (uint64_t)((nbatch + FB_BLOCK - 1) / FB_BLOCK) * nsplit > 0x7fffffffull)
+        return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large for this shape");
     arena_plan ap;
     size_t off[7];
     plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off);
@@ -929,35 +1170,41 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     uint32_t *d_fields = (uint32_t *)(a + off_fields);
     uint8_t *d_mv = (uint8_t *)(a + off_mv);
     const uint8_t *rng_ptr = (const uint8_t *)d_rng64;
-    if (!rng_ptr) {   // thread_rng() stand-in: OS CSPRNG (verify_multiple, mod.rs:455-470)
-        std::vector<uint8_t> h(nbatch * 64);
-        size_t got = 0;
-        while (got < h.size()) {
-            const ssize_t r = getrandom(h.data() + got, h.size() - got, 0);
-            if (r <= 0) return fail(c, BPGPU_ERR_HIP, "getrandom failed");
-            got += (size_t)r;
-        }
-        HIPCHK(c, hipMemcpyAsync(a + off_rng, h.data(), h.size(), hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipStreamSynchronize(s));   // h goes out of scope
+    if (!rng_ptr) {   // thread_rng() stand-in: OS CSPRNG (verify_multiple, mod.rs:455-470), staged in pinned memory
+        char *h = nullptr;
+        rc = pin_alloc(c, s, nbatch * 64, &h);
+        if (rc) return rc;
+        rc = os_random(c, h, nbatch * 64);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(a + off_rng, h, nbatch * 64, hipMemcpyHostToDevice, s));
         rng_ptr = (const uint8_t *)(a + off_rng);
     }
     const uint8_t *wts_ptr = (const uint8_t *)d_weights64;
     if (rlc && !wts_ptr) {   // the combination weights must be unpredictable to the prover: OS CSPRNG
-        std::vector<uint8_t> h(nbatch * 64);
-        size_t got = 0;
-        while (got < h.size()) {
-            const ssize_t r = getrandom(h.data() + got, h.size() - got, 0);
-            if (r <= 0) return fail(c, BPGPU_ERR_HIP, "getrandom failed");
-            got += (size_t)r;
-        }
-        HIPCHK(c, hipMemcpyAsync(a + off_wts, h.data(), h.size(), hipMemcpyHostToDevice, s));
-        HIPCHK(c, hipStreamSynchronize(s));
+        char *h = nullptr;
+        rc = pin_alloc(c, s, nbatch * 64, &h);
+        if (rc) return rc;
+        rc = os_random(c, h, nbatch * 64);
+        if (rc) return rc;
+        HIPCHK(c, hipMemcpyAsync(a + off_wts, h, nbatch * 64, hipMemcpyHostToDevice, s));
         wts_ptr = (const uint8_t *)(a + off_wts);
     }
     if (c->rp_status_dirty) HIPCHK(c, hipMemsetAsync(d_status, 0, c->rp_status_cap * 4, s));
     c->rp_status_dirty = true;   // until the kernel that resets the words has been enqueued
     rp_strobe_init init;
-    make_strobe_init(init, label, label_len, n, m);
+    uint32_t ts_flags = 0;
+    if (tr.d_ts_in || tr.shared_ts) {
+        ts_flags = BP_TS_DOMSEP;
+        if (tr.shared_ts) strobe_init_from_state(init, tr.shared_ts);
+        else memset(&init, 0, sizeof init);
+    } else if (tr.d_ts_out) {   // label + states wanted back: start every proof from Transcript::new(label) and replay the domain separator on the device
+        uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
+        bpgpu_transcript_new(tr.label, tr.label_len, st0);
+        strobe_init_from_state(init, st0);
+        ts_flags = BP_TS_DOMSEP;
+    } else {
+        make_strobe_init(init, tr.label, tr.label_len, n, m);
+    }
     const uint32_t nb32 = (uint32_t)nbatch;
     // the proof-specific ("variable-base") terms: decomposition into chunks of 32 is cached per (batch, U)
     vb_dev d{};
@@ -979,7 +1226,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const uint32_t n_pt = shape_verdict ? 0 : (nb32 * sh.U + RP_BLOCK - 1) / RP_BLOCK;
     LAUNCH(c, s, "rp_stage1", k_rp_stage1, n_tr + n_pt, RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
            (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, d.recoded, d_digits,
-           rlc ? wts_ptr : (const uint8_t *)nullptr);
+           rlc ? wts_ptr : (const uint8_t *)nullptr, ts_flags, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out);
     if (shape_verdict) {
         HIPCHK(c, hipMemsetAsync(d_mv, 1, nbatch, s));
         LAUNCH(c, s, "rp_verdict", k_rp_verdict, (nb32 + 63) / 64, 64, nb32, d_status, d_mv, (uint8_t *)d_verdict);
@@ -1060,125 +1307,165 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     return BPGPU_OK;
 }
 
-extern "C" int bpgpu_rangeproof_verify_batch_dev(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
-                                                 const void *d_commitments, const uint8_t *label, size_t label_len, const void *d_rng64,
-                                                 void *d_verdict, void *d_msm_out, void *stream) {
-    if (!c || (nbatch && (!d_proofs || !d_verdict || (m && !d_commitments))) || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
-    if (((uintptr_t)d_proofs | (uintptr_t)d_commitments | (uintptr_t)d_rng64) & 3)
+// ---- entry points: device pointers ----------------------------------------------------------------------
+static int rp_dev_call(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len, const void *d_commitments,
+                       const rp_transcripts &tr, const void *d_rng64, void *d_verdict, void *d_msm_out, void *stream, bool rlc,
+                       const void *d_weights64, void *d_batch_out) {
+    if (!c || (nbatch && (!d_proofs || !d_verdict || (m && !d_commitments))) || (tr.label_len && !tr.label)) return BPGPU_ERR_INVALID_ARG;
+    if (((uintptr_t)d_proofs | (uintptr_t)d_commitments | (uintptr_t)d_rng64 | (uintptr_t)d_weights64 | (uintptr_t)tr.d_ts_in | (uintptr_t)tr.d_ts_out) & 3)
         return fail(c, BPGPU_ERR_INVALID_ARG, "device buffers must be 4-byte aligned");
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    return rp_verify_dev_locked(c, n, m, nbatch, d_proofs, proof_len, d_commitments, label, label_len, d_rng64, d_verdict, d_msm_out,
-                                stream ? (hipStream_t)stream : c->stream);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    rc = rp_verify_dev_locked(c, n, m, nbatch, d_proofs, proof_len, d_commitments, tr, d_rng64, d_verdict, d_msm_out, s, rlc, d_weights64, d_batch_out);
+    const int rc2 = ctx_leave(c, s);
+    return rc ? rc : rc2;
 }
 
-extern "C" int bpgpu_rangeproof_verify_batch(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len,
-                                             const uint8_t *commitments, const uint8_t *label, size_t label_len, const uint8_t *rng64,
-                                             uint8_t *verdict, uint8_t *msm_out) {
-    if (!c || (nbatch && (!proofs || !verdict || (m && !commitments))) || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
-    if (nbatch == 0) return BPGPU_OK;
-    std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(c, hipSetDevice(c->device));
-    const size_t sz_p = align_up(nbatch * proof_len + 64), sz_c = align_up(nbatch * m * 32 + 64), sz_r = align_up(nbatch * 64),
-                 sz_v = align_up(nbatch), sz_o = align_up(nbatch * 32);
-    char *d_io = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_io, sz_p + sz_c + sz_r + sz_v + sz_o));
-    char *d_p = d_io, *d_c = d_p + sz_p, *d_r = d_c + sz_c, *d_v = d_r + sz_r, *d_o = d_v + sz_v;
-    hipStream_t s = c->stream;
-    int rc = BPGPU_OK;
-    do {
-        if (hipMemcpyAsync(d_p, proofs, nbatch * proof_len, hipMemcpyHostToDevice, s) != hipSuccess ||
-            (m && hipMemcpyAsync(d_c, commitments, nbatch * m * 32, hipMemcpyHostToDevice, s) != hipSuccess) ||
-            (rng64 && hipMemcpyAsync(d_r, rng64, nbatch * 64, hipMemcpyHostToDevice, s) != hipSuccess)) {
-            rc = fail(c, BPGPU_ERR_HIP, "H2D copy failed");
-            break;
-        }
-        rc = rp_verify_dev_locked(c, n, m, nbatch, d_p, proof_len, d_c, label, label_len, rng64 ? d_r : nullptr, d_v, msm_out ? d_o : nullptr, s);
-        if (rc) break;
-        if (hipMemcpyAsync(verdict, d_v, nbatch, hipMemcpyDeviceToHost, s) != hipSuccess ||
-            (msm_out && hipMemcpyAsync(msm_out, d_o, nbatch * 32, hipMemcpyDeviceToHost, s) != hipSuccess) ||
-            hipStreamSynchronize(s) != hipSuccess) {
-            rc = fail(c, BPGPU_ERR_HIP, "D2H copy / sync failed: %s", hipGetErrorString(hipGetLastError()));
-            break;
-        }
-    } while (0);
-    hipStreamSynchronize(s);
-    hipFree(d_io);
-    return rc;
+extern "C" int bpgpu_rangeproof_verify_batch_dev(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
+                                                 const void *d_commitments, const uint8_t *label, size_t label_len, const void *d_rng64,
+                                                 void *d_verdict, void *d_msm_out, void *stream) {
+    rp_transcripts tr;
+    tr.label = label;
+    tr.label_len = label_len;
+    return rp_dev_call(c, n, m, nbatch, d_proofs, proof_len, d_commitments, tr, d_rng64, d_verdict, d_msm_out, stream, false, nullptr, nullptr);
 }
 
-// ---- batch combination entry points (rlc.h; SURVEY 8f-3, additional to the reference's API) ---------------
+extern "C" int bpgpu_rangeproof_verify_batch_ts_dev(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
+                                                    const void *d_commitments, const uint8_t *shared_transcript, const void *d_transcripts,
+                                                    const void *d_rng64, void *d_verdict, void *d_msm_out, void *d_transcripts_out,
+                                                    void *stream) {
+    if (!c) return BPGPU_ERR_INVALID_ARG;
+    if ((shared_transcript != nullptr) == (d_transcripts != nullptr))
+        return fail(c, BPGPU_ERR_INVALID_ARG, "give exactly one of shared_transcript / d_transcripts");
+    rp_transcripts tr;
+    tr.shared_ts = shared_transcript;
+    tr.d_ts_in = d_transcripts;
+    tr.d_ts_out = d_transcripts_out;
+    return rp_dev_call(c, n, m, nbatch, d_proofs, proof_len, d_commitments, tr, d_rng64, d_verdict, d_msm_out, stream, false, nullptr, nullptr);
+}
+
 extern "C" int bpgpu_rangeproof_verify_rlc_dev(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
                                                const void *d_commitments, const uint8_t *label, size_t label_len, const void *d_rng64,
                                                const void *d_weights64, void *d_verdict, void *d_batch_out, void *stream) {
-    if (!c || (nbatch && (!d_proofs || !d_verdict || (m && !d_commitments))) || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
-    if (((uintptr_t)d_proofs | (uintptr_t)d_commitments | (uintptr_t)d_rng64 | (uintptr_t)d_weights64) & 3)
-        return fail(c, BPGPU_ERR_INVALID_ARG, "device pointers must be 4-byte aligned");
-    std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(c, hipSetDevice(c->device));
-    return rp_verify_dev_locked(c, n, m, nbatch, d_proofs, proof_len, d_commitments, label, label_len, d_rng64, d_verdict, nullptr,
-                                stream ? (hipStream_t)stream : c->stream, true, d_weights64, d_batch_out);
+    rp_transcripts tr;
+    tr.label = label;
+    tr.label_len = label_len;
+    return rp_dev_call(c, n, m, nbatch, d_proofs, proof_len, d_commitments, tr, d_rng64, d_verdict, nullptr, stream, true, d_weights64, d_batch_out);
 }
 
-extern "C" int bpgpu_rangeproof_verify_rlc(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len,
-                                           const uint8_t *commitments, const uint8_t *label, size_t label_len, const uint8_t *rng64,
-                                           const uint8_t *weights64, uint8_t *verdict, uint8_t *batch_out) {
-    if (!c || (nbatch && (!proofs || !verdict || (m && !commitments))) || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
+// ---- entry points: host pointers -------------------------------------------------------------------------
+// Inputs are packed into the context's pinned staging buffer and go to the persistent device IO buffer in ONE
+// asynchronous copy; results come back in one copy; one wait at the end.  No allocation in steady state.
+static int rp_host_call(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len, const uint8_t *commitments,
+                        rp_transcripts tr, const uint8_t *ts_in_host, const uint8_t *rng64, uint8_t *verdict, uint8_t *msm_out,
+                        uint8_t *ts_out_host, bool rlc, const uint8_t *weights64, uint8_t *batch_out) {
+    if (!c || (nbatch && (!proofs || !verdict || (m && !commitments))) || (tr.label_len && !tr.label)) return BPGPU_ERR_INVALID_ARG;
     if (nbatch == 0) {
         if (batch_out) memset(batch_out, 0, 33);
         return BPGPU_OK;
     }
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
-    const size_t sz_p = align_up(nbatch * proof_len + 64), sz_c = align_up(nbatch * m * 32 + 64), sz_r = align_up(nbatch * 64),
-                 sz_v = align_up(nbatch), sz_o = align_up(64);
-    char *d_io = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d_io, sz_p + sz_c + 2 * sz_r + sz_v + sz_o));
-    char *d_p = d_io, *d_c = d_p + sz_p, *d_r = d_c + sz_c, *d_w = d_r + sz_r, *d_v = d_w + sz_r, *d_o = d_v + sz_v;
+    const size_t TS = BPGPU_TRANSCRIPT_BYTES;
+    const size_t sz_p = align_up(nbatch * proof_len + 64), sz_c = align_up(nbatch * m * 32 + 64), sz_r = rng64 ? align_up(nbatch * 64) : 0,
+                 sz_w = weights64 ? align_up(nbatch * 64) : 0, sz_ti = ts_in_host ? align_up(nbatch * TS) : 0;
+    const size_t sz_in = sz_p + sz_c + sz_r + sz_w + sz_ti;
+    const size_t sz_v = align_up(nbatch), sz_o = msm_out ? align_up(nbatch * 32) : 0, sz_b = rlc ? align_up(64) : 0,
+                 sz_to = ts_out_host ? align_up(nbatch * TS) : 0;
+    const size_t sz_out = sz_v + sz_o + sz_b + sz_to;
     hipStream_t s = c->stream;
-    int rc = BPGPU_OK;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    rc = io_reserve(c, sz_in + sz_out);
+    if (rc) return rc;
+    char *h = nullptr;
+    rc = pin_alloc(c, s, sz_in + sz_out, &h);
+    if (rc) return rc;
+    char *d = c->io_dev;
+    char *d_p = d, *d_c = d_p + sz_p, *d_r = d_c + sz_c, *d_w = d_r + sz_r, *d_ti = d_w + sz_w;
+    char *d_v = d + sz_in, *d_o = d_v + sz_v, *d_b = d_o + sz_o, *d_to = d_b + sz_b;
+    memcpy(h, proofs, nbatch * proof_len);
+    if (m) memcpy(h + sz_p, commitments, nbatch * m * 32);
+    if (rng64) memcpy(h + sz_p + sz_c, rng64, nbatch * 64);
+    if (weights64) memcpy(h + sz_p + sz_c + sz_r, weights64, nbatch * 64);
+    if (ts_in_host) memcpy(h + sz_p + sz_c + sz_r + sz_w, ts_in_host, nbatch * TS);
+    HIPCHK(c, hipMemcpyAsync(d, h, sz_in, hipMemcpyHostToDevice, s));
+    tr.d_ts_in = ts_in_host ? d_ti : nullptr;
+    tr.d_ts_out = ts_out_host ? d_to : nullptr;
+    char *h_out = h + sz_in;
+    rc = rp_verify_dev_locked(c, n, m, nbatch, d_p, proof_len, d_c, tr, rng64 ? d_r : nullptr, d_v, msm_out ? d_o : nullptr, s, rlc,
+                              weights64 ? d_w : nullptr, rlc ? d_b : nullptr);
+    if (!rc && hipMemcpyAsync(h_out, d_v, sz_out, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+    int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
+    if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
+    if (rlc && (uint8_t)h_out[sz_v + sz_o] != 0) {
+        // the combination is not the identity: some proof fails -- find out which, proof by proof (inputs are still on the device)
+        uint8_t bo[33];
+        memcpy(bo, h_out + sz_v + sz_o, 33);
+        rc = ctx_enter(c, s);
+        if (rc) return rc;
+        rc = rp_verify_dev_locked(c, n, m, nbatch, d_p, proof_len, d_c, tr, rng64 ? d_r : nullptr, d_v, nullptr, s);
+        if (!rc && hipMemcpyAsync(h_out, d_v, sz_v, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+        rc2 = ctx_leave(c, s);
+        rc3 = host_wait(c, s);
+        if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
+        memcpy(h_out + sz_v + sz_o, bo, 33);
+    }
+    memcpy(verdict, h_out, nbatch);
+    if (msm_out) memcpy(msm_out, h_out + sz_v, nbatch * 32);
+    if (rlc && batch_out) memcpy(batch_out, h_out + sz_v + sz_o, 33);
+    if (ts_out_host) memcpy(ts_out_host, h_out + sz_v + sz_o + sz_b, nbatch * TS);
+    return BPGPU_OK;
+}
+
+extern "C" int bpgpu_rangeproof_verify_batch(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len,
+                                             const uint8_t *commitments, const uint8_t *label, size_t label_len, const uint8_t *rng64,
+                                             uint8_t *verdict, uint8_t *msm_out) {
+    rp_transcripts tr;
+    tr.label = label;
+    tr.label_len = label_len;
+    return rp_host_call(c, n, m, nbatch, proofs, proof_len, commitments, tr, nullptr, rng64, verdict, msm_out, nullptr, false, nullptr, nullptr);
+}
+
+extern "C" int bpgpu_rangeproof_verify_batch_ts(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len,
+                                                const uint8_t *commitments, const uint8_t *transcripts, size_t transcript_stride,
+                                                const uint8_t *rng64, uint8_t *verdict, uint8_t *msm_out, uint8_t *transcripts_out) {
+    if (!c) return BPGPU_ERR_INVALID_ARG;
+    if (!transcripts || (transcript_stride != 0 && transcript_stride != BPGPU_TRANSCRIPT_BYTES))
+        return fail(c, BPGPU_ERR_INVALID_ARG, "transcripts missing, or transcript_stride neither 0 nor BPGPU_TRANSCRIPT_BYTES");
+    if (transcript_stride)
+        for (size_t b = 0; b < nbatch; b++)
+            if (!ts_state_ok(transcripts + b * BPGPU_TRANSCRIPT_BYTES)) return fail(c, BPGPU_ERR_INVALID_ARG, "malformed transcript state %zu", b);
+    rp_transcripts tr;
+    if (!transcript_stride) tr.shared_ts = transcripts;
+    return rp_host_call(c, n, m, nbatch, proofs, proof_len, commitments, tr, transcript_stride ? transcripts : nullptr, rng64, verdict, msm_out,
+                        transcripts_out, false, nullptr, nullptr);
+}
+
+// ---- batch combination entry points (rlc.h; SURVEY 8f-3, additional to the reference's API) ---------------
+extern "C" int bpgpu_rangeproof_verify_rlc(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len,
+                                           const uint8_t *commitments, const uint8_t *label, size_t label_len, const uint8_t *rng64,
+                                           const uint8_t *weights64, uint8_t *verdict, uint8_t *batch_out) {
+    rp_transcripts tr;
+    tr.label = label;
+    tr.label_len = label_len;
     uint8_t bo[33];
-    do {
-        if (hipMemcpyAsync(d_p, proofs, nbatch * proof_len, hipMemcpyHostToDevice, s) != hipSuccess ||
-            (m && hipMemcpyAsync(d_c, commitments, nbatch * m * 32, hipMemcpyHostToDevice, s) != hipSuccess) ||
-            (rng64 && hipMemcpyAsync(d_r, rng64, nbatch * 64, hipMemcpyHostToDevice, s) != hipSuccess) ||
-            (weights64 && hipMemcpyAsync(d_w, weights64, nbatch * 64, hipMemcpyHostToDevice, s) != hipSuccess)) {
-            rc = fail(c, BPGPU_ERR_HIP, "H2D copy failed");
-            break;
-        }
-        rc = rp_verify_dev_locked(c, n, m, nbatch, d_p, proof_len, d_c, label, label_len, rng64 ? d_r : nullptr, d_v, nullptr, s, true,
-                                  weights64 ? d_w : nullptr, d_o);
-        if (rc) break;
-        if (hipMemcpyAsync(bo, d_o, 33, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-            rc = fail(c, BPGPU_ERR_HIP, "D2H copy / sync failed: %s", hipGetErrorString(hipGetLastError()));
-            break;
-        }
-        if (bo[0] != 0) {   // the combination is not the identity: some proof fails -- find out which, proof by proof
-            rc = rp_verify_dev_locked(c, n, m, nbatch, d_p, proof_len, d_c, label, label_len, rng64 ? d_r : nullptr, d_v, nullptr, s);
-            if (rc) break;
-        }
-        if (hipMemcpyAsync(verdict, d_v, nbatch, hipMemcpyDeviceToHost, s) != hipSuccess || hipStreamSynchronize(s) != hipSuccess) {
-            rc = fail(c, BPGPU_ERR_HIP, "D2H copy / sync failed: %s", hipGetErrorString(hipGetLastError()));
-            break;
-        }
-        if (batch_out) memcpy(batch_out, bo, 33);
-    } while (0);
-    hipStreamSynchronize(s);
-    hipFree(d_io);
-    return rc;
+    return rp_host_call(c, n, m, nbatch, proofs, proof_len, commitments, tr, nullptr, rng64, verdict, nullptr, nullptr, true, weights64,
+                        batch_out ? batch_out : bo);
 }
 
 // ============================================================================
 // stand-alone inner-product proofs
 // ============================================================================
-extern "C" int bpgpu_ipp_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, const uint8_t *proofs, size_t proof_len, const uint8_t *label,
-                                      size_t label_len, const uint8_t *G_factors, const uint8_t *H_factors, const uint8_t *P,
-                                      const uint8_t *Q, const uint8_t *G, const uint8_t *H, uint8_t *verdict, uint8_t *msm_out) {
-    if (!c || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
-    if (nbatch == 0) return BPGPU_OK;
-    if (!proofs || !verdict || !P || !Q || (n && (!G_factors || !H_factors || !G || !H))) return BPGPU_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(c, hipSetDevice(c->device));
+static int ipp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t nbatch, const void *d_proofs, size_t proof_len, const uint8_t *label,
+                                 size_t label_len, const uint8_t *shared_ts, const void *d_Gf, const void *d_Hf, const void *d_P,
+                                 const void *d_Q, const void *d_G, const void *d_H, int bases_shared, void *d_verdict, void *d_msm_out,
+                                 hipStream_t s) {
+    if (nbatch > 0x7fffffffu / 64) return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large");
+    if (shared_ts && !ts_state_ok(shared_ts)) return fail(c, BPGPU_ERR_INVALID_ARG, "malformed transcript state");
     // InnerProductProof::from_bytes, length part (ipp.rs:374-388)
     size_t k = 0;
     bool fmt = false;
@@ -1192,8 +1479,8 @@ extern "C" int bpgpu_ipp_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, con
         }
     }
     if (fmt) {
-        memset(verdict, BPGPU_VERDICT_FORMAT_ERROR, nbatch);
-        if (msm_out) memset(msm_out, 0, nbatch * 32);
+        HIPCHK(c, hipMemsetAsync(d_verdict, BPGPU_VERDICT_FORMAT_ERROR, nbatch, s));
+        if (d_msm_out) HIPCHK(c, hipMemsetAsync(d_msm_out, 0, nbatch * 32, s));
         return BPGPU_OK;
     }
     ipp_shape sh;
@@ -1201,70 +1488,115 @@ extern "C" int bpgpu_ipp_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, con
     sh.k = (uint32_t)k;
     sh.proof_len = (uint32_t)proof_len;
     sh.nproofs = (uint32_t)nbatch;
+    sh.bases_shared = bases_shared ? 1u : 0u;
     if (n == ((size_t)1 << k) && k > BP_RP_MAX_K) return fail(c, BPGPU_ERR_INVALID_ARG, "n > 2^%d not supported", BP_RP_MAX_K);
     sh.shape_verdict = (n == ((size_t)1 << k)) ? 0 : BPGPU_VERDICT_VERIFICATION_ERROR;   // ipp.rs:203-211
     const size_t n_eff = sh.shape_verdict ? 0 : n;
     sh.N = (uint32_t)(2 * n_eff + 2 * (sh.shape_verdict ? 0 : k) + 2);
-    if (sh.shape_verdict) {
-        sh.n = 0;   // only the canonical-scalar check runs
-    }
+    if (sh.shape_verdict) sh.n = 0;   // only the canonical-scalar check runs
     const size_t N = sh.N;
-    // staging (host pointers in; everything else lives in one allocation)
-    const size_t sz_pr = align_up(nbatch * proof_len + 64), sz_f = align_up(nbatch * n * 32 + 64), sz_pq = align_up(nbatch * 32 + 64);
+    if ((uint64_t)nbatch * N > 0x7fffffffull / 64) return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large for this shape");
+    // scratch: the (scalar, point) term lists, front-end status, MSM status / result; own allocation because the MSM below
+    // claims the arena
     const size_t sz_terms = align_up(nbatch * N * 32 + 64), sz_st = align_up(nbatch * 4), sz_b = align_up(nbatch + 64), sz_o = align_up(nbatch * 32 + 64);
-    char *d = nullptr;
-    HIPCHK(c, hipMalloc((void **)&d, sz_pr + 4 * sz_f + 2 * sz_pq + 2 * sz_terms + sz_st + 2 * sz_b + sz_o));
-    char *d_pr = d, *d_gf = d_pr + sz_pr, *d_hf = d_gf + sz_f, *d_g = d_hf + sz_f, *d_h = d_g + sz_f, *d_p = d_h + sz_f, *d_q = d_p + sz_pq;
-    char *d_sc = d_q + sz_pq, *d_pt = d_sc + sz_terms, *d_stat = d_pt + sz_terms, *d_mst = d_stat + sz_st, *d_ver = d_mst + sz_b, *d_out = d_ver + sz_b;
+    const size_t need = 2 * sz_terms + sz_st + sz_b + sz_o;
+    if (c->ipp_cap < need) {
+        HIPCHK(c, hipDeviceSynchronize());
+        if (c->ipp_buf) HIPCHK(c, hipFree(c->ipp_buf));
+        c->ipp_buf = nullptr;
+        c->ipp_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->ipp_buf, need + need / 4));
+        c->ipp_cap = need + need / 4;
+    }
+    char *d_sc = c->ipp_buf, *d_pt = d_sc + sz_terms, *d_stat = d_pt + sz_terms, *d_mst = d_stat + sz_st, *d_out = d_mst + sz_b;
+    HIPCHK(c, hipMemsetAsync(d_sc, 0, 2 * sz_terms + sz_st, s));   // scalars, points, status
+    rp_strobe_init init;
+    {   // Transcript::new(label) [or the caller's transcript] + innerproduct_domain_sep(n) (transcript.rs:50-53), once for the batch
+        uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
+        if (shared_ts) memcpy(st0, shared_ts, BPGPU_TRANSCRIPT_BYTES);
+        else bpgpu_transcript_new(label, label_len, st0);
+        uint32_t w[50];
+        strobe t;
+        ts_to_strobe(t, w, st0);
+        const uint8_t ipp[6] = {'i', 'p', 'p', ' ', 'v', '1'}, ln[1] = {'n'};
+        merlin_append_message(t, DOM_SEP, 7, ipp, 6);
+        merlin_append_u64(t, ln, 1, n);
+        memcpy(init.w, w, 200);
+        init.pos = t.pos;
+        init.pos_begin = t.pos_begin;
+        init.cur_flags = t.cur_flags;
+    }
+    const uint32_t nb32 = (uint32_t)nbatch;
+    LAUNCH(c, s, "ipp_prepare", k_ipp_prepare, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, init, (const uint8_t *)d_proofs, (const uint8_t *)d_Gf,
+           (const uint8_t *)d_Hf, (const uint8_t *)d_P, (const uint8_t *)d_Q, (const uint8_t *)d_G, (const uint8_t *)d_H, (uint32_t *)d_sc,
+           (uint32_t *)d_pt, (uint32_t *)d_stat);
+    std::vector<uint32_t> nt(nbatch, (uint32_t)N);
+    int rc = msm_batch_dev_locked(c, nbatch, nt.data(), d_sc, d_pt, d_out, d_mst, s);
+    if (rc) return rc;
+    LAUNCH(c, s, "ipp_verdict", k_ipp_verdict, (nb32 + 63) / 64, 64, nb32, (const uint32_t *)d_stat, (const uint8_t *)d_mst, (const uint32_t *)d_out,
+           (uint8_t *)d_verdict);
+    if (d_msm_out) HIPCHK(c, hipMemcpyAsync(d_msm_out, d_out, nbatch * 32, hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipGetLastError());
+    return BPGPU_OK;
+}
+
+extern "C" int bpgpu_ipp_verify_batch_dev(bpgpu_ctx *c, size_t n, size_t nbatch, const void *d_proofs, size_t proof_len, const uint8_t *label,
+                                          size_t label_len, const uint8_t *shared_transcript, const void *d_G_factors, const void *d_H_factors,
+                                          const void *d_P, const void *d_Q, const void *d_G, const void *d_H, int bases_shared, void *d_verdict,
+                                          void *d_msm_out, void *stream) {
+    if (!c || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0) return BPGPU_OK;
+    if (!d_proofs || !d_verdict || !d_P || !d_Q || (n && (!d_G_factors || !d_H_factors || !d_G || !d_H))) return BPGPU_ERR_INVALID_ARG;
+    if (((uintptr_t)d_proofs | (uintptr_t)d_G_factors | (uintptr_t)d_H_factors | (uintptr_t)d_P | (uintptr_t)d_Q | (uintptr_t)d_G | (uintptr_t)d_H) & 3)
+        return fail(c, BPGPU_ERR_INVALID_ARG, "device buffers must be 4-byte aligned");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    rc = ipp_verify_dev_locked(c, n, nbatch, d_proofs, proof_len, label, label_len, shared_transcript, d_G_factors, d_H_factors, d_P, d_Q, d_G, d_H,
+                               bases_shared, d_verdict, d_msm_out, s);
+    const int rc2 = ctx_leave(c, s);
+    return rc ? rc : rc2;
+}
+
+extern "C" int bpgpu_ipp_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, const uint8_t *proofs, size_t proof_len, const uint8_t *label,
+                                      size_t label_len, const uint8_t *G_factors, const uint8_t *H_factors, const uint8_t *P,
+                                      const uint8_t *Q, const uint8_t *G, const uint8_t *H, uint8_t *verdict, uint8_t *msm_out) {
+    if (!c || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0) return BPGPU_OK;
+    if (!proofs || !verdict || !P || !Q || (n && (!G_factors || !H_factors || !G || !H))) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t sz_pr = align_up(nbatch * proof_len + 64), sz_f = align_up(nbatch * n * 32 + 64), sz_pq = align_up(nbatch * 32 + 64);
+    const size_t sz_in = sz_pr + 4 * sz_f + 2 * sz_pq, sz_v = align_up(nbatch), sz_o = align_up(nbatch * 32);
     hipStream_t s = c->stream;
-    int rc = BPGPU_OK;
-    do {
-        bool ok = hipMemcpyAsync(d_pr, proofs, nbatch * proof_len, hipMemcpyHostToDevice, s) == hipSuccess &&
-                  hipMemcpyAsync(d_p, P, nbatch * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
-                  hipMemcpyAsync(d_q, Q, nbatch * 32, hipMemcpyHostToDevice, s) == hipSuccess;
-        if (n) {
-            ok = ok && hipMemcpyAsync(d_gf, G_factors, nbatch * n * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
-                 hipMemcpyAsync(d_hf, H_factors, nbatch * n * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
-                 hipMemcpyAsync(d_g, G, nbatch * n * 32, hipMemcpyHostToDevice, s) == hipSuccess &&
-                 hipMemcpyAsync(d_h, H, nbatch * n * 32, hipMemcpyHostToDevice, s) == hipSuccess;
-        }
-        ok = ok && hipMemsetAsync(d_sc, 0, 2 * sz_terms + sz_st, s) == hipSuccess;   // scalars, points, status
-        if (!ok) {
-            rc = fail(c, BPGPU_ERR_HIP, "H2D copy failed");
-            break;
-        }
-        rp_strobe_init init;
-        {   // Transcript::new(label) + innerproduct_domain_sep(n) (transcript.rs:50-53), once for the batch
-            kstate st;
-            st.w = init.w;
-            st.stride = 1;
-            strobe t;
-            merlin_strobe_init(t, st);
-            const uint8_t dom[7] = {'d', 'o', 'm', '-', 's', 'e', 'p'}, ipp[6] = {'i', 'p', 'p', ' ', 'v', '1'}, ln[1] = {'n'};
-            merlin_append_message(t, dom, 7, label, (uint32_t)label_len);
-            merlin_append_message(t, dom, 7, ipp, 6);
-            merlin_append_u64(t, ln, 1, n);
-            init.pos = t.pos;
-            init.pos_begin = t.pos_begin;
-            init.cur_flags = t.cur_flags;
-        }
-        const uint32_t nb32 = (uint32_t)nbatch;
-        LAUNCH(c, s, "ipp_prepare", k_ipp_prepare, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, init, (const uint8_t *)d_pr, (const uint8_t *)d_gf,
-               (const uint8_t *)d_hf, (const uint8_t *)d_p, (const uint8_t *)d_q, (const uint8_t *)d_g, (const uint8_t *)d_h, (uint32_t *)d_sc,
-               (uint32_t *)d_pt, (uint32_t *)d_stat);
-        std::vector<uint32_t> nt(nbatch, (uint32_t)N);
-        rc = msm_batch_dev_locked(c, nbatch, nt.data(), d_sc, d_pt, d_out, d_mst, s);
-        if (rc) break;
-        LAUNCH(c, s, "ipp_verdict", k_ipp_verdict, (nb32 + 63) / 64, 64, nb32, (const uint32_t *)d_stat, (const uint8_t *)d_mst, (const uint32_t *)d_out,
-               (uint8_t *)d_ver);
-        if (hipMemcpyAsync(verdict, d_ver, nbatch, hipMemcpyDeviceToHost, s) != hipSuccess ||
-            (msm_out && hipMemcpyAsync(msm_out, d_out, nbatch * 32, hipMemcpyDeviceToHost, s) != hipSuccess) ||
-            hipStreamSynchronize(s) != hipSuccess) {
-            rc = fail(c, BPGPU_ERR_HIP, "D2H copy / sync failed: %s", hipGetErrorString(hipGetLastError()));
-            break;
-        }
-    } while (0);
-    hipStreamSynchronize(s);
-    hipFree(d);
-    return rc;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    rc = io_reserve(c, sz_in + sz_v + sz_o);
+    if (rc) return rc;
+    char *h = nullptr;
+    rc = pin_alloc(c, s, sz_in + sz_v + sz_o, &h);
+    if (rc) return rc;
+    char *d = c->io_dev;
+    char *d_pr = d, *d_gf = d_pr + sz_pr, *d_hf = d_gf + sz_f, *d_g = d_hf + sz_f, *d_h = d_g + sz_f, *d_p = d_h + sz_f, *d_q = d_p + sz_pq;
+    char *d_v = d + sz_in, *d_o = d_v + sz_v;
+    memcpy(h, proofs, nbatch * proof_len);
+    if (n) {
+        memcpy(h + sz_pr, G_factors, nbatch * n * 32);
+        memcpy(h + sz_pr + sz_f, H_factors, nbatch * n * 32);
+        memcpy(h + sz_pr + 2 * sz_f, G, nbatch * n * 32);
+        memcpy(h + sz_pr + 3 * sz_f, H, nbatch * n * 32);
+    }
+    memcpy(h + sz_pr + 4 * sz_f, P, nbatch * 32);
+    memcpy(h + sz_pr + 4 * sz_f + sz_pq, Q, nbatch * 32);
+    HIPCHK(c, hipMemcpyAsync(d, h, sz_in, hipMemcpyHostToDevice, s));
+    rc = ipp_verify_dev_locked(c, n, nbatch, d_pr, proof_len, label, label_len, nullptr, d_gf, d_hf, d_p, d_q, d_g, d_h, 0, d_v, d_o, s);
+    char *h_out = h + sz_in;
+    if (!rc && hipMemcpyAsync(h_out, d_v, sz_v + sz_o, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+    const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
+    if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
+    memcpy(verdict, h_out, nbatch);
+    if (msm_out) memcpy(msm_out, h_out + sz_v, nbatch * 32);
+    return BPGPU_OK;
 }

@@ -15,6 +15,7 @@ struct ipp_shape {
     uint32_t N;                 // terms: 2n + 2k + 2
     uint32_t proof_len, nproofs;
     uint32_t shape_verdict;     // != 0: n != 2^k (VerificationError, ipp.rs:203-211): only parse
+    uint32_t bases_shared;      // != 0: G, H hold n encodings used by every proof (the reference's callers pass bp_gens.G/H)
 };
 
 // thread p.  Outputs are pre-zeroed by the host, so rejected proofs contribute identity terms.
@@ -115,9 +116,10 @@ BP_HD void ipp_prepare_thread(uint32_t p, ipp_shape sh, const rp_strobe_init &in
         sc28_montmul(r, r, fm);
         sc_from_mont28(t0, r);                          // (b / s_i) h_i on H_i
         store_words8(sc_out + (1 + n + i) * 8, t0);
-        load_words8(w, G + ((uint64_t)p * n + i) * 32);
+        const uint64_t bi = sh.bases_shared ? (uint64_t)i : (uint64_t)p * n + i;
+        load_words8(w, G + bi * 32);
         for (int q = 0; q < 8; q++) pt_out[(1 + i) * 8 + q] = w[q];
-        load_words8(w, H + ((uint64_t)p * n + i) * 32);
+        load_words8(w, H + bi * 32);
         for (int q = 0; q < 8; q++) pt_out[(1 + n + i) * 8 + q] = w[q];
     }
     // - P

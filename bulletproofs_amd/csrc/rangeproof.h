@@ -109,13 +109,35 @@ BP_HD void rp_challenge_scalar(strobe &t, const uint8_t *label, uint32_t label_l
     sc_from_wide(out, w);
 }
 
+// ---- transcripts across the ABI (include/bpgpu.h BPGPU_TRANSCRIPT_BYTES) ---------------------------------
+// one state = 52 words: the 50 sponge words, then pos | pos_begin << 8 | cur_flags << 16, then 0
+#define BP_TS_WORDS 52
+#define BP_TS_DOMSEP 1u   // the start state is the caller's transcript: rangeproof_domain_sep(n, m) is applied on the device
+BP_HD uint32_t rp_ts_meta(uint32_t pos, uint32_t pos_begin, uint32_t cur_flags) { return (pos & 0xffu) | ((pos_begin & 0xffu) << 8) | ((cur_flags & 0xffu) << 16); }
+// the untouched input state of proof p -> ts_out (proofs the parser / the parameter checks reject)
+BP_HD void rp_ts_passthrough(uint32_t p, const rp_strobe_init &init, const uint32_t *ts_in, uint32_t *ts_out) {
+    if (!ts_out) return;
+    uint32_t *o = ts_out + (uint64_t)p * BP_TS_WORDS;
+    if (ts_in) {
+        for (uint32_t i = 0; i < BP_TS_WORDS; i++) o[i] = ts_in[(uint64_t)p * BP_TS_WORDS + i];
+    } else {
+        for (uint32_t i = 0; i < 50; i++) o[i] = init.w[i];
+        o[50] = rp_ts_meta(init.pos, init.pos_begin, init.cur_flags);
+        o[51] = 0;
+    }
+}
+
 // ---- stage 1: parse + transcript ------------------------------------------------------
 // thread p.  `st` = this lane's 50-word sponge state (LDS on the device).
 // Outputs: fields (plain scalars) and status[p] (0, VerificationError, FormatError).  The per-proof points
 // (A,S,T1,T2,L_*,R_*,V_*) are decoded straight from the proof bytes by rp_points_thread, which does not
 // depend on the transcript and therefore shares a launch with it.
+// ts_flags / ts_in / ts_out: caller-supplied transcripts (bpgpu_rangeproof_verify_batch_ts): the start state is
+// ts_in[p] if given, else `init`; with BP_TS_DOMSEP it does not contain rangeproof_domain_sep(n, m) yet
+// (transcript.rs:44-48), which is then applied here; ts_out[p] (optional) receives the advanced state.
 BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &init, kstate st, const uint8_t *proofs,
-                                const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields, uint32_t *status) {
+                                const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields, uint32_t *status,
+                                uint32_t ts_flags = 0, const uint32_t *ts_in = nullptr, uint32_t *ts_out = nullptr) {
     const uint32_t B = sh.nproofs, k = sh.k;
     const uint8_t *pr = proofs + (uint64_t)p * sh.proof_len;
     const rp_fields fl = rp_field_layout(k, sh.m);
@@ -130,10 +152,12 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
     load_words8(b.v, pr + 224 + 64 * k + 32);  fmt_ok = fmt_ok && sc_is_canonical_sc(b);
     if (!fmt_ok) {
         status_raise(status + p, BP_VERDICT_FORMAT);   // FormatError outranks whatever the point decoder reports
+        rp_ts_passthrough(p, init, ts_in, ts_out);
         return;
     }
     if (sh.shape_verdict) {
         status_raise(status + p, sh.shape_verdict);
+        rp_ts_passthrough(p, init, ts_in, ts_out);
         return;
     }
     rp_store(fields, B, RPF_TX, p, tx);
@@ -144,10 +168,26 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
 
     strobe t;
     t.st = st;
-    for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, init.w[i]);
-    t.pos = init.pos;
-    t.pos_begin = init.pos_begin;
-    t.cur_flags = init.cur_flags;
+    if (ts_in) {
+        const uint32_t *src = ts_in + (uint64_t)p * BP_TS_WORDS;
+        for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, src[i]);
+        const uint32_t meta = src[50];
+        t.pos = meta & 0xffu;
+        t.pos_begin = (meta >> 8) & 0xffu;
+        t.cur_flags = (meta >> 16) & 0xffu;
+    } else {
+        for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, init.w[i]);
+        t.pos = init.pos;
+        t.pos_begin = init.pos_begin;
+        t.cur_flags = init.cur_flags;
+    }
+    if (ts_flags & BP_TS_DOMSEP) {   // rangeproof_domain_sep(n, m), transcript.rs:44-48
+        const uint8_t dsep[7] = {'d', 'o', 'm', '-', 's', 'e', 'p'}, l_n[1] = {'n'}, l_m[1] = {'m'};
+        const uint8_t rpv1[13] = {'r', 'a', 'n', 'g', 'e', 'p', 'r', 'o', 'o', 'f', ' ', 'v', '1'};
+        merlin_append_message(t, dsep, 7, rpv1, 13);
+        merlin_append_u64(t, l_n, 1, sh.n);
+        merlin_append_u64(t, l_m, 1, sh.m);
+    }
 
     bool verr = false;
     const uint8_t lV[1] = {'V'}, lA[1] = {'A'}, lS[1] = {'S'}, ly[1] = {'y'}, lz[1] = {'z'}, lx[1] = {'x'}, lw[1] = {'w'},
@@ -212,6 +252,12 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
         rp_store(fields, B, fl.u + i, p, u);
     }
     if (verr) status_raise(status + p, BP_VERDICT_VERIFICATION);
+    if (ts_out) {
+        uint32_t *o = ts_out + (uint64_t)p * BP_TS_WORDS;
+        for (uint32_t i = 0; i < 50; i++) o[i] = ks_get32(st, i);
+        o[50] = rp_ts_meta(t.pos, t.pos_begin, t.cur_flags);
+        o[51] = 0;
+    }
 }
 
 // ---- stage 1b: per-proof points -----------------------------------------------------------

@@ -19,7 +19,7 @@ def gather_verdicts(local_verdicts, world):
     """all_gather of equal-shaped uint8 verdict tensors; returns a [world, ...] tensor on every rank."""
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return local_verdicts.unsqueeze(0)
     out = [torch.empty_like(local_verdicts) for _ in range(world)]
     dist.all_gather(out, local_verdicts)
@@ -29,7 +29,7 @@ def gather_verdicts(local_verdicts, world):
 def max_over_ranks(value, world, device=None):
     import torch
     import torch.distributed as dist
-    if world == 1:
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
         return float(value)
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -26,21 +26,18 @@ def load_fixture(name):
     label = blob[off:off + label_len]
     off += label_len
     rec = proof_len + 32 * m
-    proofs, coms = bytearray(), bytearray()
-    for i in range(count):
-        proofs += blob[off + rec * i:off + rec * i + proof_len]
-        coms += blob[off + rec * i + proof_len:off + rec * (i + 1)]
-    return Fixture(name, n, m, count, proof_len, label, bytes(proofs), bytes(coms))
+    import numpy as np
+    recs = np.frombuffer(blob, dtype=np.uint8, count=rec * count, offset=off).reshape(count, rec)
+    return Fixture(name, n, m, count, proof_len, label, recs[:, :proof_len].tobytes(), recs[:, proof_len:].tobytes())
 
 
 def tile_batch(fx, batch, first=0):
     """`batch` proofs starting at logical index `first`, cycling through the fixture's distinct proofs."""
-    proofs, coms = bytearray(), bytearray()
-    for i in range(batch):
-        j = (first + i) % fx.count
-        proofs += fx.proofs[j * fx.proof_len:(j + 1) * fx.proof_len]
-        coms += fx.commitments[j * 32 * fx.m:(j + 1) * 32 * fx.m]
-    return bytes(proofs), bytes(coms)
+    import numpy as np
+    idx = (first + np.arange(batch)) % fx.count
+    p = np.frombuffer(fx.proofs, dtype=np.uint8).reshape(fx.count, fx.proof_len)[idx]
+    c = np.frombuffer(fx.commitments, dtype=np.uint8).reshape(fx.count, 32 * fx.m)[idx]
+    return p.tobytes(), c.tobytes()
 
 
 def shard_range(total, world_size, rank):

@@ -24,7 +24,11 @@
  *     the context's own stream), enqueue asynchronously and return.
  *   - one context serves one device; calls on one context are serialised by an
  *     internal mutex (the reference's calls are &self and re-entrant; use one
- *     context per host thread for concurrency).
+ *     context per host thread for concurrency).  A context owns ONE set of device
+ *     scratch buffers: work enqueued on it is ordered.  If consecutive `_dev` calls
+ *     on one context name different streams, the library makes the later stream
+ *     wait (hipStreamWaitEvent) for the earlier call's kernels, so results stay
+ *     correct -- but only one context per stream gives overlap.
  *   - throughput: a batch is a chain of a few dependent launches, several of them
  *     narrow, so one stream cannot fill the device.  Keep many batches in flight:
  *     one context per HIP stream (the generator tables are shared by the contexts
@@ -72,6 +76,8 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
  *                           table (n_gens * ceil(255/W) * 2^(W-1) * 128 bytes) fits fixed_table_max_bytes
  *   "fixed_table_max_bytes" HBM budget of the tables (default 96 GiB; the MI355X has 288 GB)
  *   "fixed_splits"          workgroups the generator terms of one proof block are split over (0 = auto)
+ *   "host_sync_blocking"    1: host-pointer entry points wait for their results on a blocking event (the calling
+ *                           thread sleeps: right for many host threads, one context each); 0 (default): spin-wait
  *   "horner_lanes"          lanes per Horner chain of the proof-specific terms in the range-proof path:
  *                           4 (16 chains per wavefront: least total work, best with several batches in flight),
  *                           64 (one wavefront per chain: lowest latency of a single small batch), 0 = auto (4)
@@ -126,6 +132,21 @@ int bpgpu_msm_batch_shared_dev(bpgpu_ctx *ctx, size_t n, size_t m, size_t nbatch
                                const void *d_gen_scalars, const void *d_uniq_scalars, const void *d_uniq_points,
                                void *d_out, void *d_status, void *stream);
 
+/* ---- Merlin transcripts across the boundary ------------------------------------------
+ * The reference's verifiers take `transcript: &mut Transcript` (range_proof/mod.rs:345-353,
+ * inner_product_proof.rs:260-270): it may already hold application messages and is left advanced.
+ * A transcript crosses this ABI as its 208-byte state, which is the in-memory image of merlin's
+ * Strobe128 { state: [u8; 200] (align 8), pos: u8, pos_begin: u8, cur_flags: u8 }:
+ *   [0,200) sponge bytes, [200] pos, [201] pos_begin, [202] cur_flags, [203,208) zero.
+ * The three helpers run on the host (no GPU needed) and are Transcript::new / append_message /
+ * challenge_bytes of src/transcript.rs's dependency (merlin 2.x) on that representation. */
+#define BPGPU_TRANSCRIPT_BYTES 208
+int bpgpu_transcript_new(const uint8_t *label, size_t label_len, uint8_t state[BPGPU_TRANSCRIPT_BYTES]);
+int bpgpu_transcript_append_message(uint8_t state[BPGPU_TRANSCRIPT_BYTES], const uint8_t *label, size_t label_len,
+                                    const uint8_t *msg, size_t msg_len);
+int bpgpu_transcript_challenge_bytes(uint8_t state[BPGPU_TRANSCRIPT_BYTES], const uint8_t *label, size_t label_len,
+                                     uint8_t *out, size_t out_len);
+
 /* ---- range-proof verification ---------------------------------------------------
  * nbatch independent calls of
  *   RangeProof::from_bytes(proof)?.verify_multiple_with_rng(bp_gens, pc_gens,
@@ -146,6 +167,25 @@ int bpgpu_rangeproof_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t m, size_t
                                       const void *d_proofs, size_t proof_len, const void *d_commitments,
                                       const uint8_t *label, size_t label_len, const void *d_rng64,
                                       void *d_verdict, void *d_msm_out, void *stream);
+
+/* The same verification on caller-supplied transcripts (the full `&mut Transcript` semantics of mod.rs:345-353):
+ *   transcripts       : transcript_stride == 0: ONE state (208 bytes) every proof of the batch starts from;
+ *                       transcript_stride == BPGPU_TRANSCRIPT_BYTES: nbatch states, one per proof
+ *   transcripts_out   : optional nbatch x 208 bytes: each proof's transcript as verify_multiple_with_rng leaves it
+ *                       (after the last inner-product challenge).  A proof rejected by from_bytes or by the parameter
+ *                       checks (FormatError, InvalidBitsize, InvalidGeneratorsLength) gets its input state back, as in
+ *                       the reference; for other rejected proofs the reference stops replaying at the offending
+ *                       message, here the state is the fully replayed one.
+ * `_dev`: `shared_transcript` is a HOST pointer to one state (or NULL), `d_transcripts` a device pointer to nbatch
+ * states (or NULL); exactly one of the two must be given. */
+int bpgpu_rangeproof_verify_batch_ts(bpgpu_ctx *ctx, size_t n, size_t m, size_t nbatch,
+                                     const uint8_t *proofs, size_t proof_len, const uint8_t *commitments,
+                                     const uint8_t *transcripts, size_t transcript_stride, const uint8_t *rng64,
+                                     uint8_t *verdict, uint8_t *msm_out, uint8_t *transcripts_out);
+int bpgpu_rangeproof_verify_batch_ts_dev(bpgpu_ctx *ctx, size_t n, size_t m, size_t nbatch,
+                                         const void *d_proofs, size_t proof_len, const void *d_commitments,
+                                         const uint8_t *shared_transcript, const void *d_transcripts, const void *d_rng64,
+                                         void *d_verdict, void *d_msm_out, void *d_transcripts_out, void *stream);
 
 /* ---- batch-combined verification (ADDITIONAL entry point; not a call of the reference) ---------------
  * The reference verifies one proof per MSM (verify_multiple checks ONE aggregated proof: mod.rs:345-452).
@@ -184,6 +224,16 @@ int bpgpu_ipp_verify_batch(bpgpu_ctx *ctx, size_t n, size_t nbatch, const uint8_
                            const uint8_t *label, size_t label_len, const uint8_t *G_factors, const uint8_t *H_factors,
                            const uint8_t *P, const uint8_t *Q, const uint8_t *G, const uint8_t *H,
                            uint8_t *verdict, uint8_t *msm_out);
+
+/* Device-pointer variant.  bases_shared != 0: every proof of the batch uses the SAME generator vectors, as the
+ * reference's callers do (G = bp_gens.G(n, m), H = bp_gens.H(n, m)): d_G and d_H then hold n x 32 bytes instead of
+ * nbatch x n x 32.  transcript: shared_transcript (host, 208 bytes, may hold earlier messages) if not NULL, else
+ * Transcript::new(label). */
+int bpgpu_ipp_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t nbatch, const void *d_proofs, size_t proof_len,
+                               const uint8_t *label, size_t label_len, const uint8_t *shared_transcript,
+                               const void *d_G_factors, const void *d_H_factors, const void *d_P, const void *d_Q,
+                               const void *d_G, const void *d_H, int bases_shared,
+                               void *d_verdict, void *d_msm_out, void *stream);
 
 /* ---- instrumentation -----------------------------------------------------------
  * When enabled, every kernel launch is bracketed by HIP events on its stream;

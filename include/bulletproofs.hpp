@@ -5,7 +5,8 @@
 //   ProofError ............ src/errors.rs:12-54
 //   PedersenGens .......... src/generators.rs:30-53        (default() = basepoint + hashed blinding base)
 //   BulletproofGens ....... src/generators.rs:157-204      (new(gens_capacity, party_capacity))
-//   Transcript ............ merlin::Transcript::new(label)  (the engine replays it from the label)
+//   Transcript ............ merlin::Transcript: new / append_message / append_u64 / challenge_bytes, held as its
+//                           208-byte STROBE state; verifiers take it by reference and leave it advanced
 //   RangeProof ............ src/range_proof/mod.rs:59-76, from_bytes 504-538, to_bytes 487-500,
 //                           verify_single[_with_rng] 316-342, verify_multiple[_with_rng] 345-470
 // plus verify_batch, the batched entry point this engine exists for.  No arithmetic happens on the
@@ -58,6 +59,7 @@ class GpuError : public std::runtime_error {
 class PedersenGens {
   public:
     CompressedRistretto B{}, B_blinding{};
+    bool operator==(const PedersenGens &o) const { return B == o.B && B_blinding == o.B_blinding; }
 };
 
 class BulletproofGens {
@@ -78,20 +80,53 @@ class BulletproofGens {
         if (bpgpu_gens_export(ctx_.get(), nullptr, nullptr, pc.B.data(), pc.B_blinding.data()) != BPGPU_OK) throw GpuError(bpgpu_last_error(ctx_.get()));
         return pc;
     }
+    // The verifier multiplies by pc_gens.B / B_blinding (mod.rs:439-440); the device tables hold the bases of this
+    // BulletproofGens.  Any other PedersenGens would silently verify a different statement: refuse it.
+    void check_pedersen(const PedersenGens &pc) const {
+        if (!(pc == pedersen())) throw std::invalid_argument("pc_gens differs from the Pedersen bases in the device tables (load custom bases with bpgpu_gens_load)");
+    }
 
   private:
     std::shared_ptr<bpgpu_ctx> ctx_;
 };
 
-// merlin::Transcript as far as this path needs it: a fresh transcript named by its label
+// merlin::Transcript, held as its 208-byte STROBE-128 state (bpgpu.h BPGPU_TRANSCRIPT_BYTES).  It may absorb
+// application messages before it is handed to a verifier, and a verifier leaves it advanced, as
+// verify_multiple_with_rng(&mut transcript, ...) does (mod.rs:345-353).
 class Transcript {
   public:
-    explicit Transcript(const std::string &label) : label_(label.begin(), label.end()) {}
-    Transcript(const uint8_t *label, size_t n) : label_(label, label + n) {}
-    const std::vector<uint8_t> &label() const { return label_; }
+    explicit Transcript(const std::string &label) : Transcript(reinterpret_cast<const uint8_t *>(label.data()), label.size()) {}
+    Transcript(const uint8_t *label, size_t n) : fresh_label_(label, label + n), fresh_(true) {
+        if (bpgpu_transcript_new(label, n, state_.data()) != BPGPU_OK) throw std::invalid_argument("bpgpu_transcript_new");
+    }
+    void append_message(const std::string &label, const uint8_t *msg, size_t n) {
+        if (bpgpu_transcript_append_message(state_.data(), reinterpret_cast<const uint8_t *>(label.data()), label.size(), msg, n) != BPGPU_OK)
+            throw std::invalid_argument("bpgpu_transcript_append_message");
+        fresh_ = false;
+    }
+    void append_u64(const std::string &label, uint64_t x) {
+        uint8_t b[8];
+        for (int i = 0; i < 8; i++) b[i] = static_cast<uint8_t>(x >> (8 * i));
+        append_message(label, b, 8);
+    }
+    void challenge_bytes(const std::string &label, uint8_t *out, size_t n) {
+        if (bpgpu_transcript_challenge_bytes(state_.data(), reinterpret_cast<const uint8_t *>(label.data()), label.size(), out, n) != BPGPU_OK)
+            throw std::invalid_argument("bpgpu_transcript_challenge_bytes");
+        fresh_ = false;
+    }
+    const std::array<uint8_t, BPGPU_TRANSCRIPT_BYTES> &state() const { return state_; }
+    std::array<uint8_t, BPGPU_TRANSCRIPT_BYTES> &state_mut() {
+        fresh_ = false;
+        return state_;
+    }
+    // the label while the transcript is still exactly Transcript::new(label) (what the batch-combined entry point needs)
+    bool is_fresh() const { return fresh_; }
+    const std::vector<uint8_t> &label() const { return fresh_label_; }
 
   private:
-    std::vector<uint8_t> label_;
+    std::array<uint8_t, BPGPU_TRANSCRIPT_BYTES> state_{};
+    std::vector<uint8_t> fresh_label_;
+    bool fresh_;
 };
 
 namespace detail {
@@ -126,38 +161,59 @@ class RangeProof {
     const std::vector<uint8_t> &to_bytes() const { return bytes_; }
 
     // verify_multiple_with_rng: rng64 = the 64 bytes the rng would hand Scalar::random (mod.rs:396)
-    Status verify_multiple_with_rng(const BulletproofGens &bp_gens, const PedersenGens &, const Transcript &transcript,
+    // (`transcript` is `&mut Transcript`: it may hold earlier messages and is left advanced)
+    Status verify_multiple_with_rng(const BulletproofGens &bp_gens, const PedersenGens &pc_gens, Transcript &transcript,
                                     const std::vector<CompressedRistretto> &value_commitments, size_t n, const uint8_t *rng64) const {
+        bp_gens.check_pedersen(pc_gens);
         uint8_t verdict = 0;
-        const int rc = bpgpu_rangeproof_verify_batch(bp_gens.ctx(), n, value_commitments.size(), 1, bytes_.data(), bytes_.size(),
-                                                     value_commitments.empty() ? nullptr : value_commitments[0].data(), transcript.label().data(),
-                                                     transcript.label().size(), rng64, &verdict, nullptr);
+        std::array<uint8_t, BPGPU_TRANSCRIPT_BYTES> in = transcript.state();
+        const int rc = bpgpu_rangeproof_verify_batch_ts(bp_gens.ctx(), n, value_commitments.size(), 1, bytes_.data(), bytes_.size(),
+                                                        value_commitments.empty() ? nullptr : value_commitments[0].data(), in.data(),
+                                                        BPGPU_TRANSCRIPT_BYTES, rng64, &verdict, nullptr, transcript.state_mut().data());
         if (rc != BPGPU_OK) throw GpuError(bpgpu_last_error(bp_gens.ctx()));
         return verdict == 0 ? Status::Ok() : Status::Err(static_cast<ProofError>(verdict));
     }
+    Status verify_multiple_with_rng(const BulletproofGens &bp_gens, const PedersenGens &pc_gens, Transcript &&transcript,
+                                    const std::vector<CompressedRistretto> &value_commitments, size_t n, const uint8_t *rng64) const {
+        return verify_multiple_with_rng(bp_gens, pc_gens, transcript, value_commitments, n, rng64);
+    }
     // verify_multiple: thread_rng() -> the library draws from the OS CSPRNG
-    Status verify_multiple(const BulletproofGens &bp_gens, const PedersenGens &pc_gens, const Transcript &transcript,
+    Status verify_multiple(const BulletproofGens &bp_gens, const PedersenGens &pc_gens, Transcript &transcript,
                            const std::vector<CompressedRistretto> &value_commitments, size_t n) const {
         return verify_multiple_with_rng(bp_gens, pc_gens, transcript, value_commitments, n, nullptr);
     }
-    Status verify_single_with_rng(const BulletproofGens &bp_gens, const PedersenGens &pc_gens, const Transcript &transcript,
+    Status verify_multiple(const BulletproofGens &bp_gens, const PedersenGens &pc_gens, Transcript &&transcript,
+                           const std::vector<CompressedRistretto> &value_commitments, size_t n) const {
+        return verify_multiple_with_rng(bp_gens, pc_gens, transcript, value_commitments, n, nullptr);
+    }
+    Status verify_single_with_rng(const BulletproofGens &bp_gens, const PedersenGens &pc_gens, Transcript &transcript,
                                   const CompressedRistretto &V, size_t n, const uint8_t *rng64) const {
         return verify_multiple_with_rng(bp_gens, pc_gens, transcript, {V}, n, rng64);
     }
-    Status verify_single(const BulletproofGens &bp_gens, const PedersenGens &pc_gens, const Transcript &transcript,
+    Status verify_single_with_rng(const BulletproofGens &bp_gens, const PedersenGens &pc_gens, Transcript &&transcript,
+                                  const CompressedRistretto &V, size_t n, const uint8_t *rng64) const {
+        return verify_multiple_with_rng(bp_gens, pc_gens, transcript, {V}, n, rng64);
+    }
+    Status verify_single(const BulletproofGens &bp_gens, const PedersenGens &pc_gens, Transcript &transcript,
+                         const CompressedRistretto &V, size_t n) const {
+        return verify_multiple_with_rng(bp_gens, pc_gens, transcript, {V}, n, nullptr);
+    }
+    Status verify_single(const BulletproofGens &bp_gens, const PedersenGens &pc_gens, Transcript &&transcript,
                          const CompressedRistretto &V, size_t n) const {
         return verify_multiple_with_rng(bp_gens, pc_gens, transcript, {V}, n, nullptr);
     }
 
-    // Batched form: proofs[i].verify_multiple(bp_gens, pc_gens, &mut Transcript::new(label), &commitments[i], n)
-    // for all i in one GPU pass.  All proofs must share the aggregation size m and the byte length.
-    static std::vector<Status> verify_batch(const BulletproofGens &bp_gens, const PedersenGens &, const Transcript &transcript,
+    // Batched form: proofs[i].verify_multiple(bp_gens, pc_gens, &mut transcript.clone(), &commitments[i], n)
+    // for all i in one GPU pass (`transcript` itself is not advanced).  All proofs must share the aggregation size m
+    // and the byte length.
+    static std::vector<Status> verify_batch(const BulletproofGens &bp_gens, const PedersenGens &pc_gens, const Transcript &transcript,
                                             const std::vector<std::vector<uint8_t>> &proofs,
                                             const std::vector<std::vector<CompressedRistretto>> &commitments, size_t n,
                                             const uint8_t *rng64 = nullptr) {
         const size_t nb = proofs.size();
         std::vector<Status> out;
         if (nb == 0) return out;
+        bp_gens.check_pedersen(pc_gens);
         const size_t m = commitments.at(0).size(), len = proofs[0].size();
         std::vector<uint8_t> flat(nb * len), vs(nb * m * 32), verdict(nb);
         for (size_t i = 0; i < nb; i++) {
@@ -165,8 +221,8 @@ class RangeProof {
             std::memcpy(&flat[i * len], proofs[i].data(), len);
             for (size_t j = 0; j < m; j++) std::memcpy(&vs[(i * m + j) * 32], commitments[i][j].data(), 32);
         }
-        const int rc = bpgpu_rangeproof_verify_batch(bp_gens.ctx(), n, m, nb, flat.data(), len, vs.data(), transcript.label().data(),
-                                                     transcript.label().size(), rng64, verdict.data(), nullptr);
+        const int rc = bpgpu_rangeproof_verify_batch_ts(bp_gens.ctx(), n, m, nb, flat.data(), len, vs.data(), transcript.state().data(), 0, rng64,
+                                                        verdict.data(), nullptr, nullptr);
         if (rc != BPGPU_OK) throw GpuError(bpgpu_last_error(bp_gens.ctx()));
         for (size_t i = 0; i < nb; i++) out.push_back(verdict[i] == 0 ? Status::Ok() : Status::Err(static_cast<ProofError>(verdict[i])));
         return out;
@@ -175,13 +231,16 @@ class RangeProof {
     // Same verdicts through the batch-combined check (bpgpu_rangeproof_verify_rlc, no counterpart in the crate): one
     // identity test for the whole batch when every proof verifies, per-proof re-verification inside the call when
     // not.  weights64 = nullptr draws the combination weights from the OS CSPRNG.
-    static std::vector<Status> verify_batch_combined(const BulletproofGens &bp_gens, const PedersenGens &, const Transcript &transcript,
+    // This entry point replays every proof's transcript from its label: `transcript` must be a fresh Transcript(label).
+    static std::vector<Status> verify_batch_combined(const BulletproofGens &bp_gens, const PedersenGens &pc_gens, const Transcript &transcript,
                                                      const std::vector<std::vector<uint8_t>> &proofs,
                                                      const std::vector<std::vector<CompressedRistretto>> &commitments, size_t n,
                                                      const uint8_t *rng64 = nullptr, const uint8_t *weights64 = nullptr) {
         const size_t nb = proofs.size();
         std::vector<Status> out;
         if (nb == 0) return out;
+        bp_gens.check_pedersen(pc_gens);
+        if (!transcript.is_fresh()) throw std::invalid_argument("verify_batch_combined needs a fresh Transcript(label); use verify_batch for pre-bound transcripts");
         const size_t m = commitments.at(0).size(), len = proofs[0].size();
         std::vector<uint8_t> flat(nb * len), vs(nb * m * 32), verdict(nb);
         for (size_t i = 0; i < nb; i++) {

@@ -62,6 +62,16 @@ int oracle_verify(const oracle_gens *g, const uint8_t *proof, size_t proof_len,
                   const uint8_t *commitments, size_t m, size_t n,
                   const uint8_t *label, size_t label_len, const uint8_t rng64[64],
                   uint8_t msm_out[32]);
+/* The same call with the caller's transcript (mod.rs:345-353 takes `transcript: &mut Transcript`, which may already
+ * hold application messages and is left advanced).  state: 208 bytes = Strobe128 { state[200], pos, pos_begin,
+ * cur_flags } + 5 zero bytes, read and written back.  oracle_transcript_* = Transcript::new / append_message /
+ * challenge_bytes on that representation. */
+int oracle_verify_ts(const oracle_gens *g, const uint8_t *proof, size_t proof_len,
+                     const uint8_t *commitments, size_t m, size_t n,
+                     uint8_t state[208], const uint8_t rng64[64], uint8_t msm_out[32]);
+void oracle_transcript_new(const uint8_t *label, size_t label_len, uint8_t state[208]);
+void oracle_transcript_append_message(uint8_t state[208], const char *label, const uint8_t *msg, size_t n);
+void oracle_transcript_challenge_bytes(uint8_t state[208], const char *label, uint8_t *out, size_t n);
 /* same transcript replay + scalar assembly, but returns the MSM terms instead:
  * scalars_out / points_out: N x 32 bytes, N = 2nm + 2lg(nm) + m + 6, order of mod.rs:422-443 */
 int oracle_verify_terms(const oracle_gens *g, const uint8_t *proof, size_t proof_len,
@@ -76,6 +86,9 @@ int oracle_verify_terms(const oracle_gens *g, const uint8_t *proof, size_t proof
 int oracle_prove(const oracle_gens *g, const uint64_t *values, const uint8_t *blindings, size_t m, size_t n,
                  const uint8_t *label, size_t label_len, const uint8_t *seed, size_t seed_len,
                  uint8_t *proof_out, uint8_t *commitments_out);
+
+int oracle_prove_ts(const oracle_gens *g, const uint64_t *values, const uint8_t *blindings, size_t m, size_t n,
+                    uint8_t state[208], const uint8_t *seed, size_t seed_len, uint8_t *proof_out, uint8_t *commitments_out);
 
 /* Stand-alone inner-product proof (src/inner_product_proof.rs).
  * oracle_ipp_verify = InnerProductProof::from_bytes(proof)?.verify(n, &mut Transcript::new(label), G_factors,

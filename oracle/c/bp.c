@@ -193,10 +193,22 @@ static void delta(sc *r, size_t n, size_t m, const sc *y, const sc *z) {
 
 /* Transcript replay + scalar assembly.  On success fills scalars[N] and
  * pts[N] (32-byte encodings, reference order) and *n_terms. */
+static int verify_terms_core_t(const oracle_gens *g, const uint8_t *proof, size_t proof_len,
+                               const uint8_t *commitments, size_t m, size_t n,
+                               merlin_transcript *tp, const uint8_t rng64[64],
+                               sc **scalars_out, uint8_t **pts_out, size_t *n_terms);
 static int verify_terms_core(const oracle_gens *g, const uint8_t *proof, size_t proof_len,
                              const uint8_t *commitments, size_t m, size_t n,
                              const uint8_t *label, size_t label_len, const uint8_t rng64[64],
                              sc **scalars_out, uint8_t **pts_out, size_t *n_terms) {
+    merlin_transcript t; merlin_init(&t, label, label_len);   /* &mut Transcript::new(label) */
+    return verify_terms_core_t(g, proof, proof_len, commitments, m, n, &t, rng64, scalars_out, pts_out, n_terms);
+}
+/* the caller's transcript may already hold messages; it is left advanced (mod.rs:345-353: transcript: &mut Transcript) */
+static int verify_terms_core_t(const oracle_gens *g, const uint8_t *proof, size_t proof_len,
+                               const uint8_t *commitments, size_t m, size_t n,
+                               merlin_transcript *tp, const uint8_t rng64[64],
+                               sc **scalars_out, uint8_t **pts_out, size_t *n_terms) {
     parsed_proof pp;
     int rc = parse_proof(&pp, proof, proof_len);
     if (rc) return rc;
@@ -204,7 +216,7 @@ static int verify_terms_core(const oracle_gens *g, const uint8_t *proof, size_t 
     if (g->gens_capacity < n) return ORACLE_ERR_INVALID_GENERATORS_LENGTH;
     if (g->party_capacity < m) return ORACLE_ERR_INVALID_GENERATORS_LENGTH;
 
-    merlin_transcript t; merlin_init(&t, label, label_len);
+#define t (*tp)
     merlin_append_message(&t, "dom-sep", (const uint8_t *)"rangeproof v1", 13);
     merlin_append_u64(&t, "n", n); merlin_append_u64(&t, "m", m);
     for (size_t j = 0; j < m; j++) merlin_append_message(&t, "V", commitments + 32 * j, 32);
@@ -297,6 +309,7 @@ static int verify_terms_core(const oracle_gens *g, const uint8_t *proof, size_t 
     free(s);
     *scalars_out = sc_out; *pts_out = pt_out; *n_terms = N;
     return 0;
+#undef t
 }
 
 int oracle_verify_terms(const oracle_gens *g, const uint8_t *proof, size_t proof_len,
@@ -313,12 +326,41 @@ int oracle_verify_terms(const oracle_gens *g, const uint8_t *proof, size_t proof
     return 0;
 }
 
+static int verify_tail(const oracle_gens *g, sc *s, uint8_t *p, size_t N, size_t m, size_t n, uint8_t msm_out[32]);
 int oracle_verify(const oracle_gens *g, const uint8_t *proof, size_t proof_len,
                   const uint8_t *commitments, size_t m, size_t n,
                   const uint8_t *label, size_t label_len, const uint8_t rng64[64], uint8_t msm_out[32]) {
     sc *s; uint8_t *p; size_t N;
     int rc = verify_terms_core(g, proof, proof_len, commitments, m, n, label, label_len, rng64, &s, &p, &N);
     if (rc) return rc;
+    return verify_tail(g, s, p, N, m, n, msm_out);
+}
+/* ---- transcripts across the boundary: 208-byte state = st[200] | pos | pos_begin | cur_flags | 5 zero bytes
+ * (the in-memory layout of merlin's Strobe128; include/bpgpu.h BPGPU_TRANSCRIPT_BYTES) ---- */
+static void ts_load(merlin_transcript *t, const uint8_t s[208]) { memcpy(t->st, s, 200); t->pos = s[200]; t->pos_begin = s[201]; t->cur_flags = s[202]; }
+static void ts_store(uint8_t s[208], const merlin_transcript *t) { memset(s, 0, 208); memcpy(s, t->st, 200); s[200] = t->pos; s[201] = t->pos_begin; s[202] = t->cur_flags; }
+void oracle_transcript_new(const uint8_t *label, size_t label_len, uint8_t state[208]) {
+    merlin_transcript t; merlin_init(&t, label, label_len); ts_store(state, &t);
+}
+void oracle_transcript_append_message(uint8_t state[208], const char *label, const uint8_t *msg, size_t n) {
+    merlin_transcript t; ts_load(&t, state); merlin_append_message(&t, label, msg, n); ts_store(state, &t);
+}
+void oracle_transcript_challenge_bytes(uint8_t state[208], const char *label, uint8_t *out, size_t n) {
+    merlin_transcript t; ts_load(&t, state); merlin_challenge_bytes(&t, label, out, n); ts_store(state, &t);
+}
+/* verify_multiple_with_rng(bp_gens, pc_gens, transcript, ...) with the caller's transcript: state in, advanced state out */
+int oracle_verify_ts(const oracle_gens *g, const uint8_t *proof, size_t proof_len,
+                     const uint8_t *commitments, size_t m, size_t n,
+                     uint8_t state[208], const uint8_t rng64[64], uint8_t msm_out[32]) {
+    sc *s; uint8_t *p; size_t N;
+    merlin_transcript t; ts_load(&t, state);
+    int rc = verify_terms_core_t(g, proof, proof_len, commitments, m, n, &t, rng64, &s, &p, &N);
+    ts_store(state, &t);
+    if (rc) return rc;
+    return verify_tail(g, s, p, N, m, n, msm_out);
+}
+static int verify_tail(const oracle_gens *g, sc *s, uint8_t *p, size_t N, size_t m, size_t n, uint8_t msm_out[32]) {
+    int rc;
     size_t lg_n = 0; while (((size_t)1 << lg_n) < n * m) lg_n++;
     ge_p3 *pts = malloc(N * sizeof(ge_p3));
     int bad = 0;
@@ -399,15 +441,30 @@ static void ipp_create(merlin_transcript *t, const ge_p3 *Q, const sc *Hf /* y^-
     free(sv); free(pv);
 }
 
+static int prove_core(const oracle_gens *g, const uint64_t *values, const uint8_t *blindings, size_t m, size_t n,
+                      merlin_transcript *tp, const uint8_t *seed, size_t seed_len, uint8_t *proof_out, uint8_t *commitments_out);
 int oracle_prove(const oracle_gens *g, const uint64_t *values, const uint8_t *blindings, size_t m, size_t n,
                  const uint8_t *label, size_t label_len, const uint8_t *seed, size_t seed_len,
                  uint8_t *proof_out, uint8_t *commitments_out) {
+    merlin_transcript t; merlin_init(&t, label, label_len);
+    return prove_core(g, values, blindings, m, n, &t, seed, seed_len, proof_out, commitments_out);
+}
+/* prove_multiple_with_rng on the caller's transcript (208-byte state, read and written back) */
+int oracle_prove_ts(const oracle_gens *g, const uint64_t *values, const uint8_t *blindings, size_t m, size_t n,
+                    uint8_t state[208], const uint8_t *seed, size_t seed_len, uint8_t *proof_out, uint8_t *commitments_out) {
+    merlin_transcript t; ts_load(&t, state);
+    int rc = prove_core(g, values, blindings, m, n, &t, seed, seed_len, proof_out, commitments_out);
+    ts_store(state, &t);
+    return rc;
+}
+static int prove_core(const oracle_gens *g, const uint64_t *values, const uint8_t *blindings, size_t m, size_t n,
+                      merlin_transcript *tp, const uint8_t *seed, size_t seed_len, uint8_t *proof_out, uint8_t *commitments_out) {
     if (!(n == 8 || n == 16 || n == 32 || n == 64)) return ORACLE_ERR_INVALID_BITSIZE;
     if (m == 0 || (m & (m - 1))) return 5; /* InvalidAggregation */
     if (g->gens_capacity < n || g->party_capacity < m) return ORACLE_ERR_INVALID_GENERATORS_LENGTH;
     size_t nm = n * m;
     keccak_sponge rng; shake256_init(&rng); sponge_absorb(&rng, seed, seed_len);
-    merlin_transcript t; merlin_init(&t, label, label_len);
+#define t (*tp)
     merlin_append_message(&t, "dom-sep", (const uint8_t *)"rangeproof v1", 13);
     merlin_append_u64(&t, "n", n); merlin_append_u64(&t, "m", m);
 
@@ -504,6 +561,7 @@ int oracle_prove(const oracle_gens *g, const uint64_t *values, const uint8_t *bl
     free(l0); free(l1); free(r0); free(r1); free(t0v); free(t1v); free(t2v); free(t1b); free(t2b); free(ozz);
     free(lv); free(rv); free(Hf); free(Gv); free(Hv);
     return 0;
+#undef t
 }
 
 /* ---------------- stand-alone inner-product proof (ipp.rs:260-326, 373-407, 433-497) ---------------- */

@@ -23,6 +23,24 @@ def build(force=False):
     return _SO
 
 
+def build_native():
+    """bench.py's cpu_baseline leg: rebuild the oracle with -march=native on the box it is timed on (the committed
+    Makefile targets x86-64-v3 so that the checker built in the authoring container runs anywhere).  Must be called
+    before the library is first loaded; returns True when the native build is the one in use."""
+    global _SO
+    if _lib is not None:
+        return _SO.endswith("liboracle_native.so")
+    so = os.path.join(_HERE, "liboracle_native.so")
+    try:
+        srcs = [os.path.join(_HERE, "c", f) for f in ("ge.c", "merlin.c", "bp.c")]
+        subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=gnu11", "-w", "-shared", "-o", so] + srcs + ["-lpthread"],
+                              stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _SO = so
+        return True
+    except Exception:
+        return False
+
+
 _lib = None
 
 
@@ -49,8 +67,13 @@ def lib():
     L.oracle_msm.argtypes = [sz, u8p, u8p, C.c_int, u8p]
     L.oracle_last_msm_ops.restype = C.c_uint64
     L.oracle_verify.argtypes = [vp, u8p, sz, u8p, sz, sz, u8p, sz, u8p, u8p]
+    L.oracle_verify_ts.argtypes = [vp, u8p, sz, u8p, sz, sz, u8p, u8p, u8p]
+    L.oracle_transcript_new.argtypes = [u8p, sz, u8p]
+    L.oracle_transcript_append_message.argtypes = [u8p, u8p, u8p, sz]
+    L.oracle_transcript_challenge_bytes.argtypes = [u8p, u8p, u8p, sz]
     L.oracle_verify_terms.argtypes = [vp, u8p, sz, u8p, sz, sz, u8p, sz, u8p, u8p, u8p, C.POINTER(sz)]
     L.oracle_prove.argtypes = [vp, C.POINTER(C.c_uint64), u8p, sz, sz, u8p, sz, u8p, sz, u8p, u8p]
+    L.oracle_prove_ts.argtypes = [vp, C.POINTER(C.c_uint64), u8p, sz, sz, u8p, u8p, sz, u8p, u8p]
     L.oracle_verify_batch.restype = C.c_double
     L.oracle_verify_batch.argtypes = [vp, sz, u8p, sz, u8p, sz, sz, u8p, sz, u8p, u8p, u8p, C.c_int]
     L.oracle_prove_batch.restype = C.c_double
@@ -110,6 +133,34 @@ def verify(gens, proof, commitments, n, label, rng64):
     return rc, out.raw
 
 
+def transcript_new(label):
+    st = C.create_string_buffer(208)
+    lib().oracle_transcript_new(label, len(label), st)
+    return st.raw
+
+
+def transcript_append_message(state, label, msg):
+    st = C.create_string_buffer(state, 208)
+    lib().oracle_transcript_append_message(st, label, msg, len(msg))
+    return st.raw
+
+
+def transcript_challenge_bytes(state, label, n):
+    st = C.create_string_buffer(state, 208)
+    out = C.create_string_buffer(n)
+    lib().oracle_transcript_challenge_bytes(st, label, out, n)
+    return st.raw, out.raw
+
+
+def verify_ts(gens, proof, commitments, n, state, rng64):
+    """verify_multiple_with_rng with the caller's transcript state (208 bytes); returns (rc, msm encoding, advanced state)."""
+    m = len(commitments) // 32
+    out = C.create_string_buffer(32)
+    st = C.create_string_buffer(state, 208)
+    rc = lib().oracle_verify_ts(gens.h, proof, len(proof), commitments, m, n, st, rng64, out)
+    return rc, out.raw, st.raw
+
+
 def verify_terms(gens, proof, commitments, n, label, rng64):
     m = len(commitments) // 32
     N = n_terms(n, m) if n * m > 0 else 0
@@ -132,6 +183,19 @@ def prove(gens, values, blindings, n, label, seed):
     if rc:
         raise ValueError("oracle_prove failed: %s" % ERR_NAMES.get(rc, rc))
     return proof.raw, com.raw
+
+
+def prove_ts(gens, values, blindings, n, state, seed):
+    """prove_multiple_with_rng on a caller-supplied transcript state; returns (proof, commitments, advanced state)."""
+    m = len(values)
+    vals = (C.c_uint64 * m)(*values)
+    proof = C.create_string_buffer(proof_len(n, m))
+    com = C.create_string_buffer(32 * m)
+    st = C.create_string_buffer(state, 208)
+    rc = lib().oracle_prove_ts(gens.h, vals, blindings, m, n, st, seed, len(seed), proof, com)
+    if rc:
+        raise ValueError("oracle_prove_ts failed: %s" % ERR_NAMES.get(rc, rc))
+    return proof.raw, com.raw, st.raw
 
 
 def prove_batch(gens, values, blindings, m, n, label, seed, threads=1):

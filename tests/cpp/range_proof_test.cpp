@@ -46,8 +46,15 @@ int main() {
             // and the negative directions the reference only covers indirectly
             Transcript other("other label");
             CHECK(proof.verify_multiple(bp_gens, pc_gens, other, vs, n) == Status::Err(ProofError::VerificationError));
-            CHECK(proof.verify_multiple(bp_gens, pc_gens, transcript, vs, 12) == Status::Err(ProofError::InvalidBitsize));
-            if (m == 1) CHECK(proof.verify_single(bp_gens, pc_gens, transcript, vc[0], n) == Status::Ok());
+            CHECK(proof.verify_multiple(bp_gens, pc_gens, Transcript(GOLDEN_LABEL), vs, 12) == Status::Err(ProofError::InvalidBitsize));
+            if (m == 1) CHECK(proof.verify_single(bp_gens, pc_gens, Transcript(GOLDEN_LABEL), vc[0], n) == Status::Ok());
+            // `transcript` is &mut: the first call left it advanced, so it no longer matches a second verification
+            CHECK(!transcript.is_fresh());
+            CHECK(proof.verify_multiple(bp_gens, pc_gens, transcript, vs, n) == Status::Err(ProofError::VerificationError));
+            // a transcript that absorbed an application message first is a different statement
+            Transcript bound(GOLDEN_LABEL);
+            bound.append_message("app", reinterpret_cast<const uint8_t *>("ctx"), 3);
+            CHECK(proof.verify_multiple(bp_gens, pc_gens, bound, vs, n) == Status::Err(ProofError::VerificationError));
         }
     }
     // from_bytes error behaviour (mod.rs:505-524)
@@ -61,6 +68,18 @@ int main() {
     BulletproofGens small(8, 1);
     auto p16 = std::get<RangeProof>(RangeProof::from_bytes(hex_decode(GOLDEN_PROOFS[1][0])));
     CHECK(p16.verify_single(small, small.pedersen(), Transcript(GOLDEN_LABEL), vc[0], 16) == Status::Err(ProofError::InvalidGeneratorsLength));
+    // a PedersenGens other than the one in the device tables is refused, not silently ignored
+    {
+        PedersenGens other_pc = pc_gens;
+        other_pc.B = vc[0];
+        bool threw = false;
+        try {
+            (void)p16.verify_single(bp_gens, other_pc, Transcript(GOLDEN_LABEL), vc[0], 16);
+        } catch (const std::invalid_argument &) {
+            threw = true;
+        }
+        CHECK(threw);
+    }
     // batched form
     std::vector<std::vector<uint8_t>> proofs(5, hex_decode(GOLDEN_PROOFS[3][0]));
     proofs[2][130] ^= 1;

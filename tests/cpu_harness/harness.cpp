@@ -412,7 +412,7 @@ int h_ipp_verify(uint32_t n, uint32_t nbatch, const uint8_t *proofs, uint32_t pr
                  uint8_t *verdict_out, uint8_t *msm_out) {
     if (proof_len % 32 || proof_len / 32 < 2 || (proof_len / 32 - 2) % 2) return -1;
     uint32_t k = (proof_len / 32 - 2) / 2;
-    ipp_shape sh; sh.n = n; sh.k = k; sh.proof_len = proof_len; sh.nproofs = nbatch;
+    ipp_shape sh; sh.bases_shared = 0; sh.n = n; sh.k = k; sh.proof_len = proof_len; sh.nproofs = nbatch;
     sh.shape_verdict = (n == (1u << k)) ? 0 : BP_VERDICT_VERIFICATION;
     if (sh.shape_verdict) sh.n = 0;
     sh.N = 2 * sh.n + 2 * (sh.shape_verdict ? 0 : k) + 2;

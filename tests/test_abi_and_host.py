@@ -57,9 +57,11 @@ def test_workload_fixtures_and_figures():
     sys.path.insert(0, ROOT)
     from bulletproofs_amd import workload as wl
     fx = wl.load_fixture("cfg2_n64_m1")
-    assert (fx.n, fx.m, fx.count, fx.proof_len) == (64, 1, 1024, 672) and fx.label == b"AggregateRangeProofBenchmark"
-    p, c = wl.tile_batch(fx, 1030, first=1020)
+    assert (fx.n, fx.m, fx.count, fx.proof_len) == (64, 1, 8192, 672) and fx.label == b"AggregateRangeProofBenchmark"
+    p, c = wl.tile_batch(fx, 1030, first=8188)
     assert len(p) == 1030 * 672 and p[4 * 672:5 * 672] == fx.proofs[:672] and len(c) == 1030 * 32
+    assert len(set(fx.proofs[i * 672:(i + 1) * 672] for i in range(fx.count))) == fx.count   # all distinct
+    assert wl.load_fixture("cfg3_n64_m16").count >= 256 and wl.load_fixture("cfg4_n64_m32").count >= 512
     # SURVEY.md Appendix B / section 8d figures
     assert [wl.msm_terms(*s) for s in ((32, 1), (64, 1), (64, 16), (64, 32))] == [81, 147, 2090, 4156]
     assert [wl.reference_point_ops(N) for N in (147, 2090, 4156, 6179)] == [7704, 77608, 145786, 212545]
@@ -80,3 +82,30 @@ def test_fixture_proofs_verify_with_oracle(oracle):
         _, v, _ = oracle.verify_batch(g, fx.proofs[:cnt * fx.proof_len], fx.commitments[:cnt * 32 * fx.m], fx.m, fx.n, fx.label,
                                       bytes(range(64)) * cnt, threads=2)
         assert v == bytes(cnt)
+
+
+def test_transcript_helpers_match_merlin_kat_and_oracle(oracle):
+    """bpgpu_transcript_new / append_message / challenge_bytes run on the host (no GPU): the Merlin known-answer vector of
+    SURVEY.md Appendix A, and state-for-state agreement with the oracle's Merlin across rate-boundary crossings."""
+    sys.path.insert(0, ROOT)
+    from bulletproofs_amd._lib import transcript_new, transcript_append_message, transcript_challenge_bytes, TRANSCRIPT_BYTES
+    s = transcript_new(b"test protocol")
+    assert len(s) == TRANSCRIPT_BYTES == 208 and s[203:] == bytes(5)
+    s = transcript_append_message(s, b"some label", b"some data")
+    s, ch = transcript_challenge_bytes(s, b"challenge", 32)
+    assert ch.hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
+    a, b = transcript_new(b""), oracle.transcript_new(b"")
+    assert a == b
+    for i, n in enumerate((0, 1, 31, 165, 166, 167, 500)):
+        msg = bytes((7 * i + j) & 0xff for j in range(n))
+        a, b = transcript_append_message(a, b"lbl%d" % i, msg), oracle.transcript_append_message(b, b"lbl%d" % i, msg)
+        assert a == b
+        (a, ca), (b, cb) = transcript_challenge_bytes(a, b"ch", 64 + n), oracle.transcript_challenge_bytes(b, b"ch", 64 + n)
+        assert a == b and ca == cb
+    # malformed states are refused, not executed
+    import pytest as _pt
+    from bulletproofs_amd import BpgpuError
+    bad = bytearray(a)
+    bad[200] = 200
+    with _pt.raises(BpgpuError):
+        transcript_append_message(bytes(bad), b"x", b"y")

@@ -47,3 +47,47 @@ def test_make_ipp_verify(ctx, oracle, n):
     assert list(v) == [1]
     v = ctx.ipp_verify_batch(n, insts[0]["proof"][:-1], pl - 1, b"x", insts[0]["Gf"], insts[0]["Hf"], insts[0]["P"], insts[0]["Q"], insts[0]["G"], insts[0]["H"])
     assert list(v) == [2]
+
+
+@pytest.mark.parametrize("n", [2, 64])
+def test_ipp_device_pointers_shared_bases_and_prebound_transcript(ctx, oracle, n):
+    """bpgpu_ipp_verify_batch_dev: device pointers, G / H given ONCE for the batch (the reference's callers pass the same
+    generator vectors for every proof, ipp.rs:260-270), and a caller transcript that already holds messages."""
+    import torch
+    import bulletproofs_amd as bp
+    L = bp.lib()
+    dev = torch.device("cuda", 0)
+    inst = oracle.ipp_test_instance(n, b"innerproducttest", b"shared-%d" % n)
+    pl = len(inst["proof"])
+    bad = bytearray(inst["proof"])
+    bad[-40] ^= 1
+    proofs = inst["proof"] + bytes(bad) + inst["proof"] + inst["proof"]
+    P = inst["P"] * 2 + inst["Q"] + inst["P"]
+    nb = 4
+    to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d = {k: to_dev(v) for k, v in dict(pr=proofs, Gf=inst["Gf"] * nb, Hf=inst["Hf"] * nb, P=P, Q=inst["Q"] * nb, G=inst["G"], H=inst["H"]).items()}
+    d_v = torch.full((nb,), 255, dtype=torch.uint8, device=dev)
+    d_o = torch.zeros((nb, 32), dtype=torch.uint8, device=dev)
+    s = torch.cuda.Stream(device=dev)
+    rc = L.bpgpu_ipp_verify_batch_dev(ctx.h, n, nb, d["pr"].data_ptr(), pl, b"innerproducttest", 16, None, d["Gf"].data_ptr(), d["Hf"].data_ptr(),
+                                      d["P"].data_ptr(), d["Q"].data_ptr(), d["G"].data_ptr(), d["H"].data_ptr(), 1, d_v.data_ptr(), d_o.data_ptr(),
+                                      s.cuda_stream)
+    assert rc == 0
+    s.synchronize()
+    got, out = bytes(d_v.cpu().numpy()), d_o.cpu().numpy().tobytes()
+    for j in range(nb):
+        erc, em = oracle.ipp_verify(n, proofs[pl * j:pl * (j + 1)], b"innerproducttest", inst["Gf"], inst["Hf"], P[32 * j:32 * j + 32], inst["Q"],
+                                    inst["G"], inst["H"])
+        assert got[j] == erc and out[32 * j:32 * j + 32] == em, (n, j)
+    assert list(got) == [0, 1, 1, 0]
+    # a transcript with history: the fresh-label proof no longer verifies against it, and it equals the label path when
+    # the state is exactly Transcript::new(label)
+    from bulletproofs_amd._lib import transcript_new, transcript_append_message
+    st = transcript_new(b"innerproducttest")
+    for state, expect in ((st, [0, 1, 1, 0]), (transcript_append_message(st, b"x", b"y"), [1, 1, 1, 1])):
+        rc = L.bpgpu_ipp_verify_batch_dev(ctx.h, n, nb, d["pr"].data_ptr(), pl, None, 0, state, d["Gf"].data_ptr(), d["Hf"].data_ptr(),
+                                          d["P"].data_ptr(), d["Q"].data_ptr(), d["G"].data_ptr(), d["H"].data_ptr(), 1, d_v.data_ptr(), None,
+                                          s.cuda_stream)
+        assert rc == 0
+        s.synchronize()
+        assert list(d_v.cpu().numpy()) == expect

@@ -13,9 +13,9 @@ sys.path[:0] = [os.path.join(ROOT, "oracle")]
 import pyoracle as O
 
 CONFIGS = [  # name, n, m, distinct proofs
-    ("cfg2_n64_m1", 64, 1, 1024),
-    ("cfg3_n64_m16", 64, 16, 64),
-    ("cfg4_n64_m32", 64, 32, 32),
+    ("cfg2_n64_m1", 64, 1, 8192),
+    ("cfg3_n64_m16", 64, 16, 256),
+    ("cfg4_n64_m32", 64, 32, 512),
     ("cfg1_n32_m1", 32, 1, 4),
 ]
 LABEL = b"AggregateRangeProofBenchmark"   # benches/range_proof.rs:80 of the reference
