@@ -92,6 +92,7 @@ struct bpgpu_ctx {
     size_t io_cap = 0;
     char *ipp_buf = nullptr;                 // term lists of the stand-alone inner-product verifier
     size_t ipp_cap = 0;
+    uint32_t bucket_min = 0;                 // terms per MSM from which the bucket path is taken (0 = BK_MIN_TERMS; huge = never)
     bool sync_blocking = false;              // host entry points: sleep on a blocking event instead of spinning
     hipEvent_t done_ev = nullptr;
     // profiling
@@ -340,6 +341,11 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
         c->sync_blocking = value != 0;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "bucket_min_terms")) {
+        if (value < 0 || value > 0x7fffffff) return fail(c, BPGPU_ERR_INVALID_ARG, "bucket_min_terms out of range");
+        c->bucket_min = (uint32_t)value;
+        return BPGPU_OK;
+    }
     return fail(c, BPGPU_ERR_INVALID_ARG, "unknown option %s", key);
 }
 
@@ -352,6 +358,7 @@ int bpgpu_ctx_get_option(bpgpu_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "fixed_splits")) *value = c->splits;
     else if (!strcmp(key, "horner_lanes")) *value = c->horner_lanes;
     else if (!strcmp(key, "host_sync_blocking")) *value = c->sync_blocking ? 1 : 0;
+    else if (!strcmp(key, "bucket_min_terms")) *value = c->bucket_min ? c->bucket_min : BK_MIN_TERMS;
     else return fail(c, BPGPU_ERR_INVALID_ARG, "unknown option %s", key);
     return BPGPU_OK;
 }
@@ -674,9 +681,102 @@ static int enqueue_vb_uniform(bpgpu_ctx *c, hipStream_t s, size_t nbatch, size_t
     return vb_launch(c, s, pd->total, (uint32_t)pd->n_chunks, nbatch, d_scalars, d_points, d_status, d);
 }
 
+// ============================================================================
+// bucket (Pippenger) path for MSMs with many variable-base terms (bucket.h)
+// ============================================================================
+struct bk_dev {
+    uint32_t *msm_first;   // [nmsm + 1]
+    fb_entry *pts;         // [total] affine Niels records
+    uint32_t *rwords;      // [total][BK_RWORDS]
+    uint32_t *idx;         // [nwin][total]
+    bk_desc *desc;         // [nmsm * nwin][half]
+    ge_ext *bsum;          // [nmsm * nwin][half]
+    uint32_t *colq16;      // [nmsm][64][32 words]
+    ge_ext *hq;            // [nmsm]
+};
+static uint32_t pick_bucket_c(size_t terms_per_msm) { return terms_per_msm >= 6000 ? 12u : 8u; }
+static void plan_bucket(arena_plan &ap, size_t nmsm, size_t total, bk_params prm, size_t off[8]) {
+    off[0] = ap.add((nmsm + 1) * 4);
+    off[1] = ap.add(total * sizeof(fb_entry) + 16);
+    off[2] = ap.add(total * BK_RWORDS * 4 + 16);
+    off[3] = ap.add((size_t)prm.nwin * total * 4 + 16);
+    off[4] = ap.add(nmsm * prm.nwin * prm.half * sizeof(bk_desc));
+    off[5] = ap.add(nmsm * prm.nwin * prm.half * sizeof(ge_ext));
+    off[6] = ap.add(nmsm * 64 * 128);
+    off[7] = ap.add(nmsm * sizeof(ge_ext));
+}
+static void bucket_bind(bpgpu_ctx *c, const size_t off[8], bk_dev &d) {
+    char *a = c->arena;
+    d.msm_first = (uint32_t *)(a + off[0]);
+    d.pts = (fb_entry *)(a + off[1]);
+    d.rwords = (uint32_t *)(a + off[2]);
+    d.idx = (uint32_t *)(a + off[3]);
+    d.desc = (bk_desc *)(a + off[4]);
+    d.bsum = (ge_ext *)(a + off[5]);
+    d.colq16 = (uint32_t *)(a + off[6]);
+    d.hq = (ge_ext *)(a + off[7]);
+}
+// first-term offsets of the MSMs -> device (through pinned staging)
+static int bucket_upload_first(bpgpu_ctx *c, hipStream_t s, size_t nmsm, const uint32_t *n_terms, size_t uniform_per, bk_dev &d) {
+    char *h = nullptr;
+    int rc = pin_alloc(c, s, (nmsm + 1) * 4, &h);
+    if (rc) return rc;
+    uint32_t *f = (uint32_t *)h;
+    uint32_t t0 = 0;
+    for (size_t b = 0; b < nmsm; b++) {
+        f[b] = t0;
+        t0 += n_terms ? n_terms[b] : (uint32_t)uniform_per;
+    }
+    f[nmsm] = t0;
+    HIPCHK(c, hipMemcpyAsync(d.msm_first, h, (nmsm + 1) * 4, hipMemcpyHostToDevice, s));
+    return BPGPU_OK;
+}
+// sort -> bucket sums -> window sums -> Horner chain; leaves the MSM sums in d.hq
+static int enqueue_bucket_tail(bpgpu_ctx *c, hipStream_t s, bk_params prm, size_t nmsm, size_t total, bk_dev &d) {
+    const uint32_t nbw = (uint32_t)(nmsm * prm.nwin), tot32 = (uint32_t)total;
+    if (prm.lanes == 64) LAUNCH(c, s, "bk_sort", k_bk_sort<64>, nbw, 64, prm, d.msm_first, tot32, 0, d.rwords, d.idx, d.desc, (const uint32_t *)nullptr, 0u);
+    else LAUNCH(c, s, "bk_sort", k_bk_sort<256>, nbw, 256, prm, d.msm_first, tot32, 0, d.rwords, d.idx, d.desc, (const uint32_t *)nullptr, 0u);
+    const uint32_t nt = nbw * prm.half;
+    LAUNCH(c, s, "bk_accum", k_bk_accum, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, prm, tot32, d.desc, d.idx, d.pts, d.bsum);
+    if (prm.lanes == 64) LAUNCH(c, s, "bk_reduce", k_bk_reduce<64>, nbw, 64, prm, d.bsum, d.colq16);
+    else LAUNCH(c, s, "bk_reduce", k_bk_reduce<256>, nbw, 256, prm, d.bsum, d.colq16);
+    LAUNCH(c, s, "horner_wave", k_horner_wave, (uint32_t)nmsm, 64, d.colq16, d.hq);
+    return BPGPU_OK;
+}
+static bool bucket_fits(size_t nmsm, size_t total, bk_params prm) {
+    return (uint64_t)nmsm * prm.nwin * prm.half <= 0x7fffffffull && (uint64_t)total * prm.nwin <= 0x7fffffffull;
+}
+
 static int msm_batch_dev_locked(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_terms, const void *d_scalars, const void *d_points,
                                 void *d_out, void *d_status_bytes, hipStream_t s) {
     if (nbatch == 0) return BPGPU_OK;
+    {   // many terms per MSM: bucket path (bucket.h); otherwise the table-lookup path below
+        uint64_t total = 0;
+        for (size_t b = 0; b < nbatch; b++) total += n_terms[b];
+        const bk_params prm = bk_make(pick_bucket_c(total / nbatch));
+        if (total / nbatch >= (c->bucket_min ? c->bucket_min : BK_MIN_TERMS) && bucket_fits(nbatch, total, prm)) {
+            arena_plan ap;
+            size_t off[8];
+            plan_bucket(ap, nbatch, total, prm, off);
+            const size_t off_status = ap.add(nbatch * 4);
+            int rc = arena_reserve(c, ap.total);
+            if (rc) return rc;
+            bk_dev d;
+            bucket_bind(c, off, d);
+            uint32_t *d_status = (uint32_t *)(c->arena + off_status);
+            HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
+            rc = bucket_upload_first(c, s, nbatch, n_terms, 0, d);
+            if (rc) return rc;
+            LAUNCH(c, s, "bk_prepare", k_bk_prepare, ((uint32_t)total + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, (uint32_t)total, (uint32_t)nbatch, d.msm_first,
+                   (const uint32_t *)d_scalars, (const uint32_t *)d_points, d.pts, d.rwords, d_status, prm);
+            rc = enqueue_bucket_tail(c, s, prm, nbatch, total, d);
+            if (rc) return rc;
+            LAUNCH(c, s, "vb_horner", k_vb_horner, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d.hq, d_status, (uint32_t *)d_out);
+            LAUNCH(c, s, "status_bytes", k_status_bytes, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d_status, (uint8_t *)d_status_bytes);
+            HIPCHK(c, hipGetLastError());
+            return BPGPU_OK;
+        }
+    }
     vb_plan pl;
     make_vb_plan(pl, nbatch, n_terms);
     arena_plan ap;
@@ -807,9 +907,12 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
     int rc = gen_ids_for(c, n, m, &d_ids);
     if (rc) return rc;
     const uint32_t nsplit = pick_splits(c, nbatch, npairs);
+    const bk_params bkp = bk_make(pick_bucket_c(n_unique));
+    const bool use_bucket = n_unique >= (c->bucket_min ? c->bucket_min : BK_MIN_TERMS) && bucket_fits(nbatch, nbatch * n_unique, bkp);
     arena_plan ap;
-    size_t off[7];
-    plan_vb_uniform(ap, nbatch, n_unique, off);
+    size_t off[7], boff[8];
+    if (use_bucket) plan_bucket(ap, nbatch, nbatch * n_unique, bkp, boff);
+    else plan_vb_uniform(ap, nbatch, n_unique, off);
     const size_t off_status = ap.add(nbatch * 4);
     const size_t off_digits = ap.add((size_t)npairs * nbatch * sizeof(fb_digit) + 16);
     const size_t off_partial = ap.add((size_t)2 * nsplit * nbatch * sizeof(ge_ext) + 16);
@@ -820,7 +923,18 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
     ge_ext *d_partial = (ge_ext *)(c->arena + off_partial);
     HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
     vb_dev d{};
-    if (n_unique) {
+    if (use_bucket) {   // many per-MSM points (the R1CS verifier's shape, r1cs/verifier.rs:459-491): bucket path
+        bk_dev bd;
+        bucket_bind(c, boff, bd);
+        rc = bucket_upload_first(c, s, nbatch, nullptr, n_unique, bd);
+        if (rc) return rc;
+        const uint32_t total = (uint32_t)(nbatch * n_unique);
+        LAUNCH(c, s, "bk_prepare", k_bk_prepare, (total + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, total, (uint32_t)nbatch, bd.msm_first,
+               (const uint32_t *)d_uniq_scalars, (const uint32_t *)d_uniq_points, bd.pts, bd.rwords, d_status, bkp);
+        rc = enqueue_bucket_tail(c, s, bkp, nbatch, total, bd);
+        if (rc) return rc;
+        d.hq = bd.hq;
+    } else if (n_unique) {
         rc = enqueue_vb_uniform(c, s, nbatch, n_unique, off, (const uint32_t *)d_uniq_scalars, (const uint32_t *)d_uniq_points, d_status, d);
         if (rc) return rc;
     }
@@ -1135,9 +1249,14 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         (uint64_t)nbatch * ((sh.U + BP_VB_CHUNK - 1) / BP_VB_CHUNK) * 64 > 0x7fffffffull || (uint64_t)(sh.nm / 4 + 1) * nbatch > 0x7fffffffull ||
         (uint64_t)((nbatch + FB_BLOCK - 1) / FB_BLOCK) * nsplit > 0x7fffffffull)
         return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large for this shape");
+    // batch combination with enough per-proof terms: ONE bucket MSM (bucket.h) over all proofs' weighted terms
+    const size_t rlc_terms = (size_t)nbatch * sh.U;
+    const bk_params bkp = bk_make(pick_bucket_c(rlc_terms));
+    const bool rlc_bucket = rlc && !shape_verdict && rlc_terms >= (c->bucket_min ? c->bucket_min : BK_MIN_TERMS) && bucket_fits(1, rlc_terms, bkp);
     arena_plan ap;
-    size_t off[7];
-    plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off);
+    size_t off[7], boff[8];
+    if (rlc_bucket) plan_bucket(ap, 1, rlc_terms, bkp, boff);
+    else plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off);
     const size_t off_digits = ap.add((size_t)npairs * nbatch * sizeof(fb_digit) + 16);
     const size_t off_partial = ap.add((size_t)2 * nsplit * nbatch * sizeof(ge_ext) + 16);
     const size_t off_fields = ap.add((size_t)fl.count * nbatch * BP_RP_REC * 4 + 16);
@@ -1208,8 +1327,10 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const uint32_t nb32 = (uint32_t)nbatch;
     // the proof-specific ("variable-base") terms: decomposition into chunks of 32 is cached per (batch, U)
     vb_dev d{};
+    bk_dev bd{};
+    if (rlc_bucket) bucket_bind(c, boff, bd);
     bpgpu_ctx::plan_dev *pd = nullptr;
-    if (!shape_verdict) {
+    if (!shape_verdict && !rlc_bucket) {
         rc = uniform_plan(c, nbatch, sh.U, &pd);
         if (rc) return rc;
         vb_bind(c, off, d);
@@ -1225,8 +1346,9 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const uint32_t n_tr = (nb32 + RP_BLOCK - 1) / RP_BLOCK;
     const uint32_t n_pt = shape_verdict ? 0 : (nb32 * sh.U + RP_BLOCK - 1) / RP_BLOCK;
     LAUNCH(c, s, "rp_stage1", k_rp_stage1, n_tr + n_pt, RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
-           (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, d.recoded, d_digits,
-           rlc ? wts_ptr : (const uint8_t *)nullptr, ts_flags, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out);
+           (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits,
+           rlc ? wts_ptr : (const uint8_t *)nullptr, ts_flags, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
+           rlc_bucket ? bd.pts : (fb_entry *)nullptr, rlc_bucket ? bkp.c : 0u);
     if (shape_verdict) {
         HIPCHK(c, hipMemsetAsync(d_mv, 1, nbatch, s));
         LAUNCH(c, s, "rp_verdict", k_rp_verdict, (nb32 + 63) / 64, 64, nb32, d_status, d_mv, (uint8_t *)d_verdict);
@@ -1236,8 +1358,34 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         c->rp_status_dirty = false;
         return BPGPU_OK;
     }
-    const uint32_t nexp = (sh.nm / 4) * nb32, nwin = (uint32_t)pd->n_chunks * 64;   // four generator indices per lane
+    const uint32_t nexp = (sh.nm / 4) * nb32, nwin = rlc_bucket ? 0u : (uint32_t)pd->n_chunks * 64;   // four generator indices per lane
     const uint32_t n_win = (nwin + BP_BLOCK - 1) / BP_BLOCK, n_exp = (nexp + BP_BLOCK - 1) / BP_BLOCK;
+    if (rlc_bucket) {
+        // ---- batch combination, bucket variant: R = sum_i rho_i MegaCheck_i with the per-proof terms as ONE MSM ----
+        unsigned long long *d_acc = (unsigned long long *)(a + off_acc);
+        HIPCHK(c, hipMemsetAsync(d_acc, 0, (size_t)n_gen_terms * 10 * 8, s));
+        LAUNCH(c, s, "rlc_stage3", k_rlc_stage3, n_exp, BP_BLOCK, 0u, 0u, (const vb_chunk *)nullptr, (const ge_cached *)nullptr, (const uint32_t *)nullptr,
+               (ge_ext *)nullptr, nexp, sh, prm, d_fields, d_status, d_acc, (nbatch % 64 == 0) ? 1 : 0);
+        const uint32_t tot32 = (uint32_t)rlc_terms;
+        if (bkp.lanes == 64) LAUNCH(c, s, "bk_sort", k_bk_sort<64>, bkp.nwin, 64, bkp, (const uint32_t *)nullptr, tot32, 1, bd.rwords, bd.idx, bd.desc, d_status, sh.U);
+        else LAUNCH(c, s, "bk_sort", k_bk_sort<256>, bkp.nwin, 256, bkp, (const uint32_t *)nullptr, tot32, 1, bd.rwords, bd.idx, bd.desc, d_status, sh.U);
+        fb_digit *d_dig1 = (fb_digit *)(a + off_dig1);
+        ge_ext *d_part1 = (ge_ext *)(a + off_part1);
+        uint32_t *d_ctl = (uint32_t *)(a + off_res1 + sizeof(ge_ext));
+        const uint32_t nt = bkp.nwin * bkp.half, n_acc = (nt + BP_BLOCK - 1) / BP_BLOCK, n_sc = (n_gen_terms + BP_BLOCK - 1) / BP_BLOCK;
+        LAUNCH(c, s, "rlc_accum", k_rlc_accum_scalars, n_acc + n_sc, BP_BLOCK, n_acc, nt, bkp, tot32, bd.desc, bd.idx, bd.pts, bd.bsum, n_gen_terms,
+               (const unsigned long long *)d_acc, d_dig1, prm, d_ctl);
+        if (bkp.lanes == 64) LAUNCH(c, s, "bk_reduce", k_bk_reduce<64>, bkp.nwin, 64, bkp, bd.bsum, bd.colq16);
+        else LAUNCH(c, s, "bk_reduce", k_bk_reduce<256>, bkp.nwin, 256, bkp, bd.bsum, bd.colq16);
+        LAUNCH(c, s, "rlc_stage4", k_rlc_stage4b, 1 + nsplit1, FB_BLOCK, bd.colq16, bd.hq, prm, nsplit1, npairs, d_ids, d_dig1, c->d_table, d_part1);
+        if (d_batch_out)
+            LAUNCH(c, s, "rlc_finish", k_rlc_finish<true>, 1, 64, nsplit1, bd.hq, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)d_batch_out);
+        else
+            LAUNCH(c, s, "rlc_finish", k_rlc_finish<false>, 1, 64, nsplit1, bd.hq, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)nullptr);
+        HIPCHK(c, hipGetLastError());
+        c->rp_status_dirty = false;
+        return BPGPU_OK;
+    }
     if (rlc) {
         // ---- batch combination (rlc.h): R = sum_i rho_i MegaCheck_i ---------------------------------------
         unsigned long long *d_acc = (unsigned long long *)(a + off_acc);

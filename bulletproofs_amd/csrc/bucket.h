@@ -1,0 +1,309 @@
+// Bucket ("Pippenger") multiscalar multiplication over variable-base points -- the algorithm the reference
+// reaches through RistrettoPoint::optional_multiscalar_mul for large inputs (upstream curve25519-dalek switches to
+// its Pippenger implementation at 190 terms; call sites src/r1cs/verifier.rs:459-491 with 2081 per-proof points,
+// src/range_proof/mod.rs:421-445 for aggregated proofs), here laid out for a GPU:
+//
+//   bk_prepare : lane = term            decode the point into affine Niels form (one 128-byte record), check and
+//                                       recode the scalar: r = s + sum_w half * 2^(c w), so that window w's signed
+//                                       digit is ((r >> c w) & (2^c - 1)) - half
+//   bk_sort    : workgroup = (MSM, window)   counting sort of the MSM's terms by |digit| in LDS (histogram, scan,
+//                                       scatter of term indices), then a second counting sort of the BUCKETS by
+//                                       their population, so that the 64 lanes of a wavefront own buckets of
+//                                       (nearly) equal length
+//   bk_accum   : lane = (MSM, window, bucket rank)   bucket sum: one mixed addition (7 multiplications) per listed
+//                                       term, software-pipelined gathers of the 128-byte point records
+//   bk_reduce  : workgroup = (MSM, window)   sum_j j * B_j by a tree of running sums: every node keeps
+//                                       (S, A) = (sum of its buckets, sum of (j - j0 + 1) B_j) and a parent of k children
+//                                       of width w forms S = sum S_i, A = sum A_i + w * sum i S_i with one running sum
+//   then the window sums enter the existing Horner chain (horner_wave.h) as radix-16 column sums: window w of c
+//   bits is column (c/4) w, the columns in between are the identity.
+//
+// c = 8 (32 windows x 128 buckets) for MSMs of a few hundred to a few thousand terms, c = 12 (22 windows x 2048
+// buckets) beyond: the per-window cost is N + 2^(c-1) * ~3.7 additions.  Results are bit-identical to the
+// table-lookup path (msm_vb.h) and to the oracle because only the canonical encoding of the sum is ever compared:
+// the order of additions inside a bucket (set by atomics) does not change the group element.
+//
+// The workgroup-cooperative stages are written as per-lane PHASE functions separated by barriers, so that the CPU
+// harness (tests/cpu_harness) runs the identical code with a loop over lanes per phase.
+#ifndef BPGPU_BUCKET_H
+#define BPGPU_BUCKET_H
+#include "msm_fixed.h"
+
+namespace bp {
+
+struct bk_params {
+    uint32_t c;      // window bits: 8 or 12
+    uint32_t nwin;   // windows: 32 (c = 8), 22 (c = 12; the last one holds bit 252 and the recoding carry)
+    uint32_t half;   // 2^(c-1) buckets per window (magnitudes 1 .. half)
+    uint32_t lanes;  // lanes of a (MSM, window) workgroup in bk_sort / bk_reduce: 64 (c = 8), 256 (c = 12)
+};
+BP_HD bk_params bk_make(uint32_t c) {
+    bk_params p;
+    p.c = c;
+    p.nwin = c == 8 ? 32u : 22u;
+    p.half = 1u << (c - 1);
+    p.lanes = c == 8 ? 64u : 256u;
+    return p;
+}
+#define BK_RWORDS 9          // recoded scalar: < 2^264
+#define BK_MIN_TERMS 192     // below this many terms per MSM the table-lookup path (msm_vb.h) is used
+
+// bucket descriptor, sorted by population (descending) inside each (MSM, window)
+struct bk_desc {
+    uint32_t off;      // first entry of the bucket's list in idx[window][msm_first + ...]
+    uint32_t cnt;      // entries
+    uint32_t bucket;   // magnitude - 1
+    uint32_t pad;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BK_ATOMIC_ADD(p, v) atomicAdd((p), (v))
+#else
+static inline uint32_t bk_host_atomic_add(uint32_t *p, uint32_t v) {
+    const uint32_t o = *p;
+    *p = o + v;
+    return o;
+}
+#define BK_ATOMIC_ADD(p, v) bk_host_atomic_add((p), (v))
+#endif
+
+// r = s + sum_{w < nwin} half << (c w)   (s canonical, < 2^253; r < 2^(c nwin))
+BP_HD void bk_recode(uint32_t r[BK_RWORDS], const uint32_t s[8], bk_params prm) {
+#pragma unroll
+    for (int i = 0; i < 8; i++) r[i] = s[i];
+    r[8] = 0;
+    for (uint32_t w = 0; w < prm.nwin; w++) {
+        const uint32_t bit = w * prm.c + (prm.c - 1);
+        uint32_t idx = bit >> 5;
+        uint64_t t = (uint64_t)r[idx] + (1u << (bit & 31));
+        r[idx] = (uint32_t)t;
+        uint32_t carry = (uint32_t)(t >> 32);
+        while (carry && ++idx < BK_RWORDS) {
+            t = (uint64_t)r[idx] + carry;
+            r[idx] = (uint32_t)t;
+            carry = (uint32_t)(t >> 32);
+        }
+    }
+}
+// signed digit of window w: in [-half, half)
+BP_HD int bk_digit(const uint32_t *r /*BK_RWORDS words*/, uint32_t w, bk_params prm) {
+    const uint32_t bit = w * prm.c, idx = bit >> 5, sh = bit & 31;
+    uint64_t two = (uint64_t)r[idx];
+    if (idx + 1 < BK_RWORDS) two |= (uint64_t)r[idx + 1] << 32;
+    return (int)((uint32_t)(two >> sh) & ((1u << prm.c) - 1u)) - (int)prm.half;
+}
+
+// decoded point -> affine Niels record (the decoder returns Z = 1)
+BP_HD void bk_store_point(fb_entry *dst, const ge_ext &p) {
+    const fe d2 = BP_FE_D2;
+    fb_entry e;
+    fe_add(e.ypx, p.Y, p.X);
+    fe_carry(e.ypx);
+    fe_sub(e.ymx, p.Y, p.X);
+    fe_mul(e.t2d, p.T, d2);
+    e.pad[0] = 0;
+    e.pad[1] = 0;
+    *dst = e;
+}
+
+// which MSM term t belongs to: msm_first[b] <= t < msm_first[b + 1]
+BP_HD uint32_t bk_find_msm(uint32_t t, const uint32_t *msm_first, uint32_t nbatch) {
+    uint32_t lo = 0, hi = nbatch;   // invariant: msm_first[lo] <= t < msm_first[hi]
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (msm_first[mid] <= t) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// ---- stage 1: lane = term ----------------------------------------------------------------------------------
+BP_HD void bk_prepare_thread(uint32_t t, uint32_t nbatch, const uint32_t *msm_first, const uint32_t *scalars, const uint32_t *points,
+                             fb_entry *pts, uint32_t *rwords, uint32_t *status, bk_params prm) {
+    uint32_t sw[8], pw[8], r[BK_RWORDS];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        sw[i] = scalars[8 * (uint64_t)t + i];
+        pw[i] = points[8 * (uint64_t)t + i];
+    }
+    const uint32_t msm = bk_find_msm(t, msm_first, nbatch);
+    ge_ext p;
+    const bool ok = ristretto_decompress(p, pw);
+    const bool canon = sc_is_canonical(sw);
+    if (!canon) status_raise(status + msm, BP_STATUS_BAD_SCALAR);
+    else if (!ok) status_raise(status + msm, BP_STATUS_BAD_POINT);
+    bk_recode(r, sw, prm);
+#pragma unroll
+    for (int i = 0; i < BK_RWORDS; i++) rwords[BK_RWORDS * (uint64_t)t + i] = r[i];
+    bk_store_point(pts + t, p);
+}
+
+// ---- stage 2: workgroup = (MSM b, window w); LDS: cnt[half], off[half], part[lanes], hist2[256] ------------------
+// All phases take (lane, seg) where seg describes the workgroup's MSM segment.
+struct bk_seg {
+    uint32_t first, count;   // the MSM's terms: [first, first + count)
+    uint32_t w;              // window
+    // batch-combination mode: term t belongs to proof t / skip_div; terms of proofs whose status word is set stay out
+    const uint32_t *skip_status;
+    uint32_t skip_div;
+};
+BP_HD bool bk_term_skipped(const bk_seg &sg, uint32_t t) { return sg.skip_status && sg.skip_status[t / sg.skip_div] != 0; }
+struct bk_lds {
+    uint32_t *cnt;    // [half] bucket populations, later the scatter cursors
+    uint32_t *off;    // [half] exclusive prefix of cnt
+    uint32_t *part;   // [lanes] scan partials
+    uint32_t *hist2;  // [256] histogram of min(cnt, 255), later the descriptor cursors
+};
+BP_HD void bk_sort_p0(uint32_t lane, bk_params prm, const bk_lds &l) {   // clear
+    for (uint32_t j = lane; j < prm.half; j += prm.lanes) l.cnt[j] = 0;
+    for (uint32_t j = lane; j < 256; j += prm.lanes) l.hist2[j] = 0;
+}
+BP_HD void bk_sort_p1(uint32_t lane, bk_params prm, const bk_seg &sg, const uint32_t *rwords, const bk_lds &l) {   // histogram
+    for (uint32_t i = lane; i < sg.count; i += prm.lanes) {
+        if (bk_term_skipped(sg, sg.first + i)) continue;
+        const int d = bk_digit(rwords + BK_RWORDS * (uint64_t)(sg.first + i), sg.w, prm);
+        if (d != 0) BK_ATOMIC_ADD(&l.cnt[(uint32_t)(d < 0 ? -d : d) - 1], 1u);
+    }
+}
+BP_HD void bk_sort_p2(uint32_t lane, bk_params prm, const bk_lds &l) {   // per-lane partial sums of a contiguous chunk
+    const uint32_t per = prm.half / prm.lanes;
+    uint32_t s = 0;
+    for (uint32_t j = lane * per; j < (lane + 1) * per; j++) s += l.cnt[j];
+    l.part[lane] = s;
+}
+BP_HD void bk_sort_p3(uint32_t lane, bk_params prm, const bk_lds &l) {   // lane 0: scan of the partials (<= 256 entries)
+    if (lane != 0) return;
+    uint32_t run = 0;
+    for (uint32_t i = 0; i < prm.lanes; i++) {
+        const uint32_t v = l.part[i];
+        l.part[i] = run;
+        run += v;
+    }
+}
+BP_HD void bk_sort_p4(uint32_t lane, bk_params prm, const bk_lds &l) {   // offsets of the chunk + histogram of populations
+    const uint32_t per = prm.half / prm.lanes;
+    uint32_t run = l.part[lane];
+    for (uint32_t j = lane * per; j < (lane + 1) * per; j++) {
+        const uint32_t cn = l.cnt[j];
+        l.off[j] = run;
+        run += cn;
+        BK_ATOMIC_ADD(&l.hist2[cn < 255 ? cn : 255], 1u);
+    }
+}
+BP_HD void bk_sort_p5(uint32_t lane, const bk_lds &l) {   // lane 0: descending scan: first descriptor slot of each population class
+    if (lane != 0) return;
+    uint32_t run = 0;
+    for (int k = 255; k >= 0; k--) {
+        const uint32_t v = l.hist2[k];
+        l.hist2[k] = run;
+        run += v;
+    }
+}
+BP_HD void bk_sort_p6(uint32_t lane, bk_params prm, const bk_seg &sg, const bk_lds &l, bk_desc *desc /*this workgroup's [half]*/) {
+    // descriptors sorted by population (descending); cnt[] becomes the scatter cursor
+    const uint32_t per = prm.half / prm.lanes;
+    for (uint32_t j = lane * per; j < (lane + 1) * per; j++) {
+        const uint32_t cn = l.cnt[j];
+        const uint32_t pos = BK_ATOMIC_ADD(&l.hist2[cn < 255 ? cn : 255], 1u);
+        bk_desc d;
+        d.off = sg.first + l.off[j];
+        d.cnt = cn;
+        d.bucket = j;
+        d.pad = 0;
+        desc[pos] = d;
+        l.cnt[j] = l.off[j];
+    }
+}
+BP_HD void bk_sort_p7(uint32_t lane, bk_params prm, const bk_seg &sg, const uint32_t *rwords, const bk_lds &l, uint32_t *idx_w /*idx of window w: [total]*/) {
+    for (uint32_t i = lane; i < sg.count; i += prm.lanes) {
+        const uint32_t t = sg.first + i;
+        if (bk_term_skipped(sg, t)) continue;
+        const int d = bk_digit(rwords + BK_RWORDS * (uint64_t)t, sg.w, prm);
+        if (d != 0) {
+            const uint32_t pos = BK_ATOMIC_ADD(&l.cnt[(uint32_t)(d < 0 ? -d : d) - 1], 1u);
+            idx_w[sg.first + pos] = t | (d < 0 ? 0x80000000u : 0u);
+        }
+    }
+}
+
+// ---- stage 3: lane = (workgroup id bw, rank r) ------------------------------------------------------------------
+BP_HD void bk_accum_thread(uint32_t bw, uint32_t r, bk_params prm, const bk_desc *desc, const uint32_t *idx_w, const fb_entry *pts, ge_ext *bsum) {
+    const bk_desc d = desc[(uint64_t)bw * prm.half + r];
+    ge_ext acc;
+    ge_identity(acc);
+    if (d.cnt) {
+        uint32_t e_cur = idx_w[d.off];
+        fb_line line_cur;
+        fb_load_line(line_cur, pts + (e_cur & 0x7fffffffu));
+        for (uint32_t i = 0; i < d.cnt; i++) {
+            fb_line line_next = line_cur;
+            uint32_t e_next = 0;
+            if (i + 1 < d.cnt) {
+                e_next = idx_w[d.off + i + 1];
+                fb_load_line(line_next, pts + (e_next & 0x7fffffffu));
+            }
+            ge_niels n;
+#pragma unroll
+            for (int q = 0; q < 10; q++) {
+                n.ypx.v[q] = line_cur.w[q];
+                n.ymx.v[q] = line_cur.w[10 + q];
+                n.t2d.v[q] = line_cur.w[20 + q];
+            }
+            const bool neg = (e_cur >> 31) != 0;
+            if (i == 0) ge_from_niels(acc, n, neg);
+            else ge_madd(acc, acc, n, neg);
+            line_cur = line_next;
+            e_cur = e_next;
+        }
+    }
+    bsum[(uint64_t)bw * prm.half + d.bucket] = acc;
+}
+
+// ---- stage 4: workgroup = (MSM, window): sum_j (j + 1) * B_j, j = bucket index ----------------------------------
+// leaf: lane l owns the m = half / lanes buckets [l m, (l + 1) m)
+BP_HD void bk_reduce_leaf(uint32_t lane, bk_params prm, const ge_ext *bsum_bw /*[half]*/, ge_ext *S, ge_ext *A) {
+    const uint32_t m = prm.half / prm.lanes, j0 = lane * m;
+    ge_ext run = bsum_bw[j0 + m - 1], acc = run;
+    for (uint32_t i = m - 1; i-- > 0;) {
+        const ge_ext q = bsum_bw[j0 + i];
+        ge_add(run, run, q);
+        ge_add(acc, acc, run);
+    }
+    S[lane] = run;
+    A[lane] = acc;
+}
+// one level: node g (stored at slot g * k * stride) absorbs its k children at slots (g k + i) stride; a child spans
+// `width` buckets.  S = sum S_i, A = sum A_i + width * sum i S_i.  width is a power of two.
+BP_HD void bk_reduce_node(uint32_t g, uint32_t k, uint32_t stride, uint32_t width, ge_ext *S, ge_ext *A) {
+    const uint32_t base = g * k * stride;
+    ge_ext run = S[base + (k - 1) * stride], acc = run, asum = A[base + (k - 1) * stride];
+    for (uint32_t i = k - 1; i-- > 1;) {
+        const ge_ext s = S[base + i * stride], a = A[base + i * stride];
+        ge_add(run, run, s);
+        ge_add(acc, acc, run);     // after the loop: acc = sum_{i >= 1} i S_i
+        ge_add(asum, asum, a);
+    }
+    {
+        const ge_ext s0 = S[base], a0 = A[base];
+        ge_add(run, run, s0);
+        ge_add(asum, asum, a0);
+    }
+    for (uint32_t wd = width; wd > 1; wd >>= 1) ge_dbl(acc, acc, wd == 2);
+    ge_add(asum, asum, acc);
+    S[base] = run;
+    A[base] = asum;
+}
+// children per level for `lanes` leaves: 64 = 8 x 8, 256 = 8 x 8 x 4
+BP_HD uint32_t bk_reduce_fanout(uint32_t nodes) { return nodes >= 8 ? 8u : nodes; }
+
+// window sum -> the MSM's radix-16 column sums for the wavefront Horner chain: column (c/4) w carries the window
+// sum, the columns up to the next window (if they exist) the identity
+BP_HD void bk_emit_columns(uint32_t w, bk_params prm, const ge_ext &sum, uint32_t *colq16_msm /*[64][32 words]*/) {
+    const uint32_t per = prm.c / 4, c0 = w * per;
+    ge_ext id;
+    ge_identity(id);
+    for (uint32_t i = 0; i < per && c0 + i < BP_VB_WINDOWS; i++) vb_encode_colq16(colq16_msm + (uint64_t)(c0 + i) * 32, i == 0 ? sum : id);
+}
+
+}  // namespace bp
+#endif

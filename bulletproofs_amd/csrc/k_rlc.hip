@@ -104,6 +104,34 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rlc_colsum_scalars(uint32_t n_red,
     }
 }
 
+// bucket variant (bucket.h) of the per-proof terms: blocks [0, n_acc) accumulate the buckets of the ONE multiscalar
+// multiplication over all proofs' weighted terms  ||  the combined generator coefficients (as above)
+__global__ void __launch_bounds__(BP_BLOCK) k_rlc_accum_scalars(uint32_t n_acc, uint32_t nthreads, bk_params bk, uint32_t total, const bk_desc *desc,
+                                                                 const uint32_t *idx, const fb_entry *pts, ge_ext *bsum, uint32_t n_rows,
+                                                                 const unsigned long long *acc, fb_digit *digits, fb_params prm, uint32_t *ctl) {
+    if (blockIdx.x < n_acc) {
+        const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
+        if (tid >= nthreads) return;
+        const uint32_t bw = tid / bk.half, r = tid - bw * bk.half;
+        bk_accum_thread(bw, r, bk, desc, idx + (uint64_t)bw * total, pts, bsum);   // one MSM: bw = window
+    } else {
+        rlc_scalars_lane((blockIdx.x - n_acc) * BP_BLOCK + threadIdx.x, n_rows, acc, digits, prm, ctl, 0u);
+    }
+}
+// block 0: the Horner chain over the window sums (radix-16 column sums written by k_bk_reduce)  ||  the table walk
+// for a batch of one (block -> split as in k_fb_accum with one proof block)
+__global__ void __launch_bounds__(FB_BLOCK) k_rlc_stage4b(const uint32_t *colq16, ge_ext *hq, fb_params prm, uint32_t nsplit, uint32_t npairs,
+                                                           const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial) {
+    if (blockIdx.x == 0) {
+        hw_horner_msm((const uint16_t *)colq16, hq);
+        return;
+    }
+    const uint32_t split = blockIdx.x - 1;
+    const uint32_t per = (npairs + nsplit - 1) / nsplit;
+    const uint32_t q0 = split * per, q1 = (q0 + per < npairs) ? q0 + per : npairs;
+    if (threadIdx.x == 0) fb_accum_thread(0, split, q0 < npairs ? q0 : npairs, q1, prm, 1, gen_ids, digits, table, partial);
+}
+
 // Tail of the combined check, ONE wavefront: the 64 lanes add up the batch-of-one table walk's partial points
 // (and the Horner result), fold them through LDS, lane 0 tests the identity (WITH_OUT: and encodes R); then
 // every proof's verdict is written: the front end's status if set, else 0 when R is the identity, UNDECIDED

@@ -17,7 +17,7 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1(rp_shape sh, rp_strobe_i
                                                          const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields,
                                                          ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m,
                                                          uint32_t *recoded, fb_digit *digits, const uint8_t *rho64, uint32_t ts_flags,
-                                                         const uint32_t *ts_in, uint32_t *ts_out) {
+                                                         const uint32_t *ts_in, uint32_t *ts_out, fb_entry *bk_pts, uint32_t bk_c) {
     __shared__ uint32_t lds[50 * RP_BLOCK];   // sponge states, word-major: word w of lane t at w*RP_BLOCK + t
     if (blockIdx.x < n_tr) {
         const uint32_t p = blockIdx.x * RP_BLOCK + threadIdx.x;
@@ -26,11 +26,11 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1(rp_shape sh, rp_strobe_i
         st.stride = RP_BLOCK;
         if (p < sh.nproofs) {
             rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields, status, ts_flags, ts_in, ts_out);
-            if (!sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64);
+            if (!sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64, bk_c);
         }
     } else {
         const uint32_t t = (blockIdx.x - n_tr) * RP_BLOCK + threadIdx.x;
-        if (t < sh.nproofs * sh.U) rp_points_thread(t, sh, proofs, commitments, tab, status);
+        if (t < sh.nproofs * sh.U) rp_points_thread(t, sh, proofs, commitments, tab, status, bk_pts);
     }
 }
 

@@ -10,6 +10,7 @@
 #include "rlc.h"
 #include "rangeproof.h"
 #include "ipp.h"
+#include "bucket.h"
 
 #define BP_BLOCK 64   // one wavefront per workgroup: under contention a CU rarely has room for four waves of one group at once (256: -8% at 48 streams)
 #define FB_BLOCK 64
@@ -32,7 +33,7 @@ __global__ void k_fb_reduce(uint32_t nthreads, uint32_t nproofs, uint32_t nsplit
 __global__ void k_shared_finish(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, int have_unique, const ge_ext *partial, const uint32_t *status, uint32_t *out_words, uint8_t *verdict);
 template <bool WITH_OUT>
 __global__ void k_finish8(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, const ge_ext *partial, uint32_t *status, uint32_t *out_words, uint8_t *verdict, int reset_status);
-__global__ void k_rp_stage1(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs, const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields, ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m, uint32_t *recoded, fb_digit *digits, const uint8_t *rho64, uint32_t ts_flags, const uint32_t *ts_in, uint32_t *ts_out);
+__global__ void k_rp_stage1(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs, const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields, ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m, uint32_t *recoded, fb_digit *digits, const uint8_t *rho64, uint32_t ts_flags, const uint32_t *ts_in, uint32_t *ts_out, fb_entry *bk_pts, uint32_t bk_c);
 __global__ void k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, ge_cached *colc, uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits, const uint32_t *status);
 template <bool QUAD>
 __global__ void k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge_ext *part, const ge_cached *colc, ge_ext *hq, fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit, uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial);
@@ -44,5 +45,16 @@ __global__ void k_rp_verdict(uint32_t n, uint32_t *status, const uint8_t *msm_ve
 __global__ void k_ipp_prepare(ipp_shape sh, rp_strobe_init init, const uint8_t *proofs, const uint8_t *Gf, const uint8_t *Hf, const uint8_t *P, const uint8_t *Q, const uint8_t *G, const uint8_t *H, uint32_t *scalars, uint32_t *points, uint32_t *status);
 __global__ void k_ipp_verdict(uint32_t n, const uint32_t *status, const uint8_t *msm_status, const uint32_t *msm_out, uint8_t *verdict);
 __global__ void k_from_uniform(uint32_t n, const uint32_t *uniform, uint32_t *out);
+
+// k_rlc.hip, bucket variant of the batch combination
+__global__ void k_rlc_accum_scalars(uint32_t n_acc, uint32_t nthreads, bk_params bk, uint32_t total, const bk_desc *desc, const uint32_t *idx, const fb_entry *pts, ge_ext *bsum, uint32_t n_rows, const unsigned long long *acc, fb_digit *digits, fb_params prm, uint32_t *ctl);
+__global__ void k_rlc_stage4b(const uint32_t *colq16, ge_ext *hq, fb_params prm, uint32_t nsplit, uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial);
+// k_bucket.hip
+__global__ void k_bk_prepare(uint32_t total, uint32_t nbatch, const uint32_t *msm_first, const uint32_t *scalars, const uint32_t *points, fb_entry *pts, uint32_t *rwords, uint32_t *status, bk_params prm);
+template <int LANES>
+__global__ void k_bk_sort(bk_params prm, const uint32_t *msm_first, uint32_t total, int single, const uint32_t *rwords, uint32_t *idx, bk_desc *desc, const uint32_t *skip_status, uint32_t skip_div);
+__global__ void k_bk_accum(uint32_t nthreads, bk_params prm, uint32_t total, const bk_desc *desc, const uint32_t *idx, const fb_entry *pts, ge_ext *bsum);
+template <int LANES>
+__global__ void k_bk_reduce(bk_params prm, const ge_ext *bsum, uint32_t *colq16);
 
 #endif

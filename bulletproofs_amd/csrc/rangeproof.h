@@ -17,6 +17,7 @@
 #include "msm_fixed.h"
 #include "sc25519.h"
 #include "scinv.h"
+#include "bucket.h"
 
 namespace bp {
 
@@ -273,13 +274,16 @@ BP_HD const uint8_t *rp_unique_point_ptr(const rp_shape &sh, const uint8_t *proo
 }
 // thread t = p * U + u: decode the point (mod.rs:433-443 .decompress()) and build its {1..8}P table.
 // An undecodable point is the Option::None of optional_multiscalar_mul -> VerificationError (mod.rs:445).
-BP_HD void rp_points_thread(uint32_t t, rp_shape sh, const uint8_t *proofs, const uint8_t *commitments, ge_cached *tab, uint32_t *status) {
+// pts (optional, instead of tab): bucket path (bucket.h) -- store the point as one affine Niels record instead.
+BP_HD void rp_points_thread(uint32_t t, rp_shape sh, const uint8_t *proofs, const uint8_t *commitments, ge_cached *tab, uint32_t *status,
+                            fb_entry *pts = nullptr) {
     const uint32_t p = t / sh.U, u = t - p * sh.U;
     uint32_t w[8];
     load_words8(w, rp_unique_point_ptr(sh, proofs, commitments, p, u));
     ge_ext pt;
     if (!ristretto_decompress(pt, w)) status_raise(status + p, BP_VERDICT_VERIFICATION);
-    vb_build_table(tab + 8 * (uint64_t)t, pt);
+    if (pts) bk_store_point(pts + t, pt);
+    else vb_build_table(tab + 8 * (uint64_t)t, pt);
 }
 
 // sum_{i<2^lg} x^i by repeated doubling (src/util.rs:240-256); Montgomery form in and out
@@ -320,13 +324,22 @@ BP_HD void store_recoded(uint32_t *dst, const sc &s) {
     for (int q = 0; q < 8; q++) dst[q] = r[q];
 }
 
-// a coefficient held in Montgomery form -> (times the proof's batch weight, if any) -> radix-16 recoding
-BP_HD void rp_emit_coeff(uint32_t *dst, const sc28 &vm, const sc28 *rho_m) {
+// a coefficient held in Montgomery form -> (times the proof's batch weight, if any) -> coefficient u of the proof's
+// list `us`: radix-16 recoding (8 words per coefficient), or -- bk_c != 0, bucket path -- the c-bit window recoding
+// of bucket.h (BK_RWORDS words per coefficient)
+BP_HD void rp_emit_coeff(uint32_t *us, uint32_t u, const sc28 &vm, const sc28 *rho_m, uint32_t bk_c) {
     sc28 t = vm;
     if (rho_m) sc28_montmul(t, vm, *rho_m);
     sc s;
     sc_from_mont28(s, t);
-    store_recoded(dst, s);
+    if (bk_c) {
+        uint32_t r[BK_RWORDS];
+        bk_recode(r, s.v, bk_make(bk_c));
+#pragma unroll
+        for (int q = 0; q < BK_RWORDS; q++) us[u * BK_RWORDS + q] = r[q];
+    } else {
+        store_recoded(us + u * 8, s);
+    }
 }
 
 // ---- stage 2: per-proof scalars -----------------------------------------------------------
@@ -337,7 +350,7 @@ BP_HD void rp_emit_coeff(uint32_t *dst, const sc28 &vm, const sc28 *rho_m) {
 // multiplied by its weight rho_p = from_bytes_mod_order_wide(rho64[p]); the B_blinding / B coefficients go to
 // the ROW0 / ROW1 fields instead of `digits` (they are summed over the batch in the next launch).
 BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t lg_m, uint32_t *fields, uint32_t *recoded,
-                              fb_digit *digits, const uint32_t *status, const uint8_t *rho64 = nullptr) {
+                              fb_digit *digits, const uint32_t *status, const uint8_t *rho64 = nullptr, uint32_t bk_c = 0) {
     if (status[p] != 0) return;   // digits/scalars of rejected proofs are never consumed (finish masks them)
     const uint32_t B = sh.nproofs, k = sh.k;
     const rp_fields fl = rp_field_layout(k, sh.m);
@@ -374,7 +387,7 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
     }
     sc28 inv;
     sc28_invert_mont_safegcd(inv, acc);                   // (y * prod u_i)^-1
-    uint32_t *us = recoded + (uint64_t)p * sh.U * 8;
+    uint32_t *us = recoded + (uint64_t)p * sh.U * (bk_c ? BK_RWORDS : 8);
     for (uint32_t ii = k; ii-- > 0;) {
         sc28 pre, uim, sq;
         rp_load28(pre, fields, B, fl.uinv_m + ii, p);
@@ -383,9 +396,9 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
         sc28_montmul(inv, inv, um);                       // drop u_ii from the running inverse
         rp_store28(fields, B, fl.uinv_m + ii, p, uim);
         sc28_montmul(sq, um, um);                         // u_i^2   -> L_i coefficient
-        rp_emit_coeff(us + (4 + ii) * 8, sq, rho);
+        rp_emit_coeff(us, 4 + ii, sq, rho, bk_c);
         sc28_montmul(sq, uim, uim);                       // u_i^-2  -> R_i coefficient
-        rp_emit_coeff(us + (4 + k + ii) * 8, sq, rho);
+        rp_emit_coeff(us, 4 + k + ii, sq, rho, bk_c);
     }
     // what is left in inv is y^-1: table of y^-(2^b)
     {
@@ -446,17 +459,17 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
     {
         sc28 one_m;
         sc28_one_mont(one_m);
-        rp_emit_coeff(us + 0 * 8, one_m, rho);
+        rp_emit_coeff(us, 0, one_m, rho, bk_c);
     }
-    rp_emit_coeff(us + 1 * 8, xm, rho);
-    rp_emit_coeff(us + 2 * 8, cxm, rho);
-    rp_emit_coeff(us + 3 * 8, cxxm, rho);
+    rp_emit_coeff(us, 1, xm, rho, bk_c);
+    rp_emit_coeff(us, 2, cxm, rho, bk_c);
+    rp_emit_coeff(us, 3, cxxm, rho, bk_c);
     // V_j coefficients c z^2 z^j, and the z^2 z^j table
     {
         sc28 czzj, zzj = zzm;
         sc28_montmul(czzj, cm, zzm);
         for (uint32_t j = 0; j < sh.m; j++) {
-            rp_emit_coeff(us + (4 + 2 * k + j) * 8, czzj, rho);
+            rp_emit_coeff(us, 4 + 2 * k + j, czzj, rho, bk_c);
             if (rho) {
                 sc28 t;
                 sc28_montmul(t, zzj, rho_m);

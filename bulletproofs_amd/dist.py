@@ -8,6 +8,8 @@ def init(backend, device=None):
     import torch.distributed as dist
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
     os.environ.setdefault("MASTER_PORT", "29531")
+    if backend == "gloo":   # single-node use: bind the loopback device instead of resolving the (possibly unresolvable) hostname
+        os.environ.setdefault("GLOO_SOCKET_IFNAME", "lo")
     if backend == "nccl" and device is not None:
         dist.init_process_group(backend, device_id=device)
     else:

@@ -12,6 +12,8 @@
 #include "../../bulletproofs_amd/csrc/ipp.h"
 #include "../../bulletproofs_amd/csrc/scinv.h"
 #include "../../bulletproofs_amd/csrc/rlc.h"
+#include "../../bulletproofs_amd/csrc/bucket.h"
+#include <algorithm>
 #include <cstdio>
 #include <cstring>
 #include <vector>
@@ -432,6 +434,72 @@ int h_ipp_verify(uint32_t n, uint32_t nbatch, const uint8_t *proofs, uint32_t pr
     h_msm_vb(nbatch, nt.data(), (const uint8_t *)scal.data(), (const uint8_t *)pts.data(), out.data(), mst.data());
     for (uint32_t p = 0; p < nbatch; p++) ipp_verdict_thread(p, status.data(), mst.data(), (const uint32_t *)out.data(), verdict_out);
     if (msm_out) memcpy(msm_out, out.data(), (size_t)nbatch * 32);
+    return 0;
+}
+
+// The bucket (Pippenger) MSM pipeline, lane by lane and phase by phase (bucket.h; the same bodies as k_bucket.hip).
+// c = 8 or 12.  skip_div != 0: ONE MSM over all terms, terms of "proof" t / skip_div are left out when skip[proof] != 0.
+int h_msm_bucket(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, const uint8_t *points, uint32_t c,
+                 const uint32_t *skip, uint32_t skip_div, uint8_t *out, uint8_t *status_out) {
+    const bk_params prm = bk_make(c);
+    std::vector<uint32_t> msm_first(nbatch + 1, 0);
+    for (uint32_t b = 0; b < nbatch; b++) msm_first[b + 1] = msm_first[b] + n_terms[b];
+    const uint32_t total = msm_first[nbatch];
+    const bool single = skip_div != 0;
+    const uint32_t nmsm = single ? 1 : nbatch, nbw = nmsm * prm.nwin;
+    std::vector<fb_entry> pts(total + 1);
+    std::vector<uint32_t> rwords((size_t)total * BK_RWORDS + BK_RWORDS), status(nbatch + 1, 0), idx((size_t)prm.nwin * total + 1, 0xdeadbeefu);
+    for (uint32_t t = 0; t < total; t++)
+        bk_prepare_thread(t, nbatch, msm_first.data(), (const uint32_t *)scalars, (const uint32_t *)points, pts.data(), rwords.data(), status.data(), prm);
+    std::vector<bk_desc> desc((size_t)nbw * prm.half);
+    std::vector<uint32_t> l_cnt(prm.half), l_off(prm.half), l_part(prm.lanes), l_hist2(256);
+    bk_lds l; l.cnt = l_cnt.data(); l.off = l_off.data(); l.part = l_part.data(); l.hist2 = l_hist2.data();
+    for (uint32_t bw = 0; bw < nbw; bw++) {
+        const uint32_t b = bw / prm.nwin;
+        bk_seg sg; sg.w = bw - b * prm.nwin; sg.first = single ? 0 : msm_first[b]; sg.count = single ? total : msm_first[b + 1] - sg.first;
+        sg.skip_status = single ? skip : nullptr; sg.skip_div = skip_div ? skip_div : 1;
+        uint32_t *idx_w = idx.data() + (size_t)sg.w * total;
+        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p0(lane, prm, l);
+        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p1(lane, prm, sg, rwords.data(), l);
+        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p2(lane, prm, l);
+        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p3(lane, prm, l);
+        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p4(lane, prm, l);
+        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p5(lane, l);
+        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p6(lane, prm, sg, l, desc.data() + (size_t)bw * prm.half);
+        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p7(lane, prm, sg, rwords.data(), l, idx_w);
+        // descriptors are sorted by population (clamped at 255), descending, and partition the window's listed terms
+        uint32_t listed = 0;
+        for (uint32_t r = 0; r < prm.half; r++) {
+            const bk_desc &d = desc[(size_t)bw * prm.half + r];
+            if (r && std::min(d.cnt, 255u) > std::min(desc[(size_t)bw * prm.half + r - 1].cnt, 255u)) return -3;
+            listed += d.cnt;
+        }
+        if (listed > sg.count) return -4;
+    }
+    std::vector<ge_ext> bsum((size_t)nbw * prm.half);
+    for (uint32_t tid = 0; tid < nbw * prm.half; tid++) {
+        const uint32_t bw = tid / prm.half, r = tid - bw * prm.half, w = bw % prm.nwin;
+        bk_accum_thread(bw, r, prm, desc.data(), idx.data() + (size_t)w * total, pts.data(), bsum.data());
+    }
+    std::vector<uint32_t> colq16((size_t)nmsm * 64 * 32 + 32, 0);
+    std::vector<ge_ext> S(prm.lanes), A(prm.lanes);
+    for (uint32_t bw = 0; bw < nbw; bw++) {
+        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_reduce_leaf(lane, prm, bsum.data() + (size_t)bw * prm.half, S.data(), A.data());
+        uint32_t nodes = prm.lanes, stride = 1, width = prm.half / prm.lanes;
+        while (nodes > 1) {
+            const uint32_t k = bk_reduce_fanout(nodes), groups = nodes / k;
+            for (uint32_t lane = 0; lane < groups; lane++) bk_reduce_node(lane, k, stride, width, S.data(), A.data());
+            nodes = groups; stride *= k; width *= k;
+        }
+        const uint32_t b = bw / prm.nwin, w = bw - b * prm.nwin;
+        bk_emit_columns(w, prm, A[0], colq16.data() + (size_t)b * 64 * 32);
+    }
+    std::vector<ge_ext> hq(nmsm + 1);
+    std::vector<uint32_t> outw((size_t)nmsm * 8 + 8), st1(nmsm + 1, 0);
+    for (uint32_t b = 0; b < nmsm; b++) hw_horner_msm((const uint16_t *)(colq16.data() + (size_t)b * 64 * 32), &hq[b]);
+    for (uint32_t b = 0; b < nmsm; b++) vb_horner_thread(b, nullptr, hq.data(), single ? st1.data() : status.data(), outw.data(), nullptr);
+    memcpy(out, outw.data(), (size_t)nmsm * 32);
+    for (uint32_t b = 0; b < nbatch; b++) status_out[b] = (uint8_t)status[b];
     return 0;
 }
 }

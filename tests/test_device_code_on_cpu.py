@@ -155,6 +155,49 @@ def test_variable_base_pipeline_lane_by_lane(H, oracle):
     assert st.raw[0] == 2
 
 
+@pytest.mark.parametrize("c", [8, 12])
+def test_bucket_msm_pipeline_phase_by_phase(H, oracle, c):
+    """bucket.h (Pippenger: counting sort by digit, population-sorted buckets, running-sum tree, Horner over the window
+    sums) with the kernels' own per-lane phase functions: ragged sizes incl. empty MSMs, edge scalars, repeated and
+    negated points (complete addition formulas), undecodable point / non-canonical scalar, and the single-MSM mode with
+    skipped "proofs" of the batch combination."""
+    sizes = [0, 1, 2, 70, 300] if c == 8 else [0, 3, 150]
+    S = P = b""
+    for k, n in enumerate(sizes):
+        S += b"".join(_sc(b"b%d-s%d" % (k, i)) for i in range(n))
+        P += b"".join(_pt(oracle, b"b%d-p%d" % (k, i % 40)) for i in range(n))   # points repeat: buckets see P + P and P - P
+    nt = (C.c_uint32 * len(sizes))(*sizes)
+    out, st = C.create_string_buffer(32 * len(sizes)), C.create_string_buffer(len(sizes))
+    assert H.h_msm_bucket(len(sizes), nt, S, P, c, None, 0, out, st) == 0
+    off = 0
+    for k, n in enumerate(sizes):
+        assert st.raw[k] == 0 and out.raw[32 * k:32 * k + 32] == oracle.msm(S[off:off + 32 * n], P[off:off + 32 * n])[1], (c, k)
+        off += 32 * n
+    sp = [0, 1, T.L - 1, 8, int("8" * 63, 16) % T.L, 2**252, 2**252 + 1, (1 << (c - 1)), (1 << (c - 1)) - 1, (1 << c) - 1, T.L - (1 << (c - 1))]
+    s = b"".join(x.to_bytes(32, "little") for x in sp)
+    p = b"".join(_pt(oracle, b"bsp%d" % (i % 3)) for i in range(len(sp)))
+    nt1 = (C.c_uint32 * 1)(len(sp))
+    assert H.h_msm_bucket(1, nt1, s, p, c, None, 0, out, st) == 0
+    assert out.raw[:32] == oracle.msm(s, p)[1] and st.raw[0] == 0
+    bad = bytearray(p)
+    bad[0] |= 1
+    H.h_msm_bucket(1, nt1, s, bytes(bad), c, None, 0, out, st)
+    assert st.raw[0] == 1 and out.raw[:32] == bytes(32)
+    s2 = bytearray(s)
+    s2[0:32] = T.L.to_bytes(32, "little")
+    H.h_msm_bucket(1, nt1, bytes(s2), p, c, None, 0, out, st)
+    assert st.raw[0] == 2
+    # single-MSM mode: 6 "proofs" of 5 terms each, proofs 1 and 4 rejected -> their terms stay out of the combination
+    n = 30
+    s = b"".join(_sc(b"rl-s%d" % i) for i in range(n))
+    p = b"".join(_pt(oracle, b"rl-p%d" % i) for i in range(n))
+    nts = (C.c_uint32 * 6)(*[5] * 6)
+    skip = (C.c_uint32 * 6)(0, 1, 0, 0, 2, 0)
+    assert H.h_msm_bucket(6, nts, s, p, c, skip, 5, out, st) == 0
+    keep = [i for i in range(n) if i // 5 not in (1, 4)]
+    assert out.raw[:32] == oracle.msm(b"".join(s[32 * i:32 * i + 32] for i in keep), b"".join(p[32 * i:32 * i + 32] for i in keep))[1]
+
+
 @pytest.mark.parametrize("W,nsplit", [(4, 3), (5, 8), (7, 1)])
 def test_shared_generator_pipeline_lane_by_lane(H, oracle, W, nsplit):
     g = oracle.Gens(8, 2)

@@ -54,6 +54,10 @@ def test_bench_runs_with_n_ranks(gpus):
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "12", "--warmup", "2", "--streams", "4",
                           "--window-bits", "10", "--no-cpu-baseline", "--no-extra"], env=env, capture_output=True, text=True, timeout=900)
+    if out.returncode != 0:   # keep the ranks' own tracebacks (gpurun_out/ travels back from the GPU box)
+        os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+        with open(os.path.join(ROOT, "gpurun_out", "test_bench_ranks_%d.err" % gpus), "w") as f:
+            f.write(out.stderr)
     assert out.returncode == 0, out.stderr[-3000:]
     line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
     j = json.loads(line)

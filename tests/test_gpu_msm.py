@@ -205,3 +205,49 @@ def test_device_pointer_entry_points_with_torch_streams(oracle):
     rc = L.bpgpu_rangeproof_verify_batch_dev(c.h, 8, 1, 1, d_misc.data_ptr() + 1, 480, d_misc.data_ptr(), b"x", 1, None, d_st.data_ptr(), None, None)
     assert rc == -1
     c.close()
+
+
+def _fast_points(oracle, seed, n, distinct=257):
+    """n encodings drawn (with repetition) from `distinct` derived points: large MSMs without n Elligator calls in Python"""
+    base = _points(oracle, seed, min(n, distinct))
+    k = len(base) // 32
+    return b"".join(base[32 * ((7 * i + i // k) % k):32 * ((7 * i + i // k) % k) + 32] for i in range(n))
+
+
+def _fast_scalars(seed, n):
+    raw = bytearray(hashlib.shake_256(seed).digest(32 * n))
+    for i in range(31, len(raw), 32):
+        raw[i] &= 0x0f            # < 2^252 < l: canonical
+    return bytes(raw)
+
+
+@pytest.mark.parametrize("sizes", [[256], [2081], [6179], [20000], [0, 300, 192, 1000, 5, 191, 2081], [7000, 0, 6500]])
+def test_bucket_path_sizes_bit_exact(ctx, oracle, sizes):
+    """The bucket (Pippenger) path of bpgpu_msm_batch (bucket.h: taken from 192 terms per MSM on average; c = 8 below 6000
+    terms, c = 12 above): sizes around the thresholds, the R1CS verifier's 2081 / 6179 (r1cs/verifier.rs:459-491), 20 000,
+    ragged batches with empty MSMs -- each result bit-exact vs the oracle's MSM (reference split Straus / Pippenger), and
+    equal to the table-lookup path on the same inputs."""
+    import bulletproofs_amd as bp
+    S = b"".join(_fast_scalars(b"bk-%d-%d" % (k, n), n) for k, n in enumerate(sizes))
+    P = b"".join(_fast_points(oracle, b"bk-%d" % k, n) for k, n in enumerate(sizes))
+    out, st = ctx.msm_batch(sizes, S, P)
+    off = 0
+    for k, n in enumerate(sizes):
+        exp = oracle.msm(S[off:off + 32 * n], P[off:off + 32 * n])
+        off += 32 * n
+        assert st[k] == 0 and out[32 * k:32 * k + 32] == exp[1], (k, n)
+    c2 = bp.Context(0)
+    c2.set_option("bucket_min_terms", 2**31 - 1)       # force the table-lookup path
+    out2, st2 = c2.msm_batch(sizes, S, P)
+    c2.close()
+    assert out2 == out and st2 == st
+    if sizes == [2081]:      # a bad point / a non-canonical scalar inside a bucket-path MSM
+        bad = bytearray(P)
+        bad[32 * 1000] |= 1
+        o, s_ = ctx.msm_batch(sizes, S, bytes(bad))
+        assert s_[0] == 1 and o == bytes(32)
+        L = 2**252 + 27742317777372353535851937790883648493
+        s2 = bytearray(S)
+        s2[32 * 77:32 * 78] = L.to_bytes(32, "little")
+        o, s_ = ctx.msm_batch(sizes, bytes(s2), P)
+        assert s_[0] == 2
