@@ -59,6 +59,8 @@ def parse_args():
                     help="independent (context, HIP stream) pairs the steps are issued on round-robin, so that "
                          "consecutive batches overlap on the device (one context per stream, as bpgpu.h prescribes "
                          "for concurrent callers)")
+    ap.add_argument("--bucket-min", type=int, default=0, help="bucket_min_terms option of the library (0 = default; a huge value forces the table-lookup path)")
+    ap.add_argument("--cfg5-only", type=int, default=0, help="run only the cfg5-shape MSM figure on this many streams and print it")
     ap.add_argument("--repeat", type=int, default=0, help="timed regions of K steps each (0 = auto: 1 when K steps reach steady state, else enough for ~1 s); the median is reported")
     ap.add_argument("--same-input", action="store_true", help="verify the SAME slice every step (the round-1 behaviour; for the cache A/B in DESIGN.md)")
     ap.add_argument("--rlc", action="store_true",
@@ -156,9 +158,11 @@ class RangeProofBench:
         for _ in range(nstreams):
             c_ = bp.Context(local_dev, fixed_window_bits=a.window_bits or None, horner_lanes=a.horner_lanes or None,
                             fixed_splits=a.splits or None, fixed_table_max_bytes=a.table_bytes or None)
+            if a.bucket_min:
+                c_.set_option("bucket_min_terms", a.bucket_min)
             c_.gens_create(fx.n, fx.m)
             self.ctxs.append(c_)
-        self.streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(nstreams - 1)]
+        self.streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
         self.d_verdicts = None
         self.issued = 0
 
@@ -208,8 +212,9 @@ class RangeProofBench:
         for i in range(K):
             self.step(g0 + i, self.d_verdicts[i], rlc)
         t_enq = time.perf_counter() - t0
-        for s_ in self.streams[1:]:
-            self.streams[0].wait_stream(s_)                  # verdicts of every stream are complete before the gather
+        cur = torch.cuda.current_stream()
+        for s_ in self.streams:
+            cur.wait_stream(s_)                              # verdicts of every stream are complete before the gather
         allv = gather(self.d_verdicts[:K]) if gather else None
         fence()
         dt = time.perf_counter() - t0
@@ -323,7 +328,7 @@ def roofline_block(cfg, n, m, batch, kern, value, wl, events_every, default_batc
             "kernels_us": {k: round(v[1] / v[0] * 1e3, 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}}
 
 
-def bench_cfg5_shape(a, local_dev, steps=48):
+def bench_cfg5_shape(a, local_dev, steps=48, nstreams=8):
     """BASELINE config 5's MSM shape: N = 6179 = 4098 generator terms (tables) + 2081 per-MSM points, batches of 64 MSMs,
     through bpgpu_msm_batch_shared_dev; inputs resident in HBM.  Informational (`extra`)."""
     import torch
@@ -332,10 +337,11 @@ def bench_cfg5_shape(a, local_dev, steps=48):
     L = bp.lib()
     n, m, nb, nu = 2048, 1, 64, 2081
     ng = 2 * n * m + 2
-    nstreams = 8
     ctxs = []
     for _ in range(nstreams):
         c_ = bp.Context(local_dev)
+        if a.bucket_min:
+            c_.set_option("bucket_min_terms", a.bucket_min)
         c_.gens_create(n, m)
         ctxs.append(c_)
     G, H, B, Bb = ctxs[0].gens_export()
@@ -424,6 +430,9 @@ def self_launch(a):
 
 def main():
     a = parse_args()
+    if a.cfg5_only:
+        print(json.dumps(bench_cfg5_shape(a, 0, 48, a.cfg5_only)))
+        return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)
     import torch

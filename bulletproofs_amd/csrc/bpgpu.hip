@@ -691,11 +691,12 @@ struct bk_dev {
     uint32_t *idx;         // [nwin][total]
     bk_desc *desc;         // [nmsm * nwin][half]
     ge_ext *bsum;          // [nmsm * nwin][half]
+    ge_ext *gS, *gA;       // [nmsm * nwin][leaves]: bottom level of the running-sum tree
     uint32_t *colq16;      // [nmsm][64][32 words]
     ge_ext *hq;            // [nmsm]
 };
 static uint32_t pick_bucket_c(size_t terms_per_msm) { return terms_per_msm >= 6000 ? 12u : 8u; }
-static void plan_bucket(arena_plan &ap, size_t nmsm, size_t total, bk_params prm, size_t off[8]) {
+static void plan_bucket(arena_plan &ap, size_t nmsm, size_t total, bk_params prm, size_t off[10]) {
     off[0] = ap.add((nmsm + 1) * 4);
     off[1] = ap.add(total * sizeof(fb_entry) + 16);
     off[2] = ap.add(total * BK_RWORDS * 4 + 16);
@@ -704,8 +705,10 @@ static void plan_bucket(arena_plan &ap, size_t nmsm, size_t total, bk_params prm
     off[5] = ap.add(nmsm * prm.nwin * prm.half * sizeof(ge_ext));
     off[6] = ap.add(nmsm * 64 * 128);
     off[7] = ap.add(nmsm * sizeof(ge_ext));
+    off[8] = ap.add(nmsm * prm.nwin * bk_leaves(prm) * sizeof(ge_ext));
+    off[9] = ap.add(nmsm * prm.nwin * bk_leaves(prm) * sizeof(ge_ext));
 }
-static void bucket_bind(bpgpu_ctx *c, const size_t off[8], bk_dev &d) {
+static void bucket_bind(bpgpu_ctx *c, const size_t off[10], bk_dev &d) {
     char *a = c->arena;
     d.msm_first = (uint32_t *)(a + off[0]);
     d.pts = (fb_entry *)(a + off[1]);
@@ -715,6 +718,15 @@ static void bucket_bind(bpgpu_ctx *c, const size_t off[8], bk_dev &d) {
     d.bsum = (ge_ext *)(a + off[5]);
     d.colq16 = (uint32_t *)(a + off[6]);
     d.hq = (ge_ext *)(a + off[7]);
+    d.gS = (ge_ext *)(a + off[8]);
+    d.gA = (ge_ext *)(a + off[9]);
+}
+// bucket sums -> window sums (running-sum tree: wide leaf level, packed upper levels) -> column sums for the Horner chain
+static void enqueue_bucket_reduce(bpgpu_ctx *c, hipStream_t s, bk_params prm, uint32_t nbw, bk_dev &d) {
+    const uint32_t nl = nbw * bk_leaves(prm);
+    LAUNCH(c, s, "bk_leaf", k_bk_leaf, (nl + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nl, prm, d.bsum, d.gS, d.gA);
+    if (prm.c == 8) LAUNCH(c, s, "bk_tree", k_bk_tree<8>, (nbw + 63) / 64, 64, prm, nbw, d.gS, d.gA, d.colq16);
+    else LAUNCH(c, s, "bk_tree", k_bk_tree<12>, (nbw + 1) / 2, 64, prm, nbw, d.gS, d.gA, d.colq16);
 }
 // first-term offsets of the MSMs -> device (through pinned staging)
 static int bucket_upload_first(bpgpu_ctx *c, hipStream_t s, size_t nmsm, const uint32_t *n_terms, size_t uniform_per, bk_dev &d) {
@@ -738,8 +750,7 @@ static int enqueue_bucket_tail(bpgpu_ctx *c, hipStream_t s, bk_params prm, size_
     else LAUNCH(c, s, "bk_sort", k_bk_sort<256>, nbw, 256, prm, d.msm_first, tot32, 0, d.rwords, d.idx, d.desc, (const uint32_t *)nullptr, 0u);
     const uint32_t nt = nbw * prm.half;
     LAUNCH(c, s, "bk_accum", k_bk_accum, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, prm, tot32, d.desc, d.idx, d.pts, d.bsum);
-    if (prm.lanes == 64) LAUNCH(c, s, "bk_reduce", k_bk_reduce<64>, nbw, 64, prm, d.bsum, d.colq16);
-    else LAUNCH(c, s, "bk_reduce", k_bk_reduce<256>, nbw, 256, prm, d.bsum, d.colq16);
+    enqueue_bucket_reduce(c, s, prm, nbw, d);
     LAUNCH(c, s, "horner_wave", k_horner_wave, (uint32_t)nmsm, 64, d.colq16, d.hq);
     return BPGPU_OK;
 }
@@ -756,7 +767,7 @@ static int msm_batch_dev_locked(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_t
         const bk_params prm = bk_make(pick_bucket_c(total / nbatch));
         if (total / nbatch >= (c->bucket_min ? c->bucket_min : BK_MIN_TERMS) && bucket_fits(nbatch, total, prm)) {
             arena_plan ap;
-            size_t off[8];
+            size_t off[10];
             plan_bucket(ap, nbatch, total, prm, off);
             const size_t off_status = ap.add(nbatch * 4);
             int rc = arena_reserve(c, ap.total);
@@ -910,7 +921,7 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
     const bk_params bkp = bk_make(pick_bucket_c(n_unique));
     const bool use_bucket = n_unique >= (c->bucket_min ? c->bucket_min : BK_MIN_TERMS) && bucket_fits(nbatch, nbatch * n_unique, bkp);
     arena_plan ap;
-    size_t off[7], boff[8];
+    size_t off[7], boff[10];
     if (use_bucket) plan_bucket(ap, nbatch, nbatch * n_unique, bkp, boff);
     else plan_vb_uniform(ap, nbatch, n_unique, off);
     const size_t off_status = ap.add(nbatch * 4);
@@ -1252,9 +1263,9 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     // batch combination with enough per-proof terms: ONE bucket MSM (bucket.h) over all proofs' weighted terms
     const size_t rlc_terms = (size_t)nbatch * sh.U;
     const bk_params bkp = bk_make(pick_bucket_c(rlc_terms));
-    const bool rlc_bucket = rlc && !shape_verdict && rlc_terms >= (c->bucket_min ? c->bucket_min : BK_MIN_TERMS) && bucket_fits(1, rlc_terms, bkp);
+    const bool rlc_bucket = rlc && !shape_verdict && rlc_terms >= (c->bucket_min ? c->bucket_min : BK_RLC_MIN_TERMS) && bucket_fits(1, rlc_terms, bkp);
     arena_plan ap;
-    size_t off[7], boff[8];
+    size_t off[7], boff[10];
     if (rlc_bucket) plan_bucket(ap, 1, rlc_terms, bkp, boff);
     else plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off);
     const size_t off_digits = ap.add((size_t)npairs * nbatch * sizeof(fb_digit) + 16);
@@ -1375,8 +1386,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         const uint32_t nt = bkp.nwin * bkp.half, n_acc = (nt + BP_BLOCK - 1) / BP_BLOCK, n_sc = (n_gen_terms + BP_BLOCK - 1) / BP_BLOCK;
         LAUNCH(c, s, "rlc_accum", k_rlc_accum_scalars, n_acc + n_sc, BP_BLOCK, n_acc, nt, bkp, tot32, bd.desc, bd.idx, bd.pts, bd.bsum, n_gen_terms,
                (const unsigned long long *)d_acc, d_dig1, prm, d_ctl);
-        if (bkp.lanes == 64) LAUNCH(c, s, "bk_reduce", k_bk_reduce<64>, bkp.nwin, 64, bkp, bd.bsum, bd.colq16);
-        else LAUNCH(c, s, "bk_reduce", k_bk_reduce<256>, bkp.nwin, 256, bkp, bd.bsum, bd.colq16);
+        enqueue_bucket_reduce(c, s, bkp, bkp.nwin, bd);
         LAUNCH(c, s, "rlc_stage4", k_rlc_stage4b, 1 + nsplit1, FB_BLOCK, bd.colq16, bd.hq, prm, nsplit1, npairs, d_ids, d_dig1, c->d_table, d_part1);
         if (d_batch_out)
             LAUNCH(c, s, "rlc_finish", k_rlc_finish<true>, 1, 64, nsplit1, bd.hq, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)d_batch_out);

@@ -12,14 +12,15 @@
 //                                       (nearly) equal length
 //   bk_accum   : lane = (MSM, window, bucket rank)   bucket sum: one mixed addition (7 multiplications) per listed
 //                                       term, software-pipelined gathers of the 128-byte point records
-//   bk_reduce  : workgroup = (MSM, window)   sum_j j * B_j by a tree of running sums: every node keeps
+//   bk_leaf / bk_tree : window sum = sum_j j * B_j by a tree of running sums: every node keeps
 //                                       (S, A) = (sum of its buckets, sum of (j - j0 + 1) B_j) and a parent of k children
-//                                       of width w forms S = sum S_i, A = sum A_i + w * sum i S_i with one running sum
+//                                       of width w forms S = sum S_i, A = sum A_i + w * sum i S_i with one running sum;
+//                                       lane = leaf for the bottom level, upper levels packed many windows per wavefront
 //   then the window sums enter the existing Horner chain (horner_wave.h) as radix-16 column sums: window w of c
 //   bits is column (c/4) w, the columns in between are the identity.
 //
-// c = 8 (32 windows x 128 buckets) for MSMs of a few hundred to a few thousand terms, c = 12 (22 windows x 2048
-// buckets) beyond: the per-window cost is N + 2^(c-1) * ~3.7 additions.  Results are bit-identical to the
+// c = 8 (32 windows x 128 buckets) for MSMs of up to a few thousand terms, c = 12 (22 windows x 2048
+// buckets) beyond: the per-window cost is N + 2^(c-1) * ~2.5 additions.  Results are bit-identical to the
 // table-lookup path (msm_vb.h) and to the oracle because only the canonical encoding of the sum is ever compared:
 // the order of additions inside a bucket (set by atomics) does not change the group element.
 //
@@ -46,7 +47,14 @@ BP_HD bk_params bk_make(uint32_t c) {
     return p;
 }
 #define BK_RWORDS 9          // recoded scalar: < 2^264
-#define BK_MIN_TERMS 192     // below this many terms per MSM the table-lookup path (msm_vb.h) is used
+// Measured crossovers (MI355X, tools/msm_crossover.py, profiles/r02/msm_crossover.txt): a single MSM gains from the
+// buckets from ~2000 terms (1.8x at 8192, 3.1x at 20 000, 6.6x at 65 536), a batch of 64 MSMs from ~1500 terms per MSM
+// (1.25x at 2081, 1.43x at 4096); below that the per-point 8-entry tables of msm_vb.h win (fewer, wider launches).
+#define BK_MIN_TERMS 1536     // terms per MSM from which the bucket path is taken (option "bucket_min_terms")
+// The batch-combined range-proof check is ONE MSM over batch * (4 + 2k + m) terms, but it sits in a chain of narrow
+// launches where the extra sort / tree levels cost latency: measured at 17 408 terms (cfg2, batch 1024) the bucket
+// variant does 7.5 M proofs/s against 8.1 M/s, so it is taken only for larger combinations.
+#define BK_RLC_MIN_TERMS 49152
 
 // bucket descriptor, sorted by population (descending) inside each (MSM, window)
 struct bk_desc {
@@ -67,21 +75,36 @@ static inline uint32_t bk_host_atomic_add(uint32_t *p, uint32_t v) {
 #define BK_ATOMIC_ADD(p, v) bk_host_atomic_add((p), (v))
 #endif
 
-// r = s + sum_{w < nwin} half << (c w)   (s canonical, < 2^253; r < 2^(c nwin))
-BP_HD void bk_recode(uint32_t r[BK_RWORDS], const uint32_t s[8], bk_params prm) {
+// r = s + k l + sum_{w < nwin} half << (c w),  k = a pseudo-random multiple count derived from the term index `salt`.
+// Adding multiples of the group order l does not change the result: l P lies in the 4-torsion for every decoded
+// ristretto point (they are even points of the curve), and the ristretto encoding is invariant under it -- the same
+// fact that makes P + (l - 1) P encode as the identity.  What it buys: the scalar the windows see is uniform over
+// [0, K l) whatever the caller's scalars are, so (i) the TOP window, which for canonical scalars (< 2^253) would only
+// ever hold the digits 0, 1, 2 -- i.e. one bucket with half of all terms, a serial chain for one lane -- is as evenly
+// populated as the others, and (ii) equal or structured scalars (all ones, small values) no longer pile up in one
+// bucket per window.  K = 7 (c = 8: 7 l < 2^255 - 2^247) / 1024 (c = 12: 1024 l < 2^263), so r < 2^(c nwin).
+BP_HD void bk_recode(uint32_t r[BK_RWORDS], const uint32_t s[8], bk_params prm, uint32_t salt) {
+    const uint32_t l[8] = BP_L_WORDS;
+    const uint32_t h = (salt * 0x9E3779B1u) >> 12;
+    const uint32_t k = prm.c == 8 ? h % 7u : (h & 1023u);
+    uint64_t carry = 0;
 #pragma unroll
-    for (int i = 0; i < 8; i++) r[i] = s[i];
-    r[8] = 0;
+    for (int i = 0; i < 8; i++) {
+        const uint64_t t = (uint64_t)s[i] + (uint64_t)k * l[i] + carry;
+        r[i] = (uint32_t)t;
+        carry = t >> 32;
+    }
+    r[8] = (uint32_t)carry;
     for (uint32_t w = 0; w < prm.nwin; w++) {
         const uint32_t bit = w * prm.c + (prm.c - 1);
         uint32_t idx = bit >> 5;
         uint64_t t = (uint64_t)r[idx] + (1u << (bit & 31));
         r[idx] = (uint32_t)t;
-        uint32_t carry = (uint32_t)(t >> 32);
-        while (carry && ++idx < BK_RWORDS) {
-            t = (uint64_t)r[idx] + carry;
+        uint32_t cy = (uint32_t)(t >> 32);
+        while (cy && ++idx < BK_RWORDS) {
+            t = (uint64_t)r[idx] + cy;
             r[idx] = (uint32_t)t;
-            carry = (uint32_t)(t >> 32);
+            cy = (uint32_t)(t >> 32);
         }
     }
 }
@@ -132,7 +155,7 @@ BP_HD void bk_prepare_thread(uint32_t t, uint32_t nbatch, const uint32_t *msm_fi
     const bool canon = sc_is_canonical(sw);
     if (!canon) status_raise(status + msm, BP_STATUS_BAD_SCALAR);
     else if (!ok) status_raise(status + msm, BP_STATUS_BAD_POINT);
-    bk_recode(r, sw, prm);
+    bk_recode(r, sw, prm, t);
 #pragma unroll
     for (int i = 0; i < BK_RWORDS; i++) rwords[BK_RWORDS * (uint64_t)t + i] = r[i];
     bk_store_point(pts + t, p);
@@ -232,16 +255,16 @@ BP_HD void bk_accum_thread(uint32_t bw, uint32_t r, bk_params prm, const bk_desc
     ge_ext acc;
     ge_identity(acc);
     if (d.cnt) {
+        // software pipeline: the index of term i+2 and the point record of term i+1 are in flight while term i is added
         uint32_t e_cur = idx_w[d.off];
+        uint32_t e_next = d.cnt > 1 ? idx_w[d.off + 1] : 0u;
         fb_line line_cur;
         fb_load_line(line_cur, pts + (e_cur & 0x7fffffffu));
         for (uint32_t i = 0; i < d.cnt; i++) {
             fb_line line_next = line_cur;
-            uint32_t e_next = 0;
-            if (i + 1 < d.cnt) {
-                e_next = idx_w[d.off + i + 1];
-                fb_load_line(line_next, pts + (e_next & 0x7fffffffu));
-            }
+            uint32_t e_next2 = 0;
+            if (i + 1 < d.cnt) fb_load_line(line_next, pts + (e_next & 0x7fffffffu));
+            if (i + 2 < d.cnt) e_next2 = idx_w[d.off + i + 2];
             ge_niels n;
 #pragma unroll
             for (int q = 0; q < 10; q++) {
@@ -254,47 +277,53 @@ BP_HD void bk_accum_thread(uint32_t bw, uint32_t r, bk_params prm, const bk_desc
             else ge_madd(acc, acc, n, neg);
             line_cur = line_next;
             e_cur = e_next;
+            e_next = e_next2;
         }
     }
     bsum[(uint64_t)bw * prm.half + d.bucket] = acc;
 }
 
-// ---- stage 4: workgroup = (MSM, window): sum_j (j + 1) * B_j, j = bucket index ----------------------------------
-// leaf: lane l owns the m = half / lanes buckets [l m, (l + 1) m)
-BP_HD void bk_reduce_leaf(uint32_t lane, bk_params prm, const ge_ext *bsum_bw /*[half]*/, ge_ext *S, ge_ext *A) {
-    const uint32_t m = prm.half / prm.lanes, j0 = lane * m;
-    ge_ext run = bsum_bw[j0 + m - 1], acc = run;
+// ---- stage 4: window sum = sum_j (j + 1) * B_j, j = bucket index, by a tree of running sums ------------------------
+// Every node of the tree covers a contiguous range of buckets [j0, j0 + width) and keeps
+//     S = sum of its buckets,   A = sum_j (j - j0 + 1) B_j .
+// A leaf forms both with one running sum over its m buckets (2 m - 2 additions); a parent of k children of `width`
+// buckets each forms S = sum S_i, A = sum A_i + width * sum_i i S_i with one running sum over the children
+// (3 k - 2 additions + lg(width) doublings).  The root's A is the window sum.
+// Leaves are wide (one lane per leaf of every window of every MSM: bk_leaf_thread); the upper levels are packed so
+// that a wavefront serves many windows at once (k_bk_tree).
+BP_HD uint32_t bk_leaves(bk_params prm) { return prm.c == 8 ? 8u : 256u; }   // leaves per window: 16 / 8 buckets each
+// tid = bw * leaves + l
+BP_HD void bk_leaf_thread(uint32_t tid, bk_params prm, const ge_ext *bsum, ge_ext *gS, ge_ext *gA) {
+    const uint32_t nl = bk_leaves(prm), bw = tid / nl, l = tid - bw * nl, m = prm.half / nl;
+    const ge_ext *b = bsum + (uint64_t)bw * prm.half + (uint64_t)l * m;
+    ge_ext run = b[m - 1], acc = run;
     for (uint32_t i = m - 1; i-- > 0;) {
-        const ge_ext q = bsum_bw[j0 + i];
+        const ge_ext q = b[i];
         ge_add(run, run, q);
         ge_add(acc, acc, run);
     }
-    S[lane] = run;
-    A[lane] = acc;
+    gS[tid] = run;
+    gA[tid] = acc;
 }
-// one level: node g (stored at slot g * k * stride) absorbs its k children at slots (g k + i) stride; a child spans
-// `width` buckets.  S = sum S_i, A = sum A_i + width * sum i S_i.  width is a power of two.
-BP_HD void bk_reduce_node(uint32_t g, uint32_t k, uint32_t stride, uint32_t width, ge_ext *S, ge_ext *A) {
-    const uint32_t base = g * k * stride;
-    ge_ext run = S[base + (k - 1) * stride], acc = run, asum = A[base + (k - 1) * stride];
+// parent of the k children at S[first + i * stride], A[first + i * stride]; a child spans `width` buckets (a power of two)
+BP_HD void bk_combine(ge_ext &S_out, ge_ext &A_out, const ge_ext *S, const ge_ext *A, uint32_t first, uint32_t k, uint32_t stride, uint32_t width) {
+    ge_ext run = S[first + (k - 1) * stride], acc = run, asum = A[first + (k - 1) * stride];
     for (uint32_t i = k - 1; i-- > 1;) {
-        const ge_ext s = S[base + i * stride], a = A[base + i * stride];
+        const ge_ext s = S[first + i * stride], a = A[first + i * stride];
         ge_add(run, run, s);
         ge_add(acc, acc, run);     // after the loop: acc = sum_{i >= 1} i S_i
         ge_add(asum, asum, a);
     }
     {
-        const ge_ext s0 = S[base], a0 = A[base];
+        const ge_ext s0 = S[first], a0 = A[first];
         ge_add(run, run, s0);
         ge_add(asum, asum, a0);
     }
     for (uint32_t wd = width; wd > 1; wd >>= 1) ge_dbl(acc, acc, wd == 2);
     ge_add(asum, asum, acc);
-    S[base] = run;
-    A[base] = asum;
+    S_out = run;
+    A_out = asum;
 }
-// children per level for `lanes` leaves: 64 = 8 x 8, 256 = 8 x 8 x 4
-BP_HD uint32_t bk_reduce_fanout(uint32_t nodes) { return nodes >= 8 ? 8u : nodes; }
 
 // window sum -> the MSM's radix-16 column sums for the wavefront Horner chain: column (c/4) w carries the window
 // sum, the columns up to the next window (if they exist) the identity

@@ -57,28 +57,49 @@ __global__ void __launch_bounds__(BP_BLOCK) k_bk_accum(uint32_t nthreads, bk_par
     bk_accum_thread(bw, r, prm, desc, idx + (uint64_t)w * total, pts, bsum);
 }
 
-// workgroup = (MSM, window): running-sum tree over the window's buckets, then the window sum goes to the MSM's
-// radix-16 column sums (colq16[b][64][32 words]) for the Horner chain
-template <int LANES>
-__global__ void __launch_bounds__(LANES) k_bk_reduce(bk_params prm, const ge_ext *bsum, uint32_t *colq16) {
-    __shared__ ge_ext S[LANES], A[LANES];
-    const uint32_t bw = blockIdx.x, lane = threadIdx.x;
-    bk_reduce_leaf(lane, prm, bsum + (uint64_t)bw * prm.half, S, A);
-    __syncthreads();
-    uint32_t nodes = LANES, stride = 1, width = prm.half / LANES;
-    while (nodes > 1) {
-        const uint32_t k = bk_reduce_fanout(nodes), groups = nodes / k;
-        if (lane < groups) bk_reduce_node(lane, k, stride, width, S, A);
-        __syncthreads();
-        nodes = groups;
-        stride *= k;
-        width *= k;
-    }
-    if (lane == 0) {
+// bottom level of the running-sum tree: lane = (MSM, window, leaf)
+__global__ void __launch_bounds__(BP_BLOCK) k_bk_leaf(uint32_t nthreads, bk_params prm, const ge_ext *bsum, ge_ext *gS, ge_ext *gA) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < nthreads) bk_leaf_thread(tid, prm, bsum, gS, gA);
+}
+
+// upper levels, packed: c = 8: 8 leaves per window -> one lane per window (64 windows per wavefront);
+// c = 12: 256 leaves per window -> 32 + 4 + 1 nodes, two windows per wavefront, levels exchanged through LDS.
+// The root's A is the window sum; it goes to the MSM's radix-16 column sums (colq16[b][64][32 words]).
+template <int C>
+__global__ void __launch_bounds__(64) k_bk_tree(bk_params prm, uint32_t nbw, const ge_ext *gS, const ge_ext *gA, uint32_t *colq16) {
+    const uint32_t lane = threadIdx.x;
+    if (C == 8) {
+        const uint32_t bw = blockIdx.x * 64 + lane;
+        if (bw >= nbw) return;
+        ge_ext S, A;
+        bk_combine(S, A, gS, gA, bw * 8, 8, 1, 16);
         const uint32_t b = bw / prm.nwin, w = bw - b * prm.nwin;
-        const ge_ext sum = A[0];
-        bk_emit_columns(w, prm, sum, colq16 + (uint64_t)b * 64 * 32);
+        bk_emit_columns(w, prm, A, colq16 + (uint64_t)b * 64 * 32);
+    } else {
+        __shared__ ge_ext lS[64], lA[64];
+        const uint32_t wi = lane >> 5, g = lane & 31, bw = blockIdx.x * 2 + wi;
+        const bool live = bw < nbw;
+        ge_ext S, A;
+        if (live) {
+            bk_combine(S, A, gS, gA, bw * 256 + g * 8, 8, 1, 8);          // 256 leaves of 8 buckets -> 32 nodes of 64
+            lS[lane] = S;
+            lA[lane] = A;
+        }
+        __syncthreads();
+        if (live && g < 4) bk_combine(S, A, lS, lA, wi * 32 + g * 8, 8, 1, 64);   // -> 4 nodes of 512
+        __syncthreads();
+        if (live && g < 4) {
+            lS[wi * 32 + g * 8] = S;
+            lA[wi * 32 + g * 8] = A;
+        }
+        __syncthreads();
+        if (live && g == 0) {
+            bk_combine(S, A, lS, lA, wi * 32, 4, 8, 512);                  // -> the window sum
+            const uint32_t b = bw / prm.nwin, w = bw - b * prm.nwin;
+            bk_emit_columns(w, prm, A, colq16 + (uint64_t)b * 64 * 32);
+        }
     }
 }
-template __global__ void k_bk_reduce<64>(bk_params, const ge_ext *, uint32_t *);
-template __global__ void k_bk_reduce<256>(bk_params, const ge_ext *, uint32_t *);
+template __global__ void k_bk_tree<8>(bk_params, uint32_t, const ge_ext *, const ge_ext *, uint32_t *);
+template __global__ void k_bk_tree<12>(bk_params, uint32_t, const ge_ext *, const ge_ext *, uint32_t *);

@@ -327,14 +327,14 @@ BP_HD void store_recoded(uint32_t *dst, const sc &s) {
 // a coefficient held in Montgomery form -> (times the proof's batch weight, if any) -> coefficient u of the proof's
 // list `us`: radix-16 recoding (8 words per coefficient), or -- bk_c != 0, bucket path -- the c-bit window recoding
 // of bucket.h (BK_RWORDS words per coefficient)
-BP_HD void rp_emit_coeff(uint32_t *us, uint32_t u, const sc28 &vm, const sc28 *rho_m, uint32_t bk_c) {
+BP_HD void rp_emit_coeff(uint32_t *us, uint32_t u, const sc28 &vm, const sc28 *rho_m, uint32_t bk_c, uint32_t salt = 0) {
     sc28 t = vm;
     if (rho_m) sc28_montmul(t, vm, *rho_m);
     sc s;
     sc_from_mont28(s, t);
     if (bk_c) {
         uint32_t r[BK_RWORDS];
-        bk_recode(r, s.v, bk_make(bk_c));
+        bk_recode(r, s.v, bk_make(bk_c), salt + u);
 #pragma unroll
         for (int q = 0; q < BK_RWORDS; q++) us[u * BK_RWORDS + q] = r[q];
     } else {
@@ -396,9 +396,9 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
         sc28_montmul(inv, inv, um);                       // drop u_ii from the running inverse
         rp_store28(fields, B, fl.uinv_m + ii, p, uim);
         sc28_montmul(sq, um, um);                         // u_i^2   -> L_i coefficient
-        rp_emit_coeff(us, 4 + ii, sq, rho, bk_c);
+        rp_emit_coeff(us, 4 + ii, sq, rho, bk_c, p * sh.U);
         sc28_montmul(sq, uim, uim);                       // u_i^-2  -> R_i coefficient
-        rp_emit_coeff(us, 4 + k + ii, sq, rho, bk_c);
+        rp_emit_coeff(us, 4 + k + ii, sq, rho, bk_c, p * sh.U);
     }
     // what is left in inv is y^-1: table of y^-(2^b)
     {
@@ -459,17 +459,17 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
     {
         sc28 one_m;
         sc28_one_mont(one_m);
-        rp_emit_coeff(us, 0, one_m, rho, bk_c);
+        rp_emit_coeff(us, 0, one_m, rho, bk_c, p * sh.U);
     }
-    rp_emit_coeff(us, 1, xm, rho, bk_c);
-    rp_emit_coeff(us, 2, cxm, rho, bk_c);
-    rp_emit_coeff(us, 3, cxxm, rho, bk_c);
+    rp_emit_coeff(us, 1, xm, rho, bk_c, p * sh.U);
+    rp_emit_coeff(us, 2, cxm, rho, bk_c, p * sh.U);
+    rp_emit_coeff(us, 3, cxxm, rho, bk_c, p * sh.U);
     // V_j coefficients c z^2 z^j, and the z^2 z^j table
     {
         sc28 czzj, zzj = zzm;
         sc28_montmul(czzj, cm, zzm);
         for (uint32_t j = 0; j < sh.m; j++) {
-            rp_emit_coeff(us, 4 + 2 * k + j, czzj, rho, bk_c);
+            rp_emit_coeff(us, 4 + 2 * k + j, czzj, rho, bk_c, p * sh.U);
             if (rho) {
                 sc28 t;
                 sc28_montmul(t, zzj, rho_m);

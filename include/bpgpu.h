@@ -77,7 +77,9 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
  *   "fixed_table_max_bytes" HBM budget of the tables (default 96 GiB; the MI355X has 288 GB)
  *   "fixed_splits"          workgroups the generator terms of one proof block are split over (0 = auto)
  *   "bucket_min_terms"      variable-base terms per MSM from which the bucket (Pippenger) path is taken instead of the
- *                           table-lookup one (default 192; a huge value disables it).  Results are bit-identical.
+ *                           table-lookup one (default 1536; the batch-combined check, one MSM over all proofs' terms,
+ *                           switches at 49152 terms unless this option is set; a huge value disables the bucket
+ *                           path, 1 forces it).  Results are bit-identical either way.
  *   "host_sync_blocking"    1: host-pointer entry points wait for their results on a blocking event (the calling
  *                           thread sleeps: right for many host threads, one context each); 0 (default): spin-wait
  *   "horner_lanes"          lanes per Horner chain of the proof-specific terms in the range-proof path:

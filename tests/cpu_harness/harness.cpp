@@ -482,17 +482,24 @@ int h_msm_bucket(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalar
         bk_accum_thread(bw, r, prm, desc.data(), idx.data() + (size_t)w * total, pts.data(), bsum.data());
     }
     std::vector<uint32_t> colq16((size_t)nmsm * 64 * 32 + 32, 0);
-    std::vector<ge_ext> S(prm.lanes), A(prm.lanes);
+    // running-sum tree: leaf level lane by lane, then the packed upper levels exactly as k_bk_tree walks them
+    const uint32_t nl = bk_leaves(prm);
+    std::vector<ge_ext> gS((size_t)nbw * nl), gA((size_t)nbw * nl);
+    for (uint32_t tid = 0; tid < nbw * nl; tid++) bk_leaf_thread(tid, prm, bsum.data(), gS.data(), gA.data());
     for (uint32_t bw = 0; bw < nbw; bw++) {
-        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_reduce_leaf(lane, prm, bsum.data() + (size_t)bw * prm.half, S.data(), A.data());
-        uint32_t nodes = prm.lanes, stride = 1, width = prm.half / prm.lanes;
-        while (nodes > 1) {
-            const uint32_t k = bk_reduce_fanout(nodes), groups = nodes / k;
-            for (uint32_t lane = 0; lane < groups; lane++) bk_reduce_node(lane, k, stride, width, S.data(), A.data());
-            nodes = groups; stride *= k; width *= k;
+        ge_ext S, A;
+        if (prm.c == 8) {
+            bk_combine(S, A, gS.data(), gA.data(), bw * 8, 8, 1, 16);
+        } else {
+            std::vector<ge_ext> lS(32), lA(32);
+            for (uint32_t g = 0; g < 32; g++) bk_combine(lS[g], lA[g], gS.data(), gA.data(), bw * 256 + g * 8, 8, 1, 8);
+            ge_ext s4[4], a4[4];
+            for (uint32_t g = 0; g < 4; g++) bk_combine(s4[g], a4[g], lS.data(), lA.data(), g * 8, 8, 1, 64);
+            for (uint32_t g = 0; g < 4; g++) { lS[g * 8] = s4[g]; lA[g * 8] = a4[g]; }
+            bk_combine(S, A, lS.data(), lA.data(), 0, 4, 8, 512);
         }
         const uint32_t b = bw / prm.nwin, w = bw - b * prm.nwin;
-        bk_emit_columns(w, prm, A[0], colq16.data() + (size_t)b * 64 * 32);
+        bk_emit_columns(w, prm, A, colq16.data() + (size_t)b * 64 * 32);
     }
     std::vector<ge_ext> hq(nmsm + 1);
     std::vector<uint32_t> outw((size_t)nmsm * 8 + 8), st1(nmsm + 1, 0);

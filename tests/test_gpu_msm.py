@@ -223,14 +223,16 @@ def _fast_scalars(seed, n):
 
 @pytest.mark.parametrize("sizes", [[256], [2081], [6179], [20000], [0, 300, 192, 1000, 5, 191, 2081], [7000, 0, 6500]])
 def test_bucket_path_sizes_bit_exact(ctx, oracle, sizes):
-    """The bucket (Pippenger) path of bpgpu_msm_batch (bucket.h: taken from 192 terms per MSM on average; c = 8 below 6000
-    terms, c = 12 above): sizes around the thresholds, the R1CS verifier's 2081 / 6179 (r1cs/verifier.rs:459-491), 20 000,
+    """The bucket (Pippenger) path of bpgpu_msm_batch (bucket.h; forced here with bucket_min_terms = 1, by default taken
+    from 1536 terms per MSM on average; c = 8 below 6000 terms, c = 12 above): sizes around the thresholds, the R1CS verifier's 2081 / 6179 (r1cs/verifier.rs:459-491), 20 000,
     ragged batches with empty MSMs -- each result bit-exact vs the oracle's MSM (reference split Straus / Pippenger), and
     equal to the table-lookup path on the same inputs."""
     import bulletproofs_amd as bp
     S = b"".join(_fast_scalars(b"bk-%d-%d" % (k, n), n) for k, n in enumerate(sizes))
     P = b"".join(_fast_points(oracle, b"bk-%d" % k, n) for k, n in enumerate(sizes))
-    out, st = ctx.msm_batch(sizes, S, P)
+    cb = bp.Context(0)
+    cb.set_option("bucket_min_terms", 1)                # force the bucket path
+    out, st = cb.msm_batch(sizes, S, P)
     off = 0
     for k, n in enumerate(sizes):
         exp = oracle.msm(S[off:off + 32 * n], P[off:off + 32 * n])
@@ -241,13 +243,15 @@ def test_bucket_path_sizes_bit_exact(ctx, oracle, sizes):
     out2, st2 = c2.msm_batch(sizes, S, P)
     c2.close()
     assert out2 == out and st2 == st
+    assert ctx.msm_batch(sizes, S, P) == (out, st)      # and whatever the default picks
     if sizes == [2081]:      # a bad point / a non-canonical scalar inside a bucket-path MSM
         bad = bytearray(P)
         bad[32 * 1000] |= 1
-        o, s_ = ctx.msm_batch(sizes, S, bytes(bad))
+        o, s_ = cb.msm_batch(sizes, S, bytes(bad))
         assert s_[0] == 1 and o == bytes(32)
         L = 2**252 + 27742317777372353535851937790883648493
         s2 = bytearray(S)
         s2[32 * 77:32 * 78] = L.to_bytes(32, "little")
-        o, s_ = ctx.msm_batch(sizes, bytes(s2), P)
+        o, s_ = cb.msm_batch(sizes, bytes(s2), P)
         assert s_[0] == 2
+    cb.close()
