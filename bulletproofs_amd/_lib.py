@@ -21,6 +21,7 @@ EXPORTS = [
     "bpgpu_profile_enable", "bpgpu_profile_reset", "bpgpu_profile_report",
     "bpgpu_transcript_new", "bpgpu_transcript_append_message", "bpgpu_transcript_challenge_bytes",
     "bpgpu_rangeproof_verify_batch_ts", "bpgpu_rangeproof_verify_batch_ts_dev", "bpgpu_ipp_verify_batch_dev",
+    "bpgpu_ipp_create_batch",
 ]
 
 TRANSCRIPT_BYTES = 208
@@ -77,6 +78,7 @@ def lib():
     L.bpgpu_rangeproof_verify_batch_ts.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p, u8p]
     L.bpgpu_rangeproof_verify_batch_ts_dev.argtypes = [vp, sz, sz, sz, vp, sz, vp, u8p, vp, vp, vp, vp, vp, vp]
     L.bpgpu_ipp_verify_batch_dev.argtypes = [vp, sz, sz, vp, sz, u8p, sz, u8p, vp, vp, vp, vp, vp, vp, i, vp, vp, vp]
+    L.bpgpu_ipp_create_batch.argtypes = [vp, sz, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, i, u8p, u8p, u8p, u8p]
     L.bpgpu_profile_enable.argtypes = [vp, i]
     L.bpgpu_profile_reset.argtypes = [vp]
     L.bpgpu_profile_report.argtypes = [vp, C.c_char_p, sz]
@@ -241,6 +243,17 @@ class Context:
         msm = C.create_string_buffer(32 * max(nb, 1)) if want_msm else None
         self._chk(self._L.bpgpu_ipp_verify_batch(self.h, n, nb, proofs, proof_len, label, len(label), Gf, Hf, P, Q, G, H, verdict, msm))
         return (verdict.raw[:nb], msm.raw[:32 * nb]) if want_msm else verdict.raw[:nb]
+
+    def ipp_create_batch(self, n, Q, Gf, Hf, G, H, a, b, label=b"", transcript=None):
+        """InnerProductProof::create for nbatch proofs (bpgpu_ipp_create_batch).  G/H of n*32 bytes = bases shared by the batch.
+        Returns (proofs bytes, status bytes)."""
+        nb = len(Q) // 32
+        assert len(a) == len(b) == len(Gf) == len(Hf) == 32 * n * nb and len(G) == len(H) and len(G) in (32 * n, 32 * n * nb)
+        shared = 1 if (len(G) == 32 * n and nb != 1) else 0
+        pl = 32 * (2 * (n.bit_length() - 1) + 2)
+        out, st = C.create_string_buffer(pl * max(nb, 1)), C.create_string_buffer(max(nb, 1))
+        self._chk(self._L.bpgpu_ipp_create_batch(self.h, n, nb, label, len(label), transcript, Q, Gf, Hf, G, H, shared, a, b, out, st))
+        return out.raw[:pl * nb], st.raw[:nb]
 
     # ---- instrumentation ----
     def profile_enable(self, on=True):

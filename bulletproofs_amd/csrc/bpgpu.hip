@@ -1758,3 +1758,107 @@ extern "C" int bpgpu_ipp_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, con
     if (msm_out) memcpy(msm_out, h_out + sz_v, nbatch * 32);
     return BPGPU_OK;
 }
+
+// ============================================================================
+// batched inner-product-proof creation (ipp_prover.h)
+// ============================================================================
+extern "C" int bpgpu_ipp_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, const uint8_t *label, size_t label_len, const uint8_t *shared_transcript,
+                                      const uint8_t *Q, const uint8_t *G_factors, const uint8_t *H_factors, const uint8_t *G, const uint8_t *H,
+                                      int bases_shared, const uint8_t *a, const uint8_t *b, uint8_t *proofs_out, uint8_t *status_out) {
+    if (!c || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0) return BPGPU_OK;
+    if (!Q || !G_factors || !H_factors || !G || !H || !a || !b || !proofs_out || !status_out) return BPGPU_ERR_INVALID_ARG;
+    if (n == 0 || (n & (n - 1))) return fail(c, BPGPU_ERR_INVALID_ARG, "n must be a power of two (ipp.rs:54-59)");
+    size_t k = 0;
+    while (((size_t)1 << k) < n) k++;
+    if (k > BP_RP_MAX_K) return fail(c, BPGPU_ERR_INVALID_ARG, "n > 2^%d not supported", BP_RP_MAX_K);
+    if ((uint64_t)nbatch * 2 * (n + 1) > 0x7fffffffull / 64) return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large for this shape");
+    if (shared_transcript && !ts_state_ok(shared_transcript)) return fail(c, BPGPU_ERR_INVALID_ARG, "malformed transcript state");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    const size_t proof_len = 32 * (2 * k + 2), TS = BPGPU_TRANSCRIPT_BYTES;
+    // ---- inputs: one pinned staging block -> the persistent device IO buffer
+    const size_t sz_v = align_up(nbatch * n * 32 + 64), sz_q = align_up(nbatch * 32 + 64), sz_base = align_up((bases_shared ? 1 : nbatch) * n * 32 + 64),
+                 sz_ts = align_up(nbatch * TS);
+    const size_t sz_in = 4 * sz_v + sz_q + 2 * sz_base + sz_ts, sz_out = align_up(nbatch * proof_len) + align_up(nbatch);
+    rc = io_reserve(c, sz_in + sz_out);
+    if (rc) return rc;
+    char *h = nullptr;
+    rc = pin_alloc(c, s, sz_in + sz_out, &h);
+    if (rc) return rc;
+    char *d_a = c->io_dev, *d_b = d_a + sz_v, *d_gf = d_b + sz_v, *d_hf = d_gf + sz_v, *d_q = d_hf + sz_v, *d_G = d_q + sz_q, *d_H = d_G + sz_base,
+         *d_ts = d_H + sz_base, *d_proofs = c->io_dev + sz_in, *d_stb = d_proofs + align_up(nbatch * proof_len);
+    memcpy(h, a, nbatch * n * 32);
+    memcpy(h + sz_v, b, nbatch * n * 32);
+    memcpy(h + 2 * sz_v, G_factors, nbatch * n * 32);
+    memcpy(h + 3 * sz_v, H_factors, nbatch * n * 32);
+    memcpy(h + 4 * sz_v, Q, nbatch * 32);
+    memcpy(h + 4 * sz_v + sz_q, G, (bases_shared ? 1 : nbatch) * n * 32);
+    memcpy(h + 4 * sz_v + sz_q + sz_base, H, (bases_shared ? 1 : nbatch) * n * 32);
+    {   // every proof's transcript after innerproduct_domain_sep(n) (transcript.rs:50-53)
+        uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
+        if (shared_transcript) memcpy(st0, shared_transcript, TS);
+        else bpgpu_transcript_new(label, label_len, st0);
+        uint32_t w[50];
+        strobe t;
+        ts_to_strobe(t, w, st0);
+        const uint8_t ipp[6] = {'i', 'p', 'p', ' ', 'v', '1'}, ln[1] = {'n'};
+        merlin_append_message(t, DOM_SEP, 7, ipp, 6);
+        merlin_append_u64(t, ln, 1, n);
+        ts_from_strobe(st0, t);
+        for (size_t p = 0; p < nbatch; p++) memcpy(h + 4 * sz_v + sz_q + 2 * sz_base + p * TS, st0, TS);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->io_dev, h, sz_in, hipMemcpyHostToDevice, s));
+    // ---- working set (own allocation: the MSM below claims the arena)
+    const size_t N = n + 1, w_v = align_up(nbatch * n * 32), w_u = align_up(nbatch * 32), w_terms = align_up(2 * nbatch * N * 32 + 64),
+                 w_out = align_up(2 * nbatch * 32), w_st = align_up(2 * nbatch + 64), w_status = align_up(nbatch * 4);
+    const size_t need = 4 * w_v + 2 * w_u + 2 * w_terms + w_out + w_st + w_status;
+    if (c->ipp_cap < need) {
+        HIPCHK(c, hipDeviceSynchronize());
+        if (c->ipp_buf) HIPCHK(c, hipFree(c->ipp_buf));
+        c->ipp_buf = nullptr;
+        c->ipp_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->ipp_buf, need + need / 4));
+        c->ipp_cap = need + need / 4;
+    }
+    char *wb = c->ipp_buf;
+    uint32_t *w_a = (uint32_t *)wb, *w_b = (uint32_t *)(wb + w_v), *w_G = (uint32_t *)(wb + 2 * w_v), *w_H = (uint32_t *)(wb + 3 * w_v);
+    uint32_t *w_uu = (uint32_t *)(wb + 4 * w_v), *w_ui = (uint32_t *)(wb + 4 * w_v + w_u);
+    uint32_t *m_sc = (uint32_t *)(wb + 4 * w_v + 2 * w_u), *m_pt = (uint32_t *)((char *)m_sc + w_terms), *m_out = (uint32_t *)((char *)m_pt + w_terms);
+    uint8_t *m_st = (uint8_t *)m_out + w_out;
+    uint32_t *d_status = (uint32_t *)(m_st + w_st);
+    HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
+    HIPCHK(c, hipMemsetAsync(d_proofs, 0, nbatch * proof_len, s));
+    ippc_shape sh;
+    sh.n = (uint32_t)n;
+    sh.k = (uint32_t)k;
+    sh.nproofs = (uint32_t)nbatch;
+    sh.bases_shared = bases_shared ? 1u : 0u;
+    const uint32_t nb32 = (uint32_t)nbatch, nt32 = (uint32_t)(nbatch * n);
+    LAUNCH(c, s, "ippc_init", k_ippc_init, (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt32, sh, (const uint8_t *)d_a, (const uint8_t *)d_b, (const uint8_t *)d_gf,
+           (const uint8_t *)d_hf, w_a, w_b, w_G, w_H, d_status);
+    std::vector<uint32_t> nterms(2 * nbatch, (uint32_t)N);
+    const uint32_t n_q = (nb32 + BP_BLOCK - 1) / BP_BLOCK;
+    for (uint32_t j = 0; j < k; j++) {
+        LAUNCH(c, s, "ippc_terms", k_ippc_terms, n_q + (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_q, nt32, sh, j, (const uint32_t *)w_a, (const uint32_t *)w_b,
+               (const uint32_t *)w_G, (const uint32_t *)w_H, (const uint8_t *)d_G, (const uint8_t *)d_H, (const uint8_t *)d_q, m_sc, m_pt);
+        rc = msm_batch_dev_locked(c, 2 * nbatch, nterms.data(), m_sc, m_pt, m_out, m_st, s);   // all L_j and R_j of the batch (ipp.rs:87-113)
+        if (rc) return rc;
+        LAUNCH(c, s, "ippc_challenge", k_ippc_challenge, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, j, (const uint32_t *)m_out, (const uint8_t *)m_st,
+               (uint32_t *)d_ts, w_uu, w_ui, (uint8_t *)d_proofs, (uint32_t)proof_len, d_status);
+        LAUNCH(c, s, "ippc_fold", k_ippc_fold, (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt32, sh, j, (const uint32_t *)w_uu, (const uint32_t *)w_ui, w_a, w_b, w_G,
+               w_H);
+    }
+    LAUNCH(c, s, "ippc_final", k_ippc_final, (nb32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, sh, (const uint32_t *)w_a, (const uint32_t *)w_b, (uint8_t *)d_proofs,
+           (uint32_t)proof_len, (const uint32_t *)d_status, (uint8_t *)d_stb);
+    char *h_out = h + sz_in;
+    if (hipMemcpyAsync(h_out, d_proofs, sz_out, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+    const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
+    if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
+    memcpy(proofs_out, h_out, nbatch * proof_len);
+    memcpy(status_out, h_out + align_up(nbatch * proof_len), nbatch);
+    return BPGPU_OK;
+}

@@ -11,6 +11,7 @@
 #include "rangeproof.h"
 #include "ipp.h"
 #include "bucket.h"
+#include "ipp_prover.h"
 
 #define BP_BLOCK 64   // one wavefront per workgroup: under contention a CU rarely has room for four waves of one group at once (256: -8% at 48 streams)
 #define FB_BLOCK 64
@@ -49,6 +50,12 @@ __global__ void k_from_uniform(uint32_t n, const uint32_t *uniform, uint32_t *ou
 // k_rlc.hip, bucket variant of the batch combination
 __global__ void k_rlc_accum_scalars(uint32_t n_acc, uint32_t nthreads, bk_params bk, uint32_t total, const bk_desc *desc, const uint32_t *idx, const fb_entry *pts, ge_ext *bsum, uint32_t n_rows, const unsigned long long *acc, fb_digit *digits, fb_params prm, uint32_t *ctl);
 __global__ void k_rlc_stage4b(const uint32_t *colq16, ge_ext *hq, fb_params prm, uint32_t nsplit, uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial);
+// k_ippc.hip
+__global__ void k_ippc_init(uint32_t nthreads, ippc_shape sh, const uint8_t *a_in, const uint8_t *b_in, const uint8_t *Gf, const uint8_t *Hf, uint32_t *a, uint32_t *b, uint32_t *wG, uint32_t *wH, uint32_t *status);
+__global__ void k_ippc_terms(uint32_t n_q, uint32_t nthreads, ippc_shape sh, uint32_t j, const uint32_t *a, const uint32_t *b, const uint32_t *wG, const uint32_t *wH, const uint8_t *G, const uint8_t *H, const uint8_t *Q, uint32_t *msm_sc, uint32_t *msm_pt);
+__global__ void k_ippc_challenge(ippc_shape sh, uint32_t j, const uint32_t *msm_out, const uint8_t *msm_status, uint32_t *ts, uint32_t *u, uint32_t *uinv, uint8_t *proofs, uint32_t proof_len, uint32_t *status);
+__global__ void k_ippc_fold(uint32_t nthreads, ippc_shape sh, uint32_t j, const uint32_t *u, const uint32_t *uinv, uint32_t *a, uint32_t *b, uint32_t *wG, uint32_t *wH);
+__global__ void k_ippc_final(ippc_shape sh, const uint32_t *a, const uint32_t *b, uint8_t *proofs, uint32_t proof_len, const uint32_t *status, uint8_t *status_out);
 // k_bucket.hip
 __global__ void k_bk_prepare(uint32_t total, uint32_t nbatch, const uint32_t *msm_first, const uint32_t *scalars, const uint32_t *points, fb_entry *pts, uint32_t *rwords, uint32_t *status, bk_params prm);
 template <int LANES>

@@ -239,6 +239,27 @@ int bpgpu_ipp_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t nbatch, const vo
                                const void *d_G, const void *d_H, int bases_shared,
                                void *d_verdict, void *d_msm_out, void *stream);
 
+/* ---- batched inner-product-proof creation (prover side) --------------------------------
+ * nbatch independent calls of
+ *   InnerProductProof::create(&mut transcript, &Q, G_factors, H_factors, G_vec, H_vec, a_vec, b_vec).to_bytes()
+ * (src/inner_product_proof.rs:38-193), all of one size n (a power of two): per round the reference forms L and R with
+ * two (2n'+1)-term multiscalar multiplications (ipp.rs:87-113) and folds the generators with 2n' two-term ones
+ * (ipp.rs:127-178); here all proofs advance round by round together and every L_j / R_j is one multiscalar
+ * multiplication over the ORIGINAL points (csrc/ipp_prover.h), which yields the same group elements: proofs are
+ * byte-identical to the reference algorithm's.
+ *   transcript  : shared_transcript (host, 208 bytes, may hold earlier messages) if not NULL, else Transcript::new(label);
+ *                 innerproduct_domain_sep(n) is applied here, as create() does
+ *   Q           : nbatch x 32;  G_factors, H_factors, a, b : nbatch x n x 32 (canonical scalars)
+ *   G, H        : nbatch x n x 32, or n x 32 when bases_shared != 0 (compressed points)
+ *   proofs_out  : nbatch x 32 * (2 lg n + 2) bytes: L_1 R_1 ... L_k R_k a b   (InnerProductProof::to_bytes, ipp.rs:334-345)
+ *   status      : nbatch bytes, BPGPU_MSM_* (a point that does not decode / a non-canonical scalar: that proof is void)
+ * VARIABLE TIME in the secret vectors a, b -- as the reference's create(), which calls vartime_multiscalar_mul -- and
+ * therefore no replacement for the constant-time commitments of the range-proof parties (party.rs:119-124). */
+int bpgpu_ipp_create_batch(bpgpu_ctx *ctx, size_t n, size_t nbatch, const uint8_t *label, size_t label_len,
+                           const uint8_t *shared_transcript, const uint8_t *Q, const uint8_t *G_factors,
+                           const uint8_t *H_factors, const uint8_t *G, const uint8_t *H, int bases_shared,
+                           const uint8_t *a, const uint8_t *b, uint8_t *proofs_out, uint8_t *status);
+
 /* ---- instrumentation -----------------------------------------------------------
  * When enabled, every kernel launch is bracketed by HIP events on its stream;
  * bpgpu_profile_report writes one line per kernel: "name launches total_ms". */

@@ -99,6 +99,10 @@ int oracle_prove_ts(const oracle_gens *g, const uint64_t *values, const uint8_t 
 int oracle_ipp_verify(size_t n, const uint8_t *proof, size_t proof_len, const uint8_t *label, size_t label_len,
                       const uint8_t *G_factors, const uint8_t *H_factors, const uint8_t P[32], const uint8_t Q[32],
                       const uint8_t *G, const uint8_t *H, uint8_t msm_out[32]);
+/* InnerProductProof::create(&mut Transcript::new(label), &Q, G_factors = 1, H_factors, G, H, a, b).to_bytes()
+ * (ipp.rs:38-193): proof_out = 32 * (2 lg n + 2) bytes. */
+int oracle_ipp_create(size_t n, const uint8_t *label, size_t label_len, const uint8_t Q[32], const uint8_t *Hf,
+                      const uint8_t *G, const uint8_t *H, const uint8_t *a, const uint8_t *b, uint8_t *proof_out);
 int oracle_ipp_test_instance(size_t n, const uint8_t *label, size_t label_len, const uint8_t *seed, size_t seed_len,
                              uint8_t *proof_out, uint8_t P_out[32], uint8_t Q_out[32], uint8_t *G_out, uint8_t *H_out,
                              uint8_t *Gf_out, uint8_t *Hf_out);

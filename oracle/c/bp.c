@@ -624,6 +624,30 @@ int oracle_ipp_verify(size_t n, const uint8_t *proof, size_t proof_len, const ui
     return rc;
 }
 
+/* InnerProductProof::create(...).to_bytes() (ipp.rs:38-193, 334-345) with G_factors = 1 (what the reference's callers
+ * pass: range_proof/dealer.rs, ipp.rs:454) -- the oracle for the GPU's batched prover.  Returns 1 if a point does not decode. */
+int oracle_ipp_create(size_t n, const uint8_t *label, size_t label_len, const uint8_t Q[32], const uint8_t *Hf,
+                      const uint8_t *G, const uint8_t *H, const uint8_t *a, const uint8_t *b, uint8_t *proof_out) {
+    ge_init();
+    size_t lg = 0; while (((size_t)1 << lg) < n) lg++;
+    ge_p3 Qp, *Gv = malloc(n * sizeof(ge_p3)), *Hv = malloc(n * sizeof(ge_p3));
+    sc *av = malloc(n * sizeof(sc)), *bv = malloc(n * sizeof(sc)), *hf = malloc(n * sizeof(sc));
+    int bad = ristretto_decompress(&Qp, Q) != 0;
+    for (size_t i = 0; i < n; i++) {
+        if (ristretto_decompress(&Gv[i], G + 32 * i)) bad = 1;
+        if (ristretto_decompress(&Hv[i], H + 32 * i)) bad = 1;
+        sc_from_bytes_mod_order(&av[i], a + 32 * i); sc_from_bytes_mod_order(&bv[i], b + 32 * i); sc_from_bytes_mod_order(&hf[i], Hf + 32 * i);
+    }
+    if (!bad) {
+        merlin_transcript t; merlin_init(&t, label, label_len);
+        sc af, bf;
+        ipp_create(&t, &Qp, hf, Gv, Hv, av, bv, n, proof_out, &af, &bf);
+        sc_tobytes(proof_out + 64 * lg, &af); sc_tobytes(proof_out + 64 * lg + 32, &bf);
+    }
+    free(Gv); free(Hv); free(av); free(bv); free(hf);
+    return bad;
+}
+
 int oracle_ipp_test_instance(size_t n, const uint8_t *label, size_t label_len, const uint8_t *seed, size_t seed_len,
                              uint8_t *proof_out, uint8_t P_out[32], uint8_t Q_out[32], uint8_t *G_out, uint8_t *H_out,
                              uint8_t *Gf_out, uint8_t *Hf_out) {

@@ -80,6 +80,7 @@ def lib():
     L.oracle_prove_batch.argtypes = [vp, sz, C.POINTER(C.c_uint64), u8p, sz, sz, u8p, sz, u8p, sz, u8p, u8p, C.c_int]
     L.oracle_ipp_verify.argtypes = [sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.oracle_ipp_test_instance.argtypes = [sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
+    L.oracle_ipp_create.argtypes = [sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.oracle_msm_batch.restype = C.c_double
     L.oracle_msm_batch.argtypes = [sz, sz, u8p, u8p, C.c_int, u8p, u8p, C.c_int]
     _lib = L
@@ -235,6 +236,14 @@ def ipp_test_instance(n, label, seed):
                                         bufs["H"], bufs["Gf"], bufs["Hf"])
     assert rc == 0
     return {k: v.raw for k, v in bufs.items()}
+
+
+def ipp_create(n, label, Q, Hf, G, H, a, b):
+    """InnerProductProof::create(...).to_bytes() with G_factors = 1 (ipp.rs:38-193)."""
+    lg = n.bit_length() - 1
+    out = C.create_string_buffer(32 * (2 * lg + 2))
+    rc = lib().oracle_ipp_create(n, label, len(label), Q, Hf, G, H, a, b, out)
+    return rc, out.raw
 
 
 def ipp_verify(n, proof, label, Gf, Hf, P, Q, G, H):

@@ -13,6 +13,7 @@
 #include "../../bulletproofs_amd/csrc/scinv.h"
 #include "../../bulletproofs_amd/csrc/rlc.h"
 #include "../../bulletproofs_amd/csrc/bucket.h"
+#include "../../bulletproofs_amd/csrc/ipp_prover.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -507,6 +508,44 @@ int h_msm_bucket(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalar
     for (uint32_t b = 0; b < nmsm; b++) vb_horner_thread(b, nullptr, hq.data(), single ? st1.data() : status.data(), outw.data(), nullptr);
     memcpy(out, outw.data(), (size_t)nmsm * 32);
     for (uint32_t b = 0; b < nbatch; b++) status_out[b] = (uint8_t)status[b];
+    return 0;
+}
+
+// The batched inner-product-proof prover (ipp_prover.h), lane by lane; the MSMs go through the variable-base pipeline
+// emulation above.  ts0: the 208-byte transcript state BEFORE innerproduct_domain_sep(n).
+int h_ipp_create(uint32_t n, uint32_t nbatch, const uint8_t *ts0, const uint8_t *Q, const uint8_t *Gf, const uint8_t *Hf, const uint8_t *G,
+                 const uint8_t *H, int bases_shared, const uint8_t *a_in, const uint8_t *b_in, uint8_t *proofs, uint8_t *status_out) {
+    uint32_t k = 0; while ((1u << k) < n) k++;
+    ippc_shape sh; sh.n = n; sh.k = k; sh.nproofs = nbatch; sh.bases_shared = bases_shared ? 1 : 0;
+    const uint32_t proof_len = 32 * (2 * k + 2), N = n + 1;
+    std::vector<uint32_t> a((size_t)nbatch * n * 8), b(a.size()), wG(a.size()), wH(a.size()), status(nbatch + 1, 0), u((size_t)nbatch * 8), ui(u.size());
+    std::vector<uint32_t> ts((size_t)nbatch * BP_TS_WORDS);
+    {
+        uint32_t w[50]; memcpy(w, ts0, 200);
+        strobe t; t.st.w = w; t.st.stride = 1; t.pos = ts0[200]; t.pos_begin = ts0[201]; t.cur_flags = ts0[202];
+        const uint8_t dom[7] = {'d','o','m','-','s','e','p'}, ipp[6] = {'i','p','p',' ','v','1'}, ln[1] = {'n'};
+        merlin_append_message(t, dom, 7, ipp, 6); merlin_append_u64(t, ln, 1, n);
+        for (uint32_t p = 0; p < nbatch; p++) {
+            memcpy(&ts[(size_t)p * BP_TS_WORDS], w, 200);
+            ts[(size_t)p * BP_TS_WORDS + 50] = rp_ts_meta(t.pos, t.pos_begin, t.cur_flags);
+            ts[(size_t)p * BP_TS_WORDS + 51] = 0;
+        }
+    }
+    for (uint32_t tid = 0; tid < nbatch * n; tid++) ippc_init_thread(tid, sh, a_in, b_in, Gf, Hf, a.data(), b.data(), wG.data(), wH.data(), status.data());
+    std::vector<uint32_t> msc((size_t)2 * nbatch * N * 8 + 8), mpt(msc.size()), mout((size_t)2 * nbatch * 8 + 8), nt(2 * nbatch, N);
+    std::vector<uint8_t> mst(2 * nbatch + 1);
+    memset(proofs, 0, (size_t)nbatch * proof_len);
+    for (uint32_t j = 0; j < k; j++) {
+        for (uint32_t p = 0; p < nbatch; p++) ippc_q_thread(p, sh, j, a.data(), b.data(), Q, msc.data(), mpt.data());
+        for (uint32_t tid = 0; tid < nbatch * n; tid++) ippc_terms_thread(tid, sh, j, a.data(), b.data(), wG.data(), wH.data(), G, H, msc.data(), mpt.data());
+        h_msm_vb(2 * nbatch, nt.data(), (const uint8_t *)msc.data(), (const uint8_t *)mpt.data(), (uint8_t *)mout.data(), mst.data());
+        for (uint32_t p = 0; p < nbatch; p++) {
+            uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;
+            ippc_challenge_thread(p, sh, j, st, mout.data(), mst.data(), ts.data(), u.data(), ui.data(), proofs, proof_len, status.data());
+        }
+        for (uint32_t tid = 0; tid < nbatch * n; tid++) ippc_fold_thread(tid, sh, j, u.data(), ui.data(), a.data(), b.data(), wG.data(), wH.data());
+    }
+    for (uint32_t p = 0; p < nbatch; p++) { ippc_final_thread(p, sh, a.data(), b.data(), proofs, proof_len); status_out[p] = (uint8_t)status[p]; }
     return 0;
 }
 }
