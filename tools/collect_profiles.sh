@@ -1,23 +1,42 @@
 #!/bin/bash
-# Runs on the GPU box (via gpurun): rocprofv3 kernel stats of the default bench command, plus separate
-# --pmc passes for HBM traffic (FETCH_SIZE / WRITE_SIZE), written under gpurun_out/prof_$1/.
-TAG=${1:-r01}
+# Runs on the GPU box (via gpurun): rocprofv3 kernel stats of the bench commands, plus separate --pmc passes
+# (kernel-trace only, no other trace domains) for HBM traffic (FETCH_SIZE / WRITE_SIZE) and VALU work
+# (SQ_INSTS_VALU) per kernel, for cfg2 (the headline), cfg3 and the cfg5 MSM shape.  Output: gpurun_out/prof_$1/.
+TAG=${1:-r02}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/pf /tmp/pm1 /tmp/pm2
-rocprofv3 --kernel-trace --stats -d /tmp/pf -o t --output-format csv -- python $REPO/bench.py --no-cpu-baseline > /tmp/pf.log 2>&1
-cp $(find /tmp/pf -name "*kernel_stats.csv" | head -1) $OUT/bench_default_kernel_stats.csv
-grep '"metric"' /tmp/pf.log > $OUT/bench_default_under_rocprof.json
-rocprofv3 --kernel-trace --stats -d /tmp/pf1 -o t --output-format csv -- python $REPO/bench.py --no-cpu-baseline --streams 1 > /tmp/pf1.log 2>&1
-cp $(find /tmp/pf1 -name "*kernel_stats.csv" | head -1) $OUT/bench_streams1_kernel_stats.csv
-grep '"metric"' /tmp/pf1.log > $OUT/bench_streams1_under_rocprof.json
-# counters in their own passes (kernel-trace only, no other trace domains)
-rocprofv3 --kernel-trace --pmc FETCH_SIZE -d /tmp/pm1 -o t --output-format csv -- python $REPO/bench.py --no-cpu-baseline --steps 8 --warmup 2 --streams 1 > /tmp/pm1.log 2>&1
-rocprofv3 --kernel-trace --pmc WRITE_SIZE -d /tmp/pm2 -o t --output-format csv -- python $REPO/bench.py --no-cpu-baseline --steps 8 --warmup 2 --streams 1 > /tmp/pm2.log 2>&1
-# VALU instruction mix / work per launch (tools/pmc_insts.sh writes gpurun_out/pmc_insts/)
-$REPO/tools/pmc_insts.sh > $OUT/pmc_insts.log 2>&1; cp $REPO/gpurun_out/pmc_insts/insts.json $OUT/pmc_instruction_mix_streams1.json; cp $REPO/gpurun_out/pmc_insts/valu_work_cfg2.json $OUT/valu_work_cfg2.json
+B="python $REPO/bench.py --no-cpu-baseline --no-extra"
+
+stats() {  # name, args...: kernel stats csv + the bench line measured under the profiler
+  local name=$1; shift
+  rm -rf /tmp/pf_$name
+  rocprofv3 --kernel-trace --stats -d /tmp/pf_$name -o t --output-format csv -- "$@" > /tmp/pf_$name.log 2>&1
+  cp $(find /tmp/pf_$name -name "*kernel_stats.csv" | head -1) $OUT/${name}_kernel_stats.csv
+  grep -E '^\{' /tmp/pf_$name.log > $OUT/${name}_under_rocprof.json
+}
+pmc() {  # name, counter list (quoted), args...
+  local name=$1 ctr=$2; shift 2
+  rm -rf /tmp/pm_$name
+  rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pm_$name -o t --output-format csv -- "$@" > /tmp/pm_$name.log 2>&1
+}
+
+stats bench_default $B
+stats bench_streams1 $B --streams 1 --steps 256 --warmup 16
+stats bench_cfg3 $B --config cfg3 --streams 64 --steps 640 --warmup 64
+stats bench_cfg5 python $REPO/bench.py --cfg5-only 8
+
+for cfg in cfg2 cfg3; do
+  A="$B --config $cfg --steps 8 --warmup 2 --streams 1"
+  pmc ${cfg}_fetch FETCH_SIZE $A
+  pmc ${cfg}_write WRITE_SIZE $A
+  pmc ${cfg}_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" $A
+done
+pmc cfg5_fetch FETCH_SIZE python $REPO/bench.py --cfg5-only 1
+pmc cfg5_write WRITE_SIZE python $REPO/bench.py --cfg5-only 1
+pmc cfg5_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" python $REPO/bench.py --cfg5-only 1
+
 python - <<PY
 import csv, collections, json, glob, re
 def short(name):
@@ -25,26 +44,31 @@ def short(name):
     n = re.sub(r"^void\s+", "", n)
     n = re.sub(r"<.*$", "", n)
     return n[2:] if n.startswith("k_") else n
-out = {}
-for d, name in (("/tmp/pm1", "FETCH_SIZE"), ("/tmp/pm2", "WRITE_SIZE")):
+def per_kernel(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     acc = collections.defaultdict(lambda: [0, 0.0])
     for r in csv.DictReader(open(f)):
-        if r["Counter_Name"] != name: continue
+        if r["Counter_Name"] != counter: continue
         k = short(r["Kernel_Name"])
         acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"])
-    out[name] = {k: {"dispatches": v[0], "avg_per_dispatch": v[1] / v[0]} for k, v in acc.items()}
-json.dump(out, open("$OUT/pmc_fetch_write_raw.json", "w"), indent=1)
-# HBM bytes per launch, corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE is in KB and counts a
-# 128-byte request as 64 bytes (x2); WRITE_SIZE is in KB
-traffic = {"_note": "HBM bytes per launch = 2*FETCH_SIZE[KB]*1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B, "
-           "MI355X_MICROARCH.md section HBM) + WRITE_SIZE[KB]*1024; separate --pmc passes of "
-           "bench.py --steps 8 --warmup 2 --streams 1 (cfg2, batch 1024), tools/collect_profiles.sh; raw counters in "
-           "profiles/$TAG/pmc_fetch_write_raw.json"}
-for k in out["FETCH_SIZE"]:
-    rd = out["FETCH_SIZE"][k]["avg_per_dispatch"]; wr = out["WRITE_SIZE"].get(k, {"avg_per_dispatch": 0})["avg_per_dispatch"]
-    traffic[k] = int(2 * rd * 1024 + wr * 1024)
-json.dump(traffic, open("$OUT/pmc_traffic_cfg2.json", "w"), indent=1)
-for k, v in sorted(((k, v) for k, v in traffic.items() if k != "_note"), key=lambda kv: -kv[1])[:14]:
-    print("HBM bytes/launch %-28s %14d" % (k, v))
+    return {k: {"dispatches": v[0], "avg_per_dispatch": v[1] / v[0]} for k, v in acc.items()}
+for cfg, what in (("cfg2", "bench.py --config cfg2 --steps 8 --warmup 2 --streams 1 (batch 1024)"),
+                  ("cfg3", "bench.py --config cfg3 --steps 8 --warmup 2 --streams 1 (batch 256)"),
+                  ("cfg5", "bench.py --cfg5-only 1 (batches of 64 MSMs of 6179 terms)")):
+    rd, wr = per_kernel("/tmp/pm_%s_fetch" % cfg, "FETCH_SIZE"), per_kernel("/tmp/pm_%s_write" % cfg, "WRITE_SIZE")
+    json.dump({"FETCH_SIZE": rd, "WRITE_SIZE": wr}, open("$OUT/pmc_fetch_write_raw_%s.json" % cfg, "w"), indent=1)
+    # HBM bytes per launch, corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE is in KB and counts a
+    # 128-byte request as 64 bytes (x2); WRITE_SIZE is in KB
+    traffic = {"_note": "HBM bytes per launch = 2*FETCH_SIZE[KB]*1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md "
+               "section HBM) + WRITE_SIZE[KB]*1024; separate rocprofv3 --pmc passes of %s, tools/collect_profiles.sh; raw counters in "
+               "profiles/$TAG/pmc_fetch_write_raw_%s.json" % (what, cfg)}
+    for k in rd:
+        traffic[k] = int(2 * rd[k]["avg_per_dispatch"] * 1024 + wr.get(k, {"avg_per_dispatch": 0})["avg_per_dispatch"] * 1024)
+    json.dump(traffic, open("$OUT/pmc_traffic_%s.json" % cfg, "w"), indent=1)
+    va = per_kernel("/tmp/pm_%s_valu" % cfg, "SQ_INSTS_VALU")
+    work = {"_note": "SQ_INSTS_VALU per launch (wavefront-instructions), rocprofv3 --pmc pass of %s, tools/collect_profiles.sh; one batch = one launch of "
+            "each rp_* / finish8 kernel" % what, "_mad_u64_fraction": 0.58}
+    for k in va: work[k] = int(va[k]["avg_per_dispatch"])
+    json.dump(work, open("$OUT/valu_work_%s.json" % cfg, "w"), indent=1)
+    print(cfg, "HBM bytes/launch:", {k: v for k, v in sorted(traffic.items(), key=lambda kv: -kv[1] if isinstance(kv[1], int) else 0)[:8] if k != "_note"})
 PY
