@@ -692,11 +692,12 @@ struct bk_dev {
     bk_desc *desc;         // [nmsm * nwin][half]
     ge_ext *bsum;          // [nmsm * nwin][half]
     ge_ext *gS, *gA;       // [nmsm * nwin][leaves]: bottom level of the running-sum tree
+    uint32_t *gcnt, *gcur; // [nmsm * nwin][half]: global histogram / scatter cursors of the split sort (large MSMs)
     uint32_t *colq16;      // [nmsm][64][32 words]
     ge_ext *hq;            // [nmsm]
 };
 static uint32_t pick_bucket_c(size_t terms_per_msm) { return terms_per_msm >= 6000 ? 12u : 8u; }
-static void plan_bucket(arena_plan &ap, size_t nmsm, size_t total, bk_params prm, size_t off[10]) {
+static void plan_bucket(arena_plan &ap, size_t nmsm, size_t total, bk_params prm, size_t off[12]) {
     off[0] = ap.add((nmsm + 1) * 4);
     off[1] = ap.add(total * sizeof(fb_entry) + 16);
     off[2] = ap.add(total * BK_RWORDS * 4 + 16);
@@ -707,8 +708,10 @@ static void plan_bucket(arena_plan &ap, size_t nmsm, size_t total, bk_params prm
     off[7] = ap.add(nmsm * sizeof(ge_ext));
     off[8] = ap.add(nmsm * prm.nwin * bk_leaves(prm) * sizeof(ge_ext));
     off[9] = ap.add(nmsm * prm.nwin * bk_leaves(prm) * sizeof(ge_ext));
+    off[10] = ap.add(nmsm * prm.nwin * prm.half * 4);
+    off[11] = ap.add(nmsm * prm.nwin * prm.half * 4);
 }
-static void bucket_bind(bpgpu_ctx *c, const size_t off[10], bk_dev &d) {
+static void bucket_bind(bpgpu_ctx *c, const size_t off[12], bk_dev &d) {
     char *a = c->arena;
     d.msm_first = (uint32_t *)(a + off[0]);
     d.pts = (fb_entry *)(a + off[1]);
@@ -720,6 +723,31 @@ static void bucket_bind(bpgpu_ctx *c, const size_t off[10], bk_dev &d) {
     d.hq = (ge_ext *)(a + off[7]);
     d.gS = (ge_ext *)(a + off[8]);
     d.gA = (ge_ext *)(a + off[9]);
+    d.gcnt = (uint32_t *)(a + off[10]);
+    d.gcur = (uint32_t *)(a + off[11]);
+}
+// counting sort of the terms of every (MSM, window) by digit + population sort of the buckets.  Few thousand terms per
+// MSM: one workgroup per (MSM, window), everything in LDS; more: the terms are shared by nsub workgroups (global
+// histogram, one scan workgroup, scatter through global cursors).  per_msm: the largest term count of one MSM.
+static int enqueue_bucket_sort(bpgpu_ctx *c, hipStream_t s, bk_params prm, uint32_t nmsm, uint32_t total, size_t per_msm, int single, bk_dev &d,
+                               const uint32_t *skip_status, uint32_t skip_div) {
+    const uint32_t nbw = nmsm * prm.nwin;
+    if (per_msm < 32768) {
+        if (prm.lanes == 64) LAUNCH(c, s, "bk_sort", k_bk_sort<64>, nbw, 64, prm, d.msm_first, total, single, d.rwords, d.idx, d.desc, skip_status, skip_div);
+        else LAUNCH(c, s, "bk_sort", k_bk_sort<256>, nbw, 256, prm, d.msm_first, total, single, d.rwords, d.idx, d.desc, skip_status, skip_div);
+        return BPGPU_OK;
+    }
+    uint32_t nsub = (uint32_t)((per_msm + 4095) / 4096);
+    if (nsub > 128) nsub = 128;
+    HIPCHK(c, hipMemsetAsync(d.gcnt, 0, (size_t)nbw * prm.half * 4, s));
+    for (int phase = 0; phase < 3; phase++) {
+        const uint32_t grid = phase == 1 ? nbw : nbw * nsub;
+        if (prm.lanes == 64)
+            LAUNCH(c, s, "bk_sort", k_bk_sort_big<64>, grid, 64, phase, nsub, prm, d.msm_first, total, single, d.rwords, d.idx, d.desc, d.gcnt, d.gcur, skip_status, skip_div);
+        else
+            LAUNCH(c, s, "bk_sort", k_bk_sort_big<256>, grid, 256, phase, nsub, prm, d.msm_first, total, single, d.rwords, d.idx, d.desc, d.gcnt, d.gcur, skip_status, skip_div);
+    }
+    return BPGPU_OK;
 }
 // bucket sums -> window sums (running-sum tree: wide leaf level, packed upper levels) -> column sums for the Horner chain
 static void enqueue_bucket_reduce(bpgpu_ctx *c, hipStream_t s, bk_params prm, uint32_t nbw, bk_dev &d) {
@@ -744,10 +772,10 @@ static int bucket_upload_first(bpgpu_ctx *c, hipStream_t s, size_t nmsm, const u
     return BPGPU_OK;
 }
 // sort -> bucket sums -> window sums -> Horner chain; leaves the MSM sums in d.hq
-static int enqueue_bucket_tail(bpgpu_ctx *c, hipStream_t s, bk_params prm, size_t nmsm, size_t total, bk_dev &d) {
+static int enqueue_bucket_tail(bpgpu_ctx *c, hipStream_t s, bk_params prm, size_t nmsm, size_t total, size_t per_msm, bk_dev &d) {
     const uint32_t nbw = (uint32_t)(nmsm * prm.nwin), tot32 = (uint32_t)total;
-    if (prm.lanes == 64) LAUNCH(c, s, "bk_sort", k_bk_sort<64>, nbw, 64, prm, d.msm_first, tot32, 0, d.rwords, d.idx, d.desc, (const uint32_t *)nullptr, 0u);
-    else LAUNCH(c, s, "bk_sort", k_bk_sort<256>, nbw, 256, prm, d.msm_first, tot32, 0, d.rwords, d.idx, d.desc, (const uint32_t *)nullptr, 0u);
+    int rcs = enqueue_bucket_sort(c, s, prm, (uint32_t)nmsm, tot32, per_msm, 0, d, nullptr, 0u);
+    if (rcs) return rcs;
     const uint32_t nt = nbw * prm.half;
     LAUNCH(c, s, "bk_accum", k_bk_accum, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, prm, tot32, d.desc, d.idx, d.pts, d.bsum);
     enqueue_bucket_reduce(c, s, prm, nbw, d);
@@ -767,7 +795,7 @@ static int msm_batch_dev_locked(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_t
         const bk_params prm = bk_make(pick_bucket_c(total / nbatch));
         if (total / nbatch >= (c->bucket_min ? c->bucket_min : BK_MIN_TERMS) && bucket_fits(nbatch, total, prm)) {
             arena_plan ap;
-            size_t off[10];
+            size_t off[12];
             plan_bucket(ap, nbatch, total, prm, off);
             const size_t off_status = ap.add(nbatch * 4);
             int rc = arena_reserve(c, ap.total);
@@ -780,7 +808,9 @@ static int msm_batch_dev_locked(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_t
             if (rc) return rc;
             LAUNCH(c, s, "bk_prepare", k_bk_prepare, ((uint32_t)total + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, (uint32_t)total, (uint32_t)nbatch, d.msm_first,
                    (const uint32_t *)d_scalars, (const uint32_t *)d_points, d.pts, d.rwords, d_status, prm);
-            rc = enqueue_bucket_tail(c, s, prm, nbatch, total, d);
+            size_t per_msm = 0;
+            for (size_t b = 0; b < nbatch; b++) per_msm = n_terms[b] > per_msm ? n_terms[b] : per_msm;
+            rc = enqueue_bucket_tail(c, s, prm, nbatch, total, per_msm, d);
             if (rc) return rc;
             LAUNCH(c, s, "vb_horner", k_vb_horner, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d.hq, d_status, (uint32_t *)d_out);
             LAUNCH(c, s, "status_bytes", k_status_bytes, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d_status, (uint8_t *)d_status_bytes);
@@ -921,7 +951,7 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
     const bk_params bkp = bk_make(pick_bucket_c(n_unique));
     const bool use_bucket = n_unique >= (c->bucket_min ? c->bucket_min : BK_MIN_TERMS) && bucket_fits(nbatch, nbatch * n_unique, bkp);
     arena_plan ap;
-    size_t off[7], boff[10];
+    size_t off[7], boff[12];
     if (use_bucket) plan_bucket(ap, nbatch, nbatch * n_unique, bkp, boff);
     else plan_vb_uniform(ap, nbatch, n_unique, off);
     const size_t off_status = ap.add(nbatch * 4);
@@ -942,7 +972,7 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
         const uint32_t total = (uint32_t)(nbatch * n_unique);
         LAUNCH(c, s, "bk_prepare", k_bk_prepare, (total + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, total, (uint32_t)nbatch, bd.msm_first,
                (const uint32_t *)d_uniq_scalars, (const uint32_t *)d_uniq_points, bd.pts, bd.rwords, d_status, bkp);
-        rc = enqueue_bucket_tail(c, s, bkp, nbatch, total, bd);
+        rc = enqueue_bucket_tail(c, s, bkp, nbatch, total, n_unique, bd);
         if (rc) return rc;
         d.hq = bd.hq;
     } else if (n_unique) {
@@ -1265,7 +1295,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const bk_params bkp = bk_make(pick_bucket_c(rlc_terms));
     const bool rlc_bucket = rlc && !shape_verdict && rlc_terms >= (c->bucket_min ? c->bucket_min : BK_RLC_MIN_TERMS) && bucket_fits(1, rlc_terms, bkp);
     arena_plan ap;
-    size_t off[7], boff[10];
+    size_t off[7], boff[12];
     if (rlc_bucket) plan_bucket(ap, 1, rlc_terms, bkp, boff);
     else plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off);
     const size_t off_digits = ap.add((size_t)npairs * nbatch * sizeof(fb_digit) + 16);
@@ -1378,8 +1408,8 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         LAUNCH(c, s, "rlc_stage3", k_rlc_stage3, n_exp, BP_BLOCK, 0u, 0u, (const vb_chunk *)nullptr, (const ge_cached *)nullptr, (const uint32_t *)nullptr,
                (ge_ext *)nullptr, nexp, sh, prm, d_fields, d_status, d_acc, (nbatch % 64 == 0) ? 1 : 0);
         const uint32_t tot32 = (uint32_t)rlc_terms;
-        if (bkp.lanes == 64) LAUNCH(c, s, "bk_sort", k_bk_sort<64>, bkp.nwin, 64, bkp, (const uint32_t *)nullptr, tot32, 1, bd.rwords, bd.idx, bd.desc, d_status, sh.U);
-        else LAUNCH(c, s, "bk_sort", k_bk_sort<256>, bkp.nwin, 256, bkp, (const uint32_t *)nullptr, tot32, 1, bd.rwords, bd.idx, bd.desc, d_status, sh.U);
+        rc = enqueue_bucket_sort(c, s, bkp, 1u, tot32, rlc_terms, 1, bd, d_status, sh.U);
+        if (rc) return rc;
         fb_digit *d_dig1 = (fb_digit *)(a + off_dig1);
         ge_ext *d_part1 = (ge_ext *)(a + off_part1);
         uint32_t *d_ctl = (uint32_t *)(a + off_res1 + sizeof(ge_ext));

@@ -52,9 +52,10 @@ BP_HD bk_params bk_make(uint32_t c) {
 // (1.25x at 2081, 1.43x at 4096); below that the per-point 8-entry tables of msm_vb.h win (fewer, wider launches).
 #define BK_MIN_TERMS 1536     // terms per MSM from which the bucket path is taken (option "bucket_min_terms")
 // The batch-combined range-proof check is ONE MSM over batch * (4 + 2k + m) terms, but it sits in a chain of narrow
-// launches where the extra sort / tree levels cost latency: measured at 17 408 terms (cfg2, batch 1024) the bucket
-// variant does 7.5 M proofs/s against 8.1 M/s, so it is taken only for larger combinations.
-#define BK_RLC_MIN_TERMS 49152
+// launches where the extra sort / tree levels cost latency: measured (cfg2 proofs, 17 terms each) the bucket variant
+// does 7.5 M proofs/s against 8.1 M/s at batch 1024 (17 408 terms), 10.7 against 9.8 at batch 2048, 13.5 - 14.4
+// against 10.7 at batch 4096, 12.6 against 10.8 at batch 16 384: it is taken from 32 768 terms.
+#define BK_RLC_MIN_TERMS 32768
 
 // bucket descriptor, sorted by population (descending) inside each (MSM, window)
 struct bk_desc {
@@ -166,11 +167,14 @@ BP_HD void bk_prepare_thread(uint32_t t, uint32_t nbatch, const uint32_t *msm_fi
 struct bk_seg {
     uint32_t first, count;   // the MSM's terms: [first, first + count)
     uint32_t w;              // window
+    uint32_t sub, nsub;      // this workgroup's share of the terms: [count sub / nsub, count (sub + 1) / nsub)  (1 of 1: all)
     // batch-combination mode: term t belongs to proof t / skip_div; terms of proofs whose status word is set stay out
     const uint32_t *skip_status;
     uint32_t skip_div;
 };
 BP_HD bool bk_term_skipped(const bk_seg &sg, uint32_t t) { return sg.skip_status && sg.skip_status[t / sg.skip_div] != 0; }
+BP_HD uint32_t bk_sub_lo(const bk_seg &sg) { return (uint32_t)((uint64_t)sg.count * sg.sub / sg.nsub); }
+BP_HD uint32_t bk_sub_hi(const bk_seg &sg) { return (uint32_t)((uint64_t)sg.count * (sg.sub + 1) / sg.nsub); }
 struct bk_lds {
     uint32_t *cnt;    // [half] bucket populations, later the scatter cursors
     uint32_t *off;    // [half] exclusive prefix of cnt
@@ -182,7 +186,7 @@ BP_HD void bk_sort_p0(uint32_t lane, bk_params prm, const bk_lds &l) {   // clea
     for (uint32_t j = lane; j < 256; j += prm.lanes) l.hist2[j] = 0;
 }
 BP_HD void bk_sort_p1(uint32_t lane, bk_params prm, const bk_seg &sg, const uint32_t *rwords, const bk_lds &l) {   // histogram
-    for (uint32_t i = lane; i < sg.count; i += prm.lanes) {
+    for (uint32_t i = bk_sub_lo(sg) + lane; i < bk_sub_hi(sg); i += prm.lanes) {
         if (bk_term_skipped(sg, sg.first + i)) continue;
         const int d = bk_digit(rwords + BK_RWORDS * (uint64_t)(sg.first + i), sg.w, prm);
         if (d != 0) BK_ATOMIC_ADD(&l.cnt[(uint32_t)(d < 0 ? -d : d) - 1], 1u);
@@ -238,7 +242,7 @@ BP_HD void bk_sort_p6(uint32_t lane, bk_params prm, const bk_seg &sg, const bk_l
     }
 }
 BP_HD void bk_sort_p7(uint32_t lane, bk_params prm, const bk_seg &sg, const uint32_t *rwords, const bk_lds &l, uint32_t *idx_w /*idx of window w: [total]*/) {
-    for (uint32_t i = lane; i < sg.count; i += prm.lanes) {
+    for (uint32_t i = bk_sub_lo(sg) + lane; i < bk_sub_hi(sg); i += prm.lanes) {
         const uint32_t t = sg.first + i;
         if (bk_term_skipped(sg, t)) continue;
         const int d = bk_digit(rwords + BK_RWORDS * (uint64_t)t, sg.w, prm);
@@ -247,6 +251,24 @@ BP_HD void bk_sort_p7(uint32_t lane, bk_params prm, const bk_seg &sg, const uint
             idx_w[sg.first + pos] = t | (d < 0 ? 0x80000000u : 0u);
         }
     }
+}
+
+// Large MSMs (tens of thousands of terms and more): the terms of one (MSM, window) are shared by `nsub` workgroups.
+// Each histograms its share in LDS and merges into a global histogram (bk_sort_merge); ONE workgroup per (MSM, window)
+// then scans / emits the descriptors (p2 .. p6 on a copy of the global histogram) and publishes the cursors; the
+// scatter (p7) runs again on all `nsub` workgroups with the cursors in global memory.
+BP_HD void bk_sort_merge(uint32_t lane, bk_params prm, const bk_lds &l, uint32_t *gcnt /*[half] of this (MSM, window)*/) {
+    for (uint32_t j = lane; j < prm.half; j += prm.lanes) {
+        const uint32_t v = l.cnt[j];
+        if (v) BK_ATOMIC_ADD(&gcnt[j], v);
+    }
+}
+BP_HD void bk_sort_load(uint32_t lane, bk_params prm, const bk_lds &l, const uint32_t *gcnt) {
+    for (uint32_t j = lane; j < prm.half; j += prm.lanes) l.cnt[j] = gcnt[j];
+    for (uint32_t j = lane; j < 256; j += prm.lanes) l.hist2[j] = 0;
+}
+BP_HD void bk_sort_publish(uint32_t lane, bk_params prm, const bk_lds &l, uint32_t *gcur) {
+    for (uint32_t j = lane; j < prm.half; j += prm.lanes) gcur[j] = l.cnt[j];
 }
 
 // ---- stage 3: lane = (workgroup id bw, rank r) ------------------------------------------------------------------

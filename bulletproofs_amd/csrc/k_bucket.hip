@@ -22,6 +22,8 @@ __global__ void __launch_bounds__(LANES) k_bk_sort(bk_params prm, const uint32_t
     sg.w = bw - b * prm.nwin;
     sg.first = single ? 0u : msm_first[b];
     sg.count = single ? total : msm_first[b + 1] - sg.first;
+    sg.sub = 0;
+    sg.nsub = 1;
     sg.skip_status = skip_status;
     sg.skip_div = skip_div ? skip_div : 1u;
     bk_lds l;
@@ -48,6 +50,58 @@ __global__ void __launch_bounds__(LANES) k_bk_sort(bk_params prm, const uint32_t
 }
 template __global__ void k_bk_sort<64>(bk_params, const uint32_t *, uint32_t, int, const uint32_t *, uint32_t *, bk_desc *, const uint32_t *, uint32_t);
 template __global__ void k_bk_sort<256>(bk_params, const uint32_t *, uint32_t, int, const uint32_t *, uint32_t *, bk_desc *, const uint32_t *, uint32_t);
+
+// ---- the same sort for large MSMs, three launches: histogram (nsub workgroups per (MSM, window)), scan, scatter ----
+// phase 0: blockIdx.x = bw * nsub + sub: local histogram -> global gcnt[bw][half] (zeroed by the host)
+// phase 1: blockIdx.x = bw: scan, population sort, descriptors; cursors -> gcur[bw][half]
+// phase 2: blockIdx.x = bw * nsub + sub: scatter through the global cursors
+template <int LANES>
+__global__ void __launch_bounds__(LANES) k_bk_sort_big(int phase, uint32_t nsub, bk_params prm, const uint32_t *msm_first, uint32_t total, int single,
+                                                        const uint32_t *rwords, uint32_t *idx, bk_desc *desc, uint32_t *gcnt, uint32_t *gcur,
+                                                        const uint32_t *skip_status, uint32_t skip_div) {
+    __shared__ uint32_t s_cnt[2048], s_off[2048], s_part[256], s_hist2[256];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t bw = phase == 1 ? blockIdx.x : blockIdx.x / nsub, b = bw / prm.nwin;
+    bk_seg sg;
+    sg.w = bw - b * prm.nwin;
+    sg.first = single ? 0u : msm_first[b];
+    sg.count = single ? total : msm_first[b + 1] - sg.first;
+    sg.sub = phase == 1 ? 0u : blockIdx.x - bw * nsub;
+    sg.nsub = phase == 1 ? 1u : nsub;
+    sg.skip_status = skip_status;
+    sg.skip_div = skip_div ? skip_div : 1u;
+    bk_lds l;
+    l.cnt = s_cnt;
+    l.off = s_off;
+    l.part = s_part;
+    l.hist2 = s_hist2;
+    if (phase == 0) {
+        bk_sort_p0(lane, prm, l);
+        __syncthreads();
+        bk_sort_p1(lane, prm, sg, rwords, l);
+        __syncthreads();
+        bk_sort_merge(lane, prm, l, gcnt + (uint64_t)bw * prm.half);
+    } else if (phase == 1) {
+        bk_sort_load(lane, prm, l, gcnt + (uint64_t)bw * prm.half);
+        __syncthreads();
+        bk_sort_p2(lane, prm, l);
+        __syncthreads();
+        bk_sort_p3(lane, prm, l);
+        __syncthreads();
+        bk_sort_p4(lane, prm, l);
+        __syncthreads();
+        bk_sort_p5(lane, l);
+        __syncthreads();
+        bk_sort_p6(lane, prm, sg, l, desc + (uint64_t)bw * prm.half);
+        __syncthreads();
+        bk_sort_publish(lane, prm, l, gcur + (uint64_t)bw * prm.half);
+    } else {
+        l.cnt = gcur + (uint64_t)bw * prm.half;
+        bk_sort_p7(lane, prm, sg, rwords, l, idx + (uint64_t)sg.w * total);
+    }
+}
+template __global__ void k_bk_sort_big<64>(int, uint32_t, bk_params, const uint32_t *, uint32_t, int, const uint32_t *, uint32_t *, bk_desc *, uint32_t *, uint32_t *, const uint32_t *, uint32_t);
+template __global__ void k_bk_sort_big<256>(int, uint32_t, bk_params, const uint32_t *, uint32_t, int, const uint32_t *, uint32_t *, bk_desc *, uint32_t *, uint32_t *, const uint32_t *, uint32_t);
 
 __global__ void __launch_bounds__(BP_BLOCK) k_bk_accum(uint32_t nthreads, bk_params prm, uint32_t total, const bk_desc *desc, const uint32_t *idx,
                                                         const fb_entry *pts, ge_ext *bsum) {

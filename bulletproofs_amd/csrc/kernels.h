@@ -60,6 +60,8 @@ __global__ void k_ippc_final(ippc_shape sh, const uint32_t *a, const uint32_t *b
 __global__ void k_bk_prepare(uint32_t total, uint32_t nbatch, const uint32_t *msm_first, const uint32_t *scalars, const uint32_t *points, fb_entry *pts, uint32_t *rwords, uint32_t *status, bk_params prm);
 template <int LANES>
 __global__ void k_bk_sort(bk_params prm, const uint32_t *msm_first, uint32_t total, int single, const uint32_t *rwords, uint32_t *idx, bk_desc *desc, const uint32_t *skip_status, uint32_t skip_div);
+template <int LANES>
+__global__ void k_bk_sort_big(int phase, uint32_t nsub, bk_params prm, const uint32_t *msm_first, uint32_t total, int single, const uint32_t *rwords, uint32_t *idx, bk_desc *desc, uint32_t *gcnt, uint32_t *gcur, const uint32_t *skip_status, uint32_t skip_div);
 __global__ void k_bk_accum(uint32_t nthreads, bk_params prm, uint32_t total, const bk_desc *desc, const uint32_t *idx, const fb_entry *pts, ge_ext *bsum);
 __global__ void k_bk_leaf(uint32_t nthreads, bk_params prm, const ge_ext *bsum, ge_ext *gS, ge_ext *gA);
 template <int C>

@@ -78,7 +78,7 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
  *   "fixed_splits"          workgroups the generator terms of one proof block are split over (0 = auto)
  *   "bucket_min_terms"      variable-base terms per MSM from which the bucket (Pippenger) path is taken instead of the
  *                           table-lookup one (default 1536; the batch-combined check, one MSM over all proofs' terms,
- *                           switches at 49152 terms unless this option is set; a huge value disables the bucket
+ *                           switches at 32768 terms unless this option is set; a huge value disables the bucket
  *                           path, 1 forces it).  Results are bit-identical either way.
  *   "host_sync_blocking"    1: host-pointer entry points wait for their results on a blocking event (the calling
  *                           thread sleeps: right for many host threads, one context each); 0 (default): spin-wait

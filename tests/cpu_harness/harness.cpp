@@ -441,7 +441,7 @@ int h_ipp_verify(uint32_t n, uint32_t nbatch, const uint8_t *proofs, uint32_t pr
 // The bucket (Pippenger) MSM pipeline, lane by lane and phase by phase (bucket.h; the same bodies as k_bucket.hip).
 // c = 8 or 12.  skip_div != 0: ONE MSM over all terms, terms of "proof" t / skip_div are left out when skip[proof] != 0.
 int h_msm_bucket(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, const uint8_t *points, uint32_t c,
-                 const uint32_t *skip, uint32_t skip_div, uint8_t *out, uint8_t *status_out) {
+                 const uint32_t *skip, uint32_t skip_div, uint32_t nsub, uint8_t *out, uint8_t *status_out) {
     const bk_params prm = bk_make(c);
     std::vector<uint32_t> msm_first(nbatch + 1, 0);
     for (uint32_t b = 0; b < nbatch; b++) msm_first[b + 1] = msm_first[b] + n_terms[b];
@@ -460,14 +460,38 @@ int h_msm_bucket(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalar
         bk_seg sg; sg.w = bw - b * prm.nwin; sg.first = single ? 0 : msm_first[b]; sg.count = single ? total : msm_first[b + 1] - sg.first;
         sg.skip_status = single ? skip : nullptr; sg.skip_div = skip_div ? skip_div : 1;
         uint32_t *idx_w = idx.data() + (size_t)sg.w * total;
-        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p0(lane, prm, l);
-        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p1(lane, prm, sg, rwords.data(), l);
-        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p2(lane, prm, l);
-        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p3(lane, prm, l);
-        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p4(lane, prm, l);
-        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p5(lane, l);
-        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p6(lane, prm, sg, l, desc.data() + (size_t)bw * prm.half);
-        for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p7(lane, prm, sg, rwords.data(), l, idx_w);
+        sg.sub = 0; sg.nsub = 1;
+        if (nsub <= 1) {
+            for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p0(lane, prm, l);
+            for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p1(lane, prm, sg, rwords.data(), l);
+            for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p2(lane, prm, l);
+            for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p3(lane, prm, l);
+            for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p4(lane, prm, l);
+            for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p5(lane, l);
+            for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p6(lane, prm, sg, l, desc.data() + (size_t)bw * prm.half);
+            for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p7(lane, prm, sg, rwords.data(), l, idx_w);
+        } else {   // the split sort of large MSMs: nsub workgroups histogram / scatter, one scans (k_bk_sort_big)
+            std::vector<uint32_t> gcnt(prm.half, 0), gcur(prm.half, 0);
+            for (uint32_t sub = 0; sub < nsub; sub++) {
+                sg.sub = sub; sg.nsub = nsub;
+                for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p0(lane, prm, l);
+                for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p1(lane, prm, sg, rwords.data(), l);
+                for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_merge(lane, prm, l, gcnt.data());
+            }
+            sg.sub = 0; sg.nsub = 1;
+            for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_load(lane, prm, l, gcnt.data());
+            for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p2(lane, prm, l);
+            for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p3(lane, prm, l);
+            for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p4(lane, prm, l);
+            for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p5(lane, l);
+            for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p6(lane, prm, sg, l, desc.data() + (size_t)bw * prm.half);
+            for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_publish(lane, prm, l, gcur.data());
+            bk_lds lg = l; lg.cnt = gcur.data();
+            for (uint32_t sub = 0; sub < nsub; sub++) {
+                sg.sub = sub; sg.nsub = nsub;
+                for (uint32_t lane = 0; lane < prm.lanes; lane++) bk_sort_p7(lane, prm, sg, rwords.data(), lg, idx_w);
+            }
+        }
         // descriptors are sorted by population (clamped at 255), descending, and partition the window's listed terms
         uint32_t listed = 0;
         for (uint32_t r = 0; r < prm.half; r++) {

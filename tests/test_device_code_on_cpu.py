@@ -206,7 +206,9 @@ def test_bucket_msm_pipeline_phase_by_phase(H, oracle, c):
         P += b"".join(_pt(oracle, b"b%d-p%d" % (k, i % 40)) for i in range(n))   # points repeat: buckets see P + P and P - P
     nt = (C.c_uint32 * len(sizes))(*sizes)
     out, st = C.create_string_buffer(32 * len(sizes)), C.create_string_buffer(len(sizes))
-    assert H.h_msm_bucket(len(sizes), nt, S, P, c, None, 0, out, st) == 0
+    assert H.h_msm_bucket(len(sizes), nt, S, P, c, None, 0, 1, out, st) == 0
+    out_b = C.create_string_buffer(32 * len(sizes))
+    assert H.h_msm_bucket(len(sizes), nt, S, P, c, None, 0, 3, out_b, st) == 0 and out_b.raw == out.raw   # split sort (large MSMs)
     off = 0
     for k, n in enumerate(sizes):
         assert st.raw[k] == 0 and out.raw[32 * k:32 * k + 32] == oracle.msm(S[off:off + 32 * n], P[off:off + 32 * n])[1], (c, k)
@@ -215,15 +217,15 @@ def test_bucket_msm_pipeline_phase_by_phase(H, oracle, c):
     s = b"".join(x.to_bytes(32, "little") for x in sp)
     p = b"".join(_pt(oracle, b"bsp%d" % (i % 3)) for i in range(len(sp)))
     nt1 = (C.c_uint32 * 1)(len(sp))
-    assert H.h_msm_bucket(1, nt1, s, p, c, None, 0, out, st) == 0
+    assert H.h_msm_bucket(1, nt1, s, p, c, None, 0, 1, out, st) == 0
     assert out.raw[:32] == oracle.msm(s, p)[1] and st.raw[0] == 0
     bad = bytearray(p)
     bad[0] |= 1
-    H.h_msm_bucket(1, nt1, s, bytes(bad), c, None, 0, out, st)
+    H.h_msm_bucket(1, nt1, s, bytes(bad), c, None, 0, 1, out, st)
     assert st.raw[0] == 1 and out.raw[:32] == bytes(32)
     s2 = bytearray(s)
     s2[0:32] = T.L.to_bytes(32, "little")
-    H.h_msm_bucket(1, nt1, bytes(s2), p, c, None, 0, out, st)
+    H.h_msm_bucket(1, nt1, bytes(s2), p, c, None, 0, 1, out, st)
     assert st.raw[0] == 2
     # single-MSM mode: 6 "proofs" of 5 terms each, proofs 1 and 4 rejected -> their terms stay out of the combination
     n = 30
@@ -231,7 +233,7 @@ def test_bucket_msm_pipeline_phase_by_phase(H, oracle, c):
     p = b"".join(_pt(oracle, b"rl-p%d" % i) for i in range(n))
     nts = (C.c_uint32 * 6)(*[5] * 6)
     skip = (C.c_uint32 * 6)(0, 1, 0, 0, 2, 0)
-    assert H.h_msm_bucket(6, nts, s, p, c, skip, 5, out, st) == 0
+    assert H.h_msm_bucket(6, nts, s, p, c, skip, 5, 2, out, st) == 0
     keep = [i for i in range(n) if i // 5 not in (1, 4)]
     assert out.raw[:32] == oracle.msm(b"".join(s[32 * i:32 * i + 32] for i in keep), b"".join(p[32 * i:32 * i + 32] for i in keep))[1]
 

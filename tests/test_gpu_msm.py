@@ -221,7 +221,7 @@ def _fast_scalars(seed, n):
     return bytes(raw)
 
 
-@pytest.mark.parametrize("sizes", [[256], [2081], [6179], [20000], [0, 300, 192, 1000, 5, 191, 2081], [7000, 0, 6500]])
+@pytest.mark.parametrize("sizes", [[256], [2081], [6179], [20000], [40000], [0, 300, 192, 1000, 5, 191, 2081], [7000, 0, 6500]])
 def test_bucket_path_sizes_bit_exact(ctx, oracle, sizes):
     """The bucket (Pippenger) path of bpgpu_msm_batch (bucket.h; forced here with bucket_min_terms = 1, by default taken
     from 1536 terms per MSM on average; c = 8 below 6000 terms, c = 12 above): sizes around the thresholds, the R1CS verifier's 2081 / 6179 (r1cs/verifier.rs:459-491), 20 000,

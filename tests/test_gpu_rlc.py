@@ -17,7 +17,7 @@ L = 2**252 + 27742317777372353535851937790883648493
 @pytest.fixture(scope="module", params=["lookup", "bucket"])
 def ctx64x8(request):
     """Both variants of the per-proof terms: the 8-entry-table window sums (msm_vb.h) and the ONE bucket MSM over all
-    proofs' weighted terms (bucket.h; by default taken from 49152 terms per combination)."""
+    proofs' weighted terms (bucket.h; by default taken from 32768 terms per combination)."""
     import bulletproofs_amd as bp
     c = bp.Context(0)
     c.set_option("bucket_min_terms", 1 if request.param == "bucket" else 2**31 - 1)
