@@ -26,8 +26,10 @@ def test_deserialize_and_verify(golden):
             assert proof.verify_multiple(bp_gens, pc_gens, transcript, vc[0:m], n) is None   # == Ok(())
             with pytest.raises(VerificationError):
                 proof.verify_multiple(bp_gens, pc_gens, Transcript(b"another label"), vc[0:m], n)
+            before = transcript.state
             with pytest.raises(InvalidBitsize):
                 proof.verify_multiple(bp_gens, pc_gens, transcript, vc[0:m], 24)
+            assert transcript.state == before      # the bitsize check precedes any transcript operation (mod.rs:358-360)
     with pytest.raises(FormatError):
         RangeProof.from_bytes(bytes.fromhex(proofs[0][0])[:-1])
     res = RangeProof.verify_batch(bp_gens, pc_gens, Transcript(b"Deserialize-And-Verify Test"),

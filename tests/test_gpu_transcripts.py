@@ -125,3 +125,43 @@ def test_reference_api_transcript_is_mut(oracle, oracle_gens_64_8):
         RangeProof.from_bytes(pr).verify_single(bp_gens, pc_gens, Transcript(b"app"), cm, 64)
     with pytest.raises(ValueError):
         RangeProof.from_bytes(pr).verify_single(bp_gens, PedersenGens(pc_gens.B_blinding, pc_gens.B), Transcript(b"app"), cm, 64)
+
+
+def test_rejected_before_the_transcript_is_touched(ctx64x8, oracle, oracle_gens_64_8, golden):
+    """FormatError (length or scalar), InvalidBitsize, InvalidGeneratorsLength are decided before the reference touches the
+    transcript (mod.rs:358-366, 504-538): the caller gets its state back unchanged, for one shared state and for
+    per-proof states."""
+    case = [x for x in golden["cases"] if x["n"] == 32 and x["m"] == 2][0]
+    pr = bytes.fromhex(case["proof"])
+    vc = golden["vc_bytes"][:64]
+    st = _bound_state(oracle, 3)
+    rng = bytes(range(64))
+    for states in (st, st + _bound_state(oracle, 4)):          # shared / per proof
+        nb = 2
+        # malformed length for the whole batch
+        v, ts = ctx64x8.rangeproof_verify_batch_ts(32, 2, pr[:-1] * nb, len(pr) - 1, vc * nb, states, rng * nb, want_transcripts=True)
+        assert list(v) == [2, 2] and ts == (states if len(states) == 416 else states * 2)
+        # bitsize / generator capacity
+        v, ts = ctx64x8.rangeproof_verify_batch_ts(24, 2, pr * nb, len(pr), vc * nb, states, rng * nb, want_transcripts=True)
+        assert list(v) == [3, 3] and ts == (states if len(states) == 416 else states * 2)
+        v, ts = ctx64x8.rangeproof_verify_batch_ts(32, 16, pr * nb, len(pr), golden["vc_bytes"][:32] * 16 * nb, states, rng * nb, want_transcripts=True)
+        assert list(v) == [4, 4] and ts == (states if len(states) == 416 else states * 2)
+    # and a valid golden proof on a fresh state handed over as state: Ok, state advanced exactly as the oracle's
+    fresh = oracle.transcript_new(golden["label"])
+    v, ts = ctx64x8.rangeproof_verify_batch_ts(32, 2, pr, len(pr), vc, fresh, rng, want_transcripts=True)
+    rc, _, est = oracle.verify_ts(oracle_gens_64_8, pr, vc, 32, fresh, rng)
+    assert list(v) == [0] and rc == 0 and ts == est
+
+
+def test_many_batch_shapes_evict_cached_decompositions(ctx64x8, oracle, oracle_gens_64_8, golden):
+    """The per-context cache of work decompositions is bounded (32 entries, least recently used evicted): 40 different batch
+    sizes, then the first ones again -- every verdict still equals the oracle's."""
+    case = [x for x in golden["cases"] if x["n"] == 64 and x["m"] == 1][0]
+    pr = bytes.fromhex(case["proof"])
+    bad = bytearray(pr)
+    bad[130] ^= 4
+    vc = golden["vc_bytes"][:32]
+    for nb in list(range(1, 41)) + [1, 2, 3]:
+        proofs = b"".join(bytes(bad) if i % 3 == 1 else pr for i in range(nb))
+        v = ctx64x8.rangeproof_verify_batch(64, 1, proofs, len(pr), vc * nb, golden["label"], bytes(64 * nb))
+        assert list(v) == [1 if i % 3 == 1 else 0 for i in range(nb)], nb
