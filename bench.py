@@ -324,6 +324,8 @@ def roofline_block(cfg, n, m, batch, kern, value, wl, events_every, default_batc
             "timing": "start/stop events attached to the dispatches (hipExtLaunchKernelGGL) of every %s stream, on their launch stream, inside the "
                       "timed region; kernel begin..end as in rocprofv3's kernel trace" % ("8th" if events_every == 8 else ""),
             "note": "the path is bound by integer VALU issue, not HBM: ~10 field multiplications per input byte, so the HBM fraction is ~1e-3 by construction",
+            "dominant_by": "VALU work (half of a batch's wavefront-instructions) and all of the table traffic; by slot time under load the narrow, latency-bound "
+                           "rp_stage1 (one lane per proof: 12 Keccak-f per proof) is comparable -- see kernels_us",
             "valu": valu,
             "kernels_us": {k: round(v[1] / v[0] * 1e3, 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}}
 
@@ -493,18 +495,21 @@ def main():
     roof = roofline_block(a.config, n, m, batch, r["kern"], value, wl, r["events_every"], default_batch) if rank == 0 else None
     b.close()
     if world == 1 and not a.rlc and not a.no_extra and a.steps >= 8 and a.config == "cfg2":
-        # (2) BASELINE config 3 (aggregated m = 16, batch 256) and (3) config 5's MSM shape, each with its own roofline
-        try:
-            b3 = RangeProofBench(a, "cfg3", 256, min(64, nstreams), rank, local_dev)
-            r3 = timed(b3, 640 if a.steps >= 640 else max(a.steps, 8), 64 if a.steps >= 640 else 8, fence, 0)
-            v3 = 256 * (640 if a.steps >= 640 else max(a.steps, 8)) / r3["elapsed"]
-            extra["cfg3"] = {"workload": "cfg3: batch of 256 aggregated m=16 64-bit range proofs (MSM of 2090 terms each), %d distinct proofs" % b3.distinct,
-                             "verifications_per_s": round(v3, 1), "regions": len(r3["regions"]), "streams": b3.nstreams,
-                             "fixed_window_bits": b3.ctxs[0].get_option("fixed_window_bits"),
-                             "roofline": roofline_block("cfg3", 64, 16, 256, r3["kern"], v3, wl, r3["events_every"], 256)}
-            b3.close()
-        except Exception as e:   # informational: never fails the headline line
-            extra["cfg3"] = {"error": str(e)}
+        # (2) BASELINE configs 3 and 4 (aggregated m = 16 at batch 256, m = 32 at 512 per GPU) and (3) config 5's MSM shape,
+        # each with its own roofline
+        for cfg_x, batch_x, streams_x, m_x, terms_x in (("cfg3", 256, 64, 16, 2090), ("cfg4", 512, 32, 32, 4156)):
+            try:
+                bx = RangeProofBench(a, cfg_x, batch_x, min(streams_x, nstreams), rank, local_dev)
+                kx = (640 if cfg_x == "cfg3" else 256) if a.steps >= 640 else max(a.steps, 8)
+                rx = timed(bx, kx, 64 if a.steps >= 640 else 8, fence, 0)
+                vx = batch_x * kx / rx["elapsed"]
+                extra[cfg_x] = {"workload": "%s: batch of %d aggregated m=%d 64-bit range proofs (MSM of %d terms each), %d distinct proofs" % (cfg_x, batch_x, m_x, terms_x, bx.distinct),
+                                "verifications_per_s": round(vx, 1), "steps": kx, "regions": len(rx["regions"]), "streams": bx.nstreams,
+                                "fixed_window_bits": bx.ctxs[0].get_option("fixed_window_bits"),
+                                "roofline": roofline_block(cfg_x, 64, m_x, batch_x, rx["kern"], vx, wl, rx["events_every"], batch_x)}
+                bx.close()
+            except Exception as e:   # informational: never fails the headline line
+                extra[cfg_x] = {"error": str(e)}
         try:
             extra["cfg5_shape"] = bench_cfg5_shape(a, local_dev)
         except Exception as e:

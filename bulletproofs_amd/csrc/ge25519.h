@@ -70,10 +70,11 @@ BP_HD void ge_add_cached(ge_ext &r, const ge_ext &p, const ge_cached &q, bool ne
     fe_add(dpc, d, c);                  // lazy (3x)
     fe_select(f, dmc, dpc, neg);
     fe_select(g, dpc, dmc, neg);
-    fe_mul(r.X, e, f);
-    fe_mul(r.Y, g, h);
+    // second operand = the one fe_mul premultiplies by 19: e and g serve two products each (18 instead of 27 multiplies)
+    fe_mul(r.X, f, e);
+    fe_mul(r.Y, h, g);
     fe_mul(r.Z, f, g);
-    fe_mul(r.T, e, h);
+    fe_mul(r.T, h, e);
 }
 
 // mixed addition with an affine Niels point: 7M
@@ -94,10 +95,11 @@ BP_HD void ge_madd(ge_ext &r, const ge_ext &p, const ge_niels &q, bool neg) {
     fe_add(dpc, d, c);
     fe_select(f, dmc, dpc, neg);
     fe_select(g, dpc, dmc, neg);
-    fe_mul(r.X, e, f);
-    fe_mul(r.Y, g, h);
+    // second operand = the one fe_mul premultiplies by 19: e and g serve two products each (18 instead of 27 multiplies)
+    fe_mul(r.X, f, e);
+    fe_mul(r.Y, h, g);
     fe_mul(r.Z, f, g);
-    fe_mul(r.T, e, h);
+    fe_mul(r.T, h, e);
 }
 
 // r = +-q for an affine Niels point: what ge_madd(identity, q, neg) computes, with its constant operands folded
@@ -137,10 +139,10 @@ BP_HD void ge_dbl(ge_ext &r, const ge_ext &p, bool with_t = true) {
     fe_sub(g, yy, xx);                  //          (=  G)
     fe_sub(e, s, h);                    //          (=  E)
     fe_sub(f, zz2, g);                  //          (= -F)
-    fe_mul(r.X, e, f);
+    fe_mul(r.X, f, e);
     fe_mul(r.Y, h, g);
-    fe_mul(r.Z, g, f);
-    if (with_t) fe_mul(r.T, e, h);
+    fe_mul(r.Z, f, g);
+    if (with_t) fe_mul(r.T, h, e);
 }
 
 BP_HD void ge_neg(ge_ext &r, const ge_ext &p) {

@@ -27,7 +27,7 @@ stats bench_streams1 $B --streams 1 --steps 256 --warmup 16
 stats bench_cfg3 $B --config cfg3 --streams 64 --steps 640 --warmup 64
 stats bench_cfg5 python $REPO/bench.py --cfg5-only 8
 
-for cfg in cfg2 cfg3; do
+for cfg in cfg2 cfg3 cfg4; do
   A="$B --config $cfg --steps 8 --warmup 2 --streams 1"
   pmc ${cfg}_fetch FETCH_SIZE $A
   pmc ${cfg}_write WRITE_SIZE $A
@@ -54,6 +54,7 @@ def per_kernel(d, counter):
     return {k: {"dispatches": v[0], "avg_per_dispatch": v[1] / v[0]} for k, v in acc.items()}
 for cfg, what in (("cfg2", "bench.py --config cfg2 --steps 8 --warmup 2 --streams 1 (batch 1024)"),
                   ("cfg3", "bench.py --config cfg3 --steps 8 --warmup 2 --streams 1 (batch 256)"),
+                  ("cfg4", "bench.py --config cfg4 --steps 8 --warmup 2 --streams 1 (batch 512)"),
                   ("cfg5", "bench.py --cfg5-only 1 (batches of 64 MSMs of 6179 terms)")):
     rd, wr = per_kernel("/tmp/pm_%s_fetch" % cfg, "FETCH_SIZE"), per_kernel("/tmp/pm_%s_write" % cfg, "WRITE_SIZE")
     json.dump({"FETCH_SIZE": rd, "WRITE_SIZE": wr}, open("$OUT/pmc_fetch_write_raw_%s.json" % cfg, "w"), indent=1)
