@@ -1876,16 +1876,18 @@ extern "C" int bpgpu_ipp_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, con
         LAUNCH(c, s, "ippc_terms", k_ippc_terms, n_q + (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_q, nt32, sh, j, (const uint32_t *)w_a, (const uint32_t *)w_b,
                (const uint32_t *)w_G, (const uint32_t *)w_H, (const uint8_t *)d_G, (const uint8_t *)d_H, (const uint8_t *)d_q, m_sc, m_pt);
         rc = msm_batch_dev_locked(c, 2 * nbatch, nterms.data(), m_sc, m_pt, m_out, m_st, s);   // all L_j and R_j of the batch (ipp.rs:87-113)
-        if (rc) return rc;
+        if (rc) break;   // (falls through to the common tail: the stream is drained before the staging buffers are reused)
         LAUNCH(c, s, "ippc_challenge", k_ippc_challenge, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, j, (const uint32_t *)m_out, (const uint8_t *)m_st,
                (uint32_t *)d_ts, w_uu, w_ui, (uint8_t *)d_proofs, (uint32_t)proof_len, d_status);
         LAUNCH(c, s, "ippc_fold", k_ippc_fold, (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt32, sh, j, (const uint32_t *)w_uu, (const uint32_t *)w_ui, w_a, w_b, w_G,
                w_H);
     }
-    LAUNCH(c, s, "ippc_final", k_ippc_final, (nb32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, sh, (const uint32_t *)w_a, (const uint32_t *)w_b, (uint8_t *)d_proofs,
-           (uint32_t)proof_len, (const uint32_t *)d_status, (uint8_t *)d_stb);
     char *h_out = h + sz_in;
-    if (hipMemcpyAsync(h_out, d_proofs, sz_out, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+    if (!rc) {
+        LAUNCH(c, s, "ippc_final", k_ippc_final, (nb32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, sh, (const uint32_t *)w_a, (const uint32_t *)w_b, (uint8_t *)d_proofs,
+               (uint32_t)proof_len, (const uint32_t *)d_status, (uint8_t *)d_stb);
+        if (hipMemcpyAsync(h_out, d_proofs, sz_out, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+    }
     const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
     if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
     memcpy(proofs_out, h_out, nbatch * proof_len);

@@ -36,7 +36,7 @@ struct bk_params {
     uint32_t c;      // window bits: 8 or 12
     uint32_t nwin;   // windows: 32 (c = 8), 22 (c = 12; the last one holds bit 252 and the recoding carry)
     uint32_t half;   // 2^(c-1) buckets per window (magnitudes 1 .. half)
-    uint32_t lanes;  // lanes of a (MSM, window) workgroup in bk_sort / bk_reduce: 64 (c = 8), 256 (c = 12)
+    uint32_t lanes;  // lanes of a (MSM, window) workgroup in bk_sort: 64 (c = 8), 256 (c = 12)
 };
 BP_HD bk_params bk_make(uint32_t c) {
     bk_params p;

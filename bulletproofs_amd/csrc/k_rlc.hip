@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rlc_accum_scalars(uint32_t n_acc, 
         rlc_scalars_lane((blockIdx.x - n_acc) * BP_BLOCK + threadIdx.x, n_rows, acc, digits, prm, ctl, 0u);
     }
 }
-// block 0: the Horner chain over the window sums (radix-16 column sums written by k_bk_reduce)  ||  the table walk
+// block 0: the Horner chain over the window sums (radix-16 column sums written by k_bk_tree)  ||  the table walk
 // for a batch of one (block -> split as in k_fb_accum with one proof block)
 __global__ void __launch_bounds__(FB_BLOCK) k_rlc_stage4b(const uint32_t *colq16, ge_ext *hq, fb_params prm, uint32_t nsplit, uint32_t npairs,
                                                            const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial) {
