@@ -93,6 +93,10 @@ struct bpgpu_ctx {
     char *ipp_buf = nullptr;                 // term lists of the stand-alone inner-product verifier
     size_t ipp_cap = 0;
     uint32_t bucket_min = 0;                 // terms per MSM from which the bucket path is taken (0 = BK_MIN_TERMS; huge = never)
+    // second stream for the generator-table half of a shared-generator MSM: it is independent of the per-MSM points'
+    // half until the finish, so the two halves run side by side (fork after the status memset, join before the finish)
+    hipStream_t stream2 = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     bool sync_blocking = false;              // host entry points: sleep on a blocking event instead of spinning
     hipEvent_t done_ev = nullptr;
     // profiling
@@ -279,7 +283,10 @@ int bpgpu_ctx_create(int device, bpgpu_ctx **out) {
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->order_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->pin_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess) {
+        hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return BPGPU_ERR_HIP;
     }
@@ -303,6 +310,9 @@ void bpgpu_ctx_destroy(bpgpu_ctx *c) {
     if (c->order_ev) hipEventDestroy(c->order_ev);
     if (c->pin_ev) hipEventDestroy(c->pin_ev);
     if (c->done_ev) hipEventDestroy(c->done_ev);
+    if (c->fork_ev) hipEventDestroy(c->fork_ev);
+    if (c->join_ev) hipEventDestroy(c->join_ev);
+    if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->rp_status) hipFree(c->rp_status);
     if (c->d_gens) hipFree(c->d_gens);
     release_table(c);
@@ -963,6 +973,22 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
     fb_digit *d_digits = (fb_digit *)(c->arena + off_digits);
     ge_ext *d_partial = (ge_ext *)(c->arena + off_partial);
     HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
+    // the generator-table half (recode, walk, partial reduction) on the context's second stream, beside the per-MSM points
+    hipStream_t s2 = n_unique ? c->stream2 : s;
+    if (s2 != s) {
+        HIPCHK(c, hipEventRecord(c->fork_ev, s));
+        HIPCHK(c, hipStreamWaitEvent(s2, c->fork_ev, 0));
+    }
+    const uint32_t nrec = n_gen_terms * (uint32_t)nbatch;
+    LAUNCH(c, s2, "fb_recode", k_fb_recode, (nrec + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nrec, prm, (uint32_t)nbatch, n_gen_terms,
+           (const uint32_t *)d_gen_scalars, d_digits, d_status);
+    const uint32_t nblk_p = (uint32_t)((nbatch + FB_BLOCK - 1) / FB_BLOCK);
+    LAUNCH(c, s2, "fb_accum", k_fb_accum, nblk_p * nsplit, FB_BLOCK, prm, (uint32_t)nbatch, nblk_p, nsplit, npairs, d_ids, d_digits,
+           c->d_table, d_partial);
+    ge_ext *d_red = nullptr;
+    uint32_t nred = 0;
+    enqueue_fb_reduce(c, s2, (uint32_t)nbatch, nsplit, d_partial, &d_red, &nred);
+    if (s2 != s) HIPCHK(c, hipEventRecord(c->join_ev, s2));
     vb_dev d{};
     if (use_bucket) {   // many per-MSM points (the R1CS verifier's shape, r1cs/verifier.rs:459-491): bucket path
         bk_dev bd;
@@ -979,15 +1005,7 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
         rc = enqueue_vb_uniform(c, s, nbatch, n_unique, off, (const uint32_t *)d_uniq_scalars, (const uint32_t *)d_uniq_points, d_status, d);
         if (rc) return rc;
     }
-    const uint32_t nrec = n_gen_terms * (uint32_t)nbatch;
-    LAUNCH(c, s, "fb_recode", k_fb_recode, (nrec + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nrec, prm, (uint32_t)nbatch, n_gen_terms,
-           (const uint32_t *)d_gen_scalars, d_digits, d_status);
-    const uint32_t nblk_p = (uint32_t)((nbatch + FB_BLOCK - 1) / FB_BLOCK);
-    LAUNCH(c, s, "fb_accum", k_fb_accum, nblk_p * nsplit, FB_BLOCK, prm, (uint32_t)nbatch, nblk_p, nsplit, npairs, d_ids, d_digits,
-           c->d_table, d_partial);
-    ge_ext *d_red = nullptr;
-    uint32_t nred = 0;
-    enqueue_fb_reduce(c, s, (uint32_t)nbatch, nsplit, d_partial, &d_red, &nred);
+    if (s2 != s) HIPCHK(c, hipStreamWaitEvent(s, c->join_ev, 0));
     LAUNCH(c, s, "shared_finish", k_shared_finish, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, nred, d.hq, n_unique ? 1 : 0,
            d_red, d_status, (uint32_t *)d_out, (uint8_t *)d_verdict);
     if (d_status_bytes)
