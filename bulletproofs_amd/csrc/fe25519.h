@@ -23,7 +23,7 @@
 
 #if defined(__HIPCC__)
 #define BP_HD __host__ __device__ __forceinline__
-#define BP_HD_NOINLINE __host__ __device__ __attribute__((noinline))   // one copy of a big body (I-cache)
+#define BP_HD_NOINLINE __host__ __device__ inline __attribute__((noinline))   // one copy of a big body (I-cache)
 #else
 #define BP_HD inline
 #define BP_HD_NOINLINE inline
