@@ -21,7 +21,7 @@ EXPORTS = [
     "bpgpu_profile_enable", "bpgpu_profile_reset", "bpgpu_profile_report",
     "bpgpu_transcript_new", "bpgpu_transcript_append_message", "bpgpu_transcript_challenge_bytes",
     "bpgpu_rangeproof_verify_batch_ts", "bpgpu_rangeproof_verify_batch_ts_dev", "bpgpu_ipp_verify_batch_dev",
-    "bpgpu_ipp_create_batch",
+    "bpgpu_ipp_create_batch", "bpgpu_rangeproof_prove_batch",
 ]
 
 TRANSCRIPT_BYTES = 208
@@ -79,6 +79,7 @@ def lib():
     L.bpgpu_rangeproof_verify_batch_ts_dev.argtypes = [vp, sz, sz, sz, vp, sz, vp, u8p, vp, vp, vp, vp, vp, vp]
     L.bpgpu_ipp_verify_batch_dev.argtypes = [vp, sz, sz, vp, sz, u8p, sz, u8p, vp, vp, vp, vp, vp, vp, i, vp, vp, vp]
     L.bpgpu_ipp_create_batch.argtypes = [vp, sz, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, i, u8p, u8p, u8p, u8p]
+    L.bpgpu_rangeproof_prove_batch.argtypes = [vp, sz, sz, sz, C.POINTER(C.c_uint64), u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
     L.bpgpu_profile_enable.argtypes = [vp, i]
     L.bpgpu_profile_reset.argtypes = [vp]
     L.bpgpu_profile_report.argtypes = [vp, C.c_char_p, sz]
@@ -254,6 +255,21 @@ class Context:
         out, st = C.create_string_buffer(pl * max(nb, 1)), C.create_string_buffer(max(nb, 1))
         self._chk(self._L.bpgpu_ipp_create_batch(self.h, n, nb, label, len(label), transcript, Q, Gf, Hf, G, H, shared, a, b, out, st))
         return out.raw[:pl * nb], st.raw[:nb]
+
+    def rangeproof_prove_batch(self, n, m, values, blindings, label=b"", transcript=None, rng=None, want_transcripts=False):
+        """RangeProof::prove_multiple_with_rng for len(values) / m proofs (bpgpu_rangeproof_prove_batch): returns
+        (proofs bytes, commitments bytes[, final transcript states])."""
+        nb = len(values) // m
+        assert len(values) == nb * m and len(blindings) == 32 * nb * m
+        per = 64 * (m * (2 * n + 2) + 2 * m)
+        assert rng is None or len(rng) == per * nb
+        pl = 32 * (9 + 2 * ((n * m).bit_length() - 1))
+        va = (C.c_uint64 * max(len(values), 1))(*values)
+        proofs, coms = C.create_string_buffer(pl * max(nb, 1)), C.create_string_buffer(32 * m * max(nb, 1))
+        tso = C.create_string_buffer(TRANSCRIPT_BYTES * max(nb, 1)) if want_transcripts else None
+        self._chk(self._L.bpgpu_rangeproof_prove_batch(self.h, n, m, nb, va, blindings, label, len(label), transcript, rng, proofs, coms, tso))
+        out = (proofs.raw[:pl * nb], coms.raw[:32 * m * nb])
+        return out + (tso.raw[:TRANSCRIPT_BYTES * nb],) if want_transcripts else out
 
     # ---- instrumentation ----
     def profile_enable(self, on=True):

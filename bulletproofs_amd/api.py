@@ -116,6 +116,24 @@ class RangeProof:
     def to_bytes(self):
         return self._raw
 
+    @staticmethod
+    def prove_multiple_with_rng(bp_gens, pc_gens, transcript, values, blindings, n, rng_bytes=None):
+        """RangeProof::prove_multiple_with_rng (mod.rs:234-288) on the GPU (variable time: see include/bpgpu.h).  values: ints,
+        blindings: 32-byte scalars; rng_bytes: the bytes the rng would hand Scalar::random, in the reference's draw order
+        (None = OS CSPRNG).  Returns (RangeProof, [commitment bytes]); `transcript` is left advanced."""
+        bp_gens._check_pedersen(pc_gens)
+        m = len(values)
+        proofs, coms, ts = bp_gens.ctx.rangeproof_prove_batch(n, m, list(values), b"".join(blindings), transcript=transcript.state, rng=rng_bytes,
+                                                            want_transcripts=True)
+        transcript.state = ts
+        transcript.fresh_label = None
+        return RangeProof(proofs), [coms[32 * j:32 * j + 32] for j in range(m)]
+
+    @staticmethod
+    def prove_single_with_rng(bp_gens, pc_gens, transcript, v, v_blinding, n, rng_bytes=None):
+        proof, coms = RangeProof.prove_multiple_with_rng(bp_gens, pc_gens, transcript, [v], [v_blinding], n, rng_bytes)
+        return proof, coms[0]
+
     def verify_multiple_with_rng(self, bp_gens, pc_gens, transcript, value_commitments, n, rng64):
         """Ok(()) -> returns None; Err(e) -> raises e.  rng64 = the 64 bytes Scalar::random(rng) would draw (mod.rs:396);
         None = thread_rng()."""

@@ -92,6 +92,8 @@ struct bpgpu_ctx {
     size_t io_cap = 0;
     char *ipp_buf = nullptr;                 // term lists of the stand-alone inner-product verifier
     size_t ipp_cap = 0;
+    char *rpp_buf = nullptr;                 // working set of the batched range-proof prover
+    size_t rpp_cap = 0;
     uint32_t bucket_min = 0;                 // terms per MSM from which the bucket path is taken (0 = BK_MIN_TERMS; huge = never)
     // second stream for the generator-table half of a shared-generator MSM: it is independent of the per-MSM points'
     // half until the finish, so the two halves run side by side (fork after the status memset, join before the finish)
@@ -305,6 +307,7 @@ void bpgpu_ctx_destroy(bpgpu_ctx *c) {
     if (c->arena) hipFree(c->arena);
     if (c->io_dev) hipFree(c->io_dev);
     if (c->ipp_buf) hipFree(c->ipp_buf);
+    if (c->rpp_buf) hipFree(c->rpp_buf);
     if (c->pin) hipHostFree(c->pin);
     for (char *q : c->pin_retired) hipHostFree(q);
     if (c->order_ev) hipEventDestroy(c->order_ev);
@@ -1807,6 +1810,56 @@ extern "C" int bpgpu_ipp_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, con
     return BPGPU_OK;
 }
 
+// The rounds of InnerProductProof::create for nbatch proofs (ipp_prover.h): inputs and outputs in device memory.
+// d_ts: the proofs' transcript states AFTER innerproduct_domain_sep(n), advanced in place.  The k (L, R) pairs and the
+// final a, b go to d_proofs + p * proof_stride (+ 64 j, + 64 k); status_bytes (optional): BPGPU_MSM_* per proof.
+static int ippc_core(bpgpu_ctx *c, hipStream_t s, size_t n, size_t k, size_t nbatch, const void *d_a, const void *d_b, const void *d_gf, const void *d_hf,
+                     const void *d_q, const void *d_G, const void *d_H, int bases_shared, uint32_t *d_ts, uint8_t *d_proofs, size_t proof_stride,
+                     uint8_t *d_status_bytes) {
+    const size_t N = n + 1, w_v = align_up(nbatch * n * 32), w_u = align_up(nbatch * 32), w_terms = align_up(2 * nbatch * N * 32 + 64),
+                 w_out = align_up(2 * nbatch * 32), w_st = align_up(2 * nbatch + 64), w_status = align_up(nbatch * 4);
+    const size_t need = 4 * w_v + 2 * w_u + 2 * w_terms + w_out + w_st + w_status;
+    if (c->ipp_cap < need) {
+        HIPCHK(c, hipDeviceSynchronize());
+        if (c->ipp_buf) HIPCHK(c, hipFree(c->ipp_buf));
+        c->ipp_buf = nullptr;
+        c->ipp_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->ipp_buf, need + need / 4));
+        c->ipp_cap = need + need / 4;
+    }
+    char *wb = c->ipp_buf;
+    uint32_t *w_a = (uint32_t *)wb, *w_b = (uint32_t *)(wb + w_v), *w_G = (uint32_t *)(wb + 2 * w_v), *w_H = (uint32_t *)(wb + 3 * w_v);
+    uint32_t *w_uu = (uint32_t *)(wb + 4 * w_v), *w_ui = (uint32_t *)(wb + 4 * w_v + w_u);
+    uint32_t *m_sc = (uint32_t *)(wb + 4 * w_v + 2 * w_u), *m_pt = (uint32_t *)((char *)m_sc + w_terms), *m_out = (uint32_t *)((char *)m_pt + w_terms);
+    uint8_t *m_st = (uint8_t *)m_out + w_out;
+    uint32_t *d_status = (uint32_t *)(m_st + w_st);
+    HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
+    ippc_shape sh;
+    sh.n = (uint32_t)n;
+    sh.k = (uint32_t)k;
+    sh.nproofs = (uint32_t)nbatch;
+    sh.bases_shared = bases_shared ? 1u : 0u;
+    const uint32_t nb32 = (uint32_t)nbatch, nt32 = (uint32_t)(nbatch * n);
+    LAUNCH(c, s, "ippc_init", k_ippc_init, (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt32, sh, (const uint8_t *)d_a, (const uint8_t *)d_b, (const uint8_t *)d_gf,
+           (const uint8_t *)d_hf, w_a, w_b, w_G, w_H, d_status);
+    std::vector<uint32_t> nterms(2 * nbatch, (uint32_t)N);
+    const uint32_t n_q = (nb32 + BP_BLOCK - 1) / BP_BLOCK;
+    for (uint32_t j = 0; j < k; j++) {
+        LAUNCH(c, s, "ippc_terms", k_ippc_terms, n_q + (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_q, nt32, sh, j, (const uint32_t *)w_a, (const uint32_t *)w_b,
+               (const uint32_t *)w_G, (const uint32_t *)w_H, (const uint8_t *)d_G, (const uint8_t *)d_H, (const uint8_t *)d_q, m_sc, m_pt);
+        int rc = msm_batch_dev_locked(c, 2 * nbatch, nterms.data(), m_sc, m_pt, m_out, m_st, s);   // all L_j and R_j of the batch (ipp.rs:87-113)
+        if (rc) return rc;   // (callers drain the stream before they reuse their staging buffers)
+        LAUNCH(c, s, "ippc_challenge", k_ippc_challenge, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, j, (const uint32_t *)m_out, (const uint8_t *)m_st,
+               d_ts, w_uu, w_ui, d_proofs, (uint32_t)proof_stride, d_status);
+        LAUNCH(c, s, "ippc_fold", k_ippc_fold, (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt32, sh, j, (const uint32_t *)w_uu, (const uint32_t *)w_ui, w_a, w_b, w_G,
+               w_H);
+    }
+    LAUNCH(c, s, "ippc_final", k_ippc_final, (nb32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, sh, (const uint32_t *)w_a, (const uint32_t *)w_b, d_proofs,
+           (uint32_t)proof_stride, (const uint32_t *)d_status, d_status_bytes);
+    HIPCHK(c, hipGetLastError());
+    return BPGPU_OK;
+}
+
 // ============================================================================
 // batched inner-product-proof creation (ipp_prover.h)
 // ============================================================================
@@ -1860,55 +1913,168 @@ extern "C" int bpgpu_ipp_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, con
         for (size_t p = 0; p < nbatch; p++) memcpy(h + 4 * sz_v + sz_q + 2 * sz_base + p * TS, st0, TS);
     }
     HIPCHK(c, hipMemcpyAsync(c->io_dev, h, sz_in, hipMemcpyHostToDevice, s));
-    // ---- working set (own allocation: the MSM below claims the arena)
-    const size_t N = n + 1, w_v = align_up(nbatch * n * 32), w_u = align_up(nbatch * 32), w_terms = align_up(2 * nbatch * N * 32 + 64),
-                 w_out = align_up(2 * nbatch * 32), w_st = align_up(2 * nbatch + 64), w_status = align_up(nbatch * 4);
-    const size_t need = 4 * w_v + 2 * w_u + 2 * w_terms + w_out + w_st + w_status;
-    if (c->ipp_cap < need) {
-        HIPCHK(c, hipDeviceSynchronize());
-        if (c->ipp_buf) HIPCHK(c, hipFree(c->ipp_buf));
-        c->ipp_buf = nullptr;
-        c->ipp_cap = 0;
-        HIPCHK(c, hipMalloc((void **)&c->ipp_buf, need + need / 4));
-        c->ipp_cap = need + need / 4;
-    }
-    char *wb = c->ipp_buf;
-    uint32_t *w_a = (uint32_t *)wb, *w_b = (uint32_t *)(wb + w_v), *w_G = (uint32_t *)(wb + 2 * w_v), *w_H = (uint32_t *)(wb + 3 * w_v);
-    uint32_t *w_uu = (uint32_t *)(wb + 4 * w_v), *w_ui = (uint32_t *)(wb + 4 * w_v + w_u);
-    uint32_t *m_sc = (uint32_t *)(wb + 4 * w_v + 2 * w_u), *m_pt = (uint32_t *)((char *)m_sc + w_terms), *m_out = (uint32_t *)((char *)m_pt + w_terms);
-    uint8_t *m_st = (uint8_t *)m_out + w_out;
-    uint32_t *d_status = (uint32_t *)(m_st + w_st);
-    HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
     HIPCHK(c, hipMemsetAsync(d_proofs, 0, nbatch * proof_len, s));
-    ippc_shape sh;
-    sh.n = (uint32_t)n;
-    sh.k = (uint32_t)k;
-    sh.nproofs = (uint32_t)nbatch;
-    sh.bases_shared = bases_shared ? 1u : 0u;
-    const uint32_t nb32 = (uint32_t)nbatch, nt32 = (uint32_t)(nbatch * n);
-    LAUNCH(c, s, "ippc_init", k_ippc_init, (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt32, sh, (const uint8_t *)d_a, (const uint8_t *)d_b, (const uint8_t *)d_gf,
-           (const uint8_t *)d_hf, w_a, w_b, w_G, w_H, d_status);
-    std::vector<uint32_t> nterms(2 * nbatch, (uint32_t)N);
-    const uint32_t n_q = (nb32 + BP_BLOCK - 1) / BP_BLOCK;
-    for (uint32_t j = 0; j < k; j++) {
-        LAUNCH(c, s, "ippc_terms", k_ippc_terms, n_q + (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_q, nt32, sh, j, (const uint32_t *)w_a, (const uint32_t *)w_b,
-               (const uint32_t *)w_G, (const uint32_t *)w_H, (const uint8_t *)d_G, (const uint8_t *)d_H, (const uint8_t *)d_q, m_sc, m_pt);
-        rc = msm_batch_dev_locked(c, 2 * nbatch, nterms.data(), m_sc, m_pt, m_out, m_st, s);   // all L_j and R_j of the batch (ipp.rs:87-113)
-        if (rc) break;   // (falls through to the common tail: the stream is drained before the staging buffers are reused)
-        LAUNCH(c, s, "ippc_challenge", k_ippc_challenge, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, j, (const uint32_t *)m_out, (const uint8_t *)m_st,
-               (uint32_t *)d_ts, w_uu, w_ui, (uint8_t *)d_proofs, (uint32_t)proof_len, d_status);
-        LAUNCH(c, s, "ippc_fold", k_ippc_fold, (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt32, sh, j, (const uint32_t *)w_uu, (const uint32_t *)w_ui, w_a, w_b, w_G,
-               w_H);
-    }
+    // ---- rounds (ippc_core: own working set, the batched MSMs claim the arena)
+    rc = ippc_core(c, s, n, k, nbatch, d_a, d_b, d_gf, d_hf, d_q, d_G, d_H, bases_shared, (uint32_t *)d_ts, (uint8_t *)d_proofs, proof_len, (uint8_t *)d_stb);
     char *h_out = h + sz_in;
-    if (!rc) {
-        LAUNCH(c, s, "ippc_final", k_ippc_final, (nb32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, sh, (const uint32_t *)w_a, (const uint32_t *)w_b, (uint8_t *)d_proofs,
-               (uint32_t)proof_len, (const uint32_t *)d_status, (uint8_t *)d_stb);
-        if (hipMemcpyAsync(h_out, d_proofs, sz_out, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
-    }
+    if (!rc && hipMemcpyAsync(h_out, d_proofs, sz_out, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
     const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
     if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
     memcpy(proofs_out, h_out, nbatch * proof_len);
     memcpy(status_out, h_out + align_up(nbatch * proof_len), nbatch);
+    return BPGPU_OK;
+}
+
+// ============================================================================
+// batched range-proof creation (rp_prover.h)
+// ============================================================================
+extern "C" int bpgpu_rangeproof_prove_batch(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const uint64_t *values, const uint8_t *blindings,
+                                            const uint8_t *label, size_t label_len, const uint8_t *shared_transcript, const uint8_t *rng,
+                                            uint8_t *proofs_out, uint8_t *commitments_out, uint8_t *transcripts_out) {
+    if (!c || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0) return BPGPU_OK;
+    if (!values || !blindings || !proofs_out || !commitments_out) return BPGPU_ERR_INVALID_ARG;
+    // the parameter checks of prove_multiple_with_rng / Party::new / Dealer::new (mod.rs:244-246, party.rs:41-53, dealer.rs:34-60)
+    if (!(n == 8 || n == 16 || n == 32 || n == 64)) return fail(c, BPGPU_ERR_INVALID_ARG, "InvalidBitsize: n must be 8, 16, 32 or 64");
+    if (m == 0 || (m & (m - 1))) return fail(c, BPGPU_ERR_INVALID_ARG, "InvalidAggregation: m must be a power of two");
+    if (shared_transcript && !ts_state_ok(shared_transcript)) return fail(c, BPGPU_ERR_INVALID_ARG, "malformed transcript state");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_table) return fail(c, BPGPU_ERR_NO_GENS, "generators not loaded");
+    if (c->gens_capacity < n || c->party_capacity < m) return fail(c, BPGPU_ERR_NO_GENS, "InvalidGeneratorsLength: generators too small for n=%zu m=%zu", n, m);
+    if (n < 64)
+        for (size_t i = 0; i < nbatch * m; i++)
+            if (values[i] >> n) return fail(c, BPGPU_ERR_INVALID_ARG, "value %zu does not fit %zu bits", i, n);   // (the reference would prove a false statement's bits silently; refuse)
+    const size_t nm = n * m;
+    size_t k = 0;
+    while (((size_t)1 << k) < nm) k++;
+    if (k > BP_RP_MAX_K) return fail(c, BPGPU_ERR_INVALID_ARG, "n*m > 2^%d not supported", BP_RP_MAX_K);
+    rpp_shape sh;
+    sh.n = (uint32_t)n;
+    sh.m = (uint32_t)m;
+    sh.nm = (uint32_t)nm;
+    sh.k = (uint32_t)k;
+    sh.nproofs = (uint32_t)nbatch;
+    sh.proof_len = (uint32_t)(32 * (9 + 2 * k));
+    sh.n_gen_terms = (uint32_t)(2 * nm + 2);
+    sh.rng_per_proof = (uint32_t)(64 * (m * (2 * n + 2) + 2 * m));
+    const size_t nmsm1 = nbatch * (2 + m), TS = BPGPU_TRANSCRIPT_BYTES, proof_len = sh.proof_len;
+    const uint64_t gs_bytes = (uint64_t)nmsm1 * sh.n_gen_terms * 32;
+    if (gs_bytes > (4ull << 30) || (uint64_t)nmsm1 * sh.n_gen_terms > 0x7fffffffull || (uint64_t)nbatch * nm > 0x7fffffffull / 64)
+        return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large for this shape");
+    hipStream_t s = c->stream;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    // ---- inputs through pinned staging into the persistent IO buffer
+    const size_t sz_val = align_up(nbatch * m * 8), sz_bl = align_up(nbatch * m * 32), sz_rng = align_up(nbatch * sh.rng_per_proof), sz_ts = align_up(nbatch * TS);
+    const size_t sz_in = sz_val + sz_bl + sz_rng + sz_ts;
+    const size_t sz_pr = align_up(nbatch * proof_len), sz_cm = align_up(nbatch * m * 32);
+    const size_t sz_out = sz_pr + sz_cm + sz_ts;
+    rc = io_reserve(c, sz_in + sz_out);
+    if (rc) return rc;
+    char *h = nullptr;
+    rc = pin_alloc(c, s, sz_in + sz_out, &h);
+    if (rc) return rc;
+    memcpy(h, values, nbatch * m * 8);
+    memcpy(h + sz_val, blindings, nbatch * m * 32);
+    if (rng) memcpy(h + sz_val + sz_bl, rng, nbatch * sh.rng_per_proof);
+    else {   // thread_rng() of prove_multiple (mod.rs:291-310): OS CSPRNG
+        rc = os_random(c, h + sz_val + sz_bl, nbatch * sh.rng_per_proof);
+        if (rc) return rc;
+    }
+    uint8_t st_start[BPGPU_TRANSCRIPT_BYTES];
+    {   // every proof's transcript after rangeproof_domain_sep(n, m) (transcript.rs:44-48)
+        if (shared_transcript) memcpy(st_start, shared_transcript, TS);
+        else bpgpu_transcript_new(label, label_len, st_start);
+        uint32_t w[50];
+        strobe t;
+        ts_to_strobe(t, w, st_start);
+        const uint8_t rp[13] = {'r', 'a', 'n', 'g', 'e', 'p', 'r', 'o', 'o', 'f', ' ', 'v', '1'}, ln[1] = {'n'}, lm[1] = {'m'};
+        merlin_append_message(t, DOM_SEP, 7, rp, 13);
+        merlin_append_u64(t, ln, 1, n);
+        merlin_append_u64(t, lm, 1, m);
+        uint8_t st1[BPGPU_TRANSCRIPT_BYTES];
+        ts_from_strobe(st1, t);
+        for (size_t p = 0; p < nbatch; p++) memcpy(h + sz_val + sz_bl + sz_rng + p * TS, st1, TS);
+    }
+    char *d_in = c->io_dev;
+    const uint64_t *d_values = (const uint64_t *)d_in;
+    const uint8_t *d_bl = (const uint8_t *)(d_in + sz_val), *d_rng = (const uint8_t *)(d_in + sz_val + sz_bl);
+    uint32_t *d_ts = (uint32_t *)(d_in + sz_val + sz_bl + sz_rng);
+    uint8_t *d_proofs = (uint8_t *)(d_in + sz_in), *d_coms = d_proofs + sz_pr;
+    HIPCHK(c, hipMemcpyAsync(d_in, h, sz_in, hipMemcpyHostToDevice, s));
+    // ---- working set
+    const size_t w_gs = align_up(gs_bytes), w_mo = align_up(nmsm1 * 32), w_ms = align_up(nmsm1 + 64), w_f = align_up(RPP_FIXED * nbatch * 32),
+                 w_p = align_up(RPP_PARTY_FIELDS * nbatch * m * 32), w_v = align_up(nbatch * nm * 32), w_q = align_up(nbatch * 32), w_gen = align_up(nm * 32);
+    const size_t need = w_gs + w_mo + w_ms + w_f + w_p + 10 * w_v + w_q + 2 * w_gen;
+    if (c->rpp_cap < need) {
+        HIPCHK(c, hipDeviceSynchronize());
+        if (c->rpp_buf) HIPCHK(c, hipFree(c->rpp_buf));
+        c->rpp_buf = nullptr;
+        c->rpp_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->rpp_buf, need + need / 8));
+        c->rpp_cap = need + need / 8;
+    }
+    char *wb = c->rpp_buf;
+    uint32_t *gsc = (uint32_t *)wb, *mo = (uint32_t *)(wb + w_gs);
+    uint8_t *mst = (uint8_t *)mo + w_mo;
+    uint32_t *fields = (uint32_t *)(mst + w_ms), *party = (uint32_t *)((char *)fields + w_f);
+    char *vv = (char *)party + w_p;
+    uint32_t *sL = (uint32_t *)vv, *sR = (uint32_t *)(vv + w_v), *l0 = (uint32_t *)(vv + 2 * w_v), *l1 = (uint32_t *)(vv + 3 * w_v), *r0 = (uint32_t *)(vv + 4 * w_v),
+             *r1 = (uint32_t *)(vv + 5 * w_v), *avec = (uint32_t *)(vv + 6 * w_v), *bvec = (uint32_t *)(vv + 7 * w_v), *Gf = (uint32_t *)(vv + 8 * w_v),
+             *Hf = (uint32_t *)(vv + 9 * w_v);
+    uint32_t *qenc = (uint32_t *)(vv + 10 * w_v), *Genc = (uint32_t *)((char *)qenc + w_q), *Henc = (uint32_t *)((char *)Genc + w_gen);
+    const uint32_t nb32 = (uint32_t)nbatch, nbits = (uint32_t)(nbatch * nm), n_b = (nb32 + BP_BLOCK - 1) / BP_BLOCK;
+    do {
+        uint32_t *d_ids = nullptr;
+        rc = gen_ids_for(c, n, m, &d_ids);
+        if (rc) break;
+        LAUNCH(c, s, "gather32", k_gather32, ((uint32_t)(2 * nm) + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, (uint32_t)(2 * nm), (const uint32_t *)(d_ids + 2),
+               (const uint32_t *)c->d_gens, Genc);   // G(n, m) then H(n, m): Henc = Genc + nm records when w_gen is exact
+        if (hipMemsetAsync(gsc, 0, gs_bytes, s) != hipSuccess || hipMemsetAsync(d_proofs, 0, sz_pr, s) != hipSuccess) {
+            rc = fail(c, BPGPU_ERR_HIP, "memset failed");
+            break;
+        }
+        // (1) V_j, A, S
+        LAUNCH(c, s, "rpp_commit1", k_rpp_commit1, n_b + (nbits + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_b, nbits, sh, d_values, d_bl, d_rng, gsc, party, sL, sR);
+        rc = msm_shared_dev_locked(c, n, m, nmsm1, 0, gsc, nullptr, nullptr, mo, mst, nullptr, s);
+        if (rc) break;
+        LAUNCH(c, s, "rpp_chal1", k_rpp_chal1, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, (const uint32_t *)mo, d_ts, fields, d_proofs, d_coms);
+        // (2) polynomials, T_1, T_2
+        const uint32_t npar = (uint32_t)(nbatch * m);
+        LAUNCH(c, s, "rpp_poly", k_rpp_poly, (npar + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, npar, sh, d_values, (const uint32_t *)fields, (const uint32_t *)sL,
+               (const uint32_t *)sR, l0, l1, r0, r1, party);
+        if (hipMemsetAsync(gsc, 0, (size_t)2 * nbatch * sh.n_gen_terms * 32, s) != hipSuccess) {
+            rc = fail(c, BPGPU_ERR_HIP, "memset failed");
+            break;
+        }
+        LAUNCH(c, s, "rpp_tcommit", k_rpp_tcommit, n_b, BP_BLOCK, sh, d_rng, gsc, party);
+        rc = msm_shared_dev_locked(c, n, m, 2 * nbatch, 0, gsc, nullptr, nullptr, mo, mst, nullptr, s);
+        if (rc) break;
+        // (3) x, t_x ..., w; Q = w B; the inner-product argument's inputs
+        if (hipMemsetAsync(gsc, 0, (size_t)nbatch * sh.n_gen_terms * 32, s) != hipSuccess) {
+            rc = fail(c, BPGPU_ERR_HIP, "memset failed");
+            break;
+        }
+        LAUNCH(c, s, "rpp_chal2", k_rpp_chal2, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, (const uint32_t *)mo, d_ts, fields, (const uint32_t *)party, gsc,
+               d_proofs);
+        LAUNCH(c, s, "rpp_vectors", k_rpp_vectors, (nbits + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nbits, sh, (const uint32_t *)fields, (const uint32_t *)l0,
+               (const uint32_t *)l1, (const uint32_t *)r0, (const uint32_t *)r1, avec, bvec, Gf, Hf);
+        rc = msm_shared_dev_locked(c, n, m, nbatch, 0, gsc, nullptr, nullptr, qenc, mst, nullptr, s);
+        if (rc) break;
+        // (4) InnerProductProof::create over G(n, m), H(n, m) (dealer.rs:281-293): L, R pairs and a, b behind the 7 fixed elements
+        rc = ippc_core(c, s, nm, k, nbatch, avec, bvec, Gf, Hf, qenc, Genc, Genc + 8 * nm, 1, d_ts, d_proofs + 224, proof_len, nullptr);
+    } while (0);
+    char *h_out = h + sz_in;
+    if (!rc) {
+        if (hipMemcpyAsync(d_coms + sz_cm, d_ts, nbatch * TS, hipMemcpyDeviceToDevice, s) != hipSuccess ||
+            hipMemcpyAsync(h_out, d_proofs, sz_out, hipMemcpyDeviceToHost, s) != hipSuccess)
+            rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+    }
+    const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
+    if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
+    memcpy(proofs_out, h_out, nbatch * proof_len);
+    memcpy(commitments_out, h_out + sz_pr, nbatch * m * 32);
+    if (transcripts_out) memcpy(transcripts_out, h_out + sz_pr + sz_cm, nbatch * TS);
     return BPGPU_OK;
 }

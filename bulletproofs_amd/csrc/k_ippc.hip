@@ -44,5 +44,5 @@ __global__ void __launch_bounds__(BP_BLOCK) k_ippc_final(ippc_shape sh, const ui
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
     if (p >= sh.nproofs) return;
     ippc_final_thread(p, sh, a, b, proofs, proof_len);
-    status_out[p] = (uint8_t)status[p];
+    if (status_out) status_out[p] = (uint8_t)status[p];
 }

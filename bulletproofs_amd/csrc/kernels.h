@@ -12,6 +12,7 @@
 #include "ipp.h"
 #include "bucket.h"
 #include "ipp_prover.h"
+#include "rp_prover.h"
 
 #define BP_BLOCK 64   // one wavefront per workgroup: under contention a CU rarely has room for four waves of one group at once (256: -8% at 48 streams)
 #define FB_BLOCK 64
@@ -50,6 +51,14 @@ __global__ void k_from_uniform(uint32_t n, const uint32_t *uniform, uint32_t *ou
 // k_rlc.hip, bucket variant of the batch combination
 __global__ void k_rlc_accum_scalars(uint32_t n_acc, uint32_t nthreads, bk_params bk, uint32_t total, const bk_desc *desc, const uint32_t *idx, const fb_entry *pts, ge_ext *bsum, uint32_t n_rows, const unsigned long long *acc, fb_digit *digits, fb_params prm, uint32_t *ctl);
 __global__ void k_rlc_stage4b(const uint32_t *colq16, ge_ext *hq, fb_params prm, uint32_t nsplit, uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial);
+// k_rpp.hip
+__global__ void k_rpp_commit1(uint32_t n_b, uint32_t nthreads, rpp_shape sh, const uint64_t *values, const uint8_t *blindings, const uint8_t *rng, uint32_t *gen_scalars, uint32_t *party, uint32_t *sL, uint32_t *sR);
+__global__ void k_rpp_chal1(rpp_shape sh, const uint32_t *msm_out, uint32_t *ts, uint32_t *fields, uint8_t *proofs, uint8_t *commitments);
+__global__ void k_rpp_poly(uint32_t nthreads, rpp_shape sh, const uint64_t *values, const uint32_t *fields, const uint32_t *sL, const uint32_t *sR, uint32_t *l0, uint32_t *l1, uint32_t *r0, uint32_t *r1, uint32_t *party);
+__global__ void k_rpp_tcommit(rpp_shape sh, const uint8_t *rng, uint32_t *gen_scalars, uint32_t *party);
+__global__ void k_rpp_chal2(rpp_shape sh, const uint32_t *msm_out, uint32_t *ts, uint32_t *fields, const uint32_t *party, uint32_t *gen_scalars, uint8_t *proofs);
+__global__ void k_rpp_vectors(uint32_t nthreads, rpp_shape sh, const uint32_t *fields, const uint32_t *l0, const uint32_t *l1, const uint32_t *r0, const uint32_t *r1, uint32_t *a_vec, uint32_t *b_vec, uint32_t *Gf, uint32_t *Hf);
+__global__ void k_gather32(uint32_t count, const uint32_t *ids, const uint32_t *src, uint32_t *dst);
 // k_ippc.hip
 __global__ void k_ippc_init(uint32_t nthreads, ippc_shape sh, const uint8_t *a_in, const uint8_t *b_in, const uint8_t *Gf, const uint8_t *Hf, uint32_t *a, uint32_t *b, uint32_t *wG, uint32_t *wH, uint32_t *status);
 __global__ void k_ippc_terms(uint32_t n_q, uint32_t nthreads, ippc_shape sh, uint32_t j, const uint32_t *a, const uint32_t *b, const uint32_t *wG, const uint32_t *wH, const uint8_t *G, const uint8_t *H, const uint8_t *Q, uint32_t *msm_sc, uint32_t *msm_pt);

@@ -260,6 +260,30 @@ int bpgpu_ipp_create_batch(bpgpu_ctx *ctx, size_t n, size_t nbatch, const uint8_
                            const uint8_t *H_factors, const uint8_t *G, const uint8_t *H, int bases_shared,
                            const uint8_t *a, const uint8_t *b, uint8_t *proofs_out, uint8_t *status);
 
+/* ---- batched range-proof creation (prover side) ------------------------------------------
+ * nbatch independent calls of
+ *   RangeProof::prove_multiple_with_rng(bp_gens, pc_gens, &mut transcript, &values, &blindings, n, rng)
+ * (src/range_proof/mod.rs:234-288, running the dealer / party protocol of party.rs and dealer.rs in-line), all of one
+ * shape (n, m = values per proof): every commitment (V_j, A, S, T_1, T_2, Q) is a multiscalar multiplication over the
+ * generator tables, the inner-product argument is bpgpu_ipp_create_batch's (csrc/rp_prover.h).  Byte-identical to the
+ * reference algorithm given the same random scalars.
+ *   values      : nbatch x m u64 (each < 2^n);  blindings : nbatch x m x 32 bytes (Scalars, reduced mod l)
+ *   transcript  : shared_transcript (host, 208 bytes, may hold earlier messages) if not NULL, else Transcript::new(label)
+ *   rng         : nbatch x 64 * (m * (2n + 2) + 2m) bytes = what the rng would hand Scalar::random, in the order the
+ *                 reference draws: per party j: a_blinding, s_blinding, s_L[0..n), s_R[0..n); then per party j:
+ *                 t_1_blinding, t_2_blinding.  NULL = OS CSPRNG (the thread_rng() of prove_multiple).
+ *   proofs_out  : nbatch x 32 * (9 + 2 lg(n m)) bytes (RangeProof::to_bytes);  commitments_out : nbatch x m x 32 bytes
+ *   transcripts_out : optional nbatch x 208 bytes: each proof's transcript as the prover leaves it
+ * Returns BPGPU_ERR_INVALID_ARG for the reference's InvalidBitsize / InvalidAggregation (m not a power of two) / a value
+ * that does not fit n bits, BPGPU_ERR_NO_GENS for InvalidGeneratorsLength.
+ * VARIABLE TIME in the secrets (values, blindings, s_L, s_R): the reference computes A and S with its constant-time
+ * multiscalar_mul (party.rs:99-124); this engine has no constant-time path.  For provers whose GPU an adversary
+ * cannot observe. */
+int bpgpu_rangeproof_prove_batch(bpgpu_ctx *ctx, size_t n, size_t m, size_t nbatch, const uint64_t *values,
+                                 const uint8_t *blindings, const uint8_t *label, size_t label_len,
+                                 const uint8_t *shared_transcript, const uint8_t *rng,
+                                 uint8_t *proofs_out, uint8_t *commitments_out, uint8_t *transcripts_out);
+
 /* ---- instrumentation -----------------------------------------------------------
  * When enabled, every kernel launch is bracketed by HIP events on its stream;
  * bpgpu_profile_report writes one line per kernel: "name launches total_ms". */

@@ -14,6 +14,7 @@
 #include "../../bulletproofs_amd/csrc/rlc.h"
 #include "../../bulletproofs_amd/csrc/bucket.h"
 #include "../../bulletproofs_amd/csrc/ipp_prover.h"
+#include "../../bulletproofs_amd/csrc/rp_prover.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -570,6 +571,81 @@ int h_ipp_create(uint32_t n, uint32_t nbatch, const uint8_t *ts0, const uint8_t 
         for (uint32_t tid = 0; tid < nbatch * n; tid++) ippc_fold_thread(tid, sh, j, u.data(), ui.data(), a.data(), b.data(), wG.data(), wH.data());
     }
     for (uint32_t p = 0; p < nbatch; p++) { ippc_final_thread(p, sh, a.data(), b.data(), proofs, proof_len); status_out[p] = (uint8_t)status[p]; }
+    return 0;
+}
+
+// The batched range-proof prover (rp_prover.h), lane by lane: commitments through the shared-generator pipeline emulation
+// (h_msm_shared, tables of window W), the inner-product argument through h_ipp_create's rounds.
+// gens: [B_blinding, B, G(party-major, capacity), H(...)] encodings; ts0: 208-byte transcript state before rangeproof_domain_sep.
+int h_rp_prove(uint32_t W, uint32_t gens_capacity, uint32_t party_capacity, const uint8_t *gens, uint32_t n, uint32_t m, uint32_t nbatch,
+               const uint64_t *values, const uint8_t *blindings, const uint8_t *ts0, const uint8_t *rng, uint8_t *proofs, uint8_t *commitments,
+               uint8_t *ts_out) {
+    rpp_shape sh; sh.n = n; sh.m = m; sh.nm = n * m; sh.k = 0; while ((1u << sh.k) < sh.nm) sh.k++;
+    sh.nproofs = nbatch; sh.proof_len = 32 * (9 + 2 * sh.k); sh.n_gen_terms = 2 * sh.nm + 2; sh.rng_per_proof = 64 * (m * (2 * n + 2) + 2 * m);
+    const uint32_t nm = sh.nm, tot = gens_capacity * party_capacity, n_loaded = 2 + 2 * tot;
+    std::vector<uint32_t> ids; ids.push_back(0); ids.push_back(1);
+    for (uint32_t j = 0; j < m; j++) for (uint32_t i = 0; i < n; i++) ids.push_back(2 + j * gens_capacity + i);
+    for (uint32_t j = 0; j < m; j++) for (uint32_t i = 0; i < n; i++) ids.push_back(2 + tot + j * gens_capacity + i);
+    std::vector<uint32_t> ts((size_t)nbatch * BP_TS_WORDS);
+    {
+        uint32_t w[50]; memcpy(w, ts0, 200);
+        strobe t; t.st.w = w; t.st.stride = 1; t.pos = ts0[200]; t.pos_begin = ts0[201]; t.cur_flags = ts0[202];
+        const uint8_t dom[7] = {'d','o','m','-','s','e','p'}, rp[13] = {'r','a','n','g','e','p','r','o','o','f',' ','v','1'}, ln[1] = {'n'}, lm[1] = {'m'};
+        merlin_append_message(t, dom, 7, rp, 13); merlin_append_u64(t, ln, 1, n); merlin_append_u64(t, lm, 1, m);
+        for (uint32_t p = 0; p < nbatch; p++) {
+            memcpy(&ts[(size_t)p * BP_TS_WORDS], w, 200);
+            ts[(size_t)p * BP_TS_WORDS + 50] = rp_ts_meta(t.pos, t.pos_begin, t.cur_flags); ts[(size_t)p * BP_TS_WORDS + 51] = 0;
+        }
+    }
+    const uint32_t nmsm1 = nbatch * (2 + m);
+    std::vector<uint32_t> gsc((size_t)nmsm1 * sh.n_gen_terms * 8, 0), mo((size_t)nmsm1 * 8 + 8), fields((size_t)RPP_FIXED * nbatch * 8),
+        party((size_t)RPP_PARTY_FIELDS * nbatch * m * 8);
+    std::vector<uint8_t> mst(nmsm1 + 1), mver(nmsm1 + 1);
+    std::vector<uint32_t> sL((size_t)nbatch * nm * 8), sR(sL.size()), l0(sL.size()), l1(sL.size()), r0(sL.size()), r1(sL.size()), av(sL.size()), bv(sL.size()),
+        Gf(sL.size()), Hf(sL.size());
+    memset(proofs, 0, (size_t)nbatch * sh.proof_len);
+    for (uint32_t p = 0; p < nbatch; p++) rpp_blind_thread(p, sh, values, blindings, rng, gsc.data(), party.data());
+    for (uint32_t tid = 0; tid < nbatch * nm; tid++) rpp_bits_thread(tid, sh, values, rng, gsc.data(), sL.data(), sR.data());
+    if (h_msm_shared(W, 3, n_loaded, gens, sh.n_gen_terms, ids.data(), nmsm1, 0, (const uint8_t *)gsc.data(), nullptr, nullptr, (uint8_t *)mo.data(), mst.data(), mver.data())) return -1;
+    for (uint32_t p = 0; p < nbatch; p++) { uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1; rpp_chal1_thread(p, sh, st, mo.data(), ts.data(), fields.data(), proofs, commitments); }
+    for (uint32_t tid = 0; tid < nbatch * m; tid++) rpp_poly_thread(tid, sh, values, fields.data(), sL.data(), sR.data(), l0.data(), l1.data(), r0.data(), r1.data(), party.data());
+    std::fill(gsc.begin(), gsc.end(), 0u);
+    for (uint32_t p = 0; p < nbatch; p++) rpp_tcommit_thread(p, sh, rng, gsc.data(), party.data());
+    if (h_msm_shared(W, 2, n_loaded, gens, sh.n_gen_terms, ids.data(), 2 * nbatch, 0, (const uint8_t *)gsc.data(), nullptr, nullptr, (uint8_t *)mo.data(), mst.data(), mver.data())) return -2;
+    std::fill(gsc.begin(), gsc.end(), 0u);
+    for (uint32_t p = 0; p < nbatch; p++) { uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1; rpp_chal2_thread(p, sh, st, mo.data(), ts.data(), fields.data(), party.data(), gsc.data(), proofs); }
+    for (uint32_t tid = 0; tid < nbatch * nm; tid++) rpp_vectors_thread(tid, sh, fields.data(), l0.data(), l1.data(), r0.data(), r1.data(), av.data(), bv.data(), Gf.data(), Hf.data());
+    std::vector<uint32_t> qenc((size_t)nbatch * 8 + 8);
+    if (h_msm_shared(W, 1, n_loaded, gens, sh.n_gen_terms, ids.data(), nbatch, 0, (const uint8_t *)gsc.data(), nullptr, nullptr, (uint8_t *)qenc.data(), mst.data(), mver.data())) return -3;
+    // inner-product rounds (the body of h_ipp_create on the advanced transcripts)
+    std::vector<uint32_t> Genc((size_t)2 * nm * 8);
+    for (uint32_t t = 0; t < 2 * nm; t++) memcpy(&Genc[(size_t)t * 8], gens + 32 * (size_t)ids[2 + t], 32);
+    ippc_shape ish; ish.n = nm; ish.k = sh.k; ish.nproofs = nbatch; ish.bases_shared = 1;
+    const uint32_t N = nm + 1;
+    std::vector<uint32_t> a((size_t)nbatch * nm * 8), b(a.size()), wG(a.size()), wH(a.size()), status(nbatch + 1, 0), u((size_t)nbatch * 8), ui(u.size());
+    for (uint32_t tid = 0; tid < nbatch * nm; tid++)
+        ippc_init_thread(tid, ish, (const uint8_t *)av.data(), (const uint8_t *)bv.data(), (const uint8_t *)Gf.data(), (const uint8_t *)Hf.data(), a.data(), b.data(), wG.data(), wH.data(), status.data());
+    std::vector<uint32_t> msc((size_t)2 * nbatch * N * 8 + 8), mpt(msc.size()), mout((size_t)2 * nbatch * 8 + 8), nt(2 * nbatch, N);
+    std::vector<uint8_t> mst2(2 * nbatch + 1);
+    for (uint32_t j = 0; j < sh.k; j++) {
+        for (uint32_t p = 0; p < nbatch; p++) ippc_q_thread(p, ish, j, a.data(), b.data(), (const uint8_t *)qenc.data(), msc.data(), mpt.data());
+        for (uint32_t tid = 0; tid < nbatch * nm; tid++)
+            ippc_terms_thread(tid, ish, j, a.data(), b.data(), wG.data(), wH.data(), (const uint8_t *)Genc.data(), (const uint8_t *)(Genc.data() + (size_t)8 * nm), msc.data(), mpt.data());
+        h_msm_vb(2 * nbatch, nt.data(), (const uint8_t *)msc.data(), (const uint8_t *)mpt.data(), (uint8_t *)mout.data(), mst2.data());
+        for (uint32_t p = 0; p < nbatch; p++) {
+            uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;
+            ippc_challenge_thread(p, ish, j, st, mout.data(), mst2.data(), ts.data(), u.data(), ui.data(), proofs + 224, sh.proof_len, status.data());
+        }
+        for (uint32_t tid = 0; tid < nbatch * nm; tid++) ippc_fold_thread(tid, ish, j, u.data(), ui.data(), a.data(), b.data(), wG.data(), wH.data());
+    }
+    for (uint32_t p = 0; p < nbatch; p++) ippc_final_thread(p, ish, a.data(), b.data(), proofs + 224, sh.proof_len);
+    if (ts_out)
+        for (uint32_t p = 0; p < nbatch; p++) {
+            memset(ts_out + (size_t)p * 208, 0, 208); memcpy(ts_out + (size_t)p * 208, &ts[(size_t)p * BP_TS_WORDS], 200);
+            const uint32_t meta = ts[(size_t)p * BP_TS_WORDS + 50];
+            ts_out[(size_t)p * 208 + 200] = meta & 0xff; ts_out[(size_t)p * 208 + 201] = (meta >> 8) & 0xff; ts_out[(size_t)p * 208 + 202] = (meta >> 16) & 0xff;
+        }
+    for (uint32_t p = 0; p < nbatch; p++) if (status[p]) return -10;
     return 0;
 }
 }

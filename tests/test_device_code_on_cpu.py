@@ -155,6 +155,34 @@ def test_variable_base_pipeline_lane_by_lane(H, oracle):
     assert st.raw[0] == 2
 
 
+@pytest.mark.parametrize("n,m", [(8, 1), (8, 2), (16, 4)])
+def test_batched_rangeproof_prover_lane_by_lane(H, oracle, n, m):
+    """rp_prover.h: RangeProof::prove_multiple_with_rng (mod.rs:234-288; party.rs, dealer.rs) with every commitment as a
+    multiscalar multiplication over the generator tables and the inner-product argument of ipp_prover.h -- proofs,
+    commitments and final transcripts byte-identical to the oracle's prover given the same random scalars (the oracle draws
+    them from SHAKE256(seed): the same bytes are handed to the device code), and the oracle's verifier accepts."""
+    nb = 3
+    g = oracle.Gens(n, m)
+    G, Hh, B, Bb = g.export()
+    gens = Bb + B + G + Hh
+    vals = [int.from_bytes(hashlib.shake_256(b"pv%d-%d-%d" % (n, m, i)).digest(8), "little") % (1 << n) for i in range(nb * m)]
+    bl = b"".join(hashlib.shake_256(b"pb%d-%d-%d" % (n, m, i)).digest(32) for i in range(nb * m))   # arbitrary 32 bytes: reduced mod l
+    per = 64 * (m * (2 * n + 2) + 2 * m)
+    seeds = [b"rpp-%d-%d-%d" % (n, m, p) for p in range(nb)]
+    rng = b"".join(hashlib.shake_256(sd).digest(per) for sd in seeds)
+    st0 = oracle.transcript_append_message(oracle.transcript_new(b"prover"), b"ctx", b"hello")
+    pl = oracle.proof_len(n, m)
+    proofs, coms, ts = C.create_string_buffer(pl * nb), C.create_string_buffer(32 * m * nb), C.create_string_buffer(208 * nb)
+    va = (C.c_uint64 * len(vals))(*vals)
+    assert H.h_rp_prove(4, n, m, gens, n, m, nb, va, bl, st0, rng, proofs, coms, ts) == 0
+    for p in range(nb):
+        epr, ecm, ets = oracle.prove_ts(g, vals[p * m:(p + 1) * m], bl[32 * m * p:32 * m * (p + 1)], n, st0, seeds[p])
+        assert coms.raw[32 * m * p:32 * m * (p + 1)] == ecm, (n, m, p)
+        assert proofs.raw[pl * p:pl * (p + 1)] == epr, (n, m, p)
+        assert ts.raw[208 * p:208 * (p + 1)] == ets
+        assert oracle.verify_ts(g, epr, ecm, n, st0, bytes(64))[0] == 0
+
+
 @pytest.mark.parametrize("n", [1, 2, 8, 32])
 def test_batched_ipp_prover_lane_by_lane(H, oracle, n):
     """ipp_prover.h (InnerProductProof::create without folding the generators: every L_j / R_j is one MSM over the original

@@ -66,3 +66,58 @@ def test_create_error_statuses(ctx, oracle):
     import bulletproofs_amd as bp
     with pytest.raises(bp.BpgpuError):
         ctx.ipp_create_batch(6, inst["Q"], inst["Gf"][:192], inst["Hf"][:192], inst["G"][:192], inst["H"][:192], a[:192], b[:192])
+
+
+@pytest.mark.parametrize("n,m,nb", [(64, 1, 48), (32, 4, 10), (8, 2, 5), (64, 16, 3)])
+def test_rangeproof_prove_batch_is_byte_identical_to_oracle(oracle, n, m, nb):
+    """bpgpu_rangeproof_prove_batch == the oracle's prove_multiple_with_rng restatement (mod.rs:234-288, party.rs, dealer.rs)
+    on the same random scalars: proofs, commitments and final transcripts byte for byte; the GPU verifier accepts the
+    proofs on the same (pre-bound) transcript and rejects them on another one."""
+    import bulletproofs_amd as bp
+    ctx = bp.Context(0, fixed_window_bits=12)
+    ctx.gens_create(n, m)
+    g = oracle.Gens(n, m)
+    vals = [int.from_bytes(hashlib.shake_256(b"gv%d-%d-%d" % (n, m, i)).digest(8), "little") % (1 << n) for i in range(nb * m)]
+    vals[0] = (1 << n) - 1
+    vals[-1] = 0
+    bl = b"".join(hashlib.shake_256(b"gb%d-%d-%d" % (n, m, i)).digest(32) for i in range(nb * m))
+    per = 64 * (m * (2 * n + 2) + 2 * m)
+    seeds = [b"grpp-%d-%d-%d" % (n, m, p) for p in range(nb)]
+    rng = b"".join(hashlib.shake_256(sd).digest(per) for sd in seeds)
+    st0 = oracle.transcript_append_message(oracle.transcript_new(b"prover"), b"ctx", b"gpu")
+    pl = oracle.proof_len(n, m)
+    proofs, coms, ts = ctx.rangeproof_prove_batch(n, m, vals, bl, transcript=st0, rng=rng, want_transcripts=True)
+    for p in range(nb if n * m <= 256 else 2):
+        epr, ecm, ets = oracle.prove_ts(g, vals[p * m:(p + 1) * m], bl[32 * m * p:32 * m * (p + 1)], n, st0, seeds[p])
+        assert coms[32 * m * p:32 * m * (p + 1)] == ecm and proofs[pl * p:pl * (p + 1)] == epr and ts[208 * p:208 * (p + 1)] == ets, (n, m, p)
+    v, ts_v = ctx.rangeproof_verify_batch_ts(n, m, proofs, pl, coms, st0, bytes(64 * nb), want_transcripts=True)
+    assert v == bytes(nb) and ts_v == ts            # prover and verifier leave the same transcript
+    assert all(x == 1 for x in ctx.rangeproof_verify_batch(n, m, proofs, pl, coms, b"prover", bytes(64 * nb)))
+    # label form + library randomness: proofs verify, and differ from call to call
+    p1, c1 = ctx.rangeproof_prove_batch(n, m, vals, bl, label=b"lbl")
+    p2, c2 = ctx.rangeproof_prove_batch(n, m, vals, bl, label=b"lbl")
+    assert c1 == c2 == coms and p1 != p2
+    assert ctx.rangeproof_verify_batch(n, m, p1, pl, c1, b"lbl") == bytes(nb)
+    # parameter errors of the reference: InvalidBitsize, InvalidAggregation, InvalidGeneratorsLength, value out of range
+    for bad_n, bad_m, bad_vals in ((24, m, vals), (n, 3, vals[:3 * (len(vals) // 3) if len(vals) >= 3 else 0] or [0, 0, 0]), (n, 2 * m, vals * 2)):
+        with pytest.raises(bp.BpgpuError):
+            ctx.rangeproof_prove_batch(bad_n, bad_m, bad_vals, bytes(32 * len(bad_vals)), label=b"x")
+    if n < 64:
+        with pytest.raises(bp.BpgpuError):
+            ctx.rangeproof_prove_batch(n, m, [1 << n] + vals[1:], bl, label=b"x")
+    ctx.close()
+
+
+def test_reference_api_prove_then_verify(oracle):
+    from bulletproofs_amd import BulletproofGens, RangeProof, Transcript
+    bp_gens = BulletproofGens(64, 4, fixed_window_bits=12)
+    pc_gens = bp_gens.pedersen()
+    tp = Transcript(b"doctest example")
+    secrets = [4242344947, 3718732727, 2255562556, 2526146994]           # README.md of the reference: the aggregated example
+    blindings = [hashlib.shake_256(b"rb%d" % i).digest(31) + b"\x00" for i in range(4)]
+    proof, commitments = RangeProof.prove_multiple_with_rng(bp_gens, pc_gens, tp, secrets, blindings, 32)
+    tv = Transcript(b"doctest example")
+    assert RangeProof.from_bytes(proof.to_bytes()).verify_multiple(bp_gens, pc_gens, tv, commitments, 32) is None
+    assert tv.state == tp.state
+    g = oracle.Gens(64, 4)
+    assert oracle.verify(g, proof.to_bytes(), b"".join(commitments), 32, b"doctest example", bytes(64))[0] == 0
