@@ -494,6 +494,19 @@ def main():
                                 "every 8th batch carries planted invalid proofs and must come back undecided" % batch}
     roof = roofline_block(a.config, n, m, batch, r["kern"], value, wl, r["events_every"], default_batch) if rank == 0 else None
     b.close()
+    if world == 1 and not a.rlc and not a.no_extra and a.steps >= 8 and a.config == "cfg2" and not a.batch:
+        # the batch-combined entry point at batches of 4096: from 32768 terms the per-proof points of the whole batch go through
+        # ONE bucket (Pippenger) MSM (csrc/bucket.h)
+        try:
+            b4 = RangeProofBench(a, "cfg2", 4096, min(32, nstreams), rank, local_dev, rlc=True)
+            k4 = 256 if a.steps >= 640 else max(a.steps, 8)
+            r4 = timed(b4, k4, 32 if a.steps >= 640 else 8, fence, 0)
+            extra["rlc_batch4096"] = {"verifications_per_s": round(4096 * k4 / r4["elapsed"], 1), "steps": k4, "streams": b4.nstreams, "regions": len(r4["regions"]),
+                                      "kernels_us": {k_: round(v_[1] / v_[0] * 1e3, 2) for k_, v_ in sorted(r4["kern"].items(), key=lambda kv: -kv[1][1])},
+                                      "note": "bpgpu_rangeproof_verify_rlc_dev on batches of 4096 cfg2 proofs (69632 per-proof terms per combination: bucket MSM)"}
+            b4.close()
+        except Exception as e:
+            extra["rlc_batch4096"] = {"error": str(e)}
     if world == 1 and not a.rlc and not a.no_extra and a.steps >= 8 and a.config == "cfg2":
         # (2) BASELINE configs 3 and 4 (aggregated m = 16 at batch 256, m = 32 at 512 per GPU) and (3) config 5's MSM shape,
         # each with its own roofline

@@ -8,7 +8,8 @@
 //   Transcript ............ merlin::Transcript: new / append_message / append_u64 / challenge_bytes, held as its
 //                           208-byte STROBE state; verifiers take it by reference and leave it advanced
 //   RangeProof ............ src/range_proof/mod.rs:59-76, from_bytes 504-538, to_bytes 487-500,
-//                           verify_single[_with_rng] 316-342, verify_multiple[_with_rng] 345-470
+//                           verify_single[_with_rng] 316-342, verify_multiple[_with_rng] 345-470,
+//                           prove_single/multiple_with_rng 115-288 (variable time on the GPU)
 // plus verify_batch, the batched entry point this engine exists for.  No arithmetic happens on the
 // host: parsing checks lengths and scalar canonicity (so from_bytes fails where the reference's does)
 // and everything else is one call into the GPU library.  There is no CPU fallback.
@@ -20,6 +21,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <variant>
 #include <vector>
 
@@ -158,6 +160,36 @@ class RangeProof {
         return p;
     }
     static std::variant<RangeProof, ProofError> from_bytes(const std::vector<uint8_t> &v) { return from_bytes(v.data(), v.size()); }
+
+    // RangeProof::prove_multiple_with_rng (mod.rs:234-288) on the GPU: (proof, value commitments).  `transcript` is &mut
+    // (left advanced).  rng_bytes: the bytes the rng would hand Scalar::random, in the reference's draw order --
+    // 64 * (m (2n + 2) + 2m) of them -- or nullptr for the OS CSPRNG.  VARIABLE TIME in the secrets (see bpgpu.h).
+    static std::pair<RangeProof, std::vector<CompressedRistretto>> prove_multiple_with_rng(const BulletproofGens &bp_gens, const PedersenGens &pc_gens,
+                                                                                           Transcript &transcript, const std::vector<uint64_t> &values,
+                                                                                           const std::vector<ScalarBytes> &blindings, size_t n,
+                                                                                           const uint8_t *rng_bytes = nullptr) {
+        bp_gens.check_pedersen(pc_gens);
+        const size_t m = values.size();
+        if (blindings.size() != m) throw std::invalid_argument("prove_multiple: WrongNumBlindingFactors");
+        size_t k = 0;
+        while ((size_t(1) << k) < n * m) k++;
+        RangeProof p;
+        p.bytes_.resize(32 * (9 + 2 * k));
+        std::vector<CompressedRistretto> vc(m);
+        std::vector<uint8_t> bl(32 * m);
+        for (size_t j = 0; j < m; j++) std::memcpy(&bl[32 * j], blindings[j].data(), 32);
+        std::array<uint8_t, BPGPU_TRANSCRIPT_BYTES> in = transcript.state();
+        const int rc = bpgpu_rangeproof_prove_batch(bp_gens.ctx(), n, m, 1, values.data(), bl.data(), nullptr, 0, in.data(), rng_bytes, p.bytes_.data(),
+                                                    m ? vc[0].data() : nullptr, transcript.state_mut().data());
+        if (rc != BPGPU_OK) throw GpuError(bpgpu_last_error(bp_gens.ctx()));
+        return {p, vc};
+    }
+    static std::pair<RangeProof, CompressedRistretto> prove_single_with_rng(const BulletproofGens &bp_gens, const PedersenGens &pc_gens, Transcript &transcript,
+                                                                            uint64_t v, const ScalarBytes &v_blinding, size_t n,
+                                                                            const uint8_t *rng_bytes = nullptr) {
+        auto r = prove_multiple_with_rng(bp_gens, pc_gens, transcript, {v}, {v_blinding}, n, rng_bytes);
+        return {r.first, r.second[0]};
+    }
     const std::vector<uint8_t> &to_bytes() const { return bytes_; }
 
     // verify_multiple_with_rng: rng64 = the 64 bytes the rng would hand Scalar::random (mod.rs:396)

@@ -80,6 +80,17 @@ int main() {
         }
         CHECK(threw);
     }
+    // prove on the GPU, verify on the GPU: the README example of the reference (create and verify a 32-bit range proof)
+    {
+        Transcript prover_transcript("doctest example");
+        ScalarBytes blinding{};
+        blinding[0] = 7;
+        auto made = RangeProof::prove_single_with_rng(bp_gens, pc_gens, prover_transcript, 1037578891ull, blinding, 32);
+        Transcript verifier_transcript("doctest example");
+        CHECK(made.first.verify_single(bp_gens, pc_gens, verifier_transcript, made.second, 32) == Status::Ok());
+        CHECK(verifier_transcript.state() == prover_transcript.state());
+        CHECK(made.first.verify_single(bp_gens, pc_gens, Transcript("another"), made.second, 32) == Status::Err(ProofError::VerificationError));
+    }
     // batched form
     std::vector<std::vector<uint8_t>> proofs(5, hex_decode(GOLDEN_PROOFS[3][0]));
     proofs[2][130] ^= 1;
