@@ -69,7 +69,8 @@ def parse_args():
     ap.add_argument("--cpu-threads", type=int, default=0, help="threads of the CPU baseline (0 = all cores)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the informational figures (batch-combined mode, cfg3, cfg5 shape)")
-    ap.add_argument("--events-all", action="store_true", help="attach kernel start/stop events on every stream (default: every 8th when steps >= 8 x streams)")
+    ap.add_argument("--no-events", action="store_true", help="no kernel start/stop events in the timed region (no roofline block): measures their perturbation")
+    ap.add_argument("--events-all", action="store_true", help="attach kernel start/stop events on every stream (default: every 32nd when steps >= 8 x streams)")
     return ap.parse_args()
 
 
@@ -247,7 +248,7 @@ class RangeProofBench:
         self.ctxs = []
 
 
-def timed(b, K, warmup, fence, repeat, gather=None, events_all=False):
+def timed(b, K, warmup, fence, repeat, gather=None, events_all=False, no_events=False):
     """context set-up, warmup, then R regions of K steps; returns dict(elapsed (median), regions, enqueue, kern, allv)"""
     for k in range(min(b.nstreams, max(K, 1))):              # context set-up (not a warmup step): the first call on a context
         b.step(k, _scratch_row(b))                           # sizes its arena and caches the work decomposition
@@ -256,8 +257,11 @@ def timed(b, K, warmup, fence, repeat, gather=None, events_all=False):
         b.region(warmup, fence)
     for c_ in b.ctxs:
         c_.profile_reset()
-    sparse = (K >= 8 * b.nstreams) and not events_all       # start/stop events cost ~5 % when attached to every launch of every stream
-    b.set_profile(True, 8 if sparse else 1)
+    # start/stop events attached to a dispatch cost queue time: measured at the default workload, events on every 8th stream
+    # lower the throughput by 4 % (5.25 vs 5.47 M/s, --no-events), so long runs sample every 32nd stream (~1 %)
+    sparse = (K >= 8 * b.nstreams) and not events_all
+    every = max(1, min(32, b.nstreams // 4)) if sparse else 1
+    b.set_profile(not no_events, every)
     regs, enq, allv = [], [], None
     dt, te, allv = b.region(K, fence, gather)
     regs.append(dt)
@@ -274,7 +278,7 @@ def timed(b, K, warmup, fence, repeat, gather=None, events_all=False):
         enq.append(te)
     b.set_profile(False)
     return {"elapsed": statistics.median(regs), "regions": regs, "enqueue": statistics.median(enq), "kern": b.kernel_times(), "allv": allv,
-            "events_every": 8 if sparse else 1}
+            "events_every": every}
 
 
 def _scratch_row(b):
@@ -322,7 +326,7 @@ def roofline_block(cfg, n, m, batch, kern, value, wl, events_every, default_batc
             "frac": achieved / 8000.0, "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt,
             "algorithmic_bytes_per_launch": alg_bytes,
             "timing": "start/stop events attached to the dispatches (hipExtLaunchKernelGGL) of every %s stream, on their launch stream, inside the "
-                      "timed region; kernel begin..end as in rocprofv3's kernel trace" % ("8th" if events_every == 8 else ""),
+                      "timed region; kernel begin..end as in rocprofv3's kernel trace" % (("%dth" % events_every) if events_every > 1 else ""),
             "note": "the path is bound by integer VALU issue, not HBM: ~10 field multiplications per input byte, so the HBM fraction is ~1e-3 by construction",
             "dominant_by": "VALU work (half of a batch's wavefront-instructions) and all of the table traffic; by slot time under load the narrow, latency-bound "
                            "rp_stage1 (one lane per proof: 12 Keccak-f per proof) is comparable -- see kernels_us",
@@ -473,7 +477,7 @@ def main():
 
     # the final identity-check gather: one collective (RCCL; gloo on host copies when ranks share a GPU)
     gather = (lambda v: bpdist.gather_verdicts(v.cpu() if oversub else v, world)) if world > 1 else None
-    r = timed(b, a.steps, a.warmup, fence, a.repeat, gather, a.events_all)
+    r = timed(b, a.steps, a.warmup, fence, a.repeat, gather, a.events_all, a.no_events)
     elapsed = bpdist.max_over_ranks(r["elapsed"], world, None if oversub else dev)
     if world > 1 and a.steps:     # every rank's verdict rows arrived and carry that rank's planted pattern
         allv = r["allv"]
