@@ -1813,9 +1813,19 @@ extern "C" int bpgpu_ipp_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, con
 // The rounds of InnerProductProof::create for nbatch proofs (ipp_prover.h): inputs and outputs in device memory.
 // d_ts: the proofs' transcript states AFTER innerproduct_domain_sep(n), advanced in place.  The k (L, R) pairs and the
 // final a, b go to d_proofs + p * proof_stride (+ 64 j, + 64 k); status_bytes (optional): BPGPU_MSM_* per proof.
+// `fixed` (optional): G, H are the context's G(gn, gm), H(gn, gm) (n = gn gm) and Q = w B with w[p] given: every L_j / R_j
+// is a pure generator-table MSM (msm_shared's walk) instead of a variable-base one -- no point decoding, no Horner chain.
+struct ippc_fixed {
+    size_t gn, gm;
+    const uint32_t *w;       // [nbatch][8 words]
+    uint32_t *gen_scalars;   // scratch, >= 2 nbatch (2n + 2) scalars
+};
+static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, size_t n_unique, const void *d_gen_scalars,
+                                 const void *d_uniq_scalars, const void *d_uniq_points, void *d_out, void *d_status_bytes,
+                                 void *d_verdict, hipStream_t s);
 static int ippc_core(bpgpu_ctx *c, hipStream_t s, size_t n, size_t k, size_t nbatch, const void *d_a, const void *d_b, const void *d_gf, const void *d_hf,
                      const void *d_q, const void *d_G, const void *d_H, int bases_shared, uint32_t *d_ts, uint8_t *d_proofs, size_t proof_stride,
-                     uint8_t *d_status_bytes) {
+                     uint8_t *d_status_bytes, const ippc_fixed *fixed = nullptr) {
     const size_t N = n + 1, w_v = align_up(nbatch * n * 32), w_u = align_up(nbatch * 32), w_terms = align_up(2 * nbatch * N * 32 + 64),
                  w_out = align_up(2 * nbatch * 32), w_st = align_up(2 * nbatch + 64), w_status = align_up(nbatch * 4);
     const size_t need = 4 * w_v + 2 * w_u + 2 * w_terms + w_out + w_st + w_status;
@@ -1845,9 +1855,16 @@ static int ippc_core(bpgpu_ctx *c, hipStream_t s, size_t n, size_t k, size_t nba
     std::vector<uint32_t> nterms(2 * nbatch, (uint32_t)N);
     const uint32_t n_q = (nb32 + BP_BLOCK - 1) / BP_BLOCK;
     for (uint32_t j = 0; j < k; j++) {
-        LAUNCH(c, s, "ippc_terms", k_ippc_terms, n_q + (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_q, nt32, sh, j, (const uint32_t *)w_a, (const uint32_t *)w_b,
-               (const uint32_t *)w_G, (const uint32_t *)w_H, (const uint8_t *)d_G, (const uint8_t *)d_H, (const uint8_t *)d_q, m_sc, m_pt);
-        int rc = msm_batch_dev_locked(c, 2 * nbatch, nterms.data(), m_sc, m_pt, m_out, m_st, s);   // all L_j and R_j of the batch (ipp.rs:87-113)
+        int rc;
+        if (fixed) {
+            LAUNCH(c, s, "ippc_terms", k_ippc_terms_fixed, n_q + (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_q, nt32, sh, j, (const uint32_t *)w_a,
+                   (const uint32_t *)w_b, (const uint32_t *)w_G, (const uint32_t *)w_H, fixed->w, fixed->gen_scalars);
+            rc = msm_shared_dev_locked(c, fixed->gn, fixed->gm, 2 * nbatch, 0, fixed->gen_scalars, nullptr, nullptr, m_out, m_st, nullptr, s);
+        } else {
+            LAUNCH(c, s, "ippc_terms", k_ippc_terms, n_q + (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_q, nt32, sh, j, (const uint32_t *)w_a, (const uint32_t *)w_b,
+                   (const uint32_t *)w_G, (const uint32_t *)w_H, (const uint8_t *)d_G, (const uint8_t *)d_H, (const uint8_t *)d_q, m_sc, m_pt);
+            rc = msm_batch_dev_locked(c, 2 * nbatch, nterms.data(), m_sc, m_pt, m_out, m_st, s);   // all L_j and R_j of the batch (ipp.rs:87-113)
+        }
         if (rc) return rc;   // (callers drain the stream before they reuse their staging buffers)
         LAUNCH(c, s, "ippc_challenge", k_ippc_challenge, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, j, (const uint32_t *)m_out, (const uint8_t *)m_st,
                d_ts, w_uu, w_ui, d_proofs, (uint32_t)proof_stride, d_status);
@@ -2060,10 +2077,14 @@ extern "C" int bpgpu_rangeproof_prove_batch(bpgpu_ctx *c, size_t n, size_t m, si
                d_proofs);
         LAUNCH(c, s, "rpp_vectors", k_rpp_vectors, (nbits + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nbits, sh, (const uint32_t *)fields, (const uint32_t *)l0,
                (const uint32_t *)l1, (const uint32_t *)r0, (const uint32_t *)r1, avec, bvec, Gf, Hf);
-        rc = msm_shared_dev_locked(c, n, m, nbatch, 0, gsc, nullptr, nullptr, qenc, mst, nullptr, s);
-        if (rc) break;
-        // (4) InnerProductProof::create over G(n, m), H(n, m) (dealer.rs:281-293): L, R pairs and a, b behind the 7 fixed elements
-        rc = ippc_core(c, s, nm, k, nbatch, avec, bvec, Gf, Hf, qenc, Genc, Genc + 8 * nm, 1, d_ts, d_proofs + 224, proof_len, nullptr);
+        // (4) InnerProductProof::create over G(n, m), H(n, m) with Q = w B (dealer.rs:279-293): every L_j / R_j is a generator-table
+        // MSM (the Q term is (c w) on B); L, R pairs and a, b go behind the 7 fixed elements of the proof
+        ippc_fixed fx;
+        fx.gn = n;
+        fx.gm = m;
+        fx.w = fields + (size_t)RPP_W * nbatch * 8;
+        fx.gen_scalars = gsc;
+        rc = ippc_core(c, s, nm, k, nbatch, avec, bvec, Gf, Hf, qenc, Genc, Genc + 8 * nm, 1, d_ts, d_proofs + 224, proof_len, nullptr, &fx);
     } while (0);
     char *h_out = h + sz_in;
     if (!rc) {

@@ -118,6 +118,59 @@ BP_HD void ippc_q_thread(uint32_t p, ippc_shape sh, uint32_t j, const uint32_t *
     }
 }
 
+// ---- the same round when G, H are the context's generators G(n, m), H(n, m) and Q = w B (the range-proof prover,
+// dealer.rs:279-293): L_j and R_j are pure generator-table MSMs.  Row 2p (L) and 2p + 1 (R) of a [2 nproofs][2 nm + 2]
+// scalar array in the table order (B_blinding, B, G.., H..): every slot is written (zero where a generator does not
+// occur), the Q term becomes (c w) on B.
+BP_HD void ippc_terms_fixed_thread(uint32_t tid, ippc_shape sh, uint32_t j, const uint32_t *a, const uint32_t *b, const uint32_t *wG, const uint32_t *wH,
+                                   uint32_t *gen_scalars) {
+    const uint32_t n = sh.n, p = tid / n, t = tid - p * n;
+    const uint32_t nj = n >> j, np = nj >> 1;
+    const uint32_t tt = t & (nj - 1), i = tt & (np - 1), hi = tt >= np ? 1u : 0u;
+    const uint32_t row_len = 2 * n + 2;
+    const uint64_t pa = (uint64_t)p * n;
+    uint32_t *rowL = gen_scalars + (uint64_t)(2 * p) * row_len * 8, *rowR = rowL + (uint64_t)row_len * 8;
+    sc x, w, r, zero;
+    sc_0(zero);
+    ippc_ld(x, a + 8 * (pa + (hi ? i : i + np)));
+    ippc_ld(w, wG + 8 * (pa + t));
+    sc_mul(r, x, w);
+    ippc_st(rowL + (uint64_t)(2 + t) * 8, hi ? r : zero);          // a_L[i] wG(t) G_t on L when t is in the right half
+    ippc_st(rowR + (uint64_t)(2 + t) * 8, hi ? zero : r);          // a_R[i] wG(t) G_t on R when in the left half
+    ippc_ld(x, b + 8 * (pa + (hi ? i : i + np)));
+    ippc_ld(w, wH + 8 * (pa + t));
+    sc_mul(r, x, w);
+    ippc_st(rowL + (uint64_t)(2 + n + t) * 8, hi ? zero : r);      // b_R[i] wH(t) H_t on L when in the left half
+    ippc_st(rowR + (uint64_t)(2 + n + t) * 8, hi ? r : zero);      // b_L[i] wH(t) H_t on R when in the right half
+}
+// lane = proof: (c_L w) and (c_R w) on B, zero on B_blinding
+BP_HD void ippc_q_fixed_thread(uint32_t p, ippc_shape sh, uint32_t j, const uint32_t *a, const uint32_t *b, const uint32_t *w_all, uint32_t *gen_scalars) {
+    const uint32_t n = sh.n, np = (n >> j) >> 1, row_len = 2 * n + 2;
+    const uint64_t pa = (uint64_t)p * n;
+    sc c, s0, s1, x, y, wq, zero;
+    sc_0(s0);
+    sc_0(s1);
+    sc_0(zero);
+    for (uint32_t i = 0; i < np; i++) {
+        ippc_ld(x, a + 8 * (pa + i));
+        ippc_ld(y, b + 8 * (pa + i + np));
+        sc_mul(c, x, y);
+        sc_add(s0, s0, c);
+        ippc_ld(x, a + 8 * (pa + i + np));
+        ippc_ld(y, b + 8 * (pa + i));
+        sc_mul(c, x, y);
+        sc_add(s1, s1, c);
+    }
+    ippc_ld(wq, w_all + 8 * (uint64_t)p);
+    sc_mul(s0, s0, wq);
+    sc_mul(s1, s1, wq);
+    uint32_t *rowL = gen_scalars + (uint64_t)(2 * p) * row_len * 8, *rowR = rowL + (uint64_t)row_len * 8;
+    ippc_st(rowL, zero);
+    ippc_st(rowR, zero);
+    ippc_st(rowL + 8, s0);
+    ippc_st(rowR + 8, s1);
+}
+
 // lane = proof, after round j's MSMs: L, R -> proof bytes and transcript (ipp.rs:115-119), u and u^-1
 // ts: the proof's transcript state (BP_TS_WORDS words), read and written back
 BP_HD void ippc_challenge_thread(uint32_t p, ippc_shape sh, uint32_t j, kstate st, const uint32_t *msm_out /*[2 nproofs][8]*/, const uint8_t *msm_status,

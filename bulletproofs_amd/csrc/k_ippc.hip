@@ -23,6 +23,18 @@ __global__ void __launch_bounds__(BP_BLOCK) k_ippc_terms(uint32_t n_q, uint32_t 
     }
 }
 
+// the same for G, H = the context's generators and Q = w B: rows of generator-table scalars instead of (scalar, point) lists
+__global__ void __launch_bounds__(BP_BLOCK) k_ippc_terms_fixed(uint32_t n_q, uint32_t nthreads, ippc_shape sh, uint32_t j, const uint32_t *a, const uint32_t *b,
+                                                                const uint32_t *wG, const uint32_t *wH, const uint32_t *w_all, uint32_t *gen_scalars) {
+    if (blockIdx.x < n_q) {
+        const uint32_t p = blockIdx.x * BP_BLOCK + threadIdx.x;
+        if (p < sh.nproofs) ippc_q_fixed_thread(p, sh, j, a, b, w_all, gen_scalars);
+    } else {
+        const uint32_t tid = (blockIdx.x - n_q) * BP_BLOCK + threadIdx.x;
+        if (tid < nthreads) ippc_terms_fixed_thread(tid, sh, j, a, b, wG, wH, gen_scalars);
+    }
+}
+
 __global__ void __launch_bounds__(RP_BLOCK) k_ippc_challenge(ippc_shape sh, uint32_t j, const uint32_t *msm_out, const uint8_t *msm_status, uint32_t *ts,
                                                               uint32_t *u, uint32_t *uinv, uint8_t *proofs, uint32_t proof_len, uint32_t *status) {
     __shared__ uint32_t lds[50 * RP_BLOCK];

@@ -62,6 +62,7 @@ __global__ void k_gather32(uint32_t count, const uint32_t *ids, const uint32_t *
 // k_ippc.hip
 __global__ void k_ippc_init(uint32_t nthreads, ippc_shape sh, const uint8_t *a_in, const uint8_t *b_in, const uint8_t *Gf, const uint8_t *Hf, uint32_t *a, uint32_t *b, uint32_t *wG, uint32_t *wH, uint32_t *status);
 __global__ void k_ippc_terms(uint32_t n_q, uint32_t nthreads, ippc_shape sh, uint32_t j, const uint32_t *a, const uint32_t *b, const uint32_t *wG, const uint32_t *wH, const uint8_t *G, const uint8_t *H, const uint8_t *Q, uint32_t *msm_sc, uint32_t *msm_pt);
+__global__ void k_ippc_terms_fixed(uint32_t n_q, uint32_t nthreads, ippc_shape sh, uint32_t j, const uint32_t *a, const uint32_t *b, const uint32_t *wG, const uint32_t *wH, const uint32_t *w_all, uint32_t *gen_scalars);
 __global__ void k_ippc_challenge(ippc_shape sh, uint32_t j, const uint32_t *msm_out, const uint8_t *msm_status, uint32_t *ts, uint32_t *u, uint32_t *uinv, uint8_t *proofs, uint32_t proof_len, uint32_t *status);
 __global__ void k_ippc_fold(uint32_t nthreads, ippc_shape sh, uint32_t j, const uint32_t *u, const uint32_t *uinv, uint32_t *a, uint32_t *b, uint32_t *wG, uint32_t *wH);
 __global__ void k_ippc_final(ippc_shape sh, const uint32_t *a, const uint32_t *b, uint8_t *proofs, uint32_t proof_len, const uint32_t *status, uint8_t *status_out);

@@ -615,23 +615,18 @@ int h_rp_prove(uint32_t W, uint32_t gens_capacity, uint32_t party_capacity, cons
     std::fill(gsc.begin(), gsc.end(), 0u);
     for (uint32_t p = 0; p < nbatch; p++) { uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1; rpp_chal2_thread(p, sh, st, mo.data(), ts.data(), fields.data(), party.data(), gsc.data(), proofs); }
     for (uint32_t tid = 0; tid < nbatch * nm; tid++) rpp_vectors_thread(tid, sh, fields.data(), l0.data(), l1.data(), r0.data(), r1.data(), av.data(), bv.data(), Gf.data(), Hf.data());
-    std::vector<uint32_t> qenc((size_t)nbatch * 8 + 8);
-    if (h_msm_shared(W, 1, n_loaded, gens, sh.n_gen_terms, ids.data(), nbatch, 0, (const uint8_t *)gsc.data(), nullptr, nullptr, (uint8_t *)qenc.data(), mst.data(), mver.data())) return -3;
-    // inner-product rounds (the body of h_ipp_create on the advanced transcripts)
-    std::vector<uint32_t> Genc((size_t)2 * nm * 8);
-    for (uint32_t t = 0; t < 2 * nm; t++) memcpy(&Genc[(size_t)t * 8], gens + 32 * (size_t)ids[2 + t], 32);
+    // inner-product rounds over the generator tables (ippc_*_fixed_thread: Q = w B folded into the B coefficient)
     ippc_shape ish; ish.n = nm; ish.k = sh.k; ish.nproofs = nbatch; ish.bases_shared = 1;
-    const uint32_t N = nm + 1;
     std::vector<uint32_t> a((size_t)nbatch * nm * 8), b(a.size()), wG(a.size()), wH(a.size()), status(nbatch + 1, 0), u((size_t)nbatch * 8), ui(u.size());
     for (uint32_t tid = 0; tid < nbatch * nm; tid++)
         ippc_init_thread(tid, ish, (const uint8_t *)av.data(), (const uint8_t *)bv.data(), (const uint8_t *)Gf.data(), (const uint8_t *)Hf.data(), a.data(), b.data(), wG.data(), wH.data(), status.data());
-    std::vector<uint32_t> msc((size_t)2 * nbatch * N * 8 + 8), mpt(msc.size()), mout((size_t)2 * nbatch * 8 + 8), nt(2 * nbatch, N);
-    std::vector<uint8_t> mst2(2 * nbatch + 1);
+    std::vector<uint32_t> mout((size_t)2 * nbatch * 8 + 8);
+    std::vector<uint8_t> mst2(2 * nbatch + 1), mver2(2 * nbatch + 1);
+    const uint32_t *w_all = fields.data() + (size_t)RPP_W * nbatch * 8;
     for (uint32_t j = 0; j < sh.k; j++) {
-        for (uint32_t p = 0; p < nbatch; p++) ippc_q_thread(p, ish, j, a.data(), b.data(), (const uint8_t *)qenc.data(), msc.data(), mpt.data());
-        for (uint32_t tid = 0; tid < nbatch * nm; tid++)
-            ippc_terms_thread(tid, ish, j, a.data(), b.data(), wG.data(), wH.data(), (const uint8_t *)Genc.data(), (const uint8_t *)(Genc.data() + (size_t)8 * nm), msc.data(), mpt.data());
-        h_msm_vb(2 * nbatch, nt.data(), (const uint8_t *)msc.data(), (const uint8_t *)mpt.data(), (uint8_t *)mout.data(), mst2.data());
+        for (uint32_t p = 0; p < nbatch; p++) ippc_q_fixed_thread(p, ish, j, a.data(), b.data(), w_all, gsc.data());
+        for (uint32_t tid = 0; tid < nbatch * nm; tid++) ippc_terms_fixed_thread(tid, ish, j, a.data(), b.data(), wG.data(), wH.data(), gsc.data());
+        if (h_msm_shared(W, 2, n_loaded, gens, sh.n_gen_terms, ids.data(), 2 * nbatch, 0, (const uint8_t *)gsc.data(), nullptr, nullptr, (uint8_t *)mout.data(), mst2.data(), mver2.data())) return -4;
         for (uint32_t p = 0; p < nbatch; p++) {
             uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;
             ippc_challenge_thread(p, ish, j, st, mout.data(), mst2.data(), ts.data(), u.data(), ui.data(), proofs + 224, sh.proof_len, status.data());
