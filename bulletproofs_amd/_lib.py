@@ -21,7 +21,7 @@ EXPORTS = [
     "bpgpu_profile_enable", "bpgpu_profile_reset", "bpgpu_profile_report",
     "bpgpu_transcript_new", "bpgpu_transcript_append_message", "bpgpu_transcript_challenge_bytes",
     "bpgpu_rangeproof_verify_batch_ts", "bpgpu_rangeproof_verify_batch_ts_dev", "bpgpu_ipp_verify_batch_dev",
-    "bpgpu_ipp_create_batch", "bpgpu_rangeproof_prove_batch",
+    "bpgpu_ipp_create_batch", "bpgpu_rangeproof_prove_batch", "bpgpu_rangeproof_verify_batch_submit", "bpgpu_ctx_collect",
 ]
 
 TRANSCRIPT_BYTES = 208
@@ -80,6 +80,8 @@ def lib():
     L.bpgpu_ipp_verify_batch_dev.argtypes = [vp, sz, sz, vp, sz, u8p, sz, u8p, vp, vp, vp, vp, vp, vp, i, vp, vp, vp]
     L.bpgpu_ipp_create_batch.argtypes = [vp, sz, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, i, u8p, u8p, u8p, u8p]
     L.bpgpu_rangeproof_prove_batch.argtypes = [vp, sz, sz, sz, C.POINTER(C.c_uint64), u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
+    L.bpgpu_rangeproof_verify_batch_submit.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p]
+    L.bpgpu_ctx_collect.argtypes = [vp]
     L.bpgpu_profile_enable.argtypes = [vp, i]
     L.bpgpu_profile_reset.argtypes = [vp]
     L.bpgpu_profile_report.argtypes = [vp, C.c_char_p, sz]
@@ -202,6 +204,20 @@ class Context:
         self._chk(self._L.bpgpu_rangeproof_verify_batch(self.h, n, m, nb, proofs, proof_len, commitments, label, len(label),
                                                         rng64, verdict, msm))
         return (verdict.raw[:nb], msm.raw[:32 * nb]) if want_msm else verdict.raw[:nb]
+
+    def rangeproof_verify_batch_submit(self, n, m, proofs, proof_len, commitments, label, rng64=None):
+        """Asynchronous bpgpu_rangeproof_verify_batch: returns at once; collect() returns the verdict bytes."""
+        nb = len(proofs) // proof_len if proof_len else 0
+        assert len(proofs) == nb * proof_len and len(commitments) == 32 * m * nb
+        self._pending = (C.create_string_buffer(max(nb, 1)), nb)
+        self._chk(self._L.bpgpu_rangeproof_verify_batch_submit(self.h, n, m, nb, proofs, proof_len, commitments, label, len(label), rng64,
+                                                               self._pending[0], None))
+
+    def collect(self):
+        self._chk(self._L.bpgpu_ctx_collect(self.h))
+        buf, nb = self._pending
+        self._pending = None
+        return buf.raw[:nb]
 
     def rangeproof_verify_batch_ts(self, n, m, proofs, proof_len, commitments, transcripts, rng64=None, want_msm=False,
                                    want_transcripts=False):

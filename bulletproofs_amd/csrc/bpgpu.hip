@@ -99,6 +99,14 @@ struct bpgpu_ctx {
     // half until the finish, so the two halves run side by side (fork after the status memset, join before the finish)
     hipStream_t stream2 = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    // result of a submitted (not yet collected) host-pointer call: where its outputs sit in the pinned buffer and where the
+    // caller wants them (bpgpu_rangeproof_verify_batch_submit / bpgpu_ctx_collect)
+    struct pending_result {
+        bool active = false;
+        const char *h_out = nullptr;
+        size_t nbatch = 0, off_msm = 0, off_ts = 0;
+        uint8_t *verdict = nullptr, *msm_out = nullptr, *ts_out = nullptr;
+    } pend;
     bool sync_blocking = false;              // host entry points: sleep on a blocking event instead of spinning
     hipEvent_t done_ev = nullptr;
     // profiling
@@ -201,8 +209,14 @@ struct arena_plan {
 
 static uint64_t table_bytes(uint32_t n_gens, uint32_t W);
 
+static int collect_locked(bpgpu_ctx *c);
+static int host_wait(bpgpu_ctx *c, hipStream_t s);
 // ---- ordering of calls on one context (see bpgpu_ctx::order_ev) ----
 static int ctx_enter(bpgpu_ctx *c, hipStream_t s) {
+    if (c->pend.active) {   // a submitted call's results still sit in the staging buffers: deliver them first
+        int rcp = collect_locked(c);
+        if (rcp) return rcp;
+    }
     c->pin_off = 0;
     if (!c->pin_retired.empty()) {
         if (c->pin_pending) HIPCHK(c, hipEventSynchronize(c->pin_ev));
@@ -269,6 +283,18 @@ static int host_wait(bpgpu_ctx *c, hipStream_t s) {
     return BPGPU_OK;
 }
 static int os_random(bpgpu_ctx *c, char *dst, size_t bytes);
+// finish a submitted call: wait for its stream work and hand the results to the caller's buffers
+static int collect_locked(bpgpu_ctx *c) {
+    if (!c->pend.active) return BPGPU_OK;
+    bpgpu_ctx::pending_result p = c->pend;
+    c->pend.active = false;
+    int rc = host_wait(c, c->stream);
+    if (rc) return rc;
+    memcpy(p.verdict, p.h_out, p.nbatch);
+    if (p.msm_out) memcpy(p.msm_out, p.h_out + p.off_msm, p.nbatch * 32);
+    if (p.ts_out) memcpy(p.ts_out, p.h_out + p.off_ts, p.nbatch * BPGPU_TRANSCRIPT_BYTES);
+    return BPGPU_OK;
+}
 
 extern "C" {
 
@@ -300,6 +326,7 @@ void bpgpu_ctx_destroy(bpgpu_ctx *c) {
     if (!c) return;
     hipSetDevice(c->device);
     hipDeviceSynchronize();
+    c->pend.active = false;   // results of a submitted call nobody collected are dropped
     drain_profile(c);
     for (auto e : c->ev_pool) hipEventDestroy(e);
     for (auto &kv : c->gen_ids_cache) hipFree(kv.second);
@@ -1570,7 +1597,7 @@ extern "C" int bpgpu_rangeproof_verify_rlc_dev(bpgpu_ctx *c, size_t n, size_t m,
 // asynchronous copy; results come back in one copy; one wait at the end.  No allocation in steady state.
 static int rp_host_call(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len, const uint8_t *commitments,
                         rp_transcripts tr, const uint8_t *ts_in_host, const uint8_t *rng64, uint8_t *verdict, uint8_t *msm_out,
-                        uint8_t *ts_out_host, bool rlc, const uint8_t *weights64, uint8_t *batch_out) {
+                        uint8_t *ts_out_host, bool rlc, const uint8_t *weights64, uint8_t *batch_out, bool submit = false) {
     if (!c || (nbatch && (!proofs || !verdict || (m && !commitments))) || (tr.label_len && !tr.label)) return BPGPU_ERR_INVALID_ARG;
     if (nbatch == 0) {
         if (batch_out) memset(batch_out, 0, 33);
@@ -1608,6 +1635,19 @@ static int rp_host_call(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const u
     rc = rp_verify_dev_locked(c, n, m, nbatch, d_p, proof_len, d_c, tr, rng64 ? d_r : nullptr, d_v, msm_out ? d_o : nullptr, s, rlc,
                               weights64 ? d_w : nullptr, rlc ? d_b : nullptr);
     if (!rc && hipMemcpyAsync(h_out, d_v, sz_out, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+    if (submit && !rc) {   // asynchronous form: leave the results in flight; bpgpu_ctx_collect (or the next call) delivers them
+        const int rcl = ctx_leave(c, s);
+        if (rcl) return rcl;
+        c->pend.active = true;
+        c->pend.h_out = h_out;
+        c->pend.nbatch = nbatch;
+        c->pend.off_msm = sz_v;
+        c->pend.off_ts = sz_v + sz_o + sz_b;
+        c->pend.verdict = verdict;
+        c->pend.msm_out = msm_out;
+        c->pend.ts_out = ts_out_host;
+        return BPGPU_OK;
+    }
     int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
     if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
     if (rlc && (uint8_t)h_out[sz_v + sz_o] != 0) {
@@ -1637,6 +1677,23 @@ extern "C" int bpgpu_rangeproof_verify_batch(bpgpu_ctx *c, size_t n, size_t m, s
     tr.label = label;
     tr.label_len = label_len;
     return rp_host_call(c, n, m, nbatch, proofs, proof_len, commitments, tr, nullptr, rng64, verdict, msm_out, nullptr, false, nullptr, nullptr);
+}
+
+// asynchronous forms: enqueue and return; verdict / msm_out (and the input buffers' contents are already staged) are
+// filled by bpgpu_ctx_collect or implicitly by the next call on the context
+extern "C" int bpgpu_rangeproof_verify_batch_submit(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len,
+                                                    const uint8_t *commitments, const uint8_t *label, size_t label_len, const uint8_t *rng64,
+                                                    uint8_t *verdict, uint8_t *msm_out) {
+    rp_transcripts tr;
+    tr.label = label;
+    tr.label_len = label_len;
+    return rp_host_call(c, n, m, nbatch, proofs, proof_len, commitments, tr, nullptr, rng64, verdict, msm_out, nullptr, false, nullptr, nullptr, true);
+}
+extern "C" int bpgpu_ctx_collect(bpgpu_ctx *c) {
+    if (!c) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    return collect_locked(c);
 }
 
 extern "C" int bpgpu_rangeproof_verify_batch_ts(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len,

@@ -172,6 +172,17 @@ int bpgpu_rangeproof_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t m, size_t
                                       const uint8_t *label, size_t label_len, const void *d_rng64,
                                       void *d_verdict, void *d_msm_out, void *stream);
 
+/* Asynchronous form of bpgpu_rangeproof_verify_batch for a host thread that keeps several contexts busy: the inputs are
+ * staged (the caller may reuse its input buffers at once), the work is enqueued, the call returns.  `verdict` / `msm_out`
+ * are filled by bpgpu_ctx_collect(ctx) -- or implicitly by the next call made on this context -- and must stay valid
+ * until then.  One submitted call per context at a time.  A single thread cycling over ~32 contexts reaches the
+ * throughput of one thread per context (tools/host_api_rate.py --pipelined). */
+int bpgpu_rangeproof_verify_batch_submit(bpgpu_ctx *ctx, size_t n, size_t m, size_t nbatch,
+                                         const uint8_t *proofs, size_t proof_len, const uint8_t *commitments,
+                                         const uint8_t *label, size_t label_len, const uint8_t *rng64,
+                                         uint8_t *verdict, uint8_t *msm_out);
+int bpgpu_ctx_collect(bpgpu_ctx *ctx);
+
 /* The same verification on caller-supplied transcripts (the full `&mut Transcript` semantics of mod.rs:345-353):
  *   transcripts       : transcript_stride == 0: ONE state (208 bytes) every proof of the batch starts from;
  *                       transcript_stride == BPGPU_TRANSCRIPT_BYTES: nbatch states, one per proof

@@ -72,3 +72,43 @@ def test_interleaved_streams_give_oracle_verdicts(oracle, oracle_gens_64_8):
                 assert list(got[r, k]) == e, (r, k)
     for c in ctxs:
         c.close()
+
+
+def test_submit_collect_pipelining_one_thread(oracle, oracle_gens_64_8):
+    """bpgpu_rangeproof_verify_batch_submit / bpgpu_ctx_collect: one host thread keeps several contexts busy; results are
+    delivered by collect() or implicitly by the next call on the context; every verdict equals the oracle's."""
+    import bulletproofs_amd as bp
+    n, m, nb, nctx = 64, 1, 128, 5
+    vals = [int.from_bytes(hashlib.shake_256(b"pv%d" % i).digest(8), "little") for i in range(nb)]
+    bl = b"".join(hashlib.shake_256(b"pb%d" % i).digest(31) + b"\x00" for i in range(nb))
+    proofs, coms = oracle.prove_batch(oracle_gens_64_8, vals, bl, m, n, b"pipe", b"seed", threads=os.cpu_count() or 1)
+    pl = oracle.proof_len(n, m)
+    ctxs = []
+    for _ in range(nctx):
+        c = bp.Context(0)
+        c.gens_create(64, 8)
+        ctxs.append(c)
+    variants = []
+    for k in range(7):
+        pb = bytearray(proofs)
+        for i in range(k, nb, 9 + k):
+            pb[i * pl + 128 + k] ^= 1
+        rng = hashlib.shake_256(b"pipe-rng%d" % k).digest(64 * nb)
+        _, ev, _ = oracle.verify_batch(oracle_gens_64_8, bytes(pb), coms, m, n, b"pipe", rng, threads=os.cpu_count() or 1)
+        variants.append((bytes(pb), rng, ev))
+    inflight = [None] * nctx
+    for i in range(40):
+        k = i % nctx
+        if inflight[k] is not None:
+            assert ctxs[k].collect() == inflight[k], i
+        pb, rng, ev = variants[i % 7]
+        ctxs[k].rangeproof_verify_batch_submit(n, m, pb, pl, coms, b"pipe", rng)
+        inflight[k] = ev
+    # implicit delivery: a synchronous call on a context with a submitted call pending first completes that one
+    buf0 = ctxs[0]._pending[0]
+    v = ctxs[0].rangeproof_verify_batch(n, m, variants[3][0], pl, coms, b"pipe", variants[3][1])
+    assert v == variants[3][2] and buf0.raw[:nb] == inflight[0]
+    for k in range(1, nctx):
+        assert ctxs[k].collect() == inflight[k]
+    for c in ctxs:
+        c.close()

@@ -24,6 +24,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1024)
     ap.add_argument("--calls", type=int, default=40, help="calls per thread")
     ap.add_argument("--blocking", type=int, default=-1, help="host_sync_blocking option (default: try both)")
+    ap.add_argument("--pipelined", default="", help="comma list of context counts: ONE host thread cycling over that many contexts with "
+                                                   "bpgpu_rangeproof_verify_batch_submit / bpgpu_ctx_collect")
     a = ap.parse_args()
     import bulletproofs_amd as bp
     from bulletproofs_amd import workload as wl
@@ -36,6 +38,34 @@ def main():
     sl = [(planted[j * a.batch * fx.proof_len:(j + 1) * a.batch * fx.proof_len], coms[j * a.batch * 32:(j + 1) * a.batch * 32], bytes(expect[j]))
           for j in range(nsl)]
     rng = hashlib.shake_256(b"host-rate").digest(64 * a.batch)
+    for nctx in [int(x) for x in a.pipelined.split(",") if x]:
+        ctxs = []
+        for _ in range(nctx):
+            c = bp.Context(0)
+            c.gens_create(64, 1)
+            ctxs.append(c)
+        for phase, rounds in (("warm", 2), ("timed", a.calls)):
+            t0 = time.perf_counter()
+            inflight = [None] * nctx
+            done = 0
+            for i in range(rounds * nctx):
+                k = i % nctx
+                if inflight[k] is not None:
+                    assert ctxs[k].collect() == inflight[k]
+                    done += 1
+                p, cm, e = sl[i % nsl]
+                ctxs[k].rangeproof_verify_batch_submit(fx.n, fx.m, p, fx.proof_len, cm, fx.label, rng)
+                inflight[k] = e
+            for k in range(nctx):
+                if inflight[k] is not None:
+                    assert ctxs[k].collect() == inflight[k]
+            dt = time.perf_counter() - t0
+        print("host-pointer entry point, ONE thread pipelining %3d contexts (submit/collect) x %d calls of batch %d: %.3f M verifications/s"
+              % (nctx, a.calls, a.batch, rounds * nctx * a.batch / dt / 1e6), flush=True)
+        for c in ctxs:
+            c.close()
+    if a.pipelined and a.threads == "0":
+        return
     for blocking in ([0, 1] if a.blocking < 0 else [a.blocking]):
         for T in [int(x) for x in a.threads.split(",")]:
             ctxs = []
