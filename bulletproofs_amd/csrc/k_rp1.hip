@@ -13,7 +13,11 @@ using namespace bp;
 // steps, the U coefficient recodings, the Montgomery tables for launch 2), lane = proof  ||  [n_tr, ..) decode
 // the proof's and the commitments' points straight from the input bytes and build their 8-entry tables,
 // lane = point
-__global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs,
+// Two wavefronts per SIMD (256 registers, 1.2 kB of scratch per lane instead of 502 registers): alone the launch takes
+// 407 instead of 400 us, but a wavefront that needs a whole SIMD's register file waits for a completely free SIMD and,
+// while it waits, holds up the dispatch of the queues behind it -- with 128 streams in flight the cap is worth +2...+4 %
+// (5.43 -> 5.67 and 5.22 -> 5.33 M/s on two boxes, interleaved A/B; three waves per SIMD: no gain, more spills).
+__global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(RP_BLOCK) k_rp_stage1(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs,
                                                          const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields,
                                                          ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m,
                                                          uint32_t *recoded, fb_digit *digits, const uint8_t *rho64, uint32_t ts_flags,
