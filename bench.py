@@ -248,7 +248,7 @@ class RangeProofBench:
         self.ctxs = []
 
 
-def timed(b, K, warmup, fence, repeat, gather=None, events_all=False, no_events=False):
+def timed(b, K, warmup, fence, repeat, gather=None, events_all=False, no_events=False, agree=None):
     """context set-up, warmup, then R regions of K steps; returns dict(elapsed (median), regions, enqueue, kern, allv)"""
     for k in range(min(b.nstreams, max(K, 1))):              # context set-up (not a warmup step): the first call on a context
         b.step(k, _scratch_row(b))                           # sizes its arena and caches the work decomposition
@@ -266,12 +266,15 @@ def timed(b, K, warmup, fence, repeat, gather=None, events_all=False, no_events=
     dt, te, allv = b.region(K, fence, gather)
     regs.append(dt)
     enq.append(te)
+    # the number of regions must be the same on every rank (each region ends in collectives): derive it from the slowest
+    # rank's first region, not from the local clock
+    dt_all = agree(dt) if agree else dt
     if repeat > 0:
         R = repeat
-    elif K >= b.nstreams and dt >= 0.25:
+    elif K >= b.nstreams and dt_all >= 0.25:
         R = 1
     else:
-        R = int(min(50, max(3, math.ceil(1.0 / max(dt, 1e-4)))))
+        R = int(min(50, max(3, math.ceil(1.0 / max(dt_all, 1e-4)))))
     for _ in range(R - 1):
         dt, te, _ = b.region(K, fence, gather)
         regs.append(dt)
@@ -477,7 +480,8 @@ def main():
 
     # the final identity-check gather: one collective (RCCL; gloo on host copies when ranks share a GPU)
     gather = (lambda v: bpdist.gather_verdicts(v.cpu() if oversub else v, world)) if world > 1 else None
-    r = timed(b, a.steps, a.warmup, fence, a.repeat, gather, a.events_all, a.no_events)
+    agree = (lambda x: bpdist.max_over_ranks(x, world, None if oversub else dev)) if world > 1 else None
+    r = timed(b, a.steps, a.warmup, fence, a.repeat, gather, a.events_all, a.no_events, agree)
     elapsed = bpdist.max_over_ranks(r["elapsed"], world, None if oversub else dev)
     if world > 1 and a.steps:     # every rank's verdict rows arrived and carry that rank's planted pattern
         allv = r["allv"]

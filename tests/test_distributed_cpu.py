@@ -51,3 +51,66 @@ def test_sharded_verify_and_gather_world2():
         assert p.exitcode == 0
     for rank, allv, tmax in res:
         assert allv == [0, 0, 0, 0, 1, 0] and tmax == 2.0
+
+
+class _FakeCtx:
+    def profile_reset(self):
+        pass
+
+    def profile_enable(self, on):
+        pass
+
+    def profile_report(self):
+        return {}
+
+
+class _FakeRunner:
+    """stands in for bench.py's runner: a region 'takes' a rank-dependent time and ends in one collective, as the real one does"""
+    def __init__(self, rank, world):
+        self.nstreams, self.ctxs, self.d_verdicts, self.rank, self.world, self.regions = 4, [_FakeCtx()], [0], rank, world, 0
+
+    def step(self, k, row):
+        pass
+
+    def region(self, K, fence, gather=None):
+        from bulletproofs_amd import dist as bpdist
+        self.regions += 1
+        bpdist.max_over_ranks(0.0, self.world)           # the per-region collective: unequal region counts would deadlock here
+        return (0.02 if self.rank == 0 else 0.2), 0.0, None
+
+    def set_profile(self, on, every=1):
+        pass
+
+    def kernel_times(self):
+        return {}
+
+
+def _timed_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    sys.path.insert(0, ROOT)
+    import torch
+    import bench
+    from bulletproofs_amd import dist as bpdist
+    bpdist.init("gloo")
+    b = _FakeRunner(rank, world)
+    r = bench.timed(b, 12, 0, lambda: None, 0, None, False, True, lambda x: bpdist.max_over_ranks(x, world))
+    q.put((rank, len(r["regions"])))
+    torch.distributed.barrier()
+    torch.distributed.destroy_process_group()
+
+
+def test_bench_region_count_agrees_across_ranks_world2():
+    """bench.py repeats short timed regions; the repeat count must come from the slowest rank, or ranks whose clocks differ
+    run different numbers of collectives and the job deadlocks (seen at --gpus 2 on one box)."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 30100 + (os.getpid() % 400)
+    procs = [ctx.Process(target=_timed_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=180) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1] == 5                         # ceil(1 / 0.2) regions on both ranks

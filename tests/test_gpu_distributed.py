@@ -43,7 +43,7 @@ print("nccl-ok")
 def test_rccl_world_of_one_gathers_engine_verdicts():
     env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(29600 + os.getpid() % 300),
                HSA_ENABLE_IPC_MODE_LEGACY="0")
-    out = subprocess.run([sys.executable, "-c", _NCCL_SNIPPET % ROOT], env=env, capture_output=True, text=True, timeout=600)
+    out = subprocess.run([sys.executable, "-c", _NCCL_SNIPPET % ROOT], env=env, capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "nccl-ok" in out.stdout, out.stderr[-2000:]
 
 
@@ -53,7 +53,7 @@ def test_bench_runs_with_n_ranks(gpus):
     every verdict row against the planted pattern, so a line printed = verdicts correct on every rank."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "12", "--warmup", "2", "--streams", "4",
-                          "--window-bits", "10", "--no-cpu-baseline", "--no-extra"], env=env, capture_output=True, text=True, timeout=900)
+                          "--window-bits", "10", "--no-cpu-baseline", "--no-extra"], env=env, capture_output=True, text=True, timeout=300)
     if out.returncode != 0:   # keep the ranks' own tracebacks (gpurun_out/ travels back from the GPU box)
         os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
         with open(os.path.join(ROOT, "gpurun_out", "test_bench_ranks_%d.err" % gpus), "w") as f:
