@@ -55,8 +55,8 @@ def parse_args():
     ap.add_argument("--table-bytes", type=int, default=0, help="HBM budget of the generator tables (default: library default)")
     ap.add_argument("--splits", type=int, default=0, help="workgroups the generator terms of a proof block are split over (default: library default)")
     ap.add_argument("--horner-lanes", type=int, default=0, choices=[0, 4, 64], help="lanes per Horner chain (default: library default)")
-    ap.add_argument("--streams", type=int, default=128,
-                    help="independent (context, HIP stream) pairs the steps are issued on round-robin, so that "
+    ap.add_argument("--streams", type=int, default=0,
+                    help="(default 128; 12 for runs of fewer steps than that) independent (context, HIP stream) pairs the steps are issued on round-robin, so that "
                          "consecutive batches overlap on the device (one context per stream, as bpgpu.h prescribes "
                          "for concurrent callers)")
     ap.add_argument("--bucket-min", type=int, default=0, help="bucket_min_terms option of the library (0 = default; a huge value forces the table-lookup path)")
@@ -259,8 +259,10 @@ def timed(b, K, warmup, fence, repeat, gather=None, events_all=False, no_events=
         c_.profile_reset()
     # start/stop events attached to a dispatch cost queue time: measured at the default workload, events on every 8th stream
     # lower the throughput by 4 % (5.25 vs 5.47 M/s, --no-events), so long runs sample every 32nd stream (~1 %)
+    # (5.52 vs 5.50); a short burst pays more -- at --steps 20, events on all 20 streams cost 6 % (3.82 vs 4.05 M/s) -- so
+    # short runs sample every 4th stream: with the >= 4 repeated regions that still gives launches >= steps
     sparse = (K >= 8 * b.nstreams) and not events_all
-    every = max(1, min(32, b.nstreams // 4)) if sparse else 1
+    every = 1 if events_all else max(1, min(32, b.nstreams // 4)) if sparse else max(1, min(4, b.nstreams // 4))
     b.set_profile(not no_events, every)
     regs, enq, allv = [], [], None
     dt, te, allv = b.region(K, fence, gather)
@@ -328,8 +330,8 @@ def roofline_block(cfg, n, m, batch, kern, value, wl, events_every, default_batc
     return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
             "frac": achieved / 8000.0, "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt,
             "algorithmic_bytes_per_launch": alg_bytes,
-            "timing": "start/stop events attached to the dispatches (hipExtLaunchKernelGGL) of every %s stream, on their launch stream, inside the "
-                      "timed region; kernel begin..end as in rocprofv3's kernel trace" % (("%dth" % events_every) if events_every > 1 else ""),
+            "timing": "start/stop events attached to the dispatches (hipExtLaunchKernelGGL) of every %sstream, on their launch stream, inside the "
+                      "timed region; kernel begin..end as in rocprofv3's kernel trace" % ({1: "", 2: "2nd ", 3: "3rd "}.get(events_every, "%dth " % events_every)),
             "note": "the path is bound by integer VALU issue, not HBM: ~10 field multiplications per input byte, so the HBM fraction is ~1e-3 by construction",
             "dominant_by": "VALU work (half of a batch's wavefront-instructions) and all of the table traffic; by slot time under load the narrow, latency-bound "
                            "rp_stage1 (one lane per proof: 12 Keccak-f per proof) is comparable -- see kernels_us",
@@ -467,7 +469,14 @@ def main():
 
     fx_name, default_batch = wl.CONFIGS[a.config]
     batch = a.batch or default_batch
+    auto_streams = a.streams <= 0
+    if auto_streams:
+        a.streams = 128
     nstreams = max(1, min(a.streams, max(a.steps, 1)))
+    if a.steps < a.streams and auto_streams:
+        # a burst shorter than the stream count never reaches the steady state the 128 streams are for: it is served best by
+        # fewer streams than hardware queues (K = 20 on 5/8/10/12/16/20 streams: 3.3/3.8/4.25/4.27/4.22/4.05 M/s)
+        nstreams = min(nstreams, 12)
     b = RangeProofBench(a, a.config, batch, nstreams, rank, local_dev, rlc=a.rlc)
     n, m = b.fx.n, b.fx.m
     N_terms = wl.msm_terms(n, m)
