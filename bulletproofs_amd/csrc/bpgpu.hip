@@ -1867,6 +1867,145 @@ extern "C" int bpgpu_ipp_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, con
     return BPGPU_OK;
 }
 
+// LinearProof::verify for nbatch proofs (linear.h): front end (lane = proof) -> bpgpu_msm_batch's MSM -> verdicts.
+// G (n encodings), F, B are shared by the batch; b is per proof unless b_shared.
+static int lin_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t nbatch, const void *d_proofs, size_t proof_len, const uint8_t *label,
+                                 size_t label_len, const uint8_t *shared_ts, const void *d_C, const void *d_G, const void *d_F,
+                                 const void *d_B, const void *d_b, int b_shared, void *d_verdict, void *d_msm_out, hipStream_t s) {
+    if (nbatch > 0x7fffffffu / 64) return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large");
+    if (shared_ts && !ts_state_ok(shared_ts)) return fail(c, BPGPU_ERR_INVALID_ARG, "malformed transcript state");
+    // LinearProof::from_bytes, length part (linear_proof.rs:350-366)
+    size_t k = 0;
+    bool fmt = false;
+    if (proof_len % 32 != 0) fmt = true;
+    else {
+        const size_t ne = proof_len / 32;
+        if (ne < 3 || (ne - 3) % 2 != 0) fmt = true;
+        else {
+            k = (ne - 3) / 2;
+            if (k >= 32) fmt = true;
+        }
+    }
+    if (fmt) {
+        HIPCHK(c, hipMemsetAsync(d_verdict, BPGPU_VERDICT_FORMAT_ERROR, nbatch, s));
+        if (d_msm_out) HIPCHK(c, hipMemsetAsync(d_msm_out, 0, nbatch * 32, s));
+        return BPGPU_OK;
+    }
+    lin_shape sh;
+    sh.n = (uint32_t)n;
+    sh.k = (uint32_t)k;
+    sh.proof_len = (uint32_t)proof_len;
+    sh.nproofs = (uint32_t)nbatch;
+    sh.b_shared = b_shared ? 1u : 0u;
+    if (n == ((size_t)1 << k) && k > BP_RP_MAX_K) return fail(c, BPGPU_ERR_INVALID_ARG, "n > 2^%d not supported", BP_RP_MAX_K);
+    sh.shape_verdict = (n == ((size_t)1 << k)) ? 0 : BPGPU_VERDICT_VERIFICATION_ERROR;   // linear_proof.rs:263-265
+    if (sh.shape_verdict) sh.n = 0;   // only the canonical-scalar check runs
+    sh.N = (uint32_t)(sh.shape_verdict ? 4 : n + 2 * k + 4);
+    const size_t N = sh.N;
+    if ((uint64_t)nbatch * N > 0x7fffffffull / 64) return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large for this shape");
+    const size_t sz_terms = align_up(nbatch * N * 32 + 64), sz_st = align_up(nbatch * 4), sz_b = align_up(nbatch + 64), sz_o = align_up(nbatch * 32 + 64);
+    const size_t need = 2 * sz_terms + sz_st + sz_b + sz_o;
+    if (c->ipp_cap < need) {
+        HIPCHK(c, hipDeviceSynchronize());
+        if (c->ipp_buf) HIPCHK(c, hipFree(c->ipp_buf));
+        c->ipp_buf = nullptr;
+        c->ipp_cap = 0;
+        HIPCHK(c, hipMalloc((void **)&c->ipp_buf, need + need / 4));
+        c->ipp_cap = need + need / 4;
+    }
+    char *d_sc = c->ipp_buf, *d_pt = d_sc + sz_terms, *d_stat = d_pt + sz_terms, *d_mst = d_stat + sz_st, *d_out = d_mst + sz_b;
+    HIPCHK(c, hipMemsetAsync(d_sc, 0, 2 * sz_terms + sz_st, s));   // scalars, points, status
+    rp_strobe_init init;
+    {   // Transcript::new(label) [or the caller's transcript] + innerproduct_domain_sep(n) (linear_proof.rs:196), once for the batch
+        uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
+        if (shared_ts) memcpy(st0, shared_ts, BPGPU_TRANSCRIPT_BYTES);
+        else bpgpu_transcript_new(label, label_len, st0);
+        uint32_t w[50];
+        strobe t;
+        ts_to_strobe(t, w, st0);
+        const uint8_t ipp[6] = {'i', 'p', 'p', ' ', 'v', '1'}, ln[1] = {'n'};
+        merlin_append_message(t, DOM_SEP, 7, ipp, 6);
+        merlin_append_u64(t, ln, 1, n);
+        memcpy(init.w, w, 200);
+        init.pos = t.pos;
+        init.pos_begin = t.pos_begin;
+        init.cur_flags = t.cur_flags;
+    }
+    const uint32_t nb32 = (uint32_t)nbatch;
+    LAUNCH(c, s, "lin_prepare", k_lin_prepare, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, init, (const uint8_t *)d_proofs, (const uint8_t *)d_C,
+           (const uint8_t *)d_b, (const uint8_t *)d_G, (const uint8_t *)d_F, (const uint8_t *)d_B, (uint32_t *)d_sc, (uint32_t *)d_pt,
+           (uint32_t *)d_stat);
+    std::vector<uint32_t> nt(nbatch, (uint32_t)N);
+    int rc = msm_batch_dev_locked(c, nbatch, nt.data(), d_sc, d_pt, d_out, d_mst, s);
+    if (rc) return rc;
+    LAUNCH(c, s, "lin_verdict", k_ipp_verdict, (nb32 + 63) / 64, 64, nb32, (const uint32_t *)d_stat, (const uint8_t *)d_mst, (const uint32_t *)d_out,
+           (uint8_t *)d_verdict);
+    if (d_msm_out) HIPCHK(c, hipMemcpyAsync(d_msm_out, d_out, nbatch * 32, hipMemcpyDeviceToDevice, s));
+    HIPCHK(c, hipGetLastError());
+    return BPGPU_OK;
+}
+
+extern "C" int bpgpu_linear_verify_batch_dev(bpgpu_ctx *c, size_t n, size_t nbatch, const void *d_proofs, size_t proof_len, const uint8_t *label,
+                                             size_t label_len, const uint8_t *shared_transcript, const void *d_C, const void *d_G,
+                                             const void *d_F, const void *d_B, const void *d_b, int b_shared, void *d_verdict, void *d_msm_out,
+                                             void *stream) {
+    if (!c || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0) return BPGPU_OK;
+    if (!d_proofs || !d_verdict || !d_C || !d_F || !d_B || (n && (!d_G || !d_b))) return BPGPU_ERR_INVALID_ARG;
+    if (((uintptr_t)d_proofs | (uintptr_t)d_C | (uintptr_t)d_G | (uintptr_t)d_F | (uintptr_t)d_B | (uintptr_t)d_b) & 3)
+        return fail(c, BPGPU_ERR_INVALID_ARG, "device buffers must be 4-byte aligned");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    rc = lin_verify_dev_locked(c, n, nbatch, d_proofs, proof_len, label, label_len, shared_transcript, d_C, d_G, d_F, d_B, d_b, b_shared, d_verdict,
+                               d_msm_out, s);
+    const int rc2 = ctx_leave(c, s);
+    return rc ? rc : rc2;
+}
+
+extern "C" int bpgpu_linear_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, const uint8_t *proofs, size_t proof_len, const uint8_t *label,
+                                         size_t label_len, const uint8_t *shared_transcript, const uint8_t *C, const uint8_t *G, const uint8_t *F,
+                                         const uint8_t *B, const uint8_t *b, int b_shared, uint8_t *verdict, uint8_t *msm_out) {
+    if (!c || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0) return BPGPU_OK;
+    if (!proofs || !verdict || !C || !F || !B || (n && (!G || !b))) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    const size_t nb_b = b_shared ? 1 : nbatch;
+    const size_t sz_pr = align_up(nbatch * proof_len + 64), sz_c = align_up(nbatch * 32 + 64), sz_g = align_up(n * 32 + 64), sz_fb = align_up(64 + 64),
+                 sz_bv = align_up(nb_b * n * 32 + 64);
+    const size_t sz_in = sz_pr + sz_c + sz_g + sz_fb + sz_bv, sz_v = align_up(nbatch), sz_o = align_up(nbatch * 32);
+    hipStream_t s = c->stream;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    rc = io_reserve(c, sz_in + sz_v + sz_o);
+    if (rc) return rc;
+    char *h = nullptr;
+    rc = pin_alloc(c, s, sz_in + sz_v + sz_o, &h);
+    if (rc) return rc;
+    char *d = c->io_dev;
+    char *d_pr = d, *d_c = d_pr + sz_pr, *d_g = d_c + sz_c, *d_fb = d_g + sz_g, *d_bv = d_fb + sz_fb, *d_v = d + sz_in, *d_o = d_v + sz_v;
+    memcpy(h, proofs, nbatch * proof_len);
+    memcpy(h + sz_pr, C, nbatch * 32);
+    if (n) {
+        memcpy(h + sz_pr + sz_c, G, n * 32);
+        memcpy(h + sz_pr + sz_c + sz_g + sz_fb, b, nb_b * n * 32);
+    }
+    memcpy(h + sz_pr + sz_c + sz_g, F, 32);
+    memcpy(h + sz_pr + sz_c + sz_g + 32, B, 32);
+    HIPCHK(c, hipMemcpyAsync(d, h, sz_in, hipMemcpyHostToDevice, s));
+    rc = lin_verify_dev_locked(c, n, nbatch, d_pr, proof_len, label, label_len, shared_transcript, d_c, d_g, d_fb, d_fb + 32, d_bv, b_shared, d_v, d_o, s);
+    char *h_out = h + sz_in;
+    if (!rc && hipMemcpyAsync(h_out, d_v, sz_v + sz_o, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+    const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
+    if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
+    memcpy(verdict, h_out, nbatch);
+    if (msm_out) memcpy(msm_out, h_out + sz_v, nbatch * 32);
+    return BPGPU_OK;
+}
+
 // The rounds of InnerProductProof::create for nbatch proofs (ipp_prover.h): inputs and outputs in device memory.
 // d_ts: the proofs' transcript states AFTER innerproduct_domain_sep(n), advanced in place.  The k (L, R) pairs and the
 // final a, b go to d_proofs + p * proof_stride (+ 64 j, + 64 k); status_bytes (optional): BPGPU_MSM_* per proof.

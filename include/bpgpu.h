@@ -250,6 +250,33 @@ int bpgpu_ipp_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t nbatch, const vo
                                const void *d_G, const void *d_H, int bases_shared,
                                void *d_verdict, void *d_msm_out, void *stream);
 
+/* ---- linear proofs (LinearProof, `pub use` src/lib.rs:36) --------------------------------
+ * nbatch independent calls of
+ *   LinearProof::from_bytes(proof)?.verify(&mut transcript, &C, &G, &F, &B, b_vec)
+ * (src/linear_proof.rs:175-236, 240-312, 350-394), all of one size n = G.len() = b_vec.len(): the proof that
+ * <a, b> = c for a committed secret a and the public b.  The three multiscalar multiplications and the comparison of
+ * verify() (:207-236) run as ONE multiscalar multiplication of n + 2 lg(n) + 4 terms per proof whose result must be
+ * the identity; transcript replay, the fold of b and the subset products run on the device (csrc/linear.h).
+ *   proofs  : nbatch x proof_len bytes, proof_len = 32*(2*lg(n) + 3) for valid input (L_j, R_j pairs, S, a, r)
+ *   transcript : shared_transcript (host, 208 bytes, may hold earlier messages) if not NULL, else Transcript::new(label);
+ *             every proof starts from it (the reference's &mut Transcript is consumed, not returned)
+ *   C       : nbatch x 32 bytes (compressed commitments)
+ *   G       : n x 32 bytes, F, B : 32 bytes each -- compressed points shared by the batch (the reference's callers pass
+ *             bp_gens.share(0).G(n), pedersen B and B_blinding: linear_proof.rs:405-411); the encodings given here are
+ *             what the transcript absorbs (G_i.compress(), :201-205), so they must be canonical
+ *   b       : nbatch x n x 32 bytes canonical scalars, or n x 32 when b_shared != 0
+ *   verdict : nbatch bytes, BPGPU_VERDICT_* (FormatError: proof length, non-canonical a, r or b_i; VerificationError:
+ *             n != 2^lg_n, an identity L_j / R_j, an undecodable point, or expect_S != S)
+ *   msm_out : optional nbatch x 32 bytes, compress(expect_S - S) for parity tests */
+int bpgpu_linear_verify_batch(bpgpu_ctx *ctx, size_t n, size_t nbatch, const uint8_t *proofs, size_t proof_len,
+                              const uint8_t *label, size_t label_len, const uint8_t *shared_transcript,
+                              const uint8_t *C, const uint8_t *G, const uint8_t *F, const uint8_t *B,
+                              const uint8_t *b, int b_shared, uint8_t *verdict, uint8_t *msm_out);
+int bpgpu_linear_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t nbatch, const void *d_proofs, size_t proof_len,
+                                  const uint8_t *label, size_t label_len, const uint8_t *shared_transcript,
+                                  const void *d_C, const void *d_G, const void *d_F, const void *d_B,
+                                  const void *d_b, int b_shared, void *d_verdict, void *d_msm_out, void *stream);
+
 /* ---- batched inner-product-proof creation (prover side) --------------------------------
  * nbatch independent calls of
  *   InnerProductProof::create(&mut transcript, &Q, G_factors, H_factors, G_vec, H_vec, a_vec, b_vec).to_bytes()

@@ -107,6 +107,20 @@ int oracle_ipp_test_instance(size_t n, const uint8_t *label, size_t label_len, c
                              uint8_t *proof_out, uint8_t P_out[32], uint8_t Q_out[32], uint8_t *G_out, uint8_t *H_out,
                              uint8_t *Gf_out, uint8_t *Hf_out);
 
+/* LinearProof (src/linear_proof.rs; public type, `pub use` lib.rs:36): proves <a, b> = c for secret a and public b.
+ * oracle_linear_create = LinearProof::create(transcript, rng, &C, r, a, b, G, &F, &B).to_bytes() (linear_proof.rs:40-173):
+ * state = the caller's transcript (208-byte form, not written back); rng = the bytes the rng yields, 64 per
+ * Scalar::random in draw order (s_j, t_j per round; s_star, t_star): 64 * (2 lg n + 2); proof_out: 32 * (2 lg n + 3).
+ * Returns 0; 5 = InvalidInputLength (n not a power of two); 1 = a point does not decode.
+ * oracle_linear_verify = LinearProof::from_bytes(proof)?.verify(transcript, &C, &G, &F, &B, b) (:175-236, 350-394);
+ * msm_out (optional) = compress(expect_S - S).  No reference test holds a fixed vector for this type (its tests are
+ * random round trips, :397-488): parity here is pinned by the independent Python twin only. */
+int oracle_linear_create(size_t n, const uint8_t state[208], const uint8_t *rng, const uint8_t C[32], const uint8_t r[32],
+                         const uint8_t *a, const uint8_t *b, const uint8_t *G, const uint8_t F[32], const uint8_t B[32],
+                         uint8_t *proof_out);
+int oracle_linear_verify(size_t n, const uint8_t *proof, size_t proof_len, const uint8_t state[208], const uint8_t C[32],
+                         const uint8_t *G, const uint8_t F[32], const uint8_t B[32], const uint8_t *b, uint8_t msm_out[32]);
+
 /* Batch drivers (independent proofs, equal shape), `threads` worker threads.
  * verdicts[i] = error code.  Returns wall seconds. */
 double oracle_verify_batch(const oracle_gens *g, size_t nbatch, const uint8_t *proofs, size_t proof_len,

@@ -679,6 +679,147 @@ int oracle_ipp_test_instance(size_t n, const uint8_t *label, size_t label_len, c
     return 0;
 }
 
+/* ---------------- LinearProof (src/linear_proof.rs) ---------------- */
+static void linear_public_inputs(merlin_transcript *t, size_t n, const uint8_t C[32], const uint8_t *b, const uint8_t *G,
+                                 const uint8_t F[32], const uint8_t B[32]) {
+    /* linear_proof.rs:73-83 (create) = :196-206 (verify) */
+    merlin_append_message(t, "dom-sep", (const uint8_t *)"ipp v1", 6);
+    merlin_append_u64(t, "n", n);
+    merlin_append_message(t, "C", C, 32);
+    for (size_t i = 0; i < n; i++) merlin_append_message(t, "b_i", b + 32 * i, 32);
+    for (size_t i = 0; i < n; i++) merlin_append_message(t, "G_i", G + 32 * i, 32);
+    merlin_append_message(t, "F", F, 32);
+    merlin_append_message(t, "B", B, 32);
+}
+
+/* LinearProof::create(transcript, rng, C, r, a_vec, b_vec, G_vec, F, B).to_bytes() (linear_proof.rs:40-173, 322-331).
+ * rng: the bytes the rng yields, 64 per Scalar::random, in draw order (s_j, t_j per round, then s_star, t_star):
+ * 64 * (2 lg n + 2) bytes.  b must be canonical (it is a Vec<Scalar> upstream).  Returns 0, 5 for InvalidInputLength
+ * (n not a power of two), 1 when a point does not decode. */
+int oracle_linear_create(size_t n, const uint8_t state[208], const uint8_t *rng, const uint8_t C[32], const uint8_t r_in[32],
+                         const uint8_t *a_in, const uint8_t *b_in, const uint8_t *G_in, const uint8_t F_in[32],
+                         const uint8_t B_in[32], uint8_t *proof_out) {
+    ge_init();
+    if (n == 0 || (n & (n - 1))) return 5;
+    merlin_transcript t; ts_load(&t, state);
+    ge_p3 F, B, *G = malloc(n * sizeof(ge_p3)), *pv = malloc((n + 2) * sizeof(ge_p3));
+    sc *a = malloc(n * sizeof(sc)), *b = malloc(n * sizeof(sc)), *sv = malloc((n + 2) * sizeof(sc)), r;
+    int bad = ristretto_decompress(&F, F_in) != 0 || ristretto_decompress(&B, B_in) != 0;
+    for (size_t i = 0; i < n; i++) {
+        if (ristretto_decompress(&G[i], G_in + 32 * i)) bad = 1;
+        sc_from_bytes_mod_order(&a[i], a_in + 32 * i); sc_from_bytes_mod_order(&b[i], b_in + 32 * i);
+    }
+    sc_from_bytes_mod_order(&r, r_in);
+    if (!bad) {
+        linear_public_inputs(&t, n, C, b_in, G_in, F_in, B_in);
+        size_t round = 0, draw = 0, m = n;
+        while (m != 1) {
+            m /= 2;
+            sc *aL = a, *aR = a + m, *bL = b, *bR = b + m;
+            ge_p3 *GL = G, *GR = G + m;
+            sc cL, cR, sj, tj;
+            inner_product(&cL, aL, bR, m); inner_product(&cR, aR, bL, m);
+            sc_from_wide(&sj, rng + 64 * draw++); sc_from_wide(&tj, rng + 64 * draw++);
+            ge_p3 Lp, Rp;
+            for (size_t i = 0; i < m; i++) { sv[i] = aL[i]; pv[i] = GR[i]; }
+            sv[m] = sj; pv[m] = B; sv[m + 1] = cL; pv[m + 1] = F;
+            ge_msm_vartime(&Lp, m + 2, sv, pv);                      /* L = a_L * G_R + s_j * B + c_L * F */
+            for (size_t i = 0; i < m; i++) { sv[i] = aR[i]; pv[i] = GL[i]; }
+            sv[m] = tj; pv[m] = B; sv[m + 1] = cR; pv[m + 1] = F;
+            ge_msm_vartime(&Rp, m + 2, sv, pv);                      /* R = a_R * G_L + t_j * B + c_R * F */
+            uint8_t *Lb = proof_out + 64 * round, *Rb = Lb + 32;
+            ristretto_compress(Lb, &Lp); ristretto_compress(Rb, &Rp);
+            merlin_append_message(&t, "L", Lb, 32); merlin_append_message(&t, "R", Rb, 32);
+            sc x, xi; challenge_scalar(&t, "x_j", &x); sc_invert(&xi, &x);
+            for (size_t i = 0; i < m; i++) {
+                sc t0;
+                sc_mul(&t0, &xi, &aR[i]); sc_add(&aL[i], &aL[i], &t0);     /* a_L + x^-1 a_R */
+                sc_mul(&t0, &x, &bR[i]); sc_add(&bL[i], &bL[i], &t0);      /* b_L + x b_R */
+                sc s2[2]; ge_p3 p2[2];
+                sc_from_u64(&s2[0], 1); s2[1] = x; p2[0] = GL[i]; p2[1] = GR[i];
+                ge_msm_straus(&GL[i], 2, s2, p2);                          /* G_L + x G_R */
+            }
+            sc t0, t1; sc_mul(&t0, &x, &sj); sc_mul(&t1, &xi, &tj); sc_add(&r, &r, &t0); sc_add(&r, &r, &t1);
+            round++;
+        }
+        sc s_star, t_star; sc_from_wide(&s_star, rng + 64 * draw++); sc_from_wide(&t_star, rng + 64 * draw++);
+        sc s3[3]; ge_p3 p3[3], Sp;
+        s3[0] = t_star; p3[0] = B; sc_mul(&s3[1], &s_star, &b[0]); p3[1] = F; s3[2] = s_star; p3[2] = G[0];
+        ge_msm_straus(&Sp, 3, s3, p3);                                     /* S = t* B + s* b_0 F + s* G_0 */
+        uint8_t *Sb = proof_out + 64 * round;
+        ristretto_compress(Sb, &Sp);
+        merlin_append_message(&t, "S", Sb, 32);
+        sc xs, a_star, r_star, t0;
+        challenge_scalar(&t, "x_star", &xs);
+        sc_mul(&t0, &xs, &a[0]); sc_add(&a_star, &s_star, &t0);
+        sc_mul(&t0, &xs, &r); sc_add(&r_star, &t_star, &t0);
+        sc_tobytes(Sb + 32, &a_star); sc_tobytes(Sb + 64, &r_star);
+    }
+    free(G); free(pv); free(a); free(b); free(sv);
+    return bad;
+}
+
+/* LinearProof::from_bytes(proof)?.verify(transcript, C, G, F, B, b_vec) (linear_proof.rs:175-236, 240-312, 350-394).
+ * msm_out (optional) = compress(expect_S - S).  Returns ORACLE_OK / ORACLE_ERR_*. */
+int oracle_linear_verify(size_t n, const uint8_t *proof, size_t proof_len, const uint8_t state[208], const uint8_t C[32],
+                         const uint8_t *G, const uint8_t F[32], const uint8_t B[32], const uint8_t *b_in, uint8_t msm_out[32]) {
+    ge_init();
+    if (proof_len % 32 != 0) return ORACLE_ERR_FORMAT;
+    size_t ne = proof_len / 32;
+    if (ne < 3 || (ne - 3) % 2 != 0) return ORACLE_ERR_FORMAT;
+    size_t lg_n = (ne - 3) / 2;
+    if (lg_n >= 32) return ORACLE_ERR_FORMAT;
+    const uint8_t *Sb = proof + 64 * lg_n;
+    sc a, r;
+    if (sc_from_canonical_bytes(&a, Sb + 32)) return ORACLE_ERR_FORMAT;
+    if (sc_from_canonical_bytes(&r, Sb + 64)) return ORACLE_ERR_FORMAT;
+    merlin_transcript t; ts_load(&t, state);
+    linear_public_inputs(&t, n, C, b_in, G, F, B);
+    /* verification_scalars (:240-290) */
+    if (n != ((size_t)1 << lg_n)) return ORACLE_ERR_VERIFICATION;
+    sc *b = malloc((n + 1) * sizeof(sc)), x[32], xinv[32];
+    for (size_t i = 0; i < n; i++) sc_from_bytes_mod_order(&b[i], b_in + 32 * i);
+    size_t m = n;
+    for (size_t j = 0; j < lg_n; j++) {
+        if (validate_and_append_point(&t, "L", proof + 64 * j) || validate_and_append_point(&t, "R", proof + 64 * j + 32)) { free(b); return ORACLE_ERR_VERIFICATION; }
+        challenge_scalar(&t, "x_j", &x[j]);
+        m /= 2;
+        for (size_t i = 0; i < m; i++) { sc t0; sc_mul(&t0, &x[j], &b[m + i]); sc_add(&b[i], &b[i], &t0); }
+        sc_invert(&xinv[j], &x[j]);
+    }
+    sc b0 = b[0];
+    merlin_append_message(&t, "S", Sb, 32);
+    sc xs; challenge_scalar(&t, "x_star", &xs);
+    /* subset products (:299-314) */
+    sc *s = b;   /* reuse */
+    sc_from_u64(&s[0], 1);
+    for (size_t i = 1; i < n; i++) {
+        size_t lg_i = 63 - (size_t)__builtin_clzll((unsigned long long)i);
+        sc_mul(&s[i], &s[i - ((size_t)1 << lg_i)], &x[(lg_n - 1) - lg_i]);
+    }
+    /* expect_S - S = r B + a b_0 F - x* C - x* sum (x_j L_j + x_j^-1 R_j) + a sum s_i G_i - S  (:214-231) */
+    size_t N = n + 2 * lg_n + 4, o = 0;
+    sc *scal = malloc(N * sizeof(sc)), nxs, one; ge_p3 *pts = malloc(N * sizeof(ge_p3));
+    int bad = 0;
+    sc_neg(&nxs, &xs); sc_from_u64(&one, 1);
+    scal[o] = r; if (ristretto_decompress(&pts[o], B)) bad = 1; o++;
+    sc_mul(&scal[o], &a, &b0); if (ristretto_decompress(&pts[o], F)) bad = 1; o++;
+    scal[o] = nxs; if (ristretto_decompress(&pts[o], C)) bad = 1; o++;
+    for (size_t j = 0; j < lg_n; j++) { sc_mul(&scal[o], &nxs, &x[j]); if (ristretto_decompress(&pts[o], proof + 64 * j)) bad = 1; o++; }
+    for (size_t j = 0; j < lg_n; j++) { sc_mul(&scal[o], &nxs, &xinv[j]); if (ristretto_decompress(&pts[o], proof + 64 * j + 32)) bad = 1; o++; }
+    for (size_t i = 0; i < n; i++) { sc_mul(&scal[o], &a, &s[i]); if (ristretto_decompress(&pts[o], G + 32 * i)) bad = 1; o++; }
+    sc_neg(&scal[o], &one); if (ristretto_decompress(&pts[o], Sb)) bad = 1; o++;
+    int rc;
+    if (bad) { rc = ORACLE_ERR_VERIFICATION; if (msm_out) memset(msm_out, 0xff, 32); }
+    else {
+        ge_p3 res; msm_dispatch(&res, N, scal, pts, 0);
+        if (msm_out) ristretto_compress(msm_out, &res);
+        rc = ge_is_identity(&res) ? ORACLE_OK : ORACLE_ERR_VERIFICATION;   /* expect_S == S (ristretto equality) */
+    }
+    free(b); free(scal); free(pts);
+    return rc;
+}
+
 /* ---------------- threaded batch drivers ---------------- */
 typedef struct {
     int kind, tid, threads;

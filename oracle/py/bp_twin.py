@@ -782,3 +782,100 @@ def ipp_verify(proof_bytes, n, transcript, G_factors, H_factors, P, Q, G, H):
     if any(p is None for p in Ls + Rs):
         raise VerificationError()
     return compress(msm(scalars, [Q] + list(G) + list(H) + Ls + Rs + [P]))
+
+
+# ----------------------------------------------------------------------------
+# LinearProof (src/linear_proof.rs): <a, b> = c for secret a, public b
+# ----------------------------------------------------------------------------
+def _linear_public_inputs(transcript, n, C, b_vec, G, F, B):
+    """linear_proof.rs:73-83 / 196-206; G, F, B are extended tuples, C bytes"""
+    transcript.innerproduct_domain_sep(n)
+    transcript.append_point(b"C", C)
+    for x in b_vec:
+        transcript.append_scalar(b"b_i", x)
+    for p in G:
+        transcript.append_point(b"G_i", compress(p))
+    transcript.append_point(b"F", compress(F))
+    transcript.append_point(b"B", compress(B))
+
+
+def linear_create(transcript, rng, C, r, a_vec, b_vec, G_vec, F, B):
+    """LinearProof::create(...).to_bytes() (linear_proof.rs:40-173, 322-331); rng.scalar() = Scalar::random"""
+    n = len(b_vec)
+    assert len(G_vec) == n and len(a_vec) == n and n & (n - 1) == 0 and n
+    _linear_public_inputs(transcript, n, C, b_vec, G_vec, F, B)
+    a, b, G = list(a_vec), list(b_vec), list(G_vec)
+    out = b""
+    while n != 1:
+        n //= 2
+        aL, aR, bL, bR, GL, GR = a[:n], a[n:], b[:n], b[n:], G[:n], G[n:]
+        cL, cR = inner_product(aL, bR), inner_product(aR, bL)
+        sj, tj = rng.scalar(), rng.scalar()
+        Lp = compress(msm(aL + [sj, cL], GR + [B, F]))
+        Rp = compress(msm(aR + [tj, cR], GL + [B, F]))
+        out += Lp + Rp
+        transcript.append_point(b"L", Lp)
+        transcript.append_point(b"R", Rp)
+        x = transcript.challenge_scalar(b"x_j")
+        xi = sc_inv(x)
+        a = [(aL[i] + xi * aR[i]) % L for i in range(n)]
+        b = [(bL[i] + x * bR[i]) % L for i in range(n)]
+        G = [msm([1, x], [GL[i], GR[i]]) for i in range(n)]
+        r = (r + x * sj + xi * tj) % L
+    s_star, t_star = rng.scalar(), rng.scalar()
+    S = compress(msm([t_star, s_star * b[0] % L, s_star], [B, F, G[0]]))
+    transcript.append_point(b"S", S)
+    x_star = transcript.challenge_scalar(b"x_star")
+    a_star = (s_star + x_star * a[0]) % L
+    r_star = (t_star + x_star * r) % L
+    return out + S + a_star.to_bytes(32, "little") + r_star.to_bytes(32, "little")
+
+
+def linear_verify(proof_bytes, transcript, C, G, F, B, b_vec):
+    """LinearProof::from_bytes + verify (linear_proof.rs:175-236, 240-312, 350-394), computed the way the reference does:
+    separate sums, then expect_S compared with S.  Returns compress(expect_S - S) (all-zero == Ok)."""
+    pb = proof_bytes
+    if len(pb) % 32 != 0 or len(pb) // 32 < 3 or (len(pb) // 32 - 3) % 2:
+        raise FormatError()
+    lg_n = (len(pb) // 32 - 3) // 2
+    if lg_n >= 32:
+        raise FormatError()
+    Lv = [pb[64 * i:64 * i + 32] for i in range(lg_n)]
+    Rv = [pb[64 * i + 32:64 * i + 64] for i in range(lg_n)]
+    Sb = pb[64 * lg_n:64 * lg_n + 32]
+    a = _canonical_scalar(pb[64 * lg_n + 32:64 * lg_n + 64])
+    r = _canonical_scalar(pb[64 * lg_n + 64:64 * lg_n + 96])
+    n = len(b_vec)
+    if len(G) != n:
+        raise InvalidGeneratorsLength()
+    _linear_public_inputs(transcript, n, C, b_vec, G, F, B)
+    if n != (1 << lg_n):
+        raise VerificationError()
+    b = list(b_vec)
+    ch = []
+    m = n
+    for Lb, Rb in zip(Lv, Rv):
+        transcript.validate_and_append_point(b"L", Lb)
+        transcript.validate_and_append_point(b"R", Rb)
+        x = transcript.challenge_scalar(b"x_j")
+        ch.append(x)
+        m //= 2
+        b = [(b[i] + x * b[m + i]) % L for i in range(m)]
+    ch_inv = [sc_inv(x) for x in ch]
+    b0 = b[0]
+    transcript.append_point(b"S", Sb)
+    x_star = transcript.challenge_scalar(b"x_star")
+    Ls, Rs = [decompress(x) for x in Lv], [decompress(x) for x in Rv]
+    if any(p is None for p in Ls + Rs):
+        raise VerificationError()
+    LR = msm(ch + ch_inv, Ls + Rs) if lg_n else msm([0], [B])
+    s = [1]
+    for i in range(1, n):
+        lg_i = i.bit_length() - 1
+        s.append(s[i - (1 << lg_i)] * ch[(lg_n - 1) - lg_i] % L)
+    G0 = msm(s, list(G))
+    Sp, Cp = decompress(Sb), decompress(C)
+    if Sp is None or Cp is None:
+        raise VerificationError()
+    expect = msm([r, a * b0 % L, (-x_star) % L, (-x_star) % L, a], [B, F, Cp, LR, G0])
+    return compress(pt_add(expect, pt_neg(Sp)))

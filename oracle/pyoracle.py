@@ -81,6 +81,8 @@ def lib():
     L.oracle_ipp_verify.argtypes = [sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.oracle_ipp_test_instance.argtypes = [sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.oracle_ipp_create.argtypes = [sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
+    L.oracle_linear_create.argtypes = [sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
+    L.oracle_linear_verify.argtypes = [sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.oracle_msm_batch.restype = C.c_double
     L.oracle_msm_batch.argtypes = [sz, sz, u8p, u8p, C.c_int, u8p, u8p, C.c_int]
     _lib = L
@@ -250,3 +252,48 @@ def ipp_verify(n, proof, label, Gf, Hf, P, Q, G, H):
     out = C.create_string_buffer(32)
     rc = lib().oracle_ipp_verify(n, proof, len(proof), label, len(label), Gf, Hf, P, Q, G, H, out)
     return rc, out.raw
+
+
+def linear_create(n, state, rng, Cc, r, a, b, G, F, B):
+    """LinearProof::create(transcript, rng, &C, r, a, b, G, &F, &B).to_bytes() (linear_proof.rs:40-173); rng = 64 bytes per
+    Scalar::random in draw order.  Returns (rc, proof bytes)."""
+    lg = max(n, 1).bit_length() - 1
+    assert len(rng) >= 64 * (2 * lg + 2)
+    out = C.create_string_buffer(32 * (2 * lg + 3))
+    rc = lib().oracle_linear_create(n, state, rng, Cc, r, a, b, G, F, B, out)
+    return rc, out.raw
+
+
+def linear_verify(n, proof, state, Cc, G, F, B, b):
+    """LinearProof::from_bytes(proof)?.verify(transcript, &C, &G, &F, &B, b) (linear_proof.rs:175-236): (code, compress(expect_S - S))"""
+    out = C.create_string_buffer(32)
+    rc = lib().oracle_linear_verify(n, proof, len(proof), state, Cc, G, F, B, b, out)
+    return rc, out.raw
+
+
+def linear_test_instance(n, seed, label=b"linearprooftest"):
+    """The reference's test_helper(n) (linear_proof.rs:401-466) with a SHAKE256(seed) rng: G = bp_gens.share(0).G(n),
+    F = pedersen B, B = pedersen B_blinding, random a, b, r, C = <a, G> + r B + <a, b> F.  Returns a dict of byte strings."""
+    import hashlib
+    lg = n.bit_length() - 1
+    g = Gens(n, 1)
+    Gc, _, Bp, Bb = g.export()
+    stream = hashlib.shake_256(seed).digest(64 * (2 * n + 1 + 2 * lg + 2))
+    L = lib()
+
+    def wide(i):
+        o = C.create_string_buffer(32)
+        L.oracle_scalar_from_wide(stream[64 * i:64 * i + 64], o)
+        return o.raw
+    a = b"".join(wide(i) for i in range(n))
+    b = b"".join(wide(n + i) for i in range(n))
+    r = wide(2 * n)
+    ell = 2 ** 252 + 27742317777372353535851937790883648493
+    c = sum(int.from_bytes(a[32 * i:32 * i + 32], "little") * int.from_bytes(b[32 * i:32 * i + 32], "little") for i in range(n)) % ell
+    rcm, Cc = msm(a + r + c.to_bytes(32, "little"), Gc[:32 * n] + Bb + Bp)
+    assert rcm == 0
+    st = transcript_new(label)
+    rng = stream[64 * (2 * n + 1):]
+    rc, proof = linear_create(n, st, rng, Cc, r, a, b, Gc[:32 * n], Bp, Bb)
+    assert rc == 0
+    return dict(n=n, proof=proof, C=Cc, G=Gc[:32 * n], F=Bp, B=Bb, a=a, b=b, r=r, rng=rng, label=label)

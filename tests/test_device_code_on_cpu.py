@@ -409,6 +409,52 @@ def test_batch_combination_pipeline_lane_by_lane(H, oracle, golden):
                 assert list(vd.raw) == [5, 5, 2, 1, 5]
 
 
+def _linear_cases(oracle, n, tag):
+    """five proofs of size n on the reference's test shape (linear_proof.rs:401-466): valid, a tampered, r non-canonical,
+    an identity L_0 (or S undecodable at n = 1), wrong commitment"""
+    insts = [oracle.linear_test_instance(n, b"%s-%d-%d" % (tag, n, j)) for j in range(5)]
+    pl = len(insts[0]["proof"])
+    bad = bytearray(insts[1]["proof"])
+    bad[pl - 64] ^= 1                               # a tampered: still canonical with overwhelming probability
+    insts[1] = dict(insts[1], proof=bytes(bad))
+    fmt = bytearray(insts[2]["proof"])
+    fmt[pl - 32:] = b"\xff" * 32                    # r >= l: FormatError (from_bytes, linear_proof.rs:383-384)
+    insts[2] = dict(insts[2], proof=bytes(fmt))
+    und = bytearray(insts[3]["proof"])
+    if n > 1:
+        und[0:32] = bytes(32)                       # L_0 = identity encoding: validate_and_append_point fails (:272)
+    else:
+        und[0] |= 1                                 # S: negative field element, does not decode (:217)
+    insts[3] = dict(insts[3], proof=bytes(und))
+    insts[4] = dict(insts[4], C=insts[0]["C"])      # somebody else's commitment
+    return insts, pl
+
+
+@pytest.mark.parametrize("n", [1, 2, 16, 64])
+def test_linear_proof_front_end_lane_by_lane(H, oracle, n):
+    """lin_prepare (public inputs, rounds, Gray-code subset products, <s, b>) + the variable-base pipeline against the
+    oracle's restatement of LinearProof::verify (linear_proof.rs:175-236); sizes of the reference's tests (:470-487)."""
+    insts, pl = _linear_cases(oracle, n, b"hlin")
+    cat = lambda key: b"".join(i[key] for i in insts)
+    nb = len(insts)
+    vd, mo = C.create_string_buffer(nb), C.create_string_buffer(32 * nb)
+    g0 = insts[0]
+    assert H.h_lin_verify(n, nb, cat("proof"), pl, g0["label"], len(g0["label"]), cat("C"), g0["G"], g0["F"], g0["B"], cat("b"), 0, vd, mo) == 0
+    st = oracle.transcript_new(g0["label"])
+    for j, inst in enumerate(insts):
+        rc, em = oracle.linear_verify(n, inst["proof"], st, inst["C"], inst["G"], inst["F"], inst["B"], inst["b"])
+        assert vd.raw[j] == rc, (n, j, vd.raw[j], rc)
+        if rc != 2 and not (j == 3):
+            assert mo.raw[32 * j:32 * j + 32] == em, (n, j)
+    assert list(vd.raw) == [0, 1, 2, 1, 1]
+    # one public vector shared by the batch; wrong n for the proof length
+    vd2 = C.create_string_buffer(2)
+    assert H.h_lin_verify(n, 2, g0["proof"] * 2, pl, g0["label"], len(g0["label"]), g0["C"] * 2, g0["G"], g0["F"], g0["B"], g0["b"], 1, vd2, None) == 0
+    assert list(vd2.raw) == [0, 0]
+    assert H.h_lin_verify(2 * n, 1, g0["proof"], pl, g0["label"], len(g0["label"]), g0["C"], g0["G"] * 2, g0["F"], g0["B"], g0["b"] * 2, 0, vd2, None) == 0
+    assert vd2.raw[0] == 1 == oracle.linear_verify(2 * n, g0["proof"], st, g0["C"], g0["G"] * 2, g0["F"], g0["B"], g0["b"] * 2)[0]
+
+
 @pytest.mark.parametrize("n", [1, 2, 4, 32])
 def test_standalone_ipp_front_end_lane_by_lane(H, oracle, n):
     """ipp_prepare (transcript, batch inversion, s_i products) + the variable-base pipeline against the oracle's

@@ -1,0 +1,86 @@
+"""GPU parity for bpgpu_linear_verify_batch (LinearProof::from_bytes + verify, src/linear_proof.rs:175-236, 240-312,
+350-394); sizes of the reference's own tests (linear_proof.rs:470-487: test_helper(n) for n in {1, 16, 32, 64}) plus 2 and
+256, against the C oracle (itself pinned by the Python twin: tests/test_oracle.py)."""
+import hashlib
+
+import pytest
+
+from test_device_code_on_cpu import _linear_cases
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import bulletproofs_amd as bp
+    c = bp.Context(0)
+    yield c
+    c.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 16, 32, 64])
+def test_linear_verify_cases(ctx, oracle, n):
+    insts, pl = _linear_cases(oracle, n, b"glin")
+    cat = lambda key: b"".join(i[key] for i in insts)
+    g0 = insts[0]
+    verdict, msm = ctx.linear_verify_batch(n, cat("proof"), pl, cat("C"), g0["G"], g0["F"], g0["B"], cat("b"), label=g0["label"], want_msm=True)
+    st = oracle.transcript_new(g0["label"])
+    for j, inst in enumerate(insts):
+        rc, em = oracle.linear_verify(n, inst["proof"], st, inst["C"], inst["G"], inst["F"], inst["B"], inst["b"])
+        assert verdict[j] == rc, (n, j)
+        if rc != 2 and j != 3:
+            assert msm[32 * j:32 * j + 32] == em, (n, j)          # bit-exact, also for the non-identity results
+    assert list(verdict) == [0, 1, 2, 1, 1]
+    # wrong n for the proof length (linear_proof.rs:263-265), and a truncated proof (FormatError, :351-360)
+    assert list(ctx.linear_verify_batch(2 * n, g0["proof"], pl, g0["C"], g0["G"] * 2, g0["F"], g0["B"], g0["b"] * 2, label=g0["label"])) == [1]
+    assert list(ctx.linear_verify_batch(n, g0["proof"][:-1] * 2, pl - 1, g0["C"] * 2, g0["G"], g0["F"], g0["B"], g0["b"] * 2, label=g0["label"])) == [2, 2]
+
+
+def test_linear_verify_batch_of_many_with_shared_public_vector_and_caller_transcript(ctx, oracle):
+    """200 proofs for one public vector b over a transcript that already holds an application message; every 7th proof
+    belongs to another transcript and must fail"""
+    n, nb = 16, 200
+    base = oracle.linear_test_instance(n, b"glin-many")
+    st_app = oracle.transcript_append_message(oracle.transcript_new(b"app protocol"), b"ctx", b"session 42")
+    st_other = oracle.transcript_new(b"another protocol")
+    ell = 2 ** 252 + 27742317777372353535851937790883648493
+    proofs, Cs, expect = [], [], []
+    for j in range(nb):
+        stream = hashlib.shake_256(b"many%d" % j).digest(64 * (n + 1 + 2 * 4 + 2))
+        red = lambda i: (int.from_bytes(stream[64 * i:64 * i + 64], "little") % ell).to_bytes(32, "little")
+        a = b"".join(red(i) for i in range(n))
+        r = red(n)
+        c = sum(int.from_bytes(a[32 * i:32 * i + 32], "little") * int.from_bytes(base["b"][32 * i:32 * i + 32], "little") for i in range(n)) % ell
+        rcm, Cc = oracle.msm(a + r + c.to_bytes(32, "little"), base["G"] + base["B"] + base["F"])
+        assert rcm == 0
+        wrong = j % 7 == 6
+        rc, pr = oracle.linear_create(n, st_other if wrong else st_app, stream[64 * (n + 1):], Cc, r, a, base["b"], base["G"], base["F"], base["B"])
+        assert rc == 0
+        proofs.append(pr)
+        Cs.append(Cc)
+        expect.append(1 if wrong else 0)
+    pl = len(proofs[0])
+    verdict, msm = ctx.linear_verify_batch(n, b"".join(proofs), pl, b"".join(Cs), base["G"], base["F"], base["B"], base["b"], transcript=st_app,
+                                           want_msm=True)
+    assert list(verdict) == expect
+    for j in (0, 6, 13, 199):
+        rc, em = oracle.linear_verify(n, proofs[j], st_app, Cs[j], base["G"], base["F"], base["B"], base["b"])
+        assert rc == expect[j] and msm[32 * j:32 * j + 32] == em
+
+
+def test_linear_verify_n256_uses_the_bucket_msm(ctx, oracle):
+    """n = 256: 276 terms per proof; 8 proofs (2208 terms) cross the bucket threshold of the variable-base MSM"""
+    n = 256
+    insts = [oracle.linear_test_instance(n, b"glin256-%d" % j) for j in range(8)]
+    bad = bytearray(insts[5]["proof"])
+    bad[-1 - 32] ^= 1
+    insts[5] = dict(insts[5], proof=bytes(bad))
+    cat = lambda key: b"".join(i[key] for i in insts)
+    g0 = insts[0]
+    pl = len(g0["proof"])
+    verdict, msm = ctx.linear_verify_batch(n, cat("proof"), pl, cat("C"), g0["G"], g0["F"], g0["B"], cat("b"), label=g0["label"], want_msm=True)
+    st = oracle.transcript_new(g0["label"])
+    for j, inst in enumerate(insts):
+        rc, em = oracle.linear_verify(n, inst["proof"], st, inst["C"], inst["G"], inst["F"], inst["B"], inst["b"])
+        assert verdict[j] == rc and msm[32 * j:32 * j + 32] == em, j
+    assert list(verdict) == [0, 0, 0, 0, 0, 1, 0, 0]

@@ -197,3 +197,51 @@ def test_standalone_ipp_reference_test_shape(oracle, n):
     assert rc == 1 and out == tw != bytes(32)
     assert oracle.ipp_verify(2 * n, inst["proof"], b"innerproducttest", inst["Gf"] * 2, inst["Hf"] * 2, inst["P"], inst["Q"], inst["G"] * 2, inst["H"] * 2)[0] == 1
     assert oracle.ipp_verify(n, inst["proof"][:-1], b"x", inst["Gf"], inst["Hf"], inst["P"], inst["Q"], inst["G"], inst["H"])[0] == 2
+
+
+class _BytesRng:
+    """the rng of the twin's prover reading the same 64-byte draws the C oracle is given"""
+    def __init__(self, b):
+        self.b, self.o = b, 0
+
+    def scalar(self):
+        v = int.from_bytes(self.b[self.o:self.o + 64], "little") % T.L
+        self.o += 64
+        return v
+
+
+@pytest.mark.parametrize("n", [1, 2, 8])
+def test_linear_proof_c_equals_twin(oracle, n):
+    """LinearProof (src/linear_proof.rs) has no fixed vectors upstream (its tests are random round trips, :397-488): the C
+    restatement is pinned by the independent Python twin -- byte-identical proofs from create, identical verify outputs
+    (including the non-identity encoding of a tampered proof) -- and by the round trip itself."""
+    inst = oracle.linear_test_instance(n, b"olin%d" % n)
+    assert len(inst["proof"]) == 32 * (2 * (n.bit_length() - 1) + 3)                     # serialized_size (:318-320)
+    iv = lambda bs: [int.from_bytes(bs[32 * i:32 * i + 32], "little") for i in range(len(bs) // 32)]
+    G = [T.decompress(inst["G"][32 * i:32 * i + 32]) for i in range(n)]
+    F, B = T.decompress(inst["F"]), T.decompress(inst["B"])
+    tp = T.linear_create(T.Transcript(inst["label"]), _BytesRng(inst["rng"]), inst["C"], iv(inst["r"])[0], iv(inst["a"]), iv(inst["b"]), G, F, B)
+    assert tp == inst["proof"]
+    st = oracle.transcript_new(inst["label"])
+    rc, out = oracle.linear_verify(n, inst["proof"], st, inst["C"], inst["G"], inst["F"], inst["B"], inst["b"])
+    assert rc == 0 and out == bytes(32)
+    assert T.linear_verify(inst["proof"], T.Transcript(inst["label"]), inst["C"], G, F, B, iv(inst["b"])) == bytes(32)
+    bad = bytearray(inst["proof"])
+    bad[-64] ^= 1                                                                          # a tampered
+    rc, out = oracle.linear_verify(n, bytes(bad), st, inst["C"], inst["G"], inst["F"], inst["B"], inst["b"])
+    assert rc == 1 and out != bytes(32)
+    assert T.linear_verify(bytes(bad), T.Transcript(inst["label"]), inst["C"], G, F, B, iv(inst["b"])) == out
+    # a transcript that already holds application messages, on both sides
+    st2 = oracle.transcript_append_message(st, b"app", b"hello")
+    t2 = T.Transcript(inst["label"])
+    t2.append_message(b"app", b"hello")
+    rc, p2 = oracle.linear_create(n, st2, inst["rng"], inst["C"], inst["r"], inst["a"], inst["b"], inst["G"], inst["F"], inst["B"])
+    assert rc == 0 and p2 != inst["proof"]
+    assert oracle.linear_verify(n, p2, st2, inst["C"], inst["G"], inst["F"], inst["B"], inst["b"])[0] == 0
+    assert oracle.linear_verify(n, p2, st, inst["C"], inst["G"], inst["F"], inst["B"], inst["b"])[0] == 1
+    assert T.linear_verify(p2, t2, inst["C"], G, F, B, iv(inst["b"])) == bytes(32)
+    # from_bytes (:350-394)
+    for cut in (31, 64, 32 * (2 * (n.bit_length() - 1) + 3) + 32):
+        assert oracle.linear_verify(n, inst["proof"][:cut] if cut < len(inst["proof"]) else inst["proof"] + bytes(32), st, inst["C"], inst["G"],
+                                    inst["F"], inst["B"], inst["b"])[0] == 2
+    assert oracle.linear_create(3, st, inst["rng"] * 2, inst["C"], inst["r"], inst["a"] * 3, inst["b"] * 3, inst["G"] * 3, inst["F"], inst["B"])[0] == 5
