@@ -83,8 +83,8 @@ def lib():
     L.bpgpu_rangeproof_prove_batch.argtypes = [vp, sz, sz, sz, C.POINTER(C.c_uint64), u8p, u8p, sz, u8p, u8p, u8p, u8p, u8p]
     L.bpgpu_rangeproof_verify_batch_submit.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p]
     L.bpgpu_ctx_collect.argtypes = [vp]
-    L.bpgpu_linear_verify_batch.argtypes = [vp, sz, sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, i, u8p, u8p]
-    L.bpgpu_linear_verify_batch_dev.argtypes = [vp, sz, sz, vp, sz, u8p, sz, u8p, vp, vp, vp, vp, vp, i, vp, vp, vp]
+    L.bpgpu_linear_verify_batch.argtypes = [vp, sz, sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, i, u8p, u8p, u8p]
+    L.bpgpu_linear_verify_batch_dev.argtypes = [vp, sz, sz, vp, sz, u8p, sz, u8p, vp, vp, vp, vp, vp, i, vp, vp, vp, vp]
     L.bpgpu_profile_enable.argtypes = [vp, i]
     L.bpgpu_profile_reset.argtypes = [vp]
     L.bpgpu_profile_report.argtypes = [vp, C.c_char_p, sz]
@@ -264,7 +264,7 @@ class Context:
         self._chk(self._L.bpgpu_ipp_verify_batch(self.h, n, nb, proofs, proof_len, label, len(label), Gf, Hf, P, Q, G, H, verdict, msm))
         return (verdict.raw[:nb], msm.raw[:32 * nb]) if want_msm else verdict.raw[:nb]
 
-    def linear_verify_batch(self, n, proofs, proof_len, Cs, G, F, B, b, label=b"", transcript=None, want_msm=False):
+    def linear_verify_batch(self, n, proofs, proof_len, Cs, G, F, B, b, label=b"", transcript=None, want_msm=False, want_transcripts=False):
         """LinearProof::verify for len(Cs) / 32 proofs (bpgpu_linear_verify_batch).  G: n points shared by the batch; b: per-proof
         vectors (nb * n scalars) or one shared vector (n scalars)."""
         nb = len(Cs) // 32
@@ -272,9 +272,11 @@ class Context:
         shared = 1 if (len(b) == 32 * n and nb != 1) else 0
         verdict = C.create_string_buffer(max(nb, 1))
         msm = C.create_string_buffer(32 * max(nb, 1)) if want_msm else None
+        tso = C.create_string_buffer(TRANSCRIPT_BYTES * max(nb, 1)) if want_transcripts else None
         self._chk(self._L.bpgpu_linear_verify_batch(self.h, n, nb, proofs, proof_len, label, len(label), transcript, Cs, G, F, B, b, shared,
-                                                    verdict, msm))
-        return (verdict.raw[:nb], msm.raw[:32 * nb]) if want_msm else verdict.raw[:nb]
+                                                    verdict, msm, tso))
+        out = (verdict.raw[:nb],) + ((msm.raw[:32 * nb],) if want_msm else ()) + ((tso.raw[:TRANSCRIPT_BYTES * nb],) if want_transcripts else ())
+        return out if len(out) > 1 else out[0]
 
     def ipp_create_batch(self, n, Q, Gf, Hf, G, H, a, b, label=b"", transcript=None):
         """InnerProductProof::create for nbatch proofs (bpgpu_ipp_create_batch).  G/H of n*32 bytes = bases shared by the batch.

@@ -187,3 +187,59 @@ class RangeProof:
         v, _, _ = bp_gens.ctx.rangeproof_verify_rlc(n, m, b"".join(raw), ln, b"".join(b"".join(c) for c in commitments), label, rng64,
                                                     weights64)
         return [None if x == 0 else _BY_CODE[x]() for x in v]
+
+
+class LinearProof:
+    """src/linear_proof.rs (`pub use` lib.rs:36): the proof that <a, b> = c for a committed secret vector a and a public
+    vector b.  Verification runs on the device (bpgpu_linear_verify_batch)."""
+
+    def __init__(self, raw):
+        self._raw = raw
+
+    @staticmethod
+    def from_bytes(b):
+        """linear_proof.rs:350-394; raises FormatError."""
+        b = bytes(b)
+        ne = len(b) // 32
+        if len(b) % 32 != 0 or ne < 3 or (ne - 3) % 2 != 0 or (ne - 3) // 2 >= 32:
+            raise FormatError()
+        for off in (len(b) - 64, len(b) - 32):
+            if int.from_bytes(b[off:off + 32], "little") >= _L:
+                raise FormatError()
+        return LinearProof(b)
+
+    def to_bytes(self):
+        return self._raw
+
+    def serialized_size(self):
+        return len(self._raw)
+
+    def verify(self, transcript, C, G, F, B, b_vec, ctx):
+        """LinearProof::verify(&self, transcript, C, G, F, B, b_vec) (linear_proof.rs:175-236): Ok(()) -> None, Err(e) -> raises e.
+        C, F, B and the entries of G are 32-byte compressed points, b_vec 32-byte canonical scalars; ctx: the Context (or a
+        BulletproofGens) whose device runs the check.  The transcript is left advanced as the reference leaves it."""
+        c = getattr(ctx, "ctx", ctx)
+        if len(G) != len(b_vec):
+            raise InvalidGeneratorsLength()
+        v, ts = c.linear_verify_batch(len(b_vec), self._raw, len(self._raw), bytes(C), b"".join(bytes(g) for g in G), bytes(F), bytes(B),
+                                      b"".join(bytes(x) for x in b_vec), transcript=transcript.state, want_transcripts=True)
+        transcript.state = ts
+        transcript.fresh_label = None
+        if v[0] != 0:
+            raise _BY_CODE[v[0]]()
+
+    @staticmethod
+    def verify_batch(ctx, transcript, proofs, Cs, G, F, B, b_vecs):
+        """proofs[i].verify(&mut transcript.clone(), &Cs[i], G, F, B, b_vecs[i]) for all i in one GPU pass -> list of None /
+        ProofError.  b_vecs: one vector per proof, or a single vector (list of scalars) shared by all."""
+        c = getattr(ctx, "ctx", ctx)
+        if not proofs:
+            return []
+        raw = [p.to_bytes() if isinstance(p, LinearProof) else bytes(p) for p in proofs]
+        ln, n = len(raw[0]), len(G)
+        assert all(len(r) == ln for r in raw)
+        shared = len(b_vecs) == n and isinstance(b_vecs[0], (bytes, bytearray))
+        b = b"".join(bytes(x) for x in b_vecs) if shared else b"".join(b"".join(bytes(x) for x in v) for v in b_vecs)
+        v = c.linear_verify_batch(n, b"".join(raw), ln, b"".join(bytes(x) for x in Cs), b"".join(bytes(g) for g in G), bytes(F), bytes(B), b,
+                                  transcript=transcript.state)
+        return [None if x == 0 else _BY_CODE[x]() for x in v]

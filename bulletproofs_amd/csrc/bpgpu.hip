@@ -1871,7 +1871,8 @@ extern "C" int bpgpu_ipp_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, con
 // G (n encodings), F, B are shared by the batch; b is per proof unless b_shared.
 static int lin_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t nbatch, const void *d_proofs, size_t proof_len, const uint8_t *label,
                                  size_t label_len, const uint8_t *shared_ts, const void *d_C, const void *d_G, const void *d_F,
-                                 const void *d_B, const void *d_b, int b_shared, void *d_verdict, void *d_msm_out, hipStream_t s) {
+                                 const void *d_B, const void *d_b, int b_shared, void *d_verdict, void *d_msm_out, void *d_ts_out,
+                                 hipStream_t s) {
     if (nbatch > 0x7fffffffu / 64) return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large");
     if (shared_ts && !ts_state_ok(shared_ts)) return fail(c, BPGPU_ERR_INVALID_ARG, "malformed transcript state");
     // LinearProof::from_bytes, length part (linear_proof.rs:350-366)
@@ -1887,6 +1888,7 @@ static int lin_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t nbatch, const vo
         }
     }
     if (fmt) {
+        if (d_ts_out) return fail(c, BPGPU_ERR_INVALID_ARG, "proof_len is not a LinearProof length: no transcripts to return");
         HIPCHK(c, hipMemsetAsync(d_verdict, BPGPU_VERDICT_FORMAT_ERROR, nbatch, s));
         if (d_msm_out) HIPCHK(c, hipMemsetAsync(d_msm_out, 0, nbatch * 32, s));
         return BPGPU_OK;
@@ -1934,7 +1936,7 @@ static int lin_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t nbatch, const vo
     const uint32_t nb32 = (uint32_t)nbatch;
     LAUNCH(c, s, "lin_prepare", k_lin_prepare, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, init, (const uint8_t *)d_proofs, (const uint8_t *)d_C,
            (const uint8_t *)d_b, (const uint8_t *)d_G, (const uint8_t *)d_F, (const uint8_t *)d_B, (uint32_t *)d_sc, (uint32_t *)d_pt,
-           (uint32_t *)d_stat);
+           (uint32_t *)d_stat, (uint32_t *)d_ts_out);
     std::vector<uint32_t> nt(nbatch, (uint32_t)N);
     int rc = msm_batch_dev_locked(c, nbatch, nt.data(), d_sc, d_pt, d_out, d_mst, s);
     if (rc) return rc;
@@ -1948,11 +1950,11 @@ static int lin_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t nbatch, const vo
 extern "C" int bpgpu_linear_verify_batch_dev(bpgpu_ctx *c, size_t n, size_t nbatch, const void *d_proofs, size_t proof_len, const uint8_t *label,
                                              size_t label_len, const uint8_t *shared_transcript, const void *d_C, const void *d_G,
                                              const void *d_F, const void *d_B, const void *d_b, int b_shared, void *d_verdict, void *d_msm_out,
-                                             void *stream) {
+                                             void *d_transcripts_out, void *stream) {
     if (!c || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
     if (nbatch == 0) return BPGPU_OK;
     if (!d_proofs || !d_verdict || !d_C || !d_F || !d_B || (n && (!d_G || !d_b))) return BPGPU_ERR_INVALID_ARG;
-    if (((uintptr_t)d_proofs | (uintptr_t)d_C | (uintptr_t)d_G | (uintptr_t)d_F | (uintptr_t)d_B | (uintptr_t)d_b) & 3)
+    if (((uintptr_t)d_proofs | (uintptr_t)d_C | (uintptr_t)d_G | (uintptr_t)d_F | (uintptr_t)d_B | (uintptr_t)d_b | (uintptr_t)d_transcripts_out) & 3)
         return fail(c, BPGPU_ERR_INVALID_ARG, "device buffers must be 4-byte aligned");
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
@@ -1960,14 +1962,15 @@ extern "C" int bpgpu_linear_verify_batch_dev(bpgpu_ctx *c, size_t n, size_t nbat
     int rc = ctx_enter(c, s);
     if (rc) return rc;
     rc = lin_verify_dev_locked(c, n, nbatch, d_proofs, proof_len, label, label_len, shared_transcript, d_C, d_G, d_F, d_B, d_b, b_shared, d_verdict,
-                               d_msm_out, s);
+                               d_msm_out, d_transcripts_out, s);
     const int rc2 = ctx_leave(c, s);
     return rc ? rc : rc2;
 }
 
 extern "C" int bpgpu_linear_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, const uint8_t *proofs, size_t proof_len, const uint8_t *label,
                                          size_t label_len, const uint8_t *shared_transcript, const uint8_t *C, const uint8_t *G, const uint8_t *F,
-                                         const uint8_t *B, const uint8_t *b, int b_shared, uint8_t *verdict, uint8_t *msm_out) {
+                                         const uint8_t *B, const uint8_t *b, int b_shared, uint8_t *verdict, uint8_t *msm_out,
+                                         uint8_t *transcripts_out) {
     if (!c || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
     if (nbatch == 0) return BPGPU_OK;
     if (!proofs || !verdict || !C || !F || !B || (n && (!G || !b))) return BPGPU_ERR_INVALID_ARG;
@@ -1977,16 +1980,18 @@ extern "C" int bpgpu_linear_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
     const size_t sz_pr = align_up(nbatch * proof_len + 64), sz_c = align_up(nbatch * 32 + 64), sz_g = align_up(n * 32 + 64), sz_fb = align_up(64 + 64),
                  sz_bv = align_up(nb_b * n * 32 + 64);
     const size_t sz_in = sz_pr + sz_c + sz_g + sz_fb + sz_bv, sz_v = align_up(nbatch), sz_o = align_up(nbatch * 32);
+    const size_t sz_t = transcripts_out ? align_up(nbatch * BPGPU_TRANSCRIPT_BYTES) : 0;
     hipStream_t s = c->stream;
     int rc = ctx_enter(c, s);
     if (rc) return rc;
-    rc = io_reserve(c, sz_in + sz_v + sz_o);
+    rc = io_reserve(c, sz_in + sz_v + sz_o + sz_t);
     if (rc) return rc;
     char *h = nullptr;
-    rc = pin_alloc(c, s, sz_in + sz_v + sz_o, &h);
+    rc = pin_alloc(c, s, sz_in + sz_v + sz_o + sz_t, &h);
     if (rc) return rc;
     char *d = c->io_dev;
     char *d_pr = d, *d_c = d_pr + sz_pr, *d_g = d_c + sz_c, *d_fb = d_g + sz_g, *d_bv = d_fb + sz_fb, *d_v = d + sz_in, *d_o = d_v + sz_v;
+    char *d_t = transcripts_out ? d_o + sz_o : nullptr;
     memcpy(h, proofs, nbatch * proof_len);
     memcpy(h + sz_pr, C, nbatch * 32);
     if (n) {
@@ -1996,13 +2001,15 @@ extern "C" int bpgpu_linear_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
     memcpy(h + sz_pr + sz_c + sz_g, F, 32);
     memcpy(h + sz_pr + sz_c + sz_g + 32, B, 32);
     HIPCHK(c, hipMemcpyAsync(d, h, sz_in, hipMemcpyHostToDevice, s));
-    rc = lin_verify_dev_locked(c, n, nbatch, d_pr, proof_len, label, label_len, shared_transcript, d_c, d_g, d_fb, d_fb + 32, d_bv, b_shared, d_v, d_o, s);
+    rc = lin_verify_dev_locked(c, n, nbatch, d_pr, proof_len, label, label_len, shared_transcript, d_c, d_g, d_fb, d_fb + 32, d_bv, b_shared, d_v, d_o,
+                               d_t, s);
     char *h_out = h + sz_in;
-    if (!rc && hipMemcpyAsync(h_out, d_v, sz_v + sz_o, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+    if (!rc && hipMemcpyAsync(h_out, d_v, sz_v + sz_o + sz_t, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
     const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
     if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
     memcpy(verdict, h_out, nbatch);
     if (msm_out) memcpy(msm_out, h_out + sz_v, nbatch * 32);
+    if (transcripts_out) memcpy(transcripts_out, h_out + sz_v + sz_o, nbatch * BPGPU_TRANSCRIPT_BYTES);
     return BPGPU_OK;
 }
 

@@ -24,9 +24,11 @@ struct lin_shape {
 
 // thread p.  Outputs are pre-zeroed by the host, so rejected proofs contribute identity terms.
 // Term order: B, F, C, L_0.., R_0.., G_0.., S.
+// ts_out (optional): the transcript as verify() leaves it (after the x_star challenge) for proofs that reach the final
+// check; the start state for proofs rejected before that.
 BP_HD void lin_prepare_thread(uint32_t p, lin_shape sh, const rp_strobe_init &init, kstate st, const uint8_t *proofs, const uint8_t *C,
                               const uint8_t *bvec, const uint8_t *G, const uint8_t *F, const uint8_t *B, uint32_t *scalars,
-                              uint32_t *points, uint32_t *status) {
+                              uint32_t *points, uint32_t *status, uint32_t *ts_out = nullptr) {
     const uint32_t n = sh.n, k = sh.k;
     const uint8_t *pr = proofs + (uint64_t)p * sh.proof_len;
     const uint8_t *Sb = pr + 64 * k;
@@ -35,10 +37,12 @@ BP_HD void lin_prepare_thread(uint32_t p, lin_shape sh, const rp_strobe_init &in
     load_words8(r.v, Sb + 64);
     if (!sc_is_canonical_sc(a) || !sc_is_canonical_sc(r)) {
         status[p] = BP_VERDICT_FORMAT;
+        rp_ts_passthrough(p, init, nullptr, ts_out);
         return;
     }
     if (sh.shape_verdict) {
         status[p] = sh.shape_verdict;
+        rp_ts_passthrough(p, init, nullptr, ts_out);
         return;
     }
     const uint8_t *bp_ = bvec + (sh.b_shared ? 0 : (uint64_t)p * n * 32);
@@ -64,6 +68,7 @@ BP_HD void lin_prepare_thread(uint32_t p, lin_shape sh, const rp_strobe_init &in
     }
     if (fmt) {
         status[p] = BP_VERDICT_FORMAT;
+        rp_ts_passthrough(p, init, nullptr, ts_out);
         return;
     }
     for (uint32_t i = 0; i < n; i++) {
@@ -98,6 +103,7 @@ BP_HD void lin_prepare_thread(uint32_t p, lin_shape sh, const rp_strobe_init &in
     }
     if (verr) {
         status_raise(status + p, BP_VERDICT_VERIFICATION);
+        rp_ts_passthrough(p, init, nullptr, ts_out);
         return;
     }
     load_words8(w, Sb);
@@ -105,6 +111,12 @@ BP_HD void lin_prepare_thread(uint32_t p, lin_shape sh, const rp_strobe_init &in
     for (int q = 0; q < 8; q++) pt_out[(3 + 2 * k + n) * 8 + q] = w[q];
     sc xs;
     rp_challenge_scalar(t, lxs, 6, xs);
+    if (ts_out) {
+        uint32_t *o = ts_out + (uint64_t)p * BP_TS_WORDS;
+        for (uint32_t i = 0; i < 50; i++) o[i] = ks_get32(st, i);
+        o[50] = rp_ts_meta(t.pos, t.pos_begin, t.cur_flags);
+        o[51] = 0;
+    }
     sc nxs;
     sc_neg(nxs, xs);
     sc28 nxsm;

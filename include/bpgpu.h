@@ -259,7 +259,10 @@ int bpgpu_ipp_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t nbatch, const vo
  * the identity; transcript replay, the fold of b and the subset products run on the device (csrc/linear.h).
  *   proofs  : nbatch x proof_len bytes, proof_len = 32*(2*lg(n) + 3) for valid input (L_j, R_j pairs, S, a, r)
  *   transcript : shared_transcript (host, 208 bytes, may hold earlier messages) if not NULL, else Transcript::new(label);
- *             every proof starts from it (the reference's &mut Transcript is consumed, not returned)
+ *             every proof starts from it
+ *   transcripts_out : optional nbatch x 208 bytes: each proof's transcript as verify() leaves it (after the x_star
+ *             challenge, :208) when the proof reaches the final check; for proofs rejected earlier the state right after
+ *             innerproduct_domain_sep(n) (:196)
  *   C       : nbatch x 32 bytes (compressed commitments)
  *   G       : n x 32 bytes, F, B : 32 bytes each -- compressed points shared by the batch (the reference's callers pass
  *             bp_gens.share(0).G(n), pedersen B and B_blinding: linear_proof.rs:405-411); the encodings given here are
@@ -271,11 +274,12 @@ int bpgpu_ipp_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t nbatch, const vo
 int bpgpu_linear_verify_batch(bpgpu_ctx *ctx, size_t n, size_t nbatch, const uint8_t *proofs, size_t proof_len,
                               const uint8_t *label, size_t label_len, const uint8_t *shared_transcript,
                               const uint8_t *C, const uint8_t *G, const uint8_t *F, const uint8_t *B,
-                              const uint8_t *b, int b_shared, uint8_t *verdict, uint8_t *msm_out);
+                              const uint8_t *b, int b_shared, uint8_t *verdict, uint8_t *msm_out, uint8_t *transcripts_out);
 int bpgpu_linear_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t nbatch, const void *d_proofs, size_t proof_len,
                                   const uint8_t *label, size_t label_len, const uint8_t *shared_transcript,
                                   const void *d_C, const void *d_G, const void *d_F, const void *d_B,
-                                  const void *d_b, int b_shared, void *d_verdict, void *d_msm_out, void *stream);
+                                  const void *d_b, int b_shared, void *d_verdict, void *d_msm_out, void *d_transcripts_out,
+                                  void *stream);
 
 /* ---- batched inner-product-proof creation (prover side) --------------------------------
  * nbatch independent calls of

@@ -10,6 +10,7 @@
 //   RangeProof ............ src/range_proof/mod.rs:59-76, from_bytes 504-538, to_bytes 487-500,
 //                           verify_single[_with_rng] 316-342, verify_multiple[_with_rng] 345-470,
 //                           prove_single/multiple_with_rng 115-288 (variable time on the GPU)
+//   LinearProof ........... src/linear_proof.rs: from_bytes 350-394, to_bytes 322-331, verify 175-236
 // plus verify_batch, the batched entry point this engine exists for.  No arithmetic happens on the
 // host: parsing checks lengths and scalar canonicity (so from_bytes fails where the reference's does)
 // and everything else is one call into the GPU library.  There is no CPU fallback.
@@ -284,6 +285,66 @@ class RangeProof {
                                                    transcript.label().size(), rng64, weights64, verdict.data(), nullptr);
         if (rc != BPGPU_OK) throw GpuError(bpgpu_last_error(bp_gens.ctx()));
         for (size_t i = 0; i < nb; i++) out.push_back(verdict[i] == 0 ? Status::Ok() : Status::Err(static_cast<ProofError>(verdict[i])));
+        return out;
+    }
+
+  private:
+    std::vector<uint8_t> bytes_;
+};
+
+// LinearProof (src/linear_proof.rs, `pub use` lib.rs:36): <a, b> = c for a committed secret a and a public b.
+// from_bytes :350-394, to_bytes :322-331, serialized_size :318-320, verify :175-236.  The reference's verify takes no
+// generator object; here the device context that runs the check is passed explicitly (any BulletproofGens holds one).
+class LinearProof {
+  public:
+    static std::variant<LinearProof, ProofError> from_bytes(const uint8_t *slice, size_t len) {
+        if (len % 32 != 0) return ProofError::FormatError;
+        const size_t ne = len / 32;
+        if (ne < 3 || (ne - 3) % 2 != 0 || (ne - 3) / 2 >= 32) return ProofError::FormatError;
+        if (!detail::scalar_is_canonical(slice + len - 64) || !detail::scalar_is_canonical(slice + len - 32)) return ProofError::FormatError;
+        LinearProof p;
+        p.bytes_.assign(slice, slice + len);
+        return p;
+    }
+    static std::variant<LinearProof, ProofError> from_bytes(const std::vector<uint8_t> &v) { return from_bytes(v.data(), v.size()); }
+    const std::vector<uint8_t> &to_bytes() const { return bytes_; }
+    size_t serialized_size() const { return bytes_.size(); }
+
+    // LinearProof::verify(&self, transcript, C, G, F, B, b_vec); the transcript is left advanced
+    Status verify(bpgpu_ctx *ctx, Transcript &transcript, const CompressedRistretto &C, const std::vector<CompressedRistretto> &G,
+                  const CompressedRistretto &F, const CompressedRistretto &B, const std::vector<ScalarBytes> &b_vec) const {
+        if (G.size() != b_vec.size()) return Status::Err(ProofError::InvalidGeneratorsLength);   // :189-191
+        uint8_t verdict = 0;
+        std::array<uint8_t, BPGPU_TRANSCRIPT_BYTES> in = transcript.state();
+        const int rc = bpgpu_linear_verify_batch(ctx, b_vec.size(), 1, bytes_.data(), bytes_.size(), nullptr, 0, in.data(), C.data(),
+                                                 G.empty() ? nullptr : G[0].data(), F.data(), B.data(), b_vec.empty() ? nullptr : b_vec[0].data(), 0,
+                                                 &verdict, nullptr, transcript.state_mut().data());
+        if (rc != BPGPU_OK) throw GpuError(bpgpu_last_error(ctx));
+        return verdict == 0 ? Status::Ok() : Status::Err(static_cast<ProofError>(verdict));
+    }
+    // many proofs of one size over the same G, F, B in one GPU pass; b_vecs holds one public vector per proof.
+    // `transcript` is cloned per proof and not advanced.
+    static std::vector<Status> verify_batch(bpgpu_ctx *ctx, const Transcript &transcript, const std::vector<LinearProof> &proofs,
+                                            const std::vector<CompressedRistretto> &Cs, const std::vector<CompressedRistretto> &G,
+                                            const CompressedRistretto &F, const CompressedRistretto &B,
+                                            const std::vector<std::vector<ScalarBytes>> &b_vecs) {
+        const size_t nb = proofs.size(), n = G.size();
+        std::vector<Status> out;
+        if (nb == 0) return out;
+        if (Cs.size() != nb || b_vecs.size() != nb) throw std::invalid_argument("one commitment and one public vector per proof");
+        const size_t pl = proofs[0].bytes_.size();
+        std::vector<uint8_t> pb, cb, bb, verdict(nb);
+        for (size_t i = 0; i < nb; i++) {
+            if (proofs[i].bytes_.size() != pl || b_vecs[i].size() != n) throw std::invalid_argument("proofs of a batch must have one size");
+            pb.insert(pb.end(), proofs[i].bytes_.begin(), proofs[i].bytes_.end());
+            cb.insert(cb.end(), Cs[i].begin(), Cs[i].end());
+            for (const auto &x : b_vecs[i]) bb.insert(bb.end(), x.begin(), x.end());
+        }
+        const int rc = bpgpu_linear_verify_batch(ctx, n, nb, pb.data(), pl, nullptr, 0, transcript.state().data(), cb.data(),
+                                                 n ? G[0].data() : nullptr, F.data(), B.data(), n ? bb.data() : nullptr, 0, verdict.data(), nullptr,
+                                                 nullptr);
+        if (rc != BPGPU_OK) throw GpuError(bpgpu_last_error(ctx));
+        for (uint8_t v : verdict) out.push_back(v == 0 ? Status::Ok() : Status::Err(static_cast<ProofError>(v)));
         return out;
     }
 

@@ -60,3 +60,75 @@ def test_cpp_mirror_deserialize_and_verify(golden, tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr
     assert "deserialize_and_verify: ok" in out.stdout
+
+
+def _linear_replay(oracle, inst):
+    """the transcript LinearProof::verify leaves behind (linear_proof.rs:196-208), replayed with the oracle's Merlin"""
+    n = inst["n"]
+    st = oracle.transcript_new(inst["label"])
+    st = oracle.transcript_append_message(st, b"dom-sep", b"ipp v1")
+    st = oracle.transcript_append_message(st, b"n", n.to_bytes(8, "little"))
+    st = oracle.transcript_append_message(st, b"C", inst["C"])
+    for i in range(n):
+        st = oracle.transcript_append_message(st, b"b_i", inst["b"][32 * i:32 * i + 32])
+    for i in range(n):
+        st = oracle.transcript_append_message(st, b"G_i", inst["G"][32 * i:32 * i + 32])
+    st = oracle.transcript_append_message(st, b"F", inst["F"])
+    st = oracle.transcript_append_message(st, b"B", inst["B"])
+    k = n.bit_length() - 1
+    for j in range(k):
+        st = oracle.transcript_append_message(st, b"L", inst["proof"][64 * j:64 * j + 32])
+        st = oracle.transcript_append_message(st, b"R", inst["proof"][64 * j + 32:64 * j + 64])
+        st, _ = oracle.transcript_challenge_bytes(st, b"x_j", 64)
+    st = oracle.transcript_append_message(st, b"S", inst["proof"][64 * k:64 * k + 32])
+    st, _ = oracle.transcript_challenge_bytes(st, b"x_star", 64)
+    return st
+
+
+@pytest.mark.parametrize("n", [1, 16, 32, 64])
+def test_linear_proof_test_helper(oracle, n):
+    """src/linear_proof.rs:401-466 test_helper(n) for the sizes of :470-487, through the Python mirror of LinearProof: the
+    proof comes from the oracle's prover, verification from the GPU; the transcript must come back advanced exactly as the
+    reference leaves it."""
+    from bulletproofs_amd import Context, LinearProof, Transcript, VerificationError, FormatError, InvalidGeneratorsLength
+    ctx = Context(0)
+    inst = oracle.linear_test_instance(n, b"api-lin-%d" % n)
+    sp = lambda bs: [bs[32 * i:32 * i + 32] for i in range(len(bs) // 32)]
+    G, b = sp(inst["G"]), sp(inst["b"])
+    proof = LinearProof.from_bytes(inst["proof"])
+    assert proof.serialized_size() == len(proof.to_bytes()) == 32 * (2 * (n.bit_length() - 1) + 3)
+    t = Transcript(b"linearprooftest")
+    assert proof.verify(t, inst["C"], G, inst["F"], inst["B"], b, ctx) is None
+    assert t.state == _linear_replay(oracle, inst)
+    again = LinearProof.from_bytes(proof.to_bytes())
+    assert again.verify(Transcript(b"linearprooftest"), inst["C"], G, inst["F"], inst["B"], b, ctx) is None
+    with pytest.raises(VerificationError):
+        proof.verify(t, inst["C"], G, inst["F"], inst["B"], b, ctx)             # the advanced transcript is another statement
+    with pytest.raises(VerificationError):
+        proof.verify(Transcript(b"linearprooftest"), inst["B"], G, inst["F"], inst["B"], b, ctx)
+    with pytest.raises(InvalidGeneratorsLength):
+        proof.verify(Transcript(b"linearprooftest"), inst["C"], G + G[:1], inst["F"], inst["B"], b, ctx)
+    with pytest.raises(FormatError):
+        LinearProof.from_bytes(inst["proof"][:-32])
+    res = LinearProof.verify_batch(ctx, Transcript(b"linearprooftest"), [proof, again, proof], [inst["C"], inst["C"], inst["F"]], G, inst["F"],
+                                   inst["B"], [b, b, b])
+    assert res[0] is None and res[1] is None and res[2] == VerificationError()
+    ctx.close()
+
+
+def test_cpp_mirror_linear_proof(oracle, tmp_path):
+    cases = [oracle.linear_test_instance(n, b"cpp-lin-%d-%d" % (n, j)) for n, j in ((1, 0), (16, 0), (16, 1), (16, 2), (32, 0), (64, 0))]
+    with open(tmp_path / "linear_vectors.inc", "w") as f:
+        f.write("struct linear_case { size_t n; const char *proof, *C, *G, *F, *B, *b; };\nstatic const linear_case LINEAR_CASES[] = {\n")
+        for c in cases:
+            f.write('  {%d, "%s", "%s", "%s", "%s", "%s", "%s"},\n' % (c["n"], c["proof"].hex(), c["C"].hex(), c["G"].hex(), c["F"].hex(), c["B"].hex(),
+                                                                      c["b"].hex()))
+        f.write("};\n")
+    exe = tmp_path / "linear_proof_test"
+    libdir = os.path.join(ROOT, "bulletproofs_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", os.path.join(ROOT, "include"), "-I", str(tmp_path),
+                           os.path.join(ROOT, "tests", "cpp", "linear_proof_test.cpp"), "-o", str(exe),
+                           "-L", libdir, "-lbpgpu", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    assert "linear_proof: ok" in out.stdout
