@@ -22,7 +22,7 @@ EXPORTS = [
     "bpgpu_transcript_new", "bpgpu_transcript_append_message", "bpgpu_transcript_challenge_bytes",
     "bpgpu_rangeproof_verify_batch_ts", "bpgpu_rangeproof_verify_batch_ts_dev", "bpgpu_ipp_verify_batch_dev",
     "bpgpu_ipp_create_batch", "bpgpu_rangeproof_prove_batch", "bpgpu_rangeproof_verify_batch_submit", "bpgpu_ctx_collect",
-    "bpgpu_linear_verify_batch", "bpgpu_linear_verify_batch_dev",
+    "bpgpu_linear_verify_batch", "bpgpu_linear_verify_batch_dev", "bpgpu_linear_create_batch",
 ]
 
 TRANSCRIPT_BYTES = 208
@@ -84,6 +84,7 @@ def lib():
     L.bpgpu_rangeproof_verify_batch_submit.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p]
     L.bpgpu_ctx_collect.argtypes = [vp]
     L.bpgpu_linear_verify_batch.argtypes = [vp, sz, sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, i, u8p, u8p, u8p]
+    L.bpgpu_linear_create_batch.argtypes = [vp, sz, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, i, u8p, u8p, u8p, u8p, u8p, u8p]
     L.bpgpu_linear_verify_batch_dev.argtypes = [vp, sz, sz, vp, sz, u8p, sz, u8p, vp, vp, vp, vp, vp, i, vp, vp, vp, vp]
     L.bpgpu_profile_enable.argtypes = [vp, i]
     L.bpgpu_profile_reset.argtypes = [vp]
@@ -277,6 +278,20 @@ class Context:
                                                     verdict, msm, tso))
         out = (verdict.raw[:nb],) + ((msm.raw[:32 * nb],) if want_msm else ()) + ((tso.raw[:TRANSCRIPT_BYTES * nb],) if want_transcripts else ())
         return out if len(out) > 1 else out[0]
+
+    def linear_create_batch(self, n, Cs, rs, a, b, G, F, B, label=b"", transcript=None, rng=None, want_transcripts=False):
+        """LinearProof::create for len(Cs) / 32 proofs (bpgpu_linear_create_batch): returns (proofs bytes, status bytes[, transcripts])."""
+        nb = len(Cs) // 32
+        assert len(rs) == 32 * nb and len(a) == 32 * n * nb and len(b) in (32 * n, 32 * n * nb) and len(G) == 32 * n and len(F) == len(B) == 32
+        shared = 1 if (len(b) == 32 * n and nb != 1) else 0
+        lg = n.bit_length() - 1
+        assert rng is None or len(rng) == 64 * (2 * lg + 2) * nb
+        pl = 32 * (2 * lg + 3)
+        out, st = C.create_string_buffer(pl * max(nb, 1)), C.create_string_buffer(max(nb, 1))
+        tso = C.create_string_buffer(TRANSCRIPT_BYTES * max(nb, 1)) if want_transcripts else None
+        self._chk(self._L.bpgpu_linear_create_batch(self.h, n, nb, label, len(label), transcript, rng, Cs, rs, a, b, shared, G, F, B, out, st, tso))
+        res = (out.raw[:pl * nb], st.raw[:nb])
+        return res + (tso.raw[:TRANSCRIPT_BYTES * nb],) if want_transcripts else res
 
     def ipp_create_batch(self, n, Q, Gf, Hf, G, H, a, b, label=b"", transcript=None):
         """InnerProductProof::create for nbatch proofs (bpgpu_ipp_create_batch).  G/H of n*32 bytes = bases shared by the batch.

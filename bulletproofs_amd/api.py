@@ -214,6 +214,26 @@ class LinearProof:
     def serialized_size(self):
         return len(self._raw)
 
+    @staticmethod
+    def create(transcript, rng_bytes, C, r, a_vec, b_vec, G_vec, F, B, ctx):
+        """LinearProof::create(transcript, rng, &C, r, a_vec, b_vec, G_vec, &F, &B) (linear_proof.rs:40-173) on the GPU (variable
+        time, like the reference's).  rng_bytes: the 64 * (2 lg n + 2) bytes the rng would yield to Scalar::random, or None for
+        the OS CSPRNG.  The transcript is left advanced.  Raises ValueError for InvalidInputLength / InvalidGeneratorsLength."""
+        c = getattr(ctx, "ctx", ctx)
+        n = len(b_vec)
+        if len(G_vec) != n:
+            raise InvalidGeneratorsLength()
+        if len(a_vec) != n or n == 0 or n & (n - 1):
+            raise ValueError("InvalidInputLength")
+        proofs, status, ts = c.linear_create_batch(n, bytes(C), bytes(r), b"".join(bytes(x) for x in a_vec), b"".join(bytes(x) for x in b_vec),
+                                                   b"".join(bytes(g) for g in G_vec), bytes(F), bytes(B), transcript=transcript.state, rng=rng_bytes,
+                                                   want_transcripts=True)
+        if status[0] != 0:
+            raise ValueError("an input point does not decode or a scalar is not canonical")
+        transcript.state = ts
+        transcript.fresh_label = None
+        return LinearProof(proofs)
+
     def verify(self, transcript, C, G, F, B, b_vec, ctx):
         """LinearProof::verify(&self, transcript, C, G, F, B, b_vec) (linear_proof.rs:175-236): Ok(()) -> None, Err(e) -> raises e.
         C, F, B and the entries of G are 32-byte compressed points, b_vec 32-byte canonical scalars; ctx: the Context (or a

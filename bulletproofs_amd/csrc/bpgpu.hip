@@ -6,6 +6,7 @@
 
 #include <sys/random.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -2142,6 +2143,131 @@ extern "C" int bpgpu_ipp_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, con
     if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
     memcpy(proofs_out, h_out, nbatch * proof_len);
     memcpy(status_out, h_out + align_up(nbatch * proof_len), nbatch);
+    return BPGPU_OK;
+}
+
+// ============================================================================
+// batched linear-proof creation (linear_prover.h)
+// ============================================================================
+extern "C" int bpgpu_linear_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, const uint8_t *label, size_t label_len, const uint8_t *shared_transcript,
+                                         const uint8_t *rng, const uint8_t *C, const uint8_t *r, const uint8_t *a, const uint8_t *b, int b_shared,
+                                         const uint8_t *G, const uint8_t *F, const uint8_t *B, uint8_t *proofs_out, uint8_t *status_out,
+                                         uint8_t *transcripts_out) {
+    if (!c || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0) return BPGPU_OK;
+    if (!C || !r || !a || !b || !G || !F || !B || !proofs_out || !status_out) return BPGPU_ERR_INVALID_ARG;
+    if (n == 0 || (n & (n - 1))) return fail(c, BPGPU_ERR_INVALID_ARG, "InvalidInputLength: n must be a power of two (linear_proof.rs:68-70)");
+    size_t k = 0;
+    while (((size_t)1 << k) < n) k++;
+    if (k > BP_RP_MAX_K) return fail(c, BPGPU_ERR_INVALID_ARG, "n > 2^%d not supported", BP_RP_MAX_K);
+    if ((uint64_t)nbatch * (n + 4) > 0x7fffffffull / 64) return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large for this shape");
+    if (shared_transcript && !ts_state_ok(shared_transcript)) return fail(c, BPGPU_ERR_INVALID_ARG, "malformed transcript state");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    const size_t proof_len = 32 * (2 * k + 3), TS = BPGPU_TRANSCRIPT_BYTES, nd = 2 * k + 2, nb_b = b_shared ? 1 : nbatch;
+    // ---- inputs: one pinned staging block -> the persistent device IO buffer
+    const size_t sz_v = align_up(nbatch * n * 32 + 64), sz_bv = align_up(nb_b * n * 32 + 64), sz_q = align_up(nbatch * 32 + 64), sz_g = align_up(n * 32 + 64),
+                 sz_fb = align_up(64 + 64), sz_rng = align_up(nbatch * nd * 64), sz_ts = align_up(nbatch * TS);
+    const size_t sz_in = sz_v + sz_bv + 2 * sz_q + sz_g + sz_fb + sz_rng + sz_ts, sz_pr = align_up(nbatch * proof_len), sz_stb = align_up(nbatch);
+    const size_t sz_out = sz_pr + sz_stb;
+    rc = io_reserve(c, sz_in + sz_out);
+    if (rc) return rc;
+    char *h = nullptr;
+    rc = pin_alloc(c, s, sz_in + sz_out, &h);
+    if (rc) return rc;
+    char *d_a = c->io_dev, *d_b = d_a + sz_v, *d_C = d_b + sz_bv, *d_r = d_C + sz_q, *d_G = d_r + sz_q, *d_fb = d_G + sz_g, *d_rng = d_fb + sz_fb,
+         *d_ts = d_rng + sz_rng, *d_proofs = c->io_dev + sz_in, *d_stb = d_proofs + sz_pr;
+    memcpy(h, a, nbatch * n * 32);
+    memcpy(h + sz_v, b, nb_b * n * 32);
+    memcpy(h + sz_v + sz_bv, C, nbatch * 32);
+    memcpy(h + sz_v + sz_bv + sz_q, r, nbatch * 32);
+    memcpy(h + sz_v + sz_bv + 2 * sz_q, G, n * 32);
+    memcpy(h + sz_v + sz_bv + 2 * sz_q + sz_g, F, 32);
+    memcpy(h + sz_v + sz_bv + 2 * sz_q + sz_g + 32, B, 32);
+    {
+        char *h_rng = h + sz_v + sz_bv + 2 * sz_q + sz_g + sz_fb;
+        if (rng) memcpy(h_rng, rng, nbatch * nd * 64);
+        else if ((rc = os_random(c, h_rng, nbatch * nd * 64)) != 0) return rc;   // Scalar::random(&mut thread_rng())
+        // every proof's transcript after innerproduct_domain_sep(n) (linear_proof.rs:73)
+        uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
+        if (shared_transcript) memcpy(st0, shared_transcript, TS);
+        else bpgpu_transcript_new(label, label_len, st0);
+        uint32_t w[50];
+        strobe t;
+        ts_to_strobe(t, w, st0);
+        const uint8_t ipp[6] = {'i', 'p', 'p', ' ', 'v', '1'}, ln[1] = {'n'};
+        merlin_append_message(t, DOM_SEP, 7, ipp, 6);
+        merlin_append_u64(t, ln, 1, n);
+        ts_from_strobe(st0, t);
+        for (size_t p = 0; p < nbatch; p++) memcpy(h_rng + sz_rng + p * TS, st0, TS);
+    }
+    HIPCHK(c, hipMemcpyAsync(c->io_dev, h, sz_in, hipMemcpyHostToDevice, s));
+    HIPCHK(c, hipMemsetAsync(d_proofs, 0, nbatch * proof_len, s));
+    do {
+        // ---- working set (own allocation: the batched MSMs claim the arena)
+        const size_t N = n / 2 + 2, NS = n + 2;
+        const size_t w_v = align_up(nbatch * n * 32), w_u = align_up(nbatch * 32), w_d = align_up(nbatch * nd * 32),
+                     w_terms = align_up(std::max(2 * nbatch * N, nbatch * NS) * 32 + 64), w_out = align_up(2 * nbatch * 32), w_st = align_up(2 * nbatch + 64),
+                     w_status = align_up(nbatch * 4);
+        const size_t need = 3 * w_v + 3 * w_u + w_d + 2 * w_terms + w_out + w_st + w_status;
+        if (c->ipp_cap < need) {
+            if (hipDeviceSynchronize() != hipSuccess) { rc = fail(c, BPGPU_ERR_HIP, "synchronize failed"); break; }
+            if (c->ipp_buf) hipFree(c->ipp_buf);
+            c->ipp_buf = nullptr;
+            c->ipp_cap = 0;
+            if (hipMalloc((void **)&c->ipp_buf, need + need / 4) != hipSuccess) { rc = fail(c, BPGPU_ERR_HIP, "out of device memory (linear prover working set)"); break; }
+            c->ipp_cap = need + need / 4;
+        }
+        char *wb = c->ipp_buf;
+        uint32_t *w_a = (uint32_t *)wb, *w_b = (uint32_t *)(wb + w_v), *w_G = (uint32_t *)(wb + 2 * w_v);
+        uint32_t *w_r = (uint32_t *)(wb + 3 * w_v), *w_x = (uint32_t *)((char *)w_r + w_u), *w_xi = (uint32_t *)((char *)w_x + w_u);
+        uint32_t *w_dr = (uint32_t *)((char *)w_xi + w_u);
+        uint32_t *m_sc = (uint32_t *)((char *)w_dr + w_d), *m_pt = (uint32_t *)((char *)m_sc + w_terms), *m_out = (uint32_t *)((char *)m_pt + w_terms);
+        uint8_t *m_st = (uint8_t *)m_out + w_out;
+        uint32_t *d_status = (uint32_t *)(m_st + w_st);
+        if (hipMemsetAsync(d_status, 0, nbatch * 4, s) != hipSuccess) { rc = fail(c, BPGPU_ERR_HIP, "memset failed"); break; }
+        linc_shape sh;
+        sh.n = (uint32_t)n;
+        sh.k = (uint32_t)k;
+        sh.nproofs = (uint32_t)nbatch;
+        sh.b_shared = b_shared ? 1u : 0u;
+        const uint32_t nb32 = (uint32_t)nbatch, nt32 = (uint32_t)(nbatch * n), n_q = (nb32 + BP_BLOCK - 1) / BP_BLOCK;
+        LAUNCH(c, s, "linc_init", k_linc_init, (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt32, sh, (const uint8_t *)d_a, (const uint8_t *)d_b, w_a, w_b, w_G,
+               d_status);
+        LAUNCH(c, s, "linc_public", k_linc_public, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, (const uint8_t *)d_C, (const uint8_t *)d_b, (const uint8_t *)d_G,
+               (const uint8_t *)d_fb, (const uint8_t *)d_fb + 32, (const uint8_t *)d_r, (const uint8_t *)d_rng, (uint32_t *)d_ts, w_r, w_dr, d_status);
+        std::vector<uint32_t> nterms(2 * nbatch, (uint32_t)N);
+        for (uint32_t j = 0; j < k && !rc; j++) {
+            LAUNCH(c, s, "linc_terms", k_linc_terms, n_q + (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_q, nt32, sh, j, (const uint32_t *)w_a, (const uint32_t *)w_b,
+                   (const uint32_t *)w_G, (const uint32_t *)w_dr, (const uint8_t *)d_G, (const uint8_t *)d_fb, (const uint8_t *)d_fb + 32, m_sc, m_pt);
+            rc = msm_batch_dev_locked(c, 2 * nbatch, nterms.data(), m_sc, m_pt, m_out, m_st, s);   // all L_j and R_j of the batch (:104-117)
+            if (rc) break;
+            LAUNCH(c, s, "linc_challenge", k_linc_challenge, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, j, (const uint32_t *)m_out, (const uint8_t *)m_st,
+                   (uint32_t *)d_ts, (const uint32_t *)w_dr, w_r, w_x, w_xi, (uint8_t *)d_proofs, (uint32_t)proof_len, d_status);
+            LAUNCH(c, s, "linc_fold", k_linc_fold, (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt32, sh, j, (const uint32_t *)w_x, (const uint32_t *)w_xi, w_a, w_b, w_G);
+        }
+        if (rc) break;
+        LAUNCH(c, s, "linc_sterms", k_linc_sterms, n_q + (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_q, nt32, sh, (const uint32_t *)w_b, (const uint32_t *)w_G,
+               (const uint32_t *)w_dr, (const uint8_t *)d_G, (const uint8_t *)d_fb, (const uint8_t *)d_fb + 32, m_sc, m_pt);
+        std::vector<uint32_t> nts(nbatch, (uint32_t)NS);
+        rc = msm_batch_dev_locked(c, nbatch, nts.data(), m_sc, m_pt, m_out, m_st, s);               // every S (:155-157)
+        if (rc) break;
+        LAUNCH(c, s, "linc_final", k_linc_final, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, (const uint32_t *)m_out, (const uint8_t *)m_st, (uint32_t *)d_ts,
+               (const uint32_t *)w_a, (const uint32_t *)w_dr, (const uint32_t *)w_r, (uint8_t *)d_proofs, (uint32_t)proof_len, d_status, (uint8_t *)d_stb);
+        if (hipGetLastError() != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "launch failed");
+    } while (0);
+    char *h_out = h + sz_in;
+    if (!rc && hipMemcpyAsync(h_out, d_proofs, sz_out, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+    char *h_ts = h + (d_ts - c->io_dev);   // the transcript block of the staging buffer is free again: reuse it for the way back
+    if (!rc && transcripts_out && hipMemcpyAsync(h_ts, d_ts, nbatch * TS, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+    const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);   // (on an error the stream is drained before the staging buffers are reused)
+    if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
+    memcpy(proofs_out, h_out, nbatch * proof_len);
+    memcpy(status_out, h_out + sz_pr, nbatch);
+    if (transcripts_out) memcpy(transcripts_out, h_ts, nbatch * TS);
     return BPGPU_OK;
 }
 

@@ -14,6 +14,7 @@
 #include "bucket.h"
 #include "ipp_prover.h"
 #include "rp_prover.h"
+#include "linear_prover.h"
 
 #define BP_BLOCK 64   // one wavefront per workgroup: under contention a CU rarely has room for four waves of one group at once (256: -8% at 48 streams)
 #define FB_BLOCK 64
@@ -78,5 +79,14 @@ __global__ void k_bk_accum(uint32_t nthreads, bk_params prm, uint32_t total, con
 __global__ void k_bk_leaf(uint32_t nthreads, bk_params prm, const ge_ext *bsum, ge_ext *gS, ge_ext *gA);
 template <int C>
 __global__ void k_bk_tree(bk_params prm, uint32_t nbw, const ge_ext *gS, const ge_ext *gA, uint32_t *colq16);
+
+// k_linc.hip
+__global__ void k_linc_init(uint32_t nthreads, linc_shape sh, const uint8_t *a_in, const uint8_t *b_in, uint32_t *a, uint32_t *b, uint32_t *wG, uint32_t *status);
+__global__ void k_linc_public(linc_shape sh, const uint8_t *C, const uint8_t *b_in, const uint8_t *G, const uint8_t *F, const uint8_t *B, const uint8_t *r_in, const uint8_t *rng, uint32_t *ts, uint32_t *r_out, uint32_t *draws, uint32_t *status);
+__global__ void k_linc_terms(uint32_t n_q, uint32_t nthreads, linc_shape sh, uint32_t j, const uint32_t *a, const uint32_t *b, const uint32_t *wG, const uint32_t *draws, const uint8_t *G, const uint8_t *F, const uint8_t *B, uint32_t *msm_sc, uint32_t *msm_pt);
+__global__ void k_linc_challenge(linc_shape sh, uint32_t j, const uint32_t *msm_out, const uint8_t *msm_status, uint32_t *ts, const uint32_t *draws, uint32_t *r_io, uint32_t *x, uint32_t *xinv, uint8_t *proofs, uint32_t proof_len, uint32_t *status);
+__global__ void k_linc_fold(uint32_t nthreads, linc_shape sh, uint32_t j, const uint32_t *x, const uint32_t *xinv, uint32_t *a, uint32_t *b, uint32_t *wG);
+__global__ void k_linc_sterms(uint32_t n_q, uint32_t nthreads, linc_shape sh, const uint32_t *b, const uint32_t *wG, const uint32_t *draws, const uint8_t *G, const uint8_t *F, const uint8_t *B, uint32_t *msm_sc, uint32_t *msm_pt);
+__global__ void k_linc_final(linc_shape sh, const uint32_t *msm_out, const uint8_t *msm_status, uint32_t *ts, const uint32_t *a, const uint32_t *draws, const uint32_t *r, uint8_t *proofs, uint32_t proof_len, uint32_t *status, uint8_t *status_out);
 
 #endif

@@ -281,6 +281,27 @@ int bpgpu_linear_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t nbatch, const
                                   const void *d_b, int b_shared, void *d_verdict, void *d_msm_out, void *d_transcripts_out,
                                   void *stream);
 
+/* nbatch independent calls of
+ *   LinearProof::create(&mut transcript, &mut rng, &C, r, a_vec, b_vec, G_vec, &F, &B).to_bytes()
+ * (src/linear_proof.rs:40-173), all of one size n (a power of two) over the same G, F, B.  Per round the reference forms
+ * L_j, R_j with two (n'+2)-term multiscalar multiplications (:104-117) and folds the generators with n' two-term ones
+ * (:140-144); here all proofs advance round by round together and every L_j / R_j / S is one multiscalar
+ * multiplication over the ORIGINAL points (csrc/linear_prover.h): the same group elements, so the proofs are
+ * byte-identical to the reference algorithm's given the same transcript, inputs and randomness.  Variable time, like
+ * the reference's own create() (vartime_multiscalar_mul).
+ *   rng     : nbatch x 64*(2 lg n + 2) bytes: what the rng would yield to Scalar::random, 64 bytes per draw, in the
+ *             reference's draw order (s_j, t_j per round, then s_star, t_star); NULL = the OS CSPRNG
+ *   C, r    : nbatch x 32 bytes: the commitment (absorbed into the transcript as given) and its blinding factor
+ *   a       : nbatch x n x 32 canonical scalars (secret); b : nbatch x n x 32, or n x 32 when b_shared != 0 (public)
+ *   G       : n x 32 bytes; F, B : 32 bytes (compressed points, shared by the batch)
+ *   proofs_out : nbatch x 32*(2 lg n + 3) bytes; status_out : nbatch bytes (BPGPU_MSM_OK, or why no proof was made:
+ *             an undecodable point or a non-canonical scalar); transcripts_out : optional nbatch x 208 bytes, each
+ *             proof's transcript as create() leaves it */
+int bpgpu_linear_create_batch(bpgpu_ctx *ctx, size_t n, size_t nbatch, const uint8_t *label, size_t label_len,
+                              const uint8_t *shared_transcript, const uint8_t *rng, const uint8_t *C, const uint8_t *r,
+                              const uint8_t *a, const uint8_t *b, int b_shared, const uint8_t *G, const uint8_t *F,
+                              const uint8_t *B, uint8_t *proofs_out, uint8_t *status_out, uint8_t *transcripts_out);
+
 /* ---- batched inner-product-proof creation (prover side) --------------------------------
  * nbatch independent calls of
  *   InnerProductProof::create(&mut transcript, &Q, G_factors, H_factors, G_vec, H_vec, a_vec, b_vec).to_bytes()

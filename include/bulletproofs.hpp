@@ -10,7 +10,8 @@
 //   RangeProof ............ src/range_proof/mod.rs:59-76, from_bytes 504-538, to_bytes 487-500,
 //                           verify_single[_with_rng] 316-342, verify_multiple[_with_rng] 345-470,
 //                           prove_single/multiple_with_rng 115-288 (variable time on the GPU)
-//   LinearProof ........... src/linear_proof.rs: from_bytes 350-394, to_bytes 322-331, verify 175-236
+//   LinearProof ........... src/linear_proof.rs: create 40-173 (variable time on the GPU), from_bytes 350-394,
+//                           to_bytes 322-331, verify 175-236
 // plus verify_batch, the batched entry point this engine exists for.  No arithmetic happens on the
 // host: parsing checks lengths and scalar canonicity (so from_bytes fails where the reference's does)
 // and everything else is one call into the GPU library.  There is no CPU fallback.
@@ -309,6 +310,28 @@ class LinearProof {
     static std::variant<LinearProof, ProofError> from_bytes(const std::vector<uint8_t> &v) { return from_bytes(v.data(), v.size()); }
     const std::vector<uint8_t> &to_bytes() const { return bytes_; }
     size_t serialized_size() const { return bytes_.size(); }
+
+    // LinearProof::create(transcript, rng, &C, r, a_vec, b_vec, G_vec, &F, &B) (:40-173) on the GPU, variable time like the
+    // reference's.  rng_bytes: the 64 * (2 lg n + 2) bytes the rng would yield to Scalar::random (nullptr = OS CSPRNG).
+    static std::variant<LinearProof, ProofError> create(bpgpu_ctx *ctx, Transcript &transcript, const uint8_t *rng_bytes, const CompressedRistretto &C,
+                                                        const ScalarBytes &r, const std::vector<ScalarBytes> &a_vec, const std::vector<ScalarBytes> &b_vec,
+                                                        const std::vector<CompressedRistretto> &G_vec, const CompressedRistretto &F,
+                                                        const CompressedRistretto &B) {
+        const size_t n = b_vec.size();
+        if (G_vec.size() != n) return ProofError::InvalidGeneratorsLength;                                        // :61-63
+        if (a_vec.size() != n || n == 0 || (n & (n - 1))) throw std::invalid_argument("InvalidInputLength");       // :64-70
+        size_t lg = 0;
+        while ((size_t(1) << lg) < n) lg++;
+        LinearProof p;
+        p.bytes_.resize(32 * (2 * lg + 3));
+        uint8_t status = 0;
+        std::array<uint8_t, BPGPU_TRANSCRIPT_BYTES> in = transcript.state();
+        const int rc = bpgpu_linear_create_batch(ctx, n, 1, nullptr, 0, in.data(), rng_bytes, C.data(), r.data(), a_vec[0].data(), b_vec[0].data(), 0,
+                                                 G_vec[0].data(), F.data(), B.data(), p.bytes_.data(), &status, transcript.state_mut().data());
+        if (rc != BPGPU_OK) throw GpuError(bpgpu_last_error(ctx));
+        if (status != 0) throw std::invalid_argument("an input point does not decode or a scalar is not canonical");
+        return p;
+    }
 
     // LinearProof::verify(&self, transcript, C, G, F, B, b_vec); the transcript is left advanced
     Status verify(bpgpu_ctx *ctx, Transcript &transcript, const CompressedRistretto &C, const std::vector<CompressedRistretto> &G,

@@ -16,6 +16,7 @@
 #include "../../bulletproofs_amd/csrc/bucket.h"
 #include "../../bulletproofs_amd/csrc/ipp_prover.h"
 #include "../../bulletproofs_amd/csrc/rp_prover.h"
+#include "../../bulletproofs_amd/csrc/linear_prover.h"
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
@@ -601,6 +602,63 @@ int h_ipp_create(uint32_t n, uint32_t nbatch, const uint8_t *ts0, const uint8_t 
         for (uint32_t tid = 0; tid < nbatch * n; tid++) ippc_fold_thread(tid, sh, j, u.data(), ui.data(), a.data(), b.data(), wG.data(), wH.data());
     }
     for (uint32_t p = 0; p < nbatch; p++) { ippc_final_thread(p, sh, a.data(), b.data(), proofs, proof_len); status_out[p] = (uint8_t)status[p]; }
+    return 0;
+}
+
+// The batched LinearProof prover (linear_prover.h), lane by lane; MSMs through the variable-base pipeline emulation.
+// ts0: 208-byte transcript state before innerproduct_domain_sep; rng: nbatch x 64 (2k + 2) bytes.
+int h_lin_create(uint32_t n, uint32_t nbatch, const uint8_t *ts0, const uint8_t *rng, const uint8_t *Cc, const uint8_t *r_in, const uint8_t *a_in,
+                 const uint8_t *b_in, int b_shared, const uint8_t *G, const uint8_t *F, const uint8_t *B, uint8_t *proofs, uint8_t *status_out,
+                 uint8_t *ts_out) {
+    uint32_t k = 0; while ((1u << k) < n) k++;
+    linc_shape sh; sh.n = n; sh.k = k; sh.nproofs = nbatch; sh.b_shared = b_shared ? 1 : 0;
+    const uint32_t proof_len = 32 * (2 * k + 3), N = n / 2 + 2, NS = n + 2, nd = 2 * k + 2;
+    std::vector<uint32_t> a((size_t)nbatch * n * 8), b(a.size()), wG(a.size()), status(nbatch + 1, 0), x((size_t)nbatch * 8), xi(x.size()), r(x.size()),
+        draws((size_t)nbatch * nd * 8), ts((size_t)nbatch * BP_TS_WORDS);
+    {
+        uint32_t w[50]; memcpy(w, ts0, 200);
+        strobe t; t.st.w = w; t.st.stride = 1; t.pos = ts0[200]; t.pos_begin = ts0[201]; t.cur_flags = ts0[202];
+        const uint8_t dom[7] = {'d','o','m','-','s','e','p'}, ipp[6] = {'i','p','p',' ','v','1'}, ln[1] = {'n'};
+        merlin_append_message(t, dom, 7, ipp, 6); merlin_append_u64(t, ln, 1, n);
+        for (uint32_t p = 0; p < nbatch; p++) {
+            memcpy(&ts[(size_t)p * BP_TS_WORDS], w, 200);
+            ts[(size_t)p * BP_TS_WORDS + 50] = rp_ts_meta(t.pos, t.pos_begin, t.cur_flags);
+            ts[(size_t)p * BP_TS_WORDS + 51] = 0;
+        }
+    }
+    for (uint32_t tid = 0; tid < nbatch * n; tid++) linc_init_thread(tid, sh, a_in, b_in, a.data(), b.data(), wG.data(), status.data());
+    for (uint32_t p = 0; p < nbatch; p++) {
+        uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;
+        linc_public_thread(p, sh, st, Cc, b_in, G, F, B, r_in, rng, ts.data(), r.data(), draws.data(), status.data());
+    }
+    const size_t terms = std::max<size_t>((size_t)2 * nbatch * N, (size_t)nbatch * NS);
+    std::vector<uint32_t> msc(terms * 8 + 8), mpt(msc.size()), mout((size_t)2 * nbatch * 8 + 8), nt(2 * nbatch, N), nts(nbatch, NS);
+    std::vector<uint8_t> mst(2 * nbatch + 1);
+    memset(proofs, 0, (size_t)nbatch * proof_len);
+    for (uint32_t j = 0; j < k; j++) {
+        for (uint32_t p = 0; p < nbatch; p++) linc_q_thread(p, sh, j, a.data(), b.data(), draws.data(), F, B, msc.data(), mpt.data());
+        for (uint32_t tid = 0; tid < nbatch * n; tid++) linc_terms_thread(tid, sh, j, a.data(), wG.data(), G, msc.data(), mpt.data());
+        h_msm_vb(2 * nbatch, nt.data(), (const uint8_t *)msc.data(), (const uint8_t *)mpt.data(), (uint8_t *)mout.data(), mst.data());
+        for (uint32_t p = 0; p < nbatch; p++) {
+            uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;
+            linc_challenge_thread(p, sh, j, st, mout.data(), mst.data(), ts.data(), draws.data(), r.data(), x.data(), xi.data(), proofs, proof_len, status.data());
+        }
+        for (uint32_t tid = 0; tid < nbatch * n; tid++) linc_fold_thread(tid, sh, j, x.data(), xi.data(), a.data(), b.data(), wG.data());
+    }
+    for (uint32_t p = 0; p < nbatch; p++) linc_sq_thread(p, sh, b.data(), draws.data(), F, B, msc.data(), mpt.data());
+    for (uint32_t tid = 0; tid < nbatch * n; tid++) linc_sterms_thread(tid, sh, wG.data(), draws.data(), G, msc.data(), mpt.data());
+    h_msm_vb(nbatch, nts.data(), (const uint8_t *)msc.data(), (const uint8_t *)mpt.data(), (uint8_t *)mout.data(), mst.data());
+    for (uint32_t p = 0; p < nbatch; p++) {
+        uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;
+        linc_final_thread(p, sh, st, mout.data(), mst.data(), ts.data(), a.data(), draws.data(), r.data(), proofs, proof_len, status.data());
+        status_out[p] = (uint8_t)status[p];
+        if (ts_out) {
+            memset(ts_out + (size_t)p * 208, 0, 208);
+            memcpy(ts_out + (size_t)p * 208, &ts[(size_t)p * BP_TS_WORDS], 200);
+            const uint32_t meta = ts[(size_t)p * BP_TS_WORDS + 50];
+            ts_out[(size_t)p * 208 + 200] = meta & 0xff; ts_out[(size_t)p * 208 + 201] = (meta >> 8) & 0xff; ts_out[(size_t)p * 208 + 202] = (meta >> 16) & 0xff;
+        }
+    }
     return 0;
 }
 

@@ -455,6 +455,32 @@ def test_linear_proof_front_end_lane_by_lane(H, oracle, n):
     assert vd2.raw[0] == 1 == oracle.linear_verify(2 * n, g0["proof"], st, g0["C"], g0["G"] * 2, g0["F"], g0["B"], g0["b"] * 2)[0]
 
 
+@pytest.mark.parametrize("n", [1, 2, 8, 32])
+def test_linear_prover_lane_by_lane(H, oracle, n):
+    """the batched LinearProof prover (linear_prover.h: generators never folded, L_j / R_j / S over the original points)
+    produces byte-identical proofs to the oracle's restatement of LinearProof::create (linear_proof.rs:40-173), leaves the
+    transcript where the reference leaves it, and its proofs verify"""
+    nb = 3
+    insts = [oracle.linear_test_instance(n, b"hlinc-%d-%d" % (n, j)) for j in range(nb)]
+    g0 = insts[0]
+    st_app = oracle.transcript_append_message(oracle.transcript_new(b"prover app"), b"ctx", b"42")
+    cat = lambda key: b"".join(i[key] for i in insts)
+    pl = 32 * (2 * (n.bit_length() - 1) + 3)
+    proofs, stb, tso = C.create_string_buffer(pl * nb), C.create_string_buffer(nb), C.create_string_buffer(208 * nb)
+    assert H.h_lin_create(n, nb, st_app, cat("rng"), cat("C"), cat("r"), cat("a"), cat("b"), 0, g0["G"], g0["F"], g0["B"], proofs, stb, tso) == 0
+    assert list(stb.raw) == [0] * nb
+    for j, inst in enumerate(insts):
+        rc, want = oracle.linear_create(n, st_app, inst["rng"], inst["C"], inst["r"], inst["a"], inst["b"], inst["G"], inst["F"], inst["B"])
+        assert rc == 0 and proofs.raw[pl * j:pl * (j + 1)] == want, (n, j)
+        assert oracle.linear_verify(n, want, st_app, inst["C"], inst["G"], inst["F"], inst["B"], inst["b"])[0] == 0
+    # shared public vector; a non-canonical secret scalar is reported, not proved
+    a_bad = bytearray(g0["a"] * 2)
+    a_bad[32 * n:32 * n + 32] = b"\xff" * 32
+    assert H.h_lin_create(n, 2, st_app, g0["rng"] * 2, g0["C"] * 2, g0["r"] * 2, bytes(a_bad), g0["b"], 1, g0["G"], g0["F"], g0["B"], proofs, stb, None) == 0
+    assert stb.raw[0] == 0 and stb.raw[1] != 0 and proofs.raw[:pl] == oracle.linear_create(n, st_app, g0["rng"], g0["C"], g0["r"], g0["a"], g0["b"],
+                                                                                          g0["G"], g0["F"], g0["B"])[1]
+
+
 @pytest.mark.parametrize("n", [1, 2, 4, 32])
 def test_standalone_ipp_front_end_lane_by_lane(H, oracle, n):
     """ipp_prepare (transcript, batch inversion, s_i products) + the variable-base pipeline against the oracle's

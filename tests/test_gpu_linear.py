@@ -84,3 +84,54 @@ def test_linear_verify_n256_uses_the_bucket_msm(ctx, oracle):
         rc, em = oracle.linear_verify(n, inst["proof"], st, inst["C"], inst["G"], inst["F"], inst["B"], inst["b"])
         assert verdict[j] == rc and msm[32 * j:32 * j + 32] == em, j
     assert list(verdict) == [0, 0, 0, 0, 0, 1, 0, 0]
+
+
+@pytest.mark.parametrize("n", [1, 2, 16, 64])
+def test_linear_create_batch_byte_identical(ctx, oracle, n):
+    """bpgpu_linear_create_batch == the oracle's LinearProof::create (linear_proof.rs:40-173) byte for byte, on a transcript that
+    already holds an application message; the GPU verifier accepts what the GPU prover made and both leave the transcript in
+    the same state."""
+    nb = 5
+    insts = [oracle.linear_test_instance(n, b"glinc-%d-%d" % (n, j)) for j in range(nb)]
+    g0 = insts[0]
+    st_app = oracle.transcript_append_message(oracle.transcript_new(b"prover app"), b"ctx", b"42")
+    cat = lambda key: b"".join(i[key] for i in insts)
+    proofs, status, ts_p = ctx.linear_create_batch(n, cat("C"), cat("r"), cat("a"), cat("b"), g0["G"], g0["F"], g0["B"], transcript=st_app,
+                                                   rng=cat("rng"), want_transcripts=True)
+    pl = len(proofs) // nb
+    assert list(status) == [0] * nb and pl == 32 * (2 * (n.bit_length() - 1) + 3)
+    for j, inst in enumerate(insts):
+        rc, want = oracle.linear_create(n, st_app, inst["rng"], inst["C"], inst["r"], inst["a"], inst["b"], inst["G"], inst["F"], inst["B"])
+        assert rc == 0 and proofs[pl * j:pl * (j + 1)] == want, (n, j)
+    verdict, ts_v = ctx.linear_verify_batch(n, proofs, pl, cat("C"), g0["G"], g0["F"], g0["B"], cat("b"), transcript=st_app, want_transcripts=True)
+    assert list(verdict) == [0] * nb and ts_v == ts_p
+
+
+def test_linear_create_batch_of_many_with_os_randomness(ctx, oracle):
+    """300 proofs for one public vector, randomness from the OS CSPRNG: every proof verifies (GPU and, spot-checked, oracle),
+    no two proofs share their first L; a non-canonical secret scalar is reported in status instead of proved"""
+    n, nb = 16, 300
+    base = oracle.linear_test_instance(n, b"glinc-many")
+    ell = 2 ** 252 + 27742317777372353535851937790883648493
+    As, rs, Cs = [], [], []
+    for j in range(nb):
+        stream = hashlib.shake_256(b"cmany%d" % j).digest(64 * (n + 1))
+        red = lambda i: (int.from_bytes(stream[64 * i:64 * i + 64], "little") % ell).to_bytes(32, "little")
+        a = b"".join(red(i) for i in range(n))
+        r = red(n)
+        c = sum(int.from_bytes(a[32 * i:32 * i + 32], "little") * int.from_bytes(base["b"][32 * i:32 * i + 32], "little") for i in range(n)) % ell
+        rcm, Cc = oracle.msm(a + r + c.to_bytes(32, "little"), base["G"] + base["B"] + base["F"])
+        assert rcm == 0
+        As.append(a)
+        rs.append(r)
+        Cs.append(Cc)
+    As[7] = b"\xff" * 32 + As[7][32:]
+    proofs, status = ctx.linear_create_batch(n, b"".join(Cs), b"".join(rs), b"".join(As), base["b"], base["G"], base["F"], base["B"], label=b"many")
+    pl = len(proofs) // nb
+    assert [j for j in range(nb) if status[j] != 0] == [7]
+    verdict = ctx.linear_verify_batch(n, proofs, pl, b"".join(Cs), base["G"], base["F"], base["B"], base["b"], label=b"many")
+    assert [j for j in range(nb) if verdict[j] != 0] == [7]
+    assert len({proofs[pl * j:pl * j + 32] for j in range(nb) if j != 7}) == nb - 1
+    st = oracle.transcript_new(b"many")
+    for j in (0, 150, 299):
+        assert oracle.linear_verify(n, proofs[pl * j:pl * (j + 1)], st, Cs[j], base["G"], base["F"], base["B"], base["b"])[0] == 0

@@ -102,6 +102,15 @@ def test_linear_proof_test_helper(oracle, n):
     assert t.state == _linear_replay(oracle, inst)
     again = LinearProof.from_bytes(proof.to_bytes())
     assert again.verify(Transcript(b"linearprooftest"), inst["C"], G, inst["F"], inst["B"], b, ctx) is None
+    # create on the GPU (:424-436): byte-identical to the oracle's given the same rng bytes; prover and verifier transcripts agree
+    tp = Transcript(b"linearprooftest")
+    made = LinearProof.create(tp, inst["rng"], inst["C"], inst["r"], sp(inst["a"]), b, G, inst["F"], inst["B"], ctx)
+    assert made.to_bytes() == inst["proof"] and tp.state == t.state
+    fresh = LinearProof.create(Transcript(b"linearprooftest"), None, inst["C"], inst["r"], sp(inst["a"]), b, G, inst["F"], inst["B"], ctx)
+    assert fresh.to_bytes() != inst["proof"] and fresh.verify(Transcript(b"linearprooftest"), inst["C"], G, inst["F"], inst["B"], b, ctx) is None
+    if n > 2:
+        with pytest.raises(ValueError):                                           # InvalidInputLength (:64-70): 3 is not a power of two
+            LinearProof.create(Transcript(b"x"), None, inst["C"], inst["r"], sp(inst["a"])[:3], b[:3], G[:3], inst["F"], inst["B"], ctx)
     with pytest.raises(VerificationError):
         proof.verify(t, inst["C"], G, inst["F"], inst["B"], b, ctx)             # the advanced transcript is another statement
     with pytest.raises(VerificationError):
@@ -119,10 +128,9 @@ def test_linear_proof_test_helper(oracle, n):
 def test_cpp_mirror_linear_proof(oracle, tmp_path):
     cases = [oracle.linear_test_instance(n, b"cpp-lin-%d-%d" % (n, j)) for n, j in ((1, 0), (16, 0), (16, 1), (16, 2), (32, 0), (64, 0))]
     with open(tmp_path / "linear_vectors.inc", "w") as f:
-        f.write("struct linear_case { size_t n; const char *proof, *C, *G, *F, *B, *b; };\nstatic const linear_case LINEAR_CASES[] = {\n")
+        f.write("struct linear_case { size_t n; const char *proof, *C, *G, *F, *B, *b, *a, *r, *rng; };\nstatic const linear_case LINEAR_CASES[] = {\n")
         for c in cases:
-            f.write('  {%d, "%s", "%s", "%s", "%s", "%s", "%s"},\n' % (c["n"], c["proof"].hex(), c["C"].hex(), c["G"].hex(), c["F"].hex(), c["B"].hex(),
-                                                                      c["b"].hex()))
+            f.write('  {%d, %s},\n' % (c["n"], ", ".join('"%s"' % c[key].hex() for key in ("proof", "C", "G", "F", "B", "b", "a", "r", "rng"))))
         f.write("};\n")
     exe = tmp_path / "linear_proof_test"
     libdir = os.path.join(ROOT, "bulletproofs_amd", "csrc")
