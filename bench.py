@@ -538,6 +538,16 @@ def main():
                                 "fixed_window_bits": bx.ctxs[0].get_option("fixed_window_bits"),
                                 "roofline": roofline_block(cfg_x, 64, m_x, batch_x, rx["kern"], vx, wl, rx["events_every"], batch_x)}
                 bx.close()
+                if cfg_x == "cfg3" and a.steps >= 640:
+                    # the batch-combined check on the aggregated shape: one table MSM of 2050 terms per BATCH plus 40 points per proof.
+                    # Its launches are narrow (256 proofs = 4 wavefronts of transcript lanes), so the rate follows the batch size
+                    rl = {}
+                    for b_r, st_r, k_r in ((256, 64, 640), (4096, 16, 64)):
+                        br = RangeProofBench(a, "cfg3", b_r, st_r, rank, local_dev, rlc=True)
+                        rr = timed(br, k_r, st_r, fence, 0, no_events=True)
+                        rl["batch%d" % b_r] = round(b_r * k_r / rr["elapsed"], 1)
+                        br.close()
+                    extra[cfg_x]["rlc_verifications_per_s"] = rl
             except Exception as e:   # informational: never fails the headline line
                 extra[cfg_x] = {"error": str(e)}
         try:

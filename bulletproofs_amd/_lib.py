@@ -269,7 +269,8 @@ class Context:
         """LinearProof::verify for len(Cs) / 32 proofs (bpgpu_linear_verify_batch).  G: n points shared by the batch; b: per-proof
         vectors (nb * n scalars) or one shared vector (n scalars)."""
         nb = len(Cs) // 32
-        assert len(proofs) == nb * proof_len and len(G) == 32 * n and len(F) == len(B) == 32 and len(b) in (32 * n, 32 * n * nb)
+        assert len(proofs) == nb * proof_len and len(b) in (32 * n, 32 * n * nb)
+        assert (G is None and F is None and B is None) or (len(G) == 32 * n and len(F) == len(B) == 32)   # None: the context's generators
         shared = 1 if (len(b) == 32 * n and nb != 1) else 0
         verdict = C.create_string_buffer(max(nb, 1))
         msm = C.create_string_buffer(32 * max(nb, 1)) if want_msm else None

@@ -552,9 +552,10 @@ extern "C" int bpgpu_gens_export(bpgpu_ctx *c, uint8_t *G, uint8_t *H, uint8_t B
 }
 
 // id list of the generator terms of an (n, m) proof in the reference's order
-// (B_blinding, B, G(n,m), H(n,m)); ids index the loaded table
-static int gen_ids_for(bpgpu_ctx *c, size_t n, size_t m, uint32_t **out) {
-    auto key = std::make_pair(n, m);
+// (B_blinding, B, G(n,m), H(n,m)); ids index the loaded table.  g_only: (B_blinding, B, G(n,m)) -- the bases of a
+// LinearProof over bp_gens.share(j).G(n) (linear_proof.rs:405-411)
+static int gen_ids_for(bpgpu_ctx *c, size_t n, size_t m, uint32_t **out, bool g_only = false) {
+    auto key = std::make_pair(n, g_only ? m + ((size_t)1 << 40) : m);
     auto it = c->gen_ids_cache.find(key);
     if (it != c->gen_ids_cache.end()) {
         *out = it->second;
@@ -566,7 +567,7 @@ static int gen_ids_for(bpgpu_ctx *c, size_t n, size_t m, uint32_t **out) {
     ids.push_back(1);
     for (size_t j = 0; j < m; j++)
         for (size_t i = 0; i < n; i++) ids.push_back((uint32_t)(2 + j * c->gens_capacity + i));
-    for (size_t j = 0; j < m; j++)
+    for (size_t j = 0; j < m && !g_only; j++)
         for (size_t i = 0; i < n; i++) ids.push_back((uint32_t)(2 + tot + j * c->gens_capacity + i));
     uint32_t *d = nullptr;
     HIPCHK(c, hipMalloc((void **)&d, ids.size() * 4));
@@ -973,12 +974,12 @@ static void enqueue_fb_reduce(bpgpu_ctx *c, hipStream_t s, uint32_t nbatch, uint
 
 static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, size_t n_unique, const void *d_gen_scalars,
                                  const void *d_uniq_scalars, const void *d_uniq_points, void *d_out, void *d_status_bytes,
-                                 void *d_verdict, hipStream_t s) {
+                                 void *d_verdict, hipStream_t s, bool g_only = false) {
     if (nbatch == 0) return BPGPU_OK;
     if (!c->d_table) return fail(c, BPGPU_ERR_NO_GENS, "generators not loaded");
     if (n == 0 || m == 0 || n > c->gens_capacity || m > c->party_capacity)
         return fail(c, BPGPU_ERR_NO_GENS, "generators too small for n=%zu m=%zu", n, m);
-    const uint32_t n_gen_terms = (uint32_t)(2 * n * m + 2);
+    const uint32_t n_gen_terms = (uint32_t)((g_only ? 1 : 2) * n * m + 2);   // g_only: d_gen_scalars rows are (B_blinding, B, G(n, m))
     const fb_params prm = c->prm;
     const uint32_t npairs = n_gen_terms * prm.nwin;
     // thread / element counts are 32-bit in the kernels: refuse what does not fit (grids of <= 2^31 / 64 blocks)
@@ -986,7 +987,7 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
         (uint64_t)nbatch * n_unique > 0x7fffffffull / 64)
         return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large for this shape");
     uint32_t *d_ids = nullptr;
-    int rc = gen_ids_for(c, n, m, &d_ids);
+    int rc = gen_ids_for(c, n, m, &d_ids, g_only);
     if (rc) return rc;
     const uint32_t nsplit = pick_splits(c, nbatch, npairs);
     const bk_params bkp = bk_make(pick_bucket_c(n_unique));
@@ -1903,11 +1904,23 @@ static int lin_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t nbatch, const vo
     if (n == ((size_t)1 << k) && k > BP_RP_MAX_K) return fail(c, BPGPU_ERR_INVALID_ARG, "n > 2^%d not supported", BP_RP_MAX_K);
     sh.shape_verdict = (n == ((size_t)1 << k)) ? 0 : BPGPU_VERDICT_VERIFICATION_ERROR;   // linear_proof.rs:263-265
     if (sh.shape_verdict) sh.n = 0;   // only the canonical-scalar check runs
-    sh.N = (uint32_t)(sh.shape_verdict ? 4 : n + 2 * k + 4);
+    // generator-table mode: G, F, B not given = the context's bp_gens.share(0).G(n), pc_gens.B, pc_gens.B_blinding (what the
+    // reference's own callers pass, linear_proof.rs:405-411): their n + 2 coefficients go through the window tables
+    const bool fixed = d_G == nullptr && d_F == nullptr && d_B == nullptr;
+    if (fixed) {
+        if (!c->d_table) return fail(c, BPGPU_ERR_NO_GENS, "generators not loaded");
+        if (!sh.shape_verdict && n > c->gens_capacity) return fail(c, BPGPU_ERR_NO_GENS, "InvalidGeneratorsLength: generators too small for n=%zu", n);
+        d_G = c->d_gens + 2 * 8;
+        d_F = c->d_gens + 8;
+        d_B = c->d_gens;
+    }
+    sh.fixed = fixed ? 1u : 0u;
+    sh.N = (uint32_t)(fixed ? 2 * k + 2 : sh.shape_verdict ? 4 : n + 2 * k + 4);
     const size_t N = sh.N;
-    if ((uint64_t)nbatch * N > 0x7fffffffull / 64) return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large for this shape");
+    if ((uint64_t)nbatch * (n + 2 * k + 4) > 0x7fffffffull / 64) return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large for this shape");
     const size_t sz_terms = align_up(nbatch * N * 32 + 64), sz_st = align_up(nbatch * 4), sz_b = align_up(nbatch + 64), sz_o = align_up(nbatch * 32 + 64);
-    const size_t need = 2 * sz_terms + sz_st + sz_b + sz_o;
+    const size_t sz_gen = fixed ? align_up(nbatch * (sh.n + 2) * 32 + 64) : 0;
+    const size_t need = 2 * sz_terms + sz_st + sz_b + sz_o + sz_gen;
     if (c->ipp_cap < need) {
         HIPCHK(c, hipDeviceSynchronize());
         if (c->ipp_buf) HIPCHK(c, hipFree(c->ipp_buf));
@@ -1917,7 +1930,9 @@ static int lin_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t nbatch, const vo
         c->ipp_cap = need + need / 4;
     }
     char *d_sc = c->ipp_buf, *d_pt = d_sc + sz_terms, *d_stat = d_pt + sz_terms, *d_mst = d_stat + sz_st, *d_out = d_mst + sz_b;
+    char *d_gen = fixed ? d_out + sz_o : nullptr;
     HIPCHK(c, hipMemsetAsync(d_sc, 0, 2 * sz_terms + sz_st, s));   // scalars, points, status
+    if (fixed) HIPCHK(c, hipMemsetAsync(d_gen, 0, sz_gen, s));
     rp_strobe_init init;
     {   // Transcript::new(label) [or the caller's transcript] + innerproduct_domain_sep(n) (linear_proof.rs:196), once for the batch
         uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
@@ -1937,9 +1952,17 @@ static int lin_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t nbatch, const vo
     const uint32_t nb32 = (uint32_t)nbatch;
     LAUNCH(c, s, "lin_prepare", k_lin_prepare, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, init, (const uint8_t *)d_proofs, (const uint8_t *)d_C,
            (const uint8_t *)d_b, (const uint8_t *)d_G, (const uint8_t *)d_F, (const uint8_t *)d_B, (uint32_t *)d_sc, (uint32_t *)d_pt,
-           (uint32_t *)d_stat, (uint32_t *)d_ts_out);
-    std::vector<uint32_t> nt(nbatch, (uint32_t)N);
-    int rc = msm_batch_dev_locked(c, nbatch, nt.data(), d_sc, d_pt, d_out, d_mst, s);
+           (uint32_t *)d_stat, (uint32_t *)d_ts_out, (uint32_t *)d_gen);
+    int rc;
+    if (fixed && sh.shape_verdict) {      // nothing to multiply: every proof already carries its verdict
+        HIPCHK(c, hipMemsetAsync(d_mst, 0, sz_b + sz_o, s));
+        rc = BPGPU_OK;
+    } else if (fixed) {
+        rc = msm_shared_dev_locked(c, n, 1, nbatch, N, d_gen, d_sc, d_pt, d_out, d_mst, nullptr, s, true);
+    } else {
+        std::vector<uint32_t> nt(nbatch, (uint32_t)N);
+        rc = msm_batch_dev_locked(c, nbatch, nt.data(), d_sc, d_pt, d_out, d_mst, s);
+    }
     if (rc) return rc;
     LAUNCH(c, s, "lin_verdict", k_ipp_verdict, (nb32 + 63) / 64, 64, nb32, (const uint32_t *)d_stat, (const uint8_t *)d_mst, (const uint32_t *)d_out,
            (uint8_t *)d_verdict);
@@ -1954,7 +1977,8 @@ extern "C" int bpgpu_linear_verify_batch_dev(bpgpu_ctx *c, size_t n, size_t nbat
                                              void *d_transcripts_out, void *stream) {
     if (!c || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
     if (nbatch == 0) return BPGPU_OK;
-    if (!d_proofs || !d_verdict || !d_C || !d_F || !d_B || (n && (!d_G || !d_b))) return BPGPU_ERR_INVALID_ARG;
+    const bool from_gens = !d_G && !d_F && !d_B;
+    if (!d_proofs || !d_verdict || !d_C || (n && !d_b) || (!from_gens && (!d_F || !d_B || (n && !d_G)))) return BPGPU_ERR_INVALID_ARG;
     if (((uintptr_t)d_proofs | (uintptr_t)d_C | (uintptr_t)d_G | (uintptr_t)d_F | (uintptr_t)d_B | (uintptr_t)d_b | (uintptr_t)d_transcripts_out) & 3)
         return fail(c, BPGPU_ERR_INVALID_ARG, "device buffers must be 4-byte aligned");
     std::lock_guard<std::mutex> lk(c->mu);
@@ -1974,7 +1998,8 @@ extern "C" int bpgpu_linear_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
                                          uint8_t *transcripts_out) {
     if (!c || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
     if (nbatch == 0) return BPGPU_OK;
-    if (!proofs || !verdict || !C || !F || !B || (n && (!G || !b))) return BPGPU_ERR_INVALID_ARG;
+    const bool from_gens = !G && !F && !B;
+    if (!proofs || !verdict || !C || (n && !b) || (!from_gens && (!F || !B || (n && !G)))) return BPGPU_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     const size_t nb_b = b_shared ? 1 : nbatch;
@@ -1996,14 +2021,16 @@ extern "C" int bpgpu_linear_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
     memcpy(h, proofs, nbatch * proof_len);
     memcpy(h + sz_pr, C, nbatch * 32);
     if (n) {
-        memcpy(h + sz_pr + sz_c, G, n * 32);
+        if (!from_gens) memcpy(h + sz_pr + sz_c, G, n * 32);
         memcpy(h + sz_pr + sz_c + sz_g + sz_fb, b, nb_b * n * 32);
     }
-    memcpy(h + sz_pr + sz_c + sz_g, F, 32);
-    memcpy(h + sz_pr + sz_c + sz_g + 32, B, 32);
+    if (!from_gens) {
+        memcpy(h + sz_pr + sz_c + sz_g, F, 32);
+        memcpy(h + sz_pr + sz_c + sz_g + 32, B, 32);
+    }
     HIPCHK(c, hipMemcpyAsync(d, h, sz_in, hipMemcpyHostToDevice, s));
-    rc = lin_verify_dev_locked(c, n, nbatch, d_pr, proof_len, label, label_len, shared_transcript, d_c, d_g, d_fb, d_fb + 32, d_bv, b_shared, d_v, d_o,
-                               d_t, s);
+    rc = lin_verify_dev_locked(c, n, nbatch, d_pr, proof_len, label, label_len, shared_transcript, d_c, from_gens ? nullptr : d_g,
+                               from_gens ? nullptr : d_fb, from_gens ? nullptr : d_fb + 32, d_bv, b_shared, d_v, d_o, d_t, s);
     char *h_out = h + sz_in;
     if (!rc && hipMemcpyAsync(h_out, d_v, sz_v + sz_o + sz_t, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
     const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
@@ -2024,9 +2051,6 @@ struct ippc_fixed {
     const uint32_t *w;       // [nbatch][8 words]
     uint32_t *gen_scalars;   // scratch, >= 2 nbatch (2n + 2) scalars
 };
-static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, size_t n_unique, const void *d_gen_scalars,
-                                 const void *d_uniq_scalars, const void *d_uniq_points, void *d_out, void *d_status_bytes,
-                                 void *d_verdict, hipStream_t s);
 static int ippc_core(bpgpu_ctx *c, hipStream_t s, size_t n, size_t k, size_t nbatch, const void *d_a, const void *d_b, const void *d_gf, const void *d_hf,
                      const void *d_q, const void *d_G, const void *d_H, int bases_shared, uint32_t *d_ts, uint8_t *d_proofs, size_t proof_stride,
                      uint8_t *d_status_bytes, const ippc_fixed *fixed = nullptr) {

@@ -24,11 +24,12 @@ __global__ void __launch_bounds__(64) k_ipp_verdict(uint32_t n, const uint32_t *
 // LinearProof front end (linear.h): same launch shape as k_ipp_prepare -- lane = proof, sponge state in LDS word-major
 __global__ void __launch_bounds__(RP_BLOCK) k_lin_prepare(lin_shape sh, rp_strobe_init init, const uint8_t *proofs, const uint8_t *C,
                                                            const uint8_t *bvec, const uint8_t *G, const uint8_t *F, const uint8_t *B,
-                                                           uint32_t *scalars, uint32_t *points, uint32_t *status, uint32_t *ts_out) {
+                                                           uint32_t *scalars, uint32_t *points, uint32_t *status, uint32_t *ts_out,
+                                                           uint32_t *gen_sc) {
     __shared__ uint32_t lds[50 * RP_BLOCK];
     const uint32_t p = blockIdx.x * RP_BLOCK + threadIdx.x;
     kstate st;
     st.w = lds + threadIdx.x;
     st.stride = RP_BLOCK;
-    if (p < sh.nproofs) lin_prepare_thread(p, sh, init, st, proofs, C, bvec, G, F, B, scalars, points, status, ts_out);
+    if (p < sh.nproofs) lin_prepare_thread(p, sh, init, st, proofs, C, bvec, G, F, B, scalars, points, status, ts_out, gen_sc);
 }

@@ -16,20 +16,26 @@ namespace bp {
 
 struct lin_shape {
     uint32_t n, k;              // k = lg(n) as implied by the proof length
-    uint32_t N;                 // terms: n + 2k + 4
+    uint32_t N;                 // terms per proof in the (scalar, point) lists: n + 2k + 4, or 2k + 2 in generator-table mode
     uint32_t proof_len, nproofs;
     uint32_t shape_verdict;     // != 0: n != 2^k (VerificationError, linear_proof.rs:263-265): only parse
     uint32_t b_shared;          // != 0: b holds n scalars used by every proof
+    uint32_t fixed;             // != 0: G, F, B are the context's G(n) of party 0, B, B_blinding: their coefficients go to a row of
+                                // generator-table scalars (B_blinding, B, G_0..) and only C, L_j, R_j, S stay in the lists
 };
 
 // thread p.  Outputs are pre-zeroed by the host, so rejected proofs contribute identity terms.
-// Term order: B, F, C, L_0.., R_0.., G_0.., S.
+// Term order: B, F, C, L_0.., R_0.., G_0.., S; in generator-table mode (gen_sc != NULL) C, L_0.., R_0.., S in the lists and
+// (r, a b_0, a s_0, ..) in the proof's row of gen_sc.
 // ts_out (optional): the transcript as verify() leaves it (after the x_star challenge) for proofs that reach the final
 // check; the start state for proofs rejected before that.
 BP_HD void lin_prepare_thread(uint32_t p, lin_shape sh, const rp_strobe_init &init, kstate st, const uint8_t *proofs, const uint8_t *C,
                               const uint8_t *bvec, const uint8_t *G, const uint8_t *F, const uint8_t *B, uint32_t *scalars,
-                              uint32_t *points, uint32_t *status, uint32_t *ts_out = nullptr) {
+                              uint32_t *points, uint32_t *status, uint32_t *ts_out = nullptr, uint32_t *gen_sc = nullptr) {
     const uint32_t n = sh.n, k = sh.k;
+    const bool fx = gen_sc != nullptr;
+    const uint32_t iC = fx ? 0u : 2u, iL = iC + 1, iR = iL + k, iS = fx ? 2 * k + 1 : 3 + 2 * k + n, iG = 3 + 2 * k;
+    uint32_t *grow = fx ? gen_sc + (uint64_t)p * (n + 2) * 8 : nullptr;
     const uint8_t *pr = proofs + (uint64_t)p * sh.proof_len;
     const uint8_t *Sb = pr + 64 * k;
     sc a, r;
@@ -59,7 +65,7 @@ BP_HD void lin_prepare_thread(uint32_t p, lin_shape sh, const rp_strobe_init &in
     // public inputs (:196-206)
     load_words8(w, C + (uint64_t)p * 32);
     merlin_append_words8(t, lC, 1, w);
-    for (int q = 0; q < 8; q++) pt_out[2 * 8 + q] = w[q];
+    for (int q = 0; q < 8; q++) pt_out[iC * 8 + q] = w[q];
     bool fmt = false;
     for (uint32_t i = 0; i < n; i++) {
         load_words8(w, bp_ + (uint64_t)i * 32);
@@ -74,14 +80,17 @@ BP_HD void lin_prepare_thread(uint32_t p, lin_shape sh, const rp_strobe_init &in
     for (uint32_t i = 0; i < n; i++) {
         load_words8(w, G + (uint64_t)i * 32);
         merlin_append_words8(t, lG, 3, w);
-        for (int q = 0; q < 8; q++) pt_out[(3 + 2 * k + i) * 8 + q] = w[q];
+        if (!fx)
+            for (int q = 0; q < 8; q++) pt_out[(iG + i) * 8 + q] = w[q];
     }
     load_words8(w, F);
     merlin_append_words8(t, lF, 1, w);
-    for (int q = 0; q < 8; q++) pt_out[1 * 8 + q] = w[q];
+    if (!fx)
+        for (int q = 0; q < 8; q++) pt_out[1 * 8 + q] = w[q];
     load_words8(w, B);
     merlin_append_words8(t, lB, 1, w);
-    for (int q = 0; q < 8; q++) pt_out[q] = w[q];
+    if (!fx)
+        for (int q = 0; q < 8; q++) pt_out[q] = w[q];
     // rounds (:271-277)
     sc28 xm[BP_RP_MAX_K], xim[BP_RP_MAX_K], acc, inv;
     sc28_one_mont(acc);
@@ -90,11 +99,11 @@ BP_HD void lin_prepare_thread(uint32_t p, lin_shape sh, const rp_strobe_init &in
         load_words8(w, pr + 64 * j);
         verr = verr || words8_zero(w);
         merlin_append_words8(t, lL, 1, w);
-        for (int q = 0; q < 8; q++) pt_out[(3 + j) * 8 + q] = w[q];
+        for (int q = 0; q < 8; q++) pt_out[(iL + j) * 8 + q] = w[q];
         load_words8(w, pr + 64 * j + 32);
         verr = verr || words8_zero(w);
         merlin_append_words8(t, lR, 1, w);
-        for (int q = 0; q < 8; q++) pt_out[(3 + k + j) * 8 + q] = w[q];
+        for (int q = 0; q < 8; q++) pt_out[(iR + j) * 8 + q] = w[q];
         sc x;
         rp_challenge_scalar(t, lx, 3, x);
         sc_to_mont28(xm[j], x);
@@ -108,7 +117,7 @@ BP_HD void lin_prepare_thread(uint32_t p, lin_shape sh, const rp_strobe_init &in
     }
     load_words8(w, Sb);
     merlin_append_words8(t, lS, 1, w);
-    for (int q = 0; q < 8; q++) pt_out[(3 + 2 * k + n) * 8 + q] = w[q];
+    for (int q = 0; q < 8; q++) pt_out[iS * 8 + q] = w[q];
     sc xs;
     rp_challenge_scalar(t, lxs, 6, xs);
     if (ts_out) {
@@ -131,13 +140,13 @@ BP_HD void lin_prepare_thread(uint32_t p, lin_shape sh, const rp_strobe_init &in
         xim[jj] = xi;
         sc28_montmul(pm, nxsm, xm[jj]);
         sc_from_mont28(t0, pm);
-        store_words8(sc_out + (3 + jj) * 8, t0);
+        store_words8(sc_out + (iL + jj) * 8, t0);
         sc28_montmul(pm, nxsm, xi);
         sc_from_mont28(t0, pm);
-        store_words8(sc_out + (3 + k + jj) * 8, t0);
+        store_words8(sc_out + (iR + jj) * 8, t0);
     }
-    store_words8(sc_out + 2 * 8, nxs);                  // -x* on C
-    store_words8(sc_out, r);                            // r on B
+    store_words8(sc_out + iC * 8, nxs);                 // -x* on C
+    store_words8(fx ? grow : sc_out, r);                // r on B
     // s_i (subset products, :299-314) in Gray-code order; a s_i on G_i; b_0 = <s, b>
     sc28 am, s;
     sc_to_mont28(am, a);
@@ -154,7 +163,7 @@ BP_HD void lin_prepare_thread(uint32_t p, lin_shape sh, const rp_strobe_init &in
         sc28 pm, bi;
         sc28_montmul(pm, am, s);
         sc_from_mont28(t0, pm);
-        store_words8(sc_out + (3 + 2 * k + i) * 8, t0);
+        store_words8(fx ? grow + (2 + i) * 8 : sc_out + (iG + i) * 8, t0);
         load_words8(w, bp_ + (uint64_t)i * 32);
         sc28_from_words(bi, w);
         sc28_montmul(pm, s, bi);                        // Montgomery-form s times plain b_i = plain s_i b_i
@@ -166,13 +175,13 @@ BP_HD void lin_prepare_thread(uint32_t p, lin_shape sh, const rp_strobe_init &in
         sc_to_mont28(bm, b0);
         sc28_montmul(pm, am, bm);
         sc_from_mont28(t0, pm);
-        store_words8(sc_out + 1 * 8, t0);
+        store_words8(fx ? grow + 8 : sc_out + 1 * 8, t0);
     }
     {   // - S
         sc one, m1;
         sc_from_u32(one, 1);
         sc_neg(m1, one);
-        store_words8(sc_out + (3 + 2 * k + n) * 8, m1);
+        store_words8(sc_out + iS * 8, m1);
     }
 }
 

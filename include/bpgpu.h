@@ -267,6 +267,9 @@ int bpgpu_ipp_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t nbatch, const vo
  *   G       : n x 32 bytes, F, B : 32 bytes each -- compressed points shared by the batch (the reference's callers pass
  *             bp_gens.share(0).G(n), pedersen B and B_blinding: linear_proof.rs:405-411); the encodings given here are
  *             what the transcript absorbs (G_i.compress(), :201-205), so they must be canonical
+ *             G = F = B = NULL: the bases are the context's generators -- G = bp_gens.share(0).G(n), F = pc_gens.B,
+ *             B = pc_gens.B_blinding -- and their n + 2 coefficients go through the fixed-base window tables instead of
+ *             per-call point tables (the fast path; needs bpgpu_gens_create / _load with gens_capacity >= n)
  *   b       : nbatch x n x 32 bytes canonical scalars, or n x 32 when b_shared != 0
  *   verdict : nbatch bytes, BPGPU_VERDICT_* (FormatError: proof length, non-canonical a, r or b_i; VerificationError:
  *             n != 2^lg_n, an identity L_j / R_j, an undecodable point, or expect_S != S)

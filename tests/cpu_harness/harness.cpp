@@ -447,7 +447,7 @@ int h_lin_verify(uint32_t n, uint32_t nbatch, const uint8_t *proofs, uint32_t pr
                  uint8_t *verdict_out, uint8_t *msm_out) {
     if (proof_len % 32 || proof_len / 32 < 3 || (proof_len / 32 - 3) % 2) return -1;
     uint32_t k = (proof_len / 32 - 3) / 2;
-    lin_shape sh; sh.b_shared = b_shared; sh.n = n; sh.k = k; sh.proof_len = proof_len; sh.nproofs = nbatch;
+    lin_shape sh; sh.b_shared = b_shared; sh.n = n; sh.k = k; sh.proof_len = proof_len; sh.nproofs = nbatch; sh.fixed = 0;
     sh.shape_verdict = (k < 32 && n == (1u << k)) ? 0 : BP_VERDICT_VERIFICATION;
     if (sh.shape_verdict) sh.n = 0;
     sh.N = sh.shape_verdict ? 4 : n + 2 * k + 4;
@@ -465,6 +465,38 @@ int h_lin_verify(uint32_t n, uint32_t nbatch, const uint8_t *proofs, uint32_t pr
     }
     std::vector<uint8_t> out((size_t)nbatch * 32 + 32), mst(nbatch + 1);
     h_msm_vb(nbatch, nt.data(), (const uint8_t *)scal.data(), (const uint8_t *)pts.data(), out.data(), mst.data());
+    for (uint32_t p = 0; p < nbatch; p++) ipp_verdict_thread(p, status.data(), mst.data(), (const uint32_t *)out.data(), verdict_out);
+    if (msm_out) memcpy(msm_out, out.data(), (size_t)nbatch * 32);
+    return 0;
+}
+
+// The same with G, F, B = the loaded generators (generator-table mode of lin_prepare_thread): gens = [B_blinding, B, G_0..G_{n-1}]
+// encodings; the n + 2 generator coefficients go through the fixed-base table emulation (h_msm_shared), C, L_j, R_j, S through the lists.
+int h_lin_verify_fixed(uint32_t W, uint32_t n, uint32_t nbatch, const uint8_t *proofs, uint32_t proof_len, const uint8_t *label, uint32_t label_len,
+                       const uint8_t *Cc, const uint8_t *gens, const uint8_t *b, uint32_t b_shared, uint8_t *verdict_out, uint8_t *msm_out) {
+    if (proof_len % 32 || proof_len / 32 < 3 || (proof_len / 32 - 3) % 2) return -1;
+    uint32_t k = (proof_len / 32 - 3) / 2;
+    if (n != (1u << k)) return -2;
+    lin_shape sh; sh.b_shared = b_shared; sh.n = n; sh.k = k; sh.proof_len = proof_len; sh.nproofs = nbatch; sh.shape_verdict = 0; sh.fixed = 1;
+    sh.N = 2 * k + 2;
+    rp_strobe_init init;
+    {
+        kstate st; st.w = init.w; st.stride = 1; strobe t; merlin_strobe_init(t, st);
+        const uint8_t dom[7] = {'d','o','m','-','s','e','p'}, ipp[6] = {'i','p','p',' ','v','1'}, ln[1] = {'n'};
+        merlin_append_message(t, dom, 7, label, label_len); merlin_append_message(t, dom, 7, ipp, 6); merlin_append_u64(t, ln, 1, n);
+        init.pos = t.pos; init.pos_begin = t.pos_begin; init.cur_flags = t.cur_flags;
+    }
+    std::vector<uint32_t> scal((size_t)nbatch * sh.N * 8 + 8, 0), pts(scal.size(), 0), status(nbatch + 1, 0), grows((size_t)nbatch * (n + 2) * 8 + 8, 0);
+    for (uint32_t p = 0; p < nbatch; p++) {
+        uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;
+        lin_prepare_thread(p, sh, init, st, proofs, Cc, b, gens + 64, gens + 32, gens, scal.data(), pts.data(), status.data(), nullptr, grows.data());
+    }
+    std::vector<uint32_t> ids(n + 2);
+    for (uint32_t i = 0; i < n + 2; i++) ids[i] = i;
+    std::vector<uint8_t> out((size_t)nbatch * 32 + 32), mst(nbatch + 1), vd(nbatch + 1);
+    int rc = h_msm_shared(W, 2, n + 2, gens, n + 2, ids.data(), nbatch, sh.N, (const uint8_t *)grows.data(), (const uint8_t *)scal.data(), (const uint8_t *)pts.data(),
+                          out.data(), mst.data(), vd.data());
+    if (rc) return rc;
     for (uint32_t p = 0; p < nbatch; p++) ipp_verdict_thread(p, status.data(), mst.data(), (const uint32_t *)out.data(), verdict_out);
     if (msm_out) memcpy(msm_out, out.data(), (size_t)nbatch * 32);
     return 0;

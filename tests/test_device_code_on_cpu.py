@@ -447,6 +447,14 @@ def test_linear_proof_front_end_lane_by_lane(H, oracle, n):
         if rc != 2 and not (j == 3):
             assert mo.raw[32 * j:32 * j + 32] == em, (n, j)
     assert list(vd.raw) == [0, 1, 2, 1, 1]
+    # generator-table mode: the same verdicts and results when G, F, B are "the loaded generators" (B_blinding, B, G_0..)
+    if n <= 16:
+        vd3, mo3 = C.create_string_buffer(nb), C.create_string_buffer(32 * nb)
+        gens = g0["B"] + g0["F"] + g0["G"]
+        assert H.h_lin_verify_fixed(5, n, nb, cat("proof"), pl, g0["label"], len(g0["label"]), cat("C"), gens, cat("b"), 0, vd3, mo3) == 0
+        assert vd3.raw == vd.raw
+        for j in (0, 1, 4):
+            assert mo3.raw[32 * j:32 * j + 32] == mo.raw[32 * j:32 * j + 32], (n, j)
     # one public vector shared by the batch; wrong n for the proof length
     vd2 = C.create_string_buffer(2)
     assert H.h_lin_verify(n, 2, g0["proof"] * 2, pl, g0["label"], len(g0["label"]), g0["C"] * 2, g0["G"], g0["F"], g0["B"], g0["b"], 1, vd2, None) == 0

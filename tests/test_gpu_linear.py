@@ -135,3 +135,33 @@ def test_linear_create_batch_of_many_with_os_randomness(ctx, oracle):
     st = oracle.transcript_new(b"many")
     for j in (0, 150, 299):
         assert oracle.linear_verify(n, proofs[pl * j:pl * (j + 1)], st, Cs[j], base["G"], base["F"], base["B"], base["b"])[0] == 0
+
+
+@pytest.mark.parametrize("n", [1, 16, 64])
+def test_linear_verify_with_the_contexts_generators(oracle, n):
+    """G = F = B = NULL: the bases are the context's bp_gens.share(0).G(n), pc_gens.B, pc_gens.B_blinding (the reference's own
+    test shape, linear_proof.rs:405-411) and their coefficients go through the fixed-base window tables; verdicts, results and
+    returned transcripts equal the explicit-bases path and the oracle."""
+    import bulletproofs_amd as bp
+    c = bp.Context(0)
+    c.gens_create(64, 2)                         # capacity 64 >= n, two parties: only party 0's G are used
+    insts, pl = _linear_cases(oracle, n, b"gfix")
+    cat = lambda key: b"".join(i[key] for i in insts)
+    g0 = insts[0]
+    G_all, _, Bp, Bb = c.gens_export()
+    assert G_all[:32 * n] == g0["G"] and Bp == g0["F"] and Bb == g0["B"]
+    v_fix, m_fix, t_fix = c.linear_verify_batch(n, cat("proof"), pl, cat("C"), None, None, None, cat("b"), label=g0["label"], want_msm=True,
+                                                want_transcripts=True)
+    v_gen, m_gen, t_gen = c.linear_verify_batch(n, cat("proof"), pl, cat("C"), g0["G"], g0["F"], g0["B"], cat("b"), label=g0["label"], want_msm=True,
+                                                want_transcripts=True)
+    assert v_fix == v_gen and list(v_fix) == [0, 1, 2, 1, 1] and t_fix == t_gen
+    st = oracle.transcript_new(g0["label"])
+    for j in (0, 1, 4):
+        rc, em = oracle.linear_verify(n, insts[j]["proof"], st, insts[j]["C"], g0["G"], g0["F"], g0["B"], insts[j]["b"])
+        assert v_fix[j] == rc and m_fix[32 * j:32 * j + 32] == em == m_gen[32 * j:32 * j + 32], (n, j)
+    # wrong n for the proof length -> VerificationError without touching the tables; more generators than loaded -> an error, not a verdict
+    assert list(c.linear_verify_batch(2 * n, g0["proof"], pl, g0["C"], None, None, None, g0["b"] * 2, label=g0["label"])) == [1]
+    big = oracle.linear_test_instance(128, b"gfix-big")
+    with pytest.raises(bp.BpgpuError):
+        c.linear_verify_batch(128, big["proof"], len(big["proof"]), big["C"], None, None, None, big["b"], label=big["label"])
+    c.close()

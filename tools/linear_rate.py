@@ -40,6 +40,10 @@ for n, nb in ((16, 4096), (64, 1024), (64, 4096), (256, 1024)):
         four = (time.perf_counter() - t0) / reps / len(ctxs)
         return one, four
     v1, v4 = run(lambda c_: c_.linear_verify_batch(n, proofs, pl, CC, base["G"], base["F"], base["B"], base["b"], label=b"rate"))
+    for c_ in ctxs:
+        c_.gens_create(n, 1)
+    assert c0.linear_verify_batch(n, proofs, pl, CC, None, None, None, base["b"], label=b"rate") == bytes(nb)
+    f1, f4 = run(lambda c_: c_.linear_verify_batch(n, proofs, pl, CC, None, None, None, base["b"], label=b"rate"))
     p1, p4 = run(lambda c_: c_.linear_create_batch(n, CC, R, A, base["b"], base["G"], base["F"], base["B"], label=b"rate", rng=rng))
     st = O.transcript_new(b"rate")
     cnt = max(4, 2048 // n)
@@ -51,6 +55,7 @@ for n, nb in ((16, 4096), (64, 1024), (64, 4096), (256, 1024)):
     for j in range(cnt):
         O.linear_create(n, st, rng[64 * (2 * lg + 2) * j:], CC[32 * j:32 * j + 32], R[32 * j:32 * j + 32], A[32 * n * j:32 * n * (j + 1)], base["b"], base["G"], base["F"], base["B"])
     cp = cnt / (time.perf_counter() - t0)
+    print("LinearProof n=%3d batch %5d: verify, bases = the context's generators (window tables): %.2f ms = %.0f proofs/s (1 context), %.0f/s (4 contexts)" % (n, nb, f1 * 1e3, nb / f1, nb / f4))
     print("LinearProof n=%3d batch %5d: verify %.2f ms = %.0f proofs/s (1 context), %.0f/s (4 contexts)   create %.2f ms = %.0f proofs/s, %.0f/s (4 contexts)"
           "   CPU oracle, one core: verify %.0f/s, create %.0f/s" % (n, nb, v1 * 1e3, nb / v1, nb / v4, p1 * 1e3, nb / p1, nb / p4, cv, cp), flush=True)
     for c_ in ctxs:
