@@ -593,6 +593,48 @@ def main():
         except Exception as e:
             extra["prover"] = {"error": str(e)}
 
+    if world == 1 and not a.rlc and not a.no_extra and a.steps >= 8 and a.config == "cfg2" and not a.batch:
+        # (5) the other public proof type on this path, LinearProof (src/linear_proof.rs): 4096 proofs of n = 64 made by
+        # bpgpu_linear_create_batch over the context's generators, then verified (bases through the window tables); one planted
+        # wrong commitment must be the only rejection
+        try:
+            nl, nbl = 64, 4096
+            lc = bp.Context(local_dev)
+            lc.gens_create(nl, 1)
+            Gc, _, Bp_, Bb_ = lc.gens_export()
+            ell = 2 ** 252 + 27742317777372353535851937790883648493
+            sh_ = hashlib.shake_256(b"bench-linear").digest(32 * (2 * nl + 1) + 64)
+            redl = lambda o: (int.from_bytes(sh_[o:o + 32] + bytes(32), "little") % ell).to_bytes(32, "little")
+            la = b"".join(redl(32 * i) for i in range(nl))
+            lb = b"".join(redl(32 * (nl + i)) for i in range(nl))
+            lr = redl(64 * nl)
+            lcc = sum(int.from_bytes(la[32 * i:32 * i + 32], "little") * int.from_bytes(lb[32 * i:32 * i + 32], "little") for i in range(nl)) % ell
+            # C = <a, G> + r B + <a, b> F (linear_proof.rs:415-420) through the engine's own MSM
+            Cl, stl = lc.msm_batch([nl + 2], la + lr + lcc.to_bytes(32, "little"), Gc[:32 * nl] + Bb_ + Bp_)
+            assert stl == bytes(1)
+            Cs_ = bytearray(Cl * nbl)
+            Cs_[32 * 7:32 * 8] = Bp_                                  # proof 7 is checked against somebody else's commitment
+            t1 = time.perf_counter()
+            lproofs, lst = lc.linear_create_batch(nl, Cl * nbl, lr * nbl, la * nbl, lb, Gc[:32 * nl], Bp_, Bb_, label=b"bench-linear")
+            dtc = time.perf_counter() - t1
+            pll = len(lproofs) // nbl
+            lc.linear_verify_batch(nl, lproofs, pll, bytes(Cs_), None, None, None, lb, label=b"bench-linear")
+            t1 = time.perf_counter()
+            for _ in range(4):
+                lv = lc.linear_verify_batch(nl, lproofs, pll, bytes(Cs_), None, None, None, lb, label=b"bench-linear")
+            dtv = (time.perf_counter() - t1) / 4
+            okl = lst == bytes(nbl) and [i for i in range(nbl) if lv[i]] == [7]
+            extra["linear"] = {"verifications_per_s": round(nbl / dtv, 1), "proofs_created_per_s": round(nbl / dtc, 1), "verdicts_as_planted": okl,
+                               "note": "LinearProof n = %d, batches of %d from host memory on ONE context: bpgpu_linear_create_batch (OS randomness, "
+                                       "first call) then bpgpu_linear_verify_batch with the context's generators as bases" % (nl, nbl)}
+            lc.close()
+            if not okl:
+                raise SystemExit("linear-proof verdicts differ from the planted pattern -- result invalid")
+        except SystemExit:
+            raise
+        except Exception as e:
+            extra["linear"] = {"error": str(e)}
+
     if rank == 0:
         out = {
             "metric": "64-bit rangeproof verifications/sec (batched)" + (" -- batch-combined check (bpgpu_rangeproof_verify_rlc), not the headline mode" if a.rlc else ""),
