@@ -283,7 +283,8 @@ class Context:
     def linear_create_batch(self, n, Cs, rs, a, b, G, F, B, label=b"", transcript=None, rng=None, want_transcripts=False):
         """LinearProof::create for len(Cs) / 32 proofs (bpgpu_linear_create_batch): returns (proofs bytes, status bytes[, transcripts])."""
         nb = len(Cs) // 32
-        assert len(rs) == 32 * nb and len(a) == 32 * n * nb and len(b) in (32 * n, 32 * n * nb) and len(G) == 32 * n and len(F) == len(B) == 32
+        assert len(rs) == 32 * nb and len(a) == 32 * n * nb and len(b) in (32 * n, 32 * n * nb)
+        assert (G is None and F is None and B is None) or (len(G) == 32 * n and len(F) == len(B) == 32)   # None: the context's generators
         shared = 1 if (len(b) == 32 * n and nb != 1) else 0
         lg = n.bit_length() - 1
         assert rng is None or len(rng) == 64 * (2 * lg + 2) * nb

@@ -2179,7 +2179,8 @@ extern "C" int bpgpu_linear_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
                                          uint8_t *transcripts_out) {
     if (!c || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
     if (nbatch == 0) return BPGPU_OK;
-    if (!C || !r || !a || !b || !G || !F || !B || !proofs_out || !status_out) return BPGPU_ERR_INVALID_ARG;
+    const bool from_gens = !G && !F && !B;   // bases = the context's generators: every MSM through the window tables
+    if (!C || !r || !a || !b || (!from_gens && (!G || !F || !B)) || !proofs_out || !status_out) return BPGPU_ERR_INVALID_ARG;
     if (n == 0 || (n & (n - 1))) return fail(c, BPGPU_ERR_INVALID_ARG, "InvalidInputLength: n must be a power of two (linear_proof.rs:68-70)");
     size_t k = 0;
     while (((size_t)1 << k) < n) k++;
@@ -2189,6 +2190,10 @@ extern "C" int bpgpu_linear_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(c, hipSetDevice(c->device));
     hipStream_t s = c->stream;
+    if (from_gens) {
+        if (!c->d_table) return fail(c, BPGPU_ERR_NO_GENS, "generators not loaded");
+        if (n > c->gens_capacity) return fail(c, BPGPU_ERR_NO_GENS, "InvalidGeneratorsLength: generators too small for n=%zu", n);
+    }
     int rc = ctx_enter(c, s);
     if (rc) return rc;
     const size_t proof_len = 32 * (2 * k + 3), TS = BPGPU_TRANSCRIPT_BYTES, nd = 2 * k + 2, nb_b = b_shared ? 1 : nbatch;
@@ -2208,9 +2213,14 @@ extern "C" int bpgpu_linear_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
     memcpy(h + sz_v, b, nb_b * n * 32);
     memcpy(h + sz_v + sz_bv, C, nbatch * 32);
     memcpy(h + sz_v + sz_bv + sz_q, r, nbatch * 32);
-    memcpy(h + sz_v + sz_bv + 2 * sz_q, G, n * 32);
-    memcpy(h + sz_v + sz_bv + 2 * sz_q + sz_g, F, 32);
-    memcpy(h + sz_v + sz_bv + 2 * sz_q + sz_g + 32, B, 32);
+    if (!from_gens) {
+        memcpy(h + sz_v + sz_bv + 2 * sz_q, G, n * 32);
+        memcpy(h + sz_v + sz_bv + 2 * sz_q + sz_g, F, 32);
+        memcpy(h + sz_v + sz_bv + 2 * sz_q + sz_g + 32, B, 32);
+    }
+    const uint8_t *e_G = from_gens ? (const uint8_t *)(c->d_gens + 16) : (const uint8_t *)d_G;          // encodings the transcript absorbs
+    const uint8_t *e_F = from_gens ? (const uint8_t *)(c->d_gens + 8) : (const uint8_t *)d_fb;
+    const uint8_t *e_B = from_gens ? (const uint8_t *)c->d_gens : (const uint8_t *)d_fb + 32;
     {
         char *h_rng = h + sz_v + sz_bv + 2 * sz_q + sz_g + sz_fb;
         if (rng) memcpy(h_rng, rng, nbatch * nd * 64);
@@ -2234,7 +2244,7 @@ extern "C" int bpgpu_linear_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
         // ---- working set (own allocation: the batched MSMs claim the arena)
         const size_t N = n / 2 + 2, NS = n + 2;
         const size_t w_v = align_up(nbatch * n * 32), w_u = align_up(nbatch * 32), w_d = align_up(nbatch * nd * 32),
-                     w_terms = align_up(std::max(2 * nbatch * N, nbatch * NS) * 32 + 64), w_out = align_up(2 * nbatch * 32), w_st = align_up(2 * nbatch + 64),
+                     w_terms = align_up(std::max(2 * nbatch * (from_gens ? NS : N), nbatch * NS) * 32 + 64), w_out = align_up(2 * nbatch * 32), w_st = align_up(2 * nbatch + 64),
                      w_status = align_up(nbatch * 4);
         const size_t need = 3 * w_v + 3 * w_u + w_d + 2 * w_terms + w_out + w_st + w_status;
         if (c->ipp_cap < need) {
@@ -2261,23 +2271,35 @@ extern "C" int bpgpu_linear_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
         const uint32_t nb32 = (uint32_t)nbatch, nt32 = (uint32_t)(nbatch * n), n_q = (nb32 + BP_BLOCK - 1) / BP_BLOCK;
         LAUNCH(c, s, "linc_init", k_linc_init, (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt32, sh, (const uint8_t *)d_a, (const uint8_t *)d_b, w_a, w_b, w_G,
                d_status);
-        LAUNCH(c, s, "linc_public", k_linc_public, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, (const uint8_t *)d_C, (const uint8_t *)d_b, (const uint8_t *)d_G,
-               (const uint8_t *)d_fb, (const uint8_t *)d_fb + 32, (const uint8_t *)d_r, (const uint8_t *)d_rng, (uint32_t *)d_ts, w_r, w_dr, d_status);
+        LAUNCH(c, s, "linc_public", k_linc_public, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, (const uint8_t *)d_C, (const uint8_t *)d_b, e_G, e_F, e_B,
+               (const uint8_t *)d_r, (const uint8_t *)d_rng, (uint32_t *)d_ts, w_r, w_dr, d_status);
         std::vector<uint32_t> nterms(2 * nbatch, (uint32_t)N);
         for (uint32_t j = 0; j < k && !rc; j++) {
-            LAUNCH(c, s, "linc_terms", k_linc_terms, n_q + (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_q, nt32, sh, j, (const uint32_t *)w_a, (const uint32_t *)w_b,
-                   (const uint32_t *)w_G, (const uint32_t *)w_dr, (const uint8_t *)d_G, (const uint8_t *)d_fb, (const uint8_t *)d_fb + 32, m_sc, m_pt);
-            rc = msm_batch_dev_locked(c, 2 * nbatch, nterms.data(), m_sc, m_pt, m_out, m_st, s);   // all L_j and R_j of the batch (:104-117)
+            if (from_gens) {   // rows of generator-table scalars (B_blinding, B, G_0..): m_sc holds [2 nbatch][n + 2] scalars
+                LAUNCH(c, s, "linc_terms", k_linc_terms_fixed, n_q + (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_q, nt32, sh, j, (const uint32_t *)w_a,
+                       (const uint32_t *)w_b, (const uint32_t *)w_G, (const uint32_t *)w_dr, m_sc);
+                rc = msm_shared_dev_locked(c, n, 1, 2 * nbatch, 0, m_sc, nullptr, nullptr, m_out, m_st, nullptr, s, true);
+            } else {
+                LAUNCH(c, s, "linc_terms", k_linc_terms, n_q + (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_q, nt32, sh, j, (const uint32_t *)w_a, (const uint32_t *)w_b,
+                       (const uint32_t *)w_G, (const uint32_t *)w_dr, e_G, e_F, e_B, m_sc, m_pt);
+                rc = msm_batch_dev_locked(c, 2 * nbatch, nterms.data(), m_sc, m_pt, m_out, m_st, s);   // all L_j and R_j of the batch (:104-117)
+            }
             if (rc) break;
             LAUNCH(c, s, "linc_challenge", k_linc_challenge, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, j, (const uint32_t *)m_out, (const uint8_t *)m_st,
                    (uint32_t *)d_ts, (const uint32_t *)w_dr, w_r, w_x, w_xi, (uint8_t *)d_proofs, (uint32_t)proof_len, d_status);
             LAUNCH(c, s, "linc_fold", k_linc_fold, (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt32, sh, j, (const uint32_t *)w_x, (const uint32_t *)w_xi, w_a, w_b, w_G);
         }
         if (rc) break;
-        LAUNCH(c, s, "linc_sterms", k_linc_sterms, n_q + (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_q, nt32, sh, (const uint32_t *)w_b, (const uint32_t *)w_G,
-               (const uint32_t *)w_dr, (const uint8_t *)d_G, (const uint8_t *)d_fb, (const uint8_t *)d_fb + 32, m_sc, m_pt);
-        std::vector<uint32_t> nts(nbatch, (uint32_t)NS);
-        rc = msm_batch_dev_locked(c, nbatch, nts.data(), m_sc, m_pt, m_out, m_st, s);               // every S (:155-157)
+        if (from_gens) {
+            LAUNCH(c, s, "linc_sterms", k_linc_sterms_fixed, n_q + (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_q, nt32, sh, (const uint32_t *)w_b,
+                   (const uint32_t *)w_G, (const uint32_t *)w_dr, m_sc);
+            rc = msm_shared_dev_locked(c, n, 1, nbatch, 0, m_sc, nullptr, nullptr, m_out, m_st, nullptr, s, true);
+        } else {
+            LAUNCH(c, s, "linc_sterms", k_linc_sterms, n_q + (nt32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_q, nt32, sh, (const uint32_t *)w_b, (const uint32_t *)w_G,
+                   (const uint32_t *)w_dr, e_G, e_F, e_B, m_sc, m_pt);
+            std::vector<uint32_t> nts(nbatch, (uint32_t)NS);
+            rc = msm_batch_dev_locked(c, nbatch, nts.data(), m_sc, m_pt, m_out, m_st, s);               // every S (:155-157)
+        }
         if (rc) break;
         LAUNCH(c, s, "linc_final", k_linc_final, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, (const uint32_t *)m_out, (const uint8_t *)m_st, (uint32_t *)d_ts,
                (const uint32_t *)w_a, (const uint32_t *)w_dr, (const uint32_t *)w_r, (uint8_t *)d_proofs, (uint32_t)proof_len, d_status, (uint8_t *)d_stb);

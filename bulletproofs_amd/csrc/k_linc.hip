@@ -77,3 +77,26 @@ __global__ void __launch_bounds__(RP_BLOCK) k_linc_final(linc_shape sh, const ui
     linc_final_thread(p, sh, st, msm_out, msm_status, ts, a, draws, r, proofs, proof_len, status);
     if (status_out) status_out[p] = (uint8_t)status[p];
 }
+
+// generator-table mode (bases = the context's generators): rows of table scalars instead of (scalar, point) lists
+__global__ void __launch_bounds__(BP_BLOCK) k_linc_terms_fixed(uint32_t n_q, uint32_t nthreads, linc_shape sh, uint32_t j, const uint32_t *a, const uint32_t *b,
+                                                                const uint32_t *wG, const uint32_t *draws, uint32_t *gen_scalars) {
+    if (blockIdx.x < n_q) {
+        const uint32_t p = blockIdx.x * BP_BLOCK + threadIdx.x;
+        if (p < sh.nproofs) linc_q_fixed_thread(p, sh, j, a, b, draws, gen_scalars);
+    } else {
+        const uint32_t tid = (blockIdx.x - n_q) * BP_BLOCK + threadIdx.x;
+        if (tid < nthreads) linc_terms_fixed_thread(tid, sh, j, a, wG, gen_scalars);
+    }
+}
+
+__global__ void __launch_bounds__(BP_BLOCK) k_linc_sterms_fixed(uint32_t n_q, uint32_t nthreads, linc_shape sh, const uint32_t *b, const uint32_t *wG,
+                                                                 const uint32_t *draws, uint32_t *gen_scalars) {
+    if (blockIdx.x < n_q) {
+        const uint32_t p = blockIdx.x * BP_BLOCK + threadIdx.x;
+        if (p < sh.nproofs) linc_sq_fixed_thread(p, sh, b, draws, gen_scalars);
+    } else {
+        const uint32_t tid = (blockIdx.x - n_q) * BP_BLOCK + threadIdx.x;
+        if (tid < nthreads) linc_sterms_fixed_thread(tid, sh, wG, draws, gen_scalars);
+    }
+}

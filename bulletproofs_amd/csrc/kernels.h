@@ -87,6 +87,8 @@ __global__ void k_linc_terms(uint32_t n_q, uint32_t nthreads, linc_shape sh, uin
 __global__ void k_linc_challenge(linc_shape sh, uint32_t j, const uint32_t *msm_out, const uint8_t *msm_status, uint32_t *ts, const uint32_t *draws, uint32_t *r_io, uint32_t *x, uint32_t *xinv, uint8_t *proofs, uint32_t proof_len, uint32_t *status);
 __global__ void k_linc_fold(uint32_t nthreads, linc_shape sh, uint32_t j, const uint32_t *x, const uint32_t *xinv, uint32_t *a, uint32_t *b, uint32_t *wG);
 __global__ void k_linc_sterms(uint32_t n_q, uint32_t nthreads, linc_shape sh, const uint32_t *b, const uint32_t *wG, const uint32_t *draws, const uint8_t *G, const uint8_t *F, const uint8_t *B, uint32_t *msm_sc, uint32_t *msm_pt);
+__global__ void k_linc_terms_fixed(uint32_t n_q, uint32_t nthreads, linc_shape sh, uint32_t j, const uint32_t *a, const uint32_t *b, const uint32_t *wG, const uint32_t *draws, uint32_t *gen_scalars);
+__global__ void k_linc_sterms_fixed(uint32_t n_q, uint32_t nthreads, linc_shape sh, const uint32_t *b, const uint32_t *wG, const uint32_t *draws, uint32_t *gen_scalars);
 __global__ void k_linc_final(linc_shape sh, const uint32_t *msm_out, const uint8_t *msm_status, uint32_t *ts, const uint32_t *a, const uint32_t *draws, const uint32_t *r, uint8_t *proofs, uint32_t proof_len, uint32_t *status, uint8_t *status_out);
 
 #endif

@@ -149,6 +149,69 @@ BP_HD void linc_q_thread(uint32_t p, linc_shape sh, uint32_t j, const uint32_t *
     }
 }
 
+// ---- the same terms when G, F, B are the context's generators (bp_gens.share(0).G(n), pc_gens.B, pc_gens.B_blinding): L_j, R_j and S
+// are pure generator-table MSMs.  Rows 2p (L) and 2p + 1 (R) of a [2 nproofs][n + 2] scalar array in the table order
+// (B_blinding, B, G_0..): every slot is written (zero where a generator does not occur).
+BP_HD void linc_terms_fixed_thread(uint32_t tid, linc_shape sh, uint32_t j, const uint32_t *a, const uint32_t *wG, uint32_t *gen_scalars) {
+    const uint32_t n = sh.n, p = tid / n, t = tid - p * n;
+    const uint32_t nj = n >> j, np = nj >> 1;
+    const uint32_t tt = t & (nj - 1), i = tt & (np - 1), hi = tt >= np ? 1u : 0u;
+    const uint32_t row_len = n + 2;
+    const uint64_t pa = (uint64_t)p * n;
+    uint32_t *rowL = gen_scalars + (uint64_t)(2 * p) * row_len * 8, *rowR = rowL + (uint64_t)row_len * 8;
+    sc x, w, r, zero;
+    sc_0(zero);
+    ippc_ld(x, a + 8 * (pa + (hi ? i : i + np)));
+    ippc_ld(w, wG + 8 * (pa + t));
+    sc_mul(r, x, w);
+    ippc_st(rowL + (uint64_t)(2 + t) * 8, hi ? r : zero);
+    ippc_st(rowR + (uint64_t)(2 + t) * 8, hi ? zero : r);
+}
+BP_HD void linc_q_fixed_thread(uint32_t p, linc_shape sh, uint32_t j, const uint32_t *a, const uint32_t *b, const uint32_t *draws, uint32_t *gen_scalars) {
+    const uint32_t n = sh.n, np = (n >> j) >> 1, row_len = n + 2, nd = 2 * sh.k + 2;
+    const uint64_t pa = (uint64_t)p * n;
+    sc c, x, y, s0, s1;
+    sc_0(s0);
+    sc_0(s1);
+    for (uint32_t i = 0; i < np; i++) {
+        ippc_ld(x, a + 8 * (pa + i));
+        ippc_ld(y, b + 8 * (pa + i + np));
+        sc_mul(c, x, y);
+        sc_add(s0, s0, c);
+        ippc_ld(x, a + 8 * (pa + i + np));
+        ippc_ld(y, b + 8 * (pa + i));
+        sc_mul(c, x, y);
+        sc_add(s1, s1, c);
+    }
+    uint32_t *rowL = gen_scalars + (uint64_t)(2 * p) * row_len * 8, *rowR = rowL + (uint64_t)row_len * 8;
+    ippc_ld(x, draws + 8 * ((uint64_t)p * nd + 2 * j));
+    ippc_ld(y, draws + 8 * ((uint64_t)p * nd + 2 * j + 1));
+    ippc_st(rowL, x);          // s_j on B (= the table's B_blinding)
+    ippc_st(rowR, y);          // t_j
+    ippc_st(rowL + 8, s0);     // c_L on F (= the table's B)
+    ippc_st(rowR + 8, s1);     // c_R
+}
+// S: row p of a [nproofs][n + 2] array
+BP_HD void linc_sterms_fixed_thread(uint32_t tid, linc_shape sh, const uint32_t *wG, const uint32_t *draws, uint32_t *gen_scalars) {
+    const uint32_t n = sh.n, p = tid / n, t = tid - p * n, nd = 2 * sh.k + 2;
+    sc s_star, w, r;
+    ippc_ld(s_star, draws + 8 * ((uint64_t)p * nd + 2 * sh.k));
+    ippc_ld(w, wG + 8 * (uint64_t)tid);
+    sc_mul(r, s_star, w);
+    ippc_st(gen_scalars + ((uint64_t)p * (n + 2) + 2 + t) * 8, r);
+}
+BP_HD void linc_sq_fixed_thread(uint32_t p, linc_shape sh, const uint32_t *b, const uint32_t *draws, uint32_t *gen_scalars) {
+    const uint32_t n = sh.n, nd = 2 * sh.k + 2;
+    sc s_star, t_star, b0, r;
+    ippc_ld(s_star, draws + 8 * ((uint64_t)p * nd + 2 * sh.k));
+    ippc_ld(t_star, draws + 8 * ((uint64_t)p * nd + 2 * sh.k + 1));
+    ippc_ld(b0, b + 8 * (uint64_t)p * n);
+    sc_mul(r, s_star, b0);
+    uint32_t *row = gen_scalars + (uint64_t)p * (n + 2) * 8;
+    ippc_st(row, t_star);
+    ippc_st(row + 8, r);
+}
+
 // lane = proof, after round j's MSMs: L, R -> proof bytes and transcript (:119-126), x_j and its inverse,
 // r <- r + x_j s_j + x_j^-1 t_j (:148)
 BP_HD void linc_challenge_thread(uint32_t p, linc_shape sh, uint32_t j, kstate st, const uint32_t *msm_out /*[2 nproofs][8]*/, const uint8_t *msm_status,

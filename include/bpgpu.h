@@ -296,7 +296,8 @@ int bpgpu_linear_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t nbatch, const
  *             reference's draw order (s_j, t_j per round, then s_star, t_star); NULL = the OS CSPRNG
  *   C, r    : nbatch x 32 bytes: the commitment (absorbed into the transcript as given) and its blinding factor
  *   a       : nbatch x n x 32 canonical scalars (secret); b : nbatch x n x 32, or n x 32 when b_shared != 0 (public)
- *   G       : n x 32 bytes; F, B : 32 bytes (compressed points, shared by the batch)
+ *   G       : n x 32 bytes; F, B : 32 bytes (compressed points, shared by the batch); G = F = B = NULL: the context's
+ *             generators as in bpgpu_linear_verify_batch -- every L_j, R_j, S is then a pure window-table MSM
  *   proofs_out : nbatch x 32*(2 lg n + 3) bytes; status_out : nbatch bytes (BPGPU_MSM_OK, or why no proof was made:
  *             an undecodable point or a non-canonical scalar); transcripts_out : optional nbatch x 208 bytes, each
  *             proof's transcript as create() leaves it */

@@ -159,6 +159,11 @@ def test_linear_verify_with_the_contexts_generators(oracle, n):
     for j in (0, 1, 4):
         rc, em = oracle.linear_verify(n, insts[j]["proof"], st, insts[j]["C"], g0["G"], g0["F"], g0["B"], insts[j]["b"])
         assert v_fix[j] == rc and m_fix[32 * j:32 * j + 32] == em == m_gen[32 * j:32 * j + 32], (n, j)
+    # the prover over the same bases: byte-identical to the oracle's (and so to the explicit-bases path) through the window tables
+    if True:
+        rc, want = oracle.linear_create(n, st, g0["rng"], g0["C"], g0["r"], g0["a"], g0["b"], g0["G"], g0["F"], g0["B"])
+        made, stat = c.linear_create_batch(n, g0["C"] * 3, g0["r"] * 3, g0["a"] * 3, g0["b"], None, None, None, label=g0["label"], rng=g0["rng"] * 3)
+        assert rc == 0 and stat == bytes(3) and made == want * 3
     # wrong n for the proof length -> VerificationError without touching the tables; more generators than loaded -> an error, not a verdict
     assert list(c.linear_verify_batch(2 * n, g0["proof"], pl, g0["C"], None, None, None, g0["b"] * 2, label=g0["label"])) == [1]
     big = oracle.linear_test_instance(128, b"gfix-big")

@@ -44,6 +44,9 @@ for n, nb in ((16, 4096), (64, 1024), (64, 4096), (256, 1024)):
         c_.gens_create(n, 1)
     assert c0.linear_verify_batch(n, proofs, pl, CC, None, None, None, base["b"], label=b"rate") == bytes(nb)
     f1, f4 = run(lambda c_: c_.linear_verify_batch(n, proofs, pl, CC, None, None, None, base["b"], label=b"rate"))
+    assert c0.linear_create_batch(n, CC, R, A, base["b"], None, None, None, label=b"rate", rng=rng)[0] == proofs
+    q1, q4 = run(lambda c_: c_.linear_create_batch(n, CC, R, A, base["b"], None, None, None, label=b"rate", rng=rng))
+    print("LinearProof n=%3d batch %5d: create, bases = the context's generators (window tables): %.2f ms = %.0f proofs/s (1 context), %.0f/s (4 contexts)" % (n, nb, q1 * 1e3, nb / q1, nb / q4))
     p1, p4 = run(lambda c_: c_.linear_create_batch(n, CC, R, A, base["b"], base["G"], base["F"], base["B"], label=b"rate", rng=rng))
     st = O.transcript_new(b"rate")
     cnt = max(4, 2048 // n)
