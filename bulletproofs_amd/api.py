@@ -57,6 +57,34 @@ class BulletproofGens:
         _, _, B, Bb = self.ctx.gens_export()
         return PedersenGens(B, Bb)
 
+    def increase_capacity(self, new_capacity):
+        """generators.rs:177-204: extends every party's chain to new_capacity (no-op if not larger); the device tables are rebuilt."""
+        if self.gens_capacity >= new_capacity:
+            return
+        self.ctx.gens_create(new_capacity, self.party_capacity)
+        self.gens_capacity = new_capacity
+        self.__dict__.pop("_pc", None)
+
+    def _flat(self):
+        G, H, _, _ = self.ctx.gens_export()
+        return G, H
+
+    def G(self, n, m):
+        """the aggregated iterator of generators.rs:207-232: the first n generators of each of the first m parties, compressed"""
+        G, _ = self._flat()
+        c = self.gens_capacity
+        return [G[32 * (j * c + i):32 * (j * c + i) + 32] for j in range(m) for i in range(n)]
+
+    def H(self, n, m):
+        _, H = self._flat()
+        c = self.gens_capacity
+        return [H[32 * (j * c + i):32 * (j * c + i) + 32] for j in range(m) for i in range(n)]
+
+    def share(self, j):
+        """BulletproofGens::share(j) (generators.rs:168-175): .G(n) / .H(n) of party j"""
+        return BulletproofGensShare(self, j)
+
+
     def _check_pedersen(self, pc_gens):
         """The verifier multiplies by pc_gens.B / B_blinding (mod.rs:439-440); the device tables hold the bases this
         BulletproofGens was created with.  A different PedersenGens must be loaded with Context.gens_load."""
@@ -66,6 +94,23 @@ class BulletproofGens:
             self._pc = self.pedersen()
         if (bytes(pc_gens.B), bytes(pc_gens.B_blinding)) != (self._pc.B, self._pc.B_blinding):
             raise ValueError("pc_gens differs from the Pedersen bases held in the device tables (use Context.gens_load for custom bases)")
+
+
+class BulletproofGensShare:
+    """generators.rs:262-292"""
+
+    def __init__(self, gens, share):
+        self.gens, self.share_index = gens, share
+
+    def G(self, n):
+        G, _ = self.gens._flat()
+        o = self.share_index * self.gens.gens_capacity
+        return [G[32 * (o + i):32 * (o + i) + 32] for i in range(n)]
+
+    def H(self, n):
+        _, H = self.gens._flat()
+        o = self.share_index * self.gens.gens_capacity
+        return [H[32 * (o + i):32 * (o + i) + 32] for i in range(n)]
 
 
 class Transcript:

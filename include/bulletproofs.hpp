@@ -84,6 +84,19 @@ class BulletproofGens {
         if (bpgpu_gens_export(ctx_.get(), nullptr, nullptr, pc.B.data(), pc.B_blinding.data()) != BPGPU_OK) throw GpuError(bpgpu_last_error(ctx_.get()));
         return pc;
     }
+    // BulletproofGens::increase_capacity (generators.rs:177-204): no-op unless larger; the device tables are rebuilt
+    void increase_capacity(size_t new_capacity) {
+        if (gens_capacity >= new_capacity) return;
+        if (bpgpu_gens_create(ctx_.get(), new_capacity, party_capacity) != BPGPU_OK) throw GpuError(bpgpu_last_error(ctx_.get()));
+        gens_capacity = new_capacity;
+    }
+    // the aggregated iterators G(n, m) / H(n, m) (generators.rs:207-259): the first n generators of each of the first m parties
+    std::vector<CompressedRistretto> G(size_t n, size_t m) const { return slice(true, n, m, 0); }
+    std::vector<CompressedRistretto> H(size_t n, size_t m) const { return slice(false, n, m, 0); }
+    // share(j).G(n) / share(j).H(n) (generators.rs:168-175, 262-292)
+    std::vector<CompressedRistretto> share_G(size_t j, size_t n) const { return slice(true, n, 1, j); }
+    std::vector<CompressedRistretto> share_H(size_t j, size_t n) const { return slice(false, n, 1, j); }
+
     // The verifier multiplies by pc_gens.B / B_blinding (mod.rs:439-440); the device tables hold the bases of this
     // BulletproofGens.  Any other PedersenGens would silently verify a different statement: refuse it.
     void check_pedersen(const PedersenGens &pc) const {
@@ -91,6 +104,17 @@ class BulletproofGens {
     }
 
   private:
+    std::vector<CompressedRistretto> slice(bool g, size_t n, size_t m, size_t first_party) const {
+        if (n > gens_capacity || first_party + m > party_capacity) throw std::out_of_range("generators: n or party index beyond capacity");
+        const size_t tot = gens_capacity * party_capacity;
+        std::vector<uint8_t> flat(tot * 32);
+        if (bpgpu_gens_export(ctx_.get(), g ? flat.data() : nullptr, g ? nullptr : flat.data(), nullptr, nullptr) != BPGPU_OK)
+            throw GpuError(bpgpu_last_error(ctx_.get()));
+        std::vector<CompressedRistretto> out(n * m);
+        for (size_t j = 0; j < m; j++)
+            for (size_t i = 0; i < n; i++) std::memcpy(out[j * n + i].data(), &flat[((first_party + j) * gens_capacity + i) * 32], 32);
+        return out;
+    }
     std::shared_ptr<bpgpu_ctx> ctx_;
 };
 

@@ -140,3 +140,26 @@ def test_cpp_mirror_linear_proof(oracle, tmp_path):
     out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr
     assert "linear_proof: ok" in out.stdout
+
+
+def test_generators_tests_of_the_reference(oracle):
+    """src/generators.rs:300-356: aggregated_gens_iter_matches_flat_gens and resizing_small_gens_matches_creating_bigger_gens,
+    through the Python mirror (generators derived on the GPU), plus equality with the oracle's chain."""
+    from bulletproofs_amd import BulletproofGens
+    gens = BulletproofGens(64, 8)
+    for n, m in ((64, 8), (64, 4), (64, 2), (64, 1), (32, 8), (32, 4), (32, 2), (32, 1), (16, 8), (16, 4), (16, 2), (16, 1)):
+        agg_G, agg_H = gens.G(n, m), gens.H(n, m)
+        flat_G = [g for j in range(m) for g in gens.share(j).G(n)]
+        flat_H = [h for j in range(m) for h in gens.share(j).H(n)]
+        assert agg_G == flat_G and agg_H == flat_H and len(agg_G) == n * m
+    resized = BulletproofGens(32, 8)
+    before = resized.G(32, 8)
+    resized.increase_capacity(16)                      # not larger: nothing happens
+    assert resized.gens_capacity == 32 and resized.G(32, 8) == before
+    resized.increase_capacity(64)
+    for n, m in ((64, 8), (32, 8), (16, 8)):
+        assert gens.G(n, m) == resized.G(n, m) and gens.H(n, m) == resized.H(n, m)
+    oG, oH, oB, oBb = oracle.Gens(64, 8).export()
+    assert b"".join(gens.G(64, 8)) == oG and b"".join(gens.H(64, 8)) == oH
+    pc = resized.pedersen()
+    assert (pc.B, pc.B_blinding) == (oB, oBb)
