@@ -121,3 +121,42 @@ def test_reference_api_prove_then_verify(oracle):
     assert tv.state == tp.state
     g = oracle.Gens(64, 4)
     assert oracle.verify(g, proof.to_bytes(), b"".join(commitments), 32, b"doctest example", bytes(64))[0] == 0
+
+
+@pytest.fixture(scope="module")
+def gens64x8():
+    from bulletproofs_amd import BulletproofGens
+    g = BulletproofGens(64, 8, fixed_window_bits=12)
+    yield g
+    g.ctx.close()
+
+
+@pytest.mark.parametrize("n,m", [(32, 1), (32, 2), (32, 4), (32, 8), (64, 1), (64, 2), (64, 4), (64, 8)])
+def test_singleparty_create_and_verify_helper(gens64x8, oracle, n, m):
+    """src/range_proof/mod.rs:633-725: create_and_verify_n_{32,64}_m_{1,2,4,8} -- prover's scope (prove, serialize), verifier's
+    scope (deserialize, verify) -- through the Python mirror, both scopes on the GPU; the oracle verifies the same bytes."""
+    from bulletproofs_amd import RangeProof, Transcript, VerificationError
+    max_bitsize, max_parties = 64, 8
+    bp_gens, pc_gens = gens64x8, gens64x8.pedersen()
+    assert (bp_gens.gens_capacity, bp_gens.party_capacity) == (max_bitsize, max_parties)
+    # 1. prover's scope
+    rnd = hashlib.shake_256(b"create_and_verify %d %d" % (n, m)).digest(8 * m + 64 * m)
+    values = [int.from_bytes(rnd[8 * i:8 * i + 8], "little") % (1 << n) for i in range(m)]       # rng.gen_range(min, max)
+    ell = 2 ** 252 + 27742317777372353535851937790883648493
+    blindings = [(int.from_bytes(rnd[8 * m + 64 * i:8 * m + 64 * i + 64], "little") % ell).to_bytes(32, "little") for i in range(m)]
+    tp = Transcript(b"AggregatedRangeProofTest")
+    proof, value_commitments = RangeProof.prove_multiple_with_rng(bp_gens, pc_gens, tp, values, blindings, n)
+    proof_bytes = proof.to_bytes()
+    assert len(proof_bytes) == 32 * (9 + 2 * ((n * m).bit_length() - 1)) and len(value_commitments) == m
+    # 2. verifier's scope
+    parsed = RangeProof.from_bytes(proof_bytes)
+    tv = Transcript(b"AggregatedRangeProofTest")
+    assert parsed.verify_multiple(bp_gens, pc_gens, tv, value_commitments, n) is None
+    assert tv.state == tp.state
+    g = oracle.Gens(max_bitsize, max_parties)
+    assert oracle.verify(g, proof_bytes, b"".join(value_commitments), n, b"AggregatedRangeProofTest", bytes(64))[0] == 0
+    # a commitment from another proof makes it fail (the aggregation tests' negative direction)
+    if m > 1:
+        swapped = [value_commitments[1], value_commitments[0]] + value_commitments[2:]
+        with pytest.raises(VerificationError):
+            parsed.verify_multiple(bp_gens, pc_gens, Transcript(b"AggregatedRangeProofTest"), swapped, n)
