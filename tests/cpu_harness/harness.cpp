@@ -231,6 +231,15 @@ void h_sc_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
     memcpy(out, r.v, 32);
 }
 
+// sum_{i < 2^lg} x^i as the device computes it (rp_sum_of_powers_pow2: src/util.rs:240-256 for powers of two)
+void h_sum_of_powers_pow2(const uint8_t *x, uint32_t lg, uint8_t *out) {
+    sc xs, r; memcpy(xs.v, x, 32);
+    sc28 xm, rm; sc_to_mont28(xm, xs);
+    rp_sum_of_powers_pow2(rm, xm, lg);
+    sc_from_mont28(r, rm);
+    memcpy(out, r.v, 32);
+}
+
 static int g_horner_lanes = 4;
 void h_set_horner_lanes(int lanes) { g_horner_lanes = lanes; }
 

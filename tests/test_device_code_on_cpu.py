@@ -506,3 +506,44 @@ def test_standalone_ipp_front_end_lane_by_lane(H, oracle, n):
         rc, em = oracle.ipp_verify(n, inst["proof"], b"innerproducttest", inst["Gf"], inst["Hf"], inst["P"], inst["Q"], inst["G"], inst["H"])
         assert vd.raw[j] == rc and mo.raw[32 * j:32 * j + 32] == em, (n, j)
     assert list(vd.raw) == [0, 1, 1]
+
+
+def test_util_rs_scalar_tests_on_the_device_code(H, oracle):
+    """src/util.rs:274-351 -- exp_2_is_powers_of_2, test_inner_product (<a, b> = 40), test_scalar_exp (the fixed scalar),
+    test_sum_of_powers (x = 10, n in {1, .., 64}) -- against the device's scalar arithmetic (sc25519.h, rangeproof.h) compiled
+    for the host, and the oracle's; the reference's values are small enough to state as integers."""
+    ell = 2 ** 252 + 27742317777372353535851937790883648493
+    le = lambda v: (v % ell).to_bytes(32, "little")
+
+    def op(code, a, b=0):
+        o = C.create_string_buffer(32)
+        H.h_sc_op(code, le(a), le(b), o)
+        return int.from_bytes(o.raw, "little")
+    # exp_iter(2): 1, 2, 4, 8
+    acc, seen = 1, []
+    for _ in range(4):
+        seen.append(acc)
+        acc = op(0, acc, 2)
+    assert seen == [1, 2, 4, 8]
+    # inner_product([1, 2, 3, 4], [2, 3, 4, 5]) = 40
+    ip = 0
+    for a, b in zip((1, 2, 3, 4), (2, 3, 4, 5)):
+        ip = op(1, ip, op(0, a, b))
+    assert ip == 40
+    # scalar_exp_vartime on the reference's fixed scalar: repeated products against integer powers mod l
+    x = int.from_bytes(b"\x84\xfc\xbcOx\x12\xa0\x06\xd7\x91\xd9z:'\xdd\x1e!CE\xf7\xb1\xb9Vz\x810sD\x96\x85\xb5\x07", "little")
+    assert x < ell
+    acc = 1
+    for e in range(1, 65):
+        acc = op(0, acc, x)
+        if e in (1, 2, 3, 4, 5, 64):
+            assert acc == pow(x, e, ell), e
+    o = C.create_string_buffer(32)
+    oracle.lib().oracle_scalar_mul(le(x), le(x), o)
+    assert int.from_bytes(o.raw, "little") == pow(x, 2, ell)
+    assert op(0, x, op(4, x)) == 1 and op(7, x) == pow(x, ell - 2, ell) == op(8, x)         # the three inversions agree
+    # sum_of_powers(10, n): 1, 11, 1111, 11111111, ... and the closed form for the larger ones
+    for lg in range(0, 7):
+        H.h_sum_of_powers_pow2(le(10), lg, o)
+        n = 1 << lg
+        assert int.from_bytes(o.raw, "little") == sum(pow(10, i, ell) for i in range(n)) % ell == (int("1" * n) % ell), n
