@@ -23,6 +23,7 @@ EXPORTS = [
     "bpgpu_rangeproof_verify_batch_ts", "bpgpu_rangeproof_verify_batch_ts_dev", "bpgpu_ipp_verify_batch_dev",
     "bpgpu_ipp_create_batch", "bpgpu_rangeproof_prove_batch", "bpgpu_rangeproof_verify_batch_submit", "bpgpu_ctx_collect",
     "bpgpu_linear_verify_batch", "bpgpu_linear_verify_batch_dev", "bpgpu_linear_create_batch",
+    "bpgpu_rangeproof_audit_shares",
 ]
 
 TRANSCRIPT_BYTES = 208
@@ -84,6 +85,7 @@ def lib():
     L.bpgpu_rangeproof_verify_batch_submit.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p]
     L.bpgpu_ctx_collect.argtypes = [vp]
     L.bpgpu_linear_verify_batch.argtypes = [vp, sz, sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, i, u8p, u8p, u8p]
+    L.bpgpu_rangeproof_audit_shares.argtypes = [vp, sz, sz, C.POINTER(C.c_uint32), u8p, u8p, u8p, u8p, i, u8p, u8p]
     L.bpgpu_linear_create_batch.argtypes = [vp, sz, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, i, u8p, u8p, u8p, u8p, u8p, u8p]
     L.bpgpu_linear_verify_batch_dev.argtypes = [vp, sz, sz, vp, sz, u8p, sz, u8p, vp, vp, vp, vp, vp, i, vp, vp, vp, vp]
     L.bpgpu_profile_enable.argtypes = [vp, i]
@@ -264,6 +266,18 @@ class Context:
         msm = C.create_string_buffer(32 * max(nb, 1)) if want_msm else None
         self._chk(self._L.bpgpu_ipp_verify_batch(self.h, n, nb, proofs, proof_len, label, len(label), Gf, Hf, P, Q, G, H, verdict, msm))
         return (verdict.raw[:nb], msm.raw[:32 * nb]) if want_msm else verdict.raw[:nb]
+
+    def rangeproof_audit_shares(self, n, party_index, shares, bit_commitments, poly_commitments, challenges, want_checks=False):
+        """ProofShare::audit_share for len(party_index) shares (bpgpu_rangeproof_audit_shares); challenges: 96 bytes shared or per share."""
+        ns = len(party_index)
+        assert len(shares) == ns * 32 * (3 + 2 * n) and len(bit_commitments) == 96 * ns and len(poly_commitments) == 64 * ns
+        assert len(challenges) in (96, 96 * ns)
+        shared = 1 if (len(challenges) == 96 and ns != 1) else 0
+        pi = (C.c_uint32 * max(ns, 1))(*party_index)
+        verdict = C.create_string_buffer(max(ns, 1))
+        chk = C.create_string_buffer(64 * max(ns, 1)) if want_checks else None
+        self._chk(self._L.bpgpu_rangeproof_audit_shares(self.h, n, ns, pi, shares, bit_commitments, poly_commitments, challenges, shared, verdict, chk))
+        return (verdict.raw[:ns], chk.raw[:64 * ns]) if want_checks else verdict.raw[:ns]
 
     def linear_verify_batch(self, n, proofs, proof_len, Cs, G, F, B, b, label=b"", transcript=None, want_msm=False, want_transcripts=False):
         """LinearProof::verify for len(Cs) / 32 proofs (bpgpu_linear_verify_batch).  G: n points shared by the batch; b: per-proof

@@ -2041,6 +2041,89 @@ extern "C" int bpgpu_linear_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
     return BPGPU_OK;
 }
 
+// ProofShare::audit_share for nshares shares of bitsize n (audit.h): front end (lane = share) -> the ragged (2n + 3, 5) pairs of
+// multiscalar multiplications through bpgpu_msm_batch's engine -> Ok / Err per share.  Host pointers (the dealer's blame path).
+extern "C" int bpgpu_rangeproof_audit_shares(bpgpu_ctx *c, size_t n, size_t nshares, const uint32_t *party_index, const uint8_t *shares,
+                                             const uint8_t *bit_commitments, const uint8_t *poly_commitments, const uint8_t *challenges,
+                                             int challenges_shared, uint8_t *verdict, uint8_t *checks_out) {
+    if (!c) return BPGPU_ERR_INVALID_ARG;
+    if (nshares == 0) return BPGPU_OK;
+    if (!party_index || !shares || !bit_commitments || !poly_commitments || !challenges || !verdict) return BPGPU_ERR_INVALID_ARG;
+    if (!(n == 8 || n == 16 || n == 32 || n == 64)) return fail(c, BPGPU_ERR_INVALID_ARG, "InvalidBitsize: n must be 8, 16, 32 or 64 (party.rs:41-43)");
+    if ((uint64_t)nshares * (2 * n + 8) > 0x7fffffffull / 64) return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large for this shape");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (!c->d_gens) return fail(c, BPGPU_ERR_NO_GENS, "generators not loaded");
+    if (n > c->gens_capacity) {   // check_size (messages.rs:70-72): Err(()) for every share
+        memset(verdict, BPGPU_VERDICT_VERIFICATION_ERROR, nshares);
+        if (checks_out) memset(checks_out, 0, nshares * 64);
+        return BPGPU_OK;
+    }
+    hipStream_t s = c->stream;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    const size_t share_len = 32 * (3 + 2 * n), nch = challenges_shared ? 1 : nshares;
+    const size_t sz_pi = align_up(nshares * 4 + 64), sz_sh = align_up(nshares * share_len + 64), sz_bc = align_up(nshares * 96 + 64),
+                 sz_pc = align_up(nshares * 64 + 64), sz_ch = align_up(nch * 96 + 64);
+    const size_t sz_in = sz_pi + sz_sh + sz_bc + sz_pc + sz_ch, sz_v = align_up(nshares), sz_o = align_up(nshares * 64);
+    rc = io_reserve(c, sz_in + sz_v + sz_o);
+    if (rc) return rc;
+    char *h = nullptr;
+    rc = pin_alloc(c, s, sz_in + sz_v + sz_o, &h);
+    if (rc) return rc;
+    char *d = c->io_dev;
+    char *d_pi = d, *d_sh = d_pi + sz_pi, *d_bc = d_sh + sz_sh, *d_pc = d_bc + sz_bc, *d_ch = d_pc + sz_pc, *d_v = d + sz_in, *d_o = d_v + sz_v;
+    memcpy(h, party_index, nshares * 4);
+    memcpy(h + sz_pi, shares, nshares * share_len);
+    memcpy(h + sz_pi + sz_sh, bit_commitments, nshares * 96);
+    memcpy(h + sz_pi + sz_sh + sz_bc, poly_commitments, nshares * 64);
+    memcpy(h + sz_pi + sz_sh + sz_bc + sz_pc, challenges, nch * 96);
+    HIPCHK(c, hipMemcpyAsync(d, h, sz_in, hipMemcpyHostToDevice, s));
+    do {
+        const size_t per = 2 * n + 8;
+        const size_t sz_terms = align_up(nshares * per * 32 + 64), sz_st = align_up(nshares * 4), sz_b = align_up(2 * nshares + 64);
+        const size_t need = 2 * sz_terms + sz_st + sz_b;
+        if (c->ipp_cap < need) {
+            if (hipDeviceSynchronize() != hipSuccess) { rc = fail(c, BPGPU_ERR_HIP, "synchronize failed"); break; }
+            if (c->ipp_buf) hipFree(c->ipp_buf);
+            c->ipp_buf = nullptr;
+            c->ipp_cap = 0;
+            if (hipMalloc((void **)&c->ipp_buf, need + need / 4) != hipSuccess) { rc = fail(c, BPGPU_ERR_HIP, "out of device memory (share audit working set)"); break; }
+            c->ipp_cap = need + need / 4;
+        }
+        char *d_sc = c->ipp_buf, *d_pt = d_sc + sz_terms, *d_stat = d_pt + sz_terms, *d_mst = d_stat + sz_st;
+        if (hipMemsetAsync(d_sc, 0, 2 * sz_terms + sz_st, s) != hipSuccess) { rc = fail(c, BPGPU_ERR_HIP, "memset failed"); break; }
+        aud_shape sh;
+        sh.n = (uint32_t)n;
+        sh.lg_n = 0;
+        while (((size_t)1 << sh.lg_n) < n) sh.lg_n++;
+        sh.nshares = (uint32_t)nshares;
+        sh.gens_capacity = (uint32_t)c->gens_capacity;
+        sh.party_capacity = (uint32_t)c->party_capacity;
+        sh.chal_shared = challenges_shared ? 1u : 0u;
+        const uint32_t ns32 = (uint32_t)nshares;
+        LAUNCH(c, s, "aud_prepare", k_aud_prepare, (ns32 + 63) / 64, 64, sh, (const uint32_t *)d_pi, (const uint8_t *)d_sh, (const uint8_t *)d_bc,
+               (const uint8_t *)d_pc, (const uint8_t *)d_ch, (const uint32_t *)c->d_gens, (uint32_t *)d_sc, (uint32_t *)d_pt, (uint32_t *)d_stat);
+        std::vector<uint32_t> nt(2 * nshares);
+        for (size_t i = 0; i < nshares; i++) {
+            nt[2 * i] = (uint32_t)(2 * n + 3);     // P_check (messages.rs:128-141)
+            nt[2 * i + 1] = 5;                     // t_check (:149-160)
+        }
+        rc = msm_batch_dev_locked(c, 2 * nshares, nt.data(), d_sc, d_pt, d_o, d_mst, s);
+        if (rc) break;
+        LAUNCH(c, s, "aud_verdict", k_aud_verdict, (ns32 + 63) / 64, 64, ns32, (const uint32_t *)d_stat, (const uint8_t *)d_mst, (const uint32_t *)d_o,
+               (uint8_t *)d_v);
+        if (hipGetLastError() != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "launch failed");
+    } while (0);
+    char *h_out = h + sz_in;
+    if (!rc && hipMemcpyAsync(h_out, d_v, sz_v + sz_o, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+    const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
+    if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
+    memcpy(verdict, h_out, nshares);
+    if (checks_out) memcpy(checks_out, h_out + sz_v, nshares * 64);
+    return BPGPU_OK;
+}
+
 // The rounds of InnerProductProof::create for nbatch proofs (ipp_prover.h): inputs and outputs in device memory.
 // d_ts: the proofs' transcript states AFTER innerproduct_domain_sep(n), advanced in place.  The k (L, R) pairs and the
 // final a, b go to d_proofs + p * proof_stride (+ 64 j, + 64 k); status_bytes (optional): BPGPU_MSM_* per proof.

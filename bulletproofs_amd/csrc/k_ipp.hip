@@ -33,3 +33,16 @@ __global__ void __launch_bounds__(RP_BLOCK) k_lin_prepare(lin_shape sh, rp_strob
     st.stride = RP_BLOCK;
     if (p < sh.nproofs) lin_prepare_thread(p, sh, init, st, proofs, C, bvec, G, F, B, scalars, points, status, ts_out, gen_sc);
 }
+
+// ProofShare::audit_share front end (audit.h): lane = share
+__global__ void __launch_bounds__(64) k_aud_prepare(aud_shape sh, const uint32_t *party, const uint8_t *shares, const uint8_t *bit_commitments,
+                                                     const uint8_t *poly_commitments, const uint8_t *challenges, const uint32_t *gens, uint32_t *scalars,
+                                                     uint32_t *points, uint32_t *status) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < sh.nshares) aud_prepare_thread(s, sh, party, shares, bit_commitments, poly_commitments, challenges, gens, scalars, points, status);
+}
+
+__global__ void __launch_bounds__(64) k_aud_verdict(uint32_t n, const uint32_t *status, const uint8_t *msm_status, const uint32_t *msm_out, uint8_t *verdict) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s < n) aud_verdict_thread(s, status, msm_status, msm_out, verdict);
+}

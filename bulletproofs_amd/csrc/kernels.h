@@ -11,6 +11,7 @@
 #include "rangeproof.h"
 #include "ipp.h"
 #include "linear.h"
+#include "audit.h"
 #include "bucket.h"
 #include "ipp_prover.h"
 #include "rp_prover.h"
@@ -48,6 +49,8 @@ __global__ void k_rlc_finish(uint32_t nsplit, const ge_ext *hq, const ge_ext *pa
 __global__ void k_rp_verdict(uint32_t n, uint32_t *status, const uint8_t *msm_verdict, uint8_t *out);
 __global__ void k_ipp_prepare(ipp_shape sh, rp_strobe_init init, const uint8_t *proofs, const uint8_t *Gf, const uint8_t *Hf, const uint8_t *P, const uint8_t *Q, const uint8_t *G, const uint8_t *H, uint32_t *scalars, uint32_t *points, uint32_t *status);
 __global__ void k_ipp_verdict(uint32_t n, const uint32_t *status, const uint8_t *msm_status, const uint32_t *msm_out, uint8_t *verdict);
+__global__ void k_aud_prepare(aud_shape sh, const uint32_t *party, const uint8_t *shares, const uint8_t *bit_commitments, const uint8_t *poly_commitments, const uint8_t *challenges, const uint32_t *gens, uint32_t *scalars, uint32_t *points, uint32_t *status);
+__global__ void k_aud_verdict(uint32_t n, const uint32_t *status, const uint8_t *msm_status, const uint32_t *msm_out, uint8_t *verdict);
 __global__ void k_lin_prepare(lin_shape sh, rp_strobe_init init, const uint8_t *proofs, const uint8_t *C, const uint8_t *bvec, const uint8_t *G, const uint8_t *F, const uint8_t *B, uint32_t *scalars, uint32_t *points, uint32_t *status, uint32_t *ts_out, uint32_t *gen_sc);
 __global__ void k_from_uniform(uint32_t n, const uint32_t *uniform, uint32_t *out);
 

@@ -306,6 +306,27 @@ int bpgpu_linear_create_batch(bpgpu_ctx *ctx, size_t n, size_t nbatch, const uin
                               const uint8_t *a, const uint8_t *b, int b_shared, const uint8_t *G, const uint8_t *F,
                               const uint8_t *B, uint8_t *proofs_out, uint8_t *status_out, uint8_t *transcripts_out);
 
+/* ---- the dealer's share audit of the multi-party range-proof protocol ---------------------------
+ * nshares independent calls of
+ *   ProofShare::audit_share(&self, bp_gens, pc_gens, j, &bit_commitment, &bit_challenge, &poly_commitment, &poly_challenge)
+ * (src/range_proof/messages.rs:85-167): what Dealer::receive_shares runs for every party when the aggregated proof does
+ * not verify (src/range_proof/dealer.rs:303-335), to name the parties whose shares are malformed.  Per share: the check
+ * t_x == <l_vec, r_vec> and two multiscalar multiplications (2n + 3 and 5 terms, messages.rs:128-141, 149-160) whose
+ * results must be the identity; generators are the context's (bpgpu_gens_create / _load).
+ *   n           : bitsize of the shares (l_vec.len(): 8, 16, 32 or 64); n > gens_capacity fails every share (check_size)
+ *   party_index : nshares x uint32, the party position j of each share (j >= party_capacity fails that share)
+ *   shares      : nshares x 32*(3 + 2n) bytes: t_x, t_x_blinding, e_blinding, l_vec[n], r_vec[n] (canonical scalars;
+ *                 a non-canonical one fails the share -- upstream they are Scalars by type)
+ *   bit_commitments  : nshares x 96 bytes: V_j, A_j, S_j (compressed; A_j, S_j are RistrettoPoints upstream: an
+ *                 undecodable encoding fails the share here)
+ *   poly_commitments : nshares x 64 bytes: T_1_j, T_2_j
+ *   challenges  : nshares x 96 bytes (y, z, x per share), or 96 bytes when challenges_shared != 0
+ *   verdict     : nshares bytes: BPGPU_VERDICT_OK = Ok(()), BPGPU_VERDICT_VERIFICATION_ERROR = Err(())
+ *   checks_out  : optional nshares x 64 bytes: compress(P_check), compress(t_check) (parity tests) */
+int bpgpu_rangeproof_audit_shares(bpgpu_ctx *ctx, size_t n, size_t nshares, const uint32_t *party_index,
+                                  const uint8_t *shares, const uint8_t *bit_commitments, const uint8_t *poly_commitments,
+                                  const uint8_t *challenges, int challenges_shared, uint8_t *verdict, uint8_t *checks_out);
+
 /* ---- batched inner-product-proof creation (prover side) --------------------------------
  * nbatch independent calls of
  *   InnerProductProof::create(&mut transcript, &Q, G_factors, H_factors, G_vec, H_vec, a_vec, b_vec).to_bytes()

@@ -107,6 +107,19 @@ int oracle_ipp_test_instance(size_t n, const uint8_t *label, size_t label_len, c
                              uint8_t *proof_out, uint8_t P_out[32], uint8_t Q_out[32], uint8_t *G_out, uint8_t *H_out,
                              uint8_t *Gf_out, uint8_t *Hf_out);
 
+/* The MPC messages of prove_multiple (messages.rs:23-56; party.rs, dealer.rs) and the dealer's per-share audit
+ * (ProofShare::audit_share, messages.rs:85-167 -- the blame path of Dealer::receive_shares, dealer.rs:303-335).
+ * oracle_prove_shares: the same proof bytes and commitments as oracle_prove, plus per party j: bit_commitments
+ * (V_j, A_j, S_j: 96 bytes), poly_commitments (T_1_j, T_2_j: 64), shares (t_x, t_x_blinding, e_blinding, l_vec[n],
+ * r_vec[n]: 32 (3 + 2n)), and the challenges (y, z, x).  Not thread-safe (test infrastructure).
+ * oracle_audit_share: 0 = Ok(()), 1 = Err(()); out2 (optional, 64 bytes) = compress(P_check), compress(t_check). */
+int oracle_prove_shares(const oracle_gens *g, const uint64_t *values, const uint8_t *blindings, size_t m, size_t n,
+                        const uint8_t *label, size_t label_len, const uint8_t *seed, size_t seed_len,
+                        uint8_t *proof_out, uint8_t *commitments_out, uint8_t *bit_commitments, uint8_t *poly_commitments,
+                        uint8_t *shares, uint8_t challenges[96]);
+int oracle_audit_share(const oracle_gens *g, size_t n, size_t j, const uint8_t *share, const uint8_t bit_commitment[96],
+                       const uint8_t poly_commitment[64], const uint8_t challenges[96], uint8_t *out2);
+
 /* LinearProof (src/linear_proof.rs; public type, `pub use` lib.rs:36): proves <a, b> = c for secret a and public b.
  * oracle_linear_create = LinearProof::create(transcript, rng, &C, r, a, b, G, &F, &B).to_bytes() (linear_proof.rs:40-173):
  * state = the caller's transcript (208-byte form, not written back); rng = the bytes the rng yields, 64 per

@@ -441,6 +441,9 @@ static void ipp_create(merlin_transcript *t, const ge_p3 *Q, const sc *Hf /* y^-
     free(sv); free(pv);
 }
 
+/* where prove_core leaves the per-party messages of the MPC protocol (messages.rs:23-56), for oracle_prove_shares */
+typedef struct { uint8_t *bit_commitments, *poly_commitments, *shares, *challenges; } share_sink;
+static share_sink *g_share_sink = NULL;   /* (test infrastructure: single-threaded use only) */
 static int prove_core(const oracle_gens *g, const uint64_t *values, const uint8_t *blindings, size_t m, size_t n,
                       merlin_transcript *tp, const uint8_t *seed, size_t seed_len, uint8_t *proof_out, uint8_t *commitments_out);
 int oracle_prove(const oracle_gens *g, const uint64_t *values, const uint8_t *blindings, size_t m, size_t n,
@@ -489,6 +492,10 @@ static int prove_core(const oracle_gens *g, const uint64_t *values, const uint8_
         sv[0] = s_bl[j]; pv[0] = g->B_blinding;
         for (size_t i = 0; i < n; i++) { sv[1 + i] = s_L[j * n + i]; pv[1 + i] = Gj[i]; sv[1 + n + i] = s_R[j * n + i]; pv[1 + n + i] = Hj[i]; }
         ge_p3 Sj; ge_msm_vartime(&Sj, 2 * n + 1, sv, pv);
+        if (g_share_sink) {   /* BitCommitment { V_j, A_j, S_j } (messages.rs:23-28) */
+            uint8_t *bc = g_share_sink->bit_commitments + 96 * j;
+            memcpy(bc, commitments_out + 32 * j, 32); ristretto_compress(bc + 32, &Aj); ristretto_compress(bc + 64, &Sj);
+        }
         ge_add(&A, &A, &Aj); ge_add(&S, &S, &Sj);
     }
     for (size_t j = 0; j < m; j++) merlin_append_message(&t, "V", commitments_out + 32 * j, 32);
@@ -525,6 +532,9 @@ static int prove_core(const oracle_gens *g, const uint64_t *values, const uint8_
         free(ls); free(rs);
         rng_scalar(&rng, &t1b[j]); rng_scalar(&rng, &t2b[j]);
         ge_p3 c1, c2; pedersen_commit(&c1, g, &t1v[j], &t1b[j]); pedersen_commit(&c2, g, &t2v[j], &t2b[j]);
+        if (g_share_sink) {   /* PolyCommitment { T_1_j, T_2_j } (messages.rs:38-42) */
+            ristretto_compress(g_share_sink->poly_commitments + 64 * j, &c1); ristretto_compress(g_share_sink->poly_commitments + 64 * j + 32, &c2);
+        }
         ge_add(&T1, &T1, &c1); ge_add(&T2, &T2, &c2);
     }
     ristretto_compress(po + 64, &T1); ristretto_compress(po + 96, &T2);
@@ -537,12 +547,22 @@ static int prove_core(const oracle_gens *g, const uint64_t *values, const uint8_
         sc_mul(&tt, &x, &t2v[j]); sc_add(&tt, &tt, &t1v[j]); sc_mul(&tt, &x, &tt); sc_add(&tt, &tt, &t0v[j]); sc_add(&t_x, &t_x, &tt);
         sc_mul(&tt, &x, &t2b[j]); sc_add(&tt, &tt, &t1b[j]); sc_mul(&tt, &x, &tt); sc_mul(&tu, &ozz[j], &vbl[j]); sc_add(&tt, &tt, &tu); sc_add(&t_x_bl, &t_x_bl, &tt);
         sc_mul(&tt, &s_bl[j], &x); sc_add(&tt, &tt, &a_bl[j]); sc_add(&e_bl, &e_bl, &tt);
+        sc txj, txbj, ebj;
+        sc_mul(&txj, &x, &t2v[j]); sc_add(&txj, &txj, &t1v[j]); sc_mul(&txj, &x, &txj); sc_add(&txj, &txj, &t0v[j]);
+        sc_mul(&txbj, &x, &t2b[j]); sc_add(&txbj, &txbj, &t1b[j]); sc_mul(&txbj, &x, &txbj); sc_mul(&tu, &ozz[j], &vbl[j]); sc_add(&txbj, &txbj, &tu);
+        sc_mul(&ebj, &s_bl[j], &x); sc_add(&ebj, &ebj, &a_bl[j]);
         for (size_t i = 0; i < n; i++) {
             size_t q = j * n + i;
             sc_mul(&tt, &l1[q], &x); sc_add(&lv[q], &l0[q], &tt);
             sc_mul(&tt, &r1[q], &x); sc_add(&rv[q], &r0[q], &tt);
         }
+        if (g_share_sink) {   /* ProofShare { t_x, t_x_blinding, e_blinding, l_vec, r_vec } (messages.rs:50-56; party.rs:268-311) */
+            uint8_t *sh = g_share_sink->shares + 32 * (3 + 2 * n) * j;
+            sc_tobytes(sh, &txj); sc_tobytes(sh + 32, &txbj); sc_tobytes(sh + 64, &ebj);
+            for (size_t i = 0; i < n; i++) { sc_tobytes(sh + 96 + 32 * i, &lv[j * n + i]); sc_tobytes(sh + 96 + 32 * (n + i), &rv[j * n + i]); }
+        }
     }
+    if (g_share_sink) { sc_tobytes(g_share_sink->challenges, &y); sc_tobytes(g_share_sink->challenges + 32, &z); sc_tobytes(g_share_sink->challenges + 64, &x); }
     sc_tobytes(po + 128, &t_x); sc_tobytes(po + 160, &t_x_bl); sc_tobytes(po + 192, &e_bl);
     append_scalar(&t, "t_x", &t_x); append_scalar(&t, "t_x_blinding", &t_x_bl); append_scalar(&t, "e_blinding", &e_bl);
     sc w; challenge_scalar(&t, "w", &w);
@@ -562,6 +582,88 @@ static int prove_core(const oracle_gens *g, const uint64_t *values, const uint8_
     free(lv); free(rv); free(Hf); free(Gv); free(Hv);
     return 0;
 #undef t
+}
+
+/* ---------------- the MPC messages and the dealer's share audit (messages.rs) ---------------- */
+/* prove_multiple as its parties and dealer run it (mod.rs:234-288, party.rs, dealer.rs), also returning what they exchange:
+ * bit_commitments m x 96 (V_j, A_j, S_j), poly_commitments m x 64 (T_1_j, T_2_j), shares m x 32(3 + 2n)
+ * (t_x, t_x_blinding, e_blinding, l_vec, r_vec), challenges (y, z, x). */
+int oracle_prove_shares(const oracle_gens *g, const uint64_t *values, const uint8_t *blindings, size_t m, size_t n,
+                        const uint8_t *label, size_t label_len, const uint8_t *seed, size_t seed_len,
+                        uint8_t *proof_out, uint8_t *commitments_out, uint8_t *bit_commitments, uint8_t *poly_commitments,
+                        uint8_t *shares, uint8_t challenges[96]) {
+    ge_init();
+    share_sink sk = {bit_commitments, poly_commitments, shares, challenges};
+    merlin_transcript t; merlin_init(&t, label, label_len);
+    g_share_sink = &sk;
+    int rc = prove_core(g, values, blindings, m, n, &t, seed, seed_len, proof_out, commitments_out);
+    g_share_sink = NULL;
+    return rc;
+}
+
+/* ProofShare::audit_share (messages.rs:85-167) for party j: 0 = Ok(()), 1 = Err(()).
+ * out2 (optional, 64 bytes): compress(P_check), compress(t_check) -- all-zero when the share is sound. */
+int oracle_audit_share(const oracle_gens *g, size_t n, size_t j, const uint8_t *share, const uint8_t bit_commitment[96],
+                       const uint8_t poly_commitment[64], const uint8_t challenges[96], uint8_t *out2) {
+    ge_init();
+    if (out2) memset(out2, 0xff, 64);
+    if (n > g->gens_capacity || j >= g->party_capacity) return 1;                           /* check_size (:57-82) */
+    sc y, z, x, t_x, t_x_bl, e_bl, *l = malloc(n * sizeof(sc)), *r = malloc(n * sizeof(sc));
+    int bad = sc_from_canonical_bytes(&y, challenges) | sc_from_canonical_bytes(&z, challenges + 32) | sc_from_canonical_bytes(&x, challenges + 64)
+            | sc_from_canonical_bytes(&t_x, share) | sc_from_canonical_bytes(&t_x_bl, share + 32) | sc_from_canonical_bytes(&e_bl, share + 64);
+    for (size_t i = 0; i < n; i++) bad |= sc_from_canonical_bytes(&l[i], share + 96 + 32 * i) | sc_from_canonical_bytes(&r[i], share + 96 + 32 * (n + i));
+    int rc = 1;
+    if (!bad) do {
+        sc zz, minus_z, z_j, y_jn, y_jn_inv, y_inv, one, two;
+        sc_from_u64(&one, 1); sc_from_u64(&two, 2);
+        sc_mul(&zz, &z, &z); sc_neg(&minus_z, &z);
+        z_j = one; for (size_t i = 0; i < j; i++) sc_mul(&z_j, &z_j, &z);                     /* z^j */
+        y_jn = one; for (size_t i = 0; i < j * n; i++) sc_mul(&y_jn, &y_jn, &y);             /* y^(j n) */
+        sc_invert(&y_jn_inv, &y_jn); sc_invert(&y_inv, &y);
+        sc ip; inner_product(&ip, l, r, n);
+        if (!sc_eq(&t_x, &ip)) break;                                                          /* :112-114 */
+        size_t N = 2 * n + 3;
+        sc *sv = malloc(N * sizeof(sc)); ge_p3 *pv = malloc(N * sizeof(ge_p3));
+        int dec = 0;
+        sv[0] = one; dec |= ristretto_decompress(&pv[0], bit_commitment + 32);                 /* A_j */
+        sv[1] = x; dec |= ristretto_decompress(&pv[1], bit_commitment + 64);                   /* S_j */
+        sc_neg(&sv[2], &e_bl); pv[2] = g->B_blinding;
+        sc exp_2 = one, exp_y_inv = one;
+        for (size_t i = 0; i < n; i++) {
+            sc_sub(&sv[3 + i], &minus_z, &l[i]); pv[3 + i] = g->G[j * g->gens_capacity + i];   /* g_i = -z - l_i */
+            sc f, t0, t1, nr;                                                                   /* h_i (:117-126) */
+            sc_mul(&f, &exp_y_inv, &y_jn_inv);
+            sc_neg(&nr, &r[i]); sc_mul(&t0, &f, &nr);
+            sc_mul(&t1, &zz, &z_j); sc_mul(&t1, &t1, &exp_2); sc_mul(&t1, &f, &t1);
+            sc_add(&sv[3 + n + i], &z, &t0); sc_add(&sv[3 + n + i], &sv[3 + n + i], &t1);
+            pv[3 + n + i] = g->H[j * g->gens_capacity + i];
+            sc_mul(&exp_2, &exp_2, &two); sc_mul(&exp_y_inv, &exp_y_inv, &y_inv);
+        }
+        /* (A_j / S_j are RistrettoPoints in BitCommitment upstream: an undecodable encoding cannot occur there; here it fails the audit) */
+        ge_p3 P_check, t_check;
+        int ok = !dec;
+        if (ok) { ge_msm_vartime(&P_check, N, sv, pv); if (out2) ristretto_compress(out2, &P_check); ok = ge_is_identity(&P_check); }
+        free(sv); free(pv);
+        if (!ok) break;
+        ge_p3 V_j, T1, T2;
+        if (ristretto_decompress(&V_j, bit_commitment)) break;                                 /* :143 */
+        if (ristretto_decompress(&T1, poly_commitment) || ristretto_decompress(&T2, poly_commitment + 32)) break;
+        sc sy, s2, delta, t0, t1, s5[5]; ge_p3 p5[5];
+        sum_of_powers(&sy, &y, n); sum_of_powers(&s2, &two, n);
+        sc_sub(&t0, &z, &zz); sc_mul(&t0, &t0, &sy); sc_mul(&t0, &t0, &y_jn);
+        sc_mul(&t1, &z, &zz); sc_mul(&t1, &t1, &s2); sc_mul(&t1, &t1, &z_j);
+        sc_sub(&delta, &t0, &t1);
+        sc_mul(&s5[0], &zz, &z_j); p5[0] = V_j;
+        s5[1] = x; p5[1] = T1;
+        sc_mul(&s5[2], &x, &x); p5[2] = T2;
+        sc_sub(&s5[3], &delta, &t_x); p5[3] = g->B;
+        sc_neg(&s5[4], &t_x_bl); p5[4] = g->B_blinding;
+        ge_msm_vartime(&t_check, 5, s5, p5);
+        if (out2) ristretto_compress(out2 + 32, &t_check);
+        if (ge_is_identity(&t_check)) rc = 0;
+    } while (0);
+    free(l); free(r);
+    return rc;
 }
 
 /* ---------------- stand-alone inner-product proof (ipp.rs:260-326, 373-407, 433-497) ---------------- */

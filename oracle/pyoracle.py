@@ -81,6 +81,8 @@ def lib():
     L.oracle_ipp_verify.argtypes = [sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.oracle_ipp_test_instance.argtypes = [sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.oracle_ipp_create.argtypes = [sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
+    L.oracle_prove_shares.argtypes = [vp, C.POINTER(C.c_uint64), u8p, sz, sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p]
+    L.oracle_audit_share.argtypes = [vp, sz, sz, u8p, u8p, u8p, u8p, u8p]
     L.oracle_linear_create.argtypes = [sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.oracle_linear_verify.argtypes = [sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.oracle_msm_batch.restype = C.c_double
@@ -297,3 +299,24 @@ def linear_test_instance(n, seed, label=b"linearprooftest"):
     rc, proof = linear_create(n, st, rng, Cc, r, a, b, Gc[:32 * n], Bp, Bb)
     assert rc == 0
     return dict(n=n, proof=proof, C=Cc, G=Gc[:32 * n], F=Bp, B=Bb, a=a, b=b, r=r, rng=rng, label=label)
+
+
+def prove_shares(gens, values, blindings, n, label, seed):
+    """prove_multiple as parties + dealer run it, with the messages they exchange (messages.rs): returns a dict with proof,
+    commitments, bit_commitments (m x 96), poly_commitments (m x 64), shares (m x 32 (3 + 2n)), challenges (y, z, x)."""
+    m = len(values)
+    lg = (n * m).bit_length() - 1
+    bufs = dict(proof=C.create_string_buffer(32 * (9 + 2 * lg)), commitments=C.create_string_buffer(32 * m), bit_commitments=C.create_string_buffer(96 * m),
+                poly_commitments=C.create_string_buffer(64 * m), shares=C.create_string_buffer(32 * (3 + 2 * n) * m), challenges=C.create_string_buffer(96))
+    va = (C.c_uint64 * m)(*values)
+    rc = lib().oracle_prove_shares(gens.h, va, blindings, m, n, label, len(label), seed, len(seed), bufs["proof"], bufs["commitments"],
+                                   bufs["bit_commitments"], bufs["poly_commitments"], bufs["shares"], bufs["challenges"])
+    assert rc == 0, rc
+    return {k: v.raw for k, v in bufs.items()}
+
+
+def audit_share(gens, n, j, share, bit_commitment, poly_commitment, challenges):
+    """ProofShare::audit_share (messages.rs:85-167): (0 Ok / 1 Err, compress(P_check) + compress(t_check))"""
+    out = C.create_string_buffer(64)
+    rc = lib().oracle_audit_share(gens.h, n, j, share, bit_commitment, poly_commitment, challenges, out)
+    return rc, out.raw

@@ -11,6 +11,7 @@
 #include "../../bulletproofs_amd/csrc/horner_quad.h"
 #include "../../bulletproofs_amd/csrc/ipp.h"
 #include "../../bulletproofs_amd/csrc/linear.h"
+#include "../../bulletproofs_amd/csrc/audit.h"
 #include "../../bulletproofs_amd/csrc/scinv.h"
 #include "../../bulletproofs_amd/csrc/rlc.h"
 #include "../../bulletproofs_amd/csrc/bucket.h"
@@ -508,6 +509,26 @@ int h_lin_verify_fixed(uint32_t W, uint32_t n, uint32_t nbatch, const uint8_t *p
     if (rc) return rc;
     for (uint32_t p = 0; p < nbatch; p++) ipp_verdict_thread(p, status.data(), mst.data(), (const uint32_t *)out.data(), verdict_out);
     if (msm_out) memcpy(msm_out, out.data(), (size_t)nbatch * 32);
+    return 0;
+}
+
+// ProofShare::audit_share, lane by lane (audit.h): front end -> the two MSMs per share through the variable-base pipeline -> verdict.
+// gens: [B_blinding, B, G (party-major, capacity each), H (...)] encodings.
+int h_audit_shares(uint32_t n, uint32_t nshares, uint32_t gens_capacity, uint32_t party_capacity, const uint8_t *gens, const uint32_t *party,
+                   const uint8_t *shares, const uint8_t *bitc, const uint8_t *polyc, const uint8_t *chal, uint32_t chal_shared, uint8_t *verdict_out,
+                   uint8_t *checks_out) {
+    aud_shape sh; sh.n = n; sh.lg_n = 0; while ((1u << sh.lg_n) < n) sh.lg_n++;
+    sh.nshares = nshares; sh.gens_capacity = gens_capacity; sh.party_capacity = party_capacity; sh.chal_shared = chal_shared;
+    const uint32_t per = 2 * n + 8;
+    std::vector<uint32_t> scal((size_t)nshares * per * 8 + 8, 0), pts(scal.size(), 0), status(nshares + 1, 0), nt(2 * nshares);
+    for (uint32_t s = 0; s < nshares; s++) {
+        aud_prepare_thread(s, sh, party, shares, bitc, polyc, chal, (const uint32_t *)gens, scal.data(), pts.data(), status.data());
+        nt[2 * s] = 2 * n + 3; nt[2 * s + 1] = 5;
+    }
+    std::vector<uint8_t> out((size_t)nshares * 64 + 64), mst(2 * nshares + 1);
+    h_msm_vb(2 * nshares, nt.data(), (const uint8_t *)scal.data(), (const uint8_t *)pts.data(), out.data(), mst.data());
+    for (uint32_t s = 0; s < nshares; s++) aud_verdict_thread(s, status.data(), mst.data(), (const uint32_t *)out.data(), verdict_out);
+    if (checks_out) memcpy(checks_out, out.data(), (size_t)nshares * 64);
     return 0;
 }
 

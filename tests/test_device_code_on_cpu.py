@@ -547,3 +547,52 @@ def test_util_rs_scalar_tests_on_the_device_code(H, oracle):
         H.h_sum_of_powers_pow2(le(10), lg, o)
         n = 1 << lg
         assert int.from_bytes(o.raw, "little") == sum(pow(10, i, ell) for i in range(n)) % ell == (int("1" * n) % ell), n
+
+
+def _share_cases(oracle, g, n, m, tag):
+    """an honest aggregation of m parties and what its dealer would audit: returns (party indices, shares, bit commitments, poly
+    commitments, challenges, expected verdicts) with a few dishonest variations appended"""
+    vals = [((1 << n) - 1 - 977 * i) % (1 << n) for i in range(m)]
+    bl = b"".join(hashlib.shake_256(b"%s-bl%d" % (tag, i)).digest(31) + b"\x00" for i in range(m))
+    r = oracle.prove_shares(g, vals, bl, n, b"mpc audit", tag)
+    sl = 32 * (3 + 2 * n)
+    S = [r["shares"][sl * j:sl * (j + 1)] for j in range(m)]
+    BC = [r["bit_commitments"][96 * j:96 * j + 96] for j in range(m)]
+    PC = [r["poly_commitments"][64 * j:64 * j + 64] for j in range(m)]
+    idx, sh, bc, pc = list(range(m)), list(S), list(BC), list(PC)
+
+    def add(j, s_, b_, p_):
+        idx.append(j); sh.append(bytes(s_)); bc.append(bytes(b_)); pc.append(bytes(p_))
+    t = bytearray(S[0]); t[96 + 7] ^= 1; add(0, t, BC[0], PC[0])                       # l_vec tampered: t_x != <l, r>
+    t = bytearray(S[0]); t[40] ^= 1; add(0, t, BC[0], PC[0])                           # t_x_blinding tampered: t_check fails
+    t = bytearray(S[0]); t[70] ^= 1; add(0, t, BC[0], PC[0])                           # e_blinding tampered: P_check fails
+    add(0, S[0], BC[0], PC[0][32:] + PC[0][:32])                                       # T_1 and T_2 swapped
+    add(0, S[0], BC[0][:32] + BC[0][64:] + BC[0][32:64], PC[0])                        # A_j and S_j swapped
+    t = bytearray(S[0]); t[0:32] = b"\xff" * 32; add(0, t, BC[0], PC[0])               # t_x not canonical
+    if m > 1:
+        add(1, S[0], BC[0], PC[0])                                                     # party 0's share audited as party 1
+    add(m + 50, S[0], BC[0], PC[0])                                                    # j >= party_capacity (check_size)
+    return idx, sh, bc, pc, r["challenges"], [0] * m + [1] * (len(idx) - m)
+
+
+@pytest.mark.parametrize("n,m", [(8, 1), (16, 4), (64, 2)])
+def test_share_audit_lane_by_lane(H, oracle, n, m):
+    """audit.h (ProofShare::audit_share, messages.rs:85-167) against the oracle's restatement: verdicts and both check points,
+    for the honest shares of an m-party aggregation and dishonest variations of them"""
+    cap, parties = 64, 4
+    g = oracle.Gens(cap, parties)
+    Gc, Hc, Bp, Bb = g.export()
+    gens = Bb + Bp + Gc + Hc
+    idx, sh, bc, pc, chal, expect = _share_cases(oracle, g, n, m, b"haud-%d-%d" % (n, m))
+    ns = len(idx)
+    vd, chk = C.create_string_buffer(ns), C.create_string_buffer(64 * ns)
+    pi = (C.c_uint32 * ns)(*idx)
+    assert H.h_audit_shares(n, ns, cap, parties, gens, pi, b"".join(sh), b"".join(bc), b"".join(pc), chal, 1, vd, chk) == 0
+    assert list(vd.raw) == expect
+    for k in range(ns):
+        rc, out = oracle.audit_share(g, n, idx[k], sh[k], bc[k], pc[k], chal)
+        assert rc == expect[k], (k, rc)
+        if out[:32] != b"\xff" * 32:
+            assert chk.raw[64 * k:64 * k + 32] == out[:32], k
+        if out[32:] != b"\xff" * 32:
+            assert chk.raw[64 * k + 32:64 * k + 64] == out[32:], k
