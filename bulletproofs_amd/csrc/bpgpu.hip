@@ -1728,6 +1728,27 @@ extern "C" int bpgpu_rangeproof_verify_rlc(bpgpu_ctx *c, size_t n, size_t m, siz
 // ============================================================================
 // stand-alone inner-product proofs
 // ============================================================================
+// Transcript::new(label) [or the caller's 208-byte state] followed by innerproduct_domain_sep(n) (transcript.rs:50-53): the
+// batch-invariant prefix of the stand-alone inner-product and linear proofs, replayed once on the host
+static void ipp_domain_sep_state(uint8_t st0[BPGPU_TRANSCRIPT_BYTES], const uint8_t *label, size_t label_len, const uint8_t *shared_ts, size_t n,
+                                 rp_strobe_init *init) {
+    if (shared_ts) memcpy(st0, shared_ts, BPGPU_TRANSCRIPT_BYTES);
+    else bpgpu_transcript_new(label, label_len, st0);
+    uint32_t w[50];
+    strobe t;
+    ts_to_strobe(t, w, st0);
+    const uint8_t ipp[6] = {'i', 'p', 'p', ' ', 'v', '1'}, ln[1] = {'n'};
+    merlin_append_message(t, DOM_SEP, 7, ipp, 6);
+    merlin_append_u64(t, ln, 1, n);
+    ts_from_strobe(st0, t);
+    if (init) {
+        memcpy(init->w, w, 200);
+        init->pos = t.pos;
+        init->pos_begin = t.pos_begin;
+        init->cur_flags = t.cur_flags;
+    }
+}
+
 static int ipp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t nbatch, const void *d_proofs, size_t proof_len, const uint8_t *label,
                                  size_t label_len, const uint8_t *shared_ts, const void *d_Gf, const void *d_Hf, const void *d_P,
                                  const void *d_Q, const void *d_G, const void *d_H, int bases_shared, void *d_verdict, void *d_msm_out,
@@ -1779,20 +1800,9 @@ static int ipp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t nbatch, const vo
     char *d_sc = c->ipp_buf, *d_pt = d_sc + sz_terms, *d_stat = d_pt + sz_terms, *d_mst = d_stat + sz_st, *d_out = d_mst + sz_b;
     HIPCHK(c, hipMemsetAsync(d_sc, 0, 2 * sz_terms + sz_st, s));   // scalars, points, status
     rp_strobe_init init;
-    {   // Transcript::new(label) [or the caller's transcript] + innerproduct_domain_sep(n) (transcript.rs:50-53), once for the batch
+    {
         uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
-        if (shared_ts) memcpy(st0, shared_ts, BPGPU_TRANSCRIPT_BYTES);
-        else bpgpu_transcript_new(label, label_len, st0);
-        uint32_t w[50];
-        strobe t;
-        ts_to_strobe(t, w, st0);
-        const uint8_t ipp[6] = {'i', 'p', 'p', ' ', 'v', '1'}, ln[1] = {'n'};
-        merlin_append_message(t, DOM_SEP, 7, ipp, 6);
-        merlin_append_u64(t, ln, 1, n);
-        memcpy(init.w, w, 200);
-        init.pos = t.pos;
-        init.pos_begin = t.pos_begin;
-        init.cur_flags = t.cur_flags;
+        ipp_domain_sep_state(st0, label, label_len, shared_ts, n, &init);
     }
     const uint32_t nb32 = (uint32_t)nbatch;
     LAUNCH(c, s, "ipp_prepare", k_ipp_prepare, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, init, (const uint8_t *)d_proofs, (const uint8_t *)d_Gf,
@@ -1934,20 +1944,9 @@ static int lin_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t nbatch, const vo
     HIPCHK(c, hipMemsetAsync(d_sc, 0, 2 * sz_terms + sz_st, s));   // scalars, points, status
     if (fixed) HIPCHK(c, hipMemsetAsync(d_gen, 0, sz_gen, s));
     rp_strobe_init init;
-    {   // Transcript::new(label) [or the caller's transcript] + innerproduct_domain_sep(n) (linear_proof.rs:196), once for the batch
+    {
         uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
-        if (shared_ts) memcpy(st0, shared_ts, BPGPU_TRANSCRIPT_BYTES);
-        else bpgpu_transcript_new(label, label_len, st0);
-        uint32_t w[50];
-        strobe t;
-        ts_to_strobe(t, w, st0);
-        const uint8_t ipp[6] = {'i', 'p', 'p', ' ', 'v', '1'}, ln[1] = {'n'};
-        merlin_append_message(t, DOM_SEP, 7, ipp, 6);
-        merlin_append_u64(t, ln, 1, n);
-        memcpy(init.w, w, 200);
-        init.pos = t.pos;
-        init.pos_begin = t.pos_begin;
-        init.cur_flags = t.cur_flags;
+        ipp_domain_sep_state(st0, label, label_len, shared_ts, n, &init);
     }
     const uint32_t nb32 = (uint32_t)nbatch;
     LAUNCH(c, s, "lin_prepare", k_lin_prepare, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, init, (const uint8_t *)d_proofs, (const uint8_t *)d_C,
@@ -2229,15 +2228,7 @@ extern "C" int bpgpu_ipp_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, con
     memcpy(h + 4 * sz_v + sz_q + sz_base, H, (bases_shared ? 1 : nbatch) * n * 32);
     {   // every proof's transcript after innerproduct_domain_sep(n) (transcript.rs:50-53)
         uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
-        if (shared_transcript) memcpy(st0, shared_transcript, TS);
-        else bpgpu_transcript_new(label, label_len, st0);
-        uint32_t w[50];
-        strobe t;
-        ts_to_strobe(t, w, st0);
-        const uint8_t ipp[6] = {'i', 'p', 'p', ' ', 'v', '1'}, ln[1] = {'n'};
-        merlin_append_message(t, DOM_SEP, 7, ipp, 6);
-        merlin_append_u64(t, ln, 1, n);
-        ts_from_strobe(st0, t);
+        ipp_domain_sep_state(st0, label, label_len, shared_transcript, n, nullptr);
         for (size_t p = 0; p < nbatch; p++) memcpy(h + 4 * sz_v + sz_q + 2 * sz_base + p * TS, st0, TS);
     }
     HIPCHK(c, hipMemcpyAsync(c->io_dev, h, sz_in, hipMemcpyHostToDevice, s));
@@ -2310,15 +2301,7 @@ extern "C" int bpgpu_linear_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
         else if ((rc = os_random(c, h_rng, nbatch * nd * 64)) != 0) return rc;   // Scalar::random(&mut thread_rng())
         // every proof's transcript after innerproduct_domain_sep(n) (linear_proof.rs:73)
         uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
-        if (shared_transcript) memcpy(st0, shared_transcript, TS);
-        else bpgpu_transcript_new(label, label_len, st0);
-        uint32_t w[50];
-        strobe t;
-        ts_to_strobe(t, w, st0);
-        const uint8_t ipp[6] = {'i', 'p', 'p', ' ', 'v', '1'}, ln[1] = {'n'};
-        merlin_append_message(t, DOM_SEP, 7, ipp, 6);
-        merlin_append_u64(t, ln, 1, n);
-        ts_from_strobe(st0, t);
+        ipp_domain_sep_state(st0, label, label_len, shared_transcript, n, nullptr);
         for (size_t p = 0; p < nbatch; p++) memcpy(h_rng + sz_rng + p * TS, st0, TS);
     }
     HIPCHK(c, hipMemcpyAsync(c->io_dev, h, sz_in, hipMemcpyHostToDevice, s));
