@@ -1728,6 +1728,19 @@ extern "C" int bpgpu_rangeproof_verify_rlc(bpgpu_ctx *c, size_t n, size_t m, siz
 // ============================================================================
 // stand-alone inner-product proofs
 // ============================================================================
+// working set of the inner-product / linear / audit entry points (separate from the arena, which the MSMs they call claim):
+// grown on demand, never shrunk; a call that grows it first waits for everything that may still read the old block
+static int ipp_reserve(bpgpu_ctx *c, size_t need) {
+    if (c->ipp_cap >= need) return BPGPU_OK;
+    HIPCHK(c, hipDeviceSynchronize());
+    if (c->ipp_buf) HIPCHK(c, hipFree(c->ipp_buf));
+    c->ipp_buf = nullptr;
+    c->ipp_cap = 0;
+    if (hipMalloc((void **)&c->ipp_buf, need + need / 4) != hipSuccess) return fail(c, BPGPU_ERR_HIP, "out of device memory (%zu bytes of working set)", need + need / 4);
+    c->ipp_cap = need + need / 4;
+    return BPGPU_OK;
+}
+
 // Transcript::new(label) [or the caller's 208-byte state] followed by innerproduct_domain_sep(n) (transcript.rs:50-53): the
 // batch-invariant prefix of the stand-alone inner-product and linear proofs, replayed once on the host
 static void ipp_domain_sep_state(uint8_t st0[BPGPU_TRANSCRIPT_BYTES], const uint8_t *label, size_t label_len, const uint8_t *shared_ts, size_t n,
@@ -1789,13 +1802,9 @@ static int ipp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t nbatch, const vo
     // claims the arena
     const size_t sz_terms = align_up(nbatch * N * 32 + 64), sz_st = align_up(nbatch * 4), sz_b = align_up(nbatch + 64), sz_o = align_up(nbatch * 32 + 64);
     const size_t need = 2 * sz_terms + sz_st + sz_b + sz_o;
-    if (c->ipp_cap < need) {
-        HIPCHK(c, hipDeviceSynchronize());
-        if (c->ipp_buf) HIPCHK(c, hipFree(c->ipp_buf));
-        c->ipp_buf = nullptr;
-        c->ipp_cap = 0;
-        HIPCHK(c, hipMalloc((void **)&c->ipp_buf, need + need / 4));
-        c->ipp_cap = need + need / 4;
+    {
+        const int rcr = ipp_reserve(c, need);
+        if (rcr) return rcr;
     }
     char *d_sc = c->ipp_buf, *d_pt = d_sc + sz_terms, *d_stat = d_pt + sz_terms, *d_mst = d_stat + sz_st, *d_out = d_mst + sz_b;
     HIPCHK(c, hipMemsetAsync(d_sc, 0, 2 * sz_terms + sz_st, s));   // scalars, points, status
@@ -1931,13 +1940,9 @@ static int lin_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t nbatch, const vo
     const size_t sz_terms = align_up(nbatch * N * 32 + 64), sz_st = align_up(nbatch * 4), sz_b = align_up(nbatch + 64), sz_o = align_up(nbatch * 32 + 64);
     const size_t sz_gen = fixed ? align_up(nbatch * (sh.n + 2) * 32 + 64) : 0;
     const size_t need = 2 * sz_terms + sz_st + sz_b + sz_o + sz_gen;
-    if (c->ipp_cap < need) {
-        HIPCHK(c, hipDeviceSynchronize());
-        if (c->ipp_buf) HIPCHK(c, hipFree(c->ipp_buf));
-        c->ipp_buf = nullptr;
-        c->ipp_cap = 0;
-        HIPCHK(c, hipMalloc((void **)&c->ipp_buf, need + need / 4));
-        c->ipp_cap = need + need / 4;
+    {
+        const int rcr = ipp_reserve(c, need);
+        if (rcr) return rcr;
     }
     char *d_sc = c->ipp_buf, *d_pt = d_sc + sz_terms, *d_stat = d_pt + sz_terms, *d_mst = d_stat + sz_st, *d_out = d_mst + sz_b;
     char *d_gen = fixed ? d_out + sz_o : nullptr;
@@ -2082,14 +2087,8 @@ extern "C" int bpgpu_rangeproof_audit_shares(bpgpu_ctx *c, size_t n, size_t nsha
         const size_t per = 2 * n + 8;
         const size_t sz_terms = align_up(nshares * per * 32 + 64), sz_st = align_up(nshares * 4), sz_b = align_up(2 * nshares + 64);
         const size_t need = 2 * sz_terms + sz_st + sz_b;
-        if (c->ipp_cap < need) {
-            if (hipDeviceSynchronize() != hipSuccess) { rc = fail(c, BPGPU_ERR_HIP, "synchronize failed"); break; }
-            if (c->ipp_buf) hipFree(c->ipp_buf);
-            c->ipp_buf = nullptr;
-            c->ipp_cap = 0;
-            if (hipMalloc((void **)&c->ipp_buf, need + need / 4) != hipSuccess) { rc = fail(c, BPGPU_ERR_HIP, "out of device memory (share audit working set)"); break; }
-            c->ipp_cap = need + need / 4;
-        }
+        rc = ipp_reserve(c, need);
+        if (rc) break;
         char *d_sc = c->ipp_buf, *d_pt = d_sc + sz_terms, *d_stat = d_pt + sz_terms, *d_mst = d_stat + sz_st;
         if (hipMemsetAsync(d_sc, 0, 2 * sz_terms + sz_st, s) != hipSuccess) { rc = fail(c, BPGPU_ERR_HIP, "memset failed"); break; }
         aud_shape sh;
@@ -2139,13 +2138,9 @@ static int ippc_core(bpgpu_ctx *c, hipStream_t s, size_t n, size_t k, size_t nba
     const size_t N = n + 1, w_v = align_up(nbatch * n * 32), w_u = align_up(nbatch * 32), w_terms = align_up(2 * nbatch * N * 32 + 64),
                  w_out = align_up(2 * nbatch * 32), w_st = align_up(2 * nbatch + 64), w_status = align_up(nbatch * 4);
     const size_t need = 4 * w_v + 2 * w_u + 2 * w_terms + w_out + w_st + w_status;
-    if (c->ipp_cap < need) {
-        HIPCHK(c, hipDeviceSynchronize());
-        if (c->ipp_buf) HIPCHK(c, hipFree(c->ipp_buf));
-        c->ipp_buf = nullptr;
-        c->ipp_cap = 0;
-        HIPCHK(c, hipMalloc((void **)&c->ipp_buf, need + need / 4));
-        c->ipp_cap = need + need / 4;
+    {
+        const int rcr = ipp_reserve(c, need);
+        if (rcr) return rcr;
     }
     char *wb = c->ipp_buf;
     uint32_t *w_a = (uint32_t *)wb, *w_b = (uint32_t *)(wb + w_v), *w_G = (uint32_t *)(wb + 2 * w_v), *w_H = (uint32_t *)(wb + 3 * w_v);
@@ -2313,14 +2308,8 @@ extern "C" int bpgpu_linear_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
                      w_terms = align_up(std::max(2 * nbatch * (from_gens ? NS : N), nbatch * NS) * 32 + 64), w_out = align_up(2 * nbatch * 32), w_st = align_up(2 * nbatch + 64),
                      w_status = align_up(nbatch * 4);
         const size_t need = 3 * w_v + 3 * w_u + w_d + 2 * w_terms + w_out + w_st + w_status;
-        if (c->ipp_cap < need) {
-            if (hipDeviceSynchronize() != hipSuccess) { rc = fail(c, BPGPU_ERR_HIP, "synchronize failed"); break; }
-            if (c->ipp_buf) hipFree(c->ipp_buf);
-            c->ipp_buf = nullptr;
-            c->ipp_cap = 0;
-            if (hipMalloc((void **)&c->ipp_buf, need + need / 4) != hipSuccess) { rc = fail(c, BPGPU_ERR_HIP, "out of device memory (linear prover working set)"); break; }
-            c->ipp_cap = need + need / 4;
-        }
+        rc = ipp_reserve(c, need);
+        if (rc) break;
         char *wb = c->ipp_buf;
         uint32_t *w_a = (uint32_t *)wb, *w_b = (uint32_t *)(wb + w_v), *w_G = (uint32_t *)(wb + 2 * w_v);
         uint32_t *w_r = (uint32_t *)(wb + 3 * w_v), *w_x = (uint32_t *)((char *)w_r + w_u), *w_xi = (uint32_t *)((char *)w_x + w_u);
