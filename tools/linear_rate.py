@@ -7,7 +7,10 @@ sys.path[:0] = [ROOT, os.path.join(ROOT, "oracle")]
 import bulletproofs_amd as bp
 import pyoracle as O
 ELL = 2 ** 252 + 27742317777372353535851937790883648493
-for n, nb in ((16, 4096), (64, 1024), (64, 4096), (256, 1024)):
+SHAPES = ((16, 4096), (64, 1024), (64, 4096), (256, 1024))
+if len(sys.argv) == 3:          # one shape only: `linear_rate.py 64 4096` (e.g. under rocprofv3)
+    SHAPES = ((int(sys.argv[1]), int(sys.argv[2])),)
+for n, nb in SHAPES:
     base = O.linear_test_instance(n, b"rate%d" % n)
     lg = n.bit_length() - 1
     stream = hashlib.shake_256(b"rate-in%d" % n).digest(64 * (n + 1) * 64)
