@@ -29,12 +29,19 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(RP_
         st.w = lds + threadIdx.x;
         st.stride = RP_BLOCK;
         if (p < sh.nproofs) {
+            // (BP_EXP_*: timing experiments only -- tools/stage1_breakdown.py builds variants with one role compiled out)
+#ifndef BP_EXP_NOTR
             rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields, status, ts_flags, ts_in, ts_out);
+#endif
+#ifndef BP_EXP_NOSC
             if (!sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64, bk_c);
+#endif
         }
     } else {
         const uint32_t t = (blockIdx.x - n_tr) * RP_BLOCK + threadIdx.x;
+#ifndef BP_EXP_NOPT
         if (t < sh.nproofs * sh.U) rp_points_thread(t, sh, proofs, commitments, tab, status, bk_pts);
+#endif
     }
 }
 

@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
 """Dev tool (GPU box): duration of launch 1 (k_rp_stage1) at cfg2, one stream, for library builds with parts of the launch
 compiled out (ab/exp_*.so, built with -DBP_EXP_NOTR / NOSC / NOPT / NOKECCAK: timing experiments only -- their verdicts are
-meaningless).  Usage: stage1_breakdown.py <variant.so> ..."""
+meaningless).  Usage: stage1_breakdown.py <variant.so> ...
+Building a variant (in bulletproofs_amd/csrc, after a normal build):
+  hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DBP_EXP_NOSC -DBP_EXP_NOPT -c -o /tmp/k_rp1_onlytr.o k_rp1.hip
+  hipcc --offload-arch=gfx950 -shared -fPIC -o ../../ab/exp_onlytr.so $(ls build/*.o | grep -v k_rp1.o) /tmp/k_rp1_onlytr.o"""
 import os, shutil, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 LIB = os.path.join(ROOT, "bulletproofs_amd", "csrc", "libbpgpu.so")
