@@ -112,6 +112,10 @@ int oracle_ipp_test_instance(size_t n, const uint8_t *label, size_t label_len, c
  * oracle_prove_shares: the same proof bytes and commitments as oracle_prove, plus per party j: bit_commitments
  * (V_j, A_j, S_j: 96 bytes), poly_commitments (T_1_j, T_2_j: 64), shares (t_x, t_x_blinding, e_blinding, l_vec[n],
  * r_vec[n]: 32 (3 + 2n)), and the challenges (y, z, x).  Not thread-safe (test infrastructure).
+ * Pinning: the reference holds no fixed vector for these messages (its MPC tests are random round trips, mod.rs:726-841);
+ * the share export is part of the prover that is pinned through the 16 golden proofs' verifier (its proofs verify), and
+ * the audit is pinned by consistency: the honest shares of such a proof audit to two identity points, the shares of a party
+ * that committed to an out-of-range value do not (the reference's detect_dishonest_party_during_aggregation scenario).
  * oracle_audit_share: 0 = Ok(()), 1 = Err(()); out2 (optional, 64 bytes) = compress(P_check), compress(t_check). */
 int oracle_prove_shares(const oracle_gens *g, const uint64_t *values, const uint8_t *blindings, size_t m, size_t n,
                         const uint8_t *label, size_t label_len, const uint8_t *seed, size_t seed_len,
