@@ -245,3 +245,31 @@ def test_linear_proof_c_equals_twin(oracle, n):
         assert oracle.linear_verify(n, inst["proof"][:cut] if cut < len(inst["proof"]) else inst["proof"] + bytes(32), st, inst["C"], inst["G"],
                                     inst["F"], inst["B"], inst["b"])[0] == 2
     assert oracle.linear_create(3, st, inst["rng"] * 2, inst["C"], inst["r"], inst["a"] * 3, inst["b"] * 3, inst["G"] * 3, inst["F"], inst["B"])[0] == 5
+
+
+def test_share_audit_oracle_is_consistent_with_the_pinned_prover_and_verifier(oracle):
+    """messages.rs:85-167 has no fixed vectors upstream: the oracle's audit is pinned by consistency.  The shares exported by the
+    prover (whose aggregated proof the golden-vector-pinned verifier accepts) audit to two identity points; the reference's own
+    scenario (mod.rs:726-799: parties 1 and 3 commit to 64-bit values at n = 32) names exactly those two; a share audited under
+    the wrong party index, or with any field touched, fails."""
+    g = oracle.Gens(64, 4)
+    n, m = 32, 4
+    bl = b"".join(hashlib.shake_256(b"ob%d" % i).digest(31) + b"\x00" for i in range(m))
+    sl = 32 * (3 + 2 * n)
+    honest = oracle.prove_shares(g, [7, 1 << 31, 0xffffffff, 12345], bl, n, b"AggregatedRangeProofTest", b"seed-a")
+    rng64 = hashlib.shake_256(b"audit-c").digest(64)          # (an all-zero rng would make c = 0 and switch the t(x) check off)
+    assert oracle.verify(g, honest["proof"], honest["commitments"], n, b"AggregatedRangeProofTest", rng64)[0] == 0
+    assert honest["proof"] == oracle.prove(g, [7, 1 << 31, 0xffffffff, 12345], bl, n, b"AggregatedRangeProofTest", b"seed-a")[0]
+    part = lambda r, j: (r["shares"][sl * j:sl * (j + 1)], r["bit_commitments"][96 * j:96 * j + 96], r["poly_commitments"][64 * j:64 * j + 64])
+    for j in range(m):
+        rc, out = oracle.audit_share(g, n, j, *part(honest, j), honest["challenges"])
+        assert rc == 0 and out == bytes(64)
+        assert oracle.audit_share(g, n, (j + 1) % m, *part(honest, j), honest["challenges"])[0] == 1
+        s, b, p_ = part(honest, j)
+        for off in (5, 40, 70, 96 + 9, 96 + 32 * n + 3):
+            t = bytearray(s)
+            t[off] ^= 1
+            assert oracle.audit_share(g, n, j, bytes(t), b, p_, honest["challenges"])[0] == 1
+    bad = oracle.prove_shares(g, [7, (1 << 63) + 5, 9, (1 << 40) + 1], bl, n, b"AggregatedRangeProofTest", b"seed-b")
+    assert oracle.verify(g, bad["proof"], bad["commitments"], n, b"AggregatedRangeProofTest", rng64)[0] == 1
+    assert [j for j in range(m) if oracle.audit_share(g, n, j, *part(bad, j), bad["challenges"])[0] != 0] == [1, 3]
