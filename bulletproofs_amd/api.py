@@ -85,6 +85,17 @@ class BulletproofGens:
         return BulletproofGensShare(self, j)
 
 
+    def commit(self, value, blinding):
+        """PedersenGens::commit(value, blinding) (generators.rs:38-42) with this context's bases: value B + blinding B_blinding,
+        compressed.  value: int or 32-byte scalar; blinding: 32-byte scalar.  (Variable time on the GPU, unlike the reference's
+        constant-time multiscalar_mul.)"""
+        v = value.to_bytes(32, "little") if isinstance(value, int) else bytes(value)
+        _, _, B, Bb = self.ctx.gens_export()
+        out, st = self.ctx.msm_batch([2], v + bytes(blinding), B + Bb)
+        if st != bytes(1):
+            raise ValueError("scalars must be canonical")
+        return out
+
     def _check_pedersen(self, pc_gens):
         """The verifier multiplies by pc_gens.B / B_blinding (mod.rs:439-440); the device tables hold the bases this
         BulletproofGens was created with.  A different PedersenGens must be loaded with Context.gens_load."""
@@ -178,6 +189,16 @@ class RangeProof:
     def prove_single_with_rng(bp_gens, pc_gens, transcript, v, v_blinding, n, rng_bytes=None):
         proof, coms = RangeProof.prove_multiple_with_rng(bp_gens, pc_gens, transcript, [v], [v_blinding], n, rng_bytes)
         return proof, coms[0]
+
+    @staticmethod
+    def prove_multiple(bp_gens, pc_gens, transcript, values, blindings, n):
+        """RangeProof::prove_multiple (mod.rs:290-311): prove_multiple_with_rng with thread_rng() -- here the OS CSPRNG"""
+        return RangeProof.prove_multiple_with_rng(bp_gens, pc_gens, transcript, values, blindings, n, None)
+
+    @staticmethod
+    def prove_single(bp_gens, pc_gens, transcript, v, v_blinding, n):
+        """RangeProof::prove_single (mod.rs:141-158)"""
+        return RangeProof.prove_single_with_rng(bp_gens, pc_gens, transcript, v, v_blinding, n, None)
 
     def verify_multiple_with_rng(self, bp_gens, pc_gens, transcript, value_commitments, n, rng64):
         """Ok(()) -> returns None; Err(e) -> raises e.  rng64 = the 64 bytes Scalar::random(rng) would draw (mod.rs:396);

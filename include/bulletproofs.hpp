@@ -84,6 +84,20 @@ class BulletproofGens {
         if (bpgpu_gens_export(ctx_.get(), nullptr, nullptr, pc.B.data(), pc.B_blinding.data()) != BPGPU_OK) throw GpuError(bpgpu_last_error(ctx_.get()));
         return pc;
     }
+    // PedersenGens::commit(value, blinding) (generators.rs:38-42) with this context's bases, compressed (variable time on the GPU)
+    CompressedRistretto commit(const ScalarBytes &value, const ScalarBytes &blinding) const {
+        const PedersenGens pc = pedersen();
+        uint8_t sc[64], pt[64], status = 0;
+        std::memcpy(sc, value.data(), 32);
+        std::memcpy(sc + 32, blinding.data(), 32);
+        std::memcpy(pt, pc.B.data(), 32);
+        std::memcpy(pt + 32, pc.B_blinding.data(), 32);
+        const uint32_t nt = 2;
+        CompressedRistretto out{};
+        if (bpgpu_msm_batch(ctx_.get(), 1, &nt, sc, pt, out.data(), &status) != BPGPU_OK) throw GpuError(bpgpu_last_error(ctx_.get()));
+        if (status != 0) throw std::invalid_argument("commit: scalars must be canonical");
+        return out;
+    }
     // BulletproofGens::increase_capacity (generators.rs:177-204): no-op unless larger; the device tables are rebuilt
     void increase_capacity(size_t new_capacity) {
         if (gens_capacity >= new_capacity) return;
@@ -215,6 +229,16 @@ class RangeProof {
                                                                             const uint8_t *rng_bytes = nullptr) {
         auto r = prove_multiple_with_rng(bp_gens, pc_gens, transcript, {v}, {v_blinding}, n, rng_bytes);
         return {r.first, r.second[0]};
+    }
+    // prove_multiple / prove_single (mod.rs:290-311, 141-158): thread_rng() -> the OS CSPRNG
+    static std::pair<RangeProof, std::vector<CompressedRistretto>> prove_multiple(const BulletproofGens &bp_gens, const PedersenGens &pc_gens,
+                                                                                  Transcript &transcript, const std::vector<uint64_t> &values,
+                                                                                  const std::vector<ScalarBytes> &blindings, size_t n) {
+        return prove_multiple_with_rng(bp_gens, pc_gens, transcript, values, blindings, n, nullptr);
+    }
+    static std::pair<RangeProof, CompressedRistretto> prove_single(const BulletproofGens &bp_gens, const PedersenGens &pc_gens, Transcript &transcript,
+                                                                   uint64_t v, const ScalarBytes &v_blinding, size_t n) {
+        return prove_single_with_rng(bp_gens, pc_gens, transcript, v, v_blinding, n, nullptr);
     }
     const std::vector<uint8_t> &to_bytes() const { return bytes_; }
 

@@ -1,6 +1,7 @@
 """The reference's own integration test, tests/range_proof.rs::deserialize_and_verify (lines 16-95),
 written against the host-side mirrors of the crate API: Python (bulletproofs_amd.api) and C++
 (include/bulletproofs.hpp, compiled here with g++ and linked against libbpgpu.so)."""
+import hashlib
 import json
 import os
 import subprocess
@@ -163,3 +164,11 @@ def test_generators_tests_of_the_reference(oracle):
     assert b"".join(gens.G(64, 8)) == oG and b"".join(gens.H(64, 8)) == oH
     pc = resized.pedersen()
     assert (pc.B, pc.B_blinding) == (oB, oBb)
+    # PedersenGens::commit (generators.rs:38-42) against the golden value commitments: vc[j] = j B + r_j B~ is not reproducible
+    # without the reference's ChaCha rng, so against the oracle's MSM instead; then prove_single / verify_single with thread_rng
+    from bulletproofs_amd import RangeProof, Transcript
+    blind = hashlib.shake_256(b"commit").digest(31) + b"\x00"
+    want = oracle.msm((1037578891).to_bytes(32, "little") + blind, oB + oBb)[1]
+    assert resized.commit(1037578891, blind) == want
+    proof, V = RangeProof.prove_single(resized, pc, Transcript(b"doctest example"), 1037578891, blind, 32)     # README.md:120 of the reference
+    assert V == want and proof.verify_single(resized, pc, Transcript(b"doctest example"), V, 32) is None
