@@ -394,12 +394,23 @@ def bench_cfg5_shape(a, local_dev, steps=48, nstreams=8):
     L.bpgpu_msm_batch_shared_dev(ctxs[0].h, n, m, 1, nu, d_gs.data_ptr(), d_us.data_ptr(), d_up.data_ptr(), d_out1.data_ptr(), d_st[0].data_ptr(),
                                  streams[0].cuda_stream)
     torch.cuda.synchronize()
+    for c_ in ctxs:
+        c_.profile_enable(False)          # (no dispatch events on the latency measurement)
     t2 = time.perf_counter()
-    for _ in range(5):
+    for _ in range(10):
         L.bpgpu_msm_batch_shared_dev(ctxs[0].h, n, m, 1, nu, d_gs.data_ptr(), d_us.data_ptr(), d_up.data_ptr(), d_out1.data_ptr(), d_st[0].data_ptr(),
                                      streams[0].cuda_stream)
     torch.cuda.synchronize()
-    single = (time.perf_counter() - t2) / 5
+    single_b2b = (time.perf_counter() - t2) / 10
+    lat = []
+    for _ in range(10):                   # one call at a time: enqueue + launch chain + sync
+        torch.cuda.synchronize()
+        t3 = time.perf_counter()
+        L.bpgpu_msm_batch_shared_dev(ctxs[0].h, n, m, 1, nu, d_gs.data_ptr(), d_us.data_ptr(), d_up.data_ptr(), d_out1.data_ptr(), d_st[0].data_ptr(),
+                                     streams[0].cuda_stream)
+        torch.cuda.synchronize()
+        lat.append(time.perf_counter() - t3)
+    single = sorted(lat)[5]
     ok = bool((d_st == 0).all().item()) and bool((d_out[0] == d_out[nstreams - 1]).all().item()) and bool((d_out[0] != 0).any().item())
     if not ok:
         raise SystemExit("cfg5-shape MSM: bad status or streams disagree -- result invalid")
@@ -420,7 +431,7 @@ def bench_cfg5_shape(a, local_dev, steps=48, nstreams=8):
             traffic = json.load(f).get(dom)
     out = {"workload": "cfg5 shape: batches of %d MSMs of N = %d terms (%d generator terms from the tables + %d per-MSM points), %d streams" % (nb, N, ng, nu, nstreams),
            "msms_per_s": round(nb * steps / dt, 1), "terms_per_s": round(nb * steps * N / dt, 1),
-           "ms_per_batch_one_stream": round(one_batch * 1e3, 3), "ms_single_msm": round(single * 1e3, 3),
+           "ms_per_batch_one_stream": round(one_batch * 1e3, 3), "ms_single_msm": round(single * 1e3, 3), "ms_single_msm_back_to_back": round(single_b2b * 1e3, 3),
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(alg / avg_s / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
                         "frac": alg / avg_s / 1e9 / 8000.0, "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2), "launches": kern[dom][0],
                         "algorithmic_bytes_per_launch": alg,
