@@ -92,15 +92,25 @@ BP_HD void ipp_prepare_thread(uint32_t p, ipp_shape sh, const rp_strobe_init &in
     store_words8(sc_out, t0);
     load_words8(w, Q + (uint64_t)p * 32);
     for (int q = 0; q < 8; q++) pt_out[q] = w[q];
-    for (uint32_t i = 0; i < n; i++) {
-        // s_i = prod_b (bit_b(i) ? u : u^-1)[k-1-b]; its inverse has the factors swapped (ipp.rs:241-250, 283)
-        sc28 s, sinv;
-        sc28_one_mont(s);
-        sinv = s;
-        for (uint32_t bb = 0; bb < k; bb++) {
-            const bool bit = (i >> bb) & 1;
-            sc28_montmul(s, s, bit ? um[k - 1 - bb] : uim[k - 1 - bb]);
-            sc28_montmul(sinv, sinv, bit ? uim[k - 1 - bb] : um[k - 1 - bb]);
+    // s_i = prod_b (bit_b(i) ? u : u^-1)[k-1-b]; its inverse has the factors swapped (ipp.rs:241-250, 283).  Walked in
+    // Gray-code order: from one index to the next exactly one bit b flips, so s picks up u_j^2 or u_j^-2 (j = k-1-b) and
+    // 1/s the other one -- two products per index instead of 2k
+    sc28 usq[BP_RP_MAX_K], uisq[BP_RP_MAX_K], s, sinv;
+    sc28_one_mont(s);
+    for (uint32_t j = 0; j < k; j++) {
+        sc28_montsq(usq[j], um[j]);
+        sc28_montsq(uisq[j], uim[j]);
+        sc28_montmul(s, s, uim[j]);                      // s_0 = prod_j u_j^-1
+    }
+    sc28_one_mont(sinv);
+    for (uint32_t j = 0; j < k; j++) sc28_montmul(sinv, sinv, um[j]);   // 1 / s_0
+    for (uint32_t g = 0; g < n; g++) {
+        const uint32_t i = g ^ (g >> 1);
+        if (g) {
+            const uint32_t bb = (uint32_t)__builtin_ctz(g), j = k - 1 - bb;
+            const bool set = (i >> bb) & 1;
+            sc28_montmul(s, s, set ? usq[j] : uisq[j]);
+            sc28_montmul(sinv, sinv, set ? uisq[j] : usq[j]);
         }
         sc f;
         sc28 fm, r;
