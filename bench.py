@@ -56,10 +56,17 @@ def parse_args():
     ap.add_argument("--splits", type=int, default=0, help="workgroups the generator terms of a proof block are split over (default: library default)")
     ap.add_argument("--horner-lanes", type=int, default=0, choices=[0, 4, 64], help="lanes per Horner chain (default: library default)")
     ap.add_argument("--streams", type=int, default=0,
-                    help="(default 128; 12 for runs of fewer steps than that) independent (context, HIP stream) pairs the steps are issued on round-robin, so that "
-                         "consecutive batches overlap on the device (one context per stream, as bpgpu.h prescribes "
-                         "for concurrent callers)")
+                    help="(default 64) lanes of the library's pool (bpgpu_pool_create): independent (context, HIP stream) pairs its launch chains are "
+                         "issued on round-robin, so that consecutive chains overlap on the device")
+    ap.add_argument("--coalesce", type=int, default=0,
+                    help="pool option coalesce_proofs: width the pool packs consecutive submitted batches into (default: the library's, 4096; "
+                         "--coalesce = batch size means one launch chain per step, the round-2 behaviour)")
+    ap.add_argument("--direct", action="store_true",
+                    help="bypass the pool: call bpgpu_rangeproof_verify_batch_dev on --streams (context, stream) pairs round-robin (the round-2 protocol, for A/B)")
     ap.add_argument("--bucket-min", type=int, default=0, help="bucket_min_terms option of the library (0 = default; a huge value forces the table-lookup path)")
+    ap.add_argument("--single-process", action="store_true",
+                    help="with --gpus N: ONE process, ONE pool over N devices (bpgpu_pool_create), host pointers in / verdicts out; N may exceed the "
+                         "visible GPUs (shards then share devices: plumbing check)")
     ap.add_argument("--cfg5-only", type=int, default=0, help="run only the cfg5-shape MSM figure on this many streams and print it")
     ap.add_argument("--repeat", type=int, default=0, help="timed regions of K steps each (0 = auto: 1 when K steps reach steady state, else enough for ~1 s); the median is reported")
     ap.add_argument("--same-input", action="store_true", help="verify the SAME slice every step (the round-1 behaviour; for the cache A/B in DESIGN.md)")
@@ -155,17 +162,28 @@ class RangeProofBench:
         self.d_wts = to_dev(hashlib.shake_256(b"bench-wts-%d" % rank).digest(64 * batch))
         self.distinct = distinct
         self.nstreams = nstreams
-        self.ctxs = []
-        for _ in range(nstreams):
-            c_ = bp.Context(local_dev, fixed_window_bits=a.window_bits or None, horner_lanes=a.horner_lanes or None,
-                            fixed_splits=a.splits or None, fixed_table_max_bytes=a.table_bytes or None)
-            if a.bucket_min:
-                c_.set_option("bucket_min_terms", a.bucket_min)
-            c_.gens_create(fx.n, fx.m)
-            self.ctxs.append(c_)
-        self.streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
+        self.ctxs, self.streams, self.pool = [], [], None
+        self.use_pool = not (rlc or a.direct)
+        if self.use_pool:
+            # the library's scheduler: steps are SUBMITTED (device pointers) and the pool packs consecutive ones into launch chains
+            self.pool = bp.Pool((local_dev,), nstreams, fixed_window_bits=a.window_bits or None, horner_lanes=a.horner_lanes or None,
+                                fixed_splits=a.splits or None, fixed_table_max_bytes=a.table_bytes or None,
+                                bucket_min_terms=a.bucket_min or None, coalesce_proofs=a.coalesce or None)
+            self.pool.gens_create(fx.n, fx.m)
+        else:
+            for _ in range(nstreams):
+                c_ = bp.Context(local_dev, fixed_window_bits=a.window_bits or None, horner_lanes=a.horner_lanes or None,
+                                fixed_splits=a.splits or None, fixed_table_max_bytes=a.table_bytes or None)
+                if a.bucket_min:
+                    c_.set_option("bucket_min_terms", a.bucket_min)
+                c_.gens_create(fx.n, fx.m)
+                self.ctxs.append(c_)
+            self.streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
         self.d_verdicts = None
         self.issued = 0
+
+    def get_option(self, key):
+        return self.pool.get_option(key) if self.pool else self.ctxs[0].get_option(key)
 
     def slice_of(self, g):
         """which slice of the fixture global step g verifies (ranks start at different slices)"""
@@ -180,6 +198,9 @@ class RangeProofBench:
         planted = (not rlc) or (g % 8 == 7)
         base = (self.d_planted if planted else self.d_clean).data_ptr() + j * self.batch * fx.proof_len
         coms = self.d_coms.data_ptr() + j * self.batch * 32 * fx.m
+        if self.pool is not None and not rlc:
+            self.pool.submit_dev(0, fx.n, fx.m, self.batch, base, fx.proof_len, coms, fx.label, self.d_rng.data_ptr(), out_row.data_ptr())
+            return
         if rlc:
             rc = L.bpgpu_rangeproof_verify_rlc_dev(self.ctxs[k].h, fx.n, fx.m, self.batch, base, fx.proof_len, coms, fx.label, len(fx.label),
                                                    self.d_rng.data_ptr(), self.d_wts.data_ptr(), out_row.data_ptr(), None, self.streams[k].cuda_stream)
@@ -212,7 +233,11 @@ class RangeProofBench:
         t0 = time.perf_counter()
         for i in range(K):
             self.step(g0 + i, self.d_verdicts[i], rlc)
+        if self.pool is not None and not rlc:
+            self.pool.flush()                                # whatever the pool still holds back is issued now (inside the timed region)
         t_enq = time.perf_counter() - t0
+        if gather is not None and self.pool is not None:
+            self.pool.wait()                                 # the pool's streams are its own: wait for them before the collective reads the verdicts
         cur = torch.cuda.current_stream()
         for s_ in self.streams:
             cur.wait_stream(s_)                              # verdicts of every stream are complete before the gather
@@ -228,13 +253,24 @@ class RangeProofBench:
         return dt, t_enq, allv
 
     def set_profile(self, on, every=1):
+        if self.pool is not None:
+            self.pool.profile_enable(on, every)
+            return
         for c_ in self.ctxs:
             c_.profile_enable(False)
         if on:
             for c_ in self.ctxs[::every]:
                 c_.profile_enable(True)
 
+    def profile_reset(self):
+        if self.pool is not None:
+            self.pool.profile_reset()
+        for c_ in self.ctxs:
+            c_.profile_reset()
+
     def kernel_times(self):
+        if self.pool is not None:
+            return self.pool.profile_report()
         kern = {}
         for c_ in self.ctxs:
             for name, (cnt, ms) in c_.profile_report().items():
@@ -243,6 +279,9 @@ class RangeProofBench:
         return kern
 
     def close(self):
+        if self.pool is not None:
+            self.pool.close()
+            self.pool = None
         for c_ in self.ctxs:
             c_.close()
         self.ctxs = []
@@ -250,13 +289,19 @@ class RangeProofBench:
 
 def timed(b, K, warmup, fence, repeat, gather=None, events_all=False, no_events=False, agree=None):
     """context set-up, warmup, then R regions of K steps; returns dict(elapsed (median), regions, enqueue, kern, allv)"""
-    for k in range(min(b.nstreams, max(K, 1))):              # context set-up (not a warmup step): the first call on a context
-        b.step(k, _scratch_row(b))                           # sizes its arena and caches the work decomposition
+    if b.pool is not None:                                   # context set-up (not a warmup step): the first chain on a lane sizes its arena
+        b.region(max(K, 1), fence)                           # and caches the work decomposition -- one untimed region of the same shape
+        if K >= 8 * b.nstreams:
+            b.region(b.nstreams * 8, fence)
+    else:
+        for k in range(min(b.nstreams, max(K, 1))):
+            b.step(k, _scratch_row(b))
     fence()
     if warmup:
         b.region(warmup, fence)
-    for c_ in b.ctxs:
-        c_.profile_reset()
+    b.profile_reset()
+    if b.pool is not None:
+        b.pool.set_option("stat_reset", 1)
     # start/stop events attached to a dispatch cost queue time: measured at the default workload, events on every 8th stream
     # lower the throughput by 4 % (5.25 vs 5.47 M/s, --no-events), so long runs sample every 32nd stream (~1 %)
     # (5.52 vs 5.50); a short burst pays more -- at --steps 20, events on all 20 streams cost 6 % (3.82 vs 4.05 M/s) -- so
@@ -292,51 +337,85 @@ def _scratch_row(b):
     return b.d_verdicts[0]
 
 
-VALU_ISSUE_CYCLES = {"mad_u64_u32": 5.18, "other": 4.0}   # measured, profiles/r01_microbench_valu_rates.txt (wave64 on a 16-lane SIMD: 4 cycles floor)
+# Measured ceilings of the box (profiles/r01_microbench_valu_rates.txt, tools/microbench.hip): the integer multiplier issues
+# 3.035e13 v_mad_u64_u32 lane-operations/s chip-wide (5.18 cycles per wave-instruction per SIMD), and the engine's own mixed
+# point addition (ge_madd, 1235 instructions, 707 of them v_mad_u64_u32) sustains 3.14e10/s at 4 waves per SIMD = 6.06e11
+# wave-instructions/s of THIS instruction mix.  Both are reported; neither is a blend.
+MAD_LANE_OPS_PER_S = 3.035e13
+GE_MADD_WAVE_INSTR_PER_S = 3.14e10 * 1235 / 64
+HBM_PEAK = 8.0e12
+HBM_COPY_PEAK = 6.29e12       # measured device-to-device copy rate (MI355X_MICROARCH.md)
 
 
-def roofline_block(cfg, n, m, batch, kern, value, wl, events_every, default_batch):
-    """HBM roofline of the launch that carries the table walk (all of the path's HBM traffic worth the name and ~half of
-    its VALU work), plus the VALU figure that actually binds.  Algorithmic bytes per verification at the MSM boundary
-    (SURVEY.md 8d): 32 N + 32 (4+2k+m) + 32; one launch = `batch` of them."""
+def _committed(name, cfg):
+    path = os.path.join(ROOT, "profiles", "%s_%s.json" % (name, cfg))
+    if not os.path.exists(path):
+        return None
+    with open(path) as f:
+        return json.load(f)
+
+
+def roofline_block(cfg, n, m, kern, value, wl, events_every, proofs_per_launch, nsplit_note=""):
+    """Roofline bookkeeping of one configuration.
+    Top-level fields: the HBM roofline the contract asks for, of the kernel with the largest measured time -- ALGORITHMIC bytes per
+    launch (32 N + 32 (4+2k+m) + 32 per verification, times the verifications one launch carries) over the launch's
+    average duration, measured in this run by start/stop events attached to the dispatches.  The path is NOT HBM-bound -- ~10 field
+    multiplications per input byte -- so the block also carries what binds (`valu`: two fractions of measured ceilings) and the
+    counter-based HBM figures (`traffic`, `hbm_counter`: the window-table gathers are 50-70x the algorithmic bytes, on purpose).
+    Fields marked "committed" are constants from the rocprofv3 --pmc passes under profiles/ (per verification), multiplied by this
+    run's measured rate; everything else is measured live."""
     if not kern:
         return None
-    dom = "rp_stage4" if "rp_stage4" in kern else ("rlc_stage3" if "rlc_stage3" in kern else max(kern.items(), key=lambda kv: kv[1][1])[0])
+    ours = {k: v for k, v in kern.items() if k.startswith(("rp_", "finish", "rlc_", "fb_", "vb_", "bk_"))} or kern
+    dom = max(ours.items(), key=lambda kv: kv[1][1])[0]
     cnt, ms = kern[dom]
     avg_s = ms / cnt * 1e-3
-    alg_bytes = wl.algorithmic_bytes_per_verification(n, m) * batch
+    alg_per_v = wl.algorithmic_bytes_per_verification(n, m)
+    alg_bytes = alg_per_v * proofs_per_launch
     achieved = alg_bytes / avg_s / 1e9
-    traffic = None
-    tpath = os.path.join(ROOT, "profiles", "pmc_traffic_%s.json" % cfg)
-    if os.path.exists(tpath) and batch == default_batch:   # HBM bytes/launch of this kernel from the committed rocprofv3 --pmc passes
-        with open(tpath) as f:
-            traffic = json.load(f).get(dom)
-    valu = {}
-    wpath = os.path.join(ROOT, "profiles", "valu_work_%s.json" % cfg)
-    if os.path.exists(wpath) and batch == default_batch:
-        with open(wpath) as f:
-            wk = json.load(f)
-        per_batch = sum(v for k, v in wk.items() if k in kern and not k.startswith("_"))
-        frac_mad = wk.get("_mad_u64_fraction", 0.57)
-        cyc = frac_mad * VALU_ISSUE_CYCLES["mad_u64_u32"] + (1 - frac_mad) * VALU_ISSUE_CYCLES["other"]
-        peak = 1024 * 2.4e9 / cyc
-        if per_batch:
-            valu = {"wavefront_instructions_per_batch": per_batch,
-                    "achieved_wavefront_instructions_per_s": per_batch * value / batch,
-                    "peak_wavefront_instructions_per_s": peak,
-                    "utilisation": per_batch * value / batch / peak,
-                    "peak_note": "1024 SIMDs x 2.4 GHz / %.2f cycles per wave-instruction: the measured issue rates (v_mad_u64_u32 5.18 cycles, "
-                                 "other VALU 4) weighted by the measured mix (%.0f %% v_mad_u64_u32, profiles/ pmc instruction mix)" % (cyc, 100 * frac_mad)}
-    return {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 3), "peak": 8000.0, "unit": "GB/s",
-            "frac": achieved / 8000.0, "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt,
-            "algorithmic_bytes_per_launch": alg_bytes,
-            "timing": "start/stop events attached to the dispatches (hipExtLaunchKernelGGL) of every %sstream, on their launch stream, inside the "
-                      "timed region; kernel begin..end as in rocprofv3's kernel trace" % ({1: "", 2: "2nd ", 3: "3rd "}.get(events_every, "%dth " % events_every)),
-            "note": "the path is bound by integer VALU issue, not HBM: ~10 field multiplications per input byte, so the HBM fraction is ~1e-3 by construction",
-            "dominant_by": "VALU work (half of a batch's wavefront-instructions) and all of the table traffic; by slot time under load the narrow, latency-bound "
-                           "rp_stage1 (one lane per proof: 12 Keccak-f per proof) is comparable -- see kernels_us",
-            "valu": valu,
-            "kernels_us": {k: round(v[1] / v[0] * 1e3, 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}}
+    N = wl.msm_terms(n, m)
+    out = {"bound": "hbm", "binding_resource": "valu (32-bit integer multiply issue) -- see `valu`; the HBM fractions are small by construction",
+           "kernel": dom, "dominant_by": "largest total measured kernel time in this run",
+           "achieved": round(achieved, 3), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": achieved * 1e9 / HBM_PEAK,
+           "algorithmic_bytes_per_launch": int(alg_bytes), "algorithmic_bytes_per_verification": alg_per_v,
+           "verifications_per_launch": round(proofs_per_launch, 1), "avg_launch_us": round(avg_s * 1e6, 2), "launches": cnt,
+           "timing": "start/stop events attached to the dispatches (hipExtLaunchKernelGGL) of every %slane of the pool, on their launch stream, inside the "
+                     "timed region; kernel begin..end as in rocprofv3's kernel trace (durations are CONTENDED ones: other chains run beside)"
+                     % ({1: "", 2: "2nd ", 3: "3rd "}.get(events_every, "%dth " % events_every)),
+           "traffic": None}
+    tr = _committed("pmc_traffic", cfg)
+    if tr and tr.get("_proofs_per_launch"):
+        per_v = {k: v / tr["_proofs_per_launch"] for k, v in tr.items() if not k.startswith("_") and k in kern}
+        if dom in per_v:
+            out["traffic"] = int(per_v[dom] * proofs_per_launch)
+            out["traffic_note"] = ("HBM bytes of one %s launch from FETCH_SIZE / WRITE_SIZE (committed: profiles/pmc_traffic_%s.json, a rocprofv3 --pmc pass at %d "
+                                   "verifications per launch, scaled to this run's launch width): %.0fx the algorithmic bytes -- the window-table lines that "
+                                   "replace doublings" % (dom, cfg, tr["_proofs_per_launch"], per_v[dom] / alg_per_v))
+            out["traffic_GBps_while_running"] = round(per_v[dom] * proofs_per_launch / avg_s / 1e9, 1)
+        tot = sum(per_v.values())
+        out["hbm_counter"] = {"bytes_per_verification_all_kernels": int(tot), "achieved_GBps": round(tot * value / 1e9, 1),
+                              "frac_of_8TBps": tot * value / HBM_PEAK, "frac_of_measured_copy_peak": tot * value / HBM_COPY_PEAK,
+                              "source": "committed counter bytes per verification x this run's measured rate"}
+    wk = _committed("valu_work", cfg)
+    if wk and wk.get("_proofs_per_launch"):
+        wi = sum(v for k, v in wk.items() if not k.startswith("_") and k in kern) / wk["_proofs_per_launch"]
+        fm = wk.get("_mad_u64_fraction", 0.58)
+        out["valu"] = {"wave_instructions_per_verification": round(wi, 1), "mad_u64_fraction": fm,
+                       "achieved_wave_instructions_per_s": wi * value,
+                       "frac_of_mad_issue_peak": fm * wi * 64 * value / MAD_LANE_OPS_PER_S,
+                       "frac_of_ge_madd_sustained": wi * value / GE_MADD_WAVE_INSTR_PER_S,
+                       "peaks": {"v_mad_u64_u32_lane_ops_per_s": MAD_LANE_OPS_PER_S, "ge_madd_wave_instructions_per_s": round(GE_MADD_WAVE_INSTR_PER_S)},
+                       "source": "SQ_INSTS_VALU per verification: committed (profiles/valu_work_%s.json, rocprofv3 --pmc pass); rate: measured in this run; "
+                                 "peaks: measured microbenchmarks (profiles/r01_microbench_valu_rates.txt)" % cfg}
+    out["point_ops"] = {"reference_count_per_verification": wl.reference_point_ops(N),
+                        "reference_count_per_s": wl.reference_point_ops(N) * value,
+                        "executed_per_verification": wl.executed_point_ops(n, m, nsplit_note[0], nsplit_note[1]) if nsplit_note else None,
+                        "executed_per_s": wl.executed_point_ops(n, m, nsplit_note[0], nsplit_note[1]) * value if nsplit_note else None,
+                        "note": "reference count = additions + doublings of the reference's own MSM algorithm for N = %d terms (SURVEY 8d: Straus below 190 terms, "
+                                "Pippenger above); executed = what this engine performs per verification (window-table walk without doublings, 8-entry tables, "
+                                "Horner chain, partial-sum reduction) -- reported beside, never instead" % N}
+    out["kernels_us"] = {k: round(v[1] / v[0] * 1e3, 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}
+    return out
 
 
 def bench_cfg5_shape(a, local_dev, steps=48, nstreams=8):
@@ -355,15 +434,16 @@ def bench_cfg5_shape(a, local_dev, steps=48, nstreams=8):
             c_.set_option("bucket_min_terms", a.bucket_min)
         c_.gens_create(n, m)
         ctxs.append(c_)
-    G, H, B, Bb = ctxs[0].gens_export()
-    # scalars: uniform mod l (top nibble cleared keeps them canonical); points: the loaded generators in a scrambled order
-    raw = bytearray(hashlib.shake_256(b"cfg5-scalars").digest(32 * (ng + nu) * nb))
-    for i in range(31, len(raw), 32):
-        raw[i] &= 0x0f
-    gens = [G[32 * i:32 * i + 32] for i in range(n)] + [H[32 * i:32 * i + 32] for i in range(n)]
-    upts = b"".join(gens[(7 * i + 3 * b) % len(gens)] for b in range(nb) for i in range(nu))
+    # inputs as SURVEY 8d specifies: uniform scalars; per-MSM points = RistrettoPoint::from_uniform_bytes outputs (the party-1 generator
+    # chains of a (2048, 2) set, derived on the device by a small-table helper context) -- bulletproofs_amd/workload.py cfg5_inputs
+    from bulletproofs_amd import workload as wl
+    hc = bp.Context(local_dev, fixed_window_bits=2)
+    hc.gens_create(n, 2)
+    G2, H2, _, _ = hc.gens_export()
+    hc.close()
+    gsc, usc, upts = wl.cfg5_inputs(G2, H2, nb)
     to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
-    d_gs, d_us, d_up = to_dev(bytes(raw[:32 * ng * nb])), to_dev(bytes(raw[32 * ng * nb:])), to_dev(upts)
+    d_gs, d_us, d_up = to_dev(gsc), to_dev(usc), to_dev(upts)
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     d_out = torch.zeros((nstreams, nb, 32), dtype=torch.uint8, device=dev)
     d_st = torch.full((nstreams, nb), 255, dtype=torch.uint8, device=dev)
@@ -412,8 +492,13 @@ def bench_cfg5_shape(a, local_dev, steps=48, nstreams=8):
         lat.append(time.perf_counter() - t3)
     single = sorted(lat)[5]
     ok = bool((d_st == 0).all().item()) and bool((d_out[0] == d_out[nstreams - 1]).all().item()) and bool((d_out[0] != 0).any().item())
+    # MSM 0 and MSM 63 of the batch against the oracle's encodings, committed in bench_data/cfg5_expected.json (tools/gen_cfg5_expected.py)
+    with open(os.path.join(ROOT, "bench_data", "cfg5_expected.json")) as f:
+        exp5 = json.load(f)
+    got = bytes(d_out[0].cpu().numpy().reshape(-1))
+    ok = ok and got[:32].hex() == exp5["msm0"] and got[32 * (nb - 1):32 * nb].hex() == exp5["msm%d" % (nb - 1)] and bytes(d_out1[0].cpu().numpy()).hex() == exp5["msm0"]
     if not ok:
-        raise SystemExit("cfg5-shape MSM: bad status or streams disagree -- result invalid")
+        raise SystemExit("cfg5-shape MSM: bad status, streams disagree, or results differ from the committed oracle encodings -- result invalid")
     kern = {}
     for c_ in ctxs:
         c_.profile_enable(False)
@@ -422,20 +507,31 @@ def bench_cfg5_shape(a, local_dev, steps=48, nstreams=8):
             kern[name] = (o[0] + cnt, o[1] + ms)
     N = ng + nu
     alg = (32 * N + 32 * nu + 32) * nb
-    dom = max(kern.items(), key=lambda kv: kv[1][1])[0]
-    avg_s = kern[dom][1] / kern[dom][0] * 1e-3
-    traffic = None
+    by_time = max(kern.items(), key=lambda kv: kv[1][1])[0]
+    dom, traffic = by_time, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic_cfg5.json")
-    if os.path.exists(tpath):
+    if os.path.exists(tpath):      # the HBM roofline belongs to the kernel that moves the bytes (the table walk), not to the narrow one that leads by time
         with open(tpath) as f:
-            traffic = json.load(f).get(dom)
-    out = {"workload": "cfg5 shape: batches of %d MSMs of N = %d terms (%d generator terms from the tables + %d per-MSM points), %d streams" % (nb, N, ng, nu, nstreams),
+            tj = json.load(f)
+        cand = {k: tj[k] for k in kern if isinstance(tj.get(k), (int, float))}
+        if cand:
+            dom = max(cand.items(), key=lambda kv: kv[1])[0]
+            traffic = cand[dom]
+    avg_s = kern[dom][1] / kern[dom][0] * 1e-3
+    out = {"workload": "cfg5 shape: batches of %d MSMs of N = %d terms (%d generator terms from the tables + %d per-MSM from_uniform_bytes points, uniform scalars), %d streams; "
+                       "MSM 0 and MSM %d checked against committed oracle encodings" % (nb, N, ng, nu, nstreams, nb - 1),
+           "point_adds_per_s": None,
            "msms_per_s": round(nb * steps / dt, 1), "terms_per_s": round(nb * steps * N / dt, 1),
            "ms_per_batch_one_stream": round(one_batch * 1e3, 3), "ms_single_msm": round(single * 1e3, 3), "ms_single_msm_back_to_back": round(single_b2b * 1e3, 3),
            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(alg / avg_s / 1e9, 3), "peak": 8000.0, "unit": "GB/s",
                         "frac": alg / avg_s / 1e9 / 8000.0, "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2), "launches": kern[dom][0],
                         "algorithmic_bytes_per_launch": alg,
                         "kernels_us": {k: round(v[1] / v[0] * 1e3, 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}}}
+    from bulletproofs_amd.workload import reference_point_ops
+    out["point_adds_per_s"] = round(reference_point_ops(N) * out["msms_per_s"], 1)
+    out["roofline"]["dominant_by"] = "most HBM bytes per launch (committed PMC pass); by total kernel time: %s" % by_time
+    if traffic:
+        out["roofline"]["traffic_GBps_while_running"] = round(traffic / avg_s / 1e9, 1)
     for c_ in ctxs:
         c_.close()
     return out
@@ -443,17 +539,71 @@ def bench_cfg5_shape(a, local_dev, steps=48, nstreams=8):
 
 def self_launch(a):
     """`python bench.py --gpus N` outside torch.distributed.run: re-execute under it, one rank per GPU."""
-    port = 29500 + (os.getpid() % 2000)
+    import socket
+    with socket.socket() as sk:            # a port the kernel just handed out (a pid-derived one can collide on a shared box)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(a.gpus), "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     os.execv(sys.executable, cmd)
 
 
+def lanes_for(a, steps, direct):
+    """pool mode: --streams lanes (default 64).  Direct mode (round-2 protocol, batch-combined figures): 128 (context, stream) pairs,
+    12 for a burst shorter than that (K = 20 on 5/8/10/12/16/20 streams: 3.3/3.8/4.25/4.27/4.22/4.05 M/s)."""
+    if not direct:
+        return a.streams if a.streams > 0 else 64
+    if a.streams > 0:
+        return max(1, min(a.streams, max(steps, 1)))
+    return 128 if steps >= 128 else max(1, min(12, steps))
+
+
+def single_process_multi_device(a):
+    """--single-process with --gpus N: ONE process, ONE pool over N devices (bpgpu_pool_create(devices, N)), one host-pointer call per
+    step for the whole N x batch proofs -- the C-ABI's own multi-device path (contiguous shard per device, host-side gather).
+    Prints the same JSON line (PCIe-inclusive: this path hands over host buffers)."""
+    import torch
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    fx_name, default_batch = wl.CONFIGS[a.config]
+    fx = wl.load_fixture(fx_name)
+    batch = a.batch or default_batch
+    ndev = torch.cuda.device_count()
+    devices = [i % ndev for i in range(a.gpus)]
+    pool = bp.Pool(devices, a.streams if a.streams > 0 else 32, fixed_window_bits=a.window_bits or None)
+    pool.gens_create(fx.n, fx.m)
+    total = batch * a.gpus * max(a.steps, 1)
+    proofs, coms = wl.tile_batch(fx, total)
+    planted, expect = plant_invalid(proofs, fx.proof_len, batch, total // batch)
+    exp = b"".join(bytes(r) for r in expect)
+    rng = hashlib.shake_256(b"sp-rng").digest(64 * total)
+    for _ in range(max(1, min(a.warmup, 3))):
+        pool.rangeproof_verify(fx.n, fx.m, planted, fx.proof_len, coms, fx.label, rng)
+    regs = []
+    for _ in range(a.repeat or 5):
+        t0 = time.perf_counter()
+        v = pool.rangeproof_verify(fx.n, fx.m, planted, fx.proof_len, coms, fx.label, rng)
+        regs.append(time.perf_counter() - t0)
+        if v != exp:
+            raise SystemExit("verdicts differ from the planted pattern -- result invalid")
+    dt = statistics.median(regs)
+    print(json.dumps({"metric": "64-bit rangeproof verifications/sec (batched)", "value": round(total / dt, 1), "unit": "verifications/s", "n_gpus": a.gpus,
+                      "steps": a.steps, "warmup": a.warmup, "ms_per_step": round(dt / max(a.steps, 1) * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+                      "vs_baseline": None, "dtype": "u32 limbs, u64 accumulators", "data": "synthetic (bench_data/%s.bin), host memory in, verdicts out" % fx_name,
+                      "config": {"workload": "%s: ONE bpgpu_pool_rangeproof_verify call for %d proofs (%d per GPU per step x %d steps), single process over devices %s, "
+                                             "host pointers (PCIe-inclusive)" % (a.config, total, batch, a.steps, devices), "mode": "single-process multi-device pool"},
+                      "regions": [round(x, 5) for x in regs]}))
+    pool.close()
+
+
 def main():
     a = parse_args()
     if a.cfg5_only:
         print(json.dumps(bench_cfg5_shape(a, 0, 48, a.cfg5_only)))
+        return
+    if a.single_process:
+        single_process_multi_device(a)
         return
     if a.gpus > 1 and "WORLD_SIZE" not in os.environ:
         self_launch(a)
@@ -480,14 +630,8 @@ def main():
 
     fx_name, default_batch = wl.CONFIGS[a.config]
     batch = a.batch or default_batch
-    auto_streams = a.streams <= 0
-    if auto_streams:
-        a.streams = 128
-    nstreams = max(1, min(a.streams, max(a.steps, 1)))
-    if a.steps < a.streams and auto_streams:
-        # a burst shorter than the stream count never reaches the steady state the 128 streams are for: it is served best by
-        # fewer streams than hardware queues (K = 20 on 5/8/10/12/16/20 streams: 3.3/3.8/4.25/4.27/4.22/4.05 M/s)
-        nstreams = min(nstreams, 12)
+    direct = a.direct or a.rlc
+    nstreams = lanes_for(a, a.steps, direct)
     b = RangeProofBench(a, a.config, batch, nstreams, rank, local_dev, rlc=a.rlc)
     n, m = b.fx.n, b.fx.m
     N_terms = wl.msm_terms(n, m)
@@ -506,50 +650,77 @@ def main():
     if world > 1 and a.steps:     # every rank's verdict rows arrived and carry that rank's planted pattern
         allv = r["allv"]
         assert allv.shape[0] == world and bool(((allv == 0) | (allv == 1) | (allv == 5)).all().item())
-    window_bits, table_bytes = b.ctxs[0].get_option("fixed_window_bits"), b.ctxs[0].get_option("fixed_table_bytes")
+    window_bits, table_bytes = b.get_option("fixed_window_bits"), b.get_option("fixed_table_bytes")
     value = world * batch * a.steps / elapsed if a.steps else 0.0
+    ppl, splits, sched = float(batch), 64, "one launch chain per step on %d (context, stream) pairs, round-robin (bpgpu_rangeproof_verify_batch_dev)" % nstreams
+    if b.pool is not None:
+        ch, cp = b.pool.get_option("stat_chains"), b.pool.get_option("stat_chain_proofs")
+        ppl = cp / ch if ch else float(batch)
+        splits = b.pool.get_option("stat_last_splits") or 64
+        sched = ("library pool (bpgpu_pool_rangeproof_submit_dev + bpgpu_pool_flush): every step is submitted as its own batch with its own verdict buffer; "
+                 "the pool packed consecutive steps into launch chains of %.0f proofs on average (coalesce_proofs = %d) over %d lanes"
+                 % (ppl, b.pool.get_option("coalesce_proofs"), nstreams))
+    roof = roofline_block(a.config, n, m, r["kern"], value / world, wl, r["events_every"], ppl, (window_bits, splits)) if rank == 0 else None
+    b.close()
 
     extra = {}
-    if world == 1 and not a.rlc and not a.no_extra and a.steps >= 8:
+    want_extra = world == 1 and not a.rlc and not a.no_extra and a.steps >= 8
+    long_run = a.steps >= 640
+    if want_extra:
+        # (0) the same steps WITHOUT the pool's coalescing (round-2 protocol): one launch chain per step on (context, stream) pairs
+        try:
+            a.direct = True
+            bd = RangeProofBench(a, a.config, batch, lanes_for(a, a.steps, True), rank, local_dev)
+            rd = timed(bd, a.steps, a.warmup, fence, a.repeat, None, False, True)
+            extra["direct_no_pool"] = {"verifications_per_s": round(batch * a.steps / rd["elapsed"], 1), "streams": bd.nstreams, "regions": len(rd["regions"]),
+                                       "note": "bpgpu_rangeproof_verify_batch_dev, one launch chain per step (what round 2 reported as `value`)"}
+            bd.close()
+        except Exception as e:
+            extra["direct_no_pool"] = {"error": str(e)}
+        finally:
+            a.direct = False
         # (1) the same batches through the batch-combined entry point (one identity check per batch) -- never `value`
-        ks = max(b.nstreams, a.steps // 4)
-        for k in range(b.nstreams):
-            b.step(k, _scratch_row(b), True)
-        fence()
-        dt, _, _ = b.region(ks, fence, None, True)
-        extra["rlc"] = {"verifications_per_s": round(batch * ks / dt, 1), "steps": ks,
-                        "note": "bpgpu_rangeproof_verify_rlc_dev: one combined identity check per batch of %d (additional entry point, SURVEY 8f-3); "
-                                "every 8th batch carries planted invalid proofs and must come back undecided" % batch}
-    roof = roofline_block(a.config, n, m, batch, r["kern"], value, wl, r["events_every"], default_batch) if rank == 0 else None
-    b.close()
-    if world == 1 and not a.rlc and not a.no_extra and a.steps >= 8 and a.config == "cfg2" and not a.batch:
+        try:
+            br = RangeProofBench(a, a.config, batch, lanes_for(a, a.steps, True), rank, local_dev, rlc=True)
+            ks = max(br.nstreams, a.steps // 4)
+            rr = timed(br, ks, br.nstreams, fence, 1, None, False, True)
+            extra["rlc"] = {"verifications_per_s": round(batch * ks / rr["elapsed"], 1), "steps": ks,
+                            "note": "bpgpu_rangeproof_verify_rlc_dev: one combined identity check per batch of %d (additional entry point, SURVEY 8f-3); "
+                                    "every 8th batch carries planted invalid proofs and must come back undecided" % batch}
+            br.close()
+        except Exception as e:
+            extra["rlc"] = {"error": str(e)}
+    if want_extra and a.config == "cfg2" and not a.batch:
         # the batch-combined entry point at batches of 4096: from 32768 terms the per-proof points of the whole batch go through
         # ONE bucket (Pippenger) MSM (csrc/bucket.h)
         try:
-            b4 = RangeProofBench(a, "cfg2", 4096, min(32, nstreams), rank, local_dev, rlc=True)
-            k4 = 256 if a.steps >= 640 else max(a.steps, 8)
-            r4 = timed(b4, k4, 32 if a.steps >= 640 else 8, fence, 0)
+            b4 = RangeProofBench(a, "cfg2", 4096, 32 if long_run else 12, rank, local_dev, rlc=True)
+            k4 = 256 if long_run else max(a.steps, 8)
+            r4 = timed(b4, k4, 32 if long_run else 8, fence, 0)
             extra["rlc_batch4096"] = {"verifications_per_s": round(4096 * k4 / r4["elapsed"], 1), "steps": k4, "streams": b4.nstreams, "regions": len(r4["regions"]),
                                       "kernels_us": {k_: round(v_[1] / v_[0] * 1e3, 2) for k_, v_ in sorted(r4["kern"].items(), key=lambda kv: -kv[1][1])},
                                       "note": "bpgpu_rangeproof_verify_rlc_dev on batches of 4096 cfg2 proofs (69632 per-proof terms per combination: bucket MSM)"}
             b4.close()
         except Exception as e:
             extra["rlc_batch4096"] = {"error": str(e)}
-    if world == 1 and not a.rlc and not a.no_extra and a.steps >= 8 and a.config == "cfg2":
-        # (2) BASELINE configs 3 and 4 (aggregated m = 16 at batch 256, m = 32 at 512 per GPU) and (3) config 5's MSM shape,
-        # each with its own roofline
-        for cfg_x, batch_x, streams_x, m_x, terms_x in (("cfg3", 256, 64, 16, 2090), ("cfg4", 512, 32, 32, 4156)):
+    if want_extra and a.config == "cfg2":
+        # (2) BASELINE configs 3 and 4 (aggregated m = 16 at batch 256, m = 32 at 512 per GPU) through the pool, each with its own roofline,
+        # and (3) config 5's MSM shape
+        for cfg_x, batch_x, m_x, terms_x in (("cfg3", 256, 16, 2090), ("cfg4", 512, 32, 4156)):
             try:
-                bx = RangeProofBench(a, cfg_x, batch_x, min(streams_x, nstreams), rank, local_dev)
-                kx = (640 if cfg_x == "cfg3" else 256) if a.steps >= 640 else max(a.steps, 8)
-                rx = timed(bx, kx, 64 if a.steps >= 640 else 8, fence, 0)
+                bx = RangeProofBench(a, cfg_x, batch_x, lanes_for(a, a.steps, False), rank, local_dev)
+                kx = (640 if cfg_x == "cfg3" else 256) if long_run else max(a.steps, 8)
+                rx = timed(bx, kx, 64 if long_run else 8, fence, 0)
                 vx = batch_x * kx / rx["elapsed"]
-                extra[cfg_x] = {"workload": "%s: batch of %d aggregated m=%d 64-bit range proofs (MSM of %d terms each), %d distinct proofs" % (cfg_x, batch_x, m_x, terms_x, bx.distinct),
-                                "verifications_per_s": round(vx, 1), "steps": kx, "regions": len(rx["regions"]), "streams": bx.nstreams,
-                                "fixed_window_bits": bx.ctxs[0].get_option("fixed_window_bits"),
-                                "roofline": roofline_block(cfg_x, 64, m_x, batch_x, rx["kern"], vx, wl, rx["events_every"], batch_x)}
+                chx, cpx = bx.pool.get_option("stat_chains"), bx.pool.get_option("stat_chain_proofs")
+                wbx = bx.get_option("fixed_window_bits")
+                extra[cfg_x] = {"workload": "%s: batches of %d aggregated m=%d 64-bit range proofs (MSM of %d terms each), %d distinct proofs, through the pool" % (cfg_x, batch_x, m_x, terms_x, bx.distinct),
+                                "verifications_per_s": round(vx, 1), "point_adds_per_s": round(wl.reference_point_ops(terms_x) * vx, 1), "steps": kx, "regions": len(rx["regions"]),
+                                "lanes": bx.nstreams, "fixed_window_bits": wbx,
+                                "roofline": roofline_block(cfg_x, 64, m_x, rx["kern"], vx, wl, rx["events_every"], cpx / chx if chx else batch_x,
+                                                           (wbx, bx.pool.get_option("stat_last_splits") or 64))}
                 bx.close()
-                if cfg_x == "cfg3" and a.steps >= 640:
+                if cfg_x == "cfg3" and long_run:
                     # the batch-combined check on the aggregated shape: one table MSM of 2050 terms per BATCH plus 40 points per proof.
                     # Its launches are narrow (256 proofs = 4 wavefronts of transcript lanes), so the rate follows the batch size
                     rl = {}
@@ -563,10 +734,12 @@ def main():
                 extra[cfg_x] = {"error": str(e)}
         try:
             extra["cfg5_shape"] = bench_cfg5_shape(a, local_dev)
+        except SystemExit:
+            raise
         except Exception as e:
             extra["cfg5_shape"] = {"error": str(e)}
 
-    if world == 1 and not a.rlc and not a.no_extra and a.steps >= 8 and a.config == "cfg2" and not a.batch:
+    if want_extra and a.config == "cfg2" and not a.batch:
         # (4) the prover side: bpgpu_rangeproof_prove_batch, batches of 1024 single 64-bit proofs from host memory on
         # 4 host threads (one context each), every proof then verified by the engine -- variable time, see include/bpgpu.h
         try:
@@ -604,48 +777,6 @@ def main():
         except Exception as e:
             extra["prover"] = {"error": str(e)}
 
-    if world == 1 and not a.rlc and not a.no_extra and a.steps >= 8 and a.config == "cfg2" and not a.batch:
-        # (5) the other public proof type on this path, LinearProof (src/linear_proof.rs): 4096 proofs of n = 64 made by
-        # bpgpu_linear_create_batch over the context's generators, then verified (bases through the window tables); one planted
-        # wrong commitment must be the only rejection
-        try:
-            nl, nbl = 64, 4096
-            lc = bp.Context(local_dev)
-            lc.gens_create(nl, 1)
-            Gc, _, Bp_, Bb_ = lc.gens_export()
-            ell = 2 ** 252 + 27742317777372353535851937790883648493
-            sh_ = hashlib.shake_256(b"bench-linear").digest(32 * (2 * nl + 1) + 64)
-            redl = lambda o: (int.from_bytes(sh_[o:o + 32] + bytes(32), "little") % ell).to_bytes(32, "little")
-            la = b"".join(redl(32 * i) for i in range(nl))
-            lb = b"".join(redl(32 * (nl + i)) for i in range(nl))
-            lr = redl(64 * nl)
-            lcc = sum(int.from_bytes(la[32 * i:32 * i + 32], "little") * int.from_bytes(lb[32 * i:32 * i + 32], "little") for i in range(nl)) % ell
-            # C = <a, G> + r B + <a, b> F (linear_proof.rs:415-420) through the engine's own MSM
-            Cl, stl = lc.msm_batch([nl + 2], la + lr + lcc.to_bytes(32, "little"), Gc[:32 * nl] + Bb_ + Bp_)
-            assert stl == bytes(1)
-            Cs_ = bytearray(Cl * nbl)
-            Cs_[32 * 7:32 * 8] = Bp_                                  # proof 7 is checked against somebody else's commitment
-            t1 = time.perf_counter()
-            lproofs, lst = lc.linear_create_batch(nl, Cl * nbl, lr * nbl, la * nbl, lb, None, None, None, label=b"bench-linear")
-            dtc = time.perf_counter() - t1
-            pll = len(lproofs) // nbl
-            lc.linear_verify_batch(nl, lproofs, pll, bytes(Cs_), None, None, None, lb, label=b"bench-linear")
-            t1 = time.perf_counter()
-            for _ in range(4):
-                lv = lc.linear_verify_batch(nl, lproofs, pll, bytes(Cs_), None, None, None, lb, label=b"bench-linear")
-            dtv = (time.perf_counter() - t1) / 4
-            okl = lst == bytes(nbl) and [i for i in range(nbl) if lv[i]] == [7]
-            extra["linear"] = {"verifications_per_s": round(nbl / dtv, 1), "proofs_created_per_s": round(nbl / dtc, 1), "verdicts_as_planted": okl,
-                               "note": "LinearProof n = %d, batches of %d from host memory on ONE context: bpgpu_linear_create_batch (OS randomness, "
-                                       "first call) then bpgpu_linear_verify_batch, both with the context's generators as bases (window tables)" % (nl, nbl)}
-            lc.close()
-            if not okl:
-                raise SystemExit("linear-proof verdicts differ from the planted pattern -- result invalid")
-        except SystemExit:
-            raise
-        except Exception as e:
-            extra["linear"] = {"error": str(e)}
-
     if rank == 0:
         out = {
             "metric": "64-bit rangeproof verifications/sec (batched)" + (" -- batch-combined check (bpgpu_rangeproof_verify_rlc), not the headline mode" if a.rlc else ""),
@@ -655,6 +786,9 @@ def main():
             "steps": a.steps,
             "warmup": a.warmup,
             "ms_per_step": round(elapsed / max(a.steps, 1) * 1e3, 4),
+            "point_adds_per_s": round(wl.reference_point_ops(N_terms) * value, 1),
+            "point_adds_note": "the metric's second half, 'MSM point-adds/sec': A(N) x verifications/s with A(%d) = %d additions + doublings of the reference's own MSM "
+                               "algorithm (SURVEY 8d); the engine's executed count is in roofline.point_ops" % (N_terms, wl.reference_point_ops(N_terms)),
             "regions": {"count": len(r["regions"]), "seconds": [round(x, 5) for x in r["regions"]],
                         "note": "timed regions of `steps` steps each; ms_per_step and value use the median region"},
             "host_enqueue_ms_per_step": round(r["enqueue"] / max(a.steps, 1) * 1e3, 4),
@@ -664,12 +798,12 @@ def main():
             "dtype": "u32 limbs (10x25.5-bit GF(2^255-19), 8x32-bit scalars mod l), u64 accumulators",
             "data": "synthetic (oracle-proved range proofs, bench_data/%s.bin: %d distinct proofs, a different %d-slice per step%s; 3 proofs per slice carry "
                     "a flipped bit and every verdict row is checked against that pattern)" % (fx_name, b.distinct, batch, " [--same-input: one slice]" if a.same_input else ""),
-            "config": {"workload": "%s: batch of %d %s%d-bit range proofs per GPU, proof bytes -> verdict on device "
+            "config": {"workload": "%s: batch of %d %s%d-bit range proofs per GPU per step, proof bytes -> verdict on device "
                                    "(MSM of %d terms each)" % (a.config, batch, ("aggregated m=%d " % m) if m > 1 else "single ", n, N_terms),
                        "n": n, "m": m, "batch_per_gpu": batch, "global_batch": batch * world, "msm_terms": N_terms,
                        "fixed_window_bits": window_bits, "fixed_table_bytes": table_bytes,
                        "mode": "rlc (one combined identity check per batch)" if a.rlc else "per-proof verdicts (the reference's semantics)",
-                       "streams": nstreams, "parallelism": "independent proofs sharded, dp%d%s" % (world, " (ranks share GPUs: gloo gather)" if oversub else "")},
+                       "scheduler": sched, "lanes": nstreams, "parallelism": "independent proofs sharded, dp%d%s" % (world, " (ranks share GPUs: gloo gather)" if oversub else "")},
             "roofline": roof,
         }
         if extra:

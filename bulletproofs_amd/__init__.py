@@ -5,6 +5,6 @@ Host-side mirror of the reference crate's public surface for this path
 BulletproofGens, PedersenGens, ProofError, Transcript -- all of it a thin layer
 over the C ABI of libbpgpu.so (include/bpgpu.h).  No CPU fallback exists.
 """
-from ._lib import BpgpuError, Context, lib, LIB_PATH  # noqa: F401
+from ._lib import BpgpuError, Context, Pool, lib, LIB_PATH  # noqa: F401
 from .api import (BulletproofGens, BulletproofGensShare, PedersenGens, RangeProof, LinearProof, Transcript, ProofError, VerificationError,  # noqa: F401,E402
                   FormatError, InvalidBitsize, InvalidGeneratorsLength)

@@ -24,6 +24,9 @@ EXPORTS = [
     "bpgpu_ipp_create_batch", "bpgpu_rangeproof_prove_batch", "bpgpu_rangeproof_verify_batch_submit", "bpgpu_ctx_collect",
     "bpgpu_linear_verify_batch", "bpgpu_linear_verify_batch_dev", "bpgpu_linear_create_batch",
     "bpgpu_rangeproof_audit_shares",
+    "bpgpu_pool_create", "bpgpu_pool_destroy", "bpgpu_pool_last_error", "bpgpu_pool_set_option", "bpgpu_pool_get_option",
+    "bpgpu_pool_devices", "bpgpu_pool_lanes", "bpgpu_pool_lane", "bpgpu_pool_gens_create", "bpgpu_pool_gens_load",
+    "bpgpu_pool_rangeproof_verify", "bpgpu_pool_rangeproof_submit_dev", "bpgpu_pool_flush", "bpgpu_pool_wait",
 ]
 
 TRANSCRIPT_BYTES = 208
@@ -88,6 +91,23 @@ def lib():
     L.bpgpu_rangeproof_audit_shares.argtypes = [vp, sz, sz, C.POINTER(C.c_uint32), u8p, u8p, u8p, u8p, i, u8p, u8p]
     L.bpgpu_linear_create_batch.argtypes = [vp, sz, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, i, u8p, u8p, u8p, u8p, u8p, u8p]
     L.bpgpu_linear_verify_batch_dev.argtypes = [vp, sz, sz, vp, sz, u8p, sz, u8p, vp, vp, vp, vp, vp, i, vp, vp, vp, vp]
+    L.bpgpu_pool_create.argtypes = [C.POINTER(C.c_int), i, i, C.POINTER(vp)]
+    L.bpgpu_pool_destroy.argtypes = [vp]
+    L.bpgpu_pool_destroy.restype = None
+    L.bpgpu_pool_last_error.argtypes = [vp]
+    L.bpgpu_pool_last_error.restype = C.c_char_p
+    L.bpgpu_pool_set_option.argtypes = [vp, C.c_char_p, C.c_int64]
+    L.bpgpu_pool_get_option.argtypes = [vp, C.c_char_p, C.POINTER(C.c_int64)]
+    L.bpgpu_pool_devices.argtypes = [vp]
+    L.bpgpu_pool_lanes.argtypes = [vp]
+    L.bpgpu_pool_lane.argtypes = [vp, i, i]
+    L.bpgpu_pool_lane.restype = vp
+    L.bpgpu_pool_gens_create.argtypes = [vp, sz, sz]
+    L.bpgpu_pool_gens_load.argtypes = [vp, sz, sz, u8p, u8p, u8p, u8p]
+    L.bpgpu_pool_rangeproof_verify.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p]
+    L.bpgpu_pool_rangeproof_submit_dev.argtypes = [vp, i, sz, sz, sz, vp, sz, vp, u8p, sz, vp, vp, vp]
+    L.bpgpu_pool_flush.argtypes = [vp]
+    L.bpgpu_pool_wait.argtypes = [vp]
     L.bpgpu_profile_enable.argtypes = [vp, i]
     L.bpgpu_profile_reset.argtypes = [vp]
     L.bpgpu_profile_report.argtypes = [vp, C.c_char_p, sz]
@@ -118,7 +138,7 @@ def transcript_challenge_bytes(state, label, n):
     return st.raw, out.raw[:n]
 
 
-ERR_NAMES = {0: "OK", -1: "INVALID_ARG", -2: "HIP", -3: "NO_GENS", -4: "NO_DEVICE", -5: "BAD_GENERATOR"}
+ERR_NAMES = {0: "OK", -1: "INVALID_ARG", -2: "HIP", -3: "NO_GENS", -4: "NO_DEVICE", -5: "BAD_GENERATOR", -6: "HW_QUEUES"}
 
 
 class Context:
@@ -349,4 +369,117 @@ class Context:
         for line in buf.value.decode().splitlines():
             name, n, ms = line.split()
             out[name] = (int(n), float(ms))
+        return out
+
+
+def _profile_report_of(L, h):
+    buf = C.create_string_buffer(1 << 16)
+    if L.bpgpu_profile_report(h, buf, len(buf)) != 0:
+        raise BpgpuError("bpgpu_profile_report failed")
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, n, ms = line.split()
+        out[name] = (int(n), float(ms))
+    return out
+
+
+class Pool:
+    """Owns one bpgpu_pool: `lanes` contexts on each of `devices` (include/bpgpu.h, "pool").  The scheduler of the library:
+    one synchronous call for any number of proofs from host memory (verify), or asynchronous device-pointer batches that the
+    pool coalesces into wide launch chains (submit_dev / flush / wait)."""
+
+    def __init__(self, devices=(0,), lanes=0, **options):
+        self._L = lib()
+        h = C.c_void_p()
+        devs = (C.c_int * len(devices))(*devices)
+        rc = self._L.bpgpu_pool_create(devs, len(devices), lanes, C.byref(h))
+        if rc != 0:
+            raise BpgpuError("bpgpu_pool_create(devices=%s) failed: %s (no CPU fallback)" % (list(devices), ERR_NAMES.get(rc, rc)))
+        self.h = h
+        for k, v in options.items():
+            if v is not None:
+                self.set_option(k, v)
+
+    def close(self):
+        if getattr(self, "h", None):
+            self._L.bpgpu_pool_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise BpgpuError("%s: %s" % (ERR_NAMES.get(rc, rc), self._L.bpgpu_pool_last_error(self.h).decode()))
+
+    def set_option(self, key, value):
+        self._chk(self._L.bpgpu_pool_set_option(self.h, key.encode(), int(value)))
+
+    def get_option(self, key):
+        v = C.c_int64(0)
+        self._chk(self._L.bpgpu_pool_get_option(self.h, key.encode(), C.byref(v)))
+        return v.value
+
+    @property
+    def n_devices(self):
+        return self._L.bpgpu_pool_devices(self.h)
+
+    @property
+    def n_lanes(self):
+        return self._L.bpgpu_pool_lanes(self.h)
+
+    def gens_create(self, gens_capacity, party_capacity):
+        self._chk(self._L.bpgpu_pool_gens_create(self.h, gens_capacity, party_capacity))
+
+    def gens_load(self, gens_capacity, party_capacity, G, H, B, B_blinding):
+        assert len(G) == len(H) == 32 * gens_capacity * party_capacity
+        self._chk(self._L.bpgpu_pool_gens_load(self.h, gens_capacity, party_capacity, G, H, B, B_blinding))
+
+    def rangeproof_verify(self, n, m, proofs, proof_len, commitments, label, rng64=None, want_msm=False):
+        """ONE call, any number of proofs, host memory in and out (bpgpu_pool_rangeproof_verify)."""
+        nb = len(proofs) // proof_len if proof_len else 0
+        assert len(proofs) == nb * proof_len and len(commitments) == 32 * m * nb
+        assert rng64 is None or len(rng64) == 64 * nb
+        verdict = C.create_string_buffer(max(nb, 1))
+        msm = C.create_string_buffer(32 * max(nb, 1)) if want_msm else None
+        self._chk(self._L.bpgpu_pool_rangeproof_verify(self.h, n, m, nb, proofs, proof_len, commitments, label, len(label), rng64, verdict, msm))
+        return (verdict.raw[:nb], msm.raw[:32 * nb]) if want_msm else verdict.raw[:nb]
+
+    def submit_dev(self, dev_index, n, m, nbatch, d_proofs, proof_len, d_commitments, label, d_rng64, d_verdict, d_msm_out=None):
+        """queue a device-resident batch (raw device pointers as ints); see flush / wait"""
+        self._chk(self._L.bpgpu_pool_rangeproof_submit_dev(self.h, dev_index, n, m, nbatch, d_proofs, proof_len, d_commitments, label, len(label),
+                                                           d_rng64, d_verdict, d_msm_out))
+
+    def flush(self):
+        self._chk(self._L.bpgpu_pool_flush(self.h))
+
+    def wait(self):
+        self._chk(self._L.bpgpu_pool_wait(self.h))
+
+    # ---- instrumentation (per lane context) ----
+    def _lanes(self, every=1):
+        for d in range(self.n_devices):
+            for l in range(0, self.n_lanes, every):
+                yield self._L.bpgpu_pool_lane(self.h, d, l)
+
+    def profile_enable(self, on=True, every=1):
+        for h in self._lanes():
+            self._L.bpgpu_profile_enable(h, 0)
+        if on:
+            for h in self._lanes(every):
+                self._L.bpgpu_profile_enable(h, 1)
+
+    def profile_reset(self):
+        for h in self._lanes():
+            self._L.bpgpu_profile_reset(h)
+
+    def profile_report(self):
+        out = {}
+        for h in self._lanes():
+            for name, (cnt, ms) in _profile_report_of(self._L, h).items():
+                o = out.get(name, (0, 0.0))
+                out[name] = (o[0] + cnt, o[1] + ms)
         return out

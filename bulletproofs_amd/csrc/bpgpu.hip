@@ -52,6 +52,7 @@ struct bpgpu_ctx {
     uint32_t W = 0;                          // fixed-base window bits; 0 = largest that fits table_budget
     uint64_t table_budget = 96ull << 30;     // bytes of HBM the generator tables may take (a third of the MI355X's 288 GB)
     uint32_t splits = 0;
+    uint32_t splits_hint = 0;                // per-call suggestion of the pool (pick_splits), used when `splits` is 0
     uint32_t horner_lanes = 0;               // lanes per Horner chain in the range-proof path: 4, 64, 0 = auto (4)
     struct shared_table *tab_ref = nullptr;  // refcounted, shared by the contexts of one device
     // generators
@@ -84,7 +85,7 @@ struct bpgpu_ctx {
     // pinned host staging (ragged work decompositions, library-drawn randomness, the host-pointer entry points' IO):
     // copies out of it are truly asynchronous; pin_ev guards its reuse by the next call
     char *pin = nullptr;
-    size_t pin_cap = 0, pin_off = 0;
+    size_t pin_cap = 0, pin_off = 0, pin_marked = 0;   // pin_marked: bytes already guarded by a recorded pin_ev (pin_mark)
     hipEvent_t pin_ev = nullptr;
     bool pin_pending = false;
     std::vector<char *> pin_retired;         // outgrown mid-call: still referenced by that call, freed at the next one
@@ -213,13 +214,16 @@ static uint64_t table_bytes(uint32_t n_gens, uint32_t W);
 static int collect_locked(bpgpu_ctx *c);
 static int host_wait(bpgpu_ctx *c, hipStream_t s);
 // ---- ordering of calls on one context (see bpgpu_ctx::order_ev) ----
-static int ctx_enter(bpgpu_ctx *c, hipStream_t s) {
+// keep_staging: the call continues an earlier one of the same entry point and still holds pointers into the pinned staging
+// buffers (the per-proof fallback of the batch-combined check): nothing retired is freed
+static int ctx_enter(bpgpu_ctx *c, hipStream_t s, bool keep_staging = false) {
     if (c->pend.active) {   // a submitted call's results still sit in the staging buffers: deliver them first
         int rcp = collect_locked(c);
         if (rcp) return rcp;
     }
     c->pin_off = 0;
-    if (!c->pin_retired.empty()) {
+    c->pin_marked = 0;
+    if (!c->pin_retired.empty() && !keep_staging) {
         if (c->pin_pending) HIPCHK(c, hipEventSynchronize(c->pin_ev));
         c->pin_pending = false;
         for (char *q : c->pin_retired) hipHostFree(q);
@@ -232,7 +236,7 @@ static int ctx_leave(bpgpu_ctx *c, hipStream_t s) {
     HIPCHK(c, hipEventRecord(c->order_ev, s));
     c->last_stream = s;
     c->have_last = true;
-    if (c->pin_off) {   // staged bytes are in flight on s: the next call waits for them before overwriting
+    if (c->pin_off > c->pin_marked) {   // staged bytes are in flight on s: the next call waits for them before overwriting
         HIPCHK(c, hipEventRecord(c->pin_ev, s));
         c->pin_pending = true;
     }
@@ -255,9 +259,20 @@ static int pin_alloc(bpgpu_ctx *c, hipStream_t /*s*/, size_t bytes, char **out) 
         HIPCHK(c, hipHostMalloc((void **)&c->pin, cap, hipHostMallocDefault));
         c->pin_cap = cap;
         c->pin_off = 0;
+        c->pin_marked = 0;
     }
     *out = c->pin + c->pin_off;
     c->pin_off += align_up(bytes);
+    return BPGPU_OK;
+}
+// An H2D copy out of the staging buffer has just been enqueued on s and nothing else of this call will touch the bytes
+// allocated so far: record the guard event NOW rather than at the end of the call, so that the next call on this context
+// waits for the copy, not for the whole launch chain behind it (device-pointer calls that stage only their rng bytes or a
+// segment table: with many lanes in flight the host would otherwise stall on every reuse of a lane)
+static int pin_mark(bpgpu_ctx *c, hipStream_t s) {
+    HIPCHK(c, hipEventRecord(c->pin_ev, s));
+    c->pin_pending = true;
+    c->pin_marked = c->pin_off;
     return BPGPU_OK;
 }
 static int io_reserve(bpgpu_ctx *c, size_t bytes) {
@@ -936,6 +951,11 @@ extern "C" int bpgpu_msm_batch(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_te
 // ============================================================================
 static uint32_t pick_splits(bpgpu_ctx *c, size_t nbatch, uint32_t npairs) {
     if (c->splits) return c->splits;
+    if (c->splits_hint && npairs <= 8192) {   // the pool knows how much else is in flight (pool.hip flush_dev)
+        uint32_t s = c->splits_hint;
+        while (s > 8 && npairs / s < 8) s -= 8;
+        return s;
+    }
     // >= 1024 wavefronts (one per SIMD).  A lone table walk runs 1.45x faster with 4096 (4 per SIMD hide its VALU
     // dependency stalls: 4.0 ms at 2048 wavefronts vs 2.8 ms at 4096, batch 16384), but it shares its launch with the
     // longer Horner role, and with several batches in flight the device is work-bound: every split costs one
@@ -1265,7 +1285,9 @@ struct rp_transcripts {
 static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
                                 const void *d_commitments, const rp_transcripts &tr, const void *d_rng64, void *d_verdict,
                                 void *d_msm_out, hipStream_t s, bool rlc = false, const void *d_weights64 = nullptr,
-                                void *d_batch_out = nullptr) {
+                                void *d_batch_out = nullptr, const rp_seg *h_segs = nullptr, uint32_t nseg = 0, bool dev_call = false) {
+    // h_segs (bpgpu_pool_*, coalesced launch): the nbatch proofs are the concatenation of nseg submitted items, each with its
+    // own input / output buffers (d_proofs, d_commitments, d_verdict, d_msm_out unused; d_msm_out non-null = some item wants encodings)
     // rlc: batch-combination mode (bpgpu_rangeproof_verify_rlc[_dev]); d_msm_out is unused then, d_batch_out
     // (33 bytes, optional) receives the batch verdict and the encoding of the combined point
     if (nbatch == 0) {
@@ -1287,6 +1309,8 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         }
     }
     if (tr.shared_ts && !ts_state_ok(tr.shared_ts)) return fail(c, BPGPU_ERR_INVALID_ARG, "malformed transcript state");
+    if (h_segs && (all_verdict || rlc || tr.d_ts_in || tr.d_ts_out || tr.shared_ts))   // (the pool sends such items through the ordinary entry point)
+        return fail(c, BPGPU_ERR_INVALID_ARG, "coalesced launches take well-formed shapes, a label and per-proof verdicts only");
     if (all_verdict) {   // every proof of the batch has the same malformed length
         if (tr.d_ts_out) {   // FormatError leaves the caller's transcript untouched
             if (tr.d_ts_in) HIPCHK(c, hipMemcpyAsync(tr.d_ts_out, tr.d_ts_in, nbatch * BPGPU_TRANSCRIPT_BYTES, hipMemcpyDeviceToDevice, s));
@@ -1312,6 +1336,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     else if (c->gens_capacity < n || c->party_capacity < m) shape_verdict = BPGPU_VERDICT_INVALID_GENERATORS_LENGTH;
     else if (m == 0 || n * m != ((size_t)1 << k)) shape_verdict = BPGPU_VERDICT_VERIFICATION_ERROR;   // ipp.rs:209
     if (!shape_verdict && k > BP_RP_MAX_K) return fail(c, BPGPU_ERR_INVALID_ARG, "n*m > 2^%d not supported", BP_RP_MAX_K);
+    if (h_segs && shape_verdict) return fail(c, BPGPU_ERR_INVALID_ARG, "coalesced launches take well-formed shapes only");
 
     rp_shape sh;
     sh.n = (uint32_t)n;
@@ -1353,6 +1378,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const size_t off_fields = ap.add((size_t)fl.count * nbatch * BP_RP_REC * 4 + 16);
     const size_t off_mv = ap.add(nbatch);
     const size_t off_rng = ap.add(nbatch * 64);
+    const size_t off_segs = (h_segs && nseg > RP_SEG_INLINE) ? ap.add((size_t)nseg * sizeof(rp_seg)) : 0;
     // batch-combination mode: weights, coefficient accumulators, the column-sum reduction tree, and a batch-of-one
     // table walk (digits, partial sums, result)
     const uint32_t nsplit1 = rlc ? pick_splits(c, 1, npairs) : 0;
@@ -1399,6 +1425,24 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         HIPCHK(c, hipMemcpyAsync(a + off_wts, h, nbatch * 64, hipMemcpyHostToDevice, s));
         wts_ptr = (const uint8_t *)(a + off_wts);
     }
+    rp_seg_tab segtab;
+    memset(&segtab, 0, sizeof segtab);
+    if (h_segs && nseg <= RP_SEG_INLINE) {   // travels in the kernels' argument blocks
+        segtab.n = nseg;
+        memcpy(segtab.in, h_segs, (size_t)nseg * sizeof(rp_seg));
+    } else if (h_segs) {
+        char *h = nullptr;
+        rc = pin_alloc(c, s, (size_t)nseg * sizeof(rp_seg), &h);
+        if (rc) return rc;
+        memcpy(h, h_segs, (size_t)nseg * sizeof(rp_seg));
+        HIPCHK(c, hipMemcpyAsync(a + off_segs, h, (size_t)nseg * sizeof(rp_seg), hipMemcpyHostToDevice, s));
+        segtab.n = nseg;
+        segtab.ext = (const rp_seg *)(a + off_segs);
+    }
+    if (c->pin_off > c->pin_marked && dev_call) {   // rng / weights / segment table staged above, nothing else will be
+        rc = pin_mark(c, s);
+        if (rc) return rc;
+    }
     if (c->rp_status_dirty) HIPCHK(c, hipMemsetAsync(d_status, 0, c->rp_status_cap * 4, s));
     c->rp_status_dirty = true;   // until the kernel that resets the words has been enqueued
     rp_strobe_init init;
@@ -1439,7 +1483,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     LAUNCH(c, s, "rp_stage1", k_rp_stage1, n_tr + n_pt, RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
            (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits,
            rlc ? wts_ptr : (const uint8_t *)nullptr, ts_flags, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
-           rlc_bucket ? bd.pts : (fb_entry *)nullptr, rlc_bucket ? bkp.c : 0u);
+           rlc_bucket ? bd.pts : (fb_entry *)nullptr, rlc_bucket ? bkp.c : 0u, segtab);
     if (shape_verdict) {
         HIPCHK(c, hipMemsetAsync(d_mv, 1, nbatch, s));
         LAUNCH(c, s, "rp_verdict", k_rp_verdict, (nb32 + 63) / 64, 64, nb32, d_status, d_mv, (uint8_t *)d_verdict);
@@ -1537,9 +1581,9 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     uint32_t nred = 0;
     enqueue_fb_reduce(c, s, nb32, nsplit, d_partial, &d_red, &nred, 64);   // 8 lanes x <= 8 partials each in finish8
     if (d_msm_out)
-        LAUNCH(c, s, "finish8", k_finish8<true>, (nb32 + 7) / 8, 64, nb32, nred, d.hq, d_red, d_status, (uint32_t *)d_msm_out, (uint8_t *)d_verdict, 1);
+        LAUNCH(c, s, "finish8", k_finish8<true>, (nb32 + 7) / 8, 64, nb32, nred, d.hq, d_red, d_status, (uint32_t *)d_msm_out, (uint8_t *)d_verdict, 1, segtab);
     else
-        LAUNCH(c, s, "finish8", k_finish8<false>, (nb32 + 7) / 8, 64, nb32, nred, d.hq, d_red, d_status, (uint32_t *)nullptr, (uint8_t *)d_verdict, 1);
+        LAUNCH(c, s, "finish8", k_finish8<false>, (nb32 + 7) / 8, 64, nb32, nred, d.hq, d_red, d_status, (uint32_t *)nullptr, (uint8_t *)d_verdict, 1, segtab);
     HIPCHK(c, hipGetLastError());
     c->rp_status_dirty = false;
     return BPGPU_OK;
@@ -1557,7 +1601,50 @@ static int rp_dev_call(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const vo
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     int rc = ctx_enter(c, s);
     if (rc) return rc;
-    rc = rp_verify_dev_locked(c, n, m, nbatch, d_proofs, proof_len, d_commitments, tr, d_rng64, d_verdict, d_msm_out, s, rlc, d_weights64, d_batch_out);
+    rc = rp_verify_dev_locked(c, n, m, nbatch, d_proofs, proof_len, d_commitments, tr, d_rng64, d_verdict, d_msm_out, s, rlc, d_weights64, d_batch_out,
+                              nullptr, 0, true);
+    const int rc2 = ctx_leave(c, s);
+    return rc ? rc : rc2;
+}
+
+// ---- hooks of the pool (pool.hip; not part of the C ABI) -----------------------------------------------------
+// can batches of this shape share a launch chain?  (malformed lengths / parameter errors take the ordinary entry point,
+// which reports them per proof)
+bool bpgpu_internal_rp_coalescible(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len) {
+    if (proof_len % 32 != 0 || proof_len < 9 * 32 || ((proof_len / 32 - 9) & 1)) return false;
+    const size_t k = (proof_len / 32 - 9) / 2;
+    if (k > BP_RP_MAX_K || !(n == 8 || n == 16 || n == 32 || n == 64) || m == 0) return false;
+    std::lock_guard<std::mutex> lk(c->mu);
+    return c->d_table && c->gens_capacity >= n && c->party_capacity >= m && n * m == ((size_t)1 << k);
+}
+// has everything enqueued on the context's own stream completed?
+bool bpgpu_internal_idle(bpgpu_ctx *c) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (hipSetDevice(c->device) != hipSuccess) return false;
+    const hipError_t e = hipStreamQuery(c->stream);
+    if (e != hipSuccess) (void)hipGetLastError();   // hipErrorNotReady is not an error
+    return e == hipSuccess;
+}
+// one coalesced launch chain over the concatenation of `nseg` items, on the context's own stream (asynchronous)
+int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, const uint8_t *label, size_t label_len, const rp_seg *segs,
+                                  uint32_t nseg, bool any_msm, uint32_t splits_hint) {
+    if (!c || !segs || nseg == 0) return BPGPU_ERR_INVALID_ARG;
+    const size_t total = (size_t)segs[nseg - 1].first + segs[nseg - 1].count;
+    bool any_rng_missing = false;
+    for (uint32_t i = 0; i < nseg; i++) any_rng_missing = any_rng_missing || !segs[i].rng64;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    rp_transcripts tr;
+    tr.label = label;
+    tr.label_len = label_len;
+    c->splits_hint = splits_hint;
+    // d_rng64: a non-null dummy keeps the library from drawing randomness nobody reads (every item brought its own)
+    rc = rp_verify_dev_locked(c, n, m, total, nullptr, proof_len, nullptr, tr, any_rng_missing ? nullptr : (const void *)segs[0].rng64, nullptr,
+                              any_msm ? (void *)segs : nullptr, s, false, nullptr, nullptr, segs, nseg, true);
+    c->splits_hint = 0;
     const int rc2 = ctx_leave(c, s);
     return rc ? rc : rc2;
 }
@@ -1656,7 +1743,9 @@ static int rp_host_call(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const u
         // the combination is not the identity: some proof fails -- find out which, proof by proof (inputs are still on the device)
         uint8_t bo[33];
         memcpy(bo, h_out + sz_v + sz_o, 33);
-        rc = ctx_enter(c, s);
+        // h_out may sit in a buffer that the first pass outgrew (its nested allocations for library-drawn rng / weights)
+        // and retired: it must stay alive until the verdicts below have been copied out of it
+        rc = ctx_enter(c, s, true);
         if (rc) return rc;
         rc = rp_verify_dev_locked(c, n, m, nbatch, d_p, proof_len, d_c, tr, rng64 ? d_r : nullptr, d_v, nullptr, s);
         if (!rc && hipMemcpyAsync(h_out, d_v, sz_v, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(64) k_shared_finish(uint32_t nproofs, uint32_t
 // shared_finish; `reset_status` hands the status words back zeroed for the next call on this context.
 template <bool WITH_OUT>   // WITH_OUT = false: verdicts only (no compression code, a third of the registers)
 __global__ void __launch_bounds__(64) k_finish8(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, const ge_ext *partial, uint32_t *status,
-                                                 uint32_t *out_words, uint8_t *verdict, int reset_status) {
+                                                 uint32_t *out_words, uint8_t *verdict, int reset_status, rp_seg_tab segs) {
     __shared__ ge_ext xch[64];
     const uint32_t lane = threadIdx.x, j = lane & 7, p = blockIdx.x * 8 + (lane >> 3);
     const bool live = p < nproofs;
@@ -118,7 +118,12 @@ __global__ void __launch_bounds__(64) k_finish8(uint32_t nproofs, uint32_t nspli
         __syncthreads();
     }
     if (live && j == 0) {
-        shared_finish_tail(p, acc, status, WITH_OUT ? out_words : nullptr, verdict);
+        if (segs.n) {   // coalesced launch: the verdict goes to the buffers of the item the proof came with
+            const rp_seg sg = rp_seg_lookup(segs, p);
+            shared_finish_tail(p, p - sg.first, acc, status, WITH_OUT ? sg.msm_out : nullptr, sg.verdict);
+        } else {
+            shared_finish_tail(p, acc, status, WITH_OUT ? out_words : nullptr, verdict);
+        }
         if (reset_status) status[p] = 0;
     }
 }
@@ -135,5 +140,5 @@ __global__ void __launch_bounds__(64) k_from_uniform(uint32_t n, const uint32_t 
     for (int i = 0; i < 8; i++) out[8 * (uint64_t)g + i] = o[i];
 }
 
-template __global__ void k_finish8<true>(uint32_t, uint32_t, const ge_ext *, const ge_ext *, uint32_t *, uint32_t *, uint8_t *, int);
-template __global__ void k_finish8<false>(uint32_t, uint32_t, const ge_ext *, const ge_ext *, uint32_t *, uint32_t *, uint8_t *, int);
+template __global__ void k_finish8<true>(uint32_t, uint32_t, const ge_ext *, const ge_ext *, uint32_t *, uint32_t *, uint8_t *, int, rp_seg_tab);
+template __global__ void k_finish8<false>(uint32_t, uint32_t, const ge_ext *, const ge_ext *, uint32_t *, uint32_t *, uint8_t *, int, rp_seg_tab);

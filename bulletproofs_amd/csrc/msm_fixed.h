@@ -226,15 +226,19 @@ BP_HD void fb_reduce_thread(uint32_t tid, uint32_t nproofs, uint32_t nsplit, uin
 
 // ---- finish --------------------------------------------------------------------------
 // last step for proof p: compress / identity test of the accumulated point, masked by the front end's status
-BP_HD void shared_finish_tail(uint32_t p, const ge_ext &acc, const uint32_t *status, uint32_t *out_words, uint8_t *verdict) {
+// (po: the proof's index in the output arrays -- differs from p when the launch is a coalesced one, rangeproof.h rp_seg)
+BP_HD void shared_finish_tail(uint32_t p, uint32_t po, const ge_ext &acc, const uint32_t *status, uint32_t *out_words, uint8_t *verdict) {
     const bool bad = status[p] != 0;
     if (out_words) {
         uint32_t w[8];
         ristretto_compress(w, acc);
 #pragma unroll
-        for (int i = 0; i < 8; i++) out_words[8 * (uint64_t)p + i] = bad ? 0u : w[i];
+        for (int i = 0; i < 8; i++) out_words[8 * (uint64_t)po + i] = bad ? 0u : w[i];
     }
-    if (verdict) verdict[p] = bad ? (uint8_t)status[p] : (ge_is_identity(acc) ? 0 : 1);
+    if (verdict) verdict[po] = bad ? (uint8_t)status[p] : (ge_is_identity(acc) ? 0 : 1);
+}
+BP_HD void shared_finish_tail(uint32_t p, const ge_ext &acc, const uint32_t *status, uint32_t *out_words, uint8_t *verdict) {
+    shared_finish_tail(p, p, acc, status, out_words, verdict);
 }
 // lane j (0..7) of proof p: its share of the partial sums, s = j, j+8, ...; lane 7 also takes the Horner result.
 // Returns false when the lane has nothing to add (acc is then the identity).

@@ -41,6 +41,65 @@ struct rp_strobe_init {
     uint32_t pos, pos_begin, cur_flags;
 };
 
+// ---- coalesced launches (bpgpu_pool_*, include/bpgpu.h) ---------------------------------------------------------
+// Several submitted batches of one shape verified by ONE launch chain: proofs [first, first + count) of the launch are
+// item `i`'s, read from and reported to that item's own buffers.  Only the first launch (inputs) and the last one
+// (verdicts) look at the table; everything in between indexes the launch-wide scratch by the global proof number.
+struct rp_seg {
+    const uint8_t *proofs, *commitments;
+    const uint8_t *rng64;     // may be null: the launch-wide rng buffer at the proof's global index
+    uint8_t *verdict;
+    uint32_t *msm_out;        // may be null
+    uint32_t first, count;
+};
+// index of the segment holding global proof p (segs sorted by first, segs[0].first == 0)
+BP_HD uint32_t rp_seg_find(const rp_seg *segs, uint32_t nseg, uint32_t p) {
+    uint32_t lo = 0, hi = nseg;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (segs[mid].first <= p) lo = mid;
+        else hi = mid;
+    }
+    return lo;
+}
+// The table as the kernels get it, BY VALUE in their argument block: up to RP_SEG_INLINE items inline (the usual case: a few
+// batches of ~1024 proofs per chain -- no upload, no extra copy command in the stream), more through `ext` (device memory).
+// n == 0: not a coalesced launch.
+#define RP_SEG_INLINE 8
+struct rp_seg_tab {
+    const rp_seg *ext;
+    uint32_t n, pad;
+    rp_seg in[RP_SEG_INLINE];
+};
+BP_HD rp_seg rp_seg_lookup(const rp_seg_tab &t, uint32_t p) {
+    if (t.ext) return t.ext[rp_seg_find(t.ext, t.n, p)];
+    rp_seg r = t.in[0];
+#pragma unroll
+    for (uint32_t i = 1; i < RP_SEG_INLINE; i++)   // static indices only: the argument block is read with scalar loads
+        if (i < t.n && t.in[i].first <= p) r = t.in[i];
+    return r;
+}
+// one proof's inputs: its bytes, its m commitments, its 64 rng bytes
+struct rp_inputs {
+    const uint8_t *pr, *cm, *rs;
+};
+BP_HD rp_inputs rp_resolve(uint32_t p, const rp_shape &sh, const uint8_t *proofs, const uint8_t *commitments, const uint8_t *rng64,
+                           const rp_seg_tab &segs) {
+    rp_inputs in;
+    if (segs.n) {
+        const rp_seg sg = rp_seg_lookup(segs, p);
+        const uint32_t q = p - sg.first;
+        in.pr = sg.proofs + (uint64_t)q * sh.proof_len;
+        in.cm = sg.commitments + (uint64_t)q * sh.m * 32;
+        in.rs = sg.rng64 ? sg.rng64 + (uint64_t)q * 64 : (rng64 ? rng64 + (uint64_t)p * 64 : nullptr);
+    } else {
+        in.pr = proofs + (uint64_t)p * sh.proof_len;
+        in.cm = commitments + (uint64_t)p * sh.m * 32;
+        in.rs = rng64 ? rng64 + (uint64_t)p * 64 : nullptr;
+    }
+    return in;
+}
+
 // field-major scalar store
 enum {
     RPF_Y = 0, RPF_Z, RPF_X, RPF_W, RPF_C, RPF_TX, RPF_TXB, RPF_EB, RPF_A, RPF_B,
@@ -136,11 +195,11 @@ BP_HD void rp_ts_passthrough(uint32_t p, const rp_strobe_init &init, const uint3
 // ts_flags / ts_in / ts_out: caller-supplied transcripts (bpgpu_rangeproof_verify_batch_ts): the start state is
 // ts_in[p] if given, else `init`; with BP_TS_DOMSEP it does not contain rangeproof_domain_sep(n, m) yet
 // (transcript.rs:44-48), which is then applied here; ts_out[p] (optional) receives the advanced state.
-BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &init, kstate st, const uint8_t *proofs,
-                                const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields, uint32_t *status,
+// `in`: where this proof's bytes, commitments and rng bytes are (rp_resolve)
+BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &init, kstate st, const rp_inputs &in, uint32_t *fields, uint32_t *status,
                                 uint32_t ts_flags = 0, const uint32_t *ts_in = nullptr, uint32_t *ts_out = nullptr) {
     const uint32_t B = sh.nproofs, k = sh.k;
-    const uint8_t *pr = proofs + (uint64_t)p * sh.proof_len;
+    const uint8_t *pr = in.pr;
     const rp_fields fl = rp_field_layout(k, sh.m);
     uint32_t w[8];
     // --- from_bytes: the five scalars must be canonical (mod.rs:519-524, ipp.rs:401-404)
@@ -201,7 +260,7 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
 
     // V_j: append_point, no identity check (mod.rs:370-374)
     for (uint32_t j = 0; j < sh.m; j++) {
-        load_words8(w, commitments + ((uint64_t)p * sh.m + j) * 32);
+        load_words8(w, in.cm + (uint64_t)j * 32);
         merlin_append_words8(t, lV, 1, w);
     }
     // A, S: validate_and_append_point (transcript.rs:75-87)
@@ -228,7 +287,7 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
     // batching challenge c = Scalar::random(rng) (mod.rs:396): 64 rng bytes, wide-reduced
     {
         uint32_t cw[16];
-        const uint8_t *rs = rng64 + (uint64_t)p * 64;
+        const uint8_t *rs = in.rs;
         load_words8(cw, rs);
         load_words8(cw + 8, rs + 32);
         sc_from_wide(c, cw);
@@ -264,22 +323,21 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
 // ---- stage 1b: per-proof points -----------------------------------------------------------
 // unique term u of proof p, in the order A, S, T_1, T_2, L_0..L_{k-1}, R_0..R_{k-1}, V_0..V_{m-1}
 // (the non-generator part of mod.rs:433-443)
-BP_HD const uint8_t *rp_unique_point_ptr(const rp_shape &sh, const uint8_t *proofs, const uint8_t *commitments, uint32_t p, uint32_t u) {
-    const uint8_t *pr = proofs + (uint64_t)p * sh.proof_len;
+BP_HD const uint8_t *rp_unique_point_ptr(const rp_shape &sh, const rp_inputs &in, uint32_t u) {
     const uint32_t k = sh.k;
-    if (u < 4) return pr + 32 * u;
-    if (u < 4 + k) return pr + 224 + 64 * (u - 4);
-    if (u < 4 + 2 * k) return pr + 224 + 64 * (u - 4 - k) + 32;
-    return commitments + ((uint64_t)p * sh.m + (u - 4 - 2 * k)) * 32;
+    if (u < 4) return in.pr + 32 * u;
+    if (u < 4 + k) return in.pr + 224 + 64 * (u - 4);
+    if (u < 4 + 2 * k) return in.pr + 224 + 64 * (u - 4 - k) + 32;
+    return in.cm + (uint64_t)(u - 4 - 2 * k) * 32;
 }
 // thread t = p * U + u: decode the point (mod.rs:433-443 .decompress()) and build its {1..8}P table.
 // An undecodable point is the Option::None of optional_multiscalar_mul -> VerificationError (mod.rs:445).
 // pts (optional, instead of tab): bucket path (bucket.h) -- store the point as one affine Niels record instead.
-BP_HD void rp_points_thread(uint32_t t, rp_shape sh, const uint8_t *proofs, const uint8_t *commitments, ge_cached *tab, uint32_t *status,
-                            fb_entry *pts = nullptr) {
+// (p = t / U; `in` = rp_resolve(p, ...))
+BP_HD void rp_points_thread(uint32_t t, rp_shape sh, const rp_inputs &in, ge_cached *tab, uint32_t *status, fb_entry *pts = nullptr) {
     const uint32_t p = t / sh.U, u = t - p * sh.U;
     uint32_t w[8];
-    load_words8(w, rp_unique_point_ptr(sh, proofs, commitments, p, u));
+    load_words8(w, rp_unique_point_ptr(sh, in, u));
     ge_ext pt;
     if (!ristretto_decompress(pt, w)) status_raise(status + p, BP_VERDICT_VERIFICATION);
     if (pts) bk_store_point(pts + t, pt);

@@ -59,7 +59,42 @@ def reference_point_ops(N):
     return cols * (N + 2 ** w - 2) + 256
 
 
+def executed_point_ops(n, m, window_bits, nsplit):
+    """Point additions + doublings this engine performs per verification: one mixed addition per (generator,
+    window) of the table walk, `nsplit` additions to fold the per-split partial sums, per unique point 7 operations for its
+    {1..8}P table and one addition in each of the 64 radix-16 windows (plus the column sums over chunks of 32 points when
+    there are more), and one Horner chain of 252 doublings + 63 additions."""
+    k = (n * m).bit_length() - 1
+    U = 4 + 2 * k + m
+    nwin = -(-255 // window_bits)
+    chunks = -(-U // 32)
+    return (2 * n * m + 2) * nwin + nsplit + U * 7 + U * 64 + (chunks - 1) * 64 + 252 + 63
+
+
 def algorithmic_bytes_per_verification(n, m):
     """MSM-boundary figure of SURVEY.md section 8(d): 32N scalars + 32(4+2k+m) unique points + 32 result."""
     k = (n * m).bit_length() - 1
     return 32 * msm_terms(n, m) + 32 * (4 + 2 * k + m) + 32
+
+
+# ---- BASELINE config 5: the R1CS verifier's MSM shape (SURVEY.md 8d) ------------------------------------------------
+CFG5 = dict(n=2048, m=1, n_unique=2081, nbatch=64)
+
+
+def cfg5_inputs(G2, H2, nbatch=64):
+    """Inputs of the config-5 MSM batch: uniform scalars (SHAKE256-derived, top nibble cleared: canonical) for the 4098 generator
+    terms and the 2081 per-MSM points of each MSM, and the per-MSM points themselves: RistrettoPoint::from_uniform_bytes outputs,
+    as SURVEY.md 8d specifies -- the party-1 chains of BulletproofGens::new(2048, 2) (SHAKE256("GeneratorsChain" || 'G'/'H' ||
+    u32le(1)) -> from_uniform_bytes, generators.rs:58-104), 4096 points none of which is among the MSM's own generator terms
+    (party 0), rotated by 31 per MSM.  G2 / H2: the exported G / H encodings of a (2048, 2) generator set.
+    Returns (gen_scalars, uniq_scalars, uniq_points) as bytes."""
+    import hashlib
+    n, nu = CFG5["n"], CFG5["n_unique"]
+    ng = 2 * n + 2
+    raw = bytearray(hashlib.shake_256(b"cfg5-scalars").digest(32 * (ng + nu) * nbatch))
+    for i in range(31, len(raw), 32):
+        raw[i] &= 0x0f
+    assert len(G2) == len(H2) == 32 * 2 * n
+    pool = G2[32 * n:] + H2[32 * n:]                  # party 1
+    upts = b"".join(pool[32 * ((i + 31 * b) % (2 * n)):32 * ((i + 31 * b) % (2 * n)) + 32] for b in range(nbatch) for i in range(nu))
+    return bytes(raw[:32 * ng * nbatch]), bytes(raw[32 * ng * nbatch:]), upts

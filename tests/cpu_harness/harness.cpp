@@ -243,6 +243,10 @@ void h_sum_of_powers_pow2(const uint8_t *x, uint32_t lg, uint8_t *out) {
 
 static int g_horner_lanes = 4;
 void h_set_horner_lanes(int lanes) { g_horner_lanes = lanes; }
+// coalesced launches (rp_seg, bpgpu_pool_*): when set, h_rp_verify reads its inputs through a segment table whose
+// items live in separate buffers (every second one without rng bytes of its own) and reports through it
+static std::vector<uint32_t> g_seg_sizes;
+void h_set_segments(uint32_t count, const uint32_t *sizes) { g_seg_sizes.assign(sizes, sizes + count); }
 
 // Whole verification pipeline, lane by lane, in the launch structure of the HIP runtime:
 //   launch 1: rp_transcript + rp_expand_a  ||  rp_points
@@ -279,13 +283,52 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
     std::vector<uint32_t> fields((size_t)fl.count * nbatch * BP_RP_REC + 8), rec((size_t)t0 * 8 + 8, 0xdeadbeefu), status(nbatch + 1, 0), outw((size_t)nbatch * 8 + 1);
     std::vector<fb_digit> digits((size_t)npairs * nbatch + 1, 0xffff);   // poison: unwritten rows must be masked
     std::vector<ge_cached> tab((size_t)t0 * 8 + 1);
+    // coalesced launch: scatter the inputs into per-item buffers and hide the contiguous ones
+    std::vector<rp_seg> segs;
+    std::vector<std::vector<uint8_t>> seg_bufs;
+    std::vector<std::vector<uint8_t>> seg_verdict;
+    std::vector<std::vector<uint32_t>> seg_msm;
+    if (!g_seg_sizes.empty() && !weights64) {
+        uint32_t first = 0;
+        for (size_t i = 0; i < g_seg_sizes.size() && first < nbatch; i++) {
+            const uint32_t cnt = (i + 1 == g_seg_sizes.size() || first + g_seg_sizes[i] > nbatch) ? nbatch - first : g_seg_sizes[i];
+            if (cnt == 0) continue;
+            rp_seg sg;
+            seg_bufs.emplace_back(proofs + (size_t)first * proof_len, proofs + (size_t)(first + cnt) * proof_len);
+            sg.proofs = seg_bufs.back().data();
+            seg_bufs.emplace_back(commitments + (size_t)first * m * 32, commitments + (size_t)(first + cnt) * m * 32);
+            sg.commitments = seg_bufs.back().data();
+            if (i & 1) sg.rng64 = nullptr;
+            else {
+                seg_bufs.emplace_back(rng64 + (size_t)first * 64, rng64 + (size_t)(first + cnt) * 64);
+                sg.rng64 = seg_bufs.back().data();
+            }
+            seg_verdict.emplace_back(cnt, 0xee);
+            seg_msm.emplace_back((size_t)cnt * 8, 0xeeeeeeeeu);
+            sg.first = first;
+            sg.count = cnt;
+            segs.push_back(sg);
+            first += cnt;
+        }
+        for (size_t i = 0; i < segs.size(); i++) {
+            segs[i].verdict = seg_verdict[i].data();
+            segs[i].msm_out = seg_msm[i].data();
+        }
+    }
+    rp_seg_tab segtab;
+    memset(&segtab, 0, sizeof segtab);
+    segtab.n = (uint32_t)segs.size();
+    if (segs.size() <= RP_SEG_INLINE) memcpy(segtab.in, segs.data(), segs.size() * sizeof(rp_seg));   // the inline form of the argument block
+    else segtab.ext = segs.data();
+    const rp_seg_tab *sgp = segs.empty() ? nullptr : &segtab;   // (segtab.n == 0: contiguous launch)
+    const uint8_t *proofs_l1 = sgp ? nullptr : proofs, *coms_l1 = sgp ? nullptr : commitments;
     // launch 1
     for (uint32_t p = 0; p < nbatch; p++) {
         uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;
-        rp_transcript_thread(p, sh, init, st, proofs, commitments, rng64, fields.data(), status.data());
+        rp_transcript_thread(p, sh, init, st, rp_resolve(p, sh, proofs_l1, coms_l1, rng64, segtab), fields.data(), status.data());
         rp_expand_a_thread(p, sh, prm, lg_m, fields.data(), rec.data(), digits.data(), status.data(), weights64);
     }
-    for (uint32_t t = 0; t < t0; t++) rp_points_thread(t, sh, proofs, commitments, tab.data(), status.data());
+    for (uint32_t t = 0; t < t0; t++) rp_points_thread(t, sh, rp_resolve(t / sh.U, sh, proofs_l1, coms_l1, nullptr, segtab), tab.data(), status.data());
     // launch 2
     std::vector<uint64_t> acc((size_t)n_gen_terms * 10, 0);
     if (weights64) {
@@ -381,7 +424,18 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
         for (uint32_t j = 0; j < 8; j++) shared_finish8_gather(x[j], p, j, nbatch, nsplit, hq.data(), partial.data());
         for (uint32_t step = 4; step >= 1; step >>= 1)
             for (uint32_t j = 0; j < step; j++) { const ge_ext q = x[j + step]; ge_add(x[j], x[j], q); }
-        shared_finish_tail(p, x[0], status.data(), outw.data(), verdict.data());
+        if (sgp) {
+            const rp_seg sg = rp_seg_lookup(*sgp, p);
+            shared_finish_tail(p, p - sg.first, x[0], status.data(), sg.msm_out, sg.verdict);
+        } else {
+            shared_finish_tail(p, x[0], status.data(), outw.data(), verdict.data());
+        }
+    }
+    if (sgp) {   // gather the per-item outputs
+        for (size_t i = 0; i < segs.size(); i++) {
+            memcpy(verdict.data() + segs[i].first, seg_verdict[i].data(), segs[i].count);
+            memcpy(outw.data() + (size_t)segs[i].first * 8, seg_msm[i].data(), (size_t)segs[i].count * 32);
+        }
     }
     for (uint32_t p = 0; p < nbatch; p++) verdict_out[p] = verdict[p];
     if (msm_out) memcpy(msm_out, outw.data(), (size_t)nbatch * 32);

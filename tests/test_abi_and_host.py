@@ -41,6 +41,26 @@ def test_no_cpu_fallback(built):
         built.Context(0)
 
 
+def test_pool_refuses_without_device_and_with_too_few_hardware_queues(built):
+    """bpgpu_pool_create: no CPU fallback either; and it fails loudly (BPGPU_ERR_HW_QUEUES) when GPU_MAX_HW_QUEUES was set to a
+    value on which its lanes would serialise.  The library itself asks for 16 queues when the variable is unset."""
+    code = ("import os, sys; sys.path.insert(0, %r); import ctypes as C; import bulletproofs_amd as bp; L = bp.lib();"
+            "g = C.CDLL(None).getenv; g.restype = C.c_char_p; print((g(b'GPU_MAX_HW_QUEUES') or b'None').decode()); h = C.c_void_p(); d = (C.c_int * 1)(0);"
+            "print(L.bpgpu_pool_create(d, 1, 32, C.byref(h))); print(L.bpgpu_pool_create(d, 1, 2, C.byref(h)) in (0, -4));"
+            "print(L.bpgpu_pool_create(d, 0, 2, C.byref(h)))" % ROOT)
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().split()
+    assert out[0] == "16" and out[1] in ("0", "-4") and out[2] == "True" and out[3] == "-1"     # unset -> the library set 16
+    env["GPU_MAX_HW_QUEUES"] = "4"
+    out = subprocess.check_output([sys.executable, "-c", code], env=env).decode().split()
+    assert out[0] == "4" and out[1] == "-6" and out[2] == "True"                                # 32 lanes on 4 queues: refused; 2 lanes: fine
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(built.BpgpuError, match="NO_DEVICE"):
+            built.Pool((0,), 8)
+
+
 def test_product_never_imports_oracle():
     pkg = os.path.join(ROOT, "bulletproofs_amd")
     for dirpath, _, files in os.walk(pkg):

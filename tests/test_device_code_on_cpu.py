@@ -332,6 +332,41 @@ def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, gol
     assert list(vd.raw) == [2, 1, 1, 0]
 
 
+def test_coalesced_launch_segment_table_lane_by_lane(H, oracle, golden):
+    """bpgpu_pool_*'s coalesced launches (rp_seg, csrc/rangeproof.h): the proofs of one launch come from several submitted
+    items, each with its own proof / commitment / rng buffers (every second item without rng bytes of its own) and its own
+    verdict / encoding buffers.  Lane by lane: same results as the contiguous launch and as the oracle."""
+    H.h_set_horner_lanes(4)
+    label = golden["label"]
+    vc = golden["vc_bytes"]
+    case = [c for c in golden["cases"] if c["n"] == 8 and c["m"] == 2][0]
+    n, m = 8, 2
+    pr = bytes.fromhex(case["proof"])
+    nb = 11
+    plist = []
+    for b in range(nb):
+        q = bytearray(pr)
+        if b in (2, 5):
+            q[128] ^= 1 << b                                   # VerificationError
+        if b == 4:
+            q[160:192] = b"\xff" * 32                           # FormatError
+        plist.append(bytes(q))
+    proofs = b"".join(plist)
+    coms = b"".join(vc[:32 * m] if b != 6 else vc[32:32 * m] + vc[:32] for b in range(nb))
+    rng = hashlib.shake_256(b"segs").digest(64 * nb)
+    gg = oracle.Gens(n, m)
+    G2, H2, B2, Bb2 = gg.export()
+    exp = [oracle.verify(gg, plist[b], coms[32 * m * b:32 * m * (b + 1)], n, label, rng[64 * b:64 * b + 64]) for b in range(nb)]
+    assert [e[0] for e in exp] == [0, 0, 1, 0, 2, 1, 1, 0, 0, 0, 0]
+    for sizes in ([], [1] * 11, [1, 1, 1, 1, 1, 1, 1, 4], [3, 8], [2, 1, 3, 1, 4], [10, 1], [11]):   # > 8 items: table in memory, else inline
+        H.h_set_segments(len(sizes), (C.c_uint32 * max(len(sizes), 1))(*sizes))
+        vd, mo = C.create_string_buffer(nb), C.create_string_buffer(32 * nb)
+        assert H.h_rp_verify(4, 3, n, m, Bb2 + B2 + G2 + H2, n, m, nb, proofs, len(pr), coms, label, len(label), rng, vd, mo) == 0
+        for b in range(nb):
+            assert vd.raw[b] == exp[b][0] and mo.raw[32 * b:32 * b + 32] == exp[b][1], (sizes, b)
+    H.h_set_segments(0, (C.c_uint32 * 1)(0))
+
+
 def test_window_recoding_all_widths(H):
     """fb_recode / fb_nwin (msm_fixed.h): for every window width 2..20 the signed digits reconstruct the scalar and
     ceil(255 / W) windows suffice (W = 17 is the first width that saves a window: 15 instead of 16)."""

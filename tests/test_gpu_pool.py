@@ -1,0 +1,176 @@
+"""bpgpu_pool_* (include/bpgpu.h): the scheduler of the library -- ONE host-pointer call for any number of proofs, sliced
+over the pool's lanes and sharded over its devices, and asynchronous device-pointer batches coalesced into wide launch
+chains.  The call shape replaced: a loop over RangeProof::verify_multiple (src/range_proof/mod.rs:457-470).  Every verdict
+byte (and mega-check encoding) must equal the oracle's, whatever the slicing / coalescing."""
+import hashlib
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from test_gpu_bench_config import _tamper  # noqa: E402
+
+
+def _oracle_all(oracle, gens, fx, proofs, coms, rng):
+    _, ev, em = oracle.verify_batch(gens, proofs, coms, fx.m, fx.n, fx.label, rng, threads=os.cpu_count() or 1)
+    return ev, em
+
+
+def _msm_equal(ev, em, msm):
+    for i in range(len(ev)):   # the oracle leaves 0xff.. for proofs it rejects before the MSM
+        if ev[i] in (0, 1) and em[32 * i:32 * i + 32] != b"\xff" * 32:
+            assert msm[32 * i:32 * i + 32] == em[32 * i:32 * i + 32], i
+
+
+@pytest.fixture(scope="module")
+def cfg2():
+    from bulletproofs_amd import workload as wl
+    return wl.load_fixture("cfg2_n64_m1")
+
+
+def test_pool_one_call_65536_tampered_proofs_vs_oracle(oracle, cfg2):
+    """ONE call, ONE host thread, host pointers, 65 536 proofs (~5 % tampered seven ways): verdicts == oracle."""
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    fx = cfg2
+    nb = 65536
+    proofs, coms = wl.tile_batch(fx, nb)
+    proofs, coms, bad = _tamper(proofs, coms, fx.proof_len, fx.m, nb, 77)
+    rng = hashlib.shake_256(b"pool-65536").digest(64 * nb)
+    pool = bp.Pool((0,), 16)
+    pool.gens_create(64, 1)
+    verdict = pool.rangeproof_verify(fx.n, fx.m, proofs, fx.proof_len, coms, fx.label, rng)
+    ev, _ = _oracle_all(oracle, oracle.Gens(64, 1), fx, proofs, coms, rng)
+    assert verdict == ev
+    assert sum(1 for v in ev if v) == len(bad)
+    # library-drawn randomness (rng64 = NULL, the thread_rng() of verify_multiple): same verdicts
+    assert pool.rangeproof_verify(fx.n, fx.m, proofs[:5000 * fx.proof_len], fx.proof_len, coms[:5000 * 32], fx.label) == ev[:5000]
+    pool.close()
+
+
+@pytest.mark.parametrize("devices,lanes,slice_proofs", [((0,), 4, 0), ((0, 0), 3, 700), ((0, 0, 0), 2, 64)])
+def test_pool_slicing_and_sharding_bit_exact(oracle, cfg2, devices, lanes, slice_proofs):
+    """Ragged sizes, explicit slice widths, several shards (two / three pool devices on the one GPU): verdicts AND encodings
+    == oracle; an empty call and a one-proof call work."""
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    fx = cfg2
+    pool = bp.Pool(devices, lanes, fixed_window_bits=16)
+    if slice_proofs:
+        pool.set_option("slice_proofs", slice_proofs)
+    pool.gens_create(64, 1)
+    assert pool.n_devices == len(devices) and pool.n_lanes == lanes
+    gens = oracle.Gens(64, 1)
+    for nb, seed in ((0, 1), (1, 2), (3001, 3)):
+        proofs, coms = wl.tile_batch(fx, nb, first=100 * seed)
+        if nb > 1:
+            proofs, coms, _ = _tamper(proofs, coms, fx.proof_len, fx.m, nb, seed)
+        rng = hashlib.shake_256(b"pool-%d" % seed).digest(64 * nb)
+        verdict, msm = pool.rangeproof_verify(fx.n, fx.m, proofs, fx.proof_len, coms, fx.label, rng, want_msm=True)
+        if nb == 0:
+            assert verdict == b"" and msm == b""
+            continue
+        ev, em = _oracle_all(oracle, gens, fx, proofs, coms, rng)
+        assert verdict == ev
+        _msm_equal(ev, em, msm)
+    pool.close()
+
+
+def test_pool_coalesced_device_batches_vs_oracle(oracle, cfg2):
+    """submit_dev: batches of different sizes (1, 300, 1024, 2048, 77), some with their own rng bytes and some without, some
+    wanting encodings: coalesced into chains of ~1500 proofs (items split across chains), plus a malformed-length batch and
+    a parameter-error batch in the same flush; every batch's own verdict buffer == oracle."""
+    import torch
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    fx = cfg2
+    dev = torch.device("cuda", 0)
+    pool = bp.Pool((0,), 4, fixed_window_bits=16)
+    pool.set_option("coalesce_proofs", 1500)
+    pool.set_option("auto_flush_items", 1000)
+    pool.gens_create(64, 1)
+    gens = oracle.Gens(64, 1)
+    to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    sizes = [1, 300, 1024, 2048, 77, 513]
+    items, first = [], 0
+    for i, nb in enumerate(sizes):
+        proofs, coms = wl.tile_batch(fx, nb, first=first)
+        first += nb
+        if nb > 1:
+            proofs, coms, _ = _tamper(proofs, coms, fx.proof_len, fx.m, nb, 10 + i, frac=0.1)
+        rng = hashlib.shake_256(b"co-%d" % i).digest(64 * nb)
+        own_rng, want_msm = (i % 2 == 0), (i % 3 != 2)
+        d = dict(nb=nb, proofs=proofs, coms=coms, rng=rng, d_p=to_dev(proofs), d_c=to_dev(coms), d_r=to_dev(rng) if own_rng else None,
+                 d_v=torch.full((nb,), 255, dtype=torch.uint8, device=dev),
+                 d_m=torch.full((nb, 32), 255, dtype=torch.uint8, device=dev) if want_msm else None)
+        items.append(d)
+    # a batch whose proofs have a malformed length (every proof FormatError) and one checked against n = 32 (parameter error)
+    bad_len = fx.proof_len - 32
+    d_bl = to_dev(items[2]["proofs"][:bad_len * 5])
+    d_blv = torch.full((5,), 255, dtype=torch.uint8, device=dev)
+    d_n32v = torch.full((300,), 255, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for rounds in range(2):
+        for i, d in enumerate(items):
+            pool.submit_dev(0, fx.n, fx.m, d["nb"], d["d_p"].data_ptr(), fx.proof_len, d["d_c"].data_ptr(), fx.label,
+                            d["d_r"].data_ptr() if d["d_r"] is not None else None, d["d_v"].data_ptr(), d["d_m"].data_ptr() if d["d_m"] is not None else None)
+            if i == 2:
+                pool.submit_dev(0, fx.n, fx.m, 5, d_bl.data_ptr(), bad_len, items[2]["d_c"].data_ptr(), fx.label, None, d_blv.data_ptr(), None)
+            if i == 3:
+                pool.submit_dev(0, 32, fx.m, 300, items[1]["d_p"].data_ptr(), fx.proof_len, items[1]["d_c"].data_ptr(), fx.label, None, d_n32v.data_ptr(), None)
+        pool.wait()
+        for d in items:
+            ev, em = _oracle_all(oracle, gens, fx, d["proofs"], d["coms"], d["rng"])
+            assert bytes(d["d_v"].cpu().numpy()) == ev
+            if d["d_m"] is not None and d["d_r"] is not None:     # encodings depend on the rng bytes: comparable when the item brought its own
+                _msm_equal(ev, em, bytes(d["d_m"].cpu().numpy().reshape(-1)))
+            d["d_v"].fill_(255)
+        assert bytes(d_blv.cpu().numpy()) == bytes([2] * 5)                      # FormatError, as RangeProof::from_bytes
+        # n = 32 against 64-bit proofs: n * m != 2^k -> VerificationError for well-formed proofs (ipp.rs:209), Format for the others
+        ev1, _ = _oracle_all(oracle, gens, fx, items[1]["proofs"], items[1]["coms"], items[1]["rng"])
+        assert bytes(d_n32v.cpu().numpy()) == bytes(2 if v == 2 else 1 for v in ev1)
+        torch.cuda.synchronize()
+    pool.close()
+
+
+def test_pool_burst_of_20_batches_coalesced_equals_per_batch_path(oracle, cfg2):
+    """The driver's burst (20 batches of 1024 submitted back to back, then one flush): every batch's verdicts are what
+    bpgpu_rangeproof_verify_batch_dev gives for it alone, and equal the oracle on two of them."""
+    import torch
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    fx = cfg2
+    dev = torch.device("cuda", 0)
+    pool = bp.Pool((0,), 32)
+    pool.gens_create(64, 1)
+    ctx = bp.Context(0)
+    ctx.gens_create(64, 1)
+    L = bp.lib()
+    K, nb = 20, 1024
+    proofs, coms = wl.tile_batch(fx, K * nb, first=123)
+    proofs, coms, bad = _tamper(proofs, coms, fx.proof_len, fx.m, K * nb, 99, frac=0.02)
+    rng = hashlib.shake_256(b"burst").digest(64 * K * nb)
+    to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_p, d_c, d_r = to_dev(proofs), to_dev(coms), to_dev(rng)
+    d_v = torch.full((K, nb), 255, dtype=torch.uint8, device=dev)
+    d_ref = torch.full((K, nb), 255, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for k in range(K):
+        pool.submit_dev(0, fx.n, fx.m, nb, d_p.data_ptr() + k * nb * fx.proof_len, fx.proof_len, d_c.data_ptr() + k * nb * 32, fx.label,
+                        d_r.data_ptr() + k * nb * 64, d_v[k].data_ptr())
+    pool.wait()
+    for k in range(K):
+        rc = L.bpgpu_rangeproof_verify_batch_dev(ctx.h, fx.n, fx.m, nb, d_p.data_ptr() + k * nb * fx.proof_len, fx.proof_len, d_c.data_ptr() + k * nb * 32,
+                                                 fx.label, len(fx.label), d_r.data_ptr() + k * nb * 64, d_ref[k].data_ptr(), None, None)
+        assert rc == 0
+    ctx.synchronize()
+    assert bool((d_v == d_ref).all().item())
+    assert int((d_v != 0).sum().item()) == len(bad)
+    gens = oracle.Gens(64, 1)
+    for k in (0, 13):
+        ev, _ = _oracle_all(oracle, gens, fx, proofs[k * nb * fx.proof_len:(k + 1) * nb * fx.proof_len], coms[k * nb * 32:(k + 1) * nb * 32],
+                            rng[k * nb * 64:(k + 1) * nb * 64])
+        assert bytes(d_v[k].cpu().numpy()) == ev
+    ctx.close()
+    pool.close()

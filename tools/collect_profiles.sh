@@ -2,7 +2,7 @@
 # Runs on the GPU box (via gpurun): rocprofv3 kernel stats of the bench commands, plus separate --pmc passes
 # (kernel-trace only, no other trace domains) for HBM traffic (FETCH_SIZE / WRITE_SIZE) and VALU work
 # (SQ_INSTS_VALU) per kernel, for cfg2 (the headline), cfg3 and the cfg5 MSM shape.  Output: gpurun_out/prof_$1/.
-TAG=${1:-r02}
+TAG=${1:-r03}
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
@@ -23,12 +23,13 @@ pmc() {  # name, counter list (quoted), args...
 }
 
 stats bench_default $B
-stats bench_streams1 $B --streams 1 --steps 256 --warmup 16
-stats bench_cfg3 $B --config cfg3 --streams 64 --steps 640 --warmup 64
+stats bench_steps20 $B --steps 20 --warmup 5
+stats bench_streams1 $B --direct --streams 1 --steps 256 --warmup 16
+stats bench_cfg3 $B --config cfg3 --steps 640 --warmup 64
 stats bench_cfg5 python $REPO/bench.py --cfg5-only 8
 
 for cfg in cfg2 cfg3 cfg4; do
-  A="$B --config $cfg --steps 8 --warmup 2 --streams 1"
+  A="$B --direct --config $cfg --steps 8 --warmup 2 --streams 1"
   pmc ${cfg}_fetch FETCH_SIZE $A
   pmc ${cfg}_write WRITE_SIZE $A
   pmc ${cfg}_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" $A
@@ -52,24 +53,24 @@ def per_kernel(d, counter):
         k = short(r["Kernel_Name"])
         acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"])
     return {k: {"dispatches": v[0], "avg_per_dispatch": v[1] / v[0]} for k, v in acc.items()}
-for cfg, what in (("cfg2", "bench.py --config cfg2 --steps 8 --warmup 2 --streams 1 (batch 1024)"),
-                  ("cfg3", "bench.py --config cfg3 --steps 8 --warmup 2 --streams 1 (batch 256)"),
-                  ("cfg4", "bench.py --config cfg4 --steps 8 --warmup 2 --streams 1 (batch 512)"),
-                  ("cfg5", "bench.py --cfg5-only 1 (batches of 64 MSMs of 6179 terms)")):
+for cfg, what, ppl in (("cfg2", "bench.py --direct --config cfg2 --steps 8 --warmup 2 --streams 1 (batch 1024)", 1024),
+                  ("cfg3", "bench.py --direct --config cfg3 --steps 8 --warmup 2 --streams 1 (batch 256)", 256),
+                  ("cfg4", "bench.py --direct --config cfg4 --steps 8 --warmup 2 --streams 1 (batch 512)", 512),
+                  ("cfg5", "bench.py --cfg5-only 1 (batches of 64 MSMs of 6179 terms)", 64)):
     rd, wr = per_kernel("/tmp/pm_%s_fetch" % cfg, "FETCH_SIZE"), per_kernel("/tmp/pm_%s_write" % cfg, "WRITE_SIZE")
     json.dump({"FETCH_SIZE": rd, "WRITE_SIZE": wr}, open("$OUT/pmc_fetch_write_raw_%s.json" % cfg, "w"), indent=1)
     # HBM bytes per launch, corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE is in KB and counts a
     # 128-byte request as 64 bytes (x2); WRITE_SIZE is in KB
     traffic = {"_note": "HBM bytes per launch = 2*FETCH_SIZE[KB]*1024 (gfx950: FETCH_SIZE counts 128-B requests as 64 B, MI355X_MICROARCH.md "
                "section HBM) + WRITE_SIZE[KB]*1024; separate rocprofv3 --pmc passes of %s, tools/collect_profiles.sh; raw counters in "
-               "profiles/$TAG/pmc_fetch_write_raw_%s.json" % (what, cfg)}
+               "profiles/$TAG/pmc_fetch_write_raw_%s.json" % (what, cfg), "_proofs_per_launch": ppl}
     for k in rd:
         traffic[k] = int(2 * rd[k]["avg_per_dispatch"] * 1024 + wr.get(k, {"avg_per_dispatch": 0})["avg_per_dispatch"] * 1024)
     json.dump(traffic, open("$OUT/pmc_traffic_%s.json" % cfg, "w"), indent=1)
     va = per_kernel("/tmp/pm_%s_valu" % cfg, "SQ_INSTS_VALU")
     work = {"_note": "SQ_INSTS_VALU per launch (wavefront-instructions), rocprofv3 --pmc pass of %s, tools/collect_profiles.sh; one batch = one launch of "
-            "each rp_* / finish8 kernel" % what, "_mad_u64_fraction": 0.58}
+            "each rp_* / finish8 kernel" % what, "_mad_u64_fraction": 0.58, "_proofs_per_launch": ppl}
     for k in va: work[k] = int(va[k]["avg_per_dispatch"])
     json.dump(work, open("$OUT/valu_work_%s.json" % cfg, "w"), indent=1)
-    print(cfg, "HBM bytes/launch:", {k: v for k, v in sorted(traffic.items(), key=lambda kv: -kv[1] if isinstance(kv[1], int) else 0)[:8] if k != "_note"})
+    print(cfg, "HBM bytes/launch:", {k: v for k, v in sorted(traffic.items(), key=lambda kv: -kv[1] if isinstance(kv[1], int) else 0)[:8] if not k.startswith("_")})
 PY
