@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument("--coalesce", type=int, default=0,
                     help="pool option coalesce_proofs: width the pool packs consecutive submitted batches into (default: the library's, 4096; "
                          "--coalesce = batch size means one launch chain per step, the round-2 behaviour)")
+    ap.add_argument("--no-script", action="store_true", help="library option transcript_script = 0: byte-wise transcript replay (A/B of csrc/rp_script.h)")
     ap.add_argument("--direct", action="store_true",
                     help="bypass the pool: call bpgpu_rangeproof_verify_batch_dev on --streams (context, stream) pairs round-robin (the round-2 protocol, for A/B)")
     ap.add_argument("--bucket-min", type=int, default=0, help="bucket_min_terms option of the library (0 = default; a huge value forces the table-lookup path)")
@@ -168,7 +169,7 @@ class RangeProofBench:
             # the library's scheduler: steps are SUBMITTED (device pointers) and the pool packs consecutive ones into launch chains
             self.pool = bp.Pool((local_dev,), nstreams, fixed_window_bits=a.window_bits or None, horner_lanes=a.horner_lanes or None,
                                 fixed_splits=a.splits or None, fixed_table_max_bytes=a.table_bytes or None,
-                                bucket_min_terms=a.bucket_min or None, coalesce_proofs=a.coalesce or None)
+                                bucket_min_terms=a.bucket_min or None, coalesce_proofs=a.coalesce or None, transcript_script=0 if a.no_script else None)
             self.pool.gens_create(fx.n, fx.m)
         else:
             for _ in range(nstreams):
@@ -176,6 +177,8 @@ class RangeProofBench:
                                 fixed_splits=a.splits or None, fixed_table_max_bytes=a.table_bytes or None)
                 if a.bucket_min:
                     c_.set_option("bucket_min_terms", a.bucket_min)
+                if a.no_script:
+                    c_.set_option("transcript_script", 0)
                 c_.gens_create(fx.n, fx.m)
                 self.ctxs.append(c_)
             self.streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]

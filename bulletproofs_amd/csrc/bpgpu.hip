@@ -62,6 +62,8 @@ struct bpgpu_ctx {
     fb_params prm{};
     std::vector<uint8_t> h_gens;      // host copy of the encodings
     std::map<std::pair<size_t, size_t>, uint32_t *> gen_ids_cache;  // (n,m) -> device id list
+    std::map<std::vector<uint32_t>, uint32_t *> script_cache;       // (n, m, k, pos, pos_begin, flags, domsep) -> transcript script (rp_script.h)
+    bool no_script = false;                                         // option "transcript_script" = 0: byte-wise replay everywhere (A/B)
     // device-resident work decomposition of the uniform (nbatch, terms-per-MSM) variable-base plans
     struct plan_dev {
         char *mem = nullptr;
@@ -346,6 +348,7 @@ void bpgpu_ctx_destroy(bpgpu_ctx *c) {
     drain_profile(c);
     for (auto e : c->ev_pool) hipEventDestroy(e);
     for (auto &kv : c->gen_ids_cache) hipFree(kv.second);
+    for (auto &kv : c->script_cache) hipFree(kv.second);
     for (auto &kv : c->plan_cache) hipFree(kv.second.mem);
     if (c->arena) hipFree(c->arena);
     if (c->io_dev) hipFree(c->io_dev);
@@ -397,6 +400,10 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
         c->sync_blocking = value != 0;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "transcript_script")) {
+        c->no_script = value == 0;
+        return BPGPU_OK;
+    }
     if (!strcmp(key, "bucket_min_terms")) {
         if (value < 0 || value > 0x7fffffff) return fail(c, BPGPU_ERR_INVALID_ARG, "bucket_min_terms out of range");
         c->bucket_min = (uint32_t)value;
@@ -414,6 +421,7 @@ int bpgpu_ctx_get_option(bpgpu_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "fixed_splits")) *value = c->splits;
     else if (!strcmp(key, "horner_lanes")) *value = c->horner_lanes;
     else if (!strcmp(key, "host_sync_blocking")) *value = c->sync_blocking ? 1 : 0;
+    else if (!strcmp(key, "transcript_script")) *value = c->no_script ? 0 : 1;
     else if (!strcmp(key, "bucket_min_terms")) *value = c->bucket_min ? c->bucket_min : BK_MIN_TERMS;
     else return fail(c, BPGPU_ERR_INVALID_ARG, "unknown option %s", key);
     return BPGPU_OK;
@@ -1272,6 +1280,26 @@ static void make_strobe_init(rp_strobe_init &init, const uint8_t *label, size_t 
     init.cur_flags = t.cur_flags;
 }
 
+// the transcript script of a shape and start position (rp_script.h), cached on the device per context
+static int script_for(bpgpu_ctx *c, uint32_t n, uint32_t m, uint32_t k, const rp_strobe_init &init, bool domsep, const rp_script_hdr **out) {
+    std::vector<uint32_t> key = {n, m, k, init.pos, init.pos_begin, init.cur_flags, domsep ? 1u : 0u};
+    auto it = c->script_cache.find(key);
+    if (it == c->script_cache.end()) {
+        if (c->script_cache.size() >= 64) {   // bounded (callers with many different transcript positions)
+            HIPCHK(c, hipDeviceSynchronize());
+            for (auto &kv : c->script_cache) hipFree(kv.second);
+            c->script_cache.clear();
+        }
+        const std::vector<uint32_t> img = rp_script_build(n, m, k, init.pos, init.pos_begin, init.cur_flags, domsep);
+        uint32_t *d = nullptr;
+        HIPCHK(c, hipMalloc((void **)&d, img.size() * 4));
+        HIPCHK(c, hipMemcpy(d, img.data(), img.size() * 4, hipMemcpyHostToDevice));
+        it = c->script_cache.emplace(key, d).first;
+    }
+    *out = (const rp_script_hdr *)it->second;
+    return BPGPU_OK;
+}
+
 // Where a call's transcripts start: Transcript::new(label) (label), or one caller-supplied state for the whole batch
 // (shared_ts, host, 208 bytes), or one state per proof (d_ts_in, device); d_ts_out (optional): the advanced states.
 struct rp_transcripts {
@@ -1459,6 +1487,11 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     } else {
         make_strobe_init(init, tr.label, tr.label_len, n, m);
     }
+    const rp_script_hdr *d_script = nullptr;
+    if (!tr.d_ts_in && !shape_verdict && !c->no_script) {   // every proof starts from `init`: the per-shape script replaces the byte-wise replay
+        rc = script_for(c, sh.n, sh.m, sh.k, init, (ts_flags & BP_TS_DOMSEP) != 0, &d_script);
+        if (rc) return rc;
+    }
     const uint32_t nb32 = (uint32_t)nbatch;
     // the proof-specific ("variable-base") terms: decomposition into chunks of 32 is cached per (batch, U)
     vb_dev d{};
@@ -1483,7 +1516,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     LAUNCH(c, s, "rp_stage1", k_rp_stage1, n_tr + n_pt, RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
            (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits,
            rlc ? wts_ptr : (const uint8_t *)nullptr, ts_flags, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
-           rlc_bucket ? bd.pts : (fb_entry *)nullptr, rlc_bucket ? bkp.c : 0u, segtab);
+           rlc_bucket ? bd.pts : (fb_entry *)nullptr, rlc_bucket ? bkp.c : 0u, segtab, d_script);
     if (shape_verdict) {
         HIPCHK(c, hipMemsetAsync(d_mv, 1, nbatch, s));
         LAUNCH(c, s, "rp_verdict", k_rp_verdict, (nb32 + 63) / 64, 64, nb32, d_status, d_mv, (uint8_t *)d_verdict);

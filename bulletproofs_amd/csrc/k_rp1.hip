@@ -22,7 +22,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(RP_
                                                          ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m,
                                                          uint32_t *recoded, fb_digit *digits, const uint8_t *rho64, uint32_t ts_flags,
                                                          const uint32_t *ts_in, uint32_t *ts_out, fb_entry *bk_pts, uint32_t bk_c,
-                                                         rp_seg_tab segs) {
+                                                         rp_seg_tab segs, const rp_script_hdr *script) {
     __shared__ uint32_t lds[50 * RP_BLOCK];   // sponge states, word-major: word w of lane t at w*RP_BLOCK + t
     if (blockIdx.x < n_tr) {
         const uint32_t p = blockIdx.x * RP_BLOCK + threadIdx.x;
@@ -32,7 +32,10 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(RP_
         if (p < sh.nproofs) {
             // (BP_EXP_*: timing experiments only -- tools/stage1_breakdown.py builds variants with one role compiled out)
 #ifndef BP_EXP_NOTR
-            rp_transcript_thread(p, sh, init, st, rp_resolve(p, sh, proofs, commitments, rng64, segs), fields, status, ts_flags, ts_in, ts_out);
+            // the per-shape script (rp_script.h) whenever every proof starts from the same transcript; the byte-wise replay for
+            // caller-supplied per-proof states
+            if (script) rp_transcript_scripted(p, sh, init, st, rp_resolve(p, sh, proofs, commitments, rng64, segs), script, fields, status, ts_out);
+            else rp_transcript_thread(p, sh, init, st, rp_resolve(p, sh, proofs, commitments, rng64, segs), fields, status, ts_flags, ts_in, ts_out);
 #endif
 #ifndef BP_EXP_NOSC
             if (!sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64, bk_c);

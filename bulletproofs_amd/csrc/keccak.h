@@ -94,6 +94,29 @@ BP_HD void keccak_f1600(const kstate &s) {
     }
 }
 
+// the permutation with a constant XOR mask folded into the load of the first `nmask` state words (rp_script.h: all framing bytes
+// of a transcript span at once; the mask is uniform across the wavefront)
+BP_HD void keccak_f1600_masked(const kstate &s, const uint32_t *mask, uint32_t nmask) {
+    uint64_t a[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) {
+        uint32_t lo = ks_get32(s, 2 * i), hi = ks_get32(s, 2 * i + 1);
+        if ((uint32_t)(2 * i) < nmask) lo ^= mask[2 * i];
+        if ((uint32_t)(2 * i + 1) < nmask) hi ^= mask[2 * i + 1];
+        a[i] = (uint64_t)lo | ((uint64_t)hi << 32);
+    }
+#ifdef BP_EXP_NOKECCAK
+    a[0] += 1;
+#else
+    keccak_f1600_lanes(a);
+#endif
+#pragma unroll
+    for (int i = 0; i < 25; i++) {
+        ks_set32(s, 2 * i, (uint32_t)a[i]);
+        ks_set32(s, 2 * i + 1, (uint32_t)(a[i] >> 32));
+    }
+}
+
 // ---- plain sponges (generator derivation) -------------------------------------
 struct sponge {
     kstate st;

@@ -14,6 +14,7 @@
 #ifndef BPGPU_RANGEPROOF_H
 #define BPGPU_RANGEPROOF_H
 #include "keccak.h"
+#include "rp_script.h"
 #include "msm_fixed.h"
 #include "sc25519.h"
 #include "scinv.h"
@@ -316,6 +317,102 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
         uint32_t *o = ts_out + (uint64_t)p * BP_TS_WORDS;
         for (uint32_t i = 0; i < 50; i++) o[i] = ks_get32(st, i);
         o[50] = rp_ts_meta(t.pos, t.pos_begin, t.cur_flags);
+        o[51] = 0;
+    }
+}
+
+// ---- stage 1, scripted: the same replay driven by the per-shape script of rp_script.h ------------------------------------
+// Bit-identical to rp_transcript_thread when every proof of the launch starts from the same state `init` (label mode, or one
+// transcript shared by the batch).  All positions come from the script, i.e. are uniform across the wavefront: framing bytes
+// arrive as one XOR mask per permutation, 32-byte records are XORed in as words, a challenge is state words 0..15.
+BP_HD void rp_script_xor_record(const kstate &st, uint32_t pos, const uint32_t w[8]) {
+    const uint32_t wi = pos >> 2, sh = (pos & 3) * 8;
+    if (sh == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) st.w[(wi + i) * st.stride] ^= w[i];
+    } else {
+        st.w[wi * st.stride] ^= w[0] << sh;
+#pragma unroll
+        for (int i = 1; i < 8; i++) st.w[(wi + i) * st.stride] ^= (w[i] << sh) | (w[i - 1] >> (32 - sh));
+        st.w[(wi + 8) * st.stride] ^= w[7] >> (32 - sh);
+    }
+}
+BP_HD void rp_transcript_scripted(uint32_t p, rp_shape sh, const rp_strobe_init &init, kstate st, const rp_inputs &in, const rp_script_hdr *script,
+                                  uint32_t *fields, uint32_t *status, uint32_t *ts_out = nullptr) {
+    const uint32_t B = sh.nproofs, k = sh.k;
+    const uint8_t *pr = in.pr;
+    const rp_fields fl = rp_field_layout(k, sh.m);
+    uint32_t w[8];
+    // --- from_bytes: the five scalars must be canonical (mod.rs:519-524, ipp.rs:401-404)
+    sc tx, txb, eb, a, b;
+    bool fmt_ok = true;
+    load_words8(tx.v, pr + 128);   fmt_ok = fmt_ok && sc_is_canonical_sc(tx);
+    load_words8(txb.v, pr + 160);  fmt_ok = fmt_ok && sc_is_canonical_sc(txb);
+    load_words8(eb.v, pr + 192);   fmt_ok = fmt_ok && sc_is_canonical_sc(eb);
+    load_words8(a.v, pr + 224 + 64 * k);       fmt_ok = fmt_ok && sc_is_canonical_sc(a);
+    load_words8(b.v, pr + 224 + 64 * k + 32);  fmt_ok = fmt_ok && sc_is_canonical_sc(b);
+    if (!fmt_ok) {
+        status_raise(status + p, BP_VERDICT_FORMAT);
+        rp_ts_passthrough(p, init, nullptr, ts_out);
+        return;
+    }
+    if (sh.shape_verdict) {
+        status_raise(status + p, sh.shape_verdict);
+        rp_ts_passthrough(p, init, nullptr, ts_out);
+        return;
+    }
+    rp_store(fields, B, RPF_TX, p, tx);
+    rp_store(fields, B, RPF_TXB, p, txb);
+    rp_store(fields, B, RPF_EB, p, eb);
+    rp_store(fields, B, RPF_A, p, a);
+    rp_store(fields, B, RPF_B, p, b);
+    // validate_and_append_point (transcript.rs:75-87): A, S, T_1, T_2, L_i, R_i must not be the identity encoding
+    bool verr = false;
+    for (uint32_t u = 0; u < 4 + 2 * k; u++) {
+        load_words8(w, pr + (u < 4 ? 32 * u : 224 + 32 * (u - 4)));
+        verr = verr || words8_zero(w);
+    }
+    for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, init.w[i]);
+    const rp_script_op *ops = rp_script_ops(script);
+    const uint32_t *masks = rp_script_masks(script);
+    const uint32_t n_ops = script->n_ops;
+    for (uint32_t oi = 0; oi < n_ops; oi++) {
+        const rp_script_op op = ops[oi];
+        const uint8_t *src = (op.src == RS_SRC_PROOF ? pr : in.cm) + op.off;
+        if (op.kind == RS_MSG) {
+            load_words8(w, src);
+            rp_script_xor_record(st, op.pos, w);
+        } else if (op.kind == RS_MSGB) {      // the part of a record before / after a rate boundary: bytes
+            for (uint32_t q = 0; q < op.nbytes; q++) ks_xor8(st, op.pos + q, src[q]);
+        } else if (op.kind == RS_PERM) {
+            keccak_f1600_masked(st, masks + (uint64_t)op.arg * RS_MASK_WORDS, RS_MASK_WORDS);
+        } else {                              // RS_CHAL: 64 squeezed bytes = words 0..15, zeroed behind the read (STROBE's PRF)
+            uint32_t cw[16];
+#pragma unroll
+            for (int q = 0; q < 16; q++) {
+                cw[q] = ks_get32(st, q);
+                ks_set32(st, q, 0);
+            }
+            sc ch;
+            sc_from_wide(ch, cw);
+            const uint32_t id = op.arg;
+            rp_store(fields, B, id == 0 ? (uint32_t)RPF_Y : (id == 1 ? (uint32_t)RPF_Z : (id == 2 ? (uint32_t)RPF_X : (id == 3 ? (uint32_t)RPF_W : fl.u + (id - 4)))), p, ch);
+        }
+    }
+    // batching challenge c = Scalar::random(rng) (mod.rs:396): 64 rng bytes, wide-reduced
+    {
+        uint32_t cw[16];
+        sc c;
+        load_words8(cw, in.rs);
+        load_words8(cw + 8, in.rs + 32);
+        sc_from_wide(c, cw);
+        rp_store(fields, B, RPF_C, p, c);
+    }
+    if (verr) status_raise(status + p, BP_VERDICT_VERIFICATION);
+    if (ts_out) {
+        uint32_t *o = ts_out + (uint64_t)p * BP_TS_WORDS;
+        for (uint32_t i = 0; i < 50; i++) o[i] = ks_get32(st, i);
+        o[50] = rp_ts_meta(script->end_pos, script->end_pos_begin, script->end_flags);
         o[51] = 0;
     }
 }

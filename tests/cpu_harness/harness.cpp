@@ -197,6 +197,44 @@ static void make_strobe_init(rp_strobe_init &init, const uint8_t *label, uint32_
     init.pos = t.pos; init.pos_begin = t.pos_begin; init.cur_flags = t.cur_flags;
 }
 
+// The scripted transcript replay (rp_script.h + rp_transcript_scripted) against the byte-wise one (rp_transcript_thread), lane by
+// lane: same per-proof scalars, same status, same advanced transcript.  state208: the start state (Transcript::new(label) with
+// whatever the caller appended); domsep: rangeproof_domain_sep(n, m) still to be applied.  Returns 0 when everything is identical,
+// and hands back the byte-wise path's fields / status / transcripts for comparison with the oracle.
+int h_rp_transcript_compare(uint32_t n, uint32_t m, uint32_t nbatch, const uint8_t *proofs, uint32_t proof_len, const uint8_t *commitments,
+                            const uint8_t *rng64, const uint8_t *state208, int domsep, uint32_t *n_perm_out, uint8_t *status_out, uint8_t *ts_out208) {
+    uint32_t k = 0; while ((1u << k) < n * m) k++;
+    rp_shape sh; sh.n = n; sh.m = m; sh.nm = n * m; sh.k = k; sh.U = 4 + 2 * k + m; sh.proof_len = proof_len; sh.nproofs = nbatch; sh.shape_verdict = 0;
+    if (proof_len != 32 * (9 + 2 * k)) return -1;
+    rp_strobe_init init;
+    memcpy(init.w, state208, 200);
+    init.pos = state208[200]; init.pos_begin = state208[201]; init.cur_flags = state208[202];
+    const std::vector<uint32_t> img = rp_script_build(n, m, k, init.pos, init.pos_begin, init.cur_flags, domsep != 0);
+    const rp_script_hdr *script = (const rp_script_hdr *)img.data();
+    if (n_perm_out) *n_perm_out = script->n_masks;
+    const rp_fields fl = rp_field_layout(k, m);
+    const size_t nf = (size_t)fl.count * nbatch * BP_RP_REC + 8;
+    std::vector<uint32_t> f1(nf, 0xabababab), f2(nf, 0xabababab), s1(nbatch + 1, 0), s2(nbatch + 1, 0), t1((size_t)nbatch * BP_TS_WORDS, 7), t2((size_t)nbatch * BP_TS_WORDS, 7);
+    rp_seg_tab none; memset(&none, 0, sizeof none);
+    for (uint32_t p = 0; p < nbatch; p++) {
+        uint32_t w1[50], w2[50]; kstate st1, st2; st1.w = w1; st1.stride = 1; st2.w = w2; st2.stride = 1;
+        const rp_inputs in = rp_resolve(p, sh, proofs, commitments, rng64, none);
+        rp_transcript_thread(p, sh, init, st1, in, f1.data(), s1.data(), domsep ? BP_TS_DOMSEP : 0, nullptr, t1.data());
+        rp_transcript_scripted(p, sh, init, st2, in, script, f2.data(), s2.data(), t2.data());
+    }
+    for (uint32_t p = 0; p < nbatch; p++) {
+        status_out[p] = (uint8_t)s1[p];
+        memcpy(ts_out208 + (size_t)p * 208, &t1[(size_t)p * BP_TS_WORDS], 200);
+        const uint32_t meta = t1[(size_t)p * BP_TS_WORDS + 50];
+        memset(ts_out208 + (size_t)p * 208 + 200, 0, 8);
+        ts_out208[(size_t)p * 208 + 200] = meta & 0xff; ts_out208[(size_t)p * 208 + 201] = (meta >> 8) & 0xff; ts_out208[(size_t)p * 208 + 202] = (meta >> 16) & 0xff;
+    }
+    if (s1 != s2) return 1;
+    if (t1 != t2) return 2;
+    if (f1 != f2) return 3;
+    return 0;
+}
+
 void h_merlin_kat(const uint8_t *label, uint32_t label_len, const uint8_t *mlabel, uint32_t mlabel_len, const uint8_t *msg, uint32_t msg_len,
                   const uint8_t *clabel, uint32_t clabel_len, uint8_t *out, uint32_t out_len) {
     uint32_t w[50]; kstate st; st.w = w; st.stride = 1;

@@ -367,6 +367,54 @@ def test_coalesced_launch_segment_table_lane_by_lane(H, oracle, golden):
     H.h_set_segments(0, (C.c_uint32 * 1)(0))
 
 
+def test_scripted_transcript_equals_bytewise_replay_and_oracle(H, oracle, golden):
+    """rp_script.h: the verifier transcript compiled into per-shape XOR masks + record positions (launch 1's transcript role)
+    against the byte-wise STROBE replay, lane by lane -- per-proof scalars, status words, advanced transcripts -- for all golden
+    shapes, tampered copies, and start states at every rate position class (records straddling the 166-byte rate boundary,
+    a permutation falling exactly at the end of a record, the domain separator applied on the device or not); the byte-wise
+    path's final transcript is also the oracle's."""
+    from bulletproofs_amd._lib import transcript_new, transcript_append_message
+    label = golden["label"]
+    vc = golden["vc_bytes"]
+    seen_perms = set()
+    for case in golden["cases"]:
+        n, m = case["n"], case["m"]
+        pr = bytes.fromhex(case["proof"])
+        k = (n * m).bit_length() - 1
+        t0 = bytearray(pr)
+        t0[128] ^= 1                        # tampered scalar: transcript still runs
+        z = bytearray(pr)
+        z[224:256] = bytes(32)              # L_0 = identity encoding -> VerificationError from the transcript
+        f = bytearray(pr)
+        f[160:192] = b"\xff" * 32          # FormatError: transcript untouched
+        proofs = pr + bytes(t0) + bytes(z) + bytes(f)
+        nb = 4
+        coms = vc[:32 * m] * nb
+        rng = hashlib.shake_256(b"ts%d%d" % (n, m)).digest(64 * nb)
+        for pad in ([], [0], [1], [7], [60], [100, 3], [165], [166], [167, 9], [40, 40, 40]):
+            for domsep in (1, 0):
+                st = transcript_new(label)
+                for j, ln in enumerate(pad):
+                    st = transcript_append_message(st, b"pad%d" % j, bytes((ln + q) & 0xff for q in range(ln)))
+                if not domsep:
+                    st = transcript_append_message(st, b"dom-sep", b"rangeproof v1")
+                    st = transcript_append_message(st, b"n", n.to_bytes(8, "little"))
+                    st = transcript_append_message(st, b"m", m.to_bytes(8, "little"))
+                nperm = C.c_uint32(0)
+                so, to = C.create_string_buffer(nb), C.create_string_buffer(208 * nb)
+                rc = H.h_rp_transcript_compare(n, m, nb, proofs, len(pr), coms, rng, st, domsep, C.byref(nperm), so, to)
+                assert rc == 0, (n, m, pad, domsep, rc)
+                assert list(so.raw) == [0, 0, 1, 2]
+                seen_perms.add(nperm.value)
+                if len(pad) < 2:    # the oracle's verifier on the same start state ends in the same transcript (valid proof and tampered scalar)
+                    st_o = st if domsep else None
+                    if domsep:
+                        for b_ in (0, 1):
+                            rc_o, _, ts_o = oracle.verify_ts(oracle.Gens(n, m), proofs[len(pr) * b_:len(pr) * (b_ + 1)], coms[:32 * m], n, st_o, rng[64 * b_:64 * b_ + 64])
+                            assert ts_o == to.raw[208 * b_:208 * (b_ + 1)], (n, m, pad, b_)
+    assert len(seen_perms) > 3
+
+
 def test_window_recoding_all_widths(H):
     """fb_recode / fb_nwin (msm_fixed.h): for every window width 2..20 the signed digits reconstruct the scalar and
     ceil(255 / W) windows suffice (W = 17 is the first width that saves a window: 15 instead of 16)."""

