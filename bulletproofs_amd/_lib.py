@@ -23,7 +23,7 @@ EXPORTS = [
     "bpgpu_rangeproof_verify_batch_ts", "bpgpu_rangeproof_verify_batch_ts_dev", "bpgpu_ipp_verify_batch_dev",
     "bpgpu_ipp_create_batch", "bpgpu_rangeproof_prove_batch", "bpgpu_rangeproof_verify_batch_submit", "bpgpu_ctx_collect",
     "bpgpu_linear_verify_batch", "bpgpu_linear_verify_batch_dev", "bpgpu_linear_create_batch",
-    "bpgpu_rangeproof_audit_shares",
+    "bpgpu_rangeproof_audit_shares", "bpgpu_ipp_verification_scalars",
     "bpgpu_pool_create", "bpgpu_pool_destroy", "bpgpu_pool_last_error", "bpgpu_pool_set_option", "bpgpu_pool_get_option",
     "bpgpu_pool_devices", "bpgpu_pool_lanes", "bpgpu_pool_lane", "bpgpu_pool_gens_create", "bpgpu_pool_gens_load",
     "bpgpu_pool_rangeproof_verify", "bpgpu_pool_rangeproof_submit_dev", "bpgpu_pool_flush", "bpgpu_pool_wait",
@@ -91,6 +91,7 @@ def lib():
     L.bpgpu_rangeproof_audit_shares.argtypes = [vp, sz, sz, C.POINTER(C.c_uint32), u8p, u8p, u8p, u8p, i, u8p, u8p]
     L.bpgpu_linear_create_batch.argtypes = [vp, sz, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, i, u8p, u8p, u8p, u8p, u8p, u8p]
     L.bpgpu_linear_verify_batch_dev.argtypes = [vp, sz, sz, vp, sz, u8p, sz, u8p, vp, vp, vp, vp, vp, i, vp, vp, vp, vp]
+    L.bpgpu_ipp_verification_scalars.argtypes = [vp, sz, sz, u8p, sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p]
     L.bpgpu_pool_create.argtypes = [C.POINTER(C.c_int), i, i, C.POINTER(vp)]
     L.bpgpu_pool_destroy.argtypes = [vp]
     L.bpgpu_pool_destroy.restype = None
@@ -286,6 +287,22 @@ class Context:
         msm = C.create_string_buffer(32 * max(nb, 1)) if want_msm else None
         self._chk(self._L.bpgpu_ipp_verify_batch(self.h, n, nb, proofs, proof_len, label, len(label), Gf, Hf, P, Q, G, H, verdict, msm))
         return (verdict.raw[:nb], msm.raw[:32 * nb]) if want_msm else verdict.raw[:nb]
+
+    def ipp_verification_scalars(self, n, proofs, proof_len, label=b"", transcripts=None, want_transcripts=False):
+        """InnerProductProof::verification_scalars for len(proofs) / proof_len proofs (bpgpu_ipp_verification_scalars): returns
+        (u_sq bytes, u_inv_sq bytes, s bytes, status bytes[, advanced transcripts])."""
+        nb = len(proofs) // proof_len if proof_len else 0
+        k = max(0, (proof_len // 32 - 2) // 2)
+        stride = 0
+        if transcripts is not None:
+            assert len(transcripts) in (TRANSCRIPT_BYTES, TRANSCRIPT_BYTES * nb)
+            stride = 0 if (len(transcripts) == TRANSCRIPT_BYTES and nb != 1) else TRANSCRIPT_BYTES
+        us, ui = C.create_string_buffer(32 * max(k * nb, 1)), C.create_string_buffer(32 * max(k * nb, 1))
+        s_, st = C.create_string_buffer(32 * max(n * nb, 1)), C.create_string_buffer(max(nb, 1))
+        tso = C.create_string_buffer(TRANSCRIPT_BYTES * max(nb, 1)) if want_transcripts else None
+        self._chk(self._L.bpgpu_ipp_verification_scalars(self.h, n, nb, proofs, proof_len, label, len(label), transcripts, stride, us, ui, s_, tso, st))
+        out = (us.raw[:32 * k * nb], ui.raw[:32 * k * nb], s_.raw[:32 * n * nb], st.raw[:nb])
+        return out + (tso.raw[:TRANSCRIPT_BYTES * nb],) if want_transcripts else out
 
     def rangeproof_audit_shares(self, n, party_index, shares, bit_commitments, poly_commitments, challenges, want_checks=False):
         """ProofShare::audit_share for len(party_index) shares (bpgpu_rangeproof_audit_shares); challenges: 96 bytes shared or per share."""

@@ -1969,6 +1969,98 @@ extern "C" int bpgpu_ipp_verify_batch_dev(bpgpu_ctx *c, size_t n, size_t nbatch,
     return rc ? rc : rc2;
 }
 
+// InnerProductProof::from_bytes + verification_scalars (ipp.rs:198-253, 373-407) for nbatch proofs, host pointers
+extern "C" int bpgpu_ipp_verification_scalars(bpgpu_ctx *c, size_t n, size_t nbatch, const uint8_t *proofs, size_t proof_len, const uint8_t *label,
+                                              size_t label_len, const uint8_t *transcripts, size_t transcript_stride, uint8_t *u_sq, uint8_t *u_inv_sq,
+                                              uint8_t *s_out, uint8_t *transcripts_out, uint8_t *status) {
+    if (!c || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0) return BPGPU_OK;
+    if (!proofs || !status || !u_sq || !u_inv_sq || (n && !s_out)) return BPGPU_ERR_INVALID_ARG;
+    if (transcripts && transcript_stride != 0 && transcript_stride != BPGPU_TRANSCRIPT_BYTES)
+        return fail(c, BPGPU_ERR_INVALID_ARG, "transcript_stride neither 0 nor BPGPU_TRANSCRIPT_BYTES");
+    const bool per_proof = transcripts && transcript_stride;
+    if (transcripts)
+        for (size_t b = 0; b < (per_proof ? nbatch : 1); b++)
+            if (!ts_state_ok(transcripts + b * BPGPU_TRANSCRIPT_BYTES)) return fail(c, BPGPU_ERR_INVALID_ARG, "malformed transcript state %zu", b);
+    // InnerProductProof::from_bytes, length part (ipp.rs:374-388)
+    size_t k = 0;
+    bool fmt = proof_len % 32 != 0;
+    if (!fmt) {
+        const size_t ne = proof_len / 32;
+        if (ne < 2 || (ne - 2) % 2 != 0) fmt = true;
+        else {
+            k = (ne - 2) / 2;
+            if (k >= 32) fmt = true;
+        }
+    }
+    if (fmt) {
+        memset(status, BPGPU_VERDICT_FORMAT_ERROR, nbatch);
+        return BPGPU_OK;
+    }
+    const bool shape_bad = n != ((size_t)1 << k);   // ipp.rs:203-211 (k >= 32 was refused above)
+    if (!shape_bad && k > BP_RP_MAX_K) return fail(c, BPGPU_ERR_INVALID_ARG, "n > 2^%d not supported", BP_RP_MAX_K);
+    if ((uint64_t)nbatch * (n ? n : 1) > 0x7fffffffull / 64) return fail(c, BPGPU_ERR_INVALID_ARG, "batch too large for this shape");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    ipp_shape sh;
+    sh.n = (uint32_t)n;
+    sh.k = (uint32_t)k;
+    sh.N = 0;
+    sh.proof_len = (uint32_t)proof_len;
+    sh.nproofs = (uint32_t)nbatch;
+    sh.shape_verdict = shape_bad ? BPGPU_VERDICT_VERIFICATION_ERROR : 0;
+    sh.bases_shared = 0;
+    const size_t n_eff = shape_bad ? 0 : n, TS = BPGPU_TRANSCRIPT_BYTES;
+    const size_t sz_pr = align_up(nbatch * proof_len + 64), sz_ti = per_proof ? align_up(nbatch * TS) : 0;
+    const size_t sz_in = sz_pr + sz_ti;
+    const size_t sz_u = align_up(nbatch * (k ? k : 1) * 32), sz_s = align_up(nbatch * (n_eff ? n_eff : 1) * 32), sz_to = transcripts_out ? align_up(nbatch * TS) : 0,
+                 sz_st = align_up(nbatch * 4);
+    const size_t sz_out = 2 * sz_u + sz_s + sz_to + sz_st;
+    const size_t sz_tab = align_up(nbatch * (k ? k : 1) * 2 * 40);
+    hipStream_t s = c->stream;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    char *h = nullptr;
+    do {
+        rc = io_reserve(c, sz_in + sz_out + sz_tab);
+        if (rc) break;
+        rc = pin_alloc(c, s, sz_in + sz_out, &h);
+        if (rc) break;
+        char *d = c->io_dev;
+        char *d_pr = d, *d_ti = d + sz_pr, *d_us = d + sz_in, *d_ui = d_us + sz_u, *d_s = d_ui + sz_u, *d_to = d_s + sz_s, *d_st = d_to + sz_to, *d_tab = d + sz_in + sz_out;
+        memcpy(h, proofs, nbatch * proof_len);
+        if (per_proof) memcpy(h + sz_pr, transcripts, nbatch * TS);
+        if (hipMemcpyAsync(d, h, sz_in, hipMemcpyHostToDevice, s) != hipSuccess || hipMemsetAsync(d_us, 0, sz_out, s) != hipSuccess) {
+            rc = fail(c, BPGPU_ERR_HIP, "staging failed");
+            break;
+        }
+        rp_strobe_init init;
+        memset(&init, 0, sizeof init);
+        if (!per_proof) {   // one start state: innerproduct_domain_sep(n) replayed once on the host
+            uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
+            ipp_domain_sep_state(st0, label, label_len, transcripts, n, &init);
+        }
+        const uint32_t nb32 = (uint32_t)nbatch;
+        LAUNCH(c, s, "ipp_vs_front", k_ipp_vs_front, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, init, (const uint8_t *)d_pr, per_proof ? (const uint32_t *)d_ti : (const uint32_t *)nullptr,
+               (uint32_t *)d_us, (uint32_t *)d_ui, (uint32_t *)d_tab, transcripts_out ? (uint32_t *)d_to : (uint32_t *)nullptr, (uint32_t *)d_st);
+        if (n_eff) {
+            const uint32_t nt = (uint32_t)(n_eff * nbatch);
+            LAUNCH(c, s, "ipp_vs_s", k_ipp_vs_s, (nt + 63) / 64, 64, nt, sh, (const uint32_t *)d_tab, (const uint32_t *)d_st, (uint32_t *)d_s);
+        }
+        if (hipMemcpyAsync(h + sz_in, d_us, sz_out, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
+    } while (0);
+    const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
+    if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
+    const char *ho = h + sz_in;
+    memcpy(u_sq, ho, nbatch * k * 32);
+    memcpy(u_inv_sq, ho + sz_u, nbatch * k * 32);
+    if (n_eff) memcpy(s_out, ho + 2 * sz_u, nbatch * n_eff * 32);
+    if (transcripts_out) memcpy(transcripts_out, ho + 2 * sz_u + sz_s, nbatch * TS);
+    const uint32_t *st32 = (const uint32_t *)(ho + 2 * sz_u + sz_s + sz_to);
+    for (size_t b = 0; b < nbatch; b++) status[b] = (uint8_t)st32[b];
+    return BPGPU_OK;
+}
+
 extern "C" int bpgpu_ipp_verify_batch(bpgpu_ctx *c, size_t n, size_t nbatch, const uint8_t *proofs, size_t proof_len, const uint8_t *label,
                                       size_t label_len, const uint8_t *G_factors, const uint8_t *H_factors, const uint8_t *P,
                                       const uint8_t *Q, const uint8_t *G, const uint8_t *H, uint8_t *verdict, uint8_t *msm_out) {

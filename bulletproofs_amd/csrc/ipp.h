@@ -143,6 +143,120 @@ BP_HD void ipp_prepare_thread(uint32_t p, ipp_shape sh, const rp_strobe_init &in
     }
 }
 
+// ---- InnerProductProof::verification_scalars alone (ipp.rs:198-253) -- bpgpu_ipp_verification_scalars ------------------
+// The other caller besides InnerProductProof::verify is the R1CS verifier (r1cs/verifier.rs:401-404), which folds u_i^2,
+// u_i^-2 and s_i into its own multiscalar multiplication.
+// thread p: from_bytes' canonical checks, transcript replay (L_i, R_i -> u_i), one batch inversion; writes u_i^2, u_i^-2
+// (canonical bytes), the Montgomery tables (u_i, u_i^-1) for ipp_vs_s_thread, the advanced transcript.
+BP_HD void ipp_vs_front_thread(uint32_t p, ipp_shape sh, const rp_strobe_init &init, kstate st, const uint8_t *proofs, const uint32_t *ts_in,
+                               uint32_t *u_sq, uint32_t *u_inv_sq, uint32_t *tab /*[nproofs][2k][10]*/, uint32_t *ts_out, uint32_t *status) {
+    const uint32_t k = sh.k;
+    const uint8_t *pr = proofs + (uint64_t)p * sh.proof_len;
+    sc a, b;
+    load_words8(a.v, pr + 64 * k);
+    load_words8(b.v, pr + 64 * k + 32);
+    rp_strobe_init none{};
+    if (!sc_is_canonical_sc(a) || !sc_is_canonical_sc(b)) {
+        status[p] = BP_VERDICT_FORMAT;
+        rp_ts_passthrough(p, ts_in ? none : init, ts_in, ts_out);
+        return;
+    }
+    if (sh.shape_verdict) {
+        status[p] = sh.shape_verdict;
+        rp_ts_passthrough(p, ts_in ? none : init, ts_in, ts_out);
+        return;
+    }
+    strobe t;
+    t.st = st;
+    if (ts_in) {   // per-proof transcripts: innerproduct_domain_sep(n) is applied here
+        const uint32_t *src = ts_in + (uint64_t)p * BP_TS_WORDS;
+        for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, src[i]);
+        const uint32_t meta = src[50];
+        t.pos = meta & 0xffu;
+        t.pos_begin = (meta >> 8) & 0xffu;
+        t.cur_flags = (meta >> 16) & 0xffu;
+        const uint8_t dsep[7] = {'d', 'o', 'm', '-', 's', 'e', 'p'}, ipp[6] = {'i', 'p', 'p', ' ', 'v', '1'}, ln[1] = {'n'};
+        merlin_append_message(t, dsep, 7, ipp, 6);
+        merlin_append_u64(t, ln, 1, sh.n);
+    } else {       // one start state for the batch: the host already applied the domain separator
+        for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, init.w[i]);
+        t.pos = init.pos;
+        t.pos_begin = init.pos_begin;
+        t.cur_flags = init.cur_flags;
+    }
+    const uint8_t lL[1] = {'L'}, lR[1] = {'R'}, lu[1] = {'u'};
+    sc28 um[BP_RP_MAX_K], uim[BP_RP_MAX_K], acc, inv;
+    sc28_one_mont(acc);
+    uint32_t w[8];
+    bool verr = false;
+    for (uint32_t i = 0; i < k; i++) {
+        load_words8(w, pr + 64 * i);
+        verr = verr || words8_zero(w);
+        merlin_append_words8(t, lL, 1, w);
+        load_words8(w, pr + 64 * i + 32);
+        verr = verr || words8_zero(w);
+        merlin_append_words8(t, lR, 1, w);
+        sc u;
+        rp_challenge_scalar(t, lu, 1, u);
+        sc_to_mont28(um[i], u);
+        uim[i] = acc;
+        sc28_montmul(acc, acc, um[i]);
+    }
+    if (verr) {   // validate_and_append_point: an identity L_i / R_i is a VerificationError (transcript.rs:75-87)
+        status[p] = BP_VERDICT_VERIFICATION;
+        rp_ts_passthrough(p, ts_in ? none : init, ts_in, ts_out);
+        return;
+    }
+    sc28_invert_mont_safegcd(inv, acc);
+    uint32_t *tb = tab + (uint64_t)p * 2 * k * 10;
+    for (uint32_t ii = k; ii-- > 0;) {
+        sc28 ui, sq;
+        sc t0;
+        sc28_montmul(ui, inv, uim[ii]);
+        sc28_montmul(inv, inv, um[ii]);
+        sc28_montsq(sq, um[ii]);
+        sc_from_mont28(t0, sq);
+        store_words8(u_sq + ((uint64_t)p * k + ii) * 8, t0);
+        sc28_montsq(sq, ui);
+        sc_from_mont28(t0, sq);
+        store_words8(u_inv_sq + ((uint64_t)p * k + ii) * 8, t0);
+#pragma unroll
+        for (int q = 0; q < 10; q++) {
+            tb[(2 * ii) * 10 + q] = um[ii].v[q];
+            tb[(2 * ii + 1) * 10 + q] = ui.v[q];
+        }
+    }
+    if (ts_out) {
+        uint32_t *o = ts_out + (uint64_t)p * BP_TS_WORDS;
+        for (uint32_t i = 0; i < 50; i++) o[i] = ks_get32(st, i);
+        o[50] = rp_ts_meta(t.pos, t.pos_begin, t.cur_flags);
+        o[51] = 0;
+    }
+}
+// thread tid = i * nproofs + p: s_i = prod_b (bit_b(i) ? u : u^-1)[k-1-b]  (the closed form of the induction of ipp.rs:241-250)
+BP_HD void ipp_vs_s_thread(uint32_t tid, ipp_shape sh, const uint32_t *tab, const uint32_t *status, uint32_t *s_out) {
+    const uint32_t i = tid / sh.nproofs, p = tid - i * sh.nproofs, k = sh.k;
+    uint32_t *dst = s_out + ((uint64_t)p * sh.n + i) * 8;
+    if (status[p] != 0) {
+        for (int q = 0; q < 8; q++) dst[q] = 0;
+        return;
+    }
+    const uint32_t *tb = tab + (uint64_t)p * 2 * k * 10;
+    sc28 acc;
+    sc28_one_mont(acc);
+    for (uint32_t bb = 0; bb < k; bb++) {
+        const uint32_t j = k - 1 - bb;
+        const uint32_t *f = tb + (2 * j + (((i >> bb) & 1) ? 0 : 1)) * 10;
+        sc28 fm;
+#pragma unroll
+        for (int q = 0; q < 10; q++) fm.v[q] = f[q];
+        sc28_montmul(acc, acc, fm);
+    }
+    sc t0;
+    sc_from_mont28(t0, acc);
+    store_words8(dst, t0);
+}
+
 // thread p: verdict = front-end status if set, else VerificationError when a point failed to decode or the
 // difference expect_P - P is not the identity
 BP_HD void ipp_verdict_thread(uint32_t p, const uint32_t *status, const uint8_t *msm_status, const uint32_t *msm_out, uint8_t *verdict) {

@@ -48,6 +48,8 @@ template <bool WITH_OUT>
 __global__ void k_rlc_finish(uint32_t nsplit, const ge_ext *hq, const ge_ext *partial, uint32_t nproofs, uint32_t *status, uint8_t *verdict, uint8_t *batch_out);
 __global__ void k_rp_verdict(uint32_t n, uint32_t *status, const uint8_t *msm_verdict, uint8_t *out);
 __global__ void k_ipp_prepare(ipp_shape sh, rp_strobe_init init, const uint8_t *proofs, const uint8_t *Gf, const uint8_t *Hf, const uint8_t *P, const uint8_t *Q, const uint8_t *G, const uint8_t *H, uint32_t *scalars, uint32_t *points, uint32_t *status);
+__global__ void k_ipp_vs_front(ipp_shape sh, rp_strobe_init init, const uint8_t *proofs, const uint32_t *ts_in, uint32_t *u_sq, uint32_t *u_inv_sq, uint32_t *tab, uint32_t *ts_out, uint32_t *status);
+__global__ void k_ipp_vs_s(uint32_t nthreads, ipp_shape sh, const uint32_t *tab, const uint32_t *status, uint32_t *s_out);
 __global__ void k_ipp_verdict(uint32_t n, const uint32_t *status, const uint8_t *msm_status, const uint32_t *msm_out, uint8_t *verdict);
 __global__ void k_aud_prepare(aud_shape sh, const uint32_t *party, const uint8_t *shares, const uint8_t *bit_commitments, const uint8_t *poly_commitments, const uint8_t *challenges, const uint32_t *gens, uint32_t *scalars, uint32_t *points, uint32_t *status);
 __global__ void k_aud_verdict(uint32_t n, const uint32_t *status, const uint8_t *msm_status, const uint32_t *msm_out, uint8_t *verdict);

@@ -373,6 +373,21 @@ int bpgpu_rangeproof_prove_batch(bpgpu_ctx *ctx, size_t n, size_t m, size_t nbat
                                  const uint8_t *shared_transcript, const uint8_t *rng,
                                  uint8_t *proofs_out, uint8_t *commitments_out, uint8_t *transcripts_out);
 
+/* InnerProductProof::from_bytes + InnerProductProof::verification_scalars (src/inner_product_proof.rs:198-253, 373-407) for
+ * nbatch proofs: what the R1CS verifier calls (src/r1cs/verifier.rs:401-404) before it builds ITS multiscalar multiplication
+ * (r1cs/verifier.rs:459-491, served by bpgpu_msm_batch_shared), and what InnerProductProof::verify uses at ipp.rs:283.
+ *   proofs      : nbatch x proof_len bytes, InnerProductProof::to_bytes (L_0 R_0 .. L_{k-1} R_{k-1} a b)
+ *   transcript  : transcripts == NULL: Transcript::new(label);  transcript_stride == 0: ONE 208-byte state shared by the
+ *                 batch;  == BPGPU_TRANSCRIPT_BYTES: one state per proof.  innerproduct_domain_sep(n) is applied by the call.
+ *   u_sq, u_inv_sq : nbatch x k x 32 bytes (k = lg n): u_i^2 and u_i^-2 in creation order;  s : nbatch x n x 32 bytes
+ *   transcripts_out (optional) : the advanced states of the proofs with status 0 (others: unspecified)
+ *   status      : nbatch bytes: 0, BPGPU_VERDICT_VERIFICATION_ERROR (n != 2^k, or an identity L_i / R_i:
+ *                 validate_and_append_point), BPGPU_VERDICT_FORMAT_ERROR (malformed length, a / b not canonical); the outputs
+ *                 of a rejected proof are zero */
+int bpgpu_ipp_verification_scalars(bpgpu_ctx *ctx, size_t n, size_t nbatch, const uint8_t *proofs, size_t proof_len,
+                                   const uint8_t *label, size_t label_len, const uint8_t *transcripts, size_t transcript_stride,
+                                   uint8_t *u_sq, uint8_t *u_inv_sq, uint8_t *s, uint8_t *transcripts_out, uint8_t *status);
+
 /* ---- pool: the scheduler (any number of proofs per call, any number of devices) ------------
  * The reference's call shape is ONE call for as many proofs as the caller has: a loop over
  * RangeProof::verify_multiple (src/range_proof/mod.rs:457-470), from one thread or many.  A bpgpu_ctx is one launch

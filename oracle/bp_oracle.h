@@ -101,6 +101,9 @@ int oracle_ipp_verify(size_t n, const uint8_t *proof, size_t proof_len, const ui
                       const uint8_t *G, const uint8_t *H, uint8_t msm_out[32]);
 /* InnerProductProof::create(&mut Transcript::new(label), &Q, G_factors = 1, H_factors, G, H, a, b).to_bytes()
  * (ipp.rs:38-193): proof_out = 32 * (2 lg n + 2) bytes. */
+/* InnerProductProof::from_bytes + verification_scalars (ipp.rs:198-253) on the caller's transcript */
+int oracle_ipp_verification_scalars(size_t n, const uint8_t *proof, size_t proof_len, uint8_t state[208], uint8_t *u_sq,
+                                    uint8_t *u_inv_sq, uint8_t *s);
 int oracle_ipp_create(size_t n, const uint8_t *label, size_t label_len, const uint8_t Q[32], const uint8_t *Hf,
                       const uint8_t *G, const uint8_t *H, const uint8_t *a, const uint8_t *b, uint8_t *proof_out);
 int oracle_ipp_test_instance(size_t n, const uint8_t *label, size_t label_len, const uint8_t *seed, size_t seed_len,

@@ -726,6 +726,43 @@ int oracle_ipp_verify(size_t n, const uint8_t *proof, size_t proof_len, const ui
     return rc;
 }
 
+/* InnerProductProof::from_bytes (ipp.rs:373-407) + verification_scalars (ipp.rs:198-253) on the caller's transcript: the call
+ * r1cs/verifier.rs:401-404 and ipp.rs:283 make.  state: in, and advanced out when the result is Ok.  u_sq, u_inv_sq: lg_n x 32
+ * bytes; s: n x 32 bytes. */
+int oracle_ipp_verification_scalars(size_t n, const uint8_t *proof, size_t proof_len, uint8_t state[208], uint8_t *u_sq_out,
+                                    uint8_t *u_inv_sq_out, uint8_t *s_out) {
+    if (proof_len % 32 != 0) return ORACLE_ERR_FORMAT;
+    size_t ne = proof_len / 32;
+    if (ne < 2 || (ne - 2) % 2 != 0) return ORACLE_ERR_FORMAT;
+    size_t lg_n = (ne - 2) / 2;
+    if (lg_n >= 32) return ORACLE_ERR_FORMAT;
+    sc a, b;
+    if (sc_from_canonical_bytes(&a, proof + 64 * lg_n)) return ORACLE_ERR_FORMAT;
+    if (sc_from_canonical_bytes(&b, proof + 64 * lg_n + 32)) return ORACLE_ERR_FORMAT;
+    if (n != ((size_t)1 << lg_n)) return ORACLE_ERR_VERIFICATION;
+    merlin_transcript t; ts_load(&t, state);
+    merlin_append_message(&t, "dom-sep", (const uint8_t *)"ipp v1", 6);
+    merlin_append_u64(&t, "n", n);
+    sc u_sq[32], u_inv_sq[32], allinv; sc_from_u64(&allinv, 1);
+    for (size_t i = 0; i < lg_n; i++) {
+        if (validate_and_append_point(&t, "L", proof + 64 * i)) return ORACLE_ERR_VERIFICATION;
+        if (validate_and_append_point(&t, "R", proof + 64 * i + 32)) return ORACLE_ERR_VERIFICATION;
+        sc u, ui; challenge_scalar(&t, "u", &u); sc_invert(&ui, &u);
+        sc_mul(&allinv, &allinv, &ui); sc_mul(&u_sq[i], &u, &u); sc_mul(&u_inv_sq[i], &ui, &ui);
+    }
+    sc *s = malloc((n + 1) * sizeof(sc));
+    s[0] = allinv;
+    for (size_t i = 1; i < n; i++) {
+        size_t lg_i = 63 - (size_t)__builtin_clzll((unsigned long long)i);
+        sc_mul(&s[i], &s[i - ((size_t)1 << lg_i)], &u_sq[(lg_n - 1) - lg_i]);
+    }
+    for (size_t i = 0; i < lg_n; i++) { sc_tobytes(u_sq_out + 32 * i, &u_sq[i]); sc_tobytes(u_inv_sq_out + 32 * i, &u_inv_sq[i]); }
+    for (size_t i = 0; i < n; i++) sc_tobytes(s_out + 32 * i, &s[i]);
+    free(s);
+    ts_store(state, &t);
+    return ORACLE_OK;
+}
+
 /* InnerProductProof::create(...).to_bytes() (ipp.rs:38-193, 334-345) with G_factors = 1 (what the reference's callers
  * pass: range_proof/dealer.rs, ipp.rs:454) -- the oracle for the GPU's batched prover.  Returns 1 if a point does not decode. */
 int oracle_ipp_create(size_t n, const uint8_t *label, size_t label_len, const uint8_t Q[32], const uint8_t *Hf,

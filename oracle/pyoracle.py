@@ -79,6 +79,7 @@ def lib():
     L.oracle_prove_batch.restype = C.c_double
     L.oracle_prove_batch.argtypes = [vp, sz, C.POINTER(C.c_uint64), u8p, sz, sz, u8p, sz, u8p, sz, u8p, u8p, C.c_int]
     L.oracle_ipp_verify.argtypes = [sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
+    L.oracle_ipp_verification_scalars.argtypes = [sz, u8p, sz, u8p, u8p, u8p, u8p]
     L.oracle_ipp_test_instance.argtypes = [sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.oracle_ipp_create.argtypes = [sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.oracle_prove_shares.argtypes = [vp, C.POINTER(C.c_uint64), u8p, sz, sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p]
@@ -248,6 +249,15 @@ def ipp_create(n, label, Q, Hf, G, H, a, b):
     out = C.create_string_buffer(32 * (2 * lg + 2))
     rc = lib().oracle_ipp_create(n, label, len(label), Q, Hf, G, H, a, b, out)
     return rc, out.raw
+
+
+def ipp_verification_scalars(n, proof, state):
+    """InnerProductProof::verification_scalars on a 208-byte transcript state: (rc, u_sq, u_inv_sq, s, advanced state)."""
+    k = (len(proof) // 32 - 2) // 2 if len(proof) >= 64 else 0
+    us, ui, s_ = C.create_string_buffer(32 * max(k, 1)), C.create_string_buffer(32 * max(k, 1)), C.create_string_buffer(32 * max(n, 1))
+    st = C.create_string_buffer(state, 208)
+    rc = lib().oracle_ipp_verification_scalars(n, proof, len(proof), st, us, ui, s_)
+    return rc, us.raw[:32 * k], ui.raw[:32 * k], s_.raw[:32 * n], st.raw
 
 
 def ipp_verify(n, proof, label, Gf, Hf, P, Q, G, H):

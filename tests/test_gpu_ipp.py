@@ -91,3 +91,51 @@ def test_ipp_device_pointers_shared_bases_and_prebound_transcript(ctx, oracle, n
         assert rc == 0
         s.synchronize()
         assert list(d_v.cpu().numpy()) == expect
+
+
+def test_verification_scalars_export_vs_oracle(oracle):
+    """bpgpu_ipp_verification_scalars == InnerProductProof::verification_scalars (src/inner_product_proof.rs:198-253; the call of
+    src/r1cs/verifier.rs:401-404): u_i^2, u_i^-2, s_i, status and the advanced transcript against the oracle, for the sizes of the
+    reference's tests, the R1CS shape's n = 2048, label / shared-state / per-proof-state transcripts, and the three error kinds."""
+    import bulletproofs_amd as bp
+    from bulletproofs_amd._lib import transcript_new, transcript_append_message
+    ctx = bp.Context(0)
+    label = b"innerproducttest"
+    for n in (1, 2, 4, 32, 64, 2048):
+        nb = 5 if n < 2048 else 2
+        insts = [oracle.ipp_test_instance(n, label, b"gv%d-%d" % (n, i))["proof"] for i in range(nb)]
+        pl = len(insts[0])
+        bad = [bytearray(p_) for p_ in insts]
+        if n >= 2:
+            bad[1][0:32] = bytes(32)                      # identity L_0 -> VerificationError
+        bad[nb - 1][pl - 32:pl] = b"\xff" * 32            # b not canonical -> FormatError
+        proofs = b"".join(bytes(x) for x in bad)
+        st0 = transcript_new(label)
+        us, ui, s_, st, tso = ctx.ipp_verification_scalars(n, proofs, pl, label=label, want_transcripts=True)
+        k = n.bit_length() - 1
+        for i in range(nb):
+            rc, eus, eui, es, est = oracle.ipp_verification_scalars(n, bytes(bad[i]), st0)
+            assert st[i] == rc, (n, i)
+            if rc == 0:
+                assert us[32 * k * i:32 * k * (i + 1)] == eus and ui[32 * k * i:32 * k * (i + 1)] == eui and s_[32 * n * i:32 * n * (i + 1)] == es
+                assert tso[208 * i:208 * (i + 1)] == est
+            else:
+                assert s_[32 * n * i:32 * n * (i + 1)] == bytes(32 * n)
+        # the caller's transcript: one state for the batch, then one per proof (different positions)
+        shared = transcript_append_message(st0, b"earlier", b"message of the parent protocol")
+        us2, ui2, s2, st2, tso2 = ctx.ipp_verification_scalars(n, proofs, pl, transcripts=shared, want_transcripts=True)
+        per = b"".join(transcript_append_message(st0, b"p", bytes(j for j in range(3 * i + 1))) for i in range(nb))
+        us3, ui3, s3, st3, tso3 = ctx.ipp_verification_scalars(n, proofs, pl, transcripts=per, want_transcripts=True)
+        for i in range(nb):
+            for (gu, gi, gs, gst, gts, start) in ((us2, ui2, s2, st2, tso2, shared), (us3, ui3, s3, st3, tso3, per[208 * i:208 * (i + 1)])):
+                rc, eus, eui, es, est = oracle.ipp_verification_scalars(n, bytes(bad[i]), start)
+                assert gst[i] == rc
+                if rc == 0:
+                    assert gu[32 * k * i:32 * k * (i + 1)] == eus and gi[32 * k * i:32 * k * (i + 1)] == eui and gs[32 * n * i:32 * n * (i + 1)] == es
+                    assert gts[208 * i:208 * (i + 1)] == est
+        # n that does not match the proof: VerificationError for well-formed proofs, FormatError outranks it
+        _, _, _, st4 = ctx.ipp_verification_scalars(2 * n, proofs, pl, label=label)
+        assert list(st4) == [2 if i == nb - 1 else 1 for i in range(nb)]
+    _, _, _, st5 = ctx.ipp_verification_scalars(4, bytes(100), 50, label=label)      # malformed length
+    assert list(st5) == [2, 2]
+    ctx.close()

@@ -273,3 +273,34 @@ def test_share_audit_oracle_is_consistent_with_the_pinned_prover_and_verifier(or
     bad = oracle.prove_shares(g, [7, (1 << 63) + 5, 9, (1 << 40) + 1], bl, n, b"AggregatedRangeProofTest", b"seed-b")
     assert oracle.verify(g, bad["proof"], bad["commitments"], n, b"AggregatedRangeProofTest", rng64)[0] == 1
     assert [j for j in range(m) if oracle.audit_share(g, n, j, *part(bad, j), bad["challenges"])[0] != 0] == [1, 3]
+
+
+def test_ipp_verification_scalars_c_equals_twin(oracle):
+    """oracle_ipp_verification_scalars (the checker of bpgpu_ipp_verification_scalars; reference: src/inner_product_proof.rs:198-253)
+    against the independent Python twin: u_i^2, u_i^-2, s_i and the advanced transcript, for the sizes of the reference's tests
+    (ipp.rs:499-534: n = 1, 2, 4, 32, 64) and the R1CS shape's 2048; the reference's own identity s_i * s_{n-1-i} = 1 ... is not
+    one, but s_i * s_i^-1 with s^-1 = reversed s is (ipp.rs:283): checked."""
+    import bp_twin as T
+    for n in (1, 2, 4, 32, 64, 2048):
+        inst = oracle.ipp_test_instance(n, b"innerproducttest", b"vs%d" % n)
+        pr = inst["proof"]
+        st0 = oracle.transcript_new(b"innerproducttest")
+        rc, us, ui, s_, st1 = oracle.ipp_verification_scalars(n, pr, st0)
+        assert rc == 0
+        k = n.bit_length() - 1
+        t = T.Transcript(b"innerproducttest")
+        rp = T.RangeProof()
+        rp.L_vec = [pr[64 * i:64 * i + 32] for i in range(k)]
+        rp.R_vec = [pr[64 * i + 32:64 * i + 64] for i in range(k)]
+        tus, tui, ts = T.verification_scalars(rp, n, t)
+        le = lambda xs: b"".join(x.to_bytes(32, "little") for x in xs)
+        assert us == le(tus) and ui == le(tui) and s_ == le(ts)
+        assert oracle.transcript_challenge_bytes(st1, b"chk", 32)[1] == t.challenge_bytes(b"chk", 32)
+        sv = [int.from_bytes(s_[32 * i:32 * i + 32], "little") for i in range(n)]
+        assert all(sv[i] * sv[n - 1 - i] % T.L == 1 for i in range(n))                     # 1 / s_i = s_{n-1-i}
+    # error cases: wrong n, identity L point, non-canonical a
+    inst = oracle.ipp_test_instance(4, b"innerproducttest", b"e")
+    pr, st0 = inst["proof"], oracle.transcript_new(b"innerproducttest")
+    assert oracle.ipp_verification_scalars(8, pr, st0)[0] == 1
+    assert oracle.ipp_verification_scalars(4, bytes(32) + pr[32:], st0)[0] == 1
+    assert oracle.ipp_verification_scalars(4, pr[:-64] + b"\xff" * 32 + pr[-32:], st0)[0] == 2
