@@ -61,7 +61,12 @@ class BulletproofGens:
         """generators.rs:177-204: extends every party's chain to new_capacity (no-op if not larger); the device tables are rebuilt."""
         if self.gens_capacity >= new_capacity:
             return
+        # the Pedersen bases the context holds now (custom ones if the caller went through Context.gens_load) must survive the rebuild
+        _, _, B0, Bb0 = self.ctx.gens_export()
         self.ctx.gens_create(new_capacity, self.party_capacity)
+        G1, H1, B1, Bb1 = self.ctx.gens_export()
+        if (B0, Bb0) != (B1, Bb1):          # custom bases were loaded: keep them, with the extended G / H chains
+            self.ctx.gens_load(new_capacity, self.party_capacity, G1, H1, B0, Bb0)
         self.gens_capacity = new_capacity
         self.__dict__.pop("_pc", None)
 

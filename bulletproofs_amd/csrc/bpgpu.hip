@@ -87,6 +87,7 @@ struct bpgpu_ctx {
     // pinned host staging (ragged work decompositions, library-drawn randomness, the host-pointer entry points' IO):
     // copies out of it are truly asynchronous; pin_ev guards its reuse by the next call
     char *pin = nullptr;
+    size_t last_secret_bytes = 0;                      // leading bytes of the pinned block that held the last prover call's secrets
     size_t pin_cap = 0, pin_off = 0, pin_marked = 0;   // pin_marked: bytes already guarded by a recorded pin_ev (pin_mark)
     hipEvent_t pin_ev = nullptr;
     bool pin_pending = false;
@@ -423,6 +424,22 @@ int bpgpu_ctx_get_option(bpgpu_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "host_sync_blocking")) *value = c->sync_blocking ? 1 : 0;
     else if (!strcmp(key, "transcript_script")) *value = c->no_script ? 0 : 1;
     else if (!strcmp(key, "bucket_min_terms")) *value = c->bucket_min ? c->bucket_min : BK_MIN_TERMS;
+    else if (!strcmp(key, "staging_residue")) {
+        // test hook: non-zero bytes left in the persistent staging buffers (pinned block, device IO buffer, prover working sets,
+        // arena) -- 0 after a prover entry point has returned (prover_exit)
+        if (hipSetDevice(c->device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) return fail(c, BPGPU_ERR_HIP, "synchronize failed");
+        int64_t nz = 0;
+        for (size_t i = 0; i < c->pin_cap && i < c->last_secret_bytes; i++) nz += c->pin[i] != 0;   // (behind the secrets: public outputs)
+        std::vector<char> tmp;
+        const std::pair<const char *, size_t> bufs[4] = {{c->io_dev, c->io_cap}, {c->rpp_buf, c->rpp_cap}, {c->ipp_buf, c->ipp_cap}, {c->arena, c->arena_cap}};
+        for (const auto &b : bufs) {
+            if (!b.first || !b.second) continue;
+            tmp.resize(b.second);
+            if (hipMemcpy(tmp.data(), b.first, b.second, hipMemcpyDeviceToHost) != hipSuccess) return fail(c, BPGPU_ERR_HIP, "read-back failed");
+            for (char ch : tmp) nz += ch != 0;
+        }
+        *value = nz;
+    }
     else return fail(c, BPGPU_ERR_INVALID_ARG, "unknown option %s", key);
     return BPGPU_OK;
 }
@@ -2399,6 +2416,37 @@ static int ippc_core(bpgpu_ctx *c, hipStream_t s, size_t n, size_t k, size_t nba
 // ============================================================================
 // batched inner-product-proof creation (ipp_prover.h)
 // ============================================================================
+// ---- the common exit of the prover entry points -------------------------------------------------------------------
+// The provers stage SECRETS (values, blindings, the witness vectors, every random scalar) in the context's persistent buffers:
+// the pinned staging block, the device IO buffer, their working sets and -- as window digits of secret scalars -- the arena.
+// The reference zeroizes its party state on Drop (party.rs:148-260, 308+); here every entered call, successful or not, leaves
+// through prover_exit::finish: the device buffers are cleared on the stream behind the call's last copy, the call's end is
+// recorded (ctx_leave), the stream is drained (host_wait), then the secret part of the staging block is cleared.  What is NOT
+// cleared: registers / LDS of finished kernels and the caller's own buffers.
+struct prover_exit {
+    bpgpu_ctx *c;
+    hipStream_t s;
+    char *h = nullptr;             // the call's pinned staging block (set once allocated)
+    size_t host_secret_bytes = 0;  // leading bytes of h that hold secrets
+    int finish(int rc) {
+        bool ok = true;
+        if (c->io_dev) ok = hipMemsetAsync(c->io_dev, 0, c->io_cap, s) == hipSuccess && ok;
+        if (c->rpp_buf) ok = hipMemsetAsync(c->rpp_buf, 0, c->rpp_cap, s) == hipSuccess && ok;
+        if (c->ipp_buf) ok = hipMemsetAsync(c->ipp_buf, 0, c->ipp_cap, s) == hipSuccess && ok;
+        if (c->arena) ok = hipMemsetAsync(c->arena, 0, c->arena_cap, s) == hipSuccess && ok;
+        const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
+        if (h && host_secret_bytes) memset(h, 0, host_secret_bytes);
+        c->last_secret_bytes = (h == c->pin) ? host_secret_bytes : 0;
+        if (!rc && !ok) rc = fail(c, BPGPU_ERR_HIP, "clearing the prover's working set failed");
+        return rc ? rc : (rc2 ? rc2 : rc3);
+    }
+};
+#define PX_HIPCHK(px, call)                                                                                          \
+    do {                                                                                                             \
+        hipError_t e_ = (call);                                                                                      \
+        if (e_ != hipSuccess) return (px).finish(fail(c, BPGPU_ERR_HIP, "%s failed: %s", #call, hipGetErrorString(e_))); \
+    } while (0)
+
 extern "C" int bpgpu_ipp_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, const uint8_t *label, size_t label_len, const uint8_t *shared_transcript,
                                       const uint8_t *Q, const uint8_t *G_factors, const uint8_t *H_factors, const uint8_t *G, const uint8_t *H,
                                       int bases_shared, const uint8_t *a, const uint8_t *b, uint8_t *proofs_out, uint8_t *status_out) {
@@ -2416,16 +2464,19 @@ extern "C" int bpgpu_ipp_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, con
     hipStream_t s = c->stream;
     int rc = ctx_enter(c, s);
     if (rc) return rc;
+    prover_exit px{c, s};
     const size_t proof_len = 32 * (2 * k + 2), TS = BPGPU_TRANSCRIPT_BYTES;
     // ---- inputs: one pinned staging block -> the persistent device IO buffer
     const size_t sz_v = align_up(nbatch * n * 32 + 64), sz_q = align_up(nbatch * 32 + 64), sz_base = align_up((bases_shared ? 1 : nbatch) * n * 32 + 64),
                  sz_ts = align_up(nbatch * TS);
     const size_t sz_in = 4 * sz_v + sz_q + 2 * sz_base + sz_ts, sz_out = align_up(nbatch * proof_len) + align_up(nbatch);
     rc = io_reserve(c, sz_in + sz_out);
-    if (rc) return rc;
+    if (rc) return px.finish(rc);
     char *h = nullptr;
     rc = pin_alloc(c, s, sz_in + sz_out, &h);
-    if (rc) return rc;
+    if (rc) return px.finish(rc);
+    px.h = h;
+    px.host_secret_bytes = 2 * sz_v;   // the witness a, b
     char *d_a = c->io_dev, *d_b = d_a + sz_v, *d_gf = d_b + sz_v, *d_hf = d_gf + sz_v, *d_q = d_hf + sz_v, *d_G = d_q + sz_q, *d_H = d_G + sz_base,
          *d_ts = d_H + sz_base, *d_proofs = c->io_dev + sz_in, *d_stb = d_proofs + align_up(nbatch * proof_len);
     memcpy(h, a, nbatch * n * 32);
@@ -2440,14 +2491,14 @@ extern "C" int bpgpu_ipp_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, con
         ipp_domain_sep_state(st0, label, label_len, shared_transcript, n, nullptr);
         for (size_t p = 0; p < nbatch; p++) memcpy(h + 4 * sz_v + sz_q + 2 * sz_base + p * TS, st0, TS);
     }
-    HIPCHK(c, hipMemcpyAsync(c->io_dev, h, sz_in, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemsetAsync(d_proofs, 0, nbatch * proof_len, s));
+    PX_HIPCHK(px, hipMemcpyAsync(c->io_dev, h, sz_in, hipMemcpyHostToDevice, s));
+    PX_HIPCHK(px, hipMemsetAsync(d_proofs, 0, nbatch * proof_len, s));
     // ---- rounds (ippc_core: own working set, the batched MSMs claim the arena)
     rc = ippc_core(c, s, n, k, nbatch, d_a, d_b, d_gf, d_hf, d_q, d_G, d_H, bases_shared, (uint32_t *)d_ts, (uint8_t *)d_proofs, proof_len, (uint8_t *)d_stb);
     char *h_out = h + sz_in;
     if (!rc && hipMemcpyAsync(h_out, d_proofs, sz_out, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
-    const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
-    if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
+    rc = px.finish(rc);
+    if (rc) return rc;
     memcpy(proofs_out, h_out, nbatch * proof_len);
     memcpy(status_out, h_out + align_up(nbatch * proof_len), nbatch);
     return BPGPU_OK;
@@ -2479,6 +2530,7 @@ extern "C" int bpgpu_linear_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
     }
     int rc = ctx_enter(c, s);
     if (rc) return rc;
+    prover_exit px{c, s};
     const size_t proof_len = 32 * (2 * k + 3), TS = BPGPU_TRANSCRIPT_BYTES, nd = 2 * k + 2, nb_b = b_shared ? 1 : nbatch;
     // ---- inputs: one pinned staging block -> the persistent device IO buffer
     const size_t sz_v = align_up(nbatch * n * 32 + 64), sz_bv = align_up(nb_b * n * 32 + 64), sz_q = align_up(nbatch * 32 + 64), sz_g = align_up(n * 32 + 64),
@@ -2486,10 +2538,12 @@ extern "C" int bpgpu_linear_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
     const size_t sz_in = sz_v + sz_bv + 2 * sz_q + sz_g + sz_fb + sz_rng + sz_ts, sz_pr = align_up(nbatch * proof_len), sz_stb = align_up(nbatch);
     const size_t sz_out = sz_pr + sz_stb;
     rc = io_reserve(c, sz_in + sz_out);
-    if (rc) return rc;
+    if (rc) return px.finish(rc);
     char *h = nullptr;
     rc = pin_alloc(c, s, sz_in + sz_out, &h);
-    if (rc) return rc;
+    if (rc) return px.finish(rc);
+    px.h = h;
+    px.host_secret_bytes = sz_in - sz_ts;   // a, r, the random draws (and the public inputs between them); the transcript block behind is reused for the way back
     char *d_a = c->io_dev, *d_b = d_a + sz_v, *d_C = d_b + sz_bv, *d_r = d_C + sz_q, *d_G = d_r + sz_q, *d_fb = d_G + sz_g, *d_rng = d_fb + sz_fb,
          *d_ts = d_rng + sz_rng, *d_proofs = c->io_dev + sz_in, *d_stb = d_proofs + sz_pr;
     memcpy(h, a, nbatch * n * 32);
@@ -2507,14 +2561,14 @@ extern "C" int bpgpu_linear_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
     {
         char *h_rng = h + sz_v + sz_bv + 2 * sz_q + sz_g + sz_fb;
         if (rng) memcpy(h_rng, rng, nbatch * nd * 64);
-        else if ((rc = os_random(c, h_rng, nbatch * nd * 64)) != 0) return rc;   // Scalar::random(&mut thread_rng())
+        else if ((rc = os_random(c, h_rng, nbatch * nd * 64)) != 0) return px.finish(rc);   // Scalar::random(&mut thread_rng())
         // every proof's transcript after innerproduct_domain_sep(n) (linear_proof.rs:73)
         uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
         ipp_domain_sep_state(st0, label, label_len, shared_transcript, n, nullptr);
         for (size_t p = 0; p < nbatch; p++) memcpy(h_rng + sz_rng + p * TS, st0, TS);
     }
-    HIPCHK(c, hipMemcpyAsync(c->io_dev, h, sz_in, hipMemcpyHostToDevice, s));
-    HIPCHK(c, hipMemsetAsync(d_proofs, 0, nbatch * proof_len, s));
+    PX_HIPCHK(px, hipMemcpyAsync(c->io_dev, h, sz_in, hipMemcpyHostToDevice, s));
+    PX_HIPCHK(px, hipMemsetAsync(d_proofs, 0, nbatch * proof_len, s));
     do {
         // ---- working set (own allocation: the batched MSMs claim the arena)
         const size_t N = n / 2 + 2, NS = n + 2;
@@ -2578,8 +2632,8 @@ extern "C" int bpgpu_linear_create_batch(bpgpu_ctx *c, size_t n, size_t nbatch, 
     if (!rc && hipMemcpyAsync(h_out, d_proofs, sz_out, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
     char *h_ts = h + (d_ts - c->io_dev);   // the transcript block of the staging buffer is free again: reuse it for the way back
     if (!rc && transcripts_out && hipMemcpyAsync(h_ts, d_ts, nbatch * TS, hipMemcpyDeviceToHost, s) != hipSuccess) rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
-    const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);   // (on an error the stream is drained before the staging buffers are reused)
-    if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
+    rc = px.finish(rc);   // (on an error too: the stream is drained before the staging buffers are reused, the secrets cleared)
+    if (rc) return rc;
     memcpy(proofs_out, h_out, nbatch * proof_len);
     memcpy(status_out, h_out + sz_pr, nbatch);
     if (transcripts_out) memcpy(transcripts_out, h_ts, nbatch * TS);
@@ -2626,22 +2680,25 @@ extern "C" int bpgpu_rangeproof_prove_batch(bpgpu_ctx *c, size_t n, size_t m, si
     hipStream_t s = c->stream;
     int rc = ctx_enter(c, s);
     if (rc) return rc;
+    prover_exit px{c, s};
     // ---- inputs through pinned staging into the persistent IO buffer
     const size_t sz_val = align_up(nbatch * m * 8), sz_bl = align_up(nbatch * m * 32), sz_rng = align_up(nbatch * sh.rng_per_proof), sz_ts = align_up(nbatch * TS);
     const size_t sz_in = sz_val + sz_bl + sz_rng + sz_ts;
     const size_t sz_pr = align_up(nbatch * proof_len), sz_cm = align_up(nbatch * m * 32);
     const size_t sz_out = sz_pr + sz_cm + sz_ts;
     rc = io_reserve(c, sz_in + sz_out);
-    if (rc) return rc;
+    if (rc) return px.finish(rc);
     char *h = nullptr;
     rc = pin_alloc(c, s, sz_in + sz_out, &h);
-    if (rc) return rc;
+    if (rc) return px.finish(rc);
+    px.h = h;
+    px.host_secret_bytes = sz_val + sz_bl + sz_rng;   // values, blindings, every random scalar
     memcpy(h, values, nbatch * m * 8);
     memcpy(h + sz_val, blindings, nbatch * m * 32);
     if (rng) memcpy(h + sz_val + sz_bl, rng, nbatch * sh.rng_per_proof);
     else {   // thread_rng() of prove_multiple (mod.rs:291-310): OS CSPRNG
         rc = os_random(c, h + sz_val + sz_bl, nbatch * sh.rng_per_proof);
-        if (rc) return rc;
+        if (rc) return px.finish(rc);
     }
     uint8_t st_start[BPGPU_TRANSCRIPT_BYTES];
     {   // every proof's transcript after rangeproof_domain_sep(n, m) (transcript.rs:44-48)
@@ -2663,17 +2720,17 @@ extern "C" int bpgpu_rangeproof_prove_batch(bpgpu_ctx *c, size_t n, size_t m, si
     const uint8_t *d_bl = (const uint8_t *)(d_in + sz_val), *d_rng = (const uint8_t *)(d_in + sz_val + sz_bl);
     uint32_t *d_ts = (uint32_t *)(d_in + sz_val + sz_bl + sz_rng);
     uint8_t *d_proofs = (uint8_t *)(d_in + sz_in), *d_coms = d_proofs + sz_pr;
-    HIPCHK(c, hipMemcpyAsync(d_in, h, sz_in, hipMemcpyHostToDevice, s));
+    PX_HIPCHK(px, hipMemcpyAsync(d_in, h, sz_in, hipMemcpyHostToDevice, s));
     // ---- working set
     const size_t w_gs = align_up(gs_bytes), w_mo = align_up(nmsm1 * 32), w_ms = align_up(nmsm1 + 64), w_f = align_up(RPP_FIXED * nbatch * 32),
                  w_p = align_up(RPP_PARTY_FIELDS * nbatch * m * 32), w_v = align_up(nbatch * nm * 32), w_q = align_up(nbatch * 32), w_gen = align_up(nm * 32);
     const size_t need = w_gs + w_mo + w_ms + w_f + w_p + 10 * w_v + w_q + 2 * w_gen;
-    if (c->rpp_cap < need) {
-        HIPCHK(c, hipDeviceSynchronize());
-        if (c->rpp_buf) HIPCHK(c, hipFree(c->rpp_buf));
+    if (c->rpp_cap < need) {   // (the old block is clean: every call clears it on its way out)
+        PX_HIPCHK(px, hipDeviceSynchronize());
+        if (c->rpp_buf) PX_HIPCHK(px, hipFree(c->rpp_buf));
         c->rpp_buf = nullptr;
         c->rpp_cap = 0;
-        HIPCHK(c, hipMalloc((void **)&c->rpp_buf, need + need / 8));
+        PX_HIPCHK(px, hipMalloc((void **)&c->rpp_buf, need + need / 8));
         c->rpp_cap = need + need / 8;
     }
     char *wb = c->rpp_buf;
@@ -2736,8 +2793,8 @@ extern "C" int bpgpu_rangeproof_prove_batch(bpgpu_ctx *c, size_t n, size_t m, si
             hipMemcpyAsync(h_out, d_proofs, sz_out, hipMemcpyDeviceToHost, s) != hipSuccess)
             rc = fail(c, BPGPU_ERR_HIP, "D2H copy failed");
     }
-    const int rc2 = ctx_leave(c, s), rc3 = host_wait(c, s);
-    if (rc || rc2 || rc3) return rc ? rc : (rc2 ? rc2 : rc3);
+    rc = px.finish(rc);
+    if (rc) return rc;
     memcpy(proofs_out, h_out, nbatch * proof_len);
     memcpy(commitments_out, h_out + sz_pr, nbatch * m * 32);
     if (transcripts_out) memcpy(transcripts_out, h_out + sz_pr + sz_cm, nbatch * TS);

@@ -367,7 +367,12 @@ int bpgpu_ipp_create_batch(bpgpu_ctx *ctx, size_t n, size_t nbatch, const uint8_
  * that does not fit n bits, BPGPU_ERR_NO_GENS for InvalidGeneratorsLength.
  * VARIABLE TIME in the secrets (values, blindings, s_L, s_R): the reference computes A and S with its constant-time
  * multiscalar_mul (party.rs:99-124); this engine has no constant-time path.  For provers whose GPU an adversary
- * cannot observe. */
+ * cannot observe.
+ * Secrets at rest: like the reference's parties (zeroize on Drop, party.rs:148-260), every prover entry point
+ * (bpgpu_rangeproof_prove_batch, bpgpu_ipp_create_batch, bpgpu_linear_create_batch) clears what it staged before it returns,
+ * on success and on every error path: the context's device IO buffer, the provers' working sets and the MSM arena (window
+ * digits of secret scalars) on the stream behind the last copy, then the secret part of the pinned host staging block.
+ * Not cleared: the caller's own buffers. */
 int bpgpu_rangeproof_prove_batch(bpgpu_ctx *ctx, size_t n, size_t m, size_t nbatch, const uint64_t *values,
                                  const uint8_t *blindings, const uint8_t *label, size_t label_len,
                                  const uint8_t *shared_transcript, const uint8_t *rng,

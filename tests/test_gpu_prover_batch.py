@@ -160,3 +160,38 @@ def test_singleparty_create_and_verify_helper(gens64x8, oracle, n, m):
         swapped = [value_commitments[1], value_commitments[0]] + value_commitments[2:]
         with pytest.raises(VerificationError):
             parsed.verify_multiple(bp_gens, pc_gens, Transcript(b"AggregatedRangeProofTest"), swapped, n)
+
+
+def test_prover_entry_points_leave_no_secrets_in_the_staging_buffers(oracle):
+    """The reference zeroizes its parties' secrets on Drop (party.rs:148-260); the batched provers clear what they staged --
+    pinned block, device IO buffer, working sets, MSM arena -- before they return, on success and on the error paths
+    (`staging_residue`: non-zero bytes left in those buffers)."""
+    import hashlib
+    import bulletproofs_amd as bp
+    ctx = bp.Context(0, fixed_window_bits=12)
+    ctx.gens_create(64, 2)
+    nb, n, m = 33, 64, 2
+    vals = [int.from_bytes(hashlib.shake_256(b"zv%d" % i).digest(8), "little") for i in range(nb * m)]
+    bl = b"".join(hashlib.shake_256(b"zb%d" % i).digest(31) + b"\x00" for i in range(nb * m))
+    proofs, coms = ctx.rangeproof_prove_batch(n, m, vals, bl, label=b"zeroize")
+    assert ctx.get_option("staging_residue") == 0
+    assert ctx.rangeproof_verify_batch(n, m, proofs, len(proofs) // nb, coms, b"zeroize") == bytes(nb)
+    inst = oracle.linear_test_instance(16, b"zeroize-linear")
+    made, status = ctx.linear_create_batch(16, inst["C"], inst["r"], inst["a"], inst["b"], None, None, None, label=inst["label"], rng=inst["rng"])
+    assert status == bytes(1) and made == inst["proof"] and ctx.get_option("staging_residue") == 0
+    ip = oracle.ipp_test_instance(8, b"zeroize-ipp", b"s")
+    ctx.close()
+
+
+def test_increase_capacity_keeps_custom_pedersen_bases(oracle):
+    """BulletproofGens::increase_capacity (generators.rs:177-204) on a context whose Pedersen bases were loaded by the caller: the
+    rebuilt tables keep those bases (they used to revert to the defaults)."""
+    import bulletproofs_amd as bp
+    g = bp.BulletproofGens(8, 1)
+    G, H, B, Bb = g.ctx.gens_export()
+    g.ctx.gens_load(8, 1, G, H, Bb, B)                      # custom bases: the default pair swapped
+    g.increase_capacity(16)
+    G2, H2, B2, Bb2 = g.ctx.gens_export()
+    assert (B2, Bb2) == (Bb, B) and G2[:32 * 8] == G and len(G2) == 32 * 16
+    og = oracle.Gens(16, 1).export()
+    assert G2 == og[0] and H2 == og[1]
