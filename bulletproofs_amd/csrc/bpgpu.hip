@@ -100,6 +100,11 @@ struct bpgpu_ctx {
     char *rpp_buf = nullptr;                 // working set of the batched range-proof prover
     size_t rpp_cap = 0;
     uint32_t bucket_min = 0;                 // terms per MSM from which the bucket path is taken (0 = BK_MIN_TERMS; huge = never)
+    // constant-time generator-table MSMs for the prover's secret-dependent commitments (msm_fixed.h fb_accum_ct_thread): their own
+    // small-window table, built on first use
+    bool prover_ct = false;
+    fb_entry *d_table_ct = nullptr;
+    fb_params prm_ct{};
     // second stream for the generator-table half of a shared-generator MSM: it is independent of the per-MSM points'
     // half until the finish, so the two halves run side by side (fork after the status memset, join before the finish)
     hipStream_t stream2 = nullptr;
@@ -364,6 +369,7 @@ void bpgpu_ctx_destroy(bpgpu_ctx *c) {
     if (c->join_ev) hipEventDestroy(c->join_ev);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->rp_status) hipFree(c->rp_status);
+    if (c->d_table_ct) hipFree(c->d_table_ct);
     if (c->d_gens) hipFree(c->d_gens);
     release_table(c);
     if (c->stream) hipStreamDestroy(c->stream);
@@ -405,6 +411,10 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
         c->no_script = value == 0;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "prover_constant_time")) {
+        c->prover_ct = value != 0;
+        return BPGPU_OK;
+    }
     if (!strcmp(key, "bucket_min_terms")) {
         if (value < 0 || value > 0x7fffffff) return fail(c, BPGPU_ERR_INVALID_ARG, "bucket_min_terms out of range");
         c->bucket_min = (uint32_t)value;
@@ -423,6 +433,7 @@ int bpgpu_ctx_get_option(bpgpu_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "horner_lanes")) *value = c->horner_lanes;
     else if (!strcmp(key, "host_sync_blocking")) *value = c->sync_blocking ? 1 : 0;
     else if (!strcmp(key, "transcript_script")) *value = c->no_script ? 0 : 1;
+    else if (!strcmp(key, "prover_constant_time")) *value = c->prover_ct ? 1 : 0;
     else if (!strcmp(key, "bucket_min_terms")) *value = c->bucket_min ? c->bucket_min : BK_MIN_TERMS;
     else if (!strcmp(key, "staging_residue")) {
         // test hook: non-zero bytes left in the persistent staging buffers (pinned block, device IO buffer, prover working sets,
@@ -491,6 +502,10 @@ static int build_tables(bpgpu_ctx *c) {
     fb_params prm;
     prm.n_gens = (uint32_t)(2 + 2 * c->gens_capacity * c->party_capacity);
     release_table(c);
+    if (c->d_table_ct) {   // belongs to the previous generator set
+        hipFree(c->d_table_ct);
+        c->d_table_ct = nullptr;
+    }
     for (auto &kv : c->gen_ids_cache) hipFree(kv.second);
     c->gen_ids_cache.clear();
     std::lock_guard<std::mutex> lk(g_tab_mu);
@@ -551,6 +566,41 @@ static int build_tables(bpgpu_ctx *c) {
     g_tables.push_back(t);
     c->tab_ref = t;
     c->d_table = d_table;
+    return BPGPU_OK;
+}
+
+// the small-window table of the constant-time path (W = 4: 64 KiB per generator), built on first use
+static int build_ct_table(bpgpu_ctx *c) {
+    if (c->d_table_ct) return BPGPU_OK;
+    fb_params prm;
+    prm.n_gens = c->prm.n_gens;
+    prm.W = BP_FB_CT_W;
+    prm.nwin = fb_nwin(prm.W);
+    prm.half = 1u << (prm.W - 1);
+    const size_t entries = (size_t)prm.n_gens * prm.nwin * prm.half;
+    fb_entry *d_table = nullptr;
+    ge_ext *d_base = nullptr;
+    uint32_t *d_bad = nullptr;
+    if (hipMalloc((void **)&d_table, entries * sizeof(fb_entry)) != hipSuccess || hipMalloc((void **)&d_base, (size_t)prm.n_gens * prm.nwin * sizeof(ge_ext)) != hipSuccess ||
+        hipMalloc((void **)&d_bad, 4) != hipSuccess) {
+        if (d_table) hipFree(d_table);
+        if (d_base) hipFree(d_base);
+        return fail(c, BPGPU_ERR_HIP, "hipMalloc of the constant-time table failed");
+    }
+    hipMemsetAsync(d_bad, 0, 4, c->stream);
+    LAUNCH(c, c->stream, "fb_base", k_fb_base, (prm.n_gens + 63) / 64, 64, prm, c->d_gens, d_base, d_bad);
+    LAUNCH(c, c->stream, "fb_fill", k_fb_fill, (prm.n_gens * prm.nwin + 63) / 64, 64, prm, d_base, d_table);
+    const uint64_t n_groups = (entries + BP_FB_NORM_GROUP - 1) / BP_FB_NORM_GROUP;
+    LAUNCH(c, c->stream, "fb_norm", k_fb_norm, (uint32_t)((n_groups + 63) / 64), 64, n_groups, (uint64_t)entries, d_table);
+    const hipError_t e = hipStreamSynchronize(c->stream);
+    hipFree(d_base);
+    hipFree(d_bad);
+    if (e != hipSuccess) {
+        hipFree(d_table);
+        return fail(c, BPGPU_ERR_HIP, "constant-time table construction failed: %s", hipGetErrorString(e));
+    }
+    c->d_table_ct = d_table;
+    c->prm_ct = prm;
     return BPGPU_OK;
 }
 
@@ -1019,13 +1069,19 @@ static void enqueue_fb_reduce(bpgpu_ctx *c, hipStream_t s, uint32_t nbatch, uint
 
 static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, size_t n_unique, const void *d_gen_scalars,
                                  const void *d_uniq_scalars, const void *d_uniq_points, void *d_out, void *d_status_bytes,
-                                 void *d_verdict, hipStream_t s, bool g_only = false) {
+                                 void *d_verdict, hipStream_t s, bool g_only = false, bool ct = false) {
+    // ct: the constant-time walk (generator terms only: n_unique == 0) -- the prover's V, A, S, T_1, T_2
     if (nbatch == 0) return BPGPU_OK;
     if (!c->d_table) return fail(c, BPGPU_ERR_NO_GENS, "generators not loaded");
+    if (ct) {
+        if (n_unique) return fail(c, BPGPU_ERR_INVALID_ARG, "the constant-time path serves generator terms only");
+        const int rcc = build_ct_table(c);
+        if (rcc) return rcc;
+    }
     if (n == 0 || m == 0 || n > c->gens_capacity || m > c->party_capacity)
         return fail(c, BPGPU_ERR_NO_GENS, "generators too small for n=%zu m=%zu", n, m);
     const uint32_t n_gen_terms = (uint32_t)((g_only ? 1 : 2) * n * m + 2);   // g_only: d_gen_scalars rows are (B_blinding, B, G(n, m))
-    const fb_params prm = c->prm;
+    const fb_params prm = ct ? c->prm_ct : c->prm;
     const uint32_t npairs = n_gen_terms * prm.nwin;
     // thread / element counts are 32-bit in the kernels: refuse what does not fit (grids of <= 2^31 / 64 blocks)
     if ((uint64_t)n_gen_terms * nbatch > 0x7fffffffull || (uint64_t)nbatch * ((n_unique + BP_VB_CHUNK - 1) / BP_VB_CHUNK) * 64 > 0x7fffffffull ||
@@ -1057,11 +1113,18 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
         HIPCHK(c, hipStreamWaitEvent(s2, c->fork_ev, 0));
     }
     const uint32_t nrec = n_gen_terms * (uint32_t)nbatch;
-    LAUNCH(c, s2, "fb_recode", k_fb_recode, (nrec + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nrec, prm, (uint32_t)nbatch, n_gen_terms,
-           (const uint32_t *)d_gen_scalars, d_digits, d_status);
     const uint32_t nblk_p = (uint32_t)((nbatch + FB_BLOCK - 1) / FB_BLOCK);
-    LAUNCH(c, s2, "fb_accum", k_fb_accum, nblk_p * nsplit, FB_BLOCK, prm, (uint32_t)nbatch, nblk_p, nsplit, npairs, d_ids, d_digits,
-           c->d_table, d_partial);
+    if (ct) {
+        LAUNCH(c, s2, "fb_recode_ct", k_fb_recode_ct, (nrec + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nrec, prm, (uint32_t)nbatch, n_gen_terms,
+               (const uint32_t *)d_gen_scalars, d_digits);
+        LAUNCH(c, s2, "fb_accum_ct", k_fb_accum_ct, nblk_p * nsplit, FB_BLOCK, prm, (uint32_t)nbatch, nblk_p, nsplit, npairs, d_ids, d_digits,
+               c->d_table_ct, d_partial);
+    } else {
+        LAUNCH(c, s2, "fb_recode", k_fb_recode, (nrec + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nrec, prm, (uint32_t)nbatch, n_gen_terms,
+               (const uint32_t *)d_gen_scalars, d_digits, d_status);
+        LAUNCH(c, s2, "fb_accum", k_fb_accum, nblk_p * nsplit, FB_BLOCK, prm, (uint32_t)nbatch, nblk_p, nsplit, npairs, d_ids, d_digits,
+               c->d_table, d_partial);
+    }
     ge_ext *d_red = nullptr;
     uint32_t nred = 0;
     enqueue_fb_reduce(c, s2, (uint32_t)nbatch, nsplit, d_partial, &d_red, &nred);
@@ -2755,7 +2818,7 @@ extern "C" int bpgpu_rangeproof_prove_batch(bpgpu_ctx *c, size_t n, size_t m, si
         }
         // (1) V_j, A, S
         LAUNCH(c, s, "rpp_commit1", k_rpp_commit1, n_b + (nbits + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, n_b, nbits, sh, d_values, d_bl, d_rng, gsc, party, sL, sR);
-        rc = msm_shared_dev_locked(c, n, m, nmsm1, 0, gsc, nullptr, nullptr, mo, mst, nullptr, s);
+        rc = msm_shared_dev_locked(c, n, m, nmsm1, 0, gsc, nullptr, nullptr, mo, mst, nullptr, s, false, c->prover_ct);
         if (rc) break;
         LAUNCH(c, s, "rpp_chal1", k_rpp_chal1, (nb32 + RP_BLOCK - 1) / RP_BLOCK, RP_BLOCK, sh, (const uint32_t *)mo, d_ts, fields, d_proofs, d_coms);
         // (2) polynomials, T_1, T_2
@@ -2767,7 +2830,7 @@ extern "C" int bpgpu_rangeproof_prove_batch(bpgpu_ctx *c, size_t n, size_t m, si
             break;
         }
         LAUNCH(c, s, "rpp_tcommit", k_rpp_tcommit, n_b, BP_BLOCK, sh, d_rng, gsc, party);
-        rc = msm_shared_dev_locked(c, n, m, 2 * nbatch, 0, gsc, nullptr, nullptr, mo, mst, nullptr, s);
+        rc = msm_shared_dev_locked(c, n, m, 2 * nbatch, 0, gsc, nullptr, nullptr, mo, mst, nullptr, s, false, c->prover_ct);
         if (rc) break;
         // (3) x, t_x ..., w; Q = w B; the inner-product argument's inputs
         if (hipMemsetAsync(gsc, 0, (size_t)nbatch * sh.n_gen_terms * 32, s) != hipSuccess) {

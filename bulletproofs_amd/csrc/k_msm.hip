@@ -82,6 +82,22 @@ __global__ void __launch_bounds__(FB_BLOCK) k_fb_accum(fb_params prm, uint32_t n
     if (p < nproofs) fb_accum_thread(p, split, q0 < npairs ? q0 : npairs, q1, prm, nproofs, gen_ids, digits, table, partial);
 }
 
+// constant-time twins (msm_fixed.h): same grids
+__global__ void __launch_bounds__(BP_BLOCK) k_fb_recode_ct(uint32_t nthreads, fb_params prm, uint32_t nproofs, uint32_t n_gen_terms,
+                                                            const uint32_t *gen_scalars, fb_digit *digits) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < nthreads) fb_recode_ct_thread(tid, prm, nproofs, n_gen_terms, gen_scalars, digits);
+}
+__global__ void __launch_bounds__(FB_BLOCK) k_fb_accum_ct(fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit, uint32_t npairs,
+                                                           const uint32_t *__restrict__ gen_ids, const fb_digit *__restrict__ digits,
+                                                           const fb_entry *__restrict__ table, ge_ext *__restrict__ partial) {
+    const uint32_t pblk = blockIdx.x % nblk_p, split = blockIdx.x / nblk_p;
+    const uint32_t p = pblk * FB_BLOCK + threadIdx.x;
+    const uint32_t per = (npairs + nsplit - 1) / nsplit;
+    const uint32_t q0 = split * per, q1 = (q0 + per < npairs) ? q0 + per : npairs;
+    if (p < nproofs) fb_accum_ct_thread(p, split, q0 < npairs ? q0 : npairs, q1, prm, nproofs, gen_ids, digits, table, partial);
+}
+
 __global__ void __launch_bounds__(BP_BLOCK) k_fb_reduce(uint32_t nthreads, uint32_t nproofs, uint32_t nsplit, uint32_t group,
                                                          const ge_ext *partial, ge_ext *out) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;

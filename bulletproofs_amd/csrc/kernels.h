@@ -34,6 +34,8 @@ __global__ void k_fb_fill(fb_params prm, const ge_ext *base, fb_entry *table);
 __global__ void k_fb_norm(uint64_t n_groups, uint64_t n_entries, fb_entry *table);
 __global__ void k_fb_recode(uint32_t nthreads, fb_params prm, uint32_t nproofs, uint32_t n_gen_terms, const uint32_t *gen_scalars, fb_digit *digits, uint32_t *status);
 __global__ void k_fb_accum(fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit, uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial);
+__global__ void k_fb_recode_ct(uint32_t nthreads, fb_params prm, uint32_t nproofs, uint32_t n_gen_terms, const uint32_t *gen_scalars, fb_digit *digits);
+__global__ void k_fb_accum_ct(fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit, uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial);
 __global__ void k_fb_reduce(uint32_t nthreads, uint32_t nproofs, uint32_t nsplit, uint32_t group, const ge_ext *partial, ge_ext *out);
 __global__ void k_shared_finish(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, int have_unique, const ge_ext *partial, const uint32_t *status, uint32_t *out_words, uint8_t *verdict);
 template <bool WITH_OUT>

@@ -211,6 +211,81 @@ BP_HD void fb_accum_thread(uint32_t p, uint32_t split, uint32_t q0, uint32_t q1,
     partial[(uint64_t)split * nproofs + p] = acc;
 }
 
+// ---- constant-time variant (the prover's secret-dependent commitments) -----------------------------------------------
+// The reference computes V, A, S, T_1, T_2 with curve25519-dalek's constant-time multiscalar_mul (party.rs:99-124, 179-187,
+// generators.rs:39-41).  The variable-time walk above leaks a secret scalar's digits through table addresses and through the
+// skipped additions of zero digits.  This path, selected by the context option "prover_constant_time", uses a small-window
+// table (W = 4: 8 entries per (generator, window)) and for every (generator, window) pair
+//   * reads ALL 8 entries -- the addresses depend on (generator, window) only, never on the digit;
+//   * picks the wanted one with arithmetic masks, the neutral Niels element (1, 1, 0) for digit 0, sign applied by selects;
+//   * always performs the same complete mixed addition.
+// Instruction stream and memory requests are therefore the same for every scalar (checked with SQ counters for two different
+// secret sets: tools/ct_counters.sh, tests/test_gpu_prover_ct.py); results are bit-identical to the variable-time path.
+#define BP_FB_CT_W 4
+// branch-free fb_recode: adds the (public) constant sum_win half << (W win) with a full carry chain
+BP_HD void fb_recode_ct(fb_digit *digits /*stride*/, uint64_t stride, const uint32_t s[8], fb_params prm) {
+    uint32_t k[10];
+#pragma unroll
+    for (int i = 0; i < 10; i++) k[i] = 0;
+    for (uint32_t win = 0; win < prm.nwin; win++) {   // public: depends on W only
+        const uint32_t bit = win * prm.W + (prm.W - 1);
+        if ((bit >> 5) < 10) k[bit >> 5] |= 1u << (bit & 31);
+    }
+    uint32_t r[10], carry = 0;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        const uint64_t t = (uint64_t)(i < 8 ? s[i] : 0u) + k[i] + carry;
+        r[i] = (uint32_t)t;
+        carry = (uint32_t)(t >> 32);
+    }
+    for (uint32_t win = 0; win < prm.nwin; win++) {
+        const uint32_t bit = win * prm.W, idx = bit >> 5, sh = bit & 31;
+        const uint64_t two = (uint64_t)r[idx] | ((uint64_t)(idx + 1 < 10 ? r[idx + 1] : 0u) << 32);
+        digits[(uint64_t)win * stride] = (fb_digit)((two >> sh) & ((1u << prm.W) - 1u));
+    }
+}
+BP_HD void fb_recode_ct_thread(uint32_t tid, fb_params prm, uint32_t nproofs, uint32_t n_gen_terms, const uint32_t *gen_scalars, fb_digit *digits) {
+    const uint32_t g = tid / nproofs, p = tid % nproofs;
+    uint32_t s[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) s[i] = gen_scalars[((uint64_t)p * n_gen_terms + g) * 8 + i];
+    fb_recode_ct(digits + ((uint64_t)g * prm.nwin) * nproofs + p, nproofs, s, prm);   // (the prover's scalars are canonical by construction)
+}
+// thread (split, p), prm.half == 8
+BP_HD void fb_accum_ct_thread(uint32_t p, uint32_t split, uint32_t q0, uint32_t q1, fb_params prm, uint32_t nproofs, const uint32_t *gen_ids,
+                              const fb_digit *digits, const fb_entry *table, ge_ext *partial) {
+    ge_ext acc;
+    ge_identity(acc);
+    for (uint32_t q = q0; q < q1; q++) {
+        const uint32_t g = q / prm.nwin, win = q - g * prm.nwin;
+        const uint32_t *sub = (const uint32_t *)(table + ((uint64_t)gen_ids[g] * prm.nwin + win) * 8);   // 8 entries of 32 words, same address in every lane
+        const int d = (int)(digits[(uint64_t)q * nproofs + p] & 15u) - 8;
+        const int sgn = d >> 31;                          // all ones for a negative digit
+        const uint32_t a = (uint32_t)((d ^ sgn) - sgn);   // |d| in 0..8
+        uint32_t sel[30];
+#pragma unroll
+        for (int i = 0; i < 30; i++) sel[i] = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < 8; k++) {
+            const uint32_t m = 0u - (uint32_t)(a == k + 1);
+#pragma unroll
+            for (int i = 0; i < 30; i++) sel[i] |= sub[32 * k + i] & m;
+        }
+        const uint32_t m0 = 0u - (uint32_t)(a == 0);      // digit 0: the neutral element (y + x, y - x, 2dxy) = (1, 1, 0)
+        sel[0] |= 1u & m0;
+        sel[10] |= 1u & m0;
+        ge_niels n;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            n.ypx.v[i] = sel[i];
+            n.ymx.v[i] = sel[10 + i];
+            n.t2d.v[i] = sel[20 + i];
+        }
+        ge_madd(acc, acc, n, sgn != 0);                   // sign by per-limb selects inside (ge25519.h)
+    }
+    partial[(uint64_t)split * nproofs + p] = acc;
+}
+
 // ---- partial reduction -------------------------------------------------------------------
 // thread tid = g * nproofs + p: out[g][p] = sum_{r < group} partial[g*group + r][p]  (r bounded by nsplit)
 BP_HD void fb_reduce_thread(uint32_t tid, uint32_t nproofs, uint32_t nsplit, uint32_t group, const ge_ext *partial, ge_ext *out) {

@@ -13,9 +13,10 @@
 //     for each party j: a_blinding, s_blinding, s_L[0..n), s_R[0..n)   (party.rs:94-97, 119-121), then
 //     for each party j: t_1_blinding, t_2_blinding                     (party.rs:174-175),   64 bytes each (Scalar::random).
 //
-// VARIABLE TIME in the secrets (values, blindings, s_L, s_R): table lookups are indexed by their digits.  The
-// reference computes A and S with its constant-time multiscalar_mul (party.rs:99-124); this engine has no
-// constant-time path, so this entry point is for provers whose GPU is not observable by an adversary.
+// Timing: by default the table lookups are indexed by the digits of the secrets (values, blindings, s_L, s_R).  The reference
+// computes V, A, S, T_1, T_2 with its constant-time multiscalar_mul (party.rs:99-124, 179-187); the context option
+// "prover_constant_time" routes exactly those MSMs through fb_accum_ct_thread (msm_fixed.h): digit-independent addresses and
+// instruction stream, byte-identical results.
 #ifndef BPGPU_RP_PROVER_H
 #define BPGPU_RP_PROVER_H
 #include "ipp_prover.h"

@@ -83,6 +83,8 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
  *                           path, 1 forces it).  Results are bit-identical either way.
  *   "host_sync_blocking"    1: host-pointer entry points wait for their results on a blocking event (the calling
  *                           thread sleeps: right for many host threads, one context each); 0 (default): spin-wait
+ *   "prover_constant_time"  1: the prover's secret-dependent commitments through the constant-time walk (bpgpu_rangeproof_prove_batch)
+ *   "transcript_script"     0: byte-wise transcript replay instead of the per-shape script (csrc/rp_script.h; for A/B only)
  *   "horner_lanes"          lanes per Horner chain of the proof-specific terms in the range-proof path:
  *                           4 (16 chains per wavefront: least total work, best with several batches in flight),
  *                           64 (one wavefront per chain: lowest latency of a single small batch), 0 = auto (4)
@@ -365,9 +367,13 @@ int bpgpu_ipp_create_batch(bpgpu_ctx *ctx, size_t n, size_t nbatch, const uint8_
  *   transcripts_out : optional nbatch x 208 bytes: each proof's transcript as the prover leaves it
  * Returns BPGPU_ERR_INVALID_ARG for the reference's InvalidBitsize / InvalidAggregation (m not a power of two) / a value
  * that does not fit n bits, BPGPU_ERR_NO_GENS for InvalidGeneratorsLength.
- * VARIABLE TIME in the secrets (values, blindings, s_L, s_R): the reference computes A and S with its constant-time
- * multiscalar_mul (party.rs:99-124); this engine has no constant-time path.  For provers whose GPU an adversary
- * cannot observe.
+ * Timing: by default VARIABLE TIME in the secrets (values, blindings, s_L, s_R) -- the window-table walk is indexed by their
+ * digits; for provers whose GPU an adversary cannot observe.  With the context option "prover_constant_time" = 1 the
+ * secret-dependent commitments V_j, A, S, T_1, T_2 -- the ones the reference computes with its constant-time
+ * multiscalar_mul (party.rs:99-124, 179-187; generators.rs:39-41) -- take a small-window table walk whose addresses and
+ * instruction stream do not depend on the scalars (every (generator, window) pair reads all 8 table entries, selects by masks,
+ * always adds; csrc/msm_fixed.h).  Proofs are byte-identical either way.  The inner-product rounds stay variable-time, as in the
+ * reference (vartime_multiscalar_mul at ipp.rs:87-178).  Cost: ~2x the prover's time at (64, 1).
  * Secrets at rest: like the reference's parties (zeroize on Drop, party.rs:148-260), every prover entry point
  * (bpgpu_rangeproof_prove_batch, bpgpu_ipp_create_batch, bpgpu_linear_create_batch) clears what it staged before it returns,
  * on success and on every error path: the context's device IO buffer, the provers' working sets and the MSM arena (window
