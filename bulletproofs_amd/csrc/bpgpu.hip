@@ -50,7 +50,8 @@ struct bpgpu_ctx {
     size_t arena_cap = 0, arena_off = 0;
     // options
     uint32_t W = 0;                          // fixed-base window bits; 0 = largest that fits table_budget
-    uint64_t table_budget = 96ull << 30;     // bytes of HBM the generator tables may take (a third of the MI355X's 288 GB)
+    uint64_t table_budget = 160ull << 30;    // bytes of HBM the generator tables may take: 160 GiB of the MI355X's 288 GB (W = 20 / 16 / 15 for m = 1 / 16 / 32:
+                                             // +3 / +5 / +8 % over the 96 GiB of rounds 1-2, profiles/r03/window_sweep.txt); halved automatically when the allocation fails
     uint32_t splits = 0;
     uint32_t splits_hint = 0;                // per-call suggestion of the pool (pick_splits), used when `splits` is 0
     uint32_t horner_lanes = 0;               // lanes per Horner chain in the range-proof path: 4, 64, 0 = auto (4)

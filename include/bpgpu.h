@@ -75,7 +75,8 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
 /* Tunables (set before bpgpu_gens_*):
  *   "fixed_window_bits"     window W of the generator tables, 2..20; 0 (default) = the W with the fewest windows whose
  *                           table (n_gens * ceil(255/W) * 2^(W-1) * 128 bytes) fits fixed_table_max_bytes
- *   "fixed_table_max_bytes" HBM budget of the tables (default 96 GiB; the MI355X has 288 GB)
+ *   "fixed_table_max_bytes" HBM budget of the tables (default 160 GiB of the MI355X's 288 GB; a context settles for a
+ *                           smaller window when the allocation fails)
  *   "fixed_splits"          workgroups the generator terms of one proof block are split over (0 = auto)
  *   "bucket_min_terms"      variable-base terms per MSM from which the bucket (Pippenger) path is taken instead of the
  *                           table-lookup one (default 1536; the batch-combined check, one MSM over all proofs' terms,

@@ -68,6 +68,10 @@ class _FakeRunner:
     """stands in for bench.py's runner: a region 'takes' a rank-dependent time and ends in one collective, as the real one does"""
     def __init__(self, rank, world):
         self.nstreams, self.ctxs, self.d_verdicts, self.rank, self.world, self.regions = 4, [_FakeCtx()], [0], rank, world, 0
+        self.pool = None
+
+    def profile_reset(self):
+        pass
 
     def step(self, k, row):
         pass
