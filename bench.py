@@ -311,6 +311,8 @@ def timed(b, K, warmup, fence, repeat, gather=None, events_all=False, no_events=
     # short runs sample every 4th stream: with the >= 4 repeated regions that still gives launches >= steps
     sparse = (K >= 8 * b.nstreams) and not events_all
     every = 1 if events_all else max(1, min(32, b.nstreams // 4)) if sparse else max(1, min(4, b.nstreams // 4))
+    if b.pool is not None and not events_all and not sparse:
+        every = max(every, 8)      # a burst through the pool is ~5 chains on lanes 0..4: events on one of them (lane 0) per region
     b.set_profile(not no_events, every)
     regs, enq, allv = [], [], None
     dt, te, allv = b.region(K, fence, gather)

@@ -308,7 +308,9 @@ class LinearProof:
     def verify(self, transcript, C, G, F, B, b_vec, ctx):
         """LinearProof::verify(&self, transcript, C, G, F, B, b_vec) (linear_proof.rs:175-236): Ok(()) -> None, Err(e) -> raises e.
         C, F, B and the entries of G are 32-byte compressed points, b_vec 32-byte canonical scalars; ctx: the Context (or a
-        BulletproofGens) whose device runs the check.  The transcript is left advanced as the reference leaves it."""
+        BulletproofGens) whose device runs the check.  The transcript is left advanced as the reference leaves it when the proof
+        is accepted; after an Err its state is unspecified (upstream has absorbed part of the public inputs at that point, this
+        engine returns the state right after innerproduct_domain_sep(n) -- INTEGRATION.md 3c)."""
         c = getattr(ctx, "ctx", ctx)
         if len(G) != len(b_vec):
             raise InvalidGeneratorsLength()

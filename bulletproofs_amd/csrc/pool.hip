@@ -78,7 +78,7 @@ struct bpgpu_pool {
     std::vector<pool_dev *> devs;
     std::mutex mu;        // serialises the pool's own state (pending lists, options); lane contexts have their own locks
     std::string err;
-    size_t coalesce_proofs = 4096;   // target width of a coalesced launch chain
+    size_t coalesce_proofs = 5120;   // target width of a coalesced launch chain (20 x 1024 from idle: 4096 -> 5.15, 5120 -> 5.5, 6912 -> 5.3, 10240 -> 5.2 M/s)
     size_t max_chain_proofs = 16384; // never wider than this (arena of a lane: ~55 KB per proof)
     size_t slice_proofs = 0;         // host-pointer calls: proofs per slice (0 = automatic)
     size_t auto_flush_items = 0;     // flush by itself once this many items wait on a device (0 = lanes)
@@ -278,7 +278,8 @@ int bpgpu_pool_gens_load(bpgpu_pool *p, size_t gens_capacity, size_t party_capac
 // ---- host pointers, synchronous ---------------------------------------------------------------------------------
 static void ensure_workers(bpgpu_pool *p, pool_dev *d) {
     if (!d->workers.empty()) return;
-    size_t w = p->host_workers ? p->host_workers : 12;
+    // (each worker spin-waits on its stream while its chain runs: more workers than cores to spare made calls bimodal, 3.8 / 9 ms)
+    size_t w = p->host_workers ? p->host_workers : 8;
     if (w > d->lanes.size()) w = d->lanes.size();
     d->tasks.resize(w);
     for (size_t i = 0; i < w; i++) {
@@ -312,12 +313,15 @@ int bpgpu_pool_rangeproof_verify(bpgpu_pool *p, size_t n, size_t m, size_t nbatc
         const size_t lo = nbatch * di / ndev, hi = nbatch * (di + 1) / ndev;
         if (hi == lo) continue;
         size_t S = p->slice_proofs;
-        if (!S) {   // whole rounds over the workers, slices of 1024 .. 2048 proofs
-            const size_t W = d->workers.size(), T = hi - lo;
-            const size_t rounds = (T + 2048 * W - 1) / (2048 * W);
-            S = (T + rounds * W - 1) / (rounds * W);
+        if (!S) {
+            // wide slices: a launch chain costs ~1 ms of latency however narrow it is, so few chains of up to 4096 proofs beat many
+            // narrow ones (measured, 16384 proofs: slices of 512 / 1024 / 2048 / 4096 -> 2.2 / 3.6 / 4.5 / 4.7 M/s); a small call is
+            // still cut in two so that the second slice's staging copy overlaps the first one's chain
+            const size_t T = hi - lo;
+            S = (T + 1) / 2;
             S = (S + 63) & ~(size_t)63;
-            if (S < 1024) S = 1024;
+            if (S < 2048) S = 2048;
+            if (S > 4096) S = 4096;
         }
         size_t slice_no = 0;
         for (size_t a = lo; a < hi; a += S) {

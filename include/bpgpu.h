@@ -414,7 +414,7 @@ int bpgpu_ipp_verification_scalars(bpgpu_ctx *ctx, size_t n, size_t nbatch, cons
  *   - bpgpu_pool_rangeproof_submit_dev (DEVICE pointers on device `dev_index` of the pool, asynchronous): the batch is
  *     queued; bpgpu_pool_flush -- or the pool itself once "auto_flush_items" batches wait (default: one per lane) --
  *     packs consecutive queued batches of one shape (n, m, proof_len, label) into coalesced launch chains of about
- *     "coalesce_proofs" proofs (default 4096) and issues them on the lanes round-robin.  A burst of small batches is
+ *     "coalesce_proofs" proofs (default 5120) and issues them on the lanes round-robin.  A burst of small batches is
  *     thereby served as a few wide chains instead of many narrow ones (20 x 1024 proofs from an idle device: 4.2 -> 5.3 M
  *     verifications/s); every batch still gets its own verdict (and msm_out) buffer filled.  Input buffers must be complete
  *     on the device when the batch is submitted and stay valid until bpgpu_pool_wait returns (the pool's streams are not
@@ -425,8 +425,8 @@ int bpgpu_ipp_verification_scalars(bpgpu_ctx *ctx, size_t n, size_t nbatch, cons
  * is loaded if the variable is unset (the ROCm runtime reads it at the process's first HIP call); bpgpu_pool_create
  * returns BPGPU_ERR_HW_QUEUES when it finds another value.
  * Options (bpgpu_pool_set_option): "coalesce_proofs", "max_chain_proofs" (default 16384), "auto_flush_items",
- * "slice_proofs" (host-pointer calls; 0 = automatic: one round of slices over the workers, 1024..4096 proofs each),
- * "host_workers" (threads per device for host-pointer calls, default 12, at most the lanes); any other key is forwarded
+ * "slice_proofs" (host-pointer calls; 0 = automatic: 2048..4096 proofs per slice),
+ * "host_workers" (threads per device for host-pointer calls, default 8, at most the lanes); any other key is forwarded
  * to every lane context (set those before bpgpu_pool_gens_*).  Read-only statistics of the coalesced path:
  * "stat_chains", "stat_chain_proofs" (launch chains issued and the proofs they carried; set "stat_reset" to zero them),
  * "stat_last_splits". */

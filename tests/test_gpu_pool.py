@@ -174,3 +174,19 @@ def test_pool_burst_of_20_batches_coalesced_equals_per_batch_path(oracle, cfg2):
         assert bytes(d_v[k].cpu().numpy()) == ev
     ctx.close()
     pool.close()
+
+
+@pytest.mark.parametrize("ndev", [1, 2])
+def test_plain_c_client_of_the_pool(tmp_path, ndev):
+    """tests/cpp/pool_client.c, compiled with gcc against include/bpgpu.h only: one bpgpu_pool_rangeproof_verify call for 6000
+    proofs of the cfg2 fixture on one / two shards, library-drawn randomness; the rejected indices are exactly the planted ones."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = tmp_path / "pool_client"
+    libdir = os.path.join(root, "bulletproofs_amd", "csrc")
+    subprocess.check_call(["gcc", "-std=c11", "-O1", "-Wall", "-Werror", "-I", os.path.join(root, "include"), os.path.join(root, "tests", "cpp", "pool_client.c"),
+                           "-o", str(exe), "-L", libdir, "-lbpgpu", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib"])
+    out = subprocess.run([str(exe), os.path.join(root, "bench_data", "cfg2_n64_m1.bin"), str(ndev), "6000", "487"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr
+    planted = [i for i in range(6000) if i % 487 == 486]
+    assert out.stdout.strip() == "rejected %d of 6000:" % len(planted) + "".join(" %d=1" % i for i in planted)

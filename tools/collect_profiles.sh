@@ -28,6 +28,11 @@ stats bench_streams1 $B --direct --streams 1 --steps 256 --warmup 16
 stats bench_cfg3 $B --config cfg3 --steps 640 --warmup 64
 stats bench_cfg5 python $REPO/bench.py --cfg5-only 8
 
+# the library's scheduler: burst / steady / one-call rates; the constant-time prover's counters
+python $REPO/tools/pool_rate.py burst steady host > $OUT/pool_rate.txt 2>&1
+bash $REPO/tools/ct_counters.sh > $OUT/prover_constant_time_counters.txt 2>&1
+$REPO/tools/microbench_gather > $OUT/microbench_gather.txt 2>&1
+
 for cfg in cfg2 cfg3 cfg4; do
   A="$B --direct --config $cfg --steps 8 --warmup 2 --streams 1"
   pmc ${cfg}_fetch FETCH_SIZE $A
