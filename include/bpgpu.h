@@ -407,8 +407,8 @@ int bpgpu_ipp_verification_scalars(bpgpu_ctx *ctx, size_t n, size_t nbatch, cons
  * devices (the generator tables are built once per device and shared by its lanes) and does the scheduling that the
  * benchmark used to do by hand:
  *   - bpgpu_pool_rangeproof_verify (HOST pointers, synchronous, any nbatch): proofs are independent units, so device d
- *     takes the contiguous shard [nbatch d / ndev, nbatch (d+1) / ndev); a shard is cut into slices that host worker
- *     threads of the pool stage, enqueue and collect on their lanes; every slice's verdicts land at its offset of the
+ *     takes the contiguous shard [nbatch d / ndev, nbatch (d+1) / ndev); a shard is cut into slices that a few host worker
+ *     threads of the pool stage, enqueue and collect on their lanes (asynchronously: one thread keeps several chains in flight); every slice's verdicts land at its offset of the
  *     caller's buffer -- the "final gather" of SURVEY 8e is that host-side placement, no collective is involved.
  *     Verdicts are exactly those of bpgpu_rangeproof_verify_batch on the whole batch.
  *   - bpgpu_pool_rangeproof_submit_dev (DEVICE pointers on device `dev_index` of the pool, asynchronous): the batch is
@@ -426,7 +426,7 @@ int bpgpu_ipp_verification_scalars(bpgpu_ctx *ctx, size_t n, size_t nbatch, cons
  * returns BPGPU_ERR_HW_QUEUES when it finds another value.
  * Options (bpgpu_pool_set_option): "coalesce_proofs", "max_chain_proofs" (default 16384), "auto_flush_items",
  * "slice_proofs" (host-pointer calls; 0 = automatic: 2048..4096 proofs per slice),
- * "host_workers" (threads per device for host-pointer calls, default 8, at most the lanes); any other key is forwarded
+ * "host_workers" (threads per device for host-pointer calls, default 2; each drives its share of the lanes asynchronously); any other key is forwarded
  * to every lane context (set those before bpgpu_pool_gens_*).  Read-only statistics of the coalesced path:
  * "stat_chains", "stat_chain_proofs" (launch chains issued and the proofs they carried; set "stat_reset" to zero them),
  * "stat_last_splits". */
