@@ -53,6 +53,7 @@ void oracle_sha3_512(const uint8_t *in, size_t n, uint8_t out[64]);
  * algo: 0 = reference split (Straus < 190 <= Pippenger), 1 = Straus, 2 = Pippenger. */
 int oracle_msm(size_t n, const uint8_t *scalars, const uint8_t *points, int algo, uint8_t out[32]);
 uint64_t oracle_last_msm_ops(void);
+const char *oracle_backend(void);   /* "u64 5x51 serial", or the SIMD backend a -march=native build selected */
 
 /* verify_multiple_with_rng (src/range_proof/mod.rs:345-452).
  * rng64: the 64 bytes the rng would yield to Scalar::random for the batching

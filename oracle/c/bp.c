@@ -102,6 +102,7 @@ void oracle_sha3_512(const uint8_t *in, size_t n, uint8_t out[64]) { sha3_512(ou
 
 static __thread uint64_t last_msm_ops = 0;
 uint64_t oracle_last_msm_ops(void) { return last_msm_ops; }
+const char *oracle_backend(void) { return ge_backend(); }
 
 static void msm_dispatch(ge_p3 *r, size_t n, const sc *s, const ge_p3 *p, int algo) {
     if (algo == 1) ge_msm_straus(r, n, s, p);
@@ -365,14 +366,23 @@ static int verify_tail(const oracle_gens *g, sc *s, uint8_t *p, size_t N, size_t
     ge_p3 *pts = malloc(N * sizeof(ge_p3));
     int bad = 0;
     size_t gen0 = 4 + 2 * lg_n, nm = n * m;
-    for (size_t i = 0; i < N && !bad; i++) {
-        /* generator terms: use the cached decoded points (generators.rs holds them decoded) */
+    /* the proof's own points (A, S, T_1, T_2, L_i, R_i, V_j) are decoded (mod.rs:433-443), in one batch; generator terms use the
+     * cached decoded points (generators.rs holds them decoded) */
+    const uint8_t **enc = malloc(N * sizeof *enc); size_t *where = malloc(N * sizeof *where); size_t nd = 0;
+    for (size_t i = 0; i < N; i++) {
         if (i == gen0) pts[i] = g->B_blinding;
         else if (i == gen0 + 1) pts[i] = g->B;
         else if (i >= gen0 + 2 && i < gen0 + 2 + nm) { size_t q = i - gen0 - 2; pts[i] = g->G[(q / n) * g->gens_capacity + q % n]; }
         else if (i >= gen0 + 2 + nm && i < gen0 + 2 + 2 * nm) { size_t q = i - gen0 - 2 - nm; pts[i] = g->H[(q / n) * g->gens_capacity + q % n]; }
-        else if (ristretto_decompress(&pts[i], p + 32 * i) != 0) bad = 1;
+        else { enc[nd] = p + 32 * i; where[nd++] = i; }
     }
+    {
+        ge_p3 *dec = malloc((nd ? nd : 1) * sizeof(ge_p3)); int *drc = malloc((nd ? nd : 1) * sizeof(int));
+        ristretto_decompress_many(dec, enc, drc, nd);
+        for (size_t k = 0; k < nd; k++) { if (drc[k] != 0) bad = 1; pts[where[k]] = dec[k]; }
+        free(dec); free(drc);
+    }
+    free(enc); free(where);
     if (bad) { free(s); free(p); free(pts); if (msm_out) memset(msm_out, 0xff, 32); return ORACLE_ERR_VERIFICATION; }
     ge_p3 r; msm_dispatch(&r, N, s, pts, 0);
     if (msm_out) ristretto_compress(msm_out, &r);

@@ -1,6 +1,7 @@
 /* ORACLE -- TEST INFRASTRUCTURE ONLY. See ge.h. */
 #include "ge.h"
 #include <stdlib.h>
+#include "ifma4.h"   /* 4-way IFMA backend of the Straus MSM, compiled in when the target CPU has it (bench.py's -march=native build) */
 
 static const uint8_t K_D[32] = {0xa3, 0x78, 0x59, 0x13, 0xca, 0x4d, 0xeb, 0x75, 0xab, 0xd8, 0x41, 0x41, 0x4d, 0x0a, 0x70, 0x00, 0x98, 0xe8, 0x79, 0x77, 0x79, 0x40, 0xc7, 0x8c, 0x73, 0xfe, 0x6f, 0x2b, 0xee, 0x6c, 0x03, 0x52};
 static const uint8_t K_D2[32] = {0x59, 0xf1, 0xb2, 0x26, 0x94, 0x9b, 0xd6, 0xeb, 0x56, 0xb1, 0x83, 0x82, 0x9a, 0x14, 0xe0, 0x00, 0x30, 0xd1, 0xf3, 0xee, 0xf2, 0x80, 0x8e, 0x19, 0xe7, 0xfc, 0xdf, 0x56, 0xdc, 0xd9, 0x06, 0x24};
@@ -142,6 +143,97 @@ int ristretto_decompress(ge_p3 *r, const uint8_t in[32]) {
     return 0;
 }
 
+/* n decodings; rc[i] as ristretto_decompress.  On IFMA builds four at a time: the prelude and the (p-5)/8 exponentiation of the
+ * inverse square root -- 254 of a decoding's ~280 field multiplications -- run 4-way (one point per lane), the short tail per
+ * point on the scalar backend.  Same results as n calls of ristretto_decompress. */
+#ifdef ORACLE_IFMA
+static fe4 fe4_pow22523(fe4 z) {
+    fe4 t0, t1, t2, z11;
+    t0 = fe4_sq(z);
+    t1 = fe4_sq(fe4_sq(t0));
+    t1 = fe4_mul(z, t1);
+    t0 = fe4_mul(t0, t1);
+    z11 = t0; (void)z11;
+    t0 = fe4_sq(t0);
+    t0 = fe4_mul(t1, t0);
+    t1 = t0; for (int i = 0; i < 5; i++) t1 = fe4_sq(t1);
+    t0 = fe4_mul(t1, t0);
+    t1 = t0; for (int i = 0; i < 10; i++) t1 = fe4_sq(t1);
+    t1 = fe4_mul(t1, t0);
+    t2 = t1; for (int i = 0; i < 20; i++) t2 = fe4_sq(t2);
+    t1 = fe4_mul(t2, t1);
+    for (int i = 0; i < 10; i++) t1 = fe4_sq(t1);
+    t0 = fe4_mul(t1, t0);
+    t1 = t0; for (int i = 0; i < 50; i++) t1 = fe4_sq(t1);
+    t1 = fe4_mul(t1, t0);
+    t2 = t1; for (int i = 0; i < 100; i++) t2 = fe4_sq(t2);
+    t1 = fe4_mul(t2, t1);
+    for (int i = 0; i < 50; i++) t1 = fe4_sq(t1);
+    t0 = fe4_mul(t1, t0);                       /* 2^250 - 1 */
+    t0 = fe4_sq(fe4_sq(t0));
+    return fe4_mul(t0, z);                      /* 2^252 - 3 */
+}
+static void decompress4(ge_p3 r[4], const uint8_t *in[4], int rc[4]) {
+    fe s[4], one;
+    fe_1(&one);
+    for (int j = 0; j < 4; j++) {
+        uint8_t chk[32];
+        rc[j] = 0;
+        fe_frombytes(&s[j], in[j]); fe_tobytes(chk, &s[j]);
+        if (memcmp(chk, in[j], 32) != 0 || (in[j][0] & 1)) { rc[j] = -1; fe_0(&s[j]); }   /* non-canonical / negative: lane runs on 0 */
+    }
+    const fe4 S = fe4_pack(&s[0], &s[1], &s[2], &s[3]), ONE = fe4_pack(&one, &one, &one, &one), D4 = fe4_pack(&C_D, &C_D, &C_D, &C_D);
+    const fe4 SS = fe4_sq(S);
+    const fe4 U1 = fe4_reduce(fe4_add(ONE, fe4_neg(SS))), U2 = fe4_reduce(fe4_add(ONE, SS));
+    const fe4 U2S = fe4_sq(U2);
+    const fe4 TD = fe4_mul(fe4_sq(U1), D4);
+    const fe4 V = fe4_reduce(fe4_add(fe4_neg(TD), fe4_neg(U2S)));                    /* -d u1^2 - u2^2 */
+    const fe4 W = fe4_mul(V, U2S);
+    /* sqrt_ratio_i(1, W) up to the candidate root and its check */
+    const fe4 W3 = fe4_mul(fe4_sq(W), W), W7 = fe4_mul(fe4_sq(W3), W);
+    const fe4 R = fe4_mul(fe4_pow22523(W7), W3);
+    const fe4 CHK = fe4_mul(fe4_sq(R), W);
+    fe rr[4], chk[4], u1[4], u2[4], v[4];
+    fe4_unpack(&rr[0], &rr[1], &rr[2], &rr[3], &R);
+    fe4_unpack(&chk[0], &chk[1], &chk[2], &chk[3], &CHK);
+    fe4_unpack(&u1[0], &u1[1], &u1[2], &u1[3], &U1);
+    fe4_unpack(&u2[0], &u2[1], &u2[2], &u2[3], &U2);
+    fe4_unpack(&v[0], &v[1], &v[2], &v[3], &V);
+    fe neg_one, neg_i;
+    fe_neg(&neg_one, &one); fe_mul(&neg_i, &neg_one, &C_SQRT_M1);
+    for (int j = 0; j < 4; j++) {
+        fe I = rr[j], Dx, Dy, t;
+        fe_carry(&I); fe_carry(&chk[j]); fe_carry(&u1[j]); fe_carry(&u2[j]); fe_carry(&v[j]);
+        const int correct = fe_eq(&chk[j], &one), flipped = fe_eq(&chk[j], &neg_one), flipped_i = fe_eq(&chk[j], &neg_i);
+        if (flipped || flipped_i) fe_mul(&I, &I, &C_SQRT_M1);
+        fe_abs(&I);
+        const int ok = correct || flipped;
+        fe_mul(&Dx, &I, &u2[j]);
+        fe_mul(&Dy, &I, &Dx); fe_mul(&Dy, &Dy, &v[j]);
+        fe_add(&t, &s[j], &s[j]); fe_mul(&r[j].X, &t, &Dx); fe_abs(&r[j].X);
+        fe_mul(&r[j].Y, &u1[j], &Dy);
+        fe_1(&r[j].Z);
+        fe_mul(&r[j].T, &r[j].X, &r[j].Y);
+        if (!ok || fe_isneg(&r[j].T) || fe_iszero(&r[j].Y)) rc[j] = -1;
+    }
+}
+#endif
+void ristretto_decompress_many(ge_p3 *r, const uint8_t *const *in, int *rc, size_t n) {
+    ge_init();
+    size_t i = 0;
+#ifdef ORACLE_IFMA
+    for (; i + 4 <= n; i += 4) decompress4(r + i, (const uint8_t **)(in + i), rc + i);
+    if (i < n) {   /* ragged tail: pad with the last input */
+        ge_p3 t[4]; const uint8_t *pin[4]; int prc[4];
+        for (size_t j = 0; j < 4; j++) pin[j] = in[i + j < n ? i + j : n - 1];
+        decompress4(t, pin, prc);
+        for (size_t j = 0; i + j < n; j++) { r[i + j] = t[j]; rc[i + j] = prc[j]; }
+        i = n;
+    }
+#endif
+    for (; i < n; i++) rc[i] = ristretto_decompress(&r[i], in[i]);
+}
+
 void ristretto_compress(uint8_t out[32], const ge_p3 *p) {
     ge_init();
     fe u1, u2, t, I, i1, i2, zinv, den, X, Y, a, b;
@@ -213,6 +305,39 @@ static void sc_naf5(int8_t naf[257], const sc *s) {
     if (carry) naf[256] = 1;
 }
 
+#ifdef ORACLE_IFMA
+const char *ge_backend(void) { return "avx512-ifma 4-way (parallel formulas) for the Straus MSM, u64 5x51 elsewhere"; }
+/* the same Straus walk (width-5 NAF, 8 odd multiples per point) on the vector backend */
+void ge_msm_straus(ge_p3 *r, size_t n, const sc *scalars, const ge_p3 *points) {
+    ge_init();
+    ge4_init(&C_D2);
+    ge_op_counter = 0;
+    int8_t (*nafs)[257] = malloc(n * 257 + 1);
+    ge4_cached (*tab)[8] = aligned_alloc(32, (n ? n : 1) * sizeof(ge4_cached[8]));
+    for (size_t i = 0; i < n; i++) {
+        sc_naf5(nafs[i], &scalars[i]);
+        ge4 cur = ge4_from_p3(&points[i]);
+        ge4 p2 = ge4_dbl(&cur);
+        const ge4_cached c2 = ge4_to_cached(&p2);
+        tab[i][0] = ge4_to_cached(&cur);
+        for (int j = 1; j < 8; j++) { cur = ge4_add_cached(&cur, &c2, 0); tab[i][j] = ge4_to_cached(&cur); }
+    }
+    ge_p3 id; ge_identity(&id);
+    ge4 acc = ge4_from_p3(&id);
+    int started = 0;
+    for (int b = 256; b >= 0; b--) {
+        if (started) { acc = ge4_dbl(&acc); ge_op_counter++; }
+        for (size_t i = 0; i < n; i++) {
+            int d = nafs[i][b];
+            if (d > 0) { acc = ge4_add_cached(&acc, &tab[i][d >> 1], 0); started = 1; ge_op_counter++; }
+            else if (d < 0) { acc = ge4_add_cached(&acc, &tab[i][(-d) >> 1], 1); started = 1; ge_op_counter++; }
+        }
+    }
+    ge4_to_p3(r, &acc);
+    free(nafs); free(tab);
+}
+#else
+const char *ge_backend(void) { return "u64 5x51 serial"; }
 void ge_msm_straus(ge_p3 *r, size_t n, const sc *scalars, const ge_p3 *points) {
     ge_init();
     ge_op_counter = 0;
@@ -239,6 +364,7 @@ void ge_msm_straus(ge_p3 *r, size_t n, const sc *scalars, const ge_p3 *points) {
     *r = acc;
     free(nafs); free(tab);
 }
+#endif
 
 void ge_msm_pippenger(ge_p3 *r, size_t n, const sc *scalars, const ge_p3 *points) {
     ge_init();

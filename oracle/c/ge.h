@@ -37,6 +37,8 @@ extern const uint8_t RISTRETTO_BASEPOINT_COMPRESSED[32];
 /* sum s_i * P_i ; algorithm chosen like the reference's dependency */
 void ge_msm_vartime(ge_p3 *r, size_t n, const sc *scalars, const ge_p3 *points);
 void ge_msm_straus(ge_p3 *r, size_t n, const sc *scalars, const ge_p3 *points);
+const char *ge_backend(void);
+void ristretto_decompress_many(ge_p3 *r, const uint8_t *const *in, int *rc, size_t n);   /* n x ristretto_decompress (4-way on SIMD builds) */   /* which field backend this build's Straus MSM uses */
 void ge_msm_pippenger(ge_p3 *r, size_t n, const sc *scalars, const ge_p3 *points);
 /* number of point additions+doublings the last ge_msm_* call on this thread did */
 extern __thread uint64_t ge_op_counter;

@@ -80,6 +80,7 @@ def lib():
     L.oracle_prove_batch.argtypes = [vp, sz, C.POINTER(C.c_uint64), u8p, sz, sz, u8p, sz, u8p, sz, u8p, u8p, C.c_int]
     L.oracle_ipp_verify.argtypes = [sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.oracle_ipp_verification_scalars.argtypes = [sz, u8p, sz, u8p, u8p, u8p, u8p]
+    L.oracle_backend.restype = C.c_char_p
     L.oracle_ipp_test_instance.argtypes = [sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.oracle_ipp_create.argtypes = [sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
     L.oracle_prove_shares.argtypes = [vp, C.POINTER(C.c_uint64), u8p, sz, sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p]
@@ -90,6 +91,11 @@ def lib():
     L.oracle_msm_batch.argtypes = [sz, sz, u8p, u8p, C.c_int, u8p, u8p, C.c_int]
     _lib = L
     return L
+
+
+def backend():
+    """which field backend this build's Straus MSM / point decoding use ("u64 5x51 serial", or the SIMD one of a -march=native build)"""
+    return lib().oracle_backend().decode()
 
 
 def proof_len(n, m):

@@ -4,6 +4,7 @@ tests/golden/rangeproof_v1.json) and the known-answer values of SURVEY.md
 Appendix A / C."""
 import ctypes as C
 import hashlib
+import os
 
 import pytest
 
@@ -304,3 +305,63 @@ def test_ipp_verification_scalars_c_equals_twin(oracle):
     assert oracle.ipp_verification_scalars(8, pr, st0)[0] == 1
     assert oracle.ipp_verification_scalars(4, bytes(32) + pr[32:], st0)[0] == 1
     assert oracle.ipp_verification_scalars(4, pr[:-64] + b"\xff" * 32 + pr[-32:], st0)[0] == 2
+
+
+def test_vector_backend_equals_scalar_backend(oracle, golden):
+    """oracle/c/ifma4.h: the 4-way AVX-512 IFMA backend (Straus MSM with parallel point formulas, 4-way point decoding) that
+    bench.py's cpu_baseline gets from its -march=native rebuild, against the scalar u64 build the tests use: bit-identical MSM
+    encodings (edge scalars, 1..189 terms), identical verdicts / mega-check encodings on golden and tampered proofs.  On a CPU
+    without the instructions the native build IS the scalar one and the comparison is trivially true (reported in the name of
+    the backend)."""
+    import ctypes as C
+    import subprocess
+    here = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle")
+    so = os.path.join(here, "liboracle_native.so")
+    subprocess.check_call(["gcc", "-O3", "-march=native", "-fPIC", "-std=gnu11", "-w", "-shared", "-o", so] +
+                          [os.path.join(here, "c", f) for f in ("ge.c", "merlin.c", "bp.c")] + ["-lpthread"])
+    N = C.CDLL(so)
+    S = oracle.lib()
+    for L in (N, S):
+        L.oracle_backend.restype = C.c_char_p
+        L.oracle_msm.argtypes = [C.c_size_t, C.c_char_p, C.c_char_p, C.c_int, C.c_char_p]
+    assert S.oracle_backend() == b"u64 5x51 serial"
+    print("native backend:", N.oracle_backend().decode())
+    ell = 2**252 + 27742317777372353535851937790883648493
+
+    def pt(tag):
+        o = C.create_string_buffer(32)
+        S.oracle_from_uniform_bytes(hashlib.shake_256(tag).digest(64), o)
+        return o.raw
+    for n in (1, 2, 3, 4, 5, 17, 64, 147, 189):
+        pts = b"".join(pt(b"vp%d-%d" % (n, i)) for i in range(n))
+        sc = [int.from_bytes(hashlib.shake_256(b"vs%d-%d" % (n, i)).digest(64), "little") % ell for i in range(n)]
+        if n >= 4:
+            sc[0], sc[1], sc[2], sc[3] = 0, 1, ell - 1, 2**252
+        scb = b"".join(x.to_bytes(32, "little") for x in sc)
+        a, b = C.create_string_buffer(32), C.create_string_buffer(32)
+        assert S.oracle_msm(n, scb, pts, 1, a) == N.oracle_msm(n, scb, pts, 1, b) == 0
+        assert a.raw == b.raw, n
+    # an undecodable / non-canonical / negative encoding among the points: both report it
+    for bad in (b"\x01" + bytes(31), b"\xff" * 32, pt(b"x")[:31] + b"\xff"):
+        a, b = C.create_string_buffer(32), C.create_string_buffer(32)
+        pts = pt(b"g0") + pt(b"g1") + bad + pt(b"g2") + pt(b"g3")
+        assert S.oracle_msm(5, bytes(160), pts, 1, a) == N.oracle_msm(5, bytes(160), pts, 1, b) != 0
+    # whole verifications: golden proofs and tampered copies through both builds
+    N.oracle_gens_new.restype = C.c_void_p
+    N.oracle_gens_new.argtypes = [C.c_size_t, C.c_size_t]
+    N.oracle_verify.argtypes = [C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_size_t, C.c_char_p, C.c_size_t, C.c_char_p, C.c_char_p]
+    gn = N.oracle_gens_new(64, 8)
+    gs = oracle.Gens(64, 8)
+    label, vc = golden["label"], golden["vc_bytes"]
+    for case in golden["cases"]:
+        n, m = case["n"], case["m"]
+        pr = bytes.fromhex(case["proof"])
+        for k, mod in enumerate((None, (128, 1), (32, 1), (0, 0x80), (70, 4))):
+            q = bytearray(pr)
+            if mod:
+                q[mod[0]] ^= mod[1]
+            rng = hashlib.shake_256(b"vb%d%d%d" % (n, m, k)).digest(64)
+            rc_s, enc_s = oracle.verify(gs, bytes(q), vc[:32 * m], n, label, rng)
+            out = C.create_string_buffer(32)
+            rc_n = N.oracle_verify(gn, bytes(q), len(q), vc[:32 * m], m, n, label, len(label), rng, out)
+            assert rc_n == rc_s and out.raw == enc_s, (n, m, k)
