@@ -61,6 +61,7 @@ def parse_args():
     ap.add_argument("--coalesce", type=int, default=0,
                     help="pool option coalesce_proofs: width the pool packs consecutive submitted batches into (default: the library's, 4096; "
                          "--coalesce = batch size means one launch chain per step, the round-2 behaviour)")
+    ap.add_argument("--opt", default="", help="extra library options key=value[,key=value] (experiments, e.g. split_stage3=1)")
     ap.add_argument("--no-script", action="store_true", help="library option transcript_script = 0: byte-wise transcript replay (A/B of csrc/rp_script.h)")
     ap.add_argument("--direct", action="store_true",
                     help="bypass the pool: call bpgpu_rangeproof_verify_batch_dev on --streams (context, stream) pairs round-robin (the round-2 protocol, for A/B)")
@@ -173,6 +174,8 @@ class RangeProofBench:
             self.pool = bp.Pool((local_dev,), nstreams, fixed_window_bits=a.window_bits or None, horner_lanes=a.horner_lanes or None,
                                 fixed_splits=a.splits or None, fixed_table_max_bytes=a.table_bytes or None,
                                 bucket_min_terms=a.bucket_min or None, coalesce_proofs=a.coalesce or None, transcript_script=0 if a.no_script else None)
+            for kv in filter(None, a.opt.split(",")):
+                self.pool.set_option(kv.split("=")[0], int(kv.split("=")[1]))
             self.pool.gens_create(fx.n, fx.m)
         else:
             for _ in range(nstreams):

@@ -64,6 +64,8 @@ struct bpgpu_ctx {
     std::vector<uint8_t> h_gens;      // host copy of the encodings
     std::map<std::pair<size_t, size_t>, uint32_t *> gen_ids_cache;  // (n,m) -> device id list
     std::map<std::vector<uint32_t>, uint32_t *> script_cache;       // (n, m, k, pos, pos_begin, flags, domsep) -> transcript script (rp_script.h)
+    int split_stage1 = 0;                                           // experiment: point decoding as its own launch on the second stream, compiled for 1 / 2 / 3 wavefronts per SIMD
+    int split_stage3 = -1;                                          // window sums and generator exponents as two launches: 1 yes, 0 no, -1 auto (chains of >= 2048 proofs)
     bool no_script = false;                                         // option "transcript_script" = 0: byte-wise replay everywhere (A/B)
     // device-resident work decomposition of the uniform (nbatch, terms-per-MSM) variable-base plans
     struct plan_dev {
@@ -410,6 +412,15 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
     }
     if (!strcmp(key, "transcript_script")) {
         c->no_script = value == 0;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "split_stage1")) {
+        if (value < 0 || value > 3) return fail(c, BPGPU_ERR_INVALID_ARG, "split_stage1 must be 0..3");
+        c->split_stage1 = (int)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "split_stage3")) {
+        c->split_stage3 = value < 0 ? -1 : (value != 0);
         return BPGPU_OK;
     }
     if (!strcmp(key, "prover_constant_time")) {
@@ -1594,10 +1605,21 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     ge_cached *d_colc = quad ? (ge_cached *)d.colq16 : nullptr;
     const uint32_t n_tr = (nb32 + RP_BLOCK - 1) / RP_BLOCK;
     const uint32_t n_pt = shape_verdict ? 0 : (nb32 * sh.U + RP_BLOCK - 1) / RP_BLOCK;
-    LAUNCH(c, s, "rp_stage1", k_rp_stage1, n_tr + n_pt, RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
+    const bool split1 = c->split_stage1 && !shape_verdict && n_pt && s != c->stream2;
+    if (split1) {   // decode on the second stream, joined before launch 3 (which reads its tables)
+        HIPCHK(c, hipEventRecord(c->fork_ev, s));
+        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->fork_ev, 0));
+        fb_entry *bpts = rlc_bucket ? bd.pts : (fb_entry *)nullptr;
+        if (c->split_stage1 == 1) LAUNCH(c, c->stream2, "rp_points", k_rp_points<1>, n_pt, RP_BLOCK, sh, (const uint8_t *)d_proofs, (const uint8_t *)d_commitments, d.tab, d_status, bpts, segtab);
+        else if (c->split_stage1 == 2) LAUNCH(c, c->stream2, "rp_points", k_rp_points<2>, n_pt, RP_BLOCK, sh, (const uint8_t *)d_proofs, (const uint8_t *)d_commitments, d.tab, d_status, bpts, segtab);
+        else LAUNCH(c, c->stream2, "rp_points", k_rp_points<3>, n_pt, RP_BLOCK, sh, (const uint8_t *)d_proofs, (const uint8_t *)d_commitments, d.tab, d_status, bpts, segtab);
+        HIPCHK(c, hipEventRecord(c->join_ev, c->stream2));
+    }
+    LAUNCH(c, s, "rp_stage1", k_rp_stage1, n_tr + (split1 ? 0u : n_pt), RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
            (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits,
            rlc ? wts_ptr : (const uint8_t *)nullptr, ts_flags, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
            rlc_bucket ? bd.pts : (fb_entry *)nullptr, rlc_bucket ? bkp.c : 0u, segtab, d_script);
+    if (split1) HIPCHK(c, hipStreamWaitEvent(s, c->join_ev, 0));
     if (shape_verdict) {
         HIPCHK(c, hipMemsetAsync(d_mv, 1, nbatch, s));
         LAUNCH(c, s, "rp_verdict", k_rp_verdict, (nb32 + 63) / 64, 64, nb32, d_status, d_mv, (uint8_t *)d_verdict);
@@ -1676,8 +1698,18 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         return BPGPU_OK;
     }
     const bool one_chunk = pd->n_chunks == nbatch;   // U <= 32: a chunk's window sums are the MSM's column sums
-    LAUNCH(c, s, "rp_stage3", k_rp_stage3, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part,
-           (quad && one_chunk) ? d_colc : (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits, d_status);
+    // Launch 3 holds two independent roles.  Fused into one kernel they share its register allocation -- 252 VGPRs, set by the
+    // generator-exponent role, i.e. two wavefronts per SIMD also for the window sums, whose table gathers are not prefetched.
+    // As two launches the window sums get their own 128 (four wavefronts per SIMD): +1.5 ... +3 % on wide chains (same-box A/B,
+    // profiles/r03/ab_split_stage3.txt); a narrow chain keeps the fused form (one launch fewer on its latency path).
+    if (c->split_stage3 == 1 || (c->split_stage3 < 0 && nbatch >= 2048)) {
+        LAUNCH(c, s, "rp_stage3w", k_vb_window_colc, n_win, BP_BLOCK, nwin, d.chunks, d.tab, d.recoded, d.part, (quad && one_chunk) ? d_colc : (ge_cached *)nullptr);
+        LAUNCH(c, s, "rp_stage3", k_rp_stage3, n_exp, BP_BLOCK, 0u, 0u, d.chunks, d.tab, d.recoded, d.part, (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits,
+               d_status);
+    } else {
+        LAUNCH(c, s, "rp_stage3", k_rp_stage3, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part,
+               (quad && one_chunk) ? d_colc : (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits, d_status);
+    }
     if (quad && !one_chunk) {
         const uint32_t nc = nb32 * 64;
         LAUNCH(c, s, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, (uint32_t *)nullptr, d_colc);

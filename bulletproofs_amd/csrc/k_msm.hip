@@ -17,6 +17,14 @@ __global__ void __launch_bounds__(BP_BLOCK) k_vb_window(uint32_t nthreads, const
     if (tid < nthreads) vb_window_thread(tid, chunks, tab, recoded, part);
 }
 
+// the window-sum role of launch 3 as a launch of its own (experiment "split_stage3": its own register budget -- 128 VGPRs, four
+// wavefronts per SIMD -- instead of the 252 of the role-fused kernel, whose generator-exponent role sets the allocation)
+__global__ void __launch_bounds__(BP_BLOCK) k_vb_window_colc(uint32_t nthreads, const vb_chunk *chunks, const ge_cached *tab,
+                                                              const uint32_t *recoded, ge_ext *part, ge_cached *colc) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < nthreads) vb_window_thread(tid, chunks, tab, recoded, part, colc);
+}
+
 __global__ void __launch_bounds__(BP_BLOCK) k_vb_colsum(uint32_t nthreads, const uint32_t *chunk_first, const ge_ext *part,
                                                          uint32_t *colq16, ge_cached *colc) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;

@@ -49,6 +49,18 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(RP_
     }
 }
 
+// the point-decode role of launch 1 as a launch of its own (option "split_stage1": runs on the context's second stream beside the
+// transcript kernel, with its own register budget instead of the transcript role's)
+template <int WAVES>
+__global__ void __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) __launch_bounds__(RP_BLOCK) k_rp_points(rp_shape sh, const uint8_t *proofs, const uint8_t *commitments,
+                                                                                                      ge_cached *tab, uint32_t *status, fb_entry *bk_pts, rp_seg_tab segs) {
+    const uint32_t t = blockIdx.x * RP_BLOCK + threadIdx.x;
+    if (t < sh.nproofs * sh.U) rp_points_thread(t, sh, rp_resolve(t / sh.U, sh, proofs, commitments, nullptr, segs), tab, status, bk_pts);
+}
+template __global__ void k_rp_points<1>(rp_shape, const uint8_t *, const uint8_t *, ge_cached *, uint32_t *, fb_entry *, rp_seg_tab);
+template __global__ void k_rp_points<2>(rp_shape, const uint8_t *, const uint8_t *, ge_cached *, uint32_t *, fb_entry *, rp_seg_tab);
+template __global__ void k_rp_points<3>(rp_shape, const uint8_t *, const uint8_t *, ge_cached *, uint32_t *, fb_entry *, rp_seg_tab);
+
 // verdict[p] = status (Format / shape / Verification) if set, else the identity test of the mega-check
 __global__ void __launch_bounds__(64) k_rp_verdict(uint32_t n, uint32_t *status, const uint8_t *msm_verdict, uint8_t *out) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
