@@ -11,7 +11,7 @@ for r in $(seq $ROUNDS); do
     python bench.py --no-cpu-baseline $ARGS 2>&1 | tail -1 | python -c "
 import json,sys
 d=json.loads(sys.stdin.read())
-print('$v', round(d['value']), d['roofline']['kernels_us'])"
+print('$v', round(d['value']), (d.get('roofline') or {}).get('kernels_us'))"
   done
 done
 cp /tmp/keep.so bulletproofs_amd/csrc/libbpgpu.so
