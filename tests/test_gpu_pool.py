@@ -190,3 +190,60 @@ def test_plain_c_client_of_the_pool(tmp_path, ndev):
     assert out.returncode == 0, out.stderr
     planted = [i for i in range(6000) if i % 487 == 486]
     assert out.stdout.strip() == "rejected %d of 6000:" % len(planted) + "".join(" %d=1" % i for i in planted)
+
+
+def test_pool_shared_by_threads_host_and_device_paths_mixed(oracle, cfg2):
+    """One pool used from four host threads at once -- host-pointer calls of different sizes and device-pointer submissions with
+    their own flush / wait -- while the pool's own workers run: no deadlock, every verdict == oracle (the pool serialises its
+    bookkeeping internally; lanes are shared by both paths)."""
+    import threading
+    import torch
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    fx = cfg2
+    dev = torch.device("cuda", 0)
+    pool = bp.Pool((0, 0), 6, fixed_window_bits=16)
+    pool.gens_create(64, 1)
+    gens = oracle.Gens(64, 1)
+    sizes = (1500, 700, 2600, 333)
+    cases = []
+    for i, nb in enumerate(sizes):
+        proofs, coms = wl.tile_batch(fx, nb, first=977 * i)
+        proofs, coms, _ = _tamper(proofs, coms, fx.proof_len, fx.m, nb, 40 + i, frac=0.03)
+        rng = hashlib.shake_256(b"mt-%d" % i).digest(64 * nb)
+        ev, _ = _oracle_all(oracle, gens, fx, proofs, coms, rng)
+        cases.append((nb, proofs, coms, rng, ev))
+    to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    dv = [(to_dev(c[1]), to_dev(c[2]), to_dev(c[3]), torch.full((c[0],), 255, dtype=torch.uint8, device=dev)) for c in cases]
+    torch.cuda.synchronize()
+    errors = []
+
+    def host_worker(i):
+        try:
+            nb, proofs, coms, rng, ev = cases[i]
+            for _ in range(3):
+                if pool.rangeproof_verify(fx.n, fx.m, proofs, fx.proof_len, coms, fx.label, rng) != ev:
+                    errors.append("host %d" % i)
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    def dev_worker():
+        try:
+            for _ in range(3):
+                for i, (nb, *_rest) in enumerate(cases):
+                    pool.submit_dev(i % 2, fx.n, fx.m, nb, dv[i][0].data_ptr(), fx.proof_len, dv[i][1].data_ptr(), fx.label, dv[i][2].data_ptr(), dv[i][3].data_ptr())
+                pool.wait()
+                for i, c in enumerate(cases):
+                    if bytes(dv[i][3].cpu().numpy()) != c[4]:
+                        errors.append("dev %d" % i)
+                    dv[i][3].fill_(255)
+                torch.cuda.synchronize()
+        except Exception as e:   # noqa: BLE001
+            errors.append(repr(e))
+
+    ths = [threading.Thread(target=host_worker, args=(i,)) for i in range(3)] + [threading.Thread(target=dev_worker)]
+    [t.start() for t in ths]
+    [t.join(timeout=300) for t in ths]
+    assert not any(t.is_alive() for t in ths), "deadlock"
+    assert errors == []
+    pool.close()
