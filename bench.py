@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--window-bits", type=int, default=0, help="fixed-base window (default: library default)")
     ap.add_argument("--table-bytes", type=int, default=0, help="HBM budget of the generator tables (default: library default)")
     ap.add_argument("--splits", type=int, default=0, help="workgroups the generator terms of a proof block are split over (default: library default)")
-    ap.add_argument("--horner-lanes", type=int, default=0, choices=[0, 4, 64], help="lanes per Horner chain (default: library default)")
+    ap.add_argument("--horner-lanes", type=int, default=0, choices=[0, 1, 4, 64], help="lanes per Horner chain (default: library default)")
     ap.add_argument("--streams", type=int, default=0,
                     help="(default 64) lanes of the library's pool (bpgpu_pool_create): independent (context, HIP stream) pairs its launch chains are "
                          "issued on round-robin, so that consecutive chains overlap on the device")

@@ -54,7 +54,7 @@ struct bpgpu_ctx {
                                              // +3 / +5 / +8 % over the 96 GiB of rounds 1-2, profiles/r03/window_sweep.txt); halved automatically when the allocation fails
     uint32_t splits = 0;
     uint32_t splits_hint = 0;                // per-call suggestion of the pool (pick_splits), used when `splits` is 0
-    uint32_t horner_lanes = 0;               // lanes per Horner chain in the range-proof path: 4, 64, 0 = auto (4)
+    uint32_t horner_lanes = 0;               // lanes per Horner chain in the range-proof path: 1, 4, 64, 0 = auto (1 on wide chains, else 4)
     struct shared_table *tab_ref = nullptr;  // refcounted, shared by the contexts of one device
     // generators
     size_t gens_capacity = 0, party_capacity = 0;
@@ -402,7 +402,7 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
         return BPGPU_OK;
     }
     if (!strcmp(key, "horner_lanes")) {
-        if (value != 0 && value != 4 && value != 64) return fail(c, BPGPU_ERR_INVALID_ARG, "horner_lanes must be 0 (auto), 4 or 64");
+        if (value != 0 && value != 1 && value != 4 && value != 64) return fail(c, BPGPU_ERR_INVALID_ARG, "horner_lanes must be 0 (auto), 1, 4 or 64");
         c->horner_lanes = (uint32_t)value;
         return BPGPU_OK;
     }
@@ -1601,7 +1601,8 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     }
     // Horner layout: quads (16 chains per wavefront, least total work) unless the caller asked for the
     // wavefront-per-chain variant (lowest latency of a single small batch)
-    const bool quad = c->horner_lanes != 64;
+    const bool quad = c->horner_lanes != 64;          // column sums as cached points (both the quad and the one-lane chain read them)
+    const bool one_lane = c->horner_lanes == 1;
     ge_cached *d_colc = quad ? (ge_cached *)d.colq16 : nullptr;
     const uint32_t n_tr = (nb32 + RP_BLOCK - 1) / RP_BLOCK;
     const uint32_t n_pt = shape_verdict ? 0 : (nb32 * sh.U + RP_BLOCK - 1) / RP_BLOCK;
@@ -1687,7 +1688,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         if (!scalars_done)
             LAUNCH(c, s, "rlc_colsum", k_rlc_colsum_scalars, n_sc, BP_BLOCK, 0u, 0u, 0u, 1u, (const ge_ext *)cur, next, n_gen_terms,
                    (const unsigned long long *)d_acc, d_dig1, prm, d_ctl, rows);
-        LAUNCH(c, s, "rlc_stage4", k_rp_stage4<false>, 1 + nsplit1, FB_BLOCK, 1u, d_ctl + 2, cur, (const ge_cached *)nullptr, d_hq1, prm, 1u, 1u,
+        LAUNCH(c, s, "rlc_stage4", k_rp_stage4<64>, 1 + nsplit1, FB_BLOCK, 1u, d_ctl + 2, cur, (const ge_cached *)nullptr, d_hq1, prm, 1u, 1u,
                nsplit1, npairs, d_ids, d_dig1, c->d_table, d_part1);
         if (d_batch_out)
             LAUNCH(c, s, "rlc_finish", k_rlc_finish<true>, 1, 64, nsplit1, d_hq1, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)d_batch_out);
@@ -1702,25 +1703,52 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     // generator-exponent role, i.e. two wavefronts per SIMD also for the window sums, whose table gathers are not prefetched.
     // As two launches the window sums get their own 128 (four wavefronts per SIMD): +1.5 ... +3 % on wide chains (same-box A/B,
     // profiles/r03/ab_split_stage3.txt); a narrow chain keeps the fused form (one launch fewer on its latency path).
-    if (c->split_stage3 == 1 || (c->split_stage3 < 0 && nbatch >= 2048)) {
+    // The Horner chain of a proof's own terms is 252 doublings + 64 additions in series.  Narrow chains give it a quad of lanes per
+    // proof (horner_quad.h: half the latency, twice the instructions).  Wide chains are bound by work, not by the latency of one proof:
+    // they take the one-lane form, and to keep its ~1 ms of dependent instructions off the chain's critical path it goes to the context's
+    // second stream as soon as the column sums exist, beside the generator exponents and the table walk (same-box A/B: 20-step bursts
+    // +4.6 %, steady state +2.6 %; inside launch 4 the one-lane form gained 3 % in steady state and LOST 4 % on bursts --
+    // profiles/r03/ab_horner_one_lane.txt).
+    bool horner_aside = false;
+    const bool wide = c->split_stage3 == 1 || (c->split_stage3 < 0 && nbatch >= 2048);
+    if (wide) {
         LAUNCH(c, s, "rp_stage3w", k_vb_window_colc, n_win, BP_BLOCK, nwin, d.chunks, d.tab, d.recoded, d.part, (quad && one_chunk) ? d_colc : (ge_cached *)nullptr);
+        if (quad && c->horner_lanes != 4 && s != c->stream2) {
+            if (!one_chunk) {
+                const uint32_t nc = nb32 * 64;
+                LAUNCH(c, s, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, (uint32_t *)nullptr, d_colc);
+            }
+            HIPCHK(c, hipEventRecord(c->fork_ev, s));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->fork_ev, 0));
+            LAUNCH(c, c->stream2, "rp_horner1", k_rp_horner1, (nb32 + FB_BLOCK - 1) / FB_BLOCK, FB_BLOCK, nb32, d_colc, d.hq);
+            HIPCHK(c, hipEventRecord(c->join_ev, c->stream2));
+            horner_aside = true;
+        }
         LAUNCH(c, s, "rp_stage3", k_rp_stage3, n_exp, BP_BLOCK, 0u, 0u, d.chunks, d.tab, d.recoded, d.part, (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits,
                d_status);
     } else {
         LAUNCH(c, s, "rp_stage3", k_rp_stage3, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part,
                (quad && one_chunk) ? d_colc : (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits, d_status);
     }
-    if (quad && !one_chunk) {
+    if (quad && !one_chunk && !horner_aside) {
         const uint32_t nc = nb32 * 64;
         LAUNCH(c, s, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, (uint32_t *)nullptr, d_colc);
     }
     const uint32_t nblk_p = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
-    if (quad) {
+    if (horner_aside) {
+        LAUNCH(c, s, "rp_stage4", k_rp_stage4<4>, nblk_p * nsplit, FB_BLOCK, 0u, d.chunk_first, d.part, d_colc, d.hq, prm, nb32, nblk_p,
+               nsplit, npairs, d_ids, d_digits, c->d_table, d_partial);
+        HIPCHK(c, hipStreamWaitEvent(s, c->join_ev, 0));
+    } else if (quad && one_lane) {
+        const uint32_t n_hw = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
+        LAUNCH(c, s, "rp_stage4", k_rp_stage4<1>, n_hw + nblk_p * nsplit, FB_BLOCK, n_hw, d.chunk_first, d.part, d_colc, d.hq, prm, nb32, nblk_p,
+               nsplit, npairs, d_ids, d_digits, c->d_table, d_partial);
+    } else if (quad) {
         const uint32_t n_hw = (nb32 + 15) / 16;
-        LAUNCH(c, s, "rp_stage4", k_rp_stage4<true>, n_hw + nblk_p * nsplit, FB_BLOCK, n_hw, d.chunk_first, d.part, d_colc, d.hq, prm, nb32, nblk_p,
+        LAUNCH(c, s, "rp_stage4", k_rp_stage4<4>, n_hw + nblk_p * nsplit, FB_BLOCK, n_hw, d.chunk_first, d.part, d_colc, d.hq, prm, nb32, nblk_p,
                nsplit, npairs, d_ids, d_digits, c->d_table, d_partial);
     } else {
-        LAUNCH(c, s, "rp_stage4", k_rp_stage4<false>, nb32 + nblk_p * nsplit, FB_BLOCK, nb32, d.chunk_first, d.part, (const ge_cached *)nullptr, d.hq,
+        LAUNCH(c, s, "rp_stage4", k_rp_stage4<64>, nb32 + nblk_p * nsplit, FB_BLOCK, nb32, d.chunk_first, d.part, (const ge_cached *)nullptr, d.hq,
                prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, c->d_table, d_partial);
     }
     ge_ext *d_red = nullptr;

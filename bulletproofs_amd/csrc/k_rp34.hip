@@ -18,17 +18,25 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rp_stage3(uint32_t n_win, uint32_t
     }
 }
 
-// launch 4: [0, n_hw) the Horner chains of the proof-specific terms -- QUAD: one quad of lanes per proof, 16
-// proofs per wavefront, from cached column sums (horner_quad.h); otherwise one wavefront per proof, which forms
+// the one-lane Horner chains as their own launch (wide chains: issued on the context's second stream as soon as the window sums
+// exist, so that their ~1 ms of dependent instructions run beside the generator exponents and the table walk instead of after them)
+__global__ void __launch_bounds__(FB_BLOCK) k_rp_horner1(uint32_t nproofs, const ge_cached *colc, ge_ext *hq) {
+    vb_horner_cached_thread(blockIdx.x * FB_BLOCK + threadIdx.x, nproofs, colc, hq);
+}
+
+// launch 4: [0, n_hw) the Horner chains of the proof-specific terms -- HL = lanes per chain.  4: one quad of lanes per proof, 16
+// proofs per wavefront, from cached column sums (horner_quad.h); 1: one lane per proof (least work -- about half the quad's
+// instructions -- and twice its latency: the form for wide chains, msm_vb.h); 64: one wavefront per proof, which forms
 // its column sums itself (horner_wave.h)  ||  the fixed-base table walk (block -> (split, proof block) as in
 // k_fb_accum)
-template <bool QUAD>
+template <int HL>
 __global__ void __launch_bounds__(FB_BLOCK) k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge_ext *part, const ge_cached *colc,
                                                          ge_ext *hq, fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit,
                                                          uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits,
                                                          const fb_entry *table, ge_ext *partial) {
     if (blockIdx.x < n_hw) {
-        if (QUAD) hq_horner_msm(blockIdx.x * 16 + (threadIdx.x >> 2), nproofs, colc, hq);
+        if (HL == 4) hq_horner_msm(blockIdx.x * 16 + (threadIdx.x >> 2), nproofs, colc, hq);
+        else if (HL == 1) vb_horner_cached_thread(blockIdx.x * FB_BLOCK + threadIdx.x, nproofs, colc, hq);
         else hw_colsum_horner_msm(blockIdx.x, chunk_first, part, hq + blockIdx.x);
         return;
     }
@@ -48,5 +56,6 @@ __global__ void __launch_bounds__(FB_BLOCK) k_rp_stage4(uint32_t n_hw, const uin
     if (p < nproofs) fb_accum_thread(p, split, q0 < npairs ? q0 : npairs, q1, prm, nproofs, gen_ids, digits, table, partial);
 }
 
-template __global__ void k_rp_stage4<true>(uint32_t, const uint32_t *, const ge_ext *, const ge_cached *, ge_ext *, fb_params, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, const fb_digit *, const fb_entry *, ge_ext *);
-template __global__ void k_rp_stage4<false>(uint32_t, const uint32_t *, const ge_ext *, const ge_cached *, ge_ext *, fb_params, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, const fb_digit *, const fb_entry *, ge_ext *);
+template __global__ void k_rp_stage4<4>(uint32_t, const uint32_t *, const ge_ext *, const ge_cached *, ge_ext *, fb_params, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, const fb_digit *, const fb_entry *, ge_ext *);
+template __global__ void k_rp_stage4<1>(uint32_t, const uint32_t *, const ge_ext *, const ge_cached *, ge_ext *, fb_params, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, const fb_digit *, const fb_entry *, ge_ext *);
+template __global__ void k_rp_stage4<64>(uint32_t, const uint32_t *, const ge_ext *, const ge_cached *, ge_ext *, fb_params, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, const fb_digit *, const fb_entry *, ge_ext *);

@@ -45,7 +45,8 @@ __global__ void k_rp_stage1(rp_shape sh, rp_strobe_init init, uint32_t n_tr, con
 template <int WAVES>
 __global__ void k_rp_points(rp_shape sh, const uint8_t *proofs, const uint8_t *commitments, ge_cached *tab, uint32_t *status, fb_entry *bk_pts, rp_seg_tab segs);
 __global__ void k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, ge_cached *colc, uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits, const uint32_t *status);
-template <bool QUAD>
+__global__ void k_rp_horner1(uint32_t nproofs, const ge_cached *colc, ge_ext *hq);
+template <int HL>
 __global__ void k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge_ext *part, const ge_cached *colc, ge_ext *hq, fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit, uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial);
 __global__ void k_rlc_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, const uint32_t *status, unsigned long long *acc, int uniform);
 __global__ void k_rlc_colsum_scalars(uint32_t n_red, uint32_t nthreads, uint32_t rows_in, uint32_t group, const ge_ext *in, ge_ext *out, uint32_t n_rows, const unsigned long long *acc, fb_digit *digits, fb_params prm, uint32_t *ctl, uint32_t rows_out);

@@ -194,6 +194,27 @@ BP_HD void vb_horner_point(ge_ext &acc, const ge_ext *col /*64 entries*/) {
     }
 }
 
+// thread = msm: the same chain from cached column sums (what launch 3 writes for the quad chain), result to out[msm]
+BP_HD void vb_horner_cached_thread(uint32_t b, uint32_t nmsm, const ge_cached *colc, ge_ext *out) {
+    if (b >= nmsm) return;
+    const ge_cached *col = colc + (uint64_t)b * BP_VB_WINDOWS;
+    ge_ext acc;
+    ge_identity(acc);
+    ge_add_cached(acc, acc, col[BP_VB_WINDOWS - 1], false);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int w = BP_VB_WINDOWS - 2; w >= 0; w--) {
+        const ge_cached q = col[w];   // issued early: independent of the doublings
+        ge_dbl(acc, acc, false);
+        ge_dbl(acc, acc, false);
+        ge_dbl(acc, acc, false);
+        ge_dbl(acc, acc, true);
+        ge_add_cached(acc, acc, q, false);
+    }
+    out[b] = acc;
+}
+
 // thread = msm
 // `pre` (optional): Horner results already computed by the wavefront-cooperative kernel
 BP_HD void vb_horner_thread(uint32_t b, const ge_ext *col, const ge_ext *pre, const uint32_t *status, uint32_t *out /*[msm][8]*/,

@@ -87,8 +87,10 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
  *   "prover_constant_time"  1: the prover's secret-dependent commitments through the constant-time walk (bpgpu_rangeproof_prove_batch)
  *   "transcript_script"     0: byte-wise transcript replay instead of the per-shape script (csrc/rp_script.h; for A/B only)
  *   "horner_lanes"          lanes per Horner chain of the proof-specific terms in the range-proof path:
- *                           4 (16 chains per wavefront: least total work, best with several batches in flight),
- *                           64 (one wavefront per chain: lowest latency of a single small batch), 0 = auto (4)
+ *                           1 (one lane per proof: least work, longest chain; on chains of >= 2048 proofs it runs on the context's
+ *                           second stream beside the table walk), 4 (a quad per proof: twice the instructions, half the latency),
+ *                           64 (one wavefront per chain: lowest latency of a single small batch),
+ *                           0 = auto (default): 1 on chains of >= 2048 proofs, 4 below
  * get_option additionally answers "fixed_table_bytes" and the effective "fixed_window_bits".
  * Returns BPGPU_ERR_INVALID_ARG for unknown keys. */
 int bpgpu_ctx_set_option(bpgpu_ctx *ctx, const char *key, int64_t value);

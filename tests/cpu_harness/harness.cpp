@@ -452,7 +452,8 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
         for (uint32_t p = 0; p < nbatch; p++) fb_accum_thread(p, sp, q0, q1, prm, nbatch, ids.data(), digits.data(), table.data(), partial.data());
     }
     for (uint32_t b = 0; b < nbatch; b++) {
-        if (quad) hq_horner_msm(b, nbatch, colc.data(), hq.data());
+        if (g_horner_lanes == 1) vb_horner_cached_thread(b, nbatch, colc.data(), hq.data());
+        else if (quad) hq_horner_msm(b, nbatch, colc.data(), hq.data());
         else hw_colsum_horner_msm(b, chunk_first.data(), part.data(), &hq[b]);
     }
     std::vector<uint8_t> verdict(nbatch + 1);

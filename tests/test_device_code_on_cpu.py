@@ -290,7 +290,7 @@ def test_shared_generator_pipeline_lane_by_lane(H, oracle, W, nsplit):
     assert vd.raw[0] == 0 and out.raw[:32] == bytes(32)
 
 
-@pytest.mark.parametrize("horner_lanes", [4, 64])
+@pytest.mark.parametrize("horner_lanes", [1, 4, 64])
 def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, golden, horner_lanes):
     """rp_transcript -> rp_expand_a/b -> vb_* / fb_* -> finish, emulated lane by lane, on the reference's
     golden proofs (small shapes; the GPU tests cover all 16) plus tampered copies.  Both Horner layouts:

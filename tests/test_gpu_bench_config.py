@@ -162,3 +162,17 @@ def test_two_streams_on_one_context_are_ordered(oracle, oracle_gens_64_8):
         for k in range(6):
             assert bytes(got[r, k]) == sets[k][3], (r, k)
     c.close()
+
+
+@pytest.mark.parametrize("lanes", [1, 4, 64])
+def test_horner_chain_layouts_agree_with_oracle(oracle, lanes):
+    """The three layouts of the proof-specific Horner chain (one lane / one quad / one wavefront per proof) at cfg2 and at the
+    cfg3 shape (two chunks of column sums per proof), ~5 % tampered: verdicts and mega-check encodings == oracle."""
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    for name, nb in (("cfg2_n64_m1", 2500), ("cfg3_n64_m16", 200)):
+        fx = wl.load_fixture(name)
+        ctx = bp.Context(0, fixed_window_bits=12, horner_lanes=lanes)
+        ctx.gens_create(fx.n, fx.m)
+        _check(oracle, ctx, oracle.Gens(fx.n, fx.m), fx, nb, 17, 60 + lanes)
+        ctx.close()
