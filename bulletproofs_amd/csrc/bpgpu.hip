@@ -54,6 +54,8 @@ struct bpgpu_ctx {
                                              // +3 / +5 / +8 % over the 96 GiB of rounds 1-2, profiles/r03/window_sweep.txt); halved automatically when the allocation fails
     uint32_t splits = 0;
     uint32_t splits_hint = 0;                // per-call suggestion of the pool (pick_splits), used when `splits` is 0
+    uint32_t vb_radix = 0;                   // radix of the proofs' own points in the range-proof path: 16, 32 (wide chains only), 0 = default (16)
+    int a_outside = 1;                       // wide chains: A (coefficient 1) added after the Horner chain instead of carried through the window sums
     uint32_t horner_lanes = 0;               // lanes per Horner chain in the range-proof path: 1, 4, 64, 0 = auto (1 on wide chains, else 4)
     struct shared_table *tab_ref = nullptr;  // refcounted, shared by the contexts of one device
     // generators
@@ -401,6 +403,15 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
         c->splits = (uint32_t)value;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "per_proof_radix")) {
+        if (value != 0 && value != 16 && value != 32) return fail(c, BPGPU_ERR_INVALID_ARG, "per_proof_radix must be 0 (auto), 16 or 32");
+        c->vb_radix = (uint32_t)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "a_outside")) {
+        c->a_outside = value != 0;
+        return BPGPU_OK;
+    }
     if (!strcmp(key, "horner_lanes")) {
         if (value != 0 && value != 1 && value != 4 && value != 64) return fail(c, BPGPU_ERR_INVALID_ARG, "horner_lanes must be 0 (auto), 1, 4 or 64");
         c->horner_lanes = (uint32_t)value;
@@ -443,6 +454,8 @@ int bpgpu_ctx_get_option(bpgpu_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "fixed_table_max_bytes")) *value = (int64_t)c->table_budget;
     else if (!strcmp(key, "fixed_splits")) *value = c->splits;
     else if (!strcmp(key, "horner_lanes")) *value = c->horner_lanes;
+    else if (!strcmp(key, "per_proof_radix")) *value = c->vb_radix;
+    else if (!strcmp(key, "a_outside")) *value = c->a_outside;
     else if (!strcmp(key, "host_sync_blocking")) *value = c->sync_blocking ? 1 : 0;
     else if (!strcmp(key, "transcript_script")) *value = c->no_script ? 0 : 1;
     else if (!strcmp(key, "prover_constant_time")) *value = c->prover_ct ? 1 : 0;
@@ -804,11 +817,11 @@ static int uniform_plan(bpgpu_ctx *c, size_t nbatch, size_t per, bpgpu_ctx::plan
     *out = &it->second;
     return BPGPU_OK;
 }
-static void plan_vb_uniform(arena_plan &ap, size_t nbatch, size_t per, size_t off[7]) {
+static void plan_vb_uniform(arena_plan &ap, size_t nbatch, size_t per, size_t off[7], size_t tab_entries = 8) {
     const size_t n_chunks = nbatch * ((per + BP_VB_CHUNK - 1) / BP_VB_CHUNK), total = nbatch * per;
     off[0] = off[1] = off[2] = 0;   // decomposition lives in the plan cache
     off[3] = ap.add(total * 32 + 16);
-    off[4] = ap.add(total * 8 * sizeof(ge_cached) + 16);
+    off[4] = ap.add(total * tab_entries * sizeof(ge_cached) + 16);
     off[5] = ap.add(n_chunks * 64 * sizeof(ge_ext) + 16);
     off[6] = ap.add(nbatch * 64 * sizeof(ge_cached) + nbatch * sizeof(ge_ext) + 64);   // colq16 (128 B) or colc (160 B) per column, then hq
 }
@@ -1489,10 +1502,18 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const size_t rlc_terms = (size_t)nbatch * sh.U;
     const bk_params bkp = bk_make(pick_bucket_c(rlc_terms));
     const bool rlc_bucket = rlc && !shape_verdict && rlc_terms >= (c->bucket_min ? c->bucket_min : BK_RLC_MIN_TERMS) && bucket_fits(1, rlc_terms, bkp);
+    // wide per-proof chains (see launch 3 below): window sums as their own launch, the one-lane Horner chain aside on the second stream,
+    // and the proofs' own points in signed radix 32 with A (coefficient 1) outside the window sums
+    const bool wide = !rlc && !shape_verdict && (c->split_stage3 == 1 || (c->split_stage3 < 0 && nbatch >= 2048));
+    const bool aside = wide && c->horner_lanes != 4 && c->horner_lanes != 64 && s != c->stream2;
+    const bool r5 = aside && c->vb_radix == 32;
+    const bool a_out = aside && c->a_outside != 0;
+    sh.radix5 = r5 ? 1u : 0u;
+    sh.a_outside = a_out ? 1u : 0u;
     arena_plan ap;
     size_t off[7], boff[12];
     if (rlc_bucket) plan_bucket(ap, 1, rlc_terms, bkp, boff);
-    else plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off);
+    else plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off, r5 ? 16 : 8);
     const size_t off_digits = ap.add((size_t)npairs * nbatch * sizeof(fb_digit) + 16);
     const size_t off_partial = ap.add((size_t)2 * nsplit * nbatch * sizeof(ge_ext) + 16);
     const size_t off_fields = ap.add((size_t)fl.count * nbatch * BP_RP_REC * 4 + 16);
@@ -1710,17 +1731,32 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     // +4.6 %, steady state +2.6 %; inside launch 4 the one-lane form gained 3 % in steady state and LOST 4 % on bursts --
     // profiles/r03/ab_horner_one_lane.txt).
     bool horner_aside = false;
-    const bool wide = c->split_stage3 == 1 || (c->split_stage3 < 0 && nbatch >= 2048);
     if (wide) {
-        LAUNCH(c, s, "rp_stage3w", k_vb_window_colc, n_win, BP_BLOCK, nwin, d.chunks, d.tab, d.recoded, d.part, (quad && one_chunk) ? d_colc : (ge_cached *)nullptr);
-        if (quad && c->horner_lanes != 4 && s != c->stream2) {
-            if (!one_chunk) {
+        // radix 32 (option, off: 16-entry tables and 51 windows instead of 8 and 64 = 66 instead of 71 point operations per point, but
+        // 41 kB of tables per proof and a longer launch 1); A, whose coefficient is 1, added after the chain instead of carried through
+        // 64 windows and an 8-entry table
+        const bool wide_sums = r5 || a_out;
+        if (r5) {
+            const uint32_t nw5 = nb32 * BP_VB5_WINDOWS;
+            LAUNCH(c, s, "rp_stage3w", k_vb_window_wide<true>, (nw5 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nw5, sh.U, a_out ? 1u : 0u, d.tab, d.recoded, d_colc);
+        } else if (a_out) {
+            const uint32_t nw4 = nb32 * BP_VB_WINDOWS;
+            LAUNCH(c, s, "rp_stage3w", k_vb_window_wide<false>, (nw4 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nw4, sh.U, 1u, d.tab, d.recoded, d_colc);
+        } else {
+            LAUNCH(c, s, "rp_stage3w", k_vb_window_colc, n_win, BP_BLOCK, nwin, d.chunks, d.tab, d.recoded, d.part, (quad && one_chunk) ? d_colc : (ge_cached *)nullptr);
+        }
+        if (aside) {
+            if (!one_chunk && !wide_sums) {
                 const uint32_t nc = nb32 * 64;
                 LAUNCH(c, s, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, (uint32_t *)nullptr, d_colc);
             }
             HIPCHK(c, hipEventRecord(c->fork_ev, s));
             HIPCHK(c, hipStreamWaitEvent(c->stream2, c->fork_ev, 0));
-            LAUNCH(c, c->stream2, "rp_horner1", k_rp_horner1, (nb32 + FB_BLOCK - 1) / FB_BLOCK, FB_BLOCK, nb32, d_colc, d.hq);
+            const uint32_t n_hb = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
+            const ge_cached *extra = a_out ? d.tab : (const ge_cached *)nullptr;
+            if (r5) LAUNCH(c, c->stream2, "rp_horner1", k_rp_horner_wide<true>, n_hb, FB_BLOCK, nb32, d_colc, extra, 16u * sh.U, d.hq);
+            else if (a_out) LAUNCH(c, c->stream2, "rp_horner1", k_rp_horner_wide<false>, n_hb, FB_BLOCK, nb32, d_colc, extra, 8u * sh.U, d.hq);
+            else LAUNCH(c, c->stream2, "rp_horner1", k_rp_horner1, n_hb, FB_BLOCK, nb32, d_colc, d.hq);
             HIPCHK(c, hipEventRecord(c->join_ev, c->stream2));
             horner_aside = true;
         }

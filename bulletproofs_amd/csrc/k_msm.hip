@@ -25,6 +25,16 @@ __global__ void __launch_bounds__(BP_BLOCK) k_vb_window_colc(uint32_t nthreads, 
     if (tid < nthreads) vb_window_thread(tid, chunks, tab, recoded, part, colc);
 }
 
+// window sums of a wide range-proof chain (msm_vb.h): lane = (proof, window), points [k0, U) of the proof; R5 = radix 32
+template <bool R5>
+__global__ void __launch_bounds__(BP_BLOCK) k_vb_window_wide(uint32_t nthreads, uint32_t U, uint32_t k0, const ge_cached *tab, const uint32_t *recoded,
+                                                              ge_cached *colc) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < nthreads) vb_window_wide_thread<R5>(tid, U, k0, tab, recoded, colc);
+}
+template __global__ void k_vb_window_wide<false>(uint32_t, uint32_t, uint32_t, const ge_cached *, const uint32_t *, ge_cached *);
+template __global__ void k_vb_window_wide<true>(uint32_t, uint32_t, uint32_t, const ge_cached *, const uint32_t *, ge_cached *);
+
 __global__ void __launch_bounds__(BP_BLOCK) k_vb_colsum(uint32_t nthreads, const uint32_t *chunk_first, const ge_ext *part,
                                                          uint32_t *colq16, ge_cached *colc) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;

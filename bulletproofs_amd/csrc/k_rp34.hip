@@ -24,6 +24,14 @@ __global__ void __launch_bounds__(FB_BLOCK) k_rp_horner1(uint32_t nproofs, const
     vb_horner_cached_thread(blockIdx.x * FB_BLOCK + threadIdx.x, nproofs, colc, hq);
 }
 
+// the same with the point of coefficient 1 (`extra`: A as a cached point, one per proof) added after the chain; R5 = radix-32 column sums
+template <bool R5>
+__global__ void __launch_bounds__(FB_BLOCK) k_rp_horner_wide(uint32_t nproofs, const ge_cached *colc, const ge_cached *extra, uint32_t extra_stride, ge_ext *hq) {
+    vb_horner_wide_thread<R5>(blockIdx.x * FB_BLOCK + threadIdx.x, nproofs, colc, extra, extra_stride, hq);
+}
+template __global__ void k_rp_horner_wide<false>(uint32_t, const ge_cached *, const ge_cached *, uint32_t, ge_ext *);
+template __global__ void k_rp_horner_wide<true>(uint32_t, const ge_cached *, const ge_cached *, uint32_t, ge_ext *);
+
 // launch 4: [0, n_hw) the Horner chains of the proof-specific terms -- HL = lanes per chain.  4: one quad of lanes per proof, 16
 // proofs per wavefront, from cached column sums (horner_quad.h); 1: one lane per proof (least work -- about half the quad's
 // instructions -- and twice its latency: the form for wide chains, msm_vb.h); 64: one wavefront per proof, which forms

@@ -75,6 +75,25 @@ BP_HD int sc_digit16(const uint32_t r[8], int w) {
     return (int)((r[w >> 3] >> ((w & 7) * 4)) & 15u) - 8;
 }
 
+// signed radix-32 recoding (the wide range-proof chains): r = s + sum_{w<51} 16 * 32^w, digit_w = bits [5w, 5w+5) of r, minus 16,
+// in [-16, 15]; 51 digits cover a canonical scalar (r < 2^255), still 8 words
+#define BP_VB5_WINDOWS 51
+BP_HD void sc_recode32(uint32_t r[8], const uint32_t s[8]) {
+    const uint32_t bias[8] = {0x21084210u, 0x08421084u, 0x42108421u, 0x10842108u, 0x84210842u, 0x21084210u, 0x08421084u, 0x42108421u};
+    uint32_t carry = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+        uint64_t t = (uint64_t)s[i] + bias[i] + carry;
+        r[i] = (uint32_t)t;
+        carry = (uint32_t)(t >> 32);
+    }
+}
+BP_HD int sc_digit32(const uint32_t *r /*[8]*/, uint32_t w) {
+    const uint32_t bit = 5 * w, i = bit >> 5, sh = bit & 31;
+    const uint64_t v = ((uint64_t)(i < 7 ? r[i + 1] : 0u) << 32) | r[i];
+    return (int)((uint32_t)(v >> sh) & 31u) - 16;
+}
+
 // ---- stage 1 ---------------------------------------------------------------
 // multiples 1P .. 8P of a decoded point, projective Niels form
 BP_HD void vb_build_table(ge_cached *out /*[8]*/, const ge_ext &p) {
@@ -83,6 +102,23 @@ BP_HD void vb_build_table(ge_cached *out /*[8]*/, const ge_ext &p) {
     out[0] = c1;
     ge_ext cur = p;
     for (int k = 1; k < 8; k++) {
+        ge_add_cached(cur, cur, c1, false);
+        ge_to_cached(ck, cur);
+        out[k] = ck;
+    }
+}
+
+// multiples 1P .. 16P (radix-32 digits); only_first: just 1P (a point whose coefficient is known to be 1)
+BP_HD void vb_build_table16(ge_cached *out /*[16]*/, const ge_ext &p, bool only_first) {
+    ge_cached c1, ck;
+    ge_to_cached(c1, p);
+    out[0] = c1;
+    if (only_first) return;
+    ge_ext cur = p;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int k = 1; k < 16; k++) {
         ge_add_cached(cur, cur, c1, false);
         ge_to_cached(ck, cur);
         out[k] = ck;
@@ -192,6 +228,55 @@ BP_HD void vb_horner_point(ge_ext &acc, const ge_ext *col /*64 entries*/) {
         const ge_ext q = col[w];
         ge_add(acc, acc, q);
     }
+}
+
+// ---- window sums and chain of the wide range-proof chains ---------------------------------------------------------------------
+// R5: signed radix 32 (16-entry tables tab[t][16], 51 windows, sc_recode32) instead of radix 16 (8-entry tables, 64 windows).
+// thread = msm * windows + w: window sum over the msm's points [k0, U) (all in one lane: a wide chain has lanes enough); written as
+// a cached point to colc[msm][w] (stride 64)
+template <bool R5>
+BP_HD void vb_window_wide_thread(uint32_t tid, uint32_t U, uint32_t k0, const ge_cached *tab, const uint32_t *recoded, ge_cached *colc) {
+    const uint32_t nw = R5 ? BP_VB5_WINDOWS : BP_VB_WINDOWS, ne = R5 ? 16 : 8;
+    const uint32_t msm = tid / nw, w = tid - msm * nw;
+    ge_ext acc;
+    ge_identity(acc);
+    for (uint32_t k = k0; k < U; k++) {
+        const uint64_t t = (uint64_t)msm * U + k;
+        const int d = R5 ? sc_digit32(recoded + 8 * t, w) : sc_digit16(recoded + 8 * t, (int)w);
+        if (d != 0) {
+            const int a = d < 0 ? -d : d;
+            const ge_cached q = tab[ne * t + (a - 1)];
+            ge_add_cached(acc, acc, q, d < 0);
+        }
+    }
+    ge_cached cc;
+    ge_to_cached(cc, acc);
+    colc[(uint64_t)msm * 64 + w] = cc;
+}
+// thread = msm: sum_w radix^w colc[msm][w], plus `extra` (optional: one more cached point per msm at extra[msm * extra_stride] --
+// the point whose coefficient is 1)
+template <bool R5>
+BP_HD void vb_horner_wide_thread(uint32_t b, uint32_t nmsm, const ge_cached *colc, const ge_cached *extra, uint64_t extra_stride, ge_ext *out) {
+    if (b >= nmsm) return;
+    const int nw = R5 ? BP_VB5_WINDOWS : BP_VB_WINDOWS;
+    const ge_cached *col = colc + (uint64_t)b * 64;
+    ge_ext acc;
+    ge_identity(acc);
+    ge_add_cached(acc, acc, col[nw - 1], false);
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int w = nw - 2; w >= 0; w--) {
+        const ge_cached q = col[w];   // issued early: independent of the doublings
+        ge_dbl(acc, acc, false);
+        ge_dbl(acc, acc, false);
+        ge_dbl(acc, acc, false);
+        if (R5) ge_dbl(acc, acc, false);
+        ge_dbl(acc, acc, true);
+        ge_add_cached(acc, acc, q, false);
+    }
+    if (extra) ge_add_cached(acc, acc, extra[(uint64_t)b * extra_stride], false);
+    out[b] = acc;
 }
 
 // thread = msm: the same chain from cached column sums (what launch 3 writes for the quad chain), result to out[msm]

@@ -34,6 +34,8 @@ struct rp_shape {
     uint32_t proof_len;            // bytes, = 32*(9+2k)
     uint32_t nproofs;
     uint32_t shape_verdict;        // != 0: only parse, then report this verdict (InvalidBitsize, ...)
+    uint32_t radix5 = 0;           // 1: the per-proof points in signed radix 32 (16-entry tables, 51 windows, msm_vb.h); 0: radix 16
+    uint32_t a_outside = 0;        // 1: A -- coefficient 1 -- is added after the Horner chain: no recoding, only 1A in its table (wide chains)
 };
 
 // Merlin state after Transcript::new(label) + rangeproof_domain_sep(n, m), computed once on the host
@@ -438,6 +440,8 @@ BP_HD void rp_points_thread(uint32_t t, rp_shape sh, const rp_inputs &in, ge_cac
     ge_ext pt;
     if (!ristretto_decompress(pt, w)) status_raise(status + p, BP_VERDICT_VERIFICATION);
     if (pts) bk_store_point(pts + t, pt);
+    else if (sh.radix5) vb_build_table16(tab + 16 * (uint64_t)t, pt, sh.a_outside && u == 0);
+    else if (sh.a_outside && u == 0) ge_to_cached(tab[8 * (uint64_t)t], pt);
     else vb_build_table(tab + 8 * (uint64_t)t, pt);
 }
 
@@ -482,7 +486,7 @@ BP_HD void store_recoded(uint32_t *dst, const sc &s) {
 // a coefficient held in Montgomery form -> (times the proof's batch weight, if any) -> coefficient u of the proof's
 // list `us`: radix-16 recoding (8 words per coefficient), or -- bk_c != 0, bucket path -- the c-bit window recoding
 // of bucket.h (BK_RWORDS words per coefficient)
-BP_HD void rp_emit_coeff(uint32_t *us, uint32_t u, const sc28 &vm, const sc28 *rho_m, uint32_t bk_c, uint32_t salt = 0) {
+BP_HD void rp_emit_coeff(uint32_t *us, uint32_t u, const sc28 &vm, const sc28 *rho_m, uint32_t bk_c, uint32_t salt = 0, bool radix5 = false) {
     sc28 t = vm;
     if (rho_m) sc28_montmul(t, vm, *rho_m);
     sc s;
@@ -492,6 +496,11 @@ BP_HD void rp_emit_coeff(uint32_t *us, uint32_t u, const sc28 &vm, const sc28 *r
         bk_recode(r, s.v, bk_make(bk_c), salt + u);
 #pragma unroll
         for (int q = 0; q < BK_RWORDS; q++) us[u * BK_RWORDS + q] = r[q];
+    } else if (radix5) {
+        uint32_t r[8];
+        sc_recode32(r, s.v);
+#pragma unroll
+        for (int q = 0; q < 8; q++) us[u * 8 + q] = r[q];
     } else {
         store_recoded(us + u * 8, s);
     }
@@ -551,9 +560,9 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
         sc28_montmul(inv, inv, um);                       // drop u_ii from the running inverse
         rp_store28(fields, B, fl.uinv_m + ii, p, uim);
         sc28_montmul(sq, um, um);                         // u_i^2   -> L_i coefficient
-        rp_emit_coeff(us, 4 + ii, sq, rho, bk_c, p * sh.U);
+        rp_emit_coeff(us, 4 + ii, sq, rho, bk_c, p * sh.U, sh.radix5 != 0);
         sc28_montmul(sq, uim, uim);                       // u_i^-2  -> R_i coefficient
-        rp_emit_coeff(us, 4 + k + ii, sq, rho, bk_c, p * sh.U);
+        rp_emit_coeff(us, 4 + k + ii, sq, rho, bk_c, p * sh.U, sh.radix5 != 0);
     }
     // what is left in inv is y^-1: table of y^-(2^b)
     {
@@ -611,20 +620,20 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
     sc28 cxm, cxxm;
     sc28_montmul(cxm, cm, xm);
     sc28_montmul(cxxm, cxm, xm);
-    {
+    if (!sh.a_outside) {   // (wide chains add A, coefficient 1, after the Horner chain)
         sc28 one_m;
         sc28_one_mont(one_m);
-        rp_emit_coeff(us, 0, one_m, rho, bk_c, p * sh.U);
+        rp_emit_coeff(us, 0, one_m, rho, bk_c, p * sh.U, sh.radix5 != 0);
     }
-    rp_emit_coeff(us, 1, xm, rho, bk_c, p * sh.U);
-    rp_emit_coeff(us, 2, cxm, rho, bk_c, p * sh.U);
-    rp_emit_coeff(us, 3, cxxm, rho, bk_c, p * sh.U);
+    rp_emit_coeff(us, 1, xm, rho, bk_c, p * sh.U, sh.radix5 != 0);
+    rp_emit_coeff(us, 2, cxm, rho, bk_c, p * sh.U, sh.radix5 != 0);
+    rp_emit_coeff(us, 3, cxxm, rho, bk_c, p * sh.U, sh.radix5 != 0);
     // V_j coefficients c z^2 z^j, and the z^2 z^j table
     {
         sc28 czzj, zzj = zzm;
         sc28_montmul(czzj, cm, zzm);
         for (uint32_t j = 0; j < sh.m; j++) {
-            rp_emit_coeff(us, 4 + 2 * k + j, czzj, rho, bk_c, p * sh.U);
+            rp_emit_coeff(us, 4 + 2 * k + j, czzj, rho, bk_c, p * sh.U, sh.radix5 != 0);
             if (rho) {
                 sc28 t;
                 sc28_montmul(t, zzj, rho_m);

@@ -281,6 +281,15 @@ void h_sum_of_powers_pow2(const uint8_t *x, uint32_t lg, uint8_t *out) {
 
 static int g_horner_lanes = 4;
 void h_set_horner_lanes(int lanes) { g_horner_lanes = lanes; }
+void h_recode32(const uint8_t *s32, int32_t *digits51) {
+    uint32_t w[8], r[8];
+    memcpy(w, s32, 32);
+    sc_recode32(r, w);
+    for (uint32_t i = 0; i < BP_VB5_WINDOWS; i++) digits51[i] = sc_digit32(r, i);
+}
+static int g_radix5 = 0, g_a_outside = 0;   // the wide chains' forms (per-proof verification only): radix-32 window sums + chain; A added after the chain
+void h_set_radix5(int on) { g_radix5 = on; }
+void h_set_a_outside(int on) { g_a_outside = on; }
 // coalesced launches (rp_seg, bpgpu_pool_*): when set, h_rp_verify reads its inputs through a segment table whose
 // items live in separate buffers (every second one without rng bytes of its own) and reports through it
 static std::vector<uint32_t> g_seg_sizes;
@@ -300,6 +309,9 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
     uint32_t k = 0; while ((1u << k) < n * m) k++;
     uint32_t lg_m = 0; while ((1u << lg_m) < m) lg_m++;
     rp_shape sh; sh.n = n; sh.m = m; sh.nm = n * m; sh.k = k; sh.U = 4 + 2 * k + m; sh.proof_len = proof_len; sh.nproofs = nbatch; sh.shape_verdict = 0;
+    const bool r5 = g_radix5 && !weights64, a_out = g_a_outside && !weights64;
+    sh.radix5 = r5 ? 1u : 0u;
+    sh.a_outside = a_out ? 1u : 0u;
     if (proof_len != 32 * (9 + 2 * k)) return -1;
     fb_params prm; prm.W = W; prm.nwin = fb_nwin(W); prm.half = 1u << (W - 1); prm.n_gens = 2 + 2 * gens_capacity * party_capacity;
     std::vector<ge_ext> base((size_t)prm.n_gens * prm.nwin);
@@ -320,7 +332,7 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
     const uint32_t t0 = nbatch * sh.U;
     std::vector<uint32_t> fields((size_t)fl.count * nbatch * BP_RP_REC + 8), rec((size_t)t0 * 8 + 8, 0xdeadbeefu), status(nbatch + 1, 0), outw((size_t)nbatch * 8 + 1);
     std::vector<fb_digit> digits((size_t)npairs * nbatch + 1, 0xffff);   // poison: unwritten rows must be masked
-    std::vector<ge_cached> tab((size_t)t0 * 8 + 1);
+    std::vector<ge_cached> tab((size_t)t0 * (r5 ? 16 : 8) + 1);
     // coalesced launch: scatter the inputs into per-item buffers and hide the contiguous ones
     std::vector<rp_seg> segs;
     std::vector<std::vector<uint8_t>> seg_bufs;
@@ -440,9 +452,14 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
         if (msm_out) { msm_out[0] = bv; memcpy(msm_out + 1, rw, 32); }
         return 0;
     }
+    if (r5)
+        for (uint32_t tid = 0; tid < nbatch * BP_VB5_WINDOWS; tid++) vb_window_wide_thread<true>(tid, sh.U, a_out ? 1 : 0, tab.data(), rec.data(), colc.data());
+    else if (a_out)
+        for (uint32_t tid = 0; tid < nbatch * BP_VB_WINDOWS; tid++) vb_window_wide_thread<false>(tid, sh.U, 1, tab.data(), rec.data(), colc.data());
+    else
     for (uint32_t tid = 0; tid < chunks.size() * 64; tid++)
         vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data(), (quad && one_chunk) ? colc.data() : nullptr);
-    if (quad && !one_chunk)
+    if (quad && !one_chunk && !r5 && !a_out)
         for (uint32_t tid = 0; tid < nbatch * 64; tid++) vb_colsum_thread(tid, chunk_first.data(), part.data(), nullptr, nullptr, colc.data());
     // launch 3
     std::vector<ge_ext> partial((size_t)nsplit * nbatch + 1);
@@ -452,7 +469,9 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
         for (uint32_t p = 0; p < nbatch; p++) fb_accum_thread(p, sp, q0, q1, prm, nbatch, ids.data(), digits.data(), table.data(), partial.data());
     }
     for (uint32_t b = 0; b < nbatch; b++) {
-        if (g_horner_lanes == 1) vb_horner_cached_thread(b, nbatch, colc.data(), hq.data());
+        if (r5) vb_horner_wide_thread<true>(b, nbatch, colc.data(), a_out ? tab.data() : nullptr, 16ull * sh.U, hq.data());
+        else if (a_out) vb_horner_wide_thread<false>(b, nbatch, colc.data(), tab.data(), 8ull * sh.U, hq.data());
+        else if (g_horner_lanes == 1) vb_horner_cached_thread(b, nbatch, colc.data(), hq.data());
         else if (quad) hq_horner_msm(b, nbatch, colc.data(), hq.data());
         else hw_colsum_horner_msm(b, chunk_first.data(), part.data(), &hq[b]);
     }

@@ -290,12 +290,16 @@ def test_shared_generator_pipeline_lane_by_lane(H, oracle, W, nsplit):
     assert vd.raw[0] == 0 and out.raw[:32] == bytes(32)
 
 
-@pytest.mark.parametrize("horner_lanes", [1, 4, 64])
+@pytest.mark.parametrize("horner_lanes", [1, 4, 64, "radix32", "radix32+a_outside", "a_outside"])
 def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, golden, horner_lanes):
     """rp_transcript -> rp_expand_a/b -> vb_* / fb_* -> finish, emulated lane by lane, on the reference's
-    golden proofs (small shapes; the GPU tests cover all 16) plus tampered copies.  Both Horner layouts:
-    4 lanes per chain (horner_quad.h) and 64 (horner_wave.h)."""
-    H.h_set_horner_lanes(horner_lanes)
+    golden proofs (small shapes; the GPU tests cover all 16) plus tampered copies.  The Horner layouts:
+    1 lane per chain (msm_vb.h), 4 (horner_quad.h), 64 (horner_wave.h); the wide chains' forms (one-lane chain): "radix32" -- the proofs'
+    own points in signed radix 32 (16-entry tables, 51 windows); "a_outside" -- A, whose coefficient is 1, added after the chain."""
+    wide = isinstance(horner_lanes, str)
+    H.h_set_radix5(1 if wide and "radix32" in horner_lanes else 0)
+    H.h_set_a_outside(1 if wide and "a_outside" in horner_lanes else 0)
+    H.h_set_horner_lanes(1 if wide else horner_lanes)
     label = golden["label"]
     vc = golden["vc_bytes"]
     for case in golden["cases"]:
@@ -330,6 +334,21 @@ def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, gol
     assert H.h_rp_verify(4, 2, 8, 1, Bb2 + B2 + G2 + H2, 8, 1, 4, bytes(nc) + bytes(ia) + bytes(us) + pr, len(pr), vc[:32] * 4, label,
                          len(label), rng, vd, mo) == 0
     assert list(vd.raw) == [2, 1, 1, 0]
+    H.h_set_radix5(0)
+    H.h_set_a_outside(0)
+
+
+def test_radix32_recoding_reconstructs_the_scalar(H):
+    """sc_recode32 / sc_digit32 (msm_vb.h): 51 digits in [-16, 15] with sum_w d_w 32^w == s, for edge scalars and random ones."""
+    import random
+    L = 2**252 + 27742317777372353535851937790883648493
+    rnd = random.Random(5)
+    cases = [0, 1, 15, 16, 17, 31, 32, L - 1, L - 2, 2**252, 2**252 - 1, (2**255 - 1) // 31 % L] + [rnd.randrange(L) for _ in range(200)]
+    for s in cases:
+        dg = (C.c_int32 * 51)()
+        H.h_recode32(s.to_bytes(32, "little"), dg)
+        assert all(-16 <= d <= 15 for d in dg)
+        assert sum(d * 32**w for w, d in enumerate(dg)) == s
 
 
 def test_coalesced_launch_segment_table_lane_by_lane(H, oracle, golden):

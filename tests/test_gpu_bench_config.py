@@ -164,15 +164,19 @@ def test_two_streams_on_one_context_are_ordered(oracle, oracle_gens_64_8):
     c.close()
 
 
-@pytest.mark.parametrize("lanes", [1, 4, 64])
-def test_horner_chain_layouts_agree_with_oracle(oracle, lanes):
-    """The three layouts of the proof-specific Horner chain (one lane / one quad / one wavefront per proof) at cfg2 and at the
-    cfg3 shape (two chunks of column sums per proof), ~5 % tampered: verdicts and mega-check encodings == oracle."""
+@pytest.mark.parametrize("lanes,radix,a_outside", [(0, 0, 1), (0, 0, 0), (0, 32, 1), (1, 32, 0), (1, 16, 1), (4, 0, 1), (64, 0, 1)])
+def test_horner_chain_layouts_and_radices_agree_with_oracle(oracle, lanes, radix, a_outside):
+    """The layouts of the proof-specific Horner chain (one lane / one quad / one wavefront per proof; 0 = the default: one lane, on the
+    second stream, for chains of >= 2048 proofs), the radix of the proofs' own points (16, or 32 on wide chains) and A inside / outside
+    the window sums (wide chains), at cfg2 and at the cfg3 shape (two chunks of column sums per proof), wide and narrow chains,
+    ~5 % tampered: verdicts and mega-check encodings == oracle."""
     import bulletproofs_amd as bp
     from bulletproofs_amd import workload as wl
-    for name, nb in (("cfg2_n64_m1", 2500), ("cfg3_n64_m16", 200)):
+    for name, nb in (("cfg2_n64_m1", 2500), ("cfg3_n64_m16", 2100), ("cfg3_n64_m16", 200), ("cfg2_n64_m1", 77)):
         fx = wl.load_fixture(name)
         ctx = bp.Context(0, fixed_window_bits=12, horner_lanes=lanes)
+        ctx.set_option("per_proof_radix", radix)
+        ctx.set_option("a_outside", a_outside)
         ctx.gens_create(fx.n, fx.m)
-        _check(oracle, ctx, oracle.Gens(fx.n, fx.m), fx, nb, 17, 60 + lanes)
+        _check(oracle, ctx, oracle.Gens(fx.n, fx.m), fx, nb, 17, 60 + lanes + radix + a_outside)
         ctx.close()
