@@ -170,43 +170,66 @@ BP_HD void fb_load_line(fb_line &l, const fb_entry *e) {
 #pragma unroll
     for (int i = 0; i < 30; i++) l.w[i] = src[i];
 }
-BP_HD const fb_entry *fb_entry_addr(const fb_entry *table, const uint32_t *gen_ids, fb_params prm, uint32_t q, uint32_t v) {
-    const uint32_t g = q / prm.nwin, win = q - g * prm.nwin;
+// the pair index as (generator term, window), advanced without a division per pair
+struct fb_cursor {
+    uint32_t g, win;
+};
+BP_HD const fb_entry *fb_entry_at(const fb_entry *table, const uint32_t *gen_ids, fb_params prm, fb_cursor &c, uint32_t v) {
     const int d = (int)(v & (2u * prm.half - 1u)) - (int)prm.half;   // masked: rows of rejected proofs are never written
     const uint32_t a = (uint32_t)(d < 0 ? -d : d);
-    return table + ((uint64_t)gen_ids[g] * prm.nwin + win) * prm.half + (a ? a - 1 : 0);
+    const fb_entry *e = table + ((uint64_t)gen_ids[c.g] * prm.nwin + c.win) * prm.half + (a ? a - 1 : 0);
+    if (++c.win == prm.nwin) {
+        c.win = 0;
+        c.g++;
+    }
+    return e;
 }
+BP_HD void fb_accum_step(ge_ext &acc, const fb_line &line, uint32_t v, fb_params prm, bool first) {
+    const int d = (int)(v & (2u * prm.half - 1u)) - (int)prm.half;
+    if (d != 0) {
+        ge_niels n;
+#pragma unroll
+        for (int i = 0; i < 10; i++) {
+            n.ypx.v[i] = line.w[i];
+            n.ymx.v[i] = line.w[10 + i];
+            n.t2d.v[i] = line.w[20 + i];
+        }
+        if (first) ge_from_niels(acc, n, d < 0);   // the accumulator is still the identity: 1 multiplication, not 7
+        else ge_madd(acc, acc, n, d < 0);
+    }
+}
+// Two pairs per trip, two line buffers used alternately: the line of the next pair is loaded straight into the buffer the
+// previous pair has just vacated (no register copies between trips).
 BP_HD void fb_accum_thread(uint32_t p, uint32_t split, uint32_t q0, uint32_t q1, fb_params prm, uint32_t nproofs,
                            const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial) {
     ge_ext acc;
     ge_identity(acc);
     if (q0 < q1) {
-        uint32_t v_cur = digits[(uint64_t)q0 * nproofs + p];
-        uint32_t v_next = (q0 + 1 < q1) ? digits[(uint64_t)(q0 + 1) * nproofs + p] : prm.half;
-        fb_line line_cur;
-        fb_load_line(line_cur, fb_entry_addr(table, gen_ids, prm, q0, v_cur));
-        for (uint32_t q = q0; q < q1; q++) {
-            // issue the loads of the following iterations first
-            fb_line line_next = line_cur;
-            uint32_t v_next2 = prm.half;
-            if (q + 1 < q1) fb_load_line(line_next, fb_entry_addr(table, gen_ids, prm, q + 1, v_next));
-            if (q + 2 < q1) v_next2 = digits[(uint64_t)(q + 2) * nproofs + p];
-            const int d = (int)(v_cur & (2u * prm.half - 1u)) - (int)prm.half;
-            if (d != 0) {
-                ge_niels n;
-#pragma unroll
-                for (int i = 0; i < 10; i++) {
-                    n.ypx.v[i] = line_cur.w[i];
-                    n.ymx.v[i] = line_cur.w[10 + i];
-                    n.t2d.v[i] = line_cur.w[20 + i];
-                }
-                if (q == q0) ge_from_niels(acc, n, d < 0);   // the accumulator is still the identity: 1 multiplication, not 7
-                else ge_madd(acc, acc, n, d < 0);
-            }
-            line_cur = line_next;
-            v_cur = v_next;
-            v_next = v_next2;
+        const fb_digit *dg = digits + p;
+        fb_cursor cur;   // the next line to request
+        cur.g = q0 / prm.nwin;
+        cur.win = q0 - cur.g * prm.nwin;
+        uint32_t va = dg[(uint64_t)q0 * nproofs];
+        uint32_t vb = (q0 + 1 < q1) ? dg[(uint64_t)(q0 + 1) * nproofs] : prm.half;
+        fb_line la, lb;
+        fb_load_line(la, fb_entry_at(table, gen_ids, prm, cur, va));
+        // first pair on its own (the accumulator is the identity), so that the loop below is uniform
+        if (q0 + 1 < q1) fb_load_line(lb, fb_entry_at(table, gen_ids, prm, cur, vb));
+        uint32_t vc = (q0 + 2 < q1) ? dg[(uint64_t)(q0 + 2) * nproofs] : prm.half;
+        fb_accum_step(acc, la, va, prm, true);
+        // invariant at the top of a trip: pair q's line is in lb (digit vb), the digit of pair q+1 is vc, no line beyond q requested
+        uint32_t q = q0 + 1;
+        for (; q + 1 < q1; q += 2) {
+            fb_load_line(la, fb_entry_at(table, gen_ids, prm, cur, vc));                              // pair q+1
+            const uint32_t vd = (q + 2 < q1) ? dg[(uint64_t)(q + 2) * nproofs] : prm.half;            // digit of pair q+2
+            fb_accum_step(acc, lb, vb, prm, false);                                                   // pair q
+            if (q + 2 < q1) fb_load_line(lb, fb_entry_at(table, gen_ids, prm, cur, vd));              // pair q+2
+            const uint32_t ve = (q + 3 < q1) ? dg[(uint64_t)(q + 3) * nproofs] : prm.half;            // digit of pair q+3
+            fb_accum_step(acc, la, vc, prm, false);                                                   // pair q+1
+            vb = vd;
+            vc = ve;
         }
+        if (q < q1) fb_accum_step(acc, lb, vb, prm, false);   // odd tail: pair q1-1 is in lb
     }
     partial[(uint64_t)split * nproofs + p] = acc;
 }

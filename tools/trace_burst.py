@@ -26,5 +26,8 @@ depth = 0; last = ev[0][0]; hist = collections.Counter()
 for t, d in ev:
     hist[depth] += t - last; last = t; depth += d
 print("  time by concurrently running kernels:", {k: "%.2f ms" % (v / 1e6) for k, v in sorted(hist.items())})
+if len(sys.argv) > 3 and sys.argv[3] == "detail":
+    for r in sorted(reg):
+        print("    q%-3d %-22s %8.1f -> %8.1f us  (%7.1f)" % (r[3], r[2], (r[0] - t0) / 1e3, (r[1] - t0) / 1e3, (r[1] - r[0]) / 1e3))
 qs = collections.Counter(r[3] for r in reg)
 print("  queues used: %d" % len(qs), dict(qs))
