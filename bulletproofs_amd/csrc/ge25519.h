@@ -77,6 +77,37 @@ BP_HD void ge_add_cached(ge_ext &r, const ge_ext &p, const ge_cached &q, bool ne
     fe_mul(r.T, h, e);
 }
 
+// the same in two halves, so that a caller can request its next operand between them (the registers of q are free after the
+// first half): front = the four products with q and the sums, back = the four products that form the result
+struct ge_efgh {
+    fe e, f, g, h;
+};
+BP_HD void ge_add_cached_front(ge_efgh &t, const ge_ext &p, const ge_cached &q, bool neg) {
+    fe ypx, ymx, a, b, c, d, qa, qb;
+    fe_select(qa, q.YmX, q.YpX, neg);
+    fe_select(qb, q.YpX, q.YmX, neg);
+    fe_add(ypx, p.Y, p.X);              // lazy
+    fe_sub(ymx, p.Y, p.X);
+    fe_mul(a, ymx, qa);
+    fe_mul(b, ypx, qb);
+    fe_mul(c, p.T, q.T2d);
+    fe_mul(d, p.Z, q.Z);
+    fe_add(d, d, d);                    // lazy (2x)
+    fe dmc, dpc;
+    fe_sub(t.e, b, a);
+    fe_add(t.h, b, a);                  // lazy (2x)
+    fe_sub(dmc, d, c);
+    fe_add(dpc, d, c);                  // lazy (3x)
+    fe_select(t.f, dmc, dpc, neg);
+    fe_select(t.g, dpc, dmc, neg);
+}
+BP_HD void ge_add_cached_back(ge_ext &r, const ge_efgh &t) {
+    fe_mul(r.X, t.f, t.e);
+    fe_mul(r.Y, t.h, t.g);
+    fe_mul(r.Z, t.f, t.g);
+    fe_mul(r.T, t.h, t.e);
+}
+
 // mixed addition with an affine Niels point: 7M
 BP_HD void ge_madd(ge_ext &r, const ge_ext &p, const ge_niels &q, bool neg) {
     fe ypx, ymx, a, b, c, d, qa, qb;

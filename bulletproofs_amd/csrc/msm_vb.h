@@ -240,14 +240,28 @@ BP_HD void vb_window_wide_thread(uint32_t tid, uint32_t U, uint32_t k0, const ge
     const uint32_t msm = tid / nw, w = tid - msm * nw;
     ge_ext acc;
     ge_identity(acc);
+    // software-pipelined without extra registers: the table entry of point k+1 is requested between the two halves of the addition of
+    // point k, into the registers the first half has just released
+    const uint64_t t0 = (uint64_t)msm * U;
+    int d = 0;
+    ge_cached q;
+    if (k0 < U) {
+        d = R5 ? sc_digit32(recoded + 8 * (t0 + k0), w) : sc_digit16(recoded + 8 * (t0 + k0), (int)w);
+        const int a = d < 0 ? -d : d;
+        q = tab[ne * (t0 + k0) + (a ? a - 1 : 0)];
+    }
     for (uint32_t k = k0; k < U; k++) {
-        const uint64_t t = (uint64_t)msm * U + k;
-        const int d = R5 ? sc_digit32(recoded + 8 * t, w) : sc_digit16(recoded + 8 * t, (int)w);
-        if (d != 0) {
-            const int a = d < 0 ? -d : d;
-            const ge_cached q = tab[ne * t + (a - 1)];
-            ge_add_cached(acc, acc, q, d < 0);
+        ge_efgh mid;
+        const bool on = d != 0;
+        if (on) ge_add_cached_front(mid, acc, q, d < 0);
+        int dn = 0;
+        if (k + 1 < U) {
+            dn = R5 ? sc_digit32(recoded + 8 * (t0 + k + 1), w) : sc_digit16(recoded + 8 * (t0 + k + 1), (int)w);
+            const int a = dn < 0 ? -dn : dn;
+            q = tab[ne * (t0 + k + 1) + (a ? a - 1 : 0)];
         }
+        if (on) ge_add_cached_back(acc, mid);
+        d = dn;
     }
     ge_cached cc;
     ge_to_cached(cc, acc);

@@ -78,7 +78,8 @@ struct bpgpu_pool {
     std::vector<pool_dev *> devs;
     std::mutex mu;        // serialises the pool's own state (pending lists, options); lane contexts have their own locks
     std::string err;
-    size_t coalesce_proofs = 5120;   // target width of a coalesced launch chain (20 x 1024 from idle: 4096 -> 5.15, 5120 -> 5.5, 6912 -> 5.3, 10240 -> 5.2 M/s)
+    size_t coalesce_proofs = 5120;   // target width of a coalesced launch chain
+    size_t pair_limit_proofs = 24576;   // a flush of up to this many proofs is issued as at most two chains (flush_dev)
     size_t max_chain_proofs = 16384; // never wider than this (arena of a lane: ~55 KB per proof)
     size_t slice_proofs = 0;         // host-pointer calls: proofs per slice (0 = automatic)
     size_t auto_flush_items = 0;     // flush by itself once this many items wait on a device (0 = lanes)
@@ -196,6 +197,11 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
         p->slice_proofs = (size_t)value;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "pair_limit_proofs")) {
+        if (value < 0 || value > (1 << 24)) return pfail(p, BPGPU_ERR_INVALID_ARG, "pair_limit_proofs out of range");
+        p->pair_limit_proofs = (size_t)value;
+        return BPGPU_OK;
+    }
     if (!strcmp(key, "auto_flush_items")) {
         if (value < 0 || value > (1 << 20)) return pfail(p, BPGPU_ERR_INVALID_ARG, "auto_flush_items out of range");
         p->auto_flush_items = (size_t)value;
@@ -228,6 +234,7 @@ int bpgpu_pool_get_option(bpgpu_pool *p, const char *key, int64_t *value) {
     else if (!strcmp(key, "max_chain_proofs")) *value = (int64_t)p->max_chain_proofs;
     else if (!strcmp(key, "slice_proofs")) *value = (int64_t)p->slice_proofs;
     else if (!strcmp(key, "auto_flush_items")) *value = (int64_t)p->auto_flush_items;
+    else if (!strcmp(key, "pair_limit_proofs")) *value = (int64_t)p->pair_limit_proofs;
     else if (!strcmp(key, "host_workers")) *value = (int64_t)p->host_workers;
     else if (!strcmp(key, "stat_chains")) *value = (int64_t)p->stat_chains;
     else if (!strcmp(key, "stat_chain_proofs")) *value = (int64_t)p->stat_chain_proofs;
@@ -398,6 +405,10 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d) {
     // number of chains: about T / coalesce_proofs, at most one per lane; a chain takes consecutive items of one shape
     size_t G = (T + p->coalesce_proofs / 2) / p->coalesce_proofs;
     if (G < 1) G = 1;
+    // a burst that fits two chains takes two: with the one-lane Horner chains aside, 20 x 1024 from idle measured 5.6 / 5.6 / 5.8 M/s as four
+    // chains of 5120 and 5.9 ... 6.2 / 5.7 ... 5.8 / 6.0 as two of 10240 on three boxes; 40 x 1024 prefers eight of 5120 (6.05 against 5.85 as
+    // four of 10240), 8 x 1024 two of 4096 (4.7 against 4.3 ... 4.6 as one) -- profiles/r03/coalesce_sweep_after_horner_aside.txt
+    if (G > 2 && T <= p->pair_limit_proofs) G = 2;
     if (G > d->lanes.size()) G = d->lanes.size();
     size_t per = (T + G - 1) / G;
     if (per > p->max_chain_proofs) per = p->max_chain_proofs;
