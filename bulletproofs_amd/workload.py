@@ -59,16 +59,20 @@ def reference_point_ops(N):
     return cols * (N + 2 ** w - 2) + 256
 
 
-def executed_point_ops(n, m, window_bits, nsplit):
+def executed_point_ops(n, m, window_bits, nsplit, wide=True):
     """Point additions + doublings this engine performs per verification: one mixed addition per (generator,
     window) of the table walk, `nsplit` additions to fold the per-split partial sums, per unique point 7 operations for its
-    {1..8}P table and one addition in each of the 64 radix-16 windows (plus the column sums over chunks of 32 points when
-    there are more), and one Horner chain of 252 doublings + 63 additions."""
+    {1..8}P table and one addition in each of the 64 radix-16 windows, and one Horner chain of 252 doublings + 64 additions.
+    wide (chains of >= 2048 proofs, what the pool issues): A -- coefficient 1 -- has no table and no window sums, it is one addition
+    after the chain; narrow chains: A like every other point, plus the column sums over chunks of 32 points when there are more."""
     k = (n * m).bit_length() - 1
     U = 4 + 2 * k + m
     nwin = -(-255 // window_bits)
+    walk = (2 * n * m + 2) * nwin + nsplit
+    if wide:
+        return walk + (U - 1) * (7 + 64) + 1 + 252 + 64
     chunks = -(-U // 32)
-    return (2 * n * m + 2) * nwin + nsplit + U * 7 + U * 64 + (chunks - 1) * 64 + 252 + 63
+    return walk + U * (7 + 64) + (chunks - 1) * 64 + 252 + 63
 
 
 def algorithmic_bytes_per_verification(n, m):

@@ -25,6 +25,7 @@ pmc() {  # name, counter list (quoted), args...
 stats bench_default $B
 stats bench_steps20 $B --steps 20 --warmup 5
 stats bench_streams1 $B --direct --streams 1 --steps 256 --warmup 16
+stats bench_wide_chain_alone $B --direct --streams 1 --batch 5120 --steps 64 --warmup 8
 stats bench_cfg3 $B --config cfg3 --steps 640 --warmup 64
 stats bench_cfg5 python $REPO/bench.py --cfg5-only 8
 
@@ -32,9 +33,15 @@ stats bench_cfg5 python $REPO/bench.py --cfg5-only 8
 python $REPO/tools/pool_rate.py burst steady host > $OUT/pool_rate.txt 2>&1
 bash $REPO/tools/ct_counters.sh > $OUT/prover_constant_time_counters.txt 2>&1
 $REPO/tools/microbench_gather > $OUT/microbench_gather.txt 2>&1
+# the two bench lines as the driver runs them (not under the profiler)
+python $REPO/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
+python $REPO/bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
 
+# counters of the WIDE chain form (what the pool issues: >= 2048 proofs per launch chain -- one-lane Horner chain aside, window sums as
+# their own launch, A outside the window sums), one stream, no pool
+declare -A WIDE=( [cfg2]=5120 [cfg3]=2048 [cfg4]=2048 )
 for cfg in cfg2 cfg3 cfg4; do
-  A="$B --direct --config $cfg --steps 8 --warmup 2 --streams 1"
+  A="$B --direct --config $cfg --batch ${WIDE[$cfg]} --steps 6 --warmup 2 --streams 1"
   pmc ${cfg}_fetch FETCH_SIZE $A
   pmc ${cfg}_write WRITE_SIZE $A
   pmc ${cfg}_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" $A
@@ -45,11 +52,13 @@ pmc cfg5_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" python $REPO/b
 
 python - <<PY
 import csv, collections, json, glob, re
+LABEL = {"vb_window_wide": "rp_stage3w", "vb_window_colc": "rp_stage3w", "rp_horner_wide": "rp_horner1"}   # kernel -> the library's launch label (bench.py's names)
 def short(name):
     n = name.split("(")[0].strip()
     n = re.sub(r"^void\s+", "", n)
     n = re.sub(r"<.*$", "", n)
-    return n[2:] if n.startswith("k_") else n
+    n = n[2:] if n.startswith("k_") else n
+    return LABEL.get(n, n)
 def per_kernel(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
     acc = collections.defaultdict(lambda: [0, 0.0])
@@ -58,9 +67,9 @@ def per_kernel(d, counter):
         k = short(r["Kernel_Name"])
         acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"])
     return {k: {"dispatches": v[0], "avg_per_dispatch": v[1] / v[0]} for k, v in acc.items()}
-for cfg, what, ppl in (("cfg2", "bench.py --direct --config cfg2 --steps 8 --warmup 2 --streams 1 (batch 1024)", 1024),
-                  ("cfg3", "bench.py --direct --config cfg3 --steps 8 --warmup 2 --streams 1 (batch 256)", 256),
-                  ("cfg4", "bench.py --direct --config cfg4 --steps 8 --warmup 2 --streams 1 (batch 512)", 512),
+for cfg, what, ppl in (("cfg2", "bench.py --direct --config cfg2 --batch 5120 --steps 6 --warmup 2 --streams 1 (one wide chain per step)", 5120),
+                  ("cfg3", "bench.py --direct --config cfg3 --batch 2048 --steps 6 --warmup 2 --streams 1 (one wide chain per step)", 2048),
+                  ("cfg4", "bench.py --direct --config cfg4 --batch 2048 --steps 6 --warmup 2 --streams 1 (one wide chain per step)", 2048),
                   ("cfg5", "bench.py --cfg5-only 1 (batches of 64 MSMs of 6179 terms)", 64)):
     rd, wr = per_kernel("/tmp/pm_%s_fetch" % cfg, "FETCH_SIZE"), per_kernel("/tmp/pm_%s_write" % cfg, "WRITE_SIZE")
     json.dump({"FETCH_SIZE": rd, "WRITE_SIZE": wr}, open("$OUT/pmc_fetch_write_raw_%s.json" % cfg, "w"), indent=1)
@@ -73,7 +82,7 @@ for cfg, what, ppl in (("cfg2", "bench.py --direct --config cfg2 --steps 8 --war
         traffic[k] = int(2 * rd[k]["avg_per_dispatch"] * 1024 + wr.get(k, {"avg_per_dispatch": 0})["avg_per_dispatch"] * 1024)
     json.dump(traffic, open("$OUT/pmc_traffic_%s.json" % cfg, "w"), indent=1)
     va = per_kernel("/tmp/pm_%s_valu" % cfg, "SQ_INSTS_VALU")
-    work = {"_note": "SQ_INSTS_VALU per launch (wavefront-instructions), rocprofv3 --pmc pass of %s, tools/collect_profiles.sh; one batch = one launch of "
+    work = {"_note": "SQ_INSTS_VALU per launch (wavefront-instructions), rocprofv3 --pmc pass of %s, tools/collect_profiles.sh; one chain = one launch of "
             "each rp_* / finish8 kernel" % what, "_mad_u64_fraction": 0.58, "_proofs_per_launch": ppl}
     for k in va: work[k] = int(va[k]["avg_per_dispatch"])
     json.dump(work, open("$OUT/valu_work_%s.json" % cfg, "w"), indent=1)
