@@ -91,6 +91,12 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
  *                           second stream beside the table walk), 4 (a quad per proof: twice the instructions, half the latency),
  *                           64 (one wavefront per chain: lowest latency of a single small batch),
  *                           0 = auto (default): 1 on chains of >= 2048 proofs, 4 below
+ *   "a_outside"             1 (default): on chains of >= 2048 proofs A, whose coefficient is 1, is added after the Horner chain instead of
+ *                           going through a table and the window sums; 0: like every other point (for A/B)
+ *   "per_proof_radix"       radix of the proofs' own points: 0 / 16 (default), 32 (16-entry tables, 51 windows; takes effect on chains
+ *                           of >= 2048 proofs; measured +1 % steady, -4 % on bursts)
+ *   "split_stage3"          -1 (default): the window sums as their own launch on chains of >= 2048 proofs; 0 / 1: never / always
+ *   "split_stage1"          1..3: point decoding as its own launch on the second stream (experiment, default 0)
  * get_option additionally answers "fixed_table_bytes" and the effective "fixed_window_bits".
  * Returns BPGPU_ERR_INVALID_ARG for unknown keys. */
 int bpgpu_ctx_set_option(bpgpu_ctx *ctx, const char *key, int64_t value);
