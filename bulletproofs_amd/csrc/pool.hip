@@ -83,6 +83,7 @@ struct bpgpu_pool {
     size_t max_chain_proofs = 16384; // never wider than this (arena of a lane: ~55 KB per proof)
     size_t slice_proofs = 0;         // host-pointer calls: proofs per slice (0 = automatic)
     size_t auto_flush_items = 0;     // flush by itself once this many items wait on a device (0 = lanes)
+    size_t auto_flush_proofs = 0;    // ... or once this many proofs wait: they go out as ONE chain while the caller keeps submitting (0 = off)
     size_t host_workers = 0;
     // statistics of the coalesced path (get_option "stat_chains" / "stat_chain_proofs" / "stat_last_splits"; set "stat_reset")
     uint64_t stat_chains = 0, stat_chain_proofs = 0, stat_last_splits = 0;
@@ -202,6 +203,11 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
         p->pair_limit_proofs = (size_t)value;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "auto_flush_proofs")) {
+        if (value < 0 || value > (1 << 22)) return pfail(p, BPGPU_ERR_INVALID_ARG, "auto_flush_proofs out of range");
+        p->auto_flush_proofs = (size_t)value;
+        return BPGPU_OK;
+    }
     if (!strcmp(key, "auto_flush_items")) {
         if (value < 0 || value > (1 << 20)) return pfail(p, BPGPU_ERR_INVALID_ARG, "auto_flush_items out of range");
         p->auto_flush_items = (size_t)value;
@@ -234,6 +240,7 @@ int bpgpu_pool_get_option(bpgpu_pool *p, const char *key, int64_t *value) {
     else if (!strcmp(key, "max_chain_proofs")) *value = (int64_t)p->max_chain_proofs;
     else if (!strcmp(key, "slice_proofs")) *value = (int64_t)p->slice_proofs;
     else if (!strcmp(key, "auto_flush_items")) *value = (int64_t)p->auto_flush_items;
+    else if (!strcmp(key, "auto_flush_proofs")) *value = (int64_t)p->auto_flush_proofs;
     else if (!strcmp(key, "pair_limit_proofs")) *value = (int64_t)p->pair_limit_proofs;
     else if (!strcmp(key, "host_workers")) *value = (int64_t)p->host_workers;
     else if (!strcmp(key, "stat_chains")) *value = (int64_t)p->stat_chains;
@@ -389,7 +396,7 @@ int bpgpu_pool_rangeproof_verify(bpgpu_pool *p, size_t n, size_t m, size_t nbatc
 }
 
 // ---- device pointers, asynchronous ------------------------------------------------------------------------------
-static int flush_dev(bpgpu_pool *p, pool_dev *d) {
+static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain = false) {
     if (d->pending.empty()) return BPGPU_OK;
     std::vector<dev_item> items;
     items.swap(d->pending);
@@ -409,6 +416,7 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d) {
     // chains of 5120 and 5.9 ... 6.2 / 5.7 ... 5.8 / 6.0 as two of 10240 on three boxes; 40 x 1024 prefers eight of 5120 (6.05 against 5.85 as
     // four of 10240), 8 x 1024 two of 4096 (4.7 against 4.3 ... 4.6 as one) -- profiles/r03/coalesce_sweep_after_horner_aside.txt
     if (G > 2 && T <= p->pair_limit_proofs) G = 2;
+    if (one_chain) G = 1;   // a chain's worth has accumulated while the caller is still submitting: it goes out now, as it is
     if (G > d->lanes.size()) G = d->lanes.size();
     size_t per = (T + G - 1) / G;
     if (per > p->max_chain_proofs) per = p->max_chain_proofs;
@@ -496,6 +504,7 @@ int bpgpu_pool_rangeproof_submit_dev(bpgpu_pool *p, int dev_index, size_t n, siz
     d->pending_proofs += nbatch;
     const size_t limit = p->auto_flush_items ? p->auto_flush_items : d->lanes.size();
     if (d->pending.size() >= limit) return flush_dev(p, d);
+    if (p->auto_flush_proofs && d->pending_proofs >= p->auto_flush_proofs) return flush_dev(p, d, true);
     return BPGPU_OK;
 }
 

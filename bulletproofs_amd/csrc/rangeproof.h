@@ -66,9 +66,10 @@ BP_HD uint32_t rp_seg_find(const rp_seg *segs, uint32_t nseg, uint32_t p) {
     return lo;
 }
 // The table as the kernels get it, BY VALUE in their argument block: up to RP_SEG_INLINE items inline (the usual case: a few
-// batches of ~1024 proofs per chain -- no upload, no extra copy command in the stream), more through `ext` (device memory).
+// batches of ~1024 proofs per chain -- no upload, no extra copy command in the stream: 16 x 48 bytes of the argument block), more
+// through `ext` (device memory).
 // n == 0: not a coalesced launch.
-#define RP_SEG_INLINE 8
+#define RP_SEG_INLINE 16
 struct rp_seg_tab {
     const rp_seg *ext;
     uint32_t n, pad;

@@ -433,7 +433,8 @@ int bpgpu_ipp_verification_scalars(bpgpu_ctx *ctx, size_t n, size_t nbatch, cons
  * is loaded if the variable is unset (the ROCm runtime reads it at the process's first HIP call); bpgpu_pool_create
  * returns BPGPU_ERR_HW_QUEUES when it finds another value.
  * Options (bpgpu_pool_set_option): "coalesce_proofs", "max_chain_proofs" (default 16384), "pair_limit_proofs" (default 24576: a flush
- * of up to this many proofs is issued as at most two chains), "auto_flush_items",
+ * of up to this many proofs is issued as at most two chains), "auto_flush_items", "auto_flush_proofs" (default 0 = off: once this many
+ * proofs wait they leave as one chain while the caller keeps submitting; measured neutral on 20 x 1024 bursts),
  * "slice_proofs" (host-pointer calls; 0 = automatic: 2048..4096 proofs per slice),
  * "host_workers" (threads per device for host-pointer calls, default 2; each drives its share of the lanes asynchronously); any other key is forwarded
  * to every lane context (set those before bpgpu_pool_gens_*).  Read-only statistics of the coalesced path:

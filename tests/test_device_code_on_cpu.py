@@ -361,7 +361,7 @@ def test_coalesced_launch_segment_table_lane_by_lane(H, oracle, golden):
     case = [c for c in golden["cases"] if c["n"] == 8 and c["m"] == 2][0]
     n, m = 8, 2
     pr = bytes.fromhex(case["proof"])
-    nb = 11
+    nb = 19
     plist = []
     for b in range(nb):
         q = bytearray(pr)
@@ -376,8 +376,8 @@ def test_coalesced_launch_segment_table_lane_by_lane(H, oracle, golden):
     gg = oracle.Gens(n, m)
     G2, H2, B2, Bb2 = gg.export()
     exp = [oracle.verify(gg, plist[b], coms[32 * m * b:32 * m * (b + 1)], n, label, rng[64 * b:64 * b + 64]) for b in range(nb)]
-    assert [e[0] for e in exp] == [0, 0, 1, 0, 2, 1, 1, 0, 0, 0, 0]
-    for sizes in ([], [1] * 11, [1, 1, 1, 1, 1, 1, 1, 4], [3, 8], [2, 1, 3, 1, 4], [10, 1], [11]):   # > 8 items: table in memory, else inline
+    assert [e[0] for e in exp] == [0, 0, 1, 0, 2, 1, 1] + [0] * 12
+    for sizes in ([], [1] * 19, [1] * 15 + [4], [3, 16], [2, 1, 3, 1, 12], [18, 1], [19]):   # > 16 items: table in memory, else inline
         H.h_set_segments(len(sizes), (C.c_uint32 * max(len(sizes), 1))(*sizes))
         vd, mo = C.create_string_buffer(nb), C.create_string_buffer(32 * nb)
         assert H.h_rp_verify(4, 3, n, m, Bb2 + B2 + G2 + H2, n, m, nb, proofs, len(pr), coms, label, len(label), rng, vd, mo) == 0

@@ -247,3 +247,40 @@ def test_pool_shared_by_threads_host_and_device_paths_mixed(oracle, cfg2):
     assert not any(t.is_alive() for t in ths), "deadlock"
     assert errors == []
     pool.close()
+
+
+def test_pool_many_small_items_in_one_chain_and_flush_by_proofs(oracle, cfg2):
+    """40 submitted batches of 53 proofs each: one flush packs them into chains of up to 40 segments (more than the 16 that travel in
+    the kernels' argument blocks: the segment table goes through device memory); then the same with auto_flush_proofs = 1000 (a chain
+    leaves as soon as 1000 proofs wait, while the caller is still submitting).  Every batch's verdicts == oracle, chain counts as designed."""
+    import torch
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    fx = cfg2
+    dev = torch.device("cuda", 0)
+    pool = bp.Pool((0,), 8, fixed_window_bits=16)
+    pool.set_option("auto_flush_items", 1000)
+    pool.gens_create(64, 1)
+    gens = oracle.Gens(64, 1)
+    K, nb = 40, 53
+    proofs, coms = wl.tile_batch(fx, K * nb, first=4000)
+    proofs, coms, bad = _tamper(proofs, coms, fx.proof_len, fx.m, K * nb, 7, frac=0.04)
+    rng = hashlib.shake_256(b"small-items").digest(64 * K * nb)
+    ev, _ = _oracle_all(oracle, gens, fx, proofs, coms, rng)
+    to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_p, d_c, d_r = to_dev(proofs), to_dev(coms), to_dev(rng)
+    d_v = torch.full((K, nb), 255, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    for afp, chains in ((0, 1), (1000, 3)):     # 2120 proofs: one chain (coalesce_proofs 5120) / 1007 + 1007 by the proof count + the rest at the flush
+        pool.set_option("auto_flush_proofs", afp)
+        pool.set_option("stat_reset", 1)
+        for k in range(K):
+            pool.submit_dev(0, fx.n, fx.m, nb, d_p.data_ptr() + k * nb * fx.proof_len, fx.proof_len, d_c.data_ptr() + k * nb * 32, fx.label,
+                            d_r.data_ptr() + k * nb * 64, d_v[k].data_ptr())
+        pool.wait()
+        assert bytes(d_v.cpu().numpy().reshape(-1)) == ev
+        assert pool.get_option("stat_chains") == chains and pool.get_option("stat_chain_proofs") == K * nb
+        d_v.fill_(255)
+        torch.cuda.synchronize()
+    assert sum(1 for v in ev if v) == len(bad)
+    pool.close()
