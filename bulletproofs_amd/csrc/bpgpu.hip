@@ -56,7 +56,7 @@ struct bpgpu_ctx {
     uint32_t splits_hint = 0;                // per-call suggestion of the pool (pick_splits), used when `splits` is 0
     uint32_t vb_radix = 0;                   // radix of the proofs' own points in the range-proof path: 16, 32 (wide chains only), 0 = default (16)
     int a_outside = 1;                       // wide chains: A (coefficient 1) added after the Horner chain instead of carried through the window sums
-    uint32_t horner_lanes = 0;               // lanes per Horner chain in the range-proof path: 1, 4, 64, 0 = auto (1 on wide chains, else 4)
+    uint32_t horner_lanes = 0;               // lanes per Horner chain in the range-proof path: 1, 4, 64, 0 = auto (1 on wide chains, 64 up to 256 proofs, else 4)
     struct shared_table *tab_ref = nullptr;  // refcounted, shared by the contexts of one device
     // generators
     size_t gens_capacity = 0, party_capacity = 0;
@@ -1622,7 +1622,9 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     }
     // Horner layout: quads (16 chains per wavefront, least total work) unless the caller asked for the
     // wavefront-per-chain variant (lowest latency of a single small batch)
-    const bool quad = c->horner_lanes != 64;          // column sums as cached points (both the quad and the one-lane chain read them)
+    // a small batch alone is a latency matter: one wavefront per chain (0.61 instead of 0.85 ms for a single proof, tools/latency_probe.py)
+    const bool wave = c->horner_lanes == 64 || (c->horner_lanes == 0 && nbatch <= 256);
+    const bool quad = !wave;                          // column sums as cached points (both the quad and the one-lane chain read them)
     const bool one_lane = c->horner_lanes == 1;
     ge_cached *d_colc = quad ? (ge_cached *)d.colq16 : nullptr;
     const uint32_t n_tr = (nb32 + RP_BLOCK - 1) / RP_BLOCK;
