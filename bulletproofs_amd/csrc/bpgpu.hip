@@ -54,6 +54,7 @@ struct bpgpu_ctx {
                                              // +3 / +5 / +8 % over the 96 GiB of rounds 1-2, profiles/r03/window_sweep.txt); halved automatically when the allocation fails
     uint32_t splits = 0;
     uint32_t splits_hint = 0;                // per-call suggestion of the pool (pick_splits), used when `splits` is 0
+    int busy_hint = -1;                      // set by the pool per chain: 1 = other chains run beside this one (throughput forms), 0 = it is alone (latency), -1 = unknown
     uint32_t vb_radix = 0;                   // radix of the proofs' own points in the range-proof path: 16, 32 (wide chains only), 0 = default (16)
     int a_outside = 1;                       // wide chains: A (coefficient 1) added after the Horner chain instead of carried through the window sums
     uint32_t horner_lanes = 0;               // lanes per Horner chain in the range-proof path: 1, 4, 64, 0 = auto (1 on wide chains, 64 up to 256 proofs, else 4)
@@ -1505,7 +1506,11 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     // wide per-proof chains (see launch 3 below): window sums as their own launch, the one-lane Horner chain aside on the second stream,
     // and the proofs' own points in signed radix 32 with A (coefficient 1) outside the window sums
     const bool wide = !rlc && !shape_verdict && (c->split_stage3 == 1 || (c->split_stage3 < 0 && nbatch >= 2048));
-    const bool aside = wide && c->horner_lanes != 4 && c->horner_lanes != 64 && s != c->stream2;
+    // The one-lane Horner chain needs other work beside it (its 0.76 ms are hidden behind the walk of THIS chain only from ~8000 proofs):
+    // a chain alone on the device keeps the quad form -- one host call of 2048 / 4096 proofs: 1.89 / 2.73 M/s against 1.49 / 2.29 with the
+    // one-lane form, equal at 8192, 4.9 against 5.0 at 16384 (profiles/r03/host_call_horner_forms.txt).  The pool says which it is.
+    const bool throughput = c->busy_hint > 0 || (c->busy_hint < 0 && nbatch >= 8192);
+    const bool aside = wide && s != c->stream2 && (c->horner_lanes == 1 || (c->horner_lanes == 0 && throughput));
     const bool r5 = aside && c->vb_radix == 32;
     const bool a_out = aside && c->a_outside != 0;
     sh.radix5 = r5 ? 1u : 0u;
@@ -1836,6 +1841,11 @@ bool bpgpu_internal_idle(bpgpu_ctx *c) {
     const hipError_t e = hipStreamQuery(c->stream);
     if (e != hipSuccess) (void)hipGetLastError();   // hipErrorNotReady is not an error
     return e == hipSuccess;
+}
+// what the pool knows about the chains it is about to issue on this context: 1 = others run beside them, 0 = alone, -1 = forget
+void bpgpu_internal_set_busy_hint(bpgpu_ctx *c, int busy) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->busy_hint = busy;
 }
 // one coalesced launch chain over the concatenation of `nseg` items, on the context's own stream (asynchronous)
 int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, const uint8_t *label, size_t label_len, const rp_seg *segs,

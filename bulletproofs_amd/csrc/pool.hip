@@ -33,6 +33,7 @@ using namespace bp;
 
 bool bpgpu_internal_rp_coalescible(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len);
 bool bpgpu_internal_idle(bpgpu_ctx *c);
+void bpgpu_internal_set_busy_hint(bpgpu_ctx *c, int busy);
 int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, const uint8_t *label, size_t label_len, const rp_seg *segs,
                                   uint32_t nseg, bool any_msm, uint32_t splits_hint);
 
@@ -82,6 +83,7 @@ struct bpgpu_pool {
     size_t pair_limit_proofs = 24576;   // a flush of up to this many proofs is issued as at most two chains (flush_dev)
     size_t max_chain_proofs = 16384; // never wider than this (arena of a lane: ~55 KB per proof)
     size_t slice_proofs = 0;         // host-pointer calls: proofs per slice (0 = automatic)
+    size_t latency_proofs = 6144;    // a host call / a flush on an idle device of up to this many proofs is "alone": its chains take the latency forms
     size_t auto_flush_items = 0;     // flush by itself once this many items wait on a device (0 = lanes)
     size_t auto_flush_proofs = 0;    // ... or once this many proofs wait: they go out as ONE chain while the caller keeps submitting (0 = off)
     size_t host_workers = 0;
@@ -203,6 +205,11 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
         p->pair_limit_proofs = (size_t)value;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "latency_proofs")) {
+        if (value < 0 || value > (1 << 24)) return pfail(p, BPGPU_ERR_INVALID_ARG, "latency_proofs out of range");
+        p->latency_proofs = (size_t)value;
+        return BPGPU_OK;
+    }
     if (!strcmp(key, "auto_flush_proofs")) {
         if (value < 0 || value > (1 << 22)) return pfail(p, BPGPU_ERR_INVALID_ARG, "auto_flush_proofs out of range");
         p->auto_flush_proofs = (size_t)value;
@@ -241,6 +248,7 @@ int bpgpu_pool_get_option(bpgpu_pool *p, const char *key, int64_t *value) {
     else if (!strcmp(key, "slice_proofs")) *value = (int64_t)p->slice_proofs;
     else if (!strcmp(key, "auto_flush_items")) *value = (int64_t)p->auto_flush_items;
     else if (!strcmp(key, "auto_flush_proofs")) *value = (int64_t)p->auto_flush_proofs;
+    else if (!strcmp(key, "latency_proofs")) *value = (int64_t)p->latency_proofs;
     else if (!strcmp(key, "pair_limit_proofs")) *value = (int64_t)p->pair_limit_proofs;
     else if (!strcmp(key, "host_workers")) *value = (int64_t)p->host_workers;
     else if (!strcmp(key, "stat_chains")) *value = (int64_t)p->stat_chains;
@@ -335,6 +343,9 @@ int bpgpu_pool_rangeproof_verify(bpgpu_pool *p, size_t n, size_t m, size_t nbatc
             if (S > 4096) S = 4096;
         }
         const size_t W = d->workers.size(), n_slices = (hi - lo + S - 1) / S;
+        // a call of a few thousand proofs is one or two chains alone on the device: latency forms; a large one keeps the device full
+        const int busy = (hi - lo) > p->latency_proofs ? 1 : 0;
+        for (bpgpu_ctx *lc : d->lanes) bpgpu_internal_set_busy_hint(lc, busy);
         for (size_t w = 0; w < W && w < n_slices; w++) {
             // worker w: slices w, w + W, ...  on lanes w, w + W, ... (a lane always sees the same slice widths: its buffers are sized once)
             auto job = [=, &st](bpgpu_ctx *) {
@@ -402,12 +413,14 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain = false) {
     items.swap(d->pending);
     const size_t T = d->pending_proofs;
     d->pending_proofs = 0;
+    bool was_idle = false;
     // an idle pool starts again at lane 0: a caller that sends bursts keeps hitting the same few lanes, whose arenas and cached
     // work decompositions already have the right size
     {
         bool idle = true;
         for (size_t l = 0; l < d->used_lanes && idle; l++) idle = bpgpu_internal_idle(d->lanes[l]);
         if (idle) d->next_lane = d->used_lanes = 0;
+        was_idle = idle;
     }
     // number of chains: about T / coalesce_proofs, at most one per lane; a chain takes consecutive items of one shape
     size_t G = (T + p->coalesce_proofs / 2) / p->coalesce_proofs;
@@ -468,6 +481,7 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain = false) {
                 off = 0;
             }
         }
+        bpgpu_internal_set_busy_hint(c, (was_idle && T <= p->latency_proofs) ? 0 : 1);
         const int rc = bpgpu_internal_rp_verify_segs(c, head.n, head.m, head.proof_len, (const uint8_t *)head.label.data(), head.label.size(), segs.data(),
                                                      (uint32_t)segs.size(), any_msm, hint);
         if (rc && !rc_all) rc_all = pfail(p, rc, "%s", bpgpu_last_error(c));

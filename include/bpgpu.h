@@ -90,8 +90,9 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
  *                           1 (one lane per proof: least work, longest chain; on chains of >= 2048 proofs it runs on the context's
  *                           second stream beside the table walk), 4 (a quad per proof: twice the instructions, half the latency),
  *                           64 (one wavefront per chain: lowest latency of a single small batch),
- *                           0 = auto (default): 1 on chains of >= 2048 proofs, 64 up to 256 proofs (a small batch alone is a latency
- *                           matter: 0.61 instead of 0.85 ms for a single proof), 4 in between
+ *                           0 = auto (default): 64 up to 256 proofs (a small batch alone is a latency matter: 0.61 instead of 0.85 ms
+ *                           for a single proof); 1 on chains of >= 8192 proofs, and on chains of >= 2048 when the pool knows that
+ *                           other chains run beside them; 4 otherwise
  *   "a_outside"             1 (default): on chains of >= 2048 proofs A, whose coefficient is 1, is added after the Horner chain instead of
  *                           going through a table and the window sums; 0: like every other point (for A/B)
  *   "per_proof_radix"       radix of the proofs' own points: 0 / 16 (default), 32 (16-entry tables, 51 windows; takes effect on chains
@@ -434,7 +435,8 @@ int bpgpu_ipp_verification_scalars(bpgpu_ctx *ctx, size_t n, size_t nbatch, cons
  * is loaded if the variable is unset (the ROCm runtime reads it at the process's first HIP call); bpgpu_pool_create
  * returns BPGPU_ERR_HW_QUEUES when it finds another value.
  * Options (bpgpu_pool_set_option): "coalesce_proofs", "max_chain_proofs" (default 16384), "pair_limit_proofs" (default 24576: a flush
- * of up to this many proofs is issued as at most two chains), "auto_flush_items", "auto_flush_proofs" (default 0 = off: once this many
+ * of up to this many proofs is issued as at most two chains), "latency_proofs" (default 6144: a host call, or a flush on an idle device, of
+ * up to this many proofs is alone on the device -- its chains keep the quad Horner form instead of the one-lane form), "auto_flush_items", "auto_flush_proofs" (default 0 = off: once this many
  * proofs wait they leave as one chain while the caller keeps submitting; measured neutral on 20 x 1024 bursts),
  * "slice_proofs" (host-pointer calls; 0 = automatic: 2048..4096 proofs per slice),
  * "host_workers" (threads per device for host-pointer calls, default 2; each drives its share of the lanes asynchronously); any other key is forwarded

@@ -25,7 +25,7 @@ pmc() {  # name, counter list (quoted), args...
 stats bench_default $B
 stats bench_steps20 $B --steps 20 --warmup 5
 stats bench_streams1 $B --direct --streams 1 --steps 256 --warmup 16
-stats bench_wide_chain_alone $B --direct --streams 1 --batch 5120 --steps 64 --warmup 8
+stats bench_wide_chain_alone $B --direct --streams 1 --batch 5120 --steps 64 --warmup 8 --opt horner_lanes=1
 stats bench_cfg3 $B --config cfg3 --steps 640 --warmup 64
 stats bench_cfg5 python $REPO/bench.py --cfg5-only 8
 
@@ -41,7 +41,7 @@ python $REPO/bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/be
 # their own launch, A outside the window sums), one stream, no pool
 declare -A WIDE=( [cfg2]=5120 [cfg3]=2048 [cfg4]=2048 )
 for cfg in cfg2 cfg3 cfg4; do
-  A="$B --direct --config $cfg --batch ${WIDE[$cfg]} --steps 6 --warmup 2 --streams 1"
+  A="$B --direct --config $cfg --batch ${WIDE[$cfg]} --steps 6 --warmup 2 --streams 1 --opt horner_lanes=1"   # (a lone context of this width would pick the quad chain)
   pmc ${cfg}_fetch FETCH_SIZE $A
   pmc ${cfg}_write WRITE_SIZE $A
   pmc ${cfg}_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" $A
