@@ -1,7 +1,10 @@
-import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+#!/usr/bin/env python3
+"""Dev tool: one host-pointer pool call of a few thousand proofs against slice width / Horner form (tools/pool_rate.py host_rates)."""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import pool_rate as pr
 from bulletproofs_amd import workload as wl
 fx = wl.load_fixture("cfg2_n64_m1")
-for hl in (0,):
-    pr.host_rates(fx, sizes=(1024, 2048, 4096, 6144, 16384, 65536), lanes=32, horner_lanes=hl)
+for opts in ({}, {"slice_proofs": 1024}, {"slice_proofs": 1408}, {"slice_proofs": 4096}, {"slice_proofs": 1024, "host_workers": 4}):
+    pr.host_rates(fx, sizes=(4096, 8192), lanes=32, **opts)
