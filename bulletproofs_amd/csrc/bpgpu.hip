@@ -1510,7 +1510,11 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     // a chain alone on the device keeps the quad form -- one host call of 2048 / 4096 proofs: 1.89 / 2.73 M/s against 1.49 / 2.29 with the
     // one-lane form, equal at 8192, 4.9 against 5.0 at 16384 (profiles/r03/host_call_horner_forms.txt).  The pool says which it is.
     const bool throughput = c->busy_hint > 0 || (c->busy_hint < 0 && nbatch >= 8192);
-    const bool aside = wide && s != c->stream2 && (c->horner_lanes == 1 || (c->horner_lanes == 0 && throughput));
+    // a small batch alone is a latency matter: one wavefront per chain (0.61 instead of 0.85 ms for a single proof, tools/latency_probe.py)
+    // ... and so is a chain the pool knows to be alone on the device: one host call of 1024 / 2048 / 4096 proofs (slices of <= 2048) 1.37 / 2.14 /
+    // 2.84 M/s against 1.12 / 1.93 / 2.66 with the quad form; at 6144 (slices of 3072) the quad form is ahead again
+    const bool wave = c->horner_lanes == 64 || (c->horner_lanes == 0 && (nbatch <= 256 || (c->busy_hint == 0 && nbatch <= 2304)));
+    const bool aside = wide && !wave && s != c->stream2 && (c->horner_lanes == 1 || (c->horner_lanes == 0 && throughput));
     const bool r5 = aside && c->vb_radix == 32;
     const bool a_out = aside && c->a_outside != 0;
     sh.radix5 = r5 ? 1u : 0u;
@@ -1627,10 +1631,6 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     }
     // Horner layout: quads (16 chains per wavefront, least total work) unless the caller asked for the
     // wavefront-per-chain variant (lowest latency of a single small batch)
-    // a small batch alone is a latency matter: one wavefront per chain (0.61 instead of 0.85 ms for a single proof, tools/latency_probe.py)
-    // ... and so is a chain the pool knows to be alone on the device: one host call of 1024 / 2048 / 4096 proofs (slices of <= 2048) 1.37 / 2.14 /
-    // 2.84 M/s against 1.12 / 1.93 / 2.66 with the quad form; at 6144 (slices of 3072) the quad form is ahead again
-    const bool wave = c->horner_lanes == 64 || (c->horner_lanes == 0 && (nbatch <= 256 || (c->busy_hint == 0 && nbatch <= 2304)));
     const bool quad = !wave;                          // column sums as cached points (both the quad and the one-lane chain read them)
     const bool one_lane = c->horner_lanes == 1;
     ge_cached *d_colc = quad ? (ge_cached *)d.colq16 : nullptr;
