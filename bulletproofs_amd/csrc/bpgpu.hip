@@ -1416,6 +1416,43 @@ struct rp_transcripts {
     void *d_ts_out = nullptr;
 };
 
+// ---- the forms a per-proof launch chain takes -----------------------------------------------------------------------------------
+// One decision table for what used to be scattered conditions.  Inputs: the context options (0 / -1 = automatic), what the pool
+// said about the chain (busy_hint: 1 = other chains run beside it, 0 = it is alone on the device, -1 = nobody said), its width.
+//   WIDE     (>= 2048 proofs, or split_stage3 = 1): the window sums are a launch of their own -- their register allocation instead of
+//            the generator-exponent role's 252 (+1.5 ... 3 %, profiles/r03/ab_split_stage3.txt).
+//   WAVE     one wavefront per Horner chain (horner_wave.h): a small batch alone is a latency matter -- up to 256 proofs always (one call
+//            0.85 -> 0.62 ms), up to 2304 when the pool knows the chain is alone (one host call of 1024 / 2048 / 4096 proofs, slices of
+//            <= 2048: 1.37 / 2.14 / 2.84 M/s against 1.12 / 1.93 / 2.66 with quads; at 6144, slices of 3072, quads are ahead again).
+//   ASIDE    one LANE per Horner chain, as its own launch on the context's second stream right after the window sums (half the quad
+//            form's instructions, twice its latency: 0.76 ms that need other work beside them).  Wide chains when other chains run beside
+//            them, or from 8192 proofs on a context nobody told anything: +2.6 ... 3.6 % steady state, +2 ... 4.6 % on 20 x 1024 bursts;
+//            a lone host call of 2048 / 4096 proofs loses 22 / 16 % with it (profiles/r03/ab_horner_one_lane.txt, host_call_horner_forms.txt).
+//   RADIX32  with ASIDE only, option per_proof_radix = 32: 16-entry tables, 51 windows (+1 % steady, -4.5 % bursts: off by default).
+//   A_OUTSIDE with ASIDE only: A, whose coefficient is 1, is added after the chain instead of going through a table and 64 windows.
+// Otherwise: four lanes per Horner chain inside launch 4 (horner_quad.h).  Batch-combined calls and shape verdicts take none of these.
+enum { RPC_WIDE = 1, RPC_WAVE = 2, RPC_ASIDE = 4, RPC_RADIX32 = 8, RPC_A_OUTSIDE = 16 };
+static uint32_t rp_chain_forms(uint32_t horner_lanes, int split_stage3, int busy_hint, uint32_t per_proof_radix, int a_outside, size_t nbatch,
+                               bool combined_or_verdict_only, bool on_second_stream) {
+    const bool wide = !combined_or_verdict_only && (split_stage3 == 1 || (split_stage3 < 0 && nbatch >= 2048));
+    const bool throughput = busy_hint > 0 || (busy_hint < 0 && nbatch >= 8192);
+    const bool wave = horner_lanes == 64 || (horner_lanes == 0 && (nbatch <= 256 || (busy_hint == 0 && nbatch <= 2304)));
+    const bool aside = wide && !wave && !on_second_stream && (horner_lanes == 1 || (horner_lanes == 0 && throughput));
+    uint32_t f = 0;
+    if (wide) f |= RPC_WIDE;
+    if (wave) f |= RPC_WAVE;
+    if (aside) f |= RPC_ASIDE;
+    if (aside && per_proof_radix == 32) f |= RPC_RADIX32;
+    if (aside && a_outside) f |= RPC_A_OUTSIDE;
+    return f;
+}
+// (for tests/test_abi_and_host.py: the table is plain host logic)
+extern "C" uint32_t bpgpu_internal_chain_forms(int64_t horner_lanes, int64_t split_stage3, int64_t busy_hint, int64_t per_proof_radix, int64_t a_outside,
+                                               uint64_t nbatch, int combined_or_verdict_only, int on_second_stream) {
+    return rp_chain_forms((uint32_t)horner_lanes, (int)split_stage3, (int)busy_hint, (uint32_t)per_proof_radix, (int)a_outside, (size_t)nbatch,
+                          combined_or_verdict_only != 0, on_second_stream != 0);
+}
+
 static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
                                 const void *d_commitments, const rp_transcripts &tr, const void *d_rng64, void *d_verdict,
                                 void *d_msm_out, hipStream_t s, bool rlc = false, const void *d_weights64 = nullptr,
@@ -1503,20 +1540,10 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const size_t rlc_terms = (size_t)nbatch * sh.U;
     const bk_params bkp = bk_make(pick_bucket_c(rlc_terms));
     const bool rlc_bucket = rlc && !shape_verdict && rlc_terms >= (c->bucket_min ? c->bucket_min : BK_RLC_MIN_TERMS) && bucket_fits(1, rlc_terms, bkp);
-    // wide per-proof chains (see launch 3 below): window sums as their own launch, the one-lane Horner chain aside on the second stream,
-    // and the proofs' own points in signed radix 32 with A (coefficient 1) outside the window sums
-    const bool wide = !rlc && !shape_verdict && (c->split_stage3 == 1 || (c->split_stage3 < 0 && nbatch >= 2048));
-    // The one-lane Horner chain needs other work beside it (its 0.76 ms are hidden behind the walk of THIS chain only from ~8000 proofs):
-    // a chain alone on the device keeps the quad form -- one host call of 2048 / 4096 proofs: 1.89 / 2.73 M/s against 1.49 / 2.29 with the
-    // one-lane form, equal at 8192, 4.9 against 5.0 at 16384 (profiles/r03/host_call_horner_forms.txt).  The pool says which it is.
-    const bool throughput = c->busy_hint > 0 || (c->busy_hint < 0 && nbatch >= 8192);
-    // a small batch alone is a latency matter: one wavefront per chain (0.61 instead of 0.85 ms for a single proof, tools/latency_probe.py)
-    // ... and so is a chain the pool knows to be alone on the device: one host call of 1024 / 2048 / 4096 proofs (slices of <= 2048) 1.37 / 2.14 /
-    // 2.84 M/s against 1.12 / 1.93 / 2.66 with the quad form; at 6144 (slices of 3072) the quad form is ahead again
-    const bool wave = c->horner_lanes == 64 || (c->horner_lanes == 0 && (nbatch <= 256 || (c->busy_hint == 0 && nbatch <= 2304)));
-    const bool aside = wide && !wave && s != c->stream2 && (c->horner_lanes == 1 || (c->horner_lanes == 0 && throughput));
-    const bool r5 = aside && c->vb_radix == 32;
-    const bool a_out = aside && c->a_outside != 0;
+    // which forms this chain takes (rp_chain_forms above: the decision table, with the measurements behind every line)
+    const uint32_t forms = rp_chain_forms(c->horner_lanes, c->split_stage3, c->busy_hint, c->vb_radix, c->a_outside, nbatch, rlc || shape_verdict != 0,
+                                          s == c->stream2);
+    const bool wide = forms & RPC_WIDE, wave = forms & RPC_WAVE, aside = forms & RPC_ASIDE, r5 = forms & RPC_RADIX32, a_out = forms & RPC_A_OUTSIDE;
     sh.radix5 = r5 ? 1u : 0u;
     sh.a_outside = a_out ? 1u : 0u;
     arena_plan ap;
@@ -1729,21 +1756,10 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         return BPGPU_OK;
     }
     const bool one_chunk = pd->n_chunks == nbatch;   // U <= 32: a chunk's window sums are the MSM's column sums
-    // Launch 3 holds two independent roles.  Fused into one kernel they share its register allocation -- 252 VGPRs, set by the
-    // generator-exponent role, i.e. two wavefronts per SIMD also for the window sums, whose table gathers are not prefetched.
-    // As two launches the window sums get their own 128 (four wavefronts per SIMD): +1.5 ... +3 % on wide chains (same-box A/B,
-    // profiles/r03/ab_split_stage3.txt); a narrow chain keeps the fused form (one launch fewer on its latency path).
-    // The Horner chain of a proof's own terms is 252 doublings + 64 additions in series.  Narrow chains give it a quad of lanes per
-    // proof (horner_quad.h: half the latency, twice the instructions).  Wide chains are bound by work, not by the latency of one proof:
-    // they take the one-lane form, and to keep its ~1 ms of dependent instructions off the chain's critical path it goes to the context's
-    // second stream as soon as the column sums exist, beside the generator exponents and the table walk (same-box A/B: 20-step bursts
-    // +4.6 %, steady state +2.6 %; inside launch 4 the one-lane form gained 3 % in steady state and LOST 4 % on bursts --
-    // profiles/r03/ab_horner_one_lane.txt).
+    // Launch 3 holds two independent roles -- window sums and generator exponents.  Narrow chains keep them fused (one launch fewer on the
+    // latency path); wide chains split them, and may move the Horner chains to the second stream (rp_chain_forms).
     bool horner_aside = false;
     if (wide) {
-        // radix 32 (option, off: 16-entry tables and 51 windows instead of 8 and 64 = 66 instead of 71 point operations per point, but
-        // 41 kB of tables per proof and a longer launch 1); A, whose coefficient is 1, added after the chain instead of carried through
-        // 64 windows and an 8-entry table
         const bool wide_sums = r5 || a_out;
         if (r5) {
             const uint32_t nw5 = nb32 * BP_VB5_WINDOWS;

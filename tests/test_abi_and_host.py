@@ -129,3 +129,36 @@ def test_transcript_helpers_match_merlin_kat_and_oracle(oracle):
     bad[200] = 200
     with _pt.raises(BpgpuError):
         transcript_append_message(bytes(bad), b"x", b"y")
+
+
+def test_chain_form_decision_table():
+    """rp_chain_forms (csrc/bpgpu.hip): which forms a per-proof launch chain takes, as a function of the context options, the pool's
+    hint and the chain's width -- plain host logic, checked here row by row (the measurements behind each row: DESIGN.md section 4)."""
+    import ctypes as C
+    import bulletproofs_amd as bp
+    L = bp.lib()
+    f = L.bpgpu_internal_chain_forms
+    f.restype = C.c_uint32
+    f.argtypes = [C.c_int64] * 5 + [C.c_uint64, C.c_int, C.c_int]
+    WIDE, WAVE, ASIDE, R32, AOUT = 1, 2, 4, 8, 16
+
+    def forms(nbatch, lanes=0, split3=-1, busy=-1, radix=0, a_out=1, other=0, s2=0):
+        return f(lanes, split3, busy, radix, a_out, nbatch, other, s2)
+    # a context nobody told anything: wavefront chains up to 256 proofs, quads to 8191 (wide from 2048), one-lane chains aside from 8192
+    assert forms(1) == WAVE and forms(256) == WAVE and forms(257) == 0 and forms(2047) == 0
+    assert forms(2048) == WIDE and forms(8191) == WIDE
+    assert forms(8192) == WIDE | ASIDE | AOUT
+    # the pool says other chains run beside this one: the throughput forms from 2048 proofs
+    assert forms(2048, busy=1) == WIDE | ASIDE | AOUT and forms(1024, busy=1) == 0 and forms(200, busy=1) == WAVE
+    # the pool says the chain is alone: wavefront chains up to 2304 proofs, quads above -- never the one-lane form
+    assert forms(2048, busy=0) == WIDE | WAVE and forms(2304, busy=0) == WIDE | WAVE and forms(2305, busy=0) == WIDE
+    assert forms(16384, busy=0) == WIDE
+    # explicit options win; radix 32 and A outside exist only with the one-lane chain aside
+    assert forms(3000, lanes=1) == WIDE | ASIDE | AOUT and forms(3000, lanes=1, a_out=0) == WIDE | ASIDE
+    assert forms(3000, lanes=1, radix=32) == WIDE | ASIDE | R32 | AOUT and forms(3000, lanes=4, radix=32, busy=1) == WIDE
+    assert forms(3000, lanes=64, busy=1) == WIDE | WAVE and forms(100, lanes=1) == 0 and forms(100, lanes=4) == 0
+    assert forms(100000, split3=0) == 0 and forms(100000, split3=0, lanes=1) == 0
+    # a forced split on a small busy batch must not combine the wavefront chain with the one-lane launch
+    assert forms(100, split3=1, busy=1) == WIDE | WAVE
+    # batch-combined calls / verdict-only shapes, and a caller on the context's second stream: never wide / aside
+    assert forms(50000, other=1, busy=1) == 0 and forms(50000, s2=1, busy=1) == WIDE
