@@ -1050,7 +1050,7 @@ extern "C" int bpgpu_msm_batch(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_te
 // ============================================================================
 // shared-generator MSM
 // ============================================================================
-static uint32_t pick_splits(bpgpu_ctx *c, size_t nbatch, uint32_t npairs) {
+static uint32_t pick_splits(bpgpu_ctx *c, size_t nbatch, uint32_t npairs, bool walk_alone_in_launch = false) {
     if (c->splits) return c->splits;
     if (c->splits_hint && npairs <= 8192) {   // the pool knows how much else is in flight (pool.hip flush_dev)
         uint32_t s = c->splits_hint;
@@ -1064,10 +1064,15 @@ static uint32_t pick_splits(bpgpu_ctx *c, size_t nbatch, uint32_t npairs) {
     // 4.57, 32: 4.45) and with <= 64 partial sums the finish kernel needs no separate reduction launch.
     // Aggregated shapes (thousands of generator terms per proof, e.g. m = 16: 38950 pairs) are all table walk:
     // they keep the 4096-wavefront target (cfg3: 478 k/s vs 443 k/s).
+    // A wide chain whose Horner chains run aside (rp_chain_forms) has the walk alone in launch 4 and nobody told it how much else is in
+    // flight (a context on its own, >= 8192 proofs): two full rounds of three wavefronts per SIMD (a lone 16 384-proof chain ran its walk at 0.59 of the mixed-addition rate
+    // with 2048 wavefronts, profiles/r03/chain16384_alone_kernel_stats.csv).
     const uint32_t nblk = (uint32_t)((nbatch + FB_BLOCK - 1) / FB_BLOCK);
-    const uint32_t target = npairs > 8192 ? 4096 : 1024;
+    const bool lone = walk_alone_in_launch && c->busy_hint < 0;   // (a pool that said "busy" has other chains to fill the device)
+    const uint32_t target = npairs > 8192 ? 4096 : (lone ? 6144 : 1024);
     uint32_t s = (target + nblk - 1) / nblk;
     s = (s + 7) & ~7u;
+    if (lone && s > 64) s = 64;   // (more would need a reduction launch in front of the finish)
     while (s > 8 && npairs / s < 8) s -= 8;
     if (s < 8) s = 8;
     return s;
@@ -1530,7 +1535,11 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         rc = gen_ids_for(c, n, m, &d_ids);
         if (rc) return rc;
     }
-    const uint32_t nsplit = pick_splits(c, nbatch, npairs);
+    // which forms this chain takes (rp_chain_forms above: the decision table, with the measurements behind every line)
+    const uint32_t forms = rp_chain_forms(c->horner_lanes, c->split_stage3, c->busy_hint, c->vb_radix, c->a_outside, nbatch, rlc || shape_verdict != 0,
+                                          s == c->stream2);
+    const bool wide = forms & RPC_WIDE, wave = forms & RPC_WAVE, aside = forms & RPC_ASIDE, r5 = forms & RPC_RADIX32, a_out = forms & RPC_A_OUTSIDE;
+    const uint32_t nsplit = pick_splits(c, nbatch, npairs, aside);
     // thread / element counts are 32-bit in the kernels: refuse what does not fit
     if ((uint64_t)n_gen_terms * nbatch > 0x7fffffffull || (uint64_t)nbatch * sh.U > 0x7fffffffull / 64 ||
         (uint64_t)nbatch * ((sh.U + BP_VB_CHUNK - 1) / BP_VB_CHUNK) * 64 > 0x7fffffffull || (uint64_t)(sh.nm / 4 + 1) * nbatch > 0x7fffffffull ||
@@ -1540,10 +1549,6 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const size_t rlc_terms = (size_t)nbatch * sh.U;
     const bk_params bkp = bk_make(pick_bucket_c(rlc_terms));
     const bool rlc_bucket = rlc && !shape_verdict && rlc_terms >= (c->bucket_min ? c->bucket_min : BK_RLC_MIN_TERMS) && bucket_fits(1, rlc_terms, bkp);
-    // which forms this chain takes (rp_chain_forms above: the decision table, with the measurements behind every line)
-    const uint32_t forms = rp_chain_forms(c->horner_lanes, c->split_stage3, c->busy_hint, c->vb_radix, c->a_outside, nbatch, rlc || shape_verdict != 0,
-                                          s == c->stream2);
-    const bool wide = forms & RPC_WIDE, wave = forms & RPC_WAVE, aside = forms & RPC_ASIDE, r5 = forms & RPC_RADIX32, a_out = forms & RPC_A_OUTSIDE;
     sh.radix5 = r5 ? 1u : 0u;
     sh.a_outside = a_out ? 1u : 0u;
     arena_plan ap;

@@ -814,6 +814,7 @@ BP_HD void rp_expand_b4_thread(uint32_t tid, rp_shape sh, fb_params prm, const u
         }
     }
     if (status[p] != 0) return;
+    const fb_bias bias = fb_make_bias(prm);   // wavefront-uniform: once for the eight recodings below
     const rp_fields fl = rp_field_layout(k, sh.m);
     sc28 s_hi, sinv_hi, y_hi, um, uim, t;
     sc28_one_mont(s_hi);
@@ -881,8 +882,8 @@ BP_HD void rp_expand_b4_thread(uint32_t tid, rp_shape sh, fb_params prm, const u
             g_out[j] = g;
             h_out[j] = h;
         } else {
-            fb_recode(digits + ((uint64_t)(2 + i) * prm.nwin) * B + p, B, g.v, prm);
-            fb_recode(digits + ((uint64_t)(2 + sh.nm + i) * prm.nwin) * B + p, B, h.v, prm);
+            fb_recode(digits + ((uint64_t)(2 + i) * prm.nwin) * B + p, B, g.v, prm, bias);
+            fb_recode(digits + ((uint64_t)(2 + sh.nm + i) * prm.nwin) * B + p, B, h.v, prm, bias);
         }
     }
 }
