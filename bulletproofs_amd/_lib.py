@@ -27,6 +27,7 @@ EXPORTS = [
     "bpgpu_pool_create", "bpgpu_pool_destroy", "bpgpu_pool_last_error", "bpgpu_pool_set_option", "bpgpu_pool_get_option",
     "bpgpu_pool_devices", "bpgpu_pool_lanes", "bpgpu_pool_lane", "bpgpu_pool_gens_create", "bpgpu_pool_gens_load",
     "bpgpu_pool_rangeproof_verify", "bpgpu_pool_rangeproof_submit_dev", "bpgpu_pool_flush", "bpgpu_pool_wait",
+    "bpgpu_pool_rangeproof_verify_ts", "bpgpu_pool_rangeproof_submit_ts", "bpgpu_pool_ticket_done", "bpgpu_pool_ticket_wait",
 ]
 
 TRANSCRIPT_BYTES = 208
@@ -107,6 +108,10 @@ def lib():
     L.bpgpu_pool_gens_load.argtypes = [vp, sz, sz, u8p, u8p, u8p, u8p]
     L.bpgpu_pool_rangeproof_verify.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p]
     L.bpgpu_pool_rangeproof_submit_dev.argtypes = [vp, i, sz, sz, sz, vp, sz, vp, u8p, sz, vp, vp, vp]
+    L.bpgpu_pool_rangeproof_verify_ts.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p, u8p]
+    L.bpgpu_pool_rangeproof_submit_ts.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p, u8p, C.POINTER(vp)]
+    L.bpgpu_pool_ticket_done.argtypes = [vp, vp]
+    L.bpgpu_pool_ticket_wait.argtypes = [vp, vp]
     L.bpgpu_pool_flush.argtypes = [vp]
     L.bpgpu_pool_wait.argtypes = [vp]
     L.bpgpu_profile_enable.argtypes = [vp, i]
@@ -400,6 +405,27 @@ def _profile_report_of(L, h):
     return out
 
 
+class Ticket:
+    """One request in flight in the pool's combining queue (bpgpu_pool_rangeproof_submit_ts)."""
+
+    def __init__(self, pool, h, nb, verdict, msm, ts_out):
+        self.pool, self.h, self.nb, self._v, self._m, self._t = pool, h, nb, verdict, msm, ts_out
+
+    def done(self):
+        return self.h is None or self.pool._L.bpgpu_pool_ticket_done(self.pool.h, self.h) == 1
+
+    def wait(self):
+        if self.h is not None:
+            h, self.h = self.h, None
+            self.pool._chk(self.pool._L.bpgpu_pool_ticket_wait(self.pool.h, h))
+        out = [self._v.raw[:self.nb]]
+        if self._m is not None:
+            out.append(self._m.raw[:32 * self.nb])
+        if self._t is not None:
+            out.append(self._t.raw[:TRANSCRIPT_BYTES * self.nb])
+        return tuple(out) if len(out) > 1 else out[0]
+
+
 class Pool:
     """Owns one bpgpu_pool: `lanes` contexts on each of `devices` (include/bpgpu.h, "pool").  The scheduler of the library:
     one synchronous call for any number of proofs from host memory (verify), or asynchronous device-pointer batches that the
@@ -464,6 +490,39 @@ class Pool:
         msm = C.create_string_buffer(32 * max(nb, 1)) if want_msm else None
         self._chk(self._L.bpgpu_pool_rangeproof_verify(self.h, n, m, nb, proofs, proof_len, commitments, label, len(label), rng64, verdict, msm))
         return (verdict.raw[:nb], msm.raw[:32 * nb]) if want_msm else verdict.raw[:nb]
+
+    def rangeproof_verify_ts(self, n, m, proofs, proof_len, commitments, transcripts, rng64=None, want_msm=False, want_transcripts=True):
+        """The reference's call shape (bpgpu_pool_rangeproof_verify_ts): blocking, any number of threads at once; `transcripts`
+        is ONE 208-byte state for all proofs or one per proof.  Returns (verdict, [msm,] [transcripts_out])."""
+        nb = len(proofs) // proof_len if proof_len else 0
+        assert len(proofs) == nb * proof_len and len(commitments) == 32 * m * nb
+        assert len(transcripts) in (TRANSCRIPT_BYTES, TRANSCRIPT_BYTES * nb)
+        stride = TRANSCRIPT_BYTES if (len(transcripts) == TRANSCRIPT_BYTES * nb and nb != 1) or (nb == 1 and want_transcripts) else 0
+        assert rng64 is None or len(rng64) == 64 * nb
+        verdict = C.create_string_buffer(max(nb, 1))
+        msm = C.create_string_buffer(32 * max(nb, 1)) if want_msm else None
+        ts_out = C.create_string_buffer(TRANSCRIPT_BYTES * max(nb, 1)) if want_transcripts else None
+        self._chk(self._L.bpgpu_pool_rangeproof_verify_ts(self.h, n, m, nb, proofs, proof_len, commitments, transcripts, stride, rng64, verdict, msm, ts_out))
+        out = [verdict.raw[:nb]]
+        if want_msm:
+            out.append(msm.raw[:32 * nb])
+        if want_transcripts:
+            out.append(ts_out.raw[:TRANSCRIPT_BYTES * nb])
+        return tuple(out) if len(out) > 1 else out[0]
+
+    def submit_ts(self, n, m, proofs, proof_len, commitments, transcripts, rng64=None, want_msm=False, want_transcripts=True):
+        """The non-blocking form (bpgpu_pool_rangeproof_submit_ts).  Returns a Ticket; ticket.wait() -> as rangeproof_verify_ts."""
+        nb = len(proofs) // proof_len if proof_len else 0
+        assert len(proofs) == nb * proof_len and len(commitments) == 32 * m * nb
+        assert len(transcripts) in (TRANSCRIPT_BYTES, TRANSCRIPT_BYTES * nb)
+        stride = TRANSCRIPT_BYTES if (len(transcripts) == TRANSCRIPT_BYTES * nb and nb != 1) or (nb == 1 and want_transcripts) else 0
+        verdict = C.create_string_buffer(max(nb, 1))
+        msm = C.create_string_buffer(32 * max(nb, 1)) if want_msm else None
+        ts_out = C.create_string_buffer(TRANSCRIPT_BYTES * max(nb, 1)) if want_transcripts else None
+        t = C.c_void_p()
+        self._chk(self._L.bpgpu_pool_rangeproof_submit_ts(self.h, n, m, nb, proofs, proof_len, commitments, transcripts, stride, rng64, verdict, msm, ts_out,
+                                                          C.byref(t)))
+        return Ticket(self, t, nb, verdict, msm, ts_out)
 
     def submit_dev(self, dev_index, n, m, nbatch, d_proofs, proof_len, d_commitments, label, d_rng64, d_verdict, d_msm_out=None):
         """queue a device-resident batch (raw device pointers as ints); see flush / wait"""

@@ -66,19 +66,34 @@ struct bpgpu_ctx {
     fb_params prm{};
     std::vector<uint8_t> h_gens;      // host copy of the encodings
     std::map<std::pair<size_t, size_t>, uint32_t *> gen_ids_cache;  // (n,m) -> device id list
-    std::map<std::vector<uint32_t>, uint32_t *> script_cache;       // (n, m, k, pos, pos_begin, flags, domsep) -> transcript script (rp_script.h)
+    struct script_ent {
+        uint32_t *mem = nullptr;
+        size_t cap = 0;
+        uint64_t last_use = 0;
+    };
+    std::map<std::vector<uint32_t>, script_ent> script_cache;       // (n, m, k, pos, pos_begin, flags, domsep) -> transcript script (rp_script.h), LRU-bounded (script_for)
+    std::vector<uint32_t *> script_retired;
+    uint64_t script_tick = 0;
     int split_stage1 = 0;                                           // experiment: point decoding as its own launch on the second stream, compiled for 1 / 2 / 3 wavefronts per SIMD
     int split_stage3 = -1;                                          // window sums and generator exponents as two launches: 1 yes, 0 no, -1 auto (chains of >= 2048 proofs)
     bool no_script = false;                                         // option "transcript_script" = 0: byte-wise replay everywhere (A/B)
     // device-resident work decomposition of the uniform (nbatch, terms-per-MSM) variable-base plans
+    // One decomposition per terms-per-MSM value, built for a CAPACITY of MSMs: entry b of every array depends on b only, so the plan
+    // of `cap` MSMs serves any batch of up to `cap` as a prefix (the pool's combining queue issues chains of every width; keyed by
+    // (nbatch, per) the cache missed on almost every chain -- a host-side build, a hipMalloc and three blocking copies each).
     struct plan_dev {
         char *mem = nullptr;
-        size_t n_chunks = 0;
-        uint32_t total = 0;
+        size_t cap = 0, o1 = 0, o2 = 0;      // MSMs it was built for; offsets of chunk_first / term_chunk inside mem
         uint64_t last_use = 0;
     };
-    uint64_t plan_tick = 0;                  // plan_cache is bounded: least-recently-used entries are evicted
-    std::map<std::pair<size_t, size_t>, plan_dev> plan_cache;
+    struct plan_view {                       // what a call of `nbatch` MSMs sees of it
+        char *mem = nullptr;
+        size_t o1 = 0, o2 = 0, n_chunks = 0;
+        uint32_t total = 0;
+    };
+    uint64_t plan_tick = 0;                  // plan_cache is bounded: least-recently-used entries are retired
+    std::map<size_t, plan_dev> plan_cache;   // terms per MSM -> plan
+    std::vector<char *> plan_retired;        // outgrown / evicted blocks that launches in flight may still read: freed with the context
     // per-proof status words of the range-proof path: zero between calls (the last kernel of a call resets the
     // entries it used), so no memset launch is needed per call; `dirty` forces one after an aborted enqueue
     uint32_t *rp_status = nullptr;
@@ -360,8 +375,10 @@ void bpgpu_ctx_destroy(bpgpu_ctx *c) {
     drain_profile(c);
     for (auto e : c->ev_pool) hipEventDestroy(e);
     for (auto &kv : c->gen_ids_cache) hipFree(kv.second);
-    for (auto &kv : c->script_cache) hipFree(kv.second);
+    for (auto &kv : c->script_cache) hipFree(kv.second.mem);
+    for (uint32_t *q : c->script_retired) hipFree(q);
     for (auto &kv : c->plan_cache) hipFree(kv.second.mem);
+    for (char *q : c->plan_retired) hipFree(q);
     if (c->arena) hipFree(c->arena);
     if (c->io_dev) hipFree(c->io_dev);
     if (c->ipp_buf) hipFree(c->ipp_buf);
@@ -786,36 +803,51 @@ static int enqueue_vb(bpgpu_ctx *c, hipStream_t s, const vb_plan &pl, size_t nba
     return vb_launch(c, s, pl.total, (uint32_t)pl.chunks.size(), nbatch, d_scalars, d_points, d_status, d);
 }
 // uniform plans (every MSM of the batch has `per` variable-base terms): decomposition cached on the device
-static int uniform_plan(bpgpu_ctx *c, size_t nbatch, size_t per, bpgpu_ctx::plan_dev **out) {
-    auto key = std::make_pair(nbatch, per);
-    auto it = c->plan_cache.find(key);
-    if (it == c->plan_cache.end()) {
-        if (c->plan_cache.size() >= 32) {   // bounded: drop the least recently used decomposition
+static int uniform_plan(bpgpu_ctx *c, size_t nbatch, size_t per, bpgpu_ctx::plan_view *out) {
+    auto it = c->plan_cache.find(per);
+    if (it == c->plan_cache.end() || it->second.cap < nbatch) {
+        if (it != c->plan_cache.end()) {   // outgrown: launches in flight may still read the old block
+            c->plan_retired.push_back(it->second.mem);
+            c->plan_cache.erase(it);
+        } else if (c->plan_cache.size() >= 32) {   // bounded: retire the least recently used decomposition
             auto victim = c->plan_cache.begin();
             for (auto jt = c->plan_cache.begin(); jt != c->plan_cache.end(); ++jt)
                 if (jt->second.last_use < victim->second.last_use) victim = jt;
-            HIPCHK(c, hipDeviceSynchronize());   // kernels of earlier calls may still read it
-            HIPCHK(c, hipFree(victim->second.mem));
+            c->plan_retired.push_back(victim->second.mem);
             c->plan_cache.erase(victim);
         }
-        std::vector<uint32_t> nt(nbatch, (uint32_t)per);
+        if (c->plan_retired.size() > 64) {   // (only a caller that keeps changing its MSM sizes gets here)
+            HIPCHK(c, hipDeviceSynchronize());
+            for (char *q : c->plan_retired) hipFree(q);
+            c->plan_retired.clear();
+        }
+        // capacity: a power of two >= nbatch; small per-MSM term counts (the range-proof path: 17 .. 60 points per proof) start at 1024
+        // MSMs, large ones at what ~256 k terms allow (a lone 6 179-term MSM must not build the plan of a thousand of them)
+        size_t cap = 1, floor_cap = per ? (size_t)262144 / per : 1024;
+        if (floor_cap > 1024) floor_cap = 1024;
+        while (cap < nbatch || cap < floor_cap) cap *= 2;
+        std::vector<uint32_t> nt(cap, (uint32_t)per);
         vb_plan pl;
-        make_vb_plan(pl, nbatch, nt.data());
+        make_vb_plan(pl, cap, nt.data());
         bpgpu_ctx::plan_dev pd;
-        pd.n_chunks = pl.chunks.size();
-        pd.total = pl.total;
-        const size_t o1 = align_up(pl.chunks.size() * sizeof(vb_chunk) + 16), o2 = o1 + align_up((nbatch + 1) * 4);
-        const size_t tot = o2 + align_up((size_t)pl.total * 4 + 16);
+        pd.cap = cap;
+        pd.o1 = align_up(pl.chunks.size() * sizeof(vb_chunk) + 16);
+        pd.o2 = pd.o1 + align_up((cap + 1) * 4);
+        const size_t tot = pd.o2 + align_up((size_t)pl.total * 4 + 16);
         HIPCHK(c, hipMalloc((void **)&pd.mem, tot));
         if (!pl.chunks.empty()) {
             HIPCHK(c, hipMemcpy(pd.mem, pl.chunks.data(), pl.chunks.size() * sizeof(vb_chunk), hipMemcpyHostToDevice));
-            HIPCHK(c, hipMemcpy(pd.mem + o2, pl.term_chunk.data(), (size_t)pl.total * 4, hipMemcpyHostToDevice));
+            HIPCHK(c, hipMemcpy(pd.mem + pd.o2, pl.term_chunk.data(), (size_t)pl.total * 4, hipMemcpyHostToDevice));
         }
-        HIPCHK(c, hipMemcpy(pd.mem + o1, pl.chunk_first.data(), (nbatch + 1) * 4, hipMemcpyHostToDevice));
-        it = c->plan_cache.emplace(key, pd).first;
+        HIPCHK(c, hipMemcpy(pd.mem + pd.o1, pl.chunk_first.data(), (cap + 1) * 4, hipMemcpyHostToDevice));
+        it = c->plan_cache.emplace(per, pd).first;
     }
     it->second.last_use = ++c->plan_tick;
-    *out = &it->second;
+    out->mem = it->second.mem;
+    out->o1 = it->second.o1;
+    out->o2 = it->second.o2;
+    out->n_chunks = nbatch * ((per + BP_VB_CHUNK - 1) / BP_VB_CHUNK);
+    out->total = (uint32_t)(nbatch * per);
     return BPGPU_OK;
 }
 static void plan_vb_uniform(arena_plan &ap, size_t nbatch, size_t per, size_t off[7], size_t tab_entries = 8) {
@@ -828,15 +860,14 @@ static void plan_vb_uniform(arena_plan &ap, size_t nbatch, size_t per, size_t of
 }
 static int enqueue_vb_uniform(bpgpu_ctx *c, hipStream_t s, size_t nbatch, size_t per, const size_t off[7], const uint32_t *d_scalars,
                               const uint32_t *d_points, uint32_t *d_status, vb_dev &d) {
-    bpgpu_ctx::plan_dev *pd = nullptr;
-    int rc = uniform_plan(c, nbatch, per, &pd);
+    bpgpu_ctx::plan_view pv;
+    int rc = uniform_plan(c, nbatch, per, &pv);
     if (rc) return rc;
     vb_bind(c, off, d);
-    const size_t o1 = align_up(pd->n_chunks * sizeof(vb_chunk) + 16), o2 = o1 + align_up((nbatch + 1) * 4);
-    d.chunks = (vb_chunk *)pd->mem;
-    d.chunk_first = (uint32_t *)(pd->mem + o1);
-    d.term_chunk = (uint32_t *)(pd->mem + o2);
-    return vb_launch(c, s, pd->total, (uint32_t)pd->n_chunks, nbatch, d_scalars, d_points, d_status, d);
+    d.chunks = (vb_chunk *)pv.mem;
+    d.chunk_first = (uint32_t *)(pv.mem + pv.o1);
+    d.term_chunk = (uint32_t *)(pv.mem + pv.o2);
+    return vb_launch(c, s, pv.total, (uint32_t)pv.n_chunks, nbatch, d_scalars, d_points, d_status, d);
 }
 
 // ============================================================================
@@ -1391,23 +1422,47 @@ static void make_strobe_init(rp_strobe_init &init, const uint8_t *label, size_t 
     init.cur_flags = t.cur_flags;
 }
 
-// the transcript script of a shape and start position (rp_script.h), cached on the device per context
-static int script_for(bpgpu_ctx *c, uint32_t n, uint32_t m, uint32_t k, const rp_strobe_init &init, bool domsep, const rp_script_hdr **out) {
+// the transcript script of a shape and start position (rp_script.h), cached on the device per context.
+// The cache is bounded (callers whose transcripts sit at many different STROBE positions): beyond 64 entries the least recently
+// used one gives its device block to the newcomer.  Uploads come from the pinned staging buffer on the call's stream, so the
+// overwrite is ordered behind every earlier launch of this context that read the old script (ctx_enter orders the streams);
+// nothing is freed and nothing synchronises the device while other lanes are running.
+static int script_for(bpgpu_ctx *c, hipStream_t s, uint32_t n, uint32_t m, uint32_t k, const rp_strobe_init &init, bool domsep, const rp_script_hdr **out) {
     std::vector<uint32_t> key = {n, m, k, init.pos, init.pos_begin, init.cur_flags, domsep ? 1u : 0u};
     auto it = c->script_cache.find(key);
     if (it == c->script_cache.end()) {
-        if (c->script_cache.size() >= 64) {   // bounded (callers with many different transcript positions)
-            HIPCHK(c, hipDeviceSynchronize());
-            for (auto &kv : c->script_cache) hipFree(kv.second);
-            c->script_cache.clear();
-        }
         const std::vector<uint32_t> img = rp_script_build(n, m, k, init.pos, init.pos_begin, init.cur_flags, domsep);
-        uint32_t *d = nullptr;
-        HIPCHK(c, hipMalloc((void **)&d, img.size() * 4));
-        HIPCHK(c, hipMemcpy(d, img.data(), img.size() * 4, hipMemcpyHostToDevice));
-        it = c->script_cache.emplace(key, d).first;
+        const size_t bytes = img.size() * 4;
+        bpgpu_ctx::script_ent ent;
+        if (c->script_cache.size() >= 64) {
+            auto lru = c->script_cache.begin();
+            for (auto jt = c->script_cache.begin(); jt != c->script_cache.end(); ++jt)
+                if (jt->second.last_use < lru->second.last_use) lru = jt;
+            ent = lru->second;
+            c->script_cache.erase(lru);
+            if (ent.cap < bytes) {   // too small for the newcomer: parked until the context goes away (a few KB; bounded by the shapes a process uses)
+                c->script_retired.push_back(ent.mem);
+                ent.mem = nullptr;
+                ent.cap = 0;
+            }
+        }
+        if (!ent.mem) {
+            const size_t cap = bytes < 8192 ? 8192 : bytes;
+            HIPCHK(c, hipMalloc((void **)&ent.mem, cap));
+            ent.cap = cap;
+        }
+        char *h = nullptr;
+        const int rc = pin_alloc(c, s, bytes, &h);
+        if (rc) {
+            c->script_retired.push_back(ent.mem);
+            return rc;
+        }
+        memcpy(h, img.data(), bytes);
+        HIPCHK(c, hipMemcpyAsync(ent.mem, h, bytes, hipMemcpyHostToDevice, s));
+        it = c->script_cache.emplace(key, ent).first;
     }
-    *out = (const rp_script_hdr *)it->second;
+    it->second.last_use = ++c->script_tick;
+    *out = (const rp_script_hdr *)it->second.mem;
     return BPGPU_OK;
 }
 
@@ -1419,6 +1474,10 @@ struct rp_transcripts {
     const uint8_t *shared_ts = nullptr;
     const void *d_ts_in = nullptr;
     void *d_ts_out = nullptr;
+    // with d_ts_in: every state of the batch sits at this STROBE position (the pool's combining queue groups its requests that
+    // way), so the per-shape script replaces the byte-wise replay although the sponge words differ from proof to proof
+    bool ts_uniform = false;
+    uint32_t u_pos = 0, u_pos_begin = 0, u_flags = 0;
 };
 
 // ---- the forms a per-proof launch chain takes -----------------------------------------------------------------------------------
@@ -1461,7 +1520,11 @@ extern "C" uint32_t bpgpu_internal_chain_forms(int64_t horner_lanes, int64_t spl
 static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
                                 const void *d_commitments, const rp_transcripts &tr, const void *d_rng64, void *d_verdict,
                                 void *d_msm_out, hipStream_t s, bool rlc = false, const void *d_weights64 = nullptr,
-                                void *d_batch_out = nullptr, const rp_seg *h_segs = nullptr, uint32_t nseg = 0, bool dev_call = false) {
+                                void *d_batch_out = nullptr, const rp_seg *h_segs = nullptr, uint32_t nseg = 0, bool dev_call = false,
+                                bool reserve_only = false) {
+    // reserve_only: size the arena, the status words and the work decomposition for a chain of `nbatch` proofs and return --
+    // a lane of the pool's combining queue sees chains of every width and should not grow its buffers (a device-wide
+    // synchronisation each time) on the way up
     // h_segs (bpgpu_pool_*, coalesced launch): the nbatch proofs are the concatenation of nseg submitted items, each with its
     // own input / output buffers (d_proofs, d_commitments, d_verdict, d_msm_out unused; d_msm_out non-null = some item wants encodings)
     // rlc: batch-combination mode (bpgpu_rangeproof_verify_rlc[_dev]); d_msm_out is unused then, d_batch_out
@@ -1582,6 +1645,10 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         c->rp_status_cap = nbatch;
         c->rp_status_dirty = true;
     }
+    if (reserve_only) {
+        bpgpu_ctx::plan_view pv0;
+        return shape_verdict ? BPGPU_OK : uniform_plan(c, nbatch, sh.U, &pv0);
+    }
     uint32_t *d_status = c->rp_status;
     fb_digit *d_digits = (fb_digit *)(a + off_digits);
     ge_ext *d_partial = (ge_ext *)(a + off_partial);
@@ -1621,18 +1688,19 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         segtab.n = nseg;
         segtab.ext = (const rp_seg *)(a + off_segs);
     }
-    if (c->pin_off > c->pin_marked && dev_call) {   // rng / weights / segment table staged above, nothing else will be
-        rc = pin_mark(c, s);
-        if (rc) return rc;
-    }
-    if (c->rp_status_dirty) HIPCHK(c, hipMemsetAsync(d_status, 0, c->rp_status_cap * 4, s));
-    c->rp_status_dirty = true;   // until the kernel that resets the words has been enqueued
     rp_strobe_init init;
     uint32_t ts_flags = 0;
     if (tr.d_ts_in || tr.shared_ts) {
         ts_flags = BP_TS_DOMSEP;
         if (tr.shared_ts) strobe_init_from_state(init, tr.shared_ts);
-        else memset(&init, 0, sizeof init);
+        else {
+            memset(&init, 0, sizeof init);
+            if (tr.ts_uniform) {
+                init.pos = tr.u_pos;
+                init.pos_begin = tr.u_pos_begin;
+                init.cur_flags = tr.u_flags;
+            }
+        }
     } else if (tr.d_ts_out) {   // label + states wanted back: start every proof from Transcript::new(label) and replay the domain separator on the device
         uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
         bpgpu_transcript_new(tr.label, tr.label_len, st0);
@@ -1642,23 +1710,28 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         make_strobe_init(init, tr.label, tr.label_len, n, m);
     }
     const rp_script_hdr *d_script = nullptr;
-    if (!tr.d_ts_in && !shape_verdict && !c->no_script) {   // every proof starts from `init`: the per-shape script replaces the byte-wise replay
-        rc = script_for(c, sh.n, sh.m, sh.k, init, (ts_flags & BP_TS_DOMSEP) != 0, &d_script);
+    if ((!tr.d_ts_in || tr.ts_uniform) && !shape_verdict && !c->no_script) {   // every proof starts at the position of `init`: the per-shape script replaces the byte-wise replay
+        rc = script_for(c, s, sh.n, sh.m, sh.k, init, (ts_flags & BP_TS_DOMSEP) != 0, &d_script);
         if (rc) return rc;
     }
+    if (c->pin_off > c->pin_marked && dev_call) {   // rng / weights / segment table / a new transcript script staged above, nothing else will be
+        rc = pin_mark(c, s);
+        if (rc) return rc;
+    }
+    if (c->rp_status_dirty) HIPCHK(c, hipMemsetAsync(d_status, 0, c->rp_status_cap * 4, s));
+    c->rp_status_dirty = true;   // until the kernel that resets the words has been enqueued
     const uint32_t nb32 = (uint32_t)nbatch;
     // the proof-specific ("variable-base") terms: decomposition into chunks of 32 is cached per (batch, U)
     vb_dev d{};
     bk_dev bd{};
     if (rlc_bucket) bucket_bind(c, boff, bd);
-    bpgpu_ctx::plan_dev *pd = nullptr;
+    bpgpu_ctx::plan_view pv, *pd = &pv;
     if (!shape_verdict && !rlc_bucket) {
-        rc = uniform_plan(c, nbatch, sh.U, &pd);
+        rc = uniform_plan(c, nbatch, sh.U, &pv);
         if (rc) return rc;
         vb_bind(c, off, d);
-        const size_t o1 = align_up(pd->n_chunks * sizeof(vb_chunk) + 16);
-        d.chunks = (vb_chunk *)pd->mem;
-        d.chunk_first = (uint32_t *)(pd->mem + o1);
+        d.chunks = (vb_chunk *)pv.mem;
+        d.chunk_first = (uint32_t *)(pv.mem + pv.o1);
         d.hq = (ge_ext *)((char *)d.colq16 + (size_t)nbatch * 64 * sizeof(ge_cached));
     }
     // Horner layout: quads (16 chains per wavefront, least total work) unless the caller asked for the
@@ -1865,14 +1938,16 @@ bool bpgpu_internal_idle(bpgpu_ctx *c) {
     if (e != hipSuccess) (void)hipGetLastError();   // hipErrorNotReady is not an error
     return e == hipSuccess;
 }
-// what the pool knows about the chains it is about to issue on this context: 1 = others run beside them, 0 = alone, -1 = forget
+// What the pool knows about the chain it issues on this context -- busy: 1 = others run beside it, 0 = alone, -1 = nothing -- is an
+// argument of the two hooks below and is forgotten when the call returns: a lane never runs on what an earlier call left behind.
+// (bpgpu_internal_set_busy_hint stays for the host-pointer slices, whose worker sets it immediately before every submit.)
 void bpgpu_internal_set_busy_hint(bpgpu_ctx *c, int busy) {
     std::lock_guard<std::mutex> lk(c->mu);
     c->busy_hint = busy;
 }
 // one coalesced launch chain over the concatenation of `nseg` items, on the context's own stream (asynchronous)
 int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, const uint8_t *label, size_t label_len, const rp_seg *segs,
-                                  uint32_t nseg, bool any_msm, uint32_t splits_hint) {
+                                  uint32_t nseg, bool any_msm, uint32_t splits_hint, int busy) {
     if (!c || !segs || nseg == 0) return BPGPU_ERR_INVALID_ARG;
     const size_t total = (size_t)segs[nseg - 1].first + segs[nseg - 1].count;
     bool any_rng_missing = false;
@@ -1886,10 +1961,54 @@ int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof
     tr.label = label;
     tr.label_len = label_len;
     c->splits_hint = splits_hint;
+    c->busy_hint = busy;
     // d_rng64: a non-null dummy keeps the library from drawing randomness nobody reads (every item brought its own)
     rc = rp_verify_dev_locked(c, n, m, total, nullptr, proof_len, nullptr, tr, any_rng_missing ? nullptr : (const void *)segs[0].rng64, nullptr,
                               any_msm ? (void *)segs : nullptr, s, false, nullptr, nullptr, segs, nseg, true);
     c->splits_hint = 0;
+    c->busy_hint = -1;
+    const int rc2 = ctx_leave(c, s);
+    return rc ? rc : rc2;
+}
+// buffers of the context sized for chains of up to `nbatch_max` proofs of this shape (see rp_verify_dev_locked, reserve_only)
+int bpgpu_internal_rp_reserve(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, size_t nbatch_max) {
+    if (!c) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    rp_transcripts tr;
+    c->busy_hint = 1;
+    const int rc = rp_verify_dev_locked(c, n, m, nbatch_max, nullptr, proof_len, nullptr, tr, (const void *)c, nullptr, nullptr, c->stream, false, nullptr, nullptr,
+                                        nullptr, 0, true, true);
+    c->busy_hint = -1;
+    return rc;
+}
+// the context's own stream (the pool's combining queue enqueues its staging copies around the chain)
+void *bpgpu_internal_stream(bpgpu_ctx *c) { return c ? (void *)c->stream : nullptr; }
+// one launch chain over device-resident inputs on the context's own stream (asynchronous): what the combining queue of the pool
+// issues for a sealed buffer.  Transcripts: `shared_ts` (one 208-byte state for every proof; no states handed back), or one state
+// per proof in d_ts_in / d_ts_out -- with ts_uniform all of them at STROBE position (pos, pos_begin, flags): the scripted replay.
+int bpgpu_internal_rp_verify_chain(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len, const void *d_commitments,
+                                   const uint8_t *shared_ts, const void *d_ts_in, void *d_ts_out, int ts_uniform, uint32_t pos, uint32_t pos_begin,
+                                   uint32_t flags, const void *d_rng64, void *d_verdict, void *d_msm_out, uint32_t splits_hint, int busy) {
+    if (!c || !d_proofs || !d_verdict || !d_rng64 || (shared_ts == nullptr) == (d_ts_in == nullptr)) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    int rc = ctx_enter(c, s);
+    if (rc) return rc;
+    rp_transcripts tr;
+    tr.shared_ts = shared_ts;
+    tr.d_ts_in = d_ts_in;
+    tr.d_ts_out = d_ts_out;
+    tr.ts_uniform = d_ts_in && ts_uniform;
+    tr.u_pos = pos;
+    tr.u_pos_begin = pos_begin;
+    tr.u_flags = flags;
+    c->splits_hint = splits_hint;
+    c->busy_hint = busy;
+    rc = rp_verify_dev_locked(c, n, m, nbatch, d_proofs, proof_len, d_commitments, tr, d_rng64, d_verdict, d_msm_out, s, false, nullptr, nullptr, nullptr, 0, true);
+    c->splits_hint = 0;
+    c->busy_hint = -1;
     const int rc2 = ctx_leave(c, s);
     return rc ? rc : rc2;
 }

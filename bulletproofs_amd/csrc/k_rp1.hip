@@ -34,7 +34,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(RP_
 #ifndef BP_EXP_NOTR
             // the per-shape script (rp_script.h) whenever every proof starts from the same transcript; the byte-wise replay for
             // caller-supplied per-proof states
-            if (script) rp_transcript_scripted(p, sh, init, st, rp_resolve(p, sh, proofs, commitments, rng64, segs), script, fields, status, ts_out);
+            if (script) rp_transcript_scripted(p, sh, init, st, rp_resolve(p, sh, proofs, commitments, rng64, segs), script, fields, status, ts_out, ts_in);
             else rp_transcript_thread(p, sh, init, st, rp_resolve(p, sh, proofs, commitments, rng64, segs), fields, status, ts_flags, ts_in, ts_out);
 #endif
 #ifndef BP_EXP_NOSC

@@ -9,11 +9,26 @@
 //     slices staged / enqueued / collected by the workers, verdicts gathered in order into the caller's buffer;
 //   * bpgpu_pool_rangeproof_submit_dev (device pointers, asynchronous): items queue up; a flush packs consecutive items of
 //     one shape into coalesced launch chains (rp_seg, rangeproof.h) of about `coalesce_proofs` proofs and issues them on
-//     the lanes round-robin -- a burst of small batches is served as a few wide chains instead of many narrow ones.
+//     the lanes round-robin -- a burst of small batches is served as a few wide chains instead of many narrow ones;
+//   * bpgpu_pool_rangeproof_verify_ts / _submit_ts (host pointers, the reference's literal call shape: a few proofs per call,
+//     each with its own `transcript: &mut Transcript`, from any number of threads at once): the COMBINING QUEUE below -- callers
+//     copy their proofs into the open staging buffer of their (shape, transcript position) class; a buffer leaves as one launch
+//     chain when it is full or when its deadline expires; every caller is woken when ITS proofs are done.
 // No CPU fallback: creation fails without a device.
 #include <hip/hip_runtime.h>
+#include <linux/futex.h>
+#include <pthread.h>
+#include <sched.h>
+#include <sys/prctl.h>
+#include <sys/resource.h>
+#include <sys/random.h>
+#include <sys/syscall.h>
+#include <time.h>
+#include <unistd.h>
 
+#include <algorithm>
 #include <atomic>
+#include <climits>
 #include <condition_variable>
 #include <cstdarg>
 #include <cstdio>
@@ -31,11 +46,22 @@
 
 using namespace bp;
 
+static inline uint64_t now_ns_early() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+
 bool bpgpu_internal_rp_coalescible(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len);
 bool bpgpu_internal_idle(bpgpu_ctx *c);
 void bpgpu_internal_set_busy_hint(bpgpu_ctx *c, int busy);
 int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, const uint8_t *label, size_t label_len, const rp_seg *segs,
-                                  uint32_t nseg, bool any_msm, uint32_t splits_hint);
+                                  uint32_t nseg, bool any_msm, uint32_t splits_hint, int busy);
+void *bpgpu_internal_stream(bpgpu_ctx *c);
+int bpgpu_internal_rp_reserve(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, size_t nbatch_max);
+int bpgpu_internal_rp_verify_chain(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len, const void *d_commitments,
+                                   const uint8_t *shared_ts, const void *d_ts_in, void *d_ts_out, int ts_uniform, uint32_t pos, uint32_t pos_begin,
+                                   uint32_t flags, const void *d_rng64, void *d_verdict, void *d_msm_out, uint32_t splits_hint, int busy);
 
 // The ROCm runtime maps HIP streams onto GPU_MAX_HW_QUEUES hardware queues (default 4) and reads the variable when it
 // initialises, i.e. at the process's first HIP call.  Kernels of different lanes only overlap when the lanes sit on different
@@ -43,11 +69,110 @@ int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof
 // loaded, unless the caller chose a value.
 namespace {
 struct hwq_init {
-    hwq_init() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+    bool set_by_library = false;
+    hwq_init() {
+        if (!getenv("GPU_MAX_HW_QUEUES")) {
+            setenv("GPU_MAX_HW_QUEUES", "16", 0);
+            set_by_library = true;
+        }
+    }
 } g_hwq_init;
 }  // namespace
 
+// How many streams' kernels overlap on this device right now?  Sixteen streams get one single-wavefront kernel each that spins
+// for ~150 us; with q hardware queues the batch takes ceil(16 / q) x 150 us.  (Used by bpgpu_pool_create when the library itself
+// set GPU_MAX_HW_QUEUES at load time: the variable then says nothing about what the runtime read.)
+__global__ void k_pool_spin(uint64_t ticks, uint32_t *sink) {
+    const uint64_t t0 = wall_clock64();
+    uint32_t x = 0;
+    while (wall_clock64() - t0 < ticks) x++;
+    if (ticks == ~0ull) *sink = x;
+}
+static int probe_hw_queues(int device) {
+    if (hipSetDevice(device) != hipSuccess) return -1;
+    const int NS = 16;
+    hipStream_t st[NS];
+    for (int i = 0; i < NS; i++)
+        if (hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) return -1;
+    const uint64_t ticks = 15000;   // wall_clock64: 100 MHz
+    double best = 1e30;
+    for (int rep = 0; rep < 3; rep++) {   // the first round also pays for loading the code object
+        for (int i = 0; i < NS; i++) hipStreamSynchronize(st[i]);
+        const uint64_t t0 = now_ns_early();
+        for (int i = 0; i < NS; i++) hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, st[i], ticks, (uint32_t *)nullptr);
+        for (int i = 0; i < NS; i++) hipStreamSynchronize(st[i]);
+        const double us = (double)(now_ns_early() - t0) / 1000.0;
+        if (us < best) best = us;
+    }
+    for (int i = 0; i < NS; i++) hipStreamDestroy(st[i]);
+    if (hipGetLastError() != hipSuccess) return -1;
+    const double rounds = best / 150.0;   // ~1 with >= 16 queues, ~2 with 8, ~4 with 4
+    int q = (int)(16.0 / (rounds < 1.0 ? 1.0 : rounds) + 0.5);
+    return q < 1 ? 1 : q;
+}
+
 namespace {
+
+inline uint64_t now_ns() {
+    timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
+}
+// std::atomic<uint32_t> as a futex word (C++17: no atomic::wait yet)
+inline void futex_wait(std::atomic<uint32_t> *a, uint32_t expected) { syscall(SYS_futex, (uint32_t *)a, FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0); }
+inline void futex_wake_all(std::atomic<uint32_t> *a) { syscall(SYS_futex, (uint32_t *)a, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
+
+// ---- the batching challenge's randomness when the caller brings none ------------------------------------------------------
+// verify_multiple draws `c` from thread_rng() (src/range_proof/mod.rs:396, 455-470).  Here: one ChaCha20 generator per calling
+// thread, keyed from the OS CSPRNG, re-keyed from its own output after every request (fast key erasure) and from the OS every
+// 16 MiB -- a getrandom() system call per proof would cost more than staging the proof.
+struct chacha_rng {
+    uint32_t key[8];
+    uint64_t counter = 0, since_seed = ~0ull;
+};
+inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
+void chacha20_block(const uint32_t key[8], uint64_t counter, uint32_t out[16]) {
+    uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                       (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+    uint32_t x[16];
+    for (int i = 0; i < 16; i++) x[i] = in[i];
+#define BP_QR(a, b, c, d)                    \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16); \
+    x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12); \
+    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8);  \
+    x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7);
+    for (int r = 0; r < 10; r++) {
+        BP_QR(0, 4, 8, 12) BP_QR(1, 5, 9, 13) BP_QR(2, 6, 10, 14) BP_QR(3, 7, 11, 15)
+        BP_QR(0, 5, 10, 15) BP_QR(1, 6, 11, 12) BP_QR(2, 7, 8, 13) BP_QR(3, 4, 9, 14)
+    }
+#undef BP_QR
+    for (int i = 0; i < 16; i++) out[i] = x[i] + in[i];
+}
+bool fast_random(uint8_t *dst, size_t bytes) {
+    static thread_local chacha_rng g;
+    if (g.since_seed > (16ull << 20)) {
+        size_t got = 0;
+        while (got < 32) {
+            const ssize_t r = getrandom((char *)g.key + got, 32 - got, 0);
+            if (r <= 0) return false;
+            got += (size_t)r;
+        }
+        g.since_seed = 0;
+        g.counter = 0;
+    }
+    uint32_t blk[16];
+    while (bytes) {
+        chacha20_block(g.key, g.counter++, blk);
+        const size_t take = bytes < 64 ? bytes : 64;
+        memcpy(dst, blk, take);
+        dst += take;
+        bytes -= take;
+        g.since_seed += 64;
+    }
+    chacha20_block(g.key, g.counter++, blk);   // the next request runs under a key this one's output does not reveal
+    memcpy(g.key, blk, 32);
+    return true;
+}
 
 struct dev_item {   // a submitted device-pointer batch waiting for the next flush
     size_t n, m, nbatch, proof_len;
@@ -55,6 +180,79 @@ struct dev_item {   // a submitted device-pointer batch waiting for the next flu
     uint8_t *verdict, *msm;
     std::string label;
     bool same_shape(const dev_item &o) const { return n == o.n && m == o.m && proof_len == o.proof_len && label == o.label; }
+};
+
+// ---- combining queue ---------------------------------------------------------------------------------------------------
+// What a launch chain can share: the shape, and how its transcripts start --
+//   CK_SHARED  every proof from ONE 208-byte state (Transcript::new(label) of a common label, or a transcript the callers
+//              share), no states handed back: nothing per proof to upload;
+//   CK_UNIFORM one state per proof in / out, all at the same STROBE position (pos, pos_begin, cur_flags): the per-shape script
+//              (rp_script.h) still applies, only the sponge words differ;
+//   CK_MIXED   one state per proof at whatever position: the byte-wise replay.  Catch-all when too many position classes are open.
+enum { CK_SHARED = 0, CK_UNIFORM = 1, CK_MIXED = 2 };
+struct comb_key {
+    uint32_t n = 0, m = 0, proof_len = 0, mode = 0;
+    uint32_t pos = 0, pos_begin = 0, flags = 0;      // CK_UNIFORM
+    uint8_t shared[BPGPU_TRANSCRIPT_BYTES] = {0};    // CK_SHARED
+    bool operator==(const comb_key &o) const {
+        if (n != o.n || m != o.m || proof_len != o.proof_len || mode != o.mode) return false;
+        if (mode == CK_UNIFORM) return pos == o.pos && pos_begin == o.pos_begin && flags == o.flags;
+        if (mode == CK_SHARED) return memcmp(shared, o.shared, sizeof shared) == 0;
+        return true;
+    }
+};
+
+struct comb_req;
+struct pool_dev;
+enum { CB_FREE = 0, CB_OPEN, CB_SEALED, CB_ISSUING, CB_ISSUED, CB_DONE };
+// One staging buffer + the lane that runs its chain.  Inputs [proofs | commitments | rng | transcripts in] and outputs
+// [verdicts | transcripts out | encodings] sit at the same offsets of a pinned host block and of a device block.
+struct comb_buf {
+    pool_dev *dev = nullptr;
+    bpgpu_ctx *ctx = nullptr;
+    std::atomic<int> poison{0};
+    uint32_t reserved_n = 0, reserved_m = 0, reserved_len = 0, reserved_cap = 0;   // shape / width the lane's buffers were last sized for
+    hipEvent_t done_ev = nullptr;
+    char *h = nullptr, *d = nullptr;
+    size_t mem_cap = 0;
+    comb_key key;
+    uint32_t cap = 0, cap_max = 0;
+    size_t off_p = 0, off_c = 0, off_r = 0, off_t = 0, in_bytes = 0, off_v = 0, off_to = 0, off_m = 0, total = 0;
+    int st = CB_FREE;                       // under pool_dev::cmu
+    uint32_t reserved = 0;                  // proofs handed out (under cmu)
+    std::atomic<uint32_t> written{0};       // proofs whose inputs are in place
+    std::atomic<uint32_t> refs{0};          // pieces whose results have not been taken yet
+    std::atomic<uint32_t> phase{0};         // futex word: 0 until the chain's results are in `h`
+    bool any_msm = false;
+    uint64_t t_first = 0, t_last = 0;       // arrival of the first / the latest piece (ns)
+    int rc = 0;
+    std::string err;
+    struct apiece {
+        comb_req *req;
+        uint32_t first, count;
+        size_t off;
+    };
+    std::vector<apiece> async_pieces;       // pieces of tickets: delivered by the service thread
+};
+
+// one call (bpgpu_pool_rangeproof_verify_ts) or one ticket (bpgpu_pool_rangeproof_submit_ts)
+struct comb_req {
+    size_t n = 0, m = 0, nbatch = 0, proof_len = 0;
+    const uint8_t *proofs = nullptr, *coms = nullptr, *rng = nullptr, *ts_in = nullptr;   // ts_in: per proof, or null (key.shared)
+    uint8_t *verdict = nullptr, *msm = nullptr, *ts_out = nullptr;
+    bool async = false;
+    struct piece {
+        comb_buf *b;
+        uint32_t first, count;
+        size_t off;
+    };
+    std::vector<piece> pieces;              // synchronous calls: collected by the caller itself
+    size_t next_piece = 0;
+    std::atomic<uint32_t> left{1};          // tickets: pieces not delivered yet (+1 while the request is being placed); futex word
+    std::atomic<uint32_t> waiting{0};
+    std::mutex emu;                         // guards rc / err of a ticket (service thread vs. caller)
+    int rc = 0;
+    std::string err;
 };
 
 struct pool_dev {
@@ -71,6 +269,19 @@ struct pool_dev {
     std::mutex tmu;
     std::condition_variable tcv;
     bool stop = false;
+    // combining queue: its own lanes (a lane whose staging buffer callers are writing into cannot take a flush's chain meanwhile),
+    // one service thread (seals buffers by deadline, issues their chains, notices completions), one context for the requests no
+    // chain can take (malformed lengths, parameter errors: reported per proof by the ordinary entry point)
+    std::vector<comb_buf *> cbufs;
+    bpgpu_ctx *misc = nullptr;
+    std::mutex misc_mu;
+    std::mutex cmu;
+    std::condition_variable ccv, free_cv;
+    std::thread svc;
+    bool svc_running = false, cstop = false;
+    uint64_t stat_chains = 0, stat_proofs = 0, stat_requests = 0;
+    uint64_t stat_issue_ns = 0, stat_complete_ns = 0, stat_polls = 0;   // service thread: time spent issuing / completing, loop count
+    uint32_t recent_K = 0;                  // width of the chain issued last (sizes the next buffer, comb_place)
 };
 
 }  // namespace
@@ -78,7 +289,6 @@ struct pool_dev {
 struct bpgpu_pool {
     std::vector<pool_dev *> devs;
     std::mutex mu;        // serialises the pool's own state (pending lists, options); lane contexts have their own locks
-    std::string err;
     size_t coalesce_proofs = 5120;   // target width of a coalesced launch chain
     size_t pair_limit_proofs = 24576;   // a flush of up to this many proofs is issued as at most two chains (flush_dev)
     size_t max_chain_proofs = 16384; // never wider than this (arena of a lane: ~55 KB per proof)
@@ -87,17 +297,31 @@ struct bpgpu_pool {
     size_t auto_flush_items = 0;     // flush by itself once this many items wait on a device (0 = lanes)
     size_t auto_flush_proofs = 0;    // ... or once this many proofs wait: they go out as ONE chain while the caller keeps submitting (0 = off)
     size_t host_workers = 0;
+    // combining queue
+    std::atomic<uint64_t> combine_wait_ns{100000};    // a buffer leaves at the latest this long after its first proof arrived ...
+    std::atomic<uint64_t> combine_quiet_ns{20000};    // ... or when nothing has joined it for this long
+    std::atomic<uint64_t> combine_poll_ns{15000};     // the service thread's polling period while anything is open or in flight
+    std::atomic<uint32_t> combine_max_open{4};        // position classes with a buffer of their own; further classes share a CK_MIXED buffer
+    std::atomic<uint32_t> combine_busy_chains{2};     // a chain issued beside this many others (in flight or waiting) takes the throughput forms
+    std::atomic<uint32_t> combine_inflight{6};        // deadlines seal buffers only while fewer chains than this are in flight: beyond, load widens the chains
+    std::atomic<uint64_t> combine_max_age_ns{1500000}; // ... but no proof waits longer than this for its chain to be issued
+    std::atomic<int> host_path{1};                    // bpgpu_pool_rangeproof_verify: 1 = through the combining queue, 0 = the slicing workers of round 3
+    std::atomic<uint32_t> rr_dev{0};
+    std::atomic<uint64_t> gens_epoch{1};
     // statistics of the coalesced path (get_option "stat_chains" / "stat_chain_proofs" / "stat_last_splits"; set "stat_reset")
     uint64_t stat_chains = 0, stat_chain_proofs = 0, stat_last_splits = 0;
 };
 
-static int pfail(bpgpu_pool *p, int code, const char *fmt, ...) {
+// Errors are per calling thread: bpgpu_pool_last_error returns what the LAST pool call of THIS thread reported (any number of
+// threads may be inside the pool at once).
+static thread_local std::string t_pool_err;
+static int pfail(bpgpu_pool *, int code, const char *fmt, ...) {
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (p) p->err = buf;
+    t_pool_err = buf;
     return code;
 }
 
@@ -114,6 +338,14 @@ static void worker_main(pool_dev *d, size_t w) {
         }
         job(d->lanes[w]);
     }
+}
+
+// every context of a device: submit lanes, the combining queue's lanes, the odd-jobs context
+static std::vector<bpgpu_ctx *> all_ctxs(pool_dev *d) {
+    std::vector<bpgpu_ctx *> v(d->lanes);
+    for (comb_buf *b : d->cbufs) v.push_back(b->ctx);
+    if (d->misc) v.push_back(d->misc);
+    return v;
 }
 
 static void stop_workers(pool_dev *d) {
@@ -141,36 +373,71 @@ int bpgpu_pool_create(const int *devices, int ndev, int lanes_per_device, bpgpu_
                         "process's first HIP call, or leave it unset and load libbpgpu before HIP initialises)\n", q ? q : "(unset)");
         return BPGPU_ERR_HW_QUEUES;
     }
+    if (lanes_per_device > 4 && g_hwq_init.set_by_library) {
+        // The variable reads 16 because THIS library set it when it was loaded -- which only counts if the runtime had not read it
+        // before (a process that touched HIP first runs on the default 4 queues whatever the variable says now).  Ask the device.
+        const int qs = probe_hw_queues(devices[0]);
+        if (qs > 0 && qs < 8) {
+            fprintf(stderr, "libbpgpu: GPU_MAX_HW_QUEUES was set by libbpgpu at load time, but HIP had been initialised before: kernels of only "
+                            "~%d streams overlap.  Export GPU_MAX_HW_QUEUES=16 before the process's first HIP call.\n", qs);
+            return BPGPU_ERR_HW_QUEUES;
+        }
+    }
+    // lanes of the combining queue (bpgpu_pool_rangeproof_verify_ts and the host-pointer call): BPGPU_COMBINE_LANES, default 12
+    int n_comb = 12;
+    if (const char *e = getenv("BPGPU_COMBINE_LANES")) n_comb = atoi(e);
+    if (n_comb < 2) n_comb = 2;
+    if (n_comb > 64) n_comb = 64;
     bpgpu_pool *p = new bpgpu_pool();
     for (int i = 0; i < ndev; i++) {
         pool_dev *d = new pool_dev();
         d->device = devices[i];
         p->devs.push_back(d);
-        for (int l = 0; l < lanes_per_device; l++) {
+        for (int l = 0; l < lanes_per_device + n_comb + 1; l++) {
             bpgpu_ctx *c = nullptr;
             const int rc = bpgpu_ctx_create(devices[i], &c);
             if (rc) {
                 bpgpu_pool_destroy(p);
                 return rc;
             }
-            d->lanes.push_back(c);
+            if (l < lanes_per_device) d->lanes.push_back(c);
+            else if (l < lanes_per_device + n_comb) {
+                comb_buf *b = new comb_buf();
+                b->ctx = c;
+                b->dev = d;
+                d->cbufs.push_back(b);
+                if (hipSetDevice(devices[i]) != hipSuccess || hipEventCreateWithFlags(&b->done_ev, hipEventDisableTiming) != hipSuccess) {
+                    bpgpu_pool_destroy(p);
+                    return BPGPU_ERR_HIP;
+                }
+            } else d->misc = c;
         }
     }
     *out = p;
     return BPGPU_OK;
 }
 
+static void stop_service(pool_dev *d);
 void bpgpu_pool_destroy(bpgpu_pool *p) {
     if (!p) return;
     for (pool_dev *d : p->devs) {
         stop_workers(d);
+        stop_service(d);
         for (bpgpu_ctx *c : d->lanes) bpgpu_ctx_destroy(c);
+        for (comb_buf *b : d->cbufs) {
+            bpgpu_ctx_destroy(b->ctx);   // (synchronises the device: nothing of the buffer is in flight afterwards)
+            if (b->done_ev) hipEventDestroy(b->done_ev);
+            if (b->h) hipHostFree(b->h);
+            if (b->d) hipFree(b->d);
+            delete b;
+        }
+        if (d->misc) bpgpu_ctx_destroy(d->misc);
         delete d;
     }
     delete p;
 }
 
-const char *bpgpu_pool_last_error(bpgpu_pool *p) { return p ? p->err.c_str() : "null pool"; }
+const char *bpgpu_pool_last_error(bpgpu_pool *p) { return p ? t_pool_err.c_str() : "null pool"; }
 
 int bpgpu_pool_devices(bpgpu_pool *p) { return p ? (int)p->devs.size() : 0; }
 int bpgpu_pool_lanes(bpgpu_pool *p) { return (p && !p->devs.empty()) ? (int)p->devs[0]->lanes.size() : 0; }
@@ -222,6 +489,35 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
     }
     if (!strcmp(key, "stat_reset")) {
         p->stat_chains = p->stat_chain_proofs = 0;
+        for (pool_dev *d : p->devs) {
+            std::lock_guard<std::mutex> g(d->cmu);
+            d->stat_chains = d->stat_proofs = d->stat_requests = 0;
+            d->stat_issue_ns = d->stat_complete_ns = d->stat_polls = 0;
+        }
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "combine_wait_us") || !strcmp(key, "combine_quiet_us") || !strcmp(key, "combine_poll_us")) {
+        if (value < 1 || value > 1000000) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
+        (key[8] == 'w' ? p->combine_wait_ns : key[8] == 'q' ? p->combine_quiet_ns : p->combine_poll_ns) = (uint64_t)value * 1000;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "combine_busy_chains") || !strcmp(key, "combine_inflight")) {
+        if (value < 0 || value > 64) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
+        (key[8] == 'b' ? p->combine_busy_chains : p->combine_inflight) = (uint32_t)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "combine_max_age_us")) {
+        if (value < 1 || value > 10000000) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
+        p->combine_max_age_ns = (uint64_t)value * 1000;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "combine_max_open")) {
+        if (value < 1 || value > 64) return pfail(p, BPGPU_ERR_INVALID_ARG, "combine_max_open out of range");
+        p->combine_max_open = (uint32_t)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "host_path_combining")) {
+        p->host_path = value != 0;
         return BPGPU_OK;
     }
     if (!strcmp(key, "host_workers")) {
@@ -233,7 +529,7 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
     }
     // everything else is an option of the lane contexts (fixed_window_bits, horner_lanes, ...)
     for (pool_dev *d : p->devs)
-        for (bpgpu_ctx *c : d->lanes) {
+        for (bpgpu_ctx *c : all_ctxs(d)) {
             const int rc = bpgpu_ctx_set_option(c, key, value);
             if (rc) return pfail(p, rc, "%s", bpgpu_last_error(c));
         }
@@ -254,6 +550,31 @@ int bpgpu_pool_get_option(bpgpu_pool *p, const char *key, int64_t *value) {
     else if (!strcmp(key, "stat_chains")) *value = (int64_t)p->stat_chains;
     else if (!strcmp(key, "stat_chain_proofs")) *value = (int64_t)p->stat_chain_proofs;
     else if (!strcmp(key, "stat_last_splits")) *value = (int64_t)p->stat_last_splits;
+    else if (!strcmp(key, "combine_wait_us")) *value = (int64_t)(p->combine_wait_ns / 1000);
+    else if (!strcmp(key, "combine_quiet_us")) *value = (int64_t)(p->combine_quiet_ns / 1000);
+    else if (!strcmp(key, "combine_poll_us")) *value = (int64_t)(p->combine_poll_ns / 1000);
+    else if (!strcmp(key, "combine_max_open")) *value = (int64_t)p->combine_max_open;
+    else if (!strcmp(key, "combine_busy_chains")) *value = (int64_t)p->combine_busy_chains;
+    else if (!strcmp(key, "combine_inflight")) *value = (int64_t)p->combine_inflight;
+    else if (!strcmp(key, "combine_max_age_us")) *value = (int64_t)(p->combine_max_age_ns / 1000);
+    else if (!strcmp(key, "stat_svc_issue_us") || !strcmp(key, "stat_svc_complete_us") || !strcmp(key, "stat_svc_polls")) {
+        uint64_t v = 0;
+        for (pool_dev *d : p->devs) {
+            std::lock_guard<std::mutex> g(d->cmu);
+            v += key[9] == 'i' ? d->stat_issue_ns / 1000 : key[9] == 'c' ? d->stat_complete_ns / 1000 : d->stat_polls;
+        }
+        *value = (int64_t)v;
+    }
+    else if (!strcmp(key, "combine_lanes")) *value = p->devs.empty() ? 0 : (int64_t)p->devs[0]->cbufs.size();
+    else if (!strcmp(key, "host_path_combining")) *value = p->host_path;
+    else if (!strcmp(key, "stat_combined_chains") || !strcmp(key, "stat_combined_proofs") || !strcmp(key, "stat_combined_requests")) {
+        uint64_t v = 0;
+        for (pool_dev *d : p->devs) {
+            std::lock_guard<std::mutex> g(d->cmu);
+            v += key[14] == 'c' ? d->stat_chains : key[14] == 'p' ? d->stat_proofs : d->stat_requests;
+        }
+        *value = (int64_t)v;
+    }
     else if (p->devs.empty() || p->devs[0]->lanes.empty()) return BPGPU_ERR_INVALID_ARG;
     else return bpgpu_ctx_get_option(p->devs[0]->lanes[0], key, value);
     return BPGPU_OK;
@@ -268,9 +589,10 @@ static int pool_spread_gens(bpgpu_pool *p, size_t gens_capacity, size_t party_ca
     for (pool_dev *d : p->devs) {
         int rc = bpgpu_gens_export(d->lanes[0], G.data(), H.data(), B, Bb);
         if (rc) return pfail(p, rc, "%s", bpgpu_last_error(d->lanes[0]));
-        for (size_t l = 1; l < d->lanes.size(); l++) {
-            rc = bpgpu_gens_load(d->lanes[l], gens_capacity, party_capacity, G.data(), H.data(), B, Bb);
-            if (rc) return pfail(p, rc, "%s", bpgpu_last_error(d->lanes[l]));
+        const std::vector<bpgpu_ctx *> ctxs = all_ctxs(d);
+        for (size_t l = 1; l < ctxs.size(); l++) {
+            rc = bpgpu_gens_load(ctxs[l], gens_capacity, party_capacity, G.data(), H.data(), B, Bb);
+            if (rc) return pfail(p, rc, "%s", bpgpu_last_error(ctxs[l]));
         }
     }
     return BPGPU_OK;
@@ -283,6 +605,7 @@ int bpgpu_pool_gens_create(bpgpu_pool *p, size_t gens_capacity, size_t party_cap
         const int rc = bpgpu_gens_create(d->lanes[0], gens_capacity, party_capacity);
         if (rc) return pfail(p, rc, "%s", bpgpu_last_error(d->lanes[0]));
     }
+    p->gens_epoch.fetch_add(1);
     return pool_spread_gens(p, gens_capacity, party_capacity);
 }
 int bpgpu_pool_gens_load(bpgpu_pool *p, size_t gens_capacity, size_t party_capacity, const uint8_t *G, const uint8_t *H, const uint8_t B[32],
@@ -294,6 +617,7 @@ int bpgpu_pool_gens_load(bpgpu_pool *p, size_t gens_capacity, size_t party_capac
         const int rc = bpgpu_gens_load(d->lanes[0], gens_capacity, party_capacity, G, H, B, Bb);
         if (rc) return pfail(p, rc, "%s", bpgpu_last_error(d->lanes[0]));
     }
+    p->gens_epoch.fetch_add(1);
     return pool_spread_gens(p, gens_capacity, party_capacity);
 }
 
@@ -316,7 +640,14 @@ int bpgpu_pool_rangeproof_verify(bpgpu_pool *p, size_t n, size_t m, size_t nbatc
                                  const uint8_t *label, size_t label_len, const uint8_t *rng64, uint8_t *verdict, uint8_t *msm_out) {
     if (!p || (nbatch && (!proofs || !verdict || (m && !commitments))) || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
     if (nbatch == 0) return BPGPU_OK;
-    std::lock_guard<std::mutex> lk(p->mu);   // one pool call at a time (its slices use every worker anyway)
+    if (p->host_path) {
+        // through the combining queue (below): any number of threads may be in here at once, their proofs share launch chains
+        if (label_len > 0xffffffffu) return BPGPU_ERR_INVALID_ARG;
+        uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
+        bpgpu_transcript_new(label, label_len, st0);
+        return bpgpu_pool_rangeproof_verify_ts(p, n, m, nbatch, proofs, proof_len, commitments, st0, 0, rng64, verdict, msm_out, nullptr);
+    }
+    std::lock_guard<std::mutex> lk(p->mu);   // option "host_path_combining" = 0: round 3's slicing workers, one pool call at a time
     const size_t ndev = p->devs.size();
     struct shared_state {
         std::mutex mu;
@@ -406,6 +737,537 @@ int bpgpu_pool_rangeproof_verify(bpgpu_pool *p, size_t n, size_t m, size_t nbatc
     return BPGPU_OK;
 }
 
+}  // extern "C"
+
+// ---- combining queue -----------------------------------------------------------------------------------------------
+// The reference's API is one proof per call, synchronous, from as many threads as the caller likes
+// (RangeProof::verify_multiple / verify_multiple_with_rng, src/range_proof/mod.rs:345-353, 455-470).  One such call cannot fill a
+// device and a launch chain costs ~0.6 ms of latency however narrow it is, so calls that arrive close together must share a
+// chain.  Per device:
+//   * callers (any thread, short lock): find the OPEN staging buffer of their class (comb_key) or open a free one, reserve slots,
+//     copy their inputs into the pinned block OUTSIDE the lock, count themselves in (`written`);
+//   * the service thread: seals an OPEN buffer when it is full, when its first proof has waited `combine_wait_us`, or when nothing
+//     joined for `combine_quiet_us`; issues a sealed buffer whose writers are done as ONE chain on the buffer's lane (copies in,
+//     bpgpu_internal_rp_verify_chain, copies out, event); polls the events of the chains in flight;
+//   * completion: the buffer's futex word flips, every synchronous caller with a piece in it wakes, takes its own verdicts (and
+//     advanced transcripts) out of the pinned block and drops its reference; the last one returns the buffer.  Pieces of tickets
+//     (bpgpu_pool_rangeproof_submit_ts) are delivered by the service thread.
+// With all lanes busy a buffer simply keeps filling: load widens the chains by itself.
+static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+// Layout of a buffer for `cap` proofs of class `key`.  Inputs: [commitments | rng | transcripts in | proofs] -- the small
+// per-proof records first, sized for `cap`; the proofs last, so that ONE copy [0, off_p + K proof_len) carries a chain of K <= cap
+// proofs (the unused tail of the small regions rides along: a buffer opened under light traffic has a small `cap`, comb_place).
+// Outputs: [verdicts | transcripts out | encodings]: ONE copy [off_v, off_to + 208 K) back.
+static size_t cbuf_layout(comb_buf *b, const comb_key &key, uint32_t cap) {
+    const bool per = key.mode != CK_SHARED;
+    size_t o = 0;
+    b->off_c = o, o += up256((size_t)cap * key.m * 32);
+    b->off_r = o, o += up256((size_t)cap * 64);
+    b->off_t = o, o += per ? up256((size_t)cap * BPGPU_TRANSCRIPT_BYTES) : 0;
+    b->off_p = o, o += up256((size_t)cap * key.proof_len);
+    b->in_bytes = o;
+    b->off_v = o, o += up256(cap);
+    b->off_to = o, o += per ? up256((size_t)cap * BPGPU_TRANSCRIPT_BYTES) : 0;
+    b->off_m = o, o += up256((size_t)cap * 32);
+    b->total = o;
+    return o;
+}
+static int cbuf_configure(bpgpu_pool *p, pool_dev *d, comb_buf *b, const comb_key &key, uint32_t cap, uint32_t cap_max) {
+    const size_t need = cbuf_layout(b, key, cap_max);   // the blocks are sized for the widest chain of this shape once and for all
+    b->key = key;
+    b->cap = cap;
+    b->cap_max = cap_max;
+    const size_t o = cap == cap_max ? need : (cbuf_layout(b, key, cap), need);
+    if (o > b->mem_cap) {   // the first chains of a shape (the calling thread's current device is put back afterwards)
+        int prev = -1;
+        (void)hipGetDevice(&prev);
+        hipError_t e = hipSetDevice(d->device);
+        if (e == hipSuccess && b->h) e = hipHostFree(b->h);
+        b->h = nullptr;
+        if (e == hipSuccess && b->d) e = hipFree(b->d);
+        b->d = nullptr;
+        b->mem_cap = 0;
+        const size_t want = o + o / 4;
+        if (e == hipSuccess) e = hipHostMalloc((void **)&b->h, want, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipMalloc((void **)&b->d, want);
+        if (prev >= 0) (void)hipSetDevice(prev);
+        if (e != hipSuccess) {
+            if (b->h) hipHostFree(b->h);
+            b->h = nullptr;
+            return pfail(p, BPGPU_ERR_HIP, "staging buffers of the combining queue: %s", hipGetErrorString(e));
+        }
+        b->mem_cap = want;
+    }
+    return BPGPU_OK;
+}
+
+static void cbuf_release(comb_buf *b) {
+    pool_dev *d = b->dev;
+    {
+        std::lock_guard<std::mutex> lk(d->cmu);
+        b->st = CB_FREE;
+        b->reserved = 0;
+        b->written.store(0, std::memory_order_relaxed);
+        b->phase.store(0, std::memory_order_relaxed);
+        b->any_msm = false;
+        b->poison.store(0, std::memory_order_relaxed);
+        b->rc = 0;
+        b->err.clear();
+    }
+    d->free_cv.notify_all();
+}
+
+// results of proofs [first, first + count) of a finished buffer -> proofs [off, ..) of the request
+static void comb_deliver(comb_buf *b, uint32_t first, uint32_t count, comb_req *r, size_t off) {
+    if (b->rc) {   // the chain did not run: nothing may read as "verified"
+        memset(r->verdict + off, BPGPU_VERDICT_UNDECIDED, count);
+        std::lock_guard<std::mutex> g(r->emu);
+        if (!r->rc) {
+            r->rc = b->rc;
+            r->err = b->err;
+        }
+        return;
+    }
+    memcpy(r->verdict + off, b->h + b->off_v + first, count);
+    if (r->msm) memcpy(r->msm + off * 32, b->h + b->off_m + (size_t)first * 32, (size_t)count * 32);
+    if (r->ts_out) memcpy(r->ts_out + off * BPGPU_TRANSCRIPT_BYTES, b->h + b->off_to + (size_t)first * BPGPU_TRANSCRIPT_BYTES, (size_t)count * BPGPU_TRANSCRIPT_BYTES);
+}
+
+// a synchronous caller takes the next of its pieces: sleeps until that buffer's chain is done
+static void comb_collect_one(comb_req *r) {
+    const comb_req::piece pc = r->pieces[r->next_piece++];
+    comb_buf *b = pc.b;
+    while (b->phase.load(std::memory_order_acquire) == 0) futex_wait(&b->phase, 0);
+    comb_deliver(b, pc.first, pc.count, r, pc.off);
+    if (b->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) cbuf_release(b);
+}
+
+static void comb_issue(bpgpu_pool *p, pool_dev *d, comb_buf *b, uint32_t inflight, bool more_waiting) {
+    hipStream_t s = (hipStream_t)bpgpu_internal_stream(b->ctx);
+    const comb_key &k = b->key;
+    const uint32_t K = b->reserved;
+    const bool per = k.mode != CK_SHARED;
+    const size_t TS = BPGPU_TRANSCRIPT_BYTES;
+    hipError_t e = hipSuccess;
+    if (b->poison.load(std::memory_order_acquire)) {   // a writer could not draw its batching challenge: the chain must not run on predictable bytes
+        b->rc = BPGPU_ERR_HIP;
+        b->err = "getrandom failed";
+        return;
+    }
+    if (b->reserved_n != k.n || b->reserved_m != k.m || b->reserved_len != k.proof_len || b->reserved_cap < b->cap_max) {
+        // first chain of this shape on this lane: size the lane's arena for the widest chain now, not in steps on the way up
+        (void)bpgpu_internal_rp_reserve(b->ctx, k.n, k.m, k.proof_len, b->cap_max);
+        b->reserved_n = k.n, b->reserved_m = k.m, b->reserved_len = k.proof_len, b->reserved_cap = b->cap_max;
+    }
+    auto cp_in = [&](size_t off, size_t bytes) {
+        if (e == hipSuccess && bytes) e = hipMemcpyAsync(b->d + off, b->h + off, bytes, hipMemcpyHostToDevice, s);
+    };
+    auto cp_out = [&](size_t off, size_t bytes) {
+        if (e == hipSuccess && bytes) e = hipMemcpyAsync(b->h + off, b->d + off, bytes, hipMemcpyDeviceToHost, s);
+    };
+    cp_in(0, b->off_p + (size_t)K * k.proof_len);
+    int rc = BPGPU_OK;
+    if (e == hipSuccess) {
+        // what the chain should expect beside it (rp_chain_forms, pick_splits): a chain that leaves a full buffer, or while others
+        // wait or run, takes the throughput forms; a lone small one the latency forms
+        const int busy = (inflight + (more_waiting ? 1u : 0u) >= p->combine_busy_chains || K > p->latency_proofs) ? 1 : 0;
+        uint32_t hint = (uint32_t)(16384 / ((size_t)(inflight + 1) * ((K + 63) / 64)));
+        hint = (hint + 7) & ~7u;
+        if (hint < 16) hint = 16;
+        if (hint > 64) hint = 64;
+        rc = bpgpu_internal_rp_verify_chain(b->ctx, k.n, k.m, K, b->d + b->off_p, k.proof_len, b->d + b->off_c, per ? nullptr : k.shared,
+                                            per ? b->d + b->off_t : nullptr, per ? b->d + b->off_to : nullptr, k.mode == CK_UNIFORM, k.pos, k.pos_begin,
+                                            k.flags, b->d + b->off_r, b->d + b->off_v, b->any_msm ? b->d + b->off_m : nullptr, hint, busy);
+        if (rc) b->err = bpgpu_last_error(b->ctx);
+    }
+    if (e == hipSuccess && !rc) {
+        cp_out(b->off_v, per ? (b->off_to - b->off_v) + (size_t)K * TS : (size_t)K);
+        if (b->any_msm) cp_out(b->off_m, (size_t)K * 32);
+        if (e == hipSuccess) e = hipEventRecord(b->done_ev, s);
+    }
+    if (e != hipSuccess) {
+        rc = BPGPU_ERR_HIP;
+        b->err = std::string("combining queue: ") + hipGetErrorString(e);
+        (void)hipGetLastError();
+    }
+    b->rc = rc;
+}
+
+// the chain of buffer `b` is over (or never went out): publish, deliver the tickets' pieces
+static void comb_complete(pool_dev *d, comb_buf *b) {
+    std::vector<comb_buf::apiece> ap;
+    {
+        std::lock_guard<std::mutex> lk(d->cmu);
+        b->st = CB_DONE;
+        ap.swap(b->async_pieces);
+        b->refs.fetch_add(1, std::memory_order_relaxed);   // the service thread's own hold while it delivers
+    }
+    b->phase.store(1, std::memory_order_release);
+    futex_wake_all(&b->phase);
+    uint32_t drop = 1;
+    for (const comb_buf::apiece &a : ap) {
+        comb_req *r = a.req;
+        comb_deliver(b, a.first, a.count, r, a.off);
+        drop++;
+        // the ticket's owner frees it once `left` reads 0 -- under emu, so not before this thread is done with it
+        std::lock_guard<std::mutex> g(r->emu);
+        if (r->left.fetch_sub(1, std::memory_order_seq_cst) == 1 && r->waiting.load(std::memory_order_seq_cst)) futex_wake_all(&r->left);
+    }
+    if (b->refs.fetch_sub(drop, std::memory_order_acq_rel) == drop) cbuf_release(b);
+}
+
+static void svc_main(bpgpu_pool *p, pool_dev *d) {
+    (void)hipSetDevice(d->device);
+    prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);   // this thread's timed waits are tens of microseconds: the default slack is 50
+    // Hundreds of caller threads become runnable whenever a chain ends; the one thread that issues the next chain must not queue
+    // behind them for a time slice.  Best effort (needs CAP_SYS_NICE): a real-time class, else a negative nice value.  The thread
+    // sleeps whenever it has nothing to do, so it cannot monopolise a core.
+    {
+        sched_param sp{};
+        sp.sched_priority = 1;
+        if (pthread_setschedparam(pthread_self(), SCHED_RR, &sp) != 0) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), -15);
+    }
+    std::unique_lock<std::mutex> lk(d->cmu);
+    std::vector<comb_buf *> to_issue, to_complete;
+    for (;;) {
+        if (d->cstop) return;
+        bool active = false;
+        const uint64_t now = now_ns(), wait_ns = p->combine_wait_ns, quiet_ns = p->combine_quiet_ns, max_age_ns = p->combine_max_age_ns;
+        const uint32_t target = p->combine_inflight;
+        d->stat_polls++;
+        uint32_t inflight = 0, waiting = 0;
+        for (comb_buf *b : d->cbufs) {
+            if (b->st == CB_ISSUED || b->st == CB_ISSUING) inflight++;
+            if (b->st == CB_OPEN || b->st == CB_SEALED) waiting++;
+        }
+        to_issue.clear();
+        to_complete.clear();
+        for (comb_buf *b : d->cbufs) {
+            if (b->st == CB_OPEN) {
+                active = true;
+                // the deadlines are for an idle-ish device (latency); with `target` chains already running the buffer goes on
+                // filling until one of them ends -- load widens the chains by itself
+                const bool due = now - b->t_first >= wait_ns || now - b->t_last >= quiet_ns;
+                if ((due && inflight < target) || now - b->t_first >= max_age_ns) {
+                    b->st = CB_SEALED;
+                    inflight++;   // (counts against the target at once: two buffers due in the same pass)
+                }
+            }
+            if (b->st == CB_SEALED) {
+                active = true;
+                if (b->written.load(std::memory_order_acquire) == b->reserved) {
+                    b->st = CB_ISSUING;
+                    to_issue.push_back(b);
+                }
+            } else if (b->st == CB_ISSUED) {
+                active = true;
+                const hipError_t e = hipEventQuery(b->done_ev);
+                if (e != hipErrorNotReady) {
+                    if (e != hipSuccess) {
+                        b->rc = BPGPU_ERR_HIP;
+                        b->err = std::string("combining queue: ") + hipGetErrorString(e);
+                    }
+                    to_complete.push_back(b);
+                } else (void)hipGetLastError();
+            }
+        }
+        if (!to_issue.empty() || !to_complete.empty()) {
+            lk.unlock();
+            const uint64_t ta = now_ns();
+            for (comb_buf *b : to_complete) comb_complete(d, b);
+            const uint64_t tb = now_ns();
+            uint32_t running = 0;
+            for (comb_buf *b : d->cbufs) running += (b->st == CB_ISSUED);   // (st of other buffers: only this thread moves them in / out of ISSUED)
+            for (comb_buf *b : to_issue) {
+                waiting--;
+                comb_issue(p, d, b, running, waiting > 0);
+                running++;
+                if (b->rc) comb_complete(d, b);   // never went out
+                else {
+                    std::lock_guard<std::mutex> g(d->cmu);
+                    b->st = CB_ISSUED;
+                    d->stat_chains++;
+                    d->stat_proofs += b->reserved;
+                    d->recent_K = b->reserved;
+                }
+            }
+            lk.lock();
+            d->stat_complete_ns += tb - ta;
+            d->stat_issue_ns += now_ns() - tb;
+            continue;   // look again at once: issuing took tens of microseconds
+        }
+        if (active) d->ccv.wait_for(lk, std::chrono::nanoseconds((uint64_t)p->combine_poll_ns));
+        else d->ccv.wait(lk);
+    }
+}
+
+static void stop_service(pool_dev *d) {
+    {
+        std::lock_guard<std::mutex> lk(d->cmu);
+        d->cstop = true;
+    }
+    d->ccv.notify_all();
+    if (d->svc.joinable()) d->svc.join();
+}
+
+// STROBE position class of a 208-byte state
+static inline void ts_class(const uint8_t *st, comb_key &k) {
+    k.pos = st[200];
+    k.pos_begin = st[201];
+    k.flags = st[202];
+}
+static inline bool ts_ok(const uint8_t *st) { return st[200] < 166 && st[201] <= 166; }
+
+// proofs [lo, hi) of the request go to device d's queue
+static int comb_place(bpgpu_pool *p, pool_dev *d, comb_req *r, const comb_key &base, const uint8_t *shared, size_t lo, size_t hi) {
+    const size_t TS = BPGPU_TRANSCRIPT_BYTES;
+    size_t off = lo;
+    while (off < hi) {
+        comb_key key = base;
+        size_t run = hi - off;
+        if (key.mode == CK_UNIFORM) {
+            const uint8_t *st0 = r->ts_in ? r->ts_in + off * TS : shared;
+            ts_class(st0, key);
+            if (r->ts_in) {   // the stretch of this request that sits at one STROBE position
+                size_t e = off + 1;
+                while (e < hi && r->ts_in[e * TS + 200] == st0[200] && r->ts_in[e * TS + 201] == st0[201] && r->ts_in[e * TS + 202] == st0[202]) e++;
+                run = e - off;
+            }
+        }
+        comb_buf *b = nullptr;
+        uint32_t first = 0, take = 0;
+        bool wake = false;
+        {
+            std::unique_lock<std::mutex> lk(d->cmu);
+            if (!d->svc_running) {
+                d->svc = std::thread(svc_main, p, d);
+                d->svc_running = true;
+            }
+            uint32_t n_open_classes = 0;
+            comb_buf *mixed = nullptr, *freeb = nullptr;
+            for (comb_buf *cb : d->cbufs) {
+                if (cb->st == CB_FREE) {
+                    if (!freeb || cb->mem_cap > freeb->mem_cap) freeb = cb;   // (prefer one whose blocks are already large enough)
+                    continue;
+                }
+                if (cb->st != CB_OPEN) continue;
+                if (cb->key == key) b = cb;
+                if (cb->key.mode == CK_UNIFORM) n_open_classes++;
+                if (cb->key.mode == CK_MIXED && cb->key.n == key.n && cb->key.m == key.m && cb->key.proof_len == key.proof_len) mixed = cb;
+            }
+            if (!b && key.mode == CK_UNIFORM && !(freeb && n_open_classes < p->combine_max_open) && (mixed || freeb)) {
+                // too many position classes open at once (or no buffer left for a new one): the catch-all, replayed byte-wise
+                key.mode = CK_MIXED;
+                key.pos = key.pos_begin = key.flags = 0;
+                run = hi - off;
+                b = mixed;
+            }
+            if (!b) {
+                if (!freeb) {   // every lane is filling or running: take a finished piece of our own meanwhile, or wait for a buffer
+                    if (!r->async && r->next_piece < r->pieces.size()) {
+                        lk.unlock();
+                        comb_collect_one(r);
+                    } else {
+                        d->free_cv.wait_for(lk, std::chrono::microseconds(200));
+                    }
+                    continue;
+                }
+                size_t cap_max = p->coalesce_proofs;
+                if (cap_max > p->max_chain_proofs) cap_max = p->max_chain_proofs;
+                // light traffic opens a small buffer (its staging copy carries the small regions whole), heavy traffic a full-width one
+                const size_t want = std::max<size_t>((size_t)4 * d->recent_K, run);
+                const size_t cap = want <= 256 ? std::min<size_t>(256, cap_max) : want <= 1024 ? std::min<size_t>(1024, cap_max) : cap_max;
+                const int rc = cbuf_configure(p, d, freeb, key, (uint32_t)cap, (uint32_t)cap_max);
+                if (rc) return rc;
+                b = freeb;
+                b->st = CB_OPEN;
+                b->t_first = now_ns();
+                wake = true;   // the service thread may be asleep with nothing to watch
+            }
+            first = b->reserved;
+            take = (uint32_t)(run < (size_t)(b->cap - first) ? run : (size_t)(b->cap - first));
+            b->reserved += take;
+            b->t_last = first ? now_ns() : b->t_first;
+            b->refs.fetch_add(1, std::memory_order_relaxed);
+            if (r->msm) b->any_msm = true;
+            if (b->reserved == b->cap) {
+                b->st = CB_SEALED;
+                wake = true;
+            }
+            if (r->async) {
+                b->async_pieces.push_back({r, first, take, off});
+                r->left.fetch_add(1, std::memory_order_relaxed);
+            } else {
+                r->pieces.push_back({b, first, take, off});
+            }
+        }
+        if (wake) d->ccv.notify_one();
+        // ---- inputs into the pinned block (no lock held) ----
+        memcpy(b->h + b->off_p + (size_t)first * r->proof_len, r->proofs + off * r->proof_len, (size_t)take * r->proof_len);
+        memcpy(b->h + b->off_c + (size_t)first * r->m * 32, r->coms + off * r->m * 32, (size_t)take * r->m * 32);
+        if (r->rng) memcpy(b->h + b->off_r + (size_t)first * 64, r->rng + off * 64, (size_t)take * 64);
+        else if (!fast_random((uint8_t *)b->h + b->off_r + (size_t)first * 64, (size_t)take * 64)) b->poison.store(1, std::memory_order_release);
+        if (key.mode != CK_SHARED) {
+            char *dst = b->h + b->off_t + (size_t)first * TS;
+            if (r->ts_in) memcpy(dst, r->ts_in + off * TS, (size_t)take * TS);
+            else
+                for (uint32_t i = 0; i < take; i++) memcpy(dst + (size_t)i * TS, shared, TS);
+        }
+        b->written.fetch_add(take, std::memory_order_release);
+        off += take;
+    }
+    return BPGPU_OK;
+}
+
+// requests no chain can take: malformed lengths, parameter errors, missing generators -- the ordinary entry point on the odd-jobs
+// context reports them proof by proof (ProofError::FormatError / InvalidBitsize / InvalidGeneratorsLength, mod.rs:358-366, 505-510)
+static int comb_direct(bpgpu_pool *p, pool_dev *d, comb_req *r, const uint8_t *shared) {
+    std::lock_guard<std::mutex> lk(d->misc_mu);
+    const int rc = bpgpu_rangeproof_verify_batch_ts(d->misc, r->n, r->m, r->nbatch, r->proofs, r->proof_len, r->coms, r->ts_in ? r->ts_in : shared,
+                                                    r->ts_in ? BPGPU_TRANSCRIPT_BYTES : 0, r->rng, r->verdict, r->msm, r->ts_out);
+    if (rc) return pfail(p, rc, "%s", bpgpu_last_error(d->misc));
+    return BPGPU_OK;
+}
+
+// validate, classify, place.  Synchronous requests also collect; tickets return once everything is placed.
+static int comb_run_inner(bpgpu_pool *p, comb_req *r, const uint8_t *transcripts, size_t stride) {
+    if (!p || p->devs.empty()) return BPGPU_ERR_INVALID_ARG;
+    if (r->nbatch == 0) return BPGPU_OK;
+    if (!r->proofs || !r->verdict || (r->m && !r->coms) || !transcripts) return pfail(p, BPGPU_ERR_INVALID_ARG, "null argument");
+    if (stride != 0 && stride != BPGPU_TRANSCRIPT_BYTES) return pfail(p, BPGPU_ERR_INVALID_ARG, "transcript_stride neither 0 nor BPGPU_TRANSCRIPT_BYTES");
+    if (r->nbatch > 0x7fffffffu / 64) return pfail(p, BPGPU_ERR_INVALID_ARG, "batch too large");
+    for (size_t i = 0; i < (stride ? r->nbatch : 1); i++)
+        if (!ts_ok(transcripts + i * BPGPU_TRANSCRIPT_BYTES)) return pfail(p, BPGPU_ERR_INVALID_ARG, "malformed transcript state %zu", i);
+    const uint8_t *shared = stride ? nullptr : transcripts;
+    r->ts_in = stride ? transcripts : nullptr;
+    comb_key base;
+    base.n = (uint32_t)r->n;
+    base.m = (uint32_t)r->m;
+    base.proof_len = (uint32_t)r->proof_len;
+    if (shared && !r->ts_out) {
+        base.mode = CK_SHARED;
+        memcpy(base.shared, shared, BPGPU_TRANSCRIPT_BYTES);
+        memset(base.shared + 203, 0, BPGPU_TRANSCRIPT_BYTES - 203);   // (bytes behind the STROBE bookkeeping carry nothing)
+    } else base.mode = CK_UNIFORM;
+    const size_t ndev = p->devs.size();
+    pool_dev *d0 = p->devs[p->rr_dev.fetch_add(1, std::memory_order_relaxed) % ndev];
+    // can chains take this shape?  (asked of the odd-jobs context; the answer is remembered per thread until generators change)
+    static thread_local struct {
+        const bpgpu_pool *p;
+        size_t n, m, len;
+        uint64_t epoch;
+    } ok_shape = {nullptr, 0, 0, 0, 0};
+    const uint64_t epoch = p->gens_epoch.load(std::memory_order_acquire);
+    bool ok = ok_shape.p == p && ok_shape.n == r->n && ok_shape.m == r->m && ok_shape.len == r->proof_len && ok_shape.epoch == epoch;
+    if (!ok && r->n <= 0xffff && r->m <= 0xffffff && r->proof_len <= 0xffffff && bpgpu_internal_rp_coalescible(d0->misc, r->n, r->m, r->proof_len)) {
+        ok_shape = {p, r->n, r->m, r->proof_len, epoch};
+        ok = true;
+    }
+    if (!ok) {
+        return comb_direct(p, d0, r, shared);
+    }
+    {
+        std::lock_guard<std::mutex> g(d0->cmu);
+        d0->stat_requests++;
+    }
+    // Proofs are independent units: a large request takes a contiguous shard per device, a small one a single device
+    // (round-robin over the requests).  The "gather" is the placement of every piece's verdicts at its offset of the caller's buffer.
+    int rc = BPGPU_OK;
+    if (ndev == 1 || r->nbatch < 512 * ndev) {
+        rc = comb_place(p, d0, r, base, shared, 0, r->nbatch);
+    } else {
+        for (size_t di = 0; di < ndev && !rc; di++) {
+            const size_t lo = r->nbatch * di / ndev, hi = r->nbatch * (di + 1) / ndev;
+            if (hi > lo) rc = comb_place(p, p->devs[di], r, base, shared, lo, hi);
+        }
+    }
+    if (r->async) return rc;   // (comb_run drops the placement guard)
+    while (r->next_piece < r->pieces.size()) comb_collect_one(r);   // (also after a placement error: nothing stays referenced behind the caller's back)
+    if (!rc && r->rc) rc = pfail(p, r->rc, "%s", r->err.c_str());
+    return rc;
+}
+static int comb_run(bpgpu_pool *p, comb_req *r, const uint8_t *transcripts, size_t stride) {
+    const int rc = comb_run_inner(p, r, transcripts, stride);
+    if (r->async) {
+        // the placement guard goes; the ticket is complete when its last piece has been delivered (bpgpu_pool_ticket_wait)
+        std::lock_guard<std::mutex> g(r->emu);
+        r->left.fetch_sub(1, std::memory_order_seq_cst);
+        if (rc && !r->rc) {
+            r->rc = rc;
+            r->err = t_pool_err;
+        }
+    }
+    return rc;
+}
+
+// a ticket's owner sleeps until its last piece has been delivered
+static void ticket_block(comb_req *r) {
+    for (;;) {
+        uint32_t v = r->left.load(std::memory_order_acquire);
+        if (v == 0) break;
+        r->waiting.store(1, std::memory_order_seq_cst);
+        v = r->left.load(std::memory_order_seq_cst);
+        if (v == 0) break;
+        futex_wait(&r->left, v);
+    }
+    std::lock_guard<std::mutex> g(r->emu);   // the delivering thread's last touch of the request happens under emu
+}
+
+extern "C" {
+
+int bpgpu_pool_rangeproof_verify_ts(bpgpu_pool *p, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len, const uint8_t *commitments,
+                                    const uint8_t *transcripts, size_t transcript_stride, const uint8_t *rng64, uint8_t *verdict, uint8_t *msm_out,
+                                    uint8_t *transcripts_out) {
+    if (!p) return BPGPU_ERR_INVALID_ARG;
+    comb_req r;
+    r.n = n, r.m = m, r.nbatch = nbatch, r.proof_len = proof_len;
+    r.proofs = proofs, r.coms = commitments, r.rng = rng64;
+    r.verdict = verdict, r.msm = msm_out, r.ts_out = transcripts_out;
+    return comb_run(p, &r, transcripts, transcript_stride);
+}
+
+int bpgpu_pool_rangeproof_submit_ts(bpgpu_pool *p, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len, const uint8_t *commitments,
+                                    const uint8_t *transcripts, size_t transcript_stride, const uint8_t *rng64, uint8_t *verdict, uint8_t *msm_out,
+                                    uint8_t *transcripts_out, bpgpu_ticket **ticket) {
+    if (!p || !ticket) return BPGPU_ERR_INVALID_ARG;
+    *ticket = nullptr;
+    comb_req *r = new comb_req();
+    r->async = true;
+    r->n = n, r->m = m, r->nbatch = nbatch, r->proof_len = proof_len;
+    r->proofs = proofs, r->coms = commitments, r->rng = rng64;
+    r->verdict = verdict, r->msm = msm_out, r->ts_out = transcripts_out;
+    const int rc = comb_run(p, r, transcripts, transcript_stride);
+    if (rc) {   // argument errors, or placement broke off: whatever is in flight is waited for, then the error is this call's
+        const std::string keep = t_pool_err;
+        ticket_block(r);
+        delete r;
+        t_pool_err = keep;
+        return rc;
+    }
+    *ticket = (bpgpu_ticket *)r;
+    return BPGPU_OK;
+}
+
+int bpgpu_pool_ticket_done(bpgpu_pool *p, bpgpu_ticket *ticket) {
+    if (!p || !ticket) return BPGPU_ERR_INVALID_ARG;
+    return ((comb_req *)ticket)->left.load(std::memory_order_acquire) == 0 ? 1 : 0;
+}
+
+int bpgpu_pool_ticket_wait(bpgpu_pool *p, bpgpu_ticket *ticket) {
+    if (!p || !ticket) return BPGPU_ERR_INVALID_ARG;
+    comb_req *r = (comb_req *)ticket;
+    ticket_block(r);
+    const int rc = r->rc;
+    if (rc) t_pool_err = r->err;
+    delete r;
+    return rc;
+}
+
+}  // extern "C"
+
+extern "C" {
+
 // ---- device pointers, asynchronous ------------------------------------------------------------------------------
 static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain = false) {
     if (d->pending.empty()) return BPGPU_OK;
@@ -442,6 +1304,8 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain = false) {
     if (hint < 16) hint = 16;
     if (hint > 64) hint = 64;
     int rc_all = BPGPU_OK;
+    size_t n_undecided = 0;
+    std::string first_err;
     std::vector<rp_seg> segs;
     size_t i = 0, off = 0;   // item i, `off` proofs of it already placed
     while (i < items.size()) {
@@ -452,7 +1316,14 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain = false) {
             // malformed length / parameter error / missing generators: the ordinary entry point reports it proof by proof
             const int rc = bpgpu_rangeproof_verify_batch_dev(c, head.n, head.m, head.nbatch, head.proofs, head.proof_len, head.coms,
                                                              (const uint8_t *)head.label.data(), head.label.size(), head.rng, head.verdict, head.msm, nullptr);
-            if (rc && !rc_all) rc_all = pfail(p, rc, "%s", bpgpu_last_error(c));
+            if (rc) {
+                (void)hipMemsetAsync(head.verdict, BPGPU_VERDICT_UNDECIDED, head.nbatch, (hipStream_t)bpgpu_internal_stream(c));
+                n_undecided += head.nbatch;
+                if (!rc_all) {
+                    rc_all = rc;
+                    first_err = bpgpu_last_error(c);
+                }
+            }
             i++;
             off = 0;
             continue;
@@ -481,14 +1352,26 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain = false) {
                 off = 0;
             }
         }
-        bpgpu_internal_set_busy_hint(c, (was_idle && T <= p->latency_proofs) ? 0 : 1);
         const int rc = bpgpu_internal_rp_verify_segs(c, head.n, head.m, head.proof_len, (const uint8_t *)head.label.data(), head.label.size(), segs.data(),
-                                                     (uint32_t)segs.size(), any_msm, hint);
-        if (rc && !rc_all) rc_all = pfail(p, rc, "%s", bpgpu_last_error(c));
+                                                     (uint32_t)segs.size(), any_msm, hint, (was_idle && T <= p->latency_proofs) ? 0 : 1);
+        if (rc) {
+            // The chain did not go out: its items' verdict bytes must not read 0 = "verified" (a caller with zero-initialised
+            // buffers would take that for acceptance).  Every affected range gets BPGPU_VERDICT_UNDECIDED; the flush goes on with
+            // the next chain and reports the first error together with the number of proofs left undecided.
+            for (const rp_seg &sg : segs) {
+                (void)hipMemsetAsync(sg.verdict, BPGPU_VERDICT_UNDECIDED, sg.count, (hipStream_t)bpgpu_internal_stream(c));
+                n_undecided += sg.count;
+            }
+            if (!rc_all) {
+                rc_all = rc;
+                first_err = bpgpu_last_error(c);
+            }
+        }
         p->stat_chains++;
         p->stat_chain_proofs += filled;
         p->stat_last_splits = hint;
     }
+    if (rc_all) return pfail(p, rc_all, "%s (%zu proofs of this flush are marked BPGPU_VERDICT_UNDECIDED; every other verdict of it is valid)", first_err.c_str(), n_undecided);
     return rc_all;
 }
 

@@ -340,8 +340,11 @@ BP_HD void rp_script_xor_record(const kstate &st, uint32_t pos, const uint32_t w
         st.w[(wi + 8) * st.stride] ^= w[7] >> (32 - sh);
     }
 }
+// ts_in (optional): one caller-supplied start state per proof -- allowed here when all of them sit at the SAME STROBE position
+// (pos, pos_begin, cur_flags: what the script was compiled for; the pool's combining queue groups requests that way); only the
+// 50 sponge words differ from proof to proof.
 BP_HD void rp_transcript_scripted(uint32_t p, rp_shape sh, const rp_strobe_init &init, kstate st, const rp_inputs &in, const rp_script_hdr *script,
-                                  uint32_t *fields, uint32_t *status, uint32_t *ts_out = nullptr) {
+                                  uint32_t *fields, uint32_t *status, uint32_t *ts_out = nullptr, const uint32_t *ts_in = nullptr) {
     const uint32_t B = sh.nproofs, k = sh.k;
     const uint8_t *pr = in.pr;
     const rp_fields fl = rp_field_layout(k, sh.m);
@@ -356,12 +359,12 @@ BP_HD void rp_transcript_scripted(uint32_t p, rp_shape sh, const rp_strobe_init 
     load_words8(b.v, pr + 224 + 64 * k + 32);  fmt_ok = fmt_ok && sc_is_canonical_sc(b);
     if (!fmt_ok) {
         status_raise(status + p, BP_VERDICT_FORMAT);
-        rp_ts_passthrough(p, init, nullptr, ts_out);
+        rp_ts_passthrough(p, init, ts_in, ts_out);
         return;
     }
     if (sh.shape_verdict) {
         status_raise(status + p, sh.shape_verdict);
-        rp_ts_passthrough(p, init, nullptr, ts_out);
+        rp_ts_passthrough(p, init, ts_in, ts_out);
         return;
     }
     rp_store(fields, B, RPF_TX, p, tx);
@@ -375,7 +378,12 @@ BP_HD void rp_transcript_scripted(uint32_t p, rp_shape sh, const rp_strobe_init 
         load_words8(w, pr + (u < 4 ? 32 * u : 224 + 32 * (u - 4)));
         verr = verr || words8_zero(w);
     }
-    for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, init.w[i]);
+    if (ts_in) {
+        const uint32_t *src = ts_in + (uint64_t)p * BP_TS_WORDS;
+        for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, src[i]);
+    } else {
+        for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, init.w[i]);
+    }
     const rp_script_op *ops = rp_script_ops(script);
     const uint32_t *masks = rp_script_masks(script);
     const uint32_t n_ops = script->n_ops;

@@ -465,6 +465,38 @@ int bpgpu_pool_rangeproof_verify(bpgpu_pool *pool, size_t n, size_t m, size_t nb
 int bpgpu_pool_rangeproof_submit_dev(bpgpu_pool *pool, int dev_index, size_t n, size_t m, size_t nbatch, const void *d_proofs,
                                      size_t proof_len, const void *d_commitments, const uint8_t *label, size_t label_len,
                                      const void *d_rng64, void *d_verdict, void *d_msm_out);
+/* RangeProof::verify_multiple_with_rng in the reference's own call shape (src/range_proof/mod.rs:345-353, 455-470): a FEW proofs
+ * per call -- one is fine --, each with its own `transcript: &mut Transcript`, BLOCKING, from ANY number of threads at once.
+ * Calls that arrive close together share a launch chain (the pool's combining queue: one staging buffer per class of requests
+ * -- shape and STROBE position of the transcripts --, which leaves as one chain when it is full ("coalesce_proofs"), when its
+ * first proof has waited "combine_wait_us" (default 100) or when nothing joined it for "combine_quiet_us" (default 20); every
+ * caller is woken when ITS proofs are done, not when the pool drains).  Arguments as bpgpu_rangeproof_verify_batch_ts:
+ *   transcripts / transcript_stride : BPGPU_TRANSCRIPT_BYTES: one 208-byte state per proof (may have absorbed application data:
+ *                 the normal use of Merlin); 0: ONE state shared by the nbatch proofs (e.g. bpgpu_transcript_new(label))
+ *   transcripts_out (optional, nbatch x 208; may alias `transcripts` when the stride is 208): the advanced states, as
+ *                 bpgpu_rangeproof_verify_batch_ts leaves them (a FormatError proof's state is handed back untouched)
+ *   rng64 (optional): 64 bytes per proof for the batching challenge; NULL: drawn per calling thread from a ChaCha20 generator
+ *                 keyed by the OS (the thread_rng() of verify_multiple)
+ * Verdicts, encodings and states are bit-identical to bpgpu_rangeproof_verify_batch_ts on the same inputs.  Requests of any
+ * size are accepted (a large one spans several chains and, on a multi-device pool, takes a contiguous shard per device).
+ * bpgpu_pool_rangeproof_verify (label instead of transcripts) is the same call with Transcript::new(label) for every proof.
+ * On a non-zero return no verdict byte of the call reads 0: proofs whose chain failed carry BPGPU_VERDICT_UNDECIDED.
+ *
+ * bpgpu_pool_rangeproof_submit_ts: the non-blocking form.  Returns once the inputs have been copied (they may be reused at
+ * once); verdict / msm_out / transcripts_out must stay valid until bpgpu_pool_ticket_wait(ticket) has returned -- it blocks
+ * until THIS request is complete (not the pool), returns the request's error code and frees the ticket; every ticket must be
+ * waited for exactly once.  bpgpu_pool_ticket_done: 1 when wait would not block.  One thread can thereby keep thousands of
+ * single-proof requests in flight. */
+typedef struct bpgpu_ticket bpgpu_ticket;
+int bpgpu_pool_rangeproof_verify_ts(bpgpu_pool *pool, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len,
+                                    const uint8_t *commitments, const uint8_t *transcripts, size_t transcript_stride,
+                                    const uint8_t *rng64, uint8_t *verdict, uint8_t *msm_out, uint8_t *transcripts_out);
+int bpgpu_pool_rangeproof_submit_ts(bpgpu_pool *pool, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len,
+                                    const uint8_t *commitments, const uint8_t *transcripts, size_t transcript_stride,
+                                    const uint8_t *rng64, uint8_t *verdict, uint8_t *msm_out, uint8_t *transcripts_out,
+                                    bpgpu_ticket **ticket);
+int bpgpu_pool_ticket_done(bpgpu_pool *pool, bpgpu_ticket *ticket);
+int bpgpu_pool_ticket_wait(bpgpu_pool *pool, bpgpu_ticket *ticket);
 int bpgpu_pool_flush(bpgpu_pool *pool);   /* issue everything queued; returns without waiting */
 int bpgpu_pool_wait(bpgpu_pool *pool);    /* flush, then wait until every lane is idle */
 

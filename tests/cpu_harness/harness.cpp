@@ -235,6 +235,48 @@ int h_rp_transcript_compare(uint32_t n, uint32_t m, uint32_t nbatch, const uint8
     return 0;
 }
 
+// The same comparison with ONE START STATE PER PROOF, all at the same STROBE position (what the pool's combining queue hands a
+// chain: bpgpu_pool_rangeproof_verify_ts, CK_UNIFORM): scripted replay from ts_in[p] against the byte-wise replay from ts_in[p].
+// states208: nbatch x 208 bytes.  Returns 0 when identical; -2 when the states do not share a position.
+int h_rp_transcript_compare_per_proof(uint32_t n, uint32_t m, uint32_t nbatch, const uint8_t *proofs, uint32_t proof_len, const uint8_t *commitments,
+                                      const uint8_t *rng64, const uint8_t *states208, uint8_t *status_out, uint8_t *ts_out208) {
+    uint32_t k = 0; while ((1u << k) < n * m) k++;
+    rp_shape sh; sh.n = n; sh.m = m; sh.nm = n * m; sh.k = k; sh.U = 4 + 2 * k + m; sh.proof_len = proof_len; sh.nproofs = nbatch; sh.shape_verdict = 0;
+    if (proof_len != 32 * (9 + 2 * k)) return -1;
+    std::vector<uint32_t> ts_in((size_t)nbatch * BP_TS_WORDS, 0);
+    for (uint32_t p = 0; p < nbatch; p++) {
+        const uint8_t *st = states208 + (size_t)p * 208;
+        if (st[200] != states208[200] || st[201] != states208[201] || st[202] != states208[202]) return -2;
+        memcpy(&ts_in[(size_t)p * BP_TS_WORDS], st, 200);
+        ts_in[(size_t)p * BP_TS_WORDS + 50] = rp_ts_meta(st[200], st[201], st[202]);
+    }
+    rp_strobe_init init; memset(&init, 0, sizeof init);   // only the position is shared; the words come from ts_in
+    init.pos = states208[200]; init.pos_begin = states208[201]; init.cur_flags = states208[202];
+    const std::vector<uint32_t> img = rp_script_build(n, m, k, init.pos, init.pos_begin, init.cur_flags, true);
+    const rp_script_hdr *script = (const rp_script_hdr *)img.data();
+    const rp_fields fl = rp_field_layout(k, m);
+    const size_t nf = (size_t)fl.count * nbatch * BP_RP_REC + 8;
+    std::vector<uint32_t> f1(nf, 0xabababab), f2(nf, 0xabababab), s1(nbatch + 1, 0), s2(nbatch + 1, 0), t1((size_t)nbatch * BP_TS_WORDS, 7), t2((size_t)nbatch * BP_TS_WORDS, 7);
+    rp_seg_tab none; memset(&none, 0, sizeof none);
+    for (uint32_t p = 0; p < nbatch; p++) {
+        uint32_t w1[50], w2[50]; kstate st1, st2; st1.w = w1; st1.stride = 1; st2.w = w2; st2.stride = 1;
+        const rp_inputs in = rp_resolve(p, sh, proofs, commitments, rng64, none);
+        rp_transcript_thread(p, sh, init, st1, in, f1.data(), s1.data(), BP_TS_DOMSEP, ts_in.data(), t1.data());
+        rp_transcript_scripted(p, sh, init, st2, in, script, f2.data(), s2.data(), t2.data(), ts_in.data());
+    }
+    for (uint32_t p = 0; p < nbatch; p++) {
+        status_out[p] = (uint8_t)s1[p];
+        memcpy(ts_out208 + (size_t)p * 208, &t1[(size_t)p * BP_TS_WORDS], 200);
+        const uint32_t meta = t1[(size_t)p * BP_TS_WORDS + 50];
+        memset(ts_out208 + (size_t)p * 208 + 200, 0, 8);
+        ts_out208[(size_t)p * 208 + 200] = meta & 0xff; ts_out208[(size_t)p * 208 + 201] = (meta >> 8) & 0xff; ts_out208[(size_t)p * 208 + 202] = (meta >> 16) & 0xff;
+    }
+    if (s1 != s2) return 1;
+    if (t1 != t2) return 2;
+    if (f1 != f2) return 3;
+    return 0;
+}
+
 void h_merlin_kat(const uint8_t *label, uint32_t label_len, const uint8_t *mlabel, uint32_t mlabel_len, const uint8_t *msg, uint32_t msg_len,
                   const uint8_t *clabel, uint32_t clabel_len, uint8_t *out, uint32_t out_len) {
     uint32_t w[50]; kstate st; st.w = w; st.stride = 1;

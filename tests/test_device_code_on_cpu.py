@@ -434,6 +434,44 @@ def test_scripted_transcript_equals_bytewise_replay_and_oracle(H, oracle, golden
     assert len(seen_perms) > 3
 
 
+def test_scripted_transcript_with_one_start_state_per_proof(H, oracle, golden):
+    """The combining queue of the pool hands a chain one caller transcript PER PROOF, all at the same STROBE position
+    (bpgpu_pool_rangeproof_verify_ts): the scripted replay then starts from ts_in[p] instead of a common state.  Lane by lane
+    against the byte-wise replay from the same states, and against the oracle's verify_ts (advanced transcript) per proof."""
+    from bulletproofs_amd._lib import transcript_new, transcript_append_message
+    vc = golden["vc_bytes"]
+    for case in golden["cases"][::3]:
+        n, m = case["n"], case["m"]
+        pr = bytes.fromhex(case["proof"])
+        nb = 5
+        f = bytearray(pr)
+        f[160:192] = b"\xff" * 32          # FormatError: this proof's transcript is handed back untouched
+        proofs = pr * 3 + bytes(f) + pr
+        coms = vc[:32 * m] * nb
+        rng = hashlib.shake_256(b"pp%d%d" % (n, m)).digest(64 * nb)
+        for ln in (0, 5, 41, 150):         # same message LENGTH for every proof: one position class, different sponge words
+            states = b""
+            for b_ in range(nb):
+                st = transcript_new(b"app %d" % 7)
+                st = transcript_append_message(st, b"session", bytes((b_ * 31 + q) & 0xff for q in range(ln)) if ln else b"")
+                if ln == 0:
+                    st = transcript_append_message(st, b"who", bytes([65 + b_]) * 4)
+                states += st
+            assert len({states[208 * b_ + 200:208 * b_ + 203] for b_ in range(nb)}) == 1 and len({states[208 * b_:208 * b_ + 200] for b_ in range(nb)}) == nb
+            so, to = C.create_string_buffer(nb), C.create_string_buffer(208 * nb)
+            rc = H.h_rp_transcript_compare_per_proof(n, m, nb, proofs, len(pr), coms, rng, states, so, to)
+            assert rc == 0, (n, m, ln, rc)
+            assert list(so.raw) == [0, 0, 0, 2, 0]
+            assert to.raw[208 * 3:208 * 4] == states[208 * 3:208 * 4]
+            for b_ in (0, 2, 4):
+                _, _, ts_o = oracle.verify_ts(oracle.Gens(n, m), pr, coms[:32 * m], n, states[208 * b_:208 * (b_ + 1)], rng[64 * b_:64 * b_ + 64])
+                assert ts_o == to.raw[208 * b_:208 * (b_ + 1)], (n, m, ln, b_)
+        # states at different positions are refused by the harness (the queue never builds such a chain for the script)
+        st_a = transcript_append_message(transcript_new(b"a"), b"x", b"12")
+        st_b = transcript_append_message(transcript_new(b"a"), b"x", b"123")
+        assert H.h_rp_transcript_compare_per_proof(n, m, 2, pr * 2, len(pr), coms[:64 * m], rng, st_a + st_b, so, to) == -2
+
+
 def test_window_recoding_all_widths(H):
     """fb_recode / fb_nwin (msm_fixed.h): for every window width 2..20 the signed digits reconstruct the scalar and
     ceil(255 / W) windows suffice (W = 17 is the first width that saves a window: 15 instead of 16)."""

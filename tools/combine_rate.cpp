@@ -1,0 +1,209 @@
+// Rate and latency of the pool's combining queue from plain host threads (no Python in the loop):
+//   threads T [B]     T threads, each looping BLOCKING bpgpu_pool_rangeproof_verify_ts calls of B proofs (default 1), every proof with
+//                     its own transcript -- the reference's verify_multiple_with_rng call shape (src/range_proof/mod.rs:345-353)
+//   tickets T Q       T threads, each keeping Q single-proof tickets in flight (bpgpu_pool_rangeproof_submit_ts / _ticket_wait)
+//   big T NB          T threads, each looping blocking label-mode calls of NB proofs (bpgpu_pool_rangeproof_verify)
+// Inputs: the file tools/combine_rate.py writes (proofs proven on fresh and on pre-bound transcripts, a few invalid, with the
+// oracle's verdicts and advanced transcripts): EVERY result of every call is compared with it.
+// Build: g++ -O2 -std=c++17 -pthread -I include tools/combine_rate.cpp -L bulletproofs_amd/csrc -lbpgpu -Wl,-rpath,... -o combine_rate
+#include <algorithm>
+#include <atomic>
+#include <chrono>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "bpgpu.h"
+
+struct inputs {
+    uint32_t n, m, proof_len, count;
+    std::vector<uint8_t> proofs, coms, states, rng, exp_v, exp_ts, fresh;
+};
+static bool load(const char *path, inputs &in) {
+    FILE *f = fopen(path, "rb");
+    if (!f) return false;
+    uint32_t h[4];
+    if (fread(h, 4, 4, f) != 4) return false;
+    in.n = h[0], in.m = h[1], in.proof_len = h[2], in.count = h[3];
+    auto rd = [&](std::vector<uint8_t> &v, size_t per) {
+        v.resize((size_t)in.count * per);
+        return fread(v.data(), 1, v.size(), f) == v.size();
+    };
+    const bool ok = rd(in.proofs, in.proof_len) && rd(in.coms, 32 * in.m) && rd(in.states, 208) && rd(in.rng, 64) && rd(in.exp_v, 1) && rd(in.exp_ts, 208) && rd(in.fresh, 1);
+    fclose(f);
+    return ok;
+}
+static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+
+int main(int argc, char **argv) {
+    if (argc < 5) {
+        fprintf(stderr, "usage: combine_rate <inputs> <seconds> threads T [B] | tickets T Q | big T NB   (env: BP_LANES, BP_W, BP_OPTS=key=val,...)\n");
+        return 2;
+    }
+    inputs in;
+    if (!load(argv[1], in)) {
+        fprintf(stderr, "cannot read %s\n", argv[1]);
+        return 2;
+    }
+    const double seconds = atof(argv[2]);
+    const std::string mode = argv[3];
+    const int T = atoi(argv[4]);
+    const int arg2 = argc > 5 ? atoi(argv[5]) : 1;
+    const int dev = 0;
+    bpgpu_pool *pool = nullptr;
+    const int lanes = getenv("BP_LANES") ? atoi(getenv("BP_LANES")) : 8;
+    int rc = bpgpu_pool_create(&dev, 1, lanes, &pool);
+    if (rc) {
+        fprintf(stderr, "bpgpu_pool_create: %d\n", rc);
+        return 1;
+    }
+    if (getenv("BP_W")) bpgpu_pool_set_option(pool, "fixed_window_bits", atoi(getenv("BP_W")));
+    if (const char *o = getenv("BP_OPTS")) {
+        std::string s = o;
+        size_t p = 0;
+        while (p < s.size()) {
+            size_t e = s.find(',', p);
+            if (e == std::string::npos) e = s.size();
+            const std::string kv = s.substr(p, e - p);
+            const size_t q = kv.find('=');
+            if (q != std::string::npos && bpgpu_pool_set_option(pool, kv.substr(0, q).c_str(), atoll(kv.c_str() + q + 1)))
+                fprintf(stderr, "option %s refused: %s\n", kv.c_str(), bpgpu_pool_last_error(pool));
+            p = e + 1;
+        }
+    }
+    rc = bpgpu_pool_gens_create(pool, in.n, in.m);
+    if (rc) {
+        fprintf(stderr, "gens: %s\n", bpgpu_pool_last_error(pool));
+        return 1;
+    }
+    const size_t PL = in.proof_len, CM = 32 * in.m;
+    std::atomic<uint64_t> total{0}, mismatches{0}, errors{0};
+    std::vector<std::vector<float>> lat(T);
+    std::atomic<bool> stop{false};
+    std::atomic<int> ready{0};
+    auto check = [&](size_t idx, const uint8_t *v, const uint8_t *ts) {
+        bool ok = v[0] == in.exp_v[idx];
+        if (ts && in.exp_v[idx] != 2) ok = ok && memcmp(ts, &in.exp_ts[idx * 208], 208) == 0;
+        if (ts && in.exp_v[idx] == 2) ok = ok && memcmp(ts, &in.states[idx * 208], 208) == 0;
+        if (!ok) mismatches++;
+    };
+    auto worker = [&](int t) {
+        std::vector<float> &L = lat[t];
+        L.reserve(1 << 20);
+        uint64_t done = 0;
+        size_t cur = ((size_t)t * 7919) % in.count;
+        ready++;
+        while (ready.load() < T) std::this_thread::yield();
+        if (mode == "threads") {
+            const int B = arg2;
+            std::vector<uint8_t> pr(B * PL), cm(B * CM), st(B * 208), rg(B * 64), v(B), ts(B * 208);
+            std::vector<size_t> idx(B);
+            while (!stop.load(std::memory_order_relaxed)) {
+                for (int b = 0; b < B; b++) {
+                    idx[b] = cur;
+                    cur = (cur + 1) % in.count;
+                    memcpy(&pr[b * PL], &in.proofs[idx[b] * PL], PL);
+                    memcpy(&cm[b * CM], &in.coms[idx[b] * CM], CM);
+                    memcpy(&st[b * 208], &in.states[idx[b] * 208], 208);
+                    memcpy(&rg[b * 64], &in.rng[idx[b] * 64], 64);
+                }
+                const double t0 = now_s();
+                const int r = bpgpu_pool_rangeproof_verify_ts(pool, in.n, in.m, B, pr.data(), PL, cm.data(), st.data(), 208, rg.data(), v.data(), nullptr, ts.data());
+                L.push_back((float)((now_s() - t0) * 1e3));
+                if (r) errors++;
+                else
+                    for (int b = 0; b < B; b++) check(idx[b], &v[b], &ts[b * 208]);
+                done += B;
+            }
+        } else if (mode == "tickets") {
+            const int Q = arg2;
+            struct slot {
+                bpgpu_ticket *t = nullptr;
+                size_t idx = 0;
+                double t0 = 0;
+                uint8_t v[1], ts[208];
+            };
+            std::vector<slot> ring(Q);
+            size_t head = 0;
+            while (!stop.load(std::memory_order_relaxed)) {
+                slot &s = ring[head];
+                if (s.t) {
+                    if (bpgpu_pool_ticket_wait(pool, s.t)) errors++;
+                    else check(s.idx, s.v, s.ts);
+                    L.push_back((float)((now_s() - s.t0) * 1e3));
+                    s.t = nullptr;
+                    done++;
+                }
+                s.idx = cur;
+                cur = (cur + 1) % in.count;
+                s.t0 = now_s();
+                if (bpgpu_pool_rangeproof_submit_ts(pool, in.n, in.m, 1, &in.proofs[s.idx * PL], PL, &in.coms[s.idx * CM], &in.states[s.idx * 208], 208, &in.rng[s.idx * 64],
+                                                    s.v, nullptr, s.ts, &s.t)) {
+                    errors++;
+                    s.t = nullptr;
+                }
+                head = (head + 1) % Q;
+            }
+            for (slot &s : ring)
+                if (s.t) {
+                    if (bpgpu_pool_ticket_wait(pool, s.t)) errors++;
+                    else check(s.idx, s.v, s.ts);
+                    done++;
+                }
+        } else {   // big: label-mode calls of NB proofs.  Items proven on the FRESH transcript (Transcript::new("combine-rate")) keep the
+                   // oracle's verdict there; the pre-bound ones are proofs of a different statement: VerificationError (FormatError stays)
+            const int NB = arg2;
+            std::vector<uint8_t> pr((size_t)NB * PL), cm((size_t)NB * CM), rg((size_t)NB * 64), v(NB);
+            for (int b = 0; b < NB; b++) {
+                const size_t i = (cur + b) % in.count;
+                memcpy(&pr[b * PL], &in.proofs[i * PL], PL);
+                memcpy(&cm[b * CM], &in.coms[i * CM], CM);
+                memcpy(&rg[b * 64], &in.rng[i * 64], 64);
+            }
+            std::vector<uint8_t> want(NB);
+            for (int b = 0; b < NB; b++) {
+                const size_t i = (cur + b) % in.count;
+                want[b] = in.fresh[i] ? in.exp_v[i] : (in.exp_v[i] == 2 ? 2 : 1);
+            }
+            while (!stop.load(std::memory_order_relaxed)) {
+                const double t0 = now_s();
+                const int r = bpgpu_pool_rangeproof_verify(pool, in.n, in.m, NB, pr.data(), PL, cm.data(), (const uint8_t *)"combine-rate", 12, rg.data(), v.data(), nullptr);
+                L.push_back((float)((now_s() - t0) * 1e3));
+                if (r) errors++;
+                else if (v != want) mismatches++;
+                done += NB;
+            }
+        }
+        total += done;
+    };
+    std::vector<std::thread> th;
+    const double t0 = now_s();
+    for (int t = 0; t < T; t++) th.emplace_back(worker, t);
+    while (ready.load() < T) std::this_thread::yield();
+    const double t1 = now_s();
+    std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
+    stop = true;
+    for (auto &x : th) x.join();
+    const double t2 = now_s();
+    std::vector<float> all;
+    for (auto &l : lat) all.insert(all.end(), l.begin(), l.end());
+    std::sort(all.begin(), all.end());
+    auto pct = [&](double q) { return all.empty() ? 0.0 : (double)all[(size_t)(q * (all.size() - 1))]; };
+    int64_t chains = 0, cproofs = 0, iss = 0, cmp = 0, polls = 0;
+    bpgpu_pool_get_option(pool, "stat_svc_issue_us", &iss);
+    bpgpu_pool_get_option(pool, "stat_svc_complete_us", &cmp);
+    bpgpu_pool_get_option(pool, "stat_svc_polls", &polls);
+    bpgpu_pool_get_option(pool, "stat_combined_chains", &chains);
+    bpgpu_pool_get_option(pool, "stat_combined_proofs", &cproofs);
+    printf("{\"mode\": \"%s\", \"threads\": %d, \"arg\": %d, \"seconds\": %.2f, \"verifications\": %llu, \"rate_per_s\": %.0f, \"calls\": %zu, \"lat_ms\": {\"p50\": %.3f, "
+           "\"p90\": %.3f, \"p99\": %.3f, \"max\": %.3f}, \"chains\": %lld, \"proofs_per_chain\": %.1f, \"mismatches\": %llu, \"errors\": %llu, \"startup_s\": %.2f, \"svc\": {\"issue_us_per_chain\": %.1f, \"complete_us_per_chain\": %.1f, \"polls\": %lld}}\n",
+           mode.c_str(), T, arg2, t2 - t1, (unsigned long long)total.load(), (double)total.load() / (t2 - t1), all.size(), pct(0.5), pct(0.9), pct(0.99),
+           all.empty() ? 0.0 : (double)all.back(), (long long)chains, chains ? (double)cproofs / (double)chains : 0.0, (unsigned long long)mismatches.load(),
+           (unsigned long long)errors.load(), t1 - t0, chains ? (double)iss / (double)chains : 0.0, chains ? (double)cmp / (double)chains : 0.0, (long long)polls);
+    bpgpu_pool_destroy(pool);
+    return (mismatches.load() || errors.load()) ? 1 : 0;
+}
