@@ -1751,7 +1751,13 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         else LAUNCH(c, c->stream2, "rp_points", k_rp_points<3>, n_pt, RP_BLOCK, sh, (const uint8_t *)d_proofs, (const uint8_t *)d_commitments, d.tab, d_status, bpts, segtab);
         HIPCHK(c, hipEventRecord(c->join_ev, c->stream2));
     }
-    LAUNCH(c, s, "rp_stage1", k_rp_stage1, n_tr + (split1 ? 0u : n_pt), RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
+    if (d_script)
+        LAUNCH(c, s, "rp_stage1", k_rp_stage1<true>, n_tr + (split1 ? 0u : n_pt), RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
+           (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits,
+           rlc ? wts_ptr : (const uint8_t *)nullptr, ts_flags, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
+           rlc_bucket ? bd.pts : (fb_entry *)nullptr, rlc_bucket ? bkp.c : 0u, segtab, d_script);
+    else
+        LAUNCH(c, s, "rp_stage1", k_rp_stage1<false>, n_tr + (split1 ? 0u : n_pt), RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
            (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits,
            rlc ? wts_ptr : (const uint8_t *)nullptr, ts_flags, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
            rlc_bucket ? bd.pts : (fb_entry *)nullptr, rlc_bucket ? bkp.c : 0u, segtab, d_script);
@@ -1863,8 +1869,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
             HIPCHK(c, hipEventRecord(c->join_ev, c->stream2));
             horner_aside = true;
         }
-        LAUNCH(c, s, "rp_stage3", k_rp_stage3, n_exp, BP_BLOCK, 0u, 0u, d.chunks, d.tab, d.recoded, d.part, (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits,
-               d_status);
+        LAUNCH(c, s, "rp_stage3", k_rp_exponents, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
     } else {
         LAUNCH(c, s, "rp_stage3", k_rp_stage3, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part,
                (quad && one_chunk) ? d_colc : (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits, d_status);

@@ -290,7 +290,10 @@ BP_HD void fe_invert(fe &out, const fe &z) {
 BP_HD void fe_pow22523(fe &out, const fe &z) {
     fe t, z11;
     fe_pow2_250m1(t, z11, z);
-    fe_sqn(t, t, 2);
+    // two plain squarings, not fe_sqn(t, t, 2): with the in-place two-step loop here the compiler emitted twice the code for the whole
+    // chain and 301 instead of 134 registers -- every kernel that decodes or encodes a point carried it (tools/kernel_resources.py)
+    fe_sq(t, t);
+    fe_sq(t, t);
     fe_mul(out, t, z);
 }
 

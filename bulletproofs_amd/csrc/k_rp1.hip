@@ -1,5 +1,6 @@
 // k_rp1.hip: HIP kernels of libbpgpu.so (gfx950); thin __global__ wrappers around the per-lane bodies in the headers.
 #include <hip/hip_runtime.h>
+#define BP_KECCAK_OUTOFLINE 1   // byte-wise STROBE framing reaches Keccak-f[1600] through ONE out-of-line copy in this translation unit (keccak.h)
 #include "kernels.h"
 
 using namespace bp;
@@ -13,10 +14,14 @@ using namespace bp;
 // steps, the U coefficient recodings, the Montgomery tables for launch 2), lane = proof  ||  [n_tr, ..) decode
 // the proof's and the commitments' points straight from the input bytes and build their 8-entry tables,
 // lane = point
-// Two wavefronts per SIMD (256 registers, 1.2 kB of scratch per lane instead of 502 registers): alone the launch takes
-// 407 instead of 400 us, but a wavefront that needs a whole SIMD's register file waits for a completely free SIMD and,
-// while it waits, holds up the dispatch of the queues behind it -- with 128 streams in flight the cap is worth +2...+4 %
-// (5.43 -> 5.67 and 5.22 -> 5.33 M/s on two boxes, interleaved A/B; three waves per SIMD: no gain, more spills).
+// Two wavefronts per SIMD (256 registers): alone the launch takes 407 instead of 400 us, but a wavefront that needs a whole SIMD's
+// register file waits for a completely free SIMD and, while it waits, holds up the dispatch of the queues behind it -- with 128
+// streams in flight the cap is worth +2...+4 % (5.43 -> 5.67 and 5.22 -> 5.33 M/s on two boxes, interleaved A/B; three waves per
+// SIMD: no gain, more spills).
+// SCRIPTED: the kernel carries ONE transcript path -- the per-shape script (rp_script.h: every proof starts at the same STROBE
+// position; one inlined Keccak-f[1600]) or the byte-wise replay (per-proof states at different positions; ~10 framing call sites
+// around the permutation, which is therefore a function call there).  Round 3 had both in one kernel: 926 KB of machine code.
+template <bool SCRIPTED>
 __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(RP_BLOCK) k_rp_stage1(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs,
                                                          const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields,
                                                          ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m,
@@ -32,9 +37,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(RP_
         if (p < sh.nproofs) {
             // (BP_EXP_*: timing experiments only -- tools/stage1_breakdown.py builds variants with one role compiled out)
 #ifndef BP_EXP_NOTR
-            // the per-shape script (rp_script.h) whenever every proof starts from the same transcript; the byte-wise replay for
-            // caller-supplied per-proof states
-            if (script) rp_transcript_scripted(p, sh, init, st, rp_resolve(p, sh, proofs, commitments, rng64, segs), script, fields, status, ts_out, ts_in);
+            if (SCRIPTED) rp_transcript_scripted(p, sh, init, st, rp_resolve(p, sh, proofs, commitments, rng64, segs), script, fields, status, ts_out, ts_in);
             else rp_transcript_thread(p, sh, init, st, rp_resolve(p, sh, proofs, commitments, rng64, segs), fields, status, ts_flags, ts_in, ts_out);
 #endif
 #ifndef BP_EXP_NOSC
@@ -48,6 +51,12 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(RP_
 #endif
     }
 }
+template __global__ void k_rp_stage1<true>(rp_shape, rp_strobe_init, uint32_t, const uint8_t *, const uint8_t *, const uint8_t *, uint32_t *, ge_cached *, uint32_t *, fb_params,
+                                           uint32_t, uint32_t *, fb_digit *, const uint8_t *, uint32_t, const uint32_t *, uint32_t *, fb_entry *, uint32_t, rp_seg_tab,
+                                           const rp_script_hdr *);
+template __global__ void k_rp_stage1<false>(rp_shape, rp_strobe_init, uint32_t, const uint8_t *, const uint8_t *, const uint8_t *, uint32_t *, ge_cached *, uint32_t *, fb_params,
+                                            uint32_t, uint32_t *, fb_digit *, const uint8_t *, uint32_t, const uint32_t *, uint32_t *, fb_entry *, uint32_t, rp_seg_tab,
+                                            const rp_script_hdr *);
 
 // the point-decode role of launch 1 as a launch of its own (option "split_stage1": runs on the context's second stream beside the
 // transcript kernel, with its own register budget instead of the transcript role's)

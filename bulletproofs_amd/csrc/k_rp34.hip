@@ -18,6 +18,16 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rp_stage3(uint32_t n_win, uint32_t
     }
 }
 
+// the generator exponents alone (wide chains, where the window sums are a launch of their own): the role's own register allocation.
+// Two wavefronts per SIMD although 166 registers would allow three: with three, the kernel itself runs 200 instead of 290 us, but on
+// 20 x 1024 bursts the one-lane Horner chains beside it slow down by as much (1.06 -> 1.4 ms) and they are the longer path: -12 %
+// (profiles/r04/ab_exponents_*.txt).  Issue priority for the lane-serial roles (s_setprio) was measured too: neutral, not kept.
+__global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(BP_BLOCK) k_rp_exponents(uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields,
+                                                                                                 fb_digit *digits, const uint32_t *status) {
+    const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
+    if (tid < nthreads_exp) rp_expand_b4_thread(tid, sh, prm, fields, digits, status);
+}
+
 // the one-lane Horner chains as their own launch (wide chains: issued on the context's second stream as soon as the window sums
 // exist, so that their ~1 ms of dependent instructions run beside the generator exponents and the table walk instead of after them)
 __global__ void __launch_bounds__(FB_BLOCK) k_rp_horner1(uint32_t nproofs, const ge_cached *colc, ge_ext *hq) {
@@ -43,7 +53,7 @@ __global__ void __launch_bounds__(FB_BLOCK) k_rp_stage4(uint32_t n_hw, const uin
                                                          uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits,
                                                          const fb_entry *table, ge_ext *partial) {
     if (blockIdx.x < n_hw) {
-        if (HL == 4) hq_horner_msm(blockIdx.x * 16 + (threadIdx.x >> 2), nproofs, colc, hq);
+            if (HL == 4) hq_horner_msm(blockIdx.x * 16 + (threadIdx.x >> 2), nproofs, colc, hq);
         else if (HL == 1) vb_horner_cached_thread(blockIdx.x * FB_BLOCK + threadIdx.x, nproofs, colc, hq);
         else hw_colsum_horner_msm(blockIdx.x, chunk_first, part, hq + blockIdx.x);
         return;

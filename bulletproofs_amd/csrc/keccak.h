@@ -94,6 +94,16 @@ BP_HD void keccak_f1600(const kstate &s) {
     }
 }
 
+// ONE out-of-line copy per kernel for the byte-wise STROBE paths: they reach the permutation from ~10 inlined framing sites
+// (strobe_run_f below), and 24 unrolled rounds are ~50 KB of machine code each time -- round 3's launch 1 was 926 KB.  The
+// scripted replay of the range-proof path (rp_transcript_scripted) has a single call site and keeps its copy inline.
+BP_HD_NOINLINE void keccak_f1600_outofline(uint32_t *w, uint32_t stride) {
+    kstate s;
+    s.w = w;
+    s.stride = stride;
+    keccak_f1600(s);
+}
+
 // the permutation with a constant XOR mask folded into the load of the first `nmask` state words (rp_script.h: all framing bytes
 // of a transcript span at once; the mask is uniform across the wavefront)
 BP_HD void keccak_f1600_masked(const kstate &s, const uint32_t *mask, uint32_t nmask) {
@@ -173,7 +183,11 @@ BP_HD void strobe_run_f(strobe &t) {
     ks_xor8(t.st, t.pos, t.pos_begin);
     ks_xor8(t.st, t.pos + 1, 0x04);
     ks_xor8(t.st, BP_STROBE_R + 1, 0x80);
+#ifdef BP_KECCAK_OUTOFLINE   // (k_rp1.hip: the byte-wise variant of launch 1; the prover / inner-product kernels keep their inlined copies and registers)
+    keccak_f1600_outofline(t.st.w, t.st.stride);
+#else
     keccak_f1600(t.st);
+#endif
     t.pos = 0;
     t.pos_begin = 0;
 }

@@ -811,6 +811,12 @@ BP_HD void sc28_sub_lazy(sc28 &r, const sc28 &a, const sc28 &b) {
 // y^-i likewise.  g_i = -z - a s_i (mod.rs:415), h_i = z + y^-i (z^2 z^j 2^i' - b s_i^-1), j = i / n,
 // i' = i % n (mod.rs:416-419).  Writes the digits of rows 2+i and 2+nm+i, or -- g_out / h_out given (batch-
 // combination mode) -- returns the eight coefficients (zero for a rejected proof).
+// Round 3 kept the four products P[j] = u_{k-1}^{+-1} u_{k-2}^{+-1} in a register array picked by the run-time index j: 176 bytes of
+// scratch memory and 254 registers (two wavefronts per SIMD).  Now nothing is indexed at run time: the two factors of index j are
+// re-read from the field-major scalar store by ADDRESS (u or u^-1, chosen by the bits of j), as are a, b, z, -z, y^-1, y^-2 where
+// they are used -- three running products stay live across the loop, 167 registers (three wavefronts per SIMD), no scratch, no LDS
+// (a 10 KB scratchpad per wavefront was measured first: same kernel time, but its LDS footprint kept the transcript wavefronts of
+// the NEXT chain off the CUs: -12 % on 20 x 1024 bursts).  Price: one more Montgomery product per index (8 + instead of 7 +).
 BP_HD void rp_expand_b4_thread(uint32_t tid, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits,
                                const uint32_t *status, sc *g_out = nullptr, sc *h_out = nullptr) {
     const uint32_t B = sh.nproofs, k = sh.k;
@@ -824,73 +830,90 @@ BP_HD void rp_expand_b4_thread(uint32_t tid, rp_shape sh, fb_params prm, const u
     if (status[p] != 0) return;
     const fb_bias bias = fb_make_bias(prm);   // wavefront-uniform: once for the eight recodings below
     const rp_fields fl = rp_field_layout(k, sh.m);
-    sc28 s_hi, sinv_hi, y_hi, um, uim, t;
-    sc28_one_mont(s_hi);
-    sinv_hi = s_hi;
-    y_hi = s_hi;
-    for (uint32_t bb = 2; bb < k; bb++) {
-        rp_load28(um, fields, B, fl.u_m + (k - 1 - bb), p);
-        rp_load28(uim, fields, B, fl.uinv_m + (k - 1 - bb), p);
-        const bool bit = (i0 >> bb) & 1;
-        sc28 f1, f2;
+    sc28 s_hi, sinv_hi, y_hi, t;
+    {
+        sc28 um, uim;
+        sc28_one_mont(s_hi);
+        sinv_hi = s_hi;
+        y_hi = s_hi;
+        for (uint32_t bb = 2; bb < k; bb++) {
+            rp_load28(um, fields, B, fl.u_m + (k - 1 - bb), p);
+            rp_load28(uim, fields, B, fl.uinv_m + (k - 1 - bb), p);
+            const bool bit = (i0 >> bb) & 1;
+            sc28 f1, f2;
 #pragma unroll
-        for (int q = 0; q < 10; q++) {
-            f1.v[q] = bit ? um.v[q] : uim.v[q];
-            f2.v[q] = bit ? uim.v[q] : um.v[q];
-        }
-        sc28_montmul(s_hi, s_hi, f1);
-        sc28_montmul(sinv_hi, sinv_hi, f2);
-        if (bit) {
-            rp_load28(t, fields, B, fl.yinvp_m + bb, p);
-            sc28_montmul(y_hi, y_hi, t);
+            for (int q = 0; q < 10; q++) {
+                f1.v[q] = bit ? um.v[q] : uim.v[q];
+                f2.v[q] = bit ? uim.v[q] : um.v[q];
+            }
+            sc28_montmul(s_hi, s_hi, f1);
+            sc28_montmul(sinv_hi, sinv_hi, f2);
+            if (bit) {
+                rp_load28(t, fields, B, fl.yinvp_m + bb, p);
+                sc28_montmul(y_hi, y_hi, t);
+            }
         }
     }
-    // bits 0 (challenge k-1) and 1 (challenge k-2): P[j] = (bit0(j) ? A : A^-1) (bit1(j) ? Bc : Bc^-1)
-    sc28 A, Ai, Bc, Bi, P[4];
-    rp_load28(A, fields, B, fl.u_m + (k - 1), p);
-    rp_load28(Ai, fields, B, fl.uinv_m + (k - 1), p);
-    rp_load28(Bc, fields, B, fl.u_m + (k - 2), p);
-    rp_load28(Bi, fields, B, fl.uinv_m + (k - 2), p);
-    sc28_montmul(P[0], Ai, Bi);
-    sc28_montmul(P[1], A, Bi);
-    sc28_montmul(P[2], Ai, Bc);
-    sc28_montmul(P[3], A, Bc);
-    sc28 y1, y2, y3;
-    rp_load28(y1, fields, B, fl.yinvp_m + 0, p);
-    rp_load28(y2, fields, B, fl.yinvp_m + 1, p);
-    sc28_montmul(y3, y1, y2);
-    sc28 a_m, b_m;
-    sc z, minus_z;
-    rp_load28(a_m, fields, B, RPF_A_M, p);
-    rp_load28(b_m, fields, B, RPF_B_M, p);
-    rp_load(z, fields, B, RPF_Z, p);
-    rp_load(minus_z, fields, B, RPF_MINUS_Z, p);
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
+#endif
     for (uint32_t j = 0; j < 4; j++) {
         const uint32_t i = i0 + j;
-        sc28 s, sinv, yp, r, two_m, zzzj;
+        // bits 0 (challenge k-1) and 1 (challenge k-2) of the index: s_i takes u or u^-1 by the bit, s_i^-1 the other one
+        const uint32_t fa = (j & 1) ? fl.u_m + (k - 1) : fl.uinv_m + (k - 1), fa_c = (j & 1) ? fl.uinv_m + (k - 1) : fl.u_m + (k - 1);
+        const uint32_t fb = (j & 2) ? fl.u_m + (k - 2) : fl.uinv_m + (k - 2), fb_c = (j & 2) ? fl.uinv_m + (k - 2) : fl.u_m + (k - 2);
+        sc28 s, yp, r;
         sc g, h, v;
-        sc28_montmul(s, s_hi, P[j]);
-        sc28_montmul(sinv, sinv_hi, P[3 - j]);
-        if (j == 0) yp = y_hi;
-        else sc28_montmul(yp, y_hi, j == 1 ? y1 : (j == 2 ? y2 : y3));
-        sc28_montmul(t, a_m, s);
-        sc_from_mont28(v, t);
-        sc_sub(g, minus_z, v);
-        const uint32_t jj = i / sh.n, ib = i - jj * sh.n;
-        rp_load28(zzzj, fields, B, fl.zzzj_m + jj, p);
-        rp_two_pow_mont(two_m, ib);
-        sc28_montmul(r, zzzj, two_m);    // z^2 z^j 2^i'
-        sc28_montmul(t, b_m, sinv);      // b / s_i
-        sc28_sub_lazy(r, r, t);
-        sc28_montmul(r, r, yp);
-        sc_from_mont28(v, r);
-        sc_add(h, z, v);
+        // g_i = -z - a s_i
+        {
+            sc28 a_m;
+            rp_load28(t, fields, B, fa, p);
+            sc28_montmul(s, s_hi, t);
+            rp_load28(t, fields, B, fb, p);
+            sc28_montmul(s, s, t);
+            rp_load28(a_m, fields, B, RPF_A_M, p);
+            sc28_montmul(t, a_m, s);
+            sc_from_mont28(v, t);
+            sc minus_z;
+            rp_load(minus_z, fields, B, RPF_MINUS_Z, p);
+            sc_sub(g, minus_z, v);
+            // (recoded at once: g is not carried through the computation of h)
+            if (!g_out) fb_recode(digits + ((uint64_t)(2 + i) * prm.nwin) * B + p, B, g.v, prm, bias);
+        }
+        // y^-i: the high bits' product times y^-1 (bit 0 of j) and y^-2 (bit 1)
+        yp = y_hi;
+        if (j & 1) {
+            rp_load28(t, fields, B, fl.yinvp_m + 0, p);
+            sc28_montmul(yp, yp, t);
+        }
+        if (j & 2) {
+            rp_load28(t, fields, B, fl.yinvp_m + 1, p);
+            sc28_montmul(yp, yp, t);
+        }
+        // h_i = z + y^-i (z^2 z^j 2^i' - b s_i^-1)
+        {
+            sc28 sinv, b_m, two_m, zzzj;
+            rp_load28(t, fields, B, fa_c, p);
+            sc28_montmul(sinv, sinv_hi, t);
+            rp_load28(t, fields, B, fb_c, p);
+            sc28_montmul(sinv, sinv, t);
+            const uint32_t jj = i / sh.n, ib = i - jj * sh.n;
+            rp_load28(zzzj, fields, B, fl.zzzj_m + jj, p);
+            rp_two_pow_mont(two_m, ib);
+            sc28_montmul(r, zzzj, two_m);    // z^2 z^j 2^i'
+            rp_load28(b_m, fields, B, RPF_B_M, p);
+            sc28_montmul(t, b_m, sinv);      // b / s_i
+            sc28_sub_lazy(r, r, t);
+            sc28_montmul(r, r, yp);
+            sc_from_mont28(v, r);
+            sc z;
+            rp_load(z, fields, B, RPF_Z, p);
+            sc_add(h, z, v);
+        }
         if (g_out) {
             g_out[j] = g;
             h_out[j] = h;
         } else {
-            fb_recode(digits + ((uint64_t)(2 + i) * prm.nwin) * B + p, B, g.v, prm, bias);
             fb_recode(digits + ((uint64_t)(2 + sh.nm + i) * prm.nwin) * B + p, B, h.v, prm, bias);
         }
     }

@@ -4,6 +4,10 @@ import sys
 
 import pytest
 
+# The pool's lanes overlap on GPU_MAX_HW_QUEUES hardware queues, which the ROCm runtime reads at the process's FIRST HIP call:
+# it must be in the environment before any test touches torch / HIP (bpgpu_pool_create probes the device and refuses otherwise).
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "oracle", "py")):
     if p not in sys.path:
