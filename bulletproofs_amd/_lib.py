@@ -28,6 +28,7 @@ EXPORTS = [
     "bpgpu_pool_devices", "bpgpu_pool_lanes", "bpgpu_pool_lane", "bpgpu_pool_gens_create", "bpgpu_pool_gens_load",
     "bpgpu_pool_rangeproof_verify", "bpgpu_pool_rangeproof_submit_dev", "bpgpu_pool_flush", "bpgpu_pool_wait",
     "bpgpu_pool_rangeproof_verify_ts", "bpgpu_pool_rangeproof_submit_ts", "bpgpu_pool_ticket_done", "bpgpu_pool_ticket_wait",
+    "bpgpu_pool_rangeproof_submit_dev_ex", "bpgpu_pool_ticket_stream_wait",
 ]
 
 TRANSCRIPT_BYTES = 208
@@ -110,6 +111,8 @@ def lib():
     L.bpgpu_pool_rangeproof_submit_dev.argtypes = [vp, i, sz, sz, sz, vp, sz, vp, u8p, sz, vp, vp, vp]
     L.bpgpu_pool_rangeproof_verify_ts.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p, u8p]
     L.bpgpu_pool_rangeproof_submit_ts.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p, u8p, C.POINTER(vp)]
+    L.bpgpu_pool_rangeproof_submit_dev_ex.argtypes = [vp, i, sz, sz, sz, vp, sz, vp, u8p, sz, vp, vp, vp, vp, i, C.POINTER(vp)]
+    L.bpgpu_pool_ticket_stream_wait.argtypes = [vp, vp, vp]
     L.bpgpu_pool_ticket_done.argtypes = [vp, vp]
     L.bpgpu_pool_ticket_wait.argtypes = [vp, vp]
     L.bpgpu_pool_flush.argtypes = [vp]
@@ -426,6 +429,25 @@ class Ticket:
         return tuple(out) if len(out) > 1 else out[0]
 
 
+class DevTicket:
+    """One submitted device-pointer batch (bpgpu_pool_rangeproof_submit_dev_ex)."""
+
+    def __init__(self, pool, h):
+        self.pool, self.h = pool, h
+
+    def stream_wait(self, stream):
+        """make `stream` (raw hipStream_t as int; 0 = default stream) wait on the device for this batch's verdicts"""
+        self.pool._chk(self.pool._L.bpgpu_pool_ticket_stream_wait(self.pool.h, self.h, stream or None))
+
+    def done(self):
+        return self.h is None or self.pool._L.bpgpu_pool_ticket_done(self.pool.h, self.h) == 1
+
+    def wait(self):
+        if self.h is not None:
+            h, self.h = self.h, None
+            self.pool._chk(self.pool._L.bpgpu_pool_ticket_wait(self.pool.h, h))
+
+
 class Pool:
     """Owns one bpgpu_pool: `lanes` contexts on each of `devices` (include/bpgpu.h, "pool").  The scheduler of the library:
     one synchronous call for any number of proofs from host memory (verify), or asynchronous device-pointer batches that the
@@ -528,6 +550,16 @@ class Pool:
         """queue a device-resident batch (raw device pointers as ints); see flush / wait"""
         self._chk(self._L.bpgpu_pool_rangeproof_submit_dev(self.h, dev_index, n, m, nbatch, d_proofs, proof_len, d_commitments, label, len(label),
                                                            d_rng64, d_verdict, d_msm_out))
+
+    def submit_dev_ex(self, dev_index, n, m, nbatch, d_proofs, proof_len, d_commitments, label, d_rng64, d_verdict, d_msm_out=None, producer_stream=None,
+                      want_ticket=True):
+        """submit_dev with a completion contract (bpgpu_pool_rangeproof_submit_dev_ex): producer_stream = raw hipStream_t (int; 0 = the
+        legacy default stream) the inputs are produced on, or None; returns a DevTicket (or None)."""
+        t = C.c_void_p()
+        self._chk(self._L.bpgpu_pool_rangeproof_submit_dev_ex(self.h, dev_index, n, m, nbatch, d_proofs, proof_len, d_commitments, label, len(label), d_rng64,
+                                                              d_verdict, d_msm_out, producer_stream or None, 0 if producer_stream is None else 1,
+                                                              C.byref(t) if want_ticket else None))
+        return DevTicket(self, t) if want_ticket else None
 
     def flush(self):
         self._chk(self._L.bpgpu_pool_flush(self.h))

@@ -36,6 +36,7 @@
 #include <cstring>
 #include <deque>
 #include <functional>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -174,11 +175,31 @@ bool fast_random(uint8_t *dst, size_t bytes) {
     return true;
 }
 
+// A ticket is either a request of the combining queue (host pointers) or a submitted device-pointer batch
+enum { TK_COMBINE = 0x7c0b, TK_DEVICE = 0x7de0 };
+struct ev_holder {   // one recorded event, shared by the tickets of the batches a chain carried
+    hipEvent_t ev = nullptr;
+    ~ev_holder() {
+        if (ev) hipEventDestroy(ev);
+    }
+};
+struct pool_dev;
+struct dev_ticket {
+    uint32_t kind = TK_DEVICE;
+    pool_dev *d = nullptr;
+    size_t unissued = 0;                              // proofs of the batch no chain has taken yet (under bpgpu_pool::mu)
+    std::vector<std::shared_ptr<ev_holder>> done;     // recorded behind every chain that carries a piece of the batch
+    int rc = 0;
+    std::string err;
+};
+
 struct dev_item {   // a submitted device-pointer batch waiting for the next flush
     size_t n, m, nbatch, proof_len;
     const uint8_t *proofs, *coms, *rng;
     uint8_t *verdict, *msm;
     std::string label;
+    std::shared_ptr<ev_holder> ready;   // recorded on the producer's stream at submission: the chain waits for it (may be empty)
+    dev_ticket *ticket = nullptr;       // may be null
     bool same_shape(const dev_item &o) const { return n == o.n && m == o.m && proof_len == o.proof_len && label == o.label; }
 };
 
@@ -237,6 +258,7 @@ struct comb_buf {
 
 // one call (bpgpu_pool_rangeproof_verify_ts) or one ticket (bpgpu_pool_rangeproof_submit_ts)
 struct comb_req {
+    uint32_t kind = TK_COMBINE;   // (first member of both ticket types)
     size_t n = 0, m = 0, nbatch = 0, proof_len = 0;
     const uint8_t *proofs = nullptr, *coms = nullptr, *rng = nullptr, *ts_in = nullptr;   // ts_in: per proof, or null (key.shared)
     uint8_t *verdict = nullptr, *msm = nullptr, *ts_out = nullptr;
@@ -1249,13 +1271,46 @@ int bpgpu_pool_rangeproof_submit_ts(bpgpu_pool *p, size_t n, size_t m, size_t nb
     return BPGPU_OK;
 }
 
+static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain);
+// the chains that carry a device-pointer batch: issue them if they have not left yet, hand back their events
+static int dev_ticket_events(bpgpu_pool *p, dev_ticket *t, std::vector<std::shared_ptr<ev_holder>> &evs) {
+    std::lock_guard<std::mutex> lk(p->mu);
+    int rc = BPGPU_OK;
+    if (t->unissued) rc = flush_dev(p, t->d, false);
+    evs = t->done;
+    if (!rc && t->rc) rc = pfail(p, t->rc, "%s", t->err.c_str());
+    return rc;
+}
+
 int bpgpu_pool_ticket_done(bpgpu_pool *p, bpgpu_ticket *ticket) {
     if (!p || !ticket) return BPGPU_ERR_INVALID_ARG;
+    if (*(uint32_t *)ticket == TK_DEVICE) {
+        dev_ticket *t = (dev_ticket *)ticket;
+        std::lock_guard<std::mutex> lk(p->mu);
+        if (t->unissued) return 0;
+        if (hipSetDevice(t->d->device) != hipSuccess) return BPGPU_ERR_HIP;
+        for (auto &e : t->done)
+            if (hipEventQuery(e->ev) != hipSuccess) {
+                (void)hipGetLastError();
+                return 0;
+            }
+        return 1;
+    }
     return ((comb_req *)ticket)->left.load(std::memory_order_acquire) == 0 ? 1 : 0;
 }
 
 int bpgpu_pool_ticket_wait(bpgpu_pool *p, bpgpu_ticket *ticket) {
     if (!p || !ticket) return BPGPU_ERR_INVALID_ARG;
+    if (*(uint32_t *)ticket == TK_DEVICE) {
+        dev_ticket *t = (dev_ticket *)ticket;
+        std::vector<std::shared_ptr<ev_holder>> evs;
+        int rc = dev_ticket_events(p, t, evs);
+        if (hipSetDevice(t->d->device) != hipSuccess) rc = rc ? rc : BPGPU_ERR_HIP;
+        for (auto &e : evs)
+            if (hipEventSynchronize(e->ev) != hipSuccess && !rc) rc = pfail(p, BPGPU_ERR_HIP, "waiting for a chain of the batch failed");
+        delete t;
+        return rc;
+    }
     comb_req *r = (comb_req *)ticket;
     ticket_block(r);
     const int rc = r->rc;
@@ -1264,13 +1319,47 @@ int bpgpu_pool_ticket_wait(bpgpu_pool *p, bpgpu_ticket *ticket) {
     return rc;
 }
 
+int bpgpu_pool_ticket_stream_wait(bpgpu_pool *p, bpgpu_ticket *ticket, void *stream) {
+    if (!p || !ticket) return BPGPU_ERR_INVALID_ARG;
+    if (*(uint32_t *)ticket != TK_DEVICE) return pfail(p, BPGPU_ERR_INVALID_ARG, "only tickets of device-pointer batches have a device-side completion");
+    dev_ticket *t = (dev_ticket *)ticket;
+    std::vector<std::shared_ptr<ev_holder>> evs;
+    int rc = dev_ticket_events(p, t, evs);
+    if (hipSetDevice(t->d->device) != hipSuccess) return BPGPU_ERR_HIP;
+    for (auto &e : evs)
+        if (hipStreamWaitEvent((hipStream_t)stream, e->ev, 0) != hipSuccess && !rc) rc = pfail(p, BPGPU_ERR_HIP, "hipStreamWaitEvent failed");
+    return rc;
+}
+
 }  // extern "C"
 
 extern "C" {
 
 // ---- device pointers, asynchronous ------------------------------------------------------------------------------
-static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain = false) {
+// a chain (or a stand-alone call) on lane `c` carries `count` proofs of item `it`: before it is issued its stream waits for the item's
+// producer; afterwards the item's ticket gets the event recorded behind the chain
+static void chain_waits_for(bpgpu_ctx *c, const dev_item &it) {
+    if (it.ready) (void)hipStreamWaitEvent((hipStream_t)bpgpu_internal_stream(c), it.ready->ev, 0);
+}
+static void chain_carried(const dev_item &it, size_t count, const std::shared_ptr<ev_holder> &done, int rc, const char *err) {
+    if (!it.ticket) return;
+    it.ticket->unissued -= count;
+    if (done && (it.ticket->done.empty() || it.ticket->done.back() != done)) it.ticket->done.push_back(done);
+    if (rc && !it.ticket->rc) {
+        it.ticket->rc = rc;
+        it.ticket->err = err;
+    }
+}
+static std::shared_ptr<ev_holder> record_done(bpgpu_ctx *c, bool wanted) {
+    if (!wanted) return nullptr;
+    auto h = std::make_shared<ev_holder>();
+    if (hipEventCreateWithFlags(&h->ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(h->ev, (hipStream_t)bpgpu_internal_stream(c)) != hipSuccess) return nullptr;
+    return h;
+}
+
+static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
     if (d->pending.empty()) return BPGPU_OK;
+    (void)hipSetDevice(d->device);
     std::vector<dev_item> items;
     items.swap(d->pending);
     const size_t T = d->pending_proofs;
@@ -1307,6 +1396,7 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain = false) {
     size_t n_undecided = 0;
     std::string first_err;
     std::vector<rp_seg> segs;
+    std::vector<std::pair<size_t, size_t>> carried;   // (item, proofs of it) in the chain being packed
     size_t i = 0, off = 0;   // item i, `off` proofs of it already placed
     while (i < items.size()) {
         const dev_item &head = items[i];
@@ -1314,8 +1404,10 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain = false) {
         if (d->used_lanes < d->lanes.size() && d->next_lane > d->used_lanes) d->used_lanes = d->next_lane < d->lanes.size() ? d->next_lane : d->lanes.size();
         if (!bpgpu_internal_rp_coalescible(c, head.n, head.m, head.proof_len)) {
             // malformed length / parameter error / missing generators: the ordinary entry point reports it proof by proof
+            chain_waits_for(c, head);
             const int rc = bpgpu_rangeproof_verify_batch_dev(c, head.n, head.m, head.nbatch, head.proofs, head.proof_len, head.coms,
                                                              (const uint8_t *)head.label.data(), head.label.size(), head.rng, head.verdict, head.msm, nullptr);
+            chain_carried(head, head.nbatch, record_done(c, head.ticket != nullptr), rc, rc ? bpgpu_last_error(c) : "");
             if (rc) {
                 (void)hipMemsetAsync(head.verdict, BPGPU_VERDICT_UNDECIDED, head.nbatch, (hipStream_t)bpgpu_internal_stream(c));
                 n_undecided += head.nbatch;
@@ -1329,12 +1421,16 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain = false) {
             continue;
         }
         segs.clear();
+        carried.clear();
         uint32_t filled = 0;
-        bool any_msm = false;
+        bool any_msm = false, any_ticket = false;
         while (i < items.size() && filled < per && items[i].same_shape(head)) {
             const dev_item &it = items[i];
             size_t take = it.nbatch - off;
             if (take > per - filled) take = per - filled;
+            chain_waits_for(c, it);
+            carried.push_back({i, take});
+            any_ticket = any_ticket || it.ticket;
             rp_seg sg;
             sg.proofs = it.proofs + off * it.proof_len;
             sg.commitments = it.coms + off * it.m * 32;
@@ -1354,6 +1450,10 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain = false) {
         }
         const int rc = bpgpu_internal_rp_verify_segs(c, head.n, head.m, head.proof_len, (const uint8_t *)head.label.data(), head.label.size(), segs.data(),
                                                      (uint32_t)segs.size(), any_msm, hint, (was_idle && T <= p->latency_proofs) ? 0 : 1);
+        {
+            const std::shared_ptr<ev_holder> done = record_done(c, any_ticket);   // (also behind the memsets of a failed chain below: same stream)
+            for (const auto &cr : carried) chain_carried(items[cr.first], cr.second, done, rc, rc ? bpgpu_last_error(c) : "");
+        }
         if (rc) {
             // The chain did not go out: its items' verdict bytes must not read 0 = "verified" (a caller with zero-initialised
             // buffers would take that for acceptance).  Every affected range gets BPGPU_VERDICT_UNDECIDED; the flush goes on with
@@ -1375,12 +1475,13 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain = false) {
     return rc_all;
 }
 
-int bpgpu_pool_rangeproof_submit_dev(bpgpu_pool *p, int dev_index, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
-                                     const void *d_commitments, const uint8_t *label, size_t label_len, const void *d_rng64, void *d_verdict,
-                                     void *d_msm_out) {
+int bpgpu_pool_rangeproof_submit_dev_ex(bpgpu_pool *p, int dev_index, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
+                                        const void *d_commitments, const uint8_t *label, size_t label_len, const void *d_rng64, void *d_verdict,
+                                        void *d_msm_out, void *producer_stream, int have_producer, bpgpu_ticket **ticket) {
+    if (ticket) *ticket = nullptr;
     if (!p || dev_index < 0 || dev_index >= (int)p->devs.size() || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
-    if (nbatch == 0) return BPGPU_OK;
-    if (!d_proofs || !d_verdict || (m && !d_commitments)) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0 && !ticket) return BPGPU_OK;
+    if (nbatch && (!d_proofs || !d_verdict || (m && !d_commitments))) return BPGPU_ERR_INVALID_ARG;
     if (((uintptr_t)d_proofs | (uintptr_t)d_commitments | (uintptr_t)d_rng64 | (uintptr_t)d_msm_out) & 3)
         return pfail(p, BPGPU_ERR_INVALID_ARG, "device buffers must be 4-byte aligned");
     if (nbatch > 0x7fffffffu / 64) return pfail(p, BPGPU_ERR_INVALID_ARG, "batch too large");
@@ -1397,12 +1498,33 @@ int bpgpu_pool_rangeproof_submit_dev(bpgpu_pool *p, int dev_index, size_t n, siz
     it.verdict = (uint8_t *)d_verdict;
     it.msm = (uint8_t *)d_msm_out;
     it.label.assign((const char *)label, label_len);
+    if (have_producer && nbatch) {   // the inputs are complete when the work queued on the producer's stream so far is: the chain will wait for exactly that
+        (void)hipSetDevice(d->device);
+        it.ready = std::make_shared<ev_holder>();
+        if (hipEventCreateWithFlags(&it.ready->ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(it.ready->ev, (hipStream_t)producer_stream) != hipSuccess)
+            return pfail(p, BPGPU_ERR_HIP, "recording the producer's event failed");
+    }
+    if (ticket) {
+        dev_ticket *t = new dev_ticket();
+        t->d = d;
+        t->unissued = nbatch;
+        it.ticket = t;
+        *ticket = (bpgpu_ticket *)t;
+        if (nbatch == 0) return BPGPU_OK;
+    }
     d->pending.push_back(std::move(it));
     d->pending_proofs += nbatch;
     const size_t limit = p->auto_flush_items ? p->auto_flush_items : d->lanes.size();
-    if (d->pending.size() >= limit) return flush_dev(p, d);
+    if (d->pending.size() >= limit) return flush_dev(p, d, false);
     if (p->auto_flush_proofs && d->pending_proofs >= p->auto_flush_proofs) return flush_dev(p, d, true);
     return BPGPU_OK;
+}
+
+int bpgpu_pool_rangeproof_submit_dev(bpgpu_pool *p, int dev_index, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
+                                     const void *d_commitments, const uint8_t *label, size_t label_len, const void *d_rng64, void *d_verdict,
+                                     void *d_msm_out) {
+    return bpgpu_pool_rangeproof_submit_dev_ex(p, dev_index, n, m, nbatch, d_proofs, proof_len, d_commitments, label, label_len, d_rng64, d_verdict, d_msm_out,
+                                               nullptr, 0, nullptr);
 }
 
 int bpgpu_pool_flush(bpgpu_pool *p) {
@@ -1410,7 +1532,7 @@ int bpgpu_pool_flush(bpgpu_pool *p) {
     std::lock_guard<std::mutex> lk(p->mu);
     int rc_all = BPGPU_OK;
     for (pool_dev *d : p->devs) {
-        const int rc = flush_dev(p, d);
+        const int rc = flush_dev(p, d, false);
         if (rc && !rc_all) rc_all = rc;
     }
     return rc_all;

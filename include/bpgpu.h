@@ -497,6 +497,21 @@ int bpgpu_pool_rangeproof_submit_ts(bpgpu_pool *pool, size_t n, size_t m, size_t
                                     bpgpu_ticket **ticket);
 int bpgpu_pool_ticket_done(bpgpu_pool *pool, bpgpu_ticket *ticket);
 int bpgpu_pool_ticket_wait(bpgpu_pool *pool, bpgpu_ticket *ticket);
+/* bpgpu_pool_rangeproof_submit_dev with a completion contract (a service that consumes batch k while batch k+1 is queued, with no
+ * device-wide synchronisation anywhere):
+ *   producer_stream / have_producer : have_producer != 0: the batch's input buffers are complete when the work queued so far on
+ *                 `producer_stream` (a hipStream_t; NULL = the legacy default stream) is -- the chain that carries the batch waits
+ *                 for exactly that point on the device (an event recorded there now); 0: complete at submission, as before
+ *   ticket (optional): handle of THIS batch.  bpgpu_pool_ticket_stream_wait(pool, ticket, consumer_stream) makes a consumer stream
+ *                 wait, on the device, until the batch's verdicts (and encodings) are written -- it issues the pending chains of
+ *                 that device first if they have not left; bpgpu_pool_ticket_wait blocks the host until then, returns the
+ *                 batch's error code and frees the ticket (required exactly once per ticket); bpgpu_pool_ticket_done polls.
+ * On an error of the chain that carried (part of) the batch its verdict bytes read BPGPU_VERDICT_UNDECIDED, never 0. */
+int bpgpu_pool_rangeproof_submit_dev_ex(bpgpu_pool *pool, int dev_index, size_t n, size_t m, size_t nbatch, const void *d_proofs,
+                                        size_t proof_len, const void *d_commitments, const uint8_t *label, size_t label_len,
+                                        const void *d_rng64, void *d_verdict, void *d_msm_out, void *producer_stream,
+                                        int have_producer, bpgpu_ticket **ticket);
+int bpgpu_pool_ticket_stream_wait(bpgpu_pool *pool, bpgpu_ticket *ticket, void *consumer_stream);
 int bpgpu_pool_flush(bpgpu_pool *pool);   /* issue everything queued; returns without waiting */
 int bpgpu_pool_wait(bpgpu_pool *pool);    /* flush, then wait until every lane is idle */
 

@@ -37,11 +37,19 @@ def _worker(rank, world, port, q):
     torch.distributed.destroy_process_group()
 
 
+def _free_port():
+    """a rendezvous port the kernel just handed out (a pid-derived one can collide on a shared box -- bench.py's self_launch does the same)"""
+    import socket
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
 def test_sharded_verify_and_gather_world2():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 400)
+    port = _free_port()
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
@@ -109,7 +117,7 @@ def test_bench_region_count_agrees_across_ranks_world2():
     import torch.multiprocessing as mp
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 30100 + (os.getpid() % 400)
+    port = _free_port()
     procs = [ctx.Process(target=_timed_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()

@@ -135,8 +135,9 @@ def test_pool_coalesced_device_batches_vs_oracle(oracle, cfg2):
 
 
 def test_pool_burst_of_20_batches_coalesced_equals_per_batch_path(oracle, cfg2):
-    """The driver's burst (20 batches of 1024 submitted back to back, then one flush): every batch's verdicts are what
-    bpgpu_rangeproof_verify_batch_dev gives for it alone, and equal the oracle on two of them."""
+    """The driver's burst (20 batches of 1024 submitted back to back, then one flush -- two chains of 10 240 at the default
+    W = 20): every batch's verdicts are what bpgpu_rangeproof_verify_batch_dev gives for it alone, and verdicts AND 32-byte
+    mega-check encodings equal the oracle's on two of them."""
     import torch
     import bulletproofs_amd as bp
     from bulletproofs_amd import workload as wl
@@ -155,11 +156,14 @@ def test_pool_burst_of_20_batches_coalesced_equals_per_batch_path(oracle, cfg2):
     d_p, d_c, d_r = to_dev(proofs), to_dev(coms), to_dev(rng)
     d_v = torch.full((K, nb), 255, dtype=torch.uint8, device=dev)
     d_ref = torch.full((K, nb), 255, dtype=torch.uint8, device=dev)
+    d_m = torch.zeros((K, nb, 32), dtype=torch.uint8, device=dev)
     torch.cuda.synchronize()
+    pool.set_option("stat_reset", 1)
     for k in range(K):
         pool.submit_dev(0, fx.n, fx.m, nb, d_p.data_ptr() + k * nb * fx.proof_len, fx.proof_len, d_c.data_ptr() + k * nb * 32, fx.label,
-                        d_r.data_ptr() + k * nb * 64, d_v[k].data_ptr())
+                        d_r.data_ptr() + k * nb * 64, d_v[k].data_ptr(), d_m[k].data_ptr())
     pool.wait()
+    assert pool.get_option("stat_chains") == 2 and pool.get_option("stat_chain_proofs") == K * nb   # the benched form: two chains of 10 240
     for k in range(K):
         rc = L.bpgpu_rangeproof_verify_batch_dev(ctx.h, fx.n, fx.m, nb, d_p.data_ptr() + k * nb * fx.proof_len, fx.proof_len, d_c.data_ptr() + k * nb * 32,
                                                  fx.label, len(fx.label), d_r.data_ptr() + k * nb * 64, d_ref[k].data_ptr(), None, None)
@@ -169,9 +173,10 @@ def test_pool_burst_of_20_batches_coalesced_equals_per_batch_path(oracle, cfg2):
     assert int((d_v != 0).sum().item()) == len(bad)
     gens = oracle.Gens(64, 1)
     for k in (0, 13):
-        ev, _ = _oracle_all(oracle, gens, fx, proofs[k * nb * fx.proof_len:(k + 1) * nb * fx.proof_len], coms[k * nb * 32:(k + 1) * nb * 32],
-                            rng[k * nb * 64:(k + 1) * nb * 64])
+        ev, em = _oracle_all(oracle, gens, fx, proofs[k * nb * fx.proof_len:(k + 1) * nb * fx.proof_len], coms[k * nb * 32:(k + 1) * nb * 32],
+                             rng[k * nb * 64:(k + 1) * nb * 64])
         assert bytes(d_v[k].cpu().numpy()) == ev
+        _msm_equal(ev, em, bytes(d_m[k].cpu().numpy().reshape(-1)))
     ctx.close()
     pool.close()
 
@@ -283,4 +288,61 @@ def test_pool_many_small_items_in_one_chain_and_flush_by_proofs(oracle, cfg2):
         d_v.fill_(255)
         torch.cuda.synchronize()
     assert sum(1 for v in ev if v) == len(bad)
+    pool.close()
+
+
+def test_submit_dev_ex_producer_stream_and_tickets_no_device_wide_sync(oracle, cfg2):
+    """The completion contract of bpgpu_pool_rangeproof_submit_dev_ex: inputs produced on the caller's stream (behind ~ms of other work,
+    so a chain that did not wait would read garbage), one ticket per batch, a consumer stream that waits for THAT batch on the device
+    and copies its verdicts out -- batch k is consumed while batches k+1.. are queued or running; the host only ever waits on the
+    consumer stream.  Verdicts == oracle."""
+    import torch
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    fx = cfg2
+    dev = torch.device("cuda", 0)
+    pool = bp.Pool((0,), 8, fixed_window_bits=16, auto_flush_items=3)
+    pool.gens_create(64, 1)
+    K, nb = 7, 700
+    proofs, coms = wl.tile_batch(fx, K * nb, first=31)
+    proofs, coms, bad = _tamper(proofs, coms, fx.proof_len, fx.m, K * nb, 4242, frac=0.03)
+    rng = hashlib.shake_256(b"pc").digest(64 * K * nb)
+    pin = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).pin_memory()
+    h_p, h_c, h_r = pin(proofs), pin(coms), pin(rng)
+    d_p = torch.full((K * nb * fx.proof_len,), 0xA5, dtype=torch.uint8, device=dev)     # garbage until the producer's copy lands
+    d_c = torch.full((K * nb * 32,), 0xA5, dtype=torch.uint8, device=dev)
+    d_r = torch.zeros((K * nb * 64,), dtype=torch.uint8, device=dev)
+    d_v = torch.full((K, nb), 255, dtype=torch.uint8, device=dev)
+    h_v = torch.full((K, nb), 254, dtype=torch.uint8).pin_memory()
+    busy = torch.randn((4096, 4096), device=dev)
+    producer, consumer = torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    tickets = []
+    for k in range(K):
+        with torch.cuda.stream(producer):
+            for _ in range(3):
+                busy = busy @ busy * 1e-4                      # ~ms of unrelated work ahead of the inputs on the producer's stream
+            sl = slice(k * nb * fx.proof_len, (k + 1) * nb * fx.proof_len)
+            d_p[sl].copy_(h_p[sl], non_blocking=True)
+            d_c[k * nb * 32:(k + 1) * nb * 32].copy_(h_c[k * nb * 32:(k + 1) * nb * 32], non_blocking=True)
+            d_r[k * nb * 64:(k + 1) * nb * 64].copy_(h_r[k * nb * 64:(k + 1) * nb * 64], non_blocking=True)
+        tickets.append(pool.submit_dev_ex(0, fx.n, fx.m, nb, d_p.data_ptr() + k * nb * fx.proof_len, fx.proof_len, d_c.data_ptr() + k * nb * 32, fx.label,
+                                          d_r.data_ptr() + k * nb * 64, d_v[k].data_ptr(), producer_stream=producer.cuda_stream))
+        if k >= 2:   # consume batch k-2 while k-1 and k are queued / running
+            j = k - 2
+            tickets[j].stream_wait(consumer.cuda_stream)
+            with torch.cuda.stream(consumer):
+                h_v[j].copy_(d_v[j], non_blocking=True)
+    for j in (K - 2, K - 1):
+        tickets[j].stream_wait(consumer.cuda_stream)
+        with torch.cuda.stream(consumer):
+            h_v[j].copy_(d_v[j], non_blocking=True)
+    consumer.synchronize()                                       # the only host-side wait: no hipDeviceSynchronize, no pool.wait()
+    gens = oracle.Gens(64, 1)
+    ev, _ = _oracle_all(oracle, gens, fx, proofs, coms, rng)
+    assert bytes(h_v.numpy().reshape(-1)) == ev
+    assert sum(1 for v in ev if v) == len(bad)
+    assert all(t.done() for t in tickets)
+    for t in tickets:
+        t.wait()                                                 # frees the tickets (everything is complete already)
     pool.close()

@@ -164,11 +164,35 @@ def test_generators_tests_of_the_reference(oracle):
     assert b"".join(gens.G(64, 8)) == oG and b"".join(gens.H(64, 8)) == oH
     pc = resized.pedersen()
     assert (pc.B, pc.B_blinding) == (oB, oBb)
-    # PedersenGens::commit (generators.rs:38-42) against the golden value commitments: vc[j] = j B + r_j B~ is not reproducible
-    # without the reference's ChaCha rng, so against the oracle's MSM instead; then prove_single / verify_single with thread_rng
+    # PedersenGens::commit (generators.rs:38-42) against an oracle MSM (the reference-held vc[j] are checked in
+    # test_commit_and_prover_commitments_reproduce_the_references_vectors below); then prove_single / verify_single with thread_rng
     from bulletproofs_amd import RangeProof, Transcript
     blind = hashlib.shake_256(b"commit").digest(31) + b"\x00"
     want = oracle.msm((1037578891).to_bytes(32, "little") + blind, oB + oBb)[1]
     assert resized.commit(1037578891, blind) == want
     proof, V = RangeProof.prove_single(resized, pc, Transcript(b"doctest example"), 1037578891, blind, 32)     # README.md:120 of the reference
     assert V == want and proof.verify_single(resized, pc, Transcript(b"doctest example"), V, 32) is None
+
+
+def test_commit_and_prover_commitments_reproduce_the_references_vectors(golden):
+    """The only fixed vectors upstream that pin a PROVER-side MSM site: vc[j] = PedersenGens::commit(j, r_j), r_j =
+    Scalar::random(ChaChaRng::from_seed([24u8; 32])) (tests/range_proof.rs:45-78, 108-113; generators.rs:38-42; the rng is
+    restated in oracle/py/chacha_rng.py).  The GPU's commit mirror and the value commitments the GPU prover returns for the
+    same openings (RangeProof::prove_multiple, mod.rs:234-288 -> party.rs:52-57) must BE those eight encodings; the proofs it
+    makes about them verify against the golden commitments."""
+    import chacha_rng
+    from bulletproofs_amd import BulletproofGens, RangeProof, Transcript
+    r = chacha_rng.golden_blindings()
+    vc = [bytes.fromhex(h) for h in golden["value_commitments"]]
+    gens = BulletproofGens(64, 8, fixed_window_bits=10)
+    pc = gens.pedersen()
+    for j in range(8):
+        assert gens.commit(j, r[j]) == vc[j], j
+    for n, m in ((8, 1), (16, 2), (32, 4), (64, 8)):
+        proof, V = RangeProof.prove_multiple(gens, pc, Transcript(golden["label"]), list(range(m)), r[:m], n)
+        assert V == vc[:m], (n, m)
+        assert proof.verify_multiple(gens, pc, Transcript(golden["label"]), vc[:m], n) is None
+    # the constant-time commitment path of the prover (option prover_constant_time) lands on the same encodings
+    gens.ctx.set_option("prover_constant_time", 1)
+    _, V = RangeProof.prove_multiple(gens, pc, Transcript(golden["label"]), list(range(8)), r, 64)
+    assert V == vc

@@ -56,6 +56,25 @@ def test_pedersen_and_generators(oracle, oracle_gens_64_8):
             assert H[32 * (p * 64 + i):32 * (p * 64 + i) + 32] == T.compress(bg.H_vec[p][i])
 
 
+def test_golden_value_commitments_from_the_references_own_rng(oracle, oracle_gens_64_8, golden):
+    """tests/range_proof.rs:45-78, 108-113 of the reference: vc[j] = PedersenGens::commit(j, r_j) with the r_j drawn by
+    Scalar::random from ChaChaRng::from_seed([24u8; 32]) -- the one reference-held vector that pins a PROVER-side MSM site
+    (generators.rs:38-42).  The rng is restated in oracle/py/chacha_rng.py (rand_chacha 0.2: ChaCha20, djb layout); if that
+    restatement, the C oracle's MSM or the twin's arithmetic were off, none of the eight encodings would reproduce."""
+    import chacha_rng
+    assert chacha_rng.chacha20_block(bytes(32), 0).hex().startswith("76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7")   # published ChaCha20 keystream, zero key / nonce
+    r = chacha_rng.golden_blindings()
+    _, _, B, Bb = oracle_gens_64_8.export()
+    for j in range(8):
+        want = bytes.fromhex(golden["value_commitments"][j])
+        assert oracle.msm(j.to_bytes(32, "little") + r[j], B + Bb)[1] == want, j
+        assert T.compress(T.msm([j, int.from_bytes(r[j], "little")], [T.decompress(B), T.decompress(Bb)])) == want, j
+    # and the oracle prover's commitments for the same openings (what the golden proofs were proven about)
+    for m in (1, 2, 4, 8):
+        _, coms = oracle.prove(oracle_gens_64_8, list(range(m)), b"".join(r[:m]), 8, golden["label"], b"any")
+        assert coms == golden["vc_bytes"][:32 * m]
+
+
 def test_golden_proofs_verify_c_oracle(oracle, oracle_gens_64_8, golden):
     """tests/range_proof.rs:81-93: every golden proof verifies; mega-check encodes to identity."""
     for case in golden["cases"]:
