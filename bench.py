@@ -59,7 +59,7 @@ def parse_args():
                     help="(default 64) lanes of the library's pool (bpgpu_pool_create): independent (context, HIP stream) pairs its launch chains are "
                          "issued on round-robin, so that consecutive chains overlap on the device")
     ap.add_argument("--coalesce", type=int, default=0,
-                    help="pool option coalesce_proofs: width the pool packs consecutive submitted batches into (default: the library's, 4096; "
+                    help="pool option coalesce_proofs: width the pool packs consecutive submitted batches into (default: the library's, 5120; "
                          "--coalesce = batch size means one launch chain per step, the round-2 behaviour)")
     ap.add_argument("--opt", default="", help="extra library options key=value[,key=value] (experiments, e.g. split_stage3=1)")
     ap.add_argument("--no-script", action="store_true", help="library option transcript_script = 0: byte-wise transcript replay (A/B of csrc/rp_script.h)")
@@ -391,7 +391,11 @@ def roofline_block(cfg, n, m, kern, value, wl, events_every, proofs_per_launch, 
     alg_bytes = alg_per_v * proofs_per_launch
     achieved = alg_bytes / avg_s / 1e9
     N = wl.msm_terms(n, m)
-    out = {"bound": "hbm", "binding_resource": "valu (32-bit integer multiply issue) -- see `valu`; the HBM fractions are small by construction",
+    out = {"bound": "valu",
+           "bound_note": "what binds is 32-bit integer multiply issue (`valu`: two measured ceilings).  achieved / peak / unit / frac below are the "
+                         "CONTRACT's HBM figures (algorithmic bytes per launch / live launch time against 8 TB/s) -- small by construction, ~10 field "
+                         "multiplications per input byte; the counter-based HBM figures are `traffic` and `hbm_counter`",
+           "hbm_contract_bound": "hbm",
            "kernel": dom, "dominant_by": ("largest HBM traffic per launch chain (committed FETCH_SIZE / WRITE_SIZE counters)" if moved else
                                           "largest total measured kernel time in this run"),
            "largest_summed_kernel_time": by_time,
@@ -434,6 +438,42 @@ def roofline_block(cfg, n, m, kern, value, wl, events_every, proofs_per_launch, 
                                 "Pippenger above); executed = what this engine performs per verification (window-table walk without doublings, 8-entry tables, "
                                 "Horner chain, partial-sum reduction) -- reported beside, never instead" % N}
     out["kernels_us"] = {k: round(v[1] / v[0] * 1e3, 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}
+    return out
+
+
+def drop_in_call_shape(long_run):
+    """tools/combine_rate.cpp (built here with g++) against a pool of its own (W = 16 tables: 8.7 GB beside this process's): T host
+    threads looping BLOCKING single-proof bpgpu_pool_rangeproof_verify_ts calls, tickets, and two threads with 4096-proof calls."""
+    import shutil
+    import subprocess
+    root = os.path.dirname(os.path.abspath(__file__))
+    inp = os.path.join(root, "bench_data", "combine_rate_inputs.bin")
+    if not shutil.which("g++") or not os.path.exists(inp):
+        return {"error": "g++ or bench_data/combine_rate_inputs.bin missing"}
+    exe = os.path.join("/tmp", "bp_combine_rate_%d" % os.getpid())
+    lib = os.path.join(root, "bulletproofs_amd", "csrc")
+    subprocess.check_call(["g++", "-O2", "-std=c++17", "-pthread", "-I", os.path.join(root, "include"), os.path.join(root, "tools", "combine_rate.cpp"),
+                           "-L", lib, "-lbpgpu", "-Wl,-rpath," + lib, "-o", exe])
+    env = dict(os.environ, BP_LANES="8", BP_W="16", GPU_MAX_HW_QUEUES="16")
+    out = {"note": "plain host threads, one proof per blocking call, own `transcript: &mut Transcript` per proof (mod.rs:345-353); latency = call latency; "
+                   "rate = threads / latency (Little): the device is far from full in this regime, see `tickets` and `two_callers_of_4096`"}
+    secs = "2.0" if long_run else "1.0"
+    for key, mode in (("threads_1", ["threads", "1"]), ("threads_64", ["threads", "64"]), ("threads_256", ["threads", "256"]),
+                      ("tickets_16x128", ["tickets", "16", "128"]), ("two_callers_of_4096", ["big", "2", "4096"])):
+        p = subprocess.run([exe, inp, secs] + mode, env=env, capture_output=True, text=True, timeout=120)
+        line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+        if not line:
+            out[key] = {"error": p.stderr[-300:]}
+            continue
+        d = json.loads(line[-1])
+        out[key] = {"verifications_per_s": d["rate_per_s"], "latency_ms": d["lat_ms"], "proofs_per_chain": d["proofs_per_chain"], "mismatches_vs_oracle": d["mismatches"],
+                    "errors": d["errors"]}
+        if d["mismatches"] or d["errors"]:
+            raise SystemExit("the combining queue returned a result that differs from the oracle's -- result invalid")
+    try:
+        os.unlink(exe)
+    except OSError:
+        pass
     return out
 
 
@@ -795,6 +835,15 @@ def main():
             raise
         except Exception as e:
             extra["prover"] = {"error": str(e)}
+
+    if want_extra and a.config == "cfg2" and not a.batch:
+        # (5) the reference's literal call shape through the pool's combining queue (bpgpu_pool_rangeproof_verify_ts): plain host threads
+        # (a C++ client, no Python in the loop), every proof with its own transcript (half of them pre-bound), every result compared with
+        # the oracle's committed expectations (bench_data/combine_rate_inputs.bin).  PCIe-inclusive by nature; never `value`.
+        try:
+            extra["drop_in_call_shape"] = drop_in_call_shape(long_run)
+        except Exception as e:
+            extra["drop_in_call_shape"] = {"error": str(e)}
 
     if rank == 0:
         out = {

@@ -416,33 +416,42 @@ int bpgpu_ipp_verification_scalars(bpgpu_ctx *ctx, size_t n, size_t nbatch, cons
  * chain on one stream and cannot fill a device by itself; a pool owns `lanes_per_device` contexts on each of `ndev`
  * devices (the generator tables are built once per device and shared by its lanes) and does the scheduling that the
  * benchmark used to do by hand:
- *   - bpgpu_pool_rangeproof_verify (HOST pointers, synchronous, any nbatch): proofs are independent units, so device d
- *     takes the contiguous shard [nbatch d / ndev, nbatch (d+1) / ndev); a shard is cut into slices that a few host worker
- *     threads of the pool stage, enqueue and collect on their lanes (asynchronously: one thread keeps several chains in flight); every slice's verdicts land at its offset of the
- *     caller's buffer -- the "final gather" of SURVEY 8e is that host-side placement, no collective is involved.
- *     Verdicts are exactly those of bpgpu_rangeproof_verify_batch on the whole batch.
+ *   - bpgpu_pool_rangeproof_verify / bpgpu_pool_rangeproof_verify_ts (HOST pointers, blocking, any nbatch, ANY NUMBER OF THREADS AT
+ *     ONCE): the requests go through the pool's combining queue (declared below): calls that arrive close together share launch
+ *     chains, a large call spans several chains and -- proofs being independent units -- takes the contiguous shard
+ *     [nbatch d / ndev, nbatch (d+1) / ndev) of every device; every piece's verdicts land at its offset of the caller's buffer: the
+ *     "final gather" of SURVEY 8e is that host-side placement, no collective is involved.  Verdicts are exactly those of
+ *     bpgpu_rangeproof_verify_batch[_ts] on the whole batch.  (Option "host_path_combining" = 0 restores round 3's path for the label
+ *     form: one call at a time, slices staged by "host_workers" threads per device.)
  *   - bpgpu_pool_rangeproof_submit_dev (DEVICE pointers on device `dev_index` of the pool, asynchronous): the batch is
  *     queued; bpgpu_pool_flush -- or the pool itself once "auto_flush_items" batches wait (default: one per lane) --
  *     packs consecutive queued batches of one shape (n, m, proof_len, label) into coalesced launch chains of about
  *     "coalesce_proofs" proofs (default 5120) and issues them on the lanes round-robin.  A burst of small batches is
- *     thereby served as a few wide chains instead of many narrow ones (20 x 1024 proofs from an idle device: 4.2 -> 5.3 M
- *     verifications/s); every batch still gets its own verdict (and msm_out) buffer filled.  Input buffers must be complete
- *     on the device when the batch is submitted and stay valid until bpgpu_pool_wait returns (the pool's streams are not
- *     ordered against the caller's).  Batches whose length or parameters are malformed are passed to
- *     bpgpu_rangeproof_verify_batch_dev unchanged, which reports them per proof.
+ *     thereby served as a few wide chains instead of many narrow ones (20 x 1024 proofs from an idle device: 4.1 M
+ *     verifications/s as twenty chains, 5.9 - 6.2 M as two); every batch still gets its own verdict (and msm_out) buffer filled.
+ *     Input buffers must be complete on the device when the batch is submitted and stay valid until bpgpu_pool_wait returns (the
+ *     pool's streams are not ordered against the caller's) -- or use bpgpu_pool_rangeproof_submit_dev_ex below: a producer stream
+ *     the chain waits for, and a ticket per batch.  Batches whose length or parameters are malformed are passed to
+ *     bpgpu_rangeproof_verify_batch_dev unchanged, which reports them per proof.  When a chain cannot be issued, the verdict bytes
+ *     of the batches it carried are set to BPGPU_VERDICT_UNDECIDED (never left at 0 = "verified") and the flush reports the error.
  * devices: HIP ordinals, one entry per shard (an ordinal may repeat: two shards on one GPU -- what the one-GPU tests
- * do).  lanes_per_device: 0 = 32.  More than 4 lanes need 8..16 hardware queues: libbpgpu sets GPU_MAX_HW_QUEUES=16 when it
- * is loaded if the variable is unset (the ROCm runtime reads it at the process's first HIP call); bpgpu_pool_create
- * returns BPGPU_ERR_HW_QUEUES when it finds another value.
+ * do).  lanes_per_device: 0 = 32 (plus the combining queue's own lanes: environment BPGPU_COMBINE_LANES, default 12).  More than 4
+ * lanes need 8..16 hardware queues: export GPU_MAX_HW_QUEUES=16 before the process's FIRST HIP call (the ROCm runtime reads it
+ * then).  libbpgpu sets the variable when it is loaded if it is unset -- which only helps when nothing initialised HIP earlier;
+ * bpgpu_pool_create therefore returns BPGPU_ERR_HW_QUEUES when it finds another value, and, when the value is the library's own,
+ * after timing sixteen spinning single-wavefront kernels on sixteen streams (< 1 ms) and finding fewer than 8 of them overlapping.
+ * bpgpu_pool_last_error is per calling thread: what the last pool call OF THAT THREAD reported.
  * Options (bpgpu_pool_set_option): "coalesce_proofs", "max_chain_proofs" (default 16384), "pair_limit_proofs" (default 24576: a flush
  * of up to this many proofs is issued as at most two chains), "latency_proofs" (default 6144: a host call, or a flush on an idle device, of
  * up to this many proofs is alone on the device -- its chains keep the quad Horner form instead of the one-lane form), "auto_flush_items", "auto_flush_proofs" (default 0 = off: once this many
  * proofs wait they leave as one chain while the caller keeps submitting; measured neutral on 20 x 1024 bursts),
- * "slice_proofs" (host-pointer calls; 0 = automatic: 2048..4096 proofs per slice),
- * "host_workers" (threads per device for host-pointer calls, default 2; each drives its share of the lanes asynchronously); any other key is forwarded
- * to every lane context (set those before bpgpu_pool_gens_*).  Read-only statistics of the coalesced path:
- * "stat_chains", "stat_chain_proofs" (launch chains issued and the proofs they carried; set "stat_reset" to zero them),
- * "stat_last_splits". */
+ * "slice_proofs" / "host_workers" (the round-3 host path only); the combining queue: "combine_wait_us" (100), "combine_quiet_us" (20),
+ * "combine_max_age_us" (1500), "combine_inflight" (6: deadlines seal buffers only while fewer chains than this run -- beyond, load
+ * widens the chains), "combine_busy_chains" (2), "combine_max_open" (4 transcript-position classes with a buffer of their own),
+ * "combine_poll_us" (15); any other key is forwarded to every lane context (set those before bpgpu_pool_gens_*).  Read-only
+ * statistics: "stat_chains", "stat_chain_proofs" (launch chains issued by flushes and the proofs they carried; set "stat_reset" to
+ * zero all statistics), "stat_last_splits", "stat_combined_chains" / "_proofs" / "_requests", "stat_svc_issue_us" /
+ * "_complete_us" / "_polls" (the combining queue's service threads). */
 typedef struct bpgpu_pool bpgpu_pool;
 int bpgpu_pool_create(const int *devices, int ndev, int lanes_per_device, bpgpu_pool **out);
 void bpgpu_pool_destroy(bpgpu_pool *pool);

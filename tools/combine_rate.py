@@ -16,6 +16,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
 OUT = os.path.join(ROOT, "gpurun_out")
+INPUTS = os.path.join(ROOT, "bench_data", "combine_rate_inputs.bin")   # committed (written by make_inputs: `--make-inputs`)
 
 
 def make_inputs(path, count=512, n=64, m=1):
@@ -55,11 +56,16 @@ def main():
     ap.add_argument("--lanes", type=int, default=8)
     ap.add_argument("--window", type=int, default=0)
     ap.add_argument("--opts", default="")
+    ap.add_argument("--make-inputs", action="store_true", help="(re)write bench_data/combine_rate_inputs.bin with the oracle and exit")
     ap.add_argument("modes", nargs="*", default=["threads 64", "threads 256", "threads 1024", "tickets 16 64", "big 2 4096"])
     a = ap.parse_args()
     os.makedirs(OUT, exist_ok=True)
-    inp = os.path.join(OUT, "combine_rate_inputs.bin")
+    if a.make_inputs:
+        make_inputs(INPUTS)
+        return 0
+    inp = INPUTS
     if not os.path.exists(inp):
+        inp = os.path.join(OUT, "combine_rate_inputs.bin")
         make_inputs(inp)
     exe = os.path.join(OUT, "combine_rate")
     lib = os.path.join(ROOT, "bulletproofs_amd", "csrc")
