@@ -168,7 +168,7 @@ class RangeProofBench:
         self.distinct = distinct
         self.nstreams = nstreams
         self.ctxs, self.streams, self.pool = [], [], None
-        self.use_pool = not (rlc or a.direct)
+        self.use_pool = not a.direct   # (since round 4 the batch-combined check goes through the pool too: one combination per launch chain)
         if self.use_pool:
             # the library's scheduler: steps are SUBMITTED (device pointers) and the pool packs consecutive ones into launch chains
             self.pool = bp.Pool((local_dev,), nstreams, fixed_window_bits=a.window_bits or None, horner_lanes=a.horner_lanes or None,
@@ -194,6 +194,24 @@ class RangeProofBench:
     def get_option(self, key):
         return self.pool.get_option(key) if self.pool else self.ctxs[0].get_option(key)
 
+    def rlc_selfcheck(self):
+        """batch-combined mode through the pool, outside the clock: a chain of two clean batches comes back all 0 with batch verdict 0; a
+        chain holding one planted batch comes back undecided (5) for EVERY proof of the chain, batch verdict 1"""
+        torch, fx = self.torch, self.fx
+        v = torch.full((3, self.batch), 255, dtype=torch.uint8, device=self.dev)
+        bo = torch.full((3, 36), 255, dtype=torch.uint8, device=self.dev)
+        coms = self.d_coms.data_ptr()
+        for r, src in ((0, self.d_clean), (1, self.d_clean)):
+            self.pool.submit_rlc_dev(0, fx.n, fx.m, self.batch, src.data_ptr(), fx.proof_len, coms, fx.label, self.d_rng.data_ptr(), v[r].data_ptr(), bo[r].data_ptr())
+        self.pool.wait()
+        ok = bool((v[:2] == 0).all().item()) and int(bo[0][0].item()) == 0 and int(bo[1][0].item()) == 0
+        self.pool.submit_rlc_dev(0, fx.n, fx.m, self.batch, self.d_clean.data_ptr(), fx.proof_len, coms, fx.label, self.d_rng.data_ptr(), v[0].data_ptr(), bo[0].data_ptr())
+        self.pool.submit_rlc_dev(0, fx.n, fx.m, self.batch, self.d_planted.data_ptr(), fx.proof_len, coms, fx.label, self.d_rng.data_ptr(), v[2].data_ptr(), bo[2].data_ptr())
+        self.pool.wait()
+        ok = ok and bool((v[0] == 5).all().item()) and bool((v[2] == 5).all().item()) and int(bo[2][0].item()) == 1 and bool((bo[0][:33] == bo[2][:33]).all().item())
+        if not ok:
+            raise SystemExit("batch-combined check through the pool: self-check failed -- result invalid")
+
     def slice_of(self, g):
         """which slice of the fixture global step g verifies (ranks start at different slices)"""
         return 0 if self.a.same_input else (g + self.rank) % self.nslices
@@ -210,6 +228,12 @@ class RangeProofBench:
         if self.pool is not None and not rlc:
             self.pool.submit_dev(0, fx.n, fx.m, self.batch, base, fx.proof_len, coms, fx.label, self.d_rng.data_ptr(), out_row.data_ptr())
             return
+        if self.pool is not None:
+            # batch-combined mode through the pool: clean slices only in the timed steps (a planted batch makes its whole CHAIN undecided,
+            # which rlc_selfcheck verifies once, outside the clock)
+            base = self.d_clean.data_ptr() + j * self.batch * fx.proof_len
+            self.pool.submit_rlc_dev(0, fx.n, fx.m, self.batch, base, fx.proof_len, coms, fx.label, self.d_rng.data_ptr(), out_row.data_ptr())
+            return
         if rlc:
             rc = L.bpgpu_rangeproof_verify_rlc_dev(self.ctxs[k].h, fx.n, fx.m, self.batch, base, fx.proof_len, coms, fx.label, len(fx.label),
                                                    self.d_rng.data_ptr(), self.d_wts.data_ptr(), out_row.data_ptr(), None, self.streams[k].cuda_stream)
@@ -224,7 +248,9 @@ class RangeProofBench:
         torch = self.torch
         idx = torch.tensor([self.slice_of(g0 + i) for i in range(K)], device=self.dev)
         e = self.d_expect[idx]
-        if rlc:   # clean slices: all 0; planted ones: every proof undecided (5)
+        if rlc and self.pool is not None:
+            e = torch.zeros((K, self.batch), dtype=torch.uint8, device=self.dev)
+        elif rlc:   # clean slices: all 0; planted ones: every proof undecided (5)
             planted = torch.tensor([1 if (g0 + i) % 8 == 7 else 0 for i in range(K)], dtype=torch.uint8, device=self.dev)
             e = (planted * 5).unsqueeze(1).expand(K, self.batch)
         return e
@@ -242,7 +268,7 @@ class RangeProofBench:
         t0 = time.perf_counter()
         for i in range(K):
             self.step(g0 + i, self.d_verdicts[i], rlc)
-        if self.pool is not None and not rlc:
+        if self.pool is not None:
             self.pool.flush()                                # whatever the pool still holds back is issued now (inside the timed region)
         t_enq = time.perf_counter() - t0
         if gather is not None and self.pool is not None:
@@ -438,6 +464,62 @@ def roofline_block(cfg, n, m, kern, value, wl, events_every, proofs_per_launch, 
                                 "Pippenger above); executed = what this engine performs per verification (window-table walk without doublings, 8-entry tables, "
                                 "Horner chain, partial-sum reduction) -- reported beside, never instead" % N}
     out["kernels_us"] = {k: round(v[1] / v[0] * 1e3, 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}
+    return out
+
+
+def mixed_shapes(a, local_dev, long_run):
+    """ONE pool serving cfg3-shaped (m = 16) and cfg2-shaped (m = 1) proofs -- bpgpu_pool_gens_create(64, 16) +
+    bpgpu_pool_gens_add_shape(64, 1): two window tables re-balanced under the one default budget.  Each shape's rate on the shared pool
+    alone, then both in the same timed region (batches of both shapes submitted alternately); verdict rows checked against the planted
+    pattern."""
+    import torch
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    dev = torch.device("cuda", local_dev)
+    pool = bp.Pool((local_dev,), 64, fixed_table_max_bytes=a.table_bytes or None)
+    pool.gens_create(64, 16)
+    w_alone = pool.get_option("fixed_window_bits")
+    pool.gens_add_shape(64, 1)
+    out = {"windows": {"m16_alone": w_alone, "m16": pool.get_option("fixed_window_bits"), "m1": pool.get_option("secondary_window_bits")},
+           "table_bytes": pool.get_option("fixed_table_bytes") + pool.get_option("secondary_table_bytes")}
+    to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    sh = {}
+    for key, cfg, batch in (("m1", "cfg2", 1024), ("m16", "cfg3", 256)):
+        fx = wl.load_fixture(wl.CONFIGS[cfg][0])
+        ns = max(1, fx.count // batch)
+        proofs, coms = wl.tile_batch(fx, ns * batch)
+        planted, rows = plant_invalid(proofs, fx.proof_len, batch, ns)
+        sh[key] = dict(fx=fx, batch=batch, ns=ns, d_p=to_dev(planted), d_c=to_dev(coms), d_r=to_dev(hashlib.shake_256(b"mx" + key.encode()).digest(64 * batch)),
+                       d_e=torch.tensor([list(r) for r in rows], dtype=torch.uint8, device=dev))
+
+    def region(keys, K):
+        bufs = {k: torch.full((K, sh[k]["batch"]), 255, dtype=torch.uint8, device=dev) for k in keys}
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(K):
+            for k in keys:
+                x = sh[k]
+                j = i % x["ns"]
+                pool.submit_dev(0, x["fx"].n, x["fx"].m, x["batch"], x["d_p"].data_ptr() + j * x["batch"] * x["fx"].proof_len, x["fx"].proof_len,
+                                x["d_c"].data_ptr() + j * x["batch"] * 32 * x["fx"].m, x["fx"].label, x["d_r"].data_ptr(), bufs[k][i].data_ptr())
+        pool.wait()
+        dt = time.perf_counter() - t0
+        for k in keys:
+            x = sh[k]
+            exp = x["d_e"][torch.tensor([i % x["ns"] for i in range(K)], device=dev)]
+            if not bool((bufs[k] == exp).all().item()):
+                raise SystemExit("mixed shapes: verdicts differ from the planted pattern -- result invalid")
+        return dt
+
+    K = 256 if long_run else 24
+    for keys in (("m1",), ("m16",), ("m1", "m16")):
+        region(keys, K)                       # set-up (arenas, plans)
+        dts = sorted(region(keys, K) for _ in range(3))
+        name = "+".join(keys)
+        out[name] = {k: round(sh[k]["batch"] * K / dts[1], 1) for k in keys}
+    out["note"] = ("one pool, BulletproofGens(64, 16): m = 16 proofs walk the primary table, m = 1 proofs the secondary one; verifications/s of each shape "
+                   "alone on the shared pool and of both submitted alternately in one timed region (both rates hold simultaneously there)")
+    pool.close()
     return out
 
 
@@ -689,7 +771,7 @@ def main():
 
     fx_name, default_batch = wl.CONFIGS[a.config]
     batch = a.batch or default_batch
-    direct = a.direct or a.rlc
+    direct = a.direct
     nstreams = lanes_for(a, a.steps, direct)
     b = RangeProofBench(a, a.config, batch, nstreams, rank, local_dev, rlc=a.rlc)
     n, m = b.fx.n, b.fx.m
@@ -740,12 +822,14 @@ def main():
             a.direct = False
         # (1) the same batches through the batch-combined entry point (one identity check per batch) -- never `value`
         try:
-            br = RangeProofBench(a, a.config, batch, lanes_for(a, a.steps, True), rank, local_dev, rlc=True)
-            ks = max(br.nstreams, a.steps // 4)
-            rr = timed(br, ks, br.nstreams, fence, 1, None, False, True)
-            extra["rlc"] = {"verifications_per_s": round(batch * ks / rr["elapsed"], 1), "steps": ks,
-                            "note": "bpgpu_rangeproof_verify_rlc_dev: one combined identity check per batch of %d (additional entry point, SURVEY 8f-3); "
-                                    "every 8th batch carries planted invalid proofs and must come back undecided" % batch}
+            br = RangeProofBench(a, a.config, batch, lanes_for(a, a.steps, False), rank, local_dev, rlc=True)
+            br.rlc_selfcheck()
+            ks = max(64, a.steps // 4) if long_run else max(a.steps, 8)
+            rr = timed(br, ks, 16 if long_run else 4, fence, 0, None, False, True)
+            chr_, cpr = br.pool.get_option("stat_chains"), br.pool.get_option("stat_chain_proofs")
+            extra["rlc"] = {"verifications_per_s": round(batch * ks / rr["elapsed"], 1), "steps": ks, "proofs_per_combination": round(cpr / chr_, 1) if chr_ else batch,
+                            "note": "bpgpu_pool_rangeproof_submit_rlc_dev: batches of %d submitted to the pool, ONE combined identity check per launch chain "
+                                    "(additional entry point, SURVEY 8f-3); a chain holding a planted batch comes back undecided as a whole (checked outside the clock)" % batch}
             br.close()
         except Exception as e:
             extra["rlc"] = {"error": str(e)}
@@ -844,6 +928,14 @@ def main():
             extra["drop_in_call_shape"] = drop_in_call_shape(long_run)
         except Exception as e:
             extra["drop_in_call_shape"] = {"error": str(e)}
+
+    if want_extra and a.config == "cfg2" and not a.batch:
+        try:
+            extra["mixed_shapes"] = mixed_shapes(a, local_dev, long_run)
+        except SystemExit:
+            raise
+        except Exception as e:
+            extra["mixed_shapes"] = {"error": str(e)}
 
     if rank == 0:
         out = {

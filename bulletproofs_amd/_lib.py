@@ -28,7 +28,8 @@ EXPORTS = [
     "bpgpu_pool_devices", "bpgpu_pool_lanes", "bpgpu_pool_lane", "bpgpu_pool_gens_create", "bpgpu_pool_gens_load",
     "bpgpu_pool_rangeproof_verify", "bpgpu_pool_rangeproof_submit_dev", "bpgpu_pool_flush", "bpgpu_pool_wait",
     "bpgpu_pool_rangeproof_verify_ts", "bpgpu_pool_rangeproof_submit_ts", "bpgpu_pool_ticket_done", "bpgpu_pool_ticket_wait",
-    "bpgpu_pool_rangeproof_submit_dev_ex", "bpgpu_pool_ticket_stream_wait",
+    "bpgpu_pool_rangeproof_submit_dev_ex", "bpgpu_pool_ticket_stream_wait", "bpgpu_pool_rangeproof_submit_rlc_dev",
+    "bpgpu_gens_add_shape", "bpgpu_pool_gens_add_shape",
 ]
 
 TRANSCRIPT_BYTES = 208
@@ -106,6 +107,8 @@ def lib():
     L.bpgpu_pool_lane.argtypes = [vp, i, i]
     L.bpgpu_pool_lane.restype = vp
     L.bpgpu_pool_gens_create.argtypes = [vp, sz, sz]
+    L.bpgpu_gens_add_shape.argtypes = [vp, sz, sz]
+    L.bpgpu_pool_gens_add_shape.argtypes = [vp, sz, sz]
     L.bpgpu_pool_gens_load.argtypes = [vp, sz, sz, u8p, u8p, u8p, u8p]
     L.bpgpu_pool_rangeproof_verify.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p]
     L.bpgpu_pool_rangeproof_submit_dev.argtypes = [vp, i, sz, sz, sz, vp, sz, vp, u8p, sz, vp, vp, vp]
@@ -113,6 +116,7 @@ def lib():
     L.bpgpu_pool_rangeproof_submit_ts.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p, u8p, C.POINTER(vp)]
     L.bpgpu_pool_rangeproof_submit_dev_ex.argtypes = [vp, i, sz, sz, sz, vp, sz, vp, u8p, sz, vp, vp, vp, vp, i, C.POINTER(vp)]
     L.bpgpu_pool_ticket_stream_wait.argtypes = [vp, vp, vp]
+    L.bpgpu_pool_rangeproof_submit_rlc_dev.argtypes = [vp, i, sz, sz, sz, vp, sz, vp, u8p, sz, vp, vp, vp, vp, i, C.POINTER(vp)]
     L.bpgpu_pool_ticket_done.argtypes = [vp, vp]
     L.bpgpu_pool_ticket_wait.argtypes = [vp, vp]
     L.bpgpu_pool_flush.argtypes = [vp]
@@ -199,6 +203,10 @@ class Context:
     def gens_create(self, gens_capacity, party_capacity):
         self._chk(self._L.bpgpu_gens_create(self.h, gens_capacity, party_capacity))
         self.gens_capacity, self.party_capacity = gens_capacity, party_capacity
+
+    def gens_add_shape(self, n2, m2):
+        """a second, larger-window table for the smaller shape (n2, m2) (bpgpu_gens_add_shape)"""
+        self._chk(self._L.bpgpu_gens_add_shape(self.h, n2, m2))
 
     def gens_load(self, gens_capacity, party_capacity, G, H, B, B_blinding):
         assert len(G) == len(H) == 32 * gens_capacity * party_capacity
@@ -503,6 +511,10 @@ class Pool:
         assert len(G) == len(H) == 32 * gens_capacity * party_capacity
         self._chk(self._L.bpgpu_pool_gens_load(self.h, gens_capacity, party_capacity, G, H, B, B_blinding))
 
+    def gens_add_shape(self, n2, m2):
+        """a second, larger-window table for the smaller shape (n2, m2), both windows re-balanced under one budget (bpgpu_pool_gens_add_shape)"""
+        self._chk(self._L.bpgpu_pool_gens_add_shape(self.h, n2, m2))
+
     def rangeproof_verify(self, n, m, proofs, proof_len, commitments, label, rng64=None, want_msm=False):
         """ONE call, any number of proofs, host memory in and out (bpgpu_pool_rangeproof_verify)."""
         nb = len(proofs) // proof_len if proof_len else 0
@@ -559,6 +571,15 @@ class Pool:
         self._chk(self._L.bpgpu_pool_rangeproof_submit_dev_ex(self.h, dev_index, n, m, nbatch, d_proofs, proof_len, d_commitments, label, len(label), d_rng64,
                                                               d_verdict, d_msm_out, producer_stream or None, 0 if producer_stream is None else 1,
                                                               C.byref(t) if want_ticket else None))
+        return DevTicket(self, t) if want_ticket else None
+
+    def submit_rlc_dev(self, dev_index, n, m, nbatch, d_proofs, proof_len, d_commitments, label, d_rng64, d_verdict, d_batch_out=None, producer_stream=None,
+                       want_ticket=False):
+        """queue a device-resident batch for the batch-combined check (bpgpu_pool_rangeproof_submit_rlc_dev): one identity check per launch chain"""
+        t = C.c_void_p()
+        self._chk(self._L.bpgpu_pool_rangeproof_submit_rlc_dev(self.h, dev_index, n, m, nbatch, d_proofs, proof_len, d_commitments, label, len(label), d_rng64,
+                                                               d_verdict, d_batch_out, producer_stream or None, 0 if producer_stream is None else 1,
+                                                               C.byref(t) if want_ticket else None))
         return DevTicket(self, t) if want_ticket else None
 
     def flush(self):

@@ -17,6 +17,7 @@
 
 #include "../../include/bpgpu.h"
 #include "kernels.h"
+#include "hostrng.h"
 
 using namespace bp;
 
@@ -65,6 +66,18 @@ struct bpgpu_ctx {
     fb_entry *d_table = nullptr;
     fb_params prm{};
     std::vector<uint8_t> h_gens;      // host copy of the encodings
+    // A second, larger-window table for a SMALLER shape (n2 <= gens_capacity, m2 <= party_capacity) that the context also serves
+    // (bpgpu_gens_add_shape): its generators are a subset of the primary set's, re-listed compactly [B~, B, G(n2, m2), H(n2, m2)].
+    // Range proofs with n <= n2 and m <= m2 walk this table; the window pair is chosen under ONE budget (pick_window_pair).
+    struct sec_table {
+        size_t n = 0, m = 0;
+        std::vector<uint8_t> h_gens;
+        uint32_t *d_gens = nullptr;
+        fb_params prm{};
+        fb_entry *d_table = nullptr;
+        struct shared_table *ref = nullptr;
+        std::map<std::pair<size_t, size_t>, uint32_t *> ids_cache;
+    } sec;
     std::map<std::pair<size_t, size_t>, uint32_t *> gen_ids_cache;  // (n,m) -> device id list
     struct script_ent {
         uint32_t *mem = nullptr;
@@ -147,19 +160,29 @@ struct bpgpu_ctx {
     std::vector<hipEvent_t> ev_pool;
 };
 
-static void release_table(bpgpu_ctx *c) {
+static void release_ref(shared_table *&ref, fb_entry *&tab) {
     std::lock_guard<std::mutex> lk(g_tab_mu);
-    if (c->tab_ref && --c->tab_ref->refs == 0) {
-        hipFree(c->tab_ref->d_table);
+    if (ref && --ref->refs == 0) {
+        hipFree(ref->d_table);
         for (size_t i = 0; i < g_tables.size(); i++)
-            if (g_tables[i] == c->tab_ref) {
+            if (g_tables[i] == ref) {
                 g_tables.erase(g_tables.begin() + i);
                 break;
             }
-        delete c->tab_ref;
+        delete ref;
     }
-    c->tab_ref = nullptr;
-    c->d_table = nullptr;
+    ref = nullptr;
+    tab = nullptr;
+}
+static void release_table(bpgpu_ctx *c) { release_ref(c->tab_ref, c->d_table); }
+static void release_secondary(bpgpu_ctx *c) {
+    release_ref(c->sec.ref, c->sec.d_table);
+    if (c->sec.d_gens) hipFree(c->sec.d_gens);
+    c->sec.d_gens = nullptr;
+    for (auto &kv : c->sec.ids_cache) hipFree(kv.second);
+    c->sec.ids_cache.clear();
+    c->sec.h_gens.clear();
+    c->sec.n = c->sec.m = 0;
 }
 
 static int fail(bpgpu_ctx *c, int code, const char *fmt, ...) {
@@ -394,6 +417,7 @@ void bpgpu_ctx_destroy(bpgpu_ctx *c) {
     if (c->rp_status) hipFree(c->rp_status);
     if (c->d_table_ct) hipFree(c->d_table_ct);
     if (c->d_gens) hipFree(c->d_gens);
+    release_secondary(c);
     release_table(c);
     if (c->stream) hipStreamDestroy(c->stream);
     delete c;
@@ -470,6 +494,10 @@ int bpgpu_ctx_get_option(bpgpu_ctx *c, const char *key, int64_t *value) {
     if (!strcmp(key, "fixed_window_bits")) *value = c->d_table ? c->prm.W : c->W;          // effective once tables exist
     else if (!strcmp(key, "fixed_table_bytes")) *value = c->d_table ? (int64_t)table_bytes(c->prm.n_gens, c->prm.W) : 0;
     else if (!strcmp(key, "fixed_table_max_bytes")) *value = (int64_t)c->table_budget;
+    else if (!strcmp(key, "secondary_window_bits")) *value = c->sec.d_table ? c->sec.prm.W : 0;
+    else if (!strcmp(key, "secondary_table_bytes")) *value = c->sec.d_table ? (int64_t)table_bytes(c->sec.prm.n_gens, c->sec.prm.W) : 0;
+    else if (!strcmp(key, "secondary_shape_n")) *value = (int64_t)c->sec.n;
+    else if (!strcmp(key, "secondary_shape_m")) *value = (int64_t)c->sec.m;
     else if (!strcmp(key, "fixed_splits")) *value = c->splits;
     else if (!strcmp(key, "horner_lanes")) *value = c->horner_lanes;
     else if (!strcmp(key, "per_proof_radix")) *value = c->vb_radix;
@@ -540,23 +568,19 @@ int bpgpu_profile_report(bpgpu_ctx *c, char *buf, size_t cap) {
 // ============================================================================
 static uint64_t table_bytes(uint32_t n_gens, uint32_t W) { return (uint64_t)n_gens * fb_nwin(W) * (1ull << (W - 1)) * sizeof(fb_entry); }
 
-static int build_tables(bpgpu_ctx *c) {
-    // c->d_gens / c->h_gens hold n_gens compressed points
+// One window table for the generator list (h_gens on the host, d_gens on the device: n_gens compressed points): found among the tables
+// the process already holds on this device, or built.  W_fixed = 0: the fewest windows (= additions per generator term) whose table
+// fits `budget`; ties: the smaller table.
+static int build_table_set(bpgpu_ctx *c, const std::vector<uint8_t> &h_gens, const uint32_t *d_gens, uint32_t W_fixed, uint64_t budget0, fb_params *prm_out,
+                           shared_table **ref_out, fb_entry **tab_out) {
     fb_params prm;
-    prm.n_gens = (uint32_t)(2 + 2 * c->gens_capacity * c->party_capacity);
-    release_table(c);
-    if (c->d_table_ct) {   // belongs to the previous generator set
-        hipFree(c->d_table_ct);
-        c->d_table_ct = nullptr;
-    }
-    for (auto &kv : c->gen_ids_cache) hipFree(kv.second);
-    c->gen_ids_cache.clear();
+    prm.n_gens = (uint32_t)(h_gens.size() / 32);
     std::lock_guard<std::mutex> lk(g_tab_mu);
-    uint32_t W = c->W;
+    uint32_t W = W_fixed;
     fb_entry *d_table = nullptr;
     size_t entries = 0;
-    for (uint64_t budget = c->table_budget;; budget /= 2) {
-        if (c->W == 0) {   // the fewest windows (= additions per generator term) whose table fits the budget; ties: smaller table
+    for (uint64_t budget = budget0;; budget /= 2) {
+        if (W_fixed == 0) {
             W = 4;
             for (uint32_t w = 5; w <= 20; w++)
                 if (table_bytes(prm.n_gens, w) <= budget && fb_nwin(w) < fb_nwin(W)) W = w;
@@ -564,12 +588,12 @@ static int build_tables(bpgpu_ctx *c) {
         prm.W = W;
         prm.nwin = fb_nwin(W);
         prm.half = 1u << (W - 1);
-        c->prm = prm;
+        *prm_out = prm;
         for (shared_table *t : g_tables)
-            if (t->device == c->device && t->W == W && t->gens == c->h_gens) {
+            if (t->device == c->device && t->W == W && t->gens == h_gens) {
                 t->refs++;
-                c->tab_ref = t;
-                c->d_table = t->d_table;
+                *ref_out = t;
+                *tab_out = t->d_table;
                 return BPGPU_OK;
             }
         entries = (size_t)prm.n_gens * prm.nwin * prm.half;
@@ -577,7 +601,7 @@ static int build_tables(bpgpu_ctx *c) {
         (void)hipGetLastError();
         d_table = nullptr;
         // automatic window: the HBM may be shared with other tenants -- settle for a smaller table
-        if (c->W != 0 || W <= 8) return fail(c, BPGPU_ERR_HIP, "hipMalloc of %zu table bytes (W = %u) failed", entries * sizeof(fb_entry), W);
+        if (W_fixed != 0 || W <= 8) return fail(c, BPGPU_ERR_HIP, "hipMalloc of %zu table bytes (W = %u) failed", entries * sizeof(fb_entry), W);
     }
     ge_ext *d_base = nullptr;
     uint32_t *d_bad = nullptr;
@@ -587,7 +611,7 @@ static int build_tables(bpgpu_ctx *c) {
         return fail(c, BPGPU_ERR_HIP, "hipMalloc of table scratch failed");
     }
     hipMemsetAsync(d_bad, 0, 4, c->stream);
-    LAUNCH(c, c->stream, "fb_base", k_fb_base, (prm.n_gens + 63) / 64, 64, prm, c->d_gens, d_base, d_bad);
+    LAUNCH(c, c->stream, "fb_base", k_fb_base, (prm.n_gens + 63) / 64, 64, prm, d_gens, d_base, d_bad);
     LAUNCH(c, c->stream, "fb_fill", k_fb_fill, (prm.n_gens * prm.nwin + 63) / 64, 64, prm, d_base, d_table);
     const uint64_t n_groups = (entries + BP_FB_NORM_GROUP - 1) / BP_FB_NORM_GROUP;
     LAUNCH(c, c->stream, "fb_norm", k_fb_norm, (uint32_t)((n_groups + 63) / 64), 64, n_groups, (uint64_t)entries, d_table);
@@ -605,10 +629,107 @@ static int build_tables(bpgpu_ctx *c) {
         hipFree(d_table);
         return fail(c, BPGPU_ERR_BAD_GENERATOR, "a generator encoding does not decode");
     }
-    shared_table *t = new shared_table{c->device, W, c->h_gens, d_table, 1};
+    shared_table *t = new shared_table{c->device, W, h_gens, d_table, 1};
     g_tables.push_back(t);
-    c->tab_ref = t;
-    c->d_table = d_table;
+    *ref_out = t;
+    *tab_out = d_table;
+    return BPGPU_OK;
+}
+
+static int build_tables(bpgpu_ctx *c, uint32_t W_override = 0) {
+    // c->d_gens / c->h_gens hold n_gens compressed points
+    release_secondary(c);   // (belongs to the previous generator set)
+    release_table(c);
+    if (c->d_table_ct) {   // belongs to the previous generator set
+        hipFree(c->d_table_ct);
+        c->d_table_ct = nullptr;
+    }
+    for (auto &kv : c->gen_ids_cache) hipFree(kv.second);
+    c->gen_ids_cache.clear();
+    return build_table_set(c, c->h_gens, c->d_gens, W_override ? W_override : c->W, c->table_budget, &c->prm, &c->tab_ref, &c->d_table);
+}
+
+// Windows for TWO shapes under one budget (bpgpu_gens_add_shape): the pair (W1 for the primary set of n1 generators, W2 for the secondary
+// set of n2) that minimises the sum of the two walks' lengths RELATIVE to what each would get alone with the whole budget --
+// nwin(W1) / nwin(W1*) + nwin(W2) / nwin(W2*) -- among the pairs whose tables fit together; ties: fewer bytes.  W1_fixed != 0 pins W1.
+static void pick_window_pair(uint32_t n1, uint32_t n2, uint64_t budget, uint32_t W1_fixed, uint32_t *W1, uint32_t *W2) {
+    auto best_alone = [&](uint32_t ng) {
+        uint32_t W = 4;
+        for (uint32_t w = 5; w <= 20; w++)
+            if (table_bytes(ng, w) <= budget && fb_nwin(w) < fb_nwin(W)) W = w;
+        return W;
+    };
+    const double a1 = fb_nwin(best_alone(n1)), a2 = fb_nwin(best_alone(n2));
+    double best = 1e30;
+    uint64_t best_bytes = ~0ull;
+    *W1 = W1_fixed ? W1_fixed : 4;
+    *W2 = 4;
+    for (uint32_t w1 = W1_fixed ? W1_fixed : 4; w1 <= (W1_fixed ? W1_fixed : 20); w1++)
+        for (uint32_t w2 = 4; w2 <= 20; w2++) {
+            const uint64_t bytes = table_bytes(n1, w1) + table_bytes(n2, w2);
+            if (bytes > budget && !(w1 == (W1_fixed ? W1_fixed : 4) && w2 == 4)) continue;
+            const double f = fb_nwin(w1) / a1 + fb_nwin(w2) / a2;
+            if (f < best - 1e-12 || (f < best + 1e-12 && bytes < best_bytes)) {
+                best = f;
+                best_bytes = bytes;
+                *W1 = w1;
+                *W2 = w2;
+            }
+        }
+}
+// (tests/test_abi_and_host.py: the choice is plain host logic)
+extern "C" void bpgpu_internal_window_pair(uint32_t n_gens_primary, uint32_t n_gens_secondary, uint64_t budget, uint32_t W1_fixed, uint32_t *W1, uint32_t *W2) {
+    pick_window_pair(n_gens_primary, n_gens_secondary, budget, W1_fixed, W1, W2);
+}
+
+// BulletproofGens::new(gens_capacity, party_capacity) serves every (n <= gens_capacity, m <= party_capacity) (generators.rs:157-259); the
+// window table that replaces the doublings is sized for the whole set, so a service that verifies m = 16 AND m = 1 proofs walked the
+// m = 1 ones through 16-bit windows (-9 %).  This adds a second table over the sub-set (n2, m2) and re-balances both windows under the
+// context's one budget (fixed_table_max_bytes).  Called again, it replaces the secondary shape.
+extern "C" int bpgpu_gens_add_shape(bpgpu_ctx *c, size_t n2, size_t m2) {
+    if (!c || n2 == 0 || m2 == 0) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    if (c->h_gens.empty()) return fail(c, BPGPU_ERR_NO_GENS, "generators not loaded");
+    if (n2 > c->gens_capacity || m2 > c->party_capacity) return fail(c, BPGPU_ERR_NO_GENS, "the secondary shape exceeds the generator set");
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    const uint32_t n1 = (uint32_t)(2 + 2 * c->gens_capacity * c->party_capacity), ng2 = (uint32_t)(2 + 2 * n2 * m2);
+    uint32_t W1 = 0, W2 = 0;
+    pick_window_pair(n1, ng2, c->table_budget, c->W, &W1, &W2);
+    release_secondary(c);
+    if (!c->d_table || c->prm.W != W1) {   // the primary table makes room (or was dropped by the pool before the re-balancing)
+        const int rc = build_tables(c, W1);
+        if (rc) return rc;
+    }
+    const size_t tot = c->gens_capacity * c->party_capacity;
+    std::vector<uint8_t> &h2 = c->sec.h_gens;
+    h2.assign((size_t)ng2 * 32, 0);
+    memcpy(&h2[0], &c->h_gens[0], 64);   // B~, B
+    for (size_t j = 0; j < m2; j++) {
+        memcpy(&h2[64 + j * n2 * 32], &c->h_gens[64 + j * c->gens_capacity * 32], n2 * 32);
+        memcpy(&h2[64 + (m2 * n2 + j * n2) * 32], &c->h_gens[64 + (tot + j * c->gens_capacity) * 32], n2 * 32);
+    }
+    HIPCHK(c, hipMalloc((void **)&c->sec.d_gens, h2.size()));
+    HIPCHK(c, hipMemcpy(c->sec.d_gens, h2.data(), h2.size(), hipMemcpyHostToDevice));
+    const int rc = build_table_set(c, h2, c->sec.d_gens, W2, c->table_budget, &c->sec.prm, &c->sec.ref, &c->sec.d_table);
+    if (rc) {
+        release_secondary(c);
+        return rc;
+    }
+    c->sec.n = n2;
+    c->sec.m = m2;
+    return BPGPU_OK;
+}
+// the pool re-balances a whole device: every lane lets go of its tables first, so that the old and the new pair never coexist in HBM
+extern "C" int bpgpu_internal_release_tables(bpgpu_ctx *c) {
+    if (!c) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(c, hipSetDevice(c->device));
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    HIPCHK(c, hipStreamSynchronize(c->stream2));
+    release_secondary(c);
+    release_table(c);
     return BPGPU_OK;
 }
 
@@ -706,6 +827,27 @@ static int gen_ids_for(bpgpu_ctx *c, size_t n, size_t m, uint32_t **out, bool g_
     HIPCHK(c, hipMalloc((void **)&d, ids.size() * 4));
     HIPCHK(c, hipMemcpy(d, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
     c->gen_ids_cache[key] = d;
+    *out = d;
+    return BPGPU_OK;
+}
+
+// the same list relative to the secondary table's compact layout [B~, B, G(n2, m2), H(n2, m2)]
+static int gen_ids_for_secondary(bpgpu_ctx *c, size_t n, size_t m, uint32_t **out) {
+    auto key = std::make_pair(n, m);
+    auto it = c->sec.ids_cache.find(key);
+    if (it != c->sec.ids_cache.end()) {
+        *out = it->second;
+        return BPGPU_OK;
+    }
+    std::vector<uint32_t> ids = {0, 1};
+    for (size_t j = 0; j < m; j++)
+        for (size_t i = 0; i < n; i++) ids.push_back((uint32_t)(2 + j * c->sec.n + i));
+    for (size_t j = 0; j < m; j++)
+        for (size_t i = 0; i < n; i++) ids.push_back((uint32_t)(2 + c->sec.n * c->sec.m + j * c->sec.n + i));
+    uint32_t *d = nullptr;
+    HIPCHK(c, hipMalloc((void **)&d, ids.size() * 4));
+    HIPCHK(c, hipMemcpy(d, ids.data(), ids.size() * 4, hipMemcpyHostToDevice));
+    c->sec.ids_cache[key] = d;
     *out = d;
     return BPGPU_OK;
 }
@@ -1384,12 +1526,22 @@ extern "C" int bpgpu_transcript_challenge_bytes(uint8_t state[BPGPU_TRANSCRIPT_B
     return BPGPU_OK;
 }
 
+// thread_rng() stand-in (verify_multiple, mod.rs:455-470) and the batch-combination weights: a per-thread ChaCha20 generator keyed and
+// re-keyed from the OS CSPRNG (hostrng.h) -- getrandom() itself for every chain's 64 bytes per proof was the serial host cost of the
+// batch-combined path once the pool issued it (one thread, 262 KB per 4096-proof chain)
 static int os_random(bpgpu_ctx *c, char *dst, size_t bytes) {
-    size_t got = 0;
-    while (got < bytes) {
-        const ssize_t r = getrandom(dst + got, bytes - got, 0);
-        if (r <= 0) return fail(c, BPGPU_ERR_HIP, "getrandom failed");
-        got += (size_t)r;
+    if (!bp::fast_random((uint8_t *)dst, bytes)) return fail(c, BPGPU_ERR_HIP, "getrandom failed");
+    return BPGPU_OK;
+}
+// combination weights: 128 random bits per proof, zero-extended to the 64-byte wide-reduction input (a forged batch passes with
+// probability 2^-128: Schwartz-Zippel over the weight space)
+static int os_random_weights(bpgpu_ctx *c, char *dst, size_t nproofs) {
+    memset(dst, 0, nproofs * 64);
+    uint8_t buf[4096];
+    for (size_t p0 = 0; p0 < nproofs; p0 += 256) {
+        const size_t cnt = nproofs - p0 < 256 ? nproofs - p0 : 256;
+        if (!bp::fast_random(buf, cnt * 16)) return fail(c, BPGPU_ERR_HIP, "getrandom failed");
+        for (size_t i = 0; i < cnt; i++) memcpy(dst + (p0 + i) * 64, buf + i * 16, 16);
     }
     return BPGPU_OK;
 }
@@ -1548,8 +1700,8 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         }
     }
     if (tr.shared_ts && !ts_state_ok(tr.shared_ts)) return fail(c, BPGPU_ERR_INVALID_ARG, "malformed transcript state");
-    if (h_segs && (all_verdict || rlc || tr.d_ts_in || tr.d_ts_out || tr.shared_ts))   // (the pool sends such items through the ordinary entry point)
-        return fail(c, BPGPU_ERR_INVALID_ARG, "coalesced launches take well-formed shapes, a label and per-proof verdicts only");
+    if (h_segs && (all_verdict || tr.d_ts_in || tr.d_ts_out || tr.shared_ts || (rlc && d_weights64)))   // (the pool sends such items through the ordinary entry point)
+        return fail(c, BPGPU_ERR_INVALID_ARG, "coalesced launches take well-formed shapes and a label only (batch-combined ones: library-drawn weights)");
     if (all_verdict) {   // every proof of the batch has the same malformed length
         if (tr.d_ts_out) {   // FormatError leaves the caller's transcript untouched
             if (tr.d_ts_in) HIPCHK(c, hipMemcpyAsync(tr.d_ts_out, tr.d_ts_in, nbatch * BPGPU_TRANSCRIPT_BYTES, hipMemcpyDeviceToDevice, s));
@@ -1588,14 +1740,17 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     sh.shape_verdict = shape_verdict;
     uint32_t lg_m = 0;
     while (((size_t)1 << lg_m) < m) lg_m++;
-    const fb_params prm = c->prm;
+    // which window table the generator terms walk: the secondary one when the shape fits it (bpgpu_gens_add_shape), else the primary
+    const bool use_sec = c->sec.d_table && !shape_verdict && n <= c->sec.n && m <= c->sec.m;
+    const fb_params prm = use_sec ? c->sec.prm : c->prm;
+    const fb_entry *const gen_table = use_sec ? c->sec.d_table : c->d_table;
     const uint32_t n_gen_terms = shape_verdict ? 2 : (uint32_t)(2 * n * m + 2);
     const uint32_t npairs = n_gen_terms * prm.nwin;
     const rp_fields fl = rp_field_layout(sh.k, sh.m);
     uint32_t *d_ids = nullptr;
     int rc;
     if (!shape_verdict) {
-        rc = gen_ids_for(c, n, m, &d_ids);
+        rc = use_sec ? gen_ids_for_secondary(c, n, m, &d_ids) : gen_ids_for(c, n, m, &d_ids);
         if (rc) return rc;
     }
     // which forms this chain takes (rp_chain_forms above: the decision table, with the measurements behind every line)
@@ -1669,7 +1824,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         char *h = nullptr;
         rc = pin_alloc(c, s, nbatch * 64, &h);
         if (rc) return rc;
-        rc = os_random(c, h, nbatch * 64);
+        rc = os_random_weights(c, h, nbatch);
         if (rc) return rc;
         HIPCHK(c, hipMemcpyAsync(a + off_wts, h, nbatch * 64, hipMemcpyHostToDevice, s));
         wts_ptr = (const uint8_t *)(a + off_wts);
@@ -1789,11 +1944,11 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         LAUNCH(c, s, "rlc_accum", k_rlc_accum_scalars, n_acc + n_sc, BP_BLOCK, n_acc, nt, bkp, tot32, bd.desc, bd.idx, bd.pts, bd.bsum, n_gen_terms,
                (const unsigned long long *)d_acc, d_dig1, prm, d_ctl);
         enqueue_bucket_reduce(c, s, bkp, bkp.nwin, bd);
-        LAUNCH(c, s, "rlc_stage4", k_rlc_stage4b, 1 + nsplit1, FB_BLOCK, bd.colq16, bd.hq, prm, nsplit1, npairs, d_ids, d_dig1, c->d_table, d_part1);
+        LAUNCH(c, s, "rlc_stage4", k_rlc_stage4b, 1 + nsplit1, FB_BLOCK, bd.colq16, bd.hq, prm, nsplit1, npairs, d_ids, d_dig1, gen_table, d_part1);
         if (d_batch_out)
-            LAUNCH(c, s, "rlc_finish", k_rlc_finish<true>, 1, 64, nsplit1, bd.hq, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)d_batch_out);
+            LAUNCH(c, s, "rlc_finish", k_rlc_finish<true>, 1, 64, nsplit1, bd.hq, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)d_batch_out, segtab);
         else
-            LAUNCH(c, s, "rlc_finish", k_rlc_finish<false>, 1, 64, nsplit1, bd.hq, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)nullptr);
+            LAUNCH(c, s, "rlc_finish", k_rlc_finish<false>, 1, 64, nsplit1, bd.hq, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)nullptr, segtab);
         HIPCHK(c, hipGetLastError());
         c->rp_status_dirty = false;
         return BPGPU_OK;
@@ -1830,11 +1985,11 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
             LAUNCH(c, s, "rlc_colsum", k_rlc_colsum_scalars, n_sc, BP_BLOCK, 0u, 0u, 0u, 1u, (const ge_ext *)cur, next, n_gen_terms,
                    (const unsigned long long *)d_acc, d_dig1, prm, d_ctl, rows);
         LAUNCH(c, s, "rlc_stage4", k_rp_stage4<64>, 1 + nsplit1, FB_BLOCK, 1u, d_ctl + 2, cur, (const ge_cached *)nullptr, d_hq1, prm, 1u, 1u,
-               nsplit1, npairs, d_ids, d_dig1, c->d_table, d_part1);
+               nsplit1, npairs, d_ids, d_dig1, gen_table, d_part1);
         if (d_batch_out)
-            LAUNCH(c, s, "rlc_finish", k_rlc_finish<true>, 1, 64, nsplit1, d_hq1, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)d_batch_out);
+            LAUNCH(c, s, "rlc_finish", k_rlc_finish<true>, 1, 64, nsplit1, d_hq1, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)d_batch_out, segtab);
         else
-            LAUNCH(c, s, "rlc_finish", k_rlc_finish<false>, 1, 64, nsplit1, d_hq1, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)nullptr);
+            LAUNCH(c, s, "rlc_finish", k_rlc_finish<false>, 1, 64, nsplit1, d_hq1, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)nullptr, segtab);
         HIPCHK(c, hipGetLastError());
         c->rp_status_dirty = false;
         return BPGPU_OK;
@@ -1881,19 +2036,19 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const uint32_t nblk_p = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
     if (horner_aside) {
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<4>, nblk_p * nsplit, FB_BLOCK, 0u, d.chunk_first, d.part, d_colc, d.hq, prm, nb32, nblk_p,
-               nsplit, npairs, d_ids, d_digits, c->d_table, d_partial);
+               nsplit, npairs, d_ids, d_digits, gen_table, d_partial);
         HIPCHK(c, hipStreamWaitEvent(s, c->join_ev, 0));
     } else if (quad && one_lane) {
         const uint32_t n_hw = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<1>, n_hw + nblk_p * nsplit, FB_BLOCK, n_hw, d.chunk_first, d.part, d_colc, d.hq, prm, nb32, nblk_p,
-               nsplit, npairs, d_ids, d_digits, c->d_table, d_partial);
+               nsplit, npairs, d_ids, d_digits, gen_table, d_partial);
     } else if (quad) {
         const uint32_t n_hw = (nb32 + 15) / 16;
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<4>, n_hw + nblk_p * nsplit, FB_BLOCK, n_hw, d.chunk_first, d.part, d_colc, d.hq, prm, nb32, nblk_p,
-               nsplit, npairs, d_ids, d_digits, c->d_table, d_partial);
+               nsplit, npairs, d_ids, d_digits, gen_table, d_partial);
     } else {
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<64>, nb32 + nblk_p * nsplit, FB_BLOCK, nb32, d.chunk_first, d.part, (const ge_cached *)nullptr, d.hq,
-               prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, c->d_table, d_partial);
+               prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, gen_table, d_partial);
     }
     ge_ext *d_red = nullptr;
     uint32_t nred = 0;
@@ -1951,8 +2106,9 @@ void bpgpu_internal_set_busy_hint(bpgpu_ctx *c, int busy) {
     c->busy_hint = busy;
 }
 // one coalesced launch chain over the concatenation of `nseg` items, on the context's own stream (asynchronous)
+// rlc: ONE batch-combined check over all items (bpgpu_pool_rangeproof_submit_rlc_dev); any_msm then means "some item wants the 33-byte result"
 int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, const uint8_t *label, size_t label_len, const rp_seg *segs,
-                                  uint32_t nseg, bool any_msm, uint32_t splits_hint, int busy) {
+                                  uint32_t nseg, bool any_msm, uint32_t splits_hint, int busy, bool rlc) {
     if (!c || !segs || nseg == 0) return BPGPU_ERR_INVALID_ARG;
     const size_t total = (size_t)segs[nseg - 1].first + segs[nseg - 1].count;
     bool any_rng_missing = false;
@@ -1969,7 +2125,7 @@ int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof
     c->busy_hint = busy;
     // d_rng64: a non-null dummy keeps the library from drawing randomness nobody reads (every item brought its own)
     rc = rp_verify_dev_locked(c, n, m, total, nullptr, proof_len, nullptr, tr, any_rng_missing ? nullptr : (const void *)segs[0].rng64, nullptr,
-                              any_msm ? (void *)segs : nullptr, s, false, nullptr, nullptr, segs, nseg, true);
+                              (any_msm && !rlc) ? (void *)segs : nullptr, s, rlc, nullptr, (any_msm && rlc) ? (void *)segs : nullptr, segs, nseg, true);
     c->splits_hint = 0;
     c->busy_hint = -1;
     const int rc2 = ctx_leave(c, s);

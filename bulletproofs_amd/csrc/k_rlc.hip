@@ -138,7 +138,9 @@ __global__ void __launch_bounds__(FB_BLOCK) k_rlc_stage4b(const uint32_t *colq16
 // otherwise.  Status words are handed back zeroed.
 template <bool WITH_OUT>
 __global__ void __launch_bounds__(64) k_rlc_finish(uint32_t nsplit, const ge_ext *hq, const ge_ext *partial, uint32_t nproofs, uint32_t *status,
-                                                    uint8_t *verdict, uint8_t *batch_out) {
+                                                    uint8_t *verdict, uint8_t *batch_out, rp_seg_tab segs) {
+    // segs (bpgpu_pool_rangeproof_submit_rlc_dev: several submitted batches combined by ONE check): every proof's verdict goes to its own
+    // batch's buffer, and every batch that asked for it (rp_seg::msm_out doubles as its 33-byte batch_out) gets the chain's result
     __shared__ ge_ext xch[64];
     __shared__ uint32_t res[9];
     const uint32_t lane = threadIdx.x;
@@ -178,11 +180,31 @@ __global__ void __launch_bounds__(64) k_rlc_finish(uint32_t nsplit, const ge_ext
     __syncthreads();
     const uint8_t bv = (uint8_t)res[8];
     for (uint32_t p = lane; p < nproofs; p += 64) {
-        verdict[p] = status[p] ? (uint8_t)status[p] : (bv ? (uint8_t)BP_VERDICT_UNDECIDED : (uint8_t)0);
+        const uint8_t v = status[p] ? (uint8_t)status[p] : (bv ? (uint8_t)BP_VERDICT_UNDECIDED : (uint8_t)0);
+        if (segs.n) {
+            const rp_seg sg = rp_seg_lookup(segs, p);
+            sg.verdict[p - sg.first] = v;
+        } else {
+            verdict[p] = v;
+        }
         status[p] = 0;
     }
-    if (WITH_OUT && lane < 33) batch_out[lane] = lane == 0 ? bv : (uint8_t)(res[(lane - 1) >> 2] >> (8 * ((lane - 1) & 3)));
+    if (WITH_OUT && lane < 33) {
+        const uint8_t b = lane == 0 ? bv : (uint8_t)(res[(lane - 1) >> 2] >> (8 * ((lane - 1) & 3)));
+        if (segs.n) {
+            if (segs.ext) {
+                for (uint32_t i = 0; i < segs.n; i++)
+                    if (segs.ext[i].msm_out) ((uint8_t *)segs.ext[i].msm_out)[lane] = b;
+            } else {
+#pragma unroll
+                for (uint32_t i = 0; i < RP_SEG_INLINE; i++)   // (static indices: the argument block is read with scalar loads)
+                    if (i < segs.n && segs.in[i].msm_out) ((uint8_t *)segs.in[i].msm_out)[lane] = b;
+            }
+        } else {
+            batch_out[lane] = b;
+        }
+    }
 }
 
-template __global__ void k_rlc_finish<true>(uint32_t, const ge_ext *, const ge_ext *, uint32_t, uint32_t *, uint8_t *, uint8_t *);
-template __global__ void k_rlc_finish<false>(uint32_t, const ge_ext *, const ge_ext *, uint32_t, uint32_t *, uint8_t *, uint8_t *);
+template __global__ void k_rlc_finish<true>(uint32_t, const ge_ext *, const ge_ext *, uint32_t, uint32_t *, uint8_t *, uint8_t *, rp_seg_tab);
+template __global__ void k_rlc_finish<false>(uint32_t, const ge_ext *, const ge_ext *, uint32_t, uint32_t *, uint8_t *, uint8_t *, rp_seg_tab);

@@ -56,7 +56,7 @@ __global__ void k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge
 __global__ void k_rlc_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, const uint32_t *status, unsigned long long *acc, int uniform);
 __global__ void k_rlc_colsum_scalars(uint32_t n_red, uint32_t nthreads, uint32_t rows_in, uint32_t group, const ge_ext *in, ge_ext *out, uint32_t n_rows, const unsigned long long *acc, fb_digit *digits, fb_params prm, uint32_t *ctl, uint32_t rows_out);
 template <bool WITH_OUT>
-__global__ void k_rlc_finish(uint32_t nsplit, const ge_ext *hq, const ge_ext *partial, uint32_t nproofs, uint32_t *status, uint8_t *verdict, uint8_t *batch_out);
+__global__ void k_rlc_finish(uint32_t nsplit, const ge_ext *hq, const ge_ext *partial, uint32_t nproofs, uint32_t *status, uint8_t *verdict, uint8_t *batch_out, rp_seg_tab segs);
 __global__ void k_rp_verdict(uint32_t n, uint32_t *status, const uint8_t *msm_verdict, uint8_t *out);
 __global__ void k_ipp_prepare(ipp_shape sh, rp_strobe_init init, const uint8_t *proofs, const uint8_t *Gf, const uint8_t *Hf, const uint8_t *P, const uint8_t *Q, const uint8_t *G, const uint8_t *H, uint32_t *scalars, uint32_t *points, uint32_t *status);
 __global__ void k_ipp_vs_front(ipp_shape sh, rp_strobe_init init, const uint8_t *proofs, const uint32_t *ts_in, uint32_t *u_sq, uint32_t *u_inv_sq, uint32_t *tab, uint32_t *ts_out, uint32_t *status);

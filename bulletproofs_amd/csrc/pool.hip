@@ -43,6 +43,7 @@
 #include <vector>
 
 #include "../../include/bpgpu.h"
+#include "hostrng.h"
 #include "rangeproof.h"
 
 using namespace bp;
@@ -57,9 +58,10 @@ bool bpgpu_internal_rp_coalescible(bpgpu_ctx *c, size_t n, size_t m, size_t proo
 bool bpgpu_internal_idle(bpgpu_ctx *c);
 void bpgpu_internal_set_busy_hint(bpgpu_ctx *c, int busy);
 int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, const uint8_t *label, size_t label_len, const rp_seg *segs,
-                                  uint32_t nseg, bool any_msm, uint32_t splits_hint, int busy);
+                                  uint32_t nseg, bool any_msm, uint32_t splits_hint, int busy, bool rlc);
 void *bpgpu_internal_stream(bpgpu_ctx *c);
 int bpgpu_internal_rp_reserve(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, size_t nbatch_max);
+extern "C" int bpgpu_internal_release_tables(bpgpu_ctx *c);
 int bpgpu_internal_rp_verify_chain(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len, const void *d_commitments,
                                    const uint8_t *shared_ts, const void *d_ts_in, void *d_ts_out, int ts_uniform, uint32_t pos, uint32_t pos_begin,
                                    uint32_t flags, const void *d_rng64, void *d_verdict, void *d_msm_out, uint32_t splits_hint, int busy);
@@ -123,57 +125,8 @@ inline uint64_t now_ns() {
 inline void futex_wait(std::atomic<uint32_t> *a, uint32_t expected) { syscall(SYS_futex, (uint32_t *)a, FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0); }
 inline void futex_wake_all(std::atomic<uint32_t> *a) { syscall(SYS_futex, (uint32_t *)a, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
 
-// ---- the batching challenge's randomness when the caller brings none ------------------------------------------------------
-// verify_multiple draws `c` from thread_rng() (src/range_proof/mod.rs:396, 455-470).  Here: one ChaCha20 generator per calling
-// thread, keyed from the OS CSPRNG, re-keyed from its own output after every request (fast key erasure) and from the OS every
-// 16 MiB -- a getrandom() system call per proof would cost more than staging the proof.
-struct chacha_rng {
-    uint32_t key[8];
-    uint64_t counter = 0, since_seed = ~0ull;
-};
-inline uint32_t rotl32(uint32_t x, int r) { return (x << r) | (x >> (32 - r)); }
-void chacha20_block(const uint32_t key[8], uint64_t counter, uint32_t out[16]) {
-    uint32_t in[16] = {0x61707865u, 0x3320646eu, 0x79622d32u, 0x6b206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
-                       (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
-    uint32_t x[16];
-    for (int i = 0; i < 16; i++) x[i] = in[i];
-#define BP_QR(a, b, c, d)                    \
-    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 16); \
-    x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 12); \
-    x[a] += x[b]; x[d] = rotl32(x[d] ^ x[a], 8);  \
-    x[c] += x[d]; x[b] = rotl32(x[b] ^ x[c], 7);
-    for (int r = 0; r < 10; r++) {
-        BP_QR(0, 4, 8, 12) BP_QR(1, 5, 9, 13) BP_QR(2, 6, 10, 14) BP_QR(3, 7, 11, 15)
-        BP_QR(0, 5, 10, 15) BP_QR(1, 6, 11, 12) BP_QR(2, 7, 8, 13) BP_QR(3, 4, 9, 14)
-    }
-#undef BP_QR
-    for (int i = 0; i < 16; i++) out[i] = x[i] + in[i];
-}
-bool fast_random(uint8_t *dst, size_t bytes) {
-    static thread_local chacha_rng g;
-    if (g.since_seed > (16ull << 20)) {
-        size_t got = 0;
-        while (got < 32) {
-            const ssize_t r = getrandom((char *)g.key + got, 32 - got, 0);
-            if (r <= 0) return false;
-            got += (size_t)r;
-        }
-        g.since_seed = 0;
-        g.counter = 0;
-    }
-    uint32_t blk[16];
-    while (bytes) {
-        chacha20_block(g.key, g.counter++, blk);
-        const size_t take = bytes < 64 ? bytes : 64;
-        memcpy(dst, blk, take);
-        dst += take;
-        bytes -= take;
-        g.since_seed += 64;
-    }
-    chacha20_block(g.key, g.counter++, blk);   // the next request runs under a key this one's output does not reveal
-    memcpy(g.key, blk, 32);
-    return true;
-}
+// (the batching challenge's randomness when the caller brings none: hostrng.h)
+using bp::fast_random;
 
 // A ticket is either a request of the combining queue (host pointers) or a submitted device-pointer batch
 enum { TK_COMBINE = 0x7c0b, TK_DEVICE = 0x7de0 };
@@ -200,7 +153,8 @@ struct dev_item {   // a submitted device-pointer batch waiting for the next flu
     std::string label;
     std::shared_ptr<ev_holder> ready;   // recorded on the producer's stream at submission: the chain waits for it (may be empty)
     dev_ticket *ticket = nullptr;       // may be null
-    bool same_shape(const dev_item &o) const { return n == o.n && m == o.m && proof_len == o.proof_len && label == o.label; }
+    bool rlc = false;                   // batch-combined check (bpgpu_pool_rangeproof_submit_rlc_dev): `msm` is then the item's 33-byte batch_out
+    bool same_shape(const dev_item &o) const { return n == o.n && m == o.m && proof_len == o.proof_len && rlc == o.rlc && label == o.label; }
 };
 
 // ---- combining queue ---------------------------------------------------------------------------------------------------
@@ -641,6 +595,27 @@ int bpgpu_pool_gens_load(bpgpu_pool *p, size_t gens_capacity, size_t party_capac
     }
     p->gens_epoch.fetch_add(1);
     return pool_spread_gens(p, gens_capacity, party_capacity);
+}
+
+// A second shape with a window table of its own (bpgpu_gens_add_shape) on every lane of every device: all lanes let go of their tables
+// first -- the old and the new pair of tables never coexist in HBM --, then the first lane of a device builds both and the others share.
+// Call it while the pool is idle (it waits for every lane's streams).
+int bpgpu_pool_gens_add_shape(bpgpu_pool *p, size_t n2, size_t m2) {
+    if (!p || n2 == 0 || m2 == 0) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(p->mu);
+    for (pool_dev *d : p->devs) {
+        const std::vector<bpgpu_ctx *> ctxs = all_ctxs(d);
+        for (bpgpu_ctx *c : ctxs) {
+            const int rc = bpgpu_internal_release_tables(c);
+            if (rc) return pfail(p, rc, "%s", bpgpu_last_error(c));
+        }
+        for (bpgpu_ctx *c : ctxs) {
+            const int rc = bpgpu_gens_add_shape(c, n2, m2);
+            if (rc) return pfail(p, rc, "%s", bpgpu_last_error(c));
+        }
+    }
+    p->gens_epoch.fetch_add(1);
+    return BPGPU_OK;
 }
 
 // ---- host pointers, synchronous ---------------------------------------------------------------------------------
@@ -1379,7 +1354,7 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
     // a burst that fits two chains takes two: with the one-lane Horner chains aside, 20 x 1024 from idle measured 5.6 / 5.6 / 5.8 M/s as four
     // chains of 5120 and 5.9 ... 6.2 / 5.7 ... 5.8 / 6.0 as two of 10240 on three boxes; 40 x 1024 prefers eight of 5120 (6.05 against 5.85 as
     // four of 10240), 8 x 1024 two of 4096 (4.7 against 4.3 ... 4.6 as one) -- profiles/r03/coalesce_sweep_after_horner_aside.txt
-    if (G > 2 && T <= p->pair_limit_proofs) G = 2;
+    if (G > 2 && T <= p->pair_limit_proofs) G = 2;   // (batch-combined bursts too: 20 x 1024 as two combinations 5.5 M/s, as four 3.9)
     if (one_chain) G = 1;   // a chain's worth has accumulated while the caller is still submitting: it goes out now, as it is
     if (G > d->lanes.size()) G = d->lanes.size();
     size_t per = (T + G - 1) / G;
@@ -1405,8 +1380,10 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
         if (!bpgpu_internal_rp_coalescible(c, head.n, head.m, head.proof_len)) {
             // malformed length / parameter error / missing generators: the ordinary entry point reports it proof by proof
             chain_waits_for(c, head);
-            const int rc = bpgpu_rangeproof_verify_batch_dev(c, head.n, head.m, head.nbatch, head.proofs, head.proof_len, head.coms,
-                                                             (const uint8_t *)head.label.data(), head.label.size(), head.rng, head.verdict, head.msm, nullptr);
+            const int rc = head.rlc ? bpgpu_rangeproof_verify_rlc_dev(c, head.n, head.m, head.nbatch, head.proofs, head.proof_len, head.coms,
+                                                                      (const uint8_t *)head.label.data(), head.label.size(), head.rng, nullptr, head.verdict, head.msm, nullptr)
+                                    : bpgpu_rangeproof_verify_batch_dev(c, head.n, head.m, head.nbatch, head.proofs, head.proof_len, head.coms,
+                                                                        (const uint8_t *)head.label.data(), head.label.size(), head.rng, head.verdict, head.msm, nullptr);
             chain_carried(head, head.nbatch, record_done(c, head.ticket != nullptr), rc, rc ? bpgpu_last_error(c) : "");
             if (rc) {
                 (void)hipMemsetAsync(head.verdict, BPGPU_VERDICT_UNDECIDED, head.nbatch, (hipStream_t)bpgpu_internal_stream(c));
@@ -1427,7 +1404,11 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
         while (i < items.size() && filled < per && items[i].same_shape(head)) {
             const dev_item &it = items[i];
             size_t take = it.nbatch - off;
-            if (take > per - filled) take = per - filled;
+            // a batch-combined item stays whole (its 33-byte result is the result of ONE chain): it opens the next chain rather than being cut,
+            // and may stretch a chain up to max_chain_proofs; only an item wider than that is cut (its batch_out is then the last chain's)
+            if (head.rlc && off == 0 && filled > 0 && take > per - filled) break;
+            const size_t room = (head.rlc && off == 0 && take <= p->max_chain_proofs) ? take : per - filled;
+            if (take > room) take = room;
             chain_waits_for(c, it);
             carried.push_back({i, take});
             any_ticket = any_ticket || it.ticket;
@@ -1449,7 +1430,7 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
             }
         }
         const int rc = bpgpu_internal_rp_verify_segs(c, head.n, head.m, head.proof_len, (const uint8_t *)head.label.data(), head.label.size(), segs.data(),
-                                                     (uint32_t)segs.size(), any_msm, hint, (was_idle && T <= p->latency_proofs) ? 0 : 1);
+                                                     (uint32_t)segs.size(), any_msm, head.rlc ? 0u : hint, (was_idle && T <= p->latency_proofs) ? 0 : 1, head.rlc);   // (the hint is for per-proof table walks: a combined chain walks ONE 1690-pair MSM, which wants all the workgroups it can get)
         {
             const std::shared_ptr<ev_holder> done = record_done(c, any_ticket);   // (also behind the memsets of a failed chain below: same stream)
             for (const auto &cr : carried) chain_carried(items[cr.first], cr.second, done, rc, rc ? bpgpu_last_error(c) : "");
@@ -1475,9 +1456,11 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
     return rc_all;
 }
 
-int bpgpu_pool_rangeproof_submit_dev_ex(bpgpu_pool *p, int dev_index, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
-                                        const void *d_commitments, const uint8_t *label, size_t label_len, const void *d_rng64, void *d_verdict,
-                                        void *d_msm_out, void *producer_stream, int have_producer, bpgpu_ticket **ticket) {
+}  // extern "C"
+
+static int submit_dev_common(bpgpu_pool *p, int dev_index, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len, const void *d_commitments,
+                             const uint8_t *label, size_t label_len, const void *d_rng64, void *d_verdict, void *d_msm_out, void *producer_stream,
+                             int have_producer, bpgpu_ticket **ticket, bool rlc) {
     if (ticket) *ticket = nullptr;
     if (!p || dev_index < 0 || dev_index >= (int)p->devs.size() || (label_len && !label)) return BPGPU_ERR_INVALID_ARG;
     if (nbatch == 0 && !ticket) return BPGPU_OK;
@@ -1498,6 +1481,7 @@ int bpgpu_pool_rangeproof_submit_dev_ex(bpgpu_pool *p, int dev_index, size_t n, 
     it.verdict = (uint8_t *)d_verdict;
     it.msm = (uint8_t *)d_msm_out;
     it.label.assign((const char *)label, label_len);
+    it.rlc = rlc;
     if (have_producer && nbatch) {   // the inputs are complete when the work queued on the producer's stream so far is: the chain will wait for exactly that
         (void)hipSetDevice(d->device);
         it.ready = std::make_shared<ev_holder>();
@@ -1518,6 +1502,22 @@ int bpgpu_pool_rangeproof_submit_dev_ex(bpgpu_pool *p, int dev_index, size_t n, 
     if (d->pending.size() >= limit) return flush_dev(p, d, false);
     if (p->auto_flush_proofs && d->pending_proofs >= p->auto_flush_proofs) return flush_dev(p, d, true);
     return BPGPU_OK;
+}
+
+extern "C" {
+
+int bpgpu_pool_rangeproof_submit_dev_ex(bpgpu_pool *p, int dev_index, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
+                                        const void *d_commitments, const uint8_t *label, size_t label_len, const void *d_rng64, void *d_verdict,
+                                        void *d_msm_out, void *producer_stream, int have_producer, bpgpu_ticket **ticket) {
+    return submit_dev_common(p, dev_index, n, m, nbatch, d_proofs, proof_len, d_commitments, label, label_len, d_rng64, d_verdict, d_msm_out, producer_stream,
+                             have_producer, ticket, false);
+}
+
+int bpgpu_pool_rangeproof_submit_rlc_dev(bpgpu_pool *p, int dev_index, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
+                                         const void *d_commitments, const uint8_t *label, size_t label_len, const void *d_rng64, void *d_verdict,
+                                         void *d_batch_out, void *producer_stream, int have_producer, bpgpu_ticket **ticket) {
+    return submit_dev_common(p, dev_index, n, m, nbatch, d_proofs, proof_len, d_commitments, label, label_len, d_rng64, d_verdict, d_batch_out, producer_stream,
+                             have_producer, ticket, true);
 }
 
 int bpgpu_pool_rangeproof_submit_dev(bpgpu_pool *p, int dev_index, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,

@@ -119,6 +119,16 @@ int bpgpu_gens_load(bpgpu_ctx *ctx, size_t gens_capacity, size_t party_capacity,
                     const uint8_t *G, const uint8_t *H, const uint8_t B[32], const uint8_t B_blinding[32]);
 /* read back the encodings (any pointer may be NULL) */
 int bpgpu_gens_export(bpgpu_ctx *ctx, uint8_t *G, uint8_t *H, uint8_t B[32], uint8_t B_blinding[32]);
+/* A service that verifies TWO shapes (say m = 16 and m = 1 proofs) on one generator set: BulletproofGens::new(gens_capacity,
+ * party_capacity) serves every n <= gens_capacity, m <= party_capacity (src/generators.rs:157-259), but the window table that replaces
+ * the doublings is sized for the whole set -- at (64, 16) that is W = 16, and m = 1 proofs walked it 9 % slower than through their own
+ * W = 20 table.  This adds a SECOND table over the sub-set (n2, m2) of the loaded generators and re-balances both windows under the
+ * context's one budget ("fixed_table_max_bytes"): the pair minimising nwin(W1) / nwin(W1 alone) + nwin(W2) / nwin(W2 alone) -- under
+ * 160 GiB, (64, 16) + (64, 1): W = 15 (73 GB) + W = 19 (61 GB).  Range proofs with n <= n2 and m <= m2 then walk the secondary table
+ * (results are the same group elements: bit-identical verdicts and encodings).  Options (get): "secondary_window_bits",
+ * "secondary_table_bytes", "secondary_shape_n" / "_m"; "fixed_window_bits" reports the re-balanced primary window.  Calling it again
+ * replaces the secondary shape; bpgpu_gens_create / _load drop it. */
+int bpgpu_gens_add_shape(bpgpu_ctx *ctx, size_t n2, size_t m2);
 
 /* ---- multiscalar multiplication ---------------------------------------------
  * bpgpu_msm_batch: nbatch independent calls of
@@ -466,6 +476,8 @@ bpgpu_ctx *bpgpu_pool_lane(bpgpu_pool *pool, int dev_index, int lane);
 int bpgpu_pool_gens_create(bpgpu_pool *pool, size_t gens_capacity, size_t party_capacity);
 int bpgpu_pool_gens_load(bpgpu_pool *pool, size_t gens_capacity, size_t party_capacity, const uint8_t *G, const uint8_t *H,
                          const uint8_t B[32], const uint8_t B_blinding[32]);
+/* bpgpu_gens_add_shape on every lane of every device (call it while the pool is idle) */
+int bpgpu_pool_gens_add_shape(bpgpu_pool *pool, size_t n2, size_t m2);
 /* arguments as bpgpu_rangeproof_verify_batch */
 int bpgpu_pool_rangeproof_verify(bpgpu_pool *pool, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len,
                                  const uint8_t *commitments, const uint8_t *label, size_t label_len, const uint8_t *rng64,
@@ -521,6 +533,17 @@ int bpgpu_pool_rangeproof_submit_dev_ex(bpgpu_pool *pool, int dev_index, size_t 
                                         const void *d_rng64, void *d_verdict, void *d_msm_out, void *producer_stream,
                                         int have_producer, bpgpu_ticket **ticket);
 int bpgpu_pool_ticket_stream_wait(bpgpu_pool *pool, bpgpu_ticket *ticket, void *consumer_stream);
+/* bpgpu_rangeproof_verify_rlc_dev through the pool (SURVEY 8f-3's ADDITIONAL batch-combined check, no counterpart in the crate): consecutive
+ * submitted batches of one shape are combined by ONE identity check per launch chain (~coalesce_proofs proofs: from 32 768 per-proof terms
+ * the bucket MSM) instead of one per batch -- a service with batches of 1 024 gets the rate of batches of 5 120.  Weights: drawn by the
+ * library per chain (OS CSPRNG).  d_verdict: per proof 0 / the front end's status / BPGPU_VERDICT_UNDECIDED when the CHAIN's combination is
+ * not the identity -- some proof of some batch of that chain fails; which one is for the caller to find by resubmitting the undecided
+ * batches through bpgpu_pool_rangeproof_submit_dev[_ex].  d_batch_out (optional, 33 bytes, 4-byte aligned): the verdict byte and the
+ * combined point of the chain that carried the batch.  producer_stream / have_producer / ticket as bpgpu_pool_rangeproof_submit_dev_ex. */
+int bpgpu_pool_rangeproof_submit_rlc_dev(bpgpu_pool *pool, int dev_index, size_t n, size_t m, size_t nbatch, const void *d_proofs,
+                                         size_t proof_len, const void *d_commitments, const uint8_t *label, size_t label_len,
+                                         const void *d_rng64, void *d_verdict, void *d_batch_out, void *producer_stream,
+                                         int have_producer, bpgpu_ticket **ticket);
 int bpgpu_pool_flush(bpgpu_pool *pool);   /* issue everything queued; returns without waiting */
 int bpgpu_pool_wait(bpgpu_pool *pool);    /* flush, then wait until every lane is idle */
 

@@ -162,3 +162,35 @@ def test_chain_form_decision_table():
     assert forms(100, split3=1, busy=1) == WIDE | WAVE
     # batch-combined calls / verdict-only shapes, and a caller on the context's second stream: never wide / aside
     assert forms(50000, other=1, busy=1) == 0 and forms(50000, s2=1, busy=1) == WIDE
+
+
+def test_window_pair_policy_for_two_shapes_under_one_budget():
+    """bpgpu_gens_add_shape's choice is plain host logic (pick_window_pair, bpgpu.hip): the pair of windows that minimises
+    nwin(W1) / nwin(W1 alone) + nwin(W2) / nwin(W2 alone) among those whose two tables fit the budget together."""
+    import ctypes as C
+    import bulletproofs_amd as bp
+    L = bp.lib()
+    L.bpgpu_internal_window_pair.argtypes = [C.c_uint32, C.c_uint32, C.c_uint64, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]
+    L.bpgpu_internal_window_pair.restype = None
+
+    def pair(s1, s2, budget, w1_fixed=0):
+        a, b = C.c_uint32(), C.c_uint32()
+        L.bpgpu_internal_window_pair(2 + 2 * s1[0] * s1[1], 2 + 2 * s2[0] * s2[1], budget, w1_fixed, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def tbytes(shape, W):
+        return (2 + 2 * shape[0] * shape[1]) * -(-255 // W) * (1 << (W - 1)) * 128
+
+    GiB = 1 << 30
+    # the service of VERDICT r03 #8: m = 16 and m = 1 proofs under the default 160 GiB -- alone they take W = 16 (138 GB) and W = 20 (113 GB)
+    assert pair((64, 16), (64, 1), 160 * GiB) == (15, 19)
+    nw = lambda W: -(-255 // W)
+    f = lambda w1, w2: nw(w1) / 16 + nw(w2) / 13                      # relative walk lengths against the alone-optima (16 and 13 windows)
+    fits = [(a, b) for a in range(4, 21) for b in range(4, 21) if tbytes((64, 16), a) + tbytes((64, 1), b) <= 160 * GiB]
+    assert (15, 19) in fits and all(f(15, 19) <= f(a, b) + 1e-12 for a, b in fits)
+    assert pair((64, 16), (64, 1), 250 * GiB) == (16, 20)            # room for both alone-optima
+    assert pair((64, 16), (64, 1), 160 * GiB, 16) == (16, 17)        # primary window pinned by the caller: the rest goes to the secondary
+    for budget in (8 * GiB, 96 * GiB, 160 * GiB):
+        for s1, s2 in (((64, 16), (64, 1)), ((64, 32), (64, 1)), ((64, 8), (32, 1))):
+            w1, w2 = pair(s1, s2, budget)
+            assert tbytes(s1, w1) + tbytes(s2, w2) <= budget

@@ -250,3 +250,78 @@ def test_device_pointer_variant_marks_undecided(ctx64x8, golden):
         assert d_v.cpu().tolist() == exp_verdict and d_o.cpu().tolist()[0] == exp_bad
         # and the context is left clean for the per-proof path
         assert ctx64x8.rangeproof_verify_batch(64, 1, pr * 2, len(pr), golden["vc_bytes"][:32] * 2, golden["label"], None) == bytes(2)
+
+
+def test_pool_combines_submitted_batches_into_one_check_per_chain(oracle):
+    """bpgpu_pool_rangeproof_submit_rlc_dev: batches of 300 / 1024 / 77 / 513 proofs (one of them with a tampered proof and a
+    FormatError proof) submitted to the pool are combined by ONE identity check per launch chain.  Clean chains: all verdicts 0, batch
+    verdict 0, combined point = identity; the chain that holds the failing proof: every accepted proof of the chain undecided, the rejected
+    one keeps its FormatError, batch verdict 1 and the combined point equals the one bpgpu_rangeproof_verify_rlc_dev returns for the
+    concatenation -- with the library-drawn weights that is checked through linearity: R = rho_f MegaCheck_f is NOT the identity and
+    differs between two runs (fresh weights), while verdicts are identical."""
+    import torch
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    fx = wl.load_fixture("cfg2_n64_m1")
+    dev = torch.device("cuda", 0)
+    pool = bp.Pool((0,), 8, fixed_window_bits=16, coalesce_proofs=2048)
+    pool.gens_create(64, 1)
+    sizes = [300, 1024, 77, 513, 1024, 1024]
+    total = sum(sizes)
+    proofs, coms = wl.tile_batch(fx, total, first=9)
+    pb = bytearray(proofs)
+    bad_at = 300 + 1024 + 5            # inside the third batch
+    pb[bad_at * fx.proof_len + 129] ^= 4
+    fmt_at = 300 + 1024 + 40
+    pb[fmt_at * fx.proof_len + 160:fmt_at * fx.proof_len + 192] = b"\xff" * 32
+    proofs = bytes(pb)
+    rng = hashlib.shake_256(b"pool-rlc").digest(64 * total)
+    to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_p, d_c, d_r = to_dev(proofs), to_dev(coms), to_dev(rng)
+    runs = []
+    for rep in range(2):
+        d_v = torch.full((total,), 255, dtype=torch.uint8, device=dev)
+        d_b = torch.full((len(sizes), 36), 255, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        pool.set_option("stat_reset", 1)
+        off = 0
+        tickets = []
+        for i, nb in enumerate(sizes):
+            tickets.append(pool.submit_rlc_dev(0, fx.n, fx.m, nb, d_p.data_ptr() + off * fx.proof_len, fx.proof_len, d_c.data_ptr() + off * 32, fx.label,
+                                               d_r.data_ptr() + off * 64, d_v.data_ptr() + off, d_b[i].data_ptr(), want_ticket=True))
+            off += nb
+        for t in tickets:
+            t.wait()
+        chains = pool.get_option("stat_chains")
+        assert chains < len(sizes)                               # batches were combined
+        runs.append((bytes(d_v.cpu().numpy()), d_b.cpu().numpy().copy()))
+    v, b = runs[0]
+    assert runs[1][0] == v                                       # verdicts do not depend on the weights
+    # which batches shared a chain with the failing proof?  every proof of those is undecided (5) except the FormatError one (2)
+    bounds = [sum(sizes[:i]) for i in range(len(sizes) + 1)]
+    und = [i for i in range(len(sizes)) if b[i][0] != 0]
+    assert 2 in und and len(und) < len(sizes)
+    for i in range(len(sizes)):
+        seg = v[bounds[i]:bounds[i + 1]]
+        if i in und:
+            exp = bytearray(b"\x05" * sizes[i])
+            if bounds[i] <= fmt_at < bounds[i + 1]:
+                exp[fmt_at - bounds[i]] = 2
+            assert seg == bytes(exp), i
+            assert bytes(b[i][1:33]) != bytes(32)                # the combination is not the identity ...
+            assert bytes(b[i][:33]) == bytes(b[und[0]][:33])     # ... and the same point for every batch of that chain
+            assert bytes(runs[1][1][i][1:33]) != bytes(b[i][1:33])   # fresh weights: another multiple of the failing proof's mega-check
+        else:
+            assert seg == bytes(sizes[i]) and bytes(b[i][:33]) == bytes(33), i
+    # the undecided batches through the per-proof path: the pool's verdicts == oracle
+    gens = oracle.Gens(64, 1)
+    for i in und:
+        lo, hi = bounds[i], bounds[i + 1]
+        d_v2 = torch.full((hi - lo,), 255, dtype=torch.uint8, device=dev)
+        pool.submit_dev(0, fx.n, fx.m, hi - lo, d_p.data_ptr() + lo * fx.proof_len, fx.proof_len, d_c.data_ptr() + lo * 32, fx.label, d_r.data_ptr() + lo * 64,
+                        d_v2.data_ptr())
+        pool.wait()
+        _, ev, _ = oracle.verify_batch(gens, proofs[lo * fx.proof_len:hi * fx.proof_len], coms[lo * 32:hi * 32], fx.m, fx.n, fx.label, rng[64 * lo:64 * hi],
+                                       threads=os.cpu_count() or 1)
+        assert bytes(d_v2.cpu().numpy()) == ev
+    pool.close()

@@ -188,6 +188,13 @@ template <> struct F<1> { typedef fe T; static __device__ __forceinline__ void m
     static __device__ __forceinline__ void sq(T &h, const T &a) { fe_mul_k75(h, a, a); }
     static __device__ __forceinline__ void add(T &h, const T &a, const T &b) { fe_add(h, a, b); fe_carry(h); }   // K75 cannot take lazy sums
     static __device__ __forceinline__ void sub(T &h, const T &a, const T &b) { fe_sub(h, a, b); } };
+// V3 = V1 with the discipline the engine could adopt: the FIRST operand may be lazy (3x reduced), the SECOND at most one lazy sum of two
+// reduced values (19 (g_e + g_o) < 2^32); fe_sq stays the engine's own 55-product squaring.  In the madd shape only Y3 = (D + C)(B + A) has
+// two lazy operands: ONE carry.
+template <> struct F<3> { typedef fe T; static __device__ __forceinline__ void mul(T &h, const T &a, const T &b) { fe_mul_k75(h, a, b); }
+    static __device__ __forceinline__ void sq(T &h, const T &a) { fe_sq(h, a); }
+    static __device__ __forceinline__ void add(T &h, const T &a, const T &b) { fe_add(h, a, b); }
+    static __device__ __forceinline__ void sub(T &h, const T &a, const T &b) { fe_sub(h, a, b); } };
 template <> struct F<2> { typedef fs T; static __device__ __forceinline__ void mul(T &h, const T &a, const T &b) { fs_mul(h, a, b); }
     static __device__ __forceinline__ void sq(T &h, const T &a) { fs_sq(h, a); } static __device__ __forceinline__ void add(T &h, const T &a, const T &b) { fs_add(h, a, b); }
     static __device__ __forceinline__ void sub(T &h, const T &a, const T &b) { fs_sub(h, a, b); } };
@@ -201,7 +208,13 @@ template <int V> __device__ __forceinline__ void madd_shape(typename F<V>::T &X,
     A::mul(c, Tt, t2d);
     A::add(d, Z, Z);
     A::sub(e, b, a); A::sub(f, d, c); A::add(g, d, c); A::add(h, b, a);
-    A::mul(X, e, f); A::mul(Y, g, h); A::mul(Z, f, g); A::mul(Tt, e, h);
+    if (V == 3) {   // second operands: f, e (carried by the subtraction), g (one lazy sum); h x g would have two lazy sums: carry h once
+        A::mul(X, e, f); A::mul(Z, g, f); A::mul(Tt, h, e);
+        fe_carry(*(fe *)&h);
+        A::mul(Y, g, h);
+    } else {
+        A::mul(X, e, f); A::mul(Y, g, h); A::mul(Z, f, g); A::mul(Tt, e, h);
+    }
 }
 
 template <int V, int OP> __global__ void __launch_bounds__(64) k_bench(const uint32_t *in, uint32_t *out, int iters) {
@@ -238,19 +251,19 @@ int main() {
     uint32_t h_in[4096];
     uint64_t s = 88172645463325252ull;
     for (int i = 0; i < 4096; i++) { s ^= s << 13; s ^= s >> 7; s ^= s << 17; h_in[i] = (uint32_t)(s >> 11); }
-    uint32_t *d_in, *d_o[3];
+    uint32_t *d_in, *d_o[4];
     const int max_threads = 256 * 4 * 4 * 64;
     hipMalloc(&d_in, sizeof h_in); hipMemcpy(d_in, h_in, sizeof h_in, hipMemcpyHostToDevice);
-    for (int v = 0; v < 3; v++) hipMalloc(&d_o[v], (size_t)max_threads * 32);
+    for (int v = 0; v < 4; v++) hipMalloc(&d_o[v], (size_t)max_threads * 32);
     // ---- correctness: each variant against V0, few iterations of every op
-    const char *vn[3] = {"V0 10x25.5 schoolbook (100 mad)", "V1 10x25.5 Karatsuba (76 mad)", "V2 8x32 saturated (64+8 mad+addc)"};
+    const char *vn[4] = {"V0 10x25.5 schoolbook (100 mad)", "V1 10x25.5 Karatsuba (76 mad)", "V2 8x32 saturated (64+8 mad+addc)", "V3 Karatsuba, engine discipline"};
     const char *on[3] = {"fe_mul", "fe_sq", "madd-shaped"};
     std::vector<uint32_t> r0(4096 * 8), r1(4096 * 8);
     bool all_ok = true;
-#define LAUNCH(V, OP, blocks, iters) hipLaunchKernelGGL((k_bench<V, OP>), dim3(blocks), dim3(64), 0, 0, d_in, d_o[V], iters)
-#define CHECK(OP) { LAUNCH(0, OP, 64, 5); LAUNCH(1, OP, 64, 5); LAUNCH(2, OP, 64, 5); hipDeviceSynchronize(); \
+#define LAUNCH(V, OP, blocks, iters) hipLaunchKernelGGL((k_bench<V, OP>), dim3(blocks), dim3(64), 0, 0, d_in, d_o[V & 3], iters)
+#define CHECK(OP) { LAUNCH(0, OP, 64, 5); LAUNCH(1, OP, 64, 5); LAUNCH(2, OP, 64, 5); LAUNCH(3, OP, 64, 5); hipDeviceSynchronize(); \
         hipMemcpy(r0.data(), d_o[0], 4096 * 32, hipMemcpyDeviceToHost); \
-        for (int v = 1; v < 3; v++) { hipMemcpy(r1.data(), d_o[v], 4096 * 32, hipMemcpyDeviceToHost); int bad = 0; for (size_t i = 0; i < r0.size(); i++) bad += r0[i] != r1[i]; \
+        for (int v = 1; v < 4; v++) { hipMemcpy(r1.data(), d_o[v], 4096 * 32, hipMemcpyDeviceToHost); int bad = 0; for (size_t i = 0; i < r0.size(); i++) bad += r0[i] != r1[i]; \
             printf("check %-12s %s vs V0: %s\n", on[OP], vn[v], bad ? "MISMATCH" : "identical"); all_ok = all_ok && !bad; } }
     CHECK(0) CHECK(1) CHECK(2)
     // ---- throughput
@@ -259,7 +272,7 @@ int main() {
         const int blocks = 256 * 4 * wps;   // one wavefront per block: wps blocks per SIMD
 #define RUN(V, OP) { double ms = time_ms([&] { LAUNCH(V, OP, blocks, iters[OP]); }); double ops = (double)blocks * 64 * iters[OP]; \
         printf("%-12s waves/SIMD=%d  %-36s %8.3f ms  %10.3e ops/s  %7.1f cycles per wave-op per SIMD\n", on[OP], wps, vn[V], ms, ops / (ms * 1e-3), 2.4e9 * 1024.0 * 64 / (ops / (ms * 1e-3))); }
-        RUN(0, 0) RUN(1, 0) RUN(2, 0) RUN(0, 1) RUN(1, 1) RUN(2, 1) RUN(0, 2) RUN(1, 2) RUN(2, 2)
+        RUN(0, 0) RUN(1, 0) RUN(2, 0) RUN(0, 1) RUN(1, 1) RUN(2, 1) RUN(0, 2) RUN(1, 2) RUN(2, 2) RUN(3, 2)
     }
     printf("%s\n", all_ok ? "all variants agree with V0" : "SOME VARIANT DISAGREES");
     return all_ok ? 0 : 1;
