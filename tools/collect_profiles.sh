@@ -22,6 +22,7 @@ pmc() {  # name, counter list (quoted), args...
   rocprofv3 --kernel-trace --pmc $ctr -d /tmp/pm_$name -o t --output-format csv -- "$@" > /tmp/pm_$name.log 2>&1
 }
 
+if [ -z "$ONLY_PMC" ]; then
 stats bench_default $B
 stats bench_steps20 $B --steps 20 --warmup 5
 stats bench_streams1 $B --direct --streams 1 --steps 256 --warmup 16
@@ -36,12 +37,16 @@ $REPO/tools/microbench_gather > $OUT/microbench_gather.txt 2>&1
 # the two bench lines as the driver runs them (not under the profiler)
 python $REPO/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err
 python $REPO/bench.py --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err
+fi
 
 # counters of the WIDE chain form (what the pool issues: >= 2048 proofs per launch chain -- one-lane Horner chain aside, window sums as
 # their own launch, A outside the window sums), one stream, no pool
-declare -A WIDE=( [cfg2]=5120 [cfg3]=2048 [cfg4]=2048 )
+# counters of the WIDE chain form, issued the way the pool issues it (>= 2048 proofs per launch chain, other chains assumed beside it: one-lane
+# Horner chain aside on the second stream, window sums as their own launch, A outside the window sums): K steps through a one-lane pool =
+# ONE coalesced chain per region; latency_proofs=0 tells the pool not to treat the lone chain as alone (it would take the latency forms)
+declare -A WSTEPS=( [cfg2]=5 [cfg3]=8 [cfg4]=4 )    # x batch 1024 / 256 / 512 = 5120 / 2048 / 2048 proofs per chain
 for cfg in cfg2 cfg3 cfg4; do
-  A="$B --direct --config $cfg --batch ${WIDE[$cfg]} --steps 6 --warmup 2 --streams 1 --opt horner_lanes=1"   # (a lone context of this width would pick the quad chain)
+  A="$B --config $cfg --steps ${WSTEPS[$cfg]} --warmup 0 --streams 1 --repeat 3 --opt latency_proofs=0,auto_flush_items=64"
   pmc ${cfg}_fetch FETCH_SIZE $A
   pmc ${cfg}_write WRITE_SIZE $A
   pmc ${cfg}_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" $A
@@ -50,9 +55,10 @@ pmc cfg5_fetch FETCH_SIZE python $REPO/bench.py --cfg5-only 1
 pmc cfg5_write WRITE_SIZE python $REPO/bench.py --cfg5-only 1
 pmc cfg5_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" python $REPO/bench.py --cfg5-only 1
 
+python $REPO/tools/isa_mix.py > /tmp/isa_mix.json
 python - <<PY
 import csv, collections, json, glob, re
-LABEL = {"vb_window_wide": "rp_stage3w", "vb_window_colc": "rp_stage3w", "rp_horner_wide": "rp_horner1"}   # kernel -> the library's launch label (bench.py's names)
+LABEL = {"vb_window_wide": "rp_stage3w", "vb_window_colc": "rp_stage3w", "rp_horner_wide": "rp_horner1", "rp_exponents": "rp_stage3"}   # kernel -> the library's launch label (bench.py's names)
 def short(name):
     n = name.split("(")[0].strip()
     n = re.sub(r"^void\s+", "", n)
@@ -67,9 +73,9 @@ def per_kernel(d, counter):
         k = short(r["Kernel_Name"])
         acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"])
     return {k: {"dispatches": v[0], "avg_per_dispatch": v[1] / v[0]} for k, v in acc.items()}
-for cfg, what, ppl in (("cfg2", "bench.py --direct --config cfg2 --batch 5120 --steps 6 --warmup 2 --streams 1 (one wide chain per step)", 5120),
-                  ("cfg3", "bench.py --direct --config cfg3 --batch 2048 --steps 6 --warmup 2 --streams 1 (one wide chain per step)", 2048),
-                  ("cfg4", "bench.py --direct --config cfg4 --batch 2048 --steps 6 --warmup 2 --streams 1 (one wide chain per step)", 2048),
+for cfg, what, ppl in (("cfg2", "bench.py --config cfg2 --steps 5 --warmup 0 --streams 1 --opt latency_proofs=0,auto_flush_items=64 (the pool's wide chain form: one coalesced chain of 5120 per region)", 5120),
+                  ("cfg3", "bench.py --config cfg3 --steps 8 --warmup 0 --streams 1 --opt latency_proofs=0,auto_flush_items=64 (one coalesced chain of 2048 per region)", 2048),
+                  ("cfg4", "bench.py --config cfg4 --steps 4 --warmup 0 --streams 1 --opt latency_proofs=0,auto_flush_items=64 (one coalesced chain of 2048 per region)", 2048),
                   ("cfg5", "bench.py --cfg5-only 1 (batches of 64 MSMs of 6179 terms)", 64)):
     rd, wr = per_kernel("/tmp/pm_%s_fetch" % cfg, "FETCH_SIZE"), per_kernel("/tmp/pm_%s_write" % cfg, "WRITE_SIZE")
     json.dump({"FETCH_SIZE": rd, "WRITE_SIZE": wr}, open("$OUT/pmc_fetch_write_raw_%s.json" % cfg, "w"), indent=1)
@@ -83,8 +89,22 @@ for cfg, what, ppl in (("cfg2", "bench.py --direct --config cfg2 --batch 5120 --
     json.dump(traffic, open("$OUT/pmc_traffic_%s.json" % cfg, "w"), indent=1)
     va = per_kernel("/tmp/pm_%s_valu" % cfg, "SQ_INSTS_VALU")
     work = {"_note": "SQ_INSTS_VALU per launch (wavefront-instructions), rocprofv3 --pmc pass of %s, tools/collect_profiles.sh; one chain = one launch of "
-            "each rp_* / finish8 kernel" % what, "_mad_u64_fraction": 0.58, "_proofs_per_launch": ppl}
+            "each rp_* / finish8 kernel.  _mad_u64_fraction: share of v_mad_u64_u32 among the VALU instructions of each kernel's SHIPPED machine code "
+            "(static count over the disassembly, tools/isa_mix.py), weighted by the kernels' SQ_INSTS_VALU" % what, "_proofs_per_launch": ppl}
     for k in va: work[k] = int(va[k]["avg_per_dispatch"])
+    mix = json.load(open("/tmp/isa_mix.json"))
+    per_k, num, den = {}, 0.0, 0.0
+    PREF = {"rp_stage1": "k_rp_stage1<true>", "rp_stage4": "k_rp_stage4<4>", "rp_stage3w": "k_vb_window_wide<false>", "rp_horner1": "k_rp_horner_wide<false>",
+            "finish8": "k_finish8<false>", "rp_stage3": "k_rp_exponents"}   # the variants a wide chain of the pool runs
+    for full, mv in mix.items():
+        lab = short(full)
+        if lab in work and (lab not in per_k or PREF.get(lab) == re.sub(r"^void\\s+", "", full)):
+            per_k[lab] = mv["fraction"]
+    per_k = {k: fr for k, fr in per_k.items() if k.startswith(("rp_", "finish", "fb_reduce", "vb_", "bk_", "rlc_"))}   # the chain's kernels, not the table construction
+    for k, fr in per_k.items():
+        num += fr * work[k]; den += work[k]
+    work["_mad_u64_fraction"] = round(num / den, 4) if den else 0.58
+    work["_mad_u64_fraction_per_kernel"] = per_k
     json.dump(work, open("$OUT/valu_work_%s.json" % cfg, "w"), indent=1)
     print(cfg, "HBM bytes/launch:", {k: v for k, v in sorted(traffic.items(), key=lambda kv: -kv[1] if isinstance(kv[1], int) else 0)[:8] if not k.startswith("_")})
 PY
