@@ -88,6 +88,7 @@ struct bpgpu_ctx {
     std::vector<uint32_t *> script_retired;
     uint64_t script_tick = 0;
     int split_stage1 = 0;                                           // experiment: point decoding as its own launch on the second stream, compiled for 1 / 2 / 3 wavefronts per SIMD
+    int fork_early = 0;                                             // wide chains with the Horner chains aside: the window sums go to the second stream too (rp_verify_dev_locked)
     int split_stage3 = -1;                                          // window sums and generator exponents as two launches: 1 yes, 0 no, -1 auto (chains of >= 2048 proofs)
     bool no_script = false;                                         // option "transcript_script" = 0: byte-wise replay everywhere (A/B)
     // device-resident work decomposition of the uniform (nbatch, terms-per-MSM) variable-base plans
@@ -142,7 +143,7 @@ struct bpgpu_ctx {
     // second stream for the generator-table half of a shared-generator MSM: it is independent of the per-MSM points'
     // half until the finish, so the two halves run side by side (fork after the status memset, join before the finish)
     hipStream_t stream2 = nullptr;
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr, exp_ev = nullptr, fork2_ev = nullptr;
     // result of a submitted (not yet collected) host-pointer call: where its outputs sit in the pinned buffer and where the
     // caller wants them (bpgpu_rangeproof_verify_batch_submit / bpgpu_ctx_collect)
     struct pending_result {
@@ -382,7 +383,9 @@ int bpgpu_ctx_create(int device, bpgpu_ctx **out) {
         hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->exp_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->fork2_ev, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return BPGPU_ERR_HIP;
     }
@@ -413,6 +416,8 @@ void bpgpu_ctx_destroy(bpgpu_ctx *c) {
     if (c->done_ev) hipEventDestroy(c->done_ev);
     if (c->fork_ev) hipEventDestroy(c->fork_ev);
     if (c->join_ev) hipEventDestroy(c->join_ev);
+    if (c->exp_ev) hipEventDestroy(c->exp_ev);
+    if (c->fork2_ev) hipEventDestroy(c->fork2_ev);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->rp_status) hipFree(c->rp_status);
     if (c->d_table_ct) hipFree(c->d_table_ct);
@@ -470,6 +475,11 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
     if (!strcmp(key, "split_stage1")) {
         if (value < 0 || value > 3) return fail(c, BPGPU_ERR_INVALID_ARG, "split_stage1 must be 0..3");
         c->split_stage1 = (int)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "fork_early")) {
+        if (value < 0 || value > 2) return fail(c, BPGPU_ERR_INVALID_ARG, "fork_early must be 0, 1 or 2");
+        c->fork_early = (int)value;
         return BPGPU_OK;
     }
     if (!strcmp(key, "split_stage3")) {
@@ -2000,22 +2010,39 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     bool horner_aside = false;
     if (wide) {
         const bool wide_sums = r5 || a_out;
+        // After launch 1 a chain has two INDEPENDENT branches: the proof's own points (window sums -> Horner chain) and the generator terms
+        // (exponents -> table walk); they meet in the finish.  With the Horner chains aside, the whole first branch goes to the second
+        // stream right behind launch 1 (option fork_early, default on) instead of only its last kernel: the critical path of a chain
+        // loses the window sums (stage1 + max(sums + Horner, exponents + walk) + finish instead of stage1 + sums + max(Horner, exponents +
+        // walk) + finish).
+        hipStream_t sw = (aside && c->fork_early == 1) ? c->stream2 : s;
+        const bool exp_aside = aside && c->fork_early == 2;   // the generator exponents beside the window sums (second stream), the walk right behind the sums
+        if (sw != s || exp_aside) {
+            HIPCHK(c, hipEventRecord(c->fork_ev, s));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->fork_ev, 0));
+        }
+        if (exp_aside) {
+            LAUNCH(c, c->stream2, "rp_stage3", k_rp_exponents, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
+            HIPCHK(c, hipEventRecord(c->exp_ev, c->stream2));
+        }
         if (r5) {
             const uint32_t nw5 = nb32 * BP_VB5_WINDOWS;
-            LAUNCH(c, s, "rp_stage3w", k_vb_window_wide<true>, (nw5 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nw5, sh.U, a_out ? 1u : 0u, d.tab, d.recoded, d_colc);
+            LAUNCH(c, sw, "rp_stage3w", k_vb_window_wide<true>, (nw5 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nw5, sh.U, a_out ? 1u : 0u, d.tab, d.recoded, d_colc);
         } else if (a_out) {
             const uint32_t nw4 = nb32 * BP_VB_WINDOWS;
-            LAUNCH(c, s, "rp_stage3w", k_vb_window_wide<false>, (nw4 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nw4, sh.U, 1u, d.tab, d.recoded, d_colc);
+            LAUNCH(c, sw, "rp_stage3w", k_vb_window_wide<false>, (nw4 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nw4, sh.U, 1u, d.tab, d.recoded, d_colc);
         } else {
-            LAUNCH(c, s, "rp_stage3w", k_vb_window_colc, n_win, BP_BLOCK, nwin, d.chunks, d.tab, d.recoded, d.part, (quad && one_chunk) ? d_colc : (ge_cached *)nullptr);
+            LAUNCH(c, sw, "rp_stage3w", k_vb_window_colc, n_win, BP_BLOCK, nwin, d.chunks, d.tab, d.recoded, d.part, (quad && one_chunk) ? d_colc : (ge_cached *)nullptr);
         }
         if (aside) {
             if (!one_chunk && !wide_sums) {
                 const uint32_t nc = nb32 * 64;
-                LAUNCH(c, s, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, (uint32_t *)nullptr, d_colc);
+                LAUNCH(c, sw, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, (uint32_t *)nullptr, d_colc);
             }
-            HIPCHK(c, hipEventRecord(c->fork_ev, s));
-            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->fork_ev, 0));
+            if (sw == s) {
+                HIPCHK(c, hipEventRecord(exp_aside ? c->fork2_ev : c->fork_ev, s));
+                HIPCHK(c, hipStreamWaitEvent(c->stream2, exp_aside ? c->fork2_ev : c->fork_ev, 0));
+            }
             const uint32_t n_hb = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
             const ge_cached *extra = a_out ? d.tab : (const ge_cached *)nullptr;
             if (r5) LAUNCH(c, c->stream2, "rp_horner1", k_rp_horner_wide<true>, n_hb, FB_BLOCK, nb32, d_colc, extra, 16u * sh.U, d.hq);
@@ -2024,7 +2051,8 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
             HIPCHK(c, hipEventRecord(c->join_ev, c->stream2));
             horner_aside = true;
         }
-        LAUNCH(c, s, "rp_stage3", k_rp_exponents, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
+        if (exp_aside) HIPCHK(c, hipStreamWaitEvent(s, c->exp_ev, 0));
+        else LAUNCH(c, s, "rp_stage3", k_rp_exponents, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
     } else {
         LAUNCH(c, s, "rp_stage3", k_rp_stage3, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part,
                (quad && one_chunk) ? d_colc : (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits, d_status);
