@@ -47,7 +47,7 @@ BP_HD bk_params bk_make(uint32_t c) {
     return p;
 }
 #define BK_RWORDS 9          // recoded scalar: < 2^264
-// Measured crossovers (MI355X, tools/msm_crossover.py, profiles/r02/msm_crossover.txt): a single MSM gains from the
+// Measured crossovers (MI355X, tools/archive/msm_crossover.py, profiles/r02/msm_crossover.txt): a single MSM gains from the
 // buckets from ~2000 terms (1.8x at 8192, 3.1x at 20 000, 6.6x at 65 536), a batch of 64 MSMs from ~1500 terms per MSM
 // (1.25x at 2081, 1.43x at 4096); below that the per-point 8-entry tables of msm_vb.h win (fewer, wider launches).
 #define BK_MIN_TERMS 1536     // terms per MSM from which the bucket path is taken (option "bucket_min_terms")

@@ -35,7 +35,7 @@ __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(RP_
         st.w = lds + threadIdx.x;
         st.stride = RP_BLOCK;
         if (p < sh.nproofs) {
-            // (BP_EXP_*: timing experiments only -- tools/stage1_breakdown.py builds variants with one role compiled out)
+            // (BP_EXP_*: timing experiments only -- tools/archive/stage1_breakdown.py builds variants with one role compiled out)
 #ifndef BP_EXP_NOTR
             if (SCRIPTED) rp_transcript_scripted(p, sh, init, st, rp_resolve(p, sh, proofs, commitments, rng64, segs), script, fields, status, ts_out, ts_in);
             else rp_transcript_thread(p, sh, init, st, rp_resolve(p, sh, proofs, commitments, rng64, segs), fields, status, ts_flags, ts_in, ts_out);

@@ -79,7 +79,7 @@ BP_HD void keccak_f1600_lanes(uint64_t a[25]) {
 }
 
 BP_HD void keccak_f1600(const kstate &s) {
-#ifdef BP_EXP_NOKECCAK   // timing experiments only (tools/stage1_breakdown.py)
+#ifdef BP_EXP_NOKECCAK   // timing experiments only (tools/archive/stage1_breakdown.py)
     ks_set32(s, 0, ks_get32(s, 0) + 1);
     return;
 #endif

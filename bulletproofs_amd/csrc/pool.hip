@@ -83,7 +83,7 @@ struct hwq_init {
 }  // namespace
 
 // How many streams' kernels overlap on this device right now?  Sixteen streams get one single-wavefront kernel each that spins
-// for ~150 us; with q hardware queues the batch takes ceil(16 / q) x 150 us.  (Used by bpgpu_pool_create when the library itself
+// for ~1 ms (long against the launch overhead of sixteen launches); with q hardware queues the batch takes ceil(16 / q) x 1 ms.  (Used by bpgpu_pool_create when the library itself
 // set GPU_MAX_HW_QUEUES at load time: the variable then says nothing about what the runtime read.)
 __global__ void k_pool_spin(uint64_t ticks, uint32_t *sink) {
     const uint64_t t0 = wall_clock64();
@@ -97,7 +97,7 @@ static int probe_hw_queues(int device) {
     hipStream_t st[NS];
     for (int i = 0; i < NS; i++)
         if (hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) return -1;
-    const uint64_t ticks = 15000;   // wall_clock64: 100 MHz
+    const uint64_t ticks = 100000;   // wall_clock64: 100 MHz -> 1 ms
     double best = 1e30;
     for (int rep = 0; rep < 3; rep++) {   // the first round also pays for loading the code object
         for (int i = 0; i < NS; i++) hipStreamSynchronize(st[i]);
@@ -109,7 +109,7 @@ static int probe_hw_queues(int device) {
     }
     for (int i = 0; i < NS; i++) hipStreamDestroy(st[i]);
     if (hipGetLastError() != hipSuccess) return -1;
-    const double rounds = best / 150.0;   // ~1 with >= 16 queues, ~2 with 8, ~4 with 4
+    const double rounds = best / 1000.0;   // ~1 with >= 16 queues, ~2 with 8, ~4 with 4
     int q = (int)(16.0 / (rounds < 1.0 ? 1.0 : rounds) + 0.5);
     return q < 1 ? 1 : q;
 }
@@ -353,7 +353,7 @@ int bpgpu_pool_create(const int *devices, int ndev, int lanes_per_device, bpgpu_
         // The variable reads 16 because THIS library set it when it was loaded -- which only counts if the runtime had not read it
         // before (a process that touched HIP first runs on the default 4 queues whatever the variable says now).  Ask the device.
         const int qs = probe_hw_queues(devices[0]);
-        if (qs > 0 && qs < 8) {
+        if (qs > 0 && qs < 6) {   // (4 queues -- the runtime's default -- measure 4 rounds; 8 queues 2; timing noise stays well inside)
             fprintf(stderr, "libbpgpu: GPU_MAX_HW_QUEUES was set by libbpgpu at load time, but HIP had been initialised before: kernels of only "
                             "~%d streams overlap.  Export GPU_MAX_HW_QUEUES=16 before the process's first HIP call.\n", qs);
             return BPGPU_ERR_HW_QUEUES;

@@ -200,7 +200,7 @@ int bpgpu_rangeproof_verify_batch_dev(bpgpu_ctx *ctx, size_t n, size_t m, size_t
  * staged (the caller may reuse its input buffers at once), the work is enqueued, the call returns.  `verdict` / `msm_out`
  * are filled by bpgpu_ctx_collect(ctx) -- or implicitly by the next call made on this context -- and must stay valid
  * until then.  One submitted call per context at a time.  A single thread cycling over ~32 contexts reaches the
- * throughput of one thread per context (tools/host_api_rate.py --pipelined). */
+ * throughput of one thread per context (tools/archive/host_api_rate.py --pipelined). */
 int bpgpu_rangeproof_verify_batch_submit(bpgpu_ctx *ctx, size_t n, size_t m, size_t nbatch,
                                          const uint8_t *proofs, size_t proof_len, const uint8_t *commitments,
                                          const uint8_t *label, size_t label_len, const uint8_t *rng64,
@@ -449,7 +449,7 @@ int bpgpu_ipp_verification_scalars(bpgpu_ctx *ctx, size_t n, size_t nbatch, cons
  * lanes need 8..16 hardware queues: export GPU_MAX_HW_QUEUES=16 before the process's FIRST HIP call (the ROCm runtime reads it
  * then).  libbpgpu sets the variable when it is loaded if it is unset -- which only helps when nothing initialised HIP earlier;
  * bpgpu_pool_create therefore returns BPGPU_ERR_HW_QUEUES when it finds another value, and, when the value is the library's own,
- * after timing sixteen spinning single-wavefront kernels on sixteen streams (< 1 ms) and finding fewer than 8 of them overlapping.
+ * after timing sixteen single-wavefront kernels that spin 1 ms each on sixteen streams (~3 ms in all, best of three) and finding fewer than 6 of them overlapping.
  * bpgpu_pool_last_error is per calling thread: what the last pool call OF THAT THREAD reported.
  * Options (bpgpu_pool_set_option): "coalesce_proofs", "max_chain_proofs" (default 16384), "pair_limit_proofs" (default 24576: a flush
  * of up to this many proofs is issued as at most two chains), "latency_proofs" (default 6144: a host call, or a flush on an idle device, of

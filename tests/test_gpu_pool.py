@@ -346,3 +346,30 @@ def test_submit_dev_ex_producer_stream_and_tickets_no_device_wide_sync(oracle, c
     for t in tickets:
         t.wait()                                                 # frees the tickets (everything is complete already)
     pool.close()
+
+
+def test_pool_create_asks_the_device_when_the_library_set_the_queue_variable_itself():
+    """GPU_MAX_HW_QUEUES is read by the ROCm runtime at the process's first HIP call.  Unset in the environment, libbpgpu sets it when it
+    is loaded -- which helps only if nothing initialised HIP earlier.  (a) library first: the pool gets its queues (the probe sees sixteen
+    spinning kernels overlap) and works; (b) HIP first (here: a hipMalloc through ctypes on libamdhip64 before libbpgpu is loaded): the
+    variable still reads 16 afterwards, but the runtime runs on its default 4 queues -- bpgpu_pool_create must say so
+    (BPGPU_ERR_HW_QUEUES = -6), not build 8 lanes that silently serialise."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ)
+    env.pop("GPU_MAX_HW_QUEUES", None)
+    prog = ("import ctypes as C, os, sys\n"
+            "hip_first = sys.argv[1] == '1'\n"
+            "if hip_first:\n"
+            "    h = C.CDLL('libamdhip64.so'); p = C.c_void_p(); assert h.hipMalloc(C.byref(p), 1024) == 0\n"
+            "L = C.CDLL(os.path.join(%r, 'bulletproofs_amd', 'csrc', 'libbpgpu.so'))\n"
+            "pool = C.c_void_p(); d = (C.c_int * 1)(0)\n"
+            "rc = L.bpgpu_pool_create(d, 1, 8, C.byref(pool))\n"
+            "g = C.CDLL(None).getenv; g.restype = C.c_char_p\n"
+            "print('rc', rc, (g(b'GPU_MAX_HW_QUEUES') or b'None').decode())\n" % root)
+    a = subprocess.run([sys.executable, "-c", prog, "0"], env=env, capture_output=True, text=True, timeout=300)
+    assert a.stdout.strip().endswith("rc 0 16"), (a.stdout, a.stderr[-400:])
+    b = subprocess.run([sys.executable, "-c", prog, "1"], env=env, capture_output=True, text=True, timeout=300)
+    assert b.stdout.strip().endswith("rc -6 16"), (b.stdout, b.stderr[-400:])
+    assert "HIP had been initialised before" in b.stderr

@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: interleaved A/B over (library build) x (option string) on the two bench forms.  LIBS="a b" OPTS="none k=v ..." tools/r04_ab_matrix.sh
+# GPU box: interleaved A/B over (library build) x (option string) on the two bench forms.  LIBS="a b" OPTS="none k=v ..." tools/ab_matrix.sh
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 cd $REPO
 export GPU_MAX_HW_QUEUES=16

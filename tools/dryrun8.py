@@ -3,7 +3,7 @@
 eight shards / eight ranks all mapped onto device 0 (tables at W = 16 so that eight of them fit), with the host CPU seconds each
 form burns -- the question being whether 8 pools' worth of host threads starve the caller under a 16-CPU cgroup -- and the
 N = 1 torchrun form next to the plain N = 1 bench (must agree within box spread).
-    python tools/r04_dryrun8.py   ->  JSON lines on stdout"""
+    python tools/dryrun8.py   ->  JSON lines on stdout"""
 import json
 import os
 import resource

@@ -1,7 +1,7 @@
 #!/bin/bash
 # GPU box: launch 1 (k_rp_stage1) before / after -- rates (interleaved A/B), the launch alone and under contention (rocprofv3 kernel
 # stats), and its counters (instruction cache, scratch / VMEM instructions, HBM bytes), one --pmc pass per counter set.
-#   tools/r04_stage1_ab.sh name1 name2 ...      (ab/<name>.so)
+#   tools/stage1_counters.sh name1 name2 ...      (ab/<name>.so)
 REPO=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$REPO/gpurun_out/r04/stage1_ab
 mkdir -p $OUT
