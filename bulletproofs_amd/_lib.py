@@ -29,7 +29,7 @@ EXPORTS = [
     "bpgpu_pool_rangeproof_verify", "bpgpu_pool_rangeproof_submit_dev", "bpgpu_pool_flush", "bpgpu_pool_wait",
     "bpgpu_pool_rangeproof_verify_ts", "bpgpu_pool_rangeproof_submit_ts", "bpgpu_pool_ticket_done", "bpgpu_pool_ticket_wait",
     "bpgpu_pool_rangeproof_submit_dev_ex", "bpgpu_pool_ticket_stream_wait", "bpgpu_pool_rangeproof_submit_rlc_dev",
-    "bpgpu_gens_add_shape", "bpgpu_pool_gens_add_shape",
+    "bpgpu_gens_add_shape", "bpgpu_pool_gens_add_shape", "bpgpu_pool_gather_dev",
 ]
 
 TRANSCRIPT_BYTES = 208
@@ -116,6 +116,7 @@ def lib():
     L.bpgpu_pool_rangeproof_submit_ts.argtypes = [vp, sz, sz, sz, u8p, sz, u8p, u8p, sz, u8p, u8p, u8p, u8p, C.POINTER(vp)]
     L.bpgpu_pool_rangeproof_submit_dev_ex.argtypes = [vp, i, sz, sz, sz, vp, sz, vp, u8p, sz, vp, vp, vp, vp, i, C.POINTER(vp)]
     L.bpgpu_pool_ticket_stream_wait.argtypes = [vp, vp, vp]
+    L.bpgpu_pool_gather_dev.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz), vp, vp]
     L.bpgpu_pool_rangeproof_submit_rlc_dev.argtypes = [vp, i, sz, sz, sz, vp, sz, vp, u8p, sz, vp, vp, vp, vp, i, C.POINTER(vp)]
     L.bpgpu_pool_ticket_done.argtypes = [vp, vp]
     L.bpgpu_pool_ticket_wait.argtypes = [vp, vp]
@@ -581,6 +582,12 @@ class Pool:
                                                                d_verdict, d_batch_out, producer_stream or None, 0 if producer_stream is None else 1,
                                                                C.byref(t) if want_ticket else None))
         return DevTicket(self, t) if want_ticket else None
+
+    def gather_dev(self, root, parts, sizes, d_dst, stream=None):
+        """bpgpu_pool_gather_dev: every shard's device-resident verdict bytes to one buffer on pool device `root` (raw device pointers as ints)"""
+        n = self.n_devices
+        assert len(parts) == len(sizes) == n
+        self._chk(self._L.bpgpu_pool_gather_dev(self.h, root, (C.c_void_p * n)(*parts), (C.c_size_t * n)(*sizes), d_dst, stream or None))
 
     def flush(self):
         self._chk(self._L.bpgpu_pool_flush(self.h))

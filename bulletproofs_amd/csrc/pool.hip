@@ -48,7 +48,7 @@
 
 using namespace bp;
 
-static inline uint64_t now_ns_early() {
+static inline uint64_t now_ns() {
     timespec ts;
     clock_gettime(CLOCK_MONOTONIC, &ts);
     return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
@@ -101,10 +101,10 @@ static int probe_hw_queues(int device) {
     double best = 1e30;
     for (int rep = 0; rep < 3; rep++) {   // the first round also pays for loading the code object
         for (int i = 0; i < NS; i++) hipStreamSynchronize(st[i]);
-        const uint64_t t0 = now_ns_early();
+        const uint64_t t0 = now_ns();
         for (int i = 0; i < NS; i++) hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, st[i], ticks, (uint32_t *)nullptr);
         for (int i = 0; i < NS; i++) hipStreamSynchronize(st[i]);
-        const double us = (double)(now_ns_early() - t0) / 1000.0;
+        const double us = (double)(now_ns() - t0) / 1000.0;
         if (us < best) best = us;
     }
     for (int i = 0; i < NS; i++) hipStreamDestroy(st[i]);
@@ -116,11 +116,6 @@ static int probe_hw_queues(int device) {
 
 namespace {
 
-inline uint64_t now_ns() {
-    timespec ts;
-    clock_gettime(CLOCK_MONOTONIC, &ts);
-    return (uint64_t)ts.tv_sec * 1000000000ull + (uint64_t)ts.tv_nsec;
-}
 // std::atomic<uint32_t> as a futex word (C++17: no atomic::wait yet)
 inline void futex_wait(std::atomic<uint32_t> *a, uint32_t expected) { syscall(SYS_futex, (uint32_t *)a, FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0); }
 inline void futex_wake_all(std::atomic<uint32_t> *a) { syscall(SYS_futex, (uint32_t *)a, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
@@ -178,7 +173,6 @@ struct comb_key {
 };
 
 struct comb_req;
-struct pool_dev;
 enum { CB_FREE = 0, CB_OPEN, CB_SEALED, CB_ISSUING, CB_ISSUED, CB_DONE };
 // One staging buffer + the lane that runs its chain.  Inputs [proofs | commitments | rng | transcripts in] and outputs
 // [verdicts | transcripts out | encodings] sit at the same offsets of a pinned host block and of a device block.
@@ -1525,6 +1519,40 @@ int bpgpu_pool_rangeproof_submit_dev(bpgpu_pool *p, int dev_index, size_t n, siz
                                      void *d_msm_out) {
     return bpgpu_pool_rangeproof_submit_dev_ex(p, dev_index, n, m, nbatch, d_proofs, proof_len, d_commitments, label, label_len, d_rng64, d_verdict, d_msm_out,
                                                nullptr, 0, nullptr);
+}
+
+// The "final identity-check gather" for callers that keep verdicts on the devices: every shard's verdict bytes to ONE device buffer,
+// over the peer links (xGMI on an MI355X node), ordered behind the shard's own work.  Proofs are independent units, nothing else ever
+// crosses devices.  `part[d]` (device memory on pool device d, `bytes[d]` bytes, may be 0) lands at d_dst + sum of the
+// sizes before it; d_dst lives on pool device `root`.  Asynchronous on `stream` (a hipStream_t of the root device; NULL = its default
+// stream); the copies wait for everything issued so far on their source device's lanes.
+int bpgpu_pool_gather_dev(bpgpu_pool *p, int root, const void *const *part, const size_t *bytes, void *d_dst, void *stream) {
+    if (!p || root < 0 || root >= (int)p->devs.size() || !part || !bytes || !d_dst) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> lk(p->mu);
+    pool_dev *rd = p->devs[root];
+    if (hipSetDevice(rd->device) != hipSuccess) return pfail(p, BPGPU_ERR_HIP, "hipSetDevice failed");
+    size_t off = 0;
+    for (size_t di = 0; di < p->devs.size(); di++) {
+        pool_dev *d = p->devs[di];
+        if (bytes[di] == 0) continue;
+        if (!part[di]) return pfail(p, BPGPU_ERR_INVALID_ARG, "part %zu is null", di);
+        // the gather stream waits for the lanes of the source device (an event per lane that has work in flight)
+        if (hipSetDevice(d->device) != hipSuccess) return pfail(p, BPGPU_ERR_HIP, "hipSetDevice failed");
+        for (bpgpu_ctx *c : d->lanes) {
+            hipEvent_t ev;
+            if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess) return pfail(p, BPGPU_ERR_HIP, "hipEventCreate failed");
+            hipError_t e = hipEventRecord(ev, (hipStream_t)bpgpu_internal_stream(c));
+            if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)stream, ev, 0);
+            hipEventDestroy(ev);   // (released by the runtime once the recorded work has completed)
+            if (e != hipSuccess) return pfail(p, BPGPU_ERR_HIP, "ordering the gather behind device %d failed: %s", d->device, hipGetErrorString(e));
+        }
+        if (hipSetDevice(rd->device) != hipSuccess) return pfail(p, BPGPU_ERR_HIP, "hipSetDevice failed");
+        const hipError_t e = d->device == rd->device ? hipMemcpyAsync((char *)d_dst + off, part[di], bytes[di], hipMemcpyDeviceToDevice, (hipStream_t)stream)
+                                                     : hipMemcpyPeerAsync((char *)d_dst + off, rd->device, part[di], d->device, bytes[di], (hipStream_t)stream);
+        if (e != hipSuccess) return pfail(p, BPGPU_ERR_HIP, "gather copy from device %d failed: %s", d->device, hipGetErrorString(e));
+        off += bytes[di];
+    }
+    return BPGPU_OK;
 }
 
 int bpgpu_pool_flush(bpgpu_pool *p) {

@@ -544,6 +544,12 @@ int bpgpu_pool_rangeproof_submit_rlc_dev(bpgpu_pool *pool, int dev_index, size_t
                                          size_t proof_len, const void *d_commitments, const uint8_t *label, size_t label_len,
                                          const void *d_rng64, void *d_verdict, void *d_batch_out, void *producer_stream,
                                          int have_producer, bpgpu_ticket **ticket);
+/* The final gather for callers that keep verdicts on the devices (north star: "... only for the final identity-check gather"): the
+ * verdict bytes of every shard -- part[d]: device memory on pool device d, bytes[d] bytes -- to ONE buffer d_dst on pool device `root`,
+ * shard after shard, by peer copies (xGMI between the GPUs of a node), ordered on the device behind everything the pool has issued on the
+ * source device so far (flush first).  Asynchronous on `stream` (hipStream_t of the root device, NULL = default stream).  Nothing else of
+ * a verification ever crosses devices: proofs are independent units (src/range_proof/mod.rs:455-470 verifies them one by one). */
+int bpgpu_pool_gather_dev(bpgpu_pool *pool, int root, const void *const *part, const size_t *bytes, void *d_dst, void *stream);
 int bpgpu_pool_flush(bpgpu_pool *pool);   /* issue everything queued; returns without waiting */
 int bpgpu_pool_wait(bpgpu_pool *pool);    /* flush, then wait until every lane is idle */
 

@@ -373,3 +373,39 @@ def test_pool_create_asks_the_device_when_the_library_set_the_queue_variable_its
     b = subprocess.run([sys.executable, "-c", prog, "1"], env=env, capture_output=True, text=True, timeout=300)
     assert b.stdout.strip().endswith("rc -6 16"), (b.stdout, b.stderr[-400:])
     assert "HIP had been initialised before" in b.stderr
+
+
+def test_device_resident_verdicts_gathered_on_one_device(oracle, cfg2):
+    """Three shards (the one GPU three times), device-resident batches submitted per shard, verdicts gathered into ONE device buffer on
+    shard 1 by bpgpu_pool_gather_dev -- no host copy of a verdict, no pool-wide wait: the gather stream is ordered behind the shards' lanes
+    on the device.  == oracle."""
+    import torch
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    fx = cfg2
+    dev = torch.device("cuda", 0)
+    pool = bp.Pool((0, 0, 0), 4, fixed_window_bits=16)
+    pool.gens_create(64, 1)
+    sizes = [700, 0, 1300]                       # a shard with nothing to do is skipped
+    total = sum(sizes)
+    proofs, coms = wl.tile_batch(fx, total, first=77)
+    proofs, coms, bad = _tamper(proofs, coms, fx.proof_len, fx.m, total, 8)
+    rng = hashlib.shake_256(b"gather").digest(64 * total)
+    to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    d_p, d_c, d_r = to_dev(proofs), to_dev(coms), to_dev(rng)
+    parts = [torch.full((max(s, 1),), 255, dtype=torch.uint8, device=dev) for s in sizes]
+    d_all = torch.full((total,), 254, dtype=torch.uint8, device=dev)
+    gs = torch.cuda.Stream(device=dev)
+    torch.cuda.synchronize()
+    off = 0
+    for di, nb in enumerate(sizes):
+        if nb:
+            pool.submit_dev(di, fx.n, fx.m, nb, d_p.data_ptr() + off * fx.proof_len, fx.proof_len, d_c.data_ptr() + off * 32, fx.label, d_r.data_ptr() + off * 64,
+                            parts[di].data_ptr())
+        off += nb
+    pool.flush()
+    pool.gather_dev(1, [t.data_ptr() for t in parts], sizes, d_all.data_ptr(), gs.cuda_stream)
+    gs.synchronize()
+    _, ev, _ = oracle.verify_batch(oracle.Gens(64, 1), proofs, coms, fx.m, fx.n, fx.label, rng, threads=os.cpu_count() or 1)
+    assert bytes(d_all.cpu().numpy()) == ev and sum(1 for v in ev if v) == len(bad)
+    pool.close()
