@@ -1916,7 +1916,11 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         else LAUNCH(c, c->stream2, "rp_points", k_rp_points<3>, n_pt, RP_BLOCK, sh, (const uint8_t *)d_proofs, (const uint8_t *)d_commitments, d.tab, d_status, bpts, segtab);
         HIPCHK(c, hipEventRecord(c->join_ev, c->stream2));
     }
-    if (d_script)
+    if (d_script && split1)   // the lane-serial role alone, uncapped (its decode role runs on the second stream)
+        LAUNCH(c, s, "rp_stage1", k_rp_transcript, n_tr, RP_BLOCK, sh, init, (const uint8_t *)d_proofs, (const uint8_t *)d_commitments, rng_ptr, d_fields, d_status, prm,
+               lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits, rlc ? wts_ptr : (const uint8_t *)nullptr, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
+               rlc_bucket ? bkp.c : 0u, segtab, d_script);
+    else if (d_script)
         LAUNCH(c, s, "rp_stage1", k_rp_stage1<true>, n_tr + (split1 ? 0u : n_pt), RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
            (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits,
            rlc ? wts_ptr : (const uint8_t *)nullptr, ts_flags, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
