@@ -194,3 +194,26 @@ def test_window_pair_policy_for_two_shapes_under_one_budget():
         for s1, s2 in (((64, 16), (64, 1)), ((64, 32), (64, 1)), ((64, 8), (32, 1))):
             w1, w2 = pair(s1, s2, budget)
             assert tbytes(s1, w1) + tbytes(s2, w2) <= budget
+
+
+def test_hot_path_kernels_use_no_scratch_memory_and_the_build_gate_knows_every_exception():
+    """Read from the shipped code objects (tools/kernel_resources.py): the kernels of a wide launch chain -- window sums, generator
+    exponents, table walk, Horner chains, partial-sum reduction, finish -- have no private segment and no spilled registers; every kernel
+    that does is on __graft_entry__.SCRATCH_ALLOW with ceilings it respects (build() fails otherwise); launch 1's scripted variant stays
+    at or below the figures this round reached (round 3: 1152 B / 346 spills / 926 KB of code)."""
+    import glob
+    import __graft_entry__ as ge
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import kernel_resources as kr
+    objs = sorted(glob.glob(os.path.join(ROOT, "bulletproofs_amd", "csrc", "build", "*.o")))
+    if not objs:
+        ge.build()
+        objs = sorted(glob.glob(os.path.join(ROOT, "bulletproofs_amd", "csrc", "build", "*.o")))
+    assert kr.check(objs, ge.SCRATCH_ALLOW) == []
+    ks = {k["name"]: k for o in objs for k in kr.kernels_of(o)}
+    for hot in ("void k_vb_window_wide<false>", "k_rp_exponents", "k_rp_stage3", "void k_rp_stage4<4>", "void k_rp_horner_wide<false>", "k_fb_reduce",
+                "void k_finish8<false>", "k_vb_window_colc", "void k_rp_stage4<64>"):
+        assert ks[hot]["scratch"] == 0 and ks[hot]["spill_vgpr"] == 0, hot
+    s1 = ks["void k_rp_stage1<true>"]
+    assert s1["scratch"] <= 360 and s1["spill_vgpr"] <= 118 and s1["code_bytes"] <= 320 * 1024
+    assert ks["k_rp_exponents"]["vgpr"] <= 168                     # three wavefronts per SIMD would fit (measured: two are better on bursts)
