@@ -842,7 +842,8 @@ def main():
             r4 = timed(b4, k4, 32 if long_run else 8, fence, 0)
             extra["rlc_batch4096"] = {"verifications_per_s": round(4096 * k4 / r4["elapsed"], 1), "steps": k4, "streams": b4.nstreams, "regions": len(r4["regions"]),
                                       "kernels_us": {k_: round(v_[1] / v_[0] * 1e3, 2) for k_, v_ in sorted(r4["kern"].items(), key=lambda kv: -kv[1][1])},
-                                      "note": "bpgpu_rangeproof_verify_rlc_dev on batches of 4096 cfg2 proofs (69632 per-proof terms per combination: bucket MSM)"}
+                                      "note": "bpgpu_pool_rangeproof_submit_rlc_dev on batches of 4096 cfg2 proofs, one combination per batch, weights drawn by the library "
+                                              "(69632 per-proof terms per combination: bucket MSM); `streams` = lanes of the pool"}
             b4.close()
         except Exception as e:
             extra["rlc_batch4096"] = {"error": str(e)}

@@ -113,6 +113,8 @@ struct bpgpu_ctx {
     uint32_t *rp_status = nullptr;
     size_t rp_status_cap = 0;
     bool rp_status_dirty = false;
+    bool test_seed_set = false;   // bpgpu_internal_set_chain_seed (tests): the per-chain key of the device-expanded randomness
+    uint8_t test_seed[32];
     // A context has ONE arena / status buffer / plan cache, so the work of consecutive calls must not overlap on the
     // device: every call records order_ev at its end, and a call that arrives on a different stream than its
     // predecessor makes its stream wait for that event first (ctx_enter / ctx_leave).
@@ -1536,26 +1538,12 @@ extern "C" int bpgpu_transcript_challenge_bytes(uint8_t state[BPGPU_TRANSCRIPT_B
     return BPGPU_OK;
 }
 
-// thread_rng() stand-in (verify_multiple, mod.rs:455-470) and the batch-combination weights: a per-thread ChaCha20 generator keyed and
-// re-keyed from the OS CSPRNG (hostrng.h) -- getrandom() itself for every chain's 64 bytes per proof was the serial host cost of the
-// batch-combined path once the pool issued it (one thread, 262 KB per 4096-proof chain)
+// thread_rng() stand-in of the provers and of everything else that needs host-side random bytes: a per-thread ChaCha20 generator
+// keyed and re-keyed from the OS CSPRNG (hostrng.h).  (The verification chains need 32 bytes each: rp_shape::seed.)
 static int os_random(bpgpu_ctx *c, char *dst, size_t bytes) {
     if (!bp::fast_random((uint8_t *)dst, bytes)) return fail(c, BPGPU_ERR_HIP, "getrandom failed");
     return BPGPU_OK;
 }
-// combination weights: 128 random bits per proof, zero-extended to the 64-byte wide-reduction input (a forged batch passes with
-// probability 2^-128: Schwartz-Zippel over the weight space)
-static int os_random_weights(bpgpu_ctx *c, char *dst, size_t nproofs) {
-    memset(dst, 0, nproofs * 64);
-    uint8_t buf[4096];
-    for (size_t p0 = 0; p0 < nproofs; p0 += 256) {
-        const size_t cnt = nproofs - p0 < 256 ? nproofs - p0 : 256;
-        if (!bp::fast_random(buf, cnt * 16)) return fail(c, BPGPU_ERR_HIP, "getrandom failed");
-        for (size_t i = 0; i < cnt; i++) memcpy(dst + (p0 + i) * 64, buf + i * 16, 16);
-    }
-    return BPGPU_OK;
-}
-
 // the caller's transcript, not yet domain-separated: the kernel applies rangeproof_domain_sep(n, m) per proof
 static void strobe_init_from_state(rp_strobe_init &init, const uint8_t *state) {
     memcpy(init.w, state, 200);
@@ -1679,6 +1667,16 @@ extern "C" uint32_t bpgpu_internal_chain_forms(int64_t horner_lanes, int64_t spl
                           combined_or_verdict_only != 0, on_second_stream != 0);
 }
 
+// (tests: pin the key the library would draw for a chain's device-expanded randomness, so that a call WITHOUT rng / weight buffers can be
+// compared with one that passes the expansion's bytes explicitly; key = nullptr: back to the generator)
+extern "C" int bpgpu_internal_set_chain_seed(bpgpu_ctx *c, const uint8_t *key32) {
+    if (!c) return BPGPU_ERR_INVALID_ARG;
+    std::lock_guard<std::mutex> g(c->mu);
+    c->test_seed_set = key32 != nullptr;
+    if (key32) memcpy(c->test_seed, key32, 32);
+    return BPGPU_OK;
+}
+
 static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len,
                                 const void *d_commitments, const rp_transcripts &tr, const void *d_rng64, void *d_verdict,
                                 void *d_msm_out, hipStream_t s, bool rlc = false, const void *d_weights64 = nullptr,
@@ -1787,13 +1785,11 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const size_t off_partial = ap.add((size_t)2 * nsplit * nbatch * sizeof(ge_ext) + 16);
     const size_t off_fields = ap.add((size_t)fl.count * nbatch * BP_RP_REC * 4 + 16);
     const size_t off_mv = ap.add(nbatch);
-    const size_t off_rng = ap.add(nbatch * 64);
     const size_t off_segs = (h_segs && nseg > RP_SEG_INLINE) ? ap.add((size_t)nseg * sizeof(rp_seg)) : 0;
     // batch-combination mode: weights, coefficient accumulators, the column-sum reduction tree, and a batch-of-one
     // table walk (digits, partial sums, result)
     const uint32_t nsplit1 = rlc ? pick_splits(c, 1, npairs) : 0;
     const size_t n_rows0 = shape_verdict ? 0 : nbatch * ((sh.U + BP_VB_CHUNK - 1) / BP_VB_CHUNK);
-    const size_t off_wts = rlc ? ap.add(nbatch * 64) : 0;
     const size_t off_acc = rlc ? ap.add((size_t)n_gen_terms * 10 * 8) : 0;
     const size_t off_tree = rlc ? ap.add((n_rows0 / 8 + 64) * 64 * sizeof(ge_ext)) : 0;
     const size_t off_dig1 = rlc ? ap.add((size_t)npairs * sizeof(fb_digit) + 16) : 0;
@@ -1819,25 +1815,16 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     ge_ext *d_partial = (ge_ext *)(a + off_partial);
     uint32_t *d_fields = (uint32_t *)(a + off_fields);
     uint8_t *d_mv = (uint8_t *)(a + off_mv);
+    // randomness the caller did not bring -- the batching challenge's rng bytes (thread_rng() in verify_multiple, mod.rs:455-470), the
+    // combination weights (unpredictable to the prover) -- is expanded inside launch 1 from ONE key per launch chain (rp_shape::seed,
+    // rangeproof.h): drawn here from the calling thread's generator (hostrng.h), carried in the kernel's argument block
     const uint8_t *rng_ptr = (const uint8_t *)d_rng64;
-    if (!rng_ptr) {   // thread_rng() stand-in: OS CSPRNG (verify_multiple, mod.rs:455-470), staged in pinned memory
-        char *h = nullptr;
-        rc = pin_alloc(c, s, nbatch * 64, &h);
-        if (rc) return rc;
-        rc = os_random(c, h, nbatch * 64);
-        if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(a + off_rng, h, nbatch * 64, hipMemcpyHostToDevice, s));
-        rng_ptr = (const uint8_t *)(a + off_rng);
-    }
     const uint8_t *wts_ptr = (const uint8_t *)d_weights64;
-    if (rlc && !wts_ptr) {   // the combination weights must be unpredictable to the prover: OS CSPRNG
-        char *h = nullptr;
-        rc = pin_alloc(c, s, nbatch * 64, &h);
-        if (rc) return rc;
-        rc = os_random_weights(c, h, nbatch);
-        if (rc) return rc;
-        HIPCHK(c, hipMemcpyAsync(a + off_wts, h, nbatch * 64, hipMemcpyHostToDevice, s));
-        wts_ptr = (const uint8_t *)(a + off_wts);
+    if (!rng_ptr) sh.seeded |= RP_SEED_RNG;
+    if (rlc && !wts_ptr) sh.seeded |= RP_SEED_WEIGHTS;
+    if (sh.seeded) {
+        if (c->test_seed_set) memcpy(sh.seed, c->test_seed, 32);
+        else if (!bp::fast_random((uint8_t *)sh.seed, 32)) return fail(c, BPGPU_ERR_HIP, "getrandom failed");
     }
     rp_seg_tab segtab;
     memset(&segtab, 0, sizeof segtab);

@@ -84,6 +84,11 @@ static inline uint32_t bk_host_atomic_add(uint32_t *p, uint32_t v) {
 // ever hold the digits 0, 1, 2 -- i.e. one bucket with half of all terms, a serial chain for one lane -- is as evenly
 // populated as the others, and (ii) equal or structured scalars (all ones, small values) no longer pile up in one
 // bucket per window.  K = 7 (c = 8: 7 l < 2^255 - 2^247) / 1024 (c = 12: 1024 l < 2^263), so r < 2^(c nwin).
+// LIMIT of (ii): l = 2^252 + delta with delta < 2^125, so k l only stirs bits 0 .. ~134 (k delta) and 252 .. (k): scalars that agree
+// in bits 135 .. 251 still share those windows' buckets.  Measured in round 4: the batch-combined check with 128-BIT weights (A's
+// coefficient is the bare weight) put 1/9 of all proofs into ONE bucket of window 11 -- the bucket-sum launch of a 4096-proof
+// combination went from 0.21 to 2.2 ms (profiles/r04/ab_rlc_r03_vs_r04.txt).  The library's own weights are therefore full-width
+// (expanded on the device from a per-chain key, rangeproof.h: rp_shape::seed); callers who pass weights should pass uniform ones.
 BP_HD void bk_recode(uint32_t r[BK_RWORDS], const uint32_t s[8], bk_params prm, uint32_t salt) {
     const uint32_t l[8] = BP_L_WORDS;
     const uint32_t h = (salt * 0x9E3779B1u) >> 12;

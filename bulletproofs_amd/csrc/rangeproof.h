@@ -19,6 +19,7 @@
 #include "sc25519.h"
 #include "scinv.h"
 #include "bucket.h"
+#include "chacha20.h"
 
 namespace bp {
 
@@ -36,7 +37,16 @@ struct rp_shape {
     uint32_t shape_verdict;        // != 0: only parse, then report this verdict (InvalidBitsize, ...)
     uint32_t radix5 = 0;           // 1: the per-proof points in signed radix 32 (16-entry tables, 51 windows, msm_vb.h); 0: radix 16
     uint32_t a_outside = 0;        // 1: A -- coefficient 1 -- is added after the Horner chain: no recoding, only 1A in its table (wide chains)
+    // per-proof randomness the caller did not bring is expanded ON THE DEVICE from one 32-byte key per launch chain (drawn on the host
+    // by the library's generator, hostrng.h): proof p's 64 bytes are block p of ChaCha20(key, nonce = domain) -- nothing per proof is
+    // drawn, staged or copied on the host (64 bytes per proof at 6 ... 10 M proofs/s would be a core's worth of ChaCha)
+    uint32_t seeded = 0;           // RP_SEED_RNG | RP_SEED_WEIGHTS
+    uint32_t seed[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
+enum { RP_SEED_RNG = 1,        // the batching challenge's rng bytes (mod.rs:396: thread_rng() in verify_multiple), where no buffer was given
+       RP_SEED_WEIGHTS = 2 };  // the combination weights of the batch-combined check, where the caller supplied none
+// proof p's 64 pseudo-random bytes of domain `dom` (16 words, wide-reduced by the callers)
+BP_HD void rp_seed_words(uint32_t w[16], const rp_shape &sh, uint32_t p, uint32_t dom) { chacha20_block(sh.seed, (uint64_t)p, dom, 0u, w); }
 
 // Merlin state after Transcript::new(label) + rangeproof_domain_sep(n, m), computed once on the host
 struct rp_strobe_init {
@@ -292,8 +302,12 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
     {
         uint32_t cw[16];
         const uint8_t *rs = in.rs;
-        load_words8(cw, rs);
-        load_words8(cw + 8, rs + 32);
+        if (rs) {
+            load_words8(cw, rs);
+            load_words8(cw + 8, rs + 32);
+        } else {
+            rp_seed_words(cw, sh, p, RP_SEED_RNG);
+        }
         sc_from_wide(c, cw);
     }
     rp_store(fields, B, RPF_Y, p, y);
@@ -414,8 +428,12 @@ BP_HD void rp_transcript_scripted(uint32_t p, rp_shape sh, const rp_strobe_init 
     {
         uint32_t cw[16];
         sc c;
-        load_words8(cw, in.rs);
-        load_words8(cw + 8, in.rs + 32);
+        if (in.rs) {
+            load_words8(cw, in.rs);
+            load_words8(cw + 8, in.rs + 32);
+        } else {
+            rp_seed_words(cw, sh, p, RP_SEED_RNG);
+        }
         sc_from_wide(c, cw);
         rp_store(fields, B, RPF_C, p, c);
     }
@@ -530,11 +548,15 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
     sc t0, t1;
     sc28 rho_m;
     const sc28 *rho = nullptr;
-    if (rho64) {
+    if (rho64 || (sh.seeded & RP_SEED_WEIGHTS)) {
         uint32_t w16[16];
-        const uint32_t *src = (const uint32_t *)(rho64 + 64 * (uint64_t)p);
+        if (rho64) {
+            const uint32_t *src = (const uint32_t *)(rho64 + 64 * (uint64_t)p);
 #pragma unroll
-        for (int i = 0; i < 16; i++) w16[i] = src[i];
+            for (int i = 0; i < 16; i++) w16[i] = src[i];
+        } else {
+            rp_seed_words(w16, sh, p, RP_SEED_WEIGHTS);
+        }
         sc r;
         sc_from_wide(r, w16);
         sc_to_mont28(rho_m, r);

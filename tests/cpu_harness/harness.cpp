@@ -344,14 +344,35 @@ void h_set_segments(uint32_t count, const uint32_t *sizes) { g_seg_sizes.assign(
 //   launch 4: finish8
 // weights64 != nullptr: the batch-combination pipeline (rlc.h) -- verdict_out as bpgpu_rangeproof_verify_rlc_dev,
 // msm_out = 33 bytes (batch verdict, encoding of the combined point)
+// device-expanded randomness (rp_shape::seed / seeded, rangeproof.h): when set, launch 1 derives the rng bytes and / or the combination
+// weights from this key instead of reading buffers
+static uint32_t g_seed_flags = 0;
+static uint8_t g_seed[32];
+void h_set_chain_seed(const uint8_t *key32, uint32_t flags) {
+    g_seed_flags = key32 ? flags : 0;
+    if (key32) memcpy(g_seed, key32, 32);
+}
+// block p of ChaCha20(key, nonce = domain): what the expansion yields for proof p (for the tests' explicit twin)
+void h_chain_seed_block(const uint8_t *key32, uint32_t p, uint32_t dom, uint8_t *out64) {
+    uint32_t k[8], w[16];
+    memcpy(k, key32, 32);
+    chacha20_block(k, (uint64_t)p, dom, 0u, w);
+    memcpy(out64, w, 64);
+}
 static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t party_capacity, const uint8_t *gens /*Bb,B,G..,H..*/,
                 uint32_t n, uint32_t m, uint32_t nbatch, const uint8_t *proofs, uint32_t proof_len, const uint8_t *commitments,
                 const uint8_t *label, uint32_t label_len, const uint8_t *rng64, uint8_t *verdict_out, uint8_t *msm_out,
-                const uint8_t *weights64) {
+                const uint8_t *weights64, bool rlc) {
     uint32_t k = 0; while ((1u << k) < n * m) k++;
     uint32_t lg_m = 0; while ((1u << lg_m) < m) lg_m++;
     rp_shape sh; sh.n = n; sh.m = m; sh.nm = n * m; sh.k = k; sh.U = 4 + 2 * k + m; sh.proof_len = proof_len; sh.nproofs = nbatch; sh.shape_verdict = 0;
-    const bool r5 = g_radix5 && !weights64, a_out = g_a_outside && !weights64;
+    const bool r5 = g_radix5 && !rlc, a_out = g_a_outside && !rlc;
+    if (g_seed_flags) {   // device-expanded randomness (rp_shape::seed): the buffers it replaces are withheld from launch 1
+        sh.seeded = g_seed_flags;
+        memcpy(sh.seed, g_seed, 32);
+        if (g_seed_flags & RP_SEED_RNG) rng64 = nullptr;
+        if (g_seed_flags & RP_SEED_WEIGHTS) weights64 = nullptr;
+    }
     sh.radix5 = r5 ? 1u : 0u;
     sh.a_outside = a_out ? 1u : 0u;
     if (proof_len != 32 * (9 + 2 * k)) return -1;
@@ -380,7 +401,7 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
     std::vector<std::vector<uint8_t>> seg_bufs;
     std::vector<std::vector<uint8_t>> seg_verdict;
     std::vector<std::vector<uint32_t>> seg_msm;
-    if (!g_seg_sizes.empty() && !weights64) {
+    if (!g_seg_sizes.empty() && !rlc) {
         uint32_t first = 0;
         for (size_t i = 0; i < g_seg_sizes.size() && first < nbatch; i++) {
             const uint32_t cnt = (i + 1 == g_seg_sizes.size() || first + g_seg_sizes[i] > nbatch) ? nbatch - first : g_seg_sizes[i];
@@ -392,8 +413,12 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
             sg.commitments = seg_bufs.back().data();
             if (i & 1) sg.rng64 = nullptr;
             else {
-                seg_bufs.emplace_back(rng64 + (size_t)first * 64, rng64 + (size_t)(first + cnt) * 64);
-                sg.rng64 = seg_bufs.back().data();
+                if (rng64) {
+                    seg_bufs.emplace_back(rng64 + (size_t)first * 64, rng64 + (size_t)(first + cnt) * 64);
+                    sg.rng64 = seg_bufs.back().data();
+                } else {
+                    sg.rng64 = nullptr;
+                }
             }
             seg_verdict.emplace_back(cnt, 0xee);
             seg_msm.emplace_back((size_t)cnt * 8, 0xeeeeeeeeu);
@@ -423,7 +448,7 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
     for (uint32_t t = 0; t < t0; t++) rp_points_thread(t, sh, rp_resolve(t / sh.U, sh, proofs_l1, coms_l1, nullptr, segtab), tab.data(), status.data());
     // launch 2
     std::vector<uint64_t> acc((size_t)n_gen_terms * 10, 0);
-    if (weights64) {
+    if (rlc) {
         for (uint32_t tid = 0; tid < (sh.nm / 4) * nbatch; tid++) {
             const uint32_t t4 = tid / nbatch, p = tid - t4 * nbatch;
             sc g[4], h[4]; uint64_t l[10];
@@ -456,7 +481,7 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
     const bool quad = g_horner_lanes != 64;
     const bool one_chunk = chunks.size() == nbatch;
     std::vector<ge_cached> colc((size_t)nbatch * 64 + 1);
-    if (weights64) {
+    if (rlc) {
         // window sums with rejected proofs skipped, then one column sum over all chunks of all proofs (tree as on
         // the device: 16-way while > 64 rows, then 8-way, the last <= 8 rows are added by the Horner wavefront)
         for (uint32_t tid = 0; tid < chunks.size() * 64; tid++)
@@ -545,13 +570,13 @@ int h_rp_verify(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t pa
                 uint32_t nbatch, const uint8_t *proofs, uint32_t proof_len, const uint8_t *commitments, const uint8_t *label,
                 uint32_t label_len, const uint8_t *rng64, uint8_t *verdict_out, uint8_t *msm_out) {
     return rp_verify_impl(W, nsplit, gens_capacity, party_capacity, gens, n, m, nbatch, proofs, proof_len, commitments, label, label_len, rng64,
-                          verdict_out, msm_out, nullptr);
+                          verdict_out, msm_out, nullptr, false);
 }
 int h_rp_verify_rlc(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, uint32_t party_capacity, const uint8_t *gens, uint32_t n, uint32_t m,
                     uint32_t nbatch, const uint8_t *proofs, uint32_t proof_len, const uint8_t *commitments, const uint8_t *label,
                     uint32_t label_len, const uint8_t *rng64, const uint8_t *weights64, uint8_t *verdict_out, uint8_t *batch_out) {
     return rp_verify_impl(W, nsplit, gens_capacity, party_capacity, gens, n, m, nbatch, proofs, proof_len, commitments, label, label_len, rng64,
-                          verdict_out, batch_out, weights64);
+                          verdict_out, batch_out, weights64, true);
 }
 // window recoding of one scalar: returns nwin, digits[win] = unsigned W-bit value (real digit + half)
 uint32_t h_fb_recode(uint32_t W, const uint8_t *scalar, uint32_t *digits_out) {

@@ -4,7 +4,9 @@ device arithmetic and pipeline logic without a GPU; the `-m gpu` tests then only
 the same code behaves identically when launched as kernels."""
 import ctypes as C
 import hashlib
+import os
 import random
+import sys
 
 import pytest
 
@@ -547,6 +549,63 @@ def test_batch_combination_pipeline_lane_by_lane(H, oracle, golden):
             else:
                 assert included == [True, True, False, False, True] and bo.raw[0] == 1 and enc != bytes(32)
                 assert list(vd.raw) == [5, 5, 2, 1, 5]
+
+
+def test_device_expanded_randomness_lane_by_lane(H, oracle, golden):
+    """rp_shape::seed (rangeproof.h): where the caller brings no rng bytes / no combination weights, launch 1 expands them from one
+    32-byte key per launch chain -- proof p's 64 bytes are block p of ChaCha20(key, nonce = domain).  (1) the block function shared by
+    host and device code (csrc/chacha20.h) against the oracle's restatement (pinned on RFC 8439 / rand_chacha in test_oracle.py);
+    (2) the per-proof pipeline without an rng buffer == the pipeline GIVEN those blocks, encodings and verdicts, contiguous and through
+    a segment table whose odd items have no rng of their own; (3) the batch-combined pipeline without a weight buffer == the one
+    given the weight blocks (the combined point of a failing batch depends on every weight)."""
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "py"))
+    from chacha_rng import chacha20_block
+    key = hashlib.shake_256(b"chain-seed").digest(32)
+    blk = C.create_string_buffer(64)
+    for p_, dom in ((0, 1), (1, 1), (5, 2), (2**32 - 1, 2), (70000, 1)):
+        H.h_chain_seed_block(key, p_, dom, blk)
+        assert blk.raw == chacha20_block(key, p_, dom)
+    label = golden["label"]
+    vc = golden["vc_bytes"]
+    case = [c for c in golden["cases"] if c["n"] == 8 and c["m"] == 2][0]
+    n, m = 8, 2
+    pr = bytes.fromhex(case["proof"])
+    bad = bytearray(pr)
+    bad[128] ^= 1
+    fmt = bytearray(pr)
+    fmt[128:160] = b"\xff" * 32
+    batch = [pr, bytes(bad), pr, bytes(fmt), pr, pr, bytes(bad)]
+    nb = len(batch)
+    proofs, coms = b"".join(batch), vc[:32 * m] * nb
+    gg = oracle.Gens(n, m)
+    G2, H2, B2, Bb2 = gg.export()
+    gens = Bb2 + B2 + G2 + H2
+    rng_x = b"".join(chacha20_block(key, p_, 1) for p_ in range(nb))
+    wts_x = b"".join(chacha20_block(key, p_, 2) for p_ in range(nb))
+    other = hashlib.shake_256(b"unused").digest(64 * nb)
+    # (2) per-proof pipeline
+    exp = [oracle.verify(gg, batch[b], coms[32 * m * b:32 * m * (b + 1)], n, label, rng_x[64 * b:64 * b + 64]) for b in range(nb)]
+    assert [e[0] for e in exp] == [0, 1, 0, 2, 0, 0, 1]
+    for sizes in ([], [2, 1, 3, 1], [1] * 7):
+        H.h_set_segments(len(sizes), (C.c_uint32 * max(len(sizes), 1))(*sizes))
+        H.h_set_chain_seed(key, 1)
+        vd, mo = C.create_string_buffer(nb), C.create_string_buffer(32 * nb)
+        assert H.h_rp_verify(4, 3, n, m, gens, n, m, nb, proofs, len(pr), coms, label, len(label), other, vd, mo) == 0
+        H.h_set_chain_seed(None, 0)
+        for b in range(nb):
+            assert vd.raw[b] == exp[b][0] and mo.raw[32 * b:32 * b + 32] == exp[b][1], (sizes, b)
+    H.h_set_segments(0, (C.c_uint32 * 1)(0))
+    # (3) batch-combined pipeline: weights from the key (rng given), then both from the key
+    vd0, bo0 = C.create_string_buffer(nb), C.create_string_buffer(33)
+    assert H.h_rp_verify_rlc(4, 3, n, m, gens, n, m, nb, proofs, len(pr), coms, label, len(label), rng_x, wts_x, vd0, bo0) == 0
+    included, enc = _rlc_expected(oracle, gg, n, m, label, proofs, len(pr), coms, rng_x, wts_x)
+    assert bo0.raw[0] == 1 and bo0.raw[1:33] == enc and enc != bytes(32) and list(vd0.raw) == [5, 5, 5, 2, 5, 5, 5]
+    for flags, rng_arg in ((2, rng_x), (3, other)):
+        H.h_set_chain_seed(key, flags)
+        vd, bo = C.create_string_buffer(nb), C.create_string_buffer(33)
+        assert H.h_rp_verify_rlc(4, 3, n, m, gens, n, m, nb, proofs, len(pr), coms, label, len(label), rng_arg, other, vd, bo) == 0
+        H.h_set_chain_seed(None, 0)
+        assert bo.raw == bo0.raw and vd.raw == vd0.raw, flags
 
 
 def _linear_cases(oracle, n, tag):

@@ -325,3 +325,44 @@ def test_pool_combines_submitted_batches_into_one_check_per_chain(oracle):
                                        threads=os.cpu_count() or 1)
         assert bytes(d_v2.cpu().numpy()) == ev
     pool.close()
+
+
+def test_randomness_the_caller_does_not_bring_is_one_key_per_chain_expanded_on_the_device(ctx64x8, golden):
+    """No rng buffer / no weight buffer: launch 1 derives proof p's 64 bytes as block p of ChaCha20(key, nonce = domain) from ONE
+    32-byte key per launch chain (rp_shape::seed; drawn by the library's generator -- pinned here through the test hook).  The results
+    must be those of the same call GIVEN these blocks: per-proof MSM encodings (they depend on the batching challenge c) and the
+    combined point of a failing batch (it depends on every weight); with the generator's own keys two calls differ."""
+    import bulletproofs_amd as bp
+    sys_path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "py")
+    import sys
+    sys.path.insert(0, sys_path)
+    from chacha_rng import chacha20_block
+    Lb = bp.lib()
+    Lb.bpgpu_internal_set_chain_seed.argtypes = [C.c_void_p, C.c_char_p]
+    Lb.bpgpu_internal_set_chain_seed.restype = C.c_int
+    label, vc = golden["label"], golden["vc_bytes"]
+    case = [c for c in golden["cases"] if c["n"] == 64 and c["m"] == 1][0]
+    n, m = 64, 1
+    pr = bytes.fromhex(case["proof"])
+    bad = bytearray(pr)
+    bad[128] ^= 1
+    for nb in (7, 300):
+        batch = [bytes(bad) if b % 5 == 3 else pr for b in range(nb)]
+        proofs, coms = b"".join(batch), vc[:32 * m] * nb
+        key = hashlib.shake_256(b"chain-key-%d" % nb).digest(32)
+        rng_x = b"".join(chacha20_block(key, p, 1) for p in range(nb))
+        wts_x = b"".join(chacha20_block(key, p, 2) for p in range(nb))
+        assert Lb.bpgpu_internal_set_chain_seed(ctx64x8.h, key) == 0
+        try:
+            v0, ok0, e0 = ctx64x8.rangeproof_verify_rlc(n, m, proofs, len(pr), coms, label)
+            v1, ok1, e1 = ctx64x8.rangeproof_verify_rlc(n, m, proofs, len(pr), coms, label, rng_x, None)
+            v2, ok2, e2 = ctx64x8.rangeproof_verify_rlc(n, m, proofs, len(pr), coms, label, rng_x, wts_x)
+            assert e0 == e1 == e2 and e0 != bytes(32) and not ok0 and v0 == v1 == v2 == bytes(1 if b % 5 == 3 else 0 for b in range(nb))
+            p0, m0 = ctx64x8.rangeproof_verify_batch(n, m, proofs, len(pr), coms, label, None, want_msm=True)
+            p1, m1 = ctx64x8.rangeproof_verify_batch(n, m, proofs, len(pr), coms, label, rng_x, want_msm=True)
+            assert p0 == p1 == v0 and m0 == m1 and any(m0[32 * b:32 * b + 32] != bytes(32) for b in range(nb))
+        finally:
+            assert Lb.bpgpu_internal_set_chain_seed(ctx64x8.h, None) == 0
+        _, _, ea = ctx64x8.rangeproof_verify_rlc(n, m, proofs, len(pr), coms, label)
+        _, _, eb = ctx64x8.rangeproof_verify_rlc(n, m, proofs, len(pr), coms, label)
+        assert ea != eb and ea != e0 and ea != bytes(32)
