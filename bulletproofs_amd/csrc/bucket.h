@@ -87,8 +87,9 @@ static inline uint32_t bk_host_atomic_add(uint32_t *p, uint32_t v) {
 // LIMIT of (ii): l = 2^252 + delta with delta < 2^125, so k l only stirs bits 0 .. ~134 (k delta) and 252 .. (k): scalars that agree
 // in bits 135 .. 251 still share those windows' buckets.  Measured in round 4: the batch-combined check with 128-BIT weights (A's
 // coefficient is the bare weight) put 1/9 of all proofs into ONE bucket of window 11 -- the bucket-sum launch of a 4096-proof
-// combination went from 0.21 to 2.2 ms (profiles/r04/ab_rlc_r03_vs_r04.txt).  The library's own weights are therefore full-width
-// (expanded on the device from a per-chain key, rangeproof.h: rp_shape::seed); callers who pass weights should pass uniform ones.
+// combination went from 0.21 to 2.2 ms (profiles/r04/ab_rlc_r03_vs_r04.txt).  Two consequences: the library's own weights are
+// full-width (expanded on the device from a per-chain key, rangeproof.h: rp_shape::seed), and crowded buckets no longer cost a serial
+// chain whatever the scalars are (stage 3b below: a lane's share is capped, the rest is summed 64 lanes at a time).
 BP_HD void bk_recode(uint32_t r[BK_RWORDS], const uint32_t s[8], bk_params prm, uint32_t salt) {
     const uint32_t l[8] = BP_L_WORDS;
     const uint32_t h = (salt * 0x9E3779B1u) >> 12;
@@ -277,37 +278,102 @@ BP_HD void bk_sort_publish(uint32_t lane, bk_params prm, const bk_lds &l, uint32
 }
 
 // ---- stage 3: lane = (workgroup id bw, rank r) ------------------------------------------------------------------
-BP_HD void bk_accum_thread(uint32_t bw, uint32_t r, bk_params prm, const bk_desc *desc, const uint32_t *idx_w, const fb_entry *pts, ge_ext *bsum) {
+// A lane adds its whole bucket as long as that is at most `lim` = 2 x the average population + 32 terms (bk_chain_lim; with uniform
+// digits no bucket comes near it: average 34 -> largest ~60).  Of a CROWDED bucket it adds the first lim - 32; the rest (>= 33 terms)
+// is added by the heavy pass below, 64 lanes at a time.  Without this, one crowded bucket is one lane's serial chain: equal or
+// structured scalars (bits 135 .. 251 are out of bk_recode's reach) turned a launch of 0.2 ms into one of 2.2 ms with 1/9 of the
+// terms in one bucket, and made an MSM of N equal scalars N serial additions.
+#define BK_HEAVY_SLACK 32u
+BP_HD uint32_t bk_chain_lim(size_t terms_per_msm, bk_params prm) {
+    const size_t l = 2 * ((terms_per_msm + prm.half - 1) / prm.half) + BK_HEAVY_SLACK;
+    return l > 0x7fffffffu ? 0x7fffffffu : (uint32_t)l;
+}
+BP_HD uint32_t bk_lane_share(uint32_t cnt, uint32_t lim) { return cnt <= lim ? cnt : lim - BK_HEAVY_SLACK; }
+// entries [i0, i0 + n * stride) step stride of descriptor d's list -> acc (identity when n == 0): software pipeline as before -- the
+// index of term i+2 and the point record of term i+1 are in flight while term i is added
+BP_HD void bk_sum_entries(ge_ext &acc, const bk_desc &d, uint32_t i0, uint32_t stride, uint32_t n, const uint32_t *idx_w, const fb_entry *pts) {
+    ge_identity(acc);
+    if (n == 0) return;
+    const uint32_t *e = idx_w + d.off + i0;
+    uint32_t e_cur = e[0];
+    uint32_t e_next = n > 1 ? e[stride] : 0u;
+    fb_line line_cur;
+    fb_load_line(line_cur, pts + (e_cur & 0x7fffffffu));
+    for (uint32_t i = 0; i < n; i++) {
+        fb_line line_next = line_cur;
+        uint32_t e_next2 = 0;
+        if (i + 1 < n) fb_load_line(line_next, pts + (e_next & 0x7fffffffu));
+        if (i + 2 < n) e_next2 = e[(uint64_t)(i + 2) * stride];
+        ge_niels nn;
+#pragma unroll
+        for (int q = 0; q < 10; q++) {
+            nn.ypx.v[q] = line_cur.w[q];
+            nn.ymx.v[q] = line_cur.w[10 + q];
+            nn.t2d.v[q] = line_cur.w[20 + q];
+        }
+        const bool neg = (e_cur >> 31) != 0;
+        if (i == 0) ge_from_niels(acc, nn, neg);
+        else ge_madd(acc, acc, nn, neg);
+        line_cur = line_next;
+        e_cur = e_next;
+        e_next = e_next2;
+    }
+}
+BP_HD void bk_accum_thread(uint32_t bw, uint32_t r, bk_params prm, const bk_desc *desc, const uint32_t *idx_w, const fb_entry *pts, ge_ext *bsum,
+                           uint32_t lim = 0x7fffffffu) {
     const bk_desc d = desc[(uint64_t)bw * prm.half + r];
     ge_ext acc;
-    ge_identity(acc);
-    if (d.cnt) {
-        // software pipeline: the index of term i+2 and the point record of term i+1 are in flight while term i is added
-        uint32_t e_cur = idx_w[d.off];
-        uint32_t e_next = d.cnt > 1 ? idx_w[d.off + 1] : 0u;
-        fb_line line_cur;
-        fb_load_line(line_cur, pts + (e_cur & 0x7fffffffu));
-        for (uint32_t i = 0; i < d.cnt; i++) {
-            fb_line line_next = line_cur;
-            uint32_t e_next2 = 0;
-            if (i + 1 < d.cnt) fb_load_line(line_next, pts + (e_next & 0x7fffffffu));
-            if (i + 2 < d.cnt) e_next2 = idx_w[d.off + i + 2];
-            ge_niels n;
-#pragma unroll
-            for (int q = 0; q < 10; q++) {
-                n.ypx.v[q] = line_cur.w[q];
-                n.ymx.v[q] = line_cur.w[10 + q];
-                n.t2d.v[q] = line_cur.w[20 + q];
-            }
-            const bool neg = (e_cur >> 31) != 0;
-            if (i == 0) ge_from_niels(acc, n, neg);
-            else ge_madd(acc, acc, n, neg);
-            line_cur = line_next;
-            e_cur = e_next;
-            e_next = e_next2;
+    bk_sum_entries(acc, d, 0, 1, bk_lane_share(d.cnt, lim), idx_w, pts);
+    bsum[(uint64_t)bw * prm.half + d.bucket] = acc;
+}
+
+// ---- stage 3b: the heavy pass, G wavefronts per (MSM, window): wavefront g owns the descriptor ranks r = g (mod G) ---------------
+// h0: clear the list counter.  h1: the 64 lanes scan the wavefront's ranks and list those with more than `lim` terms (usually
+// none: the launch is one read of the descriptors).  Then per listed bucket: h2: lane l sums entries share + l, share + l + 64,
+// ... into xch[l]; h3(step = 32 .. 1): xch[l] += xch[l + step]; h4: lane 0 adds xch[0] to the bucket's sum.  A listed bucket costs
+// rest / 64 + 7 additions in sequence, and fewer than half / (2 G) buckets can be listed per wavefront.
+BP_HD uint32_t bk_heavy_groups(bk_params prm) { return prm.c == 8 ? 2u : 16u; }
+#define BK_HEAVY_MAX 128   // >= half / G ranks per wavefront
+struct bk_heavy_lds {
+    uint32_t *n;      // [1]
+    uint32_t *list;   // [BK_HEAVY_MAX] ranks
+    ge_ext *xch;      // [64]
+};
+BP_HD void bk_heavy_h0(uint32_t lane, const bk_heavy_lds &l) {
+    if (lane == 0) l.n[0] = 0;
+}
+BP_HD void bk_heavy_h1(uint32_t lane, uint32_t bw, uint32_t g, bk_params prm, const bk_desc *desc, uint32_t lim, const bk_heavy_lds &l) {
+    const uint32_t G = bk_heavy_groups(prm);
+    for (uint32_t r = g + G * lane; r < prm.half; r += 64 * G) {
+        if (desc[(uint64_t)bw * prm.half + r].cnt > lim) {
+            const uint32_t pos = BK_ATOMIC_ADD(l.n, 1u);
+            l.list[pos] = r;
         }
     }
-    bsum[(uint64_t)bw * prm.half + d.bucket] = acc;
+}
+BP_HD void bk_heavy_h2(uint32_t lane, uint32_t bw, uint32_t i, bk_params prm, const bk_desc *desc, uint32_t lim, const uint32_t *idx_w, const fb_entry *pts,
+                       const bk_heavy_lds &l) {
+    const bk_desc d = desc[(uint64_t)bw * prm.half + l.list[i]];
+    const uint32_t share = bk_lane_share(d.cnt, lim), rest = d.cnt - share;
+    ge_ext acc;
+    bk_sum_entries(acc, d, share + lane, 64, lane < rest ? (rest - lane + 63) / 64 : 0u, idx_w, pts);
+    l.xch[lane] = acc;
+}
+BP_HD void bk_heavy_h3(uint32_t lane, uint32_t step, const bk_heavy_lds &l) {
+    if (lane < step) {
+        ge_ext a = l.xch[lane];
+        const ge_ext q = l.xch[lane + step];
+        ge_add(a, a, q);
+        l.xch[lane] = a;
+    }
+}
+BP_HD void bk_heavy_h4(uint32_t lane, uint32_t bw, uint32_t i, bk_params prm, const bk_desc *desc, const bk_heavy_lds &l, ge_ext *bsum) {
+    if (lane != 0) return;
+    const bk_desc d = desc[(uint64_t)bw * prm.half + l.list[i]];
+    ge_ext a = bsum[(uint64_t)bw * prm.half + d.bucket];
+    const ge_ext q = l.xch[0];
+    ge_add(a, a, q);
+    bsum[(uint64_t)bw * prm.half + d.bucket] = a;
 }
 
 // ---- stage 4: window sum = sum_j (j + 1) * B_j, j = bucket index, by a tree of running sums ------------------------

@@ -104,11 +104,41 @@ template __global__ void k_bk_sort_big<64>(int, uint32_t, bk_params, const uint3
 template __global__ void k_bk_sort_big<256>(int, uint32_t, bk_params, const uint32_t *, uint32_t, int, const uint32_t *, uint32_t *, bk_desc *, uint32_t *, uint32_t *, const uint32_t *, uint32_t);
 
 __global__ void __launch_bounds__(BP_BLOCK) k_bk_accum(uint32_t nthreads, bk_params prm, uint32_t total, const bk_desc *desc, const uint32_t *idx,
-                                                        const fb_entry *pts, ge_ext *bsum) {
+                                                        const fb_entry *pts, ge_ext *bsum, uint32_t lim) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
     if (tid >= nthreads) return;
     const uint32_t bw = tid / prm.half, r = tid - bw * prm.half, w = bw % prm.nwin;
-    bk_accum_thread(bw, r, prm, desc, idx + (uint64_t)w * total, pts, bsum);
+    bk_accum_thread(bw, r, prm, desc, idx + (uint64_t)w * total, pts, bsum, lim);
+}
+
+// what crowded buckets hold beyond the lanes' share (bucket.h, stage 3b): G wavefronts per (MSM, window), blockIdx.x = bw * G + g
+__global__ void __launch_bounds__(64) k_bk_heavy(bk_params prm, uint32_t total, const bk_desc *desc, const uint32_t *idx, const fb_entry *pts, ge_ext *bsum,
+                                                  uint32_t lim) {
+    __shared__ uint32_t s_n[1], s_list[BK_HEAVY_MAX];
+    __shared__ ge_ext s_xch[64];
+    const uint32_t G = bk_heavy_groups(prm), bw = blockIdx.x / G, g = blockIdx.x - bw * G, lane = threadIdx.x, w = bw % prm.nwin;
+    bk_heavy_lds l;
+    l.n = s_n;
+    l.list = s_list;
+    l.xch = s_xch;
+    bk_heavy_h0(lane, l);
+    __syncthreads();
+    bk_heavy_h1(lane, bw, g, prm, desc, lim, l);
+    __syncthreads();
+    const uint32_t n = s_n[0];
+    const uint32_t *idx_w = idx + (uint64_t)w * total;
+#pragma unroll 1
+    for (uint32_t i = 0; i < n; i++) {
+        bk_heavy_h2(lane, bw, i, prm, desc, lim, idx_w, pts, l);
+        __syncthreads();
+#pragma unroll 1
+        for (uint32_t step = 32; step >= 1; step >>= 1) {
+            bk_heavy_h3(lane, step, l);
+            __syncthreads();
+        }
+        bk_heavy_h4(lane, bw, i, prm, desc, l, bsum);
+        __syncthreads();
+    }
 }
 
 // bottom level of the running-sum tree: lane = (MSM, window, leaf)

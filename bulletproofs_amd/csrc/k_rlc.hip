@@ -108,12 +108,12 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rlc_colsum_scalars(uint32_t n_red,
 // multiplication over all proofs' weighted terms  ||  the combined generator coefficients (as above)
 __global__ void __launch_bounds__(BP_BLOCK) k_rlc_accum_scalars(uint32_t n_acc, uint32_t nthreads, bk_params bk, uint32_t total, const bk_desc *desc,
                                                                  const uint32_t *idx, const fb_entry *pts, ge_ext *bsum, uint32_t n_rows,
-                                                                 const unsigned long long *acc, fb_digit *digits, fb_params prm, uint32_t *ctl) {
+                                                                 const unsigned long long *acc, fb_digit *digits, fb_params prm, uint32_t *ctl, uint32_t lim) {
     if (blockIdx.x < n_acc) {
         const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
         if (tid >= nthreads) return;
         const uint32_t bw = tid / bk.half, r = tid - bw * bk.half;
-        bk_accum_thread(bw, r, bk, desc, idx + (uint64_t)bw * total, pts, bsum);   // one MSM: bw = window
+        bk_accum_thread(bw, r, bk, desc, idx + (uint64_t)bw * total, pts, bsum, lim);   // one MSM: bw = window
     } else {
         rlc_scalars_lane((blockIdx.x - n_acc) * BP_BLOCK + threadIdx.x, n_rows, acc, digits, prm, ctl, 0u);
     }

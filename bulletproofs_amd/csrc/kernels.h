@@ -69,7 +69,7 @@ __global__ void k_lin_prepare(lin_shape sh, rp_strobe_init init, const uint8_t *
 __global__ void k_from_uniform(uint32_t n, const uint32_t *uniform, uint32_t *out);
 
 // k_rlc.hip, bucket variant of the batch combination
-__global__ void k_rlc_accum_scalars(uint32_t n_acc, uint32_t nthreads, bk_params bk, uint32_t total, const bk_desc *desc, const uint32_t *idx, const fb_entry *pts, ge_ext *bsum, uint32_t n_rows, const unsigned long long *acc, fb_digit *digits, fb_params prm, uint32_t *ctl);
+__global__ void k_rlc_accum_scalars(uint32_t n_acc, uint32_t nthreads, bk_params bk, uint32_t total, const bk_desc *desc, const uint32_t *idx, const fb_entry *pts, ge_ext *bsum, uint32_t n_rows, const unsigned long long *acc, fb_digit *digits, fb_params prm, uint32_t *ctl, uint32_t lim);
 __global__ void k_rlc_stage4b(const uint32_t *colq16, ge_ext *hq, fb_params prm, uint32_t nsplit, uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial);
 // k_rpp.hip
 __global__ void k_rpp_commit1(uint32_t n_b, uint32_t nthreads, rpp_shape sh, const uint64_t *values, const uint8_t *blindings, const uint8_t *rng, uint32_t *gen_scalars, uint32_t *party, uint32_t *sL, uint32_t *sR);
@@ -92,7 +92,8 @@ template <int LANES>
 __global__ void k_bk_sort(bk_params prm, const uint32_t *msm_first, uint32_t total, int single, const uint32_t *rwords, uint32_t *idx, bk_desc *desc, const uint32_t *skip_status, uint32_t skip_div);
 template <int LANES>
 __global__ void k_bk_sort_big(int phase, uint32_t nsub, bk_params prm, const uint32_t *msm_first, uint32_t total, int single, const uint32_t *rwords, uint32_t *idx, bk_desc *desc, uint32_t *gcnt, uint32_t *gcur, const uint32_t *skip_status, uint32_t skip_div);
-__global__ void k_bk_accum(uint32_t nthreads, bk_params prm, uint32_t total, const bk_desc *desc, const uint32_t *idx, const fb_entry *pts, ge_ext *bsum);
+__global__ void k_bk_accum(uint32_t nthreads, bk_params prm, uint32_t total, const bk_desc *desc, const uint32_t *idx, const fb_entry *pts, ge_ext *bsum, uint32_t lim);
+__global__ void k_bk_heavy(bk_params prm, uint32_t total, const bk_desc *desc, const uint32_t *idx, const fb_entry *pts, ge_ext *bsum, uint32_t lim);
 __global__ void k_bk_leaf(uint32_t nthreads, bk_params prm, const ge_ext *bsum, ge_ext *gS, ge_ext *gA);
 template <int C>
 __global__ void k_bk_tree(bk_params prm, uint32_t nbw, const ge_ext *gS, const ge_ext *gA, uint32_t *colq16);

@@ -711,6 +711,10 @@ int h_audit_shares(uint32_t n, uint32_t nshares, uint32_t gens_capacity, uint32_
     return 0;
 }
 
+// (tests) limit of a lane's bucket chain (>= 33): 0 = bk_chain_lim; how many buckets the last h_msm_bucket call sent through the heavy pass
+static uint32_t g_bk_cap = 0, g_bk_heavy_buckets = 0;
+void h_set_bucket_cap(uint32_t cap) { g_bk_cap = cap; }
+uint32_t h_bucket_heavy_count() { return g_bk_heavy_buckets; }
 // The bucket (Pippenger) MSM pipeline, lane by lane and phase by phase (bucket.h; the same bodies as k_bucket.hip).
 // c = 8 or 12.  skip_div != 0: ONE MSM over all terms, terms of "proof" t / skip_div are left out when skip[proof] != 0.
 int h_msm_bucket(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, const uint8_t *points, uint32_t c,
@@ -775,9 +779,32 @@ int h_msm_bucket(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalar
         if (listed > sg.count) return -4;
     }
     std::vector<ge_ext> bsum((size_t)nbw * prm.half);
+    uint32_t per_max = 0;
+    for (uint32_t b = 0; b < nbatch; b++) per_max = std::max(per_max, n_terms[b]);
+    const uint32_t lim = g_bk_cap ? g_bk_cap : bk_chain_lim(single ? total : per_max, prm);
     for (uint32_t tid = 0; tid < nbw * prm.half; tid++) {
         const uint32_t bw = tid / prm.half, r = tid - bw * prm.half, w = bw % prm.nwin;
-        bk_accum_thread(bw, r, prm, desc.data(), idx.data() + (size_t)w * total, pts.data(), bsum.data());
+        bk_accum_thread(bw, r, prm, desc.data(), idx.data() + (size_t)w * total, pts.data(), bsum.data(), lim);
+    }
+    // the heavy pass (k_bk_heavy), wavefront by wavefront and phase by phase
+    g_bk_heavy_buckets = 0;
+    const uint32_t G = bk_heavy_groups(prm);
+    for (uint32_t blk = 0; blk < nbw * G; blk++) {
+        const uint32_t bw = blk / G, g = blk - bw * G;
+        uint32_t hn[1]; std::vector<uint32_t> hlist(BK_HEAVY_MAX); std::vector<ge_ext> xch(64);
+        bk_heavy_lds hl; hl.n = hn; hl.list = hlist.data(); hl.xch = xch.data();
+        const uint32_t *idx_w = idx.data() + (size_t)(bw % prm.nwin) * total;
+        for (uint32_t lane = 0; lane < 64; lane++) bk_heavy_h0(lane, hl);
+        for (uint32_t lane = 0; lane < 64; lane++) bk_heavy_h1(lane, bw, g, prm, desc.data(), lim, hl);
+        const uint32_t hc = hn[0];
+        if (hc > BK_HEAVY_MAX) return -6;
+        g_bk_heavy_buckets += hc;
+        for (uint32_t i = 0; i < hc; i++) {
+            for (uint32_t lane = 0; lane < 64; lane++) bk_heavy_h2(lane, bw, i, prm, desc.data(), lim, idx_w, pts.data(), hl);
+            for (uint32_t step = 32; step >= 1; step >>= 1)
+                for (uint32_t lane = 0; lane < 64; lane++) bk_heavy_h3(lane, step, hl);
+            for (uint32_t lane = 0; lane < 64; lane++) bk_heavy_h4(lane, bw, i, prm, desc.data(), hl, bsum.data());
+        }
     }
     std::vector<uint32_t> colq16((size_t)nmsm * 64 * 32 + 32, 0);
     // running-sum tree: leaf level lane by lane, then the packed upper levels exactly as k_bk_tree walks them

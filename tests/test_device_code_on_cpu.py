@@ -268,6 +268,42 @@ def test_bucket_msm_pipeline_phase_by_phase(H, oracle, c):
     assert out.raw[:32] == oracle.msm(b"".join(s[32 * i:32 * i + 32] for i in keep), b"".join(p[32 * i:32 * i + 32] for i in keep))[1]
 
 
+@pytest.mark.parametrize("c", [8, 12])
+def test_bucket_msm_crowded_buckets_go_through_the_heavy_pass(H, oracle, c):
+    """bucket.h stage 3b: a lane adds its whole bucket up to `lim` terms; of a more crowded one it adds lim - 32 and the rest goes
+    64 lanes at a time (k_bk_heavy: G wavefronts per window list the crowded buckets among their ranks, strided partial sums, tree
+    through LDS, add to the bucket's sum).  Scalars that defeat bk_recode's stirring -- all equal, all small, short ones sharing
+    their high windows -- with the lowest limit (33) so that a few hundred terms reach every branch (one lane busy / all lanes /
+    several rounds; several crowded buckets per wavefront), then the natural limit.  Results == oracle; the pass reports how many
+    buckets it took."""
+    def run(scal, pts, lim):
+        n = len(scal) // 32
+        out, st = C.create_string_buffer(32), C.create_string_buffer(1)
+        H.h_set_bucket_cap(lim)
+        try:
+            assert H.h_msm_bucket(1, (C.c_uint32 * 1)(n), scal, pts, c, None, 0, 1, out, st) == 0
+        finally:
+            H.h_set_bucket_cap(0)
+        assert st.raw[0] == 0 and out.raw == oracle.msm(scal, pts)[1]
+        return H.h_bucket_heavy_count()
+    n = 400
+    pts = b"".join(_pt(oracle, b"hv-p%d" % (i % 57)) for i in range(n))
+    eq = _sc(b"hv-equal") * n
+    assert run(eq, pts, 33) > 0
+    assert run(eq, pts, 0) > 0        # natural limit (2 x 400 / half + 32): the windows in bits 135 .. 251 hold all 400 terms in ONE bucket each
+    small = b"".join((1 + (i % 3)).to_bytes(32, "little") for i in range(n))
+    assert run(small, pts, 34) > 0
+    short = b"".join(int.from_bytes(_sc(b"hv-w%d" % i)[:16], "little").to_bytes(32, "little") for i in range(n))   # 128-bit scalars: the round's finding
+    run(short, pts, 33)
+    for extra in (1, 31, 32, 33, 63, 64, 65, 129):                           # one bucket of lim + extra terms: rest = 32 + extra
+        m = 40 + extra
+        assert run(_sc(b"hv-one") * m, pts[:32 * m], 40) > 0
+    rnd = b"".join(_sc(b"hv-r%d" % i) for i in range(n))
+    assert run(rnd, pts, 0) == 0
+    many = b"".join(_sc(b"hv-m%d" % (i % 5)) for i in range(n))             # five crowded buckets of 80 per middle window
+    assert run(many, pts, 33) >= 5
+
+
 @pytest.mark.parametrize("W,nsplit", [(4, 3), (5, 8), (7, 1)])
 def test_shared_generator_pipeline_lane_by_lane(H, oracle, W, nsplit):
     g = oracle.Gens(8, 2)

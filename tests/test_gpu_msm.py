@@ -255,3 +255,39 @@ def test_bucket_path_sizes_bit_exact(ctx, oracle, sizes):
         o, s_ = cb.msm_batch(sizes, bytes(s2), P)
         assert s_[0] == 2
     cb.close()
+
+
+@pytest.mark.parametrize("n,kind", [(3000, "equal"), (8192, "ones"), (20000, "equal"), (20000, "short128"), (7000, "three-values")])
+def test_bucket_path_structured_scalars_take_the_heavy_pass(ctx, oracle, n, kind):
+    """Scalars that bk_recode's stirring cannot spread (equal, tiny, short ones that share their upper windows): whole windows'
+    worth of terms land in ONE bucket.  A lane adds at most four times the average population of its bucket; the rest goes through
+    k_bk_heavy, 64 lanes at a time (bucket.h stage 3b; lane by lane in the CPU harness).  Bit-exact vs the oracle's MSM and vs the
+    table-lookup path."""
+    import bulletproofs_amd as bp
+    L = 2**252 + 27742317777372353535851937790883648493
+    if kind == "equal":
+        S = _scalar(b"hv-eq-%d" % n) * n
+    elif kind == "ones":
+        S = (1).to_bytes(32, "little") * n
+    elif kind == "short128":
+        S = b"".join(hashlib.shake_256(b"hv-sh-%d" % i).digest(16) + bytes(16) for i in range(n))
+    else:
+        vals = [_scalar(b"hv-3-%d" % j) for j in range(3)]
+        S = b"".join(vals[i % 3] for i in range(n))
+    P = _fast_points(oracle, b"hv-%s" % kind.encode(), n)
+    exp = oracle.msm(S, P)[1]
+    cb = bp.Context(0)
+    cb.set_option("bucket_min_terms", 1)
+    out, st = cb.msm_batch([n], S, P)
+    cb.close()
+    assert st[0] == 0 and out == exp
+    assert ctx.msm_batch([n], S, P) == (out, st)
+    # a batch in which one MSM is crowded and its neighbours are not
+    S2 = _fast_scalars(b"hv-nb", 2000) + S[:32 * 2500] + _fast_scalars(b"hv-nc", 1800)
+    P2 = _fast_points(oracle, b"hv-nb", 2000) + P[:32 * 2500] + _fast_points(oracle, b"hv-nc", 1800)
+    cb = bp.Context(0)
+    cb.set_option("bucket_min_terms", 1)
+    out, st = cb.msm_batch([2000, 2500, 1800], S2, P2)
+    cb.close()
+    exp3 = [oracle.msm(S2[32 * a:32 * b], P2[32 * a:32 * b])[1] for a, b in ((0, 2000), (2000, 4500), (4500, 6300))]
+    assert st == bytes(3) and out == b"".join(exp3)

@@ -366,3 +366,29 @@ def test_randomness_the_caller_does_not_bring_is_one_key_per_chain_expanded_on_t
         _, _, ea = ctx64x8.rangeproof_verify_rlc(n, m, proofs, len(pr), coms, label)
         _, _, eb = ctx64x8.rangeproof_verify_rlc(n, m, proofs, len(pr), coms, label)
         assert ea != eb and ea != e0 and ea != bytes(32)
+
+
+def test_short_caller_weights_crowd_one_bucket_and_combine_exactly(oracle):
+    """128-bit weights (zero-extended) are valid combination weights, and the round's performance finding: proof i's A term then
+    carries the bare weight, bk_recode cannot stir bits 135 .. 251, and one proof in nine lands in the same bucket of one window
+    of the combined MSM -- more than a lane's cap from ~2400 proofs on.  The crowded bucket goes through k_bk_heavy; the combined
+    point of a batch with three failing proofs == ONE oracle MSM over all weighted terms."""
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    fx = wl.load_fixture("cfg2_n64_m1")
+    nb = 4096
+    proofs, coms = wl.tile_batch(fx, nb, first=700)
+    pb = bytearray(proofs)
+    for i in (9, 2222, 4000):
+        pb[i * fx.proof_len + 128] ^= 1
+    proofs = bytes(pb)
+    rng = hashlib.shake_256(b"rlc-short-r").digest(64 * nb)
+    w16 = hashlib.shake_256(b"rlc-short-w").digest(16 * nb)
+    wts = b"".join(w16[16 * i:16 * i + 16] + bytes(48) for i in range(nb))
+    c = bp.Context(0)
+    c.gens_create(64, 1)
+    verdict, ok, enc = c.rangeproof_verify_rlc(fx.n, fx.m, proofs, fx.proof_len, coms, fx.label, rng, wts)
+    c.close()
+    included, exp = expected_combination(oracle, oracle.Gens(64, 1), fx.n, fx.m, fx.label, proofs, fx.proof_len, coms, rng, wts)
+    assert all(included) and not ok and enc == exp and enc != bytes(32)
+    assert [i for i in range(nb) if verdict[i]] == [9, 2222, 4000]
