@@ -1122,7 +1122,8 @@ static int enqueue_bucket_tail(bpgpu_ctx *c, hipStream_t s, bk_params prm, size_
     const uint32_t nt = nbw * prm.half;
     const uint32_t lim = bk_chain_lim(per_msm, prm);
     LAUNCH(c, s, "bk_accum", k_bk_accum, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, prm, tot32, d.desc, d.idx, d.pts, d.bsum, lim);
-    LAUNCH(c, s, "bk_heavy", k_bk_heavy, nbw * bk_heavy_groups(prm), 64, prm, tot32, (const bk_desc *)d.desc, (const uint32_t *)d.idx, (const fb_entry *)d.pts, d.bsum, lim);
+    const uint32_t hg = bk_heavy_groups(prm, nmsm);
+    LAUNCH(c, s, "bk_heavy", k_bk_heavy, nbw * hg, 64, prm, tot32, (const bk_desc *)d.desc, (const uint32_t *)d.idx, (const fb_entry *)d.pts, d.bsum, lim, hg);
     enqueue_bucket_reduce(c, s, prm, nbw, d);
     LAUNCH(c, s, "horner_wave", k_horner_wave, (uint32_t)nmsm, 64, d.colq16, d.hq);
     return BPGPU_OK;
@@ -1947,7 +1948,8 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         const uint32_t lim = bk_chain_lim(rlc_terms, bkp);
         LAUNCH(c, s, "rlc_accum", k_rlc_accum_scalars, n_acc + n_sc, BP_BLOCK, n_acc, nt, bkp, tot32, bd.desc, bd.idx, bd.pts, bd.bsum, n_gen_terms,
                (const unsigned long long *)d_acc, d_dig1, prm, d_ctl, lim);
-        LAUNCH(c, s, "bk_heavy", k_bk_heavy, bkp.nwin * bk_heavy_groups(bkp), 64, bkp, tot32, (const bk_desc *)bd.desc, (const uint32_t *)bd.idx, (const fb_entry *)bd.pts, bd.bsum, lim);
+        const uint32_t hg = bk_heavy_groups(bkp, 1);
+        LAUNCH(c, s, "bk_heavy", k_bk_heavy, bkp.nwin * hg, 64, bkp, tot32, (const bk_desc *)bd.desc, (const uint32_t *)bd.idx, (const fb_entry *)bd.pts, bd.bsum, lim, hg);
         enqueue_bucket_reduce(c, s, bkp, bkp.nwin, bd);
         LAUNCH(c, s, "rlc_stage4", k_rlc_stage4b, 1 + nsplit1, FB_BLOCK, bd.colq16, bd.hq, prm, nsplit1, npairs, d_ids, d_dig1, gen_table, d_part1);
         if (d_batch_out)

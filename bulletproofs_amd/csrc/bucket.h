@@ -332,8 +332,9 @@ BP_HD void bk_accum_thread(uint32_t bw, uint32_t r, bk_params prm, const bk_desc
 // none: the launch is one read of the descriptors).  Then per listed bucket: h2: lane l sums entries share + l, share + l + 64,
 // ... into xch[l]; h3(step = 32 .. 1): xch[l] += xch[l + step]; h4: lane 0 adds xch[0] to the bucket's sum.  A listed bucket costs
 // rest / 64 + 7 additions in sequence, and fewer than half / (2 G) buckets can be listed per wavefront.
-BP_HD uint32_t bk_heavy_groups(bk_params prm) { return prm.c == 8 ? 2u : 16u; }
-#define BK_HEAVY_MAX 128   // >= half / G ranks per wavefront
+// G: 16 wavefronts per window for a lone large MSM (c = 12), 2 when the batch already brings many (MSM, window) pairs
+BP_HD uint32_t bk_heavy_groups(bk_params prm, size_t nmsm) { return (prm.c == 8 || nmsm >= 8) ? 2u : 16u; }
+#define BK_HEAVY_MAX 1024   // >= half / G ranks per wavefront
 struct bk_heavy_lds {
     uint32_t *n;      // [1]
     uint32_t *list;   // [BK_HEAVY_MAX] ranks
@@ -342,8 +343,7 @@ struct bk_heavy_lds {
 BP_HD void bk_heavy_h0(uint32_t lane, const bk_heavy_lds &l) {
     if (lane == 0) l.n[0] = 0;
 }
-BP_HD void bk_heavy_h1(uint32_t lane, uint32_t bw, uint32_t g, bk_params prm, const bk_desc *desc, uint32_t lim, const bk_heavy_lds &l) {
-    const uint32_t G = bk_heavy_groups(prm);
+BP_HD void bk_heavy_h1(uint32_t lane, uint32_t bw, uint32_t g, uint32_t G, bk_params prm, const bk_desc *desc, uint32_t lim, const bk_heavy_lds &l) {
     for (uint32_t r = g + G * lane; r < prm.half; r += 64 * G) {
         if (desc[(uint64_t)bw * prm.half + r].cnt > lim) {
             const uint32_t pos = BK_ATOMIC_ADD(l.n, 1u);

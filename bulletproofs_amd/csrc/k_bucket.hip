@@ -113,17 +113,17 @@ __global__ void __launch_bounds__(BP_BLOCK) k_bk_accum(uint32_t nthreads, bk_par
 
 // what crowded buckets hold beyond the lanes' share (bucket.h, stage 3b): G wavefronts per (MSM, window), blockIdx.x = bw * G + g
 __global__ void __launch_bounds__(64) k_bk_heavy(bk_params prm, uint32_t total, const bk_desc *desc, const uint32_t *idx, const fb_entry *pts, ge_ext *bsum,
-                                                  uint32_t lim) {
+                                                  uint32_t lim, uint32_t G) {
     __shared__ uint32_t s_n[1], s_list[BK_HEAVY_MAX];
     __shared__ ge_ext s_xch[64];
-    const uint32_t G = bk_heavy_groups(prm), bw = blockIdx.x / G, g = blockIdx.x - bw * G, lane = threadIdx.x, w = bw % prm.nwin;
+    const uint32_t bw = blockIdx.x / G, g = blockIdx.x - bw * G, lane = threadIdx.x, w = bw % prm.nwin;
     bk_heavy_lds l;
     l.n = s_n;
     l.list = s_list;
     l.xch = s_xch;
     bk_heavy_h0(lane, l);
     __syncthreads();
-    bk_heavy_h1(lane, bw, g, prm, desc, lim, l);
+    bk_heavy_h1(lane, bw, g, G, prm, desc, lim, l);
     __syncthreads();
     const uint32_t n = s_n[0];
     const uint32_t *idx_w = idx + (uint64_t)w * total;

@@ -93,7 +93,7 @@ __global__ void k_bk_sort(bk_params prm, const uint32_t *msm_first, uint32_t tot
 template <int LANES>
 __global__ void k_bk_sort_big(int phase, uint32_t nsub, bk_params prm, const uint32_t *msm_first, uint32_t total, int single, const uint32_t *rwords, uint32_t *idx, bk_desc *desc, uint32_t *gcnt, uint32_t *gcur, const uint32_t *skip_status, uint32_t skip_div);
 __global__ void k_bk_accum(uint32_t nthreads, bk_params prm, uint32_t total, const bk_desc *desc, const uint32_t *idx, const fb_entry *pts, ge_ext *bsum, uint32_t lim);
-__global__ void k_bk_heavy(bk_params prm, uint32_t total, const bk_desc *desc, const uint32_t *idx, const fb_entry *pts, ge_ext *bsum, uint32_t lim);
+__global__ void k_bk_heavy(bk_params prm, uint32_t total, const bk_desc *desc, const uint32_t *idx, const fb_entry *pts, ge_ext *bsum, uint32_t lim, uint32_t G);
 __global__ void k_bk_leaf(uint32_t nthreads, bk_params prm, const ge_ext *bsum, ge_ext *gS, ge_ext *gA);
 template <int C>
 __global__ void k_bk_tree(bk_params prm, uint32_t nbw, const ge_ext *gS, const ge_ext *gA, uint32_t *colq16);

@@ -712,8 +712,9 @@ int h_audit_shares(uint32_t n, uint32_t nshares, uint32_t gens_capacity, uint32_
 }
 
 // (tests) limit of a lane's bucket chain (>= 33): 0 = bk_chain_lim; how many buckets the last h_msm_bucket call sent through the heavy pass
-static uint32_t g_bk_cap = 0, g_bk_heavy_buckets = 0;
+static uint32_t g_bk_cap = 0, g_bk_heavy_buckets = 0, g_bk_groups = 0;
 void h_set_bucket_cap(uint32_t cap) { g_bk_cap = cap; }
+void h_set_bucket_groups(uint32_t g) { g_bk_groups = g; }
 uint32_t h_bucket_heavy_count() { return g_bk_heavy_buckets; }
 // The bucket (Pippenger) MSM pipeline, lane by lane and phase by phase (bucket.h; the same bodies as k_bucket.hip).
 // c = 8 or 12.  skip_div != 0: ONE MSM over all terms, terms of "proof" t / skip_div are left out when skip[proof] != 0.
@@ -788,14 +789,14 @@ int h_msm_bucket(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalar
     }
     // the heavy pass (k_bk_heavy), wavefront by wavefront and phase by phase
     g_bk_heavy_buckets = 0;
-    const uint32_t G = bk_heavy_groups(prm);
+    const uint32_t G = g_bk_groups ? g_bk_groups : bk_heavy_groups(prm, nmsm);
     for (uint32_t blk = 0; blk < nbw * G; blk++) {
         const uint32_t bw = blk / G, g = blk - bw * G;
         uint32_t hn[1]; std::vector<uint32_t> hlist(BK_HEAVY_MAX); std::vector<ge_ext> xch(64);
         bk_heavy_lds hl; hl.n = hn; hl.list = hlist.data(); hl.xch = xch.data();
         const uint32_t *idx_w = idx.data() + (size_t)(bw % prm.nwin) * total;
         for (uint32_t lane = 0; lane < 64; lane++) bk_heavy_h0(lane, hl);
-        for (uint32_t lane = 0; lane < 64; lane++) bk_heavy_h1(lane, bw, g, prm, desc.data(), lim, hl);
+        for (uint32_t lane = 0; lane < 64; lane++) bk_heavy_h1(lane, bw, g, G, prm, desc.data(), lim, hl);
         const uint32_t hc = hn[0];
         if (hc > BK_HEAVY_MAX) return -6;
         g_bk_heavy_buckets += hc;

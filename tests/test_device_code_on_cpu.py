@@ -302,6 +302,12 @@ def test_bucket_msm_crowded_buckets_go_through_the_heavy_pass(H, oracle, c):
     assert run(rnd, pts, 0) == 0
     many = b"".join(_sc(b"hv-m%d" % (i % 5)) for i in range(n))             # five crowded buckets of 80 per middle window
     assert run(many, pts, 33) >= 5
+    for G in (1, 2, 16):                                                     # any partition of the ranks over wavefronts
+        H.h_set_bucket_groups(G)
+        try:
+            assert run(many, pts, 33) >= 5 and run(eq, pts, 0) > 0
+        finally:
+            H.h_set_bucket_groups(0)
 
 
 @pytest.mark.parametrize("W,nsplit", [(4, 3), (5, 8), (7, 1)])
