@@ -1348,7 +1348,12 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
     // a burst that fits two chains takes two: with the one-lane Horner chains aside, 20 x 1024 from idle measured 5.6 / 5.6 / 5.8 M/s as four
     // chains of 5120 and 5.9 ... 6.2 / 5.7 ... 5.8 / 6.0 as two of 10240 on three boxes; 40 x 1024 prefers eight of 5120 (6.05 against 5.85 as
     // four of 10240), 8 x 1024 two of 4096 (4.7 against 4.3 ... 4.6 as one) -- profiles/r03/coalesce_sweep_after_horner_aside.txt
-    if (G > 2 && T <= p->pair_limit_proofs) G = 2;   // (batch-combined bursts too: 20 x 1024 as two combinations 5.5 M/s, as four 3.9)
+    // Batch-combined bursts keep the chains of coalesce_proofs: 20 x 1024 as four combinations 8.1 ... 8.3 M/s, as two 7.7 ... 7.9
+    // (profiles/r04/ab_rlc_burst_chains.txt; measured the other way round -- 3.9 against 5.5 -- while short weights still crowded one
+    // bucket of every combination)
+    bool all_rlc = !items.empty();
+    for (const dev_item &it : items) all_rlc = all_rlc && it.rlc;
+    if (G > 2 && T <= p->pair_limit_proofs && !all_rlc) G = 2;
     if (one_chain) G = 1;   // a chain's worth has accumulated while the caller is still submitting: it goes out now, as it is
     if (G > d->lanes.size()) G = d->lanes.size();
     size_t per = (T + G - 1) / G;
