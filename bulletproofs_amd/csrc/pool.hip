@@ -1326,6 +1326,47 @@ static std::shared_ptr<ev_holder> record_done(bpgpu_ctx *c, bool wanted) {
     return h;
 }
 
+// ---- how a flush of T pending proofs is cut into launch chains (plain host logic: tests/test_abi_and_host.py) -------------------------
+struct flush_plan {
+    size_t chains, per;      // at most `chains` chains of up to `per` proofs (a chain takes consecutive items of one shape)
+    uint32_t splits_hint;    // table-walk workgroups per proof block handed to the chains (bpgpu.hip pick_splits)
+};
+static flush_plan plan_flush(size_t T, size_t coalesce_proofs, size_t pair_limit_proofs, size_t max_chain_proofs, size_t lanes, bool all_rlc, bool one_chain) {
+    // number of chains: about T / coalesce_proofs, at most one per lane
+    size_t G = (T + coalesce_proofs / 2) / coalesce_proofs;
+    if (G < 1) G = 1;
+    // a burst that fits two chains takes two: with the one-lane Horner chains aside, 20 x 1024 from idle measured 5.6 / 5.6 / 5.8 M/s as four
+    // chains of 5120 and 5.9 ... 6.2 / 5.7 ... 5.8 / 6.0 as two of 10240 on three boxes; 40 x 1024 prefers eight of 5120 (6.05 against 5.85 as
+    // four of 10240), 8 x 1024 two of 4096 (4.7 against 4.3 ... 4.6 as one) -- profiles/r03/coalesce_sweep_after_horner_aside.txt
+    // Batch-combined bursts keep the chains of coalesce_proofs: 20 x 1024 as four combinations 8.1 ... 8.3 M/s, as two 7.7 ... 7.9
+    // (profiles/r04/ab_rlc_burst_chains.txt; measured the other way round -- 3.9 against 5.5 -- while short weights still crowded one
+    // bucket of every combination, DESIGN 4b)
+    if (G > 2 && T <= pair_limit_proofs && !all_rlc) G = 2;
+    if (one_chain) G = 1;   // a chain's worth has accumulated while the caller is still submitting: it goes out now, as it is
+    if (G > lanes) G = lanes;
+    size_t per = (T + G - 1) / G;
+    if (per > max_chain_proofs) per = max_chain_proofs;
+    if (per < 1) per = 1;
+    // table-walk workgroups per proof block: a few chains alone on the device want many small workgroups (short tail: measured on
+    // 20 x 1024 from idle, 5 chains: 16 splits 5.06 M/s, 32: 5.24, 64: 5.21), a full pipeline wants few (less reduction work) -- aim
+    // at ~16 k wavefronts of table walk per flush
+    const size_t n_chains = (T + per - 1) / per;
+    uint32_t hint = (uint32_t)(16384 / ((n_chains ? n_chains : 1) * ((per + 63) / 64)));
+    hint = (hint + 7) & ~7u;
+    if (hint < 16) hint = 16;
+    if (hint > 64) hint = 64;
+    flush_plan fp;
+    fp.chains = n_chains;
+    fp.per = per;
+    fp.splits_hint = hint;
+    return fp;
+}
+extern "C" void bpgpu_internal_plan_flush(uint64_t T, uint64_t coalesce_proofs, uint64_t pair_limit_proofs, uint64_t max_chain_proofs, uint64_t lanes, int all_rlc,
+                                          int one_chain, uint64_t *chains, uint64_t *per, uint32_t *splits_hint) {
+    const flush_plan fp = plan_flush((size_t)T, (size_t)coalesce_proofs, (size_t)pair_limit_proofs, (size_t)max_chain_proofs, (size_t)lanes, all_rlc != 0, one_chain != 0);
+    *chains = fp.chains, *per = fp.per, *splits_hint = fp.splits_hint;
+}
+
 static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
     if (d->pending.empty()) return BPGPU_OK;
     (void)hipSetDevice(d->device);
@@ -1342,30 +1383,11 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
         if (idle) d->next_lane = d->used_lanes = 0;
         was_idle = idle;
     }
-    // number of chains: about T / coalesce_proofs, at most one per lane; a chain takes consecutive items of one shape
-    size_t G = (T + p->coalesce_proofs / 2) / p->coalesce_proofs;
-    if (G < 1) G = 1;
-    // a burst that fits two chains takes two: with the one-lane Horner chains aside, 20 x 1024 from idle measured 5.6 / 5.6 / 5.8 M/s as four
-    // chains of 5120 and 5.9 ... 6.2 / 5.7 ... 5.8 / 6.0 as two of 10240 on three boxes; 40 x 1024 prefers eight of 5120 (6.05 against 5.85 as
-    // four of 10240), 8 x 1024 two of 4096 (4.7 against 4.3 ... 4.6 as one) -- profiles/r03/coalesce_sweep_after_horner_aside.txt
-    // Batch-combined bursts keep the chains of coalesce_proofs: 20 x 1024 as four combinations 8.1 ... 8.3 M/s, as two 7.7 ... 7.9
-    // (profiles/r04/ab_rlc_burst_chains.txt; measured the other way round -- 3.9 against 5.5 -- while short weights still crowded one
-    // bucket of every combination, DESIGN 4b)
     bool all_rlc = !items.empty();
     for (const dev_item &it : items) all_rlc = all_rlc && it.rlc;
-    if (G > 2 && T <= p->pair_limit_proofs && !all_rlc) G = 2;
-    if (one_chain) G = 1;   // a chain's worth has accumulated while the caller is still submitting: it goes out now, as it is
-    if (G > d->lanes.size()) G = d->lanes.size();
-    size_t per = (T + G - 1) / G;
-    if (per > p->max_chain_proofs) per = p->max_chain_proofs;
-    // table-walk workgroups per proof block (bpgpu.hip pick_splits): a few chains alone on the device want many small
-    // workgroups (short tail: measured on 20 x 1024 from idle, 5 chains: 16 splits 5.06 M/s, 32: 5.24, 64: 5.21), a full
-    // pipeline wants few (less reduction work) -- aim at ~16 k wavefronts of table walk per flush
-    const size_t n_chains = (T + per - 1) / per;
-    uint32_t hint = (uint32_t)(16384 / (n_chains * ((per + 63) / 64)));
-    hint = (hint + 7) & ~7u;
-    if (hint < 16) hint = 16;
-    if (hint > 64) hint = 64;
+    const flush_plan fp = plan_flush(T, p->coalesce_proofs, p->pair_limit_proofs, p->max_chain_proofs, d->lanes.size(), all_rlc, one_chain);
+    const size_t per = fp.per;
+    const uint32_t hint = fp.splits_hint;
     int rc_all = BPGPU_OK;
     size_t n_undecided = 0;
     std::string first_err;

@@ -217,3 +217,34 @@ def test_hot_path_kernels_use_no_scratch_memory_and_the_build_gate_knows_every_e
     s1 = ks["void k_rp_stage1<true>"]
     assert s1["scratch"] <= 360 and s1["spill_vgpr"] <= 118 and s1["code_bytes"] <= 320 * 1024
     assert ks["k_rp_exponents"]["vgpr"] <= 168                     # three wavefronts per SIMD would fit (measured: two are better on bursts)
+
+
+def test_flush_plan_how_pending_batches_are_cut_into_launch_chains():
+    """plan_flush (csrc/pool.hip): the pool's decision how many launch chains a flush of T pending proofs becomes -- plain host logic,
+    row by row (measurements: DESIGN 2a / 4b, profiles/r03/coalesce_sweep_after_horner_aside.txt, profiles/r04/ab_rlc_burst_chains.txt)."""
+    import ctypes as C
+    import bulletproofs_amd as bp
+    L = bp.lib()
+    f = L.bpgpu_internal_plan_flush
+    f.restype = None
+    f.argtypes = [C.c_uint64] * 5 + [C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32)]
+
+    def plan(T, rlc=0, one=0, coalesce=5120, pair=24576, mx=1 << 20, lanes=64):
+        ch, per, hint = C.c_uint64(), C.c_uint64(), C.c_uint32()
+        f(T, coalesce, pair, mx, lanes, rlc, one, C.byref(ch), C.byref(per), C.byref(hint))
+        return ch.value, per.value, hint.value
+    assert plan(1024)[:2] == (1, 1024) and plan(1)[:2] == (1, 1)
+    assert plan(8 * 1024)[:2] == (2, 4096)                       # 8 x 1024: two of 4096
+    assert plan(20 * 1024)[:2] == (2, 10240)                     # the driver's form: a burst that fits two chains takes two
+    assert plan(24576)[:2] == (2, 12288) and plan(24577)[0] == 5 # ... up to pair_limit_proofs
+    assert plan(40 * 1024)[:2] == (8, 5120)                      # 40 x 1024: eight of 5120
+    assert plan(20 * 1024, rlc=1)[:2] == (4, 5120)               # batch-combined bursts keep the chains of coalesce_proofs
+    assert plan(8 * 1024, rlc=1)[:2] == (2, 4096)
+    assert plan(20 * 1024, one=1)[:2] == (1, 20480)              # a chain's worth goes out as it is
+    assert plan(10**6, lanes=8)[0] == 8 and plan(10**6, lanes=8, mx=65536) == (16, 65536, 16)   # one chain per lane; chains never exceed max_chain_proofs
+    assert plan(20 * 1024, pair=0)[:2] == (4, 5120) and plan(20 * 1024, coalesce=2048)[:2] == (2, 10240)
+    for T in (1, 63, 64, 1024, 5120, 20480, 10**5, 10**6):       # every proof is in exactly one chain; the hint stays in [16, 64], multiples of 8
+        for rlc in (0, 1):
+            ch, per, hint = plan(T, rlc)
+            assert (ch - 1) * per < T <= ch * per and 16 <= hint <= 64 and hint % 8 == 0
+    assert plan(20 * 1024)[2] == 56 and plan(40 * 1024)[2] == 32 and plan(10**6)[2] == 16
