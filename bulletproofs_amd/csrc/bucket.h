@@ -347,7 +347,7 @@ BP_HD void bk_heavy_h1(uint32_t lane, uint32_t bw, uint32_t g, uint32_t G, bk_pa
     for (uint32_t r = g + G * lane; r < prm.half; r += 64 * G) {
         if (desc[(uint64_t)bw * prm.half + r].cnt > lim) {
             const uint32_t pos = BK_ATOMIC_ADD(l.n, 1u);
-            l.list[pos] = r;
+            if (pos < BK_HEAVY_MAX) l.list[pos] = r;   // (never more: a wavefront owns half / G <= BK_HEAVY_MAX ranks)
         }
     }
 }

@@ -125,7 +125,7 @@ __global__ void __launch_bounds__(64) k_bk_heavy(bk_params prm, uint32_t total, 
     __syncthreads();
     bk_heavy_h1(lane, bw, g, G, prm, desc, lim, l);
     __syncthreads();
-    const uint32_t n = s_n[0];
+    const uint32_t n = s_n[0] < BK_HEAVY_MAX ? s_n[0] : BK_HEAVY_MAX;
     const uint32_t *idx_w = idx + (uint64_t)w * total;
 #pragma unroll 1
     for (uint32_t i = 0; i < n; i++) {
