@@ -58,6 +58,29 @@ template __global__ void k_rp_stage1<false>(rp_shape, rp_strobe_init, uint32_t, 
                                             uint32_t, uint32_t *, fb_digit *, const uint8_t *, uint32_t, const uint32_t *, uint32_t *, fb_entry *, uint32_t, rp_seg_tab,
                                             const rp_script_hdr *);
 
+// launch 1 of a NARROW chain (option "transcript_coop", chains of up to 256 proofs): blocks [0, n_tr) = two proofs each, 32 lanes per proof
+// -- the group's leader replays the script, all lanes run the permutations together (keccak.h: keccak_f1600_masked_coop), then the
+// leader derives the per-proof scalars  ||  [n_tr, ..) the decode role as in k_rp_stage1.  No register cap: a handful of wavefronts.
+__global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1_coop(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs, const uint8_t *commitments,
+                                                             const uint8_t *rng64, uint32_t *fields, ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m,
+                                                             uint32_t *recoded, fb_digit *digits, const uint8_t *rho64, const uint32_t *ts_in, uint32_t *ts_out,
+                                                             fb_entry *bk_pts, uint32_t bk_c, rp_seg_tab segs, const rp_script_hdr *script) {
+    __shared__ uint32_t lds[2 * 52];   // one 50-word sponge state per group
+    if (blockIdx.x < n_tr) {
+        const uint32_t lane = threadIdx.x, g = lane >> 5, p = blockIdx.x * 2 + g;
+        const bool valid = p < sh.nproofs;
+        const uint32_t pp = valid ? p : sh.nproofs - 1;   // an idle group walks the script on the last proof's pointers and touches nothing
+        kstate st;
+        st.w = lds + 52 * g;
+        st.stride = 1;
+        rp_transcript_scripted_coop(pp, valid, lane, sh, init, st, rp_resolve(pp, sh, proofs, commitments, rng64, segs), script, fields, status, ts_out, ts_in);
+        if (valid && (lane & 31) == 0 && !sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64, bk_c);
+    } else {
+        const uint32_t t = (blockIdx.x - n_tr) * RP_BLOCK + threadIdx.x;
+        if (t < sh.nproofs * sh.U) rp_points_thread(t, sh, rp_resolve(t / sh.U, sh, proofs, commitments, nullptr, segs), tab, status, bk_pts);
+    }
+}
+
 // the lane-serial role of launch 1 (scripted transcript + per-proof scalars) as a launch of its own, WITHOUT the register cap of the
 // fused kernel: option "split_stage1" runs the decode role beside it on the second stream (k_rp_points).  A few dozen wavefronts: one
 // per SIMD is plenty, and without the cap nothing spills.

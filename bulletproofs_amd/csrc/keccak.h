@@ -127,6 +127,126 @@ BP_HD void keccak_f1600_masked(const kstate &s, const uint32_t *mask, uint32_t n
     }
 }
 
+// ---- Keccak-f[1600] on 25 lanes of a 32-lane group: one 64-bit state word per lane -------------------------------------------
+// For NARROW launch chains (a call of a few proofs, the combining queue's small chains) launch 1 is one lane replaying one
+// transcript: ~16 permutations x 24 rounds x ~270 dependent instructions, 13 us each at a lone wavefront's issue rate -- while
+// 63 lanes of the wavefront idle.  Here lane j = x + 5 y of a half-wavefront holds a[x, y]; a round is four exchange phases
+// (nine 64-bit fetches from other lanes: ds_bpermute_b32 pairs) and a handful of ALU operations per lane:
+//   P1  c = XOR of the lane's column (4 fetches)            P2  a ^= c[x-1] ^ rot(c[x+1], 1) (2 fetches)
+//   P3  b[pi(j)] = rot(a, rho[j]): rotate, then every lane fetches from its source (1)     P4  a = b ^ (~b[x+1] & b[x+2]) (2), iota
+// Seven times the lane-instructions of the serial form, a quarter of its latency: for latency-bound chains only (option
+// "transcript_coop").  The phase functions take the fetch as a functor, so that the CPU harness runs the same bodies on a snapshot
+// of the 25 lane values (tests/cpu_harness: keccak_coop_host).
+BP_HD uint32_t kc_rho(uint32_t j) {
+    const uint8_t R[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};
+    return R[j];
+}
+BP_HD uint32_t kc_pi_src(uint32_t i) {   // b[i] = rot(a[kc_pi_src(i)])
+    const uint8_t S[25] = {0, 6, 12, 18, 24, 3, 9, 10, 16, 22, 1, 7, 13, 19, 20, 4, 5, 11, 17, 23, 2, 8, 14, 15, 21};
+    return S[i];
+}
+BP_HD uint64_t kc_rc(uint32_t r) {
+    const uint64_t RC[24] = {
+        0x0000000000000001ULL, 0x0000000000008082ULL, 0x800000000000808aULL, 0x8000000080008000ULL,
+        0x000000000000808bULL, 0x0000000080000001ULL, 0x8000000080008081ULL, 0x8000000000008009ULL,
+        0x000000000000008aULL, 0x0000000000000088ULL, 0x0000000080008009ULL, 0x000000008000000aULL,
+        0x000000008000808bULL, 0x800000000000008bULL, 0x8000000000008089ULL, 0x8000000000008003ULL,
+        0x8000000000008002ULL, 0x8000000000000080ULL, 0x000000000000800aULL, 0x800000008000000aULL,
+        0x8000000080008081ULL, 0x8000000000008080ULL, 0x0000000080000001ULL, 0x8000000080008008ULL};
+    return RC[r];
+}
+BP_HD uint64_t kc_rotl_var(uint64_t x, uint32_t n) { return n ? (x << n) | (x >> (64 - n)) : x; }
+// G: uint64_t operator()(uint64_t mine, uint32_t src_lane): the value `mine` as lane src_lane (0 .. 24) of the group holds it
+template <class G>
+BP_HD uint64_t kc_p1(uint64_t a, uint32_t x, uint32_t y, G &g) {
+    uint64_t c = a;
+#pragma unroll
+    for (uint32_t d = 1; d < 5; d++) c ^= g(a, x + 5 * ((y + d) % 5));
+    return c;
+}
+template <class G>
+BP_HD uint64_t kc_p2(uint64_t a, uint64_t c, uint32_t x, uint32_t y, G &g) {
+    const uint64_t cm = g(c, (x + 4) % 5 + 5 * y), cp = g(c, (x + 1) % 5 + 5 * y);
+    return a ^ cm ^ ((cp << 1) | (cp >> 63));
+}
+template <class G>
+BP_HD uint64_t kc_p3(uint64_t a, uint32_t j, G &g) {
+    return g(kc_rotl_var(a, kc_rho(j)), kc_pi_src(j));
+}
+template <class G>
+BP_HD uint64_t kc_p4(uint64_t b, uint32_t x, uint32_t y, uint32_t j, uint32_t r, G &g) {
+    const uint64_t b1 = g(b, (x + 1) % 5 + 5 * y), b2 = g(b, (x + 2) % 5 + 5 * y);
+    uint64_t a = b ^ (~b1 & b2);
+    if (j == 0) a ^= kc_rc(r);
+    return a;
+}
+#if defined(__HIP_DEVICE_COMPILE__)
+struct kc_fetch_dev {
+    uint32_t base;   // first lane of this group in the wavefront (0 or 32)
+    __device__ __forceinline__ uint64_t operator()(uint64_t mine, uint32_t src) const {
+        const int addr = (int)((base + src) << 2);
+        const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)mine);
+        const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(mine >> 32));
+        return ((uint64_t)hi << 32) | lo;
+    }
+};
+// all 64 lanes of the wavefront call this together (the exchanges are wavefront-wide instructions); lanes 25 .. 31 of a group
+// run along on lane 24's coordinates and keep nothing.  st: the GROUP's sponge state (the same pointer in all its lanes, stride 1),
+// written by the group's leader before and read by it after: the caller brackets the call with workgroup barriers.
+__device__ __forceinline__ void keccak_f1600_masked_coop(const kstate &st, const uint32_t *mask, uint32_t nmask, uint32_t lane) {
+    const uint32_t jj = lane & 31, j = jj < 25 ? jj : 24, x = j % 5, y = j / 5;
+    kc_fetch_dev g;
+    g.base = lane & 32;
+    uint32_t lo = st.w[(2 * j) * st.stride], hi = st.w[(2 * j + 1) * st.stride];
+    if (2 * j < nmask) lo ^= mask[2 * j];
+    if (2 * j + 1 < nmask) hi ^= mask[2 * j + 1];
+    uint64_t a = ((uint64_t)hi << 32) | lo;
+#pragma unroll 1
+    for (uint32_t r = 0; r < 24; r++) {
+        const uint64_t c = kc_p1(a, x, y, g);
+        a = kc_p2(a, c, x, y, g);
+        const uint64_t b = kc_p3(a, j, g);
+        a = kc_p4(b, x, y, j, r, g);
+    }
+    if (jj < 25) {
+        st.w[(2 * j) * st.stride] = (uint32_t)a;
+        st.w[(2 * j + 1) * st.stride] = (uint32_t)(a >> 32);
+    }
+}
+#else
+// host twin (CPU harness): the same phase functions, every phase on a snapshot of the 25 lanes' values
+struct kc_fetch_host {
+    const uint64_t *snap;
+    uint64_t operator()(uint64_t, uint32_t src) const { return snap[src]; }
+};
+inline void keccak_f1600_masked_coop(const kstate &st, const uint32_t *mask, uint32_t nmask, uint32_t) {
+    uint64_t a[25], c[25], t[25];
+    for (uint32_t j = 0; j < 25; j++) {
+        uint32_t lo = st.w[(2 * j) * st.stride], hi = st.w[(2 * j + 1) * st.stride];
+        if (2 * j < nmask) lo ^= mask[2 * j];
+        if (2 * j + 1 < nmask) hi ^= mask[2 * j + 1];
+        a[j] = ((uint64_t)hi << 32) | lo;
+    }
+    for (uint32_t r = 0; r < 24; r++) {
+        kc_fetch_host g;
+        g.snap = a;
+        for (uint32_t j = 0; j < 25; j++) c[j] = kc_p1(a[j], j % 5, j / 5, g);
+        g.snap = c;
+        for (uint32_t j = 0; j < 25; j++) t[j] = kc_p2(a[j], c[j], j % 5, j / 5, g);
+        for (uint32_t j = 0; j < 25; j++) a[j] = kc_rotl_var(t[j], kc_rho(j));   // what lane j publishes in P3
+        g.snap = a;
+        for (uint32_t j = 0; j < 25; j++) c[j] = kc_p3(t[j], j, g);
+        g.snap = c;
+        for (uint32_t j = 0; j < 25; j++) t[j] = kc_p4(c[j], j % 5, j / 5, j, r, g);
+        for (uint32_t j = 0; j < 25; j++) a[j] = t[j];
+    }
+    for (uint32_t j = 0; j < 25; j++) {
+        st.w[(2 * j) * st.stride] = (uint32_t)a[j];
+        st.w[(2 * j + 1) * st.stride] = (uint32_t)(a[j] >> 32);
+    }
+}
+#endif
+
 // ---- plain sponges (generator derivation) -------------------------------------
 struct sponge {
     kstate st;

@@ -446,6 +446,107 @@ BP_HD void rp_transcript_scripted(uint32_t p, rp_shape sh, const rp_strobe_init 
     }
 }
 
+// The same replay for NARROW chains, 32 lanes per proof (keccak.h: keccak_f1600_masked_coop): the group's LEADER (lane 0 of the
+// half-wavefront) does everything a lane of rp_transcript_scripted does except the permutation, which all lanes of the group run
+// together on the leader's sponge state (`st`: the same LDS words in all lanes of the group, stride 1).  Every lane of the workgroup
+// walks the whole script -- the barriers and the exchanges need them all -- whatever happened to its proof: a rejected proof's
+// group permutes a state nobody reads.  valid: the group has a proof at all.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BP_GROUP_SYNC() __syncthreads()
+#else
+#define BP_GROUP_SYNC() ((void)0)
+#endif
+BP_HD void rp_transcript_scripted_coop(uint32_t p, bool valid, uint32_t lane, rp_shape sh, const rp_strobe_init &init, kstate st, const rp_inputs &in,
+                                       const rp_script_hdr *script, uint32_t *fields, uint32_t *status, uint32_t *ts_out = nullptr,
+                                       const uint32_t *ts_in = nullptr) {
+    const uint32_t B = sh.nproofs, k = sh.k;
+    const uint8_t *pr = in.pr;
+    const rp_fields fl = rp_field_layout(k, sh.m);
+    uint32_t w[8];
+    bool run = valid && (lane & 31) == 0;   // this lane does the per-proof work
+    bool verr = false;
+    if (run) {
+        sc tx, txb, eb, a, b;
+        bool fmt_ok = true;
+        load_words8(tx.v, pr + 128);   fmt_ok = fmt_ok && sc_is_canonical_sc(tx);
+        load_words8(txb.v, pr + 160);  fmt_ok = fmt_ok && sc_is_canonical_sc(txb);
+        load_words8(eb.v, pr + 192);   fmt_ok = fmt_ok && sc_is_canonical_sc(eb);
+        load_words8(a.v, pr + 224 + 64 * k);       fmt_ok = fmt_ok && sc_is_canonical_sc(a);
+        load_words8(b.v, pr + 224 + 64 * k + 32);  fmt_ok = fmt_ok && sc_is_canonical_sc(b);
+        if (!fmt_ok || sh.shape_verdict) {
+            status_raise(status + p, fmt_ok ? sh.shape_verdict : (uint32_t)BP_VERDICT_FORMAT);
+            rp_ts_passthrough(p, init, ts_in, ts_out);
+            run = false;
+        } else {
+            rp_store(fields, B, RPF_TX, p, tx);
+            rp_store(fields, B, RPF_TXB, p, txb);
+            rp_store(fields, B, RPF_EB, p, eb);
+            rp_store(fields, B, RPF_A, p, a);
+            rp_store(fields, B, RPF_B, p, b);
+            for (uint32_t u = 0; u < 4 + 2 * k; u++) {
+                load_words8(w, pr + (u < 4 ? 32 * u : 224 + 32 * (u - 4)));
+                verr = verr || words8_zero(w);
+            }
+            if (ts_in) {
+                const uint32_t *src = ts_in + (uint64_t)p * BP_TS_WORDS;
+                for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, src[i]);
+            } else {
+                for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, init.w[i]);
+            }
+        }
+    }
+    const rp_script_op *ops = rp_script_ops(script);
+    const uint32_t *masks = rp_script_masks(script);
+    const uint32_t n_ops = script->n_ops;
+    for (uint32_t oi = 0; oi < n_ops; oi++) {
+        const rp_script_op op = ops[oi];
+        if (op.kind == RS_PERM) {
+            BP_GROUP_SYNC();
+            keccak_f1600_masked_coop(st, masks + (uint64_t)op.arg * RS_MASK_WORDS, RS_MASK_WORDS, lane);
+            BP_GROUP_SYNC();
+        } else if (run) {
+            const uint8_t *src = (op.src == RS_SRC_PROOF ? pr : in.cm) + op.off;
+            if (op.kind == RS_MSG) {
+                load_words8(w, src);
+                rp_script_xor_record(st, op.pos, w);
+            } else if (op.kind == RS_MSGB) {
+                for (uint32_t q = 0; q < op.nbytes; q++) ks_xor8(st, op.pos + q, src[q]);
+            } else {
+                uint32_t cw[16];
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    cw[q] = ks_get32(st, q);
+                    ks_set32(st, q, 0);
+                }
+                sc ch;
+                sc_from_wide(ch, cw);
+                const uint32_t id = op.arg;
+                rp_store(fields, B, id == 0 ? (uint32_t)RPF_Y : (id == 1 ? (uint32_t)RPF_Z : (id == 2 ? (uint32_t)RPF_X : (id == 3 ? (uint32_t)RPF_W : fl.u + (id - 4)))), p, ch);
+            }
+        }
+    }
+    if (!run) return;
+    {
+        uint32_t cw[16];
+        sc c;
+        if (in.rs) {
+            load_words8(cw, in.rs);
+            load_words8(cw + 8, in.rs + 32);
+        } else {
+            rp_seed_words(cw, sh, p, RP_SEED_RNG);
+        }
+        sc_from_wide(c, cw);
+        rp_store(fields, B, RPF_C, p, c);
+    }
+    if (verr) status_raise(status + p, BP_VERDICT_VERIFICATION);
+    if (ts_out) {
+        uint32_t *o = ts_out + (uint64_t)p * BP_TS_WORDS;
+        for (uint32_t i = 0; i < 50; i++) o[i] = ks_get32(st, i);
+        o[50] = rp_ts_meta(script->end_pos, script->end_pos_begin, script->end_flags);
+        o[51] = 0;
+    }
+}
+
 // ---- stage 1b: per-proof points -----------------------------------------------------------
 // unique term u of proof p, in the order A, S, T_1, T_2, L_0..L_{k-1}, R_0..R_{k-1}, V_0..V_{m-1}
 // (the non-generator part of mod.rs:433-443)

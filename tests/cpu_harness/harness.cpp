@@ -215,13 +215,20 @@ int h_rp_transcript_compare(uint32_t n, uint32_t m, uint32_t nbatch, const uint8
     const rp_fields fl = rp_field_layout(k, m);
     const size_t nf = (size_t)fl.count * nbatch * BP_RP_REC + 8;
     std::vector<uint32_t> f1(nf, 0xabababab), f2(nf, 0xabababab), s1(nbatch + 1, 0), s2(nbatch + 1, 0), t1((size_t)nbatch * BP_TS_WORDS, 7), t2((size_t)nbatch * BP_TS_WORDS, 7);
+    std::vector<uint32_t> f3(nf, 0xabababab), s3(nbatch + 1, 0), t3((size_t)nbatch * BP_TS_WORDS, 7);
     rp_seg_tab none; memset(&none, 0, sizeof none);
     for (uint32_t p = 0; p < nbatch; p++) {
         uint32_t w1[50], w2[50]; kstate st1, st2; st1.w = w1; st1.stride = 1; st2.w = w2; st2.stride = 1;
         const rp_inputs in = rp_resolve(p, sh, proofs, commitments, rng64, none);
         rp_transcript_thread(p, sh, init, st1, in, f1.data(), s1.data(), domsep ? BP_TS_DOMSEP : 0, nullptr, t1.data());
         rp_transcript_scripted(p, sh, init, st2, in, script, f2.data(), s2.data(), t2.data());
+        // the narrow-chain variant (32 lanes per proof): the leader's path, the permutations through the 25-lane phase functions
+        uint32_t w3[52]; kstate st3; st3.w = w3; st3.stride = 1;
+        rp_transcript_scripted_coop(p, true, 0, sh, init, st3, in, script, f3.data(), s3.data(), t3.data());
     }
+    if (s1 != s3) return 4;
+    if (t1 != t3) return 5;
+    if (f1 != f3) return 6;
     for (uint32_t p = 0; p < nbatch; p++) {
         status_out[p] = (uint8_t)s1[p];
         memcpy(ts_out208 + (size_t)p * 208, &t1[(size_t)p * BP_TS_WORDS], 200);
@@ -257,13 +264,19 @@ int h_rp_transcript_compare_per_proof(uint32_t n, uint32_t m, uint32_t nbatch, c
     const rp_fields fl = rp_field_layout(k, m);
     const size_t nf = (size_t)fl.count * nbatch * BP_RP_REC + 8;
     std::vector<uint32_t> f1(nf, 0xabababab), f2(nf, 0xabababab), s1(nbatch + 1, 0), s2(nbatch + 1, 0), t1((size_t)nbatch * BP_TS_WORDS, 7), t2((size_t)nbatch * BP_TS_WORDS, 7);
+    std::vector<uint32_t> f3(nf, 0xabababab), s3(nbatch + 1, 0), t3((size_t)nbatch * BP_TS_WORDS, 7);
     rp_seg_tab none; memset(&none, 0, sizeof none);
     for (uint32_t p = 0; p < nbatch; p++) {
         uint32_t w1[50], w2[50]; kstate st1, st2; st1.w = w1; st1.stride = 1; st2.w = w2; st2.stride = 1;
         const rp_inputs in = rp_resolve(p, sh, proofs, commitments, rng64, none);
         rp_transcript_thread(p, sh, init, st1, in, f1.data(), s1.data(), BP_TS_DOMSEP, ts_in.data(), t1.data());
         rp_transcript_scripted(p, sh, init, st2, in, script, f2.data(), s2.data(), t2.data(), ts_in.data());
+        uint32_t w3[52]; kstate st3; st3.w = w3; st3.stride = 1;
+        rp_transcript_scripted_coop(p, true, 0, sh, init, st3, in, script, f3.data(), s3.data(), t3.data(), ts_in.data());
     }
+    if (s1 != s3) return 4;
+    if (t1 != t3) return 5;
+    if (f1 != f3) return 6;
     for (uint32_t p = 0; p < nbatch; p++) {
         status_out[p] = (uint8_t)s1[p];
         memcpy(ts_out208 + (size_t)p * 208, &t1[(size_t)p * BP_TS_WORDS], 200);
@@ -277,6 +290,17 @@ int h_rp_transcript_compare_per_proof(uint32_t n, uint32_t m, uint32_t nbatch, c
     return 0;
 }
 
+// Keccak-f[1600] through the 25-lane phase functions (keccak.h: keccak_f1600_masked_coop's host twin) and through the serial form,
+// with an optional XOR mask on the first nmask words: out_coop / out_serial = the permuted 200-byte states
+void h_keccak_coop(const uint8_t *state200, const uint32_t *mask, uint32_t nmask, uint8_t *out_coop, uint8_t *out_serial) {
+    uint32_t a[50], b[50];
+    memcpy(a, state200, 200); memcpy(b, state200, 200);
+    kstate sa, sb; sa.w = a; sa.stride = 1; sb.w = b; sb.stride = 1;
+    uint32_t zero[RS_MASK_WORDS] = {0};
+    keccak_f1600_masked_coop(sa, mask ? mask : zero, mask ? nmask : 0, 0);
+    keccak_f1600_masked(sb, mask ? mask : zero, mask ? nmask : 0);
+    memcpy(out_coop, a, 200); memcpy(out_serial, b, 200);
+}
 void h_merlin_kat(const uint8_t *label, uint32_t label_len, const uint8_t *mlabel, uint32_t mlabel_len, const uint8_t *msg, uint32_t msg_len,
                   const uint8_t *clabel, uint32_t clabel_len, uint8_t *out, uint32_t out_len) {
     uint32_t w[50]; kstate st; st.w = w; st.stride = 1;

@@ -837,3 +837,21 @@ def test_share_audit_lane_by_lane(H, oracle, n, m):
             assert chk.raw[64 * k:64 * k + 32] == out[:32], k
         if out[32:] != b"\xff" * 32:
             assert chk.raw[64 * k + 32:64 * k + 64] == out[32:], k
+
+
+def test_keccak_on_25_lanes_equals_the_serial_permutation_and_sha3(H):
+    """keccak.h: Keccak-f[1600] with one 64-bit state word per lane of a 32-lane group (option transcript_coop: narrow chains replay
+    their transcripts 32 lanes per proof) -- four exchange phases per round, each run here on a snapshot of the 25 lanes' values with
+    the kernels' own phase functions (rho offsets, the pi source table, neighbour indices).  == the serial permutation on random
+    states with and without a 42-word XOR mask; the serial one is pinned on SHA3 / SHAKE vectors elsewhere in this file, and on the
+    all-zero state's published first output lane here."""
+    z_c, z_s = C.create_string_buffer(200), C.create_string_buffer(200)
+    H.h_keccak_coop(bytes(200), None, 0, z_c, z_s)
+    assert z_c.raw == z_s.raw and z_c.raw[:8] == bytes.fromhex("e7dde140798f25f1")      # Keccak-f[1600](0): first lane F1258F7940E1DDE7
+    for i in range(40):
+        st = hashlib.shake_256(b"kc%d" % i).digest(200)
+        mask = (C.c_uint32 * 42)(*[int.from_bytes(hashlib.shake_256(b"km%d-%d" % (i, q)).digest(4), "little") for q in range(42)])
+        for nm, mk in ((0, None), (42, mask), (7, mask)):
+            a, b = C.create_string_buffer(200), C.create_string_buffer(200)
+            H.h_keccak_coop(st, mk, nm, a, b)
+            assert a.raw == b.raw and a.raw != st, (i, nm)
