@@ -99,6 +99,8 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
  *                           of >= 2048 proofs; measured +1 % steady, -4 % on bursts)
  *   "split_stage3"          -1 (default): the window sums as their own launch on chains of >= 2048 proofs; 0 / 1: never / always
  *   "split_stage1"          1..3: point decoding as its own launch on the second stream (experiment, default 0)
+ *   "transcript_coop"       1 (default): launch chains of up to 256 proofs replay their transcripts 32 lanes per proof (Keccak-f[1600]
+ *                           with one state word per lane: one blocking call of 1 proof 0.62 -> 0.53 ms); 0: one lane per proof everywhere
  * get_option additionally answers "fixed_table_bytes" and the effective "fixed_window_bits".
  * Returns BPGPU_ERR_INVALID_ARG for unknown keys. */
 int bpgpu_ctx_set_option(bpgpu_ctx *ctx, const char *key, int64_t value);
