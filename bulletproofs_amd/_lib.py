@@ -30,6 +30,7 @@ EXPORTS = [
     "bpgpu_pool_rangeproof_verify_ts", "bpgpu_pool_rangeproof_submit_ts", "bpgpu_pool_ticket_done", "bpgpu_pool_ticket_wait",
     "bpgpu_pool_rangeproof_submit_dev_ex", "bpgpu_pool_ticket_stream_wait", "bpgpu_pool_rangeproof_submit_rlc_dev",
     "bpgpu_gens_add_shape", "bpgpu_pool_gens_add_shape", "bpgpu_pool_gather_dev",
+    "bpgpu_pool_msm_batch_shared", "bpgpu_pool_msm_batch_shared_submit", "bpgpu_pool_msm_batch", "bpgpu_pool_ipp_verify", "bpgpu_pool_trace_dump",
 ]
 
 TRANSCRIPT_BYTES = 208
@@ -118,6 +119,11 @@ def lib():
     L.bpgpu_pool_ticket_stream_wait.argtypes = [vp, vp, vp]
     L.bpgpu_pool_gather_dev.argtypes = [vp, i, C.POINTER(vp), C.POINTER(sz), vp, vp]
     L.bpgpu_pool_rangeproof_submit_rlc_dev.argtypes = [vp, i, sz, sz, sz, vp, sz, vp, u8p, sz, vp, vp, vp, vp, i, C.POINTER(vp)]
+    L.bpgpu_pool_msm_batch_shared.argtypes = [vp, sz, sz, sz, sz, u8p, u8p, u8p, u8p, u8p]
+    L.bpgpu_pool_msm_batch_shared_submit.argtypes = [vp, sz, sz, sz, sz, u8p, u8p, u8p, u8p, u8p, C.POINTER(vp)]
+    L.bpgpu_pool_msm_batch.argtypes = [vp, sz, C.POINTER(C.c_uint32), u8p, u8p, u8p, u8p]
+    L.bpgpu_pool_ipp_verify.argtypes = [vp, sz, sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
+    L.bpgpu_pool_trace_dump.argtypes = [vp, C.c_char_p]
     L.bpgpu_pool_ticket_done.argtypes = [vp, vp]
     L.bpgpu_pool_ticket_wait.argtypes = [vp, vp]
     L.bpgpu_pool_flush.argtypes = [vp]
@@ -594,6 +600,36 @@ class Pool:
 
     def wait(self):
         self._chk(self._L.bpgpu_pool_wait(self.h))
+
+    # ---- the boundary function through the combining queue (blocking, any number of threads) ----
+    def msm_batch_shared(self, n, m, nbatch, n_unique, gen_scalars, uniq_scalars, uniq_points):
+        """optional_multiscalar_mul in the mega-check shape, one call per MSM (or a few) from any thread (bpgpu_pool_msm_batch_shared)."""
+        assert len(gen_scalars) == 32 * (2 * n * m + 2) * nbatch
+        assert len(uniq_scalars) == len(uniq_points) == 32 * n_unique * nbatch
+        out, st = C.create_string_buffer(32 * max(nbatch, 1)), C.create_string_buffer(max(nbatch, 1))
+        self._chk(self._L.bpgpu_pool_msm_batch_shared(self.h, n, m, nbatch, n_unique, gen_scalars, uniq_scalars, uniq_points, out, st))
+        return out.raw[:32 * nbatch], st.raw[:nbatch]
+
+    def msm_batch(self, n_terms, scalars, points):
+        """a ragged batch of multiscalar multiplications (bpgpu_pool_msm_batch): MSMs of equal length share launch chains."""
+        nb = len(n_terms)
+        assert len(scalars) == len(points) == 32 * sum(n_terms)
+        nt = (C.c_uint32 * max(nb, 1))(*n_terms)
+        out, st = C.create_string_buffer(32 * max(nb, 1)), C.create_string_buffer(max(nb, 1))
+        self._chk(self._L.bpgpu_pool_msm_batch(self.h, nb, nt, scalars, points, out, st))
+        return out.raw[:32 * nb], st.raw[:nb]
+
+    def ipp_verify(self, n, proofs, proof_len, label, Gf, Hf, P, Q, G, H, want_msm=False):
+        """InnerProductProof::verify for len(proofs) / proof_len proofs through the queue (bpgpu_pool_ipp_verify)."""
+        nb = len(proofs) // proof_len if proof_len else 0
+        assert len(Gf) == len(Hf) == len(G) == len(H) == 32 * n * nb and len(P) == len(Q) == 32 * nb
+        verdict = C.create_string_buffer(max(nb, 1))
+        msm = C.create_string_buffer(32 * max(nb, 1)) if want_msm else None
+        self._chk(self._L.bpgpu_pool_ipp_verify(self.h, n, nb, proofs, proof_len, label, len(label), Gf, Hf, P, Q, G, H, verdict, msm))
+        return (verdict.raw[:nb], msm.raw[:32 * nb]) if want_msm else verdict.raw[:nb]
+
+    def trace_dump(self, path):
+        self._chk(self._L.bpgpu_pool_trace_dump(self.h, path.encode()))
 
     # ---- instrumentation (per lane context) ----
     def _lanes(self, every=1):

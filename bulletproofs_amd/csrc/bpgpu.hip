@@ -2143,9 +2143,10 @@ void bpgpu_internal_set_busy_hint(bpgpu_ctx *c, int busy) {
 }
 // one coalesced launch chain over the concatenation of `nseg` items, on the context's own stream (asynchronous)
 // rlc: ONE batch-combined check over all items (bpgpu_pool_rangeproof_submit_rlc_dev); any_msm then means "some item wants the 33-byte result"
-int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, const uint8_t *label, size_t label_len, const rp_seg *segs,
+int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, const uint8_t *const *labels, size_t label_len, const rp_seg *segs,
                                   uint32_t nseg, bool any_msm, uint32_t splits_hint, int busy, bool rlc) {
-    if (!c || !segs || nseg == 0) return BPGPU_ERR_INVALID_ARG;
+    if (!c || !segs || nseg == 0 || !labels) return BPGPU_ERR_INVALID_ARG;
+    const uint8_t *label = labels[0];
     const size_t total = (size_t)segs[nseg - 1].first + segs[nseg - 1].count;
     bool any_rng_missing = false;
     for (uint32_t i = 0; i < nseg; i++) any_rng_missing = any_rng_missing || !segs[i].rng64;

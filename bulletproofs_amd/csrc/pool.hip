@@ -57,7 +57,7 @@ static inline uint64_t now_ns() {
 bool bpgpu_internal_rp_coalescible(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len);
 bool bpgpu_internal_idle(bpgpu_ctx *c);
 void bpgpu_internal_set_busy_hint(bpgpu_ctx *c, int busy);
-int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, const uint8_t *label, size_t label_len, const rp_seg *segs,
+int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, const uint8_t *const *labels, size_t label_len, const rp_seg *segs,
                                   uint32_t nseg, bool any_msm, uint32_t splits_hint, int busy, bool rlc);
 void *bpgpu_internal_stream(bpgpu_ctx *c);
 int bpgpu_internal_rp_reserve(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, size_t nbatch_max);
@@ -85,40 +85,63 @@ struct hwq_init {
 // How many streams' kernels overlap on this device right now?  Sixteen streams get one single-wavefront kernel each that spins
 // for ~1 ms (long against the launch overhead of sixteen launches); with q hardware queues the batch takes ceil(16 / q) x 1 ms.  (Used by bpgpu_pool_create when the library itself
 // set GPU_MAX_HW_QUEUES at load time: the variable then says nothing about what the runtime read.)
+#ifndef BPGPU_POOL_HOST_TEST
 __global__ void k_pool_spin(uint64_t ticks, uint32_t *sink) {
     const uint64_t t0 = wall_clock64();
     uint32_t x = 0;
     while (wall_clock64() - t0 < ticks) x++;
     if (ticks == ~0ull) *sink = x;
 }
+// Advisory: a device shared with another tenant queues the spin kernels behind foreign work and can read low although
+// sixteen queues exist -- the caller (bpgpu_pool_create) only refuses when a second measurement agrees.  The calling thread's current
+// device is put back; the tick count comes from the device's wall-clock rate.
 static int probe_hw_queues(int device) {
+    int prev = -1;
+    (void)hipGetDevice(&prev);
     if (hipSetDevice(device) != hipSuccess) return -1;
+    struct restore {
+        int prev;
+        ~restore() {
+            if (prev >= 0) (void)hipSetDevice(prev);
+        }
+    } put_back{prev};
+    int khz = 0;
+    if (hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, device) != hipSuccess || khz <= 0) khz = 100000;   // (gfx950: 100 MHz)
     const int NS = 16;
     hipStream_t st[NS];
     for (int i = 0; i < NS; i++)
         if (hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking) != hipSuccess) return -1;
-    const uint64_t ticks = 100000;   // wall_clock64: 100 MHz -> 1 ms
+    const uint64_t ticks = (uint64_t)khz;   // 1 ms
     double best = 1e30;
     for (int rep = 0; rep < 3; rep++) {   // the first round also pays for loading the code object
-        for (int i = 0; i < NS; i++) hipStreamSynchronize(st[i]);
+        for (int i = 0; i < NS; i++) (void)hipStreamSynchronize(st[i]);
         const uint64_t t0 = now_ns();
         for (int i = 0; i < NS; i++) hipLaunchKernelGGL(k_pool_spin, dim3(1), dim3(64), 0, st[i], ticks, (uint32_t *)nullptr);
-        for (int i = 0; i < NS; i++) hipStreamSynchronize(st[i]);
+        for (int i = 0; i < NS; i++) (void)hipStreamSynchronize(st[i]);
         const double us = (double)(now_ns() - t0) / 1000.0;
         if (us < best) best = us;
     }
-    for (int i = 0; i < NS; i++) hipStreamDestroy(st[i]);
+    for (int i = 0; i < NS; i++) (void)hipStreamDestroy(st[i]);
     if (hipGetLastError() != hipSuccess) return -1;
     const double rounds = best / 1000.0;   // ~1 with >= 16 queues, ~2 with 8, ~4 with 4
     int q = (int)(16.0 / (rounds < 1.0 ? 1.0 : rounds) + 0.5);
     return q < 1 ? 1 : q;
 }
+#else
+static int probe_hw_queues(int) { return 16; }   // (host test build: tests/cpu_pool, no device code)
+#endif
 
 namespace {
 
 // std::atomic<uint32_t> as a futex word (C++17: no atomic::wait yet)
 inline void futex_wait(std::atomic<uint32_t> *a, uint32_t expected) { syscall(SYS_futex, (uint32_t *)a, FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0); }
 inline void futex_wake_all(std::atomic<uint32_t> *a) { syscall(SYS_futex, (uint32_t *)a, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
+inline void futex_wait_ns(std::atomic<uint32_t> *a, uint32_t expected, uint64_t ns) {   // relative timeout
+    timespec ts;
+    ts.tv_sec = (time_t)(ns / 1000000000ull);
+    ts.tv_nsec = (long)(ns % 1000000000ull);
+    syscall(SYS_futex, (uint32_t *)a, FUTEX_WAIT_PRIVATE, expected, &ts, nullptr, 0);
+}
 
 // (the batching challenge's randomness when the caller brings none: hostrng.h)
 using bp::fast_random;
@@ -153,77 +176,149 @@ struct dev_item {   // a submitted device-pointer batch waiting for the next flu
 };
 
 // ---- combining queue ---------------------------------------------------------------------------------------------------
-// What a launch chain can share: the shape, and how its transcripts start --
+// Kinds of work the queue combines (one staging-buffer class never mixes kinds):
+//   CQ_RP          range proofs, proof bytes -> verdict (bpgpu_pool_rangeproof_verify[_ts], _submit_ts)
+//   CQ_MSM_SHARED  optional_multiscalar_mul in its mega-check shape: 2nm+2 generator scalars + n_unique (scalar, point) pairs per MSM
+//                  (bpgpu_pool_msm_batch_shared; src/range_proof/mod.rs:421-445, src/r1cs/verifier.rs:459-491)
+//   CQ_MSM         the same call with arbitrary points, all MSMs of a buffer `n_terms` terms long (bpgpu_pool_msm_batch; ipp.rs:308-319)
+//   CQ_IPP         InnerProductProof::verify (bpgpu_pool_ipp_verify; ipp.rs:260-326)
+enum { CQ_RP = 0, CQ_MSM_SHARED = 1, CQ_MSM = 2, CQ_IPP = 3 };
+// What a range-proof chain can share beside the shape: how its transcripts start --
 //   CK_SHARED  every proof from ONE 208-byte state (Transcript::new(label) of a common label, or a transcript the callers
 //              share), no states handed back: nothing per proof to upload;
 //   CK_UNIFORM one state per proof in / out, all at the same STROBE position (pos, pos_begin, cur_flags): the per-shape script
 //              (rp_script.h) still applies, only the sponge words differ;
 //   CK_MIXED   one state per proof at whatever position: the byte-wise replay.  Catch-all when too many position classes are open.
 enum { CK_SHARED = 0, CK_UNIFORM = 1, CK_MIXED = 2 };
-struct comb_key {
-    uint32_t n = 0, m = 0, proof_len = 0, mode = 0;
-    uint32_t pos = 0, pos_begin = 0, flags = 0;      // CK_UNIFORM
-    uint8_t shared[BPGPU_TRANSCRIPT_BYTES] = {0};    // CK_SHARED
-    bool operator==(const comb_key &o) const {
-        if (n != o.n || m != o.m || proof_len != o.proof_len || mode != o.mode) return false;
-        if (mode == CK_UNIFORM) return pos == o.pos && pos_begin == o.pos_begin && flags == o.flags;
-        if (mode == CK_SHARED) return memcmp(shared, o.shared, sizeof shared) == 0;
-        return true;
-    }
+#define CQ_MAX_IN 7
+#define CQ_MAX_OUT 3
+struct comb_key {   // compared bytewise: no padding, unused fields zero
+    uint32_t kind = 0, mode = 0;
+    uint32_t a = 0, b = 0, c = 0, d = 0;   // CQ_RP: n, m, proof_len | CQ_MSM_SHARED: n, m, n_unique | CQ_MSM: n_terms | CQ_IPP: n, proof_len
+    uint32_t pos = 0, pos_begin = 0, flags = 0, pad = 0;   // CK_UNIFORM
+    uint8_t shared[BPGPU_TRANSCRIPT_BYTES] = {0};          // CK_SHARED / CQ_IPP: the common start state
+    bool operator==(const comb_key &o) const { return memcmp(this, &o, sizeof *this) == 0; }
 };
+static_assert(sizeof(comb_key) == 40 + BPGPU_TRANSCRIPT_BYTES, "comb_key must have no padding");
+
+// bytes per item of every input / output region of a class.  The LAST input region is the one a partly filled buffer copies by
+// fill; regions of size 0 do not exist for the class.
+struct comb_regions {
+    uint32_t n_in = 0, n_out = 0, fail_out = 0;   // fail_out: the output region that receives BPGPU_VERDICT_UNDECIDED when the chain failed
+    size_t in_sz[CQ_MAX_IN] = {0}, out_sz[CQ_MAX_OUT] = {0};
+};
+enum { RP_IN_COMS = 0, RP_IN_RNG = 1, RP_IN_TS = 2, RP_IN_PROOFS = 3, RP_OUT_VERDICT = 0, RP_OUT_TS = 1, RP_OUT_MSM = 2 };
+static comb_regions regions_of(const comb_key &k) {
+    comb_regions g;
+    const size_t TS = BPGPU_TRANSCRIPT_BYTES;
+    if (k.kind == CQ_RP) {
+        const bool per = k.mode != CK_SHARED;
+        g.n_in = 4, g.n_out = 3, g.fail_out = RP_OUT_VERDICT;
+        g.in_sz[RP_IN_COMS] = (size_t)k.b * 32, g.in_sz[RP_IN_RNG] = 64, g.in_sz[RP_IN_TS] = per ? TS : 0, g.in_sz[RP_IN_PROOFS] = k.c;
+        g.out_sz[RP_OUT_VERDICT] = 1, g.out_sz[RP_OUT_TS] = per ? TS : 0, g.out_sz[RP_OUT_MSM] = 32;
+    } else if (k.kind == CQ_MSM_SHARED) {
+        g.n_in = 3, g.n_out = 2, g.fail_out = 1;
+        g.in_sz[0] = (size_t)k.c * 32, g.in_sz[1] = (size_t)k.c * 32, g.in_sz[2] = ((size_t)2 * k.a * k.b + 2) * 32;   // unique scalars, unique points, generator scalars (the largest: last)
+        g.out_sz[0] = 32, g.out_sz[1] = 1;
+    } else if (k.kind == CQ_MSM) {
+        g.n_in = 2, g.n_out = 2, g.fail_out = 1;
+        g.in_sz[0] = (size_t)k.a * 32, g.in_sz[1] = (size_t)k.a * 32;   // scalars, points
+        g.out_sz[0] = 32, g.out_sz[1] = 1;
+    } else {   // CQ_IPP
+        g.n_in = 7, g.n_out = 2, g.fail_out = 0;
+        g.in_sz[0] = 32, g.in_sz[1] = 32, g.in_sz[2] = k.b;                                // P, Q, proof
+        g.in_sz[3] = g.in_sz[4] = g.in_sz[5] = g.in_sz[6] = (size_t)k.a * 32;             // G_factors, H_factors, G, H
+        g.out_sz[0] = 1, g.out_sz[1] = 32;
+    }
+    return g;
+}
 
 struct comb_req;
 enum { CB_FREE = 0, CB_OPEN, CB_SEALED, CB_ISSUING, CB_ISSUED, CB_DONE };
-// One staging buffer + the lane that runs its chain.  Inputs [proofs | commitments | rng | transcripts in] and outputs
-// [verdicts | transcripts out | encodings] sit at the same offsets of a pinned host block and of a device block.
+// The reservation word of a staging buffer: [epoch : 32 | sealed : 1 | reserved : 31].  A caller takes slots with ONE compare-and-swap
+// (no lock): it succeeds only on the incarnation (`epoch`) the caller looked at, only while that is unsealed, and never past `cap`.
+// The service thread seals with a fetch_or; the count it reads back is the chain's final width.  A FREE buffer keeps the sealed bit.
+static constexpr uint64_t CBS_SEALED = 1ull << 31;
+static inline uint32_t cbs_epoch(uint64_t s) { return (uint32_t)(s >> 32); }
+static inline uint32_t cbs_reserved(uint64_t s) { return (uint32_t)(s & 0x7fffffffu); }
+static inline bool cbs_sealed(uint64_t s) { return (s & CBS_SEALED) != 0; }
+static inline uint64_t cbs_pack(uint32_t epoch, bool sealed, uint32_t reserved) { return ((uint64_t)epoch << 32) | (sealed ? CBS_SEALED : 0) | reserved; }
+
+// one timeline record per launch chain of the combining queue (option "combine_trace"; bpgpu_pool_trace_dump)
+struct chain_ev {
+    uint32_t buf = 0, epoch = 0, K = 0, kind = 0, n_sync = 0, n_async = 0, inflight = 0, cap = 0;
+    uint64_t t_open = 0, t_seal = 0, t_issue0 = 0, t_issue1 = 0, t_done = 0, t_deliv0 = 0, t_deliv1 = 0, t_free = 0;
+};
+struct req_ev {   // one sampled request
+    uint32_t buf = 0, epoch = 0, async = 0, nbatch = 0;
+    uint64_t t_submit = 0, t_reserved = 0, t_written = 0, t_delivered = 0, t_woken = 0;
+};
+
+// One staging buffer + the lane that runs its chain.  Input regions and output regions sit at the same offsets of a pinned host
+// block and of a device block.
 struct comb_buf {
     pool_dev *dev = nullptr;
     bpgpu_ctx *ctx = nullptr;
-    std::atomic<int> poison{0};
-    uint32_t reserved_n = 0, reserved_m = 0, reserved_len = 0, reserved_cap = 0;   // shape / width the lane's buffers were last sized for
+    uint32_t index = 0;
+    uint32_t reserved_n = 0, reserved_m = 0, reserved_len = 0, reserved_cap = 0;   // (CQ_RP) shape / width the lane's buffers were last sized for
     hipEvent_t done_ev = nullptr;
-    char *h = nullptr, *d = nullptr;
+    char *h = nullptr, *d = nullptr, *hd = nullptr;   // pinned host block, device block, the host block as the device sees it (may be null)
     size_t mem_cap = 0;
+    // ---- written by the opener (under pool_dev::cmu, buffer FREE), published by the release store of `state`; stable until FREE again
     comb_key key;
-    uint32_t cap = 0, cap_max = 0;
-    size_t off_p = 0, off_c = 0, off_r = 0, off_t = 0, in_bytes = 0, off_v = 0, off_to = 0, off_m = 0, total = 0;
-    int st = CB_FREE;                       // under pool_dev::cmu
-    uint32_t reserved = 0;                  // proofs handed out (under cmu)
-    std::atomic<uint32_t> written{0};       // proofs whose inputs are in place
-    std::atomic<uint32_t> refs{0};          // pieces whose results have not been taken yet
-    std::atomic<uint32_t> phase{0};         // futex word: 0 until the chain's results are in `h`
-    bool any_msm = false;
-    uint64_t t_first = 0, t_last = 0;       // arrival of the first / the latest piece (ns)
-    int rc = 0;
-    std::string err;
-    struct apiece {
+    comb_regions reg;
+    std::atomic<uint64_t> class_id{0};
+    std::atomic<uint32_t> cap{0};
+    uint32_t cap_max = 0;
+    size_t in_off[CQ_MAX_IN] = {0}, out_off[CQ_MAX_OUT] = {0}, in_end = 0, total = 0;
+    uint64_t t_open = 0;
+    struct piece_desc {   // written by the caller that reserved slots [first, first + count) at index `first`, before it counts itself into `written`
         comb_req *req;
-        uint32_t first, count;
+        uint32_t count, async;
         size_t off;
     };
-    std::vector<apiece> async_pieces;       // pieces of tickets: delivered by the service thread
+    std::vector<piece_desc> desc;
+    // ---- shared between callers, the service thread and the deliverers
+    std::atomic<uint64_t> state{CBS_SEALED};
+    std::atomic<int> st{CB_FREE};
+    std::atomic<uint32_t> written{0};       // items whose inputs are in place
+    std::atomic<uint32_t> delivered{0};     // items whose results have been taken; the deliverer that completes K returns the buffer
+    std::atomic<uint32_t> phase{0};         // futex word: epoch of the latest incarnation whose results are in `h`
+    std::atomic<uint32_t> n_sync{0}, n_async{0};   // pieces of blocking callers / of tickets
+    std::atomic<uint32_t> want_opt{0};      // some request wants the optional output region (encodings)
+    std::atomic<int> poison{0};
+    // ---- service thread only (and, after `phase`, whoever delivers)
+    uint32_t K = 0;                         // final width
+    uint32_t seen_reserved = 0, seen_epoch = 0;
+    uint64_t t_change = 0;                  // when `reserved` was last seen to move (quiet detection)
+    int rc = 0;
+    std::string err;
+    chain_ev ev;
 };
 
-// one call (bpgpu_pool_rangeproof_verify_ts) or one ticket (bpgpu_pool_rangeproof_submit_ts)
+// one call (bpgpu_pool_rangeproof_verify_ts, bpgpu_pool_msm_batch_shared, ...) or one ticket (bpgpu_pool_rangeproof_submit_ts)
 struct comb_req {
     uint32_t kind = TK_COMBINE;   // (first member of both ticket types)
-    size_t n = 0, m = 0, nbatch = 0, proof_len = 0;
-    const uint8_t *proofs = nullptr, *coms = nullptr, *rng = nullptr, *ts_in = nullptr;   // ts_in: per proof, or null (key.shared)
-    uint8_t *verdict = nullptr, *msm = nullptr, *ts_out = nullptr;
+    size_t nbatch = 0;
+    uint8_t *out[CQ_MAX_OUT] = {nullptr, nullptr, nullptr};   // per item, strides = the class's output region sizes
     bool async = false;
     struct piece {
         comb_buf *b;
-        uint32_t first, count;
+        uint32_t epoch, first, count;
         size_t off;
     };
-    std::vector<piece> pieces;              // synchronous calls: collected by the caller itself
+    std::vector<piece> pieces;              // blocking calls: collected by the caller itself
     size_t next_piece = 0;
-    std::atomic<uint32_t> left{1};          // tickets: pieces not delivered yet (+1 while the request is being placed); futex word
-    std::atomic<uint32_t> waiting{0};
-    std::mutex emu;                         // guards rc / err of a ticket (service thread vs. caller)
+    // tickets: [waiting : 1 | pieces not delivered yet, +1 while the request is being placed : 31]; futex word.  The deliverer's last
+    // access to the request is its fetch_sub.
+    std::atomic<uint32_t> left{1};
+    std::mutex emu;                         // guards rc / err (several deliverers may report errors)
     int rc = 0;
     std::string err;
+    req_ev ev;
+    bool traced = false;
 };
+static constexpr uint32_t TKT_WAITING = 1u << 31;
 
 struct pool_dev {
     int device = 0;
@@ -240,24 +335,46 @@ struct pool_dev {
     std::condition_variable tcv;
     bool stop = false;
     // combining queue: its own lanes (a lane whose staging buffer callers are writing into cannot take a flush's chain meanwhile),
-    // one service thread (seals buffers by deadline, issues their chains, notices completions), one context for the requests no
-    // chain can take (malformed lengths, parameter errors: reported per proof by the ordinary entry point)
+    // one service thread (seals buffers by policy, issues their chains, notices completions), one delivery thread (hands tickets
+    // their results), one context for the requests no chain can take (malformed lengths, parameter errors: reported per proof by
+    // the ordinary entry point)
     std::vector<comb_buf *> cbufs;
     bpgpu_ctx *misc = nullptr;
     std::mutex misc_mu;
-    std::mutex cmu;
-    std::condition_variable ccv, free_cv;
-    std::thread svc;
+    std::mutex cmu;                         // opening / freeing buffers, the class table; NOT taken to reserve slots in an open buffer
+    std::condition_variable free_cv;
+    // the service thread's doorbell: callers that open a buffer or take its last slot bump `kick` (and wake the thread if it sleeps);
+    // the thread reads `kick` before it looks at the buffers and sleeps only while the word still holds that value
+    std::atomic<uint32_t> kick{0}, svc_sleeping{0};
+    std::atomic<uint32_t> free_waiters{0};  // callers asleep on free_cv (counted in under cmu)
+    std::thread svc, dlv;
     bool svc_running = false, cstop = false;
-    uint64_t stat_chains = 0, stat_proofs = 0, stat_requests = 0;
-    uint64_t stat_issue_ns = 0, stat_complete_ns = 0, stat_polls = 0;   // service thread: time spent issuing / completing, loop count
-    uint32_t recent_K = 0;                  // width of the chain issued last (sizes the next buffer, comb_place)
+    struct cls_ent {
+        comb_key key;
+        uint64_t id, last_use;
+    };
+    std::vector<cls_ent> classes;           // interned class keys (under cmu); ids are never reused
+    uint64_t next_class_id = 1, class_tick = 0;
+    std::mutex dq_mu;                       // delivery queue: finished buffers that carry pieces of tickets
+    std::condition_variable dq_cv;
+    std::deque<comb_buf *> dq;
+    bool dstop = false;
+    std::atomic<uint64_t> stat_chains{0}, stat_proofs{0}, stat_requests{0};
+    std::atomic<uint64_t> stat_issue_ns{0}, stat_complete_ns{0}, stat_polls{0}, stat_deliver_ns{0};
+    std::atomic<uint32_t> recent_K{0};      // width of the chain issued last (sizes the next buffer)
+    std::mutex trace_mu;
+    std::vector<chain_ev> trace_chains;     // rings (option "combine_trace")
+    std::vector<req_ev> trace_reqs;
+    size_t trace_chain_n = 0, trace_req_n = 0;
 };
 
 }  // namespace
 
+static std::atomic<uint64_t> g_pool_uid{1};   // (a pool created at the address of a destroyed one is still another pool: per-thread caches key on this)
+
 struct bpgpu_pool {
     std::vector<pool_dev *> devs;
+    const uint64_t uid = g_pool_uid.fetch_add(1);
     std::mutex mu;        // serialises the pool's own state (pending lists, options); lane contexts have their own locks
     size_t coalesce_proofs = 5120;   // target width of a coalesced launch chain
     size_t pair_limit_proofs = 24576;   // a flush of up to this many proofs is issued as at most two chains (flush_dev)
@@ -268,6 +385,7 @@ struct bpgpu_pool {
     size_t auto_flush_proofs = 0;    // ... or once this many proofs wait: they go out as ONE chain while the caller keeps submitting (0 = off)
     size_t host_workers = 0;
     // combining queue
+    std::atomic<uint32_t> comb_cap_max{5120};         // = coalesce_proofs (readable without `mu`)
     std::atomic<uint64_t> combine_wait_ns{100000};    // a buffer leaves at the latest this long after its first proof arrived ...
     std::atomic<uint64_t> combine_quiet_ns{20000};    // ... or when nothing has joined it for this long
     std::atomic<uint64_t> combine_poll_ns{15000};     // the service thread's polling period while anything is open or in flight
@@ -275,9 +393,19 @@ struct bpgpu_pool {
     std::atomic<uint32_t> combine_busy_chains{2};     // a chain issued beside this many others (in flight or waiting) takes the throughput forms
     std::atomic<uint32_t> combine_inflight{6};        // deadlines seal buffers only while fewer chains than this are in flight: beyond, load widens the chains
     std::atomic<uint64_t> combine_max_age_ns{1500000}; // ... but no proof waits longer than this for its chain to be issued
+    // throughput regime (the chains in flight average >= combine_wide_proofs): fewer, wider chains -- at most combine_inflight_wide run,
+    // the time deadline is combine_hold_us instead of combine_wait_us, and a burst smaller than half of what runs waits for company
+    std::atomic<uint32_t> combine_wide_proofs{384};
+    std::atomic<uint32_t> combine_inflight_wide{3};
+    std::atomic<uint64_t> combine_hold_ns{400000};
+    std::atomic<uint64_t> combine_msm_bytes{32u << 20};   // staging block of a multiscalar-multiplication class (bpgpu_pool_msm_*): items per chain = this / bytes per MSM
+    std::atomic<uint32_t> combine_mapped_out{1024};   // chains of up to this many proofs write their results straight into the pinned host block (no copy command behind the chain)
+    std::atomic<uint32_t> combine_trace{0};           // ring sizes of the timeline records (0 = off)
     std::atomic<int> host_path{1};                    // bpgpu_pool_rangeproof_verify: 1 = through the combining queue, 0 = the slicing workers of round 3
     std::atomic<uint32_t> rr_dev{0};
-    std::atomic<uint64_t> gens_epoch{1};
+    std::atomic<uint64_t> gens_epoch{g_pool_uid.fetch_add(1) << 20};   // (process-wide unique: a per-thread "this shape is coalescible" answer never survives into another pool)
+    std::atomic<int> closing{0};                      // bpgpu_pool_destroy has begun: new requests are refused, waiting ones are failed
+    std::atomic<int64_t> active_calls{0};             // threads inside a combining-queue entry point
     // statistics of the coalesced path (get_option "stat_chains" / "stat_chain_proofs" / "stat_last_splits"; set "stat_reset")
     uint64_t stat_chains = 0, stat_chain_proofs = 0, stat_last_splits = 0;
 };
@@ -346,7 +474,12 @@ int bpgpu_pool_create(const int *devices, int ndev, int lanes_per_device, bpgpu_
     if (lanes_per_device > 4 && g_hwq_init.set_by_library) {
         // The variable reads 16 because THIS library set it when it was loaded -- which only counts if the runtime had not read it
         // before (a process that touched HIP first runs on the default 4 queues whatever the variable says now).  Ask the device.
-        const int qs = probe_hw_queues(devices[0]);
+        int qs = probe_hw_queues(devices[0]);
+        if (qs > 0 && qs < 6) {   // a busy or shared device can read low once: only two measurements in a row count
+            usleep(20000);
+            const int again = probe_hw_queues(devices[0]);
+            if (again > qs) qs = again;
+        }
         if (qs > 0 && qs < 6) {   // (4 queues -- the runtime's default -- measure 4 rounds; 8 queues 2; timing noise stays well inside)
             fprintf(stderr, "libbpgpu: GPU_MAX_HW_QUEUES was set by libbpgpu at load time, but HIP had been initialised before: kernels of only "
                             "~%d streams overlap.  Export GPU_MAX_HW_QUEUES=16 before the process's first HIP call.\n", qs);
@@ -375,6 +508,7 @@ int bpgpu_pool_create(const int *devices, int ndev, int lanes_per_device, bpgpu_
                 comb_buf *b = new comb_buf();
                 b->ctx = c;
                 b->dev = d;
+                b->index = (uint32_t)d->cbufs.size();
                 d->cbufs.push_back(b);
                 if (hipSetDevice(devices[i]) != hipSuccess || hipEventCreateWithFlags(&b->done_ev, hipEventDisableTiming) != hipSuccess) {
                     bpgpu_pool_destroy(p);
@@ -387,18 +521,29 @@ int bpgpu_pool_create(const int *devices, int ndev, int lanes_per_device, bpgpu_
     return BPGPU_OK;
 }
 
-static void stop_service(pool_dev *d);
+static void stop_service(bpgpu_pool *p, pool_dev *d);
+static void signal_service_stop(pool_dev *d);
+// May be called while other threads are inside the pool's blocking entry points (or hold unfinished tickets): new requests are
+// refused from now on, requests that wait in a staging buffer are failed (BPGPU_VERDICT_UNDECIDED + an error: nothing reads "verified"),
+// chains already on the device finish and are delivered, every sleeper is woken; the call returns when the last such thread has left.
+// Tickets of the combining queue stay valid (bpgpu_pool_ticket_wait reads only the ticket); tickets of device batches must have
+// been waited for.  Calling INTO the pool after bpgpu_pool_destroy has returned is the caller's bug.
 void bpgpu_pool_destroy(bpgpu_pool *p) {
     if (!p) return;
+    p->closing.store(1, std::memory_order_seq_cst);
+    for (pool_dev *d : p->devs) signal_service_stop(d);
     for (pool_dev *d : p->devs) {
         stop_workers(d);
-        stop_service(d);
+        stop_service(p, d);
+    }
+    while (p->active_calls.load(std::memory_order_acquire) != 0) usleep(50);   // (woken callers are on their way out)
+    for (pool_dev *d : p->devs) {
         for (bpgpu_ctx *c : d->lanes) bpgpu_ctx_destroy(c);
         for (comb_buf *b : d->cbufs) {
             bpgpu_ctx_destroy(b->ctx);   // (synchronises the device: nothing of the buffer is in flight afterwards)
-            if (b->done_ev) hipEventDestroy(b->done_ev);
-            if (b->h) hipHostFree(b->h);
-            if (b->d) hipFree(b->d);
+            if (b->done_ev) (void)hipEventDestroy(b->done_ev);
+            if (b->h) (void)hipHostFree(b->h);
+            if (b->d) (void)hipFree(b->d);
             delete b;
         }
         if (d->misc) bpgpu_ctx_destroy(d->misc);
@@ -424,12 +569,14 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
         if (value < 1 || value > (1 << 20)) return pfail(p, BPGPU_ERR_INVALID_ARG, "coalesce_proofs out of range");
         p->coalesce_proofs = (size_t)value;
         if (p->max_chain_proofs < p->coalesce_proofs) p->max_chain_proofs = p->coalesce_proofs;
+        p->comb_cap_max = (uint32_t)p->coalesce_proofs;
         return BPGPU_OK;
     }
     if (!strcmp(key, "max_chain_proofs")) {
         if (value < 64 || value > (1 << 22)) return pfail(p, BPGPU_ERR_INVALID_ARG, "max_chain_proofs out of range");
         p->max_chain_proofs = (size_t)value;
         if (p->coalesce_proofs > p->max_chain_proofs) p->coalesce_proofs = p->max_chain_proofs;
+        p->comb_cap_max = (uint32_t)p->coalesce_proofs;
         return BPGPU_OK;
     }
     if (!strcmp(key, "slice_proofs")) {
@@ -460,9 +607,8 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
     if (!strcmp(key, "stat_reset")) {
         p->stat_chains = p->stat_chain_proofs = 0;
         for (pool_dev *d : p->devs) {
-            std::lock_guard<std::mutex> g(d->cmu);
             d->stat_chains = d->stat_proofs = d->stat_requests = 0;
-            d->stat_issue_ns = d->stat_complete_ns = d->stat_polls = 0;
+            d->stat_issue_ns = d->stat_complete_ns = d->stat_polls = d->stat_deliver_ns = 0;
         }
         return BPGPU_OK;
     }
@@ -476,9 +622,35 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
         (key[8] == 'b' ? p->combine_busy_chains : p->combine_inflight) = (uint32_t)value;
         return BPGPU_OK;
     }
-    if (!strcmp(key, "combine_max_age_us")) {
+    if (!strcmp(key, "combine_max_age_us") || !strcmp(key, "combine_hold_us")) {
         if (value < 1 || value > 10000000) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
-        p->combine_max_age_ns = (uint64_t)value * 1000;
+        (key[8] == 'm' ? p->combine_max_age_ns : p->combine_hold_ns) = (uint64_t)value * 1000;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "combine_wide_proofs") || !strcmp(key, "combine_mapped_out")) {
+        if (value < 0 || value > (1 << 22)) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
+        (key[8] == 'w' ? p->combine_wide_proofs : p->combine_mapped_out) = (uint32_t)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "combine_inflight_wide")) {
+        if (value < 1 || value > 64) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
+        p->combine_inflight_wide = (uint32_t)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "combine_msm_bytes")) {
+        if (value < (1 << 16) || value > ((int64_t)1 << 32)) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
+        p->combine_msm_bytes = (uint64_t)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "combine_trace")) {   // ring sizes of the timeline records (chains; four times as many sampled requests); 0 = off
+        if (value < 0 || value > (1 << 20)) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
+        for (pool_dev *d : p->devs) {
+            std::lock_guard<std::mutex> g(d->trace_mu);
+            d->trace_chains.assign((size_t)value, chain_ev());
+            d->trace_reqs.assign((size_t)value * 4, req_ev());
+            d->trace_chain_n = d->trace_req_n = 0;
+        }
+        p->combine_trace = (uint32_t)value;
         return BPGPU_OK;
     }
     if (!strcmp(key, "combine_max_open")) {
@@ -527,22 +699,24 @@ int bpgpu_pool_get_option(bpgpu_pool *p, const char *key, int64_t *value) {
     else if (!strcmp(key, "combine_busy_chains")) *value = (int64_t)p->combine_busy_chains;
     else if (!strcmp(key, "combine_inflight")) *value = (int64_t)p->combine_inflight;
     else if (!strcmp(key, "combine_max_age_us")) *value = (int64_t)(p->combine_max_age_ns / 1000);
-    else if (!strcmp(key, "stat_svc_issue_us") || !strcmp(key, "stat_svc_complete_us") || !strcmp(key, "stat_svc_polls")) {
+    else if (!strcmp(key, "combine_hold_us")) *value = (int64_t)(p->combine_hold_ns / 1000);
+    else if (!strcmp(key, "combine_wide_proofs")) *value = (int64_t)p->combine_wide_proofs;
+    else if (!strcmp(key, "combine_inflight_wide")) *value = (int64_t)p->combine_inflight_wide;
+    else if (!strcmp(key, "combine_msm_bytes")) *value = (int64_t)p->combine_msm_bytes;
+    else if (!strcmp(key, "combine_mapped_out")) *value = (int64_t)p->combine_mapped_out;
+    else if (!strcmp(key, "combine_trace")) *value = (int64_t)p->combine_trace;
+    else if (!strcmp(key, "stat_svc_issue_us") || !strcmp(key, "stat_svc_complete_us") || !strcmp(key, "stat_svc_polls") || !strcmp(key, "stat_svc_deliver_us")) {
         uint64_t v = 0;
-        for (pool_dev *d : p->devs) {
-            std::lock_guard<std::mutex> g(d->cmu);
-            v += key[9] == 'i' ? d->stat_issue_ns / 1000 : key[9] == 'c' ? d->stat_complete_ns / 1000 : d->stat_polls;
-        }
+        for (pool_dev *d : p->devs)
+            v += key[9] == 'i' ? d->stat_issue_ns / 1000 : key[9] == 'c' ? d->stat_complete_ns / 1000 : key[9] == 'd' ? d->stat_deliver_ns / 1000 : d->stat_polls.load();
         *value = (int64_t)v;
     }
+    else if (!strcmp(key, "stat_active_calls")) *value = (int64_t)p->active_calls.load();
     else if (!strcmp(key, "combine_lanes")) *value = p->devs.empty() ? 0 : (int64_t)p->devs[0]->cbufs.size();
     else if (!strcmp(key, "host_path_combining")) *value = p->host_path;
     else if (!strcmp(key, "stat_combined_chains") || !strcmp(key, "stat_combined_proofs") || !strcmp(key, "stat_combined_requests")) {
         uint64_t v = 0;
-        for (pool_dev *d : p->devs) {
-            std::lock_guard<std::mutex> g(d->cmu);
-            v += key[14] == 'c' ? d->stat_chains : key[14] == 'p' ? d->stat_proofs : d->stat_requests;
-        }
+        for (pool_dev *d : p->devs) v += key[14] == 'c' ? d->stat_chains.load() : key[14] == 'p' ? d->stat_proofs.load() : d->stat_requests.load();
         *value = (int64_t)v;
     }
     else if (p->devs.empty() || p->devs[0]->lanes.empty()) return BPGPU_ERR_INVALID_ARG;
@@ -731,60 +905,63 @@ int bpgpu_pool_rangeproof_verify(bpgpu_pool *p, size_t n, size_t m, size_t nbatc
 }  // extern "C"
 
 // ---- combining queue -----------------------------------------------------------------------------------------------
-// The reference's API is one proof per call, synchronous, from as many threads as the caller likes
-// (RangeProof::verify_multiple / verify_multiple_with_rng, src/range_proof/mod.rs:345-353, 455-470).  One such call cannot fill a
-// device and a launch chain costs ~0.6 ms of latency however narrow it is, so calls that arrive close together must share a
-// chain.  Per device:
-//   * callers (any thread, short lock): find the OPEN staging buffer of their class (comb_key) or open a free one, reserve slots,
-//     copy their inputs into the pinned block OUTSIDE the lock, count themselves in (`written`);
-//   * the service thread: seals an OPEN buffer when it is full, when its first proof has waited `combine_wait_us`, or when nothing
-//     joined for `combine_quiet_us`; issues a sealed buffer whose writers are done as ONE chain on the buffer's lane (copies in,
-//     bpgpu_internal_rp_verify_chain, copies out, event); polls the events of the chains in flight;
-//   * completion: the buffer's futex word flips, every synchronous caller with a piece in it wakes, takes its own verdicts (and
-//     advanced transcripts) out of the pinned block and drops its reference; the last one returns the buffer.  Pieces of tickets
-//     (bpgpu_pool_rangeproof_submit_ts) are delivered by the service thread.
-// With all lanes busy a buffer simply keeps filling: load widens the chains by itself.
+// The reference's API is one proof (one multiscalar multiplication) per call, synchronous, from as many threads as the caller likes
+// (RangeProof::verify_multiple / verify_multiple_with_rng, src/range_proof/mod.rs:345-353, 455-470; optional_multiscalar_mul at
+// mod.rs:421-445, src/r1cs/verifier.rs:459-491, src/inner_product_proof.rs:308-319).  One such call cannot fill a device and a
+// launch chain costs ~0.5 ms of latency however narrow it is, so calls that arrive close together must share a chain.  Per device:
+//   * callers (any thread): find the open staging buffer of their class and take slots with one compare-and-swap on its
+//     reservation word -- no lock; only opening a buffer for a class that has none takes the device's queue lock --, copy their
+//     inputs into the pinned block, count themselves in (`written`);
+//   * the service thread seals an open buffer by policy (policy_seal: full, quiet, deadline, age; fewer and wider chains once the
+//     ones in flight are wide), issues a sealed buffer whose writers are done as ONE chain on the buffer's lane (copy in, the
+//     chain, results out, event), polls the events of the chains in flight, publishes completions -- and does nothing else: it
+//     never touches a request;
+//   * completion: the buffer's futex word takes the incarnation's number; every blocking caller with a piece in it wakes (one
+//     FUTEX_WAKE per chain), takes its own results out of the pinned block; pieces of tickets are handed over by the DELIVERY
+//     thread (a second thread: issuing the next chain never waits behind a thousand memcpys); whoever takes the last item returns
+//     the buffer.
+// With all chain slots busy a buffer simply keeps filling: load widens the chains by itself.
 static size_t up256(size_t x) { return (x + 255) & ~(size_t)255; }
 
-// Layout of a buffer for `cap` proofs of class `key`.  Inputs: [commitments | rng | transcripts in | proofs] -- the small
-// per-proof records first, sized for `cap`; the proofs last, so that ONE copy [0, off_p + K proof_len) carries a chain of K <= cap
-// proofs (the unused tail of the small regions rides along: a buffer opened under light traffic has a small `cap`, comb_place).
-// Outputs: [verdicts | transcripts out | encodings]: ONE copy [off_v, off_to + 208 K) back.
-static size_t cbuf_layout(comb_buf *b, const comb_key &key, uint32_t cap) {
-    const bool per = key.mode != CK_SHARED;
+// Layout of a buffer for `cap` items of class `key`: every input region sized for `cap`, then every output region.  The regions
+// are ordered small-to-large (regions_of), the largest last, so that a partly filled buffer of a class with small side records
+// travels as ONE copy [0, in_off[last] + K in_sz[last]) (comb_issue decides between that and one copy per region).
+static size_t cbuf_layout(comb_buf *b, const comb_regions &g, uint32_t cap) {
     size_t o = 0;
-    b->off_c = o, o += up256((size_t)cap * key.m * 32);
-    b->off_r = o, o += up256((size_t)cap * 64);
-    b->off_t = o, o += per ? up256((size_t)cap * BPGPU_TRANSCRIPT_BYTES) : 0;
-    b->off_p = o, o += up256((size_t)cap * key.proof_len);
-    b->in_bytes = o;
-    b->off_v = o, o += up256(cap);
-    b->off_to = o, o += per ? up256((size_t)cap * BPGPU_TRANSCRIPT_BYTES) : 0;
-    b->off_m = o, o += up256((size_t)cap * 32);
+    for (uint32_t i = 0; i < g.n_in; i++) b->in_off[i] = o, o += up256((size_t)cap * g.in_sz[i]);
+    b->in_end = o;
+    for (uint32_t i = 0; i < g.n_out; i++) b->out_off[i] = o, o += up256((size_t)cap * g.out_sz[i]);
     b->total = o;
     return o;
 }
 static int cbuf_configure(bpgpu_pool *p, pool_dev *d, comb_buf *b, const comb_key &key, uint32_t cap, uint32_t cap_max) {
-    const size_t need = cbuf_layout(b, key, cap_max);   // the blocks are sized for the widest chain of this shape once and for all
+    const comb_regions g = regions_of(key);
+    const size_t need = cbuf_layout(b, g, cap_max);   // the blocks are sized for the widest chain of this class once and for all
     b->key = key;
-    b->cap = cap;
+    b->reg = g;
     b->cap_max = cap_max;
-    const size_t o = cap == cap_max ? need : (cbuf_layout(b, key, cap), need);
-    if (o > b->mem_cap) {   // the first chains of a shape (the calling thread's current device is put back afterwards)
+    if (cap != cap_max) cbuf_layout(b, g, cap);
+    if (b->desc.size() < cap_max) b->desc.resize(cap_max);
+    if (need > b->mem_cap) {   // the first chains of a class (the calling thread's current device is put back afterwards)
         int prev = -1;
         (void)hipGetDevice(&prev);
         hipError_t e = hipSetDevice(d->device);
         if (e == hipSuccess && b->h) e = hipHostFree(b->h);
-        b->h = nullptr;
+        b->h = b->hd = nullptr;
         if (e == hipSuccess && b->d) e = hipFree(b->d);
         b->d = nullptr;
         b->mem_cap = 0;
-        const size_t want = o + o / 4;
+        const size_t want = need + need / 4;
         if (e == hipSuccess) e = hipHostMalloc((void **)&b->h, want, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void **)&b->d, want);
+        if (e == hipSuccess) {
+            void *dp = nullptr;
+            if (hipHostGetDevicePointer(&dp, b->h, 0) == hipSuccess) b->hd = (char *)dp;
+            else (void)hipGetLastError();
+        }
         if (prev >= 0) (void)hipSetDevice(prev);
         if (e != hipSuccess) {
-            if (b->h) hipHostFree(b->h);
+            if (b->h) (void)hipHostFree(b->h);
             b->h = nullptr;
             return pfail(p, BPGPU_ERR_HIP, "staging buffers of the combining queue: %s", hipGetErrorString(e));
         }
@@ -793,88 +970,139 @@ static int cbuf_configure(bpgpu_pool *p, pool_dev *d, comb_buf *b, const comb_ke
     return BPGPU_OK;
 }
 
-static void cbuf_release(comb_buf *b) {
-    pool_dev *d = b->dev;
-    {
-        std::lock_guard<std::mutex> lk(d->cmu);
-        b->st = CB_FREE;
-        b->reserved = 0;
-        b->written.store(0, std::memory_order_relaxed);
-        b->phase.store(0, std::memory_order_relaxed);
-        b->any_msm = false;
-        b->poison.store(0, std::memory_order_relaxed);
-        b->rc = 0;
-        b->err.clear();
-    }
-    d->free_cv.notify_all();
+static void trace_chain(bpgpu_pool *p, pool_dev *d, const chain_ev &ev) {
+    if (!p->combine_trace.load(std::memory_order_relaxed)) return;
+    std::lock_guard<std::mutex> g(d->trace_mu);
+    if (d->trace_chains.empty()) return;
+    d->trace_chains[d->trace_chain_n++ % d->trace_chains.size()] = ev;
+}
+static void trace_req(bpgpu_pool *p, pool_dev *d, const req_ev &ev) {
+    std::lock_guard<std::mutex> g(d->trace_mu);
+    if (d->trace_reqs.empty()) return;
+    d->trace_reqs[d->trace_req_n++ % d->trace_reqs.size()] = ev;
 }
 
-// results of proofs [first, first + count) of a finished buffer -> proofs [off, ..) of the request
+// every item of the buffer has been taken: it can serve another class.  No lock unless somebody waits for a buffer; ONE waiter is
+// woken per buffer (it passes the baton on if it ends up not needing it: comb_reserve_slow).
+static void cbuf_release(bpgpu_pool *p, comb_buf *b) {
+    pool_dev *d = b->dev;
+    b->ev.t_free = now_ns();
+    trace_chain(p, d, b->ev);
+    b->st.store(CB_FREE, std::memory_order_seq_cst);
+    if (d->free_waiters.load(std::memory_order_seq_cst) != 0) {
+        { std::lock_guard<std::mutex> lk(d->cmu); }   // (a waiter that has counted itself in is inside free_cv.wait by the time this lock is granted)
+        d->free_cv.notify_one();
+    }
+}
+static inline void cbuf_taken(bpgpu_pool *p, comb_buf *b, uint32_t count) {
+    const uint32_t K = b->K;   // (read BEFORE the count goes in: afterwards another deliverer may complete the buffer and hand it to a new class)
+    if (b->delivered.fetch_add(count, std::memory_order_acq_rel) + count == K) cbuf_release(p, b);
+}
+
+// results of items [first, first + count) of a finished buffer -> items [off, ..) of the request
 static void comb_deliver(comb_buf *b, uint32_t first, uint32_t count, comb_req *r, size_t off) {
-    if (b->rc) {   // the chain did not run: nothing may read as "verified"
-        memset(r->verdict + off, BPGPU_VERDICT_UNDECIDED, count);
-        std::lock_guard<std::mutex> g(r->emu);
+    const comb_regions &g = b->reg;
+    if (b->rc) {   // the chain did not run: nothing may read as "verified" / "computed"
+        if (r->out[g.fail_out]) memset(r->out[g.fail_out] + off * g.out_sz[g.fail_out], BPGPU_VERDICT_UNDECIDED, (size_t)count * g.out_sz[g.fail_out]);
+        std::lock_guard<std::mutex> lk(r->emu);
         if (!r->rc) {
             r->rc = b->rc;
             r->err = b->err;
         }
         return;
     }
-    memcpy(r->verdict + off, b->h + b->off_v + first, count);
-    if (r->msm) memcpy(r->msm + off * 32, b->h + b->off_m + (size_t)first * 32, (size_t)count * 32);
-    if (r->ts_out) memcpy(r->ts_out + off * BPGPU_TRANSCRIPT_BYTES, b->h + b->off_to + (size_t)first * BPGPU_TRANSCRIPT_BYTES, (size_t)count * BPGPU_TRANSCRIPT_BYTES);
+    for (uint32_t i = 0; i < g.n_out; i++)
+        if (r->out[i] && g.out_sz[i]) memcpy(r->out[i] + off * g.out_sz[i], b->h + b->out_off[i] + (size_t)first * g.out_sz[i], (size_t)count * g.out_sz[i]);
 }
 
-// a synchronous caller takes the next of its pieces: sleeps until that buffer's chain is done
-static void comb_collect_one(comb_req *r) {
+// a blocking caller takes the next of its pieces: sleeps until that incarnation of the buffer has its results
+static void comb_collect_one(bpgpu_pool *p, comb_req *r) {
     const comb_req::piece pc = r->pieces[r->next_piece++];
     comb_buf *b = pc.b;
-    while (b->phase.load(std::memory_order_acquire) == 0) futex_wait(&b->phase, 0);
+    for (;;) {
+        const uint32_t ph = b->phase.load(std::memory_order_acquire);
+        if ((int32_t)(ph - pc.epoch) >= 0) break;
+        futex_wait(&b->phase, ph);
+    }
+    if (r->traced && !r->ev.t_woken) r->ev.t_woken = now_ns();
     comb_deliver(b, pc.first, pc.count, r, pc.off);
-    if (b->refs.fetch_sub(1, std::memory_order_acq_rel) == 1) cbuf_release(b);
+    cbuf_taken(p, b, pc.count);
 }
 
+// one launch chain over the K items of a sealed buffer, on the buffer's lane
 static void comb_issue(bpgpu_pool *p, pool_dev *d, comb_buf *b, uint32_t inflight, bool more_waiting) {
     hipStream_t s = (hipStream_t)bpgpu_internal_stream(b->ctx);
     const comb_key &k = b->key;
-    const uint32_t K = b->reserved;
-    const bool per = k.mode != CK_SHARED;
-    const size_t TS = BPGPU_TRANSCRIPT_BYTES;
+    const comb_regions &g = b->reg;
+    const uint32_t K = b->K;
     hipError_t e = hipSuccess;
     if (b->poison.load(std::memory_order_acquire)) {   // a writer could not draw its batching challenge: the chain must not run on predictable bytes
         b->rc = BPGPU_ERR_HIP;
         b->err = "getrandom failed";
         return;
     }
-    if (b->reserved_n != k.n || b->reserved_m != k.m || b->reserved_len != k.proof_len || b->reserved_cap < b->cap_max) {
+    if (k.kind == CQ_RP && (b->reserved_n != k.a || b->reserved_m != k.b || b->reserved_len != k.c || b->reserved_cap < b->cap_max)) {
         // first chain of this shape on this lane: size the lane's arena for the widest chain now, not in steps on the way up
-        (void)bpgpu_internal_rp_reserve(b->ctx, k.n, k.m, k.proof_len, b->cap_max);
-        b->reserved_n = k.n, b->reserved_m = k.m, b->reserved_len = k.proof_len, b->reserved_cap = b->cap_max;
+        (void)bpgpu_internal_rp_reserve(b->ctx, k.a, k.b, k.c, b->cap_max);
+        b->reserved_n = k.a, b->reserved_m = k.b, b->reserved_len = k.c, b->reserved_cap = b->cap_max;
     }
-    auto cp_in = [&](size_t off, size_t bytes) {
-        if (e == hipSuccess && bytes) e = hipMemcpyAsync(b->d + off, b->h + off, bytes, hipMemcpyHostToDevice, s);
+    auto cp = [&](size_t off, size_t bytes, bool in) {
+        if (e != hipSuccess || !bytes) return;
+        e = in ? hipMemcpyAsync(b->d + off, b->h + off, bytes, hipMemcpyHostToDevice, s) : hipMemcpyAsync(b->h + off, b->d + off, bytes, hipMemcpyDeviceToHost, s);
     };
-    auto cp_out = [&](size_t off, size_t bytes) {
-        if (e == hipSuccess && bytes) e = hipMemcpyAsync(b->h + off, b->d + off, bytes, hipMemcpyDeviceToHost, s);
-    };
-    cp_in(0, b->off_p + (size_t)K * k.proof_len);
+    // inputs: one copy up to the fill of the last region when the unused tails that ride along are small, else one copy per region
+    {
+        const uint32_t last = g.n_in - 1;
+        const size_t span = b->in_off[last] + (size_t)K * g.in_sz[last];
+        size_t useful = 0;
+        for (uint32_t i = 0; i < g.n_in; i++) useful += (size_t)K * g.in_sz[i];
+        if (span <= (256u << 10) || span - useful <= useful / 4) cp(0, span, true);
+        else
+            for (uint32_t i = 0; i < g.n_in; i++) cp(b->in_off[i], (size_t)K * g.in_sz[i], true);
+    }
+    // outputs: narrow chains write them straight into the pinned host block (device-visible: hipHostMalloc), wide ones into the device
+    // block and one copy behind the chain brings them back
+    const bool mapped = b->hd && K <= p->combine_mapped_out.load(std::memory_order_relaxed);
+    char *ob = mapped ? b->hd : b->d;
+    const bool want_opt = b->want_opt.load(std::memory_order_acquire) != 0;
     int rc = BPGPU_OK;
     if (e == hipSuccess) {
-        // what the chain should expect beside it (rp_chain_forms, pick_splits): a chain that leaves a full buffer, or while others
-        // wait or run, takes the throughput forms; a lone small one the latency forms
-        const int busy = (inflight + (more_waiting ? 1u : 0u) >= p->combine_busy_chains || K > p->latency_proofs) ? 1 : 0;
-        uint32_t hint = (uint32_t)(16384 / ((size_t)(inflight + 1) * ((K + 63) / 64)));
-        hint = (hint + 7) & ~7u;
-        if (hint < 16) hint = 16;
-        if (hint > 64) hint = 64;
-        rc = bpgpu_internal_rp_verify_chain(b->ctx, k.n, k.m, K, b->d + b->off_p, k.proof_len, b->d + b->off_c, per ? nullptr : k.shared,
-                                            per ? b->d + b->off_t : nullptr, per ? b->d + b->off_to : nullptr, k.mode == CK_UNIFORM, k.pos, k.pos_begin,
-                                            k.flags, b->d + b->off_r, b->d + b->off_v, b->any_msm ? b->d + b->off_m : nullptr, hint, busy);
+        if (k.kind == CQ_RP) {
+            const bool per = k.mode != CK_SHARED;
+            // what the chain should expect beside it (rp_chain_forms, pick_splits): a chain that leaves a full buffer, or while others
+            // wait or run, takes the throughput forms; a lone small one the latency forms
+            const int busy = (inflight + (more_waiting ? 1u : 0u) >= p->combine_busy_chains || K > p->latency_proofs) ? 1 : 0;
+            uint32_t hint = (uint32_t)(16384 / ((size_t)(inflight + 1) * ((K + 63) / 64)));
+            hint = (hint + 7) & ~7u;
+            if (hint < 16) hint = 16;
+            if (hint > 64) hint = 64;
+            rc = bpgpu_internal_rp_verify_chain(b->ctx, k.a, k.b, K, b->d + b->in_off[RP_IN_PROOFS], k.c, b->d + b->in_off[RP_IN_COMS], per ? nullptr : k.shared,
+                                                per ? b->d + b->in_off[RP_IN_TS] : nullptr, per ? ob + b->out_off[RP_OUT_TS] : nullptr, k.mode == CK_UNIFORM, k.pos,
+                                                k.pos_begin, k.flags, b->d + b->in_off[RP_IN_RNG], ob + b->out_off[RP_OUT_VERDICT],
+                                                want_opt ? ob + b->out_off[RP_OUT_MSM] : nullptr, hint, busy);
+        } else if (k.kind == CQ_MSM_SHARED) {
+            rc = bpgpu_msm_batch_shared_dev(b->ctx, k.a, k.b, K, k.c, b->d + b->in_off[2], k.c ? b->d + b->in_off[0] : nullptr, k.c ? b->d + b->in_off[1] : nullptr,
+                                            ob + b->out_off[0], ob + b->out_off[1], nullptr);
+        } else if (k.kind == CQ_MSM) {
+            const std::vector<uint32_t> nt(K, k.a);
+            rc = bpgpu_msm_batch_dev(b->ctx, K, nt.data(), b->d + b->in_off[0], b->d + b->in_off[1], ob + b->out_off[0], ob + b->out_off[1], nullptr);
+        } else {
+            rc = bpgpu_ipp_verify_batch_dev(b->ctx, k.a, K, b->d + b->in_off[2], k.b, nullptr, 0, k.shared, b->d + b->in_off[3], b->d + b->in_off[4], b->d + b->in_off[0],
+                                            b->d + b->in_off[1], b->d + b->in_off[5], b->d + b->in_off[6], 0, ob + b->out_off[0], want_opt ? ob + b->out_off[1] : nullptr,
+                                            nullptr);
+        }
         if (rc) b->err = bpgpu_last_error(b->ctx);
     }
     if (e == hipSuccess && !rc) {
-        cp_out(b->off_v, per ? (b->off_to - b->off_v) + (size_t)K * TS : (size_t)K);
-        if (b->any_msm) cp_out(b->off_m, (size_t)K * 32);
+        if (!mapped) {
+            // the required regions in one copy (their unused tails are small: one byte / one state per item), the optional one on demand
+            const bool opt_last = (k.kind == CQ_RP || k.kind == CQ_IPP);
+            const uint32_t n_req = opt_last ? g.n_out - 1 : g.n_out;
+            uint32_t lastr = n_req - 1;
+            while (lastr > 0 && g.out_sz[lastr] == 0) lastr--;
+            cp(b->out_off[0], (b->out_off[lastr] - b->out_off[0]) + (size_t)K * g.out_sz[lastr], false);
+            if (opt_last && want_opt) cp(b->out_off[g.n_out - 1], (size_t)K * g.out_sz[g.n_out - 1], false);
+        }
         if (e == hipSuccess) e = hipEventRecord(b->done_ev, s);
     }
     if (e != hipSuccess) {
@@ -882,30 +1110,94 @@ static void comb_issue(bpgpu_pool *p, pool_dev *d, comb_buf *b, uint32_t infligh
         b->err = std::string("combining queue: ") + hipGetErrorString(e);
         (void)hipGetLastError();
     }
+    // the chain did not go out, but its staging copy may be on the stream already: nobody may refill (or free) the blocks under it
+    if (rc) (void)hipStreamSynchronize(s);
     b->rc = rc;
 }
 
-// the chain of buffer `b` is over (or never went out): publish, deliver the tickets' pieces
+// the chain of buffer `b` is over (or never went out): publish.  Blocking callers wake and help themselves; tickets are the
+// delivery thread's.
 static void comb_complete(pool_dev *d, comb_buf *b) {
-    std::vector<comb_buf::apiece> ap;
-    {
-        std::lock_guard<std::mutex> lk(d->cmu);
-        b->st = CB_DONE;
-        ap.swap(b->async_pieces);
-        b->refs.fetch_add(1, std::memory_order_relaxed);   // the service thread's own hold while it delivers
+    b->ev.t_done = now_ns();
+    const uint32_t epoch = cbs_epoch(b->state.load(std::memory_order_relaxed));
+    const bool any_async = b->n_async.load(std::memory_order_relaxed) != 0, any_sync = b->n_sync.load(std::memory_order_relaxed) != 0;
+    b->st.store(CB_DONE, std::memory_order_release);
+    b->phase.store(epoch, std::memory_order_release);
+    if (any_sync) futex_wake_all(&b->phase);
+    if (any_async) {   // (after this push the buffer may be released, reopened, ... at any moment: nothing of it is touched below)
+        {
+            std::lock_guard<std::mutex> g(d->dq_mu);
+            d->dq.push_back(b);
+        }
+        d->dq_cv.notify_one();
     }
-    b->phase.store(1, std::memory_order_release);
-    futex_wake_all(&b->phase);
-    uint32_t drop = 1;
-    for (const comb_buf::apiece &a : ap) {
-        comb_req *r = a.req;
-        comb_deliver(b, a.first, a.count, r, a.off);
-        drop++;
-        // the ticket's owner frees it once `left` reads 0 -- under emu, so not before this thread is done with it
-        std::lock_guard<std::mutex> g(r->emu);
-        if (r->left.fetch_sub(1, std::memory_order_seq_cst) == 1 && r->waiting.load(std::memory_order_seq_cst)) futex_wake_all(&r->left);
+}
+
+// the delivery thread: results of finished chains -> the buffers of the tickets' owners
+static void dlv_main(bpgpu_pool *p, pool_dev *d) {
+    for (;;) {
+        comb_buf *b;
+        {
+            std::unique_lock<std::mutex> lk(d->dq_mu);
+            d->dq_cv.wait(lk, [&] { return d->dstop || !d->dq.empty(); });
+            if (d->dq.empty()) return;
+            b = d->dq.front();
+            d->dq.pop_front();
+        }
+        const uint64_t t0 = now_ns();
+        b->ev.t_deliv0 = t0;
+        const bool tracing = p->combine_trace.load(std::memory_order_relaxed) != 0;
+        uint32_t taken = 0;
+        for (uint32_t i = 0; i < b->K;) {
+            const comb_buf::piece_desc pc = b->desc[i];
+            if (pc.async) {
+                comb_req *r = pc.req;
+                comb_deliver(b, i, pc.count, r, pc.off);
+                if (tracing && r->traced) {   // (the owner cannot free the request before the fetch_sub below)
+                    r->ev.t_delivered = now_ns();
+                    trace_req(p, d, r->ev);
+                }
+                taken += pc.count;
+                // the request may be freed by its owner as soon as `left` reads 0: the fetch_sub is this thread's last access to it
+                const uint32_t old = r->left.fetch_sub(1, std::memory_order_acq_rel);
+                if (old == (TKT_WAITING | 1u)) futex_wake_all(&r->left);   // (a wake on an address whose owner has moved on is harmless)
+            }
+            i += pc.count;
+        }
+        const uint64_t t1 = now_ns();
+        b->ev.t_deliv1 = t1;
+        d->stat_deliver_ns.fetch_add(t1 - t0, std::memory_order_relaxed);
+        cbuf_taken(p, b, taken);
     }
-    if (b->refs.fetch_sub(drop, std::memory_order_acq_rel) == drop) cbuf_release(b);
+}
+
+// Should the open buffer leave now?  r items reserved, first one arrived at t_open, the count last moved at t_change.
+// `inflight` chains carrying `inflight_items` items of range-proof classes run on the device.
+//   latency regime (what runs is narrow, or nothing runs): as soon as nothing has joined for combine_quiet_us, or the first item has
+//     waited combine_wait_us -- while fewer than combine_inflight chains run; beyond, the buffer keeps filling until one ends;
+//   throughput regime (the chains in flight average >= combine_wide_proofs): at most combine_inflight_wide chains run, the time
+//     deadline is combine_hold_us, and a burst that is quiet but smaller than half of what runs waits for company (the next
+//     completion's resubmissions) -- chains then stay about as wide as the population of requests allows instead of being cut into
+//     combine_wait_us slices of the arrival stream;
+//   always: nothing waits longer than combine_max_age_us.
+static bool policy_seal(bpgpu_pool *p, uint32_t r, uint64_t now, uint64_t t_open, uint64_t t_change, uint32_t inflight, uint64_t inflight_items, bool rp_class,
+                        uint32_t n_free) {
+    const uint64_t age = now - t_open;
+    if (age >= p->combine_max_age_ns.load(std::memory_order_relaxed)) return true;
+    // staging buffers are a resource too: with at most one left while chains run, a buffer that leaves narrow takes the last place
+    // callers could gather in -- and they would queue for a buffer instead of filling one (a convoy that keeps itself narrow)
+    if (n_free <= 1 && inflight != 0) return false;
+    const uint64_t avg = inflight ? inflight_items / inflight : 0;
+    const bool wide = rp_class && inflight && avg >= p->combine_wide_proofs.load(std::memory_order_relaxed);
+    const uint32_t c_max = wide ? p->combine_inflight_wide.load(std::memory_order_relaxed) : p->combine_inflight.load(std::memory_order_relaxed);
+    if (inflight >= c_max) return false;
+    const bool quiet = now - t_change >= p->combine_quiet_ns.load(std::memory_order_relaxed);
+    if (!wide) return quiet || age >= p->combine_wait_ns.load(std::memory_order_relaxed);
+    if (age >= p->combine_hold_ns.load(std::memory_order_relaxed)) return true;
+    return quiet && (uint64_t)r * 2 >= avg;
+}
+extern "C" int bpgpu_internal_policy_seal(bpgpu_pool *p, uint32_t r, uint64_t age_ns, uint64_t quiet_ns, uint32_t inflight, uint64_t inflight_items, uint32_t n_free) {
+    return policy_seal(p, r, 1ull << 40, (1ull << 40) - age_ns, (1ull << 40) - quiet_ns, inflight, inflight_items, true, n_free) ? 1 : 0;
 }
 
 static void svc_main(bpgpu_pool *p, pool_dev *d) {
@@ -919,39 +1211,62 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
         sp.sched_priority = 1;
         if (pthread_setschedparam(pthread_self(), SCHED_RR, &sp) != 0) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), -15);
     }
-    std::unique_lock<std::mutex> lk(d->cmu);
     std::vector<comb_buf *> to_issue, to_complete;
     for (;;) {
-        if (d->cstop) return;
-        bool active = false;
-        const uint64_t now = now_ns(), wait_ns = p->combine_wait_ns, quiet_ns = p->combine_quiet_ns, max_age_ns = p->combine_max_age_ns;
-        const uint32_t target = p->combine_inflight;
-        d->stat_polls++;
-        uint32_t inflight = 0, waiting = 0;
+        const uint32_t kick0 = d->kick.load(std::memory_order_seq_cst);   // (before the scan: whatever happens after this read rings the bell)
+        bool stopping;
+        {
+            std::lock_guard<std::mutex> lk(d->cmu);
+            stopping = d->cstop;
+        }
+        bool active = false, all_free = true;
+        const uint64_t now = now_ns();
+        d->stat_polls.fetch_add(1, std::memory_order_relaxed);
+        uint32_t inflight = 0, waiting = 0, n_free = 0;
+        uint64_t inflight_items = 0;
         for (comb_buf *b : d->cbufs) {
-            if (b->st == CB_ISSUED || b->st == CB_ISSUING) inflight++;
-            if (b->st == CB_OPEN || b->st == CB_SEALED) waiting++;
+            const int st = b->st.load(std::memory_order_acquire);
+            if (st == CB_FREE) n_free++;
+            if (st == CB_ISSUED || st == CB_ISSUING || st == CB_SEALED) {
+                inflight++;
+                if (b->key.kind == CQ_RP) inflight_items += b->K;
+            }
+            if (st == CB_OPEN || st == CB_SEALED) waiting++;
         }
         to_issue.clear();
         to_complete.clear();
         for (comb_buf *b : d->cbufs) {
-            if (b->st == CB_OPEN) {
+            int st = b->st.load(std::memory_order_acquire);
+            if (st != CB_FREE) all_free = false;
+            if (st == CB_OPEN) {
                 active = true;
-                // the deadlines are for an idle-ish device (latency); with `target` chains already running the buffer goes on
-                // filling until one of them ends -- load widens the chains by itself
-                const bool due = now - b->t_first >= wait_ns || now - b->t_last >= quiet_ns;
-                if ((due && inflight < target) || now - b->t_first >= max_age_ns) {
-                    b->st = CB_SEALED;
-                    inflight++;   // (counts against the target at once: two buffers due in the same pass)
+                uint64_t s = b->state.load(std::memory_order_acquire);
+                const uint32_t e = cbs_epoch(s), r = cbs_reserved(s);
+                if (b->seen_epoch != e) b->seen_epoch = e, b->seen_reserved = r, b->t_change = b->t_open;
+                else if (r != b->seen_reserved) b->seen_reserved = r, b->t_change = now;
+                bool seal = cbs_sealed(s);   // a caller took the last slot
+                if (!seal && (stopping || policy_seal(p, r, now, b->t_open, b->t_change, inflight, inflight_items, b->key.kind == CQ_RP, n_free))) {
+                    s = b->state.fetch_or(CBS_SEALED, std::memory_order_acq_rel);   // (slots taken since the load above are in the value this returns)
+                    seal = true;
+                }
+                if (seal) {
+                    b->K = cbs_reserved(s);
+                    b->ev = chain_ev();
+                    b->ev.buf = b->index, b->ev.epoch = e, b->ev.K = b->K, b->ev.kind = b->key.kind, b->ev.cap = b->cap.load(std::memory_order_relaxed);
+                    b->ev.t_open = b->t_open, b->ev.t_seal = now, b->ev.inflight = inflight;
+                    b->st.store(CB_SEALED, std::memory_order_release);
+                    st = CB_SEALED;
+                    inflight++;   // (counts against the limits at once: two buffers due in the same pass)
+                    if (b->key.kind == CQ_RP) inflight_items += b->K;
                 }
             }
-            if (b->st == CB_SEALED) {
+            if (st == CB_SEALED) {
                 active = true;
-                if (b->written.load(std::memory_order_acquire) == b->reserved) {
-                    b->st = CB_ISSUING;
+                if (b->written.load(std::memory_order_acquire) == b->K) {
+                    b->st.store(CB_ISSUING, std::memory_order_release);
                     to_issue.push_back(b);
                 }
-            } else if (b->st == CB_ISSUED) {
+            } else if (st == CB_ISSUED) {
                 active = true;
                 const hipError_t e = hipEventQuery(b->done_ev);
                 if (e != hipErrorNotReady) {
@@ -961,45 +1276,69 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
                     }
                     to_complete.push_back(b);
                 } else (void)hipGetLastError();
-            }
+            } else if (st == CB_DONE) active = true;   // (being delivered)
         }
         if (!to_issue.empty() || !to_complete.empty()) {
-            lk.unlock();
             const uint64_t ta = now_ns();
             for (comb_buf *b : to_complete) comb_complete(d, b);
             const uint64_t tb = now_ns();
             uint32_t running = 0;
-            for (comb_buf *b : d->cbufs) running += (b->st == CB_ISSUED);   // (st of other buffers: only this thread moves them in / out of ISSUED)
+            for (comb_buf *b : d->cbufs) running += (b->st.load(std::memory_order_relaxed) == CB_ISSUED);
             for (comb_buf *b : to_issue) {
                 waiting--;
-                comb_issue(p, d, b, running, waiting > 0);
-                running++;
+                b->n_sync.load(std::memory_order_acquire);
+                b->ev.n_sync = b->n_sync.load(std::memory_order_relaxed), b->ev.n_async = b->n_async.load(std::memory_order_relaxed);
+                b->ev.t_issue0 = now_ns();
+                if (stopping) {   // the pool is being destroyed: what has not left does not leave
+                    b->rc = BPGPU_ERR_INVALID_ARG;
+                    b->err = "the pool was destroyed while this request waited in the combining queue";
+                } else comb_issue(p, d, b, running, waiting > 0);
+                b->ev.t_issue1 = now_ns();
                 if (b->rc) comb_complete(d, b);   // never went out
                 else {
-                    std::lock_guard<std::mutex> g(d->cmu);
-                    b->st = CB_ISSUED;
-                    d->stat_chains++;
-                    d->stat_proofs += b->reserved;
-                    d->recent_K = b->reserved;
+                    running++;
+                    d->stat_chains.fetch_add(1, std::memory_order_relaxed);
+                    d->stat_proofs.fetch_add(b->K, std::memory_order_relaxed);
+                    if (b->key.kind == CQ_RP) d->recent_K.store(b->K, std::memory_order_relaxed);
+                    b->st.store(CB_ISSUED, std::memory_order_release);
                 }
             }
-            lk.lock();
-            d->stat_complete_ns += tb - ta;
-            d->stat_issue_ns += now_ns() - tb;
+            d->stat_complete_ns.fetch_add(tb - ta, std::memory_order_relaxed);
+            d->stat_issue_ns.fetch_add(now_ns() - tb, std::memory_order_relaxed);
             continue;   // look again at once: issuing took tens of microseconds
         }
-        if (active) d->ccv.wait_for(lk, std::chrono::nanoseconds((uint64_t)p->combine_poll_ns));
-        else d->ccv.wait(lk);
+        if (stopping && all_free && p->active_calls.load(std::memory_order_acquire) == 0) return;
+        // sleep: a poll period while anything is open or in flight, until the doorbell rings otherwise
+        d->svc_sleeping.store(1, std::memory_order_seq_cst);
+        if (active || stopping) futex_wait_ns(&d->kick, kick0, (uint64_t)p->combine_poll_ns);
+        else futex_wait(&d->kick, kick0);
+        d->svc_sleeping.store(0, std::memory_order_seq_cst);
     }
 }
+static inline void svc_kick(pool_dev *d) {
+    d->kick.fetch_add(1, std::memory_order_seq_cst);
+    if (d->svc_sleeping.load(std::memory_order_seq_cst)) syscall(SYS_futex, (uint32_t *)&d->kick, FUTEX_WAKE_PRIVATE, 1, nullptr, nullptr, 0);
+}
 
-static void stop_service(pool_dev *d) {
+// bpgpu_pool_destroy: first every device is told to stop (callers blocked on ANY device keep `active_calls` up, and a service thread
+// leaves only when that reads zero), then the threads are joined
+static void signal_service_stop(pool_dev *d) {
     {
         std::lock_guard<std::mutex> lk(d->cmu);
         d->cstop = true;
     }
-    d->ccv.notify_all();
+    svc_kick(d);
+    d->free_cv.notify_all();   // callers waiting for a free buffer see `closing`
+}
+static void stop_service(bpgpu_pool *, pool_dev *d) {
+    signal_service_stop(d);
     if (d->svc.joinable()) d->svc.join();
+    {
+        std::lock_guard<std::mutex> lk(d->dq_mu);
+        d->dstop = true;
+    }
+    d->dq_cv.notify_all();
+    if (d->dlv.joinable()) d->dlv.join();
 }
 
 // STROBE position class of a 208-byte state
@@ -1010,101 +1349,229 @@ static inline void ts_class(const uint8_t *st, comb_key &k) {
 }
 static inline bool ts_ok(const uint8_t *st) { return st[200] < 166 && st[201] <= 166; }
 
-// proofs [lo, hi) of the request go to device d's queue
-static int comb_place(bpgpu_pool *p, pool_dev *d, comb_req *r, const comb_key &base, const uint8_t *shared, size_t lo, size_t hi) {
+// the number of a class on a device: interned under the queue lock the first time a thread meets the class, then found in the
+// thread's own small cache (no shared memory touched).  Numbers are never reused.
+static uint64_t class_id_locked(pool_dev *d, const comb_key &key) {
+    for (pool_dev::cls_ent &c : d->classes)
+        if (c.key == key) {
+            c.last_use = ++d->class_tick;
+            return c.id;
+        }
+    if (d->classes.size() >= 64) {   // forget the class that has not been asked for for the longest time (a buffer still open under its number simply finishes)
+        size_t lru = 0;
+        for (size_t i = 1; i < d->classes.size(); i++)
+            if (d->classes[i].last_use < d->classes[lru].last_use) lru = i;
+        d->classes.erase(d->classes.begin() + (long)lru);
+    }
+    d->classes.push_back({key, d->next_class_id++, ++d->class_tick});
+    return d->classes.back().id;
+}
+struct tls_class {
+    uint64_t uid = 0;
+    pool_dev *d = nullptr;
+    comb_key key;
+    uint64_t id = 0;
+};
+static uint64_t class_id_of(bpgpu_pool *p, pool_dev *d, const comb_key &key) {
+    static thread_local tls_class cache[4];
+    static thread_local unsigned next = 0;
+    for (const tls_class &c : cache)
+        if (c.uid == p->uid && c.d == d && c.key == key) return c.id;
+    uint64_t id;
+    {
+        std::lock_guard<std::mutex> lk(d->cmu);
+        id = class_id_locked(d, key);
+    }
+    tls_class &c = cache[next++ & 3];
+    c.uid = p->uid, c.d = d, c.key = key, c.id = id;
+    return id;
+}
+
+struct comb_slot {
+    comb_buf *b = nullptr;
+    uint32_t epoch = 0, first = 0, take = 0;
+    bool filled = false;   // this reservation took the last slot: the caller seals
+};
+// slots in an open buffer of class `id`: one compare-and-swap, no lock
+static bool comb_reserve_fast(pool_dev *d, uint64_t id, size_t run, comb_slot &out) {
+    for (comb_buf *b : d->cbufs) {
+        uint64_t s = b->state.load(std::memory_order_acquire);
+        for (int tries = 0; tries < 256; tries++) {
+            if (cbs_sealed(s) || b->class_id.load(std::memory_order_relaxed) != id) break;
+            const uint32_t cap = b->cap.load(std::memory_order_relaxed), r = cbs_reserved(s);
+            if (r >= cap) break;   // (full: whoever took the last slot is about to seal it)
+            const uint32_t t = (uint32_t)(run < (size_t)(cap - r) ? run : (size_t)(cap - r));
+            // succeeds only on the incarnation `s` belongs to (its number is in the word), so `id` and `cap`, written before that
+            // incarnation was published, are the ones read above
+            if (b->state.compare_exchange_weak(s, s + t, std::memory_order_acq_rel, std::memory_order_acquire)) {
+                out.b = b, out.epoch = cbs_epoch(s), out.first = r, out.take = t, out.filled = (r + t == cap);
+                return true;
+            }
+        }
+    }
+    return false;
+}
+
+// capacity of a new buffer of class `key`
+static void comb_caps(bpgpu_pool *p, pool_dev *d, const comb_key &key, size_t run, uint32_t *cap, uint32_t *cap_max) {
+    if (key.kind == CQ_RP) {
+        size_t cm = p->comb_cap_max.load(std::memory_order_relaxed);
+        if (cm < 1) cm = 1;
+        // light traffic opens a small buffer (its staging copy carries the small regions whole), heavy traffic a full-width one
+        const size_t want = std::max<size_t>((size_t)4 * d->recent_K.load(std::memory_order_relaxed), run);
+        *cap = (uint32_t)(want <= 256 ? std::min<size_t>(256, cm) : want <= 1024 ? std::min<size_t>(1024, cm) : cm);
+        *cap_max = (uint32_t)cm;
+        return;
+    }
+    const comb_regions g = regions_of(key);
+    size_t item = 0;
+    for (uint32_t i = 0; i < g.n_in; i++) item += g.in_sz[i];
+    size_t c = (size_t)p->combine_msm_bytes.load(std::memory_order_relaxed) / (item ? item : 1);
+    if (c < 1) c = 1;
+    if (c > 1024) c = 1024;
+    *cap = *cap_max = (uint32_t)c;
+}
+
+// No open buffer of the class had room: open one (queue lock), or wait for one to come back.  `key` / `id` may change to the
+// catch-all class (CK_MIXED) when too many transcript-position classes are open.
+static int comb_reserve_slow(bpgpu_pool *p, pool_dev *d, comb_req *r, comb_key &key, uint64_t &id, size_t &run, size_t run_mixed, comb_slot &out) {
+    std::unique_lock<std::mutex> lk(d->cmu);
+    for (;;) {
+        if (p->closing.load(std::memory_order_acquire)) return pfail(p, BPGPU_ERR_INVALID_ARG, "the pool is being destroyed");
+        if (!d->svc_running) {
+            d->svc = std::thread(svc_main, p, d);
+            d->dlv = std::thread(dlv_main, p, d);
+            d->svc_running = true;
+        }
+        if (comb_reserve_fast(d, id, run, out)) {   // (opened by another thread meanwhile)
+            if (d->free_waiters.load(std::memory_order_relaxed)) {   // this thread may have been woken for a free buffer it does not need: pass it on
+                lk.unlock();
+                d->free_cv.notify_one();
+            }
+            return BPGPU_OK;
+        }
+        uint32_t n_open_classes = 0;
+        comb_buf *freeb = nullptr;
+        bool mixed_open = false;
+        for (comb_buf *cb : d->cbufs) {
+            const int st = cb->st.load(std::memory_order_acquire);   // (FREE: everything its last deliverers did is visible before the buffer is rewritten)
+            if (st == CB_FREE) {
+                if (!freeb || cb->mem_cap > freeb->mem_cap) freeb = cb;   // (prefer one whose blocks are already large enough)
+                continue;
+            }
+            if (st != CB_OPEN || cbs_sealed(cb->state.load(std::memory_order_relaxed))) continue;
+            if (cb->key.kind == CQ_RP && cb->key.mode == CK_UNIFORM) n_open_classes++;
+            if (cb->key.kind == CQ_RP && cb->key.mode == CK_MIXED && cb->key.a == key.a && cb->key.b == key.b && cb->key.c == key.c) mixed_open = true;
+        }
+        if (key.kind == CQ_RP && key.mode == CK_UNIFORM && !(freeb && n_open_classes < p->combine_max_open) && (mixed_open || freeb)) {
+            // too many position classes open at once (or no buffer left for a new one): the catch-all, replayed byte-wise
+            key.mode = CK_MIXED;
+            key.pos = key.pos_begin = key.flags = 0;
+            run = run_mixed;
+            id = class_id_locked(d, key);
+            continue;
+        }
+        if (freeb) {
+            uint32_t cap, cap_max;
+            comb_caps(p, d, key, run, &cap, &cap_max);
+            const int rc = cbuf_configure(p, d, freeb, key, cap, cap_max);
+            if (rc) return rc;
+            comb_buf *b = freeb;
+            const uint32_t t = (uint32_t)(run < (size_t)cap ? run : (size_t)cap);
+            b->class_id.store(id, std::memory_order_relaxed);
+            b->cap.store(cap, std::memory_order_relaxed);
+            b->t_open = now_ns();
+            b->K = 0;
+            b->rc = 0;
+            b->err.clear();
+            b->written.store(0, std::memory_order_relaxed);
+            b->delivered.store(0, std::memory_order_relaxed);
+            b->n_sync.store(0, std::memory_order_relaxed);
+            b->n_async.store(0, std::memory_order_relaxed);
+            b->want_opt.store(0, std::memory_order_relaxed);
+            b->poison.store(0, std::memory_order_relaxed);
+            const uint32_t e = cbs_epoch(b->state.load(std::memory_order_relaxed)) + 1;
+            b->st.store(CB_OPEN, std::memory_order_release);
+            b->state.store(cbs_pack(e, false, t), std::memory_order_release);   // publishes the incarnation (its first reservation is ours)
+            out.b = b, out.epoch = e, out.first = 0, out.take = t, out.filled = (t == cap);
+            const bool others_wait = d->free_waiters.load(std::memory_order_relaxed) != 0;
+            lk.unlock();
+            svc_kick(d);   // the service thread may be asleep with nothing to watch
+            if (others_wait) d->free_cv.notify_all();   // whoever waits for a buffer of this class can join this one now
+            return BPGPU_OK;
+        }
+        // every lane is filling or running: take a finished piece of our own meanwhile, or wait for a buffer to come back
+        if (!r->async && r->next_piece < r->pieces.size()) {
+            lk.unlock();
+            comb_collect_one(p, r);
+            lk.lock();
+        } else {
+            d->free_waiters.fetch_add(1, std::memory_order_seq_cst);
+            bool any_free = false;   // (a buffer released between the scan above and the count: its releaser saw no waiter)
+            for (comb_buf *cb : d->cbufs) any_free = any_free || cb->st.load(std::memory_order_seq_cst) == CB_FREE;
+            if (!any_free) d->free_cv.wait(lk);
+            d->free_waiters.fetch_sub(1, std::memory_order_seq_cst);
+        }
+    }
+}
+
+// items [lo, hi) of the request go to device d's queue.  src[i]: the request's region-i inputs of item `lo` (null: the class fills
+// the region itself -- rng bytes drawn here, the shared start state replicated).
+static int comb_place(bpgpu_pool *p, pool_dev *d, comb_req *r, const comb_key &base, const uint8_t *const src[CQ_MAX_IN], const uint8_t *shared, size_t lo, size_t hi) {
     const size_t TS = BPGPU_TRANSCRIPT_BYTES;
+    const uint8_t *ts_in = base.kind == CQ_RP ? src[RP_IN_TS] : nullptr;
     size_t off = lo;
     while (off < hi) {
         comb_key key = base;
         size_t run = hi - off;
-        if (key.mode == CK_UNIFORM) {
-            const uint8_t *st0 = r->ts_in ? r->ts_in + off * TS : shared;
+        if (key.kind == CQ_RP && key.mode == CK_UNIFORM) {
+            const uint8_t *st0 = ts_in ? ts_in + (off - lo) * TS : shared;
             ts_class(st0, key);
-            if (r->ts_in) {   // the stretch of this request that sits at one STROBE position
+            if (ts_in) {   // the stretch of this request that sits at one STROBE position
                 size_t e = off + 1;
-                while (e < hi && r->ts_in[e * TS + 200] == st0[200] && r->ts_in[e * TS + 201] == st0[201] && r->ts_in[e * TS + 202] == st0[202]) e++;
+                while (e < hi && ts_in[(e - lo) * TS + 200] == st0[200] && ts_in[(e - lo) * TS + 201] == st0[201] && ts_in[(e - lo) * TS + 202] == st0[202]) e++;
                 run = e - off;
             }
         }
-        comb_buf *b = nullptr;
-        uint32_t first = 0, take = 0;
-        bool wake = false;
-        {
-            std::unique_lock<std::mutex> lk(d->cmu);
-            if (!d->svc_running) {
-                d->svc = std::thread(svc_main, p, d);
-                d->svc_running = true;
-            }
-            uint32_t n_open_classes = 0;
-            comb_buf *mixed = nullptr, *freeb = nullptr;
-            for (comb_buf *cb : d->cbufs) {
-                if (cb->st == CB_FREE) {
-                    if (!freeb || cb->mem_cap > freeb->mem_cap) freeb = cb;   // (prefer one whose blocks are already large enough)
-                    continue;
-                }
-                if (cb->st != CB_OPEN) continue;
-                if (cb->key == key) b = cb;
-                if (cb->key.mode == CK_UNIFORM) n_open_classes++;
-                if (cb->key.mode == CK_MIXED && cb->key.n == key.n && cb->key.m == key.m && cb->key.proof_len == key.proof_len) mixed = cb;
-            }
-            if (!b && key.mode == CK_UNIFORM && !(freeb && n_open_classes < p->combine_max_open) && (mixed || freeb)) {
-                // too many position classes open at once (or no buffer left for a new one): the catch-all, replayed byte-wise
-                key.mode = CK_MIXED;
-                key.pos = key.pos_begin = key.flags = 0;
-                run = hi - off;
-                b = mixed;
-            }
-            if (!b) {
-                if (!freeb) {   // every lane is filling or running: take a finished piece of our own meanwhile, or wait for a buffer
-                    if (!r->async && r->next_piece < r->pieces.size()) {
-                        lk.unlock();
-                        comb_collect_one(r);
-                    } else {
-                        d->free_cv.wait_for(lk, std::chrono::microseconds(200));
-                    }
-                    continue;
-                }
-                size_t cap_max = p->coalesce_proofs;
-                if (cap_max > p->max_chain_proofs) cap_max = p->max_chain_proofs;
-                // light traffic opens a small buffer (its staging copy carries the small regions whole), heavy traffic a full-width one
-                const size_t want = std::max<size_t>((size_t)4 * d->recent_K, run);
-                const size_t cap = want <= 256 ? std::min<size_t>(256, cap_max) : want <= 1024 ? std::min<size_t>(1024, cap_max) : cap_max;
-                const int rc = cbuf_configure(p, d, freeb, key, (uint32_t)cap, (uint32_t)cap_max);
-                if (rc) return rc;
-                b = freeb;
-                b->st = CB_OPEN;
-                b->t_first = now_ns();
-                wake = true;   // the service thread may be asleep with nothing to watch
-            }
-            first = b->reserved;
-            take = (uint32_t)(run < (size_t)(b->cap - first) ? run : (size_t)(b->cap - first));
-            b->reserved += take;
-            b->t_last = first ? now_ns() : b->t_first;
-            b->refs.fetch_add(1, std::memory_order_relaxed);
-            if (r->msm) b->any_msm = true;
-            if (b->reserved == b->cap) {
-                b->st = CB_SEALED;
-                wake = true;
-            }
-            if (r->async) {
-                b->async_pieces.push_back({r, first, take, off});
-                r->left.fetch_add(1, std::memory_order_relaxed);
-            } else {
-                r->pieces.push_back({b, first, take, off});
-            }
+        uint64_t id = class_id_of(p, d, key);
+        comb_slot sl;
+        if (!comb_reserve_fast(d, id, run, sl)) {
+            const int rc = comb_reserve_slow(p, d, r, key, id, run, hi - off, sl);
+            if (rc) return rc;
         }
-        if (wake) d->ccv.notify_one();
+        comb_buf *b = sl.b;
+        const uint32_t first = sl.first, take = sl.take;
+        if (r->traced && !r->ev.t_reserved) r->ev.t_reserved = now_ns(), r->ev.buf = b->index, r->ev.epoch = sl.epoch;
+        // the piece's record, then the inputs, then `written`: the service thread issues the chain only after every reserved slot
+        // has been counted in, the deliverers read the records only after the chain
+        b->desc[first] = {r, take, r->async ? 1u : 0u, off};
+        if (r->async) {
+            r->left.fetch_add(1, std::memory_order_relaxed);
+            b->n_async.fetch_add(1, std::memory_order_relaxed);
+        } else {
+            r->pieces.push_back({b, sl.epoch, first, take, off});
+            b->n_sync.fetch_add(1, std::memory_order_relaxed);
+        }
+        const comb_regions &g = b->reg;
+        const bool opt_last = (key.kind == CQ_RP || key.kind == CQ_IPP);
+        if (opt_last && r->out[g.n_out - 1]) b->want_opt.store(1, std::memory_order_relaxed);
+        if (sl.filled) {
+            b->state.fetch_or(CBS_SEALED, std::memory_order_acq_rel);
+            svc_kick(d);
+        }
         // ---- inputs into the pinned block (no lock held) ----
-        memcpy(b->h + b->off_p + (size_t)first * r->proof_len, r->proofs + off * r->proof_len, (size_t)take * r->proof_len);
-        memcpy(b->h + b->off_c + (size_t)first * r->m * 32, r->coms + off * r->m * 32, (size_t)take * r->m * 32);
-        if (r->rng) memcpy(b->h + b->off_r + (size_t)first * 64, r->rng + off * 64, (size_t)take * 64);
-        else if (!fast_random((uint8_t *)b->h + b->off_r + (size_t)first * 64, (size_t)take * 64)) b->poison.store(1, std::memory_order_release);
-        if (key.mode != CK_SHARED) {
-            char *dst = b->h + b->off_t + (size_t)first * TS;
-            if (r->ts_in) memcpy(dst, r->ts_in + off * TS, (size_t)take * TS);
-            else
-                for (uint32_t i = 0; i < take; i++) memcpy(dst + (size_t)i * TS, shared, TS);
+        for (uint32_t i = 0; i < g.n_in; i++) {
+            const size_t sz = g.in_sz[i];
+            if (!sz) continue;
+            char *dst = b->h + b->in_off[i] + (size_t)first * sz;
+            if (src[i]) memcpy(dst, src[i] + (off - lo) * sz, (size_t)take * sz);
+            else if (key.kind == CQ_RP && i == RP_IN_RNG) {
+                if (!fast_random((uint8_t *)dst, (size_t)take * 64)) b->poison.store(1, std::memory_order_release);
+            } else if (key.kind == CQ_RP && i == RP_IN_TS) {
+                for (uint32_t j = 0; j < take; j++) memcpy(dst + (size_t)j * TS, shared, TS);
+            }
         }
+        if (r->traced) r->ev.t_written = now_ns();   // (before the count: a ticket's record is read by the delivery thread)
         b->written.fetch_add(take, std::memory_order_release);
         off += take;
     }
@@ -1113,96 +1580,136 @@ static int comb_place(bpgpu_pool *p, pool_dev *d, comb_req *r, const comb_key &b
 
 // requests no chain can take: malformed lengths, parameter errors, missing generators -- the ordinary entry point on the odd-jobs
 // context reports them proof by proof (ProofError::FormatError / InvalidBitsize / InvalidGeneratorsLength, mod.rs:358-366, 505-510)
-static int comb_direct(bpgpu_pool *p, pool_dev *d, comb_req *r, const uint8_t *shared) {
+static int comb_direct_rp(bpgpu_pool *p, pool_dev *d, comb_req *r, size_t n, size_t m, size_t proof_len, const uint8_t *const src[CQ_MAX_IN], const uint8_t *shared) {
     std::lock_guard<std::mutex> lk(d->misc_mu);
-    const int rc = bpgpu_rangeproof_verify_batch_ts(d->misc, r->n, r->m, r->nbatch, r->proofs, r->proof_len, r->coms, r->ts_in ? r->ts_in : shared,
-                                                    r->ts_in ? BPGPU_TRANSCRIPT_BYTES : 0, r->rng, r->verdict, r->msm, r->ts_out);
+    const uint8_t *ts_in = src[RP_IN_TS];
+    const int rc = bpgpu_rangeproof_verify_batch_ts(d->misc, n, m, r->nbatch, src[RP_IN_PROOFS], proof_len, src[RP_IN_COMS], ts_in ? ts_in : shared,
+                                                    ts_in ? BPGPU_TRANSCRIPT_BYTES : 0, src[RP_IN_RNG], r->out[RP_OUT_VERDICT], r->out[RP_OUT_MSM], r->out[RP_OUT_TS]);
     if (rc) return pfail(p, rc, "%s", bpgpu_last_error(d->misc));
     return BPGPU_OK;
 }
 
-// validate, classify, place.  Synchronous requests also collect; tickets return once everything is placed.
-static int comb_run_inner(bpgpu_pool *p, comb_req *r, const uint8_t *transcripts, size_t stride) {
-    if (!p || p->devs.empty()) return BPGPU_ERR_INVALID_ARG;
-    if (r->nbatch == 0) return BPGPU_OK;
-    if (!r->proofs || !r->verdict || (r->m && !r->coms) || !transcripts) return pfail(p, BPGPU_ERR_INVALID_ARG, "null argument");
-    if (stride != 0 && stride != BPGPU_TRANSCRIPT_BYTES) return pfail(p, BPGPU_ERR_INVALID_ARG, "transcript_stride neither 0 nor BPGPU_TRANSCRIPT_BYTES");
-    if (r->nbatch > 0x7fffffffu / 64) return pfail(p, BPGPU_ERR_INVALID_ARG, "batch too large");
-    for (size_t i = 0; i < (stride ? r->nbatch : 1); i++)
-        if (!ts_ok(transcripts + i * BPGPU_TRANSCRIPT_BYTES)) return pfail(p, BPGPU_ERR_INVALID_ARG, "malformed transcript state %zu", i);
-    const uint8_t *shared = stride ? nullptr : transcripts;
-    r->ts_in = stride ? transcripts : nullptr;
-    comb_key base;
-    base.n = (uint32_t)r->n;
-    base.m = (uint32_t)r->m;
-    base.proof_len = (uint32_t)r->proof_len;
-    if (shared && !r->ts_out) {
-        base.mode = CK_SHARED;
-        memcpy(base.shared, shared, BPGPU_TRANSCRIPT_BYTES);
-        memset(base.shared + 203, 0, BPGPU_TRANSCRIPT_BYTES - 203);   // (bytes behind the STROBE bookkeeping carry nothing)
-    } else base.mode = CK_UNIFORM;
+// Nothing of a request may read "verified" / "computed" unless a chain delivered it: the status bytes start as BPGPU_VERDICT_UNDECIDED, so
+// every early return (refused while the pool is destroyed, argument errors, a placement that broke off) leaves them that way.
+static inline void mark_undecided(uint8_t *status, size_t nbatch) {
+    if (status && nbatch) memset(status, BPGPU_VERDICT_UNDECIDED, nbatch);
+}
+
+// every combining-queue entry point runs inside one of these: bpgpu_pool_destroy waits for the last to leave
+struct call_guard {
+    bpgpu_pool *p;
+    bool ok;
+    explicit call_guard(bpgpu_pool *pool) : p(pool) {
+        p->active_calls.fetch_add(1, std::memory_order_acq_rel);
+        ok = !p->closing.load(std::memory_order_seq_cst);
+    }
+    ~call_guard() { p->active_calls.fetch_sub(1, std::memory_order_acq_rel); }
+};
+
+// place (one device for a small request, a contiguous shard per device for a large one: proofs / MSMs are independent units,
+// SURVEY 8e; the "gather" is the placement of every piece's results at its offset of the caller's buffers), then -- blocking
+// requests -- collect
+static int comb_run_placed(bpgpu_pool *p, comb_req *r, const comb_key &base, const uint8_t *const src[CQ_MAX_IN], const size_t in_sz[CQ_MAX_IN], const uint8_t *shared,
+                           pool_dev *d0, size_t shard_min) {
     const size_t ndev = p->devs.size();
-    pool_dev *d0 = p->devs[p->rr_dev.fetch_add(1, std::memory_order_relaxed) % ndev];
-    // can chains take this shape?  (asked of the odd-jobs context; the answer is remembered per thread until generators change)
-    static thread_local struct {
-        const bpgpu_pool *p;
-        size_t n, m, len;
-        uint64_t epoch;
-    } ok_shape = {nullptr, 0, 0, 0, 0};
-    const uint64_t epoch = p->gens_epoch.load(std::memory_order_acquire);
-    bool ok = ok_shape.p == p && ok_shape.n == r->n && ok_shape.m == r->m && ok_shape.len == r->proof_len && ok_shape.epoch == epoch;
-    if (!ok && r->n <= 0xffff && r->m <= 0xffffff && r->proof_len <= 0xffffff && bpgpu_internal_rp_coalescible(d0->misc, r->n, r->m, r->proof_len)) {
-        ok_shape = {p, r->n, r->m, r->proof_len, epoch};
-        ok = true;
+    if (p->combine_trace.load(std::memory_order_relaxed)) {
+        static thread_local uint32_t tick = 0;
+        if ((tick++ & 7) == 0) {
+            r->traced = true;
+            r->ev.t_submit = now_ns();
+            r->ev.async = r->async, r->ev.nbatch = (uint32_t)r->nbatch;
+        }
     }
-    if (!ok) {
-        return comb_direct(p, d0, r, shared);
-    }
-    {
-        std::lock_guard<std::mutex> g(d0->cmu);
-        d0->stat_requests++;
-    }
-    // Proofs are independent units: a large request takes a contiguous shard per device, a small one a single device
-    // (round-robin over the requests).  The "gather" is the placement of every piece's verdicts at its offset of the caller's buffer.
+    d0->stat_requests.fetch_add(1, std::memory_order_relaxed);
     int rc = BPGPU_OK;
-    if (ndev == 1 || r->nbatch < 512 * ndev) {
-        rc = comb_place(p, d0, r, base, shared, 0, r->nbatch);
+    if (ndev == 1 || r->nbatch < shard_min * ndev) {
+        rc = comb_place(p, d0, r, base, src, shared, 0, r->nbatch);
     } else {
         for (size_t di = 0; di < ndev && !rc; di++) {
             const size_t lo = r->nbatch * di / ndev, hi = r->nbatch * (di + 1) / ndev;
-            if (hi > lo) rc = comb_place(p, p->devs[di], r, base, shared, lo, hi);
+            if (hi <= lo) continue;
+            const uint8_t *s2[CQ_MAX_IN];
+            for (int i = 0; i < CQ_MAX_IN; i++) s2[i] = src[i] ? src[i] + lo * in_sz[i] : nullptr;
+            rc = comb_place(p, p->devs[di], r, base, s2, shared, lo, hi);
         }
     }
-    if (r->async) return rc;   // (comb_run drops the placement guard)
-    while (r->next_piece < r->pieces.size()) comb_collect_one(r);   // (also after a placement error: nothing stays referenced behind the caller's back)
+    if (r->async) return rc;   // (comb_finish_async drops the placement guard)
+    while (r->next_piece < r->pieces.size()) comb_collect_one(p, r);   // (also after a placement error: nothing stays referenced behind the caller's back)
+    if (r->traced) {
+        r->ev.t_delivered = now_ns();
+        trace_req(p, d0, r->ev);
+    }
     if (!rc && r->rc) rc = pfail(p, r->rc, "%s", r->err.c_str());
     return rc;
 }
-static int comb_run(bpgpu_pool *p, comb_req *r, const uint8_t *transcripts, size_t stride) {
-    const int rc = comb_run_inner(p, r, transcripts, stride);
-    if (r->async) {
-        // the placement guard goes; the ticket is complete when its last piece has been delivered (bpgpu_pool_ticket_wait)
+// a ticket's placement is over: the guard goes; the ticket is complete when its last piece has been delivered
+static void comb_finish_async(comb_req *r, int rc) {
+    if (rc) {
         std::lock_guard<std::mutex> g(r->emu);
-        r->left.fetch_sub(1, std::memory_order_seq_cst);
-        if (rc && !r->rc) {
+        if (!r->rc) {
             r->rc = rc;
             r->err = t_pool_err;
         }
     }
-    return rc;
+    const uint32_t old = r->left.fetch_sub(1, std::memory_order_acq_rel);
+    if (old == (TKT_WAITING | 1u)) futex_wake_all(&r->left);
 }
 
 // a ticket's owner sleeps until its last piece has been delivered
 static void ticket_block(comb_req *r) {
     for (;;) {
         uint32_t v = r->left.load(std::memory_order_acquire);
-        if (v == 0) break;
-        r->waiting.store(1, std::memory_order_seq_cst);
-        v = r->left.load(std::memory_order_seq_cst);
-        if (v == 0) break;
+        if ((v & ~TKT_WAITING) == 0) return;
+        if (!(v & TKT_WAITING)) {
+            if (!r->left.compare_exchange_weak(v, v | TKT_WAITING, std::memory_order_acq_rel, std::memory_order_acquire)) continue;
+            v |= TKT_WAITING;
+        }
         futex_wait(&r->left, v);
     }
-    std::lock_guard<std::mutex> g(r->emu);   // the delivering thread's last touch of the request happens under emu
+}
+
+// ---- range proofs through the queue -------------------------------------------------------------------------------------
+static int rp_comb_run(bpgpu_pool *p, comb_req *r, size_t n, size_t m, size_t proof_len, const uint8_t *proofs, const uint8_t *coms, const uint8_t *rng,
+                       const uint8_t *transcripts, size_t stride) {
+    if (!p || p->devs.empty()) return BPGPU_ERR_INVALID_ARG;
+    if (r->nbatch == 0) return BPGPU_OK;
+    if (!proofs || !r->out[RP_OUT_VERDICT] || (m && !coms) || !transcripts) return pfail(p, BPGPU_ERR_INVALID_ARG, "null argument");
+    if (stride != 0 && stride != BPGPU_TRANSCRIPT_BYTES) return pfail(p, BPGPU_ERR_INVALID_ARG, "transcript_stride neither 0 nor BPGPU_TRANSCRIPT_BYTES");
+    if (r->nbatch > 0x7fffffffu / 64) return pfail(p, BPGPU_ERR_INVALID_ARG, "batch too large");
+    for (size_t i = 0; i < (stride ? r->nbatch : 1); i++)
+        if (!ts_ok(transcripts + i * BPGPU_TRANSCRIPT_BYTES)) return pfail(p, BPGPU_ERR_INVALID_ARG, "malformed transcript state %zu", i);
+    const uint8_t *shared = stride ? nullptr : transcripts;
+    const uint8_t *src[CQ_MAX_IN] = {nullptr};
+    src[RP_IN_COMS] = coms, src[RP_IN_RNG] = rng, src[RP_IN_TS] = stride ? transcripts : nullptr, src[RP_IN_PROOFS] = proofs;
+    comb_key base;
+    base.kind = CQ_RP;
+    base.a = (uint32_t)n;
+    base.b = (uint32_t)m;
+    base.c = (uint32_t)proof_len;
+    if (shared && !r->out[RP_OUT_TS]) {
+        base.mode = CK_SHARED;
+        memcpy(base.shared, shared, 203);   // (bytes behind the STROBE bookkeeping carry nothing)
+    } else base.mode = CK_UNIFORM;
+    const size_t ndev = p->devs.size();
+    pool_dev *d0 = p->devs[p->rr_dev.fetch_add(1, std::memory_order_relaxed) % ndev];
+    // can chains take this shape?  (asked of the odd-jobs context; the answer is remembered per thread until generators change)
+    static thread_local struct {
+        uint64_t uid;
+        size_t n, m, len;
+        uint64_t epoch;
+    } ok_shape = {0, 0, 0, 0, 0};
+    const uint64_t epoch = p->gens_epoch.load(std::memory_order_acquire);
+    bool ok = ok_shape.uid == p->uid && ok_shape.n == n && ok_shape.m == m && ok_shape.len == proof_len && ok_shape.epoch == epoch;
+    if (!ok && n <= 0xffff && m <= 0xffffff && proof_len <= 0xffffff && bpgpu_internal_rp_coalescible(d0->misc, n, m, proof_len)) {
+        ok_shape = {p->uid, n, m, proof_len, epoch};
+        ok = true;
+    }
+    if (!ok) return comb_direct_rp(p, d0, r, n, m, proof_len, src, shared);
+    const comb_regions g = regions_of(base);
+    size_t in_sz[CQ_MAX_IN] = {0};
+    for (uint32_t i = 0; i < g.n_in; i++) in_sz[i] = g.in_sz[i];
+    in_sz[RP_IN_TS] = BPGPU_TRANSCRIPT_BYTES;   // (the caller's array stride, whatever mode the pieces end up in)
+    return comb_run_placed(p, r, base, src, in_sz, shared, d0, 512);
 }
 
 extern "C" {
@@ -1211,11 +1718,13 @@ int bpgpu_pool_rangeproof_verify_ts(bpgpu_pool *p, size_t n, size_t m, size_t nb
                                     const uint8_t *transcripts, size_t transcript_stride, const uint8_t *rng64, uint8_t *verdict, uint8_t *msm_out,
                                     uint8_t *transcripts_out) {
     if (!p) return BPGPU_ERR_INVALID_ARG;
+    mark_undecided(verdict, nbatch);
+    call_guard cg(p);
+    if (!cg.ok) return pfail(p, BPGPU_ERR_INVALID_ARG, "the pool is being destroyed");
     comb_req r;
-    r.n = n, r.m = m, r.nbatch = nbatch, r.proof_len = proof_len;
-    r.proofs = proofs, r.coms = commitments, r.rng = rng64;
-    r.verdict = verdict, r.msm = msm_out, r.ts_out = transcripts_out;
-    return comb_run(p, &r, transcripts, transcript_stride);
+    r.nbatch = nbatch;
+    r.out[RP_OUT_VERDICT] = verdict, r.out[RP_OUT_TS] = transcripts_out, r.out[RP_OUT_MSM] = msm_out;
+    return rp_comb_run(p, &r, n, m, proof_len, proofs, commitments, rng64, transcripts, transcript_stride);
 }
 
 int bpgpu_pool_rangeproof_submit_ts(bpgpu_pool *p, size_t n, size_t m, size_t nbatch, const uint8_t *proofs, size_t proof_len, const uint8_t *commitments,
@@ -1223,12 +1732,15 @@ int bpgpu_pool_rangeproof_submit_ts(bpgpu_pool *p, size_t n, size_t m, size_t nb
                                     uint8_t *transcripts_out, bpgpu_ticket **ticket) {
     if (!p || !ticket) return BPGPU_ERR_INVALID_ARG;
     *ticket = nullptr;
+    mark_undecided(verdict, nbatch);
+    call_guard cg(p);
+    if (!cg.ok) return pfail(p, BPGPU_ERR_INVALID_ARG, "the pool is being destroyed");
     comb_req *r = new comb_req();
     r->async = true;
-    r->n = n, r->m = m, r->nbatch = nbatch, r->proof_len = proof_len;
-    r->proofs = proofs, r->coms = commitments, r->rng = rng64;
-    r->verdict = verdict, r->msm = msm_out, r->ts_out = transcripts_out;
-    const int rc = comb_run(p, r, transcripts, transcript_stride);
+    r->nbatch = nbatch;
+    r->out[RP_OUT_VERDICT] = verdict, r->out[RP_OUT_TS] = transcripts_out, r->out[RP_OUT_MSM] = msm_out;
+    const int rc = rp_comb_run(p, r, n, m, proof_len, proofs, commitments, rng64, transcripts, transcript_stride);
+    comb_finish_async(r, rc);
     if (rc) {   // argument errors, or placement broke off: whatever is in flight is waited for, then the error is this call's
         const std::string keep = t_pool_err;
         ticket_block(r);
@@ -1237,6 +1749,177 @@ int bpgpu_pool_rangeproof_submit_ts(bpgpu_pool *p, size_t n, size_t m, size_t nb
         return rc;
     }
     *ticket = (bpgpu_ticket *)r;
+    return BPGPU_OK;
+}
+
+// ---- the boundary function itself through the queue: optional_multiscalar_mul, one MSM (or a few) per call, any thread ------------
+// (src/range_proof/mod.rs:421-445, src/r1cs/verifier.rs:459-491: the mega-check shape -- generator scalars + per-MSM points)
+static int msm_shared_run(bpgpu_pool *p, comb_req *r, size_t n, size_t m, size_t n_unique, const uint8_t *gen_scalars, const uint8_t *uniq_scalars,
+                          const uint8_t *uniq_points) {
+    if (!p || p->devs.empty()) return BPGPU_ERR_INVALID_ARG;
+    if (r->nbatch == 0) return BPGPU_OK;
+    if (!gen_scalars || !r->out[0] || !r->out[1] || (n_unique && (!uniq_scalars || !uniq_points))) return pfail(p, BPGPU_ERR_INVALID_ARG, "null argument");
+    pool_dev *d0 = p->devs[p->rr_dev.fetch_add(1, std::memory_order_relaxed) % p->devs.size()];
+    if (n == 0 || m == 0 || n > 65536 || m > 65536 || n * m > (1u << 20) || n_unique > (1u << 22) || r->nbatch > (1u << 24)) {
+        // nothing a chain can be sized for: the ordinary entry point on the odd-jobs context reports what is wrong
+        if (r->async) return pfail(p, BPGPU_ERR_INVALID_ARG, "shape not served by the combining queue");
+        std::lock_guard<std::mutex> lk(d0->misc_mu);
+        const int rc = bpgpu_msm_batch_shared(d0->misc, n, m, r->nbatch, n_unique, gen_scalars, uniq_scalars, uniq_points, r->out[0], r->out[1]);
+        return rc ? pfail(p, rc, "%s", bpgpu_last_error(d0->misc)) : BPGPU_OK;
+    }
+    comb_key base;
+    base.kind = CQ_MSM_SHARED;
+    base.a = (uint32_t)n, base.b = (uint32_t)m, base.c = (uint32_t)n_unique;
+    const comb_regions g = regions_of(base);
+    const uint8_t *src[CQ_MAX_IN] = {nullptr};
+    src[0] = uniq_scalars, src[1] = uniq_points, src[2] = gen_scalars;
+    size_t in_sz[CQ_MAX_IN] = {0};
+    for (uint32_t i = 0; i < g.n_in; i++) in_sz[i] = g.in_sz[i];
+    return comb_run_placed(p, r, base, src, in_sz, nullptr, d0, 64);
+}
+
+int bpgpu_pool_msm_batch_shared(bpgpu_pool *p, size_t n, size_t m, size_t nbatch, size_t n_unique, const uint8_t *gen_scalars, const uint8_t *uniq_scalars,
+                                const uint8_t *uniq_points, uint8_t *out, uint8_t *status) {
+    if (!p) return BPGPU_ERR_INVALID_ARG;
+    mark_undecided(status, nbatch);
+    call_guard cg(p);
+    if (!cg.ok) return pfail(p, BPGPU_ERR_INVALID_ARG, "the pool is being destroyed");
+    comb_req r;
+    r.nbatch = nbatch;
+    r.out[0] = out, r.out[1] = status;
+    return msm_shared_run(p, &r, n, m, n_unique, gen_scalars, uniq_scalars, uniq_points);
+}
+
+int bpgpu_pool_msm_batch_shared_submit(bpgpu_pool *p, size_t n, size_t m, size_t nbatch, size_t n_unique, const uint8_t *gen_scalars, const uint8_t *uniq_scalars,
+                                       const uint8_t *uniq_points, uint8_t *out, uint8_t *status, bpgpu_ticket **ticket) {
+    if (!p || !ticket) return BPGPU_ERR_INVALID_ARG;
+    *ticket = nullptr;
+    mark_undecided(status, nbatch);
+    call_guard cg(p);
+    if (!cg.ok) return pfail(p, BPGPU_ERR_INVALID_ARG, "the pool is being destroyed");
+    comb_req *r = new comb_req();
+    r->async = true;
+    r->nbatch = nbatch;
+    r->out[0] = out, r->out[1] = status;
+    const int rc = msm_shared_run(p, r, n, m, n_unique, gen_scalars, uniq_scalars, uniq_points);
+    comb_finish_async(r, rc);
+    if (rc) {
+        const std::string keep = t_pool_err;
+        ticket_block(r);
+        delete r;
+        t_pool_err = keep;
+        return rc;
+    }
+    *ticket = (bpgpu_ticket *)r;
+    return BPGPU_OK;
+}
+
+// vartime_multiscalar_mul / optional_multiscalar_mul with arbitrary points (ipp.rs:308-319, linear_proof.rs:217-225, messages.rs:128-149):
+// a ragged batch; MSMs of equal length share chains (class = term count), so a request is placed stretch by stretch
+int bpgpu_pool_msm_batch(bpgpu_pool *p, size_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status) {
+    if (!p || p->devs.empty()) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0) return BPGPU_OK;
+    mark_undecided(status, nbatch);
+    call_guard cg(p);
+    if (!cg.ok) return pfail(p, BPGPU_ERR_INVALID_ARG, "the pool is being destroyed");
+    if (!n_terms || !out || !status) return pfail(p, BPGPU_ERR_INVALID_ARG, "null argument");
+    uint64_t total = 0;
+    for (size_t i = 0; i < nbatch; i++) total += n_terms[i];
+    if (total && (!scalars || !points)) return pfail(p, BPGPU_ERR_INVALID_ARG, "null argument");
+    if (nbatch > 0x7fffffffu / 64 || total > 0x7fffffffu / 64) return pfail(p, BPGPU_ERR_INVALID_ARG, "batch too large");
+    pool_dev *d0 = p->devs[p->rr_dev.fetch_add(1, std::memory_order_relaxed) % p->devs.size()];
+    comb_req r;
+    r.nbatch = nbatch;
+    r.out[0] = out, r.out[1] = status;
+    d0->stat_requests.fetch_add(1, std::memory_order_relaxed);
+    int rc = BPGPU_OK;
+    size_t i = 0, term0 = 0;
+    while (i < nbatch && !rc) {
+        size_t j = i + 1;
+        while (j < nbatch && n_terms[j] == n_terms[i]) j++;
+        const size_t nt = n_terms[i];
+        if (nt == 0) {   // the empty sum: the identity (encoding 0), status 0
+            memset(out + i * 32, 0, (j - i) * 32);
+            memset(status + i, 0, j - i);
+        } else if (nt > (1u << 22)) {
+            rc = pfail(p, BPGPU_ERR_INVALID_ARG, "MSM %zu has too many terms for the combining queue", i);
+        } else {
+            comb_key base;
+            base.kind = CQ_MSM;
+            base.a = (uint32_t)nt;
+            const uint8_t *src[CQ_MAX_IN] = {nullptr};
+            src[0] = scalars + term0 * 32, src[1] = points + term0 * 32;
+            rc = comb_place(p, d0, &r, base, src, nullptr, i, j);
+        }
+        term0 += nt * (j - i);
+        i = j;
+    }
+    while (r.next_piece < r.pieces.size()) comb_collect_one(p, &r);
+    if (!rc && r.rc) rc = pfail(p, r.rc, "%s", r.err.c_str());
+    return rc;
+}
+
+// InnerProductProof::verify, one proof (or a few) per call from any thread (src/inner_product_proof.rs:260-326): proofs of one size and
+// one label share chains
+int bpgpu_pool_ipp_verify(bpgpu_pool *p, size_t n, size_t nbatch, const uint8_t *proofs, size_t proof_len, const uint8_t *label, size_t label_len,
+                          const uint8_t *G_factors, const uint8_t *H_factors, const uint8_t *P, const uint8_t *Q, const uint8_t *G, const uint8_t *H,
+                          uint8_t *verdict, uint8_t *msm_out) {
+    if (!p || p->devs.empty() || (label_len && !label) || label_len > 0xffffffffu) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch == 0) return BPGPU_OK;
+    mark_undecided(verdict, nbatch);
+    call_guard cg(p);
+    if (!cg.ok) return pfail(p, BPGPU_ERR_INVALID_ARG, "the pool is being destroyed");
+    if (!proofs || !verdict || !P || !Q || (n && (!G_factors || !H_factors || !G || !H))) return pfail(p, BPGPU_ERR_INVALID_ARG, "null argument");
+    pool_dev *d0 = p->devs[p->rr_dev.fetch_add(1, std::memory_order_relaxed) % p->devs.size()];
+    if (n == 0 || n > 65536 || proof_len == 0 || proof_len > 4096 || proof_len % 4 != 0 || nbatch > (1u << 24)) {   // (malformed lengths: reported per proof by the ordinary entry point)
+        std::lock_guard<std::mutex> lk(d0->misc_mu);
+        const int rc = bpgpu_ipp_verify_batch(d0->misc, n, nbatch, proofs, proof_len, label, label_len, G_factors, H_factors, P, Q, G, H, verdict, msm_out);
+        return rc ? pfail(p, rc, "%s", bpgpu_last_error(d0->misc)) : BPGPU_OK;
+    }
+    comb_req r;
+    r.nbatch = nbatch;
+    r.out[0] = verdict, r.out[1] = msm_out;
+    comb_key base;
+    base.kind = CQ_IPP;
+    base.a = (uint32_t)n, base.b = (uint32_t)proof_len;
+    uint8_t st0[BPGPU_TRANSCRIPT_BYTES];
+    bpgpu_transcript_new(label, label_len, st0);
+    memcpy(base.shared, st0, 203);
+    const comb_regions g = regions_of(base);
+    const uint8_t *src[CQ_MAX_IN] = {P, Q, proofs, G_factors, H_factors, G, H};
+    size_t in_sz[CQ_MAX_IN] = {0};
+    for (uint32_t i = 0; i < g.n_in; i++) in_sz[i] = g.in_sz[i];
+    return comb_run_placed(p, &r, base, src, in_sz, nullptr, d0, 256);
+}
+
+// The queue's timeline (option "combine_trace" = ring size): one JSON object per line -- {"chain": ...} for every launch chain
+// (open -> sealed -> issue begin / end -> completion seen -> delivery begin / end -> buffer free; nanoseconds of CLOCK_MONOTONIC),
+// {"req": ...} for every eighth request per thread (submit -> slots reserved -> inputs written -> delivered -> woken).
+int bpgpu_pool_trace_dump(bpgpu_pool *p, const char *path) {
+    if (!p || !path) return BPGPU_ERR_INVALID_ARG;
+    FILE *f = fopen(path, "w");
+    if (!f) return pfail(p, BPGPU_ERR_INVALID_ARG, "cannot write %s", path);
+    for (size_t di = 0; di < p->devs.size(); di++) {
+        pool_dev *d = p->devs[di];
+        std::lock_guard<std::mutex> g(d->trace_mu);
+        const size_t nc = std::min(d->trace_chain_n, d->trace_chains.size()), nr = std::min(d->trace_req_n, d->trace_reqs.size());
+        for (size_t i = 0; i < nc; i++) {
+            const chain_ev &e = d->trace_chains[i];
+            fprintf(f, "{\"chain\": {\"dev\": %zu, \"buf\": %u, \"epoch\": %u, \"kind\": %u, \"K\": %u, \"cap\": %u, \"n_sync\": %u, \"n_async\": %u, \"inflight_at_seal\": %u, "
+                       "\"t_open\": %llu, \"t_seal\": %llu, \"t_issue0\": %llu, \"t_issue1\": %llu, \"t_done\": %llu, \"t_deliv0\": %llu, \"t_deliv1\": %llu, \"t_free\": %llu}}\n",
+                    di, e.buf, e.epoch, e.kind, e.K, e.cap, e.n_sync, e.n_async, e.inflight, (unsigned long long)e.t_open, (unsigned long long)e.t_seal,
+                    (unsigned long long)e.t_issue0, (unsigned long long)e.t_issue1, (unsigned long long)e.t_done, (unsigned long long)e.t_deliv0,
+                    (unsigned long long)e.t_deliv1, (unsigned long long)e.t_free);
+        }
+        for (size_t i = 0; i < nr; i++) {
+            const req_ev &e = d->trace_reqs[i];
+            fprintf(f, "{\"req\": {\"dev\": %zu, \"buf\": %u, \"epoch\": %u, \"async\": %u, \"nbatch\": %u, \"t_submit\": %llu, \"t_reserved\": %llu, \"t_written\": %llu, "
+                       "\"t_delivered\": %llu, \"t_woken\": %llu}}\n",
+                    di, e.buf, e.epoch, e.async, e.nbatch, (unsigned long long)e.t_submit, (unsigned long long)e.t_reserved, (unsigned long long)e.t_written,
+                    (unsigned long long)e.t_delivered, (unsigned long long)e.t_woken);
+        }
+    }
+    fclose(f);
     return BPGPU_OK;
 }
 
@@ -1265,7 +1948,7 @@ int bpgpu_pool_ticket_done(bpgpu_pool *p, bpgpu_ticket *ticket) {
             }
         return 1;
     }
-    return ((comb_req *)ticket)->left.load(std::memory_order_acquire) == 0 ? 1 : 0;
+    return (((comb_req *)ticket)->left.load(std::memory_order_acquire) & ~TKT_WAITING) == 0 ? 1 : 0;
 }
 
 int bpgpu_pool_ticket_wait(bpgpu_pool *p, bpgpu_ticket *ticket) {
@@ -1392,6 +2075,7 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
     size_t n_undecided = 0;
     std::string first_err;
     std::vector<rp_seg> segs;
+    std::vector<const uint8_t *> labs;   // the label of every segment (all of one length within a chain)
     std::vector<std::pair<size_t, size_t>> carried;   // (item, proofs of it) in the chain being packed
     size_t i = 0, off = 0;   // item i, `off` proofs of it already placed
     while (i < items.size()) {
@@ -1419,6 +2103,7 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
             continue;
         }
         segs.clear();
+        labs.clear();
         carried.clear();
         uint32_t filled = 0;
         bool any_msm = false, any_ticket = false;
@@ -1443,6 +2128,7 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
             sg.count = (uint32_t)take;
             any_msm = any_msm || it.msm;
             segs.push_back(sg);
+            labs.push_back((const uint8_t *)it.label.data());
             filled += (uint32_t)take;
             off += take;
             if (off == it.nbatch) {
@@ -1450,7 +2136,7 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
                 off = 0;
             }
         }
-        const int rc = bpgpu_internal_rp_verify_segs(c, head.n, head.m, head.proof_len, (const uint8_t *)head.label.data(), head.label.size(), segs.data(),
+        const int rc = bpgpu_internal_rp_verify_segs(c, head.n, head.m, head.proof_len, labs.data(), head.label.size(), segs.data(),
                                                      (uint32_t)segs.size(), any_msm, head.rlc ? 0u : hint, (was_idle && T <= p->latency_proofs) ? 0 : 1, head.rlc);   // (the hint is for per-proof table walks: a combined chain walks ONE 1690-pair MSM, which wants all the workgroups it can get)
         {
             const std::shared_ptr<ev_holder> done = record_done(c, any_ticket);   // (also behind the memsets of a failed chain below: same stream)

@@ -526,6 +526,38 @@ int bpgpu_pool_rangeproof_submit_ts(bpgpu_pool *pool, size_t n, size_t m, size_t
                                     bpgpu_ticket **ticket);
 int bpgpu_pool_ticket_done(bpgpu_pool *pool, bpgpu_ticket *ticket);
 int bpgpu_pool_ticket_wait(bpgpu_pool *pool, bpgpu_ticket *ticket);
+/* ---- the boundary function itself through the pool: one multiscalar multiplication (or a few) per call, from any thread ------------
+ * SURVEY 8b's drop-in point is RistrettoPoint::optional_multiscalar_mul / vartime_multiscalar_mul as the crate calls it: ONE
+ * multiscalar multiplication per call (src/range_proof/mod.rs:421-445, src/r1cs/verifier.rs:459-491, src/inner_product_proof.rs:308-319,
+ * src/linear_proof.rs:217-225, src/range_proof/messages.rs:128-149), from whatever thread verifies.  One such call cannot fill a device
+ * (bpgpu_msm_batch_shared on a context of its own: 0.77 ms per 6 179-term MSM, and threads do not add up beyond one context each), so
+ * these go through the same combining queue as the range proofs: calls that arrive close together share a launch chain, every caller
+ * is woken when ITS results are there.  BLOCKING, ANY NUMBER OF THREADS AT ONCE; results bit-identical to the bpgpu_msm_batch* /
+ * bpgpu_ipp_verify_batch call on a context.
+ *   bpgpu_pool_msm_batch_shared : arguments as bpgpu_msm_batch_shared (the mega-check shape: 2nm+2 generator scalars in the order of
+ *                                 mod.rs:421-443 + n_unique (scalar, point) pairs per MSM); MSMs of one (n, m, n_unique) share chains
+ *   bpgpu_pool_msm_batch_shared_submit : the non-blocking form; out / status must stay valid until bpgpu_pool_ticket_wait(ticket)
+ *   bpgpu_pool_msm_batch        : arguments as bpgpu_msm_batch (ragged batch); MSMs of equal length share chains, so a call is placed
+ *                                 stretch by stretch of equal n_terms; an MSM of 0 terms is the identity (encoding 0, status 0)
+ *   bpgpu_pool_ipp_verify       : arguments as bpgpu_ipp_verify_batch (InnerProductProof::verify, ipp.rs:260-326); proofs of one
+ *                                 (n, proof_len, label) share chains
+ * On a non-zero return no status / verdict byte of the call reads 0: items whose chain failed carry BPGPU_VERDICT_UNDECIDED.
+ * Option "combine_msm_bytes" (default 32 MiB): staging block per chain of a multiscalar-multiplication class -- items per chain =
+ * that / input bytes per MSM (cfg5's shape, 263 KB per MSM: 127 per chain). */
+int bpgpu_pool_msm_batch_shared(bpgpu_pool *pool, size_t n, size_t m, size_t nbatch, size_t n_unique, const uint8_t *gen_scalars,
+                                const uint8_t *uniq_scalars, const uint8_t *uniq_points, uint8_t *out, uint8_t *status);
+int bpgpu_pool_msm_batch_shared_submit(bpgpu_pool *pool, size_t n, size_t m, size_t nbatch, size_t n_unique, const uint8_t *gen_scalars,
+                                       const uint8_t *uniq_scalars, const uint8_t *uniq_points, uint8_t *out, uint8_t *status,
+                                       bpgpu_ticket **ticket);
+int bpgpu_pool_msm_batch(bpgpu_pool *pool, size_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, const uint8_t *points,
+                         uint8_t *out, uint8_t *status);
+int bpgpu_pool_ipp_verify(bpgpu_pool *pool, size_t n, size_t nbatch, const uint8_t *proofs, size_t proof_len, const uint8_t *label,
+                          size_t label_len, const uint8_t *G_factors, const uint8_t *H_factors, const uint8_t *P, const uint8_t *Q,
+                          const uint8_t *G, const uint8_t *H, uint8_t *verdict, uint8_t *msm_out);
+/* The combining queue's timeline (set option "combine_trace" = ring size first): one JSON object per line -- every launch chain (opened,
+ * sealed, issue begin / end, completion seen, delivery begin / end, buffer free; CLOCK_MONOTONIC ns) and every eighth request per thread
+ * (submitted, slots reserved, inputs written, delivered, woken).  tools/combine_timeline.py turns it into "where does a request wait". */
+int bpgpu_pool_trace_dump(bpgpu_pool *pool, const char *path);
 /* bpgpu_pool_rangeproof_submit_dev with a completion contract (a service that consumes batch k while batch k+1 is queued, with no
  * device-wide synchronisation anywhere):
  *   producer_stream / have_producer : have_producer != 0: the batch's input buffers are complete when the work queued so far on
