@@ -1253,7 +1253,7 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
                     b->K = cbs_reserved(s);
                     b->ev = chain_ev();
                     b->ev.buf = b->index, b->ev.epoch = e, b->ev.K = b->K, b->ev.kind = b->key.kind, b->ev.cap = b->cap.load(std::memory_order_relaxed);
-                    b->ev.t_open = b->t_open, b->ev.t_seal = now, b->ev.inflight = inflight;
+                    b->ev.t_open = b->t_open, b->ev.t_seal = now > b->t_open ? now : b->t_open, b->ev.inflight = inflight;   // (`now` was read before the scan)
                     b->st.store(CB_SEALED, std::memory_order_release);
                     st = CB_SEALED;
                     inflight++;   // (counts against the limits at once: two buffers due in the same pass)
