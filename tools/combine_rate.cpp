@@ -3,6 +3,11 @@
 //                     its own transcript -- the reference's verify_multiple_with_rng call shape (src/range_proof/mod.rs:345-353)
 //   tickets T Q       T threads, each keeping Q single-proof tickets in flight (bpgpu_pool_rangeproof_submit_ts / _ticket_wait)
 //   big T NB          T threads, each looping blocking label-mode calls of NB proofs (bpgpu_pool_rangeproof_verify)
+//   msm T B           T threads, each looping BLOCKING bpgpu_pool_msm_batch_shared calls of B multiscalar multiplications of config 5's
+//                     shape (4098 generator terms + 2081 per-MSM points: the R1CS verifier's call, src/r1cs/verifier.rs:459-491); inputs
+//                     and the ORACLE's encodings from the file named by BP_MSM_INPUTS (bench.py writes it from workload.cfg5_inputs and
+//                     the committed bench_data/cfg5_expected.json): every result is compared
+// BP_TRACE=path: the queue's timeline (bpgpu_pool_trace_dump) of the run is written there.
 // Inputs: the file tools/combine_rate.py writes (proofs proven on fresh and on pre-bound transcripts, a few invalid, with the
 // oracle's verdicts and advanced transcripts): EVERY result of every call is compared with it.
 // Build: g++ -O2 -std=c++17 -pthread -I include tools/combine_rate.cpp -L bulletproofs_amd/csrc -lbpgpu -Wl,-rpath,... -o combine_rate
@@ -41,7 +46,7 @@ static double now_s() { return std::chrono::duration<double>(std::chrono::steady
 
 int main(int argc, char **argv) {
     if (argc < 5) {
-        fprintf(stderr, "usage: combine_rate <inputs> <seconds> threads T [B] | tickets T Q | big T NB   (env: BP_LANES, BP_W, BP_OPTS=key=val,...)\n");
+        fprintf(stderr, "usage: combine_rate <inputs> <seconds> threads T [B] | tickets T Q | big T NB | msm T B   (env: BP_LANES, BP_W, BP_OPTS=key=val,...)\n");
         return 2;
     }
     inputs in;
@@ -62,6 +67,31 @@ int main(int argc, char **argv) {
         return 1;
     }
     if (getenv("BP_W")) bpgpu_pool_set_option(pool, "fixed_window_bits", atoi(getenv("BP_W")));
+    if (getenv("BP_TRACE")) bpgpu_pool_set_option(pool, "combine_trace", 8192);
+    // msm mode: [u32 n, m, nu, count] gen_scalars | uniq_scalars | uniq_points | expected encodings (32 B each)
+    struct {
+        uint32_t n = 0, m = 0, nu = 0, count = 0;
+        std::vector<uint8_t> gs, us, up, exp;
+    } mi;
+    if (mode == "msm") {
+        const char *mp = getenv("BP_MSM_INPUTS");
+        FILE *f = mp ? fopen(mp, "rb") : nullptr;
+        uint32_t h[4];
+        if (!f || fread(h, 4, 4, f) != 4) {
+            fprintf(stderr, "msm mode needs BP_MSM_INPUTS\n");
+            return 2;
+        }
+        mi.n = h[0], mi.m = h[1], mi.nu = h[2], mi.count = h[3];
+        const size_t ng = 2 * (size_t)mi.n * mi.m + 2;
+        mi.gs.resize(ng * 32 * mi.count), mi.us.resize((size_t)mi.nu * 32 * mi.count), mi.up.resize((size_t)mi.nu * 32 * mi.count), mi.exp.resize(32 * (size_t)mi.count);
+        if (fread(mi.gs.data(), 1, mi.gs.size(), f) != mi.gs.size() || fread(mi.us.data(), 1, mi.us.size(), f) != mi.us.size() ||
+            fread(mi.up.data(), 1, mi.up.size(), f) != mi.up.size() || fread(mi.exp.data(), 1, mi.exp.size(), f) != mi.exp.size()) {
+            fprintf(stderr, "short msm input file\n");
+            return 2;
+        }
+        fclose(f);
+        in.n = mi.n, in.m = mi.m;   // (the generator set the pool derives below)
+    }
     if (const char *o = getenv("BP_OPTS")) {
         std::string s = o;
         size_t p = 0;
@@ -154,6 +184,28 @@ int main(int argc, char **argv) {
                     else check(s.idx, s.v, s.ts);
                     done++;
                 }
+        } else if (mode == "msm") {
+            const size_t B = arg2, ng = 2 * (size_t)mi.n * mi.m + 2, nu = mi.nu;
+            std::vector<uint8_t> gs(B * ng * 32), us(B * nu * 32), up(B * nu * 32), out(B * 32), st(B);
+            size_t k = ((size_t)t * 13) % mi.count;
+            while (!stop.load(std::memory_order_relaxed)) {
+                std::vector<size_t> idx(B);
+                for (size_t b = 0; b < B; b++) {
+                    idx[b] = k;
+                    k = (k + 1) % mi.count;
+                    memcpy(&gs[b * ng * 32], &mi.gs[idx[b] * ng * 32], ng * 32);
+                    memcpy(&us[b * nu * 32], &mi.us[idx[b] * nu * 32], nu * 32);
+                    memcpy(&up[b * nu * 32], &mi.up[idx[b] * nu * 32], nu * 32);
+                }
+                const double t0 = now_s();
+                const int r = bpgpu_pool_msm_batch_shared(pool, mi.n, mi.m, B, nu, gs.data(), us.data(), up.data(), out.data(), st.data());
+                L.push_back((float)((now_s() - t0) * 1e3));
+                if (r) errors++;
+                else
+                    for (size_t b = 0; b < B; b++)
+                        if (st[b] != 0 || memcmp(&out[b * 32], &mi.exp[idx[b] * 32], 32) != 0) mismatches++;
+                done += B;
+            }
         } else {   // big: label-mode calls of NB proofs.  Items proven on the FRESH transcript (Transcript::new("combine-rate")) keep the
                    // oracle's verdict there; the pre-bound ones are proofs of a different statement: VerificationError (FormatError stays)
             const int NB = arg2;
@@ -204,6 +256,7 @@ int main(int argc, char **argv) {
            mode.c_str(), T, arg2, t2 - t1, (unsigned long long)total.load(), (double)total.load() / (t2 - t1), all.size(), pct(0.5), pct(0.9), pct(0.99),
            all.empty() ? 0.0 : (double)all.back(), (long long)chains, chains ? (double)cproofs / (double)chains : 0.0, (unsigned long long)mismatches.load(),
            (unsigned long long)errors.load(), t1 - t0, chains ? (double)iss / (double)chains : 0.0, chains ? (double)cmp / (double)chains : 0.0, (long long)polls);
+    if (getenv("BP_TRACE")) bpgpu_pool_trace_dump(pool, getenv("BP_TRACE"));
     bpgpu_pool_destroy(pool);
     return (mismatches.load() || errors.load()) ? 1 : 0;
 }
