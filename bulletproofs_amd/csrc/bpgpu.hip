@@ -1637,6 +1637,9 @@ struct rp_transcripts {
     // way), so the per-shape script replaces the byte-wise replay although the sponge words differ from proof to proof
     bool ts_uniform = false;
     uint32_t u_pos = 0, u_pos_begin = 0, u_flags = 0;
+    // coalesced launches (h_segs): the label of every item, all `label_len` bytes long (`label` is item 0's).  Items whose labels differ
+    // start from their own state (rp_seg::init_w); positions depend on lengths only, so the chain's script serves them all
+    const uint8_t *const *seg_labels = nullptr;
 };
 
 // ---- the forms a per-proof launch chain takes -----------------------------------------------------------------------------------
@@ -1795,6 +1798,20 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const size_t off_fields = ap.add((size_t)fl.count * nbatch * BP_RP_REC * 4 + 16);
     const size_t off_mv = ap.add(nbatch);
     const size_t off_segs = (h_segs && nseg > RP_SEG_INLINE) ? ap.add((size_t)nseg * sizeof(rp_seg)) : 0;
+    // distinct labels among the items of a coalesced launch (usually one)
+    std::vector<uint32_t> seg_label_of;
+    std::vector<const uint8_t *> distinct_labels;
+    if (h_segs && tr.seg_labels) {
+        seg_label_of.resize(nseg);
+        for (uint32_t i = 0; i < nseg; i++) {
+            uint32_t j = 0;
+            while (j < distinct_labels.size() && tr.label_len != 0 && memcmp(distinct_labels[j], tr.seg_labels[i], tr.label_len) != 0) j++;
+            if (j == distinct_labels.size()) distinct_labels.push_back(tr.seg_labels[i]);
+            seg_label_of[i] = j;
+        }
+    }
+    const bool own_inits = distinct_labels.size() > 1;
+    const size_t off_inits = own_inits ? ap.add(distinct_labels.size() * 256) : 0;
     // batch-combination mode: weights, coefficient accumulators, the column-sum reduction tree, and a batch-of-one
     // table walk (digits, partial sums, result)
     const uint32_t nsplit1 = rlc ? pick_splits(c, 1, npairs) : 0;
@@ -1837,14 +1854,30 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     }
     rp_seg_tab segtab;
     memset(&segtab, 0, sizeof segtab);
+    if (own_inits) {   // Transcript::new(label) + rangeproof_domain_sep(n, m) of every distinct label: 50 sponge words each, staged ahead of the chain
+        char *h = nullptr;
+        rc = pin_alloc(c, s, distinct_labels.size() * 256, &h);
+        if (rc) return rc;
+        for (size_t j = 0; j < distinct_labels.size(); j++) {
+            rp_strobe_init ij;
+            make_strobe_init(ij, distinct_labels[j], tr.label_len, n, m);
+            memcpy(h + j * 256, ij.w, 200);
+        }
+        HIPCHK(c, hipMemcpyAsync(a + off_inits, h, distinct_labels.size() * 256, hipMemcpyHostToDevice, s));
+    }
+    auto seg_fix = [&](rp_seg *dst) {   // (the pool's table carries no start states: they live in this chain's arena)
+        for (uint32_t i = 0; i < nseg; i++) dst[i].init_w = own_inits ? (const uint32_t *)(a + off_inits + (size_t)seg_label_of[i] * 256) : nullptr;
+    };
     if (h_segs && nseg <= RP_SEG_INLINE) {   // travels in the kernels' argument blocks
         segtab.n = nseg;
         memcpy(segtab.in, h_segs, (size_t)nseg * sizeof(rp_seg));
+        seg_fix(segtab.in);
     } else if (h_segs) {
         char *h = nullptr;
         rc = pin_alloc(c, s, (size_t)nseg * sizeof(rp_seg), &h);
         if (rc) return rc;
         memcpy(h, h_segs, (size_t)nseg * sizeof(rp_seg));
+        seg_fix((rp_seg *)h);
         HIPCHK(c, hipMemcpyAsync(a + off_segs, h, (size_t)nseg * sizeof(rp_seg), hipMemcpyHostToDevice, s));
         segtab.n = nseg;
         segtab.ext = (const rp_seg *)(a + off_segs);
@@ -2158,6 +2191,7 @@ int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof
     rp_transcripts tr;
     tr.label = label;
     tr.label_len = label_len;
+    tr.seg_labels = labels;
     c->splits_hint = splits_hint;
     c->busy_hint = busy;
     // d_rng64: a non-null dummy keeps the library from drawing randomness nobody reads (every item brought its own)

@@ -172,7 +172,9 @@ struct dev_item {   // a submitted device-pointer batch waiting for the next flu
     std::shared_ptr<ev_holder> ready;   // recorded on the producer's stream at submission: the chain waits for it (may be empty)
     dev_ticket *ticket = nullptr;       // may be null
     bool rlc = false;                   // batch-combined check (bpgpu_pool_rangeproof_submit_rlc_dev): `msm` is then the item's 33-byte batch_out
-    bool same_shape(const dev_item &o) const { return n == o.n && m == o.m && proof_len == o.proof_len && rlc == o.rlc && label == o.label; }
+    // what lets two items share a launch chain: shape and mode -- and the LENGTH of the label, not its bytes (every transcript position
+    // depends on lengths only; items under different labels start from their own states, rp_seg::init_w)
+    bool same_shape(const dev_item &o) const { return n == o.n && m == o.m && proof_len == o.proof_len && rlc == o.rlc && label.size() == o.label.size(); }
 };
 
 // ---- combining queue ---------------------------------------------------------------------------------------------------
@@ -383,6 +385,7 @@ struct bpgpu_pool {
     size_t latency_proofs = 6144;    // a host call / a flush on an idle device of up to this many proofs is "alone": its chains take the latency forms
     size_t auto_flush_items = 0;     // flush by itself once this many items wait on a device (0 = lanes)
     size_t auto_flush_proofs = 0;    // ... or once this many proofs wait: they go out as ONE chain while the caller keeps submitting (0 = off)
+    int plan_by_work = 1;            // a flush is cut into chains by table-walk work ((2nm+2) generator terms per proof, in (64,1)-proof equivalents), not by proof count
     size_t host_workers = 0;
     // combining queue
     std::atomic<uint32_t> comb_cap_max{5120};         // = coalesce_proofs (readable without `mu`)
@@ -604,6 +607,10 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
         p->auto_flush_items = (size_t)value;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "plan_by_work")) {
+        p->plan_by_work = value != 0;
+        return BPGPU_OK;
+    }
     if (!strcmp(key, "stat_reset")) {
         p->stat_chains = p->stat_chain_proofs = 0;
         for (pool_dev *d : p->devs) {
@@ -686,6 +693,7 @@ int bpgpu_pool_get_option(bpgpu_pool *p, const char *key, int64_t *value) {
     else if (!strcmp(key, "slice_proofs")) *value = (int64_t)p->slice_proofs;
     else if (!strcmp(key, "auto_flush_items")) *value = (int64_t)p->auto_flush_items;
     else if (!strcmp(key, "auto_flush_proofs")) *value = (int64_t)p->auto_flush_proofs;
+    else if (!strcmp(key, "plan_by_work")) *value = (int64_t)p->plan_by_work;
     else if (!strcmp(key, "latency_proofs")) *value = (int64_t)p->latency_proofs;
     else if (!strcmp(key, "pair_limit_proofs")) *value = (int64_t)p->pair_limit_proofs;
     else if (!strcmp(key, "host_workers")) *value = (int64_t)p->host_workers;
@@ -1923,6 +1931,37 @@ int bpgpu_pool_trace_dump(bpgpu_pool *p, const char *path) {
     return BPGPU_OK;
 }
 
+// Diagnostics (not part of the ABI; tools/combine_rate.cpp's watchdog prints it when a run does not end): where every staging buffer of the
+// combining queue stands.  Reads the atomics only -- safe to call from any thread while the queue runs.
+extern "C" int bpgpu_internal_pool_state(bpgpu_pool *p, char *out, size_t cap) {
+    if (!p || !out || cap < 2) return BPGPU_ERR_INVALID_ARG;
+    size_t o = 0;
+    auto put = [&](const char *fmt, ...) {
+        if (o + 1 >= cap) return;
+        va_list ap;
+        va_start(ap, fmt);
+        const int n = vsnprintf(out + o, cap - o, fmt, ap);
+        va_end(ap);
+        if (n > 0) o += (size_t)n < cap - o ? (size_t)n : cap - o - 1;
+    };
+    put("pool: closing %d active_calls %lld\n", p->closing.load(), (long long)p->active_calls.load());
+    static const char *names[] = {"FREE", "OPEN", "SEALED", "ISSUING", "ISSUED", "DONE"};
+    for (size_t di = 0; di < p->devs.size(); di++) {
+        pool_dev *d = p->devs[di];
+        put(" dev %zu: kick %u svc_sleeping %u free_waiters %u chains %llu proofs %llu requests %llu polls %llu\n", di, d->kick.load(), d->svc_sleeping.load(),
+            d->free_waiters.load(), (unsigned long long)d->stat_chains.load(), (unsigned long long)d->stat_proofs.load(), (unsigned long long)d->stat_requests.load(),
+            (unsigned long long)d->stat_polls.load());
+        for (comb_buf *b : d->cbufs) {
+            const uint64_t s = b->state.load();
+            const int st = b->st.load();
+            put("  buf %2u %-7s epoch %u sealed %d reserved %u cap %u K %u written %u delivered %u phase %u n_sync %u n_async %u kind %u\n", b->index,
+                st >= 0 && st <= CB_DONE ? names[st] : "?", cbs_epoch(s), cbs_sealed(s) ? 1 : 0, cbs_reserved(s), b->cap.load(), b->K, b->written.load(),
+                b->delivered.load(), b->phase.load(), b->n_sync.load(), b->n_async.load(), b->key.kind);
+        }
+    }
+    return BPGPU_OK;
+}
+
 static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain);
 // the chains that carry a device-pointer batch: issue them if they have not left yet, hand back their events
 static int dev_ticket_events(bpgpu_pool *p, dev_ticket *t, std::vector<std::shared_ptr<ev_holder>> &evs) {
@@ -2050,13 +2089,66 @@ extern "C" void bpgpu_internal_plan_flush(uint64_t T, uint64_t coalesce_proofs, 
     *chains = fp.chains, *per = fp.per, *splits_hint = fp.splits_hint;
 }
 
+// Work, not proofs: an aggregated proof walks (2nm + 2) generator terms through the window tables, a (64, 1) proof 130 -- a burst of
+// 5120 proofs of (64, 16) is sixteen times the work of 5120 single proofs and must be cut into overlapping chains the way a burst of
+// 81 000 single proofs would be (20 x 256 proofs of m = 16 went out as ONE chain alone on the device).  plan_flush
+// therefore counts in (64,1)-proof equivalents; a chain's width in proofs of ITS shape follows from the equivalents it may carry.
+static size_t work_equiv(size_t nbatch, size_t n, size_t m) { return (nbatch * (2 * n * m + 2) + 129) / 130; }
+static size_t chain_width(size_t per_equiv, size_t n, size_t m, size_t max_chain_proofs) {
+    size_t per = (per_equiv * 130 + (2 * n * m + 2) - 1) / (2 * n * m + 2);
+    per = (per + 63) & ~(size_t)63;   // whole transcript wavefronts
+    if (per > max_chain_proofs) per = max_chain_proofs;
+    if (per < 1) per = 1;
+    return per;
+}
+extern "C" uint64_t bpgpu_internal_work_equiv(uint64_t nbatch, uint64_t n, uint64_t m) { return work_equiv((size_t)nbatch, (size_t)n, (size_t)m); }
+extern "C" uint64_t bpgpu_internal_chain_width(uint64_t per_equiv, uint64_t n, uint64_t m, uint64_t max_chain_proofs) {
+    return chain_width((size_t)per_equiv, (size_t)n, (size_t)m, (size_t)max_chain_proofs);
+}
+// The order a flush packs its items in: grouped by what lets them share a chain (dev_item::same_shape), groups in order of first
+// appearance, submission order inside a group -- alternating submissions of two shapes become two runs instead of one chain per item
+// (VERDICT r04 #3).  key[i] = any number that is equal exactly for items that may share a chain.
+static std::vector<size_t> flush_group_order(const std::vector<uint64_t> &key) {
+    std::vector<size_t> order;
+    std::vector<char> taken(key.size(), 0);
+    for (size_t i = 0; i < key.size(); i++) {
+        if (taken[i]) continue;
+        for (size_t j = i; j < key.size(); j++)
+            if (!taken[j] && key[j] == key[i]) {
+                taken[j] = 1;
+                order.push_back(j);
+            }
+    }
+    return order;
+}
+extern "C" void bpgpu_internal_flush_group_order(const uint64_t *key, uint64_t count, uint64_t *order) {
+    const std::vector<size_t> o = flush_group_order(std::vector<uint64_t>(key, key + count));
+    for (size_t i = 0; i < o.size(); i++) order[i] = o[i];
+}
+
 static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
     if (d->pending.empty()) return BPGPU_OK;
     (void)hipSetDevice(d->device);
     std::vector<dev_item> items;
-    items.swap(d->pending);
-    const size_t T = d->pending_proofs;
+    {
+        // group the pending items by shape (stable): whatever order they were submitted in, items that can share a chain lie together
+        std::vector<dev_item> pend;
+        pend.swap(d->pending);
+        std::vector<uint64_t> key(pend.size());
+        for (size_t i = 0; i < pend.size(); i++) {
+            size_t j = 0;
+            while (j < i && !pend[j].same_shape(pend[i])) j++;
+            key[i] = j;   // (index of the first item of the same shape)
+        }
+        items.reserve(pend.size());
+        for (size_t i : flush_group_order(key)) items.push_back(std::move(pend[i]));
+    }
+    size_t T = d->pending_proofs;
     d->pending_proofs = 0;
+    if (p->plan_by_work) {
+        T = 0;
+        for (const dev_item &it : items) T += work_equiv(it.nbatch, it.n ? it.n : 1, it.m ? it.m : 1);
+    }
     bool was_idle = false;
     // an idle pool starts again at lane 0: a caller that sends bursts keeps hitting the same few lanes, whose arenas and cached
     // work decompositions already have the right size
@@ -2069,7 +2161,6 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
     bool all_rlc = !items.empty();
     for (const dev_item &it : items) all_rlc = all_rlc && it.rlc;
     const flush_plan fp = plan_flush(T, p->coalesce_proofs, p->pair_limit_proofs, p->max_chain_proofs, d->lanes.size(), all_rlc, one_chain);
-    const size_t per = fp.per;
     const uint32_t hint = fp.splits_hint;
     int rc_all = BPGPU_OK;
     size_t n_undecided = 0;
@@ -2105,13 +2196,14 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
         segs.clear();
         labs.clear();
         carried.clear();
+        const size_t per = p->plan_by_work ? chain_width(fp.per, head.n, head.m, p->max_chain_proofs) : fp.per;   // proofs of THIS shape per chain
         uint32_t filled = 0;
         bool any_msm = false, any_ticket = false;
         while (i < items.size() && filled < per && items[i].same_shape(head)) {
             const dev_item &it = items[i];
             size_t take = it.nbatch - off;
             // a batch-combined item stays whole (its 33-byte result is the result of ONE chain): it opens the next chain rather than being cut,
-            // and may stretch a chain up to max_chain_proofs; only an item wider than that is cut (its batch_out is then the last chain's)
+            // and may stretch a chain up to max_chain_proofs (submit refuses wider ones: ADVICE r04)
             if (head.rlc && off == 0 && filled > 0 && take > per - filled) break;
             const size_t room = (head.rlc && off == 0 && take <= p->max_chain_proofs) ? take : per - filled;
             if (take > room) take = room;
@@ -2123,7 +2215,9 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
             sg.commitments = it.coms + off * it.m * 32;
             sg.rng64 = it.rng ? it.rng + off * 64 : nullptr;
             sg.verdict = it.verdict + off;
-            sg.msm_out = it.msm ? (uint32_t *)(it.msm + off * 32) : nullptr;
+            // (a batch-combined item's `msm` is its ONE 33-byte result, not an array: never offset -- submit refuses items a chain cannot hold whole)
+            sg.msm_out = it.msm ? (uint32_t *)(it.rlc ? it.msm : it.msm + off * 32) : nullptr;
+            sg.init_w = nullptr;   // (start states per label are staged by the lane: bpgpu_internal_rp_verify_segs)
             sg.first = filled;
             sg.count = (uint32_t)take;
             any_msm = any_msm || it.msm;
@@ -2176,6 +2270,9 @@ static int submit_dev_common(bpgpu_pool *p, int dev_index, size_t n, size_t m, s
         return pfail(p, BPGPU_ERR_INVALID_ARG, "device buffers must be 4-byte aligned");
     if (nbatch > 0x7fffffffu / 64) return pfail(p, BPGPU_ERR_INVALID_ARG, "batch too large");
     std::lock_guard<std::mutex> lk(p->mu);
+    if (rlc && nbatch > p->max_chain_proofs)   // ONE combined identity check = ONE chain: a cut item would need one 33-byte result per piece
+        return pfail(p, BPGPU_ERR_INVALID_ARG, "a batch-combined batch of %zu proofs does not fit one launch chain (max_chain_proofs = %zu): split it, or raise the option",
+                     nbatch, p->max_chain_proofs);
     pool_dev *d = p->devs[dev_index];
     dev_item it;
     it.n = n;
@@ -2206,9 +2303,17 @@ static int submit_dev_common(bpgpu_pool *p, int dev_index, size_t n, size_t m, s
     d->pending.push_back(std::move(it));
     d->pending_proofs += nbatch;
     const size_t limit = p->auto_flush_items ? p->auto_flush_items : d->lanes.size();
-    if (d->pending.size() >= limit) return flush_dev(p, d, false);
-    if (p->auto_flush_proofs && d->pending_proofs >= p->auto_flush_proofs) return flush_dev(p, d, true);
-    return BPGPU_OK;
+    int rc = BPGPU_OK;
+    if (d->pending.size() >= limit) rc = flush_dev(p, d, false);
+    else if (p->auto_flush_proofs && d->pending_proofs >= p->auto_flush_proofs) rc = flush_dev(p, d, true);
+    if (rc && ticket && *ticket) {
+        // the flush this call triggered failed: an error AND a live ticket would leave the caller guessing who owns it.  Every pending item
+        // (this one included) has been through the flush -- its chains are issued or its verdicts marked undecided --, so the ticket can go;
+        // bpgpu_pool_wait orders the caller behind whatever did go out
+        delete (dev_ticket *)*ticket;
+        *ticket = nullptr;
+    }
+    return rc;
 }
 
 extern "C" {

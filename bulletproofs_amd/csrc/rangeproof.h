@@ -63,6 +63,9 @@ struct rp_seg {
     const uint8_t *rng64;     // may be null: the launch-wide rng buffer at the proof's global index
     uint8_t *verdict;
     uint32_t *msm_out;        // may be null
+    const uint32_t *init_w;   // may be null: the chain's common start state (the kernels' `init` argument); else the 50 sponge words this item's proofs
+                              // start from -- Transcript::new(ITS label) + rangeproof_domain_sep -- at the position the chain's script was compiled for
+                              // (labels of one length share every position: items that differ only in their label share a chain)
     uint32_t first, count;
 };
 // index of the segment holding global proof p (segs sorted by first, segs[0].first == 0)
@@ -96,6 +99,7 @@ BP_HD rp_seg rp_seg_lookup(const rp_seg_tab &t, uint32_t p) {
 // one proof's inputs: its bytes, its m commitments, its 64 rng bytes
 struct rp_inputs {
     const uint8_t *pr, *cm, *rs;
+    const uint32_t *init_w;   // rp_seg::init_w of the proof's item (null: the launch-wide start state)
 };
 BP_HD rp_inputs rp_resolve(uint32_t p, const rp_shape &sh, const uint8_t *proofs, const uint8_t *commitments, const uint8_t *rng64,
                            const rp_seg_tab &segs) {
@@ -106,7 +110,9 @@ BP_HD rp_inputs rp_resolve(uint32_t p, const rp_shape &sh, const uint8_t *proofs
         in.pr = sg.proofs + (uint64_t)q * sh.proof_len;
         in.cm = sg.commitments + (uint64_t)q * sh.m * 32;
         in.rs = sg.rng64 ? sg.rng64 + (uint64_t)q * 64 : (rng64 ? rng64 + (uint64_t)p * 64 : nullptr);
+        in.init_w = sg.init_w;
     } else {
+        in.init_w = nullptr;
         in.pr = proofs + (uint64_t)p * sh.proof_len;
         in.cm = commitments + (uint64_t)p * sh.m * 32;
         in.rs = rng64 ? rng64 + (uint64_t)p * 64 : nullptr;
@@ -201,6 +207,16 @@ BP_HD void rp_ts_passthrough(uint32_t p, const rp_strobe_init &init, const uint3
     }
 }
 
+// the state a caller's `&mut Transcript` is left in when the replay stops early (an identity point: transcript.rs:75-87; n m != 2^k:
+// ipp.rs:203-211): the sponge words as they are now (+ framing bytes the scripted replay has not applied yet), STROBE's bookkeeping `meta`
+BP_HD void rp_ts_emit(uint32_t p, const kstate &st, uint32_t meta, uint32_t *ts_out, const uint32_t *pending_mask = nullptr) {
+    uint32_t *o = ts_out + (uint64_t)p * BP_TS_WORDS;
+    for (uint32_t i = 0; i < 50; i++) o[i] = ks_get32(st, i) ^ ((pending_mask && i < RS_MASK_WORDS) ? pending_mask[i] : 0u);
+    o[50] = meta;
+    o[51] = 0;
+}
+#define RP_NO_STOP 0xffffffffu
+
 // ---- stage 1: parse + transcript ------------------------------------------------------
 // thread p.  `st` = this lane's 50-word sponge state (LDS on the device).
 // Outputs: fields (plain scalars) and status[p] (0, VerificationError, FormatError).  The per-proof points
@@ -229,7 +245,11 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
         rp_ts_passthrough(p, init, ts_in, ts_out);
         return;
     }
-    if (sh.shape_verdict) {
+    // n m != 2^k (or m == 0) is found by verification_scalars (ipp.rs:203-211), i.e. AFTER the range proof's own part of the transcript:
+    // a caller that wants its transcript back gets it as of that moment; InvalidBitsize / InvalidGeneratorsLength come before any
+    // transcript operation (mod.rs:358-366)
+    const bool shape_stop = sh.shape_verdict == BP_VERDICT_VERIFICATION && ts_out;
+    if (sh.shape_verdict && !shape_stop) {
         status_raise(status + p, sh.shape_verdict);
         rp_ts_passthrough(p, init, ts_in, ts_out);
         return;
@@ -250,7 +270,8 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
         t.pos_begin = (meta >> 8) & 0xffu;
         t.cur_flags = (meta >> 16) & 0xffu;
     } else {
-        for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, init.w[i]);
+        const uint32_t *iw = in.init_w ? in.init_w : init.w;
+        for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, iw[i]);
         t.pos = init.pos;
         t.pos_begin = init.pos_begin;
         t.cur_flags = init.cur_flags;
@@ -277,21 +298,29 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
         load_words8(w, in.cm + (uint64_t)j * 32);
         merlin_append_words8(t, lV, 1, w);
     }
-    // A, S: validate_and_append_point (transcript.rs:75-87)
+    // A, S: validate_and_append_point (transcript.rs:75-87) -- the first identity encoding ends the reference's replay BEFORE the message:
+    // the state handed back is the one of that moment (the replay itself goes on: the later launches read every field)
+    bool ts_stopped = false;
+#define RP_VALIDATE(wrec)                                                                              \
+    if (words8_zero(wrec)) {                                                                           \
+        if (ts_out && !ts_stopped) rp_ts_emit(p, st, rp_ts_meta(t.pos, t.pos_begin, t.cur_flags), ts_out); \
+        ts_stopped = true;                                                                             \
+        verr = true;                                                                                   \
+    }
     load_words8(w, pr + 0);
-    verr = verr || words8_zero(w);
+    RP_VALIDATE(w)
     merlin_append_words8(t, lA, 1, w);
     load_words8(w, pr + 32);
-    verr = verr || words8_zero(w);
+    RP_VALIDATE(w)
     merlin_append_words8(t, lS, 1, w);
     sc y, z, x, wch, c;
     rp_challenge_scalar(t, ly, 1, y);
     rp_challenge_scalar(t, lz, 1, z);
     load_words8(w, pr + 64);
-    verr = verr || words8_zero(w);
+    RP_VALIDATE(w)
     merlin_append_words8(t, lT1, 3, w);
     load_words8(w, pr + 96);
-    verr = verr || words8_zero(w);
+    RP_VALIDATE(w)
     merlin_append_words8(t, lT2, 3, w);
     rp_challenge_scalar(t, lx, 1, x);
     merlin_append_words8(t, ltx, 3, tx.v);
@@ -315,27 +344,28 @@ BP_HD void rp_transcript_thread(uint32_t p, rp_shape sh, const rp_strobe_init &i
     rp_store(fields, B, RPF_X, p, x);
     rp_store(fields, B, RPF_W, p, wch);
     rp_store(fields, B, RPF_C, p, c);
+    if (shape_stop) {   // verification_scalars returns Err before innerproduct_domain_sep (ipp.rs:203-213)
+        if (!ts_stopped) rp_ts_emit(p, st, rp_ts_meta(t.pos, t.pos_begin, t.cur_flags), ts_out);
+        status_raise(status + p, sh.shape_verdict);
+        return;
+    }
     // inner-product part (ipp.rs:213-222)
     merlin_append_message(t, ldom, 7, lipp, 6);
     merlin_append_u64(t, ln, 1, sh.nm);
     for (uint32_t i = 0; i < k; i++) {
         load_words8(w, pr + 224 + 64 * i);
-        verr = verr || words8_zero(w);
+        RP_VALIDATE(w)
         merlin_append_words8(t, lL, 1, w);
         load_words8(w, pr + 224 + 64 * i + 32);
-        verr = verr || words8_zero(w);
+        RP_VALIDATE(w)
         merlin_append_words8(t, lR, 1, w);
         sc u;
         rp_challenge_scalar(t, lu, 1, u);
         rp_store(fields, B, fl.u + i, p, u);
     }
+#undef RP_VALIDATE
     if (verr) status_raise(status + p, BP_VERDICT_VERIFICATION);
-    if (ts_out) {
-        uint32_t *o = ts_out + (uint64_t)p * BP_TS_WORDS;
-        for (uint32_t i = 0; i < 50; i++) o[i] = ks_get32(st, i);
-        o[50] = rp_ts_meta(t.pos, t.pos_begin, t.cur_flags);
-        o[51] = 0;
-    }
+    if (ts_out && !ts_stopped) rp_ts_emit(p, st, rp_ts_meta(t.pos, t.pos_begin, t.cur_flags), ts_out);
 }
 
 // ---- stage 1, scripted: the same replay driven by the per-shape script of rp_script.h ------------------------------------
@@ -386,23 +416,35 @@ BP_HD void rp_transcript_scripted(uint32_t p, rp_shape sh, const rp_strobe_init 
     rp_store(fields, B, RPF_EB, p, eb);
     rp_store(fields, B, RPF_A, p, a);
     rp_store(fields, B, RPF_B, p, b);
-    // validate_and_append_point (transcript.rs:75-87): A, S, T_1, T_2, L_i, R_i must not be the identity encoding
+    // validate_and_append_point (transcript.rs:75-87): A, S, T_1, T_2, L_i, R_i must not be the identity encoding.  The bytes are read
+    // in transcript order (L_i, R_i interleaved as they lie in the proof): the first identity is where the reference's replay ends
     bool verr = false;
+    uint32_t stop_u = RP_NO_STOP;
     for (uint32_t u = 0; u < 4 + 2 * k; u++) {
         load_words8(w, pr + (u < 4 ? 32 * u : 224 + 32 * (u - 4)));
-        verr = verr || words8_zero(w);
+        if (words8_zero(w)) {
+            verr = true;
+            if (stop_u == RP_NO_STOP) stop_u = u;
+        }
     }
     if (ts_in) {
         const uint32_t *src = ts_in + (uint64_t)p * BP_TS_WORDS;
         for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, src[i]);
     } else {
-        for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, init.w[i]);
+        const uint32_t *iw = in.init_w ? in.init_w : init.w;
+        for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, iw[i]);
     }
     const rp_script_op *ops = rp_script_ops(script);
     const uint32_t *masks = rp_script_masks(script);
     const uint32_t n_ops = script->n_ops;
+    // the operation before which this proof's transcript is handed back (a rare, per-lane matter; the replay itself goes on)
+    const uint32_t stop_op = (ts_out && stop_u != RP_NO_STOP) ? rp_script_stops(script)[stop_u].op : RP_NO_STOP;
     for (uint32_t oi = 0; oi < n_ops; oi++) {
         const rp_script_op op = ops[oi];
+        if (oi == stop_op) {
+            const rp_script_stop *sp = rp_script_stops(script) + stop_u;
+            rp_ts_emit(p, st, sp->meta, ts_out, sp->mask);
+        }
         const uint8_t *src = (op.src == RS_SRC_PROOF ? pr : in.cm) + op.off;
         if (op.kind == RS_MSG) {
             load_words8(w, src);
@@ -438,12 +480,7 @@ BP_HD void rp_transcript_scripted(uint32_t p, rp_shape sh, const rp_strobe_init 
         rp_store(fields, B, RPF_C, p, c);
     }
     if (verr) status_raise(status + p, BP_VERDICT_VERIFICATION);
-    if (ts_out) {
-        uint32_t *o = ts_out + (uint64_t)p * BP_TS_WORDS;
-        for (uint32_t i = 0; i < 50; i++) o[i] = ks_get32(st, i);
-        o[50] = rp_ts_meta(script->end_pos, script->end_pos_begin, script->end_flags);
-        o[51] = 0;
-    }
+    if (ts_out && stop_op == RP_NO_STOP) rp_ts_emit(p, st, rp_ts_meta(script->end_pos, script->end_pos_begin, script->end_flags), ts_out);
 }
 
 // The same replay for NARROW chains, 32 lanes per proof (keccak.h: keccak_f1600_masked_coop): the group's LEADER (lane 0 of the
@@ -465,6 +502,7 @@ BP_HD void rp_transcript_scripted_coop(uint32_t p, bool valid, uint32_t lane, rp
     uint32_t w[8];
     bool run = valid && (lane & 31) == 0;   // this lane does the per-proof work
     bool verr = false;
+    uint32_t stop_u = RP_NO_STOP;
     if (run) {
         sc tx, txb, eb, a, b;
         bool fmt_ok = true;
@@ -485,21 +523,30 @@ BP_HD void rp_transcript_scripted_coop(uint32_t p, bool valid, uint32_t lane, rp
             rp_store(fields, B, RPF_B, p, b);
             for (uint32_t u = 0; u < 4 + 2 * k; u++) {
                 load_words8(w, pr + (u < 4 ? 32 * u : 224 + 32 * (u - 4)));
-                verr = verr || words8_zero(w);
+                if (words8_zero(w)) {
+                    verr = true;
+                    if (stop_u == RP_NO_STOP) stop_u = u;
+                }
             }
             if (ts_in) {
                 const uint32_t *src = ts_in + (uint64_t)p * BP_TS_WORDS;
                 for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, src[i]);
             } else {
-                for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, init.w[i]);
+                const uint32_t *iw = in.init_w ? in.init_w : init.w;
+                for (uint32_t i = 0; i < 50; i++) ks_set32(st, i, iw[i]);
             }
         }
     }
     const rp_script_op *ops = rp_script_ops(script);
     const uint32_t *masks = rp_script_masks(script);
     const uint32_t n_ops = script->n_ops;
+    const uint32_t stop_op = (run && ts_out && stop_u != RP_NO_STOP) ? rp_script_stops(script)[stop_u].op : RP_NO_STOP;   // (leader only)
     for (uint32_t oi = 0; oi < n_ops; oi++) {
         const rp_script_op op = ops[oi];
+        if (oi == stop_op) {   // (between permutations: the leader's sponge words are at rest)
+            const rp_script_stop *sp = rp_script_stops(script) + stop_u;
+            rp_ts_emit(p, st, sp->meta, ts_out, sp->mask);
+        }
         if (op.kind == RS_PERM) {
             BP_GROUP_SYNC();
             keccak_f1600_masked_coop(st, masks + (uint64_t)op.arg * RS_MASK_WORDS, RS_MASK_WORDS, lane);
@@ -539,12 +586,7 @@ BP_HD void rp_transcript_scripted_coop(uint32_t p, bool valid, uint32_t lane, rp
         rp_store(fields, B, RPF_C, p, c);
     }
     if (verr) status_raise(status + p, BP_VERDICT_VERIFICATION);
-    if (ts_out) {
-        uint32_t *o = ts_out + (uint64_t)p * BP_TS_WORDS;
-        for (uint32_t i = 0; i < 50; i++) o[i] = ks_get32(st, i);
-        o[50] = rp_ts_meta(script->end_pos, script->end_pos_begin, script->end_flags);
-        o[51] = 0;
-    }
+    if (ts_out && stop_op == RP_NO_STOP) rp_ts_emit(p, st, rp_ts_meta(script->end_pos, script->end_pos_begin, script->end_flags), ts_out);
 }
 
 // ---- stage 1b: per-proof points -----------------------------------------------------------

@@ -32,11 +32,23 @@ struct rp_script_op {
 struct rp_script_hdr {
     uint32_t n_ops, n_masks;
     uint32_t end_pos, end_pos_begin, end_flags;   // STROBE bookkeeping after the last challenge (for transcripts handed back)
-    uint32_t pad[3];
+    uint32_t n_stops;                             // 4 + 2k: one record per validated point, in transcript order A, S, T_1, T_2, L_0, R_0, L_1, ...
+    uint32_t pad[2];
 };
-// device layout: hdr | ops[n_ops] | masks[n_masks][RS_MASK_WORDS]
+// Where the replay STOPS when a validated point is the identity encoding: validate_and_append_point returns Err before it absorbs
+// anything of that message (src/transcript.rs:75-87; call sites mod.rs:376-393, ipp.rs:217-222), so the caller's `&mut Transcript`
+// stays as it was just before the message's framing.  Per validated point: the index of the first operation that belongs to the
+// message (the state handed back is the one BEFORE that operation), the framing bytes of the current span that the interpreter has
+// not applied yet (they normally arrive with the span's permutation mask), and STROBE's bookkeeping at that moment.
+struct rp_script_stop {
+    uint32_t op;      // stop before ops[op]
+    uint32_t meta;    // pos | pos_begin << 8 | cur_flags << 16 (the layout of word 50 of a transcript state)
+    uint32_t mask[RS_MASK_WORDS];
+};
+// device layout: hdr | ops[n_ops] | masks[n_masks][RS_MASK_WORDS] | stops[n_stops]
 BP_HD const rp_script_op *rp_script_ops(const rp_script_hdr *h) { return (const rp_script_op *)(h + 1); }
 BP_HD const uint32_t *rp_script_masks(const rp_script_hdr *h) { return (const uint32_t *)(rp_script_ops(h) + h->n_ops); }
+BP_HD const rp_script_stop *rp_script_stops(const rp_script_hdr *h) { return (const rp_script_stop *)(rp_script_masks(h) + (uint64_t)h->n_masks * RS_MASK_WORDS); }
 
 }  // namespace bp
 #include <cstring>
@@ -46,15 +58,30 @@ namespace bp {
 struct rp_script_builder {
     std::vector<rp_script_op> ops;
     std::vector<uint32_t> masks;
+    std::vector<rp_script_stop> stops;
     uint8_t cur[RS_MASK_WORDS * 4];
     uint32_t pos, pos_begin, cur_flags;
     void init(uint32_t p, uint32_t pb, uint32_t fl) {
         ops.clear();
         masks.clear();
+        stops.clear();
         for (auto &b : cur) b = 0;
         pos = p;
         pos_begin = pb;
         cur_flags = fl;
+    }
+    void mark_stop() {   // the next message is a validated point
+        rp_script_stop st{};
+        st.op = (uint32_t)ops.size();
+        st.meta = (pos & 0xffu) | ((pos_begin & 0xffu) << 8) | ((cur_flags & 0xffu) << 16);
+        for (int w = 0; w < RS_MASK_WORDS; w++)
+            st.mask[w] = (uint32_t)cur[4 * w] | ((uint32_t)cur[4 * w + 1] << 8) | ((uint32_t)cur[4 * w + 2] << 16) | ((uint32_t)cur[4 * w + 3] << 24);
+        stops.push_back(st);
+    }
+    // validate_and_append_point(label, a 32-byte record of the proof)
+    void append_point(const char *label, uint32_t label_len, uint32_t off) {
+        mark_stop();
+        append_record(label, label_len, RS_SRC_PROOF, off);
     }
     void run_f() {   // strobe_run_f (keccak.h)
         cur[pos] ^= (uint8_t)pos_begin;
@@ -147,12 +174,12 @@ inline std::vector<uint32_t> rp_script_build(uint32_t n, uint32_t m, uint32_t k,
         b.append_u64("m", 1, m);
     }
     for (uint32_t j = 0; j < m; j++) b.append_record("V", 1, RS_SRC_COMMITMENTS, 32 * j);   // mod.rs:370-374
-    b.append_record("A", 1, RS_SRC_PROOF, 0);
-    b.append_record("S", 1, RS_SRC_PROOF, 32);
+    b.append_point("A", 1, 0);
+    b.append_point("S", 1, 32);
     b.challenge("y", 1, 0);
     b.challenge("z", 1, 1);
-    b.append_record("T_1", 3, RS_SRC_PROOF, 64);
-    b.append_record("T_2", 3, RS_SRC_PROOF, 96);
+    b.append_point("T_1", 3, 64);
+    b.append_point("T_2", 3, 96);
     b.challenge("x", 1, 2);
     b.append_record("t_x", 3, RS_SRC_PROOF, 128);
     b.append_record("t_x_blinding", 12, RS_SRC_PROOF, 160);
@@ -161,8 +188,8 @@ inline std::vector<uint32_t> rp_script_build(uint32_t n, uint32_t m, uint32_t k,
     b.append_const("dom-sep", 7, (const uint8_t *)"ipp v1", 6);                              // ipp.rs:213
     b.append_u64("n", 1, (uint64_t)n * m);
     for (uint32_t i = 0; i < k; i++) {
-        b.append_record("L", 1, RS_SRC_PROOF, 224 + 64 * i);
-        b.append_record("R", 1, RS_SRC_PROOF, 224 + 64 * i + 32);
+        b.append_point("L", 1, 224 + 64 * i);
+        b.append_point("R", 1, 224 + 64 * i + 32);
         b.challenge("u", 1, 4 + i);
     }
     // bytes still pending in `cur` would be framing absorbed after the last permutation: there are none (the replay ends with a squeeze)
@@ -172,10 +199,13 @@ inline std::vector<uint32_t> rp_script_build(uint32_t n, uint32_t m, uint32_t k,
     h.end_pos = b.pos;
     h.end_pos_begin = b.pos_begin;
     h.end_flags = b.cur_flags;
-    std::vector<uint32_t> img(sizeof(rp_script_hdr) / 4 + b.ops.size() * (sizeof(rp_script_op) / 4) + b.masks.size());
+    h.n_stops = (uint32_t)b.stops.size();
+    const size_t o_ops = sizeof(rp_script_hdr) / 4, o_masks = o_ops + b.ops.size() * (sizeof(rp_script_op) / 4), o_stops = o_masks + b.masks.size();
+    std::vector<uint32_t> img(o_stops + b.stops.size() * (sizeof(rp_script_stop) / 4));
     memcpy(img.data(), &h, sizeof h);
-    if (!b.ops.empty()) memcpy(img.data() + sizeof(rp_script_hdr) / 4, b.ops.data(), b.ops.size() * sizeof(rp_script_op));
-    if (!b.masks.empty()) memcpy(img.data() + sizeof(rp_script_hdr) / 4 + b.ops.size() * (sizeof(rp_script_op) / 4), b.masks.data(), b.masks.size() * 4);
+    if (!b.ops.empty()) memcpy(img.data() + o_ops, b.ops.data(), b.ops.size() * sizeof(rp_script_op));
+    if (!b.masks.empty()) memcpy(img.data() + o_masks, b.masks.data(), b.masks.size() * 4);
+    if (!b.stops.empty()) memcpy(img.data() + o_stops, b.stops.data(), b.stops.size() * sizeof(rp_script_stop));
     return img;
 }
 

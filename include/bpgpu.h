@@ -216,9 +216,10 @@ int bpgpu_ctx_collect(bpgpu_ctx *ctx);
  *                       transcript_stride == BPGPU_TRANSCRIPT_BYTES: nbatch states, one per proof
  *   transcripts_out   : optional nbatch x 208 bytes: each proof's transcript as verify_multiple_with_rng leaves it
  *                       (after the last inner-product challenge).  A proof rejected by from_bytes or by the parameter
- *                       checks (FormatError, InvalidBitsize, InvalidGeneratorsLength) gets its input state back, as in
- *                       the reference; for other rejected proofs the reference stops replaying at the offending
- *                       message, here the state is the fully replayed one.
+ *                       checks (FormatError, InvalidBitsize, InvalidGeneratorsLength) gets its input state back; a proof
+ *                       with an identity A / S / T_1 / T_2 / L_i / R_i gets the state as of that message (nothing of it
+ *                       absorbed: validate_and_append_point, transcript.rs:75-87); n m != 2^k leaves the state as of the
+ *                       `w` challenge (verification_scalars, ipp.rs:203-211) -- on every path the reference's own state.
  * `_dev`: `shared_transcript` is a HOST pointer to one state (or NULL), `d_transcripts` a device pointer to nbatch
  * states (or NULL); exactly one of the two must be given. */
 int bpgpu_rangeproof_verify_batch_ts(bpgpu_ctx *ctx, size_t n, size_t m, size_t nbatch,

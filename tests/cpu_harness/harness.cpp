@@ -21,6 +21,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <vector>
 using namespace bp;
 
@@ -290,6 +291,30 @@ int h_rp_transcript_compare_per_proof(uint32_t n, uint32_t m, uint32_t nbatch, c
     return 0;
 }
 
+// n m != 2^k (or m == 0): verification_scalars fails AFTER the range proof's own transcript part (ipp.rs:203-211), so the caller's
+// transcript comes back as of the `w` challenge -- or as of an identity A / S / T_1 / T_2 before it.  Byte-wise replay only (the
+// library compiles no script for such a shape).  k comes from the proof's length.
+int h_rp_transcript_shape_stop(uint32_t n, uint32_t m, const uint8_t *proof, uint32_t proof_len, const uint8_t *commitments, const uint8_t *rng64,
+                               const uint8_t *state208, uint8_t *status_out, uint8_t *ts_out208) {
+    if (proof_len % 32 || proof_len < 9 * 32 || ((proof_len / 32 - 9) & 1)) return -1;
+    const uint32_t k = (proof_len / 32 - 9) / 2;
+    rp_shape sh; sh.n = n; sh.m = m; sh.nm = n * m; sh.k = k; sh.U = 4 + 2 * k + m; sh.proof_len = proof_len; sh.nproofs = 1; sh.shape_verdict = BP_VERDICT_VERIFICATION;
+    rp_strobe_init init;
+    memcpy(init.w, state208, 200);
+    init.pos = state208[200]; init.pos_begin = state208[201]; init.cur_flags = state208[202];
+    const rp_fields fl = rp_field_layout(k, m);
+    std::vector<uint32_t> f((size_t)fl.count * BP_RP_REC + 8, 0), s(2, 0), t(BP_TS_WORDS, 7);
+    rp_seg_tab none; memset(&none, 0, sizeof none);
+    uint32_t w[50]; kstate st; st.w = w; st.stride = 1;
+    rp_transcript_thread(0, sh, init, st, rp_resolve(0, sh, proof, commitments, rng64, none), f.data(), s.data(), BP_TS_DOMSEP, nullptr, t.data());
+    status_out[0] = (uint8_t)s[0];
+    memset(ts_out208, 0, 208);
+    memcpy(ts_out208, t.data(), 200);
+    const uint32_t meta = t[50];
+    ts_out208[200] = meta & 0xff; ts_out208[201] = (meta >> 8) & 0xff; ts_out208[202] = (meta >> 16) & 0xff;
+    return 0;
+}
+
 // Keccak-f[1600] through the 25-lane phase functions (keccak.h: keccak_f1600_masked_coop's host twin) and through the serial form,
 // with an optional XOR mask on the first nmask words: out_coop / out_serial = the permuted 200-byte states
 void h_keccak_coop(const uint8_t *state200, const uint32_t *mask, uint32_t nmask, uint8_t *out_coop, uint8_t *out_serial) {
@@ -360,6 +385,12 @@ void h_set_a_outside(int on) { g_a_outside = on; }
 // items live in separate buffers (every second one without rng bytes of its own) and reports through it
 static std::vector<uint32_t> g_seg_sizes;
 void h_set_segments(uint32_t count, const uint32_t *sizes) { g_seg_sizes.assign(sizes, sizes + count); }
+// ... and item i verifies under label i mod count (labels of ONE length: they share every transcript position, rp_seg::init_w)
+static std::vector<std::vector<uint8_t>> g_seg_labels;
+void h_set_segment_labels(uint32_t count, const uint8_t *labels, uint32_t label_len) {
+    g_seg_labels.clear();
+    for (uint32_t i = 0; i < count; i++) g_seg_labels.emplace_back(labels + (size_t)i * label_len, labels + (size_t)(i + 1) * label_len);
+}
 
 // Whole verification pipeline, lane by lane, in the launch structure of the HIP runtime:
 //   launch 1: rp_transcript + rp_expand_a  ||  rp_points
@@ -425,6 +456,7 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
     std::vector<std::vector<uint8_t>> seg_bufs;
     std::vector<std::vector<uint8_t>> seg_verdict;
     std::vector<std::vector<uint32_t>> seg_msm;
+    std::deque<rp_strobe_init> seg_inits;
     if (!g_seg_sizes.empty() && !rlc) {
         uint32_t first = 0;
         for (size_t i = 0; i < g_seg_sizes.size() && first < nbatch; i++) {
@@ -446,6 +478,13 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
             }
             seg_verdict.emplace_back(cnt, 0xee);
             seg_msm.emplace_back((size_t)cnt * 8, 0xeeeeeeeeu);
+            sg.init_w = nullptr;
+            if (!g_seg_labels.empty()) {   // items that differ in their label (all of one length): own start state per item
+                const std::vector<uint8_t> &lb = g_seg_labels[segs.size() % g_seg_labels.size()];
+                seg_inits.emplace_back();
+                make_strobe_init(seg_inits.back(), lb.data(), (uint32_t)lb.size(), n, m);
+                if (seg_inits.back().pos != init.pos || seg_inits.back().pos_begin != init.pos_begin || seg_inits.back().cur_flags != init.cur_flags) return -6;
+            }
             sg.first = first;
             sg.count = cnt;
             segs.push_back(sg);
@@ -454,6 +493,7 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
         for (size_t i = 0; i < segs.size(); i++) {
             segs[i].verdict = seg_verdict[i].data();
             segs[i].msm_out = seg_msm[i].data();
+            if (!seg_inits.empty()) segs[i].init_w = seg_inits[i].w;
         }
     }
     rp_seg_tab segtab;

@@ -248,3 +248,33 @@ def test_flush_plan_how_pending_batches_are_cut_into_launch_chains():
             ch, per, hint = plan(T, rlc)
             assert (ch - 1) * per < T <= ch * per and 16 <= hint <= 64 and hint % 8 == 0
     assert plan(20 * 1024)[2] == 56 and plan(40 * 1024)[2] == 32 and plan(10**6)[2] == 16
+    # ---- by work (pool option plan_by_work, default on): T counts (64,1)-proof equivalents, a chain's width follows from its shape ----
+    we, cw, go = L.bpgpu_internal_work_equiv, L.bpgpu_internal_chain_width, L.bpgpu_internal_flush_group_order
+    we.restype = cw.restype = C.c_uint64
+    we.argtypes = [C.c_uint64] * 3
+    cw.argtypes = [C.c_uint64] * 4
+    go.restype = None
+    go.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]
+    assert we(1024, 64, 1) == 1024 and we(20 * 1024, 64, 1) == 20480                 # single 64-bit proofs: nothing changes
+    assert cw(5120, 64, 1, 1 << 20) == 5120 and cw(10240, 64, 1, 1 << 20) == 10240
+    assert we(256, 64, 16) == 4037 and we(512, 64, 32) == 16140                      # an m = 16 proof walks 2050 generator terms, a single one 130
+    # BASELINE config 3 as the driver runs it, 20 x 256 proofs of (64, 16): 80 740 equivalents -> sixteen chains of up to 384 proofs, not one of 5120
+    T3 = 20 * we(256, 64, 16)
+    ch, per, _ = plan(T3)
+    assert (ch, cw(per, 64, 16, 16384)) == (16, 384)
+    # config 4, 20 x 512 proofs of (64, 32): 322 800 equivalents -> sixty-three chains (one per lane at most) of 192
+    ch, per, _ = plan(20 * we(512, 64, 32))
+    assert ch == 63 and cw(per, 64, 32, 16384) == 192
+    assert plan(20 * we(512, 64, 32), lanes=8)[0] == 8 and cw(plan(20 * we(512, 64, 32), lanes=8)[1], 64, 32, 16384) == 1344
+    assert cw(1, 64, 1, 1 << 20) == 64 and cw(10**9, 64, 1, 16384) == 16384           # whole transcript wavefronts; never wider than max_chain_proofs
+    assert cw(5120, 8, 1, 1 << 20) == 36992                                          # small shapes: wider chains for the same work
+    # ---- grouping: alternating submissions of two shapes (and of several labels of one length) become runs, order kept inside a run ----
+
+    def order(keys):
+        a = (C.c_uint64 * len(keys))(*keys)
+        o = (C.c_uint64 * len(keys))()
+        go(a, len(keys), o)
+        return list(o)
+    assert order([0, 1, 0, 1, 0, 1]) == [0, 2, 4, 1, 3, 5]
+    assert order([7, 7, 7]) == [0, 1, 2] and order([]) == [] and order([3, 2, 1]) == [0, 1, 2]
+    assert order([5, 9, 9, 5, 2, 9]) == [0, 3, 1, 2, 5, 4]

@@ -427,6 +427,24 @@ def test_coalesced_launch_segment_table_lane_by_lane(H, oracle, golden):
         assert H.h_rp_verify(4, 3, n, m, Bb2 + B2 + G2 + H2, n, m, nb, proofs, len(pr), coms, label, len(label), rng, vd, mo) == 0
         for b in range(nb):
             assert vd.raw[b] == exp[b][0] and mo.raw[32 * b:32 * b + 32] == exp[b][1], (sizes, b)
+    # items that differ only in their LABEL (one length: every transcript position is shared) ride in one chain, each from its own start
+    # state (rp_seg::init_w): the mega-check encodings under a foreign label are the oracle's, the items under the right label still verify
+    labels = [label, bytes(reversed(label)), bytes((c + 1) & 0xff for c in label)]
+    H.h_set_segment_labels(3, b"".join(labels), len(label))
+    for sizes in ([2, 1, 3, 1, 12], [1] * 19):
+        H.h_set_segments(len(sizes), (C.c_uint32 * len(sizes))(*sizes))
+        vd, mo = C.create_string_buffer(nb), C.create_string_buffer(32 * nb)
+        assert H.h_rp_verify(4, 3, n, m, Bb2 + B2 + G2 + H2, n, m, nb, proofs, len(pr), coms, label, len(label), rng, vd, mo) == 0
+        b, n_ok = 0, 0
+        for j, cnt in enumerate(sizes):
+            for _ in range(cnt):
+                e = oracle.verify(gg, plist[b], coms[32 * m * b:32 * m * (b + 1)], n, labels[j % 3], rng[64 * b:64 * b + 64])
+                assert vd.raw[b] == e[0] and mo.raw[32 * b:32 * b + 32] == e[1], (sizes, b)
+                assert (e[0] == 0) == (j % 3 == 0 and exp[b][0] == 0)
+                n_ok += e[0] == 0
+                b += 1
+        assert b == nb and n_ok > 0
+    H.h_set_segment_labels(0, b"", 0)
     H.h_set_segments(0, (C.c_uint32 * 1)(0))
 
 
@@ -514,6 +532,62 @@ def test_scripted_transcript_with_one_start_state_per_proof(H, oracle, golden):
         st_a = transcript_append_message(transcript_new(b"a"), b"x", b"12")
         st_b = transcript_append_message(transcript_new(b"a"), b"x", b"123")
         assert H.h_rp_transcript_compare_per_proof(n, m, 2, pr * 2, len(pr), coms[:64 * m], rng, st_a + st_b, so, to) == -2
+
+
+def test_transcript_handed_back_as_of_the_reference_s_early_exit(H, oracle, golden):
+    """validate_and_append_point returns Err BEFORE absorbing an identity A / S / T_1 / T_2 / L_i / R_i (transcript.rs:75-87; mod.rs:376-393,
+    ipp.rs:217-222), so the caller's `&mut Transcript` stays at that message.  An identity encoding planted at every one of the 4 + 2k
+    positions of every golden shape (and at two positions at once: the first one counts), from start states in several STROBE position
+    classes: the byte-wise, the scripted and the 32-lane replay hand back the same state (the harness compares them lane by lane), and
+    that state is the oracle's verify_ts state."""
+    from bulletproofs_amd._lib import transcript_new, transcript_append_message
+    label = golden["label"]
+    vc = golden["vc_bytes"]
+    for case in golden["cases"]:
+        n, m = case["n"], case["m"]
+        pr = bytes.fromhex(case["proof"])
+        k = (n * m).bit_length() - 1
+        offs = [0, 32, 64, 96] + [224 + 32 * j for j in range(2 * k)]   # transcript order: A, S, T_1, T_2, L_0, R_0, L_1, ...
+        variants = []
+        for u, o in enumerate(offs):
+            z = bytearray(pr)
+            z[o:o + 32] = bytes(32)
+            variants.append(bytes(z))
+        z = bytearray(pr)                      # two identities: the replay ends at the first
+        z[offs[3]:offs[3] + 32] = bytes(32)
+        z[offs[-1]:offs[-1] + 32] = bytes(32)
+        variants.append(bytes(z))
+        z = bytearray(pr)                      # an identity AND a non-canonical scalar: from_bytes fails first, transcript untouched
+        z[offs[1]:offs[1] + 32] = bytes(32)
+        z[160:192] = b"\xff" * 32
+        variants.append(bytes(z))
+        nb = len(variants)
+        proofs = b"".join(variants)
+        coms = vc[:32 * m] * nb
+        rng = hashlib.shake_256(b"stop%d%d" % (n, m)).digest(64 * nb)
+        gens = oracle.Gens(n, m)
+        for pad in ([], [3], [77], [150], [166]):
+            st = transcript_new(label)
+            for j, ln in enumerate(pad):
+                st = transcript_append_message(st, b"pad%d" % j, bytes((ln + q) & 0xff for q in range(ln)))
+            so, to = C.create_string_buffer(nb), C.create_string_buffer(208 * nb)
+            rc = H.h_rp_transcript_compare(n, m, nb, proofs, len(pr), coms, rng, st, 1, None, so, to)
+            assert rc == 0, (n, m, pad, rc)
+            for b_ in range(nb):
+                rc_o, _, ts_o = oracle.verify_ts(gens, variants[b_], coms[:32 * m], n, st, rng[64 * b_:64 * b_ + 64])
+                assert so.raw[b_] == rc_o, (n, m, pad, b_)
+                assert ts_o == to.raw[208 * b_:208 * (b_ + 1)], (n, m, pad, b_)
+            assert len({to.raw[208 * b_:208 * (b_ + 1)] for b_ in range(len(offs))}) == len(offs)   # every position leaves its own state
+        # n m != 2^k: verification_scalars fails before the inner-product domain separator (ipp.rs:203-213); byte-wise replay
+        if m >= 2:
+            st = transcript_append_message(transcript_new(label), b"pad", b"1234567")
+            z = bytearray(pr)
+            z[64:96] = bytes(32)               # ... unless an identity T_1 ends the replay earlier
+            for var in (pr, bytes(z)):
+                so, to = C.create_string_buffer(1), C.create_string_buffer(208)
+                assert H.h_rp_transcript_shape_stop(n, m // 2, var, len(pr), vc[:32 * (m // 2)], rng[:64], st, so, to) == 0
+                rc_o, _, ts_o = oracle.verify_ts(oracle.Gens(n, m // 2), var, vc[:32 * (m // 2)], n, st, rng[:64])
+                assert rc_o == 1 and so.raw[0] == 1 and ts_o == to.raw
 
 
 def test_window_recoding_all_widths(H):

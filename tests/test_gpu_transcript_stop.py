@@ -1,0 +1,146 @@
+"""The caller's `&mut Transcript` after an early `Err` (src/transcript.rs:75-87: validate_and_append_point returns before it absorbs
+an identity A / S / T_1 / T_2 / L_i / R_i -- call sites mod.rs:376-393, ipp.rs:217-222; verification_scalars bails at ipp.rs:203-211
+when n m != 2^k): the state handed back is the one of that moment, not the fully replayed one.  An identity encoding at every one of
+the 4 + 2k positions of the 16 golden shapes; verdict and 208-byte state == oracle.verify_ts through
+  * the context, per-proof states at mixed STROBE positions (byte-wise replay, k_rp_stage1<false>),
+  * the context, one shared state, a narrow batch (32-lane replay, k_rp_stage1_coop) and a wide one (scripted, k_rp_stage1<true>),
+  * the pool's combining queue: one position class (CK_UNIFORM, scripted) and more classes than buffers (CK_MIXED, byte-wise)."""
+import hashlib
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+TS = 208
+
+
+def _variants(pr, k):
+    offs = [0, 32, 64, 96] + [224 + 32 * j for j in range(2 * k)]   # transcript order: A, S, T_1, T_2, L_0, R_0, L_1, ...
+    out = []
+    for o in offs:
+        z = bytearray(pr)
+        z[o:o + 32] = bytes(32)
+        out.append(bytes(z))
+    z = bytearray(pr)               # two identities: the replay ends at the first
+    z[offs[2]:offs[2] + 32] = bytes(32)
+    z[offs[-2]:offs[-2] + 32] = bytes(32)
+    out.append(bytes(z))
+    z = bytearray(pr)               # an undecodable (non-identity) point: found by the decoder, AFTER the whole replay
+    z[offs[-1]:offs[-1] + 32] = b"\x01" + bytes(31)   # (s = 1 is "negative": rejected by the decoder)
+    out.append(bytes(z))
+    out.append(pr)
+    return out
+
+
+def _states(oracle, label, count, classes):
+    """`count` start states; classes == 1: one STROBE position, different sponge words; else `classes` different positions"""
+    sts = []
+    for i in range(count):
+        st = oracle.transcript_new(label)
+        ln = 9 if classes == 1 else 1 + (i % classes) * 3
+        st = oracle.transcript_append_message(st, b"ctx", hashlib.shake_256(b"st%d" % i).digest(ln))
+        sts.append(st)
+    return sts
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import bulletproofs_amd as bp
+    c = bp.Context(0, fixed_window_bits=12)
+    c.gens_create(64, 8)
+    yield c
+    c.close()
+
+
+@pytest.fixture(scope="module")
+def pool():
+    import bulletproofs_amd as bp
+    p = bp.Pool((0,), 4, fixed_window_bits=12)
+    p.gens_create(64, 8)
+    yield p
+    p.close()
+
+
+def _cases(golden):
+    for case in golden["cases"]:
+        n, m = case["n"], case["m"]
+        yield n, m, bytes.fromhex(case["proof"]), (n * m).bit_length() - 1
+
+
+def _compare(tag, n, m, v, ts, exp, sts_in=None):
+    for i, (rc, _, est) in enumerate(exp):
+        assert v[i] == rc, (tag, n, m, i, v[i], rc)
+        assert ts[TS * i:TS * (i + 1)] == est, (tag, n, m, i)
+
+
+def test_context_bytewise_scripted_and_32_lane_replays_stop_where_the_reference_stops(ctx, oracle, oracle_gens_64_8, golden):
+    label = golden["label"]
+    vc = golden["vc_bytes"]
+    for n, m, pr, k in _cases(golden):
+        var = _variants(pr, k)
+        nb, pl = len(var), len(pr)
+        proofs, coms = b"".join(var), vc[:32 * m] * nb
+        rng = hashlib.shake_256(b"stop-rng%d-%d" % (n, m)).digest(64 * nb)
+        # (a) per-proof states at mixed positions: the byte-wise replay
+        sts = _states(oracle, label, nb, 5)
+        exp = [oracle.verify_ts(oracle_gens_64_8, var[i], coms[:32 * m], n, sts[i], rng[64 * i:64 * i + 64]) for i in range(nb)]
+        assert [e[0] for e in exp] == [1] * (nb - 1) + [0]
+        v, _, ts = ctx.rangeproof_verify_batch_ts(n, m, proofs, pl, coms, b"".join(sts), rng, want_transcripts=True)
+        _compare("bytewise", n, m, v, ts, exp)
+        assert len({ts[TS * i:TS * (i + 1)] for i in range(nb)}) == nb
+        # (b) one shared state, narrow batch: 32 lanes per proof
+        st0 = sts[1]
+        exp0 = [oracle.verify_ts(oracle_gens_64_8, var[i], coms[:32 * m], n, st0, rng[64 * i:64 * i + 64]) for i in range(nb)]
+        v, _, ts = ctx.rangeproof_verify_batch_ts(n, m, proofs, pl, coms, st0, rng, want_transcripts=True)
+        _compare("coop", n, m, v, ts, exp0)
+        # (c) the same, wider than 256 proofs: one lane per proof, scripted
+        rep = 256 // nb + 1
+        v, _, ts = ctx.rangeproof_verify_batch_ts(n, m, proofs * rep, pl, coms * rep, st0, rng * rep, want_transcripts=True)
+        _compare("scripted", n, m, v, ts, exp0 * rep)
+
+
+def test_shape_mismatch_hands_back_the_transcript_as_of_the_w_challenge(ctx, oracle, golden):
+    """n m != 2^k: Err(VerificationError) from verification_scalars (ipp.rs:203-211), after t_x ... w were processed"""
+    label = golden["label"]
+    vc = golden["vc_bytes"]
+    for n, m, pr, k in _cases(golden):
+        if m < 2:
+            continue
+        m2 = m // 2
+        z = bytearray(pr)
+        z[64:96] = bytes(32)            # ... unless an identity T_1 ends the replay earlier
+        var = [pr, bytes(z), pr]
+        sts = _states(oracle, label, 3, 3)
+        rng = hashlib.shake_256(b"shape-rng").digest(64 * 3)
+        g2 = oracle.Gens(64, 8)
+        exp = [oracle.verify_ts(g2, var[i], vc[:32 * m2], n, sts[i], rng[64 * i:64 * i + 64]) for i in range(3)]
+        assert [e[0] for e in exp] == [1, 1, 1]
+        v, _, ts = ctx.rangeproof_verify_batch_ts(n, m2, b"".join(var), len(pr), vc[:32 * m2] * 3, b"".join(sts), rng, want_transcripts=True)
+        _compare("shape", n, m2, v, ts, exp)
+        v, _, ts = ctx.rangeproof_verify_batch_ts(n, m2, b"".join(var), len(pr), vc[:32 * m2] * 3, sts[0], rng, want_transcripts=True)
+        exp = [oracle.verify_ts(g2, var[i], vc[:32 * m2], n, sts[0], rng[64 * i:64 * i + 64]) for i in range(3)]
+        _compare("shape-shared", n, m2, v, ts, exp)
+
+
+def test_combining_queue_scripted_and_mixed_classes_stop_where_the_reference_stops(pool, oracle, oracle_gens_64_8, golden):
+    label = golden["label"]
+    vc = golden["vc_bytes"]
+    for n, m, pr, k in _cases(golden):
+        var = _variants(pr, k)
+        nb, pl = len(var), len(pr)
+        proofs, coms = b"".join(var), vc[:32 * m] * nb
+        rng = hashlib.shake_256(b"stopq-rng%d-%d" % (n, m)).digest(64 * nb)
+        for classes, max_open in ((1, 4), (6, 2)):   # one position class: the scripted chain; six classes over two buffers: the catch-all
+            sts = _states(oracle, label, nb, classes)
+            exp = [oracle.verify_ts(oracle_gens_64_8, var[i], coms[:32 * m], n, sts[i], rng[64 * i:64 * i + 64]) for i in range(nb)]
+            pool.set_option("combine_max_open", max_open)
+            try:
+                tickets = [pool.submit_ts(n, m, var[i], pl, coms[:32 * m], sts[i], rng[64 * i:64 * i + 64], want_msm=True, want_transcripts=True) for i in range(nb)]
+                got = [t.wait() for t in tickets]
+            finally:
+                pool.set_option("combine_max_open", 4)
+            for i, (gv, gm, gt) in enumerate(got):
+                assert gv[0] == exp[i][0], (classes, n, m, i)
+                assert gt == exp[i][2], (classes, n, m, i)
+            # one blocking call with all of them
+            v, _, ts = pool.rangeproof_verify_ts(n, m, proofs, pl, coms, b"".join(sts), rng, want_transcripts=True)
+            _compare("queue%d" % classes, n, m, v, ts, exp)

@@ -23,6 +23,7 @@
 #include <vector>
 
 #include "bpgpu.h"
+extern "C" int bpgpu_internal_pool_state(bpgpu_pool *, char *, size_t);   // (diagnostics hook of libbpgpu.so, not part of the ABI)
 
 struct inputs {
     uint32_t n, m, proof_len, count;
@@ -232,6 +233,23 @@ int main(int argc, char **argv) {
         }
         total += done;
     };
+    // watchdog: a run that does not end within its time + 20 s says where the queue stands, then gives up (the caller sees exit code 3
+    // and the state on stderr instead of a silent timeout)
+    std::atomic<int> phase{0};   // 0 running, 1 workers joined, 2 pool destroyed
+    std::thread([&phase, pool, seconds] {
+        const double limit = now_s() + seconds + 20.0;
+        while (now_s() < limit) {
+            if (phase.load() == 2) return;
+            std::this_thread::sleep_for(std::chrono::milliseconds(50));
+        }
+        if (phase.load() == 2) return;
+        static char buf[16384];
+        fprintf(stderr, "combine_rate: WATCHDOG -- still in phase %d (0 = workers running, 1 = destroying the pool) 20 s after the run should have ended\n", phase.load());
+        if (phase.load() == 0 && bpgpu_internal_pool_state(pool, buf, sizeof buf) == 0) fputs(buf, stderr);
+        fflush(stderr);
+        fflush(stdout);
+        _Exit(3);
+    }).detach();
     std::vector<std::thread> th;
     const double t0 = now_s();
     for (int t = 0; t < T; t++) th.emplace_back(worker, t);
@@ -240,6 +258,7 @@ int main(int argc, char **argv) {
     std::this_thread::sleep_for(std::chrono::duration<double>(seconds));
     stop = true;
     for (auto &x : th) x.join();
+    phase = 1;
     const double t2 = now_s();
     std::vector<float> all;
     for (auto &l : lat) all.insert(all.end(), l.begin(), l.end());
@@ -256,7 +275,9 @@ int main(int argc, char **argv) {
            mode.c_str(), T, arg2, t2 - t1, (unsigned long long)total.load(), (double)total.load() / (t2 - t1), all.size(), pct(0.5), pct(0.9), pct(0.99),
            all.empty() ? 0.0 : (double)all.back(), (long long)chains, chains ? (double)cproofs / (double)chains : 0.0, (unsigned long long)mismatches.load(),
            (unsigned long long)errors.load(), t1 - t0, chains ? (double)iss / (double)chains : 0.0, chains ? (double)cmp / (double)chains : 0.0, (long long)polls);
+    fflush(stdout);   // (the figures survive whatever happens during the teardown)
     if (getenv("BP_TRACE")) bpgpu_pool_trace_dump(pool, getenv("BP_TRACE"));
     bpgpu_pool_destroy(pool);
+    phase = 2;
     return (mismatches.load() || errors.load()) ? 1 : 0;
 }
