@@ -523,7 +523,7 @@ def mixed_shapes(a, local_dev, long_run):
     return out
 
 
-def drop_in_call_shape(long_run):
+def drop_in_call_shape(long_run, local_dev=0):
     """tools/combine_rate.cpp (built here with g++) against a pool of its own (W = 16 tables: 8.7 GB beside this process's): T host
     threads looping BLOCKING single-proof bpgpu_pool_rangeproof_verify_ts calls, tickets, and two threads with 4096-proof calls."""
     import shutil
@@ -552,6 +552,30 @@ def drop_in_call_shape(long_run):
                     "errors": d["errors"]}
         if d["mismatches"] or d["errors"]:
             raise SystemExit("the combining queue returned a result that differs from the oracle's -- result invalid")
+    # the boundary function itself, one multiscalar multiplication per blocking call (bpgpu_pool_msm_batch_shared; r1cs/verifier.rs:459-491's shape:
+    # config 5, 4098 generator terms + 2081 points of the caller), every result compared with the committed oracle encodings
+    try:
+        sys.path.insert(0, os.path.join(root, "tools"))
+        import make_msm_inputs
+        mpath = os.path.join("/tmp", "bp_msm_inputs_%d.bin" % os.getpid())
+        make_msm_inputs.write(mpath, local_dev)
+        env_m = dict(env, BP_W="12", BP_MSM_INPUTS=mpath)
+        for key, mode in (("msm_threads_1", ["msm", "1", "1"]), ("msm_threads_64", ["msm", "64", "1"])):
+            p = subprocess.run([exe, inp, secs] + mode, env=env_m, capture_output=True, text=True, timeout=120)
+            line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if not line:
+                out[key] = {"error": p.stderr[-300:]}
+                continue
+            d = json.loads(line[-1])
+            out[key] = {"msms_per_s": d["rate_per_s"], "latency_ms": d["lat_ms"], "msms_per_chain": d["proofs_per_chain"], "mismatches_vs_oracle": d["mismatches"],
+                        "errors": d["errors"], "note": "6179-term MSMs, host pointers in and out (264 kB per MSM over PCIe), W = 12 tables for the 4098 generators"}
+            if d["mismatches"] or d["errors"]:
+                raise SystemExit("a pooled multiscalar multiplication differs from the oracle's encoding -- result invalid")
+        os.unlink(mpath)
+    except SystemExit:
+        raise
+    except Exception as e:
+        out["msm_threads_64"] = {"error": str(e)}
     try:
         os.unlink(exe)
     except OSError:
@@ -559,7 +583,7 @@ def drop_in_call_shape(long_run):
     return out
 
 
-def bench_cfg5_shape(a, local_dev, steps=48, nstreams=8):
+def bench_cfg5_shape(a, local_dev, steps=96, nstreams=16):
     """BASELINE config 5's MSM shape: N = 6179 = 4098 generator terms (tables) + 2081 per-MSM points, batches of 64 MSMs,
     through bpgpu_msm_batch_shared_dev; inputs resident in HBM.  Informational (`extra`)."""
     import torch
@@ -773,7 +797,10 @@ def main():
     batch = a.batch or default_batch
     direct = a.direct
     nstreams = lanes_for(a, a.steps, direct)
+    t_build0 = time.perf_counter()
     b = RangeProofBench(a, a.config, batch, nstreams, rank, local_dev, rlc=a.rlc)
+    torch.cuda.synchronize()
+    build_s = time.perf_counter() - t_build0          # contexts, generators derived on the device, window tables built (every rank its own)
     n, m = b.fx.n, b.fx.m
     N_terms = wl.msm_terms(n, m)
 
@@ -793,6 +820,20 @@ def main():
         assert allv.shape[0] == world and bool(((allv == 0) | (allv == 1) | (allv == 5)).all().item())
     window_bits, table_bytes = b.get_option("fixed_window_bits"), b.get_option("fixed_table_bytes")
     value = world * batch * a.steps / elapsed if a.steps else 0.0
+    # what a SCALE record needs to speak for itself: the ranks the process group really has, its backend, every rank's own
+    # rate (its own clock, no barrier wait) and table-build time
+    per_rank = bpdist.gather_floats([batch * a.steps / r["elapsed"] if a.steps and r["elapsed"] else 0.0, build_s, float(local_dev)], world, None if oversub else dev)
+    multi = {"ranks_in_process_group": dist.get_world_size() if (world > 1 and dist.is_initialized()) else 1,
+             "backend": (dist.get_backend() if (world > 1 and dist.is_initialized()) else "none (single process, no process group)"),
+             "rccl_ranks": (dist.get_world_size() if (world > 1 and dist.is_initialized() and dist.get_backend() == "nccl") else 0),
+             "launcher": "torch.distributed.run" if "TORCHELASTIC_RUN_ID" in os.environ or "LOCAL_RANK" in os.environ else "plain python",
+             "visible_gpus": ndev, "ranks_share_gpus": oversub,
+             "per_rank_verifications_per_s": [round(x[0], 1) for x in per_rank],
+             "per_rank_table_build_s": [round(x[1], 3) for x in per_rank],
+             "per_rank_device": [int(x[2]) for x in per_rank],
+             "collective_in_timed_region": ("one all_gather of the verdict bytes per region + one MAX all-reduce of the region time" if world > 1 else "none"),
+             "note": "value = n_gpus x batch x steps / max-over-ranks time; per-rank rates are each rank's own clock around the same regions.  N = 1 under "
+                     "torch.distributed.run runs this same code without a process group (world = 1): its line equals the plain `python bench.py` line within box spread"}
     ppl, splits, sched = float(batch), 64, "one launch chain per step on %d (context, stream) pairs, round-robin (bpgpu_rangeproof_verify_batch_dev)" % nstreams
     if b.pool is not None:
         ch, cp = b.pool.get_option("stat_chains"), b.pool.get_option("stat_chain_proofs")
@@ -833,6 +874,20 @@ def main():
             br.close()
         except Exception as e:
             extra["rlc"] = {"error": str(e)}
+    if want_extra and a.config == "cfg2" and not a.window_bits and not a.table_bytes:
+        # the headline walks 113 GB of window tables (W = 20).  The same steps at W = 16 -- 8.7 GB, a budget a co-tenant can live with
+        try:
+            import copy
+            a16 = copy.copy(a)
+            a16.window_bits = 16
+            b16 = RangeProofBench(a16, a.config, batch, lanes_for(a, a.steps, False), rank, local_dev)
+            r16 = timed(b16, a.steps, a.warmup, fence, a.repeat, None, False, True)
+            extra["small_table"] = {"verifications_per_s": round(batch * a.steps / r16["elapsed"], 1), "fixed_window_bits": b16.get_option("fixed_window_bits"),
+                                    "fixed_table_bytes": b16.get_option("fixed_table_bytes"), "regions": len(r16["regions"]),
+                                    "note": "the headline's steps with 16-bit windows: 17 table lookups per generator term instead of 13, a thirteenth of the HBM"}
+            b16.close()
+        except Exception as e:
+            extra["small_table"] = {"error": str(e)}
     if want_extra and a.config == "cfg2" and not a.batch:
         # the batch-combined entry point at batches of 4096: from 32768 terms the per-proof points of the whole batch go through
         # ONE bucket (Pippenger) MSM (csrc/bucket.h)
@@ -926,7 +981,7 @@ def main():
         # (a C++ client, no Python in the loop), every proof with its own transcript (half of them pre-bound), every result compared with
         # the oracle's committed expectations (bench_data/combine_rate_inputs.bin).  PCIe-inclusive by nature; never `value`.
         try:
-            extra["drop_in_call_shape"] = drop_in_call_shape(long_run)
+            extra["drop_in_call_shape"] = drop_in_call_shape(long_run, local_dev)
         except Exception as e:
             extra["drop_in_call_shape"] = {"error": str(e)}
 
@@ -966,6 +1021,7 @@ def main():
                        "mode": "rlc (one combined identity check per batch)" if a.rlc else "per-proof verdicts (the reference's semantics)",
                        "scheduler": sched, "lanes": nstreams, "parallelism": "independent proofs sharded, dp%d%s" % (world, " (ranks share GPUs: gloo gather)" if oversub else "")},
             "roofline": roof,
+            "multi_gpu": multi,
         }
         if extra:
             out["extra"] = extra

@@ -364,6 +364,8 @@ struct pool_dev {
     std::atomic<uint64_t> stat_chains{0}, stat_proofs{0}, stat_requests{0};
     std::atomic<uint64_t> stat_issue_ns{0}, stat_complete_ns{0}, stat_polls{0}, stat_deliver_ns{0};
     std::atomic<uint32_t> recent_K{0};      // width of the chain issued last (sizes the next buffer)
+    uint32_t last_done_K[4] = {0, 0, 0, 0};      // (service thread) width of the chain of each kind that completed last: the group about to come back
+    uint64_t t_last_done[4] = {0, 0, 0, 0};
     std::mutex trace_mu;
     std::vector<chain_ev> trace_chains;     // rings (option "combine_trace")
     std::vector<req_ev> trace_reqs;
@@ -385,7 +387,14 @@ struct bpgpu_pool {
     size_t latency_proofs = 6144;    // a host call / a flush on an idle device of up to this many proofs is "alone": its chains take the latency forms
     size_t auto_flush_items = 0;     // flush by itself once this many items wait on a device (0 = lanes)
     size_t auto_flush_proofs = 0;    // ... or once this many proofs wait: they go out as ONE chain while the caller keeps submitting (0 = off)
-    int plan_by_work = 1;            // a flush is cut into chains by table-walk work ((2nm+2) generator terms per proof, in (64,1)-proof equivalents), not by proof count
+    // How a flush is cut into chains: 0 = by proof count alone (round 4); 1 = in proportion to table-walk work ((2nm+2) generator terms per
+    // proof, in (64,1)-proof equivalents: every chain carries about coalesce_proofs equivalents); 2 (default) = by proof count, but a LONE
+    // chain that carries two chains' worth of work is cut in two.  Measured on BASELINE configs 3 / 4 (profiles/r05/plan_by_work_ab.txt, one box
+    // per table): 20 x 256 proofs of m = 16 as one chain of 5120 / two of 2560 / fourteen of 384: 537 / 574 / 523 k/s; 20 x 512 of m = 32 as two
+    // of 5120 / four of 2560 / eight of 1344: 319 / 311 / 248 k/s -- what a burst wants is TWO overlapping chains, whatever the proofs weigh;
+    // launch 1's lane-serial transcript is per proof, so many narrow chains pay it many times over
+    int plan_by_work = 2;
+    size_t plan_min_chain_proofs = 0;   // ... but no chain of a burst narrower than this many proofs of its shape (0 = no floor): launch 1's lane-serial roles are per PROOF
     size_t host_workers = 0;
     // combining queue
     std::atomic<uint32_t> comb_cap_max{5120};         // = coalesce_proofs (readable without `mu`)
@@ -401,6 +410,14 @@ struct bpgpu_pool {
     std::atomic<uint32_t> combine_wide_proofs{384};
     std::atomic<uint32_t> combine_inflight_wide{3};
     std::atomic<uint64_t> combine_hold_ns{400000};
+    // cohort policy (combine_policy = 1; 0 = the two regimes above; 2, the default, = per kind of work, see svc_main): callers come back in the groups their chains released them in
+    // -- a chain's worth of requests completes at once, its owners resubmit within tens of microseconds --, so a buffer leaves as soon as the
+    // group that just finished is back (no quiet period to sit out), at most combine_cohort_inflight chains run (a chain's latency is nearly
+    // flat in its width and grows with every chain beside it: few wide chains beat many narrow ones on throughput AND latency), and a
+    // fragment that arrives while the device is busy waits for company
+    std::atomic<uint32_t> combine_policy{2};
+    std::atomic<uint32_t> combine_cohort_inflight{2};
+    std::atomic<uint64_t> combine_regroup_ns{60000};     // after a completion with nothing else in flight: this long for its callers to come back before `quiet` may seal
     std::atomic<uint64_t> combine_msm_bytes{32u << 20};   // staging block of a multiscalar-multiplication class (bpgpu_pool_msm_*): items per chain = this / bytes per MSM
     std::atomic<uint32_t> combine_mapped_out{1024};   // chains of up to this many proofs write their results straight into the pinned host block (no copy command behind the chain)
     std::atomic<uint32_t> combine_trace{0};           // ring sizes of the timeline records (0 = off)
@@ -608,7 +625,13 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
         return BPGPU_OK;
     }
     if (!strcmp(key, "plan_by_work")) {
-        p->plan_by_work = value != 0;
+        if (value < 0 || value > 2) return pfail(p, BPGPU_ERR_INVALID_ARG, "plan_by_work out of range");
+        p->plan_by_work = (int)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "plan_min_chain_proofs")) {
+        if (value < 0 || value > (1 << 22)) return pfail(p, BPGPU_ERR_INVALID_ARG, "plan_min_chain_proofs out of range");
+        p->plan_min_chain_proofs = (size_t)value;
         return BPGPU_OK;
     }
     if (!strcmp(key, "stat_reset")) {
@@ -637,6 +660,16 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
     if (!strcmp(key, "combine_wide_proofs") || !strcmp(key, "combine_mapped_out")) {
         if (value < 0 || value > (1 << 22)) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
         (key[8] == 'w' ? p->combine_wide_proofs : p->combine_mapped_out) = (uint32_t)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "combine_policy") || !strcmp(key, "combine_cohort_inflight")) {
+        if (value < 0 || value > 64 || (key[8] == 'c' && value < 1)) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
+        (key[8] == 'p' ? p->combine_policy : p->combine_cohort_inflight) = (uint32_t)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "combine_regroup_us")) {
+        if (value < 0 || value > 1000000) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
+        p->combine_regroup_ns = (uint64_t)value * 1000;
         return BPGPU_OK;
     }
     if (!strcmp(key, "combine_inflight_wide")) {
@@ -694,6 +727,7 @@ int bpgpu_pool_get_option(bpgpu_pool *p, const char *key, int64_t *value) {
     else if (!strcmp(key, "auto_flush_items")) *value = (int64_t)p->auto_flush_items;
     else if (!strcmp(key, "auto_flush_proofs")) *value = (int64_t)p->auto_flush_proofs;
     else if (!strcmp(key, "plan_by_work")) *value = (int64_t)p->plan_by_work;
+    else if (!strcmp(key, "plan_min_chain_proofs")) *value = (int64_t)p->plan_min_chain_proofs;
     else if (!strcmp(key, "latency_proofs")) *value = (int64_t)p->latency_proofs;
     else if (!strcmp(key, "pair_limit_proofs")) *value = (int64_t)p->pair_limit_proofs;
     else if (!strcmp(key, "host_workers")) *value = (int64_t)p->host_workers;
@@ -710,6 +744,9 @@ int bpgpu_pool_get_option(bpgpu_pool *p, const char *key, int64_t *value) {
     else if (!strcmp(key, "combine_hold_us")) *value = (int64_t)(p->combine_hold_ns / 1000);
     else if (!strcmp(key, "combine_wide_proofs")) *value = (int64_t)p->combine_wide_proofs;
     else if (!strcmp(key, "combine_inflight_wide")) *value = (int64_t)p->combine_inflight_wide;
+    else if (!strcmp(key, "combine_policy")) *value = (int64_t)p->combine_policy;
+    else if (!strcmp(key, "combine_cohort_inflight")) *value = (int64_t)p->combine_cohort_inflight;
+    else if (!strcmp(key, "combine_regroup_us")) *value = (int64_t)(p->combine_regroup_ns / 1000);
     else if (!strcmp(key, "combine_msm_bytes")) *value = (int64_t)p->combine_msm_bytes;
     else if (!strcmp(key, "combine_mapped_out")) *value = (int64_t)p->combine_mapped_out;
     else if (!strcmp(key, "combine_trace")) *value = (int64_t)p->combine_trace;
@@ -1127,6 +1164,8 @@ static void comb_issue(bpgpu_pool *p, pool_dev *d, comb_buf *b, uint32_t infligh
 // delivery thread's.
 static void comb_complete(pool_dev *d, comb_buf *b) {
     b->ev.t_done = now_ns();
+    d->last_done_K[b->key.kind & 3] = b->K;   // (service thread only: the group that is about to come back)
+    d->t_last_done[b->key.kind & 3] = b->ev.t_done;
     const uint32_t epoch = cbs_epoch(b->state.load(std::memory_order_relaxed));
     const bool any_async = b->n_async.load(std::memory_order_relaxed) != 0, any_sync = b->n_sync.load(std::memory_order_relaxed) != 0;
     b->st.store(CB_DONE, std::memory_order_release);
@@ -1188,6 +1227,45 @@ static void dlv_main(bpgpu_pool *p, pool_dev *d) {
 //     completion's resubmissions) -- chains then stay about as wide as the population of requests allows instead of being cut into
 //     combine_wait_us slices of the arrival stream;
 //   always: nothing waits longer than combine_max_age_us.
+// Cohort policy (combine_policy = 1).  `expected` / t_done: width and completion time of the chain of this kind that finished last --
+// its callers are on their way back.
+//   * the group is back (r >= expected): leave at once -- a lone caller's next call does not sit out a quiet period, sixty-four
+//     callers released together travel together again;
+//   * nothing runs: leave when nothing has joined for combine_quiet_us -- but within combine_regroup_us of a completion whose group
+//     is not back yet, wait for it (a straggler would otherwise leave alone the moment the big chain ends and stay out of step for
+//     good); combine_wait_us after the first arrival at the latest;
+//   * something runs (fewer than combine_cohort_inflight chains): a chain issued now slows the running one and is slowed by it -- worth
+//     it when it carries at least half the width of what runs (and is quiet), or after combine_hold_us;
+//   * combine_cohort_inflight chains run: the buffer fills until one ends;
+//   * always: nothing waits longer than combine_max_age_us.
+static bool policy_seal_cohort(bpgpu_pool *p, uint32_t r, uint64_t now, uint64_t t_open, uint64_t t_change, uint32_t inflight, uint64_t inflight_items,
+                               uint32_t n_free, uint32_t expected, uint64_t t_done) {
+    const uint64_t age = now - t_open;
+    // (the safety net is a chain's duration away, not a policy lever: with combine_cohort_inflight chains running nothing can leave anyway
+    // until one ends, and a chain a thousand proofs wide beside another takes ~1 ms)
+    if (age >= 3 * p->combine_max_age_ns.load(std::memory_order_relaxed)) return true;
+    if (n_free <= 1 && inflight != 0) return false;   // (the last place callers can gather in: see policy_seal)
+    if (inflight >= p->combine_cohort_inflight.load(std::memory_order_relaxed)) return false;
+    const uint64_t regroup = p->combine_regroup_ns.load(std::memory_order_relaxed), quiet_ns = p->combine_quiet_ns.load(std::memory_order_relaxed);
+    const bool fresh = expected != 0 && now - t_done < 4 * regroup;   // (a completion long ago says nothing about who is coming)
+    // the group is back: a handful of callers leave at once; a large group while requests are still pouring in takes them along (one poll without a newcomer)
+    if (fresh && r >= expected && (expected <= 4 || now - t_change >= quiet_ns / 2)) return true;
+    const bool quiet = now - t_change >= quiet_ns;
+    if (inflight == 0) {
+        const bool regrouping = fresh && now - t_done < regroup;
+        if (quiet && !regrouping) return true;
+        return age >= p->combine_wait_ns.load(std::memory_order_relaxed);
+    }
+    const uint64_t avg = inflight_items / inflight;
+    if (quiet && (uint64_t)r * 2 >= avg) return true;
+    return age >= p->combine_hold_ns.load(std::memory_order_relaxed);
+}
+extern "C" int bpgpu_internal_policy_seal_cohort(bpgpu_pool *p, uint32_t r, uint64_t age_ns, uint64_t quiet_ns, uint32_t inflight, uint64_t inflight_items, uint32_t n_free,
+                                                 uint32_t expected, uint64_t since_done_ns) {
+    const uint64_t now = 1ull << 40;
+    return policy_seal_cohort(p, r, now, now - age_ns, now - quiet_ns, inflight, inflight_items, n_free, expected, now - since_done_ns) ? 1 : 0;
+}
+
 static bool policy_seal(bpgpu_pool *p, uint32_t r, uint64_t now, uint64_t t_open, uint64_t t_change, uint32_t inflight, uint64_t inflight_items, bool rp_class,
                         uint32_t n_free) {
     const uint64_t age = now - t_open;
@@ -1231,12 +1309,13 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
         const uint64_t now = now_ns();
         d->stat_polls.fetch_add(1, std::memory_order_relaxed);
         uint32_t inflight = 0, waiting = 0, n_free = 0;
-        uint64_t inflight_items = 0;
+        uint64_t inflight_items = 0, inflight_all_items = 0;   // (range-proof classes only / every kind)
         for (comb_buf *b : d->cbufs) {
             const int st = b->st.load(std::memory_order_acquire);
             if (st == CB_FREE) n_free++;
             if (st == CB_ISSUED || st == CB_ISSUING || st == CB_SEALED) {
                 inflight++;
+                inflight_all_items += b->K;
                 if (b->key.kind == CQ_RP) inflight_items += b->K;
             }
             if (st == CB_OPEN || st == CB_SEALED) waiting++;
@@ -1253,7 +1332,20 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
                 if (b->seen_epoch != e) b->seen_epoch = e, b->seen_reserved = r, b->t_change = b->t_open;
                 else if (r != b->seen_reserved) b->seen_reserved = r, b->t_change = now;
                 bool seal = cbs_sealed(s);   // a caller took the last slot
-                if (!seal && (stopping || policy_seal(p, r, now, b->t_open, b->t_change, inflight, inflight_items, b->key.kind == CQ_RP, n_free))) {
+                const uint32_t kd = b->key.kind & 3;
+                // combine_policy: 0 = the two regimes for every kind; 1 = cohorts for every kind; 2 (default) = what the device measured best
+                // (profiles/r05/combine_policy_ab.txt): range proofs keep the regimes -- four to six narrow chains in flight overlap well, 64
+                // blocking threads 81 k/s against 66 k/s in cohorts, 16 x 128 tickets 795 against 700 k/s -- plus the cohort rule for a handful
+                // of callers (a lone caller's next call leaves at once: 0.557 -> 0.529 ms per call); multiscalar multiplications and
+                // inner-product proofs, whose chains are a dozen launches of bucket work each, travel in cohorts (64 threads 26.7 -> 32.5 k MSMs/s)
+                const uint32_t pol = p->combine_policy.load(std::memory_order_relaxed);
+                const bool cohort = pol == 1 || (pol == 2 && b->key.kind != CQ_RP);
+                bool due = cohort ? policy_seal_cohort(p, r, now, b->t_open, b->t_change, inflight, inflight_all_items, n_free, d->last_done_K[kd], d->t_last_done[kd])
+                                  : policy_seal(p, r, now, b->t_open, b->t_change, inflight, inflight_items, b->key.kind == CQ_RP, n_free);
+                if (!due && pol == 2 && !cohort && d->last_done_K[kd] != 0 && d->last_done_K[kd] <= 4 && r >= d->last_done_K[kd] &&
+                    now - d->t_last_done[kd] < 4 * p->combine_regroup_ns.load(std::memory_order_relaxed) && inflight == 0)
+                    due = true;   // the few callers the last chain released are all back and nothing else runs: nothing to wait for
+                if (!seal && (stopping || due)) {
                     s = b->state.fetch_or(CBS_SEALED, std::memory_order_acq_rel);   // (slots taken since the load above are in the value this returns)
                     seal = true;
                 }
@@ -1265,6 +1357,7 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
                     b->st.store(CB_SEALED, std::memory_order_release);
                     st = CB_SEALED;
                     inflight++;   // (counts against the limits at once: two buffers due in the same pass)
+                    inflight_all_items += b->K;
                     if (b->key.kind == CQ_RP) inflight_items += b->K;
                 }
             }
@@ -2105,6 +2198,21 @@ extern "C" uint64_t bpgpu_internal_work_equiv(uint64_t nbatch, uint64_t n, uint6
 extern "C" uint64_t bpgpu_internal_chain_width(uint64_t per_equiv, uint64_t n, uint64_t m, uint64_t max_chain_proofs) {
     return chain_width((size_t)per_equiv, (size_t)n, (size_t)m, (size_t)max_chain_proofs);
 }
+// plan_by_work = 2: the plan by proof count stands, except that ONE chain carrying at least two chains' worth of work (2 x coalesce_proofs
+// equivalents) becomes two -- the second chain's launch 1 then overlaps the first one's table walk, as it does in every burst of single proofs
+static flush_plan split_lone_heavy(flush_plan fp, size_t T_proofs, size_t T_work, size_t coalesce_proofs, size_t lanes, bool all_rlc, bool one_chain) {
+    if (fp.chains != 1 || one_chain || all_rlc || lanes < 2 || T_proofs < 128 || T_work < 2 * coalesce_proofs) return fp;
+    fp.per = (((T_proofs + 1) / 2) + 63) & ~(size_t)63;
+    fp.chains = (T_proofs + fp.per - 1) / fp.per;
+    return fp;
+}
+extern "C" void bpgpu_internal_split_lone_heavy(uint64_t chains, uint64_t per, uint64_t T_proofs, uint64_t T_work, uint64_t coalesce_proofs, uint64_t lanes, int all_rlc,
+                                                int one_chain, uint64_t *chains_out, uint64_t *per_out) {
+    flush_plan fp;
+    fp.chains = (size_t)chains, fp.per = (size_t)per, fp.splits_hint = 0;
+    fp = split_lone_heavy(fp, (size_t)T_proofs, (size_t)T_work, (size_t)coalesce_proofs, (size_t)lanes, all_rlc != 0, one_chain != 0);
+    *chains_out = fp.chains, *per_out = fp.per;
+}
 // The order a flush packs its items in: grouped by what lets them share a chain (dev_item::same_shape), groups in order of first
 // appearance, submission order inside a group -- alternating submissions of two shapes become two runs instead of one chain per item
 // (VERDICT r04 #3).  key[i] = any number that is equal exactly for items that may share a chain.
@@ -2143,12 +2251,11 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
         items.reserve(pend.size());
         for (size_t i : flush_group_order(key)) items.push_back(std::move(pend[i]));
     }
-    size_t T = d->pending_proofs;
+    size_t T = d->pending_proofs, T_work = 0;
     d->pending_proofs = 0;
-    if (p->plan_by_work) {
-        T = 0;
-        for (const dev_item &it : items) T += work_equiv(it.nbatch, it.n ? it.n : 1, it.m ? it.m : 1);
-    }
+    for (const dev_item &it : items) T_work += work_equiv(it.nbatch, it.n ? it.n : 1, it.m ? it.m : 1);
+    const bool by_work = p->plan_by_work == 1;
+    if (by_work) T = T_work;
     bool was_idle = false;
     // an idle pool starts again at lane 0: a caller that sends bursts keeps hitting the same few lanes, whose arenas and cached
     // work decompositions already have the right size
@@ -2160,7 +2267,8 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
     }
     bool all_rlc = !items.empty();
     for (const dev_item &it : items) all_rlc = all_rlc && it.rlc;
-    const flush_plan fp = plan_flush(T, p->coalesce_proofs, p->pair_limit_proofs, p->max_chain_proofs, d->lanes.size(), all_rlc, one_chain);
+    flush_plan fp = plan_flush(T, p->coalesce_proofs, p->pair_limit_proofs, p->max_chain_proofs, d->lanes.size(), all_rlc, one_chain);
+    if (p->plan_by_work == 2) fp = split_lone_heavy(fp, T, T_work, p->coalesce_proofs, d->lanes.size(), all_rlc, one_chain);
     const uint32_t hint = fp.splits_hint;
     int rc_all = BPGPU_OK;
     size_t n_undecided = 0;
@@ -2196,7 +2304,8 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
         segs.clear();
         labs.clear();
         carried.clear();
-        const size_t per = p->plan_by_work ? chain_width(fp.per, head.n, head.m, p->max_chain_proofs) : fp.per;   // proofs of THIS shape per chain
+        size_t per = by_work ? chain_width(fp.per, head.n, head.m, p->max_chain_proofs) : fp.per;   // proofs of THIS shape per chain
+        if (by_work && per < p->plan_min_chain_proofs) per = std::min(p->plan_min_chain_proofs, p->max_chain_proofs);
         uint32_t filled = 0;
         bool any_msm = false, any_ticket = false;
         while (i < items.size() && filled < per && items[i].same_shape(head)) {

@@ -36,3 +36,15 @@ def max_over_ranks(value, world, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def gather_floats(values, world, device=None):
+    """every rank's list of floats (equal lengths) -> [world][len] on every rank: the SCALE record's per-rank figures (rate, table build time)"""
+    import torch
+    import torch.distributed as dist
+    if world == 1 and not (dist.is_available() and dist.is_initialized()):
+        return [[float(v) for v in values]]
+    t = torch.tensor([float(v) for v in values], dtype=torch.float64, device=device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return [[float(x) for x in o.cpu().tolist()] for o in out]

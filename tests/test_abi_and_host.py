@@ -268,6 +268,22 @@ def test_flush_plan_how_pending_batches_are_cut_into_launch_chains():
     assert plan(20 * we(512, 64, 32), lanes=8)[0] == 8 and cw(plan(20 * we(512, 64, 32), lanes=8)[1], 64, 32, 16384) == 1344
     assert cw(1, 64, 1, 1 << 20) == 64 and cw(10**9, 64, 1, 16384) == 16384           # whole transcript wavefronts; never wider than max_chain_proofs
     assert cw(5120, 8, 1, 1 << 20) == 36992                                          # small shapes: wider chains for the same work
+    # ---- the default (plan_by_work = 2): by proof count, but a LONE chain with two chains' worth of work is cut in two ----
+    sl = L.bpgpu_internal_split_lone_heavy
+    sl.restype = None
+    sl.argtypes = [C.c_uint64] * 6 + [C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+
+    def split(T, Tw, rlc=0, one=0, lanes=64):
+        ch, per, _ = plan(T, rlc, one, lanes=lanes)
+        co, po = C.c_uint64(), C.c_uint64()
+        sl(ch, per, T, Tw, 5120, lanes, rlc, one, C.byref(co), C.byref(po))
+        return co.value, po.value
+    assert split(20 * 256, 20 * we(256, 64, 16)) == (2, 2560)          # config 3 as the driver runs it: two chains of 2560 instead of one of 5120
+    assert split(20 * 512, 20 * we(512, 64, 32)) == (2, 5120)          # config 4: already two chains by proof count
+    assert split(4096, 4096) == (1, 4096) and split(5120, 5120) == (1, 5120)   # single 64-bit proofs: one chain's worth stays one chain
+    assert split(1024, we(1024, 64, 16)) == (2, 512)                   # a small aggregated burst with two chains' worth of work
+    assert split(512, we(512, 64, 4)) == (1, 512) and split(100, 10**6) == (1, 100)   # ... not below two chains' worth, never chains of a few proofs
+    assert split(5120, 10**6, rlc=1) == (1, 5120) and split(5120, 10**6, one=1) == (1, 5120) and split(5120, 10**6, lanes=1) == (1, 5120)
     # ---- grouping: alternating submissions of two shapes (and of several labels of one length) become runs, order kept inside a run ----
 
     def order(keys):
@@ -278,3 +294,17 @@ def test_flush_plan_how_pending_batches_are_cut_into_launch_chains():
     assert order([0, 1, 0, 1, 0, 1]) == [0, 2, 4, 1, 3, 5]
     assert order([7, 7, 7]) == [0, 1, 2] and order([]) == [] and order([3, 2, 1]) == [0, 1, 2]
     assert order([5, 9, 9, 5, 2, 9]) == [0, 3, 1, 2, 5, 4]
+
+
+def test_integration_md_binds_every_entry_point_of_the_header():
+    """INTEGRATION.md section 1 is the reference-side binding a maintainer would add: every prototype of include/bpgpu.h has its Rust
+    `extern "C"` declaration there (tools/gen_rust_extern.py derives them from the header)."""
+    import re
+    import subprocess
+    import sys
+    out = subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "gen_rust_extern.py"), "--missing"], text=True)
+    assert out.strip() == "", "INTEGRATION.md lacks:\n" + out
+    hdr = open(os.path.join(ROOT, "include", "bpgpu.h")).read()
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    declared = set(re.findall(r"fn (bpgpu_[a-z0-9_]+)", doc))
+    assert len(declared) >= 66 and all(re.search(r"\b%s\s*\(" % n, hdr) for n in declared)   # and nothing there that the header does not have

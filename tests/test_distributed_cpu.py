@@ -32,6 +32,8 @@ def _worker(rank, world, port, q):
     local = torch.tensor(list(v), dtype=torch.uint8)
     allv = bpdist.gather_verdicts(local, world)
     tmax = bpdist.max_over_ranks(1.0 + rank, world)
+    per_rank = bpdist.gather_floats([100.0 + rank, 0.5 * rank], world)   # (the SCALE record's per-rank figures travel this way)
+    assert per_rank == [[100.0 + r_, 0.5 * r_] for r_ in range(world)]
     q.put((rank, allv.flatten().tolist(), tmax))
     torch.distributed.barrier()
     torch.distributed.destroy_process_group()

@@ -21,7 +21,7 @@ def _planted(oracle, gens, n, m, label, count, seed):
     return out
 
 
-@pytest.mark.parametrize("by_work", [0, 1])
+@pytest.mark.parametrize("by_work", [0, 1, 2])
 def test_alternating_shapes_and_four_labels_share_chains_vs_oracle(oracle, by_work):
     import torch
     import bulletproofs_amd as bp
@@ -64,9 +64,13 @@ def test_alternating_shapes_and_four_labels_share_chains_vs_oracle(oracle, by_wo
     pool.wait()
     chains, chain_proofs = pool.get_option("stat_chains"), pool.get_option("stat_chain_proofs")
     assert chain_proofs == 20 * 256 + 20 * 64
-    if by_work:
-        # 5120 single proofs + 1280 proofs of m = 16 (20 190 equivalents): two chains' worth of work -> a few chains, not forty
+    if by_work == 1:
+        # 5120 single proofs + 1280 proofs of m = 16 (25 300 equivalents): a few chains' worth of work -> a few chains, not forty
         assert chains <= 6, chains
+    elif by_work == 2:
+        # the default: by proof count (one chain's worth), cut in two because it carries several chains' worth of work: 3200 + 1920 single
+        # proofs, one chain of the 1280 aggregated ones
+        assert chains == 3, chains
     else:
         assert chains == 2 and chain_proofs / chains >= 2048    # counted in proofs: one chain per shape
     n_ok = 0

@@ -83,18 +83,19 @@ def test_context_bytewise_scripted_and_32_lane_replays_stop_where_the_reference_
         # (a) per-proof states at mixed positions: the byte-wise replay
         sts = _states(oracle, label, nb, 5)
         exp = [oracle.verify_ts(oracle_gens_64_8, var[i], coms[:32 * m], n, sts[i], rng[64 * i:64 * i + 64]) for i in range(nb)]
-        assert [e[0] for e in exp] == [1] * (nb - 1) + [0]
-        v, _, ts = ctx.rangeproof_verify_batch_ts(n, m, proofs, pl, coms, b"".join(sts), rng, want_transcripts=True)
+        assert [e[0] for e in exp] == [1] * nb          # (the last one is the untouched proof -- of another statement under these histories)
+        v, _, ts = ctx.rangeproof_verify_batch_ts(n, m, proofs, pl, coms, b"".join(sts), rng, want_msm=True, want_transcripts=True)
         _compare("bytewise", n, m, v, ts, exp)
         assert len({ts[TS * i:TS * (i + 1)] for i in range(nb)}) == nb
         # (b) one shared state, narrow batch: 32 lanes per proof
-        st0 = sts[1]
+        st0 = oracle.transcript_new(label)              # the history the golden proofs were made on: the untouched one verifies
         exp0 = [oracle.verify_ts(oracle_gens_64_8, var[i], coms[:32 * m], n, st0, rng[64 * i:64 * i + 64]) for i in range(nb)]
-        v, _, ts = ctx.rangeproof_verify_batch_ts(n, m, proofs, pl, coms, st0, rng, want_transcripts=True)
+        assert [e[0] for e in exp0] == [1] * (nb - 1) + [0]
+        v, _, ts = ctx.rangeproof_verify_batch_ts(n, m, proofs, pl, coms, st0, rng, want_msm=True, want_transcripts=True)
         _compare("coop", n, m, v, ts, exp0)
         # (c) the same, wider than 256 proofs: one lane per proof, scripted
         rep = 256 // nb + 1
-        v, _, ts = ctx.rangeproof_verify_batch_ts(n, m, proofs * rep, pl, coms * rep, st0, rng * rep, want_transcripts=True)
+        v, _, ts = ctx.rangeproof_verify_batch_ts(n, m, proofs * rep, pl, coms * rep, st0, rng * rep, want_msm=True, want_transcripts=True)
         _compare("scripted", n, m, v, ts, exp0 * rep)
 
 
@@ -114,9 +115,9 @@ def test_shape_mismatch_hands_back_the_transcript_as_of_the_w_challenge(ctx, ora
         g2 = oracle.Gens(64, 8)
         exp = [oracle.verify_ts(g2, var[i], vc[:32 * m2], n, sts[i], rng[64 * i:64 * i + 64]) for i in range(3)]
         assert [e[0] for e in exp] == [1, 1, 1]
-        v, _, ts = ctx.rangeproof_verify_batch_ts(n, m2, b"".join(var), len(pr), vc[:32 * m2] * 3, b"".join(sts), rng, want_transcripts=True)
+        v, _, ts = ctx.rangeproof_verify_batch_ts(n, m2, b"".join(var), len(pr), vc[:32 * m2] * 3, b"".join(sts), rng, want_msm=True, want_transcripts=True)
         _compare("shape", n, m2, v, ts, exp)
-        v, _, ts = ctx.rangeproof_verify_batch_ts(n, m2, b"".join(var), len(pr), vc[:32 * m2] * 3, sts[0], rng, want_transcripts=True)
+        v, _, ts = ctx.rangeproof_verify_batch_ts(n, m2, b"".join(var), len(pr), vc[:32 * m2] * 3, sts[0], rng, want_msm=True, want_transcripts=True)
         exp = [oracle.verify_ts(g2, var[i], vc[:32 * m2], n, sts[0], rng[64 * i:64 * i + 64]) for i in range(3)]
         _compare("shape-shared", n, m2, v, ts, exp)
 
@@ -142,5 +143,5 @@ def test_combining_queue_scripted_and_mixed_classes_stop_where_the_reference_sto
                 assert gv[0] == exp[i][0], (classes, n, m, i)
                 assert gt == exp[i][2], (classes, n, m, i)
             # one blocking call with all of them
-            v, _, ts = pool.rangeproof_verify_ts(n, m, proofs, pl, coms, b"".join(sts), rng, want_transcripts=True)
+            v, _, ts = pool.rangeproof_verify_ts(n, m, proofs, pl, coms, b"".join(sts), rng, want_msm=True, want_transcripts=True)
             _compare("queue%d" % classes, n, m, v, ts, exp)

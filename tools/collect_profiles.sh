@@ -45,15 +45,19 @@ fi
 # Horner chain aside on the second stream, window sums as their own launch, A outside the window sums): K steps through a one-lane pool =
 # ONE coalesced chain per region; latency_proofs=0 tells the pool not to treat the lone chain as alone (it would take the latency forms)
 declare -A WSTEPS=( [cfg2]=5 [cfg3]=8 [cfg4]=4 )    # x batch 1024 / 256 / 512 = 5120 / 2048 / 2048 proofs per chain
+PMC_CFGS=${PMC_CFGS:-"cfg2 cfg3 cfg4 cfg5"}   # (e.g. PMC_CFGS=cfg5 ONLY_PMC=1: re-collect one configuration's counters)
 for cfg in cfg2 cfg3 cfg4; do
+  case " $PMC_CFGS " in *" $cfg "*) ;; *) continue;; esac
   A="$B --config $cfg --steps ${WSTEPS[$cfg]} --warmup 0 --streams 1 --repeat 3 --opt latency_proofs=0,auto_flush_items=64"
   pmc ${cfg}_fetch FETCH_SIZE $A
   pmc ${cfg}_write WRITE_SIZE $A
   pmc ${cfg}_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" $A
 done
+case " $PMC_CFGS " in *" cfg5 "*)
 pmc cfg5_fetch FETCH_SIZE python $REPO/bench.py --cfg5-only 1
 pmc cfg5_write WRITE_SIZE python $REPO/bench.py --cfg5-only 1
 pmc cfg5_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" python $REPO/bench.py --cfg5-only 1
+;; esac
 
 python $REPO/tools/isa_mix.py > /tmp/isa_mix.json
 python - <<PY
@@ -77,6 +81,7 @@ for cfg, what, ppl in (("cfg2", "bench.py --config cfg2 --steps 5 --warmup 0 --s
                   ("cfg3", "bench.py --config cfg3 --steps 8 --warmup 0 --streams 1 --opt latency_proofs=0,auto_flush_items=64 (one coalesced chain of 2048 per region)", 2048),
                   ("cfg4", "bench.py --config cfg4 --steps 4 --warmup 0 --streams 1 --opt latency_proofs=0,auto_flush_items=64 (one coalesced chain of 2048 per region)", 2048),
                   ("cfg5", "bench.py --cfg5-only 1 (batches of 64 MSMs of 6179 terms)", 64)):
+    if cfg not in "$PMC_CFGS".split(): continue
     rd, wr = per_kernel("/tmp/pm_%s_fetch" % cfg, "FETCH_SIZE"), per_kernel("/tmp/pm_%s_write" % cfg, "WRITE_SIZE")
     json.dump({"FETCH_SIZE": rd, "WRITE_SIZE": wr}, open("$OUT/pmc_fetch_write_raw_%s.json" % cfg, "w"), indent=1)
     # HBM bytes per launch, corrected as MI355X_MICROARCH.md prescribes for gfx950: FETCH_SIZE is in KB and counts a
