@@ -542,10 +542,14 @@ def drop_in_call_shape(long_run, local_dev=0):
     secs = "2.0" if long_run else "1.0"
     for key, mode in (("threads_1", ["threads", "1"]), ("threads_64", ["threads", "64"]), ("threads_256", ["threads", "256"]),
                       ("tickets_16x128", ["tickets", "16", "128"]), ("two_callers_of_4096", ["big", "2", "4096"])):
-        p = subprocess.run([exe, inp, secs] + mode, env=env, capture_output=True, text=True, timeout=120)
+        try:   # (the client has a watchdog of its own: a run that does not end prints the queue's state and exits)
+            p = subprocess.run([exe, inp, secs] + mode, env=env, capture_output=True, text=True, timeout=90)
+        except subprocess.TimeoutExpired:
+            out[key] = {"error": "no result within 90 s"}
+            continue
         line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
         if not line:
-            out[key] = {"error": p.stderr[-300:]}
+            out[key] = {"error": p.stderr[-1500:]}
             continue
         d = json.loads(line[-1])
         out[key] = {"verifications_per_s": d["rate_per_s"], "latency_ms": d["lat_ms"], "proofs_per_chain": d["proofs_per_chain"], "mismatches_vs_oracle": d["mismatches"],
@@ -561,10 +565,14 @@ def drop_in_call_shape(long_run, local_dev=0):
         make_msm_inputs.write(mpath, local_dev)
         env_m = dict(env, BP_W="12", BP_MSM_INPUTS=mpath)
         for key, mode in (("msm_threads_1", ["msm", "1", "1"]), ("msm_threads_64", ["msm", "64", "1"])):
-            p = subprocess.run([exe, inp, secs] + mode, env=env_m, capture_output=True, text=True, timeout=120)
+            try:
+                p = subprocess.run([exe, inp, secs] + mode, env=env_m, capture_output=True, text=True, timeout=90)
+            except subprocess.TimeoutExpired:
+                out[key] = {"error": "no result within 90 s"}
+                continue
             line = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
             if not line:
-                out[key] = {"error": p.stderr[-300:]}
+                out[key] = {"error": p.stderr[-1500:]}
                 continue
             d = json.loads(line[-1])
             out[key] = {"msms_per_s": d["rate_per_s"], "latency_ms": d["lat_ms"], "msms_per_chain": d["proofs_per_chain"], "mismatches_vs_oracle": d["mismatches"],
@@ -597,6 +605,8 @@ def bench_cfg5_shape(a, local_dev, steps=96, nstreams=16):
         c_ = bp.Context(local_dev)
         if a.bucket_min:
             c_.set_option("bucket_min_terms", a.bucket_min)
+        for kv in filter(None, a.opt.split(",")):
+            c_.set_option(kv.split("=")[0], int(kv.split("=")[1]))
         c_.gens_create(n, m)
         ctxs.append(c_)
     # inputs as SURVEY 8d specifies: uniform scalars; per-MSM points = RistrettoPoint::from_uniform_bytes outputs (the party-1 generator

@@ -89,6 +89,9 @@ struct bpgpu_ctx {
     uint64_t script_tick = 0;
     int transcript_coop = 1;                                        // chains of up to 256 proofs replay their transcripts 32 lanes per proof (keccak.h): one call of 1 / 8 / 64 / 256 proofs 0.62 -> 0.53 / 0.56 / 0.57 / 0.58 ms; 0: lane = proof everywhere
     int split_stage1 = 0;                                           // experiment: point decoding as its own launch on the second stream, compiled for 1 / 2 / 3 wavefronts per SIMD
+    int msm_fork = 1;                                               // bpgpu_msm_batch_shared: the generator-table half on the second stream beside the per-MSM points (0: one stream -- with
+                                                                    // many contexts in flight two streams each outnumber the hardware queues: config 5 on 16 / 24 / 32 contexts +1.6 / +1.7 /
+                                                                    // +3.2 % MSMs/s, but one MSM alone 0.77 -> 0.98 ms: stays on; profiles/r05/msm_queue_ab.txt)
     int fork_early = 0;                                             // wide chains with the Horner chains aside: the window sums go to the second stream too (rp_verify_dev_locked)
     int split_stage3 = -1;                                          // window sums and generator exponents as two launches: 1 yes, 0 no, -1 auto (chains of >= 2048 proofs)
     bool no_script = false;                                         // option "transcript_script" = 0: byte-wise replay everywhere (A/B)
@@ -483,6 +486,10 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
     if (!strcmp(key, "split_stage1")) {
         if (value < 0 || value > 3) return fail(c, BPGPU_ERR_INVALID_ARG, "split_stage1 must be 0..3");
         c->split_stage1 = (int)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "msm_fork")) {
+        c->msm_fork = value != 0;
         return BPGPU_OK;
     }
     if (!strcmp(key, "fork_early")) {
@@ -1332,7 +1339,7 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
     ge_ext *d_partial = (ge_ext *)(c->arena + off_partial);
     HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
     // the generator-table half (recode, walk, partial reduction) on the context's second stream, beside the per-MSM points
-    hipStream_t s2 = n_unique ? c->stream2 : s;
+    hipStream_t s2 = (n_unique && c->msm_fork) ? c->stream2 : s;
     if (s2 != s) {
         HIPCHK(c, hipEventRecord(c->fork_ev, s));
         HIPCHK(c, hipStreamWaitEvent(s2, c->fork_ev, 0));
@@ -1372,9 +1379,7 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
     }
     if (s2 != s) HIPCHK(c, hipStreamWaitEvent(s, c->join_ev, 0));
     LAUNCH(c, s, "shared_finish", k_shared_finish, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, nred, d.hq, n_unique ? 1 : 0,
-           d_red, d_status, (uint32_t *)d_out, (uint8_t *)d_verdict);
-    if (d_status_bytes)
-        LAUNCH(c, s, "status_bytes", k_status_bytes, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d_status, (uint8_t *)d_status_bytes);
+           d_red, d_status, (uint32_t *)d_out, (uint8_t *)d_verdict, (uint8_t *)d_status_bytes);   // (status bytes ride along: one launch fewer)
     HIPCHK(c, hipGetLastError());
     return BPGPU_OK;
 }

@@ -124,9 +124,12 @@ __global__ void __launch_bounds__(BP_BLOCK) k_fb_reduce(uint32_t nthreads, uint3
 
 __global__ void __launch_bounds__(64) k_shared_finish(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, int have_unique,
                                                        const ge_ext *partial, const uint32_t *status, uint32_t *out_words,
-                                                       uint8_t *verdict) {
+                                                       uint8_t *verdict, uint8_t *status_bytes) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
-    if (p < nproofs) shared_finish_thread(p, nproofs, nsplit, nullptr, have_unique != 0, hq, partial, status, out_words, verdict);
+    if (p < nproofs) {
+        shared_finish_thread(p, nproofs, nsplit, nullptr, have_unique != 0, hq, partial, status, out_words, verdict);
+        if (status_bytes) status_bytes[p] = (uint8_t)status[p];   // (what k_status_bytes did as a launch of its own)
+    }
 }
 
 // One launch for the whole tail: 8 lanes per proof add up the per-split partial sums (and the Horner result),

@@ -419,6 +419,12 @@ struct bpgpu_pool {
     std::atomic<uint32_t> combine_cohort_inflight{2};
     std::atomic<uint64_t> combine_regroup_ns{60000};     // after a completion with nothing else in flight: this long for its callers to come back before `quiet` may seal
     std::atomic<uint64_t> combine_msm_bytes{32u << 20};   // staging block of a multiscalar-multiplication class (bpgpu_pool_msm_*): items per chain = this / bytes per MSM
+    // multiscalar multiplications bring 264 kB each (config 5's shape) and every byte is read exactly ONCE, by the first kernels of the chain
+    // (scalar recoding, point decoding).  1 = those kernels read the pinned host block in place instead of waiting for a staging copy of the
+    // whole buffer (7 MB per 28-MSM chain, ~0.3 ms).  Measured WORSE and therefore off: 64 blocking threads 34.2 / 33.7 k MSMs/s with the copy,
+    // 26.3 / 24.8 k/s reading in place, one thread 0.81 against 0.84 ms (profiles/r05/msm_queue_ab.txt) -- 133 000 lanes each fetching 64 bytes
+    // across PCIe pay its latency inside the decode kernel, the copy engine streams the same bytes at line rate beside other chains' kernels
+    std::atomic<uint32_t> combine_mapped_in{0};
     std::atomic<uint32_t> combine_mapped_out{1024};   // chains of up to this many proofs write their results straight into the pinned host block (no copy command behind the chain)
     std::atomic<uint32_t> combine_trace{0};           // ring sizes of the timeline records (0 = off)
     std::atomic<int> host_path{1};                    // bpgpu_pool_rangeproof_verify: 1 = through the combining queue, 0 = the slicing workers of round 3
@@ -657,6 +663,10 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
         (key[8] == 'm' ? p->combine_max_age_ns : p->combine_hold_ns) = (uint64_t)value * 1000;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "combine_mapped_in")) {
+        p->combine_mapped_in = value != 0;
+        return BPGPU_OK;
+    }
     if (!strcmp(key, "combine_wide_proofs") || !strcmp(key, "combine_mapped_out")) {
         if (value < 0 || value > (1 << 22)) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
         (key[8] == 'w' ? p->combine_wide_proofs : p->combine_mapped_out) = (uint32_t)value;
@@ -749,6 +759,7 @@ int bpgpu_pool_get_option(bpgpu_pool *p, const char *key, int64_t *value) {
     else if (!strcmp(key, "combine_regroup_us")) *value = (int64_t)(p->combine_regroup_ns / 1000);
     else if (!strcmp(key, "combine_msm_bytes")) *value = (int64_t)p->combine_msm_bytes;
     else if (!strcmp(key, "combine_mapped_out")) *value = (int64_t)p->combine_mapped_out;
+    else if (!strcmp(key, "combine_mapped_in")) *value = (int64_t)p->combine_mapped_in;
     else if (!strcmp(key, "combine_trace")) *value = (int64_t)p->combine_trace;
     else if (!strcmp(key, "stat_svc_issue_us") || !strcmp(key, "stat_svc_complete_us") || !strcmp(key, "stat_svc_polls") || !strcmp(key, "stat_svc_deliver_us")) {
         uint64_t v = 0;
@@ -1095,8 +1106,11 @@ static void comb_issue(bpgpu_pool *p, pool_dev *d, comb_buf *b, uint32_t infligh
         if (e != hipSuccess || !bytes) return;
         e = in ? hipMemcpyAsync(b->d + off, b->h + off, bytes, hipMemcpyHostToDevice, s) : hipMemcpyAsync(b->h + off, b->d + off, bytes, hipMemcpyDeviceToHost, s);
     };
-    // inputs: one copy up to the fill of the last region when the unused tails that ride along are small, else one copy per region
-    {
+    // inputs: one copy up to the fill of the last region when the unused tails that ride along are small, else one copy per region --
+    // or none at all: the MSM kinds' first kernels read the pinned block in place (combine_mapped_in)
+    const bool mapped_in = b->hd && (k.kind == CQ_MSM_SHARED || k.kind == CQ_MSM) && p->combine_mapped_in.load(std::memory_order_relaxed) != 0;
+    char *ib = mapped_in ? b->hd : b->d;
+    if (!mapped_in) {
         const uint32_t last = g.n_in - 1;
         const size_t span = b->in_off[last] + (size_t)K * g.in_sz[last];
         size_t useful = 0;
@@ -1126,11 +1140,11 @@ static void comb_issue(bpgpu_pool *p, pool_dev *d, comb_buf *b, uint32_t infligh
                                                 k.pos_begin, k.flags, b->d + b->in_off[RP_IN_RNG], ob + b->out_off[RP_OUT_VERDICT],
                                                 want_opt ? ob + b->out_off[RP_OUT_MSM] : nullptr, hint, busy);
         } else if (k.kind == CQ_MSM_SHARED) {
-            rc = bpgpu_msm_batch_shared_dev(b->ctx, k.a, k.b, K, k.c, b->d + b->in_off[2], k.c ? b->d + b->in_off[0] : nullptr, k.c ? b->d + b->in_off[1] : nullptr,
+            rc = bpgpu_msm_batch_shared_dev(b->ctx, k.a, k.b, K, k.c, ib + b->in_off[2], k.c ? ib + b->in_off[0] : nullptr, k.c ? ib + b->in_off[1] : nullptr,
                                             ob + b->out_off[0], ob + b->out_off[1], nullptr);
         } else if (k.kind == CQ_MSM) {
             const std::vector<uint32_t> nt(K, k.a);
-            rc = bpgpu_msm_batch_dev(b->ctx, K, nt.data(), b->d + b->in_off[0], b->d + b->in_off[1], ob + b->out_off[0], ob + b->out_off[1], nullptr);
+            rc = bpgpu_msm_batch_dev(b->ctx, K, nt.data(), ib + b->in_off[0], ib + b->in_off[1], ob + b->out_off[0], ob + b->out_off[1], nullptr);
         } else {
             rc = bpgpu_ipp_verify_batch_dev(b->ctx, k.a, K, b->d + b->in_off[2], k.b, nullptr, 0, k.shared, b->d + b->in_off[3], b->d + b->in_off[4], b->d + b->in_off[0],
                                             b->d + b->in_off[1], b->d + b->in_off[5], b->d + b->in_off[6], 0, ob + b->out_off[0], want_opt ? ob + b->out_off[1] : nullptr,
