@@ -592,23 +592,20 @@ def drop_in_call_shape(long_run, local_dev=0):
 
 
 def bench_cfg5_shape(a, local_dev, steps=96, nstreams=16):
-    """BASELINE config 5's MSM shape: N = 6179 = 4098 generator terms (tables) + 2081 per-MSM points, batches of 64 MSMs,
-    through bpgpu_msm_batch_shared_dev; inputs resident in HBM.  Informational (`extra`)."""
+    """BASELINE config 5's MSM shape: N = 6179 = 4098 generator terms (tables) + 2081 per-MSM points, batches of 64 MSMs, inputs resident in
+    HBM, through the library's pool: bpgpu_pool_msm_batch_shared_submit_dev issues every batch as one launch chain on the next of the pool's
+    `nstreams` lanes (the (context, stream) pairs this function used to build by hand).  Informational (`extra`)."""
     import torch
     import bulletproofs_amd as bp
     dev = torch.device("cuda", local_dev)
-    L = bp.lib()
     n, m, nb, nu = 2048, 1, 64, 2081
     ng = 2 * n * m + 2
-    ctxs = []
-    for _ in range(nstreams):
-        c_ = bp.Context(local_dev)
-        if a.bucket_min:
-            c_.set_option("bucket_min_terms", a.bucket_min)
-        for kv in filter(None, a.opt.split(",")):
-            c_.set_option(kv.split("=")[0], int(kv.split("=")[1]))
-        c_.gens_create(n, m)
-        ctxs.append(c_)
+    pool = bp.Pool((local_dev,), nstreams)
+    if a.bucket_min:
+        pool.set_option("bucket_min_terms", a.bucket_min)
+    for kv in filter(None, a.opt.split(",")):
+        pool.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    pool.gens_create(n, m)
     # inputs as SURVEY 8d specifies: uniform scalars; per-MSM points = RistrettoPoint::from_uniform_bytes outputs (the party-1 generator
     # chains of a (2048, 2) set, derived on the device by a small-table helper context) -- bulletproofs_amd/workload.py cfg5_inputs
     from bulletproofs_amd import workload as wl
@@ -619,51 +616,43 @@ def bench_cfg5_shape(a, local_dev, steps=96, nstreams=16):
     gsc, usc, upts = wl.cfg5_inputs(G2, H2, nb)
     to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
     d_gs, d_us, d_up = to_dev(gsc), to_dev(usc), to_dev(upts)
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
     d_out = torch.zeros((nstreams, nb, 32), dtype=torch.uint8, device=dev)
     d_st = torch.full((nstreams, nb), 255, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
 
-    def step(i):
+    def step(i, count=nb, out=None, ticket=False):
         k = i % nstreams
-        rc = L.bpgpu_msm_batch_shared_dev(ctxs[k].h, n, m, nb, nu, d_gs.data_ptr(), d_us.data_ptr(), d_up.data_ptr(), d_out[k].data_ptr(),
-                                          d_st[k].data_ptr(), streams[k].cuda_stream)
-        if rc != 0:
-            raise RuntimeError("bpgpu_msm_batch_shared_dev failed: %s" % L.bpgpu_last_error(ctxs[k].h).decode())
+        return pool.msm_shared_submit_dev(0, n, m, count, nu, d_gs.data_ptr(), d_us.data_ptr(), d_up.data_ptr(), (out if out is not None else d_out[k]).data_ptr(),
+                                          d_st[k].data_ptr(), want_ticket=ticket)
     for i in range(nstreams):
         step(i)
-    torch.cuda.synchronize()
-    for c_ in ctxs:
-        c_.profile_reset()
-        c_.profile_enable(True)
+    pool.wait()
+    pool.profile_reset()
+    pool.profile_enable(True)
     t0 = time.perf_counter()
     for i in range(steps):
         step(i)
-    torch.cuda.synchronize()
+    pool.wait()
     dt = time.perf_counter() - t0
-    # one stream alone: the latency of a single batch and of a single MSM
+    # one lane alone: the latency of a single batch and of a single MSM
     t1 = time.perf_counter()
     step(0)
-    torch.cuda.synchronize()
+    pool.wait()
     one_batch = time.perf_counter() - t1
     d_out1 = torch.zeros((1, 32), dtype=torch.uint8, device=dev)
-    L.bpgpu_msm_batch_shared_dev(ctxs[0].h, n, m, 1, nu, d_gs.data_ptr(), d_us.data_ptr(), d_up.data_ptr(), d_out1.data_ptr(), d_st[0].data_ptr(),
-                                 streams[0].cuda_stream)
-    torch.cuda.synchronize()
-    for c_ in ctxs:
-        c_.profile_enable(False)          # (no dispatch events on the latency measurement)
+    step(0, 1, d_out1)
+    pool.wait()
+    pool.profile_enable(False)            # (no dispatch events on the latency measurement)
+    kern = pool.profile_report()
     t2 = time.perf_counter()
-    for _ in range(10):
-        L.bpgpu_msm_batch_shared_dev(ctxs[0].h, n, m, 1, nu, d_gs.data_ptr(), d_us.data_ptr(), d_up.data_ptr(), d_out1.data_ptr(), d_st[0].data_ptr(),
-                                     streams[0].cuda_stream)
-    torch.cuda.synchronize()
+    for q in range(10):
+        step(q, 1, d_out1)                # (round-robin over ten lanes: what one caller with MSMs in a row sees)
+    pool.wait()
     single_b2b = (time.perf_counter() - t2) / 10
     lat = []
-    for _ in range(10):                   # one call at a time: enqueue + launch chain + sync
-        torch.cuda.synchronize()
+    for _ in range(10):                   # one call at a time: enqueue + launch chain + wait
         t3 = time.perf_counter()
-        L.bpgpu_msm_batch_shared_dev(ctxs[0].h, n, m, 1, nu, d_gs.data_ptr(), d_us.data_ptr(), d_up.data_ptr(), d_out1.data_ptr(), d_st[0].data_ptr(),
-                                     streams[0].cuda_stream)
-        torch.cuda.synchronize()
+        step(0, 1, d_out1, True).wait()   # (the batch's own ticket: no walk over the other lanes)
         lat.append(time.perf_counter() - t3)
     single = sorted(lat)[5]
     ok = bool((d_st == 0).all().item()) and bool((d_out[0] == d_out[nstreams - 1]).all().item()) and bool((d_out[0] != 0).any().item())
@@ -673,13 +662,7 @@ def bench_cfg5_shape(a, local_dev, steps=96, nstreams=16):
     got = bytes(d_out[0].cpu().numpy().reshape(-1))
     ok = ok and got[:32].hex() == exp5["msm0"] and got[32 * (nb - 1):32 * nb].hex() == exp5["msm%d" % (nb - 1)] and bytes(d_out1[0].cpu().numpy()).hex() == exp5["msm0"]
     if not ok:
-        raise SystemExit("cfg5-shape MSM: bad status, streams disagree, or results differ from the committed oracle encodings -- result invalid")
-    kern = {}
-    for c_ in ctxs:
-        c_.profile_enable(False)
-        for name, (cnt, ms) in c_.profile_report().items():
-            o = kern.get(name, (0, 0.0))
-            kern[name] = (o[0] + cnt, o[1] + ms)
+        raise SystemExit("cfg5-shape MSM: bad status, lanes disagree, or results differ from the committed oracle encodings -- result invalid")
     N = ng + nu
     alg = (32 * N + 32 * nu + 32) * nb
     by_time = max(kern.items(), key=lambda kv: kv[1][1])[0]
@@ -707,8 +690,8 @@ def bench_cfg5_shape(a, local_dev, steps=96, nstreams=16):
     out["roofline"]["dominant_by"] = "most HBM bytes per launch (committed PMC pass); by total kernel time: %s" % by_time
     if traffic:
         out["roofline"]["traffic_GBps_while_running"] = round(traffic / avg_s / 1e9, 1)
-    for c_ in ctxs:
-        c_.close()
+    out["through"] = "bpgpu_pool_msm_batch_shared_submit_dev on a pool of %d lanes" % nstreams
+    pool.close()
     return out
 
 

@@ -31,6 +31,7 @@ EXPORTS = [
     "bpgpu_pool_rangeproof_submit_dev_ex", "bpgpu_pool_ticket_stream_wait", "bpgpu_pool_rangeproof_submit_rlc_dev",
     "bpgpu_gens_add_shape", "bpgpu_pool_gens_add_shape", "bpgpu_pool_gather_dev",
     "bpgpu_pool_msm_batch_shared", "bpgpu_pool_msm_batch_shared_submit", "bpgpu_pool_msm_batch", "bpgpu_pool_ipp_verify", "bpgpu_pool_trace_dump",
+    "bpgpu_pool_msm_batch_shared_submit_dev",
 ]
 
 TRANSCRIPT_BYTES = 208
@@ -123,6 +124,7 @@ def lib():
     L.bpgpu_pool_msm_batch_shared_submit.argtypes = [vp, sz, sz, sz, sz, u8p, u8p, u8p, u8p, u8p, C.POINTER(vp)]
     L.bpgpu_pool_msm_batch.argtypes = [vp, sz, C.POINTER(C.c_uint32), u8p, u8p, u8p, u8p]
     L.bpgpu_pool_ipp_verify.argtypes = [vp, sz, sz, u8p, sz, u8p, sz, u8p, u8p, u8p, u8p, u8p, u8p, u8p, u8p]
+    L.bpgpu_pool_msm_batch_shared_submit_dev.argtypes = [vp, i, sz, sz, sz, sz, vp, vp, vp, vp, vp, vp, i, C.POINTER(vp)]
     L.bpgpu_pool_trace_dump.argtypes = [vp, C.c_char_p]
     L.bpgpu_pool_ticket_done.argtypes = [vp, vp]
     L.bpgpu_pool_ticket_wait.argtypes = [vp, vp]
@@ -618,6 +620,15 @@ class Pool:
         out, st = C.create_string_buffer(32 * max(nb, 1)), C.create_string_buffer(max(nb, 1))
         self._chk(self._L.bpgpu_pool_msm_batch(self.h, nb, nt, scalars, points, out, st))
         return out.raw[:32 * nb], st.raw[:nb]
+
+    def msm_shared_submit_dev(self, dev_index, n, m, nbatch, n_unique, d_gen_scalars, d_uniq_scalars, d_uniq_points, d_out, d_status, producer_stream=None,
+                              want_ticket=False):
+        """device-resident MSM batch on the next lane of pool device dev_index (bpgpu_pool_msm_batch_shared_submit_dev; raw device pointers as ints)"""
+        t = C.c_void_p()
+        self._chk(self._L.bpgpu_pool_msm_batch_shared_submit_dev(self.h, dev_index, n, m, nbatch, n_unique, d_gen_scalars, d_uniq_scalars or None, d_uniq_points or None,
+                                                                 d_out, d_status, producer_stream or None, 0 if producer_stream is None else 1,
+                                                                 C.byref(t) if want_ticket else None))
+        return DevTicket(self, t) if want_ticket else None
 
     def ipp_verify(self, n, proofs, proof_len, label, Gf, Hf, P, Q, G, H, want_msm=False):
         """InnerProductProof::verify for len(proofs) / proof_len proofs through the queue (bpgpu_pool_ipp_verify)."""

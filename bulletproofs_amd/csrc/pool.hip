@@ -2462,6 +2462,54 @@ int bpgpu_pool_rangeproof_submit_dev(bpgpu_pool *p, int dev_index, size_t n, siz
                                                nullptr, 0, nullptr);
 }
 
+// The MSM call site for callers whose inputs are already in HBM (a service that keeps proofs on the device; bench.py's config-5 figure): the
+// batch goes out at once as ONE launch chain on the next lane of the device -- the pool's lanes are what a caller would otherwise build by
+// hand as (context, stream) pairs --, ordered behind the producer's stream if one is given; the ticket completes with that chain
+// (bpgpu_pool_ticket_wait / _done / _stream_wait), bpgpu_pool_wait waits for everything.  Nothing is combined: device-resident batches
+// are as wide as their owner made them.
+int bpgpu_pool_msm_batch_shared_submit_dev(bpgpu_pool *p, int dev_index, size_t n, size_t m, size_t nbatch, size_t n_unique, const void *d_gen_scalars,
+                                           const void *d_uniq_scalars, const void *d_uniq_points, void *d_out, void *d_status, void *producer_stream, int have_producer,
+                                           bpgpu_ticket **ticket) {
+    if (ticket) *ticket = nullptr;
+    if (!p || dev_index < 0 || dev_index >= (int)p->devs.size()) return BPGPU_ERR_INVALID_ARG;
+    if (nbatch && (!d_gen_scalars || !d_out || !d_status || (n_unique && (!d_uniq_scalars || !d_uniq_points)))) return pfail(p, BPGPU_ERR_INVALID_ARG, "null argument");
+    std::lock_guard<std::mutex> lk(p->mu);
+    pool_dev *d = p->devs[dev_index];
+    if (d->lanes.empty()) return pfail(p, BPGPU_ERR_INVALID_ARG, "the pool has no submit lanes");
+    if (hipSetDevice(d->device) != hipSuccess) return pfail(p, BPGPU_ERR_HIP, "hipSetDevice failed");
+    bpgpu_ctx *c = d->lanes[d->next_lane++ % d->lanes.size()];
+    if (d->used_lanes < d->lanes.size() && d->next_lane > d->used_lanes) d->used_lanes = d->next_lane < d->lanes.size() ? d->next_lane : d->lanes.size();
+    hipStream_t s = (hipStream_t)bpgpu_internal_stream(c);
+    if (have_producer && nbatch) {   // the chain waits for what the producer has queued so far
+        ev_holder ready;
+        if (hipEventCreateWithFlags(&ready.ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ready.ev, (hipStream_t)producer_stream) != hipSuccess ||
+            hipStreamWaitEvent(s, ready.ev, 0) != hipSuccess)
+            return pfail(p, BPGPU_ERR_HIP, "ordering the chain behind the producer's stream failed");
+    }
+    int rc = BPGPU_OK;
+    if (nbatch) {
+        rc = bpgpu_msm_batch_shared_dev(c, n, m, nbatch, n_unique, d_gen_scalars, d_uniq_scalars, d_uniq_points, d_out, d_status, nullptr);
+        if (rc) return pfail(p, rc, "%s", bpgpu_last_error(c));
+    }
+    if (ticket) {
+        dev_ticket *t = new dev_ticket();
+        t->d = d;
+        t->unissued = 0;
+        if (nbatch) {
+            std::shared_ptr<ev_holder> done = record_done(c, true);
+            if (!done) {
+                delete t;
+                return pfail(p, BPGPU_ERR_HIP, "recording the chain's completion failed");
+            }
+            t->done.push_back(done);
+        }
+        *ticket = (bpgpu_ticket *)t;
+    }
+    p->stat_chains++;
+    p->stat_chain_proofs += nbatch;
+    return BPGPU_OK;
+}
+
 // The "final identity-check gather" for callers that keep verdicts on the devices: every shard's verdict bytes to ONE device buffer,
 // over the peer links (xGMI on an MI355X node), ordered behind the shard's own work.  Proofs are independent units, nothing else ever
 // crosses devices.  `part[d]` (device memory on pool device d, `bytes[d]` bytes, may be 0) lands at d_dst + sum of the

@@ -542,6 +542,12 @@ int bpgpu_pool_ticket_wait(bpgpu_pool *pool, bpgpu_ticket *ticket);
  *                                 stretch by stretch of equal n_terms; an MSM of 0 terms is the identity (encoding 0, status 0)
  *   bpgpu_pool_ipp_verify       : arguments as bpgpu_ipp_verify_batch (InnerProductProof::verify, ipp.rs:260-326); proofs of one
  *                                 (n, proof_len, label) share chains
+ *   bpgpu_pool_msm_batch_shared_submit_dev : the same call for inputs that are already in HBM (device pointers, arguments as
+ *                                 bpgpu_msm_batch_shared_dev): the batch leaves at once as ONE chain on the next lane of pool device
+ *                                 `dev_index`, behind `producer_stream` if have_producer; ticket (optional) as for
+ *                                 bpgpu_pool_rangeproof_submit_dev_ex; nothing is combined -- device-resident batches are as wide as
+ *                                 their owner made them.  The pool's lanes are the (context, stream) pairs a caller would otherwise
+ *                                 manage by hand.
  * On a non-zero return no status / verdict byte of the call reads 0: items whose chain failed carry BPGPU_VERDICT_UNDECIDED.
  * Option "combine_msm_bytes" (default 32 MiB): staging block per chain of a multiscalar-multiplication class -- items per chain =
  * that / input bytes per MSM (cfg5's shape, 263 KB per MSM: 127 per chain). */
@@ -552,6 +558,9 @@ int bpgpu_pool_msm_batch_shared_submit(bpgpu_pool *pool, size_t n, size_t m, siz
                                        bpgpu_ticket **ticket);
 int bpgpu_pool_msm_batch(bpgpu_pool *pool, size_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, const uint8_t *points,
                          uint8_t *out, uint8_t *status);
+int bpgpu_pool_msm_batch_shared_submit_dev(bpgpu_pool *pool, int dev_index, size_t n, size_t m, size_t nbatch, size_t n_unique,
+                                           const void *d_gen_scalars, const void *d_uniq_scalars, const void *d_uniq_points, void *d_out,
+                                           void *d_status, void *producer_stream, int have_producer, bpgpu_ticket **ticket);
 int bpgpu_pool_ipp_verify(bpgpu_pool *pool, size_t n, size_t nbatch, const uint8_t *proofs, size_t proof_len, const uint8_t *label,
                           size_t label_len, const uint8_t *G_factors, const uint8_t *H_factors, const uint8_t *P, const uint8_t *Q,
                           const uint8_t *G, const uint8_t *H, uint8_t *verdict, uint8_t *msm_out);

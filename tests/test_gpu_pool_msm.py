@@ -189,3 +189,46 @@ def test_inner_product_proofs_one_per_call_from_many_threads(oracle, n):
     v = pool.ipp_verify(n, i0["proof"], pl, b"other label", i0["Gf"], i0["Hf"], i0["P"], i0["Q"], i0["G"], i0["H"])
     assert list(v) == [1]
     pool.close()
+
+
+def test_device_resident_msm_batches_on_the_pool_lanes_with_tickets(oracle, pool16):
+    """bpgpu_pool_msm_batch_shared_submit_dev: MSM batches whose inputs already sit in HBM go out one chain per batch on the pool's lanes
+    (round-robin), ordered behind the producer's stream; a ticket per batch; results == oracle.  What bench.py's config-5 figure runs."""
+    import torch
+    dev = torch.device("cuda", 0)
+    g = oracle.Gens(16, 2)
+    G, H, B, Bb = g.export()
+    to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    prod = torch.cuda.Stream(device=dev)
+    batches = []
+    for k in range(9):
+        n, m, nu = ((16, 2, 9), (8, 1, 33), (16, 1, 0))[k % 3]
+        nb = 1 + 5 * k
+        cs = [_shared_case(oracle, G, H, B, Bb, n, m, nu, b"dv%d-%d" % (k, b)) for b in range(nb)]
+        h = dict(n=n, m=m, nu=nu, nb=nb, exp=[c[3] for c in cs], gs=b"".join(c[0] for c in cs), us=b"".join(c[1] for c in cs), up=b"".join(c[2] for c in cs))
+        with torch.cuda.stream(prod):   # the inputs are PRODUCED on another stream: the chain must wait for exactly that
+            h["d_gs"] = torch.frombuffer(bytearray(h["gs"]), dtype=torch.uint8).pin_memory().to(dev, non_blocking=True)
+            h["d_us"] = torch.frombuffer(bytearray(h["us"]), dtype=torch.uint8).pin_memory().to(dev, non_blocking=True) if nu else None
+            h["d_up"] = torch.frombuffer(bytearray(h["up"]), dtype=torch.uint8).pin_memory().to(dev, non_blocking=True) if nu else None
+        h["d_out"] = torch.full((nb, 32), 255, dtype=torch.uint8, device=dev)
+        h["d_st"] = torch.full((nb,), 255, dtype=torch.uint8, device=dev)
+        batches.append(h)
+    torch.cuda.current_stream().synchronize()      # (the output buffers exist; the producer stream has NOT been waited for)
+    tickets = []
+    for h in batches:
+        tickets.append(pool16.msm_shared_submit_dev(0, h["n"], h["m"], h["nb"], h["nu"], h["d_gs"].data_ptr(), h["d_us"].data_ptr() if h["nu"] else None,
+                                                    h["d_up"].data_ptr() if h["nu"] else None, h["d_out"].data_ptr(), h["d_st"].data_ptr(),
+                                                    producer_stream=prod.cuda_stream, want_ticket=True))
+    for t in tickets:
+        t.wait()
+    for k, h in enumerate(batches):
+        out, st = bytes(h["d_out"].cpu().numpy().reshape(-1)), bytes(h["d_st"].cpu().numpy())
+        for b in range(h["nb"]):
+            assert st[b] == h["exp"][b][0] == 0 and out[32 * b:32 * b + 32] == h["exp"][b][1], (k, b)
+    # without tickets: bpgpu_pool_wait covers the lanes
+    h = batches[4]
+    h["d_out"].fill_(255)
+    pool16.msm_shared_submit_dev(0, h["n"], h["m"], h["nb"], h["nu"], h["d_gs"].data_ptr(), h["d_us"].data_ptr(), h["d_up"].data_ptr(), h["d_out"].data_ptr(),
+                                 h["d_st"].data_ptr())
+    pool16.wait()
+    assert bytes(h["d_out"].cpu().numpy().reshape(-1)) == b"".join(e[1] for e in h["exp"])
