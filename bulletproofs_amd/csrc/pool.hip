@@ -292,6 +292,7 @@ struct comb_buf {
     // ---- service thread only (and, after `phase`, whoever delivers)
     uint32_t K = 0;                         // final width
     uint32_t seen_reserved = 0, seen_epoch = 0;
+    uint32_t sealed_epoch = 0;              // the incarnation the service thread sealed last: a word that still carries it is not the open buffer's
     uint64_t t_change = 0;                  // when `reserved` was last seen to move (quiet detection)
     int rc = 0;
     std::string err;
@@ -1343,6 +1344,7 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
                 active = true;
                 uint64_t s = b->state.load(std::memory_order_acquire);
                 const uint32_t e = cbs_epoch(s), r = cbs_reserved(s);
+                if (e == b->sealed_epoch) continue;   // (belt and braces beside the store order in comb_reserve_slow: never act on the previous incarnation's word)
                 if (b->seen_epoch != e) b->seen_epoch = e, b->seen_reserved = r, b->t_change = b->t_open;
                 else if (r != b->seen_reserved) b->seen_reserved = r, b->t_change = now;
                 bool seal = cbs_sealed(s);   // a caller took the last slot
@@ -1364,6 +1366,7 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
                     seal = true;
                 }
                 if (seal) {
+                    b->sealed_epoch = e;
                     b->K = cbs_reserved(s);
                     b->ev = chain_ev();
                     b->ev.buf = b->index, b->ev.epoch = e, b->ev.K = b->K, b->ev.kind = b->key.kind, b->ev.cap = b->cap.load(std::memory_order_relaxed);
@@ -1606,8 +1609,17 @@ static int comb_reserve_slow(bpgpu_pool *p, pool_dev *d, comb_req *r, comb_key &
             b->want_opt.store(0, std::memory_order_relaxed);
             b->poison.store(0, std::memory_order_relaxed);
             const uint32_t e = cbs_epoch(b->state.load(std::memory_order_relaxed)) + 1;
-            b->st.store(CB_OPEN, std::memory_order_release);
+            // The reservation word FIRST, then the buffer's state.  The other order (round 5's first build) let the service thread find
+            // `st == CB_OPEN` beside the PREVIOUS incarnation's word -- sealed, with that chain's width in it: it "sealed" the new incarnation
+            // at the old width, callers went on reserving in a word that was never sealed, `written` passed K and the buffer waited for
+            // `written == K` forever (caught by tools/combine_rate.cpp's watchdog: "SEALED epoch 496 sealed 0 reserved 256 K 81 written 256";
+            // three of twenty-three runs of the first sweep).  Callers look at the word only; the service thread looks at `st` first and its
+            // acquire load of CB_OPEN now brings the new word with it.
             b->state.store(cbs_pack(e, false, t), std::memory_order_release);   // publishes the incarnation (its first reservation is ours)
+#ifdef BPGPU_POOL_HOST_TEST
+            if (const char *dly = getenv("BP_TEST_OPEN_DELAY_US")) usleep((useconds_t)atoi(dly));   // (tests/cpu_pool: widens the window between the two stores)
+#endif
+            b->st.store(CB_OPEN, std::memory_order_release);
             out.b = b, out.epoch = e, out.first = 0, out.take = t, out.filled = (t == cap);
             const bool others_wait = d->free_waiters.load(std::memory_order_relaxed) != 0;
             lk.unlock();

@@ -83,3 +83,15 @@ def test_wide_regime_policy_is_plain_host_logic(built):
             assert q["t_submit"] <= q["t_reserved"] <= q["t_written"] <= q["t_delivered"]
             reqs += 1
     assert chains > 10 and reqs > 10
+
+
+@pytest.mark.parametrize("mode", [["tickets", "8", "64", "0.6"], ["mixed", "10", "1.0"], ["threads", "48", "3", "0.6"]])
+def test_a_buffer_opened_slowly_is_never_sealed_on_its_predecessors_word(built, mode):
+    """Round 5's first build published a reopened buffer's state (`st = CB_OPEN`) BEFORE its new reservation word; in between, the service
+    thread could read the previous incarnation's word -- sealed, with that chain's width in it -- and seal the new incarnation at the old
+    width: callers went on reserving, `written` passed K, the buffer waited for `written == K` forever (3 of 23 runs of the first GPU
+    sweep; caught by combine_rate's watchdog).  BP_TEST_OPEN_DELAY_US (host-test builds only) holds the opener between the two stores for
+    200 us: with the old order these runs hang within a second, with the word published first they complete."""
+    p, d = run(os.path.join(built, "pool_host_test"), mode, env={"BP_TEST_OPEN_DELAY_US": "200"}, timeout=120)
+    assert p.returncode == 0, p.stderr[-2000:]
+    assert d["mismatches"] == 0 and d.get("errors", 0) == 0 and d["items"] > 0
