@@ -3,7 +3,7 @@
 # shape of tools/combine_rate.cpp, chains planned by proofs vs by work on BASELINE configs 3 / 4 (20-step and 640-step forms) and on the
 # mixed-shape figure.  Writes gpurun_out/r05b/*.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r05b
 mkdir -p $OUT
 export GPU_MAX_HW_QUEUES=16

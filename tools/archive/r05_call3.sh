@@ -2,7 +2,7 @@
 # Round 5, third GPU call: parity tests of the round (fixed), the per-kind sealing policy, floors for chains planned by work, cfg5 on more streams,
 # a kernel trace of one blocking caller.  Writes gpurun_out/r05c/*.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r05c
 mkdir -p $OUT
 export GPU_MAX_HW_QUEUES=16

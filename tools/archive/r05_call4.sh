@@ -2,7 +2,7 @@
 # Round 5, fourth GPU call: the transcript-stop tests (fixed), cohort width for the MSM kinds, the default chain plan against the plan by proofs,
 # counters of launch 1 alone (issue / wait / active split) and of config 5's chain (with k_bk_heavy in it).  Writes gpurun_out/r05d/*.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 REPO=$PWD
 OUT=$REPO/gpurun_out/r05d
 mkdir -p $OUT

@@ -2,7 +2,7 @@
 # Round 5, fifth GPU call: pooled MSM chains reading their inputs in place (combine_mapped_in) against the staging copy; config 5 without the
 # second stream per context.  Writes gpurun_out/r05e/*.
 set -u
-cd "$(dirname "$0")/.."
+cd "$(dirname "$0")/../.."
 REPO=$PWD
 OUT=$REPO/gpurun_out/r05e
 mkdir -p $OUT
