@@ -150,6 +150,9 @@ struct bpgpu_ctx {
     // half until the finish, so the two halves run side by side (fork after the status memset, join before the finish)
     hipStream_t stream2 = nullptr;
     hipEvent_t fork_ev = nullptr, join_ev = nullptr, exp_ev = nullptr, fork2_ev = nullptr;
+    hipEvent_t early_ev = nullptr;                                  // recorded behind a chain's early phase when the pool asks for it (mark_early: 1 = behind launch 1, 2 = behind the
+    int mark_early = 0;                                             // generator exponents, i.e. right before the table walk): the NEXT chain of a burst starts its own early phase there
+    bool early_recorded = false;
     // result of a submitted (not yet collected) host-pointer call: where its outputs sit in the pinned buffer and where the
     // caller wants them (bpgpu_rangeproof_verify_batch_submit / bpgpu_ctx_collect)
     struct pending_result {
@@ -391,7 +394,8 @@ int bpgpu_ctx_create(int device, bpgpu_ctx **out) {
         hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess ||
         hipEventCreateWithFlags(&c->exp_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->fork2_ev, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->fork2_ev, hipEventDisableTiming) != hipSuccess ||
+        hipEventCreateWithFlags(&c->early_ev, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return BPGPU_ERR_HIP;
     }
@@ -424,6 +428,7 @@ void bpgpu_ctx_destroy(bpgpu_ctx *c) {
     if (c->join_ev) hipEventDestroy(c->join_ev);
     if (c->exp_ev) hipEventDestroy(c->exp_ev);
     if (c->fork2_ev) hipEventDestroy(c->fork2_ev);
+    if (c->early_ev) hipEventDestroy(c->early_ev);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->rp_status) hipFree(c->rp_status);
     if (c->d_table_ct) hipFree(c->d_table_ct);
@@ -1970,6 +1975,10 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
            rlc ? wts_ptr : (const uint8_t *)nullptr, ts_flags, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
            rlc_bucket ? bd.pts : (fb_entry *)nullptr, rlc_bucket ? bkp.c : 0u, segtab, d_script);
     if (split1) HIPCHK(c, hipStreamWaitEvent(s, c->join_ev, 0));
+    if (c->mark_early == 1) {
+        HIPCHK(c, hipEventRecord(c->early_ev, s));
+        c->early_recorded = true;
+    }
     if (shape_verdict) {
         HIPCHK(c, hipMemsetAsync(d_mv, 1, nbatch, s));
         LAUNCH(c, s, "rp_verdict", k_rp_verdict, (nb32 + 63) / 64, 64, nb32, d_status, d_mv, (uint8_t *)d_verdict);
@@ -2107,6 +2116,10 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         const uint32_t nc = nb32 * 64;
         LAUNCH(c, s, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, (uint32_t *)nullptr, d_colc);
     }
+    if (c->mark_early == 2) {   // everything in front of the table walk has been enqueued on s
+        HIPCHK(c, hipEventRecord(c->early_ev, s));
+        c->early_recorded = true;
+    }
     const uint32_t nblk_p = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
     if (horner_aside) {
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<4>, nblk_p * nsplit, FB_BLOCK, 0u, d.chunk_first, d.part, d_colc, d.hq, prm, nb32, nblk_p,
@@ -2206,6 +2219,18 @@ int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof
     c->busy_hint = -1;
     const int rc2 = ctx_leave(c, s);
     return rc ? rc : rc2;
+}
+// Staggered bursts (pool option "stagger_chains"): the pool asks a lane to mark the end of its chain's early phase and makes the NEXT chain's
+// stream wait for it, so that two chains of a burst do not run their latency-bound early phases against each other and then their walks
+// against each other (profiles/r05/cfg3_burst_timeline.txt): chain B's early phase runs beside chain A's walk instead.
+void bpgpu_internal_mark_early(bpgpu_ctx *c, int mode) {
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->mark_early = mode;
+    c->early_recorded = false;
+}
+void *bpgpu_internal_early_event(bpgpu_ctx *c) {   // null when the last chain recorded none (batch-combined chains, shape verdicts before the walk)
+    std::lock_guard<std::mutex> lk(c->mu);
+    return c->early_recorded ? (void *)c->early_ev : nullptr;
 }
 // buffers of the context sized for chains of up to `nbatch_max` proofs of this shape (see rp_verify_dev_locked, reserve_only)
 int bpgpu_internal_rp_reserve(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, size_t nbatch_max) {

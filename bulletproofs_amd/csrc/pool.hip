@@ -60,6 +60,8 @@ void bpgpu_internal_set_busy_hint(bpgpu_ctx *c, int busy);
 int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, const uint8_t *const *labels, size_t label_len, const rp_seg *segs,
                                   uint32_t nseg, bool any_msm, uint32_t splits_hint, int busy, bool rlc);
 void *bpgpu_internal_stream(bpgpu_ctx *c);
+void bpgpu_internal_mark_early(bpgpu_ctx *c, int mode);
+void *bpgpu_internal_early_event(bpgpu_ctx *c);
 int bpgpu_internal_rp_reserve(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, size_t nbatch_max);
 extern "C" int bpgpu_internal_release_tables(bpgpu_ctx *c);
 int bpgpu_internal_rp_verify_chain(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len, const void *d_commitments,
@@ -395,6 +397,9 @@ struct bpgpu_pool {
     // of 5120 / four of 2560 / eight of 1344: 319 / 311 / 248 k/s -- what a burst wants is TWO overlapping chains, whatever the proofs weigh;
     // launch 1's lane-serial transcript is per proof, so many narrow chains pay it many times over
     int plan_by_work = 2;
+    // Staggered bursts: chain i + 1 of a flush starts behind chain i's early phase (1: behind its launch 1; 2: behind its generator exponents, i.e.
+    // when its table walk begins) instead of beside it.  0 = all chains of a flush start at once.
+    int stagger_chains = 0;
     size_t plan_min_chain_proofs = 0;   // ... but no chain of a burst narrower than this many proofs of its shape (0 = no floor): launch 1's lane-serial roles are per PROOF
     size_t host_workers = 0;
     // combining queue
@@ -636,6 +641,11 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
         p->plan_by_work = (int)value;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "stagger_chains")) {
+        if (value < 0 || value > 2) return pfail(p, BPGPU_ERR_INVALID_ARG, "stagger_chains out of range");
+        p->stagger_chains = (int)value;
+        return BPGPU_OK;
+    }
     if (!strcmp(key, "plan_min_chain_proofs")) {
         if (value < 0 || value > (1 << 22)) return pfail(p, BPGPU_ERR_INVALID_ARG, "plan_min_chain_proofs out of range");
         p->plan_min_chain_proofs = (size_t)value;
@@ -739,6 +749,7 @@ int bpgpu_pool_get_option(bpgpu_pool *p, const char *key, int64_t *value) {
     else if (!strcmp(key, "auto_flush_proofs")) *value = (int64_t)p->auto_flush_proofs;
     else if (!strcmp(key, "plan_by_work")) *value = (int64_t)p->plan_by_work;
     else if (!strcmp(key, "plan_min_chain_proofs")) *value = (int64_t)p->plan_min_chain_proofs;
+    else if (!strcmp(key, "stagger_chains")) *value = (int64_t)p->stagger_chains;
     else if (!strcmp(key, "latency_proofs")) *value = (int64_t)p->latency_proofs;
     else if (!strcmp(key, "pair_limit_proofs")) *value = (int64_t)p->pair_limit_proofs;
     else if (!strcmp(key, "host_workers")) *value = (int64_t)p->host_workers;
@@ -2303,6 +2314,7 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
     std::vector<const uint8_t *> labs;   // the label of every segment (all of one length within a chain)
     std::vector<std::pair<size_t, size_t>> carried;   // (item, proofs of it) in the chain being packed
     size_t i = 0, off = 0;   // item i, `off` proofs of it already placed
+    void *prev_early = nullptr;   // (stagger_chains) the event behind the previous chain's early phase
     while (i < items.size()) {
         const dev_item &head = items[i];
         bpgpu_ctx *c = d->lanes[d->next_lane++ % d->lanes.size()];
@@ -2365,6 +2377,10 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
                 off = 0;
             }
         }
+        if (p->stagger_chains && !head.rlc) {
+            if (prev_early) (void)hipStreamWaitEvent((hipStream_t)bpgpu_internal_stream(c), (hipEvent_t)prev_early, 0);
+            bpgpu_internal_mark_early(c, p->stagger_chains);
+        }
         const int rc = bpgpu_internal_rp_verify_segs(c, head.n, head.m, head.proof_len, labs.data(), head.label.size(), segs.data(),
                                                      (uint32_t)segs.size(), any_msm, head.rlc ? 0u : hint, (was_idle && T <= p->latency_proofs) ? 0 : 1, head.rlc);   // (the hint is for per-proof table walks: a combined chain walks ONE 1690-pair MSM, which wants all the workgroups it can get)
         {
@@ -2383,6 +2399,10 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
                 rc_all = rc;
                 first_err = bpgpu_last_error(c);
             }
+        }
+        if (p->stagger_chains && !head.rlc) {
+            prev_early = rc ? nullptr : bpgpu_internal_early_event(c);
+            bpgpu_internal_mark_early(c, 0);
         }
         p->stat_chains++;
         p->stat_chain_proofs += filled;

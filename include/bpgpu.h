@@ -467,7 +467,16 @@ int bpgpu_ipp_verification_scalars(bpgpu_ctx *ctx, size_t n, size_t nbatch, cons
  * "slice_proofs" / "host_workers" (the round-3 host path only); the combining queue: "combine_wait_us" (100), "combine_quiet_us" (20),
  * "combine_max_age_us" (1500), "combine_inflight" (6: deadlines seal buffers only while fewer chains than this run -- beyond, load
  * widens the chains), "combine_busy_chains" (2), "combine_max_open" (4 transcript-position classes with a buffer of their own),
- * "combine_poll_us" (15); any other key is forwarded to every lane context (set those before bpgpu_pool_gens_*).  Read-only
+ * "combine_poll_us" (15), "combine_policy" (2: when a staging buffer leaves -- 0 = the two regimes for every kind of work, 1 = cohorts for
+ * every kind: a buffer leaves when the group the last chain released is back, at most "combine_cohort_inflight" (2) chains run,
+ * "combine_regroup_us" (60) for a group to come back, "combine_hold_us" (400) while the device is busy; 2 = regimes for range proofs,
+ * cohorts for the MSM / inner-product kinds, as measured: DESIGN 2b), "combine_wide_proofs" (384) / "combine_inflight_wide" (3) (the
+ * regimes' throughput regime), "combine_mapped_out" (1024: chains up to this wide write their results straight into pinned host memory),
+ * "combine_mapped_in" (0: MSM chains read their inputs in place instead of copying them first -- measured slower), "combine_msm_bytes",
+ * "combine_trace" (ring size of the timeline records, bpgpu_pool_trace_dump); the flush: "plan_by_work" (2: chains by proof count, a LONE
+ * chain that carries two chains' worth of table-walk work is cut in two; 0 = by proof count alone; 1 = in proportion to work, with
+ * "plan_min_chain_proofs" as a floor -- measured worse on aggregated shapes); any other key is forwarded to every lane context
+ * (set those before bpgpu_pool_gens_*; e.g. "msm_fork" = 0: bpgpu_msm_batch_shared's generator half on the chain's own stream).  Read-only
  * statistics: "stat_chains", "stat_chain_proofs" (launch chains issued by flushes and the proofs they carried; set "stat_reset" to
  * zero all statistics), "stat_last_splits", "stat_combined_chains" / "_proofs" / "_requests", "stat_svc_issue_us" /
  * "_complete_us" / "_polls" (the combining queue's service threads). */
