@@ -2586,8 +2586,17 @@ extern "C" int bpgpu_ipp_verification_scalars(bpgpu_ctx *c, size_t n, size_t nba
             if (k >= 32) fmt = true;
         }
     }
+    // the caller's transcript as it is handed back when nothing was absorbed: from_bytes failed, or n != 2^k (ipp.rs:203-211 returns before
+    // innerproduct_domain_sep)
+    uint8_t st_start[BPGPU_TRANSCRIPT_BYTES];
+    if (transcripts && !per_proof) memcpy(st_start, transcripts, BPGPU_TRANSCRIPT_BYTES);
+    else if (!transcripts) bpgpu_transcript_new(label, label_len, st_start);
+    auto untouched = [&](size_t b) {
+        if (transcripts_out) memcpy(transcripts_out + b * BPGPU_TRANSCRIPT_BYTES, per_proof ? transcripts + b * BPGPU_TRANSCRIPT_BYTES : st_start, BPGPU_TRANSCRIPT_BYTES);
+    };
     if (fmt) {
         memset(status, BPGPU_VERDICT_FORMAT_ERROR, nbatch);
+        for (size_t b = 0; b < nbatch; b++) untouched(b);
         return BPGPU_OK;
     }
     const bool shape_bad = n != ((size_t)1 << k);   // ipp.rs:203-211 (k >= 32 was refused above)
@@ -2650,7 +2659,12 @@ extern "C" int bpgpu_ipp_verification_scalars(bpgpu_ctx *c, size_t n, size_t nba
     if (n_eff) memcpy(s_out, ho + 2 * sz_u, nbatch * n_eff * 32);
     if (transcripts_out) memcpy(transcripts_out, ho + 2 * sz_u + sz_s, nbatch * TS);
     const uint32_t *st32 = (const uint32_t *)(ho + 2 * sz_u + sz_s + sz_to);
-    for (size_t b = 0; b < nbatch; b++) status[b] = (uint8_t)st32[b];
+    for (size_t b = 0; b < nbatch; b++) {
+        status[b] = (uint8_t)st32[b];
+        // (with one start state for the batch the device replays from the state BEHIND the domain separator: where the reference never
+        // got that far, the caller's state goes back as it came)
+        if (status[b] == BPGPU_VERDICT_FORMAT_ERROR || shape_bad) untouched(b);
+    }
     return BPGPU_OK;
 }
 

@@ -190,11 +190,19 @@ BP_HD void ipp_vs_front_thread(uint32_t p, ipp_shape sh, const rp_strobe_init &i
     uint32_t w[8];
     bool verr = false;
     for (uint32_t i = 0; i < k; i++) {
+        // validate_and_append_point returns Err BEFORE it absorbs an identity point (transcript.rs:75-87; ipp.rs:217-222): the caller's
+        // transcript is handed back as of that moment -- domain separator and earlier rounds in
         load_words8(w, pr + 64 * i);
-        verr = verr || words8_zero(w);
+        if (words8_zero(w)) {
+            if (!verr && ts_out) rp_ts_emit(p, st, rp_ts_meta(t.pos, t.pos_begin, t.cur_flags), ts_out);
+            verr = true;
+        }
         merlin_append_words8(t, lL, 1, w);
         load_words8(w, pr + 64 * i + 32);
-        verr = verr || words8_zero(w);
+        if (words8_zero(w)) {
+            if (!verr && ts_out) rp_ts_emit(p, st, rp_ts_meta(t.pos, t.pos_begin, t.cur_flags), ts_out);
+            verr = true;
+        }
         merlin_append_words8(t, lR, 1, w);
         sc u;
         rp_challenge_scalar(t, lu, 1, u);
@@ -202,9 +210,8 @@ BP_HD void ipp_vs_front_thread(uint32_t p, ipp_shape sh, const rp_strobe_init &i
         uim[i] = acc;
         sc28_montmul(acc, acc, um[i]);
     }
-    if (verr) {   // validate_and_append_point: an identity L_i / R_i is a VerificationError (transcript.rs:75-87)
+    if (verr) {   // an identity L_i / R_i is a VerificationError
         status[p] = BP_VERDICT_VERIFICATION;
-        rp_ts_passthrough(p, ts_in ? none : init, ts_in, ts_out);
         return;
     }
     sc28_invert_mont_safegcd(inv, acc);

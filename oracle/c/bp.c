@@ -755,8 +755,10 @@ int oracle_ipp_verification_scalars(size_t n, const uint8_t *proof, size_t proof
     merlin_append_u64(&t, "n", n);
     sc u_sq[32], u_inv_sq[32], allinv; sc_from_u64(&allinv, 1);
     for (size_t i = 0; i < lg_n; i++) {
-        if (validate_and_append_point(&t, "L", proof + 64 * i)) return ORACLE_ERR_VERIFICATION;
-        if (validate_and_append_point(&t, "R", proof + 64 * i + 32)) return ORACLE_ERR_VERIFICATION;
+        /* validate_and_append_point returns Err BEFORE absorbing an identity point (transcript.rs:75-87): the caller's `&mut Transcript`
+         * stays as it is at that moment -- domain separator and earlier rounds included (ipp.rs:213-222) */
+        if (validate_and_append_point(&t, "L", proof + 64 * i)) { ts_store(state, &t); return ORACLE_ERR_VERIFICATION; }
+        if (validate_and_append_point(&t, "R", proof + 64 * i + 32)) { ts_store(state, &t); return ORACLE_ERR_VERIFICATION; }
         sc u, ui; challenge_scalar(&t, "u", &u); sc_invert(&ui, &u);
         sc_mul(&allinv, &allinv, &ui); sc_mul(&u_sq[i], &u, &u); sc_mul(&u_inv_sq[i], &ui, &ui);
     }

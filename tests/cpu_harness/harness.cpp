@@ -902,6 +902,54 @@ int h_msm_bucket(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalar
 
 // The batched inner-product-proof prover (ipp_prover.h), lane by lane; the MSMs go through the variable-base pipeline
 // emulation above.  ts0: the 208-byte transcript state BEFORE innerproduct_domain_sep(n).
+// InnerProductProof::verification_scalars alone (ipp_vs_front_thread + ipp_vs_s_thread, bpgpu_ipp_verification_scalars): per-proof start
+// states (per_proof = 1: states208 holds nbatch of them, the domain separator is applied by the lane) or one for the batch (the host applies
+// innerproduct_domain_sep(n) first, as the runtime does).  Hands back status, u_i^2, u_i^-2, s_i and the transcripts as the DEVICE leaves them
+// (the runtime replaces those of FormatError / wrong-n proofs by the caller's own state afterwards in the one-state mode).
+int h_ipp_vs(uint32_t n, uint32_t nbatch, const uint8_t *proofs, uint32_t proof_len, const uint8_t *states208, int per_proof, uint8_t *status_out, uint8_t *u_sq,
+             uint8_t *u_inv_sq, uint8_t *s_out, uint8_t *ts_out208) {
+    if (proof_len % 32 || proof_len < 64 || ((proof_len / 32 - 2) & 1)) return -1;
+    const uint32_t k = (proof_len / 32 - 2) / 2;
+    ipp_shape sh; sh.n = n; sh.k = k; sh.N = 0; sh.proof_len = proof_len; sh.nproofs = nbatch; sh.shape_verdict = (n != (1u << k)) ? BP_VERDICT_VERIFICATION : 0; sh.bases_shared = 0;
+    rp_strobe_init init; memset(&init, 0, sizeof init);
+    std::vector<uint32_t> ts_in;
+    if (per_proof) {
+        ts_in.assign((size_t)nbatch * BP_TS_WORDS, 0);
+        for (uint32_t p = 0; p < nbatch; p++) {
+            const uint8_t *st = states208 + (size_t)p * 208;
+            memcpy(&ts_in[(size_t)p * BP_TS_WORDS], st, 200);
+            ts_in[(size_t)p * BP_TS_WORDS + 50] = rp_ts_meta(st[200], st[201], st[202]);
+        }
+    } else {
+        memcpy(init.w, states208, 200);
+        kstate st0; st0.w = init.w; st0.stride = 1;
+        strobe t; t.st = st0; t.pos = states208[200]; t.pos_begin = states208[201]; t.cur_flags = states208[202];
+        const uint8_t dom[7] = {'d','o','m','-','s','e','p'}, ipp[6] = {'i','p','p',' ','v','1'}, ln[1] = {'n'};
+        merlin_append_message(t, dom, 7, ipp, 6);
+        merlin_append_u64(t, ln, 1, n);
+        init.pos = t.pos; init.pos_begin = t.pos_begin; init.cur_flags = t.cur_flags;
+    }
+    std::vector<uint32_t> us((size_t)nbatch * (k ? k : 1) * 8 + 8, 0), ui((size_t)nbatch * (k ? k : 1) * 8 + 8, 0), tab((size_t)nbatch * (k ? k : 1) * 20 + 8, 0),
+        tso((size_t)nbatch * BP_TS_WORDS, 7), status(nbatch + 1, 0), sv((size_t)nbatch * (n ? n : 1) * 8 + 8, 0);
+    for (uint32_t p = 0; p < nbatch; p++) {
+        uint32_t w[50]; kstate st; st.w = w; st.stride = 1;
+        ipp_vs_front_thread(p, sh, init, st, proofs, per_proof ? ts_in.data() : nullptr, us.data(), ui.data(), tab.data(), tso.data(), status.data());
+    }
+    if (!sh.shape_verdict)
+        for (uint32_t tid = 0; tid < n * nbatch; tid++) ipp_vs_s_thread(tid, sh, tab.data(), status.data(), sv.data());
+    for (uint32_t p = 0; p < nbatch; p++) {
+        status_out[p] = (uint8_t)status[p];
+        memset(ts_out208 + (size_t)p * 208, 0, 208);
+        memcpy(ts_out208 + (size_t)p * 208, &tso[(size_t)p * BP_TS_WORDS], 200);
+        const uint32_t meta = tso[(size_t)p * BP_TS_WORDS + 50];
+        ts_out208[(size_t)p * 208 + 200] = meta & 0xff; ts_out208[(size_t)p * 208 + 201] = (meta >> 8) & 0xff; ts_out208[(size_t)p * 208 + 202] = (meta >> 16) & 0xff;
+    }
+    memcpy(u_sq, us.data(), (size_t)nbatch * k * 32);
+    memcpy(u_inv_sq, ui.data(), (size_t)nbatch * k * 32);
+    if (!sh.shape_verdict) memcpy(s_out, sv.data(), (size_t)nbatch * n * 32);
+    return 0;
+}
+
 int h_ipp_create(uint32_t n, uint32_t nbatch, const uint8_t *ts0, const uint8_t *Q, const uint8_t *Gf, const uint8_t *Hf, const uint8_t *G,
                  const uint8_t *H, int bases_shared, const uint8_t *a_in, const uint8_t *b_in, uint8_t *proofs, uint8_t *status_out) {
     uint32_t k = 0; while ((1u << k) < n) k++;

@@ -823,6 +823,35 @@ def test_standalone_ipp_front_end_lane_by_lane(H, oracle, n):
     assert list(vd.raw) == [0, 1, 1]
 
 
+@pytest.mark.parametrize("n", [2, 4, 32, 64])
+def test_verification_scalars_front_end_and_its_transcript_on_every_path(H, oracle, n):
+    """ipp_vs_front_thread / ipp_vs_s_thread (bpgpu_ipp_verification_scalars; ipp.rs:198-253): u_i^2, u_i^-2, s_i and the caller's transcript
+    against the oracle (pinned on the Python twin, tests/test_oracle.py) -- valid proofs, an identity encoding at every L_i / R_i position (the
+    state as of that message: domain separator and earlier rounds in, transcript.rs:75-87), per-proof start states and one for the batch."""
+    from bulletproofs_amd._lib import transcript_new, transcript_append_message
+    label = b"innerproducttest"
+    k = n.bit_length() - 1
+    pr = oracle.ipp_test_instance(n, label, b"hvs%d" % n)["proof"]
+    pl = len(pr)
+    variants = [pr] + [pr[:32 * u] + bytes(32) + pr[32 * u + 32:] for u in range(2 * k)]
+    nb = len(variants)
+    proofs = b"".join(variants)
+    shared = transcript_append_message(transcript_new(label), b"earlier", b"message of the parent protocol")
+    per = b"".join(transcript_append_message(transcript_new(label), b"p", bytes(j for j in range(3 * i + 1))) for i in range(nb))
+    for per_proof, states in ((0, shared), (1, per)):
+        so, us, ui = C.create_string_buffer(nb), C.create_string_buffer(32 * k * nb), C.create_string_buffer(32 * k * nb)
+        sv, to = C.create_string_buffer(32 * n * nb), C.create_string_buffer(208 * nb)
+        assert H.h_ipp_vs(n, nb, proofs, pl, states, per_proof, so, us, ui, sv, to) == 0
+        for i in range(nb):
+            start = states[208 * i:208 * (i + 1)] if per_proof else shared
+            rc, eus, eui, es, est = oracle.ipp_verification_scalars(n, variants[i], start)
+            assert so.raw[i] == rc == (0 if i == 0 else 1), (n, per_proof, i)
+            assert to.raw[208 * i:208 * (i + 1)] == est, (n, per_proof, i)
+            if rc == 0:
+                assert us.raw[32 * k * i:32 * k * (i + 1)] == eus and ui.raw[32 * k * i:32 * k * (i + 1)] == eui and sv.raw[32 * n * i:32 * n * (i + 1)] == es
+        assert len({to.raw[208 * i:208 * (i + 1)] for i in range(nb)}) == nb
+
+
 def test_util_rs_scalar_tests_on_the_device_code(H, oracle):
     """src/util.rs:274-351 -- exp_2_is_powers_of_2, test_inner_product (<a, b> = 40), test_scalar_exp (the fixed scalar),
     test_sum_of_powers (x = 10, n in {1, .., 64}) -- against the device's scalar arithmetic (sc25519.h, rangeproof.h) compiled

@@ -116,9 +116,9 @@ def test_verification_scalars_export_vs_oracle(oracle):
         for i in range(nb):
             rc, eus, eui, es, est = oracle.ipp_verification_scalars(n, bytes(bad[i]), st0)
             assert st[i] == rc, (n, i)
+            assert tso[208 * i:208 * (i + 1)] == est, (n, i, rc)          # on every path: an identity L_0 leaves the domain separator in, a malformed proof nothing
             if rc == 0:
                 assert us[32 * k * i:32 * k * (i + 1)] == eus and ui[32 * k * i:32 * k * (i + 1)] == eui and s_[32 * n * i:32 * n * (i + 1)] == es
-                assert tso[208 * i:208 * (i + 1)] == est
             else:
                 assert s_[32 * n * i:32 * n * (i + 1)] == bytes(32 * n)
         # the caller's transcript: one state for the batch, then one per proof (different positions)
@@ -130,12 +130,20 @@ def test_verification_scalars_export_vs_oracle(oracle):
             for (gu, gi, gs, gst, gts, start) in ((us2, ui2, s2, st2, tso2, shared), (us3, ui3, s3, st3, tso3, per[208 * i:208 * (i + 1)])):
                 rc, eus, eui, es, est = oracle.ipp_verification_scalars(n, bytes(bad[i]), start)
                 assert gst[i] == rc
+                assert gts[208 * i:208 * (i + 1)] == est, (n, i, rc)
                 if rc == 0:
                     assert gu[32 * k * i:32 * k * (i + 1)] == eus and gi[32 * k * i:32 * k * (i + 1)] == eui and gs[32 * n * i:32 * n * (i + 1)] == es
-                    assert gts[208 * i:208 * (i + 1)] == est
         # n that does not match the proof: VerificationError for well-formed proofs, FormatError outranks it
-        _, _, _, st4 = ctx.ipp_verification_scalars(2 * n, proofs, pl, label=label)
+        _, _, _, st4, tso4 = ctx.ipp_verification_scalars(2 * n, proofs, pl, label=label, want_transcripts=True)
         assert list(st4) == [2 if i == nb - 1 else 1 for i in range(nb)]
+        assert tso4 == st0 * nb                                            # ipp.rs:203-211: Err before the domain separator -- the transcript as it came
+        # an identity at every position of the proof: the state as of that message (ipp.rs:217-222)
+        if 2 <= n <= 64:
+            stops = [insts[0][:32 * u] + bytes(32) + insts[0][32 * u + 32:] for u in range(2 * k)]
+            _, _, _, st6, tso6 = ctx.ipp_verification_scalars(n, b"".join(stops), pl, transcripts=per[:208], want_transcripts=True)
+            for u in range(2 * k):
+                rc, _, _, _, est = oracle.ipp_verification_scalars(n, stops[u], per[:208])
+                assert st6[u] == rc == 1 and tso6[208 * u:208 * (u + 1)] == est, (n, u)
     _, _, _, st5 = ctx.ipp_verification_scalars(4, bytes(100), 50, label=label)      # malformed length
     assert list(st5) == [2, 2]
     ctx.close()

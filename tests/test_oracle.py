@@ -324,6 +324,28 @@ def test_ipp_verification_scalars_c_equals_twin(oracle):
     assert oracle.ipp_verification_scalars(8, pr, st0)[0] == 1
     assert oracle.ipp_verification_scalars(4, bytes(32) + pr[32:], st0)[0] == 1
     assert oracle.ipp_verification_scalars(4, pr[:-64] + b"\xff" * 32 + pr[-32:], st0)[0] == 2
+    # ... and what they leave in the caller's `&mut Transcript` (the twin's Transcript object is mutated as merlin's is): wrong n and a
+    # malformed proof never touch it (ipp.rs:203-211 / from_bytes); an identity L_i / R_i stops the replay BEFORE that message, with the
+    # domain separator and the earlier rounds in (transcript.rs:75-87, ipp.rs:213-222)
+    assert oracle.ipp_verification_scalars(8, pr, st0)[4] == st0
+    assert oracle.ipp_verification_scalars(4, pr[:-64] + b"\xff" * 32 + pr[-32:], st0)[4] == st0
+    for n in (2, 4, 32):
+        inst = oracle.ipp_test_instance(n, b"innerproducttest", b"stop%d" % n)
+        pr, k = inst["proof"], n.bit_length() - 1
+        seen = set()
+        for u in range(2 * k):
+            bad = pr[:32 * u] + bytes(32) + pr[32 * u + 32:]
+            rc, _, _, _, st1 = oracle.ipp_verification_scalars(n, bad, st0)
+            t = T.Transcript(b"innerproducttest")
+            rp = T.RangeProof()
+            rp.L_vec = [bad[64 * i:64 * i + 32] for i in range(k)]
+            rp.R_vec = [bad[64 * i + 32:64 * i + 64] for i in range(k)]
+            with pytest.raises(T.VerificationError):
+                T.verification_scalars(rp, n, t)
+            assert rc == 1 and st1 != st0
+            assert oracle.transcript_challenge_bytes(st1, b"chk", 32)[1] == t.challenge_bytes(b"chk", 32), (n, u)
+            seen.add(st1)
+        assert len(seen) == 2 * k
 
 
 def test_vector_backend_equals_scalar_backend(oracle, golden):
