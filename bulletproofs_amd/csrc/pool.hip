@@ -135,6 +135,19 @@ static int probe_hw_queues(int) { return 16; }   // (host test build: tests/cpu_
 
 namespace {
 
+// Host-test builds only (tests/cpu_pool): BP_TEST_DELAY="point:microseconds" holds a thread at one of the queue's publication points, which
+// widens a window of a few instructions to something a scheduler test can hit -- how the open-order bug of round 5 reproduces on demand.
+#ifdef BPGPU_POOL_HOST_TEST
+static void test_delay(int point) {
+    static const int want = [] { const char *e = getenv("BP_TEST_DELAY"); return e ? atoi(e) : -1; }();
+    static const int us = [] { const char *e = getenv("BP_TEST_DELAY"); const char *c = e ? strchr(e, ':') : nullptr; return c ? atoi(c + 1) : 100; }();
+    if (point == want) usleep((useconds_t)us);
+}
+#define TEST_DELAY(point) test_delay(point)
+#else
+#define TEST_DELAY(point) ((void)0)
+#endif
+
 // std::atomic<uint32_t> as a futex word (C++17: no atomic::wait yet)
 inline void futex_wait(std::atomic<uint32_t> *a, uint32_t expected) { syscall(SYS_futex, (uint32_t *)a, FUTEX_WAIT_PRIVATE, expected, nullptr, nullptr, 0); }
 inline void futex_wake_all(std::atomic<uint32_t> *a) { syscall(SYS_futex, (uint32_t *)a, FUTEX_WAKE_PRIVATE, INT_MAX, nullptr, nullptr, 0); }
@@ -1057,6 +1070,7 @@ static void cbuf_release(bpgpu_pool *p, comb_buf *b) {
     b->ev.t_free = now_ns();
     trace_chain(p, d, b->ev);
     b->st.store(CB_FREE, std::memory_order_seq_cst);
+    TEST_DELAY(2);
     if (d->free_waiters.load(std::memory_order_seq_cst) != 0) {
         { std::lock_guard<std::mutex> lk(d->cmu); }   // (a waiter that has counted itself in is inside free_cv.wait by the time this lock is granted)
         d->free_cv.notify_one();
@@ -1195,7 +1209,9 @@ static void comb_complete(pool_dev *d, comb_buf *b) {
     const uint32_t epoch = cbs_epoch(b->state.load(std::memory_order_relaxed));
     const bool any_async = b->n_async.load(std::memory_order_relaxed) != 0, any_sync = b->n_sync.load(std::memory_order_relaxed) != 0;
     b->st.store(CB_DONE, std::memory_order_release);
+    TEST_DELAY(3);
     b->phase.store(epoch, std::memory_order_release);
+    TEST_DELAY(4);
     if (any_sync) futex_wake_all(&b->phase);
     if (any_async) {   // (after this push the buffer may be released, reopened, ... at any moment: nothing of it is touched below)
         {
@@ -1232,6 +1248,7 @@ static void dlv_main(bpgpu_pool *p, pool_dev *d) {
                 }
                 taken += pc.count;
                 // the request may be freed by its owner as soon as `left` reads 0: the fetch_sub is this thread's last access to it
+                TEST_DELAY(9);
                 const uint32_t old = r->left.fetch_sub(1, std::memory_order_acq_rel);
                 if (old == (TKT_WAITING | 1u)) futex_wake_all(&r->left);   // (a wake on an address whose owner has moved on is harmless)
             }
@@ -1374,6 +1391,7 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
                     due = true;   // the few callers the last chain released are all back and nothing else runs: nothing to wait for
                 if (!seal && (stopping || due)) {
                     s = b->state.fetch_or(CBS_SEALED, std::memory_order_acq_rel);   // (slots taken since the load above are in the value this returns)
+                    TEST_DELAY(5);
                     seal = true;
                 }
                 if (seal) {
@@ -1438,7 +1456,9 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
         }
         if (stopping && all_free && p->active_calls.load(std::memory_order_acquire) == 0) return;
         // sleep: a poll period while anything is open or in flight, until the doorbell rings otherwise
+        TEST_DELAY(11);
         d->svc_sleeping.store(1, std::memory_order_seq_cst);
+        TEST_DELAY(12);
         if (active || stopping) futex_wait_ns(&d->kick, kick0, (uint64_t)p->combine_poll_ns);
         else futex_wait(&d->kick, kick0);
         d->svc_sleeping.store(0, std::memory_order_seq_cst);
@@ -1627,9 +1647,7 @@ static int comb_reserve_slow(bpgpu_pool *p, pool_dev *d, comb_req *r, comb_key &
             // three of twenty-three runs of the first sweep).  Callers look at the word only; the service thread looks at `st` first and its
             // acquire load of CB_OPEN now brings the new word with it.
             b->state.store(cbs_pack(e, false, t), std::memory_order_release);   // publishes the incarnation (its first reservation is ours)
-#ifdef BPGPU_POOL_HOST_TEST
-            if (const char *dly = getenv("BP_TEST_OPEN_DELAY_US")) usleep((useconds_t)atoi(dly));   // (tests/cpu_pool: widens the window between the two stores)
-#endif
+            TEST_DELAY(1);   // (between the two stores)
             b->st.store(CB_OPEN, std::memory_order_release);
             out.b = b, out.epoch = e, out.first = 0, out.take = t, out.filled = (t == cap);
             const bool others_wait = d->free_waiters.load(std::memory_order_relaxed) != 0;
@@ -1645,6 +1663,7 @@ static int comb_reserve_slow(bpgpu_pool *p, pool_dev *d, comb_req *r, comb_key &
             lk.lock();
         } else {
             d->free_waiters.fetch_add(1, std::memory_order_seq_cst);
+            TEST_DELAY(10);
             bool any_free = false;   // (a buffer released between the scan above and the count: its releaser saw no waiter)
             for (comb_buf *cb : d->cbufs) any_free = any_free || cb->st.load(std::memory_order_seq_cst) == CB_FREE;
             if (!any_free) d->free_cv.wait(lk);
@@ -1682,6 +1701,7 @@ static int comb_place(bpgpu_pool *p, pool_dev *d, comb_req *r, const comb_key &b
         if (r->traced && !r->ev.t_reserved) r->ev.t_reserved = now_ns(), r->ev.buf = b->index, r->ev.epoch = sl.epoch;
         // the piece's record, then the inputs, then `written`: the service thread issues the chain only after every reserved slot
         // has been counted in, the deliverers read the records only after the chain
+        TEST_DELAY(6);
         b->desc[first] = {r, take, r->async ? 1u : 0u, off};
         if (r->async) {
             r->left.fetch_add(1, std::memory_order_relaxed);
@@ -1694,6 +1714,7 @@ static int comb_place(bpgpu_pool *p, pool_dev *d, comb_req *r, const comb_key &b
         const bool opt_last = (key.kind == CQ_RP || key.kind == CQ_IPP);
         if (opt_last && r->out[g.n_out - 1]) b->want_opt.store(1, std::memory_order_relaxed);
         if (sl.filled) {
+            TEST_DELAY(8);
             b->state.fetch_or(CBS_SEALED, std::memory_order_acq_rel);
             svc_kick(d);
         }
@@ -1710,6 +1731,7 @@ static int comb_place(bpgpu_pool *p, pool_dev *d, comb_req *r, const comb_key &b
             }
         }
         if (r->traced) r->ev.t_written = now_ns();   // (before the count: a ticket's record is read by the delivery thread)
+        TEST_DELAY(7);
         b->written.fetch_add(take, std::memory_order_release);
         off += take;
     }

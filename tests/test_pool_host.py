@@ -90,8 +90,21 @@ def test_a_buffer_opened_slowly_is_never_sealed_on_its_predecessors_word(built, 
     """Round 5's first build published a reopened buffer's state (`st = CB_OPEN`) BEFORE its new reservation word; in between, the service
     thread could read the previous incarnation's word -- sealed, with that chain's width in it -- and seal the new incarnation at the old
     width: callers went on reserving, `written` passed K, the buffer waited for `written == K` forever (3 of 23 runs of the first GPU
-    sweep; caught by combine_rate's watchdog).  BP_TEST_OPEN_DELAY_US (host-test builds only) holds the opener between the two stores for
+    sweep; caught by combine_rate's watchdog).  BP_TEST_DELAY=1:200 (host-test builds only) holds the opener between the two stores for
     200 us: with the old order these runs hang within a second, with the word published first they complete."""
-    p, d = run(os.path.join(built, "pool_host_test"), mode, env={"BP_TEST_OPEN_DELAY_US": "200"}, timeout=120)
+    p, d = run(os.path.join(built, "pool_host_test"), mode, env={"BP_TEST_DELAY": "1:200"}, timeout=120)
     assert p.returncode == 0, p.stderr[-2000:]
     assert d["mismatches"] == 0 and d.get("errors", 0) == 0 and d["items"] > 0
+
+
+@pytest.mark.parametrize("point", list(range(1, 13)))
+def test_every_publication_point_of_the_queue_held_open(built, point):
+    """BP_TEST_DELAY=point:150 holds a thread for 150 us at one of twelve publication points of the combining queue (a reopened buffer between
+    its two stores, a freed buffer before the waiter check, a finished chain between `st = CB_DONE` and its futex word, the service thread
+    between sealing and `st = CB_SEALED`, a caller between its reservation, its record, its inputs and its count, the filler before it seals,
+    the delivery thread before its last access to a ticket, a caller about to wait for a buffer, the service thread around its sleeping flag):
+    tickets and every kind of request at once complete with every result right, whichever window is the wide one."""
+    for mode in (["tickets", "8", "64", "0.4"], ["mixed", "10", "0.6"]):
+        p, d = run(os.path.join(built, "pool_host_test"), mode, env={"BP_TEST_DELAY": "%d:150" % point}, timeout=120)
+        assert p.returncode == 0, (point, mode, p.stderr[-1500:])
+        assert d["mismatches"] == 0 and d.get("errors", 0) == 0 and d["items"] > 0, (point, mode)
