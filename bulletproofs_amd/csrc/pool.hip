@@ -413,6 +413,10 @@ struct bpgpu_pool {
     // Staggered bursts: chain i + 1 of a flush starts behind chain i's early phase (1: behind its launch 1; 2: behind its generator exponents, i.e.
     // when its table walk begins) instead of beside it.  0 = all chains of a flush start at once.
     int stagger_chains = 0;
+    // Batch-combined items of unrelated submitters normally share ONE identity check per chain: a single bad proof then leaves every
+    // proof of every batch of that chain undecided, and each submitter has to find out alone (one hostile submitter sends
+    // everybody to the slow path).  1 = a chain never carries more than one batch-combined item: a failure stays with its own batch.
+    int rlc_isolate = 0;
     size_t plan_min_chain_proofs = 0;   // ... but no chain of a burst narrower than this many proofs of its shape (0 = no floor): launch 1's lane-serial roles are per PROOF
     size_t host_workers = 0;
     // combining queue
@@ -654,6 +658,10 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
         p->plan_by_work = (int)value;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "rlc_isolate")) {
+        p->rlc_isolate = value != 0;
+        return BPGPU_OK;
+    }
     if (!strcmp(key, "stagger_chains")) {
         if (value < 0 || value > 2) return pfail(p, BPGPU_ERR_INVALID_ARG, "stagger_chains out of range");
         p->stagger_chains = (int)value;
@@ -763,6 +771,7 @@ int bpgpu_pool_get_option(bpgpu_pool *p, const char *key, int64_t *value) {
     else if (!strcmp(key, "plan_by_work")) *value = (int64_t)p->plan_by_work;
     else if (!strcmp(key, "plan_min_chain_proofs")) *value = (int64_t)p->plan_min_chain_proofs;
     else if (!strcmp(key, "stagger_chains")) *value = (int64_t)p->stagger_chains;
+    else if (!strcmp(key, "rlc_isolate")) *value = (int64_t)p->rlc_isolate;
     else if (!strcmp(key, "latency_proofs")) *value = (int64_t)p->latency_proofs;
     else if (!strcmp(key, "pair_limit_proofs")) *value = (int64_t)p->pair_limit_proofs;
     else if (!strcmp(key, "host_workers")) *value = (int64_t)p->host_workers;
@@ -2373,7 +2382,7 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
             size_t take = it.nbatch - off;
             // a batch-combined item stays whole (its 33-byte result is the result of ONE chain): it opens the next chain rather than being cut,
             // and may stretch a chain up to max_chain_proofs (submit refuses wider ones: ADVICE r04)
-            if (head.rlc && off == 0 && filled > 0 && take > per - filled) break;
+            if (head.rlc && off == 0 && filled > 0 && (take > per - filled || p->rlc_isolate)) break;
             const size_t room = (head.rlc && off == 0 && take <= p->max_chain_proofs) ? take : per - filled;
             if (take > room) take = room;
             chain_waits_for(c, it);

@@ -475,7 +475,9 @@ int bpgpu_ipp_verification_scalars(bpgpu_ctx *ctx, size_t n, size_t nbatch, cons
  * "combine_mapped_in" (0: MSM chains read their inputs in place instead of copying them first -- measured slower), "combine_msm_bytes",
  * "combine_trace" (ring size of the timeline records, bpgpu_pool_trace_dump); the flush: "plan_by_work" (2: chains by proof count, a LONE
  * chain that carries two chains' worth of table-walk work is cut in two; 0 = by proof count alone; 1 = in proportion to work, with
- * "plan_min_chain_proofs" as a floor -- measured worse on aggregated shapes); any other key is forwarded to every lane context
+ * "plan_min_chain_proofs" as a floor -- measured worse on aggregated shapes), "rlc_isolate" (0; 1 = a chain carries at most
+ * one batch-combined batch, so that a bad proof leaves only its own batch undecided instead of every batch that shared the check),
+ * "stagger_chains" (0: measured worse); any other key is forwarded to every lane context
  * (set those before bpgpu_pool_gens_*; e.g. "msm_fork" = 0: bpgpu_msm_batch_shared's generator half on the chain's own stream).  Read-only
  * statistics: "stat_chains", "stat_chain_proofs" (launch chains issued by flushes and the proofs they carried; set "stat_reset" to
  * zero all statistics), "stat_last_splits", "stat_combined_chains" / "_proofs" / "_requests", "stat_svc_issue_us" /

@@ -124,3 +124,44 @@ def test_batch_combined_item_wider_than_a_chain_is_refused(oracle):
         assert bytes(b[i][:33]) == bytes(33) and bytes(b[i][33:]) == b"\xff" * 3
     assert bytes(b[5]) == b"\xff" * 36
     pool.close()
+
+
+def test_rlc_isolate_keeps_a_bad_proof_s_damage_in_its_own_batch(oracle):
+    """Batch-combined batches of unrelated submitters share one identity check per chain by default: one bad proof leaves all of them
+    undecided.  With the pool option rlc_isolate every batch is its own combination: only the batch with the bad proof comes back undecided."""
+    import torch
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    fx = wl.load_fixture("cfg2_n64_m1")
+    dev = torch.device("cuda", 0)
+    to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
+    sizes = [200, 300, 150]
+    total = sum(sizes)
+    proofs, coms = wl.tile_batch(fx, total, first=3)
+    pb = bytearray(proofs)
+    pb[(200 + 17) * fx.proof_len + 129] ^= 4            # a tampered scalar in the second batch
+    d_p, d_c = to_dev(bytes(pb)), to_dev(coms)
+    for isolate, expect_und in ((0, [0, 1, 2]), (1, [1])):
+        pool = bp.Pool((0,), 4, fixed_window_bits=14)
+        pool.gens_create(64, 1)
+        pool.set_option("auto_flush_items", 1000)
+        pool.set_option("rlc_isolate", isolate)
+        d_v = torch.full((total,), 255, dtype=torch.uint8, device=dev)
+        d_b = torch.full((3, 36), 255, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        off = 0
+        for i, nb in enumerate(sizes):
+            pool.submit_rlc_dev(0, fx.n, fx.m, nb, d_p.data_ptr() + off * fx.proof_len, fx.proof_len, d_c.data_ptr() + off * 32, fx.label, None, d_v.data_ptr() + off,
+                                d_b[i].data_ptr())
+            off += nb
+        pool.wait()
+        assert pool.get_option("stat_chains") == (3 if isolate else 1)
+        v, b = bytes(d_v.cpu().numpy()), d_b.cpu().numpy()
+        off = 0
+        for i, nb in enumerate(sizes):
+            if i in expect_und:
+                assert v[off:off + nb] == b"\x05" * nb and b[i][0] != 0, (isolate, i)
+            else:
+                assert v[off:off + nb] == bytes(nb) and bytes(b[i][:33]) == bytes(33), (isolate, i)
+            off += nb
+        pool.close()
