@@ -63,3 +63,15 @@ def test_bench_runs_with_n_ranks(gpus):
     j = json.loads(line)
     assert j["n_gpus"] == gpus and j["steps"] == 12 and j["value"] > 0 and j["scaling"] == "weak"
     assert j["config"]["global_batch"] == 1024 * gpus and j["roofline"]["launches"] >= 12
+    # the record describes itself: the ranks the process group really had, its backend (two ranks on one GPU: gloo, so
+    # `rccl_ranks` must NOT claim them), every rank's own rate, table-build time and device
+    mg = j["multi_gpu"]
+    assert mg["ranks_in_process_group"] == gpus and len(mg["per_rank_verifications_per_s"]) == len(mg["per_rank_table_build_s"]) == len(mg["per_rank_device"]) == gpus
+    assert all(v > 0 for v in mg["per_rank_verifications_per_s"]) and all(t > 0 for t in mg["per_rank_table_build_s"])
+    import torch
+    share = gpus > torch.cuda.device_count()          # (on a multi-GPU node the two ranks get a GPU each and the backend is RCCL)
+    assert mg["ranks_share_gpus"] == share
+    if gpus == 1:
+        assert mg["backend"].startswith("none") and mg["rccl_ranks"] == 0
+    else:
+        assert mg["backend"] == ("gloo" if share else "nccl") and mg["rccl_ranks"] == (0 if share else gpus)
