@@ -11,13 +11,16 @@ ROUNDS=${1:-4}
 export GPU_MAX_HW_QUEUES=16 BP_LANES=8 BP_W=14
 g++ -O2 -std=c++17 -pthread -I include tools/combine_rate.cpp -L bulletproofs_amd/csrc -lbpgpu -Wl,-rpath,$PWD/bulletproofs_amd/csrc -o /tmp/combine_rate || exit 1
 INP=bench_data/combine_rate_inputs.bin
+python3 tools/make_msm_inputs.py /tmp/soak_msm_inputs.bin > /dev/null 2>&1 && export BP_MSM_INPUTS=/tmp/soak_msm_inputs.bin
 bad=0; n=0
 for r in $(seq 1 $ROUNDS); do
   for spec in "threads 256 1" "tickets 16 512" "threads 64 3" "tickets 4 512" "tickets 16 128|combine_inflight=2,combine_wait_us=300" "threads 256 1|combine_policy=1" \
-              "tickets 16 512|combine_policy=1,combine_cohort_inflight=3" "threads 128 2|combine_max_open=1" "big 4 1500" "tickets 32 64|combine_mapped_out=0"; do
+              "tickets 16 512|combine_policy=1,combine_cohort_inflight=3" "threads 128 2|combine_max_open=1" "big 4 1500" "tickets 32 64|combine_mapped_out=0" \
+              "msm 48 1" "msm 24 3|combine_policy=0"; do
     mode=${spec%%|*}; opts=""; [ "$spec" != "$mode" ] && opts=${spec#*|}
     n=$((n+1))
-    BP_OPTS=$opts timeout 60 /tmp/combine_rate $INP 0.6 $mode > $OUT/run.json 2> $OUT/run.err; rc=$?
+    w=$BP_W; [ "${mode%% *}" = "msm" ] && w=10      # (the MSM rows need BulletproofGens(2048, 1): small windows keep the table build short)
+    BP_W=$w BP_OPTS=$opts timeout 60 /tmp/combine_rate $INP 0.6 $mode > $OUT/run.json 2> $OUT/run.err; rc=$?
     line=$(grep '^{' $OUT/run.json | tail -1)
     ok=$(python3 -c "
 import json,sys
