@@ -87,6 +87,9 @@ struct bpgpu_ctx {
     std::map<std::vector<uint32_t>, script_ent> script_cache;       // (n, m, k, pos, pos_begin, flags, domsep) -> transcript script (rp_script.h), LRU-bounded (script_for)
     std::vector<uint32_t *> script_retired;
     uint64_t script_tick = 0;
+    int coop_defer_emit = 1;                                        // narrow chains: the scalar role's U coefficient recodings on U lanes at once (rangeproof.h rp_defer): one blocking call
+                                                                    // 0.528 / 0.528 / 0.533 -> 0.521 / 0.526 / 0.518 ms, 16 threads p50 0.64 -> 0.62 ms, 16 x 128 tickets 801 -> 819 k/s
+                                                                    // (profiles/r05/coop_defer_emit_ab.txt); 0: the leader recodes them one after the other
     int transcript_coop = 1;                                        // chains of up to 256 proofs replay their transcripts 32 lanes per proof (keccak.h): one call of 1 / 8 / 64 / 256 proofs 0.62 -> 0.53 / 0.56 / 0.57 / 0.58 ms; 0: lane = proof everywhere
     int split_stage1 = 0;                                           // experiment: point decoding as its own launch on the second stream, compiled for 1 / 2 / 3 wavefronts per SIMD
     int msm_fork = 1;                                               // bpgpu_msm_batch_shared: the generator-table half on the second stream beside the per-MSM points (0: one stream -- with
@@ -399,6 +402,7 @@ int bpgpu_ctx_create(int device, bpgpu_ctx **out) {
         delete c;
         return BPGPU_ERR_HIP;
     }
+    if (const char *e = getenv("BPGPU_COOP_DEFER_EMIT")) c->coop_defer_emit = atoi(e) != 0;   // (A/B of whole test suites: the option's default for every context of the process)
     *out = c;
     return BPGPU_OK;
 }
@@ -481,6 +485,10 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
     }
     if (!strcmp(key, "transcript_script")) {
         c->no_script = value == 0;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "coop_defer_emit")) {
+        c->coop_defer_emit = value != 0;
         return BPGPU_OK;
     }
     if (!strcmp(key, "transcript_coop")) {
@@ -1799,6 +1807,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const bool rlc_bucket = rlc && !shape_verdict && rlc_terms >= (c->bucket_min ? c->bucket_min : BK_RLC_MIN_TERMS) && bucket_fits(1, rlc_terms, bkp);
     sh.radix5 = r5 ? 1u : 0u;
     sh.a_outside = a_out ? 1u : 0u;
+    sh.defer_emit = c->coop_defer_emit ? 1u : 0u;
     arena_plan ap;
     size_t off[7], boff[12];
     if (rlc_bucket) plan_bucket(ap, 1, rlc_terms, bkp, boff);

@@ -66,6 +66,8 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1_coop(rp_shape sh, rp_str
                                                              uint32_t *recoded, fb_digit *digits, const uint8_t *rho64, const uint32_t *ts_in, uint32_t *ts_out,
                                                              fb_entry *bk_pts, uint32_t bk_c, rp_seg_tab segs, const rp_script_hdr *script) {
     __shared__ uint32_t lds[2 * 52];   // one 50-word sponge state per group
+    __shared__ sc28 dslot[2][RP_DEFER_CAP + 1];   // (option coop_defer_emit) the scalar role's coefficients, parked for the group's lanes
+    __shared__ uint32_t dmeta[2][2];
     if (blockIdx.x < n_tr) {
         const uint32_t lane = threadIdx.x, g = lane >> 5, p = blockIdx.x * 2 + g;
         const bool valid = p < sh.nproofs;
@@ -73,8 +75,17 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1_coop(rp_shape sh, rp_str
         kstate st;
         st.w = lds + 52 * g;
         st.stride = 1;
+        const bool defer = sh.defer_emit && sh.U <= RP_DEFER_CAP;   // (wavefront-uniform)
+        if ((lane & 31) == 0) dmeta[g][0] = 0;
         rp_transcript_scripted_coop(pp, valid, lane, sh, init, st, rp_resolve(pp, sh, proofs, commitments, rng64, segs), script, fields, status, ts_out, ts_in);
-        if (valid && (lane & 31) == 0 && !sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64, bk_c);
+        rp_defer df;
+        df.slot = dslot[g];
+        df.meta = dmeta[g];
+        if (valid && (lane & 31) == 0 && !sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64, bk_c, defer ? &df : nullptr);
+        if (defer) {   // the leader parked the U coefficients: one lane each recodes them
+            __syncthreads();
+            if (valid && !sh.shape_verdict) rp_emit_deferred(lane & 31, p, sh, recoded, df, bk_c);
+        }
     } else {
         const uint32_t t = (blockIdx.x - n_tr) * RP_BLOCK + threadIdx.x;
         if (t < sh.nproofs * sh.U) rp_points_thread(t, sh, rp_resolve(t / sh.U, sh, proofs, commitments, nullptr, segs), tab, status, bk_pts);

@@ -40,6 +40,8 @@ struct rp_shape {
     // per-proof randomness the caller did not bring is expanded ON THE DEVICE from one 32-byte key per launch chain (drawn on the host
     // by the library's generator, hostrng.h): proof p's 64 bytes are block p of ChaCha20(key, nonce = domain) -- nothing per proof is
     // drawn, staged or copied on the host (64 bytes per proof at 6 ... 10 M proofs/s would be a core's worth of ChaCha)
+    uint32_t defer_emit = 0;       // narrow chains (32 lanes per proof): the U coefficient recodings of the scalar role are done by U lanes at once instead of by
+                                   // the leader one after the other (rp_defer; option coop_defer_emit)
     uint32_t seeded = 0;           // RP_SEED_RNG | RP_SEED_WEIGHTS
     uint32_t seed[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -676,6 +678,26 @@ BP_HD void rp_emit_coeff(uint32_t *us, uint32_t u, const sc28 &vm, const sc28 *r
     }
 }
 
+// The scalar role of a NARROW chain has 31 idle lanes beside its leader: instead of recoding its U coefficients one after the other
+// (from Montgomery form, times the weight in batch-combination mode, into signed radix-16 digits: ~1.1 us each, U = 17 at (64, 1)) the leader
+// parks them in LDS and the lanes of its group recode one each.  slot[u] = coefficient u in Montgomery form, slot[RP_DEFER_CAP] = the
+// weight (meta[1] != 0), meta[0] = the leader got as far as parking them (a rejected proof parks nothing).
+#define RP_DEFER_CAP 96
+struct rp_defer {
+    sc28 *slot;       // [RP_DEFER_CAP + 1]
+    uint32_t *meta;   // [2]
+};
+BP_HD void rp_emit_deferred(uint32_t lane32, uint32_t p, const rp_shape &sh, uint32_t *recoded, const rp_defer &df, uint32_t bk_c) {
+    if (!df.meta[0]) return;
+    uint32_t *us = recoded + (uint64_t)p * sh.U * (bk_c ? BK_RWORDS : 8);
+    const sc28 *rho = df.meta[1] ? &df.slot[RP_DEFER_CAP] : nullptr;
+    for (uint32_t u = lane32; u < sh.U; u += 32) {
+        if (sh.a_outside && u == 0) continue;   // (wide chains add A after the Horner chain: nothing was parked for it)
+        const sc28 v = df.slot[u];
+        rp_emit_coeff(us, u, v, rho, bk_c, p * sh.U, sh.radix5 != 0);
+    }
+}
+
 // ---- stage 2: per-proof scalars -----------------------------------------------------------
 // thread p.  Writes the radix-16 recodings of the U per-proof coefficients (recoded[p][U][8], order of
 // rp_unique_point_ptr), the Montgomery-form tables for stage 3, and the digits of the B_blinding (row 0) and
@@ -684,7 +706,7 @@ BP_HD void rp_emit_coeff(uint32_t *us, uint32_t u, const sc28 &vm, const sc28 *r
 // multiplied by its weight rho_p = from_bytes_mod_order_wide(rho64[p]); the B_blinding / B coefficients go to
 // the ROW0 / ROW1 fields instead of `digits` (they are summed over the batch in the next launch).
 BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t lg_m, uint32_t *fields, uint32_t *recoded,
-                              fb_digit *digits, const uint32_t *status, const uint8_t *rho64 = nullptr, uint32_t bk_c = 0) {
+                              fb_digit *digits, const uint32_t *status, const uint8_t *rho64 = nullptr, uint32_t bk_c = 0, const rp_defer *df = nullptr) {
     if (status[p] != 0) return;   // digits/scalars of rejected proofs are never consumed (finish masks them)
     const uint32_t B = sh.nproofs, k = sh.k;
     const rp_fields fl = rp_field_layout(k, sh.m);
@@ -726,6 +748,15 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
     sc28 inv;
     sc28_invert_mont_safegcd(inv, acc);                   // (y * prod u_i)^-1
     uint32_t *us = recoded + (uint64_t)p * sh.U * (bk_c ? BK_RWORDS : 8);
+    if (df) {   // the coefficients are parked for the group's lanes (rp_emit_deferred)
+        df->meta[1] = rho ? 1u : 0u;
+        if (rho) df->slot[RP_DEFER_CAP] = rho_m;
+    }
+#define RP_EMIT(idx, val)                                                                 \
+    do {                                                                                  \
+        if (df) df->slot[(idx)] = (val);                                                  \
+        else rp_emit_coeff(us, (idx), (val), rho, bk_c, p * sh.U, sh.radix5 != 0);        \
+    } while (0)
     for (uint32_t ii = k; ii-- > 0;) {
         sc28 pre, uim, sq;
         rp_load28(pre, fields, B, fl.uinv_m + ii, p);
@@ -734,9 +765,9 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
         sc28_montmul(inv, inv, um);                       // drop u_ii from the running inverse
         rp_store28(fields, B, fl.uinv_m + ii, p, uim);
         sc28_montmul(sq, um, um);                         // u_i^2   -> L_i coefficient
-        rp_emit_coeff(us, 4 + ii, sq, rho, bk_c, p * sh.U, sh.radix5 != 0);
+        RP_EMIT(4 + ii, sq);
         sc28_montmul(sq, uim, uim);                       // u_i^-2  -> R_i coefficient
-        rp_emit_coeff(us, 4 + k + ii, sq, rho, bk_c, p * sh.U, sh.radix5 != 0);
+        RP_EMIT(4 + k + ii, sq);
     }
     // what is left in inv is y^-1: table of y^-(2^b)
     {
@@ -797,17 +828,17 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
     if (!sh.a_outside) {   // (wide chains add A, coefficient 1, after the Horner chain)
         sc28 one_m;
         sc28_one_mont(one_m);
-        rp_emit_coeff(us, 0, one_m, rho, bk_c, p * sh.U, sh.radix5 != 0);
+        RP_EMIT(0, one_m);
     }
-    rp_emit_coeff(us, 1, xm, rho, bk_c, p * sh.U, sh.radix5 != 0);
-    rp_emit_coeff(us, 2, cxm, rho, bk_c, p * sh.U, sh.radix5 != 0);
-    rp_emit_coeff(us, 3, cxxm, rho, bk_c, p * sh.U, sh.radix5 != 0);
+    RP_EMIT(1, xm);
+    RP_EMIT(2, cxm);
+    RP_EMIT(3, cxxm);
     // V_j coefficients c z^2 z^j, and the z^2 z^j table
     {
         sc28 czzj, zzj = zzm;
         sc28_montmul(czzj, cm, zzm);
         for (uint32_t j = 0; j < sh.m; j++) {
-            rp_emit_coeff(us, 4 + 2 * k + j, czzj, rho, bk_c, p * sh.U, sh.radix5 != 0);
+            RP_EMIT(4 + 2 * k + j, czzj);
             if (rho) {
                 sc28 t;
                 sc28_montmul(t, zzj, rho_m);
@@ -881,6 +912,8 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
             fb_recode(digits + ((uint64_t)1 * prm.nwin) * B + p, B, t0.v, prm);
         }
     }
+#undef RP_EMIT
+    if (df) df->meta[0] = 1;   // every coefficient is parked
 }
 
 // ---- stage 3: per-(generator, proof) scalars -------------------------------------------------

@@ -383,6 +383,8 @@ void h_set_radix5(int on) { g_radix5 = on; }
 void h_set_a_outside(int on) { g_a_outside = on; }
 // coalesced launches (rp_seg, bpgpu_pool_*): when set, h_rp_verify reads its inputs through a segment table whose
 // items live in separate buffers (every second one without rng bytes of its own) and reports through it
+static int g_defer_emit = 0;
+void h_set_defer_emit(int on) { g_defer_emit = on; }
 static std::vector<uint32_t> g_seg_sizes;
 void h_set_segments(uint32_t count, const uint32_t *sizes) { g_seg_sizes.assign(sizes, sizes + count); }
 // ... and item i verifies under label i mod count (labels of ONE length: they share every transcript position, rp_seg::init_w)
@@ -507,6 +509,13 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
     for (uint32_t p = 0; p < nbatch; p++) {
         uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;
         rp_transcript_thread(p, sh, init, st, rp_resolve(p, sh, proofs_l1, coms_l1, rng64, segtab), fields.data(), status.data());
+        if (g_defer_emit && sh.U <= RP_DEFER_CAP) {   // the narrow chain's form: the leader parks the coefficients, 32 lanes recode them (rp_defer)
+            std::vector<sc28> slots(RP_DEFER_CAP + 1);
+            uint32_t meta[2] = {0, 0};
+            rp_defer df; df.slot = slots.data(); df.meta = meta;
+            rp_expand_a_thread(p, sh, prm, lg_m, fields.data(), rec.data(), digits.data(), status.data(), weights64, 0, &df);
+            for (uint32_t lane = 0; lane < 32; lane++) rp_emit_deferred(lane, p, sh, rec.data(), df, 0);
+        } else
         rp_expand_a_thread(p, sh, prm, lg_m, fields.data(), rec.data(), digits.data(), status.data(), weights64);
     }
     for (uint32_t t = 0; t < t0; t++) rp_points_thread(t, sh, rp_resolve(t / sh.U, sh, proofs_l1, coms_l1, nullptr, segtab), tab.data(), status.data());

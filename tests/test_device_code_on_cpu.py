@@ -334,12 +334,16 @@ def test_shared_generator_pipeline_lane_by_lane(H, oracle, W, nsplit):
     assert vd.raw[0] == 0 and out.raw[:32] == bytes(32)
 
 
-@pytest.mark.parametrize("horner_lanes", [1, 4, 64, "radix32", "radix32+a_outside", "a_outside"])
+@pytest.mark.parametrize("horner_lanes", [1, 4, 64, "radix32", "radix32+a_outside", "a_outside", "64+defer_emit"])
 def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, golden, horner_lanes):
     """rp_transcript -> rp_expand_a/b -> vb_* / fb_* -> finish, emulated lane by lane, on the reference's
     golden proofs (small shapes; the GPU tests cover all 16) plus tampered copies.  The Horner layouts:
     1 lane per chain (msm_vb.h), 4 (horner_quad.h), 64 (horner_wave.h); the wide chains' forms (one-lane chain): "radix32" -- the proofs'
     own points in signed radix 32 (16-entry tables, 51 windows); "a_outside" -- A, whose coefficient is 1, added after the chain."""
+    defer = horner_lanes == "64+defer_emit"     # the narrow chain's form: the scalar role's coefficients parked by the leader, recoded by 32 lanes (rp_defer)
+    H.h_set_defer_emit(1 if defer else 0)
+    if defer:
+        horner_lanes = 64
     wide = isinstance(horner_lanes, str)
     H.h_set_radix5(1 if wide and "radix32" in horner_lanes else 0)
     H.h_set_a_outside(1 if wide and "a_outside" in horner_lanes else 0)
@@ -380,6 +384,7 @@ def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, gol
     assert list(vd.raw) == [2, 1, 1, 0]
     H.h_set_radix5(0)
     H.h_set_a_outside(0)
+    H.h_set_defer_emit(0)
 
 
 def test_radix32_recoding_reconstructs_the_scalar(H):
@@ -627,8 +632,10 @@ def _rlc_expected(oracle, gg, n, m, label, proofs, plen, coms, rng, wts):
     return included, enc
 
 
-def test_batch_combination_pipeline_lane_by_lane(H, oracle, golden):
+@pytest.mark.parametrize("defer", [0, 1])
+def test_batch_combination_pipeline_lane_by_lane(H, oracle, golden, defer):
     """rlc.h: limb accumulator, and the combined pipeline R = sum rho_i MegaCheck_i against one oracle MSM."""
+    H.h_set_defer_emit(defer)          # (1: the weighted coefficients are parked by the leader and recoded by the group's lanes, rp_defer)
     L = T.L
     random.seed(11)
     for vals in ([1], [L - 1] * 3, [random.randrange(L) for _ in range(1000)], [L - 1] * 5000):
@@ -665,6 +672,7 @@ def test_batch_combination_pipeline_lane_by_lane(H, oracle, golden):
             else:
                 assert included == [True, True, False, False, True] and bo.raw[0] == 1 and enc != bytes(32)
                 assert list(vd.raw) == [5, 5, 2, 1, 5]
+    H.h_set_defer_emit(0)
 
 
 def test_device_expanded_randomness_lane_by_lane(H, oracle, golden):
