@@ -406,3 +406,42 @@ def test_vector_backend_equals_scalar_backend(oracle, golden):
             out = C.create_string_buffer(32)
             rc_n = N.oracle_verify(gn, bytes(q), len(q), vc[:32 * m], m, n, label, len(label), rng, out)
             assert rc_n == rc_s and out.raw == enc_s, (n, m, k)
+
+
+def test_verify_ts_early_exit_states_c_equals_twin(oracle, golden):
+    """The caller's `&mut Transcript` after an early `Err` of verify_multiple_with_rng: the C oracle (the checker of the GPU's handed-back
+    states, tests/test_gpu_transcript_stop.py) against the independent Python twin, whose Transcript object is mutated the way merlin's is --
+    an identity encoding at every one of the 4 + 2k validated points of every golden shape (validate_and_append_point returns before the
+    message, transcript.rs:75-87) and a proof checked against the wrong m (verification_scalars bails before the inner-product domain
+    separator, ipp.rs:203-211).  The twin needs no generators on these paths: it raises before it assembles the points."""
+    import bp_twin as T
+
+    class Caps:   # (capacity checks only: the error paths never reach the generators)
+        gens_capacity, party_capacity = 64, 8
+
+    label, vc = golden["label"], golden["vc_bytes"]
+    gens = oracle.Gens(64, 8)
+    for case in golden["cases"]:
+        n, m = case["n"], case["m"]
+        pr = bytes.fromhex(case["proof"])
+        k = (n * m).bit_length() - 1
+        offs = [0, 32, 64, 96] + [224 + 32 * j for j in range(2 * k)]
+        st0 = oracle.transcript_append_message(oracle.transcript_new(label), b"ctx", b"bound before the proof")
+        seen = set()
+        for o in offs:
+            bad = pr[:o] + bytes(32) + pr[o + 32:]
+            rc, _, st1 = oracle.verify_ts(gens, bad, vc[:32 * m], n, st0, bytes(64))
+            t = T.Transcript(label)
+            t.append_message(b"ctx", b"bound before the proof")
+            with pytest.raises(T.VerificationError):
+                T.verification_msm_terms(T.RangeProof.from_bytes(bad), Caps, None, t, [vc[32 * j:32 * j + 32] for j in range(m)], n, 1)
+            assert rc == 1 and oracle.transcript_challenge_bytes(st1, b"chk", 32)[1] == t.challenge_bytes(b"chk", 32), (n, m, o)
+            seen.add(st1)
+        assert len(seen) == len(offs)
+        if m >= 2:   # n m/2 != 2^k
+            rc, _, st1 = oracle.verify_ts(gens, pr, vc[:32 * (m // 2)], n, st0, bytes(64))
+            t = T.Transcript(label)
+            t.append_message(b"ctx", b"bound before the proof")
+            with pytest.raises(T.VerificationError):
+                T.verification_msm_terms(T.RangeProof.from_bytes(pr), Caps, None, t, [vc[32 * j:32 * j + 32] for j in range(m // 2)], n, 1)
+            assert rc == 1 and st1 not in seen and oracle.transcript_challenge_bytes(st1, b"chk", 32)[1] == t.challenge_bytes(b"chk", 32), (n, m)
