@@ -33,6 +33,8 @@ extern "C" int bpgpu_pool_msm_batch(bpgpu_pool *, size_t, const uint32_t *, cons
 extern "C" int bpgpu_pool_ipp_verify(bpgpu_pool *, size_t, size_t, const uint8_t *, size_t, const uint8_t *, size_t, const uint8_t *, const uint8_t *, const uint8_t *,
                                      const uint8_t *, const uint8_t *, const uint8_t *, uint8_t *, uint8_t *);
 extern "C" int bpgpu_pool_trace_dump(bpgpu_pool *, const char *);
+extern "C" int bpgpu_internal_policy_seal(bpgpu_pool *, uint32_t, uint64_t, uint64_t, uint32_t, uint64_t, uint32_t);
+extern "C" int bpgpu_internal_policy_seal_cohort(bpgpu_pool *, uint32_t, uint64_t, uint64_t, uint32_t, uint64_t, uint32_t, uint32_t, uint64_t);
 
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -290,7 +292,7 @@ struct kinds {
 
 int main(int argc, char **argv) {
     if (argc < 2) {
-        fprintf(stderr, "usage: pool_host_test threads T B S | tickets T Q S | mixed T S | destroy T | flush\n");
+        fprintf(stderr, "usage: pool_host_test threads T B S | tickets T Q S | mixed T S | destroy T | flush | policy\n");
         return 2;
     }
     const std::string mode = argv[1];
@@ -484,6 +486,56 @@ int main(int argc, char **argv) {
         }
         printf("{\"mode\": \"destroy\", \"threads\": %d, \"rounds\": 6, \"items\": %llu, \"mismatches\": %llu}\n", T, (unsigned long long)g_done.load(),
                (unsigned long long)g_mismatch.load());
+    } else if (mode == "policy") {   // when a staging buffer leaves: both sealing policies row by row (plain host logic of pool.hip, default option values)
+        bpgpu_pool *pool = make_pool(1, 2);
+        uint64_t bad_rows = 0, rows = 0;
+        const uint64_t us = 1000;
+        auto regimes = [&](int want, uint32_t r, uint64_t age_us, uint64_t quiet_us, uint32_t inflight, uint64_t items, uint32_t n_free, const char *what) {
+            rows++;
+            if (bpgpu_internal_policy_seal(pool, r, age_us * us, quiet_us * us, inflight, items, n_free) != want) {
+                bad_rows++;
+                fprintf(stderr, "policy (regimes): %s\n", what);
+            }
+        };
+        auto cohort = [&](int want, uint32_t r, uint64_t age_us, uint64_t quiet_us, uint32_t inflight, uint64_t items, uint32_t n_free, uint32_t expected, uint64_t since_done_us,
+                          const char *what) {
+            rows++;
+            if (bpgpu_internal_policy_seal_cohort(pool, r, age_us * us, quiet_us * us, inflight, items, n_free, expected, since_done_us * us) != want) {
+                bad_rows++;
+                fprintf(stderr, "policy (cohorts): %s\n", what);
+            }
+        };
+        // ---- regimes (combine_quiet_us 20, combine_wait_us 100, combine_inflight 6, combine_wide_proofs 384, combine_inflight_wide 3, combine_hold_us 400, combine_max_age_us 1500)
+        regimes(0, 5, 10, 5, 0, 0, 12, "fresh arrivals keep a buffer open");
+        regimes(1, 5, 30, 25, 0, 0, 12, "nothing joined for the quiet period: leave");
+        regimes(1, 5, 120, 5, 0, 0, 12, "the first request has waited combine_wait_us: leave although requests still arrive");
+        regimes(0, 5, 120, 25, 6, 600, 5, "six narrow chains run: the buffer keeps filling");
+        regimes(1, 5, 120, 25, 5, 500, 6, "... five: it leaves");
+        regimes(0, 100, 120, 25, 3, 1500, 8, "three WIDE chains run (500 each): at most three");
+        regimes(0, 100, 120, 25, 2, 1000, 9, "two wide chains run: a quiet fragment smaller than half of what runs waits for company");
+        regimes(1, 250, 120, 25, 2, 1000, 9, "... half as wide as what runs: leaves");
+        regimes(1, 100, 450, 5, 2, 1000, 9, "... or after combine_hold_us");
+        regimes(0, 50, 200, 30, 2, 100, 1, "the last free buffer is not spent on a narrow chain while chains run");
+        regimes(1, 50, 1600, 0, 6, 3000, 1, "nothing waits longer than combine_max_age_us");
+        // ---- cohorts (combine_cohort_inflight 2, combine_regroup_us 60; the deadlines above; the safety net at 3 x combine_max_age_us)
+        cohort(1, 1, 3, 3, 0, 0, 12, 1, 8, "the lone caller the last chain released is back: leave at once, no quiet period");
+        cohort(0, 40, 12, 2, 0, 0, 12, 64, 15, "40 of the 64 callers just released are back, more arrive: wait");
+        cohort(1, 64, 20, 12, 0, 0, 12, 64, 25, "all 64 back and one poll without a newcomer: leave");
+        cohort(0, 64, 20, 2, 0, 0, 12, 64, 25, "all 64 back but requests still pour in: take them along");
+        cohort(0, 10, 40, 25, 0, 0, 12, 64, 30, "quiet, but the group that just finished is not back yet (regrouping)");
+        cohort(1, 10, 90, 25, 0, 0, 12, 64, 70, "... regroup time over: leave");
+        cohort(1, 10, 110, 2, 0, 0, 12, 64, 30, "... or combine_wait_us since the first arrival");
+        cohort(1, 10, 30, 25, 0, 0, 12, 0, 1000000, "no recent completion: the quiet rule alone");
+        cohort(0, 200, 300, 25, 2, 800, 9, 0, 1000000, "two chains run: the buffer fills until one ends");
+        cohort(0, 100, 200, 25, 1, 600, 10, 0, 1000000, "one chain of 600 runs: a quiet fragment of 100 waits for company");
+        cohort(1, 300, 200, 25, 1, 600, 10, 0, 1000000, "... half its width: leaves beside it");
+        cohort(1, 100, 450, 2, 1, 600, 10, 0, 1000000, "... or after combine_hold_us");
+        cohort(0, 50, 2000, 0, 2, 1000, 9, 0, 1000000, "with both slots busy even combine_max_age_us does not force a third chain");
+        cohort(1, 50, 4600, 0, 2, 1000, 9, 0, 1000000, "... the safety net at three times that does");
+        cohort(0, 50, 200, 30, 1, 100, 1, 50, 10, "the last free buffer is not spent while a chain runs");
+        printf("{\"mode\": \"policy\", \"items\": %llu, \"mismatches\": %llu, \"errors\": 0}\n", (unsigned long long)rows, (unsigned long long)bad_rows);
+        bpgpu_pool_destroy(pool);
+        return bad_rows ? 1 : 0;
     } else if (mode == "flush") {
         bpgpu_pool *pool = make_pool(1, 4);
         std::mt19937_64 g(5);

@@ -108,3 +108,11 @@ def test_every_publication_point_of_the_queue_held_open(built, point):
         p, d = run(os.path.join(built, "pool_host_test"), mode, env={"BP_TEST_DELAY": "%d:150" % point}, timeout=120)
         assert p.returncode == 0, (point, mode, p.stderr[-1500:])
         assert d["mismatches"] == 0 and d.get("errors", 0) == 0 and d["items"] > 0, (point, mode)
+
+
+def test_when_a_staging_buffer_leaves_both_policies_row_by_row(built):
+    """policy_seal (the two regimes) and policy_seal_cohort (cohorts), plain host logic of pool.hip, against twenty-six stated situations:
+    quiet / deadline / chains in flight / the throughput regime's "half of what runs" / the last free buffer / the safety net; a lone
+    caller that is back leaves at once, a group that is not all back is waited for, a fragment beside a wide chain waits for company."""
+    p, d = run(os.path.join(built, "pool_host_test"), ["policy"])
+    assert p.returncode == 0 and d["mismatches"] == 0 and d["items"] == 26, p.stderr[-2000:]
