@@ -89,7 +89,8 @@ struct bpgpu_ctx {
     uint64_t script_tick = 0;
     int coop_defer_emit = 1;                                        // narrow chains: the scalar role's U coefficient recodings on U lanes at once (rangeproof.h rp_defer): one blocking call
                                                                     // 0.528 / 0.528 / 0.533 -> 0.521 / 0.526 / 0.518 ms, 16 threads p50 0.64 -> 0.62 ms, 16 x 128 tickets 801 -> 819 k/s
-                                                                    // (profiles/r05/coop_defer_emit_ab.txt); 0: the leader recodes them one after the other
+                                                                    // (profiles/r05/coop_defer_emit_ab.txt; the kernel's duration for ONE proof is unchanged, 238 us: the gain is at several
+                                                                    // groups per launch); 0: the leader recodes them one after the other
     int transcript_coop = 1;                                        // chains of up to 256 proofs replay their transcripts 32 lanes per proof (keccak.h): one call of 1 / 8 / 64 / 256 proofs 0.62 -> 0.53 / 0.56 / 0.57 / 0.58 ms; 0: lane = proof everywhere
     int split_stage1 = 0;                                           // experiment: point decoding as its own launch on the second stream, compiled for 1 / 2 / 3 wavefronts per SIMD
     int msm_fork = 1;                                               // bpgpu_msm_batch_shared: the generator-table half on the second stream beside the per-MSM points (0: one stream -- with
