@@ -145,6 +145,9 @@ struct bpgpu_ctx {
     char *rpp_buf = nullptr;                 // working set of the batched range-proof prover
     size_t rpp_cap = 0;
     uint32_t bucket_min = 0;                 // terms per MSM from which the bucket path is taken (0 = BK_MIN_TERMS; huge = never)
+    int bucket_chain = 0;                    // option "bucket_chain": 0 = the fused chain (bucket2.h) where it applies, 1 = bucket.h's chain everywhere (A/B)
+    int bucket_lanes = 0;                    // option "bucket_lanes": lanes of a (MSM, window) workgroup of the fused chain (0 = by batch width; 64, 128, 256)
+    int walk_waves = 0;                      // option "fb_walk_waves": wavefronts the generator half of a fused chain is cut into (0 = 1024)
     // constant-time generator-table MSMs for the prover's secret-dependent commitments (msm_fixed.h fb_accum_ct_thread): their own
     // small-window table, built on first use
     bool prover_ct = false;
@@ -236,6 +239,18 @@ static hipEvent_t get_event(bpgpu_ctx *c) {
             (c)->pending.emplace_back(name, a_, b_);                                                        \
         } else {                                                                                            \
             hipLaunchKernelGGL(kern, dim3(grid), dim3(block), 0, s, __VA_ARGS__);                           \
+        }                                                                                                   \
+    } while (0)
+
+// the same with `shm` bytes of dynamic LDS
+#define LAUNCH_SHM(c, s, name, kern, grid, block, shm, ...)                                                 \
+    do {                                                                                                    \
+        if ((c)->prof) {                                                                                    \
+            hipEvent_t a_ = get_event(c), b_ = get_event(c);                                                \
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(block), shm, s, a_, b_, 0, __VA_ARGS__);           \
+            (c)->pending.emplace_back(name, a_, b_);                                                        \
+        } else {                                                                                            \
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(block), shm, s, __VA_ARGS__);                         \
         }                                                                                                   \
     } while (0)
 
@@ -524,6 +539,21 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
         c->bucket_min = (uint32_t)value;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "bucket_chain")) {
+        if (value < 0 || value > 1) return fail(c, BPGPU_ERR_INVALID_ARG, "bucket_chain must be 0 (fused chain where it applies) or 1 (bucket.h's chain)");
+        c->bucket_chain = (int)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "fb_walk_waves")) {
+        if (value < 0 || value > 65536) return fail(c, BPGPU_ERR_INVALID_ARG, "fb_walk_waves out of range");
+        c->walk_waves = (int)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "bucket_lanes")) {
+        if (value != 0 && value != 64 && value != 128 && value != 256) return fail(c, BPGPU_ERR_INVALID_ARG, "bucket_lanes must be 0 (auto), 64, 128 or 256");
+        c->bucket_lanes = (int)value;
+        return BPGPU_OK;
+    }
     return fail(c, BPGPU_ERR_INVALID_ARG, "unknown option %s", key);
 }
 
@@ -545,6 +575,9 @@ int bpgpu_ctx_get_option(bpgpu_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "transcript_script")) *value = c->no_script ? 0 : 1;
     else if (!strcmp(key, "prover_constant_time")) *value = c->prover_ct ? 1 : 0;
     else if (!strcmp(key, "bucket_min_terms")) *value = c->bucket_min ? c->bucket_min : BK_MIN_TERMS;
+    else if (!strcmp(key, "bucket_chain")) *value = c->bucket_chain;
+    else if (!strcmp(key, "bucket_lanes")) *value = c->bucket_lanes;
+    else if (!strcmp(key, "fb_walk_waves")) *value = c->walk_waves ? c->walk_waves : 1024;
     else if (!strcmp(key, "staging_residue")) {
         // test hook: non-zero bytes left in the persistent staging buffers (pinned block, device IO buffer, prover working sets,
         // arena) -- 0 after a prover entry point has returned (prover_exit)
@@ -1155,6 +1188,67 @@ static int enqueue_bucket_tail(bpgpu_ctx *c, hipStream_t s, bk_params prm, size_
     LAUNCH(c, s, "horner_wave", k_horner_wave, (uint32_t)nmsm, 64, d.colq16, d.hq);
     return BPGPU_OK;
 }
+// ---- the fused chain (bucket2.h): c = 8, every MSM of the batch <= BK2_MAX_TERMS terms ----------------------------------------
+static bool bucket2_applies(bpgpu_ctx *c, bk_params prm, size_t per_msm_max) { return c->bucket_chain == 0 && prm.c == BK2_C && per_msm_max <= BK2_MAX_TERMS; }
+static void plan_bucket2(arena_plan &ap, size_t nmsm, size_t total, size_t off[12]) {
+    const bk_params prm = bk_make(BK2_C);
+    off[0] = ap.add((nmsm + 1) * 4);
+    off[1] = ap.add(total * sizeof(fb_entry) + 16);
+    off[2] = ap.add((size_t)BK2_NWIN * total + 16);   // digits, window-major (bk_dev::rwords)
+    off[3] = off[4] = off[10] = off[11] = 0;          // no index lists, descriptors or global histograms
+    off[5] = ap.add(nmsm * prm.nwin * prm.half * sizeof(ge_ext));
+    off[6] = ap.add(nmsm * 64 * 128);
+    off[7] = ap.add(nmsm * sizeof(ge_ext));
+    off[8] = ap.add(nmsm * prm.nwin * bk_leaves(prm) * sizeof(ge_ext));
+    off[9] = ap.add(nmsm * prm.nwin * bk_leaves(prm) * sizeof(ge_ext));
+}
+static uint32_t bucket2_lanes(bpgpu_ctx *c, size_t nmsm) {
+    if (c->bucket_lanes) return (uint32_t)c->bucket_lanes;
+    // a wide batch fills the device with one wavefront per (MSM, window) and keeps the runs long (2 081 terms: 33 additions per
+    // lane, one head piece per lane); a lone MSM (32 workgroups in all) wants the shortest chain
+    return nmsm >= 8 ? 64u : (nmsm >= 2 ? 128u : 256u);
+}
+// decode + digits -> window workgroups (sort in LDS + bucket sums) -> window sums -> Horner chain; leaves the MSM sums in d.hq
+static int enqueue_bucket2(bpgpu_ctx *c, hipStream_t s, size_t nmsm, size_t total, size_t per_msm, const uint32_t *d_scalars, const uint32_t *d_points,
+                           uint32_t *d_status, bk_dev &d) {
+    const bk_params prm = bk_make(BK2_C);
+    const uint32_t nbw = (uint32_t)(nmsm * prm.nwin), tot32 = (uint32_t)total;
+    uint8_t *dig = (uint8_t *)d.rwords;
+    LAUNCH(c, s, "bk_prepare", k_bk2_prepare, (tot32 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, tot32, (uint32_t)nmsm, d.msm_first, d_scalars, d_points, d.pts, dig, d_status);
+    const uint32_t lanes = bucket2_lanes(c, nmsm);
+    const size_t shm = ((per_msm * 2 + 15) / 16) * 16;
+    const int xcd_map = (nmsm % 8) == 0 ? 1 : 0;
+    if (lanes == 64) LAUNCH_SHM(c, s, "bk_window", k_bk2_window<64>, nbw, 64, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
+    else if (lanes == 128) LAUNCH_SHM(c, s, "bk_window", k_bk2_window<128>, nbw, 128, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
+    else LAUNCH_SHM(c, s, "bk_window", k_bk2_window<256>, nbw, 256, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
+    const uint32_t nl = nbw * bk_leaves(prm);
+    LAUNCH(c, s, "bk_leaf", k_bk_leaf, (nl + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nl, prm, d.bsum, d.gS, d.gA);   // (the tree's upper level is the tail's first phase)
+    return BPGPU_OK;
+}
+// the generator half of a fused chain as ONE launch (msm_fixed.h: fb_walk_thread): partial sums -> partial[npart][nbatch]
+static uint32_t fb_walk_parts(bpgpu_ctx *c, size_t nbatch, uint32_t n_gen_terms) {
+    const uint32_t target = c->walk_waves ? (uint32_t)c->walk_waves : 1024u;
+    if (nbatch < 32) {   // lane = slice of one MSM's generator terms: workgroups of one wavefront
+        uint32_t nwg = (uint32_t)((target + nbatch - 1) / nbatch);
+        const uint32_t most = (n_gen_terms + 63) / 64;
+        if (nwg > most) nwg = most;
+        return nwg ? nwg : 1;
+    }
+    const uint32_t nblk_p = (uint32_t)((nbatch + 63) / 64);
+    uint32_t per = (uint32_t)(((uint64_t)n_gen_terms * nblk_p + target - 1) / target);   // generator terms per wavefront
+    if (per == 0) per = 1;
+    const uint32_t nslice = (n_gen_terms + per - 1) / per;
+    return (nslice + 3) / 4;
+}
+static void enqueue_fb_walk(bpgpu_ctx *c, hipStream_t s, fb_params prm, size_t nbatch, uint32_t n_gen_terms, uint32_t nwg, const uint32_t *d_gen_scalars, const uint32_t *d_ids,
+                            ge_ext *d_partial, uint32_t *d_status) {
+    if (nbatch < 32) {
+        LAUNCH(c, s, "fb_walk", k_fb_walk1, (uint32_t)(nwg * nbatch), 64, prm, (uint32_t)nbatch, nwg, n_gen_terms, d_gen_scalars, d_ids, (const fb_entry *)c->d_table, d_partial, d_status);
+    } else {
+        const uint32_t nblk_p = (uint32_t)((nbatch + 63) / 64);
+        LAUNCH(c, s, "fb_walk", k_fb_walk<4>, nwg * nblk_p, 256, prm, (uint32_t)nbatch, nblk_p, nwg, n_gen_terms, d_gen_scalars, d_ids, (const fb_entry *)c->d_table, d_partial, d_status);
+    }
+}
 static bool bucket_fits(size_t nmsm, size_t total, bk_params prm) {
     return (uint64_t)nmsm * prm.nwin * prm.half <= 0x7fffffffull && (uint64_t)total * prm.nwin <= 0x7fffffffull;
 }
@@ -1167,9 +1261,13 @@ static int msm_batch_dev_locked(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_t
         for (size_t b = 0; b < nbatch; b++) total += n_terms[b];
         const bk_params prm = bk_make(pick_bucket_c(total / nbatch));
         if (total / nbatch >= (c->bucket_min ? c->bucket_min : BK_MIN_TERMS) && bucket_fits(nbatch, total, prm)) {
+            size_t per_msm = 0;
+            for (size_t b = 0; b < nbatch; b++) per_msm = n_terms[b] > per_msm ? n_terms[b] : per_msm;
+            const bool fused = bucket2_applies(c, prm, per_msm);
             arena_plan ap;
             size_t off[12];
-            plan_bucket(ap, nbatch, total, prm, off);
+            if (fused) plan_bucket2(ap, nbatch, total, off);
+            else plan_bucket(ap, nbatch, total, prm, off);
             const size_t off_status = ap.add(nbatch * 4);
             int rc = arena_reserve(c, ap.total);
             if (rc) return rc;
@@ -1179,14 +1277,21 @@ static int msm_batch_dev_locked(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_t
             HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
             rc = bucket_upload_first(c, s, nbatch, n_terms, 0, d);
             if (rc) return rc;
-            LAUNCH(c, s, "bk_prepare", k_bk_prepare, ((uint32_t)total + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, (uint32_t)total, (uint32_t)nbatch, d.msm_first,
-                   (const uint32_t *)d_scalars, (const uint32_t *)d_points, d.pts, d.rwords, d_status, prm);
-            size_t per_msm = 0;
-            for (size_t b = 0; b < nbatch; b++) per_msm = n_terms[b] > per_msm ? n_terms[b] : per_msm;
-            rc = enqueue_bucket_tail(c, s, prm, nbatch, total, per_msm, d);
+            if (fused) {
+                rc = enqueue_bucket2(c, s, nbatch, total, per_msm, (const uint32_t *)d_scalars, (const uint32_t *)d_points, d_status, d);
+            } else {
+                LAUNCH(c, s, "bk_prepare", k_bk_prepare, ((uint32_t)total + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, (uint32_t)total, (uint32_t)nbatch, d.msm_first,
+                       (const uint32_t *)d_scalars, (const uint32_t *)d_points, d.pts, d.rwords, d_status, prm);
+                rc = enqueue_bucket_tail(c, s, prm, nbatch, total, per_msm, d);
+            }
             if (rc) return rc;
-            LAUNCH(c, s, "vb_horner", k_vb_horner, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d.hq, d_status, (uint32_t *)d_out);
-            LAUNCH(c, s, "status_bytes", k_status_bytes, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d_status, (uint8_t *)d_status_bytes);
+            if (fused) {
+                LAUNCH(c, s, "msm_tail", k_msm_tail, (uint32_t)nbatch, 64, (uint32_t)nbatch, 1, (const ge_ext *)d.gS, (const ge_ext *)d.gA, 0u, (const ge_ext *)nullptr,
+                       (const uint32_t *)d_status, (uint32_t *)d_out, (uint8_t *)nullptr, (uint8_t *)d_status_bytes);
+            } else {
+                LAUNCH(c, s, "vb_horner", k_vb_horner, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d.hq, d_status, (uint32_t *)d_out);
+                LAUNCH(c, s, "status_bytes", k_status_bytes, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d_status, (uint8_t *)d_status_bytes);
+            }
             HIPCHK(c, hipGetLastError());
             return BPGPU_OK;
         }
@@ -1341,9 +1446,38 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
     const bool use_bucket = n_unique >= (c->bucket_min ? c->bucket_min : BK_MIN_TERMS) && bucket_fits(nbatch, nbatch * n_unique, bkp);
     arena_plan ap;
     size_t off[7], boff[12];
-    if (use_bucket) plan_bucket(ap, nbatch, nbatch * n_unique, bkp, boff);
+    const bool fused = use_bucket && !ct && bucket2_applies(c, bkp, n_unique);
+    if (fused) plan_bucket2(ap, nbatch, nbatch * n_unique, boff);
+    else if (use_bucket) plan_bucket(ap, nbatch, nbatch * n_unique, bkp, boff);
     else plan_vb_uniform(ap, nbatch, n_unique, off);
     const size_t off_status = ap.add(nbatch * 4);
+    if (fused) {   // the fused chain: generator half = one launch, tail = one launch (bucket2.h)
+        const uint32_t nwg = fb_walk_parts(c, nbatch, n_gen_terms);
+        const size_t off_part = ap.add((size_t)nwg * nbatch * sizeof(ge_ext) + 16);
+        rc = arena_reserve(c, ap.total);
+        if (rc) return rc;
+        uint32_t *d_status = (uint32_t *)(c->arena + off_status);
+        ge_ext *d_part = (ge_ext *)(c->arena + off_part);
+        HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
+        hipStream_t s2 = c->msm_fork ? c->stream2 : s;
+        if (s2 != s) {
+            HIPCHK(c, hipEventRecord(c->fork_ev, s));
+            HIPCHK(c, hipStreamWaitEvent(s2, c->fork_ev, 0));
+        }
+        enqueue_fb_walk(c, s2, prm, nbatch, n_gen_terms, nwg, (const uint32_t *)d_gen_scalars, d_ids, d_part, d_status);
+        if (s2 != s) HIPCHK(c, hipEventRecord(c->join_ev, s2));
+        bk_dev bd;
+        bucket_bind(c, boff, bd);
+        rc = bucket_upload_first(c, s, nbatch, nullptr, n_unique, bd);
+        if (rc) return rc;
+        rc = enqueue_bucket2(c, s, nbatch, nbatch * n_unique, n_unique, (const uint32_t *)d_uniq_scalars, (const uint32_t *)d_uniq_points, d_status, bd);
+        if (rc) return rc;
+        if (s2 != s) HIPCHK(c, hipStreamWaitEvent(s, c->join_ev, 0));
+        LAUNCH(c, s, "msm_tail", k_msm_tail, (uint32_t)nbatch, 64, (uint32_t)nbatch, 1, (const ge_ext *)bd.gS, (const ge_ext *)bd.gA, nwg, (const ge_ext *)d_part,
+               (const uint32_t *)d_status, (uint32_t *)d_out, (uint8_t *)d_verdict, (uint8_t *)d_status_bytes);
+        HIPCHK(c, hipGetLastError());
+        return BPGPU_OK;
+    }
     const size_t off_digits = ap.add((size_t)npairs * nbatch * sizeof(fb_digit) + 16);
     const size_t off_partial = ap.add((size_t)2 * nsplit * nbatch * sizeof(ge_ext) + 16);
     rc = arena_reserve(c, ap.total);
@@ -1381,7 +1515,7 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
         bucket_bind(c, boff, bd);
         rc = bucket_upload_first(c, s, nbatch, nullptr, n_unique, bd);
         if (rc) return rc;
-        const uint32_t total = (uint32_t)(nbatch * n_unique);
+        const uint32_t total = (uint32_t)(nbatch * n_unique);   // (the fused chain left above: this is bucket.h's)
         LAUNCH(c, s, "bk_prepare", k_bk_prepare, (total + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, total, (uint32_t)nbatch, bd.msm_first,
                (const uint32_t *)d_uniq_scalars, (const uint32_t *)d_uniq_points, bd.pts, bd.rwords, d_status, bkp);
         rc = enqueue_bucket_tail(c, s, bkp, nbatch, total, n_unique, bd);

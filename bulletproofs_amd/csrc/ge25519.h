@@ -256,6 +256,101 @@ BP_HD bool ristretto_decompress(ge_ext &r, const uint32_t w[8]) {
     return canonical && !s_neg && ok && !fe_isneg(r.T) && !fe_iszero(r.Y);
 }
 
+// ---- the same decode with a short register footprint -------------------------------------------------------------------
+// ristretto_decompress keeps s, u1, u2, v (and the square-root helper's u, v, v^3) alive across the 252-squaring chain: with the
+// multiplication's own working set that is ~320 VGPRs, ONE wavefront per SIMD, and a decode launch of 2 081 wavefronts ran three
+// rounds of a latency-bound chain (k_bk_prepare alone: 327 us for 64 x 2 081 points, 130 us for 2 081; profiles/r06).  Here only
+// t = v u2^2 crosses the chain; afterwards the 32 input bytes are read AGAIN and s, u1, u2, v are formed a second time (five field
+// operations of ~275).  BP_OPAQUE ties the second read to the chain's result so that the compiler can neither reuse the first
+// computation nor hoist the second one above the chain.  Same result as ristretto_decompress, bit for bit (the CPU harness compares).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define BP_OPAQUE2(a, b) asm volatile("" : "+v"(a), "+v"(b))
+#else
+#define BP_OPAQUE2(a, b) ((void)0)
+#endif
+// I = 1 / sqrt(t) (or 1 / sqrt(i t)), non-negative; false when t is not a square (RFC 9496 SQRT_RATIO_M1 with u = 1)
+BP_HD bool fe_invsqrt_i(fe &I, const fe &t) {
+    const fe sqrt_m1 = BP_FE_SQRT_M1;
+    fe r;
+    {
+        fe v3, v7;
+        fe_sq(v3, t);
+        fe_mul(v3, v3, t);
+        fe_sq(v7, v3);
+        fe_mul(v7, v7, t);
+        fe_pow22523(r, v7);
+        fe_sq(v3, t);          // (formed again: v^3 does not ride through the chain)
+        fe_mul(v3, v3, t);
+        fe_mul(r, r, v3);
+    }
+    fe check, one, m1, mi;
+    fe_sq(check, r);
+    fe_mul(check, check, t);
+    fe_1(one);
+    fe_neg(m1, one);
+    fe_neg(mi, sqrt_m1);
+    const bool correct = fe_eq(check, one);
+    const bool flipped = fe_eq(check, m1);
+    const bool flipped_i = fe_eq(check, mi);
+    fe ri;
+    fe_mul(ri, r, sqrt_m1);
+    fe_select(r, r, ri, flipped || flipped_i);
+    fe_abs(r);
+    I = r;
+    return correct || flipped;
+}
+// s, u1 = 1 - s^2, u2 = 1 + s^2, v = -d u1^2 - u2^2 from the encoding's words
+BP_HD void ristretto_decode_front(fe &s, fe &u1, fe &u2, fe &v, const uint32_t w[8]) {
+    const fe d = BP_FE_D;
+    fe one, ss, u2s, t;
+    fe_1(one);
+    fe_from_words(s, w);
+    fe_sq(ss, s);
+    fe_sub(u1, one, ss);
+    fe_add(u2, one, ss);
+    fe_sq(u2s, u2);
+    fe_sq(t, u1);
+    fe_mul(t, t, d);
+    fe_neg(t, t);
+    fe_sub(v, t, u2s);
+}
+BP_HD bool ristretto_decompress_lp(ge_ext &r, const uint32_t *src /*8 words, read twice*/) {
+    fe tin;
+    bool canonical = true, s_neg;
+    {
+        uint32_t w[8], chk[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) w[i] = src[i];
+        fe s, u1, u2, v, u2s;
+        ristretto_decode_front(s, u1, u2, v, w);
+        fe_to_words(chk, s);
+#pragma unroll
+        for (int i = 0; i < 8; i++) canonical = canonical && (chk[i] == w[i]);
+        s_neg = w[0] & 1;
+        fe_sq(u2s, u2);
+        fe_mul(tin, v, u2s);
+    }
+    fe I;
+    const bool ok = fe_invsqrt_i(I, tin);
+    uint32_t w[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) w[i] = src[i];
+#pragma unroll
+    for (int i = 0; i < 8; i++) BP_OPAQUE2(w[i], I.v[0]);
+    fe s, u1, u2, v, Dx, Dy, t;
+    ristretto_decode_front(s, u1, u2, v, w);
+    fe_mul(Dx, I, u2);
+    fe_mul(Dy, I, Dx);
+    fe_mul(Dy, Dy, v);
+    fe_add(t, s, s);
+    fe_mul(r.X, t, Dx);
+    fe_abs(r.X);
+    fe_mul(r.Y, u1, Dy);
+    fe_1(r.Z);
+    fe_mul(r.T, r.X, r.Y);
+    return canonical && !s_neg && ok && !fe_isneg(r.T) && !fe_iszero(r.Y);
+}
+
 BP_HD void ristretto_compress(uint32_t out[8], const ge_ext &p) {
     const fe sqrt_m1 = BP_FE_SQRT_M1, invsqrt_a_minus_d = BP_FE_INVSQRT_A_MINUS_D;
     fe one, u1, u2, t, I, i1, i2, zinv, den, X, Y, a, b;
@@ -267,6 +362,57 @@ BP_HD void ristretto_compress(uint32_t out[8], const ge_ext &p) {
     fe_sq(t, u2);
     fe_mul(t, t, u1);
     fe_sqrt_ratio_i(I, one, t);
+    fe_mul(i1, I, u1);
+    fe_mul(i2, I, u2);
+    fe_mul(zinv, i1, i2);
+    fe_mul(zinv, zinv, p.T);
+    fe_mul(t, p.T, zinv);
+    const bool rotate = fe_isneg(t);
+    fe xr, yr, dr;
+    fe_mul(xr, p.Y, sqrt_m1);
+    fe_mul(yr, p.X, sqrt_m1);
+    fe_mul(dr, i1, invsqrt_a_minus_d);
+    fe_select(X, p.X, xr, rotate);
+    fe_select(Y, p.Y, yr, rotate);
+    fe_select(den, i2, dr, rotate);
+    fe_mul(t, X, zinv);
+    fe_cneg(Y, fe_isneg(t));
+    fe_sub(t, p.Z, Y);
+    fe_mul(t, t, den);
+    fe_abs(t);
+    fe_to_words(out, t);
+}
+
+// ristretto_compress with the short register footprint (see ristretto_decompress_lp): only t = u1 u2^2 crosses the squaring chain, the
+// point is read AGAIN from `src` afterwards (LDS or global memory) and u1, u2 are formed a second time.
+BP_HD void ristretto_compress_lp(uint32_t out[8], const ge_ext *src) {
+    const fe sqrt_m1 = BP_FE_SQRT_M1, invsqrt_a_minus_d = BP_FE_INVSQRT_A_MINUS_D;
+    fe tin;
+    {
+        const ge_ext p = *src;
+        fe u1, u2, a, b, t;
+        fe_add(a, p.Z, p.Y);
+        fe_sub(b, p.Z, p.Y);
+        fe_mul(u1, a, b);
+        fe_mul(u2, p.X, p.Y);
+        fe_sq(t, u2);
+        fe_mul(tin, t, u1);
+    }
+    fe I;
+    fe_invsqrt_i(I, tin);
+    ge_ext p = *src;
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        BP_OPAQUE2(p.X.v[i], I.v[0]);
+        BP_OPAQUE2(p.Y.v[i], I.v[0]);
+        BP_OPAQUE2(p.Z.v[i], I.v[0]);
+        BP_OPAQUE2(p.T.v[i], I.v[0]);
+    }
+    fe u1, u2, t, i1, i2, zinv, den, X, Y, a, b;
+    fe_add(a, p.Z, p.Y);
+    fe_sub(b, p.Z, p.Y);
+    fe_mul(u1, a, b);
+    fe_mul(u2, p.X, p.Y);
     fe_mul(i1, I, u1);
     fe_mul(i2, I, u2);
     fe_mul(zinv, i1, i2);

@@ -128,6 +128,22 @@ WV_FN wu32 hw_horner(const wv_ctx &cx, const uint16_t *colq16) {
     return c;
 }
 
+// The same chain over 32 window sums of 8 bits (the fused bucket chain, bucket2.h): colq8[w][4][16] u16 limbs, eight doublings
+// between additions -- 32 additions instead of the 64 of the radix-16 form, half of which added the identity.
+WV_FN wu32 hw_horner8(const wv_ctx &cx, const uint16_t *colq8) {
+    const wu32 lane = wv_lane();
+    const wu32 k = lane & 15u, row = lane >> 4;
+    wu32 c = wv_select((k == 0u) && (row == 1u || row == 2u), wv_splat(1), wv_splat(0));
+    for (int w = 31; w >= 0; w--) {
+        if (w != 31) {
+            for (int i = 0; i < 8; i++) c = hw_dbl(cx, c, row, k);
+        }
+        const wu32 q = wv_load_u16(colq8, lane + (uint32_t)(w * 64));
+        c = hw_add_cached(cx, c, q, row, k);
+    }
+    return c;
+}
+
 // one lane's 16 lazy limbs (<= 2^17) -> 10 x 25.5-bit field element (lazy, limb 0 may exceed 2^26 by 19+38*small)
 BP_HD void hw_limbs_to_fe(fe &out, const uint32_t l[16]) {
     uint32_t t[16], carry = 0;
@@ -161,6 +177,7 @@ BP_HD void hw_limbs_to_fe(fe &out, const uint32_t l[16]) {
 // runs the chain and writes the result as an extended point (4 field elements, lazy limbs).
 #if defined(__HIPCC__) && !defined(__HIP_DEVICE_COMPILE__)
 __device__ void hw_horner_msm(const uint16_t *colq16, ge_ext *out);   // host pass of hipcc: declarations only
+__device__ void hw_horner8_msm(const uint16_t *colq8, uint32_t *lds128, ge_ext *out);
 __device__ void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out);
 #elif defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void hw_horner_msm(const uint16_t *colq16, ge_ext *out) {
@@ -201,8 +218,35 @@ __device__ __forceinline__ void hw_colsum_horner_msm(uint32_t b, const uint32_t 
         ((fe *)out)[lane >> 4] = r;
     }
 }
+// the 8-bit-window chain: colq8 in LDS (or global memory), scratch `lds128` = 128 words of LDS owned by the wavefront
+__device__ __forceinline__ void hw_horner8_msm(const uint16_t *colq8, uint32_t *lds128, ge_ext *out) {
+    wv_ctx cx;
+    cx.lds = lds128;
+    const wu32 c = hw_horner8(cx, colq8);
+    const uint32_t lane = wv_lane();
+    uint32_t limbs[16];
+    wv_row_gather16(cx, c, limbs);
+    if ((lane & 15u) == 0) {
+        fe r;
+        hw_limbs_to_fe(r, limbs);
+        ((fe *)out)[lane >> 4] = r;
+    }
+}
 #else
 inline void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out);
+inline void hw_horner8_msm(const uint16_t *colq8, uint32_t *, ge_ext *out) {
+    wv_ctx cx{0};
+    const wu32 c = hw_horner8(cx, colq8);
+    wu32 limbs[16];
+    wv_row_gather16(cx, c, limbs);
+    for (int row = 0; row < 4; row++) {
+        uint32_t l[16];
+        for (int i = 0; i < 16; i++) l[i] = limbs[i].l[row * 16];
+        fe r;
+        hw_limbs_to_fe(r, l);
+        ((fe *)out)[row] = r;
+    }
+}
 inline void hw_horner_msm(const uint16_t *colq16, ge_ext *out) {
     wv_ctx cx{0};
     const wu32 c = hw_horner(cx, colq16);

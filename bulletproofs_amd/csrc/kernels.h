@@ -13,6 +13,7 @@
 #include "linear.h"
 #include "audit.h"
 #include "bucket.h"
+#include "bucket2.h"
 #include "ipp_prover.h"
 #include "rp_prover.h"
 #include "linear_prover.h"
@@ -99,6 +100,14 @@ __global__ void k_bk_heavy(bk_params prm, uint32_t total, const bk_desc *desc, c
 __global__ void k_bk_leaf(uint32_t nthreads, bk_params prm, const ge_ext *bsum, ge_ext *gS, ge_ext *gA);
 template <int C>
 __global__ void k_bk_tree(bk_params prm, uint32_t nbw, const ge_ext *gS, const ge_ext *gA, uint32_t *colq16);
+// k_bucket2.hip
+__global__ void k_bk2_prepare(uint32_t total, uint32_t nbatch, const uint32_t *msm_first, const uint32_t *scalars, const uint32_t *points, fb_entry *pts, uint8_t *dig, uint32_t *status);
+template <int LANES>
+__global__ void k_bk2_window(uint32_t nmsm, int xcd_map, const uint32_t *msm_first, uint32_t total, const uint8_t *dig, const fb_entry *pts, ge_ext *bsum);
+template <int WAVES>
+__global__ void k_fb_walk(fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nwg, uint32_t n_gen_terms, const uint32_t *gen_scalars, const uint32_t *gen_ids, const fb_entry *table, ge_ext *partial, uint32_t *status);
+__global__ void k_fb_walk1(fb_params prm, uint32_t nproofs, uint32_t nwg, uint32_t n_gen_terms, const uint32_t *gen_scalars, const uint32_t *gen_ids, const fb_entry *table, ge_ext *partial, uint32_t *status);
+__global__ void k_msm_tail(uint32_t nmsm, int have_bucket, const ge_ext *gS, const ge_ext *gA, uint32_t npart, const ge_ext *partial, const uint32_t *status, uint32_t *out_words, uint8_t *verdict, uint8_t *status_bytes);
 
 // k_linc.hip
 __global__ void k_linc_init(uint32_t nthreads, linc_shape sh, const uint8_t *a_in, const uint8_t *b_in, uint32_t *a, uint32_t *b, uint32_t *wG, uint32_t *status);

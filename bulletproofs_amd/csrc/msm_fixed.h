@@ -246,6 +246,93 @@ BP_HD void fb_accum_thread(uint32_t p, uint32_t split, uint32_t q0, uint32_t q1,
     partial[(uint64_t)split * nproofs + p] = acc;
 }
 
+// ---- the walk with the recoding folded in (round 6: bpgpu_msm_batch_shared's generator half as ONE launch) ----------------------------
+// fb_recode + fb_accum + three fb_reduce launches were five kernels for what is one pass over the scalars: the device runs only about four
+// kernels at a time whatever their width (profiles/r06/timeline_cfg5_16_before.txt: 4.05 in flight on average with 32 streams busy), so a
+// chain's throughput is set by the SUM of its kernels' durations, and the five cost 0.78 ms of a chain's 2.5.  Here a lane reads the
+// scalar of a generator term itself, recodes it in registers (no digit array: 295 kB written and read per 4 098-term MSM before) and
+// walks that generator's windows; a wavefront is one slice of the generator terms for 64 MSMs (lane = MSM, as in fb_accum_thread); the
+// wavefronts of a workgroup add their sums through LDS, so that a workgroup leaves ONE partial sum per MSM.
+//   lane (p, slice): generator terms [g0, g1) of MSM p;  gen_scalars [p][n_gen_terms][8 words]
+// The table line of window w+1 is requested while window w is added (the scalar of the next generator term is not requested ahead: the
+// eight registers it would hold through the walk cost the third wavefront per SIMD, whose work hides that load better).
+BP_HD void fb_walk_thread(ge_ext &acc, uint32_t p, uint32_t g0, uint32_t g1, fb_params prm, uint32_t n_gen_terms, const uint32_t *gen_scalars,
+                          const uint32_t *gen_ids, const fb_entry *table, uint32_t *status) {
+    ge_identity(acc);
+    if (g0 >= g1) return;
+    const fb_bias bias = fb_make_bias(prm);
+    const uint32_t W = prm.W, mask = (1u << W) - 1u;
+    const uint32_t *sp = gen_scalars + ((uint64_t)p * n_gen_terms + g0) * 8;
+    bool bad = false;
+    for (uint32_t g = g0; g < g1; g++) {
+        uint32_t r[10];
+        {
+            uint32_t s[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) s[i] = sp[8 * (uint64_t)(g - g0) + i];
+            bad = bad || !sc_is_canonical(s);
+            uint32_t carry = 0;
+#pragma unroll
+            for (int i = 0; i < 10; i++) {
+                const uint64_t t = (uint64_t)(i < 8 ? s[i] : 0u) + bias.k[i] + carry;
+                r[i] = (uint32_t)t;
+                carry = (uint32_t)(t >> 32);
+            }
+        }
+        const fb_entry *base = table + (uint64_t)gen_ids[g] * prm.nwin * prm.half;
+        uint32_t v = r[0] & mask;
+        fb_line line;
+        {
+            const int d = (int)v - (int)prm.half;
+            const uint32_t a = (uint32_t)(d < 0 ? -d : d);
+            fb_load_line(line, base + (a ? a - 1 : 0));
+        }
+        for (uint32_t win = 0; win < prm.nwin; win++) {
+#pragma unroll
+            for (int i = 0; i < 9; i++) r[i] = (r[i] >> W) | (r[i + 1] << (32 - W));
+            r[9] >>= W;
+            const uint32_t vn = r[0] & mask;
+            fb_line next = line;
+            if (win + 1 < prm.nwin) {
+                const int d = (int)vn - (int)prm.half;
+                const uint32_t a = (uint32_t)(d < 0 ? -d : d);
+                fb_load_line(next, base + (uint64_t)(win + 1) * prm.half + (a ? a - 1 : 0));
+            }
+            fb_accum_step(acc, line, v, prm, false);
+            line = next;
+            v = vn;
+        }
+    }
+    if (bad) status_raise(status + p, BP_STATUS_BAD_SCALAR);
+}
+// slice s of nslice: generator terms [g0, g1)
+BP_HD void fb_walk_slice(uint32_t &g0, uint32_t &g1, uint32_t s, uint32_t nslice, uint32_t n_gen_terms) {
+    const uint32_t per = (n_gen_terms + nslice - 1) / nslice;
+    g0 = s * per < n_gen_terms ? s * per : n_gen_terms;
+    g1 = g0 + per < n_gen_terms ? g0 + per : n_gen_terms;
+}
+// the workgroup's wavefronts fold their sums: step `half` = waves/2 .. 1: wavefronts [half, 2 half) store, [0, half) add
+BP_HD void fb_walk_fold_store(uint32_t wave, uint32_t lane, uint32_t half, const ge_ext &acc, ge_ext *xch /*[waves/2][64]*/) {
+    if (wave >= half && wave < 2 * half) xch[(uint64_t)(wave - half) * 64 + lane] = acc;
+}
+BP_HD void fb_walk_fold_add(uint32_t wave, uint32_t lane, uint32_t half, ge_ext &acc, const ge_ext *xch) {
+    if (wave < half) {
+        const ge_ext q = xch[(uint64_t)wave * 64 + lane];
+        ge_add(acc, acc, q);
+    }
+}
+
+// ONE MSM (or a few): lane = slice of the generator terms, a wavefront's 64 sums are folded in six steps through LDS, the workgroup
+// leaves one partial sum.  (With lane = MSM a lone MSM used one lane of every wavefront: 148 us for its table walk.)
+BP_HD void fb_walk1_fold(uint32_t lane, uint32_t step, ge_ext &acc, ge_ext *xch /*[64]*/, bool store_phase) {
+    if (store_phase) {
+        if (lane >= step && lane < 2 * step) xch[lane - step] = acc;
+    } else if (lane < step) {
+        const ge_ext q = xch[lane];
+        ge_add(acc, acc, q);
+    }
+}
+
 // ---- constant-time variant (the prover's secret-dependent commitments) -----------------------------------------------
 // The reference computes V, A, S, T_1, T_2 with curve25519-dalek's constant-time multiscalar_mul (party.rs:99-124, 179-187,
 // generators.rs:39-41).  The variable-time walk above leaks a secret scalar's digits through table addresses and through the

@@ -15,6 +15,7 @@
 #include "../../bulletproofs_amd/csrc/scinv.h"
 #include "../../bulletproofs_amd/csrc/rlc.h"
 #include "../../bulletproofs_amd/csrc/bucket.h"
+#include "../../bulletproofs_amd/csrc/bucket2.h"
 #include "../../bulletproofs_amd/csrc/ipp_prover.h"
 #include "../../bulletproofs_amd/csrc/rp_prover.h"
 #include "../../bulletproofs_amd/csrc/linear_prover.h"
@@ -905,6 +906,102 @@ int h_msm_bucket(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalar
     for (uint32_t b = 0; b < nmsm; b++) hw_horner_msm((const uint16_t *)(colq16.data() + (size_t)b * 64 * 32), &hq[b]);
     for (uint32_t b = 0; b < nmsm; b++) vb_horner_thread(b, nullptr, hq.data(), single ? st1.data() : status.data(), outw.data(), nullptr);
     memcpy(out, outw.data(), (size_t)nmsm * 32);
+    for (uint32_t b = 0; b < nbatch; b++) status_out[b] = (uint8_t)status[b];
+    return 0;
+}
+
+// The fused bucket chain (bucket2.h; the same bodies as k_bucket2.hip), lane by lane and phase by phase: `lanes` lanes per (MSM, window)
+// workgroup (64, 128, 256 on the device; any value >= 1 here, so that runs of one entry per lane and buckets spread over many lanes are
+// reachable with small inputs).  stats (optional, 4 words): head pieces written, buckets owned across lanes, the longest chain of head
+// pieces one owner added, entries listed in all.
+int h_msm_bucket2(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, const uint8_t *points, uint32_t lanes, uint8_t *out, uint8_t *status_out,
+                  uint32_t *stats) {
+    const bk_params prm = bk_make(BK2_C);
+    std::vector<uint32_t> msm_first(nbatch + 1, 0);
+    for (uint32_t b = 0; b < nbatch; b++) {
+        if (n_terms[b] > BK2_MAX_TERMS) return -1;
+        msm_first[b + 1] = msm_first[b] + n_terms[b];
+    }
+    const uint32_t total = msm_first[nbatch], nbw = nbatch * prm.nwin;
+    std::vector<fb_entry> pts(total + 1);
+    std::vector<uint8_t> dig((size_t)BK2_NWIN * total + 1, 0xee);
+    std::vector<uint32_t> status(nbatch + 1, 0);
+    for (uint32_t t = 0; t < total; t++)
+        bk2_prepare_thread(t, total, nbatch, msm_first.data(), (const uint32_t *)scalars, (const uint32_t *)points, pts.data(), dig.data(), status.data());
+    // the short-register decode against the plain one, point by point
+    for (uint32_t t = 0; t < total; t++) {
+        ge_ext a, b2;
+        uint32_t pw[8];
+        memcpy(pw, points + 32 * (size_t)t, 32);
+        const bool oa = ristretto_decompress(a, pw), ob = ristretto_decompress_lp(b2, (const uint32_t *)(points + 32 * (size_t)t));
+        if (oa != ob || memcmp(&a, &b2, sizeof a)) return -2;
+    }
+    std::vector<ge_ext> bsum((size_t)nbw * prm.half);
+    memset((void *)bsum.data(), 0xee, bsum.size() * sizeof(ge_ext));
+    uint32_t st[4] = {0, 0, 0, 0};
+    std::vector<uint32_t> l_cnt(BK2_HALF), l_off(BK2_HALF + 1), l_tmp(BK2_HALF);
+    std::vector<uint16_t> l_list(BK2_MAX_TERMS);
+    std::vector<ge_ext> l_head(lanes);
+    std::vector<bk2_tail> tails(lanes);
+    for (uint32_t bw = 0; bw < nbw; bw++) {
+        const uint32_t b = bw / prm.nwin, w = bw - b * prm.nwin;
+        bk2_seg sg; sg.first = msm_first[b]; sg.count = msm_first[b + 1] - sg.first; sg.lanes = lanes; sg.dig_w = dig.data() + (size_t)w * total;
+        bk2_lds l; l.cnt = l_cnt.data(); l.off = l_off.data(); l.tmp = l_tmp.data(); l.list = l_list.data(); l.head = l_head.data();
+        std::fill(l_list.begin(), l_list.end(), (uint16_t)0xffff);
+        for (uint32_t lane = 0; lane < lanes; lane++) bk2_w0(lane, sg, l);
+        for (uint32_t lane = 0; lane < lanes; lane++) bk2_w1(lane, sg, l);
+        {
+            uint32_t *src = l.cnt, *dst = l.tmp;
+            for (uint32_t s = 1; s < BK2_HALF; s <<= 1) {
+                for (uint32_t lane = 0; lane < lanes; lane++) bk2_w2_step(lane, s, sg, src, dst);
+                std::swap(src, dst);
+            }
+        }
+        for (uint32_t lane = 0; lane < lanes; lane++) bk2_w2_fin(lane, sg, l);
+        for (uint32_t lane = 0; lane < lanes; lane++) bk2_w3(lane, sg, l);
+        // the list is a permutation of the window's non-zero digits, sorted by |digit|
+        const uint32_t n = l.off[BK2_HALF];
+        if (n > sg.count) return -3;
+        for (uint32_t j = 0; j < BK2_HALF; j++) {
+            if (l.off[j] > l.off[j + 1] || l.cnt[j] != l.off[j + 1]) return -4;
+            for (uint32_t pos = l.off[j]; pos < l.off[j + 1]; pos++) {
+                const uint32_t e = l.list[pos], i = e & 0x7fffu;
+                if (i >= sg.count) return -5;
+                const int d = (int)sg.dig_w[sg.first + i] - 128;
+                if ((uint32_t)(d < 0 ? -d : d) != j + 1 || (d < 0) != ((e >> 15) != 0)) return -6;
+            }
+        }
+        st[3] += n;
+        ge_ext *bsum_w = bsum.data() + (size_t)bw * prm.half;
+        for (uint32_t lane = 0; lane < lanes; lane++) memset((void *)&l_head[lane], 0xdd, sizeof(ge_ext));
+        for (uint32_t lane = 0; lane < lanes; lane++) bk2_w4(lane, sg, l, pts.data() + sg.first, bsum_w, tails[lane]);
+        const uint32_t q = bk2_q(n, lanes);
+        for (uint32_t lane = 0; lane < lanes; lane++) {
+            if (!tails[lane].owner) continue;
+            st[1]++;
+            uint32_t chain = 0;
+            for (uint32_t k = lane + 1; k < lanes && k * q < l.off[tails[lane].bucket + 1]; k++) chain++;
+            st[0] += chain;
+            st[2] = std::max(st[2], chain);
+        }
+        for (uint32_t lane = 0; lane < lanes; lane++) bk2_w5(lane, sg, l, bsum_w, tails[lane]);
+    }
+    if (stats) memcpy(stats, st, sizeof st);
+    std::vector<uint32_t> colq16((size_t)nbatch * 64 * 32 + 32, 0);
+    const uint32_t nl = bk_leaves(prm);
+    std::vector<ge_ext> gS((size_t)nbw * nl), gA((size_t)nbw * nl);
+    for (uint32_t tid = 0; tid < nbw * nl; tid++) bk_leaf_thread(tid, prm, bsum.data(), gS.data(), gA.data());
+    for (uint32_t bw = 0; bw < nbw; bw++) {
+        ge_ext S, A;
+        bk_combine(S, A, gS.data(), gA.data(), bw * 8, 8, 1, 16);
+        const uint32_t b = bw / prm.nwin, w = bw - b * prm.nwin;
+        bk_emit_columns(w, prm, A, colq16.data() + (size_t)b * 64 * 32);
+    }
+    std::vector<ge_ext> hq(nbatch + 1);
+    std::vector<uint32_t> outw((size_t)nbatch * 8 + 8);
+    for (uint32_t b = 0; b < nbatch; b++) hw_horner_msm((const uint16_t *)(colq16.data() + (size_t)b * 64 * 32), &hq[b]);
+    for (uint32_t b = 0; b < nbatch; b++) vb_horner_thread(b, nullptr, hq.data(), status.data(), outw.data(), nullptr);
+    memcpy(out, outw.data(), (size_t)nbatch * 32);
     for (uint32_t b = 0; b < nbatch; b++) status_out[b] = (uint8_t)status[b];
     return 0;
 }

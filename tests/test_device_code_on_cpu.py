@@ -268,6 +268,75 @@ def test_bucket_msm_pipeline_phase_by_phase(H, oracle, c):
     assert out.raw[:32] == oracle.msm(b"".join(s[32 * i:32 * i + 32] for i in keep), b"".join(p[32 * i:32 * i + 32] for i in keep))[1]
 
 
+@pytest.mark.parametrize("lanes", [1, 7, 64, 128, 256])
+def test_fused_bucket_chain_phase_by_phase(H, oracle, lanes):
+    """bucket2.h (round 6: digits as window-major bytes, sort into an LDS list, equal runs of list entries per lane whatever the bucket
+    populations are, head pieces combined by the lane that owns the bucket) with the kernels' own per-lane phase functions.  Every
+    stage is checked on the way (the short-register decode == the plain one, the list is the window's non-zero digits sorted by
+    magnitude) and the encodings against the oracle: ragged sizes incl. empty MSMs and MSMs with fewer terms than lanes, edge scalars,
+    repeated and negated points, an undecodable point, a non-canonical scalar.  lanes = 1 and 7 are not device widths: they make one
+    lane's run cross many buckets / buckets of a small input span several lanes."""
+    sizes = [0, 1, 2, 70, 300, 517]
+    S = P = b""
+    for k, n in enumerate(sizes):
+        S += b"".join(_sc(b"f%d-s%d" % (k, i)) for i in range(n))
+        P += b"".join(_pt(oracle, b"f%d-p%d" % (k, i % 40)) for i in range(n))
+    nt = (C.c_uint32 * len(sizes))(*sizes)
+    out, st, stats = C.create_string_buffer(32 * len(sizes)), C.create_string_buffer(len(sizes)), (C.c_uint32 * 4)()
+    assert H.h_msm_bucket2(len(sizes), nt, S, P, lanes, out, st, stats) == 0
+    off = 0
+    for k, n in enumerate(sizes):
+        assert st.raw[k] == 0 and out.raw[32 * k:32 * k + 32] == oracle.msm(S[off:off + 32 * n], P[off:off + 32 * n])[1], (lanes, k)
+        off += 32 * n
+    if lanes == 1:
+        assert stats[0] == 0 and stats[1] == 0                    # one lane: every bucket begins and ends inside its run
+    if lanes == 7:
+        assert stats[0] > 0 and stats[1] > 0                      # buckets do span lanes
+    sp = [0, 1, T.L - 1, 8, int("8" * 63, 16) % T.L, 2**252, 2**252 + 1, 128, 127, 255, T.L - 128, 129, 256, 2**248]
+    s = b"".join(x.to_bytes(32, "little") for x in sp)
+    p = b"".join(_pt(oracle, b"fsp%d" % (i % 3)) for i in range(len(sp)))
+    nt1 = (C.c_uint32 * 1)(len(sp))
+    assert H.h_msm_bucket2(1, nt1, s, p, lanes, out, st, None) == 0
+    assert out.raw[:32] == oracle.msm(s, p)[1] and st.raw[0] == 0
+    bad = bytearray(p)
+    bad[0] |= 1
+    H.h_msm_bucket2(1, nt1, s, bytes(bad), lanes, out, st, None)
+    assert st.raw[0] == 1 and out.raw[:32] == bytes(32)
+    s2 = bytearray(s)
+    s2[0:32] = T.L.to_bytes(32, "little")
+    H.h_msm_bucket2(1, nt1, bytes(s2), p, lanes, out, st, None)
+    assert st.raw[0] == 2
+
+
+@pytest.mark.parametrize("lanes", [8, 64])
+def test_fused_bucket_chain_crowded_buckets_spread_over_lanes(H, oracle, lanes):
+    """What bucket.h needed a heavy pass for: scalars that put many terms into one bucket of a window (all equal, all small, 128-bit
+    ones sharing their high windows, five values).  In the fused chain a crowded bucket is spread over the lanes like any other run of
+    list entries; the lane in which it begins adds the other lanes' head pieces.  Results == oracle, and the statistics say that the
+    long chains of head pieces were really walked (equal scalars: one bucket per middle window holds every term -- every other lane's
+    run is a head piece behind one owner)."""
+    def run(scal, pts):
+        n = len(scal) // 32
+        out, st, stats = C.create_string_buffer(32), C.create_string_buffer(1), (C.c_uint32 * 4)()
+        assert H.h_msm_bucket2(1, (C.c_uint32 * 1)(n), scal, pts, lanes, out, st, stats) == 0
+        assert st.raw[0] == 0 and out.raw == oracle.msm(scal, pts)[1]
+        return list(stats)
+    n = 400
+    pts = b"".join(_pt(oracle, b"hv-p%d" % (i % 57)) for i in range(n))
+    eq = _sc(b"hv-equal") * n
+    q = -(-n // lanes)
+    assert run(eq, pts)[2] == -(-n // q) - 1                  # every lane with entries but the first hands a head piece to the owner
+    small = b"".join((1 + (i % 3)).to_bytes(32, "little") for i in range(n))
+    assert run(small, pts)[2] >= 2
+    short = b"".join(int.from_bytes(_sc(b"hv-w%d" % i)[:16], "little").to_bytes(32, "little") for i in range(n))
+    run(short, pts)
+    many = b"".join(_sc(b"hv-m%d" % (i % 5)) for i in range(n))
+    assert run(many, pts)[2] >= 2
+    for m in (1, 2, lanes - 1, lanes, lanes + 1, 2 * lanes + 1):             # runs of zero, one, two entries per lane
+        run(_sc(b"hv-one") * m, pts[:32 * m])
+        run(b"".join(_sc(b"hv-r%d" % i) for i in range(m)), pts[:32 * m])
+
+
 @pytest.mark.parametrize("c", [8, 12])
 def test_bucket_msm_crowded_buckets_go_through_the_heavy_pass(H, oracle, c):
     """bucket.h stage 3b: a lane adds its whole bucket up to `lim` terms; of a more crowded one it adds lim - 32 and the rest goes
