@@ -147,6 +147,8 @@ struct bpgpu_ctx {
     uint32_t bucket_min = 0;                 // terms per MSM from which the bucket path is taken (0 = BK_MIN_TERMS; huge = never)
     int bucket_chain = 0;                    // option "bucket_chain": 0 = the fused chain (bucket2.h) where it applies, 1 = bucket.h's chain everywhere (A/B)
     int bucket_lanes = 0;                    // option "bucket_lanes": lanes of a (MSM, window) workgroup of the fused chain (0 = by batch width; 64, 128, 256)
+    int fast_tail = -1;                      // option "bucket_fast_tail" (A/B): -1 = by batch width, 0 / 1 = never / always the short-chain tail
+    int bucket_two = 0;                      // option "bucket_two_buffers" (A/B): the (MSM, window) workgroups of a wide batch alternate two point-record buffers
     int walk_waves = 0;                      // option "fb_walk_waves": wavefronts the generator half of a fused chain is cut into (0 = 1024)
     // constant-time generator-table MSMs for the prover's secret-dependent commitments (msm_fixed.h fb_accum_ct_thread): their own
     // small-window table, built on first use
@@ -544,6 +546,14 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
         c->bucket_chain = (int)value;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "bucket_fast_tail")) {
+        c->fast_tail = value < 0 ? -1 : (value != 0);
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "bucket_two_buffers")) {
+        c->bucket_two = value != 0;
+        return BPGPU_OK;
+    }
     if (!strcmp(key, "fb_walk_waves")) {
         if (value < 0 || value > 65536) return fail(c, BPGPU_ERR_INVALID_ARG, "fb_walk_waves out of range");
         c->walk_waves = (int)value;
@@ -577,6 +587,8 @@ int bpgpu_ctx_get_option(bpgpu_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "bucket_min_terms")) *value = c->bucket_min ? c->bucket_min : BK_MIN_TERMS;
     else if (!strcmp(key, "bucket_chain")) *value = c->bucket_chain;
     else if (!strcmp(key, "bucket_lanes")) *value = c->bucket_lanes;
+    else if (!strcmp(key, "bucket_two_buffers")) *value = c->bucket_two;
+    else if (!strcmp(key, "bucket_fast_tail")) *value = c->fast_tail;
     else if (!strcmp(key, "fb_walk_waves")) *value = c->walk_waves ? c->walk_waves : 1024;
     else if (!strcmp(key, "staging_residue")) {
         // test hook: non-zero bytes left in the persistent staging buffers (pinned block, device IO buffer, prover working sets,
@@ -1199,9 +1211,11 @@ static void plan_bucket2(arena_plan &ap, size_t nmsm, size_t total, size_t off[1
     off[5] = ap.add(nmsm * prm.nwin * prm.half * sizeof(ge_ext));
     off[6] = ap.add(nmsm * 64 * 128);
     off[7] = ap.add(nmsm * sizeof(ge_ext));
-    off[8] = ap.add(nmsm * prm.nwin * bk_leaves(prm) * sizeof(ge_ext));
-    off[9] = ap.add(nmsm * prm.nwin * bk_leaves(prm) * sizeof(ge_ext));
+    off[8] = ap.add(nmsm * prm.nwin * BK2_FAST_LEAVES * sizeof(ge_ext));   // (8 leaves per window in a wide batch, 32 in a narrow one)
+    off[9] = ap.add(nmsm * prm.nwin * BK2_FAST_LEAVES * sizeof(ge_ext));
 }
+// narrow chains end with the short-chain tail (bucket2.h: bk2_fast_v), wide batches with the one that executes fewer instructions
+static bool bucket2_fast_tail(bpgpu_ctx *c, size_t nmsm) { return c->fast_tail < 0 ? nmsm < BK2_FAST_MAX_MSMS : c->fast_tail != 0; }
 static uint32_t bucket2_lanes(bpgpu_ctx *c, size_t nmsm) {
     if (c->bucket_lanes) return (uint32_t)c->bucket_lanes;
     // a wide batch fills the device with one wavefront per (MSM, window) and keeps the runs long (2 081 terms: 33 additions per
@@ -1218,11 +1232,17 @@ static int enqueue_bucket2(bpgpu_ctx *c, hipStream_t s, size_t nmsm, size_t tota
     const uint32_t lanes = bucket2_lanes(c, nmsm);
     const size_t shm = ((per_msm * 2 + 15) / 16) * 16;
     const int xcd_map = (nmsm % 8) == 0 ? 1 : 0;
-    if (lanes == 64) LAUNCH_SHM(c, s, "bk_window", k_bk2_window<64>, nbw, 64, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
-    else if (lanes == 128) LAUNCH_SHM(c, s, "bk_window", k_bk2_window<128>, nbw, 128, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
-    else LAUNCH_SHM(c, s, "bk_window", k_bk2_window<256>, nbw, 256, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
-    const uint32_t nl = nbw * bk_leaves(prm);
-    LAUNCH(c, s, "bk_leaf", k_bk_leaf, (nl + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nl, prm, d.bsum, d.gS, d.gA);   // (the tree's upper level is the tail's first phase)
+    if (lanes == 64 && c->bucket_two) LAUNCH_SHM(c, s, "bk_window", (k_bk2_window<64, true>), nbw, 64, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
+    else if (lanes == 64) LAUNCH_SHM(c, s, "bk_window", (k_bk2_window<64, false>), nbw, 64, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
+    else if (lanes == 128) LAUNCH_SHM(c, s, "bk_window", (k_bk2_window<128, false>), nbw, 128, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
+    else LAUNCH_SHM(c, s, "bk_window", (k_bk2_window<256, false>), nbw, 256, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
+    if (bucket2_fast_tail(c, nmsm)) {
+        const uint32_t nl = nbw * BK2_FAST_LEAVES;
+        LAUNCH(c, s, "bk_leaf", k_bk2_leafv, (nl + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nl, (const ge_ext *)d.bsum, d.gA);
+    } else {
+        const uint32_t nl = nbw * bk_leaves(prm);
+        LAUNCH(c, s, "bk_leaf", k_bk_leaf, (nl + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nl, prm, d.bsum, d.gS, d.gA);   // (the tree's upper level is the tail's first phase)
+    }
     return BPGPU_OK;
 }
 // the generator half of a fused chain as ONE launch (msm_fixed.h: fb_walk_thread): partial sums -> partial[npart][nbatch]
@@ -1286,8 +1306,12 @@ static int msm_batch_dev_locked(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_t
             }
             if (rc) return rc;
             if (fused) {
-                LAUNCH(c, s, "msm_tail", k_msm_tail, (uint32_t)nbatch, 64, (uint32_t)nbatch, 1, (const ge_ext *)d.gS, (const ge_ext *)d.gA, 0u, (const ge_ext *)nullptr,
-                       (const uint32_t *)d_status, (uint32_t *)d_out, (uint8_t *)nullptr, (uint8_t *)d_status_bytes);
+                if (bucket2_fast_tail(c, nbatch))
+                    LAUNCH(c, s, "msm_tail", k_msm_tail_fast, (uint32_t)nbatch, 256, (uint32_t)nbatch, 1, (const ge_ext *)d.gA, 0u, (const ge_ext *)nullptr,
+                           (const uint32_t *)d_status, (uint32_t *)d_out, (uint8_t *)nullptr, (uint8_t *)d_status_bytes);
+                else
+                    LAUNCH(c, s, "msm_tail", k_msm_tail, (uint32_t)nbatch, 64, (uint32_t)nbatch, 1, (const ge_ext *)d.gS, (const ge_ext *)d.gA, 0u, (const ge_ext *)nullptr,
+                           (const uint32_t *)d_status, (uint32_t *)d_out, (uint8_t *)nullptr, (uint8_t *)d_status_bytes);
             } else {
                 LAUNCH(c, s, "vb_horner", k_vb_horner, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d.hq, d_status, (uint32_t *)d_out);
                 LAUNCH(c, s, "status_bytes", k_status_bytes, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d_status, (uint8_t *)d_status_bytes);
@@ -1473,8 +1497,12 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
         rc = enqueue_bucket2(c, s, nbatch, nbatch * n_unique, n_unique, (const uint32_t *)d_uniq_scalars, (const uint32_t *)d_uniq_points, d_status, bd);
         if (rc) return rc;
         if (s2 != s) HIPCHK(c, hipStreamWaitEvent(s, c->join_ev, 0));
-        LAUNCH(c, s, "msm_tail", k_msm_tail, (uint32_t)nbatch, 64, (uint32_t)nbatch, 1, (const ge_ext *)bd.gS, (const ge_ext *)bd.gA, nwg, (const ge_ext *)d_part,
-               (const uint32_t *)d_status, (uint32_t *)d_out, (uint8_t *)d_verdict, (uint8_t *)d_status_bytes);
+        if (bucket2_fast_tail(c, nbatch))
+            LAUNCH(c, s, "msm_tail", k_msm_tail_fast, (uint32_t)nbatch, 256, (uint32_t)nbatch, 1, (const ge_ext *)bd.gA, nwg, (const ge_ext *)d_part,
+                   (const uint32_t *)d_status, (uint32_t *)d_out, (uint8_t *)d_verdict, (uint8_t *)d_status_bytes);
+        else
+            LAUNCH(c, s, "msm_tail", k_msm_tail, (uint32_t)nbatch, 64, (uint32_t)nbatch, 1, (const ge_ext *)bd.gS, (const ge_ext *)bd.gA, nwg, (const ge_ext *)d_part,
+                   (const uint32_t *)d_status, (uint32_t *)d_out, (uint8_t *)d_verdict, (uint8_t *)d_status_bytes);
         HIPCHK(c, hipGetLastError());
         return BPGPU_OK;
     }

@@ -133,8 +133,24 @@ BP_HD void bk2_load_niels(ge_niels &nn, const fb_line &line) {
         nn.t2d.v[q] = line.w[20 + q];
     }
 }
+// one entry of a lane's run: close the bucket that ended before `pos` (its sum, or head piece, is complete), then add the entry
+BP_HD void bk2_w4_step(uint32_t lane, uint32_t pos, uint32_t &j, uint32_t &bend, bool &head_piece, ge_ext &acc, const fb_line &line, uint32_t e,
+                       const bk2_lds &l, ge_ext *bsum_w) {
+    if (pos >= bend) {
+        if (head_piece) l.head[lane] = acc;
+        else bsum_w[j] = acc;
+        head_piece = false;
+        ge_identity(acc);
+        do j++;
+        while (l.off[j + 1] <= pos);
+        bend = l.off[j + 1];
+    }
+    ge_niels nn;
+    bk2_load_niels(nn, line);
+    ge_madd(acc, acc, nn, (e >> 15) != 0);   // (also for the first entry of a piece: the formulas are complete)
+}
 // w4: the lane's run of q entries.  bsum_w: this (MSM, window)'s 128 bucket sums in global memory; pts_m: the MSM's point records
-BP_HD void bk2_w4(uint32_t lane, const bk2_seg &sg, const bk2_lds &l, const fb_entry *pts_m, ge_ext *bsum_w, bk2_tail &tl) {
+BP_HD void bk2_w4(uint32_t lane, const bk2_seg &sg, const bk2_lds &l, const fb_entry *pts_m, ge_ext *bsum_w, bk2_tail &tl, bool two_buffers = false) {
     // empty buckets: the identity
     for (uint32_t j = lane; j < BK2_HALF; j += sg.lanes) {
         if (l.off[j + 1] == l.off[j]) {
@@ -153,30 +169,42 @@ BP_HD void bk2_w4(uint32_t lane, const bk2_seg &sg, const bk2_lds &l, const fb_e
     bool head_piece = lo > l.off[j];   // the lane's first piece continues a bucket that began in an earlier lane
     ge_ext acc;
     ge_identity(acc);
-    uint32_t e_cur = l.list[lo];
-    fb_line line_cur;
-    fb_load_line(line_cur, pts_m + (e_cur & 0x7fffu));
-    for (uint32_t pos = lo; pos < hi; pos++) {
-        fb_line line_next = line_cur;
-        uint32_t e_next = 0;
-        if (pos + 1 < hi) {
-            e_next = l.list[pos + 1];
-            fb_load_line(line_next, pts_m + (e_next & 0x7fffu));
+    if (two_buffers) {
+        // two line buffers used alternately (as msm_fixed.h: fb_accum_thread): the record of entry pos+1 is requested into the buffer
+        // entry pos-1 has vacated, no register copies between trips
+        uint32_t e_a = l.list[lo], e_b = 0;
+        fb_line la, lb;
+        fb_load_line(la, pts_m + (e_a & 0x7fffu));
+        for (uint32_t pos = lo; pos < hi;) {
+            if (pos + 1 < hi) {
+                e_b = l.list[pos + 1];
+                fb_load_line(lb, pts_m + (e_b & 0x7fffu));
+            }
+            bk2_w4_step(lane, pos, j, bend, head_piece, acc, la, e_a, l, bsum_w);
+            if (++pos >= hi) break;
+            if (pos + 1 < hi) {
+                e_a = l.list[pos + 1];
+                fb_load_line(la, pts_m + (e_a & 0x7fffu));
+            }
+            bk2_w4_step(lane, pos, j, bend, head_piece, acc, lb, e_b, l, bsum_w);
+            ++pos;
         }
-        if (pos >= bend) {   // the bucket ended inside the run: its sum (or head piece) is complete
-            if (head_piece) l.head[lane] = acc;
-            else bsum_w[j] = acc;
-            head_piece = false;
-            ge_identity(acc);
-            do j++;
-            while (l.off[j + 1] <= pos);
-            bend = l.off[j + 1];
+    } else {
+        // one buffer + a copy per trip: 25 registers fewer (no spills under the three-wavefront cap), ~45 moves more per entry
+        uint32_t e_cur = l.list[lo];
+        fb_line line_cur;
+        fb_load_line(line_cur, pts_m + (e_cur & 0x7fffu));
+        for (uint32_t pos = lo; pos < hi; pos++) {
+            fb_line line_next = line_cur;
+            uint32_t e_next = 0;
+            if (pos + 1 < hi) {
+                e_next = l.list[pos + 1];
+                fb_load_line(line_next, pts_m + (e_next & 0x7fffu));
+            }
+            bk2_w4_step(lane, pos, j, bend, head_piece, acc, line_cur, e_cur, l, bsum_w);
+            line_cur = line_next;
+            e_cur = e_next;
         }
-        ge_niels nn;
-        bk2_load_niels(nn, line_cur);
-        ge_madd(acc, acc, nn, (e_cur >> 15) != 0);   // (also for the first entry of a piece: the formulas are complete)
-        line_cur = line_next;
-        e_cur = e_next;
     }
     // the last piece: bucket j, entries [max(lo, off[j]), hi)
     if (head_piece) {   // the whole run lies inside a bucket that began earlier
@@ -227,12 +255,22 @@ BP_HD void bk2_tail_t2(uint32_t lane, uint32_t b, uint32_t nmsm, uint32_t npart,
     }
     if (!have) ge_identity(acc);
 }
-// fin: the MSM's sum, parked in LDS (ristretto_compress_lp reads it twice)
-BP_HD void bk2_tail_t4(uint32_t b, ge_ext *fin, const uint32_t *status, uint32_t *out_words, uint8_t *verdict, uint8_t *status_bytes) {
+// fin: the MSM's sum, parked in LDS (the encoding reads it twice).  In three steps so that the 252-squaring chain in the middle can be run
+// by the whole wavefront (horner_wave.h: hw_invsqrt_raw_fe):  t4a (lane 0)  t = u1 u2^2 and its canonical limbs;  chain: raw = t^3 (t^7)^((p-5)/8);
+// t4b (lane 0)  the encoding from raw, the verdict, the status
+BP_HD void bk2_tail_t4a(const ge_ext *fin, fe *tin, uint32_t *tw /*[8]*/) {
+    fe t;
+    ristretto_compress_front(t, fin);
+    *tin = t;
+    fe_to_words(tw, t);
+}
+BP_HD void bk2_tail_t4b(uint32_t b, const ge_ext *fin, const fe *raw, const fe *tin, const uint32_t *status, uint32_t *out_words, uint8_t *verdict, uint8_t *status_bytes) {
     const uint32_t st = status[b];
     if (out_words) {
         uint32_t w[8];
-        ristretto_compress_lp(w, fin);
+        fe I;
+        fe_invsqrt_fix(I, *raw, *tin);
+        ristretto_compress_back(w, fin, I);
 #pragma unroll
         for (int i = 0; i < 8; i++) out_words[8 * (uint64_t)b + i] = st ? 0u : w[i];
     }
@@ -240,5 +278,49 @@ BP_HD void bk2_tail_t4(uint32_t b, ge_ext *fin, const uint32_t *status, uint32_t
     if (status_bytes) status_bytes[b] = (uint8_t)st;
 }
 
+// ---- the tail for narrow chains (fewer than BK2_FAST_MAX_MSMS MSMs): leaves of 4 buckets, workgroup = 256 lanes = MSM -----------------
+// One MSM's chain ended with 30 + 27 additions in sequence (a leaf's running sum over 16 buckets, then the eight leaves of a window
+// combined by one lane) before the Horner chain could start: 167 us of the 0.65 ms a lone 6 179-term MSM took.  With lanes to spare the
+// same sums are formed with short chains:
+//   leaf l (of 32 per window) = 4 buckets: the running sums S, A (6 additions), then  V = A + 4 l S  by double-and-add in the same lane
+//   (l < 32: 6 doublings + 6 additions, the same code in every lane) -- the window sum is the sum of its 32 V;
+//   lane (w, g) of the tail adds four V, the 8 lanes of a window add theirs with three wavefront shuffles (__shfl_down of the 40 words:
+//   no LDS, no barrier);  then wavefront 0 runs the Horner chain while wavefront 1 adds the generator half's partial sums (six shuffle steps).
+// (The leaf launch spreads its 1 024 lanes per MSM over many CUs; the first version formed V in the tail's workgroup, two wavefronts per
+// SIMD of ONE CU: 77 us for what is 50 here.)  A wide batch keeps bk_leaf_thread / bk2_tail_t1: a third of the instructions.
+#define BK2_FAST_LEAVES 32u
+#define BK2_FAST_MAX_MSMS 48u
+// tid = bw * 32 + l
+BP_HD void bk2_leafv_thread(uint32_t tid, const ge_ext *bsum, ge_ext *gV) {
+    const uint32_t bw = tid / BK2_FAST_LEAVES, l = tid % BK2_FAST_LEAVES, m = BK2_HALF / BK2_FAST_LEAVES;
+    const ge_ext *b = bsum + (uint64_t)bw * BK2_HALF + (uint64_t)l * m;
+    ge_ext run = b[m - 1], acc = run;
+    for (uint32_t i = m - 1; i-- > 0;) {
+        const ge_ext q = b[i];
+        ge_add(run, run, q);
+        ge_add(acc, acc, run);
+    }
+    ge_ext Y, T;
+    ge_identity(Y);
+#pragma unroll 1
+    for (uint32_t bit = 0; bit < 5; bit++) {
+        ge_add(T, Y, run);
+        ge_select(Y, Y, T, ((l >> bit) & 1u) != 0);
+        if (bit < 4) ge_dbl(run, run);
+    }
+    ge_dbl(Y, Y, false);
+    ge_dbl(Y, Y);
+    ge_add(acc, acc, Y);
+    gV[tid] = acc;
+}
+// lane (w, g), g < 8: the sum of V[4 g .. 4 g + 4) of window w of MSM b
+BP_HD void bk2_fast_v4(uint32_t w, uint32_t g, uint32_t b, const ge_ext *gV, ge_ext &V) {
+    const ge_ext *v = gV + ((uint64_t)b * BK2_NWIN + w) * BK2_FAST_LEAVES + 4 * g;
+    V = v[0];
+    for (uint32_t i = 1; i < 4; i++) {
+        const ge_ext q = v[i];
+        ge_add(V, V, q);
+    }
+}
 }  // namespace bp
 #endif

@@ -57,14 +57,14 @@ BP_HD void ge_add_cached(ge_ext &r, const ge_ext &p, const ge_cached &q, bool ne
     fe_select(qa, q.YmX, q.YpX, neg);
     fe_select(qb, q.YpX, q.YmX, neg);
     fe_add(ypx, p.Y, p.X);              // lazy
-    fe_sub(ymx, p.Y, p.X);
+    fe_sub_rr(ymx, p.Y, p.X);           // lazy (no carry chain: the coordinates of p are reduced)
     fe_mul(a, ymx, qa);
     fe_mul(b, ypx, qb);
     fe_mul(c, p.T, q.T2d);
     fe_mul(d, p.Z, q.Z);
     fe_add(d, d, d);                    // lazy (2x)
     fe e, f, g, h, dmc, dpc;
-    fe_sub(e, b, a);
+    fe_sub_rr(e, b, a);                 // lazy
     fe_add(h, b, a);                    // lazy (2x)
     fe_sub(dmc, d, c);
     fe_add(dpc, d, c);                  // lazy (3x)
@@ -87,14 +87,14 @@ BP_HD void ge_add_cached_front(ge_efgh &t, const ge_ext &p, const ge_cached &q, 
     fe_select(qa, q.YmX, q.YpX, neg);
     fe_select(qb, q.YpX, q.YmX, neg);
     fe_add(ypx, p.Y, p.X);              // lazy
-    fe_sub(ymx, p.Y, p.X);
+    fe_sub_rr(ymx, p.Y, p.X);           // lazy
     fe_mul(a, ymx, qa);
     fe_mul(b, ypx, qb);
     fe_mul(c, p.T, q.T2d);
     fe_mul(d, p.Z, q.Z);
     fe_add(d, d, d);                    // lazy (2x)
     fe dmc, dpc;
-    fe_sub(t.e, b, a);
+    fe_sub_rr(t.e, b, a);               // lazy
     fe_add(t.h, b, a);                  // lazy (2x)
     fe_sub(dmc, d, c);
     fe_add(dpc, d, c);                  // lazy (3x)
@@ -114,13 +114,13 @@ BP_HD void ge_madd(ge_ext &r, const ge_ext &p, const ge_niels &q, bool neg) {
     fe_select(qa, q.ymx, q.ypx, neg);
     fe_select(qb, q.ypx, q.ymx, neg);
     fe_add(ypx, p.Y, p.X);
-    fe_sub(ymx, p.Y, p.X);
+    fe_sub_rr(ymx, p.Y, p.X);           // lazy (no carry chain: the coordinates of p are reduced) -- round 6
     fe_mul(a, ymx, qa);
     fe_mul(b, ypx, qb);
     fe_mul(c, p.T, q.t2d);
     fe_add(d, p.Z, p.Z);
     fe e, f, g, h, dmc, dpc;
-    fe_sub(e, b, a);
+    fe_sub_rr(e, b, a);                 // lazy; D - C below keeps its carry (D is already a sum of two)
     fe_add(h, b, a);
     fe_sub(dmc, d, c);
     fe_add(dpc, d, c);
@@ -167,7 +167,7 @@ BP_HD void ge_dbl(ge_ext &r, const ge_ext &p, bool with_t = true) {
     fe_add(s, p.X, p.Y);                // lazy
     fe_sq(s, s);
     fe_add(h, yy, xx);                  // lazy     (= -H of dbl-2008-hwcd)
-    fe_sub(g, yy, xx);                  //          (=  G)
+    fe_sub_rr(g, yy, xx);               // lazy     (=  G)
     fe_sub(e, s, h);                    //          (=  E)
     fe_sub(f, zz2, g);                  //          (= -F)
     fe_mul(r.X, f, e);
@@ -269,20 +269,22 @@ BP_HD bool ristretto_decompress(ge_ext &r, const uint32_t w[8]) {
 #define BP_OPAQUE2(a, b) ((void)0)
 #endif
 // I = 1 / sqrt(t) (or 1 / sqrt(i t)), non-negative; false when t is not a square (RFC 9496 SQRT_RATIO_M1 with u = 1)
-BP_HD bool fe_invsqrt_i(fe &I, const fe &t) {
+// in two halves, so that the tail of a narrow MSM chain can run the first one -- the 252-squaring chain -- with a wavefront per field
+// element (horner_wave.h: hw_invsqrt_raw, one 16-bit limb per lane) instead of one lane
+BP_HD void fe_invsqrt_raw(fe &r, const fe &t) {   // r = t^3 (t^7)^((p-5)/8)
+    fe v3, v7;
+    fe_sq(v3, t);
+    fe_mul(v3, v3, t);
+    fe_sq(v7, v3);
+    fe_mul(v7, v7, t);
+    fe_pow22523(r, v7);
+    fe_sq(v3, t);          // (formed again: v^3 does not ride through the chain)
+    fe_mul(v3, v3, t);
+    fe_mul(r, r, v3);
+}
+BP_HD bool fe_invsqrt_fix(fe &I, const fe &raw, const fe &t) {
     const fe sqrt_m1 = BP_FE_SQRT_M1;
-    fe r;
-    {
-        fe v3, v7;
-        fe_sq(v3, t);
-        fe_mul(v3, v3, t);
-        fe_sq(v7, v3);
-        fe_mul(v7, v7, t);
-        fe_pow22523(r, v7);
-        fe_sq(v3, t);          // (formed again: v^3 does not ride through the chain)
-        fe_mul(v3, v3, t);
-        fe_mul(r, r, v3);
-    }
+    fe r = raw;
     fe check, one, m1, mi;
     fe_sq(check, r);
     fe_mul(check, check, t);
@@ -298,6 +300,11 @@ BP_HD bool fe_invsqrt_i(fe &I, const fe &t) {
     fe_abs(r);
     I = r;
     return correct || flipped;
+}
+BP_HD bool fe_invsqrt_i(fe &I, const fe &t) {
+    fe r;
+    fe_invsqrt_raw(r, t);
+    return fe_invsqrt_fix(I, r, t);
 }
 // s, u1 = 1 - s^2, u2 = 1 + s^2, v = -d u1^2 - u2^2 from the encoding's words
 BP_HD void ristretto_decode_front(fe &s, fe &u1, fe &u2, fe &v, const uint32_t w[8]) {
@@ -385,21 +392,20 @@ BP_HD void ristretto_compress(uint32_t out[8], const ge_ext &p) {
 
 // ristretto_compress with the short register footprint (see ristretto_decompress_lp): only t = u1 u2^2 crosses the squaring chain, the
 // point is read AGAIN from `src` afterwards (LDS or global memory) and u1, u2 are formed a second time.
-BP_HD void ristretto_compress_lp(uint32_t out[8], const ge_ext *src) {
+// (front: t = u1 u2^2, the input of the inverse square root; back: the encoding from I = 1 / sqrt(t), fe_invsqrt_fix's output)
+BP_HD void ristretto_compress_front(fe &tin, const ge_ext *src) {
+    const ge_ext p = *src;
+    fe u1, u2, a, b, t;
+    fe_add(a, p.Z, p.Y);
+    fe_sub(b, p.Z, p.Y);
+    fe_mul(u1, a, b);
+    fe_mul(u2, p.X, p.Y);
+    fe_sq(t, u2);
+    fe_mul(tin, t, u1);
+}
+BP_HD void ristretto_compress_back(uint32_t out[8], const ge_ext *src, const fe &Iin) {
     const fe sqrt_m1 = BP_FE_SQRT_M1, invsqrt_a_minus_d = BP_FE_INVSQRT_A_MINUS_D;
-    fe tin;
-    {
-        const ge_ext p = *src;
-        fe u1, u2, a, b, t;
-        fe_add(a, p.Z, p.Y);
-        fe_sub(b, p.Z, p.Y);
-        fe_mul(u1, a, b);
-        fe_mul(u2, p.X, p.Y);
-        fe_sq(t, u2);
-        fe_mul(tin, t, u1);
-    }
-    fe I;
-    fe_invsqrt_i(I, tin);
+    fe I = Iin;
     ge_ext p = *src;
 #pragma unroll
     for (int i = 0; i < 10; i++) {
@@ -432,6 +438,12 @@ BP_HD void ristretto_compress_lp(uint32_t out[8], const ge_ext *src) {
     fe_mul(t, t, den);
     fe_abs(t);
     fe_to_words(out, t);
+}
+BP_HD void ristretto_compress_lp(uint32_t out[8], const ge_ext *src) {
+    fe tin, I;
+    ristretto_compress_front(tin, src);
+    fe_invsqrt_i(I, tin);
+    ristretto_compress_back(out, src, I);
 }
 
 // Elligator 2 map of RFC 9496 section 4.3.4 (one half of from_uniform_bytes)

@@ -144,6 +144,45 @@ WV_FN wu32 hw_horner8(const wv_ctx &cx, const uint16_t *colq8) {
     return c;
 }
 
+// ---- the inverse-square-root chain with a wavefront per field element ---------------------------------------------------------------
+// ge25519.h: fe_invsqrt_raw -- r = t^3 (t^7)^((p-5)/8), 254 squarings + 14 multiplications in sequence -- is what a lone MSM's canonical
+// encoding waits for at the end of its chain: 143 us in one lane (a lane alone on its SIMD issues an instruction every ~9 cycles).  With
+// one 16-bit limb per lane a multiplication is 16 multiply-accumulate steps instead of 100 (hw_mul): the same chain in ~50 us.  All four
+// rows compute the same value (the layout is the Horner chain's; a row per coordinate has nothing to do here).
+WV_FN wu32 hw_sqn(const wv_ctx &cx, wu32 x, int n, const wu32 &k) {
+    for (int i = 0; i < n; i++) x = hw_mul(cx, x, x, k);
+    return x;
+}
+// t: canonical 16-bit limbs (or "small"); returns "small" limbs
+WV_FN wu32 hw_invsqrt_raw(const wv_ctx &cx, const wu32 &t, const wu32 &k) {
+    const wu32 v3 = hw_mul(cx, hw_mul(cx, t, t, k), t, k);
+    const wu32 z = hw_mul(cx, hw_mul(cx, v3, v3, k), t, k);   // t^7
+    // z^(2^250 - 1): fe25519.h fe_pow2_250m1, step for step
+    wu32 t0 = hw_mul(cx, z, z, k);
+    wu32 t1 = hw_sqn(cx, t0, 2, k);
+    t1 = hw_mul(cx, z, t1, k);
+    t0 = hw_mul(cx, t0, t1, k);
+    t0 = hw_mul(cx, t0, t0, k);
+    t0 = hw_mul(cx, t1, t0, k);
+    t1 = hw_sqn(cx, t0, 5, k);
+    t0 = hw_mul(cx, t1, t0, k);
+    t1 = hw_sqn(cx, t0, 10, k);
+    t1 = hw_mul(cx, t1, t0, k);
+    wu32 t2 = hw_sqn(cx, t1, 20, k);
+    t1 = hw_mul(cx, t2, t1, k);
+    t1 = hw_sqn(cx, t1, 10, k);
+    t0 = hw_mul(cx, t1, t0, k);
+    t1 = hw_sqn(cx, t0, 50, k);
+    t1 = hw_mul(cx, t1, t0, k);
+    t2 = hw_sqn(cx, t1, 100, k);
+    t1 = hw_mul(cx, t2, t1, k);
+    t1 = hw_sqn(cx, t1, 50, k);
+    wu32 r = hw_mul(cx, t1, t0, k);
+    r = hw_sqn(cx, r, 2, k);
+    r = hw_mul(cx, r, z, k);                                  // z^((p-5)/8)
+    return hw_mul(cx, r, v3, k);
+}
+
 // one lane's 16 lazy limbs (<= 2^17) -> 10 x 25.5-bit field element (lazy, limb 0 may exceed 2^26 by 19+38*small)
 BP_HD void hw_limbs_to_fe(fe &out, const uint32_t l[16]) {
     uint32_t t[16], carry = 0;
@@ -178,6 +217,7 @@ BP_HD void hw_limbs_to_fe(fe &out, const uint32_t l[16]) {
 #if defined(__HIPCC__) && !defined(__HIP_DEVICE_COMPILE__)
 __device__ void hw_horner_msm(const uint16_t *colq16, ge_ext *out);   // host pass of hipcc: declarations only
 __device__ void hw_horner8_msm(const uint16_t *colq8, uint32_t *lds128, ge_ext *out);
+__device__ void hw_invsqrt_raw_fe(const uint16_t *t16, uint32_t *lds128, fe *out);
 __device__ void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out);
 #elif defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void hw_horner_msm(const uint16_t *colq16, ge_ext *out) {
@@ -232,8 +272,32 @@ __device__ __forceinline__ void hw_horner8_msm(const uint16_t *colq8, uint32_t *
         ((fe *)out)[lane >> 4] = r;
     }
 }
+// t16: the 16 canonical limbs of t (8 words of fe_to_words) in LDS; out (LDS): fe_invsqrt_raw(t), written by lane 0
+__device__ __forceinline__ void hw_invsqrt_raw_fe(const uint16_t *t16, uint32_t *lds128, fe *out) {
+    wv_ctx cx;
+    cx.lds = lds128;
+    const uint32_t lane = wv_lane(), k = lane & 15u;
+    const wu32 r = hw_invsqrt_raw(cx, wv_load_u16(t16, k), k);
+    uint32_t limbs[16];
+    wv_row_gather16(cx, r, limbs);
+    if (lane == 0) {
+        fe o;
+        hw_limbs_to_fe(o, limbs);
+        *out = o;
+    }
+}
 #else
 inline void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out);
+inline void hw_invsqrt_raw_fe(const uint16_t *t16, uint32_t *, fe *out) {
+    wv_ctx cx{0};
+    const wu32 lane = wv_lane(), k = lane & 15u;
+    const wu32 r = hw_invsqrt_raw(cx, wv_load_u16(t16, k), k);
+    wu32 limbs[16];
+    wv_row_gather16(cx, r, limbs);
+    uint32_t l[16];
+    for (int i = 0; i < 16; i++) l[i] = limbs[i].l[0];
+    hw_limbs_to_fe(*out, l);
+}
 inline void hw_horner8_msm(const uint16_t *colq8, uint32_t *, ge_ext *out) {
     wv_ctx cx{0};
     const wu32 c = hw_horner8(cx, colq8);

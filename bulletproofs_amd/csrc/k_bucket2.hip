@@ -16,8 +16,8 @@ __global__ void __launch_bounds__(BP_BLOCK, 3) k_bk2_prepare(uint32_t total, uin
 // workgroup = (MSM b, window w).  Workgroups are handed to the eight XCDs round-robin (blockIdx.x mod 8); with xcd_map the 32
 // windows of one MSM are consecutive workgroups of ONE XCD, so that the MSM's point records (128 B x terms: 266 kB at 2 081) are
 // fetched into one L2 once instead of into all eight.  Dynamic LDS: the 16-bit list, 2 bytes per term of the largest MSM.
-template <int LANES>
-__global__ void __launch_bounds__(LANES) k_bk2_window(uint32_t nmsm, int xcd_map, const uint32_t *msm_first, uint32_t total, const uint8_t *dig,
+template <int LANES, bool TWO>
+__global__ void __launch_bounds__(LANES, 3) k_bk2_window(uint32_t nmsm, int xcd_map, const uint32_t *msm_first, uint32_t total, const uint8_t *dig,
                                                        const fb_entry *pts, ge_ext *bsum) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_list[];
     __shared__ uint32_t s_cnt[BK2_HALF], s_off[BK2_HALF + 4], s_tmp[BK2_HALF];
@@ -64,13 +64,14 @@ __global__ void __launch_bounds__(LANES) k_bk2_window(uint32_t nmsm, int xcd_map
     __syncthreads();
     ge_ext *bsum_w = bsum + ((uint64_t)b * BK2_NWIN + w) * BK2_HALF;
     bk2_tail tl;
-    bk2_w4(lane, sg, l, pts + sg.first, bsum_w, tl);
+    bk2_w4(lane, sg, l, pts + sg.first, bsum_w, tl, TWO);
     __syncthreads();
     bk2_w5(lane, sg, l, bsum_w, tl);
 }
-template __global__ void k_bk2_window<64>(uint32_t, int, const uint32_t *, uint32_t, const uint8_t *, const fb_entry *, ge_ext *);
-template __global__ void k_bk2_window<128>(uint32_t, int, const uint32_t *, uint32_t, const uint8_t *, const fb_entry *, ge_ext *);
-template __global__ void k_bk2_window<256>(uint32_t, int, const uint32_t *, uint32_t, const uint8_t *, const fb_entry *, ge_ext *);
+template __global__ void k_bk2_window<64, false>(uint32_t, int, const uint32_t *, uint32_t, const uint8_t *, const fb_entry *, ge_ext *);
+template __global__ void k_bk2_window<128, false>(uint32_t, int, const uint32_t *, uint32_t, const uint8_t *, const fb_entry *, ge_ext *);
+template __global__ void k_bk2_window<256, false>(uint32_t, int, const uint32_t *, uint32_t, const uint8_t *, const fb_entry *, ge_ext *);
+template __global__ void k_bk2_window<64, true>(uint32_t, int, const uint32_t *, uint32_t, const uint8_t *, const fb_entry *, ge_ext *);
 
 // ---- the generator half as one launch (msm_fixed.h: fb_walk_thread) ------------------------------------------------------------
 // workgroup = WAVES wavefronts = WAVES slices of the generator terms for one block of 64 MSMs (lane = MSM); blockIdx.x = wg * nblk_p + pblk.
@@ -127,6 +128,8 @@ __global__ void __launch_bounds__(64) k_msm_tail(uint32_t nmsm, int have_bucket,
     __shared__ __attribute__((aligned(16))) uint32_t s_hw[128];
     __shared__ ge_ext s_xch[32];
     __shared__ ge_ext s_fin[2];   // [0] Horner result, [1] the sum that is encoded
+    __shared__ fe s_tin, s_raw;
+    __shared__ __attribute__((aligned(16))) uint32_t s_tw[8];
     const uint32_t lane = threadIdx.x, b = blockIdx.x;
     if (have_bucket) bk2_tail_t1(lane, b, gS, gA, s_colq8);
     ge_ext acc;
@@ -150,5 +153,74 @@ __global__ void __launch_bounds__(64) k_msm_tail(uint32_t nmsm, int have_bucket,
         s_fin[1] = acc;
     }
     __syncthreads();
-    if (lane == 0) bk2_tail_t4(b, &s_fin[1], status, out_words, verdict, status_bytes);
+    if (out_words) {   // the encoding's inverse square root: the wavefront's chain between two steps of lane 0
+        if (lane == 0) bk2_tail_t4a(&s_fin[1], &s_tin, s_tw);
+        __syncthreads();
+        hw_invsqrt_raw_fe((const uint16_t *)s_tw, s_hw, &s_raw);
+        __syncthreads();
+    }
+    if (lane == 0) bk2_tail_t4b(b, &s_fin[1], &s_raw, &s_tin, status, out_words, verdict, status_bytes);
+}
+
+// ---- the tail of a narrow chain (bucket2.h: bk2_leafv_thread, bk2_fast_v4): leaves of 4 buckets; workgroup = 256 lanes = MSM -------------
+__global__ void __launch_bounds__(BP_BLOCK) k_bk2_leafv(uint32_t nthreads, const ge_ext *bsum, ge_ext *gV) {
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < nthreads) bk2_leafv_thread(t, bsum, gV);
+}
+// r = the point held by lane (this lane + delta) of the wavefront (its own beyond the last lane)
+__device__ __forceinline__ void ge_shfl_down(ge_ext &r, const ge_ext &p, uint32_t delta) {
+#pragma unroll
+    for (int i = 0; i < 10; i++) {
+        r.X.v[i] = __shfl_down(p.X.v[i], delta);
+        r.Y.v[i] = __shfl_down(p.Y.v[i], delta);
+        r.Z.v[i] = __shfl_down(p.Z.v[i], delta);
+        r.T.v[i] = __shfl_down(p.T.v[i], delta);
+    }
+}
+__global__ void __launch_bounds__(256) k_msm_tail_fast(uint32_t nmsm, int have_bucket, const ge_ext *gV, uint32_t npart, const ge_ext *partial,
+                                                        const uint32_t *status, uint32_t *out_words, uint8_t *verdict, uint8_t *status_bytes) {
+    __shared__ __attribute__((aligned(16))) uint32_t s_colq8[BK2_NWIN * 32];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hw[128];
+    __shared__ ge_ext s_fin[3];   // [0] Horner result, [1] the sum that is encoded, [2] the generator half
+    __shared__ fe s_tin, s_raw;
+    __shared__ __attribute__((aligned(16))) uint32_t s_tw[8];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x;
+    if (have_bucket) {
+        const uint32_t w = tid >> 3, l = tid & 7u;
+        ge_ext V, q;
+        bk2_fast_v4(w, l, b, gV, V);
+#pragma unroll 1
+        for (uint32_t step = 4; step >= 1; step >>= 1) {   // (every lane adds: the sums of lanes l >= step are not used)
+            ge_shfl_down(q, V, step);
+            ge_add(V, V, q);
+        }
+        if (l == 0) vb_encode_colq16(s_colq8 + w * 32, V);
+    }
+    __syncthreads();
+    if (wave == 0 && have_bucket) {
+        hw_horner8_msm((const uint16_t *)s_colq8, s_hw, &s_fin[0]);
+    } else if (wave == 1) {
+        ge_ext acc, q;
+        bk2_tail_t2(lane, b, nmsm, npart, partial, acc);
+#pragma unroll 1
+        for (uint32_t step = 32; step >= 1; step >>= 1) {
+            ge_shfl_down(q, acc, step);
+            ge_add(acc, acc, q);
+        }
+        if (lane == 0) s_fin[2] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ge_ext acc = s_fin[2];
+        if (have_bucket) {
+            const ge_ext h = s_fin[0];
+            ge_add(acc, acc, h);
+        }
+        s_fin[1] = acc;
+        if (out_words) bk2_tail_t4a(&s_fin[1], &s_tin, s_tw);
+    }
+    __syncthreads();
+    if (out_words && wave == 0) hw_invsqrt_raw_fe((const uint16_t *)s_tw, s_hw, &s_raw);
+    __syncthreads();
+    if (tid == 0) bk2_tail_t4b(b, &s_fin[1], &s_raw, &s_tin, status, out_words, verdict, status_bytes);
 }

@@ -987,21 +987,42 @@ int h_msm_bucket2(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scala
         for (uint32_t lane = 0; lane < lanes; lane++) bk2_w5(lane, sg, l, bsum_w, tails[lane]);
     }
     if (stats) memcpy(stats, st, sizeof st);
-    std::vector<uint32_t> colq16((size_t)nbatch * 64 * 32 + 32, 0);
-    const uint32_t nl = bk_leaves(prm);
-    std::vector<ge_ext> gS((size_t)nbw * nl), gA((size_t)nbw * nl);
-    for (uint32_t tid = 0; tid < nbw * nl; tid++) bk_leaf_thread(tid, prm, bsum.data(), gS.data(), gA.data());
-    for (uint32_t bw = 0; bw < nbw; bw++) {
-        ge_ext S, A;
-        bk_combine(S, A, gS.data(), gA.data(), bw * 8, 8, 1, 16);
-        const uint32_t b = bw / prm.nwin, w = bw - b * prm.nwin;
-        bk_emit_columns(w, prm, A, colq16.data() + (size_t)b * 64 * 32);
+    // the chain's end, both forms (k_bucket2.hip: k_bk_leaf + k_msm_tail for wide batches, k_bk2_leafv + k_msm_tail_fast for narrow ones),
+    // phase by phase; the wavefront shuffles of the narrow form are plain sums here.  Both must give the same encodings.
+    std::vector<uint32_t> outw[2];
+    for (int fast = 0; fast < 2; fast++) {
+        outw[fast].assign((size_t)nbatch * 8 + 8, 0);
+        const uint32_t nl = fast ? BK2_FAST_LEAVES : bk_leaves(prm);
+        std::vector<ge_ext> gS((size_t)nbw * nl), gA((size_t)nbw * nl);
+        for (uint32_t tid = 0; tid < nbw * nl; tid++) {
+            if (fast) bk2_leafv_thread(tid, bsum.data(), gA.data());
+            else bk_leaf_thread(tid, prm, bsum.data(), gS.data(), gA.data());
+        }
+        for (uint32_t b = 0; b < nbatch; b++) {
+            std::vector<uint32_t> colq8(BK2_NWIN * 32, 0), hwlds(128, 0), tw(8, 0);
+            if (fast) {
+                for (uint32_t w = 0; w < BK2_NWIN; w++) {
+                    ge_ext V[8];
+                    for (uint32_t g = 0; g < 8; g++) bk2_fast_v4(w, g, b, gA.data(), V[g]);
+                    for (uint32_t step = 4; step >= 1; step >>= 1)
+                        for (uint32_t g = 0; g < step; g++) ge_add(V[g], V[g], V[g + step]);
+                    vb_encode_colq16(colq8.data() + w * 32, V[0]);
+                }
+            } else {
+                for (uint32_t lane = 0; lane < 64; lane++) bk2_tail_t1(lane, b, gS.data(), gA.data(), colq8.data());
+            }
+            ge_ext fin[2];
+            hw_horner8_msm((const uint16_t *)colq8.data(), hwlds.data(), &fin[0]);
+            fe tin, raw, raw_lane;
+            bk2_tail_t4a(&fin[0], &tin, tw.data());
+            hw_invsqrt_raw_fe((const uint16_t *)tw.data(), hwlds.data(), &raw);
+            fe_invsqrt_raw(raw_lane, tin);   // the one-lane chain: same field element
+            if (!fe_eq(raw, raw_lane)) return -8;
+            bk2_tail_t4b(b, &fin[0], &raw, &tin, status.data(), outw[fast].data(), nullptr, nullptr);
+        }
     }
-    std::vector<ge_ext> hq(nbatch + 1);
-    std::vector<uint32_t> outw((size_t)nbatch * 8 + 8);
-    for (uint32_t b = 0; b < nbatch; b++) hw_horner_msm((const uint16_t *)(colq16.data() + (size_t)b * 64 * 32), &hq[b]);
-    for (uint32_t b = 0; b < nbatch; b++) vb_horner_thread(b, nullptr, hq.data(), status.data(), outw.data(), nullptr);
-    memcpy(out, outw.data(), (size_t)nbatch * 32);
+    if (memcmp(outw[0].data(), outw[1].data(), (size_t)nbatch * 32)) return -7;
+    memcpy(out, outw[0].data(), (size_t)nbatch * 32);
     for (uint32_t b = 0; b < nbatch; b++) status_out[b] = (uint8_t)status[b];
     return 0;
 }
