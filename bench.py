@@ -685,6 +685,24 @@ def bench_cfg5_shape(a, local_dev, steps=96, nstreams=16):
                         "frac": alg / avg_s / 1e9 / 8000.0, "traffic": traffic, "avg_launch_us": round(avg_s * 1e6, 2), "launches": kern[dom][0],
                         "algorithmic_bytes_per_launch": alg,
                         "kernels_us": {k: round(v[1] / v[0] * 1e3, 2) for k, v in sorted(kern.items(), key=lambda kv: -kv[1][1])}}}
+    # what binds: instruction issue (committed SQ_INSTS_VALU of the chain's kernels at batch width x this run's rate), and the counter bytes of
+    # the whole chain against the algorithmic ones
+    wk = None
+    wpath = os.path.join(ROOT, "profiles", "valu_work_cfg5.json")
+    if os.path.exists(wpath):
+        with open(wpath) as f:
+            wk = json.load(f)
+    if wk and wk.get("_proofs_per_launch"):
+        wi = sum(v for k, v in wk.items() if not k.startswith("_") and k in kern and isinstance(v, (int, float))) / wk["_proofs_per_launch"]
+        out["roofline"]["valu"] = {"wave_instructions_per_msm": round(wi, 1), "achieved_wave_instructions_per_s": wi * out["msms_per_s"],
+                                   "frac_of_ge_madd_sustained": wi * out["msms_per_s"] / GE_MADD_WAVE_INSTR_PER_S,
+                                   "source": "SQ_INSTS_VALU per MSM: committed (profiles/valu_work_cfg5.json, the batch-of-64 launches only); rate: measured in this run"}
+    if os.path.exists(tpath) and tj.get("_proofs_per_launch"):
+        tot = sum(v for k, v in tj.items() if not k.startswith("_") and k in kern and isinstance(v, (int, float))) / tj["_proofs_per_launch"]
+        out["roofline"]["hbm_counter"] = {"bytes_per_msm_all_kernels": int(tot), "algorithmic_bytes_per_msm": alg // nb, "ratio": round(tot / (alg / nb), 1),
+                                          "achieved_GBps": round(tot * out["msms_per_s"] / 1e9, 1), "frac_of_8TBps": tot * out["msms_per_s"] / HBM_PEAK,
+                                          "note": "one 128-byte table line per generator-term addition is by design (33x of the ratio: 4098 terms x 17 windows x 128 B); "
+                                                  "the sorted index lists of the bucket stage no longer leave LDS"}
     from bulletproofs_amd.workload import reference_point_ops
     out["point_adds_per_s"] = round(reference_point_ops(N) * out["msms_per_s"], 1)
     out["roofline"]["dominant_by"] = "most HBM bytes per launch (committed PMC pass); by total kernel time: %s" % by_time

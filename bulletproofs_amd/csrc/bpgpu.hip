@@ -148,7 +148,6 @@ struct bpgpu_ctx {
     int bucket_chain = 0;                    // option "bucket_chain": 0 = the fused chain (bucket2.h) where it applies, 1 = bucket.h's chain everywhere (A/B)
     int bucket_lanes = 0;                    // option "bucket_lanes": lanes of a (MSM, window) workgroup of the fused chain (0 = by batch width; 64, 128, 256)
     int fast_tail = -1;                      // option "bucket_fast_tail" (A/B): -1 = by batch width, 0 / 1 = never / always the short-chain tail
-    int bucket_two = 0;                      // option "bucket_two_buffers" (A/B): the (MSM, window) workgroups of a wide batch alternate two point-record buffers
     int walk_waves = 0;                      // option "fb_walk_waves": wavefronts the generator half of a fused chain is cut into (0 = 1024)
     // constant-time generator-table MSMs for the prover's secret-dependent commitments (msm_fixed.h fb_accum_ct_thread): their own
     // small-window table, built on first use
@@ -550,10 +549,6 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
         c->fast_tail = value < 0 ? -1 : (value != 0);
         return BPGPU_OK;
     }
-    if (!strcmp(key, "bucket_two_buffers")) {
-        c->bucket_two = value != 0;
-        return BPGPU_OK;
-    }
     if (!strcmp(key, "fb_walk_waves")) {
         if (value < 0 || value > 65536) return fail(c, BPGPU_ERR_INVALID_ARG, "fb_walk_waves out of range");
         c->walk_waves = (int)value;
@@ -587,7 +582,6 @@ int bpgpu_ctx_get_option(bpgpu_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "bucket_min_terms")) *value = c->bucket_min ? c->bucket_min : BK_MIN_TERMS;
     else if (!strcmp(key, "bucket_chain")) *value = c->bucket_chain;
     else if (!strcmp(key, "bucket_lanes")) *value = c->bucket_lanes;
-    else if (!strcmp(key, "bucket_two_buffers")) *value = c->bucket_two;
     else if (!strcmp(key, "bucket_fast_tail")) *value = c->fast_tail;
     else if (!strcmp(key, "fb_walk_waves")) *value = c->walk_waves ? c->walk_waves : 1024;
     else if (!strcmp(key, "staging_residue")) {
@@ -1232,10 +1226,9 @@ static int enqueue_bucket2(bpgpu_ctx *c, hipStream_t s, size_t nmsm, size_t tota
     const uint32_t lanes = bucket2_lanes(c, nmsm);
     const size_t shm = ((per_msm * 2 + 15) / 16) * 16;
     const int xcd_map = (nmsm % 8) == 0 ? 1 : 0;
-    if (lanes == 64 && c->bucket_two) LAUNCH_SHM(c, s, "bk_window", (k_bk2_window<64, true>), nbw, 64, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
-    else if (lanes == 64) LAUNCH_SHM(c, s, "bk_window", (k_bk2_window<64, false>), nbw, 64, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
-    else if (lanes == 128) LAUNCH_SHM(c, s, "bk_window", (k_bk2_window<128, false>), nbw, 128, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
-    else LAUNCH_SHM(c, s, "bk_window", (k_bk2_window<256, false>), nbw, 256, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
+    if (lanes == 64) LAUNCH_SHM(c, s, "bk_window", k_bk2_window<64>, nbw, 64, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
+    else if (lanes == 128) LAUNCH_SHM(c, s, "bk_window", k_bk2_window<128>, nbw, 128, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
+    else LAUNCH_SHM(c, s, "bk_window", k_bk2_window<256>, nbw, 256, shm, (uint32_t)nmsm, xcd_map, d.msm_first, tot32, (const uint8_t *)dig, (const fb_entry *)d.pts, d.bsum);
     if (bucket2_fast_tail(c, nmsm)) {
         const uint32_t nl = nbw * BK2_FAST_LEAVES;
         LAUNCH(c, s, "bk_leaf", k_bk2_leafv, (nl + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nl, (const ge_ext *)d.bsum, d.gA);

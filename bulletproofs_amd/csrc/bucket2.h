@@ -150,7 +150,7 @@ BP_HD void bk2_w4_step(uint32_t lane, uint32_t pos, uint32_t &j, uint32_t &bend,
     ge_madd(acc, acc, nn, (e >> 15) != 0);   // (also for the first entry of a piece: the formulas are complete)
 }
 // w4: the lane's run of q entries.  bsum_w: this (MSM, window)'s 128 bucket sums in global memory; pts_m: the MSM's point records
-BP_HD void bk2_w4(uint32_t lane, const bk2_seg &sg, const bk2_lds &l, const fb_entry *pts_m, ge_ext *bsum_w, bk2_tail &tl, bool two_buffers = false) {
+BP_HD void bk2_w4(uint32_t lane, const bk2_seg &sg, const bk2_lds &l, const fb_entry *pts_m, ge_ext *bsum_w, bk2_tail &tl) {
     // empty buckets: the identity
     for (uint32_t j = lane; j < BK2_HALF; j += sg.lanes) {
         if (l.off[j + 1] == l.off[j]) {
@@ -169,42 +169,21 @@ BP_HD void bk2_w4(uint32_t lane, const bk2_seg &sg, const bk2_lds &l, const fb_e
     bool head_piece = lo > l.off[j];   // the lane's first piece continues a bucket that began in an earlier lane
     ge_ext acc;
     ge_identity(acc);
-    if (two_buffers) {
-        // two line buffers used alternately (as msm_fixed.h: fb_accum_thread): the record of entry pos+1 is requested into the buffer
-        // entry pos-1 has vacated, no register copies between trips
-        uint32_t e_a = l.list[lo], e_b = 0;
-        fb_line la, lb;
-        fb_load_line(la, pts_m + (e_a & 0x7fffu));
-        for (uint32_t pos = lo; pos < hi;) {
-            if (pos + 1 < hi) {
-                e_b = l.list[pos + 1];
-                fb_load_line(lb, pts_m + (e_b & 0x7fffu));
-            }
-            bk2_w4_step(lane, pos, j, bend, head_piece, acc, la, e_a, l, bsum_w);
-            if (++pos >= hi) break;
-            if (pos + 1 < hi) {
-                e_a = l.list[pos + 1];
-                fb_load_line(la, pts_m + (e_a & 0x7fffu));
-            }
-            bk2_w4_step(lane, pos, j, bend, head_piece, acc, lb, e_b, l, bsum_w);
-            ++pos;
+    // one record buffer and a copy per trip: alternating two buffers (no copies) needs 25 registers more, which under the
+    // three-wavefront cap spill -- measured slower (238 against 202 us for 64 MSMs, profiles/r06/cfg5_two_buffers_ab.txt)
+    uint32_t e_cur = l.list[lo];
+    fb_line line_cur;
+    fb_load_line(line_cur, pts_m + (e_cur & 0x7fffu));
+    for (uint32_t pos = lo; pos < hi; pos++) {
+        fb_line line_next = line_cur;
+        uint32_t e_next = 0;
+        if (pos + 1 < hi) {
+            e_next = l.list[pos + 1];
+            fb_load_line(line_next, pts_m + (e_next & 0x7fffu));
         }
-    } else {
-        // one buffer + a copy per trip: 25 registers fewer (no spills under the three-wavefront cap), ~45 moves more per entry
-        uint32_t e_cur = l.list[lo];
-        fb_line line_cur;
-        fb_load_line(line_cur, pts_m + (e_cur & 0x7fffu));
-        for (uint32_t pos = lo; pos < hi; pos++) {
-            fb_line line_next = line_cur;
-            uint32_t e_next = 0;
-            if (pos + 1 < hi) {
-                e_next = l.list[pos + 1];
-                fb_load_line(line_next, pts_m + (e_next & 0x7fffu));
-            }
-            bk2_w4_step(lane, pos, j, bend, head_piece, acc, line_cur, e_cur, l, bsum_w);
-            line_cur = line_next;
-            e_cur = e_next;
-        }
+        bk2_w4_step(lane, pos, j, bend, head_piece, acc, line_cur, e_cur, l, bsum_w);
+        line_cur = line_next;
+        e_cur = e_next;
     }
     // the last piece: bucket j, entries [max(lo, off[j]), hi)
     if (head_piece) {   // the whole run lies inside a bucket that began earlier

@@ -16,7 +16,7 @@ __global__ void __launch_bounds__(BP_BLOCK, 3) k_bk2_prepare(uint32_t total, uin
 // workgroup = (MSM b, window w).  Workgroups are handed to the eight XCDs round-robin (blockIdx.x mod 8); with xcd_map the 32
 // windows of one MSM are consecutive workgroups of ONE XCD, so that the MSM's point records (128 B x terms: 266 kB at 2 081) are
 // fetched into one L2 once instead of into all eight.  Dynamic LDS: the 16-bit list, 2 bytes per term of the largest MSM.
-template <int LANES, bool TWO>
+template <int LANES>
 __global__ void __launch_bounds__(LANES, 3) k_bk2_window(uint32_t nmsm, int xcd_map, const uint32_t *msm_first, uint32_t total, const uint8_t *dig,
                                                        const fb_entry *pts, ge_ext *bsum) {
     extern __shared__ __attribute__((aligned(16))) uint16_t s_list[];
@@ -64,14 +64,13 @@ __global__ void __launch_bounds__(LANES, 3) k_bk2_window(uint32_t nmsm, int xcd_
     __syncthreads();
     ge_ext *bsum_w = bsum + ((uint64_t)b * BK2_NWIN + w) * BK2_HALF;
     bk2_tail tl;
-    bk2_w4(lane, sg, l, pts + sg.first, bsum_w, tl, TWO);
+    bk2_w4(lane, sg, l, pts + sg.first, bsum_w, tl);
     __syncthreads();
     bk2_w5(lane, sg, l, bsum_w, tl);
 }
-template __global__ void k_bk2_window<64, false>(uint32_t, int, const uint32_t *, uint32_t, const uint8_t *, const fb_entry *, ge_ext *);
-template __global__ void k_bk2_window<128, false>(uint32_t, int, const uint32_t *, uint32_t, const uint8_t *, const fb_entry *, ge_ext *);
-template __global__ void k_bk2_window<256, false>(uint32_t, int, const uint32_t *, uint32_t, const uint8_t *, const fb_entry *, ge_ext *);
-template __global__ void k_bk2_window<64, true>(uint32_t, int, const uint32_t *, uint32_t, const uint8_t *, const fb_entry *, ge_ext *);
+template __global__ void k_bk2_window<64>(uint32_t, int, const uint32_t *, uint32_t, const uint8_t *, const fb_entry *, ge_ext *);
+template __global__ void k_bk2_window<128>(uint32_t, int, const uint32_t *, uint32_t, const uint8_t *, const fb_entry *, ge_ext *);
+template __global__ void k_bk2_window<256>(uint32_t, int, const uint32_t *, uint32_t, const uint8_t *, const fb_entry *, ge_ext *);
 
 // ---- the generator half as one launch (msm_fixed.h: fb_walk_thread) ------------------------------------------------------------
 // workgroup = WAVES wavefronts = WAVES slices of the generator terms for one block of 64 MSMs (lane = MSM); blockIdx.x = wg * nblk_p + pblk.

@@ -102,7 +102,7 @@ template <int C>
 __global__ void k_bk_tree(bk_params prm, uint32_t nbw, const ge_ext *gS, const ge_ext *gA, uint32_t *colq16);
 // k_bucket2.hip
 __global__ void k_bk2_prepare(uint32_t total, uint32_t nbatch, const uint32_t *msm_first, const uint32_t *scalars, const uint32_t *points, fb_entry *pts, uint8_t *dig, uint32_t *status);
-template <int LANES, bool TWO>
+template <int LANES>
 __global__ void k_bk2_window(uint32_t nmsm, int xcd_map, const uint32_t *msm_first, uint32_t total, const uint8_t *dig, const fb_entry *pts, ge_ext *bsum);
 template <int WAVES>
 __global__ void k_fb_walk(fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nwg, uint32_t n_gen_terms, const uint32_t *gen_scalars, const uint32_t *gen_ids, const fb_entry *table, ge_ext *partial, uint32_t *status);

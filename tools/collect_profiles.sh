@@ -62,7 +62,8 @@ pmc cfg5_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" python $REPO/b
 python $REPO/tools/isa_mix.py > /tmp/isa_mix.json
 python - <<PY
 import csv, collections, json, glob, re
-LABEL = {"vb_window_wide": "rp_stage3w", "vb_window_colc": "rp_stage3w", "rp_horner_wide": "rp_horner1", "rp_exponents": "rp_stage3"}   # kernel -> the library's launch label (bench.py's names)
+LABEL = {"vb_window_wide": "rp_stage3w", "vb_window_colc": "rp_stage3w", "rp_horner_wide": "rp_horner1", "rp_exponents": "rp_stage3",
+         "bk2_prepare": "bk_prepare", "bk2_window": "bk_window", "bk2_leafv": "bk_leaf_narrow", "msm_tail_fast": "msm_tail_narrow", "fb_walk1": "fb_walk_narrow"}   # kernel -> the library's launch label (bench.py's names)
 def short(name):
     n = name.split("(")[0].strip()
     n = re.sub(r"^void\s+", "", n)
@@ -71,12 +72,19 @@ def short(name):
     return LABEL.get(n, n)
 def per_kernel(d, counter):
     f = glob.glob(d + "/**/*counter_collection.csv", recursive=True)[0]
-    acc = collections.defaultdict(lambda: [0, 0.0])
+    # per kernel only the dispatches of its LARGEST grid: the bench commands also issue narrow launches of the same kernels (a lone MSM,
+    # a latency probe), and an average over both is the figure of neither (rounds 2-5 did that for cfg5: 3.58 M wavefront-instructions
+    # per MSM reported where the batch of 64 executed 5.0 M)
+    rows = collections.defaultdict(list)
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter: continue
-        k = short(r["Kernel_Name"])
-        acc[k][0] += 1; acc[k][1] += float(r["Counter_Value"])
-    return {k: {"dispatches": v[0], "avg_per_dispatch": v[1] / v[0]} for k, v in acc.items()}
+        rows[short(r["Kernel_Name"])].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+    out = {}
+    for k, v in rows.items():
+        g = max(x[0] for x in v)
+        w = [x[1] for x in v if x[0] == g]
+        out[k] = {"dispatches": len(w), "avg_per_dispatch": sum(w) / len(w), "grid": g}
+    return out
 for cfg, what, ppl in (("cfg2", "bench.py --config cfg2 --steps 5 --warmup 0 --streams 1 --opt latency_proofs=0,auto_flush_items=64 (the pool's wide chain form: one coalesced chain of 5120 per region)", 5120),
                   ("cfg3", "bench.py --config cfg3 --steps 8 --warmup 0 --streams 1 --opt latency_proofs=0,auto_flush_items=64 (one coalesced chain of 2048 per region)", 2048),
                   ("cfg4", "bench.py --config cfg4 --steps 4 --warmup 0 --streams 1 --opt latency_proofs=0,auto_flush_items=64 (one coalesced chain of 2048 per region)", 2048),
@@ -105,7 +113,7 @@ for cfg, what, ppl in (("cfg2", "bench.py --config cfg2 --steps 5 --warmup 0 --s
         lab = short(full)
         if lab in work and (lab not in per_k or PREF.get(lab) == re.sub(r"^void\\s+", "", full)):
             per_k[lab] = mv["fraction"]
-    per_k = {k: fr for k, fr in per_k.items() if k.startswith(("rp_", "finish", "fb_reduce", "vb_", "bk_", "rlc_"))}   # the chain's kernels, not the table construction
+    per_k = {k: fr for k, fr in per_k.items() if k.startswith(("rp_", "finish", "fb_reduce", "fb_walk", "msm_tail", "vb_", "bk_", "rlc_"))}   # the chain's kernels, not the table construction
     for k, fr in per_k.items():
         num += fr * work[k]; den += work[k]
     work["_mad_u64_fraction"] = round(num / den, 4) if den else 0.58
