@@ -92,11 +92,9 @@ struct bpgpu_ctx {
                                                                     // (profiles/r05/coop_defer_emit_ab.txt; the kernel's duration for ONE proof is unchanged, 238 us: the gain is at several
                                                                     // groups per launch); 0: the leader recodes them one after the other
     int transcript_coop = 1;                                        // chains of up to 256 proofs replay their transcripts 32 lanes per proof (keccak.h): one call of 1 / 8 / 64 / 256 proofs 0.62 -> 0.53 / 0.56 / 0.57 / 0.58 ms; 0: lane = proof everywhere
-    int split_stage1 = 0;                                           // experiment: point decoding as its own launch on the second stream, compiled for 1 / 2 / 3 wavefronts per SIMD
     int msm_fork = 1;                                               // bpgpu_msm_batch_shared: the generator-table half on the second stream beside the per-MSM points (0: one stream -- with
                                                                     // many contexts in flight two streams each outnumber the hardware queues: config 5 on 16 / 24 / 32 contexts +1.6 / +1.7 /
                                                                     // +3.2 % MSMs/s, but one MSM alone 0.77 -> 0.98 ms: stays on; profiles/r05/msm_queue_ab.txt)
-    int fork_early = 0;                                             // wide chains with the Horner chains aside: the window sums go to the second stream too (rp_verify_dev_locked)
     int split_stage3 = -1;                                          // window sums and generator exponents as two launches: 1 yes, 0 no, -1 auto (chains of >= 2048 proofs)
     bool no_script = false;                                         // option "transcript_script" = 0: byte-wise replay everywhere (A/B)
     // device-resident work decomposition of the uniform (nbatch, terms-per-MSM) variable-base plans
@@ -157,10 +155,7 @@ struct bpgpu_ctx {
     // second stream for the generator-table half of a shared-generator MSM: it is independent of the per-MSM points'
     // half until the finish, so the two halves run side by side (fork after the status memset, join before the finish)
     hipStream_t stream2 = nullptr;
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr, exp_ev = nullptr, fork2_ev = nullptr;
-    hipEvent_t early_ev = nullptr;                                  // recorded behind a chain's early phase when the pool asks for it (mark_early: 1 = behind launch 1, 2 = behind the
-    int mark_early = 0;                                             // generator exponents, i.e. right before the table walk): the NEXT chain of a burst starts its own early phase there
-    bool early_recorded = false;
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     // result of a submitted (not yet collected) host-pointer call: where its outputs sit in the pinned buffer and where the
     // caller wants them (bpgpu_rangeproof_verify_batch_submit / bpgpu_ctx_collect)
     struct pending_result {
@@ -412,10 +407,7 @@ int bpgpu_ctx_create(int device, bpgpu_ctx **out) {
         hipEventCreateWithFlags(&c->done_ev, hipEventDisableTiming | hipEventBlockingSync) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream2, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreateWithFlags(&c->fork_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->exp_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->fork2_ev, hipEventDisableTiming) != hipSuccess ||
-        hipEventCreateWithFlags(&c->early_ev, hipEventDisableTiming) != hipSuccess) {
+        hipEventCreateWithFlags(&c->join_ev, hipEventDisableTiming) != hipSuccess) {
         delete c;
         return BPGPU_ERR_HIP;
     }
@@ -447,9 +439,6 @@ void bpgpu_ctx_destroy(bpgpu_ctx *c) {
     if (c->done_ev) hipEventDestroy(c->done_ev);
     if (c->fork_ev) hipEventDestroy(c->fork_ev);
     if (c->join_ev) hipEventDestroy(c->join_ev);
-    if (c->exp_ev) hipEventDestroy(c->exp_ev);
-    if (c->fork2_ev) hipEventDestroy(c->fork2_ev);
-    if (c->early_ev) hipEventDestroy(c->early_ev);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->rp_status) hipFree(c->rp_status);
     if (c->d_table_ct) hipFree(c->d_table_ct);
@@ -513,18 +502,8 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
         c->transcript_coop = (int)value;
         return BPGPU_OK;
     }
-    if (!strcmp(key, "split_stage1")) {
-        if (value < 0 || value > 3) return fail(c, BPGPU_ERR_INVALID_ARG, "split_stage1 must be 0..3");
-        c->split_stage1 = (int)value;
-        return BPGPU_OK;
-    }
     if (!strcmp(key, "msm_fork")) {
         c->msm_fork = value != 0;
-        return BPGPU_OK;
-    }
-    if (!strcmp(key, "fork_early")) {
-        if (value < 0 || value > 2) return fail(c, BPGPU_ERR_INVALID_ARG, "fork_early must be 0, 1 or 2");
-        c->fork_early = (int)value;
         return BPGPU_OK;
     }
     if (!strcmp(key, "split_stage3")) {
@@ -2110,40 +2089,21 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     ge_cached *d_colc = quad ? (ge_cached *)d.colq16 : nullptr;
     const uint32_t n_tr = (nb32 + RP_BLOCK - 1) / RP_BLOCK;
     const uint32_t n_pt = shape_verdict ? 0 : (nb32 * sh.U + RP_BLOCK - 1) / RP_BLOCK;
-    const bool split1 = c->split_stage1 && !shape_verdict && n_pt && s != c->stream2;
-    if (split1) {   // decode on the second stream, joined before launch 3 (which reads its tables)
-        HIPCHK(c, hipEventRecord(c->fork_ev, s));
-        HIPCHK(c, hipStreamWaitEvent(c->stream2, c->fork_ev, 0));
-        fb_entry *bpts = rlc_bucket ? bd.pts : (fb_entry *)nullptr;
-        if (c->split_stage1 == 1) LAUNCH(c, c->stream2, "rp_points", k_rp_points<1>, n_pt, RP_BLOCK, sh, (const uint8_t *)d_proofs, (const uint8_t *)d_commitments, d.tab, d_status, bpts, segtab);
-        else if (c->split_stage1 == 2) LAUNCH(c, c->stream2, "rp_points", k_rp_points<2>, n_pt, RP_BLOCK, sh, (const uint8_t *)d_proofs, (const uint8_t *)d_commitments, d.tab, d_status, bpts, segtab);
-        else LAUNCH(c, c->stream2, "rp_points", k_rp_points<3>, n_pt, RP_BLOCK, sh, (const uint8_t *)d_proofs, (const uint8_t *)d_commitments, d.tab, d_status, bpts, segtab);
-        HIPCHK(c, hipEventRecord(c->join_ev, c->stream2));
-    }
-    if (d_script && split1)   // the lane-serial role alone, uncapped (its decode role runs on the second stream)
-        LAUNCH(c, s, "rp_stage1", k_rp_transcript, n_tr, RP_BLOCK, sh, init, (const uint8_t *)d_proofs, (const uint8_t *)d_commitments, rng_ptr, d_fields, d_status, prm,
-               lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits, rlc ? wts_ptr : (const uint8_t *)nullptr, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
-               rlc_bucket ? bkp.c : 0u, segtab, d_script);
-    else if (d_script && c->transcript_coop && nbatch <= 256)   // narrow chain: 32 lanes per proof for the permutations (two proofs per workgroup)
+    if (d_script && c->transcript_coop && nbatch <= 256)   // narrow chain: 32 lanes per proof for the permutations (two proofs per workgroup)
         LAUNCH(c, s, "rp_stage1", k_rp_stage1_coop, (nb32 + 1) / 2 + n_pt, RP_BLOCK, sh, init, (nb32 + 1) / 2, (const uint8_t *)d_proofs,
            (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits,
            rlc ? wts_ptr : (const uint8_t *)nullptr, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
            rlc_bucket ? bd.pts : (fb_entry *)nullptr, rlc_bucket ? bkp.c : 0u, segtab, d_script);
     else if (d_script)
-        LAUNCH(c, s, "rp_stage1", k_rp_stage1<true>, n_tr + (split1 ? 0u : n_pt), RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
+        LAUNCH(c, s, "rp_stage1", k_rp_stage1<true>, n_tr + n_pt, RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
            (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits,
            rlc ? wts_ptr : (const uint8_t *)nullptr, ts_flags, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
            rlc_bucket ? bd.pts : (fb_entry *)nullptr, rlc_bucket ? bkp.c : 0u, segtab, d_script);
     else
-        LAUNCH(c, s, "rp_stage1", k_rp_stage1<false>, n_tr + (split1 ? 0u : n_pt), RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
+        LAUNCH(c, s, "rp_stage1", k_rp_stage1<false>, n_tr + n_pt, RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
            (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits,
            rlc ? wts_ptr : (const uint8_t *)nullptr, ts_flags, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
            rlc_bucket ? bd.pts : (fb_entry *)nullptr, rlc_bucket ? bkp.c : 0u, segtab, d_script);
-    if (split1) HIPCHK(c, hipStreamWaitEvent(s, c->join_ev, 0));
-    if (c->mark_early == 1) {
-        HIPCHK(c, hipEventRecord(c->early_ev, s));
-        c->early_recorded = true;
-    }
     if (shape_verdict) {
         HIPCHK(c, hipMemsetAsync(d_mv, 1, nbatch, s));
         LAUNCH(c, s, "rp_verdict", k_rp_verdict, (nb32 + 63) / 64, 64, nb32, d_status, d_mv, (uint8_t *)d_verdict);
@@ -2231,20 +2191,9 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     if (wide) {
         const bool wide_sums = r5 || a_out;
         // After launch 1 a chain has two INDEPENDENT branches: the proof's own points (window sums -> Horner chain) and the generator terms
-        // (exponents -> table walk); they meet in the finish.  With the Horner chains aside, the whole first branch goes to the second
-        // stream right behind launch 1 (option fork_early, default on) instead of only its last kernel: the critical path of a chain
-        // loses the window sums (stage1 + max(sums + Horner, exponents + walk) + finish instead of stage1 + sums + max(Horner, exponents +
-        // walk) + finish).
-        hipStream_t sw = (aside && c->fork_early == 1) ? c->stream2 : s;
-        const bool exp_aside = aside && c->fork_early == 2;   // the generator exponents beside the window sums (second stream), the walk right behind the sums
-        if (sw != s || exp_aside) {
-            HIPCHK(c, hipEventRecord(c->fork_ev, s));
-            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->fork_ev, 0));
-        }
-        if (exp_aside) {
-            LAUNCH(c, c->stream2, "rp_stage3", k_rp_exponents, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
-            HIPCHK(c, hipEventRecord(c->exp_ev, c->stream2));
-        }
+        // (exponents -> table walk); they meet in the finish.  With the Horner chains aside, the first branch's LAST kernel goes to the
+        // second stream.  (Moving the whole branch there, or the exponents instead, were options until round 6: no gain in their A/B.)
+        hipStream_t sw = s;
         if (r5) {
             const uint32_t nw5 = nb32 * BP_VB5_WINDOWS;
             LAUNCH(c, sw, "rp_stage3w", k_vb_window_wide<true>, (nw5 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nw5, sh.U, a_out ? 1u : 0u, d.tab, d.recoded, d_colc);
@@ -2259,10 +2208,8 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
                 const uint32_t nc = nb32 * 64;
                 LAUNCH(c, sw, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, (uint32_t *)nullptr, d_colc);
             }
-            if (sw == s) {
-                HIPCHK(c, hipEventRecord(exp_aside ? c->fork2_ev : c->fork_ev, s));
-                HIPCHK(c, hipStreamWaitEvent(c->stream2, exp_aside ? c->fork2_ev : c->fork_ev, 0));
-            }
+            HIPCHK(c, hipEventRecord(c->fork_ev, s));
+            HIPCHK(c, hipStreamWaitEvent(c->stream2, c->fork_ev, 0));
             const uint32_t n_hb = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
             const ge_cached *extra = a_out ? d.tab : (const ge_cached *)nullptr;
             if (r5) LAUNCH(c, c->stream2, "rp_horner1", k_rp_horner_wide<true>, n_hb, FB_BLOCK, nb32, d_colc, extra, 16u * sh.U, d.hq);
@@ -2271,8 +2218,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
             HIPCHK(c, hipEventRecord(c->join_ev, c->stream2));
             horner_aside = true;
         }
-        if (exp_aside) HIPCHK(c, hipStreamWaitEvent(s, c->exp_ev, 0));
-        else LAUNCH(c, s, "rp_stage3", k_rp_exponents, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
+        LAUNCH(c, s, "rp_stage3", k_rp_exponents, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
     } else {
         LAUNCH(c, s, "rp_stage3", k_rp_stage3, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part,
                (quad && one_chunk) ? d_colc : (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits, d_status);
@@ -2280,10 +2226,6 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     if (quad && !one_chunk && !horner_aside) {
         const uint32_t nc = nb32 * 64;
         LAUNCH(c, s, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, (uint32_t *)nullptr, d_colc);
-    }
-    if (c->mark_early == 2) {   // everything in front of the table walk has been enqueued on s
-        HIPCHK(c, hipEventRecord(c->early_ev, s));
-        c->early_recorded = true;
     }
     const uint32_t nblk_p = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
     if (horner_aside) {
@@ -2384,18 +2326,6 @@ int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof
     c->busy_hint = -1;
     const int rc2 = ctx_leave(c, s);
     return rc ? rc : rc2;
-}
-// Staggered bursts (pool option "stagger_chains"): the pool asks a lane to mark the end of its chain's early phase and makes the NEXT chain's
-// stream wait for it, so that two chains of a burst do not run their latency-bound early phases against each other and then their walks
-// against each other (profiles/r05/cfg3_burst_timeline.txt): chain B's early phase runs beside chain A's walk instead.
-void bpgpu_internal_mark_early(bpgpu_ctx *c, int mode) {
-    std::lock_guard<std::mutex> lk(c->mu);
-    c->mark_early = mode;
-    c->early_recorded = false;
-}
-void *bpgpu_internal_early_event(bpgpu_ctx *c) {   // null when the last chain recorded none (batch-combined chains, shape verdicts before the walk)
-    std::lock_guard<std::mutex> lk(c->mu);
-    return c->early_recorded ? (void *)c->early_ev : nullptr;
 }
 // buffers of the context sized for chains of up to `nbatch_max` proofs of this shape (see rp_verify_dev_locked, reserve_only)
 int bpgpu_internal_rp_reserve(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, size_t nbatch_max) {

@@ -92,36 +92,6 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1_coop(rp_shape sh, rp_str
     }
 }
 
-// the lane-serial role of launch 1 (scripted transcript + per-proof scalars) as a launch of its own, WITHOUT the register cap of the
-// fused kernel: option "split_stage1" runs the decode role beside it on the second stream (k_rp_points).  A few dozen wavefronts: one
-// per SIMD is plenty, and without the cap nothing spills.
-__global__ void __launch_bounds__(RP_BLOCK) k_rp_transcript(rp_shape sh, rp_strobe_init init, const uint8_t *proofs, const uint8_t *commitments, const uint8_t *rng64,
-                                                            uint32_t *fields, uint32_t *status, fb_params prm, uint32_t lg_m, uint32_t *recoded, fb_digit *digits,
-                                                            const uint8_t *rho64, const uint32_t *ts_in, uint32_t *ts_out, uint32_t bk_c, rp_seg_tab segs,
-                                                            const rp_script_hdr *script) {
-    __shared__ uint32_t lds[50 * RP_BLOCK];
-    const uint32_t p = blockIdx.x * RP_BLOCK + threadIdx.x;
-    kstate st;
-    st.w = lds + threadIdx.x;
-    st.stride = RP_BLOCK;
-    if (p < sh.nproofs) {
-        rp_transcript_scripted(p, sh, init, st, rp_resolve(p, sh, proofs, commitments, rng64, segs), script, fields, status, ts_out, ts_in);
-        if (!sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64, bk_c);
-    }
-}
-
-// the point-decode role of launch 1 as a launch of its own (option "split_stage1": runs on the context's second stream beside the
-// transcript kernel, with its own register budget instead of the transcript role's)
-template <int WAVES>
-__global__ void __attribute__((amdgpu_waves_per_eu(WAVES, WAVES))) __launch_bounds__(RP_BLOCK) k_rp_points(rp_shape sh, const uint8_t *proofs, const uint8_t *commitments,
-                                                                                                      ge_cached *tab, uint32_t *status, fb_entry *bk_pts, rp_seg_tab segs) {
-    const uint32_t t = blockIdx.x * RP_BLOCK + threadIdx.x;
-    if (t < sh.nproofs * sh.U) rp_points_thread(t, sh, rp_resolve(t / sh.U, sh, proofs, commitments, nullptr, segs), tab, status, bk_pts);
-}
-template __global__ void k_rp_points<1>(rp_shape, const uint8_t *, const uint8_t *, ge_cached *, uint32_t *, fb_entry *, rp_seg_tab);
-template __global__ void k_rp_points<2>(rp_shape, const uint8_t *, const uint8_t *, ge_cached *, uint32_t *, fb_entry *, rp_seg_tab);
-template __global__ void k_rp_points<3>(rp_shape, const uint8_t *, const uint8_t *, ge_cached *, uint32_t *, fb_entry *, rp_seg_tab);
-
 // verdict[p] = status (Format / shape / Verification) if set, else the identity test of the mega-check
 __global__ void __launch_bounds__(64) k_rp_verdict(uint32_t n, uint32_t *status, const uint8_t *msm_verdict, uint8_t *out) {
     const uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;

@@ -60,8 +60,6 @@ void bpgpu_internal_set_busy_hint(bpgpu_ctx *c, int busy);
 int bpgpu_internal_rp_verify_segs(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, const uint8_t *const *labels, size_t label_len, const rp_seg *segs,
                                   uint32_t nseg, bool any_msm, uint32_t splits_hint, int busy, bool rlc);
 void *bpgpu_internal_stream(bpgpu_ctx *c);
-void bpgpu_internal_mark_early(bpgpu_ctx *c, int mode);
-void *bpgpu_internal_early_event(bpgpu_ctx *c);
 int bpgpu_internal_rp_reserve(bpgpu_ctx *c, size_t n, size_t m, size_t proof_len, size_t nbatch_max);
 extern "C" int bpgpu_internal_release_tables(bpgpu_ctx *c);
 int bpgpu_internal_rp_verify_chain(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len, const void *d_commitments,
@@ -366,7 +364,8 @@ struct pool_dev {
     std::atomic<uint32_t> kick{0}, svc_sleeping{0};
     std::atomic<uint32_t> free_waiters{0};  // callers asleep on free_cv (counted in under cmu)
     std::thread svc, dlv;
-    bool svc_running = false, cstop = false;
+    bool svc_running = false;
+    std::atomic<bool> cstop{false};   // (atomic: the service thread reads it on every poll and must never wait for `cmu`, which a caller may hold across a buffer's first allocation)
     struct cls_ent {
         comb_key key;
         uint64_t id, last_use;
@@ -403,21 +402,14 @@ struct bpgpu_pool {
     size_t latency_proofs = 6144;    // a host call / a flush on an idle device of up to this many proofs is "alone": its chains take the latency forms
     size_t auto_flush_items = 0;     // flush by itself once this many items wait on a device (0 = lanes)
     size_t auto_flush_proofs = 0;    // ... or once this many proofs wait: they go out as ONE chain while the caller keeps submitting (0 = off)
-    // How a flush is cut into chains: 0 = by proof count alone (round 4); 1 = in proportion to table-walk work ((2nm+2) generator terms per
-    // proof, in (64,1)-proof equivalents: every chain carries about coalesce_proofs equivalents); 2 (default) = by proof count, but a LONE
-    // chain that carries two chains' worth of work is cut in two.  Measured on BASELINE configs 3 / 4 (profiles/r05/plan_by_work_ab.txt, one box
-    // per table): 20 x 256 proofs of m = 16 as one chain of 5120 / two of 2560 / fourteen of 384: 537 / 574 / 523 k/s; 20 x 512 of m = 32 as two
-    // of 5120 / four of 2560 / eight of 1344: 319 / 311 / 248 k/s -- what a burst wants is TWO overlapping chains, whatever the proofs weigh;
-    // launch 1's lane-serial transcript is per proof, so many narrow chains pay it many times over
-    int plan_by_work = 2;
-    // Staggered bursts: chain i + 1 of a flush starts behind chain i's early phase (1: behind its launch 1; 2: behind its generator exponents, i.e.
-    // when its table walk begins) instead of beside it.  0 = all chains of a flush start at once.
-    int stagger_chains = 0;
+    // A flush is cut into chains by proof count, except that a LONE chain carrying two chains' worth of table-walk work is cut in two
+    // (split_lone_heavy).  Two alternatives were built, measured and removed in round 6: chains in proportion to work (BASELINE configs 3 / 4:
+    // -4 % / -23 %, profiles/r05/plan_by_work_ab.txt -- a burst wants TWO overlapping chains whatever the proofs weigh) and staggered starts
+    // (chain i + 1 behind chain i's early phase: slower in every row of profiles/r05/stagger_chains_ab.txt).
     // Batch-combined items of unrelated submitters normally share ONE identity check per chain: a single bad proof then leaves every
     // proof of every batch of that chain undecided, and each submitter has to find out alone (one hostile submitter sends
     // everybody to the slow path).  1 = a chain never carries more than one batch-combined item: a failure stays with its own batch.
     int rlc_isolate = 0;
-    size_t plan_min_chain_proofs = 0;   // ... but no chain of a burst narrower than this many proofs of its shape (0 = no floor): launch 1's lane-serial roles are per PROOF
     size_t host_workers = 0;
     // combining queue
     std::atomic<uint32_t> comb_cap_max{5120};         // = coalesce_proofs (readable without `mu`)
@@ -433,21 +425,17 @@ struct bpgpu_pool {
     std::atomic<uint32_t> combine_wide_proofs{384};
     std::atomic<uint32_t> combine_inflight_wide{3};
     std::atomic<uint64_t> combine_hold_ns{400000};
-    // cohort policy (combine_policy = 1; 0 = the two regimes above; 2, the default, = per kind of work, see svc_main): callers come back in the groups their chains released them in
+    // cohort policy (the multiscalar-multiplication and inner-product kinds, see svc_main; range proofs keep the two regimes above): callers come back in the groups their chains released them in
     // -- a chain's worth of requests completes at once, its owners resubmit within tens of microseconds --, so a buffer leaves as soon as the
     // group that just finished is back (no quiet period to sit out), at most combine_cohort_inflight chains run (a chain's latency is nearly
     // flat in its width and grows with every chain beside it: few wide chains beat many narrow ones on throughput AND latency), and a
     // fragment that arrives while the device is busy waits for company
-    std::atomic<uint32_t> combine_policy{2};
     std::atomic<uint32_t> combine_cohort_inflight{2};
     std::atomic<uint64_t> combine_regroup_ns{60000};     // after a completion with nothing else in flight: this long for its callers to come back before `quiet` may seal
     std::atomic<uint64_t> combine_msm_bytes{32u << 20};   // staging block of a multiscalar-multiplication class (bpgpu_pool_msm_*): items per chain = this / bytes per MSM
-    // multiscalar multiplications bring 264 kB each (config 5's shape) and every byte is read exactly ONCE, by the first kernels of the chain
-    // (scalar recoding, point decoding).  1 = those kernels read the pinned host block in place instead of waiting for a staging copy of the
-    // whole buffer (7 MB per 28-MSM chain, ~0.3 ms).  Measured WORSE and therefore off: 64 blocking threads 34.2 / 33.7 k MSMs/s with the copy,
-    // 26.3 / 24.8 k/s reading in place, one thread 0.81 against 0.84 ms (profiles/r05/msm_queue_ab.txt) -- 133 000 lanes each fetching 64 bytes
-    // across PCIe pay its latency inside the decode kernel, the copy engine streams the same bytes at line rate beside other chains' kernels
-    std::atomic<uint32_t> combine_mapped_in{0};
+    // (Reading an MSM chain's 7 MB of inputs in place from the pinned block instead of staging them was measured and removed: 64 blocking
+    // threads 34 -> 26 k MSMs/s, profiles/r05/msm_queue_ab.txt -- 133 000 lanes fetching 64 bytes each across PCIe pay its latency inside
+    // the decode kernel, the copy engine streams the same bytes at line rate beside other chains' kernels.)
     std::atomic<uint32_t> combine_mapped_out{1024};   // chains of up to this many proofs write their results straight into the pinned host block (no copy command behind the chain)
     std::atomic<uint32_t> combine_trace{0};           // ring sizes of the timeline records (0 = off)
     std::atomic<int> host_path{1};                    // bpgpu_pool_rangeproof_verify: 1 = through the combining queue, 0 = the slicing workers of round 3
@@ -653,23 +641,8 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
         p->auto_flush_items = (size_t)value;
         return BPGPU_OK;
     }
-    if (!strcmp(key, "plan_by_work")) {
-        if (value < 0 || value > 2) return pfail(p, BPGPU_ERR_INVALID_ARG, "plan_by_work out of range");
-        p->plan_by_work = (int)value;
-        return BPGPU_OK;
-    }
     if (!strcmp(key, "rlc_isolate")) {
         p->rlc_isolate = value != 0;
-        return BPGPU_OK;
-    }
-    if (!strcmp(key, "stagger_chains")) {
-        if (value < 0 || value > 2) return pfail(p, BPGPU_ERR_INVALID_ARG, "stagger_chains out of range");
-        p->stagger_chains = (int)value;
-        return BPGPU_OK;
-    }
-    if (!strcmp(key, "plan_min_chain_proofs")) {
-        if (value < 0 || value > (1 << 22)) return pfail(p, BPGPU_ERR_INVALID_ARG, "plan_min_chain_proofs out of range");
-        p->plan_min_chain_proofs = (size_t)value;
         return BPGPU_OK;
     }
     if (!strcmp(key, "stat_reset")) {
@@ -680,9 +653,9 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
         }
         return BPGPU_OK;
     }
-    if (!strcmp(key, "combine_wait_us") || !strcmp(key, "combine_quiet_us") || !strcmp(key, "combine_poll_us")) {
+    if (!strcmp(key, "combine_wait_us") || !strcmp(key, "combine_quiet_us")) {
         if (value < 1 || value > 1000000) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
-        (key[8] == 'w' ? p->combine_wait_ns : key[8] == 'q' ? p->combine_quiet_ns : p->combine_poll_ns) = (uint64_t)value * 1000;
+        (key[8] == 'w' ? p->combine_wait_ns : p->combine_quiet_ns) = (uint64_t)value * 1000;
         return BPGPU_OK;
     }
     if (!strcmp(key, "combine_busy_chains") || !strcmp(key, "combine_inflight")) {
@@ -690,33 +663,14 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
         (key[8] == 'b' ? p->combine_busy_chains : p->combine_inflight) = (uint32_t)value;
         return BPGPU_OK;
     }
-    if (!strcmp(key, "combine_max_age_us") || !strcmp(key, "combine_hold_us")) {
+    if (!strcmp(key, "combine_max_age_us")) {
         if (value < 1 || value > 10000000) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
-        (key[8] == 'm' ? p->combine_max_age_ns : p->combine_hold_ns) = (uint64_t)value * 1000;
+        p->combine_max_age_ns = (uint64_t)value * 1000;
         return BPGPU_OK;
     }
-    if (!strcmp(key, "combine_mapped_in")) {
-        p->combine_mapped_in = value != 0;
-        return BPGPU_OK;
-    }
-    if (!strcmp(key, "combine_wide_proofs") || !strcmp(key, "combine_mapped_out")) {
+    if (!strcmp(key, "combine_mapped_out")) {
         if (value < 0 || value > (1 << 22)) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
-        (key[8] == 'w' ? p->combine_wide_proofs : p->combine_mapped_out) = (uint32_t)value;
-        return BPGPU_OK;
-    }
-    if (!strcmp(key, "combine_policy") || !strcmp(key, "combine_cohort_inflight")) {
-        if (value < 0 || value > 64 || (key[8] == 'c' && value < 1)) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
-        (key[8] == 'p' ? p->combine_policy : p->combine_cohort_inflight) = (uint32_t)value;
-        return BPGPU_OK;
-    }
-    if (!strcmp(key, "combine_regroup_us")) {
-        if (value < 0 || value > 1000000) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
-        p->combine_regroup_ns = (uint64_t)value * 1000;
-        return BPGPU_OK;
-    }
-    if (!strcmp(key, "combine_inflight_wide")) {
-        if (value < 1 || value > 64) return pfail(p, BPGPU_ERR_INVALID_ARG, "%s out of range", key);
-        p->combine_inflight_wide = (uint32_t)value;
+        p->combine_mapped_out = (uint32_t)value;
         return BPGPU_OK;
     }
     if (!strcmp(key, "combine_msm_bytes")) {
@@ -760,6 +714,21 @@ int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {
     return BPGPU_OK;
 }
 
+// The constants of the two sealing policies and the service thread's polling period: chosen by the sweeps of round 5 (profiles/r05/
+// combine_sweep_first_call.txt, combine_policy_ab.txt), not part of the option surface; the scheduler's test suite (tests/cpu_pool) moves them
+// to reach every branch.  hold_us, wide_proofs, inflight_wide, cohort_inflight, regroup_us, poll_us.
+int bpgpu_internal_pool_tune(bpgpu_pool *p, const char *key, int64_t value) {
+    if (!p || !key || value < 0) return BPGPU_ERR_INVALID_ARG;
+    if (!strcmp(key, "hold_us")) p->combine_hold_ns = (uint64_t)value * 1000;
+    else if (!strcmp(key, "wide_proofs")) p->combine_wide_proofs = (uint32_t)value;
+    else if (!strcmp(key, "inflight_wide")) p->combine_inflight_wide = value < 1 ? 1u : (uint32_t)value;
+    else if (!strcmp(key, "cohort_inflight")) p->combine_cohort_inflight = value < 1 ? 1u : (uint32_t)value;
+    else if (!strcmp(key, "regroup_us")) p->combine_regroup_ns = (uint64_t)value * 1000;
+    else if (!strcmp(key, "poll_us")) p->combine_poll_ns = (value < 1 ? 1 : (uint64_t)value) * 1000;
+    else return BPGPU_ERR_INVALID_ARG;
+    return BPGPU_OK;
+}
+
 int bpgpu_pool_get_option(bpgpu_pool *p, const char *key, int64_t *value) {
     if (!p || !key || !value) return BPGPU_ERR_INVALID_ARG;
     std::lock_guard<std::mutex> lk(p->mu);
@@ -768,9 +737,6 @@ int bpgpu_pool_get_option(bpgpu_pool *p, const char *key, int64_t *value) {
     else if (!strcmp(key, "slice_proofs")) *value = (int64_t)p->slice_proofs;
     else if (!strcmp(key, "auto_flush_items")) *value = (int64_t)p->auto_flush_items;
     else if (!strcmp(key, "auto_flush_proofs")) *value = (int64_t)p->auto_flush_proofs;
-    else if (!strcmp(key, "plan_by_work")) *value = (int64_t)p->plan_by_work;
-    else if (!strcmp(key, "plan_min_chain_proofs")) *value = (int64_t)p->plan_min_chain_proofs;
-    else if (!strcmp(key, "stagger_chains")) *value = (int64_t)p->stagger_chains;
     else if (!strcmp(key, "rlc_isolate")) *value = (int64_t)p->rlc_isolate;
     else if (!strcmp(key, "latency_proofs")) *value = (int64_t)p->latency_proofs;
     else if (!strcmp(key, "pair_limit_proofs")) *value = (int64_t)p->pair_limit_proofs;
@@ -780,20 +746,12 @@ int bpgpu_pool_get_option(bpgpu_pool *p, const char *key, int64_t *value) {
     else if (!strcmp(key, "stat_last_splits")) *value = (int64_t)p->stat_last_splits;
     else if (!strcmp(key, "combine_wait_us")) *value = (int64_t)(p->combine_wait_ns / 1000);
     else if (!strcmp(key, "combine_quiet_us")) *value = (int64_t)(p->combine_quiet_ns / 1000);
-    else if (!strcmp(key, "combine_poll_us")) *value = (int64_t)(p->combine_poll_ns / 1000);
     else if (!strcmp(key, "combine_max_open")) *value = (int64_t)p->combine_max_open;
     else if (!strcmp(key, "combine_busy_chains")) *value = (int64_t)p->combine_busy_chains;
     else if (!strcmp(key, "combine_inflight")) *value = (int64_t)p->combine_inflight;
     else if (!strcmp(key, "combine_max_age_us")) *value = (int64_t)(p->combine_max_age_ns / 1000);
-    else if (!strcmp(key, "combine_hold_us")) *value = (int64_t)(p->combine_hold_ns / 1000);
-    else if (!strcmp(key, "combine_wide_proofs")) *value = (int64_t)p->combine_wide_proofs;
-    else if (!strcmp(key, "combine_inflight_wide")) *value = (int64_t)p->combine_inflight_wide;
-    else if (!strcmp(key, "combine_policy")) *value = (int64_t)p->combine_policy;
-    else if (!strcmp(key, "combine_cohort_inflight")) *value = (int64_t)p->combine_cohort_inflight;
-    else if (!strcmp(key, "combine_regroup_us")) *value = (int64_t)(p->combine_regroup_ns / 1000);
     else if (!strcmp(key, "combine_msm_bytes")) *value = (int64_t)p->combine_msm_bytes;
     else if (!strcmp(key, "combine_mapped_out")) *value = (int64_t)p->combine_mapped_out;
-    else if (!strcmp(key, "combine_mapped_in")) *value = (int64_t)p->combine_mapped_in;
     else if (!strcmp(key, "combine_trace")) *value = (int64_t)p->combine_trace;
     else if (!strcmp(key, "stat_svc_issue_us") || !strcmp(key, "stat_svc_complete_us") || !strcmp(key, "stat_svc_polls") || !strcmp(key, "stat_svc_deliver_us")) {
         uint64_t v = 0;
@@ -1042,9 +1000,21 @@ static int cbuf_configure(bpgpu_pool *p, pool_dev *d, comb_buf *b, const comb_ke
         b->d = nullptr;
         b->mem_cap = 0;
         const size_t want = need + need / 4;
-        if (e == hipSuccess) e = hipHostMalloc((void **)&b->h, want, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc((void **)&b->d, want);
+        // Kernels of narrow chains write verdicts straight into this block and the host reads them after hipEventQuery on an event without
+        // a system-scope release: the block must be fine-grained (coherent) whatever HIP_HOST_COHERENT says.  When the coherent mapped
+        // allocation is refused the block is plain pinned memory and every chain takes the copy path (hd stays null).
+        bool coherent = true;
         if (e == hipSuccess) {
+            e = hipHostMalloc((void **)&b->h, want, hipHostMallocCoherent | hipHostMallocMapped);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                coherent = false;
+                b->h = nullptr;
+                e = hipHostMalloc((void **)&b->h, want, hipHostMallocDefault);
+            }
+        }
+        if (e == hipSuccess) e = hipMalloc((void **)&b->d, want);
+        if (e == hipSuccess && coherent) {
             void *dp = nullptr;
             if (hipHostGetDevicePointer(&dp, b->h, 0) == hipSuccess) b->hd = (char *)dp;
             else (void)hipGetLastError();
@@ -1141,11 +1111,9 @@ static void comb_issue(bpgpu_pool *p, pool_dev *d, comb_buf *b, uint32_t infligh
         if (e != hipSuccess || !bytes) return;
         e = in ? hipMemcpyAsync(b->d + off, b->h + off, bytes, hipMemcpyHostToDevice, s) : hipMemcpyAsync(b->h + off, b->d + off, bytes, hipMemcpyDeviceToHost, s);
     };
-    // inputs: one copy up to the fill of the last region when the unused tails that ride along are small, else one copy per region --
-    // or none at all: the MSM kinds' first kernels read the pinned block in place (combine_mapped_in)
-    const bool mapped_in = b->hd && (k.kind == CQ_MSM_SHARED || k.kind == CQ_MSM) && p->combine_mapped_in.load(std::memory_order_relaxed) != 0;
-    char *ib = mapped_in ? b->hd : b->d;
-    if (!mapped_in) {
+    // inputs: one copy up to the fill of the last region when the unused tails that ride along are small, else one copy per region
+    char *ib = b->d;
+    {
         const uint32_t last = g.n_in - 1;
         const size_t span = b->in_off[last] + (size_t)K * g.in_sz[last];
         size_t useful = 0;
@@ -1279,7 +1247,7 @@ static void dlv_main(bpgpu_pool *p, pool_dev *d) {
 //     completion's resubmissions) -- chains then stay about as wide as the population of requests allows instead of being cut into
 //     combine_wait_us slices of the arrival stream;
 //   always: nothing waits longer than combine_max_age_us.
-// Cohort policy (combine_policy = 1).  `expected` / t_done: width and completion time of the chain of this kind that finished last --
+// Cohort policy (the multiscalar-multiplication and inner-product kinds).  `expected` / t_done: width and completion time of the chain of this kind that finished last --
 // its callers are on their way back.
 //   * the group is back (r >= expected): leave at once -- a lone caller's next call does not sit out a quiet period, sixty-four
 //     callers released together travel together again;
@@ -1342,21 +1310,23 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
     (void)hipSetDevice(d->device);
     prctl(PR_SET_TIMERSLACK, 1000UL, 0, 0, 0);   // this thread's timed waits are tens of microseconds: the default slack is 50
     // Hundreds of caller threads become runnable whenever a chain ends; the one thread that issues the next chain must not queue
-    // behind them for a time slice.  Best effort (needs CAP_SYS_NICE): a real-time class, else a negative nice value.  The thread
-    // sleeps whenever it has nothing to do, so it cannot monopolise a core.
+    // behind them for a time slice.  By default the thread only asks for a negative nice value (best effort, no effect without the
+    // privilege); a real-time class inside a host application is the application's decision: environment BPGPU_SERVICE_SCHED=rr
+    // (SCHED_RR priority 1, needs CAP_SYS_NICE), =none (leave the thread alone).  The thread sleeps whenever it has nothing to do.
     {
-        sched_param sp{};
-        sp.sched_priority = 1;
-        if (pthread_setschedparam(pthread_self(), SCHED_RR, &sp) != 0) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), -15);
+        const char *how = getenv("BPGPU_SERVICE_SCHED");
+        if (how && !strcmp(how, "rr")) {
+            sched_param sp{};
+            sp.sched_priority = 1;
+            if (pthread_setschedparam(pthread_self(), SCHED_RR, &sp) != 0) (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), -15);
+        } else if (!how || strcmp(how, "none")) {
+            (void)setpriority(PRIO_PROCESS, (id_t)syscall(SYS_gettid), -15);
+        }
     }
     std::vector<comb_buf *> to_issue, to_complete;
     for (;;) {
         const uint32_t kick0 = d->kick.load(std::memory_order_seq_cst);   // (before the scan: whatever happens after this read rings the bell)
-        bool stopping;
-        {
-            std::lock_guard<std::mutex> lk(d->cmu);
-            stopping = d->cstop;
-        }
+        const bool stopping = d->cstop.load(std::memory_order_acquire);
         bool active = false, all_free = true;
         const uint64_t now = now_ns();
         d->stat_polls.fetch_add(1, std::memory_order_relaxed);
@@ -1386,16 +1356,15 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
                 else if (r != b->seen_reserved) b->seen_reserved = r, b->t_change = now;
                 bool seal = cbs_sealed(s);   // a caller took the last slot
                 const uint32_t kd = b->key.kind & 3;
-                // combine_policy: 0 = the two regimes for every kind; 1 = cohorts for every kind; 2 (default) = what the device measured best
-                // (profiles/r05/combine_policy_ab.txt): range proofs keep the regimes -- four to six narrow chains in flight overlap well, 64
+                // per kind of work, as the device measured best (profiles/r05/combine_policy_ab.txt; "cohorts for every kind" and "regimes for
+                // every kind" were options until round 6): range proofs keep the regimes -- four to six narrow chains in flight overlap well, 64
                 // blocking threads 81 k/s against 66 k/s in cohorts, 16 x 128 tickets 795 against 700 k/s -- plus the cohort rule for a handful
                 // of callers (a lone caller's next call leaves at once: 0.557 -> 0.529 ms per call); multiscalar multiplications and
                 // inner-product proofs, whose chains are a dozen launches of bucket work each, travel in cohorts (64 threads 26.7 -> 32.5 k MSMs/s)
-                const uint32_t pol = p->combine_policy.load(std::memory_order_relaxed);
-                const bool cohort = pol == 1 || (pol == 2 && b->key.kind != CQ_RP);
+                const bool cohort = b->key.kind != CQ_RP;
                 bool due = cohort ? policy_seal_cohort(p, r, now, b->t_open, b->t_change, inflight, inflight_all_items, n_free, d->last_done_K[kd], d->t_last_done[kd])
                                   : policy_seal(p, r, now, b->t_open, b->t_change, inflight, inflight_items, b->key.kind == CQ_RP, n_free);
-                if (!due && pol == 2 && !cohort && d->last_done_K[kd] != 0 && d->last_done_K[kd] <= 4 && r >= d->last_done_K[kd] &&
+                if (!due && !cohort && d->last_done_K[kd] != 0 && d->last_done_K[kd] <= 4 && r >= d->last_done_K[kd] &&
                     now - d->t_last_done[kd] < 4 * p->combine_regroup_ns.load(std::memory_order_relaxed) && inflight == 0)
                     due = true;   // the few callers the last chain released are all back and nothing else runs: nothing to wait for
                 if (!seal && (stopping || due)) {
@@ -1481,10 +1450,7 @@ static inline void svc_kick(pool_dev *d) {
 // bpgpu_pool_destroy: first every device is told to stop (callers blocked on ANY device keep `active_calls` up, and a service thread
 // leaves only when that reads zero), then the threads are joined
 static void signal_service_stop(pool_dev *d) {
-    {
-        std::lock_guard<std::mutex> lk(d->cmu);
-        d->cstop = true;
-    }
+    d->cstop.store(true, std::memory_order_release);
     svc_kick(d);
     d->free_cv.notify_all();   // callers waiting for a free buffer see `closing`
 }
@@ -1934,6 +1900,7 @@ static int msm_shared_run(bpgpu_pool *p, comb_req *r, size_t n, size_t m, size_t
         if (r->async) return pfail(p, BPGPU_ERR_INVALID_ARG, "shape not served by the combining queue");
         std::lock_guard<std::mutex> lk(d0->misc_mu);
         const int rc = bpgpu_msm_batch_shared(d0->misc, n, m, r->nbatch, n_unique, gen_scalars, uniq_scalars, uniq_points, r->out[0], r->out[1]);
+        if (rc) mark_undecided(r->out[1], r->nbatch);   // (no status byte of a failed call reads 0, whatever the context wrote)
         return rc ? pfail(p, rc, "%s", bpgpu_last_error(d0->misc)) : BPGPU_OK;
     }
     comb_key base;
@@ -2007,9 +1974,7 @@ int bpgpu_pool_msm_batch(bpgpu_pool *p, size_t nbatch, const uint32_t *n_terms, 
         size_t j = i + 1;
         while (j < nbatch && n_terms[j] == n_terms[i]) j++;
         const size_t nt = n_terms[i];
-        if (nt == 0) {   // the empty sum: the identity (encoding 0), status 0
-            memset(out + i * 32, 0, (j - i) * 32);
-            memset(status + i, 0, j - i);
+        if (nt == 0) {   // the empty sum (written below, once every other stretch has come back without an error)
         } else if (nt > (1u << 22)) {
             rc = pfail(p, BPGPU_ERR_INVALID_ARG, "MSM %zu has too many terms for the combining queue", i);
         } else {
@@ -2025,6 +1990,15 @@ int bpgpu_pool_msm_batch(bpgpu_pool *p, size_t nbatch, const uint32_t *n_terms, 
     }
     while (r.next_piece < r.pieces.size()) comb_collect_one(p, &r);
     if (!rc && r.rc) rc = pfail(p, r.rc, "%s", r.err.c_str());
+    if (rc) {   // the header's promise: on a non-zero return no status byte of the call reads 0
+        mark_undecided(status, nbatch);
+        return rc;
+    }
+    for (size_t k = 0; k < nbatch; k++)
+        if (n_terms[k] == 0) {   // the empty sum: the identity (encoding 0), status 0
+            memset(out + k * 32, 0, 32);
+            status[k] = 0;
+        }
     return rc;
 }
 
@@ -2043,6 +2017,7 @@ int bpgpu_pool_ipp_verify(bpgpu_pool *p, size_t n, size_t nbatch, const uint8_t 
     if (n == 0 || n > 65536 || proof_len == 0 || proof_len > 4096 || proof_len % 4 != 0 || nbatch > (1u << 24)) {   // (malformed lengths: reported per proof by the ordinary entry point)
         std::lock_guard<std::mutex> lk(d0->misc_mu);
         const int rc = bpgpu_ipp_verify_batch(d0->misc, n, nbatch, proofs, proof_len, label, label_len, G_factors, H_factors, P, Q, G, H, verdict, msm_out);
+        if (rc) mark_undecided(verdict, nbatch);   // (whatever the context wrote before it failed: no verdict byte of a failed call reads 0)
         return rc ? pfail(p, rc, "%s", bpgpu_last_error(d0->misc)) : BPGPU_OK;
     }
     comb_req r;
@@ -2255,18 +2230,8 @@ extern "C" void bpgpu_internal_plan_flush(uint64_t T, uint64_t coalesce_proofs, 
 // 81 000 single proofs would be (20 x 256 proofs of m = 16 went out as ONE chain alone on the device).  plan_flush
 // therefore counts in (64,1)-proof equivalents; a chain's width in proofs of ITS shape follows from the equivalents it may carry.
 static size_t work_equiv(size_t nbatch, size_t n, size_t m) { return (nbatch * (2 * n * m + 2) + 129) / 130; }
-static size_t chain_width(size_t per_equiv, size_t n, size_t m, size_t max_chain_proofs) {
-    size_t per = (per_equiv * 130 + (2 * n * m + 2) - 1) / (2 * n * m + 2);
-    per = (per + 63) & ~(size_t)63;   // whole transcript wavefronts
-    if (per > max_chain_proofs) per = max_chain_proofs;
-    if (per < 1) per = 1;
-    return per;
-}
 extern "C" uint64_t bpgpu_internal_work_equiv(uint64_t nbatch, uint64_t n, uint64_t m) { return work_equiv((size_t)nbatch, (size_t)n, (size_t)m); }
-extern "C" uint64_t bpgpu_internal_chain_width(uint64_t per_equiv, uint64_t n, uint64_t m, uint64_t max_chain_proofs) {
-    return chain_width((size_t)per_equiv, (size_t)n, (size_t)m, (size_t)max_chain_proofs);
-}
-// plan_by_work = 2: the plan by proof count stands, except that ONE chain carrying at least two chains' worth of work (2 x coalesce_proofs
+// The plan by proof count stands, except that ONE chain carrying at least two chains' worth of work (2 x coalesce_proofs
 // equivalents) becomes two -- the second chain's launch 1 then overlaps the first one's table walk, as it does in every burst of single proofs
 static flush_plan split_lone_heavy(flush_plan fp, size_t T_proofs, size_t T_work, size_t coalesce_proofs, size_t lanes, bool all_rlc, bool one_chain) {
     if (fp.chains != 1 || one_chain || all_rlc || lanes < 2 || T_proofs < 128 || T_work < 2 * coalesce_proofs) return fp;
@@ -2322,8 +2287,6 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
     size_t T = d->pending_proofs, T_work = 0;
     d->pending_proofs = 0;
     for (const dev_item &it : items) T_work += work_equiv(it.nbatch, it.n ? it.n : 1, it.m ? it.m : 1);
-    const bool by_work = p->plan_by_work == 1;
-    if (by_work) T = T_work;
     bool was_idle = false;
     // an idle pool starts again at lane 0: a caller that sends bursts keeps hitting the same few lanes, whose arenas and cached
     // work decompositions already have the right size
@@ -2336,7 +2299,7 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
     bool all_rlc = !items.empty();
     for (const dev_item &it : items) all_rlc = all_rlc && it.rlc;
     flush_plan fp = plan_flush(T, p->coalesce_proofs, p->pair_limit_proofs, p->max_chain_proofs, d->lanes.size(), all_rlc, one_chain);
-    if (p->plan_by_work == 2) fp = split_lone_heavy(fp, T, T_work, p->coalesce_proofs, d->lanes.size(), all_rlc, one_chain);
+    fp = split_lone_heavy(fp, T, T_work, p->coalesce_proofs, d->lanes.size(), all_rlc, one_chain);
     const uint32_t hint = fp.splits_hint;
     int rc_all = BPGPU_OK;
     size_t n_undecided = 0;
@@ -2345,7 +2308,6 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
     std::vector<const uint8_t *> labs;   // the label of every segment (all of one length within a chain)
     std::vector<std::pair<size_t, size_t>> carried;   // (item, proofs of it) in the chain being packed
     size_t i = 0, off = 0;   // item i, `off` proofs of it already placed
-    void *prev_early = nullptr;   // (stagger_chains) the event behind the previous chain's early phase
     while (i < items.size()) {
         const dev_item &head = items[i];
         bpgpu_ctx *c = d->lanes[d->next_lane++ % d->lanes.size()];
@@ -2373,8 +2335,7 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
         segs.clear();
         labs.clear();
         carried.clear();
-        size_t per = by_work ? chain_width(fp.per, head.n, head.m, p->max_chain_proofs) : fp.per;   // proofs of THIS shape per chain
-        if (by_work && per < p->plan_min_chain_proofs) per = std::min(p->plan_min_chain_proofs, p->max_chain_proofs);
+        const size_t per = fp.per;   // proofs per chain
         uint32_t filled = 0;
         bool any_msm = false, any_ticket = false;
         while (i < items.size() && filled < per && items[i].same_shape(head)) {
@@ -2408,10 +2369,6 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
                 off = 0;
             }
         }
-        if (p->stagger_chains && !head.rlc) {
-            if (prev_early) (void)hipStreamWaitEvent((hipStream_t)bpgpu_internal_stream(c), (hipEvent_t)prev_early, 0);
-            bpgpu_internal_mark_early(c, p->stagger_chains);
-        }
         const int rc = bpgpu_internal_rp_verify_segs(c, head.n, head.m, head.proof_len, labs.data(), head.label.size(), segs.data(),
                                                      (uint32_t)segs.size(), any_msm, head.rlc ? 0u : hint, (was_idle && T <= p->latency_proofs) ? 0 : 1, head.rlc);   // (the hint is for per-proof table walks: a combined chain walks ONE 1690-pair MSM, which wants all the workgroups it can get)
         {
@@ -2430,10 +2387,6 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
                 rc_all = rc;
                 first_err = bpgpu_last_error(c);
             }
-        }
-        if (p->stagger_chains && !head.rlc) {
-            prev_early = rc ? nullptr : bpgpu_internal_early_event(c);
-            bpgpu_internal_mark_early(c, 0);
         }
         p->stat_chains++;
         p->stat_chain_proofs += filled;

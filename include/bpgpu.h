@@ -98,9 +98,15 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
  *   "per_proof_radix"       radix of the proofs' own points: 0 / 16 (default), 32 (16-entry tables, 51 windows; takes effect on chains
  *                           of >= 2048 proofs; measured +1 % steady, -4 % on bursts)
  *   "split_stage3"          -1 (default): the window sums as their own launch on chains of >= 2048 proofs; 0 / 1: never / always
- *   "split_stage1"          1..3: point decoding as its own launch on the second stream (experiment, default 0)
  *   "transcript_coop"       1 (default): launch chains of up to 256 proofs replay their transcripts 32 lanes per proof (Keccak-f[1600]
  *                           with one state word per lane: one blocking call of 1 proof 0.62 -> 0.53 ms); 0: one lane per proof everywhere
+ *   "msm_fork"              1 (default): bpgpu_msm_batch_shared's generator half on the context's second stream beside the per-MSM points; 0: one stream
+ *   "bucket_chain"          0 (default): MSMs of up to 6144 variable-base terms take the fused bucket chain (csrc/bucket2.h: decode, one LDS
+ *                           sort + accumulate workgroup per (MSM, window), one tail launch); 1: bucket.h's chain everywhere (for A/B)
+ *   "bucket_lanes"          lanes of a (MSM, window) workgroup of the fused chain: 0 = by batch width (default), 64, 128, 256
+ *   "bucket_fast_tail"      -1 (default): batches of fewer than 48 MSMs end with the short-chain tail (leaves of 4 buckets, shuffle sums);
+ *                           0 / 1: never / always
+ *   "fb_walk_waves"         wavefronts the generator half of a fused chain is cut into (0 = 1024)
  * get_option additionally answers "fixed_table_bytes" and the effective "fixed_window_bits".
  * Returns BPGPU_ERR_INVALID_ARG for unknown keys. */
 int bpgpu_ctx_set_option(bpgpu_ctx *ctx, const char *key, int64_t value);
@@ -460,28 +466,36 @@ int bpgpu_ipp_verification_scalars(bpgpu_ctx *ctx, size_t n, size_t nbatch, cons
  * bpgpu_pool_create therefore returns BPGPU_ERR_HW_QUEUES when it finds another value, and, when the value is the library's own,
  * after timing sixteen single-wavefront kernels that spin 1 ms each on sixteen streams (~3 ms in all, best of three) and finding fewer than 6 of them overlapping.
  * bpgpu_pool_last_error is per calling thread: what the last pool call OF THAT THREAD reported.
- * Options (bpgpu_pool_set_option): "coalesce_proofs", "max_chain_proofs" (default 16384), "pair_limit_proofs" (default 24576: a flush
- * of up to this many proofs is issued as at most two chains), "latency_proofs" (default 6144: a host call, or a flush on an idle device, of
- * up to this many proofs is alone on the device -- its chains keep the quad Horner form instead of the one-lane form), "auto_flush_items", "auto_flush_proofs" (default 0 = off: once this many
- * proofs wait they leave as one chain while the caller keeps submitting; measured neutral on 20 x 1024 bursts),
- * "slice_proofs" / "host_workers" (the round-3 host path only); the combining queue: "combine_wait_us" (100), "combine_quiet_us" (20),
- * "combine_max_age_us" (1500), "combine_inflight" (6: deadlines seal buffers only while fewer chains than this run -- beyond, load
- * widens the chains), "combine_busy_chains" (2), "combine_max_open" (4 transcript-position classes with a buffer of their own),
- * "combine_poll_us" (15), "combine_policy" (2: when a staging buffer leaves -- 0 = the two regimes for every kind of work, 1 = cohorts for
- * every kind: a buffer leaves when the group the last chain released is back, at most "combine_cohort_inflight" (2) chains run,
- * "combine_regroup_us" (60) for a group to come back, "combine_hold_us" (400) while the device is busy; 2 = regimes for range proofs,
- * cohorts for the MSM / inner-product kinds, as measured: DESIGN 2b), "combine_wide_proofs" (384) / "combine_inflight_wide" (3) (the
- * regimes' throughput regime), "combine_mapped_out" (1024: chains up to this wide write their results straight into pinned host memory),
- * "combine_mapped_in" (0: MSM chains read their inputs in place instead of copying them first -- measured slower), "combine_msm_bytes",
- * "combine_trace" (ring size of the timeline records, bpgpu_pool_trace_dump); the flush: "plan_by_work" (2: chains by proof count, a LONE
- * chain that carries two chains' worth of table-walk work is cut in two; 0 = by proof count alone; 1 = in proportion to work, with
- * "plan_min_chain_proofs" as a floor -- measured worse on aggregated shapes), "rlc_isolate" (0; 1 = a chain carries at most
- * one batch-combined batch, so that a bad proof leaves only its own batch undecided instead of every batch that shared the check),
- * "stagger_chains" (0: measured worse); any other key is forwarded to every lane context
- * (set those before bpgpu_pool_gens_*; e.g. "msm_fork" = 0: bpgpu_msm_batch_shared's generator half on the chain's own stream).  Read-only
- * statistics: "stat_chains", "stat_chain_proofs" (launch chains issued by flushes and the proofs they carried; set "stat_reset" to
- * zero all statistics), "stat_last_splits", "stat_combined_chains" / "_proofs" / "_requests", "stat_svc_issue_us" /
- * "_complete_us" / "_polls" (the combining queue's service threads). */
+ * Options (bpgpu_pool_set_option; one line each, every one of them is flipped by a test -- tests/test_abi_and_host.py::
+ * test_every_pool_option_is_documented_and_settable, tests/cpu_pool):
+ *   "coalesce_proofs"      5120   target width of a coalesced launch chain
+ *   "max_chain_proofs"     16384  no chain wider than this (a lane's arena: ~55 KB per proof)
+ *   "pair_limit_proofs"    24576  a flush of up to this many proofs is issued as at most two chains
+ *   "latency_proofs"       6144   a host call, or a flush on an idle device, of up to this many proofs is alone: its chains take the latency forms
+ *   "auto_flush_items"     0      flush by itself once this many items wait on a device (0 = the number of lanes)
+ *   "auto_flush_proofs"    0      ... or once this many proofs wait (0 = off)
+ *   "slice_proofs"         0      host-pointer calls of the round-3 host path: proofs per slice (0 = automatic)
+ *   "host_workers"         0      ... and its worker threads (set before the first host-pointer call)
+ *   "host_path_combining"  1      bpgpu_pool_rangeproof_verify through the combining queue (0 = the round-3 slicing workers)
+ *   "rlc_isolate"          0      1 = a chain carries at most one batch-combined batch: a bad proof leaves only its own batch undecided
+ *   "combine_wait_us"      100    a staging buffer leaves at the latest this long after its first request arrived ...
+ *   "combine_quiet_us"     20     ... or when nothing has joined it for this long
+ *   "combine_max_age_us"   1500   ... and no request waits longer than this for its chain to be issued
+ *   "combine_inflight"     6      deadlines seal buffers only while fewer chains than this run: beyond, load widens the chains
+ *   "combine_busy_chains"  2      a chain issued beside this many others takes the throughput forms
+ *   "combine_max_open"     4      transcript-position classes with a staging buffer of their own
+ *   "combine_mapped_out"   1024   chains up to this wide write their results straight into pinned host memory
+ *   "combine_msm_bytes"    32 MiB staging block of a multiscalar-multiplication class: MSMs per chain = this / bytes per MSM
+ *   "combine_trace"        0      ring size of the timeline records (bpgpu_pool_trace_dump)
+ *   "stat_reset"           -      zero all statistics
+ * Any other key is forwarded to every lane context (set those before bpgpu_pool_gens_*).  When a staging buffer leaves is decided per
+ * kind of work, as measured: range proofs by the deadlines above in two regimes, multiscalar multiplications and inner-product
+ * proofs in cohorts (a buffer leaves when the group the last chain released is back); the constants of both policies are not options.
+ * Removed in round 6 because their own A/B refuted them (the tables stay under profiles/r05/): "plan_by_work", "plan_min_chain_proofs",
+ * "stagger_chains", "combine_policy", "combine_mapped_in"; context keys "split_stage1", "fork_early".
+ * Read-only statistics (bpgpu_pool_get_option): "stat_chains", "stat_chain_proofs" (launch chains issued by flushes and the proofs they
+ * carried), "stat_last_splits", "stat_combined_chains" / "_proofs" / "_requests", "stat_svc_issue_us" / "_complete_us" / "_polls" /
+ * "_deliver_us" (the combining queue's service threads), "stat_active_calls", "combine_lanes". */
 typedef struct bpgpu_pool bpgpu_pool;
 int bpgpu_pool_create(const int *devices, int ndev, int lanes_per_device, bpgpu_pool **out);
 void bpgpu_pool_destroy(bpgpu_pool *pool);

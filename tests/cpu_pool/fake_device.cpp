@@ -387,8 +387,6 @@ bool bpgpu_internal_rp_coalescible(bpgpu_ctx *c, size_t n, size_t m, size_t proo
 bool bpgpu_internal_idle(bpgpu_ctx *c) { return hipStreamQuery(c->stream) == hipSuccess; }
 void bpgpu_internal_set_busy_hint(bpgpu_ctx *, int) {}
 void *bpgpu_internal_stream(bpgpu_ctx *c) { return c ? (void *)c->stream : nullptr; }
-void bpgpu_internal_mark_early(bpgpu_ctx *, int) {}                      // (pool option stagger_chains: the fake chain has no phases)
-void *bpgpu_internal_early_event(bpgpu_ctx *) { return nullptr; }
 int bpgpu_internal_rp_reserve(bpgpu_ctx *, size_t, size_t, size_t, size_t) { return BPGPU_OK; }
 int bpgpu_internal_rp_verify_chain(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch, const void *d_proofs, size_t proof_len, const void *d_coms, const uint8_t *shared_ts,
                                    const void *d_ts_in, void *d_ts_out, int, uint32_t, uint32_t, uint32_t, const void *d_rng64, void *d_verdict, void *d_msm_out, uint32_t,

@@ -26,6 +26,7 @@
 
 extern "C" void fake_set_model(uint64_t base_us, uint64_t item_ns, uint64_t beside_us);
 extern "C" void fake_fail_next_chains(int n);
+extern "C" int bpgpu_internal_pool_tune(bpgpu_pool *, const char *, int64_t);
 extern "C" int bpgpu_pool_msm_batch_shared(bpgpu_pool *, size_t, size_t, size_t, size_t, const uint8_t *, const uint8_t *, const uint8_t *, uint8_t *, uint8_t *);
 extern "C" int bpgpu_pool_msm_batch_shared_submit(bpgpu_pool *, size_t, size_t, size_t, size_t, const uint8_t *, const uint8_t *, const uint8_t *, uint8_t *, uint8_t *,
                                                   bpgpu_ticket **);
@@ -401,12 +402,15 @@ int main(int argc, char **argv) {
         // one thread changes the queue's options while the others run
         std::thread tuner([&] {
             std::mt19937_64 g(77);
-            const char *keys[] = {"combine_wait_us", "combine_quiet_us", "combine_inflight", "combine_inflight_wide", "combine_max_open", "combine_hold_us", "combine_wide_proofs",
+            // (inflight_wide, hold_us, wide_proofs: constants of the sealing policy, moved through the library's test hook)
+            const char *keys[] = {"combine_wait_us", "combine_quiet_us", "combine_inflight", "inflight_wide", "combine_max_open", "hold_us", "wide_proofs",
                                   "combine_mapped_out", "coalesce_proofs"};
             const int64_t lo[] = {5, 2, 1, 1, 1, 20, 8, 0, 64}, hi[] = {300, 60, 8, 4, 6, 800, 2000, 4096, 5120};
             while (!stop.load(std::memory_order_relaxed)) {
                 const int i = (int)(g() % 9);
-                bpgpu_pool_set_option(pool, keys[i], lo[i] + (int64_t)(g() % (uint64_t)(hi[i] - lo[i] + 1)));
+                const int64_t v = lo[i] + (int64_t)(g() % (uint64_t)(hi[i] - lo[i] + 1));
+                if (strncmp(keys[i], "co", 2)) bpgpu_internal_pool_tune(pool, keys[i], v);
+                else bpgpu_pool_set_option(pool, keys[i], v);
                 std::this_thread::sleep_for(std::chrono::milliseconds(3));
             }
         });

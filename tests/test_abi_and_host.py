@@ -248,27 +248,16 @@ def test_flush_plan_how_pending_batches_are_cut_into_launch_chains():
             ch, per, hint = plan(T, rlc)
             assert (ch - 1) * per < T <= ch * per and 16 <= hint <= 64 and hint % 8 == 0
     assert plan(20 * 1024)[2] == 56 and plan(40 * 1024)[2] == 32 and plan(10**6)[2] == 16
-    # ---- by work (pool option plan_by_work, default on): T counts (64,1)-proof equivalents, a chain's width follows from its shape ----
-    we, cw, go = L.bpgpu_internal_work_equiv, L.bpgpu_internal_chain_width, L.bpgpu_internal_flush_group_order
-    we.restype = cw.restype = C.c_uint64
+    # ---- table-walk work in (64,1)-proof equivalents (what split_lone_heavy weighs; planning chains in PROPORTION to it was an option until
+    # round 6: measured worse on BASELINE configs 3 / 4, profiles/r05/plan_by_work_ab.txt) ----
+    we, go = L.bpgpu_internal_work_equiv, L.bpgpu_internal_flush_group_order
+    we.restype = C.c_uint64
     we.argtypes = [C.c_uint64] * 3
-    cw.argtypes = [C.c_uint64] * 4
     go.restype = None
     go.argtypes = [C.POINTER(C.c_uint64), C.c_uint64, C.POINTER(C.c_uint64)]
     assert we(1024, 64, 1) == 1024 and we(20 * 1024, 64, 1) == 20480                 # single 64-bit proofs: nothing changes
-    assert cw(5120, 64, 1, 1 << 20) == 5120 and cw(10240, 64, 1, 1 << 20) == 10240
     assert we(256, 64, 16) == 4037 and we(512, 64, 32) == 16140                      # an m = 16 proof walks 2050 generator terms, a single one 130
-    # BASELINE config 3 as the driver runs it, 20 x 256 proofs of (64, 16): 80 740 equivalents -> sixteen chains of up to 384 proofs, not one of 5120
-    T3 = 20 * we(256, 64, 16)
-    ch, per, _ = plan(T3)
-    assert (ch, cw(per, 64, 16, 16384)) == (16, 384)
-    # config 4, 20 x 512 proofs of (64, 32): 322 800 equivalents -> sixty-three chains (one per lane at most) of 192
-    ch, per, _ = plan(20 * we(512, 64, 32))
-    assert ch == 63 and cw(per, 64, 32, 16384) == 192
-    assert plan(20 * we(512, 64, 32), lanes=8)[0] == 8 and cw(plan(20 * we(512, 64, 32), lanes=8)[1], 64, 32, 16384) == 1344
-    assert cw(1, 64, 1, 1 << 20) == 64 and cw(10**9, 64, 1, 16384) == 16384           # whole transcript wavefronts; never wider than max_chain_proofs
-    assert cw(5120, 8, 1, 1 << 20) == 36992                                          # small shapes: wider chains for the same work
-    # ---- the default (plan_by_work = 2): by proof count, but a LONE chain with two chains' worth of work is cut in two ----
+    # ---- by proof count, but a LONE chain with two chains' worth of work is cut in two ----
     sl = L.bpgpu_internal_split_lone_heavy
     sl.restype = None
     sl.argtypes = [C.c_uint64] * 6 + [C.c_int, C.c_int, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
@@ -308,3 +297,27 @@ def test_integration_md_binds_every_entry_point_of_the_header():
     doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     declared = set(re.findall(r"fn (bpgpu_[a-z0-9_]+)", doc))
     assert len(declared) >= 66 and all(re.search(r"\b%s\s*\(" % n, hdr) for n in declared)   # and nothing there that the header does not have
+
+
+def _pool_option_table():
+    """the documented pool options of include/bpgpu.h: [(key, default)]"""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    txt = open(os.path.join(root, "include", "bpgpu.h")).read()
+    sec = txt[txt.index(" * Options (bpgpu_pool_set_option;"):txt.index(" * Any other key is forwarded to every lane context")]
+    return re.findall(r'^ \*   "([a-z_]+)"\s+(\S+)', sec, re.M)
+
+
+def test_every_pool_option_is_documented_and_settable():
+    """the pool's option surface is what include/bpgpu.h lists, one line per key, at most 20 keys; every key the
+    scheduler's bpgpu_pool_set_option handles is in that table and vice versa (the option branches round 5's own A/B refuted are gone)."""
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    src = open(os.path.join(root, "bulletproofs_amd", "csrc", "pool.hip")).read()
+    body = src[src.index("int bpgpu_pool_set_option(bpgpu_pool *p, const char *key, int64_t value) {"):src.index("int bpgpu_internal_pool_tune(")]
+    handled = set(re.findall(r'!strcmp\(key, "([a-z_]+)"\)', body))
+    documented = [k for k, _ in _pool_option_table()]
+    assert len(documented) == len(set(documented)) <= 20, documented
+    assert handled == set(documented), (sorted(handled - set(documented)), sorted(set(documented) - handled))
+    for gone in ("plan_by_work", "plan_min_chain_proofs", "stagger_chains", "combine_policy", "combine_mapped_in", "split_stage1", "fork_early"):
+        assert '"%s")' % gone not in src and '"%s")' % gone not in open(os.path.join(root, "bulletproofs_amd", "csrc", "bpgpu.hip")).read(), gone

@@ -21,8 +21,7 @@ def _planted(oracle, gens, n, m, label, count, seed):
     return out
 
 
-@pytest.mark.parametrize("by_work", [0, 1, 2])
-def test_alternating_shapes_and_four_labels_share_chains_vs_oracle(oracle, by_work):
+def test_alternating_shapes_and_four_labels_share_chains_vs_oracle(oracle):
     import torch
     import bulletproofs_amd as bp
     from bulletproofs_amd import workload as wl
@@ -36,7 +35,6 @@ def test_alternating_shapes_and_four_labels_share_chains_vs_oracle(oracle, by_wo
     pool.gens_create(64, 16)
     pool.gens_add_shape(64, 1)
     pool.set_option("auto_flush_items", 1000)
-    pool.set_option("plan_by_work", by_work)
     gens = oracle.Gens(64, 16)
     to_dev = lambda b: torch.frombuffer(bytearray(b), dtype=torch.uint8).to(dev)
     items = []
@@ -64,15 +62,9 @@ def test_alternating_shapes_and_four_labels_share_chains_vs_oracle(oracle, by_wo
     pool.wait()
     chains, chain_proofs = pool.get_option("stat_chains"), pool.get_option("stat_chain_proofs")
     assert chain_proofs == 20 * 256 + 20 * 64
-    if by_work == 1:
-        # 5120 single proofs + 1280 proofs of m = 16 (25 300 equivalents): a few chains' worth of work -> a few chains, not forty
-        assert chains <= 6, chains
-    elif by_work == 2:
-        # the default: by proof count (one chain's worth), cut in two because it carries several chains' worth of work: 3200 + 1920 single
-        # proofs, one chain of the 1280 aggregated ones
-        assert chains == 3, chains
-    else:
-        assert chains == 2 and chain_proofs / chains >= 2048    # counted in proofs: one chain per shape
+    # by proof count (one chain's worth), cut in two because it carries several chains' worth of work: 3200 + 1920 single proofs, one chain of
+    # the 1280 aggregated ones
+    assert chains == 3, chains
     n_ok = 0
     for i, d in enumerate(items):
         fx = d["fx"]

@@ -4,6 +4,7 @@ chains.  The call shape replaced: a loop over RangeProof::verify_multiple (src/r
 byte (and mega-check encoding) must equal the oracle's, whatever the slicing / coalescing."""
 import hashlib
 import os
+import sys
 
 import pytest
 
@@ -450,4 +451,47 @@ def test_gather_between_distinct_devices_over_the_peer_links(oracle, cfg2):
     gs.synchronize()
     _, ev, _ = oracle.verify_batch(oracle.Gens(64, 1), proofs, coms, fx.m, fx.n, fx.label, rng, threads=os.cpu_count() or 1)
     assert bytes(d_all.cpu().numpy()) == ev and sum(1 for v in ev if v) == len(bad)
+    pool.close()
+
+
+def test_every_documented_pool_option_flips_on_a_live_pool(oracle, cfg2):
+    """include/bpgpu.h's option table, key by key: set a non-default value, read it back, verify a batch with it in force (verdicts ==
+    oracle), set the default back.  Keys the table does not list are refused unless a lane context knows them; the keys removed in round 6
+    are refused."""
+    import bulletproofs_amd as bp
+    sys.path.insert(0, os.path.dirname(__file__))
+    from test_abi_and_host import _pool_option_table
+    fx = cfg2
+    nb = 96
+    proofs = bytearray(fx.proofs[:nb * fx.proof_len])
+    proofs[7 * fx.proof_len + 200] ^= 4
+    proofs = bytes(proofs)
+    coms = fx.commitments[:nb * 32 * fx.m]
+    rng = hashlib.shake_256(b"opt-rng").digest(64 * nb)
+    gens = oracle.Gens(64, 1)
+    _, ev, _ = oracle.verify_batch(gens, proofs, coms, fx.m, fx.n, fx.label, rng, threads=4)
+    pool = bp.Pool((0,), 4, fixed_window_bits=8)
+    pool.gens_create(64, 1)
+    other = {"coalesce_proofs": 2048, "max_chain_proofs": 8192, "pair_limit_proofs": 4096, "latency_proofs": 64, "auto_flush_items": 3, "auto_flush_proofs": 512,
+             "slice_proofs": 32, "host_workers": 2, "host_path_combining": 0, "rlc_isolate": 1, "combine_wait_us": 250, "combine_quiet_us": 7,
+             "combine_max_age_us": 900, "combine_inflight": 2, "combine_busy_chains": 1, "combine_max_open": 2, "combine_mapped_out": 0,
+             "combine_msm_bytes": 1 << 20, "combine_trace": 64}
+    table = _pool_option_table()
+    assert {k for k, _ in table} == set(other) | {"stat_reset"}
+    for key, _ in table:
+        if key == "stat_reset":
+            pool.set_option(key, 1)
+            assert pool.get_option("stat_chains") == 0
+            continue
+        before = pool.get_option(key)
+        assert before != other[key], key
+        pool.set_option(key, other[key])
+        assert pool.get_option(key) == other[key], key
+        assert pool.rangeproof_verify(fx.n, fx.m, proofs, fx.proof_len, coms, fx.label, rng) == ev, key
+        if key != "host_workers":          # (fixed once the worker threads of the slicing path exist)
+            pool.set_option(key, before)
+            assert pool.get_option(key) == before, key
+    for gone in ("plan_by_work", "stagger_chains", "combine_policy", "combine_mapped_in", "split_stage1", "fork_early", "no_such_key"):
+        with pytest.raises(Exception):
+            pool.set_option(gone, 1)
     pool.close()
