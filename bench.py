@@ -523,6 +523,22 @@ def mixed_shapes(a, local_dev, long_run):
     return out
 
 
+def _outliers(stderr_text):
+    """tools/combine_rate.cpp's outlier report: every call above 5 x p99 with the time it returned at; `latency_ms.max` of all rows so far was
+    a call of the first milliseconds (the first chain of a staging-buffer class allocates its pinned block and sizes a lane's arena)"""
+    for ln in stderr_text.splitlines():
+        if ln.startswith('{"outliers_above_5x_p99"'):
+            try:
+                o = json.loads(ln)
+            except ValueError:
+                return {}
+            first = [k for k in o if k.startswith("of_them_in_first_")]
+            return {"steady_latency_ms": o["steady_lat_ms"], "outliers_above_5x_p99": o["outliers_above_5x_p99"],
+                    (first[0] if first else "of_them_at_start"): o[first[0]] if first else None,
+                    "outliers_lat_ms_when_ms_thread_call": o["listed_as_lat_ms_when_ms_thread_call"][:8], "cgroup_cpu": o.get("cgroup_cpu")}
+    return {}
+
+
 def drop_in_call_shape(long_run, local_dev=0):
     """tools/combine_rate.cpp (built here with g++) against a pool of its own (W = 16 tables: 8.7 GB beside this process's): T host
     threads looping BLOCKING single-proof bpgpu_pool_rangeproof_verify_ts calls, tickets, and two threads with 4096-proof calls."""
@@ -554,6 +570,7 @@ def drop_in_call_shape(long_run, local_dev=0):
         d = json.loads(line[-1])
         out[key] = {"verifications_per_s": d["rate_per_s"], "latency_ms": d["lat_ms"], "proofs_per_chain": d["proofs_per_chain"], "mismatches_vs_oracle": d["mismatches"],
                     "errors": d["errors"]}
+        out[key].update(_outliers(p.stderr))
         if d["mismatches"] or d["errors"]:
             raise SystemExit("the combining queue returned a result that differs from the oracle's -- result invalid")
     # the boundary function itself, one multiscalar multiplication per blocking call (bpgpu_pool_msm_batch_shared; r1cs/verifier.rs:459-491's shape:
@@ -577,6 +594,7 @@ def drop_in_call_shape(long_run, local_dev=0):
             d = json.loads(line[-1])
             out[key] = {"msms_per_s": d["rate_per_s"], "latency_ms": d["lat_ms"], "msms_per_chain": d["proofs_per_chain"], "mismatches_vs_oracle": d["mismatches"],
                         "errors": d["errors"], "note": "6179-term MSMs, host pointers in and out (264 kB per MSM over PCIe), W = 12 tables for the 4098 generators"}
+            out[key].update(_outliers(p.stderr))
             if d["mismatches"] or d["errors"]:
                 raise SystemExit("a pooled multiscalar multiplication differs from the oracle's encoding -- result invalid")
         os.unlink(mpath)
@@ -886,19 +904,31 @@ def main():
         except Exception as e:
             extra["rlc"] = {"error": str(e)}
     if want_extra and a.config == "cfg2" and not a.window_bits and not a.table_bytes:
-        # the headline walks 113 GB of window tables (W = 20).  The same steps at W = 16 -- 8.7 GB, a budget a co-tenant can live with
-        try:
-            import copy
-            a16 = copy.copy(a)
-            a16.window_bits = 16
-            b16 = RangeProofBench(a16, a.config, batch, lanes_for(a, a.steps, False), rank, local_dev)
-            r16 = timed(b16, a.steps, a.warmup, fence, a.repeat, None, False, True)
-            extra["small_table"] = {"verifications_per_s": round(batch * a.steps / r16["elapsed"], 1), "fixed_window_bits": b16.get_option("fixed_window_bits"),
-                                    "fixed_table_bytes": b16.get_option("fixed_table_bytes"), "regions": len(r16["regions"]),
-                                    "note": "the headline's steps with 16-bit windows: 17 table lookups per generator term instead of 13, a thirteenth of the HBM"}
-            b16.close()
-        except Exception as e:
-            extra["small_table"] = {"error": str(e)}
+        # the headline walks 113 GB of window tables (W = 20).  The same steps at W = 16 (8.7 GB, a budget a co-tenant can live with) and
+        # W = 18 (33 GB): the curve the default is chosen from -- table bytes, build time, rate
+        import copy
+        curve = [{"fixed_window_bits": window_bits, "fixed_table_bytes": table_bytes, "build_s": round(build_s, 3), "verifications_per_s": round(value, 1),
+                  "lookups_per_generator_term": -(-254 // window_bits) if window_bits else None}]
+        for wb in (18, 16):
+            try:
+                aw = copy.copy(a)
+                aw.window_bits = wb
+                t_b0 = time.perf_counter()
+                bw = RangeProofBench(aw, a.config, batch, lanes_for(a, a.steps, False), rank, local_dev)
+                bs = time.perf_counter() - t_b0
+                rw = timed(bw, a.steps, a.warmup, fence, a.repeat, None, False, True)
+                row = {"fixed_window_bits": bw.get_option("fixed_window_bits"), "fixed_table_bytes": bw.get_option("fixed_table_bytes"), "build_s": round(bs, 3),
+                       "verifications_per_s": round(batch * a.steps / rw["elapsed"], 1), "lookups_per_generator_term": -(-254 // wb), "regions": len(rw["regions"])}
+                curve.append(row)
+                if wb == 16:
+                    extra["small_table"] = dict(row, note="the headline's steps with 16-bit windows: 16 table lookups per generator term instead of 13, a thirteenth of the HBM")
+                bw.close()
+            except Exception as e:
+                curve.append({"fixed_window_bits": wb, "error": str(e)})
+        extra["table_curve"] = {"rows": curve,
+                                "note": "same steps, same box, the pool's window width as the only change: HBM spent on the generator tables against the rate.  The "
+                                        "default (largest table that fits the 160 GiB budget) buys the last ~10 % with 100 GB; a service that shares the device sets "
+                                        "fixed_window_bits = 16 or 18 (or fixed_table_max_bytes) and keeps 90-97 % of the rate"}
     if want_extra and a.config == "cfg2" and not a.batch:
         # the batch-combined entry point at batches of 4096: from 32768 terms the per-proof points of the whole batch go through
         # ONE bucket (Pippenger) MSM (csrc/bucket.h)

@@ -38,7 +38,9 @@ struct shared_table {
     fb_entry *d_table;
     int refs;
 };
-static std::mutex g_tab_mu;
+static std::mutex g_tab_mu;                 // the list below
+static std::mutex g_tab_build_mu[64];       // one table under construction per DEVICE (two contexts of a device asking for the same table: the second
+                                            // one waits and finds it); tables of different devices are built at the same time (pool over N devices)
 static std::vector<shared_table *> g_tables;
 
 struct bpgpu_ctx {
@@ -632,7 +634,7 @@ static int build_table_set(bpgpu_ctx *c, const std::vector<uint8_t> &h_gens, con
                            shared_table **ref_out, fb_entry **tab_out) {
     fb_params prm;
     prm.n_gens = (uint32_t)(h_gens.size() / 32);
-    std::lock_guard<std::mutex> lk(g_tab_mu);
+    std::lock_guard<std::mutex> lk_build(g_tab_build_mu[(unsigned)c->device & 63u]);
     uint32_t W = W_fixed;
     fb_entry *d_table = nullptr;
     size_t entries = 0;
@@ -646,13 +648,16 @@ static int build_table_set(bpgpu_ctx *c, const std::vector<uint8_t> &h_gens, con
         prm.nwin = fb_nwin(W);
         prm.half = 1u << (W - 1);
         *prm_out = prm;
-        for (shared_table *t : g_tables)
-            if (t->device == c->device && t->W == W && t->gens == h_gens) {
-                t->refs++;
-                *ref_out = t;
-                *tab_out = t->d_table;
-                return BPGPU_OK;
-            }
+        {
+            std::lock_guard<std::mutex> lk(g_tab_mu);
+            for (shared_table *t : g_tables)
+                if (t->device == c->device && t->W == W && t->gens == h_gens) {
+                    t->refs++;
+                    *ref_out = t;
+                    *tab_out = t->d_table;
+                    return BPGPU_OK;
+                }
+        }
         entries = (size_t)prm.n_gens * prm.nwin * prm.half;
         if (hipMalloc((void **)&d_table, entries * sizeof(fb_entry)) == hipSuccess) break;
         (void)hipGetLastError();
@@ -687,7 +692,10 @@ static int build_table_set(bpgpu_ctx *c, const std::vector<uint8_t> &h_gens, con
         return fail(c, BPGPU_ERR_BAD_GENERATOR, "a generator encoding does not decode");
     }
     shared_table *t = new shared_table{c->device, W, h_gens, d_table, 1};
-    g_tables.push_back(t);
+    {
+        std::lock_guard<std::mutex> lk(g_tab_mu);
+        g_tables.push_back(t);
+    }
     *ref_out = t;
     *tab_out = d_table;
     return BPGPU_OK;

@@ -789,28 +789,111 @@ static int pool_spread_gens(bpgpu_pool *p, size_t gens_capacity, size_t party_ca
     }
     return BPGPU_OK;
 }
+// What the FIRST request of a service used to pay (tools/combine_rate.cpp's outlier report, profiles/r06/call_shape_outliers_before.txt: every
+// latency maximum of the call-shape rows -- 16 .. 31 ms against a p99 of 0.9 .. 4 ms -- was call number 0 of its thread, 23 ms): the
+// staging blocks of its buffer class (pinned + device allocation), the lane's arena for chains of that shape, and the code objects of the
+// chain's kernels (the runtime loads them at their first launch).  bpgpu_pool_gens_* now does all three once: every free staging buffer
+// gets blocks for the per-proof class of the set's own shape, every combining lane sizes its arena for it, and one chain of one (invalid)
+// proof runs on every device.
+static void comb_caps(bpgpu_pool *p, pool_dev *d, const comb_key &key, size_t run, uint32_t *cap, uint32_t *cap_max);
+static size_t cbuf_layout(comb_buf *b, const comb_regions &g, uint32_t cap);
+static int cbuf_alloc(bpgpu_pool *p, pool_dev *d, comb_buf *b, size_t need);
+static void pool_prewarm_buffers(bpgpu_pool *p, size_t n, size_t m) {
+    size_t nm = n * m, lg = 0;
+    while (((size_t)1 << lg) < nm) lg++;
+    if (((size_t)1 << lg) != nm) return;   // (no proof of this shape exists: nothing to foresee)
+    comb_key key;
+    key.kind = CQ_RP;
+    key.a = (uint32_t)n, key.b = (uint32_t)m, key.c = (uint32_t)(32 * (9 + 2 * lg));
+    key.mode = CK_UNIFORM;
+    for (pool_dev *d : p->devs) {
+        std::lock_guard<std::mutex> lk(d->cmu);
+        uint32_t cap = 0, cap_max = 0;
+        comb_caps(p, d, key, 1, &cap, &cap_max);
+        for (comb_buf *b : d->cbufs) {
+            if (b->st.load(std::memory_order_acquire) != CB_FREE) continue;   // (a pool that is already serving: whatever is in use stays as it is)
+            const size_t need = cbuf_layout(b, regions_of(key), cap_max);
+            if (need > b->mem_cap && cbuf_alloc(p, d, b, need)) continue;
+            if (b->reserved_n != key.a || b->reserved_m != key.b || b->reserved_len != key.c || b->reserved_cap < cap_max) {
+                if (bpgpu_internal_rp_reserve(b->ctx, key.a, key.b, key.c, cap_max) == BPGPU_OK)
+                    b->reserved_n = key.a, b->reserved_m = key.b, b->reserved_len = key.c, b->reserved_cap = cap_max;
+            }
+        }
+    }
+}
+// one chain of one all-zero proof per device through the queue (verdict: not verified; nobody looks at it)
+static void pool_prewarm_chain(bpgpu_pool *p, size_t n, size_t m) {
+    size_t nm = n * m, lg = 0;
+    while (((size_t)1 << lg) < nm) lg++;
+    if (((size_t)1 << lg) != nm || getenv("BPGPU_NO_PREWARM")) return;
+    const size_t plen = 32 * (9 + 2 * lg);
+    std::vector<uint8_t> proof(plen, 0), coms(32 * m, 0), rng(64, 1);
+    uint8_t st[BPGPU_TRANSCRIPT_BYTES], v = 0;
+    bpgpu_transcript_new((const uint8_t *)"", 0, st);
+    const std::string keep = t_pool_err;
+    for (size_t i = 0; i < p->devs.size(); i++)   // (the queue hands consecutive calls to consecutive devices)
+        (void)bpgpu_pool_rangeproof_verify_ts(p, n, m, 1, proof.data(), plen, coms.data(), st, 0, rng.data(), &v, nullptr, nullptr);
+    t_pool_err = keep;
+}
+
+// The generator tables of a pool over N devices are built by N threads at once (a table is seconds of one device's time: 2.3 s for the
+// 113 GB of the (64, 1) set; eight devices in a row were eight times that before the first proof could be verified).  Devices that repeat
+// in the pool's list (two shards on one GPU: the one-GPU tests) share a table through the context layer's cache and are served in turn.
+static int on_every_device(bpgpu_pool *p, const std::function<int(pool_dev *)> &f) {
+    for (pool_dev *d : p->devs)
+        if (d->lanes.empty()) return BPGPU_ERR_INVALID_ARG;
+    std::vector<int> rcs(p->devs.size(), BPGPU_OK);
+    std::vector<std::thread> th;
+    std::vector<std::vector<size_t>> by_ordinal;   // shards of one physical device run one after the other (they share the table cache)
+    for (size_t i = 0; i < p->devs.size(); i++) {
+        size_t g = 0;
+        while (g < by_ordinal.size() && p->devs[by_ordinal[g][0]]->device != p->devs[i]->device) g++;
+        if (g == by_ordinal.size()) by_ordinal.emplace_back();
+        by_ordinal[g].push_back(i);
+    }
+    for (const std::vector<size_t> &grp : by_ordinal)
+        th.emplace_back([&, grp] {
+            for (size_t i : grp) {
+                (void)hipSetDevice(p->devs[i]->device);
+                rcs[i] = f(p->devs[i]);
+            }
+        });
+    for (std::thread &t : th) t.join();
+    for (size_t i = 0; i < p->devs.size(); i++)
+        if (rcs[i]) return pfail(p, rcs[i], "%s", bpgpu_last_error(p->devs[i]->lanes[0]));
+    return BPGPU_OK;
+}
+
 int bpgpu_pool_gens_create(bpgpu_pool *p, size_t gens_capacity, size_t party_capacity) {
     if (!p || gens_capacity == 0 || party_capacity == 0) return BPGPU_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(p->mu);
-    for (pool_dev *d : p->devs) {
-        if (d->lanes.empty()) return BPGPU_ERR_INVALID_ARG;
-        const int rc = bpgpu_gens_create(d->lanes[0], gens_capacity, party_capacity);
-        if (rc) return pfail(p, rc, "%s", bpgpu_last_error(d->lanes[0]));
+    std::unique_lock<std::mutex> lk(p->mu);
+    {
+        const int rc = on_every_device(p, [&](pool_dev *d) { return bpgpu_gens_create(d->lanes[0], gens_capacity, party_capacity); });
+        if (rc) return rc;
     }
     p->gens_epoch.fetch_add(1);
-    return pool_spread_gens(p, gens_capacity, party_capacity);
+    const int rc = pool_spread_gens(p, gens_capacity, party_capacity);
+    if (rc) return rc;
+    pool_prewarm_buffers(p, gens_capacity, party_capacity);
+    lk.unlock();
+    pool_prewarm_chain(p, gens_capacity, party_capacity);
+    return BPGPU_OK;
 }
 int bpgpu_pool_gens_load(bpgpu_pool *p, size_t gens_capacity, size_t party_capacity, const uint8_t *G, const uint8_t *H, const uint8_t B[32],
                          const uint8_t Bb[32]) {
     if (!p || !G || !H || !B || !Bb || gens_capacity == 0 || party_capacity == 0) return BPGPU_ERR_INVALID_ARG;
-    std::lock_guard<std::mutex> lk(p->mu);
-    for (pool_dev *d : p->devs) {
-        if (d->lanes.empty()) return BPGPU_ERR_INVALID_ARG;
-        const int rc = bpgpu_gens_load(d->lanes[0], gens_capacity, party_capacity, G, H, B, Bb);
-        if (rc) return pfail(p, rc, "%s", bpgpu_last_error(d->lanes[0]));
+    std::unique_lock<std::mutex> lk(p->mu);
+    {
+        const int rc = on_every_device(p, [&](pool_dev *d) { return bpgpu_gens_load(d->lanes[0], gens_capacity, party_capacity, G, H, B, Bb); });
+        if (rc) return rc;
     }
     p->gens_epoch.fetch_add(1);
-    return pool_spread_gens(p, gens_capacity, party_capacity);
+    const int rc = pool_spread_gens(p, gens_capacity, party_capacity);
+    if (rc) return rc;
+    pool_prewarm_buffers(p, gens_capacity, party_capacity);
+    lk.unlock();
+    pool_prewarm_chain(p, gens_capacity, party_capacity);
+    return BPGPU_OK;
 }
 
 // A second shape with a window table of its own (bpgpu_gens_add_shape) on every lane of every device: all lanes let go of their tables
@@ -982,15 +1065,9 @@ static size_t cbuf_layout(comb_buf *b, const comb_regions &g, uint32_t cap) {
     b->total = o;
     return o;
 }
-static int cbuf_configure(bpgpu_pool *p, pool_dev *d, comb_buf *b, const comb_key &key, uint32_t cap, uint32_t cap_max) {
-    const comb_regions g = regions_of(key);
-    const size_t need = cbuf_layout(b, g, cap_max);   // the blocks are sized for the widest chain of this class once and for all
-    b->key = key;
-    b->reg = g;
-    b->cap_max = cap_max;
-    if (cap != cap_max) cbuf_layout(b, g, cap);
-    if (b->desc.size() < cap_max) b->desc.resize(cap_max);
-    if (need > b->mem_cap) {   // the first chains of a class (the calling thread's current device is put back afterwards)
+// the two staging blocks of a buffer (pinned host + device), at least `need` bytes each (the calling thread's current device is put back)
+static int cbuf_alloc(bpgpu_pool *p, pool_dev *d, comb_buf *b, size_t need) {
+    {
         int prev = -1;
         (void)hipGetDevice(&prev);
         hipError_t e = hipSetDevice(d->device);
@@ -1027,6 +1104,17 @@ static int cbuf_configure(bpgpu_pool *p, pool_dev *d, comb_buf *b, const comb_ke
         }
         b->mem_cap = want;
     }
+    return BPGPU_OK;
+}
+static int cbuf_configure(bpgpu_pool *p, pool_dev *d, comb_buf *b, const comb_key &key, uint32_t cap, uint32_t cap_max) {
+    const comb_regions g = regions_of(key);
+    const size_t need = cbuf_layout(b, g, cap_max);   // the blocks are sized for the widest chain of this class once and for all
+    b->key = key;
+    b->reg = g;
+    b->cap_max = cap_max;
+    if (cap != cap_max) cbuf_layout(b, g, cap);
+    if (b->desc.size() < cap_max) b->desc.resize(cap_max);
+    if (need > b->mem_cap) return cbuf_alloc(p, d, b, need);   // the first chains of a class that bpgpu_pool_gens_* did not foresee
     return BPGPU_OK;
 }
 

@@ -43,6 +43,30 @@ static bool load(const char *path, inputs &in) {
     fclose(f);
     return ok;
 }
+// CPU-bandwidth throttling of the container (cgroup v2 cpu.stat, v1 cpu/cpu.stat): periods seen, periods throttled, time throttled (us).
+// A pool under a CPU quota stalls for the rest of a 100 ms period once its threads have used the quota up: every caller's latency then
+// shows a spike at a period boundary -- not the library's, but it must be told apart from the library's.
+struct cg_stat { long long periods = -1, throttled = -1, usec = -1; };
+static cg_stat read_cg() {
+    cg_stat r;
+    const char *paths[] = {"/sys/fs/cgroup/cpu.stat", "/sys/fs/cgroup/cpu/cpu.stat", "/sys/fs/cgroup/cpu,cpuacct/cpu.stat"};
+    for (const char *pth : paths) {
+        FILE *f = fopen(pth, "r");
+        if (!f) continue;
+        char k[64];
+        long long v;
+        while (fscanf(f, "%63s %lld", k, &v) == 2) {
+            if (!strcmp(k, "nr_periods")) r.periods = v;
+            else if (!strcmp(k, "nr_throttled")) r.throttled = v;
+            else if (!strcmp(k, "throttled_usec")) r.usec = v;
+            else if (!strcmp(k, "throttled_time")) r.usec = v / 1000;
+        }
+        fclose(f);
+        if (r.periods >= 0) break;
+    }
+    return r;
+}
+static double g_run0 = 0;
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 int main(int argc, char **argv) {
@@ -113,7 +137,7 @@ int main(int argc, char **argv) {
     }
     const size_t PL = in.proof_len, CM = 32 * in.m;
     std::atomic<uint64_t> total{0}, mismatches{0}, errors{0};
-    std::vector<std::vector<float>> lat(T);
+    std::vector<std::vector<float>> lat(T), when(T);   // latency of every call / when it returned (ms since the run began)
     std::atomic<bool> stop{false};
     std::atomic<int> ready{0};
     auto check = [&](size_t idx, const uint8_t *v, const uint8_t *ts) {
@@ -123,8 +147,9 @@ int main(int argc, char **argv) {
         if (!ok) mismatches++;
     };
     auto worker = [&](int t) {
-        std::vector<float> &L = lat[t];
+        std::vector<float> &L = lat[t], &Wn = when[t];
         L.reserve(1 << 20);
+        Wn.reserve(1 << 20);
         uint64_t done = 0;
         size_t cur = ((size_t)t * 7919) % in.count;
         ready++;
@@ -144,7 +169,7 @@ int main(int argc, char **argv) {
                 }
                 const double t0 = now_s();
                 const int r = bpgpu_pool_rangeproof_verify_ts(pool, in.n, in.m, B, pr.data(), PL, cm.data(), st.data(), 208, rg.data(), v.data(), nullptr, ts.data());
-                L.push_back((float)((now_s() - t0) * 1e3));
+                { const double e_ = now_s(); L.push_back((float)((e_ - t0) * 1e3)); Wn.push_back((float)((e_ - g_run0) * 1e3)); }
                 if (r) errors++;
                 else
                     for (int b = 0; b < B; b++) check(idx[b], &v[b], &ts[b * 208]);
@@ -165,7 +190,7 @@ int main(int argc, char **argv) {
                 if (s.t) {
                     if (bpgpu_pool_ticket_wait(pool, s.t)) errors++;
                     else check(s.idx, s.v, s.ts);
-                    L.push_back((float)((now_s() - s.t0) * 1e3));
+                    { const double e_ = now_s(); L.push_back((float)((e_ - s.t0) * 1e3)); Wn.push_back((float)((e_ - g_run0) * 1e3)); }
                     s.t = nullptr;
                     done++;
                 }
@@ -200,7 +225,7 @@ int main(int argc, char **argv) {
                 }
                 const double t0 = now_s();
                 const int r = bpgpu_pool_msm_batch_shared(pool, mi.n, mi.m, B, nu, gs.data(), us.data(), up.data(), out.data(), st.data());
-                L.push_back((float)((now_s() - t0) * 1e3));
+                { const double e_ = now_s(); L.push_back((float)((e_ - t0) * 1e3)); Wn.push_back((float)((e_ - g_run0) * 1e3)); }
                 if (r) errors++;
                 else
                     for (size_t b = 0; b < B; b++)
@@ -225,7 +250,7 @@ int main(int argc, char **argv) {
             while (!stop.load(std::memory_order_relaxed)) {
                 const double t0 = now_s();
                 const int r = bpgpu_pool_rangeproof_verify(pool, in.n, in.m, NB, pr.data(), PL, cm.data(), (const uint8_t *)"combine-rate", 12, rg.data(), v.data(), nullptr);
-                L.push_back((float)((now_s() - t0) * 1e3));
+                { const double e_ = now_s(); L.push_back((float)((e_ - t0) * 1e3)); Wn.push_back((float)((e_ - g_run0) * 1e3)); }
                 if (r) errors++;
                 else if (v != want) mismatches++;
                 done += NB;
@@ -252,6 +277,8 @@ int main(int argc, char **argv) {
     }).detach();
     std::vector<std::thread> th;
     const double t0 = now_s();
+    g_run0 = now_s();
+    const cg_stat cg0 = read_cg();
     for (int t = 0; t < T; t++) th.emplace_back(worker, t);
     while (ready.load() < T) std::this_thread::yield();
     const double t1 = now_s();
@@ -260,9 +287,14 @@ int main(int argc, char **argv) {
     for (auto &x : th) x.join();
     phase = 1;
     const double t2 = now_s();
-    std::vector<float> all;
+    std::vector<float> all, steady;
     for (auto &l : lat) all.insert(all.end(), l.begin(), l.end());
+    const float warm_ms = getenv("BP_WARM_MS") ? (float)atof(getenv("BP_WARM_MS")) : 100.0f;   // calls that RETURNED within this time of the start are "start-up"
+    for (int t = 0; t < T; t++)
+        for (size_t i = 0; i < lat[t].size(); i++)
+            if (when[t][i] > warm_ms) steady.push_back(lat[t][i]);
     std::sort(all.begin(), all.end());
+    std::sort(steady.begin(), steady.end());
     auto pct = [&](double q) { return all.empty() ? 0.0 : (double)all[(size_t)(q * (all.size() - 1))]; };
     int64_t chains = 0, cproofs = 0, iss = 0, cmp = 0, polls = 0;
     bpgpu_pool_get_option(pool, "stat_svc_issue_us", &iss);
@@ -270,6 +302,31 @@ int main(int argc, char **argv) {
     bpgpu_pool_get_option(pool, "stat_svc_polls", &polls);
     bpgpu_pool_get_option(pool, "stat_combined_chains", &chains);
     bpgpu_pool_get_option(pool, "stat_combined_proofs", &cproofs);
+    {
+        // every call above 5 x p99: how long, when it returned, which call of its thread it was
+        const double lim = 5.0 * (all.empty() ? 0.0 : (double)all[(size_t)(0.99 * (all.size() - 1))]);
+        std::string o = "[";
+        int n_out = 0, n_start = 0;
+        for (int t = 0; t < T; t++)
+            for (size_t i = 0; i < lat[t].size(); i++)
+                if (lat[t][i] > lim) {
+                    if (when[t][i] <= warm_ms) n_start++;
+                    if (n_out < 24) {
+                        char buf[96];
+                        snprintf(buf, sizeof buf, "%s[%.2f, %.1f, %d, %zu]", n_out ? ", " : "", lat[t][i], when[t][i], t, i);
+                        o += buf;
+                    }
+                    n_out++;
+                }
+        o += "]";
+        auto spct = [&](double q) { return steady.empty() ? 0.0 : (double)steady[(size_t)(q * (steady.size() - 1))]; };
+        const cg_stat cg1 = read_cg();
+        fprintf(stderr, "{\"outliers_above_5x_p99\": %d, \"of_them_in_first_%.0f_ms\": %d, \"listed_as_lat_ms_when_ms_thread_call\": %s, "
+                        "\"steady_lat_ms\": {\"p50\": %.3f, \"p99\": %.3f, \"max\": %.3f, \"calls\": %zu}, "
+                        "\"cgroup_cpu\": {\"periods\": %lld, \"periods_throttled\": %lld, \"throttled_ms\": %.1f}}\n",
+                n_out, warm_ms, n_start, o.c_str(), spct(0.5), spct(0.99), steady.empty() ? 0.0 : (double)steady.back(), steady.size(),
+                cg1.periods - cg0.periods, cg1.throttled - cg0.throttled, (double)(cg1.usec - cg0.usec) / 1e3);
+    }
     printf("{\"mode\": \"%s\", \"threads\": %d, \"arg\": %d, \"seconds\": %.2f, \"verifications\": %llu, \"rate_per_s\": %.0f, \"calls\": %zu, \"lat_ms\": {\"p50\": %.3f, "
            "\"p90\": %.3f, \"p99\": %.3f, \"max\": %.3f}, \"chains\": %lld, \"proofs_per_chain\": %.1f, \"mismatches\": %llu, \"errors\": %llu, \"startup_s\": %.2f, \"svc\": {\"issue_us_per_chain\": %.1f, \"complete_us_per_chain\": %.1f, \"polls\": %lld}}\n",
            mode.c_str(), T, arg2, t2 - t1, (unsigned long long)total.load(), (double)total.load() / (t2 - t1), all.size(), pct(0.5), pct(0.9), pct(0.99),
