@@ -926,7 +926,8 @@ def main():
             except Exception as e:
                 curve.append({"fixed_window_bits": wb, "error": str(e)})
         extra["table_curve"] = {"rows": curve,
-                                "note": "same steps, same box, the pool's window width as the only change: HBM spent on the generator tables against the rate.  The "
+                                "note": "same steps, same box, the pool's window width as the only change: HBM spent on the generator tables against the rate (build_s: wall time of "
+                                        "creating the pool, deriving the generators and building the table -- including the return of the previous pool's table to the allocator).  The "
                                         "default (largest table that fits the 160 GiB budget) buys the last ~10 % with 100 GB; a service that shares the device sets "
                                         "fixed_window_bits = 16 or 18 (or fixed_table_max_bytes) and keeps 90-97 % of the rate"}
     if want_extra and a.config == "cfg2" and not a.batch:

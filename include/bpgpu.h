@@ -33,7 +33,7 @@
  *     narrow, so one stream cannot fill the device.  Keep many batches in flight:
  *     one context per HIP stream (the generator tables are shared by the contexts
  *     of a process), ~48 streams, and GPU_MAX_HW_QUEUES=16 in the environment
- *     (ROCm's default of 4 hardware queues serialises the streams; DESIGN.md 2).
+ *     (ROCm's default of 4 hardware queues serialises the streams; DESIGN.md 5).
  */
 #ifndef BPGPU_H
 #define BPGPU_H
@@ -489,7 +489,7 @@ int bpgpu_ipp_verification_scalars(bpgpu_ctx *ctx, size_t n, size_t nbatch, cons
  *   "combine_trace"        0      ring size of the timeline records (bpgpu_pool_trace_dump)
  *   "stat_reset"           -      zero all statistics
  * Any other key is forwarded to every lane context (set those before bpgpu_pool_gens_*).  When a staging buffer leaves is decided per
- * kind of work, as measured: range proofs by the deadlines above in two regimes, multiscalar multiplications and inner-product
+ * kind of work, as measured (profiles/r05/combine_policy_ab.txt): range proofs by the deadlines above in two regimes, multiscalar multiplications and inner-product
  * proofs in cohorts (a buffer leaves when the group the last chain released is back); the constants of both policies are not options.
  * Removed in round 6 because their own A/B refuted them (the tables stay under profiles/r05/): "plan_by_work", "plan_min_chain_proofs",
  * "stagger_chains", "combine_policy", "combine_mapped_in"; context keys "split_stage1", "fork_early".
