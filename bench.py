@@ -580,7 +580,7 @@ def drop_in_call_shape(long_run, local_dev=0):
         import make_msm_inputs
         mpath = os.path.join("/tmp", "bp_msm_inputs_%d.bin" % os.getpid())
         make_msm_inputs.write(mpath, local_dev)
-        env_m = dict(env, BP_W="12", BP_MSM_INPUTS=mpath)
+        env_m = dict(env, BP_W="0", BP_MSM_INPUTS=mpath)   # (0 = the library's default: the largest table that fits its budget -- 146 GB, W = 15; this process holds no table of its own at this point)
         for key, mode in (("msm_threads_1", ["msm", "1", "1"]), ("msm_threads_64", ["msm", "64", "1"])):
             try:
                 p = subprocess.run([exe, inp, secs] + mode, env=env_m, capture_output=True, text=True, timeout=90)
@@ -593,7 +593,7 @@ def drop_in_call_shape(long_run, local_dev=0):
                 continue
             d = json.loads(line[-1])
             out[key] = {"msms_per_s": d["rate_per_s"], "latency_ms": d["lat_ms"], "msms_per_chain": d["proofs_per_chain"], "mismatches_vs_oracle": d["mismatches"],
-                        "errors": d["errors"], "note": "6179-term MSMs, host pointers in and out (264 kB per MSM over PCIe), W = 12 tables for the 4098 generators"}
+                        "errors": d["errors"], "note": "6179-term MSMs, host pointers in and out (264 kB per MSM over PCIe), default tables for the 4098 generators (W = 15, 146 GB)"}
             out[key].update(_outliers(p.stderr))
             if d["mismatches"] or d["errors"]:
                 raise SystemExit("a pooled multiscalar multiplication differs from the oracle's encoding -- result invalid")

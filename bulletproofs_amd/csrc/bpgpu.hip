@@ -564,7 +564,7 @@ int bpgpu_ctx_get_option(bpgpu_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "bucket_chain")) *value = c->bucket_chain;
     else if (!strcmp(key, "bucket_lanes")) *value = c->bucket_lanes;
     else if (!strcmp(key, "bucket_fast_tail")) *value = c->fast_tail;
-    else if (!strcmp(key, "fb_walk_waves")) *value = c->walk_waves ? c->walk_waves : 1024;
+    else if (!strcmp(key, "fb_walk_waves")) *value = c->walk_waves ? c->walk_waves : 2048;
     else if (!strcmp(key, "staging_residue")) {
         // test hook: non-zero bytes left in the persistent staging buffers (pinned block, device IO buffer, prover working sets,
         // arena) -- 0 after a prover entry point has returned (prover_exit)
@@ -1227,7 +1227,7 @@ static int enqueue_bucket2(bpgpu_ctx *c, hipStream_t s, size_t nmsm, size_t tota
 }
 // the generator half of a fused chain as ONE launch (msm_fixed.h: fb_walk_thread): partial sums -> partial[npart][nbatch]
 static uint32_t fb_walk_parts(bpgpu_ctx *c, size_t nbatch, uint32_t n_gen_terms) {
-    const uint32_t target = c->walk_waves ? (uint32_t)c->walk_waves : 1024u;
+    const uint32_t target = c->walk_waves ? (uint32_t)c->walk_waves : 2048u;   // (512 / 1024 / 2048 / 4096: 109 / 111 / 113 / 113 k MSMs/s, profiles/r06/cfg5_two_buffers_uncapped_and_walk_waves_ab.txt)
     if (nbatch < 32) {   // lane = slice of one MSM's generator terms: workgroups of one wavefront
         uint32_t nwg = (uint32_t)((target + nbatch - 1) / nbatch);
         const uint32_t most = (n_gen_terms + 63) / 64;

@@ -170,7 +170,8 @@ BP_HD void bk2_w4(uint32_t lane, const bk2_seg &sg, const bk2_lds &l, const fb_e
     ge_ext acc;
     ge_identity(acc);
     // one record buffer and a copy per trip: alternating two buffers (no copies) needs 25 registers more, which under the
-    // three-wavefront cap spill -- measured slower (238 against 202 us for 64 MSMs, profiles/r06/cfg5_two_buffers_ab.txt)
+    // three-wavefront cap spill -- measured slower (238 against 202 us for 64 MSMs, profiles/r06/cfg5_two_buffers_ab.txt); uncapped
+    // (191 registers, two wavefronts per SIMD) it is slower too: 108.5-109.4 against 110.9-111.4 k MSMs/s (cfg5_two_buffers_uncapped_and_walk_waves_ab.txt)
     uint32_t e_cur = l.list[lo];
     fb_line line_cur;
     fb_load_line(line_cur, pts_m + (e_cur & 0x7fffu));

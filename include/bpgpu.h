@@ -106,7 +106,7 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
  *   "bucket_lanes"          lanes of a (MSM, window) workgroup of the fused chain: 0 = by batch width (default), 64, 128, 256
  *   "bucket_fast_tail"      -1 (default): batches of fewer than 48 MSMs end with the short-chain tail (leaves of 4 buckets, shuffle sums);
  *                           0 / 1: never / always
- *   "fb_walk_waves"         wavefronts the generator half of a fused chain is cut into (0 = 1024)
+ *   "fb_walk_waves"         wavefronts the generator half of a fused chain is cut into (0 = 2048)
  * get_option additionally answers "fixed_table_bytes" and the effective "fixed_window_bits".
  * Returns BPGPU_ERR_INVALID_ARG for unknown keys. */
 int bpgpu_ctx_set_option(bpgpu_ctx *ctx, const char *key, int64_t value);
