@@ -147,6 +147,7 @@ struct bpgpu_ctx {
     uint32_t bucket_min = 0;                 // terms per MSM from which the bucket path is taken (0 = BK_MIN_TERMS; huge = never)
     int bucket_chain = 0;                    // option "bucket_chain": 0 = the fused chain (bucket2.h) where it applies, 1 = bucket.h's chain everywhere (A/B)
     int bucket_lanes = 0;                    // option "bucket_lanes": lanes of a (MSM, window) workgroup of the fused chain (0 = by batch width; 64, 128, 256)
+    int exp_pairs = 1;                       // option "exponent_pairs": the generator-exponent role handles mirrored pairs of indices (0: four consecutive indices per lane, for A/B)
     int fast_tail = -1;                      // option "bucket_fast_tail" (A/B): -1 = by batch width, 0 / 1 = never / always the short-chain tail
     int walk_waves = 0;                      // option "fb_walk_waves": wavefronts the generator half of a fused chain is cut into (0 = 1024)
     // constant-time generator-table MSMs for the prover's secret-dependent commitments (msm_fixed.h fb_accum_ct_thread): their own
@@ -526,6 +527,10 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
         c->bucket_chain = (int)value;
         return BPGPU_OK;
     }
+    if (!strcmp(key, "exponent_pairs")) {
+        c->exp_pairs = value != 0;
+        return BPGPU_OK;
+    }
     if (!strcmp(key, "bucket_fast_tail")) {
         c->fast_tail = value < 0 ? -1 : (value != 0);
         return BPGPU_OK;
@@ -564,6 +569,7 @@ int bpgpu_ctx_get_option(bpgpu_ctx *c, const char *key, int64_t *value) {
     else if (!strcmp(key, "bucket_chain")) *value = c->bucket_chain;
     else if (!strcmp(key, "bucket_lanes")) *value = c->bucket_lanes;
     else if (!strcmp(key, "bucket_fast_tail")) *value = c->fast_tail;
+    else if (!strcmp(key, "exponent_pairs")) *value = c->exp_pairs;
     else if (!strcmp(key, "fb_walk_waves")) *value = c->walk_waves ? c->walk_waves : 2048;
     else if (!strcmp(key, "staging_residue")) {
         // test hook: non-zero bytes left in the persistent staging buffers (pinned block, device IO buffer, prover working sets,
@@ -2121,7 +2127,8 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         c->rp_status_dirty = false;
         return BPGPU_OK;
     }
-    const uint32_t nexp = (sh.nm / 4) * nb32, nwin = rlc_bucket ? 0u : (uint32_t)pd->n_chunks * 64;   // four generator indices per lane
+    const bool pairs = !rlc && c->exp_pairs && sh.nm >= 8;   // the per-proof check: eight generator indices per lane, in mirrored pairs (rp_expand_b8_thread)
+    const uint32_t nexp = (sh.nm / (pairs ? 8 : 4)) * nb32, nwin = rlc_bucket ? 0u : (uint32_t)pd->n_chunks * 64;   // four generator indices per lane (eight in pairs)
     const uint32_t n_win = (nwin + BP_BLOCK - 1) / BP_BLOCK, n_exp = (nexp + BP_BLOCK - 1) / BP_BLOCK;
     if (rlc_bucket) {
         // ---- batch combination, bucket variant: R = sum_i rho_i MegaCheck_i with the per-proof terms as ONE MSM ----
@@ -2226,10 +2233,13 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
             HIPCHK(c, hipEventRecord(c->join_ev, c->stream2));
             horner_aside = true;
         }
-        LAUNCH(c, s, "rp_stage3", k_rp_exponents, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
+        if (pairs) LAUNCH(c, s, "rp_stage3", k_rp_exponents<true>, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
+        else LAUNCH(c, s, "rp_stage3", k_rp_exponents<false>, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
     } else {
-        LAUNCH(c, s, "rp_stage3", k_rp_stage3, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part,
-               (quad && one_chunk) ? d_colc : (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits, d_status);
+        if (pairs) LAUNCH(c, s, "rp_stage3", k_rp_stage3<true>, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part,
+                          (quad && one_chunk) ? d_colc : (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits, d_status);
+        else LAUNCH(c, s, "rp_stage3", k_rp_stage3<false>, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part,
+                    (quad && one_chunk) ? d_colc : (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits, d_status);
     }
     if (quad && !one_chunk && !horner_aside) {
         const uint32_t nc = nb32 * 64;

@@ -5,6 +5,7 @@
 using namespace bp;
 
 // launch 3: [0, n_win) per-chunk window sums of the proof-specific points  ||  the 2nm generator exponents
+template <bool PAIRS>
 __global__ void __launch_bounds__(BP_BLOCK) k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab,
                                                          const uint32_t *recoded, ge_ext *part, ge_cached *colc, uint32_t nthreads_exp,
                                                          rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits,
@@ -14,19 +15,32 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rp_stage3(uint32_t n_win, uint32_t
         if (tid < nthreads_win) vb_window_thread(tid, chunks, tab, recoded, part, colc);
     } else {
         const uint32_t tid = (blockIdx.x - n_win) * BP_BLOCK + threadIdx.x;
-        if (tid < nthreads_exp) rp_expand_b4_thread(tid, sh, prm, fields, digits, status);
+        if (tid < nthreads_exp) {
+            if (PAIRS) rp_expand_b8_thread(tid, sh, prm, fields, digits, status);
+            else rp_expand_b4_thread(tid, sh, prm, fields, digits, status);
+        }
     }
 }
+template __global__ void k_rp_stage3<false>(uint32_t, uint32_t, const vb_chunk *, const ge_cached *, const uint32_t *, ge_ext *, ge_cached *, uint32_t, rp_shape, fb_params,
+                                            const uint32_t *, fb_digit *, const uint32_t *);
+template __global__ void k_rp_stage3<true>(uint32_t, uint32_t, const vb_chunk *, const ge_cached *, const uint32_t *, ge_ext *, ge_cached *, uint32_t, rp_shape, fb_params,
+                                           const uint32_t *, fb_digit *, const uint32_t *);
 
 // the generator exponents alone (wide chains, where the window sums are a launch of their own): the role's own register allocation.
 // Two wavefronts per SIMD although 166 registers would allow three: with three, the kernel itself runs 200 instead of 290 us, but on
 // 20 x 1024 bursts the one-lane Horner chains beside it slow down by as much (1.06 -> 1.4 ms) and they are the longer path: -12 %
 // (profiles/r04/ab_exponents_*.txt).  Issue priority for the lane-serial roles (s_setprio) was measured too: neutral, not kept.
+template <bool PAIRS>
 __global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(BP_BLOCK) k_rp_exponents(uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields,
                                                                                                  fb_digit *digits, const uint32_t *status) {
     const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
-    if (tid < nthreads_exp) rp_expand_b4_thread(tid, sh, prm, fields, digits, status);
+    if (tid < nthreads_exp) {
+        if (PAIRS) rp_expand_b8_thread(tid, sh, prm, fields, digits, status);   // (round 6: mirrored pairs of indices share s_i and s_i^-1)
+        else rp_expand_b4_thread(tid, sh, prm, fields, digits, status);
+    }
 }
+template __global__ void k_rp_exponents<false>(uint32_t, rp_shape, fb_params, const uint32_t *, fb_digit *, const uint32_t *);
+template __global__ void k_rp_exponents<true>(uint32_t, rp_shape, fb_params, const uint32_t *, fb_digit *, const uint32_t *);
 
 // the one-lane Horner chains as their own launch (wide chains: issued on the context's second stream as soon as the window sums
 // exist, so that their ~1 ms of dependent instructions run beside the generator exponents and the table walk instead of after them)

@@ -1117,5 +1117,112 @@ BP_HD void rp_expand_b4_thread(uint32_t tid, rp_shape sh, fb_params prm, const u
     }
 }
 
+
+// EIGHT generator indices per thread, in mirrored pairs (round 6): tid = t * nproofs + p, t < nm/8; the four indices i = 4t .. 4t+3 of the
+// lower half and their mirror images i' = nm - 1 - i.  nm is a power of two, so the bits of i' are the complements of the bits of i:
+//     s_i' = s_i^-1,   s_i'^-1 = s_i      (ipp.rs:241-250: s_i takes u or u^-1 by the bit)
+// -- the two products a lane forms for index i (s_i for g_i, s_i^-1 for h_i) are exactly the two that index i' needs, in the other
+// roles: g_i' = -z - a s_i^-1, h_i' = z + y^-i' (z^2 z^j' 2^i'' - b s_i).  A pair of indices costs 2 (k - 2) / 4 + 4 products for s and
+// s^-1 once instead of twice: 25.5 Montgomery products per pair instead of 34.5 at k = 12 (m = 32) -- -24 % of the role.  y^-i' is
+// the product over the bits that i does NOT have: the high-bit loop multiplies one of two running products per bit (as many products as
+// before per pair of lanes).  j' = m - 1 - j, i'' = n - 1 - (i mod n).
+BP_HD void rp_expand_b8_thread(uint32_t tid, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits, const uint32_t *status) {
+    const uint32_t B = sh.nproofs, k = sh.k;
+    const uint32_t t8 = tid / B, p = tid - t8 * B, i0 = 4 * t8;
+    if (status[p] != 0) return;
+    const fb_bias bias = fb_make_bias(prm);
+    const rp_fields fl = rp_field_layout(k, sh.m);
+    sc28 s_hi, sinv_hi, y_hi, yc_hi, t;   // yc_hi: y^-(the high bits i0 does not have)
+    {
+        sc28 um, uim;
+        sc28_one_mont(s_hi);
+        sinv_hi = s_hi;
+        y_hi = s_hi;
+        yc_hi = s_hi;
+        for (uint32_t bb = 2; bb < k; bb++) {
+            rp_load28(um, fields, B, fl.u_m + (k - 1 - bb), p);
+            rp_load28(uim, fields, B, fl.uinv_m + (k - 1 - bb), p);
+            const bool bit = (i0 >> bb) & 1;
+            sc28 f1, f2;
+#pragma unroll
+            for (int q = 0; q < 10; q++) {
+                f1.v[q] = bit ? um.v[q] : uim.v[q];
+                f2.v[q] = bit ? uim.v[q] : um.v[q];
+            }
+            sc28_montmul(s_hi, s_hi, f1);
+            sc28_montmul(sinv_hi, sinv_hi, f2);
+            rp_load28(t, fields, B, fl.yinvp_m + bb, p);
+            if (bit) sc28_montmul(y_hi, y_hi, t);
+            else sc28_montmul(yc_hi, yc_hi, t);
+        }
+    }
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (uint32_t j = 0; j < 4; j++) {
+        const uint32_t i = i0 + j, im = sh.nm - 1 - i;
+        const uint32_t fa = (j & 1) ? fl.u_m + (k - 1) : fl.uinv_m + (k - 1), fa_c = (j & 1) ? fl.uinv_m + (k - 1) : fl.u_m + (k - 1);
+        const uint32_t fb = (j & 2) ? fl.u_m + (k - 2) : fl.uinv_m + (k - 2), fb_c = (j & 2) ? fl.uinv_m + (k - 2) : fl.u_m + (k - 2);
+        sc28 s, sinv;
+        rp_load28(t, fields, B, fa, p);
+        sc28_montmul(s, s_hi, t);
+        rp_load28(t, fields, B, fb, p);
+        sc28_montmul(s, s, t);
+        rp_load28(t, fields, B, fa_c, p);
+        sc28_montmul(sinv, sinv_hi, t);
+        rp_load28(t, fields, B, fb_c, p);
+        sc28_montmul(sinv, sinv, t);
+        // the pair: (index, its s, its s^-1, y^-index from the running product `yh` and the low bits `lo`)
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+        for (uint32_t side = 0; side < 2; side++) {
+            const uint32_t idx = side ? im : i, lo = side ? (3u - j) : j;
+            sc28 sg, sh_, yp, r;
+#pragma unroll
+            for (int q = 0; q < 10; q++) {
+                sg.v[q] = side ? sinv.v[q] : s.v[q];      // s_idx
+                sh_.v[q] = side ? s.v[q] : sinv.v[q];     // s_idx^-1
+                yp.v[q] = side ? yc_hi.v[q] : y_hi.v[q];
+            }
+            sc g, h, v;
+            {   // g_idx = -z - a s_idx
+                sc28 a_m;
+                rp_load28(a_m, fields, B, RPF_A_M, p);
+                sc28_montmul(t, a_m, sg);
+                sc_from_mont28(v, t);
+                sc minus_z;
+                rp_load(minus_z, fields, B, RPF_MINUS_Z, p);
+                sc_sub(g, minus_z, v);
+                fb_recode(digits + ((uint64_t)(2 + idx) * prm.nwin) * B + p, B, g.v, prm, bias);
+            }
+            if (lo & 1) {
+                rp_load28(t, fields, B, fl.yinvp_m + 0, p);
+                sc28_montmul(yp, yp, t);
+            }
+            if (lo & 2) {
+                rp_load28(t, fields, B, fl.yinvp_m + 1, p);
+                sc28_montmul(yp, yp, t);
+            }
+            {   // h_idx = z + y^-idx (z^2 z^j 2^i' - b s_idx^-1)
+                sc28 b_m, two_m, zzzj;
+                const uint32_t jj = idx / sh.n, ib = idx - jj * sh.n;
+                rp_load28(zzzj, fields, B, fl.zzzj_m + jj, p);
+                rp_two_pow_mont(two_m, ib);
+                sc28_montmul(r, zzzj, two_m);
+                rp_load28(b_m, fields, B, RPF_B_M, p);
+                sc28_montmul(t, b_m, sh_);
+                sc28_sub_lazy(r, r, t);
+                sc28_montmul(r, r, yp);
+                sc_from_mont28(v, r);
+                sc z;
+                rp_load(z, fields, B, RPF_Z, p);
+                sc_add(h, z, v);
+                fb_recode(digits + ((uint64_t)(2 + sh.nm + idx) * prm.nwin) * B + p, B, h.v, prm, bias);
+            }
+        }
+    }
+}
+
 }  // namespace bp
 #endif

@@ -106,6 +106,8 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
  *   "bucket_lanes"          lanes of a (MSM, window) workgroup of the fused chain: 0 = by batch width (default), 64, 128, 256
  *   "bucket_fast_tail"      -1 (default): batches of fewer than 48 MSMs end with the short-chain tail (leaves of 4 buckets, shuffle sums);
  *                           0 / 1: never / always
+ *   "exponent_pairs"        1 (default): the generator-exponent role handles index i together with nm-1-i (they share s_i and s_i^-1: -24 % of
+ *                           the role's Montgomery products); 0: four consecutive indices per lane (for A/B)
  *   "fb_walk_waves"         wavefronts the generator half of a fused chain is cut into (0 = 2048)
  * get_option additionally answers "fixed_table_bytes" and the effective "fixed_window_bits".
  * Returns BPGPU_ERR_INVALID_ARG for unknown keys. */

@@ -540,6 +540,19 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
         }
     } else {
         for (uint32_t tid = 0; tid < (sh.nm / 4) * nbatch; tid++) rp_expand_b4_thread(tid, sh, prm, fields.data(), digits.data(), status.data());
+        // the mirrored-pair form of the role (rp_expand_b8_thread, what the device runs since round 6): the same digits, every row
+        if (sh.nm >= 8) {
+            std::vector<fb_digit> d4(digits), d8(digits);
+            const size_t rows0 = (size_t)2 * prm.nwin * nbatch, rows1 = (size_t)(2 + 2 * sh.nm) * prm.nwin * nbatch;
+            for (size_t q = rows0; q < rows1 && q < d8.size(); q++) d8[q] = (fb_digit)0x5a5a5a5a;
+            for (uint32_t tid = 0; tid < (sh.nm / 8) * nbatch; tid++) rp_expand_b8_thread(tid, sh, prm, fields.data(), d8.data(), status.data());
+            for (uint32_t p = 0; p < nbatch; p++) {
+                if (status[p] != 0) continue;   // (rows of rejected proofs are never written by either form)
+                for (size_t row = 2; row < 2 + 2 * (size_t)sh.nm; row++)
+                    for (uint32_t w = 0; w < prm.nwin; w++)
+                        if (d8[(row * prm.nwin + w) * nbatch + p] != d4[(row * prm.nwin + w) * nbatch + p]) return -77;
+            }
+        }
     }
     std::vector<vb_chunk> chunks; std::vector<uint32_t> chunk_first(nbatch + 1); uint32_t tt = 0;
     for (uint32_t b = 0; b < nbatch; b++) {

@@ -66,6 +66,7 @@ static cg_stat read_cg() {
     }
     return r;
 }
+extern "C" int bpgpu_internal_pool_tune(bpgpu_pool *, const char *, int64_t);
 static double g_run0 = 0;
 static double now_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
@@ -127,6 +128,19 @@ int main(int argc, char **argv) {
             const size_t q = kv.find('=');
             if (q != std::string::npos && bpgpu_pool_set_option(pool, kv.substr(0, q).c_str(), atoll(kv.c_str() + q + 1)))
                 fprintf(stderr, "option %s refused: %s\n", kv.c_str(), bpgpu_pool_last_error(pool));
+            p = e + 1;
+        }
+    }
+    if (const char *o = getenv("BP_TUNE")) {   // constants of the sealing policies (not options: the library's test hook), "key=value,..."
+        std::string s = o;
+        size_t p = 0;
+        while (p < s.size()) {
+            size_t e = s.find(',', p);
+            if (e == std::string::npos) e = s.size();
+            const std::string kv = s.substr(p, e - p);
+            const size_t q = kv.find('=');
+            if (q != std::string::npos && bpgpu_internal_pool_tune(pool, kv.substr(0, q).c_str(), atoll(kv.c_str() + q + 1)))
+                fprintf(stderr, "tune %s refused\n", kv.c_str());
             p = e + 1;
         }
     }

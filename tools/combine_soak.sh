@@ -14,9 +14,9 @@ INP=bench_data/combine_rate_inputs.bin
 python3 tools/make_msm_inputs.py /tmp/soak_msm_inputs.bin > /dev/null 2>&1 && export BP_MSM_INPUTS=/tmp/soak_msm_inputs.bin
 bad=0; n=0
 for r in $(seq 1 $ROUNDS); do
-  for spec in "threads 256 1" "tickets 16 512" "threads 64 3" "tickets 4 512" "tickets 16 128|combine_inflight=2,combine_wait_us=300" "threads 256 1|combine_policy=1" \
+  for spec in "threads 256 1" "tickets 16 512" "threads 64 3" "tickets 4 512" "tickets 16 128|combine_inflight=2,combine_wait_us=300" "threads 256 1|combine_busy_chains=1" \
               "tickets 16 512|combine_inflight=3" "threads 128 2|combine_max_open=1" "big 4 1500" "tickets 32 64|combine_mapped_out=0" \
-              "msm 48 1" "msm 24 3|combine_policy=0"; do
+              "msm 48 1" "msm 24 3|combine_msm_bytes=4194304"; do
     mode=${spec%%|*}; opts=""; [ "$spec" != "$mode" ] && opts=${spec#*|}
     n=$((n+1))
     w=$BP_W; [ "${mode%% *}" = "msm" ] && w=10      # (the MSM rows need BulletproofGens(2048, 1): small windows keep the table build short)
