@@ -181,3 +181,20 @@ def test_horner_chain_layouts_and_radices_agree_with_oracle(oracle, lanes, radix
         ctx.gens_create(fx.n, fx.m)
         _check(oracle, ctx, oracle.Gens(fx.n, fx.m), fx, nb, 17, 60 + lanes + radix + a_outside)
         ctx.close()
+
+
+@pytest.mark.parametrize("pairs", [0, 1])
+def test_generator_exponent_role_in_pairs_and_in_fours_agree_with_oracle(oracle, pairs):
+    """Option exponent_pairs (round 6: index i together with nm - 1 - i, sharing s_i and s_i^-1) off and on, narrow and wide chains of the
+    single and the m = 16 shape, ~5 % tampered: verdicts and mega-check encodings == oracle.  (The 16 golden shapes, n = 8 .. 64 and m = 1 .. 8 --
+    nm = 8: one lane holds all eight indices of a proof -- run with the default, pairs, in test_gpu_rangeproof.py.)"""
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    for name, nb in (("cfg2_n64_m1", 2300), ("cfg3_n64_m16", 2100), ("cfg3_n64_m16", 130), ("cfg2_n64_m1", 61)):
+        fx = wl.load_fixture(name)
+        ctx = bp.Context(0, fixed_window_bits=12)
+        ctx.set_option("exponent_pairs", pairs)
+        assert ctx.get_option("exponent_pairs") == pairs
+        ctx.gens_create(fx.n, fx.m)
+        _check(oracle, ctx, oracle.Gens(fx.n, fx.m), fx, nb, 17, 90 + pairs)
+        ctx.close()

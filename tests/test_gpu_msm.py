@@ -291,3 +291,38 @@ def test_bucket_path_structured_scalars_take_the_heavy_pass(ctx, oracle, n, kind
     cb.close()
     exp3 = [oracle.msm(S2[32 * a:32 * b], P2[32 * a:32 * b])[1] for a, b in ((0, 2000), (2000, 4500), (4500, 6300))]
     assert st == bytes(3) and out == b"".join(exp3)
+
+
+@pytest.mark.parametrize("nb", [1, 3, 50])
+def test_fused_bucket_chain_options_all_give_the_oracle_encoding(oracle, nb):
+    """Every option of the fused bucket chain (include/bpgpu.h: bucket_chain, bucket_lanes, bucket_fast_tail, fb_walk_waves) flipped on the
+    config-5 shape at three batch widths (one MSM: 256-lane window workgroups + the short-chain tail; 3: 128 lanes; 50: one wavefront per
+    (MSM, window) + the one-lane-per-window tail): the same encodings as the oracle's, whatever the decomposition."""
+    import bulletproofs_amd as bp
+    c = bp.Context(0, fixed_window_bits=6)
+    c.gens_create(2048, 1)
+    g = oracle.Gens(2048, 1)
+    G, H, B, Bb = g.export()
+    n, m, nu = 2048, 1, 700
+    ngen = 2 * n * m + 2
+    gen_pts = Bb + B + G + H
+    pts1 = _points(oracle, b"opt-u", nu)
+    GS = b"".join(_scalar(b"opt-g%d" % (i % (2 * ngen))) for i in range(ngen * nb))
+    US = b"".join(_scalar(b"opt-u%d" % (i % (3 * nu))) for i in range(nu * nb))
+    UP = pts1 * nb
+    c.set_option("bucket_min_terms", 1)
+    expect = b""
+    for b in range(min(nb, 3)):     # (the inputs repeat with period 2 / 3 MSMs: three oracle MSMs cover every batch width)
+        scs = GS[32 * ngen * b:32 * ngen * (b + 1)] + US[32 * nu * b:32 * nu * (b + 1)]
+        expect += oracle.msm(scs, gen_pts + pts1)[1]
+    base, _ = c.msm_batch_shared(n, m, nb, nu, GS, US, UP)
+    assert base[:len(expect)] == expect
+    for key, values in (("bucket_chain", (1,)), ("bucket_lanes", (64, 128, 256)), ("bucket_fast_tail", (0, 1)), ("fb_walk_waves", (64, 4096))):
+        before = c.get_option(key)
+        for v in values:
+            c.set_option(key, v)
+            assert c.get_option(key) == v
+            out, st = c.msm_batch_shared(n, m, nb, nu, GS, US, UP)
+            assert st == bytes(nb) and out == base, (key, v)
+        c.set_option(key, before if key != "fb_walk_waves" else 0)
+    c.close()
