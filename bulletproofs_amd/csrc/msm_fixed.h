@@ -255,7 +255,9 @@ BP_HD void fb_accum_thread(uint32_t p, uint32_t split, uint32_t q0, uint32_t q1,
 // wavefronts of a workgroup add their sums through LDS, so that a workgroup leaves ONE partial sum per MSM.
 //   lane (p, slice): generator terms [g0, g1) of MSM p;  gen_scalars [p][n_gen_terms][8 words]
 // The table line of window w+1 is requested while window w is added (the scalar of the next generator term is not requested ahead: the
-// eight registers it would hold through the walk cost the third wavefront per SIMD, whose work hides that load better).
+// eight registers it would hold through the walk cost the third wavefront per SIMD, whose work hides that load better).  Two line
+// buffers used alternately (no copy between windows: -4.5 % instructions per addition) spill 58 registers under the 168-register cap and were
+// measured slower, 109-110 against 115-117 k MSMs/s (profiles/r06/cfg5_walk_two_buffers_ab.txt) -- as in the bucket stage's loop.
 BP_HD void fb_walk_thread(ge_ext &acc, uint32_t p, uint32_t g0, uint32_t g1, fb_params prm, uint32_t n_gen_terms, const uint32_t *gen_scalars,
                           const uint32_t *gen_ids, const fb_entry *table, uint32_t *status) {
     ge_identity(acc);

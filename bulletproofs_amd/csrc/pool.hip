@@ -814,9 +814,12 @@ static void pool_prewarm_buffers(bpgpu_pool *p, size_t n, size_t m) {
             if (b->st.load(std::memory_order_acquire) != CB_FREE) continue;   // (a pool that is already serving: whatever is in use stays as it is)
             const size_t need = cbuf_layout(b, regions_of(key), cap_max);
             if (need > b->mem_cap && cbuf_alloc(p, d, b, need)) continue;
-            if (b->reserved_n != key.a || b->reserved_m != key.b || b->reserved_len != key.c || b->reserved_cap < cap_max) {
-                if (bpgpu_internal_rp_reserve(b->ctx, key.a, key.b, key.c, cap_max) == BPGPU_OK)
-                    b->reserved_n = key.a, b->reserved_m = key.b, b->reserved_len = key.c, b->reserved_cap = cap_max;
+            // (an aggregated shape's arena is ~0.3 MB per proof: sized here for the narrow chains a service's first callers form, a wide
+            // chain grows it when it comes -- twelve lanes x 5120 proofs would take 17 GB at nm = 2048 before anybody asked)
+            const uint32_t rcap = nm > 256 ? std::min<uint32_t>(cap_max, 512) : cap_max;
+            if (b->reserved_n != key.a || b->reserved_m != key.b || b->reserved_len != key.c || b->reserved_cap < rcap) {
+                if (bpgpu_internal_rp_reserve(b->ctx, key.a, key.b, key.c, rcap) == BPGPU_OK)
+                    b->reserved_n = key.a, b->reserved_m = key.b, b->reserved_len = key.c, b->reserved_cap = rcap;
             }
         }
     }

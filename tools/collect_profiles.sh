@@ -75,15 +75,17 @@ def per_kernel(d, counter):
     # per kernel only the dispatches of its LARGEST grid: the bench commands also issue narrow launches of the same kernels (a lone MSM,
     # a latency probe), and an average over both is the figure of neither (rounds 2-5 did that for cfg5: 3.58 M wavefront-instructions
     # per MSM reported where the batch of 64 executed 5.0 M)
-    rows = collections.defaultdict(list)
+    rows = collections.defaultdict(lambda: collections.defaultdict(list))   # label -> (kernel variant, grid) -> values
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter: continue
-        rows[short(r["Kernel_Name"])].append((int(r["Grid_Size"]), float(r["Counter_Value"])))
+        full = re.sub(r"\(.*", "", r["Kernel_Name"]).strip()
+        rows[short(r["Kernel_Name"])][(full, int(r["Grid_Size"]))].append(float(r["Counter_Value"]))
     out = {}
-    for k, v in rows.items():
-        g = max(x[0] for x in v)
-        w = [x[1] for x in v if x[0] == g]
-        out[k] = {"dispatches": len(w), "avg_per_dispatch": sum(w) / len(w), "grid": g}
+    for k, groups in rows.items():
+        # the chain's own launches of this label: the (variant, grid) group with the largest value per dispatch (a warm-up chain of one
+        # proof, a latency probe and a lone MSM launch the same kernels -- or their narrow-chain variants -- at other grids)
+        (full, g), w = max(groups.items(), key=lambda kv: sum(kv[1]) / len(kv[1]))
+        out[k] = {"dispatches": len(w), "avg_per_dispatch": sum(w) / len(w), "grid": g, "variant": full}
     return out
 for cfg, what, ppl in (("cfg2", "bench.py --config cfg2 --steps 5 --warmup 0 --streams 1 --opt latency_proofs=0,auto_flush_items=64 (the pool's wide chain form: one coalesced chain of 5120 per region)", 5120),
                   ("cfg3", "bench.py --config cfg3 --steps 8 --warmup 0 --streams 1 --opt latency_proofs=0,auto_flush_items=64 (one coalesced chain of 2048 per region)", 2048),
