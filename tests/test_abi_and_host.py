@@ -211,12 +211,15 @@ def test_hot_path_kernels_use_no_scratch_memory_and_the_build_gate_knows_every_e
         objs = sorted(glob.glob(os.path.join(ROOT, "bulletproofs_amd", "csrc", "build", "*.o")))
     assert kr.check(objs, ge.SCRATCH_ALLOW) == []
     ks = {k["name"]: k for o in objs for k in kr.kernels_of(o)}
-    for hot in ("void k_vb_window_wide<false>", "k_rp_exponents", "k_rp_stage3", "void k_rp_stage4<4>", "void k_rp_horner_wide<false>", "k_fb_reduce",
+    for hot in ("void k_vb_window_wide<false>", "void k_rp_exponents<true>", "void k_rp_exponents<false>", "void k_rp_stage3<true>", "void k_rp_stage3<false>",
+                "void k_bk2_window<64>", "void k_bk2_window<256>", "k_bk2_leafv", "k_msm_tail", "k_msm_tail_fast", "void k_rp_stage4<4>", "void k_rp_horner_wide<false>", "k_fb_reduce",
                 "void k_finish8<false>", "k_vb_window_colc", "void k_rp_stage4<64>"):
         assert ks[hot]["scratch"] == 0 and ks[hot]["spill_vgpr"] == 0, hot
     s1 = ks["void k_rp_stage1<true>"]
     assert s1["scratch"] <= 360 and s1["spill_vgpr"] <= 118 and s1["code_bytes"] <= 320 * 1024
-    assert ks["k_rp_exponents"]["vgpr"] <= 168                     # three wavefronts per SIMD would fit (measured: two are better on bursts)
+    assert ks["void k_rp_exponents<false>"]["vgpr"] <= 168         # three wavefronts per SIMD would fit (measured: two are better on bursts)
+    assert ks["void k_rp_exponents<true>"]["vgpr"] <= 256          # the paired form: pinned at two wavefronts per SIMD, four running products live
+    assert ks["void k_bk2_window<64>"]["vgpr"] <= 168 and ks["k_bk2_prepare"]["vgpr"] <= 168   # three wavefronts per SIMD: the fused bucket chain's wide launches
 
 
 def test_flush_plan_how_pending_batches_are_cut_into_launch_chains():
