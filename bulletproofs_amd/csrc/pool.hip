@@ -2322,6 +2322,7 @@ extern "C" void bpgpu_internal_plan_flush(uint64_t T, uint64_t coalesce_proofs, 
 // therefore counts in (64,1)-proof equivalents; a chain's width in proofs of ITS shape follows from the equivalents it may carry.
 static size_t work_equiv(size_t nbatch, size_t n, size_t m) { return (nbatch * (2 * n * m + 2) + 129) / 130; }
 extern "C" uint64_t bpgpu_internal_work_equiv(uint64_t nbatch, uint64_t n, uint64_t m) { return work_equiv((size_t)nbatch, (size_t)n, (size_t)m); }
+// (Round 6 re-checked the count: config 3's burst of 5120 proofs as 2 / 3 / 4 / 6 chains: 564 / 552 / 549 / 547 k/s, profiles/r06/cfg3_burst_chain_count_ab.txt.)
 // The plan by proof count stands, except that ONE chain carrying at least two chains' worth of work (2 x coalesce_proofs
 // equivalents) becomes two -- the second chain's launch 1 then overlaps the first one's table walk, as it does in every burst of single proofs
 static flush_plan split_lone_heavy(flush_plan fp, size_t T_proofs, size_t T_work, size_t coalesce_proofs, size_t lanes, bool all_rlc, bool one_chain) {
