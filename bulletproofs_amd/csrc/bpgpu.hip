@@ -93,6 +93,10 @@ struct bpgpu_ctx {
                                                                     // 0.528 / 0.528 / 0.533 -> 0.521 / 0.526 / 0.518 ms, 16 threads p50 0.64 -> 0.62 ms, 16 x 128 tickets 801 -> 819 k/s
                                                                     // (profiles/r05/coop_defer_emit_ab.txt; the kernel's duration for ONE proof is unchanged, 238 us: the gain is at several
                                                                     // groups per launch); 0: the leader recodes them one after the other
+    int narrow_chunk = 0;                                           // narrow chains: per-proof points per (chunk, window) lane of launch 3; 0 = ~sqrt(U) (the Horner wavefront adds the chunks' rows), 32 = one chunk
+    int exp_single = 1;                                             // narrow chains: the generator-exponent role with one index per lane (rp_expand_b1_thread); 0: as wide chains
+    int coop_split = 1;                                             // narrow chains, per-proof check: the k + 1 inversions on k + 1 lanes of the group at once, the basepoint coefficients as a
+                                                                    // role of launch 3 (rangeproof.h rp_split_invert_lane / rp_rows_thread); 0: the leader does it all (A/B: profiles/r06/coop_split_ab.txt)
     int transcript_coop = 1;                                        // chains of up to 256 proofs replay their transcripts 32 lanes per proof (keccak.h): one call of 1 / 8 / 64 / 256 proofs 0.62 -> 0.53 / 0.56 / 0.57 / 0.58 ms; 0: lane = proof everywhere
     int msm_fork = 1;                                               // bpgpu_msm_batch_shared: the generator-table half on the second stream beside the per-MSM points (0: one stream -- with
                                                                     // many contexts in flight two streams each outnumber the hardware queues: config 5 on 16 / 24 / 32 contexts +1.6 / +1.7 /
@@ -114,7 +118,7 @@ struct bpgpu_ctx {
         uint32_t total = 0;
     };
     uint64_t plan_tick = 0;                  // plan_cache is bounded: least-recently-used entries are retired
-    std::map<size_t, plan_dev> plan_cache;   // terms per MSM -> plan
+    std::map<size_t, plan_dev> plan_cache;   // terms per MSM (| chunk size << 40) -> plan
     std::vector<char *> plan_retired;        // outgrown / evicted blocks that launches in flight may still read: freed with the context
     // per-proof status words of the range-proof path: zero between calls (the last kernel of a call resets the
     // entries it used), so no memset launch is needed per call; `dirty` forces one after an aborted enqueue
@@ -414,6 +418,9 @@ int bpgpu_ctx_create(int device, bpgpu_ctx **out) {
         delete c;
         return BPGPU_ERR_HIP;
     }
+    if (const char *e = getenv("BPGPU_COOP_SPLIT")) c->coop_split = atoi(e) != 0;
+    if (const char *e = getenv("BPGPU_EXP_SINGLE")) c->exp_single = atoi(e) != 0;
+    if (const char *e = getenv("BPGPU_NARROW_CHUNK")) c->narrow_chunk = atoi(e);
     if (const char *e = getenv("BPGPU_COOP_DEFER_EMIT")) c->coop_defer_emit = atoi(e) != 0;   // (A/B of whole test suites: the option's default for every context of the process)
     *out = c;
     return BPGPU_OK;
@@ -494,6 +501,19 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
     }
     if (!strcmp(key, "transcript_script")) {
         c->no_script = value == 0;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "exp_single")) {
+        c->exp_single = value != 0;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "coop_split")) {
+        c->coop_split = value != 0;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "narrow_chunk")) {
+        if (value < 0 || value > BP_VB_CHUNK) return fail(c, BPGPU_ERR_INVALID_ARG, "narrow_chunk must be 0 (automatic) or 2 .. 32");
+        c->narrow_chunk = (int)value;
         return BPGPU_OK;
     }
     if (!strcmp(key, "coop_defer_emit")) {
@@ -931,16 +951,16 @@ struct vb_plan {
     std::vector<uint32_t> chunk_first, term_chunk;
     uint32_t total = 0;
 };
-static void make_vb_plan(vb_plan &pl, size_t nbatch, const uint32_t *n_terms) {
+static void make_vb_plan(vb_plan &pl, size_t nbatch, const uint32_t *n_terms, uint32_t chunk = BP_VB_CHUNK) {
     pl.chunk_first.resize(nbatch + 1);
     uint32_t t0 = 0;
     for (size_t b = 0; b < nbatch; b++) {
         pl.chunk_first[b] = (uint32_t)pl.chunks.size();
-        for (uint32_t k = 0; k < n_terms[b]; k += BP_VB_CHUNK) {
+        for (uint32_t k = 0; k < n_terms[b]; k += chunk) {
             vb_chunk ch;
             ch.msm = (uint32_t)b;
             ch.first = t0 + k;
-            ch.count = n_terms[b] - k < BP_VB_CHUNK ? n_terms[b] - k : BP_VB_CHUNK;
+            ch.count = n_terms[b] - k < chunk ? n_terms[b] - k : chunk;
             ch.pad = 0;
             for (uint32_t i = 0; i < ch.count; i++) pl.term_chunk.push_back((uint32_t)pl.chunks.size());
             pl.chunks.push_back(ch);
@@ -1016,8 +1036,10 @@ static int enqueue_vb(bpgpu_ctx *c, hipStream_t s, const vb_plan &pl, size_t nba
     return vb_launch(c, s, pl.total, (uint32_t)pl.chunks.size(), nbatch, d_scalars, d_points, d_status, d);
 }
 // uniform plans (every MSM of the batch has `per` variable-base terms): decomposition cached on the device
-static int uniform_plan(bpgpu_ctx *c, size_t nbatch, size_t per, bpgpu_ctx::plan_view *out) {
-    auto it = c->plan_cache.find(per);
+// chunk: terms per (chunk, window) lane -- BP_VB_CHUNK, or fewer for narrow chains (rp_narrow_chunk): part of the cache key
+static int uniform_plan(bpgpu_ctx *c, size_t nbatch, size_t per, bpgpu_ctx::plan_view *out, uint32_t chunk = BP_VB_CHUNK) {
+    const size_t key = per | ((size_t)chunk << 40);
+    auto it = c->plan_cache.find(key);
     if (it == c->plan_cache.end() || it->second.cap < nbatch) {
         if (it != c->plan_cache.end()) {   // outgrown: launches in flight may still read the old block
             c->plan_retired.push_back(it->second.mem);
@@ -1041,7 +1063,7 @@ static int uniform_plan(bpgpu_ctx *c, size_t nbatch, size_t per, bpgpu_ctx::plan
         while (cap < nbatch || cap < floor_cap) cap *= 2;
         std::vector<uint32_t> nt(cap, (uint32_t)per);
         vb_plan pl;
-        make_vb_plan(pl, cap, nt.data());
+        make_vb_plan(pl, cap, nt.data(), chunk);
         bpgpu_ctx::plan_dev pd;
         pd.cap = cap;
         pd.o1 = align_up(pl.chunks.size() * sizeof(vb_chunk) + 16);
@@ -1053,18 +1075,18 @@ static int uniform_plan(bpgpu_ctx *c, size_t nbatch, size_t per, bpgpu_ctx::plan
             HIPCHK(c, hipMemcpy(pd.mem + pd.o2, pl.term_chunk.data(), (size_t)pl.total * 4, hipMemcpyHostToDevice));
         }
         HIPCHK(c, hipMemcpy(pd.mem + pd.o1, pl.chunk_first.data(), (cap + 1) * 4, hipMemcpyHostToDevice));
-        it = c->plan_cache.emplace(per, pd).first;
+        it = c->plan_cache.emplace(key, pd).first;
     }
     it->second.last_use = ++c->plan_tick;
     out->mem = it->second.mem;
     out->o1 = it->second.o1;
     out->o2 = it->second.o2;
-    out->n_chunks = nbatch * ((per + BP_VB_CHUNK - 1) / BP_VB_CHUNK);
+    out->n_chunks = nbatch * ((per + chunk - 1) / chunk);
     out->total = (uint32_t)(nbatch * per);
     return BPGPU_OK;
 }
-static void plan_vb_uniform(arena_plan &ap, size_t nbatch, size_t per, size_t off[7], size_t tab_entries = 8) {
-    const size_t n_chunks = nbatch * ((per + BP_VB_CHUNK - 1) / BP_VB_CHUNK), total = nbatch * per;
+static void plan_vb_uniform(arena_plan &ap, size_t nbatch, size_t per, size_t off[7], size_t tab_entries = 8, size_t chunk = BP_VB_CHUNK) {
+    const size_t n_chunks = nbatch * ((per + chunk - 1) / chunk), total = nbatch * per;
     off[0] = off[1] = off[2] = 0;   // decomposition lives in the plan cache
     off[3] = ap.add(total * 32 + 16);
     off[4] = ap.add(total * tab_entries * sizeof(ge_cached) + 16);
@@ -1954,13 +1976,24 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const size_t rlc_terms = (size_t)nbatch * sh.U;
     const bk_params bkp = bk_make(pick_bucket_c(rlc_terms));
     const bool rlc_bucket = rlc && !shape_verdict && rlc_terms >= (c->bucket_min ? c->bucket_min : BK_RLC_MIN_TERMS) && bucket_fits(1, rlc_terms, bkp);
+    // Narrow chains (one wavefront per Horner chain, which adds the chunks' window sums itself): a (chunk, window) lane adding all U table
+    // entries one after the other is ~50 us of a one-proof chain's launch 3.  With chunks of ~sqrt(U) terms a lane adds ~sqrt(U) entries
+    // and the Horner wavefront's lane w adds ~sqrt(U) rows: 8 additions in sequence instead of 16 at U = 17.  (Option narrow_chunk.)
+    uint32_t narrow_q = (uint32_t)c->narrow_chunk;
+    if (narrow_q == 0) {
+        narrow_q = 4;
+        while (narrow_q * narrow_q < sh.U) narrow_q++;
+    }
+    narrow_q = narrow_q < 2 ? 2u : (narrow_q > BP_VB_CHUNK ? (uint32_t)BP_VB_CHUNK : narrow_q);
+    const bool narrow_ok = !rlc && !shape_verdict && (c->horner_lanes == 0 || c->horner_lanes == 64);   // (narrow chains of this context take the wavefront-per-chain form)
+    const uint32_t vb_chunk_sz = (wave && !wide && narrow_ok && nbatch <= 256) ? narrow_q : (uint32_t)BP_VB_CHUNK;
     sh.radix5 = r5 ? 1u : 0u;
     sh.a_outside = a_out ? 1u : 0u;
     sh.defer_emit = c->coop_defer_emit ? 1u : 0u;
     arena_plan ap;
     size_t off[7], boff[12];
     if (rlc_bucket) plan_bucket(ap, 1, rlc_terms, bkp, boff);
-    else plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off, r5 ? 16 : 8);
+    else plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off, r5 ? 16 : 8, vb_chunk_sz);
     const size_t off_digits = ap.add((size_t)npairs * nbatch * sizeof(fb_digit) + 16);
     const size_t off_partial = ap.add((size_t)2 * nsplit * nbatch * sizeof(ge_ext) + 16);
     const size_t off_fields = ap.add((size_t)fl.count * nbatch * BP_RP_REC * 4 + 16);
@@ -1989,7 +2022,10 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const size_t off_dig1 = rlc ? ap.add((size_t)npairs * sizeof(fb_digit) + 16) : 0;
     const size_t off_part1 = rlc ? ap.add((size_t)2 * nsplit1 * sizeof(ge_ext) + 16) : 0;
     const size_t off_res1 = rlc ? ap.add(sizeof(ge_ext) + 64) : 0;   // Horner result, then 8 result words, verdict byte, chunk bounds
-    rc = arena_reserve(c, ap.total);
+    size_t arena_need = ap.total;
+    if (reserve_only && narrow_ok && nbatch > 256)   // (a lane sized for wide chains also sees narrow ones, whose window sums come in more, smaller chunks)
+        arena_need += (size_t)256 * ((sh.U + narrow_q - 1) / narrow_q) * 64 * sizeof(ge_ext);
+    rc = arena_reserve(c, arena_need);
     if (rc) return rc;
     char *a = c->arena;
     if (c->rp_status_cap < nbatch) {
@@ -2002,7 +2038,12 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     }
     if (reserve_only) {
         bpgpu_ctx::plan_view pv0;
-        return shape_verdict ? BPGPU_OK : uniform_plan(c, nbatch, sh.U, &pv0);
+        if (shape_verdict) return BPGPU_OK;
+        if (narrow_ok && narrow_q != BP_VB_CHUNK) {
+            rc = uniform_plan(c, nbatch < 256 ? nbatch : 256, sh.U, &pv0, narrow_q);
+            if (rc) return rc;
+        }
+        return (nbatch > 256 || vb_chunk_sz == BP_VB_CHUNK) ? uniform_plan(c, nbatch, sh.U, &pv0) : BPGPU_OK;
     }
     uint32_t *d_status = c->rp_status;
     fb_digit *d_digits = (fb_digit *)(a + off_digits);
@@ -2089,7 +2130,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     if (rlc_bucket) bucket_bind(c, boff, bd);
     bpgpu_ctx::plan_view pv, *pd = &pv;
     if (!shape_verdict && !rlc_bucket) {
-        rc = uniform_plan(c, nbatch, sh.U, &pv);
+        rc = uniform_plan(c, nbatch, sh.U, &pv, vb_chunk_sz);
         if (rc) return rc;
         vb_bind(c, off, d);
         d.chunks = (vb_chunk *)pv.mem;
@@ -2103,7 +2144,9 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     ge_cached *d_colc = quad ? (ge_cached *)d.colq16 : nullptr;
     const uint32_t n_tr = (nb32 + RP_BLOCK - 1) / RP_BLOCK;
     const uint32_t n_pt = shape_verdict ? 0 : (nb32 * sh.U + RP_BLOCK - 1) / RP_BLOCK;
-    if (d_script && c->transcript_coop && nbatch <= 256)   // narrow chain: 32 lanes per proof for the permutations (two proofs per workgroup)
+    const bool coop = d_script && c->transcript_coop && nbatch <= 256;
+    sh.coop_split = (coop && c->coop_split && !rlc && !wide && !shape_verdict && sh.k < 32) ? 1u : 0u;   // (launch 3 then carries the basepoint-coefficient role)
+    if (coop)   // narrow chain: 32 lanes per proof for the permutations (two proofs per workgroup)
         LAUNCH(c, s, "rp_stage1", k_rp_stage1_coop, (nb32 + 1) / 2 + n_pt, RP_BLOCK, sh, init, (nb32 + 1) / 2, (const uint8_t *)d_proofs,
            (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits,
            rlc ? wts_ptr : (const uint8_t *)nullptr, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
@@ -2127,8 +2170,10 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         c->rp_status_dirty = false;
         return BPGPU_OK;
     }
-    const bool pairs = !rlc && c->exp_pairs && sh.nm >= 8;   // the per-proof check: eight generator indices per lane, in mirrored pairs (rp_expand_b8_thread)
-    const uint32_t nexp = (sh.nm / (pairs ? 8 : 4)) * nb32, nwin = rlc_bucket ? 0u : (uint32_t)pd->n_chunks * 64;   // four generator indices per lane (eight in pairs)
+    // the generator-exponent role: one index per lane for narrow chains (latency), eight in mirrored pairs otherwise (rp_expand_b8_thread: least work)
+    const bool exp_single = !rlc && !wide && c->exp_single && nbatch <= 256 && sh.nm >= 4;
+    const bool pairs = !rlc && !exp_single && c->exp_pairs && sh.nm >= 8;
+    const uint32_t nexp = (exp_single ? sh.nm : sh.nm / (pairs ? 8 : 4)) * nb32, nwin = rlc_bucket ? 0u : (uint32_t)pd->n_chunks * 64;   // four generator indices per lane (eight in pairs)
     const uint32_t n_win = (nwin + BP_BLOCK - 1) / BP_BLOCK, n_exp = (nexp + BP_BLOCK - 1) / BP_BLOCK;
     if (rlc_bucket) {
         // ---- batch combination, bucket variant: R = sum_i rho_i MegaCheck_i with the per-proof terms as ONE MSM ----
@@ -2236,10 +2281,14 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         if (pairs) LAUNCH(c, s, "rp_stage3", k_rp_exponents<true>, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
         else LAUNCH(c, s, "rp_stage3", k_rp_exponents<false>, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
     } else {
-        if (pairs) LAUNCH(c, s, "rp_stage3", k_rp_stage3<true>, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part,
-                          (quad && one_chunk) ? d_colc : (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits, d_status);
-        else LAUNCH(c, s, "rp_stage3", k_rp_stage3<false>, n_win + n_exp, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part,
-                    (quad && one_chunk) ? d_colc : (ge_cached *)nullptr, nexp, sh, prm, d_fields, d_digits, d_status);
+        const uint32_t nrows = sh.coop_split ? nb32 : 0u, n_rows = (nrows + BP_BLOCK - 1) / BP_BLOCK;
+        ge_cached *colc3 = (quad && one_chunk) ? d_colc : (ge_cached *)nullptr;
+        if (exp_single) LAUNCH(c, s, "rp_stage3", k_rp_stage3<2>, n_win + n_exp + n_rows, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part, colc3, nexp, sh, prm,
+                               d_fields, d_digits, d_status, n_exp, nrows, lg_m);
+        else if (pairs) LAUNCH(c, s, "rp_stage3", k_rp_stage3<1>, n_win + n_exp + n_rows, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part, colc3, nexp, sh, prm,
+                               d_fields, d_digits, d_status, n_exp, nrows, lg_m);
+        else LAUNCH(c, s, "rp_stage3", k_rp_stage3<0>, n_win + n_exp + n_rows, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part, colc3, nexp, sh, prm,
+                    d_fields, d_digits, d_status, n_exp, nrows, lg_m);
     }
     if (quad && !one_chunk && !horner_aside) {
         const uint32_t nc = nb32 * 64;

@@ -68,6 +68,8 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1_coop(rp_shape sh, rp_str
     __shared__ uint32_t lds[2 * 52];   // one 50-word sponge state per group
     __shared__ sc28 dslot[2][RP_DEFER_CAP + 1];   // (option coop_defer_emit) the scalar role's coefficients, parked for the group's lanes
     __shared__ uint32_t dmeta[2][2];
+    __shared__ uint32_t spark[2][32 * 8];   // (option coop_split) the k + 1 values the group's lanes invert, one each
+    __shared__ uint32_t sgo[2];
     if (blockIdx.x < n_tr) {
         const uint32_t lane = threadIdx.x, g = lane >> 5, p = blockIdx.x * 2 + g;
         const bool valid = p < sh.nproofs;
@@ -76,12 +78,27 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1_coop(rp_shape sh, rp_str
         st.w = lds + 52 * g;
         st.stride = 1;
         const bool defer = sh.defer_emit && sh.U <= RP_DEFER_CAP;   // (wavefront-uniform)
-        if ((lane & 31) == 0) dmeta[g][0] = 0;
+        const bool split = sh.coop_split && !rho64 && !bk_c && !(sh.seeded & RP_SEED_WEIGHTS) && sh.k < 32;   // (launch-uniform)
+        if ((lane & 31) == 0) {
+            dmeta[g][0] = 0;
+            sgo[g] = 0;
+        }
         rp_transcript_scripted_coop(pp, valid, lane, sh, init, st, rp_resolve(pp, sh, proofs, commitments, rng64, segs), script, fields, status, ts_out, ts_in);
         rp_defer df;
         df.slot = dslot[g];
         df.meta = dmeta[g];
-        if (valid && (lane & 31) == 0 && !sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64, bk_c, defer ? &df : nullptr);
+        if (split) {   // the inversions on k + 1 lanes at once; the leader forms the rest; the basepoint coefficients wait for launch 3
+            rp_split sp;
+            sp.park = spark[g];
+            sp.go = sgo + g;
+            if (valid && (lane & 31) == 0) rp_split_park(p, sh, fields, status, sp);
+            __syncthreads();
+            if (valid) rp_split_invert_lane(lane & 31, p, sh, fields, recoded, sp, defer ? &df : nullptr);
+            if (valid && (lane & 31) == 0 && !sh.shape_verdict)
+                rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, nullptr, 0, defer ? &df : nullptr, RP_SKIP_INV | RP_SKIP_ROWS);
+        } else if (valid && (lane & 31) == 0 && !sh.shape_verdict) {
+            rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64, bk_c, defer ? &df : nullptr);
+        }
         if (defer) {   // the leader parked the U coefficients: one lane each recodes them
             __syncthreads();
             if (valid && !sh.shape_verdict) rp_emit_deferred(lane & 31, p, sh, recoded, df, bk_c);

@@ -4,27 +4,35 @@
 
 using namespace bp;
 
-// launch 3: [0, n_win) per-chunk window sums of the proof-specific points  ||  the 2nm generator exponents
-template <bool PAIRS>
+// launch 3: [0, n_win) per-chunk window sums of the proof-specific points  ||  the 2nm generator exponents  ||  (narrow chains with
+// option coop_split: nthreads_rows = proofs, else 0) the B_blinding / B coefficients, lane = proof
+// FORM: 0 four indices per lane, 1 eight in mirrored pairs (least work), 2 one index per lane (least latency: chains of <= 256 proofs)
+template <int FORM>
 __global__ void __launch_bounds__(BP_BLOCK) k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab,
                                                          const uint32_t *recoded, ge_ext *part, ge_cached *colc, uint32_t nthreads_exp,
                                                          rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits,
-                                                         const uint32_t *status) {
+                                                         const uint32_t *status, uint32_t n_exp, uint32_t nthreads_rows, uint32_t lg_m) {
     if (blockIdx.x < n_win) {
         const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
         if (tid < nthreads_win) vb_window_thread(tid, chunks, tab, recoded, part, colc);
-    } else {
+    } else if (blockIdx.x < n_win + n_exp) {
         const uint32_t tid = (blockIdx.x - n_win) * BP_BLOCK + threadIdx.x;
         if (tid < nthreads_exp) {
-            if (PAIRS) rp_expand_b8_thread(tid, sh, prm, fields, digits, status);
+            if (FORM == 1) rp_expand_b8_thread(tid, sh, prm, fields, digits, status);
+            else if (FORM == 2) rp_expand_b1_thread(tid, sh, prm, fields, digits, status);
             else rp_expand_b4_thread(tid, sh, prm, fields, digits, status);
         }
+    } else {
+        const uint32_t tid = (blockIdx.x - n_win - n_exp) * BP_BLOCK + threadIdx.x;
+        if (tid < nthreads_rows) rp_rows_thread(tid, sh, prm, lg_m, fields, digits, status);
     }
 }
-template __global__ void k_rp_stage3<false>(uint32_t, uint32_t, const vb_chunk *, const ge_cached *, const uint32_t *, ge_ext *, ge_cached *, uint32_t, rp_shape, fb_params,
-                                            const uint32_t *, fb_digit *, const uint32_t *);
-template __global__ void k_rp_stage3<true>(uint32_t, uint32_t, const vb_chunk *, const ge_cached *, const uint32_t *, ge_ext *, ge_cached *, uint32_t, rp_shape, fb_params,
-                                           const uint32_t *, fb_digit *, const uint32_t *);
+template __global__ void k_rp_stage3<0>(uint32_t, uint32_t, const vb_chunk *, const ge_cached *, const uint32_t *, ge_ext *, ge_cached *, uint32_t, rp_shape, fb_params,
+                                        const uint32_t *, fb_digit *, const uint32_t *, uint32_t, uint32_t, uint32_t);
+template __global__ void k_rp_stage3<1>(uint32_t, uint32_t, const vb_chunk *, const ge_cached *, const uint32_t *, ge_ext *, ge_cached *, uint32_t, rp_shape, fb_params,
+                                        const uint32_t *, fb_digit *, const uint32_t *, uint32_t, uint32_t, uint32_t);
+template __global__ void k_rp_stage3<2>(uint32_t, uint32_t, const vb_chunk *, const ge_cached *, const uint32_t *, ge_ext *, ge_cached *, uint32_t, rp_shape, fb_params,
+                                        const uint32_t *, fb_digit *, const uint32_t *, uint32_t, uint32_t, uint32_t);
 
 // the generator exponents alone (wide chains, where the window sums are a launch of their own): the role's own register allocation.
 // Two wavefronts per SIMD although 166 registers would allow three: with three, the kernel itself runs 200 instead of 290 us, but on

@@ -134,6 +134,7 @@ BP_HD void keccak_f1600_masked(const kstate &s, const uint32_t *mask, uint32_t n
 // (nine 64-bit fetches from other lanes: ds_bpermute_b32 pairs) and a handful of ALU operations per lane:
 //   P1  c = XOR of the lane's column (4 fetches)            P2  a ^= c[x-1] ^ rot(c[x+1], 1) (2 fetches)
 //   P3  b[pi(j)] = rot(a, rho[j]): rotate, then every lane fetches from its source (1)     P4  a = b ^ (~b[x+1] & b[x+2]) (2), iota
+// (round 6: P2 and P3 are one stage, see kc_p23)
 // Seven times the lane-instructions of the serial form, a quarter of its latency: for latency-bound chains only (option
 // "transcript_coop").  The phase functions take the fetch as a functor, so that the CPU harness runs the same bodies on a snapshot
 // of the 25 lane values (tests/cpu_harness: keccak_coop_host).
@@ -156,26 +157,29 @@ BP_HD uint64_t kc_rc(uint32_t r) {
     return RC[r];
 }
 BP_HD uint64_t kc_rotl_var(uint64_t x, uint32_t n) { return n ? (x << n) | (x >> (64 - n)) : x; }
-// G: uint64_t operator()(uint64_t mine, uint32_t src_lane): the value `mine` as lane src_lane (0 .. 24) of the group holds it
+// G: uint64_t operator()(uint64_t mine, uint32_t src_lane, int which): the value `mine` as lane src_lane (0 .. 24) of the group holds it
+// (`which` names the exchanged quantity for the host twin, whose lanes are array slots: 0 = the state word, 1 = the column parity)
+// Round 6: THREE exchange stages per round instead of four -- theta's second half rides on the pi fetch: lane j fetches its source's
+// state word AND the two column parities that source would have fetched (parities are the same in every row: taken from row 0), applies
+// theta and the source's rho rotation itself.  Nine 64-bit fetches per round as before, one dependent LDS round trip (~120 cycles of a
+// lone wavefront) fewer.
 template <class G>
 BP_HD uint64_t kc_p1(uint64_t a, uint32_t x, uint32_t y, G &g) {
     uint64_t c = a;
 #pragma unroll
-    for (uint32_t d = 1; d < 5; d++) c ^= g(a, x + 5 * ((y + d) % 5));
+    for (uint32_t d = 1; d < 5; d++) c ^= g(a, x + 5 * ((y + d) % 5), 0);
     return c;
 }
+// b[j] = rot(a[src] ^ c[src.x - 1] ^ rot(c[src.x + 1], 1), rho[src]), src = kc_pi_src(j)
 template <class G>
-BP_HD uint64_t kc_p2(uint64_t a, uint64_t c, uint32_t x, uint32_t y, G &g) {
-    const uint64_t cm = g(c, (x + 4) % 5 + 5 * y), cp = g(c, (x + 1) % 5 + 5 * y);
-    return a ^ cm ^ ((cp << 1) | (cp >> 63));
-}
-template <class G>
-BP_HD uint64_t kc_p3(uint64_t a, uint32_t j, G &g) {
-    return g(kc_rotl_var(a, kc_rho(j)), kc_pi_src(j));
+BP_HD uint64_t kc_p23(uint64_t a, uint64_t c, uint32_t src, uint32_t rho_src, G &g) {
+    const uint32_t sx = src % 5;
+    const uint64_t as = g(a, src, 0), cm = g(c, (sx + 4) % 5, 1), cp = g(c, (sx + 1) % 5, 1);
+    return kc_rotl_var(as ^ cm ^ ((cp << 1) | (cp >> 63)), rho_src);
 }
 template <class G>
 BP_HD uint64_t kc_p4(uint64_t b, uint32_t x, uint32_t y, uint32_t j, uint32_t r, G &g) {
-    const uint64_t b1 = g(b, (x + 1) % 5 + 5 * y), b2 = g(b, (x + 2) % 5 + 5 * y);
+    const uint64_t b1 = g(b, (x + 1) % 5 + 5 * y, 0), b2 = g(b, (x + 2) % 5 + 5 * y, 0);
     uint64_t a = b ^ (~b1 & b2);
     if (j == 0) a ^= kc_rc(r);
     return a;
@@ -183,7 +187,7 @@ BP_HD uint64_t kc_p4(uint64_t b, uint32_t x, uint32_t y, uint32_t j, uint32_t r,
 #if defined(__HIP_DEVICE_COMPILE__)
 struct kc_fetch_dev {
     uint32_t base;   // first lane of this group in the wavefront (0 or 32)
-    __device__ __forceinline__ uint64_t operator()(uint64_t mine, uint32_t src) const {
+    __device__ __forceinline__ uint64_t operator()(uint64_t mine, uint32_t src, int) const {
         const int addr = (int)((base + src) << 2);
         const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)mine);
         const uint32_t hi = (uint32_t)__builtin_amdgcn_ds_bpermute(addr, (int)(uint32_t)(mine >> 32));
@@ -195,6 +199,7 @@ struct kc_fetch_dev {
 // written by the group's leader before and read by it after: the caller brackets the call with workgroup barriers.
 __device__ __forceinline__ void keccak_f1600_masked_coop(const kstate &st, const uint32_t *mask, uint32_t nmask, uint32_t lane) {
     const uint32_t jj = lane & 31, j = jj < 25 ? jj : 24, x = j % 5, y = j / 5;
+    const uint32_t src = kc_pi_src(j), rho_src = kc_rho(src);
     kc_fetch_dev g;
     g.base = lane & 32;
     uint32_t lo = st.w[(2 * j) * st.stride], hi = st.w[(2 * j + 1) * st.stride];
@@ -204,8 +209,7 @@ __device__ __forceinline__ void keccak_f1600_masked_coop(const kstate &st, const
 #pragma unroll 1
     for (uint32_t r = 0; r < 24; r++) {
         const uint64_t c = kc_p1(a, x, y, g);
-        a = kc_p2(a, c, x, y, g);
-        const uint64_t b = kc_p3(a, j, g);
+        const uint64_t b = kc_p23(a, c, src, rho_src, g);
         a = kc_p4(b, x, y, j, r, g);
     }
     if (jj < 25) {
@@ -216,8 +220,8 @@ __device__ __forceinline__ void keccak_f1600_masked_coop(const kstate &st, const
 #else
 // host twin (CPU harness): the same phase functions, every phase on a snapshot of the 25 lanes' values
 struct kc_fetch_host {
-    const uint64_t *snap;
-    uint64_t operator()(uint64_t, uint32_t src) const { return snap[src]; }
+    const uint64_t *snap[2];
+    uint64_t operator()(uint64_t, uint32_t src, int which) const { return snap[which][src]; }
 };
 inline void keccak_f1600_masked_coop(const kstate &st, const uint32_t *mask, uint32_t nmask, uint32_t) {
     uint64_t a[25], c[25], t[25];
@@ -229,16 +233,14 @@ inline void keccak_f1600_masked_coop(const kstate &st, const uint32_t *mask, uin
     }
     for (uint32_t r = 0; r < 24; r++) {
         kc_fetch_host g;
-        g.snap = a;
+        g.snap[0] = a;
+        g.snap[1] = nullptr;
         for (uint32_t j = 0; j < 25; j++) c[j] = kc_p1(a[j], j % 5, j / 5, g);
-        g.snap = c;
-        for (uint32_t j = 0; j < 25; j++) t[j] = kc_p2(a[j], c[j], j % 5, j / 5, g);
-        for (uint32_t j = 0; j < 25; j++) a[j] = kc_rotl_var(t[j], kc_rho(j));   // what lane j publishes in P3
-        g.snap = a;
-        for (uint32_t j = 0; j < 25; j++) c[j] = kc_p3(t[j], j, g);
-        g.snap = c;
-        for (uint32_t j = 0; j < 25; j++) t[j] = kc_p4(c[j], j % 5, j / 5, j, r, g);
-        for (uint32_t j = 0; j < 25; j++) a[j] = t[j];
+        g.snap[1] = c;
+        for (uint32_t j = 0; j < 25; j++) t[j] = kc_p23(a[j], c[j], kc_pi_src(j), kc_rho(kc_pi_src(j)), g);
+        g.snap[0] = t;
+        for (uint32_t j = 0; j < 25; j++) c[j] = kc_p4(t[j], j % 5, j / 5, j, r, g);
+        for (uint32_t j = 0; j < 25; j++) a[j] = c[j];
     }
     for (uint32_t j = 0; j < 25; j++) {
         st.w[(2 * j) * st.stride] = (uint32_t)a[j];

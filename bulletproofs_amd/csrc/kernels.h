@@ -45,8 +45,8 @@ template <bool WITH_OUT>
 __global__ void k_finish8(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, const ge_ext *partial, uint32_t *status, uint32_t *out_words, uint8_t *verdict, int reset_status, rp_seg_tab segs);
 __global__ void k_rp_stage1_coop(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs, const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields, ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m, uint32_t *recoded, fb_digit *digits, const uint8_t *rho64, const uint32_t *ts_in, uint32_t *ts_out, fb_entry *bk_pts, uint32_t bk_c, rp_seg_tab segs, const rp_script_hdr *script);
 template <bool SCRIPTED> __global__ void k_rp_stage1(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs, const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields, ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m, uint32_t *recoded, fb_digit *digits, const uint8_t *rho64, uint32_t ts_flags, const uint32_t *ts_in, uint32_t *ts_out, fb_entry *bk_pts, uint32_t bk_c, rp_seg_tab segs, const rp_script_hdr *script);
-template <bool PAIRS>
-__global__ void k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, ge_cached *colc, uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits, const uint32_t *status);
+template <int FORM>
+__global__ void k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, ge_cached *colc, uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits, const uint32_t *status, uint32_t n_exp, uint32_t nthreads_rows, uint32_t lg_m);
 template <bool PAIRS>
 __global__ void k_rp_exponents(uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits, const uint32_t *status);
 __global__ void k_rp_horner1(uint32_t nproofs, const ge_cached *colc, ge_ext *hq);

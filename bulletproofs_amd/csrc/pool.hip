@@ -810,9 +810,16 @@ static void pool_prewarm_buffers(bpgpu_pool *p, size_t n, size_t m) {
         std::lock_guard<std::mutex> lk(d->cmu);
         uint32_t cap = 0, cap_max = 0;
         comb_caps(p, d, key, 1, &cap, &cap_max);
+        uint32_t n_msm_sized = 0;
         for (comb_buf *b : d->cbufs) {
             if (b->st.load(std::memory_order_acquire) != CB_FREE) continue;   // (a pool that is already serving: whatever is in use stays as it is)
-            const size_t need = cbuf_layout(b, regions_of(key), cap_max);
+            size_t need = cbuf_layout(b, regions_of(key), cap_max);
+            // three of them also get room for a multiscalar-multiplication class (bpgpu_pool_msm_*: combine_msm_bytes of inputs + results) -- a
+            // request picks the free buffer with the largest blocks, and two chains in flight + one filling is what the cohort policy runs
+            if (n_msm_sized < 3) {
+                need = std::max<size_t>(need, (size_t)p->combine_msm_bytes.load(std::memory_order_relaxed) + ((size_t)1 << 20));
+                n_msm_sized++;
+            }
             if (need > b->mem_cap && cbuf_alloc(p, d, b, need)) continue;
             // (an aggregated shape's arena is ~0.3 MB per proof: sized here for the narrow chains a service's first callers form, a wide
             // chain grows it when it comes -- twelve lanes x 5120 proofs would take 17 GB at nm = 2048 before anybody asked)
@@ -834,8 +841,26 @@ static void pool_prewarm_chain(bpgpu_pool *p, size_t n, size_t m) {
     uint8_t st[BPGPU_TRANSCRIPT_BYTES], v = 0;
     bpgpu_transcript_new((const uint8_t *)"", 0, st);
     const std::string keep = t_pool_err;
+    // (the warm chains are nobody's requests: the stat_combined_* counters read as before them -- unless the pool is already serving)
+    const bool quiet = p->active_calls.load() == 0;
+    std::vector<uint64_t> before;
+    for (pool_dev *d : p->devs) before.insert(before.end(), {d->stat_chains.load(), d->stat_proofs.load(), d->stat_requests.load()});
     for (size_t i = 0; i < p->devs.size(); i++)   // (the queue hands consecutive calls to consecutive devices)
         (void)bpgpu_pool_rangeproof_verify_ts(p, n, m, 1, proof.data(), plen, coms.data(), st, 0, rng.data(), &v, nullptr, nullptr);
+    // ... and one multiscalar multiplication over the set's generators + 1 536 identity points (all scalars zero): the fused bucket chain's
+    // kernels (their own code object) are resident before the first bpgpu_pool_msm_* call (which used to take 13 - 31 ms)
+    if (nm <= 4096) {
+        const size_t ng = 2 * nm + 2, nu = 1536;
+        std::vector<uint8_t> gs(ng * 32, 0), us(nu * 32, 0), up(nu * 32, 0), out(32, 0);
+        uint8_t st1 = 0;
+        for (size_t i = 0; i < p->devs.size(); i++) (void)bpgpu_pool_msm_batch_shared(p, n, m, 1, nu, gs.data(), us.data(), up.data(), out.data(), &st1);
+    }
+    if (quiet && p->active_calls.load() == 0)
+        for (size_t i = 0; i < p->devs.size(); i++) {
+            p->devs[i]->stat_chains.store(before[3 * i]);
+            p->devs[i]->stat_proofs.store(before[3 * i + 1]);
+            p->devs[i]->stat_requests.store(before[3 * i + 2]);
+        }
     t_pool_err = keep;
 }
 

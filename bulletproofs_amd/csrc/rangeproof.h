@@ -42,6 +42,8 @@ struct rp_shape {
     // drawn, staged or copied on the host (64 bytes per proof at 6 ... 10 M proofs/s would be a core's worth of ChaCha)
     uint32_t defer_emit = 0;       // narrow chains (32 lanes per proof): the U coefficient recodings of the scalar role are done by U lanes at once instead of by
                                    // the leader one after the other (rp_defer; option coop_defer_emit)
+    uint32_t coop_split = 0;       // narrow chains, per-proof check: the k + 1 inversions run on k + 1 lanes of the group at once (rp_split_invert_lane) and the two
+                                   // basepoint coefficients are formed in launch 3 beside the exponents (rp_rows_thread); option coop_split
     uint32_t seeded = 0;           // RP_SEED_RNG | RP_SEED_WEIGHTS
     uint32_t seed[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
@@ -705,8 +707,12 @@ BP_HD void rp_emit_deferred(uint32_t lane32, uint32_t p, const rp_shape &sh, uin
 // rho64 (optional): batch-combination mode (bpgpu_rangeproof_verify_rlc): every coefficient of proof p is
 // multiplied by its weight rho_p = from_bytes_mod_order_wide(rho64[p]); the B_blinding / B coefficients go to
 // the ROW0 / ROW1 fields instead of `digits` (they are summed over the batch in the next launch).
+// skip (narrow chains, option coop_split; never with weights): RP_SKIP_INV -- the inversions, u_i^2, u_i^-2 and the y^-(2^b) table were
+// written by the group's lanes (rp_split_invert_lane); RP_SKIP_ROWS -- the B_blinding / B coefficients are formed in launch 3 (rp_rows_thread).
+enum { RP_SKIP_INV = 1, RP_SKIP_ROWS = 2 };
 BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t lg_m, uint32_t *fields, uint32_t *recoded,
-                              fb_digit *digits, const uint32_t *status, const uint8_t *rho64 = nullptr, uint32_t bk_c = 0, const rp_defer *df = nullptr) {
+                              fb_digit *digits, const uint32_t *status, const uint8_t *rho64 = nullptr, uint32_t bk_c = 0, const rp_defer *df = nullptr,
+                              uint32_t skip = 0) {
     if (status[p] != 0) return;   // digits/scalars of rejected proofs are never consumed (finish masks them)
     const uint32_t B = sh.nproofs, k = sh.k;
     const rp_fields fl = rp_field_layout(k, sh.m);
@@ -728,14 +734,20 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
         rho = &rho_m;
     }
     sc28 ym;
-    {
+    if (!(skip & RP_SKIP_INV) || !(skip & RP_SKIP_ROWS)) {
         sc y;
         rp_load(y, fields, B, RPF_Y, p);
         sc_to_mont28(ym, y);
     }
+#define RP_EMIT(idx, val)                                                                 \
+    do {                                                                                  \
+        if (df) df->slot[(idx)] = (val);                                                  \
+        else rp_emit_coeff(recoded + (uint64_t)p * sh.U * (bk_c ? BK_RWORDS : 8), (idx), (val), rho, bk_c, p * sh.U, sh.radix5 != 0);        \
+    } while (0)
 
     // batch inversion of (y, u_0, .., u_{k-1}) (Scalar::batch_invert, ipp.rs:226-227; y.invert(), mod.rs:414),
     // everything in Montgomery form; prefix products are parked in the uinv_m slots (overwritten below)
+    if (!(skip & RP_SKIP_INV)) {
     sc28 acc = ym, um;
     sc u;
     for (uint32_t i = 0; i < k; i++) {
@@ -747,16 +759,6 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
     }
     sc28 inv;
     sc28_invert_mont_safegcd(inv, acc);                   // (y * prod u_i)^-1
-    uint32_t *us = recoded + (uint64_t)p * sh.U * (bk_c ? BK_RWORDS : 8);
-    if (df) {   // the coefficients are parked for the group's lanes (rp_emit_deferred)
-        df->meta[1] = rho ? 1u : 0u;
-        if (rho) df->slot[RP_DEFER_CAP] = rho_m;
-    }
-#define RP_EMIT(idx, val)                                                                 \
-    do {                                                                                  \
-        if (df) df->slot[(idx)] = (val);                                                  \
-        else rp_emit_coeff(us, (idx), (val), rho, bk_c, p * sh.U, sh.radix5 != 0);        \
-    } while (0)
     for (uint32_t ii = k; ii-- > 0;) {
         sc28 pre, uim, sq;
         rp_load28(pre, fields, B, fl.uinv_m + ii, p);
@@ -776,6 +778,11 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
             rp_store28(fields, B, fl.yinvp_m + bb, p, pw);
             sc28_montmul(pw, pw, pw);
         }
+    }
+    }   // (!RP_SKIP_INV)
+    if (df) {   // the coefficients are parked for the group's lanes (rp_emit_deferred)
+        df->meta[1] = rho ? 1u : 0u;
+        if (rho) df->slot[RP_DEFER_CAP] = rho_m;
     }
     // (the remaining inputs are loaded only now: nothing but y and the u_i is live across the inversion)
     sc z, x, w, c, tx, txb, eb, a, b;
@@ -851,7 +858,7 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
         }
     }
     // B_blinding coefficient: -e_blinding - c t_x_blinding  (row 0)
-    {
+    if (!(skip & RP_SKIP_ROWS)) {
         sc28 pm;
         sc28_montmul(pm, cm, txbm);
         sc_from_mont28(t0, pm);
@@ -868,7 +875,7 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
         }
     }
     // B coefficient: w (t_x - a b) + c (delta(y,z) - t_x)  (row 1)
-    {
+    if (!(skip & RP_SKIP_ROWS)) {
         sc28 abm, pm, sum_ym, sum_zm, dm;
         sc ab, dl, sum_2;
         sc28_montmul(abm, am, bm);
@@ -914,6 +921,134 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
     }
 #undef RP_EMIT
     if (df) df->meta[0] = 1;   // every coefficient is parked
+}
+
+// ---- the scalar role of a NARROW chain, split (option coop_split; per-proof check only, never with weights) -----------------------
+// After its transcript the leader of a 32-lane group used to spend ~125 us alone: 6 prefix products, one inversion by division steps
+// (~60 us), 4 products per round to peel the u_i^-1 off again, the y^-(2^b) table, and ~35 products for the two basepoint coefficients.
+// Split three ways:
+//   * lanes 0 .. k of the group invert ONE value each -- u_0 .. u_{k-1} and y -- in lockstep (the division steps have a fixed structure,
+//     scinv.h), then square their value and its inverse: no prefix / suffix products at all, and lane k runs the y^-(2^b) squarings;
+//   * the leader forms what is left of rp_expand_a_thread (the x, z, c coefficients, the z tables);
+//   * the B_blinding / B coefficients -- the longest chain of products, needed by launch 4 only -- are a role of launch 3 (rp_rows_thread).
+// Same values mod l everywhere (the Montgomery-form fields are lazy representatives and may differ in their limbs; every digit that
+// leaves the stage is recoded from a canonical scalar).
+struct rp_split {
+    uint32_t *park;   // [32][8]: canonical u_0 .. u_{k-1}, y -- parked by the leader for the group's lanes
+    uint32_t *go;     // [1]: the proof is still undecided (status 0)
+};
+// leader, after the transcript
+BP_HD void rp_split_park(uint32_t p, const rp_shape &sh, const uint32_t *fields, const uint32_t *status, const rp_split &sp) {
+    const uint32_t B = sh.nproofs, k = sh.k;
+    const bool go = status[p] == 0 && !sh.shape_verdict && k < 32;
+    sp.go[0] = go ? 1u : 0u;
+    if (!go) return;
+    const rp_fields fl = rp_field_layout(k, sh.m);
+    sc v;
+    for (uint32_t i = 0; i <= k; i++) {
+        rp_load(v, fields, B, i < k ? fl.u + i : (uint32_t)RPF_Y, p);
+#pragma unroll
+        for (int q = 0; q < 8; q++) sp.park[8 * i + q] = v.v[q];
+    }
+}
+// lane i = 0 .. k of the group (the others return at once)
+BP_HD void rp_split_invert_lane(uint32_t i, uint32_t p, const rp_shape &sh, uint32_t *fields, uint32_t *recoded, const rp_split &sp, const rp_defer *df) {
+    const uint32_t B = sh.nproofs, k = sh.k;
+    if (!sp.go[0] || i > k) return;
+    const rp_fields fl = rp_field_layout(k, sh.m);
+    sc v, vi;
+#pragma unroll
+    for (int q = 0; q < 8; q++) v.v[q] = sp.park[8 * i + q];
+    sc_invert_safegcd(vi, v);
+    sc28 vm, im, sq, isq;
+    sc_to_mont28(vm, v);
+    sc_to_mont28(im, vi);
+    sc28_montmul(sq, vm, vm);
+    sc28_montmul(isq, im, im);
+    if (i < k) {
+        rp_store28(fields, B, fl.u_m + i, p, vm);
+        rp_store28(fields, B, fl.uinv_m + i, p, im);
+        if (df) {
+            df->slot[4 + i] = sq;           // u_i^2   -> L_i coefficient
+            df->slot[4 + k + i] = isq;      // u_i^-2  -> R_i coefficient
+        } else {
+            uint32_t *us = recoded + (uint64_t)p * sh.U * 8;
+            rp_emit_coeff(us, 4 + i, sq, nullptr, 0, p * sh.U, sh.radix5 != 0);
+            rp_emit_coeff(us, 4 + k + i, isq, nullptr, 0, p * sh.U, sh.radix5 != 0);
+        }
+    } else {   // y: the table of y^-(2^b)
+        rp_store28(fields, B, fl.yinvp_m + 0, p, im);
+        sc28 pw = isq;
+        for (uint32_t bb = 1; bb < k; bb++) {
+            rp_store28(fields, B, fl.yinvp_m + bb, p, pw);
+            sc28_montmul(pw, pw, pw);
+        }
+    }
+}
+// launch 3, lane = proof: the digits of the B_blinding (row 0) and B (row 1) coefficients from the fields launch 1 left
+// (mod.rs:422-432's last two scalars; delta: mod.rs:587-593)
+BP_HD void rp_rows_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t lg_m, const uint32_t *fields, fb_digit *digits, const uint32_t *status) {
+    if (status[p] != 0) return;
+    const uint32_t B = sh.nproofs, k = sh.k;
+    sc y, z, zz, w, c, tx, txb, eb, t0, t1;
+    rp_load(y, fields, B, RPF_Y, p);
+    rp_load(z, fields, B, RPF_Z, p);
+    rp_load(zz, fields, B, RPF_ZZ, p);
+    rp_load(w, fields, B, RPF_W, p);
+    rp_load(c, fields, B, RPF_C, p);
+    rp_load(tx, fields, B, RPF_TX, p);
+    rp_load(txb, fields, B, RPF_TXB, p);
+    rp_load(eb, fields, B, RPF_EB, p);
+    sc28 ym, zm, zzm, wm, cm, txbm, am, bm;
+    sc_to_mont28(ym, y);
+    sc_to_mont28(wm, w);
+    sc_to_mont28(cm, c);
+    sc_to_mont28(txbm, txb);
+    rp_load28(zm, fields, B, RPF_Z_M, p);
+    rp_load28(zzm, fields, B, RPF_ZZ_M, p);
+    rp_load28(am, fields, B, RPF_A_M, p);
+    rp_load28(bm, fields, B, RPF_B_M, p);
+    {   // -e_blinding - c t_x_blinding
+        sc28 pm;
+        sc28_montmul(pm, cm, txbm);
+        sc_from_mont28(t0, pm);
+        sc_add(t0, t0, eb);
+        sc_neg(t0, t0);
+        fb_recode(digits + ((uint64_t)0 * prm.nwin) * B + p, B, t0.v, prm);
+    }
+    {   // w (t_x - a b) + c (delta(y,z) - t_x)
+        sc28 abm, pm, sum_ym, sum_zm, dm;
+        sc ab, dl, sum_2;
+        sc28_montmul(abm, am, bm);
+        sc_from_mont28(ab, abm);
+        sc_sub(t0, tx, ab);
+        sc_to_mont28(pm, t0);
+        sc28_montmul(pm, wm, pm);
+        sc_from_mont28(t0, pm);
+        rp_sum_of_powers_pow2(sum_ym, ym, k);
+        rp_sum_of_powers_pow2(sum_zm, zm, lg_m);
+        sc_0(sum_2);
+        if (sh.n >= 64) { sum_2.v[0] = 0xffffffffu; sum_2.v[1] = 0xffffffffu; }
+        else if (sh.n >= 32) { sum_2.v[0] = 0xffffffffu; sum_2.v[1] = (sh.n == 32) ? 0u : ((1u << (sh.n - 32)) - 1u); }
+        else sum_2.v[0] = (1u << sh.n) - 1u;
+        sc_sub(t1, z, zz);
+        sc_to_mont28(dm, t1);
+        sc28_montmul(dm, dm, sum_ym);
+        sc_from_mont28(dl, dm);
+        sc28 z3m, s2m;
+        sc28_montmul(z3m, zzm, zm);
+        sc_to_mont28(s2m, sum_2);
+        sc28_montmul(z3m, z3m, s2m);
+        sc28_montmul(z3m, z3m, sum_zm);
+        sc_from_mont28(t1, z3m);
+        sc_sub(dl, dl, t1);
+        sc_sub(t1, dl, tx);
+        sc_to_mont28(pm, t1);
+        sc28_montmul(pm, cm, pm);
+        sc_from_mont28(t1, pm);
+        sc_add(t0, t0, t1);
+        fb_recode(digits + ((uint64_t)1 * prm.nwin) * B + p, B, t0.v, prm);
+    }
 }
 
 // ---- stage 3: per-(generator, proof) scalars -------------------------------------------------
@@ -1015,8 +1150,9 @@ BP_HD void sc28_sub_lazy(sc28 &r, const sc28 &a, const sc28 &b) {
 // they are used -- three running products stay live across the loop, 167 registers (three wavefronts per SIMD), no scratch, no LDS
 // (a 10 KB scratchpad per wavefront was measured first: same kernel time, but its LDS footprint kept the transcript wavefronts of
 // the NEXT chain off the CUs: -12 % on 20 x 1024 bursts).  Price: one more Montgomery product per index (8 + instead of 7 +).
+// j_lo .. j_hi: which of the four indices this lane handles (all four: the throughput form; one: rp_expand_b1_thread)
 BP_HD void rp_expand_b4_thread(uint32_t tid, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits,
-                               const uint32_t *status, sc *g_out = nullptr, sc *h_out = nullptr) {
+                               const uint32_t *status, sc *g_out = nullptr, sc *h_out = nullptr, uint32_t j_lo = 0, uint32_t j_hi = 4) {
     const uint32_t B = sh.nproofs, k = sh.k;
     const uint32_t t4 = tid / B, p = tid - t4 * B, i0 = 4 * t4;
     if (g_out) {
@@ -1055,7 +1191,7 @@ BP_HD void rp_expand_b4_thread(uint32_t tid, rp_shape sh, fb_params prm, const u
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll 1
 #endif
-    for (uint32_t j = 0; j < 4; j++) {
+    for (uint32_t j = j_lo; j < j_hi; j++) {
         const uint32_t i = i0 + j;
         // bits 0 (challenge k-1) and 1 (challenge k-2) of the index: s_i takes u or u^-1 by the bit, s_i^-1 the other one
         const uint32_t fa = (j & 1) ? fl.u_m + (k - 1) : fl.uinv_m + (k - 1), fa_c = (j & 1) ? fl.uinv_m + (k - 1) : fl.u_m + (k - 1);
@@ -1116,7 +1252,13 @@ BP_HD void rp_expand_b4_thread(uint32_t tid, rp_shape sh, fb_params prm, const u
         }
     }
 }
-
+// ONE generator index per thread (narrow chains: launch 3 is latency, not work): tid = i * nproofs + p, i < nm.  The lane forms the shared
+// products of bits >= 2 itself (k - 2 rounds) and then the one index: ~21 Montgomery products in sequence instead of ~55 (four indices)
+// or ~80 (the mirrored pairs); 1.6 x the role's instructions, which a chain of <= 256 proofs does not notice.  Same code, same digits.
+BP_HD void rp_expand_b1_thread(uint32_t tid, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits, const uint32_t *status) {
+    const uint32_t B = sh.nproofs, i = tid / B, p = tid - i * B;
+    rp_expand_b4_thread((i >> 2) * B + p, sh, prm, fields, digits, status, nullptr, nullptr, i & 3, (i & 3) + 1);
+}
 
 // EIGHT generator indices per thread, in mirrored pairs (round 6): tid = t * nproofs + p, t < nm/8; the four indices i = 4t .. 4t+3 of the
 // lower half and their mirror images i' = nm - 1 - i.  nm is a power of two, so the bits of i' are the complements of the bits of i:

@@ -386,6 +386,8 @@ void h_set_a_outside(int on) { g_a_outside = on; }
 // items live in separate buffers (every second one without rng bytes of its own) and reports through it
 static int g_defer_emit = 0;
 void h_set_defer_emit(int on) { g_defer_emit = on; }
+static int g_coop_split = 0;   // the narrow chain's split scalar role (rp_split_*, rp_rows_thread); per-proof verification only
+void h_set_coop_split(int on) { g_coop_split = on; }
 static std::vector<uint32_t> g_seg_sizes;
 void h_set_segments(uint32_t count, const uint32_t *sizes) { g_seg_sizes.assign(sizes, sizes + count); }
 // ... and item i verifies under label i mod count (labels of ONE length: they share every transcript position, rp_seg::init_w)
@@ -510,6 +512,17 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
     for (uint32_t p = 0; p < nbatch; p++) {
         uint32_t stw[50]; kstate st; st.w = stw; st.stride = 1;
         rp_transcript_thread(p, sh, init, st, rp_resolve(p, sh, proofs_l1, coms_l1, rng64, segtab), fields.data(), status.data());
+        if (g_coop_split && !rlc && sh.k < 32) {   // the narrow chain's split form, phase by phase as k_rp_stage1_coop runs it (launch 2 below adds rp_rows_thread)
+            std::vector<sc28> slots(RP_DEFER_CAP + 1);
+            uint32_t meta[2] = {0, 0}, park[32 * 8], go = 0;
+            const bool defer = g_defer_emit && sh.U <= RP_DEFER_CAP;
+            rp_defer df; df.slot = slots.data(); df.meta = meta;
+            rp_split sp; sp.park = park; sp.go = &go;
+            rp_split_park(p, sh, fields.data(), status.data(), sp);
+            for (uint32_t lane = 0; lane < 32; lane++) rp_split_invert_lane(lane, p, sh, fields.data(), rec.data(), sp, defer ? &df : nullptr);
+            rp_expand_a_thread(p, sh, prm, lg_m, fields.data(), rec.data(), digits.data(), status.data(), nullptr, 0, defer ? &df : nullptr, RP_SKIP_INV | RP_SKIP_ROWS);
+            if (defer) for (uint32_t lane = 0; lane < 32; lane++) rp_emit_deferred(lane, p, sh, rec.data(), df, 0);
+        } else
         if (g_defer_emit && sh.U <= RP_DEFER_CAP) {   // the narrow chain's form: the leader parks the coefficients, 32 lanes recode them (rp_defer)
             std::vector<sc28> slots(RP_DEFER_CAP + 1);
             uint32_t meta[2] = {0, 0};
@@ -540,6 +553,8 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
         }
     } else {
         for (uint32_t tid = 0; tid < (sh.nm / 4) * nbatch; tid++) rp_expand_b4_thread(tid, sh, prm, fields.data(), digits.data(), status.data());
+        if (g_coop_split && sh.k < 32)
+            for (uint32_t p = 0; p < nbatch; p++) rp_rows_thread(p, sh, prm, lg_m, fields.data(), digits.data(), status.data());
         // the mirrored-pair form of the role (rp_expand_b8_thread, what the device runs since round 6): the same digits, every row
         if (sh.nm >= 8) {
             std::vector<fb_digit> d4(digits), d8(digits);
@@ -551,6 +566,19 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
                 for (size_t row = 2; row < 2 + 2 * (size_t)sh.nm; row++)
                     for (uint32_t w = 0; w < prm.nwin; w++)
                         if (d8[(row * prm.nwin + w) * nbatch + p] != d4[(row * prm.nwin + w) * nbatch + p]) return -77;
+            }
+        }
+        // ... and the one-index-per-lane form of narrow chains (rp_expand_b1_thread)
+        if (sh.nm >= 4) {
+            std::vector<fb_digit> d1(digits);
+            const size_t rows0 = (size_t)2 * prm.nwin * nbatch, rows1 = (size_t)(2 + 2 * sh.nm) * prm.nwin * nbatch;
+            for (size_t q = rows0; q < rows1 && q < d1.size(); q++) d1[q] = (fb_digit)0x5a5a5a5a;
+            for (uint32_t tid = 0; tid < sh.nm * nbatch; tid++) rp_expand_b1_thread(tid, sh, prm, fields.data(), d1.data(), status.data());
+            for (uint32_t p = 0; p < nbatch; p++) {
+                if (status[p] != 0) continue;
+                for (size_t row = 2; row < 2 + 2 * (size_t)sh.nm; row++)
+                    for (uint32_t w = 0; w < prm.nwin; w++)
+                        if (d1[(row * prm.nwin + w) * nbatch + p] != digits[(row * prm.nwin + w) * nbatch + p]) return -78;
             }
         }
     }

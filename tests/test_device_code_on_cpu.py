@@ -403,15 +403,17 @@ def test_shared_generator_pipeline_lane_by_lane(H, oracle, W, nsplit):
     assert vd.raw[0] == 0 and out.raw[:32] == bytes(32)
 
 
-@pytest.mark.parametrize("horner_lanes", [1, 4, 64, "radix32", "radix32+a_outside", "a_outside", "64+defer_emit"])
+@pytest.mark.parametrize("horner_lanes", [1, 4, 64, "radix32", "radix32+a_outside", "a_outside", "64+defer_emit", "64+split", "64+defer_emit+split"])
 def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, golden, horner_lanes):
     """rp_transcript -> rp_expand_a/b -> vb_* / fb_* -> finish, emulated lane by lane, on the reference's
     golden proofs (small shapes; the GPU tests cover all 16) plus tampered copies.  The Horner layouts:
     1 lane per chain (msm_vb.h), 4 (horner_quad.h), 64 (horner_wave.h); the wide chains' forms (one-lane chain): "radix32" -- the proofs'
     own points in signed radix 32 (16-entry tables, 51 windows); "a_outside" -- A, whose coefficient is 1, added after the chain."""
-    defer = horner_lanes == "64+defer_emit"     # the narrow chain's form: the scalar role's coefficients parked by the leader, recoded by 32 lanes (rp_defer)
+    defer = isinstance(horner_lanes, str) and "defer_emit" in horner_lanes   # the narrow chain's form: the scalar role's coefficients parked by the leader, recoded by 32 lanes (rp_defer)
+    split = isinstance(horner_lanes, str) and "split" in horner_lanes        # ... and its split scalar role (round 6): k + 1 lanes invert one value each, the basepoint coefficients are a role of the next launch
     H.h_set_defer_emit(1 if defer else 0)
-    if defer:
+    H.h_set_coop_split(1 if split else 0)
+    if defer or split:
         horner_lanes = 64
     wide = isinstance(horner_lanes, str)
     H.h_set_radix5(1 if wide and "radix32" in horner_lanes else 0)
@@ -454,6 +456,7 @@ def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, gol
     H.h_set_radix5(0)
     H.h_set_a_outside(0)
     H.h_set_defer_emit(0)
+    H.h_set_coop_split(0)
 
 
 def test_radix32_recoding_reconstructs_the_scalar(H):
