@@ -93,8 +93,9 @@ struct bpgpu_ctx {
                                                                     // 0.528 / 0.528 / 0.533 -> 0.521 / 0.526 / 0.518 ms, 16 threads p50 0.64 -> 0.62 ms, 16 x 128 tickets 801 -> 819 k/s
                                                                     // (profiles/r05/coop_defer_emit_ab.txt; the kernel's duration for ONE proof is unchanged, 238 us: the gain is at several
                                                                     // groups per launch); 0: the leader recodes them one after the other
-    int narrow_chunk = 0;                                           // narrow chains: per-proof points per (chunk, window) lane of launch 3; 0 = ~sqrt(U) (the Horner wavefront adds the chunks' rows), 32 = one chunk
+    int narrow_chunk = 0;                                           // narrow chains: per-proof points per (chunk, window) lane of launch 3; 0 = 8 (the Horner wavefront adds the chunks' rows), 32 = one chunk
     int exp_single = 1;                                             // narrow chains: the generator-exponent role with one index per lane (rp_expand_b1_thread); 0: as wide chains
+    int narrow_walk = 1;                                            // narrow chains: the table walk with lane = split and the partial sums folded in launch 4 (k_rp34.hip rp_walk_narrow); 0: thread = proof
     int coop_split = 1;                                             // narrow chains, per-proof check: the k + 1 inversions on k + 1 lanes of the group at once, the basepoint coefficients as a
                                                                     // role of launch 3 (rangeproof.h rp_split_invert_lane / rp_rows_thread); 0: the leader does it all (A/B: profiles/r06/coop_split_ab.txt)
     int transcript_coop = 1;                                        // chains of up to 256 proofs replay their transcripts 32 lanes per proof (keccak.h): one call of 1 / 8 / 64 / 256 proofs 0.62 -> 0.53 / 0.56 / 0.57 / 0.58 ms; 0: lane = proof everywhere
@@ -419,6 +420,7 @@ int bpgpu_ctx_create(int device, bpgpu_ctx **out) {
         return BPGPU_ERR_HIP;
     }
     if (const char *e = getenv("BPGPU_COOP_SPLIT")) c->coop_split = atoi(e) != 0;
+    if (const char *e = getenv("BPGPU_NARROW_WALK")) c->narrow_walk = atoi(e) != 0;
     if (const char *e = getenv("BPGPU_EXP_SINGLE")) c->exp_single = atoi(e) != 0;
     if (const char *e = getenv("BPGPU_NARROW_CHUNK")) c->narrow_chunk = atoi(e);
     if (const char *e = getenv("BPGPU_COOP_DEFER_EMIT")) c->coop_defer_emit = atoi(e) != 0;   // (A/B of whole test suites: the option's default for every context of the process)
@@ -505,6 +507,10 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
     }
     if (!strcmp(key, "exp_single")) {
         c->exp_single = value != 0;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "narrow_walk")) {
+        c->narrow_walk = value != 0;
         return BPGPU_OK;
     }
     if (!strcmp(key, "coop_split")) {
@@ -1966,7 +1972,13 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const uint32_t forms = rp_chain_forms(c->horner_lanes, c->split_stage3, c->busy_hint, c->vb_radix, c->a_outside, nbatch, rlc || shape_verdict != 0,
                                           s == c->stream2);
     const bool wide = forms & RPC_WIDE, wave = forms & RPC_WAVE, aside = forms & RPC_ASIDE, r5 = forms & RPC_RADIX32, a_out = forms & RPC_A_OUTSIDE;
-    const uint32_t nsplit = pick_splits(c, nbatch, npairs, aside);
+    uint32_t nsplit = pick_splits(c, nbatch, npairs, aside);
+    // narrow chains in the wavefront-per-chain form: the walk with lane = split, a multiple of 64 splits per proof (rp_walk_narrow)
+    const bool narrow_walk = wave && !wide && !rlc && nbatch <= 256 && c->narrow_walk;
+    if (narrow_walk) {
+        nsplit = (nsplit + FB_BLOCK - 1) / FB_BLOCK * FB_BLOCK;
+        while (nsplit > FB_BLOCK && npairs / nsplit < 4) nsplit -= FB_BLOCK;
+    }
     // thread / element counts are 32-bit in the kernels: refuse what does not fit
     if ((uint64_t)n_gen_terms * nbatch > 0x7fffffffull || (uint64_t)nbatch * sh.U > 0x7fffffffull / 64 ||
         (uint64_t)nbatch * ((sh.U + BP_VB_CHUNK - 1) / BP_VB_CHUNK) * 64 > 0x7fffffffull || (uint64_t)(sh.nm / 4 + 1) * nbatch > 0x7fffffffull ||
@@ -1977,13 +1989,10 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const bk_params bkp = bk_make(pick_bucket_c(rlc_terms));
     const bool rlc_bucket = rlc && !shape_verdict && rlc_terms >= (c->bucket_min ? c->bucket_min : BK_RLC_MIN_TERMS) && bucket_fits(1, rlc_terms, bkp);
     // Narrow chains (one wavefront per Horner chain, which adds the chunks' window sums itself): a (chunk, window) lane adding all U table
-    // entries one after the other is ~50 us of a one-proof chain's launch 3.  With chunks of ~sqrt(U) terms a lane adds ~sqrt(U) entries
-    // and the Horner wavefront's lane w adds ~sqrt(U) rows: 8 additions in sequence instead of 16 at U = 17.  (Option narrow_chunk.)
+    // entries one after the other is ~50 us of a one-proof chain's launch 3.  With chunks of 8 terms a lane adds 8 entries and the Horner
+    // wavefront's lane w adds the U / 8 rows of its window.  (Option narrow_chunk.)
     uint32_t narrow_q = (uint32_t)c->narrow_chunk;
-    if (narrow_q == 0) {
-        narrow_q = 4;
-        while (narrow_q * narrow_q < sh.U) narrow_q++;
-    }
+    if (narrow_q == 0) narrow_q = 8;   // (A/B at U = 17, profiles/r06/narrow_chain_ab.txt: 3 / 5 / 8 / 32 -> one call 0.456 / 0.457 / 0.448 / 0.464 ms; launch 3 is then bound by its basepoint-coefficient role)
     narrow_q = narrow_q < 2 ? 2u : (narrow_q > BP_VB_CHUNK ? (uint32_t)BP_VB_CHUNK : narrow_q);
     const bool narrow_ok = !rlc && !shape_verdict && (c->horner_lanes == 0 || c->horner_lanes == 64);   // (narrow chains of this context take the wavefront-per-chain form)
     const uint32_t vb_chunk_sz = (wave && !wide && narrow_ok && nbatch <= 256) ? narrow_q : (uint32_t)BP_VB_CHUNK;
@@ -2235,7 +2244,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
             LAUNCH(c, s, "rlc_colsum", k_rlc_colsum_scalars, n_sc, BP_BLOCK, 0u, 0u, 0u, 1u, (const ge_ext *)cur, next, n_gen_terms,
                    (const unsigned long long *)d_acc, d_dig1, prm, d_ctl, rows);
         LAUNCH(c, s, "rlc_stage4", k_rp_stage4<64>, 1 + nsplit1, FB_BLOCK, 1u, d_ctl + 2, cur, (const ge_cached *)nullptr, d_hq1, prm, 1u, 1u,
-               nsplit1, npairs, d_ids, d_dig1, gen_table, d_part1);
+               nsplit1, npairs, d_ids, d_dig1, gen_table, d_part1, 0u);
         if (d_batch_out)
             LAUNCH(c, s, "rlc_finish", k_rlc_finish<true>, 1, 64, nsplit1, d_hq1, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)d_batch_out, segtab);
         else
@@ -2295,26 +2304,36 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         LAUNCH(c, s, "vb_colsum", k_vb_colsum, (nc + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nc, d.chunk_first, d.part, (uint32_t *)nullptr, d_colc);
     }
     const uint32_t nblk_p = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
+    uint32_t nparts = nsplit;   // partial sums per proof that launch 4 leaves
     if (horner_aside) {
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<4>, nblk_p * nsplit, FB_BLOCK, 0u, d.chunk_first, d.part, d_colc, d.hq, prm, nb32, nblk_p,
-               nsplit, npairs, d_ids, d_digits, gen_table, d_partial);
+               nsplit, npairs, d_ids, d_digits, gen_table, d_partial, 0u);
         HIPCHK(c, hipStreamWaitEvent(s, c->join_ev, 0));
     } else if (quad && one_lane) {
         const uint32_t n_hw = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<1>, n_hw + nblk_p * nsplit, FB_BLOCK, n_hw, d.chunk_first, d.part, d_colc, d.hq, prm, nb32, nblk_p,
-               nsplit, npairs, d_ids, d_digits, gen_table, d_partial);
+               nsplit, npairs, d_ids, d_digits, gen_table, d_partial, 0u);
     } else if (quad) {
         const uint32_t n_hw = (nb32 + 15) / 16;
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<4>, n_hw + nblk_p * nsplit, FB_BLOCK, n_hw, d.chunk_first, d.part, d_colc, d.hq, prm, nb32, nblk_p,
-               nsplit, npairs, d_ids, d_digits, gen_table, d_partial);
+               nsplit, npairs, d_ids, d_digits, gen_table, d_partial, 0u);
+    } else if (narrow_walk) {   // lane = split: a proof's partial sums are folded inside launch 4 (k_rp34.hip: rp_walk_narrow)
+        nparts = nsplit / FB_BLOCK;
+        LAUNCH(c, s, "rp_stage4", k_rp_stage4<64>, nb32 + nb32 * nparts, FB_BLOCK, nb32, d.chunk_first, d.part, (const ge_cached *)nullptr, d.hq,
+               prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, gen_table, d_partial, 1u);
     } else {
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<64>, nb32 + nblk_p * nsplit, FB_BLOCK, nb32, d.chunk_first, d.part, (const ge_cached *)nullptr, d.hq,
-               prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, gen_table, d_partial);
+               prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, gen_table, d_partial, 0u);
     }
     ge_ext *d_red = nullptr;
     uint32_t nred = 0;
-    enqueue_fb_reduce(c, s, nb32, nsplit, d_partial, &d_red, &nred, 64);   // 8 lanes x <= 8 partials each in finish8
-    if (d_msm_out)
+    enqueue_fb_reduce(c, s, nb32, nparts, d_partial, &d_red, &nred, 64);   // 8 lanes x <= 8 partials each in finish8
+    if (nred == 1 && narrow_walk) {   // one partial sum + the Horner result per proof: lane = proof
+        if (d_msm_out)
+            LAUNCH(c, s, "finish1", k_finish1<true>, (nb32 + 63) / 64, 64, nb32, d.hq, d_red, d_status, (uint32_t *)d_msm_out, (uint8_t *)d_verdict, 1, segtab);
+        else
+            LAUNCH(c, s, "finish1", k_finish1<false>, (nb32 + 63) / 64, 64, nb32, d.hq, d_red, d_status, (uint32_t *)nullptr, (uint8_t *)d_verdict, 1, segtab);
+    } else if (d_msm_out)
         LAUNCH(c, s, "finish8", k_finish8<true>, (nb32 + 7) / 8, 64, nb32, nred, d.hq, d_red, d_status, (uint32_t *)d_msm_out, (uint8_t *)d_verdict, 1, segtab);
     else
         LAUNCH(c, s, "finish8", k_finish8<false>, (nb32 + 7) / 8, 64, nb32, nred, d.hq, d_red, d_status, (uint32_t *)nullptr, (uint8_t *)d_verdict, 1, segtab);

@@ -70,6 +70,10 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1_coop(rp_shape sh, rp_str
     __shared__ uint32_t dmeta[2][2];
     __shared__ uint32_t spark[2][32 * 8];   // (option coop_split) the k + 1 values the group's lanes invert, one each
     __shared__ uint32_t sgo[2];
+    __shared__ uint32_t schal[2][16 * 32];  // the raw challenges, parked by the leader for the lanes that reduce them
+    __shared__ uint32_t sflag[2];
+    __shared__ uint32_t sstage[2][RP_COOP_STAGE_WORDS];   // the proof's bytes and its commitments
+    __shared__ uint32_t sops[RP_COOP_OPS_CAP * 4 + RP_COOP_MASKS_CAP * RS_MASK_WORDS];   // the script's operations and masks (the same for both groups)
     if (blockIdx.x < n_tr) {
         const uint32_t lane = threadIdx.x, g = lane >> 5, p = blockIdx.x * 2 + g;
         const bool valid = p < sh.nproofs;
@@ -78,26 +82,55 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1_coop(rp_shape sh, rp_str
         st.w = lds + 52 * g;
         st.stride = 1;
         const bool defer = sh.defer_emit && sh.U <= RP_DEFER_CAP;   // (wavefront-uniform)
-        const bool split = sh.coop_split && !rho64 && !bk_c && !(sh.seeded & RP_SEED_WEIGHTS) && sh.k < 32;   // (launch-uniform)
+        const bool split = sh.coop_split && !rho64 && !bk_c && !(sh.seeded & RP_SEED_WEIGHTS) && sh.k <= 26;   // (launch-uniform)
         if ((lane & 31) == 0) {
             dmeta[g][0] = 0;
             sgo[g] = 0;
+            sflag[g] = 0;
         }
-        rp_transcript_scripted_coop(pp, valid, lane, sh, init, st, rp_resolve(pp, sh, proofs, commitments, rng64, segs), script, fields, status, ts_out, ts_in);
+        rp_inputs in = rp_resolve(pp, sh, proofs, commitments, rng64, segs);
         rp_defer df;
         df.slot = dslot[g];
         df.meta = dmeta[g];
-        if (split) {   // the inversions on k + 1 lanes at once; the leader forms the rest; the basepoint coefficients wait for launch 3
+        if (split) {
+            // everything the leader would fetch from global memory one dependent load after the other, staged by all lanes at once
+            const rp_script_op *ops_l = nullptr;
+            const uint32_t *masks_l = nullptr;
+            if (script->n_ops <= RP_COOP_OPS_CAP && script->n_masks <= RP_COOP_MASKS_CAP) {
+                const uint32_t *src = (const uint32_t *)rp_script_ops(script);
+                const uint32_t nw = script->n_ops * 4 + script->n_masks * RS_MASK_WORDS;   // (the masks follow the operations)
+                for (uint32_t i = lane; i < nw; i += RP_BLOCK) sops[i] = src[i];
+                ops_l = (const rp_script_op *)sops;
+                masks_l = sops + script->n_ops * 4;
+            }
+            const uint32_t pw = sh.proof_len / 4, cw = 8 * sh.m;
+            if (pw + cw <= RP_COOP_STAGE_WORDS) {
+                const uint32_t *s0 = (const uint32_t *)in.pr, *s1 = (const uint32_t *)in.cm;
+                for (uint32_t i = lane & 31; i < pw; i += 32) sstage[g][i] = s0[i];
+                for (uint32_t i = lane & 31; i < cw; i += 32) sstage[g][pw + i] = s1[i];
+                in.pr = (const uint8_t *)sstage[g];
+                in.cm = (const uint8_t *)(sstage[g] + pw);
+            }
+            __syncthreads();
+            rp_chal_park cp;
+            cp.raw = schal[g];
+            cp.flag = sflag + g;
+            rp_transcript_scripted_coop(pp, valid, lane, sh, init, st, in, script, fields, status, ts_out, ts_in, &cp, ops_l, masks_l);
+            __syncthreads();
+            // the 5 + k challenges reduced on 5 + k lanes; the k + 1 inversions on k + 1 lanes; the leader forms the rest; the basepoint
+            // coefficients wait for launch 3
             rp_split sp;
             sp.park = spark[g];
             sp.go = sgo + g;
-            if (valid && (lane & 31) == 0) rp_split_park(p, sh, fields, status, sp);
+            if (valid) rp_coop_reduce_lane(lane & 31, p, sh, cp, fields, sp.park);
+            if ((lane & 31) == 0) sgo[g] = (valid && (sflag[g] & 2u) && !sh.shape_verdict) ? 1u : 0u;
             __syncthreads();
             if (valid) rp_split_invert_lane(lane & 31, p, sh, fields, recoded, sp, defer ? &df : nullptr);
             if (valid && (lane & 31) == 0 && !sh.shape_verdict)
                 rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, nullptr, 0, defer ? &df : nullptr, RP_SKIP_INV | RP_SKIP_ROWS);
-        } else if (valid && (lane & 31) == 0 && !sh.shape_verdict) {
-            rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64, bk_c, defer ? &df : nullptr);
+        } else {
+            rp_transcript_scripted_coop(pp, valid, lane, sh, init, st, in, script, fields, status, ts_out, ts_in);
+            if (valid && (lane & 31) == 0 && !sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64, bk_c, defer ? &df : nullptr);
         }
         if (defer) {   // the leader parked the U coefficients: one lane each recodes them
             __syncthreads();

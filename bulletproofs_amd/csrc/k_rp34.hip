@@ -69,15 +69,44 @@ template __global__ void k_rp_horner_wide<true>(uint32_t, const ge_cached *, con
 // instructions -- and twice its latency: the form for wide chains, msm_vb.h); 64: one wavefront per proof, which forms
 // its column sums itself (horner_wave.h)  ||  the fixed-base table walk (block -> (split, proof block) as in
 // k_fb_accum)
+// The walk of a NARROW chain (walk_form 1; nsplit a multiple of 64): workgroup L = (proof, group of 64 splits), lane = split -- the 64 partial
+// sums of a proof sit in ONE wavefront and are folded through LDS (six levels) while the Horner wavefronts are still running, instead
+// of in the finish kernel behind them (8 lanes x 8 partial sums in sequence + three levels: 40 us of a one-proof chain).  With thread =
+// proof (the wide form below) a one-proof chain had 64 workgroups of one active lane each.
+__device__ __forceinline__ void rp_walk_narrow(uint32_t L, fb_params prm, uint32_t nproofs, uint32_t nsplit, uint32_t npairs, const uint32_t *gen_ids,
+                                               const fb_digit *digits, const fb_entry *table, ge_ext *partial) {
+    __shared__ ge_ext xch[FB_BLOCK];
+    const uint32_t nsg = nsplit / FB_BLOCK, p = L / nsg, sg = L - p * nsg, lane = threadIdx.x, split = sg * FB_BLOCK + lane;
+    const uint32_t per = (npairs + nsplit - 1) / nsplit;
+    const uint32_t q0 = split * per, q1 = (q0 + per < npairs) ? q0 + per : npairs;
+    ge_ext acc;
+    fb_accum_point(acc, p, q0 < npairs ? q0 : npairs, q1, prm, nproofs, gen_ids, digits, table);
+#pragma unroll 1
+    for (uint32_t step = FB_BLOCK / 2; step >= 1; step >>= 1) {
+        xch[lane] = acc;
+        __syncthreads();
+        if (lane < step) {
+            const ge_ext q = xch[lane + step];
+            ge_add(acc, acc, q);
+        }
+        __syncthreads();
+    }
+    if (lane == 0) partial[(uint64_t)sg * nproofs + p] = acc;
+}
+
 template <int HL>
 __global__ void __launch_bounds__(FB_BLOCK) k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge_ext *part, const ge_cached *colc,
                                                          ge_ext *hq, fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit,
                                                          uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits,
-                                                         const fb_entry *table, ge_ext *partial) {
+                                                         const fb_entry *table, ge_ext *partial, uint32_t walk_form) {
     if (blockIdx.x < n_hw) {
             if (HL == 4) hq_horner_msm(blockIdx.x * 16 + (threadIdx.x >> 2), nproofs, colc, hq);
         else if (HL == 1) vb_horner_cached_thread(blockIdx.x * FB_BLOCK + threadIdx.x, nproofs, colc, hq);
         else hw_colsum_horner_msm(blockIdx.x, chunk_first, part, hq + blockIdx.x);
+        return;
+    }
+    if (HL == 64 && walk_form == 1) {
+        rp_walk_narrow(blockIdx.x - n_hw, prm, nproofs, nsplit, npairs, gen_ids, digits, table, partial);
         return;
     }
     const uint32_t L = blockIdx.x - n_hw;
@@ -96,6 +125,6 @@ __global__ void __launch_bounds__(FB_BLOCK) k_rp_stage4(uint32_t n_hw, const uin
     if (p < nproofs) fb_accum_thread(p, split, q0 < npairs ? q0 : npairs, q1, prm, nproofs, gen_ids, digits, table, partial);
 }
 
-template __global__ void k_rp_stage4<4>(uint32_t, const uint32_t *, const ge_ext *, const ge_cached *, ge_ext *, fb_params, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, const fb_digit *, const fb_entry *, ge_ext *);
-template __global__ void k_rp_stage4<1>(uint32_t, const uint32_t *, const ge_ext *, const ge_cached *, ge_ext *, fb_params, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, const fb_digit *, const fb_entry *, ge_ext *);
-template __global__ void k_rp_stage4<64>(uint32_t, const uint32_t *, const ge_ext *, const ge_cached *, ge_ext *, fb_params, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, const fb_digit *, const fb_entry *, ge_ext *);
+template __global__ void k_rp_stage4<4>(uint32_t, const uint32_t *, const ge_ext *, const ge_cached *, ge_ext *, fb_params, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, const fb_digit *, const fb_entry *, ge_ext *, uint32_t);
+template __global__ void k_rp_stage4<1>(uint32_t, const uint32_t *, const ge_ext *, const ge_cached *, ge_ext *, fb_params, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, const fb_digit *, const fb_entry *, ge_ext *, uint32_t);
+template __global__ void k_rp_stage4<64>(uint32_t, const uint32_t *, const ge_ext *, const ge_cached *, ge_ext *, fb_params, uint32_t, uint32_t, uint32_t, uint32_t, const uint32_t *, const fb_digit *, const fb_entry *, ge_ext *, uint32_t);

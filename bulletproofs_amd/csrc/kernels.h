@@ -41,6 +41,7 @@ __global__ void k_fb_accum_ct(fb_params prm, uint32_t nproofs, uint32_t nblk_p, 
 __global__ void k_fb_reduce(uint32_t nthreads, uint32_t nproofs, uint32_t nsplit, uint32_t group, const ge_ext *partial, ge_ext *out);
 __global__ void k_shared_finish(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, int have_unique, const ge_ext *partial, const uint32_t *status, uint32_t *out_words, uint8_t *verdict,
                                 uint8_t *status_bytes);
+template <bool WITH_OUT> __global__ void k_finish1(uint32_t nproofs, const ge_ext *hq, const ge_ext *partial, uint32_t *status, uint32_t *out_words, uint8_t *verdict, int reset_status, rp_seg_tab segs);
 template <bool WITH_OUT>
 __global__ void k_finish8(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, const ge_ext *partial, uint32_t *status, uint32_t *out_words, uint8_t *verdict, int reset_status, rp_seg_tab segs);
 __global__ void k_rp_stage1_coop(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs, const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields, ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m, uint32_t *recoded, fb_digit *digits, const uint8_t *rho64, const uint32_t *ts_in, uint32_t *ts_out, fb_entry *bk_pts, uint32_t bk_c, rp_seg_tab segs, const rp_script_hdr *script);
@@ -55,7 +56,7 @@ __global__ void k_rp_horner_wide(uint32_t nproofs, const ge_cached *colc, const 
 template <bool R5>
 __global__ void k_vb_window_wide(uint32_t nthreads, uint32_t U, uint32_t k0, const ge_cached *tab, const uint32_t *recoded, ge_cached *colc);
 template <int HL>
-__global__ void k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge_ext *part, const ge_cached *colc, ge_ext *hq, fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit, uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial);
+__global__ void k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge_ext *part, const ge_cached *colc, ge_ext *hq, fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit, uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial, uint32_t walk_form);
 __global__ void k_rlc_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, const uint32_t *status, unsigned long long *acc, int uniform);
 __global__ void k_rlc_colsum_scalars(uint32_t n_red, uint32_t nthreads, uint32_t rows_in, uint32_t group, const ge_ext *in, ge_ext *out, uint32_t n_rows, const unsigned long long *acc, fb_digit *digits, fb_params prm, uint32_t *ctl, uint32_t rows_out);
 template <bool WITH_OUT>

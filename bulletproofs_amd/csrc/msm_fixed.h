@@ -212,9 +212,8 @@ BP_HD void fb_accum_step(ge_ext &acc, const fb_line &line, uint32_t v, fb_params
 }
 // Two pairs per trip, two line buffers used alternately: the line of the next pair is loaded straight into the buffer the
 // previous pair has just vacated (no register copies between trips).
-BP_HD void fb_accum_thread(uint32_t p, uint32_t split, uint32_t q0, uint32_t q1, fb_params prm, uint32_t nproofs,
-                           const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial) {
-    ge_ext acc;
+BP_HD void fb_accum_point(ge_ext &acc, uint32_t p, uint32_t q0, uint32_t q1, fb_params prm, uint32_t nproofs,
+                          const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table) {
     ge_identity(acc);
     if (q0 < q1) {
         const fb_digit *dg = digits + p;
@@ -243,6 +242,11 @@ BP_HD void fb_accum_thread(uint32_t p, uint32_t split, uint32_t q0, uint32_t q1,
         }
         if (q < q1) fb_accum_step(acc, lb, vb, prm, false);   // odd tail: pair q1-1 is in lb
     }
+}
+BP_HD void fb_accum_thread(uint32_t p, uint32_t split, uint32_t q0, uint32_t q1, fb_params prm, uint32_t nproofs,
+                           const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial) {
+    ge_ext acc;
+    fb_accum_point(acc, p, q0, q1, prm, nproofs, gen_ids, digits, table);
     partial[(uint64_t)split * nproofs + p] = acc;
 }
 

@@ -497,9 +497,21 @@ BP_HD void rp_transcript_scripted(uint32_t p, rp_shape sh, const rp_strobe_init 
 #else
 #define BP_GROUP_SYNC() ((void)0)
 #endif
+// cp (narrow chains, option coop_split): the leader does not reduce the 64-byte challenges mod l between the permutations (~2 us each on a
+// lone lane, 5 + k of them: nothing in a VERIFIER's transcript depends on a challenge's value) -- it parks the raw words, and the group's
+// lanes reduce one each afterwards (rp_coop_reduce_lane).  ops_l / masks_l: the script's operations and masks staged in LDS by the caller
+// (every operation fetched from global memory is a dependent ~0.5 us on the leader's path; ~50 operations per proof).
+#define RP_COOP_STAGE_WORDS 640    // proof + commitments staged per group (2560 bytes: up to (64, 32), 992 + 1024)
+#define RP_COOP_OPS_CAP 160        // operations of a script staged per workgroup (16 bytes each; (64, 1): 53, (64, 32): 92)
+#define RP_COOP_MASKS_CAP 24       // ... and its permutation masks (168 bytes each; (64, 1): 13)
+struct rp_chal_park {
+    uint32_t *raw;    // [5 + k][16]: y, z, x, w, u_0 .. u_{k-1}, then the 64 rng bytes of the batching challenge c
+    uint32_t *flag;   // [1]: bit 0 -- the leader replayed the whole script (the parked words are valid); bit 1 -- and the proof is still undecided
+};
 BP_HD void rp_transcript_scripted_coop(uint32_t p, bool valid, uint32_t lane, rp_shape sh, const rp_strobe_init &init, kstate st, const rp_inputs &in,
                                        const rp_script_hdr *script, uint32_t *fields, uint32_t *status, uint32_t *ts_out = nullptr,
-                                       const uint32_t *ts_in = nullptr) {
+                                       const uint32_t *ts_in = nullptr, const rp_chal_park *cp = nullptr, const rp_script_op *ops_l = nullptr,
+                                       const uint32_t *masks_l = nullptr) {
     const uint32_t B = sh.nproofs, k = sh.k;
     const uint8_t *pr = in.pr;
     const rp_fields fl = rp_field_layout(k, sh.m);
@@ -541,8 +553,8 @@ BP_HD void rp_transcript_scripted_coop(uint32_t p, bool valid, uint32_t lane, rp
             }
         }
     }
-    const rp_script_op *ops = rp_script_ops(script);
-    const uint32_t *masks = rp_script_masks(script);
+    const rp_script_op *ops = ops_l ? ops_l : rp_script_ops(script);
+    const uint32_t *masks = masks_l ? masks_l : rp_script_masks(script);
     const uint32_t n_ops = script->n_ops;
     const uint32_t stop_op = (run && ts_out && stop_u != RP_NO_STOP) ? rp_script_stops(script)[stop_u].op : RP_NO_STOP;   // (leader only)
     for (uint32_t oi = 0; oi < n_ops; oi++) {
@@ -562,6 +574,13 @@ BP_HD void rp_transcript_scripted_coop(uint32_t p, bool valid, uint32_t lane, rp
                 rp_script_xor_record(st, op.pos, w);
             } else if (op.kind == RS_MSGB) {
                 for (uint32_t q = 0; q < op.nbytes; q++) ks_xor8(st, op.pos + q, src[q]);
+            } else if (cp) {
+                uint32_t *dst = cp->raw + 16 * op.arg;
+#pragma unroll
+                for (int q = 0; q < 16; q++) {
+                    dst[q] = ks_get32(st, q);
+                    ks_set32(st, q, 0);
+                }
             } else {
                 uint32_t cw[16];
 #pragma unroll
@@ -586,11 +605,35 @@ BP_HD void rp_transcript_scripted_coop(uint32_t p, bool valid, uint32_t lane, rp
         } else {
             rp_seed_words(cw, sh, p, RP_SEED_RNG);
         }
-        sc_from_wide(c, cw);
-        rp_store(fields, B, RPF_C, p, c);
+        if (cp) {
+#pragma unroll
+            for (int q = 0; q < 16; q++) cp->raw[16 * (4 + k) + q] = cw[q];
+            cp->flag[0] = verr ? 1u : 3u;
+        } else {
+            sc_from_wide(c, cw);
+            rp_store(fields, B, RPF_C, p, c);
+        }
     }
     if (verr) status_raise(status + p, BP_VERDICT_VERIFICATION);
     if (ts_out && stop_op == RP_NO_STOP) rp_ts_emit(p, st, rp_ts_meta(script->end_pos, script->end_pos_begin, script->end_flags), ts_out);
+}
+// lane id = 0 .. 4 + k of the group, after the leader's replay: reduce parked challenge `id` mod l (Scalar::from_bytes_mod_order_wide,
+// transcript.rs:93) into its field; y and the u_i are also parked in canonical form for the lanes that invert them (rp_split_invert_lane)
+BP_HD void rp_coop_reduce_lane(uint32_t id, uint32_t p, const rp_shape &sh, const rp_chal_park &cp, uint32_t *fields, uint32_t *park) {
+    const uint32_t B = sh.nproofs, k = sh.k;
+    if (!(cp.flag[0] & 1u) || id > 4 + k) return;
+    const rp_fields fl = rp_field_layout(k, sh.m);
+    uint32_t cw[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) cw[q] = cp.raw[16 * id + q];
+    sc ch;
+    sc_from_wide(ch, cw);
+    rp_store(fields, B, id == 0 ? (uint32_t)RPF_Y : (id == 1 ? (uint32_t)RPF_Z : (id == 2 ? (uint32_t)RPF_X : (id == 3 ? (uint32_t)RPF_W : (id == 4 + k ? (uint32_t)RPF_C : fl.u + (id - 4))))), p, ch);
+    if (park && (id == 0 || (id >= 4 && id < 4 + k))) {
+        uint32_t *dst = park + 8 * (id == 0 ? k : id - 4);
+#pragma unroll
+        for (int q = 0; q < 8; q++) dst[q] = ch.v[q];
+    }
 }
 
 // ---- stage 1b: per-proof points -----------------------------------------------------------
@@ -934,23 +977,9 @@ BP_HD void rp_expand_a_thread(uint32_t p, rp_shape sh, fb_params prm, uint32_t l
 // Same values mod l everywhere (the Montgomery-form fields are lazy representatives and may differ in their limbs; every digit that
 // leaves the stage is recoded from a canonical scalar).
 struct rp_split {
-    uint32_t *park;   // [32][8]: canonical u_0 .. u_{k-1}, y -- parked by the leader for the group's lanes
-    uint32_t *go;     // [1]: the proof is still undecided (status 0)
+    uint32_t *park;   // [32][8]: canonical u_0 .. u_{k-1}, y -- parked by the lanes that reduced them (rp_coop_reduce_lane)
+    uint32_t *go;     // [1]: the proof is still undecided
 };
-// leader, after the transcript
-BP_HD void rp_split_park(uint32_t p, const rp_shape &sh, const uint32_t *fields, const uint32_t *status, const rp_split &sp) {
-    const uint32_t B = sh.nproofs, k = sh.k;
-    const bool go = status[p] == 0 && !sh.shape_verdict && k < 32;
-    sp.go[0] = go ? 1u : 0u;
-    if (!go) return;
-    const rp_fields fl = rp_field_layout(k, sh.m);
-    sc v;
-    for (uint32_t i = 0; i <= k; i++) {
-        rp_load(v, fields, B, i < k ? fl.u + i : (uint32_t)RPF_Y, p);
-#pragma unroll
-        for (int q = 0; q < 8; q++) sp.park[8 * i + q] = v.v[q];
-    }
-}
 // lane i = 0 .. k of the group (the others return at once)
 BP_HD void rp_split_invert_lane(uint32_t i, uint32_t p, const rp_shape &sh, uint32_t *fields, uint32_t *recoded, const rp_split &sp, const rp_defer *df) {
     const uint32_t B = sh.nproofs, k = sh.k;

@@ -218,6 +218,7 @@ int h_rp_transcript_compare(uint32_t n, uint32_t m, uint32_t nbatch, const uint8
     const size_t nf = (size_t)fl.count * nbatch * BP_RP_REC + 8;
     std::vector<uint32_t> f1(nf, 0xabababab), f2(nf, 0xabababab), s1(nbatch + 1, 0), s2(nbatch + 1, 0), t1((size_t)nbatch * BP_TS_WORDS, 7), t2((size_t)nbatch * BP_TS_WORDS, 7);
     std::vector<uint32_t> f3(nf, 0xabababab), s3(nbatch + 1, 0), t3((size_t)nbatch * BP_TS_WORDS, 7);
+    std::vector<uint32_t> f4(nf, 0xabababab), s4(nbatch + 1, 0), t4((size_t)nbatch * BP_TS_WORDS, 7);
     rp_seg_tab none; memset(&none, 0, sizeof none);
     for (uint32_t p = 0; p < nbatch; p++) {
         uint32_t w1[50], w2[50]; kstate st1, st2; st1.w = w1; st1.stride = 1; st2.w = w2; st2.stride = 1;
@@ -227,7 +228,26 @@ int h_rp_transcript_compare(uint32_t n, uint32_t m, uint32_t nbatch, const uint8
         // the narrow-chain variant (32 lanes per proof): the leader's path, the permutations through the 25-lane phase functions
         uint32_t w3[52]; kstate st3; st3.w = w3; st3.stride = 1;
         rp_transcript_scripted_coop(p, true, 0, sh, init, st3, in, script, f3.data(), s3.data(), t3.data());
+        // ... and with the challenges parked raw by the leader and reduced by the group's lanes (option coop_split), operations and masks from a staged copy
+        if (k <= 26) {
+            uint32_t w4[52]; kstate st4; st4.w = w4; st4.stride = 1;
+            std::vector<uint32_t> raw(16 * 32, 0xdeadbeef), park(32 * 8, 0xdeadbeef);
+            uint32_t flag = 0;
+            rp_chal_park cp; cp.raw = raw.data(); cp.flag = &flag;
+            std::vector<uint32_t> staged((const uint32_t *)rp_script_ops(script), (const uint32_t *)rp_script_ops(script) + script->n_ops * 4 + script->n_masks * RS_MASK_WORDS);
+            rp_transcript_scripted_coop(p, true, 0, sh, init, st4, in, script, f4.data(), s4.data(), t4.data(), nullptr, &cp, (const rp_script_op *)staged.data(),
+                                        staged.data() + script->n_ops * 4);
+            for (uint32_t id = 0; id < 32; id++) rp_coop_reduce_lane(id, p, sh, cp, f4.data(), park.data());
+            if (flag & 1u) {   // what the lanes that invert read: y and the u_i in canonical form
+                for (uint32_t i = 0; i <= k; i++) {
+                    sc v; rp_load(v, f1.data(), nbatch, i < k ? fl.u + i : (uint32_t)RPF_Y, p);
+                    for (int q = 0; q < 8; q++) if (park[8 * i + q] != v.v[q]) return 10;
+                }
+                if (((flag >> 1) & 1u) != (s1[p] == 0 ? 1u : 0u)) return 11;
+            } else if (s1[p] == 0) return 12;
+        }
     }
+    if (k <= 26 && (s1 != s4 || t1 != t4 || f1 != f4)) return 13;
     if (s1 != s3) return 4;
     if (t1 != t3) return 5;
     if (f1 != f3) return 6;
@@ -267,6 +287,7 @@ int h_rp_transcript_compare_per_proof(uint32_t n, uint32_t m, uint32_t nbatch, c
     const size_t nf = (size_t)fl.count * nbatch * BP_RP_REC + 8;
     std::vector<uint32_t> f1(nf, 0xabababab), f2(nf, 0xabababab), s1(nbatch + 1, 0), s2(nbatch + 1, 0), t1((size_t)nbatch * BP_TS_WORDS, 7), t2((size_t)nbatch * BP_TS_WORDS, 7);
     std::vector<uint32_t> f3(nf, 0xabababab), s3(nbatch + 1, 0), t3((size_t)nbatch * BP_TS_WORDS, 7);
+    std::vector<uint32_t> f4(nf, 0xabababab), s4(nbatch + 1, 0), t4((size_t)nbatch * BP_TS_WORDS, 7);
     rp_seg_tab none; memset(&none, 0, sizeof none);
     for (uint32_t p = 0; p < nbatch; p++) {
         uint32_t w1[50], w2[50]; kstate st1, st2; st1.w = w1; st1.stride = 1; st2.w = w2; st2.stride = 1;
@@ -275,7 +296,16 @@ int h_rp_transcript_compare_per_proof(uint32_t n, uint32_t m, uint32_t nbatch, c
         rp_transcript_scripted(p, sh, init, st2, in, script, f2.data(), s2.data(), t2.data(), ts_in.data());
         uint32_t w3[52]; kstate st3; st3.w = w3; st3.stride = 1;
         rp_transcript_scripted_coop(p, true, 0, sh, init, st3, in, script, f3.data(), s3.data(), t3.data(), ts_in.data());
+        if (k <= 26) {
+            uint32_t w4[52]; kstate st4; st4.w = w4; st4.stride = 1;
+            std::vector<uint32_t> raw(16 * 32, 0xdeadbeef), park(32 * 8, 0xdeadbeef);
+            uint32_t flag = 0;
+            rp_chal_park cp; cp.raw = raw.data(); cp.flag = &flag;
+            rp_transcript_scripted_coop(p, true, 0, sh, init, st4, in, script, f4.data(), s4.data(), t4.data(), ts_in.data(), &cp);
+            for (uint32_t id = 0; id < 32; id++) rp_coop_reduce_lane(id, p, sh, cp, f4.data(), park.data());
+        }
     }
+    if (k <= 26 && (s1 != s4 || t1 != t4 || f1 != f4)) return 13;
     if (s1 != s3) return 4;
     if (t1 != t3) return 5;
     if (f1 != f3) return 6;
@@ -518,7 +548,14 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
             const bool defer = g_defer_emit && sh.U <= RP_DEFER_CAP;
             rp_defer df; df.slot = slots.data(); df.meta = meta;
             rp_split sp; sp.park = park; sp.go = &go;
-            rp_split_park(p, sh, fields.data(), status.data(), sp);
+            go = status[p] == 0 ? 1u : 0u;   // (on the device the lanes that reduce the challenges park y and the u_i: rp_coop_reduce_lane, h_rp_transcript_compare)
+            if (go) {
+                const rp_fields fl = rp_field_layout(sh.k, sh.m);
+                for (uint32_t i = 0; i <= sh.k; i++) {
+                    sc v; rp_load(v, fields.data(), nbatch, i < sh.k ? fl.u + i : (uint32_t)RPF_Y, p);
+                    for (int q = 0; q < 8; q++) park[8 * i + q] = v.v[q];
+                }
+            }
             for (uint32_t lane = 0; lane < 32; lane++) rp_split_invert_lane(lane, p, sh, fields.data(), rec.data(), sp, defer ? &df : nullptr);
             rp_expand_a_thread(p, sh, prm, lg_m, fields.data(), rec.data(), digits.data(), status.data(), nullptr, 0, defer ? &df : nullptr, RP_SKIP_INV | RP_SKIP_ROWS);
             if (defer) for (uint32_t lane = 0; lane < 32; lane++) rp_emit_deferred(lane, p, sh, rec.data(), df, 0);
