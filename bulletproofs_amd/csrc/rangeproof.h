@@ -988,7 +988,7 @@ BP_HD void rp_split_invert_lane(uint32_t i, uint32_t p, const rp_shape &sh, uint
     sc v, vi;
 #pragma unroll
     for (int q = 0; q < 8; q++) v.v[q] = sp.park[8 * i + q];
-    sc_invert_safegcd(vi, v);
+    sc_invert_safegcd_var(vi, v);
     sc28 vm, im, sq, isq;
     sc_to_mont28(vm, v);
     sc_to_mont28(im, vi);

@@ -173,6 +173,76 @@ BP_HD void sc_invert_safegcd(sc &r, const sc &a) {
     inv_normalize(r, d, f.v[8] >> 31);
 }
 
+// ---- the variable-time form (round 6; narrow chains, where the inversion is ~60 us of a one-proof chain's critical path) ----------------
+// The same transition matrices and updates, but the 30 division steps of a batch are not taken one by one: runs of zero bits of g are
+// shifted out at once (count trailing zeros), and when g is odd up to six of its low bits are cancelled by ONE multiple of f --
+// w = -g f^-1 mod 2^b with f^-1 = f (2 - f^2) mod 64 (one Newton step from f^-1 = f mod 8) -- as in the well-known variable-time
+// "modinv" formulation (classic delta = 1 division steps, eta = -delta).  ~7 trips of ~20 instructions per batch instead of 30 x ~20,
+// and the outer loop ends when g is 0 (~18 batches on 253-bit inputs instead of a fixed 20).  Lanes of a wavefront that run it together
+// diverge only inside a batch.  Nothing here is secret (a verifier's challenges); the result is the same canonical inverse.
+BP_HD int32_t inv_divsteps30_var(int32_t eta, uint32_t f, uint32_t g, inv_mat &t) {
+    uint32_t u = 1, v = 0, q = 0, r = 1;
+    int i = 30;
+    for (;;) {
+        const int zeros = __builtin_ctz(g | (0xffffffffu << i));   // sentinel: never counts past the i steps that are left
+        g >>= zeros;
+        u <<= zeros;
+        v <<= zeros;
+        eta -= zeros;
+        i -= zeros;
+        if (i == 0) break;
+        if (eta < 0) {   // delta > 0 and g odd: (f, g) <- (g, -f)
+            uint32_t tmp;
+            eta = -eta;
+            tmp = f; f = g; g = 0u - tmp;
+            tmp = u; u = q; q = 0u - tmp;
+            tmp = v; v = r; r = 0u - tmp;
+        }
+        // cancel the low min(eta + 1, i, 6) bits of g: no more than i (the batch ends there), no more than eta + 1 (its sign flips there)
+        const int limit = (eta + 1) > i ? i : (eta + 1);
+        const uint32_t m = (0xffffffffu >> (32 - limit)) & 63u;
+        const uint32_t w = (f * g * (f * f - 2u)) & m;
+        g += f * w;
+        q += u * w;
+        r += v * w;
+    }
+    t.u = (int32_t)u;
+    t.v = (int32_t)v;
+    t.q = (int32_t)q;
+    t.r = (int32_t)r;
+    return eta;
+}
+// r = a^-1 mod l (canonical in, canonical out; 0 -> 0), variable time
+BP_HD void sc_invert_safegcd_var(sc &r, const sc &a) {
+    const int32_t L[9] = BP_INV_L30;
+    s30 f, g, d, e;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+        f.v[i] = L[i];
+        d.v[i] = 0;
+        e.v[i] = (i == 0);
+        const int lo = (30 * i) >> 5, sh = (30 * i) & 31;
+        uint32_t x = a.v[lo] >> sh;
+        if (sh > 2 && lo + 1 < 8) x |= a.v[lo + 1] << (32 - sh);
+        g.v[i] = (int32_t)(x & BP_INV_M30);
+    }
+    int32_t eta = -1;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll 1
+#endif
+    for (int it = 0; it < 26; it++) {   // (25 batches cover the proven 735-step bound of classic division steps on 256-bit inputs)
+        inv_mat t;
+        eta = inv_divsteps30_var(eta, (uint32_t)f.v[0], (uint32_t)g.v[0], t);
+        inv_update_de(d, e, t);
+        inv_update_fg(f, g, t);
+        int32_t nz = 0;
+#pragma unroll
+        for (int i = 0; i < 9; i++) nz |= g.v[i];
+        if (nz == 0) break;
+    }
+    inv_normalize(r, d, f.v[8] >> 31);
+}
+
 // Montgomery form in and out (drop-in for sc28_invert_mont)
 BP_HD void sc28_invert_mont_safegcd(sc28 &r, const sc28 &am) {
     sc a, ai;

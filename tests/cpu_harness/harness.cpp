@@ -374,7 +374,7 @@ void h_sha3_512(const uint8_t *in, uint32_t n, uint8_t *out) {
     uint32_t w[50]; kstate st; st.w = w; st.stride = 1; sponge k; sponge_init(k, st, BP_SHA3_512_RATE);
     sponge_absorb(k, in, n); sponge_finish(k, 0x06); sponge_squeeze(k, out, 64);
 }
-// op: 0 mul 1 add 2 sub 3 neg 4 invert 5 from_wide(a||b) 6 montmul
+// op: 0 mul 1 add 2 sub 3 neg 4 invert 5 from_wide(a||b) 6 montmul 7 / 8 division-step inversion 9 its variable-time form
 void h_sc_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
     sc x, y, r; memcpy(x.v, a, 32); memcpy(y.v, b, 32);
     switch (op) {
@@ -387,6 +387,7 @@ void h_sc_op(int op, const uint8_t *a, const uint8_t *b, uint8_t *out) {
     case 6: { sc28 a28, b28, t28; sc28_from_sc(a28, x); sc28_from_sc(b28, y); sc28_montmul(t28, a28, b28); sc28_to_mont(t28, t28); sc28_to_mont(t28, t28); sc_from_mont28(r, t28); } break;  // lazy chain: ((xy/R)*R*R)/R = xy
     case 7: sc_invert_safegcd(r, x); break;
     case 8: { sc28 m28, i28; sc_to_mont28(m28, x); sc28_invert_mont_safegcd(i28, m28); sc_from_mont28(r, i28); } break;
+    case 9: sc_invert_safegcd_var(r, x); break;
     default: sc_0(r);
     }
     memcpy(out, r.v, 32);

@@ -98,13 +98,16 @@ def test_scalar_field_keccak_merlin(H):
         if i < 8 and x:
             assert scop(4, x) == pow(x, L - 2, L)
         # division-step inversion (scinv.h): same canonical result as the l-2 exponentiation, 0 -> 0
-        assert scop(7, x) == pow(x, L - 2, L) and scop(8, x) == pow(x, L - 2, L)
+        assert scop(7, x) == pow(x, L - 2, L) and scop(8, x) == pow(x, L - 2, L) and scop(9, x) == pow(x, L - 2, L)
         lo, hi = random.randrange(2**256), random.randrange(2**256)
         assert scop(5, lo, hi) == (lo + (hi << 256)) % L
     assert scop(5, 2**256 - 1, 2**256 - 1) == (2**512 - 1) % L
     for x in [3, 2**30, 2**30 - 1, 2**60 + 1, (L - 1) // 2, (L + 1) // 2, 2**252 - 1, 2**252 + 1] + [random.randrange(L) for _ in range(400)] \
             + [random.randrange(2**b) for b in range(1, 253, 3)] + [L - random.randrange(1, 2**b) for b in range(1, 250, 5)]:
         assert scop(7, x) == pow(x, L - 2, L), hex(x)
+        assert scop(9, x) == pow(x, L - 2, L), hex(x)   # the variable-time form narrow chains run (round 6)
+    for x in [random.randrange(L) for _ in range(3000)]:
+        assert scop(9, x) == pow(x, L - 2, L), hex(x)
     out = C.create_string_buffer(32)
     H.h_merlin_kat(b"test protocol", 13, b"some label", 10, b"some data", 9, b"challenge", 9, out, 32)
     assert out.raw.hex() == "d5a21972d0d5fe320c0d263fac7fffb8145aa640af6e9bca177c03c7efcf0615"
