@@ -96,6 +96,7 @@ struct bpgpu_ctx {
     int narrow_chunk = 0;                                           // narrow chains: per-proof points per (chunk, window) lane of launch 3; 0 = 8 (the Horner wavefront adds the chunks' rows), 32 = one chunk
     int exp_single = 1;                                             // narrow chains: the generator-exponent role with one index per lane (rp_expand_b1_thread); 0: as wide chains
     int narrow_walk = 1;                                            // narrow chains: the table walk with lane = split and the partial sums folded in launch 4 (k_rp34.hip rp_walk_narrow); 0: thread = proof
+    int narrow_hi_max = 32;                                         // chains of up to this many proofs give every per-proof point a second table (2^128 P) and run a 32-window Horner chain; 0: never
     int coop_split = 1;                                             // narrow chains, per-proof check: the k + 1 inversions on k + 1 lanes of the group at once, the basepoint coefficients as a
                                                                     // role of launch 3 (rangeproof.h rp_split_invert_lane / rp_rows_thread); 0: the leader does it all (A/B: profiles/r06/coop_split_ab.txt)
     int transcript_coop = 1;                                        // chains of up to 256 proofs replay their transcripts 32 lanes per proof (keccak.h): one call of 1 / 8 / 64 / 256 proofs 0.62 -> 0.53 / 0.56 / 0.57 / 0.58 ms; 0: lane = proof everywhere
@@ -421,6 +422,7 @@ int bpgpu_ctx_create(int device, bpgpu_ctx **out) {
     }
     if (const char *e = getenv("BPGPU_COOP_SPLIT")) c->coop_split = atoi(e) != 0;
     if (const char *e = getenv("BPGPU_NARROW_WALK")) c->narrow_walk = atoi(e) != 0;
+    if (const char *e = getenv("BPGPU_NARROW_HI_MAX")) c->narrow_hi_max = atoi(e);
     if (const char *e = getenv("BPGPU_EXP_SINGLE")) c->exp_single = atoi(e) != 0;
     if (const char *e = getenv("BPGPU_NARROW_CHUNK")) c->narrow_chunk = atoi(e);
     if (const char *e = getenv("BPGPU_COOP_DEFER_EMIT")) c->coop_defer_emit = atoi(e) != 0;   // (A/B of whole test suites: the option's default for every context of the process)
@@ -507,6 +509,11 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
     }
     if (!strcmp(key, "exp_single")) {
         c->exp_single = value != 0;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "narrow_hi_max")) {
+        if (value < 0 || value > 256) return fail(c, BPGPU_ERR_INVALID_ARG, "narrow_hi_max must be 0 .. 256");
+        c->narrow_hi_max = (int)value;
         return BPGPU_OK;
     }
     if (!strcmp(key, "narrow_walk")) {
@@ -1975,7 +1982,12 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     uint32_t nsplit = pick_splits(c, nbatch, npairs, aside);
     // narrow chains in the wavefront-per-chain form: the walk with lane = split, a multiple of 64 splits per proof (rp_walk_narrow)
     const bool narrow_walk = wave && !wide && !rlc && nbatch <= 256 && c->narrow_walk;
+    // ... and for VERY narrow ones every per-proof point gets a second table, of its 2^128 multiple, built beside the transcript by a wavefront
+    // of its own (k_rp_stage1_coop's third role): the Horner chain has 32 windows, and the walk twice the splits to end with it
+    const bool will_script = (!tr.d_ts_in || tr.ts_uniform) && !shape_verdict && !c->no_script;
+    const bool narrow_hi = narrow_walk && will_script && c->transcript_coop && c->coop_split && !shape_verdict && (int64_t)nbatch <= (int64_t)c->narrow_hi_max;
     if (narrow_walk) {
+        if (narrow_hi && nsplit < 2 * FB_BLOCK) nsplit = 2 * FB_BLOCK;
         nsplit = (nsplit + FB_BLOCK - 1) / FB_BLOCK * FB_BLOCK;
         while (nsplit > FB_BLOCK && npairs / nsplit < 4) nsplit -= FB_BLOCK;
     }
@@ -2002,7 +2014,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     arena_plan ap;
     size_t off[7], boff[12];
     if (rlc_bucket) plan_bucket(ap, 1, rlc_terms, bkp, boff);
-    else plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off, r5 ? 16 : 8, vb_chunk_sz);
+    else plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off, (r5 || narrow_hi) ? 16 : 8, vb_chunk_sz);
     const size_t off_digits = ap.add((size_t)npairs * nbatch * sizeof(fb_digit) + 16);
     const size_t off_partial = ap.add((size_t)2 * nsplit * nbatch * sizeof(ge_ext) + 16);
     const size_t off_fields = ap.add((size_t)fl.count * nbatch * BP_RP_REC * 4 + 16);
@@ -2155,11 +2167,14 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const uint32_t n_pt = shape_verdict ? 0 : (nb32 * sh.U + RP_BLOCK - 1) / RP_BLOCK;
     const bool coop = d_script && c->transcript_coop && nbatch <= 256;
     sh.coop_split = (coop && c->coop_split && !rlc && !wide && !shape_verdict && sh.k < 32) ? 1u : 0u;   // (launch 3 then carries the basepoint-coefficient role)
+    const bool hi = narrow_hi && coop && sh.coop_split;
+    sh.narrow_hi = hi ? 1u : 0u;
+    ge_cached *tab_hi = hi ? d.tab + (size_t)8 * nb32 * sh.U : (ge_cached *)nullptr;
     if (coop)   // narrow chain: 32 lanes per proof for the permutations (two proofs per workgroup)
-        LAUNCH(c, s, "rp_stage1", k_rp_stage1_coop, (nb32 + 1) / 2 + n_pt, RP_BLOCK, sh, init, (nb32 + 1) / 2, (const uint8_t *)d_proofs,
+        LAUNCH(c, s, "rp_stage1", k_rp_stage1_coop, (nb32 + 1) / 2 + n_pt + (hi ? nb32 * sh.U : 0u), RP_BLOCK, sh, init, (nb32 + 1) / 2, (const uint8_t *)d_proofs,
            (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits,
            rlc ? wts_ptr : (const uint8_t *)nullptr, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
-           rlc_bucket ? bd.pts : (fb_entry *)nullptr, rlc_bucket ? bkp.c : 0u, segtab, d_script);
+           rlc_bucket ? bd.pts : (fb_entry *)nullptr, rlc_bucket ? bkp.c : 0u, segtab, d_script, n_pt, tab_hi);
     else if (d_script)
         LAUNCH(c, s, "rp_stage1", k_rp_stage1<true>, n_tr + n_pt, RP_BLOCK, sh, init, n_tr, (const uint8_t *)d_proofs,
            (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits,
@@ -2293,11 +2308,11 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         const uint32_t nrows = sh.coop_split ? nb32 : 0u, n_rows = (nrows + BP_BLOCK - 1) / BP_BLOCK;
         ge_cached *colc3 = (quad && one_chunk) ? d_colc : (ge_cached *)nullptr;
         if (exp_single) LAUNCH(c, s, "rp_stage3", k_rp_stage3<2>, n_win + n_exp + n_rows, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part, colc3, nexp, sh, prm,
-                               d_fields, d_digits, d_status, n_exp, nrows, lg_m);
+                               d_fields, d_digits, d_status, n_exp, nrows, lg_m, (const ge_cached *)tab_hi);
         else if (pairs) LAUNCH(c, s, "rp_stage3", k_rp_stage3<1>, n_win + n_exp + n_rows, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part, colc3, nexp, sh, prm,
-                               d_fields, d_digits, d_status, n_exp, nrows, lg_m);
+                               d_fields, d_digits, d_status, n_exp, nrows, lg_m, (const ge_cached *)tab_hi);
         else LAUNCH(c, s, "rp_stage3", k_rp_stage3<0>, n_win + n_exp + n_rows, BP_BLOCK, n_win, nwin, d.chunks, d.tab, d.recoded, d.part, colc3, nexp, sh, prm,
-                    d_fields, d_digits, d_status, n_exp, nrows, lg_m);
+                    d_fields, d_digits, d_status, n_exp, nrows, lg_m, (const ge_cached *)tab_hi);
     }
     if (quad && !one_chunk && !horner_aside) {
         const uint32_t nc = nb32 * 64;
@@ -2320,7 +2335,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     } else if (narrow_walk) {   // lane = split: a proof's partial sums are folded inside launch 4 (k_rp34.hip: rp_walk_narrow)
         nparts = nsplit / FB_BLOCK;
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<64>, nb32 + nb32 * nparts, FB_BLOCK, nb32, d.chunk_first, d.part, (const ge_cached *)nullptr, d.hq,
-               prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, gen_table, d_partial, 1u);
+               prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, gen_table, d_partial, hi ? 3u : 1u);
     } else {
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<64>, nb32 + nblk_p * nsplit, FB_BLOCK, nb32, d.chunk_first, d.part, (const ge_cached *)nullptr, d.hq,
                prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, gen_table, d_partial, 0u);
@@ -2328,11 +2343,11 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     ge_ext *d_red = nullptr;
     uint32_t nred = 0;
     enqueue_fb_reduce(c, s, nb32, nparts, d_partial, &d_red, &nred, 64);   // 8 lanes x <= 8 partials each in finish8
-    if (nred == 1 && narrow_walk) {   // one partial sum + the Horner result per proof: lane = proof
+    if (nred <= 4 && narrow_walk) {   // a few partial sums + the Horner result per proof: lane = proof
         if (d_msm_out)
-            LAUNCH(c, s, "finish1", k_finish1<true>, (nb32 + 63) / 64, 64, nb32, d.hq, d_red, d_status, (uint32_t *)d_msm_out, (uint8_t *)d_verdict, 1, segtab);
+            LAUNCH(c, s, "finish1", k_finish1<true>, (nb32 + 63) / 64, 64, nb32, nred, d.hq, d_red, d_status, (uint32_t *)d_msm_out, (uint8_t *)d_verdict, 1, segtab);
         else
-            LAUNCH(c, s, "finish1", k_finish1<false>, (nb32 + 63) / 64, 64, nb32, d.hq, d_red, d_status, (uint32_t *)nullptr, (uint8_t *)d_verdict, 1, segtab);
+            LAUNCH(c, s, "finish1", k_finish1<false>, (nb32 + 63) / 64, 64, nb32, nred, d.hq, d_red, d_status, (uint32_t *)nullptr, (uint8_t *)d_verdict, 1, segtab);
     } else if (d_msm_out)
         LAUNCH(c, s, "finish8", k_finish8<true>, (nb32 + 7) / 8, 64, nb32, nred, d.hq, d_red, d_status, (uint32_t *)d_msm_out, (uint8_t *)d_verdict, 1, segtab);
     else

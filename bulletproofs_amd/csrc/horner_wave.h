@@ -110,13 +110,15 @@ WV_FN wu32 hw_add_cached(const wv_ctx &cx, const wu32 &c, const wu32 &q, const w
 
 // The whole chain for one MSM.  colq16: this MSM's 64 column sums, [w][4][16] u16 limbs of the
 // canonical encodings of (Y-X, Y+X, Z, 2dT).  Returns the running point (row r = coordinate r).
-WV_FN wu32 hw_horner(const wv_ctx &cx, const uint16_t *colq16) {
+// nwin: 64, or 32 for a very narrow chain whose points come with a second table of their 2^128 multiples (hw_point_shift: the upper 32
+// digits of a coefficient then select from that table and are added into the columns of the lower 32 -- half the dependent doublings)
+WV_FN wu32 hw_horner(const wv_ctx &cx, const uint16_t *colq16, int nwin = BP_VB_WINDOWS) {
     const wu32 lane = wv_lane();
     const wu32 k = lane & 15u, row = lane >> 4;
     // identity (0 : 1 : 1 : 0)
     wu32 c = wv_select((k == 0u) && (row == 1u || row == 2u), wv_splat(1), wv_splat(0));
-    for (int w = BP_VB_WINDOWS - 1; w >= 0; w--) {
-        if (w != BP_VB_WINDOWS - 1) {
+    for (int w = nwin - 1; w >= 0; w--) {
+        if (w != nwin - 1) {
             c = hw_dbl(cx, c, row, k);
             c = hw_dbl(cx, c, row, k);
             c = hw_dbl(cx, c, row, k);
@@ -141,6 +143,14 @@ WV_FN wu32 hw_horner8(const wv_ctx &cx, const uint16_t *colq8) {
         const wu32 q = wv_load_u16(colq8, lane + (uint32_t)(w * 64));
         c = hw_add_cached(cx, c, q, row, k);
     }
+    return c;
+}
+
+// 2^n * point: c holds limb k of coordinate `row` (X, Y, Z; row 3 is not read by a doubling)
+WV_FN wu32 hw_shift(const wv_ctx &cx, wu32 c, int n) {
+    const wu32 lane = wv_lane();
+    const wu32 k = lane & 15u, row = lane >> 4;
+    for (int i = 0; i < n; i++) c = hw_dbl(cx, c, row, k);
     return c;
 }
 
@@ -218,7 +228,9 @@ BP_HD void hw_limbs_to_fe(fe &out, const uint32_t l[16]) {
 __device__ void hw_horner_msm(const uint16_t *colq16, ge_ext *out);   // host pass of hipcc: declarations only
 __device__ void hw_horner8_msm(const uint16_t *colq8, uint32_t *lds128, ge_ext *out);
 __device__ void hw_invsqrt_raw_fe(const uint16_t *t16, uint32_t *lds128, fe *out);
-__device__ void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out);
+__device__ void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out, bool half = false);
+__device__ void hw_point_shift(const ge_ext &p, int n, ge_ext *out);
+__device__ void hw_ristretto_decode(ge_ext &r, const uint32_t w[8]);
 #elif defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void hw_horner_msm(const uint16_t *colq16, ge_ext *out) {
     __shared__ __attribute__((aligned(16))) uint32_t hw_lds[128];
@@ -237,25 +249,63 @@ __device__ __forceinline__ void hw_horner_msm(const uint16_t *colq16, ge_ext *ou
 // Fused variant: the wavefront first forms its MSM's 64 column sums itself (lane w = window w: add the
 // chunks' partial sums, re-encode as 16-bit limbs into LDS) and then runs the chain from LDS -- one launch
 // and no [msm][64][128 B] round trip through HBM.
-__device__ __forceinline__ void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out) {
+// half: 32 columns -- lane w < 32 adds lane w + 32's sum (the upper digits' window sums, formed from the tables of the 2^128 multiples)
+// to its own before the chain, which then has 32 windows
+__device__ __forceinline__ void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out, bool half = false) {
     __shared__ __attribute__((aligned(16))) uint32_t hw_lds2[128];
     __shared__ __attribute__((aligned(16))) uint32_t hw_colq[64 * 32];
     const uint32_t lane = wv_lane();
     {
         ge_ext acc;
         vb_colsum_acc(acc, b, lane, chunk_first, part);
-        vb_encode_colq16(hw_colq + lane * 32, acc);
+        if (half) {   // (wavefront-uniform)
+            ge_ext *x = (ge_ext *)hw_colq;   // 32 x 160 bytes of the 8 KB, overwritten by the encodings below
+            if (lane >= 32) x[lane - 32] = acc;
+            WV_LDS_ORDER();
+            if (lane < 32) {
+                const ge_ext q = x[lane];
+                ge_add(acc, acc, q);
+            }
+            WV_LDS_ORDER();
+        }
+        if (!half || lane < 32) vb_encode_colq16(hw_colq + lane * 32, acc);
     }
     WV_LDS_ORDER();
     wv_ctx cx;
     cx.lds = hw_lds2;
-    const wu32 c = hw_horner(cx, (const uint16_t *)hw_colq);
+    const wu32 c = hw_horner(cx, (const uint16_t *)hw_colq, half ? 32 : BP_VB_WINDOWS);
     uint32_t limbs[16];
     wv_row_gather16(cx, c, limbs);
     if ((lane & 15u) == 0) {
         fe r;
         hw_limbs_to_fe(r, limbs);
         ((fe *)out)[lane >> 4] = r;
+    }
+}
+// q = 2^n p with the whole wavefront (every lane holds p; q is written to `out`, LDS or global, by four lanes -- one coordinate each)
+__device__ __forceinline__ void hw_point_shift(const ge_ext &p, int n, ge_ext *out) {
+    __shared__ __attribute__((aligned(16))) uint32_t hw_lds3[128];
+    __shared__ __attribute__((aligned(16))) uint32_t hw_pt[32];
+    const uint32_t lane = wv_lane(), k = lane & 15u, row = lane >> 4;
+    if (k == 0) {
+        uint32_t w[8];
+        fe sel;
+#pragma unroll
+        for (int i = 0; i < 10; i++) sel.v[i] = row == 0 ? p.X.v[i] : (row == 1 ? p.Y.v[i] : (row == 2 ? p.Z.v[i] : p.T.v[i]));   // (limb-wise: no indexed copy of a struct)
+        fe_to_words(w, sel);
+#pragma unroll
+        for (int i = 0; i < 8; i++) hw_pt[8 * row + i] = w[i];
+    }
+    WV_LDS_ORDER();
+    wv_ctx cx;
+    cx.lds = hw_lds3;
+    const wu32 c = hw_shift(cx, wv_load_u16((const uint16_t *)hw_pt, lane), n);
+    uint32_t limbs[16];
+    wv_row_gather16(cx, c, limbs);
+    if (k == 0) {
+        fe r;
+        hw_limbs_to_fe(r, limbs);
+        ((fe *)out)[row] = r;
     }
 }
 // the 8-bit-window chain: colq8 in LDS (or global memory), scratch `lds128` = 128 words of LDS owned by the wavefront
@@ -286,8 +336,56 @@ __device__ __forceinline__ void hw_invsqrt_raw_fe(const uint16_t *t16, uint32_t 
         *out = o;
     }
 }
+// RFC 9496 decode with the whole wavefront: every lane forms the cheap ends (s, u1, u2, v and t = v u2^2 before; the sign fix-ups, x, y
+// after), the 254-squaring chain between them runs one limb per lane (~57 us instead of ~120 in one lane).  The point only -- whether
+// the encoding was valid is the decode role's business (rp_points_thread reports it); every lane returns the same r.
+__device__ __forceinline__ void hw_ristretto_decode(ge_ext &r, const uint32_t w[8]) {
+    __shared__ __attribute__((aligned(16))) uint32_t hd_l128[128];
+    __shared__ __attribute__((aligned(16))) uint32_t hd_tw[8];
+    __shared__ fe hd_raw;
+    fe s, u1, u2, v, u2s, tin;
+    ristretto_decode_front(s, u1, u2, v, w);
+    fe_sq(u2s, u2);
+    fe_mul(tin, v, u2s);
+    if (wv_lane() == 0) {
+        uint32_t tw[8];
+        fe_to_words(tw, tin);
+#pragma unroll
+        for (int i = 0; i < 8; i++) hd_tw[i] = tw[i];
+    }
+    WV_LDS_ORDER();
+    hw_invsqrt_raw_fe((const uint16_t *)hd_tw, hd_l128, &hd_raw);
+    WV_LDS_ORDER();
+    const fe raw = hd_raw;
+    fe I, Dx, Dy, t;
+    (void)fe_invsqrt_fix(I, raw, tin);
+    fe_mul(Dx, I, u2);
+    fe_mul(Dy, I, Dx);
+    fe_mul(Dy, Dy, v);
+    fe_add(t, s, s);
+    fe_mul(r.X, t, Dx);
+    fe_abs(r.X);
+    fe_mul(r.Y, u1, Dy);
+    fe_1(r.Z);
+    fe_mul(r.T, r.X, r.Y);
+}
 #else
-inline void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out);
+inline void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out, bool half = false);
+inline void hw_point_shift(const ge_ext &p, int n, ge_ext *out) {
+    uint32_t pt[32];
+    fe_to_words(pt, p.X); fe_to_words(pt + 8, p.Y); fe_to_words(pt + 16, p.Z); fe_to_words(pt + 24, p.T);
+    wv_ctx cx{0};
+    const wu32 c = hw_shift(cx, wv_load_u16((const uint16_t *)pt, wv_lane()), n);
+    wu32 limbs[16];
+    wv_row_gather16(cx, c, limbs);
+    for (int row = 0; row < 4; row++) {
+        uint32_t l[16];
+        for (int i = 0; i < 16; i++) l[i] = limbs[i].l[row * 16];
+        fe r;
+        hw_limbs_to_fe(r, l);
+        ((fe *)out)[row] = r;
+    }
+}
 inline void hw_invsqrt_raw_fe(const uint16_t *t16, uint32_t *, fe *out) {
     wv_ctx cx{0};
     const wu32 lane = wv_lane(), k = lane & 15u;
@@ -297,6 +395,26 @@ inline void hw_invsqrt_raw_fe(const uint16_t *t16, uint32_t *, fe *out) {
     uint32_t l[16];
     for (int i = 0; i < 16; i++) l[i] = limbs[i].l[0];
     hw_limbs_to_fe(*out, l);
+}
+inline void hw_ristretto_decode(ge_ext &r, const uint32_t w[8]) {
+    fe s, u1, u2, v, u2s, tin, raw;
+    ristretto_decode_front(s, u1, u2, v, w);
+    fe_sq(u2s, u2);
+    fe_mul(tin, v, u2s);
+    uint32_t tw[8];
+    fe_to_words(tw, tin);
+    hw_invsqrt_raw_fe((const uint16_t *)tw, nullptr, &raw);
+    fe I, Dx, Dy, t;
+    (void)fe_invsqrt_fix(I, raw, tin);
+    fe_mul(Dx, I, u2);
+    fe_mul(Dy, I, Dx);
+    fe_mul(Dy, Dy, v);
+    fe_add(t, s, s);
+    fe_mul(r.X, t, Dx);
+    fe_abs(r.X);
+    fe_mul(r.Y, u1, Dy);
+    fe_1(r.Z);
+    fe_mul(r.T, r.X, r.Y);
 }
 inline void hw_horner8_msm(const uint16_t *colq8, uint32_t *, ge_ext *out) {
     wv_ctx cx{0};
@@ -311,9 +429,9 @@ inline void hw_horner8_msm(const uint16_t *colq8, uint32_t *, ge_ext *out) {
         ((fe *)out)[row] = r;
     }
 }
-inline void hw_horner_msm(const uint16_t *colq16, ge_ext *out) {
+inline void hw_horner_msm(const uint16_t *colq16, ge_ext *out, int nwin = BP_VB_WINDOWS) {
     wv_ctx cx{0};
-    const wu32 c = hw_horner(cx, colq16);
+    const wu32 c = hw_horner(cx, colq16, nwin);
     wu32 limbs[16];
     wv_row_gather16(cx, c, limbs);
     for (int row = 0; row < 4; row++) {
@@ -324,14 +442,19 @@ inline void hw_horner_msm(const uint16_t *colq16, ge_ext *out) {
         ((fe *)out)[row] = r;
     }
 }
-inline void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out) {
+inline void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out, bool half) {
     uint32_t colq[64 * 32];
-    for (uint32_t w = 0; w < 64; w++) {
+    for (uint32_t w = 0; w < (half ? 32u : 64u); w++) {
         ge_ext acc;
         vb_colsum_acc(acc, b, w, chunk_first, part);
+        if (half) {
+            ge_ext hi;
+            vb_colsum_acc(hi, b, w + 32, chunk_first, part);
+            ge_add(acc, acc, hi);
+        }
         vb_encode_colq16(colq + w * 32, acc);
     }
-    hw_horner_msm((const uint16_t *)colq, out);
+    hw_horner_msm((const uint16_t *)colq, out, half ? 32 : BP_VB_WINDOWS);
 }
 #endif
 

@@ -167,13 +167,16 @@ __global__ void __launch_bounds__(64) k_finish8(uint32_t nproofs, uint32_t nspli
 
 // the tail of a narrow chain whose walk folded its partial sums itself (rp_walk_narrow): lane = proof, Horner result + one partial sum
 template <bool WITH_OUT>
-__global__ void __launch_bounds__(64) k_finish1(uint32_t nproofs, const ge_ext *hq, const ge_ext *partial, uint32_t *status, uint32_t *out_words, uint8_t *verdict,
-                                                 int reset_status, rp_seg_tab segs) {
+__global__ void __launch_bounds__(64) k_finish1(uint32_t nproofs, uint32_t nparts, const ge_ext *hq, const ge_ext *partial, uint32_t *status, uint32_t *out_words,
+                                                 uint8_t *verdict, int reset_status, rp_seg_tab segs) {
     const uint32_t p = blockIdx.x * 64 + threadIdx.x;
     if (p >= nproofs) return;
     ge_ext acc = hq[p];
-    const ge_ext q = partial[p];
-    ge_add(acc, acc, q);
+#pragma unroll 1
+    for (uint32_t j = 0; j < nparts; j++) {
+        const ge_ext q = partial[(uint64_t)j * nproofs + p];
+        ge_add(acc, acc, q);
+    }
     if (segs.n) {
         const rp_seg sg = rp_seg_lookup(segs, p);
         shared_finish_tail(p, p - sg.first, acc, status, WITH_OUT ? sg.msm_out : nullptr, sg.verdict);
@@ -182,8 +185,8 @@ __global__ void __launch_bounds__(64) k_finish1(uint32_t nproofs, const ge_ext *
     }
     if (reset_status) status[p] = 0;
 }
-template __global__ void k_finish1<true>(uint32_t, const ge_ext *, const ge_ext *, uint32_t *, uint32_t *, uint8_t *, int, rp_seg_tab);
-template __global__ void k_finish1<false>(uint32_t, const ge_ext *, const ge_ext *, uint32_t *, uint32_t *, uint8_t *, int, rp_seg_tab);
+template __global__ void k_finish1<true>(uint32_t, uint32_t, const ge_ext *, const ge_ext *, uint32_t *, uint32_t *, uint8_t *, int, rp_seg_tab);
+template __global__ void k_finish1<false>(uint32_t, uint32_t, const ge_ext *, const ge_ext *, uint32_t *, uint32_t *, uint8_t *, int, rp_seg_tab);
 
 // generator derivation: 64 uniform bytes -> RistrettoPoint::from_uniform_bytes -> encoding
 __global__ void __launch_bounds__(64) k_from_uniform(uint32_t n, const uint32_t *uniform, uint32_t *out) {

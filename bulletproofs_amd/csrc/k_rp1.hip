@@ -64,7 +64,7 @@ template __global__ void k_rp_stage1<false>(rp_shape, rp_strobe_init, uint32_t, 
 __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1_coop(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs, const uint8_t *commitments,
                                                              const uint8_t *rng64, uint32_t *fields, ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m,
                                                              uint32_t *recoded, fb_digit *digits, const uint8_t *rho64, const uint32_t *ts_in, uint32_t *ts_out,
-                                                             fb_entry *bk_pts, uint32_t bk_c, rp_seg_tab segs, const rp_script_hdr *script) {
+                                                             fb_entry *bk_pts, uint32_t bk_c, rp_seg_tab segs, const rp_script_hdr *script, uint32_t n_pt, ge_cached *tab_hi) {
     __shared__ uint32_t lds[2 * 52];   // one 50-word sponge state per group
     __shared__ sc28 dslot[2][RP_DEFER_CAP + 1];   // (option coop_defer_emit) the scalar role's coefficients, parked for the group's lanes
     __shared__ uint32_t dmeta[2][2];
@@ -126,8 +126,10 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1_coop(rp_shape sh, rp_str
             if ((lane & 31) == 0) sgo[g] = (valid && (sflag[g] & 2u) && !sh.shape_verdict) ? 1u : 0u;
             __syncthreads();
             if (valid) rp_split_invert_lane(lane & 31, p, sh, fields, recoded, sp, defer ? &df : nullptr);
+#ifndef BP_EXP_NOREST   // timing experiments only
             if (valid && (lane & 31) == 0 && !sh.shape_verdict)
                 rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, nullptr, 0, defer ? &df : nullptr, RP_SKIP_INV | RP_SKIP_ROWS);
+#endif
         } else {
             rp_transcript_scripted_coop(pp, valid, lane, sh, init, st, in, script, fields, status, ts_out, ts_in);
             if (valid && (lane & 31) == 0 && !sh.shape_verdict) rp_expand_a_thread(p, sh, prm, lg_m, fields, recoded, digits, status, rho64, bk_c, defer ? &df : nullptr);
@@ -136,9 +138,30 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1_coop(rp_shape sh, rp_str
             __syncthreads();
             if (valid && !sh.shape_verdict) rp_emit_deferred(lane & 31, p, sh, recoded, df, bk_c);
         }
-    } else {
+    } else if (blockIdx.x < n_tr + n_pt) {
         const uint32_t t = (blockIdx.x - n_tr) * RP_BLOCK + threadIdx.x;
         if (t < sh.nproofs * sh.U) rp_points_thread(t, sh, rp_resolve(t / sh.U, sh, proofs, commitments, nullptr, segs), tab, status, bk_pts);
+    } else {
+        // Very narrow chains (sh.narrow_hi): one WAVEFRONT per per-proof point decodes it again (the inverse square root's 254 squarings one limb
+        // per lane: hw_ristretto_decode) and doubles it 128 times in the wavefront-cooperative form (horner_wave.h: ~0.45 us per doubling
+        // instead of ~2.5 in one lane), then builds the 8-entry table of Q = 2^128 P.
+        // A coefficient s = s_lo + 2^128 s_hi contributes s_lo P + s_hi Q: 32 windows for the Horner chain instead of 64 -- 124 dependent
+        // doublings on the chain's critical path instead of 252; the other 128 run here, beside the transcript.  (A, whose coefficient
+        // is 1, has no upper digits: skipped.)
+        __shared__ ge_ext hi_pt;
+        const uint32_t t = blockIdx.x - n_tr - n_pt, p = t / sh.U, u = t - p * sh.U;
+        if (u == 0) return;
+        const rp_inputs in = rp_resolve(p, sh, proofs, commitments, nullptr, segs);
+        uint32_t w[8];
+        load_words8(w, rp_unique_point_ptr(sh, in, u));
+        ge_ext pt;
+        hw_ristretto_decode(pt, w);   // (an undecodable point is reported by the decode role; its tables are never used)
+        hw_point_shift(pt, 128, &hi_pt);
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            const ge_ext q = hi_pt;
+            vb_build_table(tab_hi + 8 * (uint64_t)t, q);
+        }
     }
 }
 

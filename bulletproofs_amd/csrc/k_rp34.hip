@@ -11,10 +11,10 @@ template <int FORM>
 __global__ void __launch_bounds__(BP_BLOCK) k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab,
                                                          const uint32_t *recoded, ge_ext *part, ge_cached *colc, uint32_t nthreads_exp,
                                                          rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits,
-                                                         const uint32_t *status, uint32_t n_exp, uint32_t nthreads_rows, uint32_t lg_m) {
+                                                         const uint32_t *status, uint32_t n_exp, uint32_t nthreads_rows, uint32_t lg_m, const ge_cached *tab_hi) {
     if (blockIdx.x < n_win) {
         const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
-        if (tid < nthreads_win) vb_window_thread(tid, chunks, tab, recoded, part, colc);
+        if (tid < nthreads_win) vb_window_thread(tid, chunks, tab, recoded, part, colc, nullptr, tab_hi);
     } else if (blockIdx.x < n_win + n_exp) {
         const uint32_t tid = (blockIdx.x - n_win) * BP_BLOCK + threadIdx.x;
         if (tid < nthreads_exp) {
@@ -28,11 +28,11 @@ __global__ void __launch_bounds__(BP_BLOCK) k_rp_stage3(uint32_t n_win, uint32_t
     }
 }
 template __global__ void k_rp_stage3<0>(uint32_t, uint32_t, const vb_chunk *, const ge_cached *, const uint32_t *, ge_ext *, ge_cached *, uint32_t, rp_shape, fb_params,
-                                        const uint32_t *, fb_digit *, const uint32_t *, uint32_t, uint32_t, uint32_t);
+                                        const uint32_t *, fb_digit *, const uint32_t *, uint32_t, uint32_t, uint32_t, const ge_cached *);
 template __global__ void k_rp_stage3<1>(uint32_t, uint32_t, const vb_chunk *, const ge_cached *, const uint32_t *, ge_ext *, ge_cached *, uint32_t, rp_shape, fb_params,
-                                        const uint32_t *, fb_digit *, const uint32_t *, uint32_t, uint32_t, uint32_t);
+                                        const uint32_t *, fb_digit *, const uint32_t *, uint32_t, uint32_t, uint32_t, const ge_cached *);
 template __global__ void k_rp_stage3<2>(uint32_t, uint32_t, const vb_chunk *, const ge_cached *, const uint32_t *, ge_ext *, ge_cached *, uint32_t, rp_shape, fb_params,
-                                        const uint32_t *, fb_digit *, const uint32_t *, uint32_t, uint32_t, uint32_t);
+                                        const uint32_t *, fb_digit *, const uint32_t *, uint32_t, uint32_t, uint32_t, const ge_cached *);
 
 // the generator exponents alone (wide chains, where the window sums are a launch of their own): the role's own register allocation.
 // Two wavefronts per SIMD although 166 registers would allow three: with three, the kernel itself runs 200 instead of 290 us, but on
@@ -102,10 +102,10 @@ __global__ void __launch_bounds__(FB_BLOCK) k_rp_stage4(uint32_t n_hw, const uin
     if (blockIdx.x < n_hw) {
             if (HL == 4) hq_horner_msm(blockIdx.x * 16 + (threadIdx.x >> 2), nproofs, colc, hq);
         else if (HL == 1) vb_horner_cached_thread(blockIdx.x * FB_BLOCK + threadIdx.x, nproofs, colc, hq);
-        else hw_colsum_horner_msm(blockIdx.x, chunk_first, part, hq + blockIdx.x);
+        else hw_colsum_horner_msm(blockIdx.x, chunk_first, part, hq + blockIdx.x, (walk_form & 2u) != 0);   // (bit 1: 32 windows, the upper digits' sums folded in)
         return;
     }
-    if (HL == 64 && walk_form == 1) {
+    if (HL == 64 && (walk_form & 1u)) {
         rp_walk_narrow(blockIdx.x - n_hw, prm, nproofs, nsplit, npairs, gen_ids, digits, table, partial);
         return;
     }

@@ -206,12 +206,16 @@ __device__ __forceinline__ void keccak_f1600_masked_coop(const kstate &st, const
     if (2 * j < nmask) lo ^= mask[2 * j];
     if (2 * j + 1 < nmask) hi ^= mask[2 * j + 1];
     uint64_t a = ((uint64_t)hi << 32) | lo;
+#ifdef BP_EXP_NOKECCAK   // timing experiments only
+    a += 1;
+#else
 #pragma unroll 1
     for (uint32_t r = 0; r < 24; r++) {
         const uint64_t c = kc_p1(a, x, y, g);
         const uint64_t b = kc_p23(a, c, src, rho_src, g);
         a = kc_p4(b, x, y, j, r, g);
     }
+#endif
     if (jj < 25) {
         st.w[(2 * j) * st.stride] = (uint32_t)a;
         st.w[(2 * j + 1) * st.stride] = (uint32_t)(a >> 32);

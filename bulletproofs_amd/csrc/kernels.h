@@ -41,13 +41,13 @@ __global__ void k_fb_accum_ct(fb_params prm, uint32_t nproofs, uint32_t nblk_p, 
 __global__ void k_fb_reduce(uint32_t nthreads, uint32_t nproofs, uint32_t nsplit, uint32_t group, const ge_ext *partial, ge_ext *out);
 __global__ void k_shared_finish(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, int have_unique, const ge_ext *partial, const uint32_t *status, uint32_t *out_words, uint8_t *verdict,
                                 uint8_t *status_bytes);
-template <bool WITH_OUT> __global__ void k_finish1(uint32_t nproofs, const ge_ext *hq, const ge_ext *partial, uint32_t *status, uint32_t *out_words, uint8_t *verdict, int reset_status, rp_seg_tab segs);
+template <bool WITH_OUT> __global__ void k_finish1(uint32_t nproofs, uint32_t nparts, const ge_ext *hq, const ge_ext *partial, uint32_t *status, uint32_t *out_words, uint8_t *verdict, int reset_status, rp_seg_tab segs);
 template <bool WITH_OUT>
 __global__ void k_finish8(uint32_t nproofs, uint32_t nsplit, const ge_ext *hq, const ge_ext *partial, uint32_t *status, uint32_t *out_words, uint8_t *verdict, int reset_status, rp_seg_tab segs);
-__global__ void k_rp_stage1_coop(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs, const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields, ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m, uint32_t *recoded, fb_digit *digits, const uint8_t *rho64, const uint32_t *ts_in, uint32_t *ts_out, fb_entry *bk_pts, uint32_t bk_c, rp_seg_tab segs, const rp_script_hdr *script);
+__global__ void k_rp_stage1_coop(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs, const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields, ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m, uint32_t *recoded, fb_digit *digits, const uint8_t *rho64, const uint32_t *ts_in, uint32_t *ts_out, fb_entry *bk_pts, uint32_t bk_c, rp_seg_tab segs, const rp_script_hdr *script, uint32_t n_pt, ge_cached *tab_hi);
 template <bool SCRIPTED> __global__ void k_rp_stage1(rp_shape sh, rp_strobe_init init, uint32_t n_tr, const uint8_t *proofs, const uint8_t *commitments, const uint8_t *rng64, uint32_t *fields, ge_cached *tab, uint32_t *status, fb_params prm, uint32_t lg_m, uint32_t *recoded, fb_digit *digits, const uint8_t *rho64, uint32_t ts_flags, const uint32_t *ts_in, uint32_t *ts_out, fb_entry *bk_pts, uint32_t bk_c, rp_seg_tab segs, const rp_script_hdr *script);
 template <int FORM>
-__global__ void k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, ge_cached *colc, uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits, const uint32_t *status, uint32_t n_exp, uint32_t nthreads_rows, uint32_t lg_m);
+__global__ void k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, ge_cached *colc, uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits, const uint32_t *status, uint32_t n_exp, uint32_t nthreads_rows, uint32_t lg_m, const ge_cached *tab_hi);
 template <bool PAIRS>
 __global__ void k_rp_exponents(uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits, const uint32_t *status);
 __global__ void k_rp_horner1(uint32_t nproofs, const ge_cached *colc, ge_ext *hq);

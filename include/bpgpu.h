@@ -100,6 +100,15 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
  *   "split_stage3"          -1 (default): the window sums as their own launch on chains of >= 2048 proofs; 0 / 1: never / always
  *   "transcript_coop"       1 (default): launch chains of up to 256 proofs replay their transcripts 32 lanes per proof (Keccak-f[1600]
  *                           with one state word per lane: one blocking call of 1 proof 0.62 -> 0.53 ms); 0: one lane per proof everywhere
+ *   narrow chains (up to 256 proofs: the crate's own call shape, the combining queue's small chains; round 6):
+ *   "coop_split"            1 (default): launch 1 stages the proof, the script and its masks in LDS, the 5 + k challenges are reduced on
+ *                           5 + k lanes, the k + 1 inversions run on k + 1 lanes at once, the basepoint coefficients are a role of launch 3;
+ *                           0: the group's leader does all of it (k_rp_stage1_coop 227 -> 157 us for one proof)
+ *   "exp_single"            1 (default): the generator-exponent role with one index per lane (launch 3: 73 -> 33 us); 0: as wide chains
+ *   "narrow_chunk"          per-proof points per (chunk, window) lane of launch 3: 0 = 8 (default), 2 .. 32; 32 = one chunk
+ *   "narrow_walk"           1 (default): the table walk with lane = split, a proof's partial sums folded inside launch 4 (finish 40 -> 5 us)
+ *   "narrow_hi_max"         chains of up to this many proofs (default 32; 0: never) give every per-proof point a second table, of its
+ *                           2^128 multiple (a wavefront per point, beside the transcript), and run a 32-window Horner chain
  *   "msm_fork"              1 (default): bpgpu_msm_batch_shared's generator half on the context's second stream beside the per-MSM points; 0: one stream
  *   "bucket_chain"          0 (default): MSMs of up to 6144 variable-base terms take the fused bucket chain (csrc/bucket2.h: decode, one LDS
  *                           sort + accumulate workgroup per (MSM, window), one tail launch); 1: bucket.h's chain everywhere (for A/B)

@@ -419,6 +419,8 @@ static int g_defer_emit = 0;
 void h_set_defer_emit(int on) { g_defer_emit = on; }
 static int g_coop_split = 0;   // the narrow chain's split scalar role (rp_split_*, rp_rows_thread); per-proof verification only
 void h_set_coop_split(int on) { g_coop_split = on; }
+static int g_narrow_hi = 0;    // very narrow chains: second tables of the points' 2^128 multiples (hw_point_shift), 32-window chain; with horner_lanes 64 only
+void h_set_narrow_hi(int on) { g_narrow_hi = on; }
 static std::vector<uint32_t> g_seg_sizes;
 void h_set_segments(uint32_t count, const uint32_t *sizes) { g_seg_sizes.assign(sizes, sizes + count); }
 // ... and item i verifies under label i mod count (labels of ONE length: they share every transcript position, rp_seg::init_w)
@@ -571,6 +573,32 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
         rp_expand_a_thread(p, sh, prm, lg_m, fields.data(), rec.data(), digits.data(), status.data(), weights64);
     }
     for (uint32_t t = 0; t < t0; t++) rp_points_thread(t, sh, rp_resolve(t / sh.U, sh, proofs_l1, coms_l1, nullptr, segtab), tab.data(), status.data());
+    const bool hi = g_narrow_hi && !rlc && !r5 && !a_out && g_horner_lanes == 64;
+    std::vector<ge_cached> tab_hi(hi ? (size_t)t0 * 8 + 1 : 1);
+    if (hi) {   // k_rp_stage1_coop's third role: one wavefront per point, Q = 2^128 P by 128 wavefront-cooperative doublings, then Q's table
+        for (uint32_t t = 0; t < t0; t++) {
+            const uint32_t p = t / sh.U, u = t - p * sh.U;
+            if (u == 0) continue;
+            uint32_t w[8];
+            load_words8(w, rp_unique_point_ptr(sh, rp_resolve(p, sh, proofs_l1, coms_l1, nullptr, segtab), u));
+            ge_ext pt, q, pt_ref;
+            hw_ristretto_decode(pt, w);
+            if (ristretto_decompress(pt_ref, w)) {   // (a valid encoding: the wavefront's decode is the lane's, coordinate for coordinate)
+                uint32_t a[8], b[8];
+                fe_to_words(a, pt.X); fe_to_words(b, pt_ref.X); if (memcmp(a, b, 32)) return -91;
+                fe_to_words(a, pt.Y); fe_to_words(b, pt_ref.Y); if (memcmp(a, b, 32)) return -92;
+                fe_to_words(a, pt.T); fe_to_words(b, pt_ref.T); if (memcmp(a, b, 32)) return -93;
+            }
+            hw_point_shift(pt, 128, &q);
+            vb_build_table(tab_hi.data() + 8 * (size_t)t, q);
+            // cross-check: the lane-serial doublings give the same point (projectively)
+            ge_ext r = pt;
+            for (int i = 0; i < 128; i++) ge_dbl(r, r, true);
+            uint32_t e1[8], e2[8];
+            ristretto_compress(e1, q); ristretto_compress(e2, r);
+            if (memcmp(e1, e2, 32)) return -90;
+        }
+    }
     // launch 2
     std::vector<uint64_t> acc((size_t)n_gen_terms * 10, 0);
     if (rlc) {
@@ -678,7 +706,7 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
         for (uint32_t tid = 0; tid < nbatch * BP_VB_WINDOWS; tid++) vb_window_wide_thread<false>(tid, sh.U, 1, tab.data(), rec.data(), colc.data());
     else
     for (uint32_t tid = 0; tid < chunks.size() * 64; tid++)
-        vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data(), (quad && one_chunk) ? colc.data() : nullptr);
+        vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data(), (quad && one_chunk) ? colc.data() : nullptr, nullptr, hi ? tab_hi.data() : nullptr);
     if (quad && !one_chunk && !r5 && !a_out)
         for (uint32_t tid = 0; tid < nbatch * 64; tid++) vb_colsum_thread(tid, chunk_first.data(), part.data(), nullptr, nullptr, colc.data());
     // launch 3
@@ -693,7 +721,7 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
         else if (a_out) vb_horner_wide_thread<false>(b, nbatch, colc.data(), tab.data(), 8ull * sh.U, hq.data());
         else if (g_horner_lanes == 1) vb_horner_cached_thread(b, nbatch, colc.data(), hq.data());
         else if (quad) hq_horner_msm(b, nbatch, colc.data(), hq.data());
-        else hw_colsum_horner_msm(b, chunk_first.data(), part.data(), &hq[b]);
+        else hw_colsum_horner_msm(b, chunk_first.data(), part.data(), &hq[b], hi);
     }
     std::vector<uint8_t> verdict(nbatch + 1);
     // launch 4 (k_finish8): 8 lanes per proof gather, 3-level fold, lane 0 finishes
