@@ -154,6 +154,17 @@ WV_FN wu32 hw_shift(const wv_ctx &cx, wu32 c, int n) {
     return c;
 }
 
+// the running point in cached row order (Y-X | Y+X | Z | 2dT), "small" limbs: one multiplication slot -- rows 0..2 by 1 (which normalises
+// them), row 3 by 2d.  d2l: this lane's limb of 2d.
+WV_FN wu32 hw_to_cached(const wv_ctx &cx, const wu32 &c, const wu32 &d2l, const wu32 &row, const wu32 &k) {
+    wu32 r4[4];
+    wv_rows4(cx, c, r4);
+    const wu32 x = r4[0], y = r4[1];
+    const wu32 in = wv_select(row == 0u, hw_sub(y, x, k), wv_select(row == 1u, y + x, c));
+    const wu32 f = wv_select(row == 3u, d2l, wv_select(k == 0u, wv_splat(1), wv_splat(0)));
+    return hw_mul(cx, in, f, k);
+}
+
 // ---- the inverse-square-root chain with a wavefront per field element ---------------------------------------------------------------
 // ge25519.h: fe_invsqrt_raw -- r = t^3 (t^7)^((p-5)/8), 254 squarings + 14 multiplications in sequence -- is what a lone MSM's canonical
 // encoding waits for at the end of its chain: 143 us in one lane (a lane alone on its SIMD issues an instruction every ~9 cycles).  With
@@ -231,6 +242,7 @@ __device__ void hw_invsqrt_raw_fe(const uint16_t *t16, uint32_t *lds128, fe *out
 __device__ void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out, bool half = false);
 __device__ void hw_point_shift(const ge_ext &p, int n, ge_ext *out);
 __device__ void hw_ristretto_decode(ge_ext &r, const uint32_t w[8]);
+__device__ void hw_shift_table8(const ge_ext &p, int n, ge_cached *out8);
 #elif defined(__HIP_DEVICE_COMPILE__)
 __device__ __forceinline__ void hw_horner_msm(const uint16_t *colq16, ge_ext *out) {
     __shared__ __attribute__((aligned(16))) uint32_t hw_lds[128];
@@ -306,6 +318,49 @@ __device__ __forceinline__ void hw_point_shift(const ge_ext &p, int n, ge_ext *o
         fe r;
         hw_limbs_to_fe(r, limbs);
         ((fe *)out)[row] = r;
+    }
+}
+// out8[e] = (e + 1) 2^n p as cached points, e = 0 .. 7 (what vb_build_table makes of 2^n p in one lane: ~25 us; here ~10), the whole
+// chain in the wavefront's layout -- no trip through one lane between the doublings and the table
+__device__ __forceinline__ void hw_store_cached(const wv_ctx &cx, const wu32 &ce, ge_cached *out, uint32_t row, uint32_t k) {
+    uint32_t limbs[16];
+    wv_row_gather16(cx, ce, limbs);
+    if (k == 0) {
+        fe r;
+        hw_limbs_to_fe(r, limbs);
+        fe_carry(r);   // (stored operands are reduced: ge_add_cached subtracts them without a carry chain)
+        if (row == 0) out->YmX = r;
+        else if (row == 1) out->YpX = r;
+        else if (row == 2) out->Z = r;
+        else out->T2d = r;
+    }
+}
+__device__ __forceinline__ void hw_shift_table8(const ge_ext &p, int n, ge_cached *out8) {
+    __shared__ __attribute__((aligned(16))) uint32_t hw_lds4[128];
+    __shared__ __attribute__((aligned(16))) uint32_t hw_pt4[40];
+    const uint32_t lane = wv_lane(), k = lane & 15u, row = lane >> 4;
+    if (k == 0) {
+        uint32_t w[8];
+        fe sel;
+        const fe d2 = BP_FE_D2;
+#pragma unroll
+        for (int i = 0; i < 10; i++) sel.v[i] = row == 0 ? p.X.v[i] : (row == 1 ? p.Y.v[i] : (row == 2 ? p.Z.v[i] : d2.v[i]));   // (row 3 of a doubling's input is not read: it carries 2d to LDS)
+        fe_to_words(w, sel);
+#pragma unroll
+        for (int i = 0; i < 8; i++) hw_pt4[8 * row + i] = w[i];
+    }
+    WV_LDS_ORDER();
+    wv_ctx cx;
+    cx.lds = hw_lds4;
+    const wu32 d2l = wv_load_u16((const uint16_t *)hw_pt4, 48u + k);
+    wu32 cur = hw_shift(cx, wv_load_u16((const uint16_t *)hw_pt4, lane), n);
+    const wu32 c1 = hw_to_cached(cx, cur, d2l, row, k);
+    hw_store_cached(cx, c1, out8, row, k);
+#pragma unroll 1
+    for (int e = 1; e < 8; e++) {
+        cur = hw_add_cached(cx, cur, c1, row, k);
+        const wu32 ce = hw_to_cached(cx, cur, d2l, row, k);
+        hw_store_cached(cx, ce, out8 + e, row, k);
     }
 }
 // the 8-bit-window chain: colq8 in LDS (or global memory), scratch `lds128` = 128 words of LDS owned by the wavefront
@@ -395,6 +450,33 @@ inline void hw_invsqrt_raw_fe(const uint16_t *t16, uint32_t *, fe *out) {
     uint32_t l[16];
     for (int i = 0; i < 16; i++) l[i] = limbs[i].l[0];
     hw_limbs_to_fe(*out, l);
+}
+inline void hw_shift_table8(const ge_ext &p, int n, ge_cached *out8) {
+    uint32_t pt[32];
+    const fe d2 = BP_FE_D2;
+    fe_to_words(pt, p.X); fe_to_words(pt + 8, p.Y); fe_to_words(pt + 16, p.Z); fe_to_words(pt + 24, d2);
+    wv_ctx cx{0};
+    const wu32 lane = wv_lane(), k = lane & 15u, row = lane >> 4;
+    const wu32 d2l = wv_load_u16((const uint16_t *)pt, k + 48u);
+    wu32 cur = hw_shift(cx, wv_load_u16((const uint16_t *)pt, lane), n);
+    const wu32 c1 = hw_to_cached(cx, cur, d2l, row, k);
+    for (int e = 0; e < 8; e++) {
+        if (e) cur = hw_add_cached(cx, cur, c1, row, k);
+        const wu32 ce = e ? hw_to_cached(cx, cur, d2l, row, k) : c1;
+        wu32 limbs[16];
+        wv_row_gather16(cx, ce, limbs);
+        for (int r = 0; r < 4; r++) {
+            uint32_t l[16];
+            for (int i = 0; i < 16; i++) l[i] = limbs[i].l[r * 16];
+            fe f;
+            hw_limbs_to_fe(f, l);
+            fe_carry(f);
+            if (r == 0) out8[e].YmX = f;
+            else if (r == 1) out8[e].YpX = f;
+            else if (r == 2) out8[e].Z = f;
+            else out8[e].T2d = f;
+        }
+    }
 }
 inline void hw_ristretto_decode(ge_ext &r, const uint32_t w[8]) {
     fe s, u1, u2, v, u2s, tin, raw;

@@ -148,7 +148,6 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1_coop(rp_shape sh, rp_str
         // A coefficient s = s_lo + 2^128 s_hi contributes s_lo P + s_hi Q: 32 windows for the Horner chain instead of 64 -- 124 dependent
         // doublings on the chain's critical path instead of 252; the other 128 run here, beside the transcript.  (A, whose coefficient
         // is 1, has no upper digits: skipped.)
-        __shared__ ge_ext hi_pt;
         const uint32_t t = blockIdx.x - n_tr - n_pt, p = t / sh.U, u = t - p * sh.U;
         if (u == 0) return;
         const rp_inputs in = rp_resolve(p, sh, proofs, commitments, nullptr, segs);
@@ -156,12 +155,7 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1_coop(rp_shape sh, rp_str
         load_words8(w, rp_unique_point_ptr(sh, in, u));
         ge_ext pt;
         hw_ristretto_decode(pt, w);   // (an undecodable point is reported by the decode role; its tables are never used)
-        hw_point_shift(pt, 128, &hi_pt);
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            const ge_ext q = hi_pt;
-            vb_build_table(tab_hi + 8 * (uint64_t)t, q);
-        }
+        hw_shift_table8(pt, 128, tab_hi + 8 * (uint64_t)t);   // (the eight multiples of Q in the wavefront's layout too: ~10 us instead of ~25 in one lane)
     }
 }
 

@@ -379,6 +379,8 @@ struct pool_dev {
     std::atomic<uint64_t> stat_chains{0}, stat_proofs{0}, stat_requests{0};
     std::atomic<uint64_t> stat_issue_ns{0}, stat_complete_ns{0}, stat_polls{0}, stat_deliver_ns{0};
     std::atomic<uint32_t> recent_K{0};      // width of the chain issued last (sizes the next buffer)
+    uint64_t ema_small_ns = 0;                    // (service thread) running mean of issue end -> completion seen over range-proof chains of <= 4 proofs: when such a chain
+                                                  // is due, the thread polls instead of sleeping out its period (svc_main)
     uint32_t last_done_K[4] = {0, 0, 0, 0};      // (service thread) width of the chain of each kind that completed last: the group about to come back
     uint64_t t_last_done[4] = {0, 0, 0, 0};
     std::mutex trace_mu;
@@ -1297,6 +1299,10 @@ static void comb_issue(bpgpu_pool *p, pool_dev *d, comb_buf *b, uint32_t infligh
 // delivery thread's.
 static void comb_complete(pool_dev *d, comb_buf *b) {
     b->ev.t_done = now_ns();
+    if (b->key.kind == CQ_RP && b->K <= 4 && b->rc == 0 && b->ev.t_issue1 && b->ev.t_done > b->ev.t_issue1) {
+        const uint64_t dur = b->ev.t_done - b->ev.t_issue1;
+        if (dur < 5000000) d->ema_small_ns = d->ema_small_ns ? (7 * d->ema_small_ns + dur) / 8 : dur;
+    }
     d->last_done_K[b->key.kind & 3] = b->K;   // (service thread only: the group that is about to come back)
     d->t_last_done[b->key.kind & 3] = b->ev.t_done;
     const uint32_t epoch = cbs_epoch(b->state.load(std::memory_order_relaxed));
@@ -1444,6 +1450,7 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
         const uint32_t kick0 = d->kick.load(std::memory_order_seq_cst);   // (before the scan: whatever happens after this read rings the bell)
         const bool stopping = d->cstop.load(std::memory_order_acquire);
         bool active = false, all_free = true;
+        uint64_t soonest_due = UINT64_MAX;   // when the next narrow chain in flight should be complete (ema_small_ns)
         const uint64_t now = now_ns();
         d->stat_polls.fetch_add(1, std::memory_order_relaxed);
         uint32_t inflight = 0, waiting = 0, n_free = 0;
@@ -1516,7 +1523,13 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
                         b->err = std::string("combining queue: ") + hipGetErrorString(e);
                     }
                     to_complete.push_back(b);
-                } else (void)hipGetLastError();
+                } else {
+                    (void)hipGetLastError();
+                    if (b->key.kind == CQ_RP && b->K <= 4 && d->ema_small_ns) {   // a narrow chain's caller is blocked on exactly this: know when it is due
+                        const uint64_t due = b->ev.t_issue1 + d->ema_small_ns;
+                        if (due < soonest_due) soonest_due = due;
+                    }
+                }
             } else if (st == CB_DONE) active = true;   // (being delivered)
         }
         if (!to_issue.empty() || !to_complete.empty()) {
@@ -1553,8 +1566,17 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
         TEST_DELAY(11);
         d->svc_sleeping.store(1, std::memory_order_seq_cst);
         TEST_DELAY(12);
-        if (active || stopping) futex_wait_ns(&d->kick, kick0, (uint64_t)p->combine_poll_ns);
-        else futex_wait(&d->kick, kick0);
+        if (active || stopping) {
+            // a chain of a proof or two that is due within the polling period: sleep up to 3 us before it is due, then poll without sleeping
+            // (at most 40 us past the estimate) -- its caller sits on a futex for exactly this completion (one blocking call: -7 us)
+            uint64_t nap = (uint64_t)p->combine_poll_ns;
+            if (soonest_due != UINT64_MAX && !stopping) {
+                const uint64_t t = now_ns();
+                if (t + 3000 >= soonest_due) nap = t < soonest_due + 40000 ? 0 : nap;
+                else if (soonest_due - t - 3000 < nap) nap = soonest_due - t - 3000;
+            }
+            if (nap) futex_wait_ns(&d->kick, kick0, nap);
+        } else futex_wait(&d->kick, kick0);
         d->svc_sleeping.store(0, std::memory_order_seq_cst);
     }
 }

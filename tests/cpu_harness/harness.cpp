@@ -590,7 +590,19 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
                 fe_to_words(a, pt.T); fe_to_words(b, pt_ref.T); if (memcmp(a, b, 32)) return -93;
             }
             hw_point_shift(pt, 128, &q);
-            vb_build_table(tab_hi.data() + 8 * (size_t)t, q);
+            hw_shift_table8(pt, 128, tab_hi.data() + 8 * (size_t)t);
+            {   // the wavefront's table holds the same eight points as the lane's (vb_build_table): e Q + entry == (e + 2) Q ... compared as encodings
+                ge_cached ref[8];
+                vb_build_table(ref, q);
+                for (int e = 0; e < 8; e++) {
+                    ge_ext a, b, idn; ge_identity(idn);
+                    ge_add_cached(a, idn, tab_hi[8 * (size_t)t + e], false);
+                    ge_add_cached(b, idn, ref[e], false);
+                    uint32_t ea[8], eb[8];
+                    ristretto_compress(ea, a); ristretto_compress(eb, b);
+                    if (memcmp(ea, eb, 32)) return -94;
+                }
+            }
             // cross-check: the lane-serial doublings give the same point (projectively)
             ge_ext r = pt;
             for (int i = 0; i < 128; i++) ge_dbl(r, r, true);
