@@ -211,9 +211,9 @@ def test_hot_path_kernels_use_no_scratch_memory_and_the_build_gate_knows_every_e
         objs = sorted(glob.glob(os.path.join(ROOT, "bulletproofs_amd", "csrc", "build", "*.o")))
     assert kr.check(objs, ge.SCRATCH_ALLOW) == []
     ks = {k["name"]: k for o in objs for k in kr.kernels_of(o)}
-    for hot in ("void k_vb_window_wide<false>", "void k_rp_exponents<true>", "void k_rp_exponents<false>", "void k_rp_stage3<true>", "void k_rp_stage3<false>",
+    for hot in ("void k_vb_window_wide<false>", "void k_rp_exponents<true>", "void k_rp_exponents<false>", "void k_rp_stage3<0>", "void k_rp_stage3<1>", "void k_rp_stage3<2>",
                 "void k_bk2_window<64>", "void k_bk2_window<256>", "k_bk2_leafv", "k_msm_tail", "k_msm_tail_fast", "void k_rp_stage4<4>", "void k_rp_horner_wide<false>", "k_fb_reduce",
-                "void k_finish8<false>", "k_vb_window_colc", "void k_rp_stage4<64>"):
+                "void k_finish8<false>", "void k_finish1<false>", "k_vb_window_colc", "void k_rp_stage4<64>"):
         assert ks[hot]["scratch"] == 0 and ks[hot]["spill_vgpr"] == 0, hot
     s1 = ks["void k_rp_stage1<true>"]
     assert s1["scratch"] <= 360 and s1["spill_vgpr"] <= 118 and s1["code_bytes"] <= 320 * 1024

@@ -107,7 +107,7 @@ def test_single_proof_calls_from_64_threads_own_transcripts_vs_oracle(oracle, po
     assert sum(1 for e in exp if e[0] == 0) > len(items) // 2
     chains, reqs, proofs = (pool64.get_option("stat_combined_" + k) for k in ("chains", "requests", "proofs"))
     assert reqs == len(items) and proofs == sum(1 for it in items if len(it[0]) == pl)
-    assert chains < reqs / 3, (chains, reqs)      # calls were combined (64 threads in lockstep: tens of proofs per chain)
+    assert chains < reqs / 2, (chains, reqs)      # calls were combined (round 6's narrow chain is a third shorter: Python threads meet in it less often than the 3 per chain of round 5)
 
 
 def test_many_position_classes_fall_back_to_bytewise_chain(oracle, pool64):

@@ -1,0 +1,18 @@
+#!/bin/bash
+# round 6, call 35: whole GPU suite + smoke + the driver's bench forms on the tree with the narrow-chain work
+REPO=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$REPO/gpurun_out/r06_call35
+mkdir -p $OUT
+cd $REPO
+timeout 2400 python -m pytest tests -x -q -m gpu > $OUT/pytest_gpu_full.txt 2>&1; tail -3 $OUT/pytest_gpu_full.txt
+python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" > $OUT/smoke.txt 2>&1; tail -1 $OUT/smoke.txt
+cd /tmp && export TMPDIR=/tmp
+python $REPO/bench.py > $OUT/bench_default.json 2> $OUT/bench_default.err; python -c "
+import json
+j = json.loads([l for l in open('$OUT/bench_default.json') if l.startswith('{')][-1])
+print('default:', j['value'], j['ms_per_step'], {k: (v.get('verifications_per_s') or v.get('msms_per_s'), v['latency_ms']['p50'], v['latency_ms']['p99'], v['latency_ms']['max']) for k, v in j['extra']['drop_in_call_shape'].items() if isinstance(v, dict) and 'latency_ms' in v})
+print({k: (v.get('value') if isinstance(v, dict) else v) for k, v in j['extra'].items() if k in ('cfg3', 'cfg4', 'cfg5_shape', 'rlc', 'rlc_batch4096', 'prover')})"
+python $REPO/bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_steps20.json 2> $OUT/bench_steps20.err; python -c "
+import json
+j = json.loads([l for l in open('$OUT/bench_steps20.json') if l.startswith('{')][-1])
+print('steps20:', j['value'], j['ms_per_step'], {k: (v.get('verifications_per_s') or v.get('msms_per_s'), v['latency_ms']['p50'], v['latency_ms']['p99'], v['latency_ms']['max']) for k, v in j['extra']['drop_in_call_shape'].items() if isinstance(v, dict) and 'latency_ms' in v})"
