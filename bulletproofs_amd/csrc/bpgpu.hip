@@ -97,6 +97,7 @@ struct bpgpu_ctx {
     int exp_single = 1;                                             // narrow chains: the generator-exponent role with one index per lane (rp_expand_b1_thread); 0: as wide chains
     int narrow_walk = 1;                                            // narrow chains: the table walk with lane = split and the partial sums folded in launch 4 (k_rp34.hip rp_walk_narrow); 0: thread = proof
     int narrow_hi_max = 32;                                         // chains of up to this many proofs give every per-proof point a second table (2^128 P) and run a 32-window Horner chain; 0: never
+    int narrow_fused_finish = 1;                                    // narrow chains, verdicts only: the last workgroup of a proof in launch 4 finishes it (no finish launch)
     int coop_split = 1;                                             // narrow chains, per-proof check: the k + 1 inversions on k + 1 lanes of the group at once, the basepoint coefficients as a
                                                                     // role of launch 3 (rangeproof.h rp_split_invert_lane / rp_rows_thread); 0: the leader does it all (A/B: profiles/r06/coop_split_ab.txt)
     int transcript_coop = 1;                                        // chains of up to 256 proofs replay their transcripts 32 lanes per proof (keccak.h): one call of 1 / 8 / 64 / 256 proofs 0.62 -> 0.53 / 0.56 / 0.57 / 0.58 ms; 0: lane = proof everywhere
@@ -126,6 +127,8 @@ struct bpgpu_ctx {
     // entries it used), so no memset launch is needed per call; `dirty` forces one after an aborted enqueue
     uint32_t *rp_status = nullptr;
     size_t rp_status_cap = 0;
+    uint32_t *fin_cnt = nullptr;             // [256] arrival counters of the narrow chain's fused finish (k_rp_stage4<64>: the last workgroup of a proof finishes it and
+                                             // hands its counter back zeroed)
     bool rp_status_dirty = false;
     bool test_seed_set = false;   // bpgpu_internal_set_chain_seed (tests): the per-chain key of the device-expanded randomness
     uint8_t test_seed[32];
@@ -422,6 +425,7 @@ int bpgpu_ctx_create(int device, bpgpu_ctx **out) {
     }
     if (const char *e = getenv("BPGPU_COOP_SPLIT")) c->coop_split = atoi(e) != 0;
     if (const char *e = getenv("BPGPU_NARROW_WALK")) c->narrow_walk = atoi(e) != 0;
+    if (const char *e = getenv("BPGPU_NARROW_FUSED_FINISH")) c->narrow_fused_finish = atoi(e) != 0;
     if (const char *e = getenv("BPGPU_NARROW_HI_MAX")) c->narrow_hi_max = atoi(e);
     if (const char *e = getenv("BPGPU_EXP_SINGLE")) c->exp_single = atoi(e) != 0;
     if (const char *e = getenv("BPGPU_NARROW_CHUNK")) c->narrow_chunk = atoi(e);
@@ -455,6 +459,7 @@ void bpgpu_ctx_destroy(bpgpu_ctx *c) {
     if (c->join_ev) hipEventDestroy(c->join_ev);
     if (c->stream2) hipStreamDestroy(c->stream2);
     if (c->rp_status) hipFree(c->rp_status);
+    if (c->fin_cnt) hipFree(c->fin_cnt);
     if (c->d_table_ct) hipFree(c->d_table_ct);
     if (c->d_gens) hipFree(c->d_gens);
     release_secondary(c);
@@ -514,6 +519,10 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
     if (!strcmp(key, "narrow_hi_max")) {
         if (value < 0 || value > 256) return fail(c, BPGPU_ERR_INVALID_ARG, "narrow_hi_max must be 0 .. 256");
         c->narrow_hi_max = (int)value;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "narrow_fused_finish")) {
+        c->narrow_fused_finish = value != 0;
         return BPGPU_OK;
     }
     if (!strcmp(key, "narrow_walk")) {
@@ -2049,6 +2058,10 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     rc = arena_reserve(c, arena_need);
     if (rc) return rc;
     char *a = c->arena;
+    if (!c->fin_cnt) {
+        HIPCHK(c, hipMalloc((void **)&c->fin_cnt, 256 * 4));
+        HIPCHK(c, hipMemset(c->fin_cnt, 0, 256 * 4));
+    }
     if (c->rp_status_cap < nbatch) {
         if (c->rp_status) HIPCHK(c, hipFree(c->rp_status));
         c->rp_status = nullptr;
@@ -2259,7 +2272,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
             LAUNCH(c, s, "rlc_colsum", k_rlc_colsum_scalars, n_sc, BP_BLOCK, 0u, 0u, 0u, 1u, (const ge_ext *)cur, next, n_gen_terms,
                    (const unsigned long long *)d_acc, d_dig1, prm, d_ctl, rows);
         LAUNCH(c, s, "rlc_stage4", k_rp_stage4<64>, 1 + nsplit1, FB_BLOCK, 1u, d_ctl + 2, cur, (const ge_cached *)nullptr, d_hq1, prm, 1u, 1u,
-               nsplit1, npairs, d_ids, d_dig1, gen_table, d_part1, 0u);
+               nsplit1, npairs, d_ids, d_dig1, gen_table, d_part1, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint8_t *)nullptr, rp_seg_tab{});
         if (d_batch_out)
             LAUNCH(c, s, "rlc_finish", k_rlc_finish<true>, 1, 64, nsplit1, d_hq1, d_part1, nb32, d_status, (uint8_t *)d_verdict, (uint8_t *)d_batch_out, segtab);
         else
@@ -2320,25 +2333,36 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     }
     const uint32_t nblk_p = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
     uint32_t nparts = nsplit;   // partial sums per proof that launch 4 leaves
+    // verdicts only (the crate's own call: nobody asks for the mega-check's encoding) and at most four partial sums per proof: the LAST of a proof's
+    // 1 + nsplit / 64 workgroups of launch 4 to arrive adds them to the Horner result and writes the verdict -- no finish launch (option narrow_fused_finish)
+    // (same-box A/B, profiles/r06/fused_finish_ab.txt: 64 threads +5 %, 256 threads +3 %, tickets and 16 threads unchanged, ONE proof per chain -2.5 % -- the
+    // finisher's three additions then follow the Horner wavefront instead of overlapping with the launch of the next kernel: chains of >= 8 proofs only)
+    const bool fused_finish = narrow_walk && c->narrow_fused_finish && nbatch >= 8 && !d_msm_out && nsplit / FB_BLOCK <= 4 && !(quad || horner_aside);
     if (horner_aside) {
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<4>, nblk_p * nsplit, FB_BLOCK, 0u, d.chunk_first, d.part, d_colc, d.hq, prm, nb32, nblk_p,
-               nsplit, npairs, d_ids, d_digits, gen_table, d_partial, 0u);
+               nsplit, npairs, d_ids, d_digits, gen_table, d_partial, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint8_t *)nullptr, rp_seg_tab{});
         HIPCHK(c, hipStreamWaitEvent(s, c->join_ev, 0));
     } else if (quad && one_lane) {
         const uint32_t n_hw = (nb32 + FB_BLOCK - 1) / FB_BLOCK;
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<1>, n_hw + nblk_p * nsplit, FB_BLOCK, n_hw, d.chunk_first, d.part, d_colc, d.hq, prm, nb32, nblk_p,
-               nsplit, npairs, d_ids, d_digits, gen_table, d_partial, 0u);
+               nsplit, npairs, d_ids, d_digits, gen_table, d_partial, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint8_t *)nullptr, rp_seg_tab{});
     } else if (quad) {
         const uint32_t n_hw = (nb32 + 15) / 16;
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<4>, n_hw + nblk_p * nsplit, FB_BLOCK, n_hw, d.chunk_first, d.part, d_colc, d.hq, prm, nb32, nblk_p,
-               nsplit, npairs, d_ids, d_digits, gen_table, d_partial, 0u);
+               nsplit, npairs, d_ids, d_digits, gen_table, d_partial, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint8_t *)nullptr, rp_seg_tab{});
     } else if (narrow_walk) {   // lane = split: a proof's partial sums are folded inside launch 4 (k_rp34.hip: rp_walk_narrow)
         nparts = nsplit / FB_BLOCK;
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<64>, nb32 + nb32 * nparts, FB_BLOCK, nb32, d.chunk_first, d.part, (const ge_cached *)nullptr, d.hq,
-               prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, gen_table, d_partial, hi ? 3u : 1u);
+               prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, gen_table, d_partial, (hi ? 3u : 1u) | (fused_finish ? 4u : 0u), c->fin_cnt, d_status,
+               (uint8_t *)d_verdict, segtab);
     } else {
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<64>, nb32 + nblk_p * nsplit, FB_BLOCK, nb32, d.chunk_first, d.part, (const ge_cached *)nullptr, d.hq,
-               prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, gen_table, d_partial, 0u);
+               prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, gen_table, d_partial, 0u, (uint32_t *)nullptr, (uint32_t *)nullptr, (uint8_t *)nullptr, rp_seg_tab{});
+    }
+    if (fused_finish) {   // (the last workgroup of every proof has written its verdict and zeroed its status word)
+        HIPCHK(c, hipGetLastError());
+        c->rp_status_dirty = false;
+        return BPGPU_OK;
     }
     ge_ext *d_red = nullptr;
     uint32_t nred = 0;

@@ -56,7 +56,7 @@ __global__ void k_rp_horner_wide(uint32_t nproofs, const ge_cached *colc, const 
 template <bool R5>
 __global__ void k_vb_window_wide(uint32_t nthreads, uint32_t U, uint32_t k0, const ge_cached *tab, const uint32_t *recoded, ge_cached *colc);
 template <int HL>
-__global__ void k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge_ext *part, const ge_cached *colc, ge_ext *hq, fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit, uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial, uint32_t walk_form);
+__global__ void k_rp_stage4(uint32_t n_hw, const uint32_t *chunk_first, const ge_ext *part, const ge_cached *colc, ge_ext *hq, fb_params prm, uint32_t nproofs, uint32_t nblk_p, uint32_t nsplit, uint32_t npairs, const uint32_t *gen_ids, const fb_digit *digits, const fb_entry *table, ge_ext *partial, uint32_t walk_form, uint32_t *fin_cnt, uint32_t *status, uint8_t *verdict, rp_seg_tab segs);
 __global__ void k_rlc_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, const uint32_t *status, unsigned long long *acc, int uniform);
 __global__ void k_rlc_colsum_scalars(uint32_t n_red, uint32_t nthreads, uint32_t rows_in, uint32_t group, const ge_ext *in, ge_ext *out, uint32_t n_rows, const unsigned long long *acc, fb_digit *digits, fb_params prm, uint32_t *ctl, uint32_t rows_out);
 template <bool WITH_OUT>

@@ -109,6 +109,8 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
  *   "narrow_walk"           1 (default): the table walk with lane = split, a proof's partial sums folded inside launch 4 (finish 40 -> 5 us)
  *   "narrow_hi_max"         chains of up to this many proofs (default 32; 0: never) give every per-proof point a second table, of its
  *                           2^128 multiple (a wavefront per point, beside the transcript), and run a 32-window Horner chain
+ *   "narrow_fused_finish"   1 (default): verdict-only calls, chains of 8 .. 256 proofs: the last workgroup of a proof in launch 4 adds up its pieces
+ *                           and writes the verdict (no finish launch); 0: k_finish1
  *   "msm_fork"              1 (default): bpgpu_msm_batch_shared's generator half on the context's second stream beside the per-MSM points; 0: one stream
  *   "bucket_chain"          0 (default): MSMs of up to 6144 variable-base terms take the fused bucket chain (csrc/bucket2.h: decode, one LDS
  *                           sort + accumulate workgroup per (MSM, window), one tail launch); 1: bucket.h's chain everywhere (for A/B)

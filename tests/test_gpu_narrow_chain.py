@@ -1,5 +1,5 @@
 """The narrow chain's round-6 forms (chains of up to 256 proofs; csrc/k_rp1.hip k_rp_stage1_coop, k_rp34.hip): every option that selects
-one -- coop_split, exp_single, narrow_chunk, narrow_walk, narrow_hi_max -- flipped on its own and all together, against the default
+one -- coop_split, exp_single, narrow_chunk, narrow_walk, narrow_hi_max, narrow_fused_finish -- flipped on its own and all together, against the default
 build of the chain AND the oracle: verdicts, mega-check encodings and advanced transcripts must be bit-identical whatever the form
 (src/range_proof/mod.rs:345-452 is one function; how the device cuts it into lanes is nobody's business but ours)."""
 import hashlib
@@ -20,6 +20,8 @@ FORMS = [
     {"narrow_hi_max": 256},
     {"narrow_hi_max": 256, "narrow_chunk": 5},
     {"coop_split": 0, "narrow_hi_max": 256},   # (second tables need the split launch 1: falls back to 64 windows)
+    {"narrow_fused_finish": 0},
+    {"narrow_fused_finish": 0, "narrow_hi_max": 0},
 ]
 
 
@@ -59,6 +61,12 @@ def test_every_form_on_golden_shapes_and_ragged_widths(contexts, oracle, oracle_
             for i, r in enumerate(res[1:]):
                 assert r == res[0], (n, m, nb, FORMS[i + 1])
             assert list(res[0][0]) == [[0, 1, 2, 1, 1, 0][i % 6] for i in range(nb)]
+            # verdicts only (the crate's call: the last workgroup of a proof in launch 4 finishes it), twice in a row on every context
+            for rep in range(2):
+                for i, c in enumerate(contexts):
+                    v = c.rangeproof_verify_batch(n, m, proofs, len(pr), coms, label, rng)
+                    v = v[0] if isinstance(v, tuple) else v
+                    assert bytes(v) == bytes(res[0][0]), (n, m, nb, rep, FORMS[i])
             if nb == 2:
                 rc, enc = oracle.verify(oracle_gens_64_8, bytes(bad), vc[:32 * m], n, label, rng[64:128])[:2]
                 assert rc == 1 and enc == res[-2][1][32:64]
