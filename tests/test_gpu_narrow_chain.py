@@ -111,3 +111,42 @@ def test_every_form_with_caller_transcripts_and_the_bench_shape(contexts, oracle
     for i in range(nb):   # the advanced transcripts are the oracle's
         rc, _, ts = oracle.verify_ts(oracle_gens_64_8, proofs[pl * i:pl * (i + 1)], coms[32 * m * i:32 * m * (i + 1)], n, states[i], rng[64 * i:64 * i + 64])
         assert rc == res[0][0][i] and ts == res[0][2][208 * i:208 * (i + 1)]
+
+
+@pytest.mark.parametrize("fixture,party", [("cfg3_n64_m16", 16), ("cfg4_n64_m32", 32)])
+def test_aggregated_shapes_in_narrow_chains(oracle, fixture, party):
+    """BASELINE configs 3 and 4 (m = 16 / 32: U = 40 / 58 per-proof points, k = 10 / 11 rounds) as NARROW chains -- a service's single
+    aggregated proof per call -- in round 5's form, the rebuilt form without and with second tables: all equal, and equal to the oracle."""
+    import bulletproofs_amd as bp
+    from bulletproofs_amd import workload as wl
+    fx = wl.load_fixture(fixture)
+    forms = [FORMS[0], {"narrow_hi_max": 0}, {"narrow_hi_max": 256}, {"narrow_hi_max": 256, "narrow_fused_finish": 0, "narrow_chunk": 5}]
+    ctxs = []
+    for f in forms:
+        c = bp.Context(0)
+        c.set_option("fixed_window_bits", 12)    # (small tables: this test is about the chain's form)
+        for k, v in f.items():
+            c.set_option(k, v)
+        c.gens_create(64, party)
+        ctxs.append(c)
+    g = oracle.Gens(64, party)
+    try:
+        for nb in (1, 3, 9):
+            proofs, coms = wl.tile_batch(fx, nb, first=1)
+            pb = bytearray(proofs)
+            if nb > 1:
+                pb[(nb - 1) * fx.proof_len + 128] ^= 1     # the last one fails its check
+            proofs = bytes(pb)
+            rng = hashlib.shake_256(b"narrow-agg-%d-%d" % (party, nb)).digest(64 * nb)
+            res = [c.rangeproof_verify_batch(fx.n, fx.m, proofs, fx.proof_len, coms, fx.label, rng, want_msm=True) for c in ctxs]
+            for i, r in enumerate(res[1:]):
+                assert r == res[0], (fixture, nb, forms[i + 1])
+            _, ev, em = oracle.verify_batch(g, proofs, coms, fx.m, fx.n, fx.label, rng, threads=4)
+            assert res[0][0] == ev and res[0][1] == em
+            assert list(ev) == [0] * (nb - 1) + [1 if nb > 1 else 0]
+            for c in ctxs:   # verdicts only
+                v = c.rangeproof_verify_batch(fx.n, fx.m, proofs, fx.proof_len, coms, fx.label, rng)
+                assert bytes(v) == bytes(ev)
+    finally:
+        for c in ctxs:
+            c.close()
