@@ -609,6 +609,44 @@ def drop_in_call_shape(long_run, local_dev=0):
     return out
 
 
+def bench_msm_small(local_dev):
+    """The boundary function itself at the reference's own MSM size (SURVEY 8a6: optional_multiscalar_mul for ONE 64-bit single proof, N = 147;
+    mod.rs:421): one blocking bpgpu_msm_batch call per MSM from one thread, host pointers in and out; points = party-0 generators of a (128, 1)
+    set (valid encodings derived on the device), scalars = SHAKE256 mod l.  Latency only -- parity of this path is tests/test_gpu_msm.py's
+    business (bit-exact vs the oracle incl. the golden sizes).  Informational (`extra`)."""
+    import hashlib
+    import bulletproofs_amd as bp
+    L = 2**252 + 27742317777372353535851937790883648493
+    hc = bp.Context(local_dev, fixed_window_bits=2)
+    hc.gens_create(128, 1)
+    G, H, _, _ = hc.gens_export()
+    pts = (G + H)
+    out = {"note": "one blocking bpgpu_msm_batch call, one MSM of N variable-base terms (no tables), p50 of 300 calls after 30; narrow form (msm_narrow, DESIGN 3.5) vs the batch form"}
+    for n in (29, 147, 542):
+        S = b"".join((int.from_bytes(hashlib.shake_256(b"msm-small-%d-%d" % (n, i)).digest(64), "little") % L).to_bytes(32, "little") for i in range(n))
+        P = (pts * ((n + 255) // 256))[:32 * n]
+        row = {}
+        ref = None
+        for form in (1, 0):
+            hc.set_option("msm_narrow", form)
+            for _ in range(30):
+                res = hc.msm_batch([n], S, P)
+            if ref is None:
+                ref = res
+            elif res != ref:
+                raise SystemExit("bpgpu_msm_batch: the narrow and the batch form disagree -- result invalid")
+            ts = []
+            for _ in range(300):
+                t0 = time.perf_counter()
+                hc.msm_batch([n], S, P)
+                ts.append(time.perf_counter() - t0)
+            ts.sort()
+            row["ms_p50" if form else "ms_p50_batch_form"] = round(ts[150] * 1e3, 3)
+        out["n_%d" % n] = row
+    hc.close()
+    return out
+
+
 def bench_cfg5_shape(a, local_dev, steps=96, nstreams=16):
     """BASELINE config 5's MSM shape: N = 6179 = 4098 generator terms (tables) + 2081 per-MSM points, batches of 64 MSMs, inputs resident in
     HBM, through the library's pool: bpgpu_pool_msm_batch_shared_submit_dev issues every batch as one launch chain on the next of the pool's
@@ -979,6 +1017,12 @@ def main():
             raise
         except Exception as e:
             extra["cfg5_shape"] = {"error": str(e)}
+        try:
+            extra["msm_small_single_call"] = bench_msm_small(local_dev)
+        except SystemExit:
+            raise
+        except Exception as e:
+            extra["msm_small_single_call"] = {"error": str(e)}
 
     if want_extra and a.config == "cfg2" and not a.batch:
         # (4) the prover side: bpgpu_rangeproof_prove_batch, batches of 1024 single 64-bit proofs from host memory on

@@ -98,6 +98,7 @@ struct bpgpu_ctx {
     int narrow_walk = 1;                                            // narrow chains: the table walk with lane = split and the partial sums folded in launch 4 (k_rp34.hip rp_walk_narrow); 0: thread = proof
     int narrow_hi_max = 32;                                         // chains of up to this many proofs give every per-proof point a second table (2^128 P) and run a 32-window Horner chain; 0: never
     int narrow_fused_finish = 1;                                    // narrow chains, verdicts only: the last workgroup of a proof in launch 4 finishes it (no finish launch)
+    int msm_narrow = 1;                                             // bpgpu_msm_batch with <= 16 MSMs of <= 768 terms in all: second tables, ~sqrt(N) chunks, one tail launch (k_vb_*_hi / k_vb_tail_narrow)
     int coop_split = 1;                                             // narrow chains, per-proof check: the k + 1 inversions on k + 1 lanes of the group at once, the basepoint coefficients as a
                                                                     // role of launch 3 (rangeproof.h rp_split_invert_lane / rp_rows_thread); 0: the leader does it all (A/B: profiles/r06/coop_split_ab.txt)
     int transcript_coop = 1;                                        // chains of up to 256 proofs replay their transcripts 32 lanes per proof (keccak.h): one call of 1 / 8 / 64 / 256 proofs 0.62 -> 0.53 / 0.56 / 0.57 / 0.58 ms; 0: lane = proof everywhere
@@ -523,6 +524,10 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
     }
     if (!strcmp(key, "narrow_fused_finish")) {
         c->narrow_fused_finish = value != 0;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "msm_narrow")) {
+        c->msm_narrow = value != 0;
         return BPGPU_OK;
     }
     if (!strcmp(key, "narrow_walk")) {
@@ -1003,12 +1008,12 @@ struct vb_dev {
     uint32_t *colq16;   // [msm][64][4][8 words]: column sums as 16-bit limbs for the wavefront Horner
     ge_ext *hq;         // [msm] Horner results
 };
-static void plan_vb(arena_plan &ap, const vb_plan &pl, size_t nbatch, size_t off[7]) {
+static void plan_vb(arena_plan &ap, const vb_plan &pl, size_t nbatch, size_t off[7], size_t tab_entries = 8) {
     off[0] = ap.add(pl.chunks.size() * sizeof(vb_chunk) + 16);
     off[1] = ap.add((nbatch + 1) * 4);
     off[2] = ap.add((size_t)pl.total * 4 + 16);
     off[3] = ap.add((size_t)pl.total * 32 + 16);
-    off[4] = ap.add((size_t)pl.total * 8 * sizeof(ge_cached) + 16);
+    off[4] = ap.add((size_t)pl.total * tab_entries * sizeof(ge_cached) + 16);
     off[5] = ap.add(pl.chunks.size() * 64 * sizeof(ge_ext) + 16);
     off[6] = ap.add(nbatch * 64 * sizeof(ge_cached) + nbatch * sizeof(ge_ext) + 64);   // colq16 (128 B) or colc (160 B) per column, then hq
 }
@@ -1039,7 +1044,7 @@ static int vb_launch(bpgpu_ctx *c, hipStream_t s, uint32_t total, uint32_t n_chu
 }
 // ragged plans: upload the decomposition into the arena every call
 static int enqueue_vb(bpgpu_ctx *c, hipStream_t s, const vb_plan &pl, size_t nbatch, const size_t off[7],
-                      const uint32_t *d_scalars, const uint32_t *d_points, uint32_t *d_status, vb_dev &d) {
+                      const uint32_t *d_scalars, const uint32_t *d_points, uint32_t *d_status, vb_dev &d, bool upload_only = false) {
     vb_bind(c, off, d);
     // the plan is a local of the caller: stage it in pinned memory, which outlives the asynchronous copies
     const size_t b0 = pl.chunks.size() * sizeof(vb_chunk), b1 = (size_t)pl.total * 4, b2 = (nbatch + 1) * 4;
@@ -1055,6 +1060,7 @@ static int enqueue_vb(bpgpu_ctx *c, hipStream_t s, const vb_plan &pl, size_t nba
     }
     memcpy(h2, pl.chunk_first.data(), b2);
     HIPCHK(c, hipMemcpyAsync(d.chunk_first, h2, b2, hipMemcpyHostToDevice, s));
+    if (upload_only) return BPGPU_OK;
     return vb_launch(c, s, pl.total, (uint32_t)pl.chunks.size(), nbatch, d_scalars, d_points, d_status, d);
 }
 // uniform plans (every MSM of the batch has `per` variable-base terms): decomposition cached on the device
@@ -1350,17 +1356,43 @@ static int msm_batch_dev_locked(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_t
             return BPGPU_OK;
         }
     }
+    // a few small MSMs (the boundary function called from one thread: nothing else to fill the device with): the narrow form -- second
+    // tables, chunks of ~sqrt(N) terms, one tail launch (k_msm.hip: k_vb_prepare_hi / k_vb_window_hi / k_vb_tail_narrow)
+    uint64_t tot_terms = 0, max_terms = 0;
+    for (size_t b = 0; b < nbatch; b++) {
+        tot_terms += n_terms[b];
+        if (n_terms[b] > max_terms) max_terms = n_terms[b];
+    }
+    const bool narrow = c->msm_narrow && nbatch <= 16 && tot_terms > 0 && tot_terms <= 768;   // (same-box A/B, profiles/r06/msm_narrow_ab.txt: 29 / 147 / 542 terms 0.44 / 0.475 / 0.52 -> 0.33 / 0.38 / 0.465 ms per blocking call; 1024 terms 0.56 -> 0.59: the wavefront-per-term role then needs a second round)
+    uint32_t chunk = BP_VB_CHUNK;
+    if (narrow) {
+        chunk = 4;
+        while ((uint64_t)chunk * chunk < max_terms && chunk < BP_VB_CHUNK) chunk++;
+    }
     vb_plan pl;
-    make_vb_plan(pl, nbatch, n_terms);
+    make_vb_plan(pl, nbatch, n_terms, chunk);
     arena_plan ap;
     size_t off[7];
-    plan_vb(ap, pl, nbatch, off);
+    plan_vb(ap, pl, nbatch, off, narrow ? 16 : 8);
     const size_t off_status = ap.add(nbatch * 4);
     int rc = arena_reserve(c, ap.total);
     if (rc) return rc;
     uint32_t *d_status = (uint32_t *)(c->arena + off_status);
     HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
     vb_dev d;
+    if (narrow) {
+        rc = enqueue_vb(c, s, pl, nbatch, off, (const uint32_t *)d_scalars, (const uint32_t *)d_points, d_status, d, true);
+        if (rc) return rc;
+        const uint32_t total = pl.total, n_lb = (total + BP_BLOCK - 1) / BP_BLOCK, nt = (uint32_t)pl.chunks.size() * 64;
+        ge_cached *tab_hi = d.tab + (size_t)8 * total;
+        LAUNCH(c, s, "vb_prepare", k_vb_prepare_hi, n_lb + total, BP_BLOCK, total, n_lb, d.chunks, d.term_chunk, (const uint32_t *)d_scalars, (const uint32_t *)d_points,
+               d.tab, d.recoded, d_status, tab_hi);
+        LAUNCH(c, s, "vb_window", k_vb_window_hi, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, d.chunks, d.tab, d.recoded, d.part, (const ge_cached *)tab_hi);
+        LAUNCH(c, s, "vb_tail", k_vb_tail_narrow, (uint32_t)nbatch, 64, (uint32_t)nbatch, d.chunk_first, d.part, (const uint32_t *)d_status, (uint32_t *)d_out,
+               (uint8_t *)d_status_bytes);
+        HIPCHK(c, hipGetLastError());
+        return BPGPU_OK;
+    }
     rc = enqueue_vb(c, s, pl, nbatch, off, (const uint32_t *)d_scalars, (const uint32_t *)d_points, d_status, d);
     if (rc) return rc;
     LAUNCH(c, s, "vb_horner", k_vb_horner, ((uint32_t)nbatch + 63) / 64, 64, (uint32_t)nbatch, d.hq, d_status, (uint32_t *)d_out);

@@ -17,6 +17,50 @@ __global__ void __launch_bounds__(BP_BLOCK) k_vb_window(uint32_t nthreads, const
     if (tid < nthreads) vb_window_thread(tid, chunks, tab, recoded, part);
 }
 
+// ---- a FEW small MSMs per call (option msm_narrow; <= 16 MSMs, <= 768 terms: optional_multiscalar_mul in its Straus-size regime, mod.rs:421,
+// ipp.rs:308, one call from one thread): three launches instead of six, the playbook of the narrow range-proof chain --
+//   1  lane = term: decode + 8-entry table (vb_prepare_thread)  ||  one WAVEFRONT per term: wavefront-cooperative decode, 128 cooperative
+//      doublings, the table of Q = 2^128 P (hw_ristretto_decode, hw_shift_table8)
+//   2  window sums in chunks of ~sqrt(N) terms; windows 32 .. 63 select from Q's tables
+//   3  one wavefront per MSM: adds the chunks' rows, folds window w + 32 into window w, a 32-window Horner chain (124 dependent doublings
+//      instead of 252), then the encoding with its inverse square root as a wavefront chain, the status byte
+__global__ void __launch_bounds__(BP_BLOCK) k_vb_prepare_hi(uint32_t total, uint32_t n_lane_blocks, const vb_chunk *chunks, const uint32_t *term_chunk,
+                                                             const uint32_t *scalars, const uint32_t *points, ge_cached *tab, uint32_t *recoded,
+                                                             uint32_t *status, ge_cached *tab_hi) {
+    if (blockIdx.x < n_lane_blocks) {
+        const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+        if (t < total) vb_prepare_thread(t, chunks, term_chunk, scalars, points, tab, recoded, status);
+    } else {
+        const uint32_t t = blockIdx.x - n_lane_blocks;
+        uint32_t pw[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) pw[i] = points[8 * (uint64_t)t + i];
+        ge_ext pt;
+        hw_ristretto_decode(pt, pw);   // (an undecodable point is reported by the lane role; its tables are never used)
+        hw_shift_table8(pt, 128, tab_hi + 8 * (uint64_t)t);
+    }
+}
+__global__ void __launch_bounds__(BP_BLOCK) k_vb_window_hi(uint32_t nthreads, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part,
+                                                            const ge_cached *tab_hi) {
+    const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
+    if (tid < nthreads) vb_window_thread(tid, chunks, tab, recoded, part, nullptr, nullptr, tab_hi);
+}
+__global__ void __launch_bounds__(64) k_vb_tail_narrow(uint32_t nbatch, const uint32_t *chunk_first, const ge_ext *part, const uint32_t *status, uint32_t *out_words,
+                                                        uint8_t *status_bytes) {
+    __shared__ ge_ext s_fin;
+    __shared__ fe s_tin, s_raw;
+    __shared__ __attribute__((aligned(16))) uint32_t s_tw[8];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hw[128];
+    const uint32_t b = blockIdx.x;
+    hw_colsum_horner_msm(b, chunk_first, part, &s_fin, true);
+    __syncthreads();
+    if (threadIdx.x == 0) bk2_tail_t4a(&s_fin, &s_tin, s_tw);
+    __syncthreads();
+    hw_invsqrt_raw_fe((const uint16_t *)s_tw, s_hw, &s_raw);
+    __syncthreads();
+    if (threadIdx.x == 0) bk2_tail_t4b(b, &s_fin, &s_raw, &s_tin, status, out_words, nullptr, status_bytes);
+}
+
 // the window-sum role of launch 3 as a launch of its own (experiment "split_stage3": its own register budget -- 128 VGPRs, four
 // wavefronts per SIMD -- instead of the 252 of the role-fused kernel, whose generator-exponent role sets the allocation)
 __global__ void __launch_bounds__(BP_BLOCK) k_vb_window_colc(uint32_t nthreads, const vb_chunk *chunks, const ge_cached *tab,

@@ -111,6 +111,9 @@ const char *bpgpu_last_error(bpgpu_ctx *ctx);
  *                           2^128 multiple (a wavefront per point, beside the transcript), and run a 32-window Horner chain
  *   "narrow_fused_finish"   1 (default): verdict-only calls, chains of 8 .. 256 proofs: the last workgroup of a proof in launch 4 adds up its pieces
  *                           and writes the verdict (no finish launch); 0: k_finish1
+ *   "msm_narrow"            1 (default): bpgpu_msm_batch with at most 16 MSMs of at most 768 terms in all (the boundary function called from one
+ *                           thread with a Straus-size MSM) runs three launches: decode beside a wavefront per term that builds the table of
+ *                           2^128 P, window sums in ~sqrt(N) chunks, one tail (32-window Horner chain + encoding); 0: the batch form
  *   "msm_fork"              1 (default): bpgpu_msm_batch_shared's generator half on the context's second stream beside the per-MSM points; 0: one stream
  *   "bucket_chain"          0 (default): MSMs of up to 6144 variable-base terms take the fused bucket chain (csrc/bucket2.h: decode, one LDS
  *                           sort + accumulate workgroup per (MSM, window), one tail launch); 1: bucket.h's chain everywhere (for A/B)

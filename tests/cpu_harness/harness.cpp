@@ -137,6 +137,45 @@ void h_msm_vb(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, 
     memcpy(out, outw.data(), (size_t)nbatch * 32);
     for (uint32_t b = 0; b < nbatch; b++) status_out[b] = (uint8_t)status[b];
 }
+// The narrow form of the same pipeline (k_vb_prepare_hi / k_vb_window_hi / k_vb_tail_narrow: a few small MSMs per call): chunks of `chunk` terms,
+// second tables of the 2^128 multiples from the wavefront-cooperative decode + doublings, 32-window chain, encoding through the split
+// inverse-square-root (lane 0 front / wavefront chain / lane 0 back).
+void h_msm_vb_narrow(uint32_t nbatch, const uint32_t *n_terms, uint32_t chunk, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status_out) {
+    std::vector<vb_chunk> chunks; std::vector<uint32_t> chunk_first(nbatch + 1), term_chunk;
+    uint32_t t0 = 0;
+    for (uint32_t b = 0; b < nbatch; b++) {
+        chunk_first[b] = (uint32_t)chunks.size();
+        for (uint32_t k = 0; k < n_terms[b]; k += chunk) {
+            vb_chunk c; c.msm = b; c.first = t0 + k; c.count = n_terms[b] - k < chunk ? n_terms[b] - k : chunk; c.pad = 0;
+            for (uint32_t i = 0; i < c.count; i++) term_chunk.push_back((uint32_t)chunks.size());
+            chunks.push_back(c);
+        }
+        t0 += n_terms[b];
+    }
+    chunk_first[nbatch] = (uint32_t)chunks.size();
+    const uint32_t total = t0;
+    std::vector<ge_cached> tab((size_t)total * 8 + 1), tab_hi((size_t)total * 8 + 1);
+    std::vector<uint32_t> rec((size_t)total * 8 + 1), status(nbatch + 1, 0), outw((size_t)nbatch * 8 + 1);
+    std::vector<ge_ext> part(chunks.size() * 64 + 1);
+    for (uint32_t t = 0; t < total; t++)
+        vb_prepare_thread(t, chunks.data(), term_chunk.data(), (const uint32_t *)scalars, (const uint32_t *)points, tab.data(), rec.data(), status.data());
+    for (uint32_t t = 0; t < total; t++) {
+        ge_ext pt;
+        hw_ristretto_decode(pt, (const uint32_t *)points + 8 * (size_t)t);
+        hw_shift_table8(pt, 128, tab_hi.data() + 8 * (size_t)t);
+    }
+    for (uint32_t tid = 0; tid < chunks.size() * 64; tid++) vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data(), nullptr, nullptr, tab_hi.data());
+    std::vector<uint8_t> sb(nbatch + 1);
+    for (uint32_t b = 0; b < nbatch; b++) {
+        ge_ext fin; fe tin, raw; uint32_t tw[8];
+        hw_colsum_horner_msm(b, chunk_first.data(), part.data(), &fin, true);
+        bk2_tail_t4a(&fin, &tin, tw);
+        hw_invsqrt_raw_fe((const uint16_t *)tw, nullptr, &raw);
+        bk2_tail_t4b(b, &fin, &raw, &tin, status.data(), outw.data(), nullptr, sb.data());
+    }
+    memcpy(out, outw.data(), (size_t)nbatch * 32);
+    for (uint32_t b = 0; b < nbatch; b++) status_out[b] = sb[b];
+}
 // Emulates the shared-generator pipeline (table build, recode, split accumulation, finish).
 // gens: n_gens_loaded compressed points in table order; gen_ids: n_gen_terms ids (the (n,m) subset).
 int h_msm_shared(uint32_t W, uint32_t nsplit, uint32_t n_gens_loaded, const uint8_t *gens, uint32_t n_gen_terms, const uint32_t *gen_ids,

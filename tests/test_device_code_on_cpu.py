@@ -160,6 +160,35 @@ def test_variable_base_pipeline_lane_by_lane(H, oracle):
     assert st.raw[0] == 2
 
 
+def test_variable_base_pipeline_narrow_form_lane_by_lane(H, oracle):
+    """The narrow form of the small-MSM pipeline (option msm_narrow: k_vb_prepare_hi / k_vb_window_hi / k_vb_tail_narrow): chunks of ~sqrt(N)
+    terms, second tables of the points' 2^128 multiples (wavefront-cooperative decode + 128 cooperative doublings + the cooperative table),
+    32-window chain, encoding through the split inverse square root -- lane for lane on the host, against the oracle."""
+    sizes = [0, 1, 2, 31, 33, 70]
+    S = P = b""
+    for k, n in enumerate(sizes):
+        S += b"".join(_sc(b"n%d-s%d" % (k, i)) for i in range(n))
+        P += b"".join(_pt(oracle, b"n%d-p%d" % (k, i)) for i in range(n))
+    nt = (C.c_uint32 * len(sizes))(*sizes)
+    out, st = C.create_string_buffer(32 * len(sizes)), C.create_string_buffer(len(sizes))
+    for chunk in (4, 9, 32):
+        H.h_msm_vb_narrow(len(sizes), nt, chunk, S, P, out, st)
+        off = 0
+        for k, n in enumerate(sizes):
+            assert st.raw[k] == 0 and out.raw[32 * k:32 * k + 32] == oracle.msm(S[off:off + 32 * n], P[off:off + 32 * n])[1], (chunk, k)
+            off += 32 * n
+    sp = [0, 1, T.L - 1, 8, int("8" * 63, 16) % T.L, 2**252, 2**128, 2**128 - 1, (2**124 - 1) << 128]
+    s = b"".join(x.to_bytes(32, "little") for x in sp)
+    p = b"".join(_pt(oracle, b"nsp%d" % i) for i in range(len(sp)))
+    nt = (C.c_uint32 * 1)(len(sp))
+    H.h_msm_vb_narrow(1, nt, 4, s, p, out, st)
+    assert out.raw[:32] == oracle.msm(s, p)[1] and st.raw[0] == 0
+    bad = bytearray(p)
+    bad[0] |= 1
+    H.h_msm_vb_narrow(1, nt, 4, s, bytes(bad), out, st)
+    assert st.raw[0] == 1 and out.raw[:32] == bytes(32)
+
+
 @pytest.mark.parametrize("n,m", [(8, 1), (8, 2), (16, 4)])
 def test_batched_rangeproof_prover_lane_by_lane(H, oracle, n, m):
     """rp_prover.h: RangeProof::prove_multiple_with_rng (mod.rs:234-288; party.rs, dealer.rs) with every commitment as a

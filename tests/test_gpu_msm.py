@@ -326,3 +326,49 @@ def test_fused_bucket_chain_options_all_give_the_oracle_encoding(oracle, nb):
             assert st == bytes(nb) and out == base, (key, v)
         c.set_option(key, before if key != "fb_walk_waves" else 0)
     c.close()
+
+
+def test_few_small_msms_take_the_narrow_form_and_agree_with_the_batch_form_and_the_oracle(oracle):
+    """Option msm_narrow (round 6; csrc/k_msm.hip k_vb_prepare_hi / k_vb_window_hi / k_vb_tail_narrow): at most 16 MSMs of at most 768 terms
+    in all -- optional_multiscalar_mul called from one thread with a Straus-size MSM (src/range_proof/mod.rs:421, inner_product_proof.rs:308) --
+    run with second tables of the points' 2^128 multiples and a 32-window chain.  Same encodings and status bytes as the batch form and the
+    oracle: the reference's golden MSM sizes, ragged batches with empty MSMs, edge scalars (hi or lo half zero, l - 1), undecodable points,
+    non-canonical scalars."""
+    import bulletproofs_amd as bp
+    a, b = bp.Context(0), bp.Context(0)
+    a.set_option("msm_narrow", 0)
+    b.set_option("msm_narrow", 1)
+    L = 2**252 + 27742317777372353535851937790883648493
+    try:
+        for k, sizes in enumerate([[147], [29], [1], [768], [1024], [81, 0, 148], [48] * 16, [0], [0, 0, 3], [542, 220], [1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15, 16]]):
+            S, P = b"", b""
+            for j, n in enumerate(sizes):
+                s, p = _rand_msm(oracle, b"nm%d-%d" % (k, j), n)
+                S += s
+                P += p
+            ra, rb = a.msm_batch(sizes, S, P), b.msm_batch(sizes, S, P)
+            assert ra == rb, sizes
+            off = 0
+            for j, n in enumerate(sizes):
+                exp = oracle.msm(S[off:off + 32 * n], P[off:off + 32 * n])
+                off += 32 * n
+                assert rb[1][j] == 0 and rb[0][32 * j:32 * j + 32] == exp[1], (sizes, j)
+        sp = [0, 1, L - 1, 8, int("8" * 63, 16) % L, 2**252, 7, 2**128, 2**128 - 1, (2**124 - 1) << 128, 2**252 + 1]
+        s = b"".join(x.to_bytes(32, "little") for x in sp)
+        p = _points(oracle, b"nedge", len(sp))
+        ra, rb = a.msm_batch([len(sp)], s, p), b.msm_batch([len(sp)], s, p)
+        assert ra == rb and rb[1][0] == 0 and rb[0] == oracle.msm(s, p)[1]
+        # P - P: the identity's all-zero encoding; then an undecodable point and a non-canonical scalar: status bytes 1 / 2, zero encodings
+        one, m1 = (1).to_bytes(32, "little"), (L - 1).to_bytes(32, "little")
+        assert b.msm_batch([2], one + m1, p[:32] * 2) == (bytes(32), bytes(1))
+        bad_pt = bytes([p[0] | 1]) + p[1:32]
+        sizes = [3, 2, 4]
+        S = s[:32 * 9]
+        P = p[:64] + bad_pt + p[96:32 * 9]
+        S2 = S[:32 * 3] + (L).to_bytes(32, "little") + S[32 * 4:]
+        for SS, PP in ((S, P), (S2, p[:32 * 9])):
+            ra, rb = a.msm_batch(sizes, SS, PP), b.msm_batch(sizes, SS, PP)
+            assert ra == rb and list(rb[1]).count(0) == 2
+    finally:
+        a.close()
+        b.close()
