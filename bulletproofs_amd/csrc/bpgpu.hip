@@ -1535,8 +1535,50 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
     const bool fused = use_bucket && !ct && bucket2_applies(c, bkp, n_unique);
     if (fused) plan_bucket2(ap, nbatch, nbatch * n_unique, boff);
     else if (use_bucket) plan_bucket(ap, nbatch, nbatch * n_unique, bkp, boff);
-    else plan_vb_uniform(ap, nbatch, n_unique, off);
+    // a few MSMs with a few points of their own (the mega-check of ONE proof as the caller's own MSM call: 130 generator terms + 17 points): the
+    // narrow form -- second tables, ~sqrt chunks, the generator half as one launch with the recoding in registers, one tail launch
+    const bool narrow_sh = c->msm_narrow && !ct && !use_bucket && n_unique > 0 && nbatch <= 16 && nbatch * n_unique <= 768;
+    uint32_t sh_chunk = BP_VB_CHUNK;
+    if (narrow_sh) {
+        sh_chunk = 4;
+        while ((size_t)sh_chunk * sh_chunk < n_unique && sh_chunk < BP_VB_CHUNK) sh_chunk++;
+    }
+    if (!fused && !use_bucket) plan_vb_uniform(ap, nbatch, n_unique, off, narrow_sh ? 16 : 8, sh_chunk);
     const size_t off_status = ap.add(nbatch * 4);
+    if (narrow_sh) {
+        const uint32_t nwg = fb_walk_parts(c, nbatch, n_gen_terms);
+        const size_t off_part = ap.add((size_t)nwg * nbatch * sizeof(ge_ext) + 16);
+        rc = arena_reserve(c, ap.total);
+        if (rc) return rc;
+        uint32_t *d_status = (uint32_t *)(c->arena + off_status);
+        ge_ext *d_part = (ge_ext *)(c->arena + off_part);
+        HIPCHK(c, hipMemsetAsync(d_status, 0, nbatch * 4, s));
+        hipStream_t s2 = c->msm_fork ? c->stream2 : s;
+        if (s2 != s) {
+            HIPCHK(c, hipEventRecord(c->fork_ev, s));
+            HIPCHK(c, hipStreamWaitEvent(s2, c->fork_ev, 0));
+        }
+        enqueue_fb_walk(c, s2, prm, nbatch, n_gen_terms, nwg, (const uint32_t *)d_gen_scalars, d_ids, d_part, d_status);
+        if (s2 != s) HIPCHK(c, hipEventRecord(c->join_ev, s2));
+        bpgpu_ctx::plan_view pv;
+        rc = uniform_plan(c, nbatch, n_unique, &pv, sh_chunk);
+        if (rc) return rc;
+        vb_dev d{};
+        vb_bind(c, off, d);
+        d.chunks = (vb_chunk *)pv.mem;
+        d.chunk_first = (uint32_t *)(pv.mem + pv.o1);
+        d.term_chunk = (uint32_t *)(pv.mem + pv.o2);
+        const uint32_t total = pv.total, n_lb = (total + BP_BLOCK - 1) / BP_BLOCK, nt = (uint32_t)pv.n_chunks * 64;
+        ge_cached *tab_hi = d.tab + (size_t)8 * total;
+        LAUNCH(c, s, "vb_prepare", k_vb_prepare_hi, n_lb + total, BP_BLOCK, total, n_lb, d.chunks, d.term_chunk, (const uint32_t *)d_uniq_scalars,
+               (const uint32_t *)d_uniq_points, d.tab, d.recoded, d_status, tab_hi);
+        LAUNCH(c, s, "vb_window", k_vb_window_hi, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, d.chunks, d.tab, d.recoded, d.part, (const ge_cached *)tab_hi);
+        if (s2 != s) HIPCHK(c, hipStreamWaitEvent(s, c->join_ev, 0));
+        LAUNCH(c, s, "msm_tail", k_shared_tail_narrow, (uint32_t)nbatch, 128, (uint32_t)nbatch, d.chunk_first, d.part, nwg, (const ge_ext *)d_part,
+               (const uint32_t *)d_status, (uint32_t *)d_out, (uint8_t *)d_verdict, (uint8_t *)d_status_bytes);
+        HIPCHK(c, hipGetLastError());
+        return BPGPU_OK;
+    }
     if (fused) {   // the fused chain: generator half = one launch, tail = one launch (bucket2.h)
         const uint32_t nwg = fb_walk_parts(c, nbatch, n_gen_terms);
         const size_t off_part = ap.add((size_t)nwg * nbatch * sizeof(ge_ext) + 16);

@@ -223,3 +223,39 @@ __global__ void __launch_bounds__(256) k_msm_tail_fast(uint32_t nmsm, int have_b
     __syncthreads();
     if (tid == 0) bk2_tail_t4b(b, &s_fin[1], &s_raw, &s_tin, status, out_words, verdict, status_bytes);
 }
+
+// The tail of bpgpu_msm_batch_shared in the narrow small-MSM form (k_msm.hip: k_vb_prepare_hi / k_vb_window_hi; option msm_narrow): wavefront 0 adds the chunks' rows and runs the 32-window chain over the caller's own points,
+// wavefront 1 adds the generator half's partial sums (k_fb_walk*: one launch on the second stream) with six shuffle steps; then the encoding
+__global__ void __launch_bounds__(128) k_shared_tail_narrow(uint32_t nmsm, const uint32_t *chunk_first, const ge_ext *part, uint32_t npart, const ge_ext *partial,
+                                                             const uint32_t *status, uint32_t *out_words, uint8_t *verdict, uint8_t *status_bytes) {
+    __shared__ ge_ext s_fin[3];   // [0] the chain's result, [1] the sum that is encoded, [2] the generator half
+    __shared__ fe s_tin, s_raw;
+    __shared__ __attribute__((aligned(16))) uint32_t s_tw[8];
+    __shared__ __attribute__((aligned(16))) uint32_t s_hw[128];
+    const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x;
+    if (wave == 0) {
+        hw_colsum_horner_msm(b, chunk_first, part, &s_fin[0], true);
+    } else {
+        ge_ext acc, q;
+        bk2_tail_t2(lane, b, nmsm, npart, partial, acc);
+#pragma unroll 1
+        for (uint32_t step = 32; step >= 1; step >>= 1) {
+            ge_shfl_down(q, acc, step);
+            ge_add(acc, acc, q);
+        }
+        if (lane == 0) s_fin[2] = acc;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ge_ext acc = s_fin[2];
+        const ge_ext h = s_fin[0];
+        ge_add(acc, acc, h);
+        s_fin[1] = acc;
+        if (out_words) bk2_tail_t4a(&s_fin[1], &s_tin, s_tw);
+    }
+    __syncthreads();
+    if (out_words && wave == 0) hw_invsqrt_raw_fe((const uint16_t *)s_tw, s_hw, &s_raw);
+    __syncthreads();
+    if (tid == 0) bk2_tail_t4b(b, &s_fin[1], &s_raw, &s_tin, status, out_words, verdict, status_bytes);
+}
+

@@ -372,3 +372,42 @@ def test_few_small_msms_take_the_narrow_form_and_agree_with_the_batch_form_and_t
     finally:
         a.close()
         b.close()
+
+
+def test_msm_batch_shared_narrow_form_vs_batch_form_and_oracle(oracle):
+    """bpgpu_msm_batch_shared with a few MSMs of a few own points -- the mega-check of ONE 64-bit proof as the caller's own MSM call (130 generator
+    terms from the tables + 17 points; src/range_proof/mod.rs:421-445) -- in the narrow form (option msm_narrow: k_vb_prepare_hi, k_vb_window_hi,
+    the generator half as one launch, k_shared_tail_narrow) against the batch form and the oracle; the real terms of a golden-shape proof included."""
+    import bulletproofs_amd as bp
+    a, b = bp.Context(0, fixed_window_bits=10), bp.Context(0, fixed_window_bits=10)
+    a.set_option("msm_narrow", 0)
+    b.set_option("msm_narrow", 1)
+    g = oracle.Gens(64, 1)
+    G, H, B, Bb = g.export()
+    for c in (a, b):
+        c.gens_load(64, 1, G, H, B, Bb)
+    n, m = 64, 1
+    ngen = 2 * n * m + 2
+    gen_pts = Bb + B + G + H
+    try:
+        for nb, nu in ((1, 17), (1, 1), (3, 40), (16, 48), (2, 300), (1, 768), (1, 769)):
+            GS, US, UP = b"", b"", b""
+            for i in range(nb):
+                GS += b"".join(_scalar(b"sg%d-%d-%d" % (nb, i, j)) for j in range(ngen))
+                s, p = _rand_msm(oracle, b"su%d-%d-%d" % (nb, nu, i), nu)
+                US += s
+                UP += p
+            ra, rb = a.msm_batch_shared(n, m, nb, nu, GS, US, UP), b.msm_batch_shared(n, m, nb, nu, GS, US, UP)
+            assert ra == rb, (nb, nu)
+            for i in range(min(nb, 3)):
+                exp = oracle.msm(GS[32 * ngen * i:32 * ngen * (i + 1)] + US[32 * nu * i:32 * nu * (i + 1)], gen_pts + UP[32 * nu * i:32 * nu * (i + 1)])
+                assert rb[1][i] == 0 and rb[0][32 * i:32 * i + 32] == exp[1], (nb, nu, i)
+        # an undecodable point of the caller: status 1, zero encoding, in both forms
+        s, p = _rand_msm(oracle, b"bad", 17)
+        p = p[:64] + bytes([p[64] | 1]) + p[65:]
+        gs = b"".join(_scalar(b"bg%d" % j) for j in range(ngen))
+        ra, rb = a.msm_batch_shared(n, m, 1, 17, gs, s, p), b.msm_batch_shared(n, m, 1, 17, gs, s, p)
+        assert ra == rb and rb[1][0] == 1 and rb[0] == bytes(32)
+    finally:
+        a.close()
+        b.close()
