@@ -99,6 +99,7 @@ struct bpgpu_ctx {
     int narrow_hi_max = 32;                                         // chains of up to this many proofs give every per-proof point a second table (2^128 P) and run a 32-window Horner chain; 0: never
     int narrow_fused_finish = 1;                                    // narrow chains, verdicts only: the last workgroup of a proof in launch 4 finishes it (no finish launch)
     int msm_narrow = 1;                                             // bpgpu_msm_batch with <= 16 MSMs of <= 768 terms in all: second tables, ~sqrt(N) chunks, one tail launch (k_vb_*_hi / k_vb_tail_narrow)
+    int narrow_hi4_max = 0;                                         // chains of up to this many proofs: tables of the 2^64, 2^128 and 2^192 multiples, 16-window chain (0: never)
     int coop_split = 1;                                             // narrow chains, per-proof check: the k + 1 inversions on k + 1 lanes of the group at once, the basepoint coefficients as a
                                                                     // role of launch 3 (rangeproof.h rp_split_invert_lane / rp_rows_thread); 0: the leader does it all (A/B: profiles/r06/coop_split_ab.txt)
     int transcript_coop = 1;                                        // chains of up to 256 proofs replay their transcripts 32 lanes per proof (keccak.h): one call of 1 / 8 / 64 / 256 proofs 0.62 -> 0.53 / 0.56 / 0.57 / 0.58 ms; 0: lane = proof everywhere
@@ -428,6 +429,7 @@ int bpgpu_ctx_create(int device, bpgpu_ctx **out) {
     if (const char *e = getenv("BPGPU_NARROW_WALK")) c->narrow_walk = atoi(e) != 0;
     if (const char *e = getenv("BPGPU_NARROW_FUSED_FINISH")) c->narrow_fused_finish = atoi(e) != 0;
     if (const char *e = getenv("BPGPU_NARROW_HI_MAX")) c->narrow_hi_max = atoi(e);
+    if (const char *e = getenv("BPGPU_NARROW_HI4_MAX")) c->narrow_hi4_max = atoi(e);
     if (const char *e = getenv("BPGPU_EXP_SINGLE")) c->exp_single = atoi(e) != 0;
     if (const char *e = getenv("BPGPU_NARROW_CHUNK")) c->narrow_chunk = atoi(e);
     if (const char *e = getenv("BPGPU_COOP_DEFER_EMIT")) c->coop_defer_emit = atoi(e) != 0;   // (A/B of whole test suites: the option's default for every context of the process)
@@ -515,6 +517,11 @@ int bpgpu_ctx_set_option(bpgpu_ctx *c, const char *key, int64_t value) {
     }
     if (!strcmp(key, "exp_single")) {
         c->exp_single = value != 0;
+        return BPGPU_OK;
+    }
+    if (!strcmp(key, "narrow_hi4_max")) {
+        if (value < 0 || value > 256) return fail(c, BPGPU_ERR_INVALID_ARG, "narrow_hi4_max must be 0 .. 256");
+        c->narrow_hi4_max = (int)value;
         return BPGPU_OK;
     }
     if (!strcmp(key, "narrow_hi_max")) {
@@ -2069,8 +2076,10 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     // of its own (k_rp_stage1_coop's third role): the Horner chain has 32 windows, and the walk twice the splits to end with it
     const bool will_script = (!tr.d_ts_in || tr.ts_uniform) && !shape_verdict && !c->no_script;
     const bool narrow_hi = narrow_walk && will_script && c->transcript_coop && c->coop_split && !shape_verdict && (int64_t)nbatch <= (int64_t)c->narrow_hi_max;
+    const uint32_t hi_levels = !narrow_hi ? 1u : ((int64_t)nbatch <= (int64_t)c->narrow_hi4_max ? 4u : 2u);   // (the very narrowest: three more tables per point, a 16-window chain)
     if (narrow_walk) {
         if (narrow_hi && nsplit < 2 * FB_BLOCK) nsplit = 2 * FB_BLOCK;
+        if (hi_levels == 4 && nsplit < 4 * FB_BLOCK) nsplit = 4 * FB_BLOCK;
         nsplit = (nsplit + FB_BLOCK - 1) / FB_BLOCK * FB_BLOCK;
         while (nsplit > FB_BLOCK && npairs / nsplit < 4) nsplit -= FB_BLOCK;
     }
@@ -2097,7 +2106,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     arena_plan ap;
     size_t off[7], boff[12];
     if (rlc_bucket) plan_bucket(ap, 1, rlc_terms, bkp, boff);
-    else plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off, (r5 || narrow_hi) ? 16 : 8, vb_chunk_sz);
+    else plan_vb_uniform(ap, nbatch, shape_verdict ? 0 : sh.U, off, narrow_hi ? 8 * hi_levels : (r5 ? 16 : 8), vb_chunk_sz);
     const size_t off_digits = ap.add((size_t)npairs * nbatch * sizeof(fb_digit) + 16);
     const size_t off_partial = ap.add((size_t)2 * nsplit * nbatch * sizeof(ge_ext) + 16);
     const size_t off_fields = ap.add((size_t)fl.count * nbatch * BP_RP_REC * 4 + 16);
@@ -2255,10 +2264,10 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     const bool coop = d_script && c->transcript_coop && nbatch <= 256;
     sh.coop_split = (coop && c->coop_split && !rlc && !wide && !shape_verdict && sh.k < 32) ? 1u : 0u;   // (launch 3 then carries the basepoint-coefficient role)
     const bool hi = narrow_hi && coop && sh.coop_split;
-    sh.narrow_hi = hi ? 1u : 0u;
+    sh.narrow_hi = hi ? hi_levels : 0u;
     ge_cached *tab_hi = hi ? d.tab + (size_t)8 * nb32 * sh.U : (ge_cached *)nullptr;
     if (coop)   // narrow chain: 32 lanes per proof for the permutations (two proofs per workgroup)
-        LAUNCH(c, s, "rp_stage1", k_rp_stage1_coop, (nb32 + 1) / 2 + n_pt + (hi ? nb32 * sh.U : 0u), RP_BLOCK, sh, init, (nb32 + 1) / 2, (const uint8_t *)d_proofs,
+        LAUNCH(c, s, "rp_stage1", k_rp_stage1_coop, (nb32 + 1) / 2 + n_pt + (hi ? (hi_levels - 1) * nb32 * sh.U : 0u), RP_BLOCK, sh, init, (nb32 + 1) / 2, (const uint8_t *)d_proofs,
            (const uint8_t *)d_commitments, rng_ptr, d_fields, d.tab, d_status, prm, lg_m, rlc_bucket ? bd.rwords : d.recoded, d_digits,
            rlc ? wts_ptr : (const uint8_t *)nullptr, (const uint32_t *)tr.d_ts_in, (uint32_t *)tr.d_ts_out,
            rlc_bucket ? bd.pts : (fb_entry *)nullptr, rlc_bucket ? bkp.c : 0u, segtab, d_script, n_pt, tab_hi);
@@ -2427,7 +2436,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     } else if (narrow_walk) {   // lane = split: a proof's partial sums are folded inside launch 4 (k_rp34.hip: rp_walk_narrow)
         nparts = nsplit / FB_BLOCK;
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<64>, nb32 + nb32 * nparts, FB_BLOCK, nb32, d.chunk_first, d.part, (const ge_cached *)nullptr, d.hq,
-               prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, gen_table, d_partial, (hi ? 3u : 1u) | (fused_finish ? 4u : 0u), c->fin_cnt, d_status,
+               prm, nb32, nblk_p, nsplit, npairs, d_ids, d_digits, gen_table, d_partial, (hi ? (hi_levels == 4 ? 9u : 3u) : 1u) | (fused_finish ? 4u : 0u), c->fin_cnt, d_status,
                (uint8_t *)d_verdict, segtab);
     } else {
         LAUNCH(c, s, "rp_stage4", k_rp_stage4<64>, nb32 + nblk_p * nsplit, FB_BLOCK, nb32, d.chunk_first, d.part, (const ge_cached *)nullptr, d.hq,

@@ -239,7 +239,7 @@ BP_HD void hw_limbs_to_fe(fe &out, const uint32_t l[16]) {
 __device__ void hw_horner_msm(const uint16_t *colq16, ge_ext *out);   // host pass of hipcc: declarations only
 __device__ void hw_horner8_msm(const uint16_t *colq8, uint32_t *lds128, ge_ext *out);
 __device__ void hw_invsqrt_raw_fe(const uint16_t *t16, uint32_t *lds128, fe *out);
-__device__ void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out, bool half = false);
+__device__ void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out, int nlev = 1);
 __device__ void hw_point_shift(const ge_ext &p, int n, ge_ext *out);
 __device__ void hw_ristretto_decode(ge_ext &r, const uint32_t w[8]);
 __device__ void hw_shift_table8(const ge_ext &p, int n, ge_cached *out8);
@@ -261,31 +261,35 @@ __device__ __forceinline__ void hw_horner_msm(const uint16_t *colq16, ge_ext *ou
 // Fused variant: the wavefront first forms its MSM's 64 column sums itself (lane w = window w: add the
 // chunks' partial sums, re-encode as 16-bit limbs into LDS) and then runs the chain from LDS -- one launch
 // and no [msm][64][128 B] round trip through HBM.
-// half: 32 columns -- lane w < 32 adds lane w + 32's sum (the upper digits' window sums, formed from the tables of the 2^128 multiples)
-// to its own before the chain, which then has 32 windows
-__device__ __forceinline__ void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out, bool half = false) {
+// nlev = 2 / 4 (very narrow chains: tables of the 2^128, or 2^64 / 2^128 / 2^192, multiples of every point): 64 / nlev columns -- lane w < 64 / nlev
+// adds the sums of lanes w + 64 / nlev, ... (the upper digits' window sums, formed from those tables) to its own before the chain, which then
+// has 64 / nlev windows
+__device__ __forceinline__ void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out, int nlev = 1) {
     __shared__ __attribute__((aligned(16))) uint32_t hw_lds2[128];
     __shared__ __attribute__((aligned(16))) uint32_t hw_colq[64 * 32];
-    const uint32_t lane = wv_lane();
+    const uint32_t lane = wv_lane(), wl = 64u / (uint32_t)nlev;
     {
         ge_ext acc;
         vb_colsum_acc(acc, b, lane, chunk_first, part);
-        if (half) {   // (wavefront-uniform)
-            ge_ext *x = (ge_ext *)hw_colq;   // 32 x 160 bytes of the 8 KB, overwritten by the encodings below
-            if (lane >= 32) x[lane - 32] = acc;
+        if (nlev > 1) {   // (wavefront-uniform)
+            ge_ext *x = (ge_ext *)hw_colq;   // <= 48 x 160 bytes of the 8 KB, overwritten by the encodings below
+            if (lane >= wl) x[lane - wl] = acc;
             WV_LDS_ORDER();
-            if (lane < 32) {
-                const ge_ext q = x[lane];
-                ge_add(acc, acc, q);
+            if (lane < wl) {
+#pragma unroll 1
+                for (uint32_t j = 0; j + 1 < (uint32_t)nlev; j++) {
+                    const ge_ext q = x[lane + j * wl];
+                    ge_add(acc, acc, q);
+                }
             }
             WV_LDS_ORDER();
         }
-        if (!half || lane < 32) vb_encode_colq16(hw_colq + lane * 32, acc);
+        if (lane < wl) vb_encode_colq16(hw_colq + lane * 32, acc);
     }
     WV_LDS_ORDER();
     wv_ctx cx;
     cx.lds = hw_lds2;
-    const wu32 c = hw_horner(cx, (const uint16_t *)hw_colq, half ? 32 : BP_VB_WINDOWS);
+    const wu32 c = hw_horner(cx, (const uint16_t *)hw_colq, (int)wl);
     uint32_t limbs[16];
     wv_row_gather16(cx, c, limbs);
     if ((lane & 15u) == 0) {
@@ -425,7 +429,7 @@ __device__ __forceinline__ void hw_ristretto_decode(ge_ext &r, const uint32_t w[
     fe_mul(r.T, r.X, r.Y);
 }
 #else
-inline void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out, bool half = false);
+inline void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out, int nlev = 1);
 inline void hw_point_shift(const ge_ext &p, int n, ge_ext *out) {
     uint32_t pt[32];
     fe_to_words(pt, p.X); fe_to_words(pt + 8, p.Y); fe_to_words(pt + 16, p.Z); fe_to_words(pt + 24, p.T);
@@ -524,19 +528,20 @@ inline void hw_horner_msm(const uint16_t *colq16, ge_ext *out, int nwin = BP_VB_
         ((fe *)out)[row] = r;
     }
 }
-inline void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out, bool half) {
+inline void hw_colsum_horner_msm(uint32_t b, const uint32_t *chunk_first, const ge_ext *part, ge_ext *out, int nlev) {
     uint32_t colq[64 * 32];
-    for (uint32_t w = 0; w < (half ? 32u : 64u); w++) {
+    const uint32_t wl = 64u / (uint32_t)nlev;
+    for (uint32_t w = 0; w < wl; w++) {
         ge_ext acc;
         vb_colsum_acc(acc, b, w, chunk_first, part);
-        if (half) {
+        for (uint32_t j = 1; j < (uint32_t)nlev; j++) {
             ge_ext hi;
-            vb_colsum_acc(hi, b, w + 32, chunk_first, part);
+            vb_colsum_acc(hi, b, w + j * wl, chunk_first, part);
             ge_add(acc, acc, hi);
         }
         vb_encode_colq16(colq + w * 32, acc);
     }
-    hw_horner_msm((const uint16_t *)colq, out, half ? 32 : BP_VB_WINDOWS);
+    hw_horner_msm((const uint16_t *)colq, out, (int)wl);
 }
 #endif
 

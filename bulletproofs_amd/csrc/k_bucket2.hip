@@ -234,7 +234,7 @@ __global__ void __launch_bounds__(128) k_shared_tail_narrow(uint32_t nmsm, const
     __shared__ __attribute__((aligned(16))) uint32_t s_hw[128];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x;
     if (wave == 0) {
-        hw_colsum_horner_msm(b, chunk_first, part, &s_fin[0], true);
+        hw_colsum_horner_msm(b, chunk_first, part, &s_fin[0], 2);
     } else {
         ge_ext acc, q;
         bk2_tail_t2(lane, b, nmsm, npart, partial, acc);

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(64) k_vb_tail_narrow(uint32_t nbatch, const ui
     __shared__ __attribute__((aligned(16))) uint32_t s_tw[8];
     __shared__ __attribute__((aligned(16))) uint32_t s_hw[128];
     const uint32_t b = blockIdx.x;
-    hw_colsum_horner_msm(b, chunk_first, part, &s_fin, true);
+    hw_colsum_horner_msm(b, chunk_first, part, &s_fin, 2);
     __syncthreads();
     if (threadIdx.x == 0) bk2_tail_t4a(&s_fin, &s_tin, s_tw);
     __syncthreads();

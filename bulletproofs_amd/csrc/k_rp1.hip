@@ -148,14 +148,15 @@ __global__ void __launch_bounds__(RP_BLOCK) k_rp_stage1_coop(rp_shape sh, rp_str
         // A coefficient s = s_lo + 2^128 s_hi contributes s_lo P + s_hi Q: 32 windows for the Horner chain instead of 64 -- 124 dependent
         // doublings on the chain's critical path instead of 252; the other 128 run here, beside the transcript.  (A, whose coefficient
         // is 1, has no upper digits: skipped.)
-        const uint32_t t = blockIdx.x - n_tr - n_pt, p = t / sh.U, u = t - p * sh.U;
+        // (sh.narrow_hi = 4: three such tables per point -- 2^64 P, 2^128 P, 2^192 P, a wavefront each -- and a 16-window chain)
+        const uint32_t idx = blockIdx.x - n_tr - n_pt, npts = sh.nproofs * sh.U, lv = idx / npts + 1, t = idx - (lv - 1) * npts, p = t / sh.U, u = t - p * sh.U;
         if (u == 0) return;
         const rp_inputs in = rp_resolve(p, sh, proofs, commitments, nullptr, segs);
         uint32_t w[8];
         load_words8(w, rp_unique_point_ptr(sh, in, u));
         ge_ext pt;
         hw_ristretto_decode(pt, w);   // (an undecodable point is reported by the decode role; its tables are never used)
-        hw_shift_table8(pt, 128, tab_hi + 8 * (uint64_t)t);   // (the eight multiples of Q in the wavefront's layout too: ~10 us instead of ~25 in one lane)
+        hw_shift_table8(pt, (int)(lv * (256u / sh.narrow_hi)), tab_hi + 8 * ((uint64_t)(lv - 1) * npts + t));   // (the eight multiples of Q in the wavefront's layout too: ~10 us instead of ~25 in one lane)
     }
 }
 

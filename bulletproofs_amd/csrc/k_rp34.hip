@@ -21,7 +21,7 @@ __global__ void __launch_bounds__(BP_BLOCK, FORM == 1 ? 1 : BP_STAGE3_WAVES) k_r
                                                          const uint32_t *status, uint32_t n_exp, uint32_t nthreads_rows, uint32_t lg_m, const ge_cached *tab_hi) {
     if (blockIdx.x < n_win) {
         const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
-        if (tid < nthreads_win) vb_window_thread(tid, chunks, tab, recoded, part, colc, nullptr, tab_hi);
+        if (tid < nthreads_win) vb_window_thread(tid, chunks, tab, recoded, part, colc, nullptr, tab_hi, sh.narrow_hi, (uint64_t)8 * sh.nproofs * sh.U);
     } else if (blockIdx.x < n_win + n_exp) {
         const uint32_t tid = (blockIdx.x - n_win) * BP_BLOCK + threadIdx.x;
         if (tid < nthreads_exp) {
@@ -140,7 +140,7 @@ __global__ void __launch_bounds__(FB_BLOCK) k_rp_stage4(uint32_t n_hw, const uin
             if (HL == 4) hq_horner_msm(blockIdx.x * 16 + (threadIdx.x >> 2), nproofs, colc, hq);
         else if (HL == 1) vb_horner_cached_thread(blockIdx.x * FB_BLOCK + threadIdx.x, nproofs, colc, hq);
         else {
-            hw_colsum_horner_msm(blockIdx.x, chunk_first, part, hq + blockIdx.x, (walk_form & 2u) != 0);   // (bit 1: 32 windows, the upper digits' sums folded in)
+            hw_colsum_horner_msm(blockIdx.x, chunk_first, part, hq + blockIdx.x, (walk_form & 8u) ? 4 : ((walk_form & 2u) ? 2 : 1));   // (bit 1 / bit 3: 32 / 16 windows, the upper digits' sums folded in)
             if (walk_form & 4u) {   // (bit 2: the fused finish; four lanes wrote the result's coordinates)
                 __threadfence();
                 __syncthreads();

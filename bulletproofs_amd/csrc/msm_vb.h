@@ -153,13 +153,17 @@ BP_HD void vb_prepare_thread(uint32_t t, const vb_chunk *chunks, const uint32_t 
 // written as a cached point to colc[msm][w] (input of the quad Horner chain, horner_quad.h) instead of part.
 // skip_status (optional): MSMs whose status word is set contribute the identity (batch-combination mode,
 // where the window sums of all proofs are added together afterwards).
-// tab_hi (optional; very narrow chains): the tables of the points' 2^128 multiples -- windows 32 .. 63 select from them, and the chain that
-// follows adds window w + 32's sum to window w's (hw_colsum_horner_msm, half)
+// tab_hi (optional; very narrow chains): the tables of the points' 2^128 multiples (hi_levels = 2), or of their 2^64, 2^128 and 2^192 multiples
+// one after the other, lv_stride entries each (hi_levels = 4) -- windows 64 / levels .. 63 select from them, and the chain that follows adds the
+// sums of windows w + 64 / levels, ... to window w's (hw_colsum_horner_msm)
 BP_HD void vb_window_thread(uint32_t tid, const vb_chunk *chunks, const ge_cached *tab,
                             const uint32_t *recoded, ge_ext *part /*[chunk][64]*/, ge_cached *colc = nullptr,
-                            const uint32_t *skip_status = nullptr, const ge_cached *tab_hi = nullptr) {
+                            const uint32_t *skip_status = nullptr, const ge_cached *tab_hi = nullptr, uint32_t hi_levels = 2, uint64_t lv_stride = 0) {
     const uint32_t c = tid >> 6, w = tid & 63;
-    if (tab_hi && w >= 32) tab = tab_hi;
+    if (tab_hi) {
+        const uint32_t lv = w / (64u / hi_levels);
+        if (lv) tab = tab_hi + (uint64_t)(lv - 1) * lv_stride;
+    }
     const vb_chunk ch = chunks[c];
     ge_ext acc;
     ge_identity(acc);

@@ -42,7 +42,8 @@ struct rp_shape {
     // drawn, staged or copied on the host (64 bytes per proof at 6 ... 10 M proofs/s would be a core's worth of ChaCha)
     uint32_t defer_emit = 0;       // narrow chains (32 lanes per proof): the U coefficient recodings of the scalar role are done by U lanes at once instead of by
                                    // the leader one after the other (rp_defer; option coop_defer_emit)
-    uint32_t narrow_hi = 0;        // very narrow chains: every per-proof point also has the table of its 2^128 multiple (k_rp_stage1_coop's third role), the Horner chain 32 windows
+    uint32_t narrow_hi = 0;        // very narrow chains: 2 -- every per-proof point also has the table of its 2^128 multiple (k_rp_stage1_coop's third role), the Horner chain 32
+                                   // windows; 4 -- of its 2^64, 2^128 and 2^192 multiples, 16 windows; 0 -- one table, 64 windows
     uint32_t coop_split = 0;       // narrow chains, per-proof check: the k + 1 inversions run on k + 1 lanes of the group at once (rp_split_invert_lane) and the two
                                    // basepoint coefficients are formed in launch 3 beside the exponents (rp_rows_thread); option coop_split
     uint32_t seeded = 0;           // RP_SEED_RNG | RP_SEED_WEIGHTS

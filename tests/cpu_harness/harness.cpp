@@ -168,7 +168,7 @@ void h_msm_vb_narrow(uint32_t nbatch, const uint32_t *n_terms, uint32_t chunk, c
     std::vector<uint8_t> sb(nbatch + 1);
     for (uint32_t b = 0; b < nbatch; b++) {
         ge_ext fin; fe tin, raw; uint32_t tw[8];
-        hw_colsum_horner_msm(b, chunk_first.data(), part.data(), &fin, true);
+        hw_colsum_horner_msm(b, chunk_first.data(), part.data(), &fin, 2);
         bk2_tail_t4a(&fin, &tin, tw);
         hw_invsqrt_raw_fe((const uint16_t *)tw, nullptr, &raw);
         bk2_tail_t4b(b, &fin, &raw, &tin, status.data(), outw.data(), nullptr, sb.data());
@@ -613,9 +613,13 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
     }
     for (uint32_t t = 0; t < t0; t++) rp_points_thread(t, sh, rp_resolve(t / sh.U, sh, proofs_l1, coms_l1, nullptr, segtab), tab.data(), status.data());
     const bool hi = g_narrow_hi && !rlc && !r5 && !a_out && g_horner_lanes == 64;
-    std::vector<ge_cached> tab_hi(hi ? (size_t)t0 * 8 + 1 : 1);
-    if (hi) {   // k_rp_stage1_coop's third role: one wavefront per point, Q = 2^128 P by 128 wavefront-cooperative doublings, then Q's table
+    const uint32_t hi_lev = hi ? (uint32_t)g_narrow_hi : 1u;   // 2: tables of 2^128 P; 4: of 2^64 P, 2^128 P, 2^192 P
+    std::vector<ge_cached> tab_hi(hi ? (size_t)t0 * 8 * (hi_lev - 1) + 1 : 1);
+    if (hi) {   // k_rp_stage1_coop's third role: one wavefront per (point, level), Q = 2^(256 lv / levels) P by wavefront-cooperative doublings, then Q's table
+      for (uint32_t lv = 1; lv < hi_lev; lv++)
         for (uint32_t t = 0; t < t0; t++) {
+            const int nshift = (int)(lv * (256u / hi_lev));
+            ge_cached *dst = tab_hi.data() + 8 * ((size_t)(lv - 1) * t0 + t);
             const uint32_t p = t / sh.U, u = t - p * sh.U;
             if (u == 0) continue;
             uint32_t w[8];
@@ -628,14 +632,14 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
                 fe_to_words(a, pt.Y); fe_to_words(b, pt_ref.Y); if (memcmp(a, b, 32)) return -92;
                 fe_to_words(a, pt.T); fe_to_words(b, pt_ref.T); if (memcmp(a, b, 32)) return -93;
             }
-            hw_point_shift(pt, 128, &q);
-            hw_shift_table8(pt, 128, tab_hi.data() + 8 * (size_t)t);
+            hw_point_shift(pt, nshift, &q);
+            hw_shift_table8(pt, nshift, dst);
             {   // the wavefront's table holds the same eight points as the lane's (vb_build_table): e Q + entry == (e + 2) Q ... compared as encodings
                 ge_cached ref[8];
                 vb_build_table(ref, q);
                 for (int e = 0; e < 8; e++) {
                     ge_ext a, b, idn; ge_identity(idn);
-                    ge_add_cached(a, idn, tab_hi[8 * (size_t)t + e], false);
+                    ge_add_cached(a, idn, dst[e], false);
                     ge_add_cached(b, idn, ref[e], false);
                     uint32_t ea[8], eb[8];
                     ristretto_compress(ea, a); ristretto_compress(eb, b);
@@ -644,7 +648,7 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
             }
             // cross-check: the lane-serial doublings give the same point (projectively)
             ge_ext r = pt;
-            for (int i = 0; i < 128; i++) ge_dbl(r, r, true);
+            for (int i = 0; i < nshift; i++) ge_dbl(r, r, true);
             uint32_t e1[8], e2[8];
             ristretto_compress(e1, q); ristretto_compress(e2, r);
             if (memcmp(e1, e2, 32)) return -90;
@@ -757,7 +761,7 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
         for (uint32_t tid = 0; tid < nbatch * BP_VB_WINDOWS; tid++) vb_window_wide_thread<false>(tid, sh.U, 1, tab.data(), rec.data(), colc.data());
     else
     for (uint32_t tid = 0; tid < chunks.size() * 64; tid++)
-        vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data(), (quad && one_chunk) ? colc.data() : nullptr, nullptr, hi ? tab_hi.data() : nullptr);
+        vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data(), (quad && one_chunk) ? colc.data() : nullptr, nullptr, hi ? tab_hi.data() : nullptr, hi_lev, (uint64_t)8 * t0);
     if (quad && !one_chunk && !r5 && !a_out)
         for (uint32_t tid = 0; tid < nbatch * 64; tid++) vb_colsum_thread(tid, chunk_first.data(), part.data(), nullptr, nullptr, colc.data());
     // launch 3
@@ -772,7 +776,7 @@ static int rp_verify_impl(uint32_t W, uint32_t nsplit, uint32_t gens_capacity, u
         else if (a_out) vb_horner_wide_thread<false>(b, nbatch, colc.data(), tab.data(), 8ull * sh.U, hq.data());
         else if (g_horner_lanes == 1) vb_horner_cached_thread(b, nbatch, colc.data(), hq.data());
         else if (quad) hq_horner_msm(b, nbatch, colc.data(), hq.data());
-        else hw_colsum_horner_msm(b, chunk_first.data(), part.data(), &hq[b], hi);
+        else hw_colsum_horner_msm(b, chunk_first.data(), part.data(), &hq[b], (int)hi_lev);
     }
     std::vector<uint8_t> verdict(nbatch + 1);
     // launch 4 (k_finish8): 8 lanes per proof gather, 3-level fold, lane 0 finishes

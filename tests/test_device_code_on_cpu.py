@@ -435,7 +435,7 @@ def test_shared_generator_pipeline_lane_by_lane(H, oracle, W, nsplit):
     assert vd.raw[0] == 0 and out.raw[:32] == bytes(32)
 
 
-@pytest.mark.parametrize("horner_lanes", [1, 4, 64, "radix32", "radix32+a_outside", "a_outside", "64+defer_emit", "64+split", "64+defer_emit+split", "64+defer_emit+split+hi"])
+@pytest.mark.parametrize("horner_lanes", [1, 4, 64, "radix32", "radix32+a_outside", "a_outside", "64+defer_emit", "64+split", "64+defer_emit+split", "64+defer_emit+split+hi", "64+defer_emit+split+hi4"])
 def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, golden, horner_lanes):
     """rp_transcript -> rp_expand_a/b -> vb_* / fb_* -> finish, emulated lane by lane, on the reference's
     golden proofs (small shapes; the GPU tests cover all 16) plus tampered copies.  The Horner layouts:
@@ -445,7 +445,7 @@ def test_full_verification_pipeline_lane_by_lane_on_golden_proofs(H, oracle, gol
     split = isinstance(horner_lanes, str) and "split" in horner_lanes        # ... and its split scalar role (round 6): k + 1 lanes invert one value each, the basepoint coefficients are a role of the next launch
     H.h_set_defer_emit(1 if defer else 0)
     H.h_set_coop_split(1 if split else 0)
-    H.h_set_narrow_hi(1 if isinstance(horner_lanes, str) and "+hi" in horner_lanes else 0)   # ... and for very narrow ones second tables of the points' 2^128 multiples, a 32-window chain
+    H.h_set_narrow_hi((4 if "+hi4" in horner_lanes else 2) if isinstance(horner_lanes, str) and "+hi" in horner_lanes else 0)   # ... and for very narrow ones second tables of the points' 2^128 multiples, a 32-window chain
     if defer or split:
         horner_lanes = 64
     wide = isinstance(horner_lanes, str)

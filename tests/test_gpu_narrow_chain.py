@@ -1,5 +1,5 @@
 """The narrow chain's round-6 forms (chains of up to 256 proofs; csrc/k_rp1.hip k_rp_stage1_coop, k_rp34.hip): every option that selects
-one -- coop_split, exp_single, narrow_chunk, narrow_walk, narrow_hi_max, narrow_fused_finish -- flipped on its own and all together, against the default
+one -- coop_split, exp_single, narrow_chunk, narrow_walk, narrow_hi_max, narrow_hi4_max, narrow_fused_finish -- flipped on its own and all together, against the default
 build of the chain AND the oracle: verdicts, mega-check encodings and advanced transcripts must be bit-identical whatever the form
 (src/range_proof/mod.rs:345-452 is one function; how the device cuts it into lanes is nobody's business but ours)."""
 import hashlib
@@ -20,6 +20,9 @@ FORMS = [
     {"narrow_hi_max": 256},
     {"narrow_hi_max": 256, "narrow_chunk": 5},
     {"coop_split": 0, "narrow_hi_max": 256},   # (second tables need the split launch 1: falls back to 64 windows)
+    {"narrow_hi4_max": 256},                   # (chains of up to narrow_hi_max = 32 proofs then take four table levels and a 16-window chain)
+    {"narrow_hi4_max": 4, "narrow_chunk": 6},
+    {"narrow_hi4_max": 256, "narrow_hi_max": 256, "narrow_fused_finish": 0},
     {"narrow_fused_finish": 0},
     {"narrow_fused_finish": 0, "narrow_hi_max": 0},
 ]
@@ -120,7 +123,7 @@ def test_aggregated_shapes_in_narrow_chains(oracle, fixture, party):
     import bulletproofs_amd as bp
     from bulletproofs_amd import workload as wl
     fx = wl.load_fixture(fixture)
-    forms = [FORMS[0], {"narrow_hi_max": 0}, {"narrow_hi_max": 256}, {"narrow_hi_max": 256, "narrow_fused_finish": 0, "narrow_chunk": 5}]
+    forms = [FORMS[0], {"narrow_hi_max": 0}, {"narrow_hi_max": 256}, {"narrow_hi_max": 256, "narrow_fused_finish": 0, "narrow_chunk": 5}, {"narrow_hi4_max": 256}]
     ctxs = []
     for f in forms:
         c = bp.Context(0)
