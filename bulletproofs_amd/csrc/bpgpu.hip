@@ -99,7 +99,8 @@ struct bpgpu_ctx {
     int narrow_hi_max = 32;                                         // chains of up to this many proofs give every per-proof point a second table (2^128 P) and run a 32-window Horner chain; 0: never
     int narrow_fused_finish = 1;                                    // narrow chains, verdicts only: the last workgroup of a proof in launch 4 finishes it (no finish launch)
     int msm_narrow = 1;                                             // bpgpu_msm_batch with <= 16 MSMs of <= 768 terms in all: second tables, ~sqrt(N) chunks, one tail launch (k_vb_*_hi / k_vb_tail_narrow)
-    int narrow_hi4_max = 0;                                         // chains of up to this many proofs: tables of the 2^64, 2^128 and 2^192 multiples, 16-window chain (0: never)
+    int narrow_hi4_max = 4;                                         // chains of up to this many proofs: tables of the 2^64, 2^128 and 2^192 multiples, 16-window chain (0: never).  Same-box A/B
+                                                                    // (profiles/r06/narrow_hi4_ab.txt): one call 0.315 -> 0.29 ms; at <= 8 the 16 / 64 / 256-thread rows are unchanged, at 32 they lose 5 - 15 %
     int coop_split = 1;                                             // narrow chains, per-proof check: the k + 1 inversions on k + 1 lanes of the group at once, the basepoint coefficients as a
                                                                     // role of launch 3 (rangeproof.h rp_split_invert_lane / rp_rows_thread); 0: the leader does it all (A/B: profiles/r06/coop_split_ab.txt)
     int transcript_coop = 1;                                        // chains of up to 256 proofs replay their transcripts 32 lanes per proof (keccak.h): one call of 1 / 8 / 64 / 256 proofs 0.62 -> 0.53 / 0.56 / 0.57 / 0.58 ms; 0: lane = proof everywhere
@@ -1380,7 +1381,9 @@ static int msm_batch_dev_locked(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_t
     make_vb_plan(pl, nbatch, n_terms, chunk);
     arena_plan ap;
     size_t off[7];
-    plan_vb(ap, pl, nbatch, off, narrow ? 16 : 8);
+    const uint32_t lev = narrow ? 2u : 1u;   // (four table levels -- a 16-window chain, as the narrowest range-proof chains take -- were measured here: no gain,
+                                             // profiles/r06/msm_narrow_four_levels_ab.txt: this call's long pole is its first launch, not the chain)
+    plan_vb(ap, pl, nbatch, off, 8 * lev);
     const size_t off_status = ap.add(nbatch * 4);
     int rc = arena_reserve(c, ap.total);
     if (rc) return rc;
@@ -1392,11 +1395,11 @@ static int msm_batch_dev_locked(bpgpu_ctx *c, size_t nbatch, const uint32_t *n_t
         if (rc) return rc;
         const uint32_t total = pl.total, n_lb = (total + BP_BLOCK - 1) / BP_BLOCK, nt = (uint32_t)pl.chunks.size() * 64;
         ge_cached *tab_hi = d.tab + (size_t)8 * total;
-        LAUNCH(c, s, "vb_prepare", k_vb_prepare_hi, n_lb + total, BP_BLOCK, total, n_lb, d.chunks, d.term_chunk, (const uint32_t *)d_scalars, (const uint32_t *)d_points,
-               d.tab, d.recoded, d_status, tab_hi);
-        LAUNCH(c, s, "vb_window", k_vb_window_hi, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, d.chunks, d.tab, d.recoded, d.part, (const ge_cached *)tab_hi);
+        LAUNCH(c, s, "vb_prepare", k_vb_prepare_hi, n_lb + (lev - 1) * total, BP_BLOCK, total, n_lb, d.chunks, d.term_chunk, (const uint32_t *)d_scalars, (const uint32_t *)d_points,
+               d.tab, d.recoded, d_status, tab_hi, lev);
+        LAUNCH(c, s, "vb_window", k_vb_window_hi, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, d.chunks, d.tab, d.recoded, d.part, (const ge_cached *)tab_hi, lev, total);
         LAUNCH(c, s, "vb_tail", k_vb_tail_narrow, (uint32_t)nbatch, 64, (uint32_t)nbatch, d.chunk_first, d.part, (const uint32_t *)d_status, (uint32_t *)d_out,
-               (uint8_t *)d_status_bytes);
+               (uint8_t *)d_status_bytes, lev);
         HIPCHK(c, hipGetLastError());
         return BPGPU_OK;
     }
@@ -1550,7 +1553,8 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
         sh_chunk = 4;
         while ((size_t)sh_chunk * sh_chunk < n_unique && sh_chunk < BP_VB_CHUNK) sh_chunk++;
     }
-    if (!fused && !use_bucket) plan_vb_uniform(ap, nbatch, n_unique, off, narrow_sh ? 16 : 8, sh_chunk);
+    const uint32_t sh_lev = narrow_sh ? 2u : 1u;
+    if (!fused && !use_bucket) plan_vb_uniform(ap, nbatch, n_unique, off, 8 * sh_lev, sh_chunk);
     const size_t off_status = ap.add(nbatch * 4);
     if (narrow_sh) {
         const uint32_t nwg = fb_walk_parts(c, nbatch, n_gen_terms);
@@ -1577,12 +1581,12 @@ static int msm_shared_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch
         d.term_chunk = (uint32_t *)(pv.mem + pv.o2);
         const uint32_t total = pv.total, n_lb = (total + BP_BLOCK - 1) / BP_BLOCK, nt = (uint32_t)pv.n_chunks * 64;
         ge_cached *tab_hi = d.tab + (size_t)8 * total;
-        LAUNCH(c, s, "vb_prepare", k_vb_prepare_hi, n_lb + total, BP_BLOCK, total, n_lb, d.chunks, d.term_chunk, (const uint32_t *)d_uniq_scalars,
-               (const uint32_t *)d_uniq_points, d.tab, d.recoded, d_status, tab_hi);
-        LAUNCH(c, s, "vb_window", k_vb_window_hi, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, d.chunks, d.tab, d.recoded, d.part, (const ge_cached *)tab_hi);
+        LAUNCH(c, s, "vb_prepare", k_vb_prepare_hi, n_lb + (sh_lev - 1) * total, BP_BLOCK, total, n_lb, d.chunks, d.term_chunk, (const uint32_t *)d_uniq_scalars,
+               (const uint32_t *)d_uniq_points, d.tab, d.recoded, d_status, tab_hi, sh_lev);
+        LAUNCH(c, s, "vb_window", k_vb_window_hi, (nt + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nt, d.chunks, d.tab, d.recoded, d.part, (const ge_cached *)tab_hi, sh_lev, total);
         if (s2 != s) HIPCHK(c, hipStreamWaitEvent(s, c->join_ev, 0));
         LAUNCH(c, s, "msm_tail", k_shared_tail_narrow, (uint32_t)nbatch, 128, (uint32_t)nbatch, d.chunk_first, d.part, nwg, (const ge_ext *)d_part,
-               (const uint32_t *)d_status, (uint32_t *)d_out, (uint8_t *)d_verdict, (uint8_t *)d_status_bytes);
+               (const uint32_t *)d_status, (uint32_t *)d_out, (uint8_t *)d_verdict, (uint8_t *)d_status_bytes, sh_lev);
         HIPCHK(c, hipGetLastError());
         return BPGPU_OK;
     }
@@ -2450,7 +2454,7 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
     ge_ext *d_red = nullptr;
     uint32_t nred = 0;
     enqueue_fb_reduce(c, s, nb32, nparts, d_partial, &d_red, &nred, 64);   // 8 lanes x <= 8 partials each in finish8
-    if (nred <= 4 && narrow_walk) {   // a few partial sums + the Horner result per proof: lane = proof
+    if (nred <= 2 && narrow_walk) {   // one or two partial sums + the Horner result per proof: lane = proof (more: eight lanes per proof and a three-level fold, below)
         if (d_msm_out)
             LAUNCH(c, s, "finish1", k_finish1<true>, (nb32 + 63) / 64, 64, nb32, nred, d.hq, d_red, d_status, (uint32_t *)d_msm_out, (uint8_t *)d_verdict, 1, segtab);
         else

@@ -227,14 +227,14 @@ __global__ void __launch_bounds__(256) k_msm_tail_fast(uint32_t nmsm, int have_b
 // The tail of bpgpu_msm_batch_shared in the narrow small-MSM form (k_msm.hip: k_vb_prepare_hi / k_vb_window_hi; option msm_narrow): wavefront 0 adds the chunks' rows and runs the 32-window chain over the caller's own points,
 // wavefront 1 adds the generator half's partial sums (k_fb_walk*: one launch on the second stream) with six shuffle steps; then the encoding
 __global__ void __launch_bounds__(128) k_shared_tail_narrow(uint32_t nmsm, const uint32_t *chunk_first, const ge_ext *part, uint32_t npart, const ge_ext *partial,
-                                                             const uint32_t *status, uint32_t *out_words, uint8_t *verdict, uint8_t *status_bytes) {
+                                                             const uint32_t *status, uint32_t *out_words, uint8_t *verdict, uint8_t *status_bytes, uint32_t levels) {
     __shared__ ge_ext s_fin[3];   // [0] the chain's result, [1] the sum that is encoded, [2] the generator half
     __shared__ fe s_tin, s_raw;
     __shared__ __attribute__((aligned(16))) uint32_t s_tw[8];
     __shared__ __attribute__((aligned(16))) uint32_t s_hw[128];
     const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, b = blockIdx.x;
     if (wave == 0) {
-        hw_colsum_horner_msm(b, chunk_first, part, &s_fin[0], 2);
+        hw_colsum_horner_msm(b, chunk_first, part, &s_fin[0], (int)levels);
     } else {
         ge_ext acc, q;
         bk2_tail_t2(lane, b, nmsm, npart, partial, acc);

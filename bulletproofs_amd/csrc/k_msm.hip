@@ -24,35 +24,36 @@ __global__ void __launch_bounds__(BP_BLOCK) k_vb_window(uint32_t nthreads, const
 //   2  window sums in chunks of ~sqrt(N) terms; windows 32 .. 63 select from Q's tables
 //   3  one wavefront per MSM: adds the chunks' rows, folds window w + 32 into window w, a 32-window Horner chain (124 dependent doublings
 //      instead of 252), then the encoding with its inverse square root as a wavefront chain, the status byte
+// (levels = 4, calls of <= 256 terms: three such wavefronts per term -- 2^64 P, 2^128 P, 2^192 P -- and a 16-window chain)
 __global__ void __launch_bounds__(BP_BLOCK) k_vb_prepare_hi(uint32_t total, uint32_t n_lane_blocks, const vb_chunk *chunks, const uint32_t *term_chunk,
                                                              const uint32_t *scalars, const uint32_t *points, ge_cached *tab, uint32_t *recoded,
-                                                             uint32_t *status, ge_cached *tab_hi) {
+                                                             uint32_t *status, ge_cached *tab_hi, uint32_t levels) {
     if (blockIdx.x < n_lane_blocks) {
         const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
         if (t < total) vb_prepare_thread(t, chunks, term_chunk, scalars, points, tab, recoded, status);
     } else {
-        const uint32_t t = blockIdx.x - n_lane_blocks;
+        const uint32_t idx = blockIdx.x - n_lane_blocks, lv = idx / total + 1, t = idx - (lv - 1) * total;
         uint32_t pw[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) pw[i] = points[8 * (uint64_t)t + i];
         ge_ext pt;
         hw_ristretto_decode(pt, pw);   // (an undecodable point is reported by the lane role; its tables are never used)
-        hw_shift_table8(pt, 128, tab_hi + 8 * (uint64_t)t);
+        hw_shift_table8(pt, (int)(lv * (256u / levels)), tab_hi + 8 * ((uint64_t)(lv - 1) * total + t));
     }
 }
 __global__ void __launch_bounds__(BP_BLOCK) k_vb_window_hi(uint32_t nthreads, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part,
-                                                            const ge_cached *tab_hi) {
+                                                            const ge_cached *tab_hi, uint32_t levels, uint32_t total) {
     const uint32_t tid = blockIdx.x * blockDim.x + threadIdx.x;
-    if (tid < nthreads) vb_window_thread(tid, chunks, tab, recoded, part, nullptr, nullptr, tab_hi);
+    if (tid < nthreads) vb_window_thread(tid, chunks, tab, recoded, part, nullptr, nullptr, tab_hi, levels, (uint64_t)8 * total);
 }
 __global__ void __launch_bounds__(64) k_vb_tail_narrow(uint32_t nbatch, const uint32_t *chunk_first, const ge_ext *part, const uint32_t *status, uint32_t *out_words,
-                                                        uint8_t *status_bytes) {
+                                                        uint8_t *status_bytes, uint32_t levels) {
     __shared__ ge_ext s_fin;
     __shared__ fe s_tin, s_raw;
     __shared__ __attribute__((aligned(16))) uint32_t s_tw[8];
     __shared__ __attribute__((aligned(16))) uint32_t s_hw[128];
     const uint32_t b = blockIdx.x;
-    hw_colsum_horner_msm(b, chunk_first, part, &s_fin, 2);
+    hw_colsum_horner_msm(b, chunk_first, part, &s_fin, (int)levels);
     __syncthreads();
     if (threadIdx.x == 0) bk2_tail_t4a(&s_fin, &s_tin, s_tw);
     __syncthreads();

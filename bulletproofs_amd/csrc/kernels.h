@@ -26,10 +26,10 @@ using namespace bp;
 
 __global__ void k_vb_prepare(uint32_t total, const vb_chunk *chunks, const uint32_t *term_chunk, const uint32_t *scalars, const uint32_t *points, ge_cached *tab, uint32_t *recoded, uint32_t *status);
 __global__ void k_vb_window(uint32_t nthreads, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part);
-__global__ void k_vb_prepare_hi(uint32_t total, uint32_t n_lane_blocks, const vb_chunk *chunks, const uint32_t *term_chunk, const uint32_t *scalars, const uint32_t *points, ge_cached *tab, uint32_t *recoded, uint32_t *status, ge_cached *tab_hi);
-__global__ void k_vb_window_hi(uint32_t nthreads, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, const ge_cached *tab_hi);
-__global__ void k_vb_tail_narrow(uint32_t nbatch, const uint32_t *chunk_first, const ge_ext *part, const uint32_t *status, uint32_t *out_words, uint8_t *status_bytes);
-__global__ void k_shared_tail_narrow(uint32_t nmsm, const uint32_t *chunk_first, const ge_ext *part, uint32_t npart, const ge_ext *partial, const uint32_t *status, uint32_t *out_words, uint8_t *verdict, uint8_t *status_bytes);
+__global__ void k_vb_prepare_hi(uint32_t total, uint32_t n_lane_blocks, const vb_chunk *chunks, const uint32_t *term_chunk, const uint32_t *scalars, const uint32_t *points, ge_cached *tab, uint32_t *recoded, uint32_t *status, ge_cached *tab_hi, uint32_t levels);
+__global__ void k_vb_window_hi(uint32_t nthreads, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, const ge_cached *tab_hi, uint32_t levels, uint32_t total);
+__global__ void k_vb_tail_narrow(uint32_t nbatch, const uint32_t *chunk_first, const ge_ext *part, const uint32_t *status, uint32_t *out_words, uint8_t *status_bytes, uint32_t levels);
+__global__ void k_shared_tail_narrow(uint32_t nmsm, const uint32_t *chunk_first, const ge_ext *part, uint32_t npart, const ge_ext *partial, const uint32_t *status, uint32_t *out_words, uint8_t *verdict, uint8_t *status_bytes, uint32_t levels);
 __global__ void k_vb_window_colc(uint32_t nthreads, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, ge_cached *colc);
 __global__ void k_vb_colsum(uint32_t nthreads, const uint32_t *chunk_first, const ge_ext *part, uint32_t *colq16, ge_cached *colc);
 __global__ void k_horner_wave(const uint32_t *colq16, ge_ext *hq);

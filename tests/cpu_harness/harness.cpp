@@ -140,7 +140,7 @@ void h_msm_vb(uint32_t nbatch, const uint32_t *n_terms, const uint8_t *scalars, 
 // The narrow form of the same pipeline (k_vb_prepare_hi / k_vb_window_hi / k_vb_tail_narrow: a few small MSMs per call): chunks of `chunk` terms,
 // second tables of the 2^128 multiples from the wavefront-cooperative decode + doublings, 32-window chain, encoding through the split
 // inverse-square-root (lane 0 front / wavefront chain / lane 0 back).
-void h_msm_vb_narrow(uint32_t nbatch, const uint32_t *n_terms, uint32_t chunk, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status_out) {
+void h_msm_vb_narrow(uint32_t nbatch, const uint32_t *n_terms, uint32_t chunk, uint32_t levels, const uint8_t *scalars, const uint8_t *points, uint8_t *out, uint8_t *status_out) {
     std::vector<vb_chunk> chunks; std::vector<uint32_t> chunk_first(nbatch + 1), term_chunk;
     uint32_t t0 = 0;
     for (uint32_t b = 0; b < nbatch; b++) {
@@ -154,21 +154,23 @@ void h_msm_vb_narrow(uint32_t nbatch, const uint32_t *n_terms, uint32_t chunk, c
     }
     chunk_first[nbatch] = (uint32_t)chunks.size();
     const uint32_t total = t0;
-    std::vector<ge_cached> tab((size_t)total * 8 + 1), tab_hi((size_t)total * 8 + 1);
+    std::vector<ge_cached> tab((size_t)total * 8 + 1), tab_hi((size_t)total * 8 * (levels - 1) + 1);
     std::vector<uint32_t> rec((size_t)total * 8 + 1), status(nbatch + 1, 0), outw((size_t)nbatch * 8 + 1);
     std::vector<ge_ext> part(chunks.size() * 64 + 1);
     for (uint32_t t = 0; t < total; t++)
         vb_prepare_thread(t, chunks.data(), term_chunk.data(), (const uint32_t *)scalars, (const uint32_t *)points, tab.data(), rec.data(), status.data());
-    for (uint32_t t = 0; t < total; t++) {
-        ge_ext pt;
-        hw_ristretto_decode(pt, (const uint32_t *)points + 8 * (size_t)t);
-        hw_shift_table8(pt, 128, tab_hi.data() + 8 * (size_t)t);
-    }
-    for (uint32_t tid = 0; tid < chunks.size() * 64; tid++) vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data(), nullptr, nullptr, tab_hi.data());
+    for (uint32_t lv = 1; lv < levels; lv++)
+        for (uint32_t t = 0; t < total; t++) {
+            ge_ext pt;
+            hw_ristretto_decode(pt, (const uint32_t *)points + 8 * (size_t)t);
+            hw_shift_table8(pt, (int)(lv * (256u / levels)), tab_hi.data() + 8 * ((size_t)(lv - 1) * total + t));
+        }
+    for (uint32_t tid = 0; tid < chunks.size() * 64; tid++)
+        vb_window_thread(tid, chunks.data(), tab.data(), rec.data(), part.data(), nullptr, nullptr, tab_hi.data(), levels, (uint64_t)8 * total);
     std::vector<uint8_t> sb(nbatch + 1);
     for (uint32_t b = 0; b < nbatch; b++) {
         ge_ext fin; fe tin, raw; uint32_t tw[8];
-        hw_colsum_horner_msm(b, chunk_first.data(), part.data(), &fin, 2);
+        hw_colsum_horner_msm(b, chunk_first.data(), part.data(), &fin, (int)levels);
         bk2_tail_t4a(&fin, &tin, tw);
         hw_invsqrt_raw_fe((const uint16_t *)tw, nullptr, &raw);
         bk2_tail_t4b(b, &fin, &raw, &tin, status.data(), outw.data(), nullptr, sb.data());

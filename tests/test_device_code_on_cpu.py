@@ -171,21 +171,22 @@ def test_variable_base_pipeline_narrow_form_lane_by_lane(H, oracle):
         P += b"".join(_pt(oracle, b"n%d-p%d" % (k, i)) for i in range(n))
     nt = (C.c_uint32 * len(sizes))(*sizes)
     out, st = C.create_string_buffer(32 * len(sizes)), C.create_string_buffer(len(sizes))
-    for chunk in (4, 9, 32):
-        H.h_msm_vb_narrow(len(sizes), nt, chunk, S, P, out, st)
+    for chunk, levels in ((4, 2), (9, 2), (32, 2), (9, 4)):   # (levels 4: tables of 2^64 P, 2^128 P, 2^192 P, a 16-window chain)
+        H.h_msm_vb_narrow(len(sizes), nt, chunk, levels, S, P, out, st)
         off = 0
         for k, n in enumerate(sizes):
-            assert st.raw[k] == 0 and out.raw[32 * k:32 * k + 32] == oracle.msm(S[off:off + 32 * n], P[off:off + 32 * n])[1], (chunk, k)
+            assert st.raw[k] == 0 and out.raw[32 * k:32 * k + 32] == oracle.msm(S[off:off + 32 * n], P[off:off + 32 * n])[1], (chunk, levels, k)
             off += 32 * n
     sp = [0, 1, T.L - 1, 8, int("8" * 63, 16) % T.L, 2**252, 2**128, 2**128 - 1, (2**124 - 1) << 128]
     s = b"".join(x.to_bytes(32, "little") for x in sp)
     p = b"".join(_pt(oracle, b"nsp%d" % i) for i in range(len(sp)))
     nt = (C.c_uint32 * 1)(len(sp))
-    H.h_msm_vb_narrow(1, nt, 4, s, p, out, st)
-    assert out.raw[:32] == oracle.msm(s, p)[1] and st.raw[0] == 0
+    for levels in (2, 4):
+        H.h_msm_vb_narrow(1, nt, 4, levels, s, p, out, st)
+        assert out.raw[:32] == oracle.msm(s, p)[1] and st.raw[0] == 0
     bad = bytearray(p)
     bad[0] |= 1
-    H.h_msm_vb_narrow(1, nt, 4, s, bytes(bad), out, st)
+    H.h_msm_vb_narrow(1, nt, 4, 4, s, bytes(bad), out, st)
     assert st.raw[0] == 1 and out.raw[:32] == bytes(32)
 
 
