@@ -2242,7 +2242,10 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         rc = pin_mark(c, s);
         if (rc) return rc;
     }
-    if (c->rp_status_dirty) HIPCHK(c, hipMemsetAsync(d_status, 0, c->rp_status_cap * 4, s));
+    if (c->rp_status_dirty) {   // (a chain whose enqueue failed half way: its status words and arrival counters were not handed back clean)
+        HIPCHK(c, hipMemsetAsync(d_status, 0, c->rp_status_cap * 4, s));
+        HIPCHK(c, hipMemsetAsync(c->fin_cnt, 0, 256 * 4, s));
+    }
     c->rp_status_dirty = true;   // until the kernel that resets the words has been enqueued
     const uint32_t nb32 = (uint32_t)nbatch;
     // the proof-specific ("variable-base") terms: decomposition into chunks of 32 is cached per (batch, U)
