@@ -657,6 +657,8 @@ BP_HD void rp_points_thread(uint32_t t, rp_shape sh, const rp_inputs &in, ge_cac
     uint32_t w[8];
     load_words8(w, rp_unique_point_ptr(sh, in, u));
     ge_ext pt;
+    // (the short-register decode of bucket2.h here: 117 -> 81 spilled registers in k_rp_stage1<true>, no difference in any bench form --
+    // profiles/r06/stage1_short_register_decode_ab.txt; not kept)
     if (!ristretto_decompress(pt, w)) status_raise(status + p, BP_VERDICT_VERIFICATION);
     if (pts) bk_store_point(pts + t, pt);
     else if (sh.radix5) vb_build_table16(tab + 16 * (uint64_t)t, pt, sh.a_outside && u == 0);
