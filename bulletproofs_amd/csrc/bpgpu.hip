@@ -2381,6 +2381,10 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
         // (exponents -> table walk); they meet in the finish.  With the Horner chains aside, the first branch's LAST kernel goes to the
         // second stream.  (Moving the whole branch there, or the exponents instead, were options until round 6: no gain in their A/B.)
         hipStream_t sw = s;
+        // (A burst of two wide chains runs its phases in lockstep -- profiles/r06/headline_burst_kernel_sequence.txt: both window sums, then both
+        // exponent launches, 470 us at two wavefronts per SIMD beside nothing but the Horner chains, then the walks.  Issuing the exponents on the second
+        // stream FIRST, under the window sums, was built and measured on the same box: no difference in any bench form, cfg4 -1.3 %
+        // (profiles/r06/exp_early_ab.txt) -- removed again.)
         if (r5) {
             const uint32_t nw5 = nb32 * BP_VB5_WINDOWS;
             LAUNCH(c, sw, "rp_stage3w", k_vb_window_wide<true>, (nw5 + BP_BLOCK - 1) / BP_BLOCK, BP_BLOCK, nw5, sh.U, a_out ? 1u : 0u, d.tab, d.recoded, d_colc);
