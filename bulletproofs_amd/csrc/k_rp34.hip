@@ -45,8 +45,11 @@ template __global__ void k_rp_stage3<2>(uint32_t, uint32_t, const vb_chunk *, co
 // Two wavefronts per SIMD although 166 registers would allow three: with three, the kernel itself runs 200 instead of 290 us, but on
 // 20 x 1024 bursts the one-lane Horner chains beside it slow down by as much (1.06 -> 1.4 ms) and they are the longer path: -12 %
 // (profiles/r04/ab_exponents_*.txt).  Issue priority for the lane-serial roles (s_setprio) was measured too: neutral, not kept.
+#ifndef BP_EXP_WAVES
+#define BP_EXP_WAVES 2
+#endif
 template <bool PAIRS>
-__global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(BP_BLOCK) k_rp_exponents(uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields,
+__global__ void __attribute__((amdgpu_waves_per_eu(BP_EXP_WAVES, BP_EXP_WAVES))) __launch_bounds__(BP_BLOCK) k_rp_exponents(uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields,
                                                                                                  fb_digit *digits, const uint32_t *status) {
     const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
     if (tid < nthreads_exp) {
