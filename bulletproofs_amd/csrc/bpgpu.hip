@@ -101,6 +101,7 @@ struct bpgpu_ctx {
     int msm_narrow = 1;                                             // bpgpu_msm_batch with <= 16 MSMs of <= 768 terms in all: second tables, ~sqrt(N) chunks, one tail launch (k_vb_*_hi / k_vb_tail_narrow)
     int narrow_hi4_max = 4;                                         // chains of up to this many proofs: tables of the 2^64, 2^128 and 2^192 multiples, 16-window chain (0: never).  Same-box A/B
                                                                     // (profiles/r06/narrow_hi4_ab.txt): one call 0.315 -> 0.29 ms; at <= 8 the 16 / 64 / 256-thread rows are unchanged, at 32 they lose 5 - 15 %
+    int exp_w3_min_nm = 1024;                                       // wide chains of shapes with at least this many generator pairs run the exponent launch at three wavefronts per SIMD (k_rp_exponents_w3)
     int coop_split = 1;                                             // narrow chains, per-proof check: the k + 1 inversions on k + 1 lanes of the group at once, the basepoint coefficients as a
                                                                     // role of launch 3 (rangeproof.h rp_split_invert_lane / rp_rows_thread); 0: the leader does it all (A/B: profiles/r06/coop_split_ab.txt)
     int transcript_coop = 1;                                        // chains of up to 256 proofs replay their transcripts 32 lanes per proof (keccak.h): one call of 1 / 8 / 64 / 256 proofs 0.62 -> 0.53 / 0.56 / 0.57 / 0.58 ms; 0: lane = proof everywhere
@@ -427,6 +428,7 @@ int bpgpu_ctx_create(int device, bpgpu_ctx **out) {
         return BPGPU_ERR_HIP;
     }
     if (const char *e = getenv("BPGPU_COOP_SPLIT")) c->coop_split = atoi(e) != 0;
+    if (const char *e = getenv("BPGPU_EXP_W3_MIN_NM")) c->exp_w3_min_nm = atoi(e);   // (A/B only)
     if (const char *e = getenv("BPGPU_NARROW_WALK")) c->narrow_walk = atoi(e) != 0;
     if (const char *e = getenv("BPGPU_NARROW_FUSED_FINISH")) c->narrow_fused_finish = atoi(e) != 0;
     if (const char *e = getenv("BPGPU_NARROW_HI_MAX")) c->narrow_hi_max = atoi(e);
@@ -2409,7 +2411,8 @@ static int rp_verify_dev_locked(bpgpu_ctx *c, size_t n, size_t m, size_t nbatch,
             HIPCHK(c, hipEventRecord(c->join_ev, c->stream2));
             horner_aside = true;
         }
-        if (pairs) LAUNCH(c, s, "rp_stage3", k_rp_exponents<true>, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
+        if (pairs && sh.nm >= (uint32_t)c->exp_w3_min_nm) LAUNCH(c, s, "rp_stage3", k_rp_exponents_w3, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);   // (aggregated shapes: three wavefronts per SIMD)
+        else if (pairs) LAUNCH(c, s, "rp_stage3", k_rp_exponents<true>, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
         else LAUNCH(c, s, "rp_stage3", k_rp_exponents<false>, n_exp, BP_BLOCK, nexp, sh, prm, d_fields, d_digits, d_status);
     } else {
         const uint32_t nrows = sh.coop_split ? nb32 : 0u, n_rows = (nrows + BP_BLOCK - 1) / BP_BLOCK;

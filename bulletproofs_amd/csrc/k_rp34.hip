@@ -45,11 +45,8 @@ template __global__ void k_rp_stage3<2>(uint32_t, uint32_t, const vb_chunk *, co
 // Two wavefronts per SIMD although 166 registers would allow three: with three, the kernel itself runs 200 instead of 290 us, but on
 // 20 x 1024 bursts the one-lane Horner chains beside it slow down by as much (1.06 -> 1.4 ms) and they are the longer path: -12 %
 // (profiles/r04/ab_exponents_*.txt).  Issue priority for the lane-serial roles (s_setprio) was measured too: neutral, not kept.
-#ifndef BP_EXP_WAVES
-#define BP_EXP_WAVES 2
-#endif
 template <bool PAIRS>
-__global__ void __attribute__((amdgpu_waves_per_eu(BP_EXP_WAVES, BP_EXP_WAVES))) __launch_bounds__(BP_BLOCK) k_rp_exponents(uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields,
+__global__ void __attribute__((amdgpu_waves_per_eu(2, 2))) __launch_bounds__(BP_BLOCK) k_rp_exponents(uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields,
                                                                                                  fb_digit *digits, const uint32_t *status) {
     const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
     if (tid < nthreads_exp) {
@@ -59,6 +56,14 @@ __global__ void __attribute__((amdgpu_waves_per_eu(BP_EXP_WAVES, BP_EXP_WAVES)))
 }
 template __global__ void k_rp_exponents<false>(uint32_t, rp_shape, fb_params, const uint32_t *, fb_digit *, const uint32_t *);
 template __global__ void k_rp_exponents<true>(uint32_t, rp_shape, fb_params, const uint32_t *, fb_digit *, const uint32_t *);
+// The paired form at THREE wavefronts per SIMD (168 registers, 27 spilled) for aggregated shapes (nm >= 1024: the role is thousands of indices per
+// proof and a larger share of the chain): same-box A/B of the 20-step bursts, profiles/r06/exponent_waves_ab.txt -- m = 32 +1.9 %, m = 16 +0.7 %; the
+// single-proof shape loses (bursts 6.25 -> 5.96 M/s: the one-lane Horner chains beside it) and keeps two.
+__global__ void __attribute__((amdgpu_waves_per_eu(3, 3))) __launch_bounds__(BP_BLOCK) k_rp_exponents_w3(uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields,
+                                                                                                    fb_digit *digits, const uint32_t *status) {
+    const uint32_t tid = blockIdx.x * BP_BLOCK + threadIdx.x;
+    if (tid < nthreads_exp) rp_expand_b8_thread(tid, sh, prm, fields, digits, status);
+}
 
 // the one-lane Horner chains as their own launch (wide chains: issued on the context's second stream as soon as the window sums
 // exist, so that their ~1 ms of dependent instructions run beside the generator exponents and the table walk instead of after them)

@@ -54,6 +54,7 @@ template <int FORM>
 __global__ void k_rp_stage3(uint32_t n_win, uint32_t nthreads_win, const vb_chunk *chunks, const ge_cached *tab, const uint32_t *recoded, ge_ext *part, ge_cached *colc, uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits, const uint32_t *status, uint32_t n_exp, uint32_t nthreads_rows, uint32_t lg_m, const ge_cached *tab_hi);
 template <bool PAIRS>
 __global__ void k_rp_exponents(uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits, const uint32_t *status);
+__global__ void k_rp_exponents_w3(uint32_t nthreads_exp, rp_shape sh, fb_params prm, const uint32_t *fields, fb_digit *digits, const uint32_t *status);
 __global__ void k_rp_horner1(uint32_t nproofs, const ge_cached *colc, ge_ext *hq);
 template <bool R5>
 __global__ void k_rp_horner_wide(uint32_t nproofs, const ge_cached *colc, const ge_cached *extra, uint32_t extra_stride, ge_ext *hq);
