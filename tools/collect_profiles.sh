@@ -62,7 +62,7 @@ pmc cfg5_valu "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" python $REPO/b
 python $REPO/tools/isa_mix.py > /tmp/isa_mix.json
 python - <<PY
 import csv, collections, json, glob, re
-LABEL = {"vb_window_wide": "rp_stage3w", "vb_window_colc": "rp_stage3w", "rp_horner_wide": "rp_horner1", "rp_exponents": "rp_stage3",
+LABEL = {"vb_window_wide": "rp_stage3w", "vb_window_colc": "rp_stage3w", "rp_horner_wide": "rp_horner1", "rp_exponents": "rp_stage3", "rp_exponents_w3": "rp_stage3",
          "bk2_prepare": "bk_prepare", "bk2_window": "bk_window", "bk2_leafv": "bk_leaf_narrow", "msm_tail_fast": "msm_tail_narrow", "fb_walk1": "fb_walk_narrow"}   # kernel -> the library's launch label (bench.py's names)
 def short(name):
     n = name.split("(")[0].strip()
