@@ -420,7 +420,8 @@ struct bpgpu_pool {
     std::atomic<uint64_t> combine_poll_ns{15000};     // the service thread's polling period while anything is open or in flight
     std::atomic<uint32_t> combine_max_open{4};        // position classes with a buffer of their own; further classes share a CK_MIXED buffer
     std::atomic<uint32_t> combine_busy_chains{2};     // a chain issued beside this many others (in flight or waiting) takes the throughput forms
-    std::atomic<uint32_t> combine_inflight{6};        // deadlines seal buffers only while fewer chains than this are in flight: beyond, load widens the chains
+    std::atomic<uint32_t> combine_inflight{4};        // deadlines seal buffers only while fewer chains than this are in flight: beyond, load widens the chains.  (6 until the narrow
+                                                      // chain was rebuilt in round 6; re-swept on the shorter chain, profiles/r06/seal_sweep_1.txt / _2.txt: 256 threads +4 %, tickets +2.5 ... 7 %)
     std::atomic<uint64_t> combine_max_age_ns{1500000}; // ... but no proof waits longer than this for its chain to be issued
     // throughput regime (the chains in flight average >= combine_wide_proofs): fewer, wider chains -- at most combine_inflight_wide run,
     // the time deadline is combine_hold_us instead of combine_wait_us, and a burst smaller than half of what runs waits for company

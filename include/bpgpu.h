@@ -499,7 +499,7 @@ int bpgpu_ipp_verification_scalars(bpgpu_ctx *ctx, size_t n, size_t nbatch, cons
  *   "combine_wait_us"      100    a staging buffer leaves at the latest this long after its first request arrived ...
  *   "combine_quiet_us"     20     ... or when nothing has joined it for this long
  *   "combine_max_age_us"   1500   ... and no request waits longer than this for its chain to be issued
- *   "combine_inflight"     6      deadlines seal buffers only while fewer chains than this run: beyond, load widens the chains
+ *   "combine_inflight"     4      deadlines seal buffers only while fewer chains than this run: beyond, load widens the chains
  *   "combine_busy_chains"  2      a chain issued beside this many others takes the throughput forms
  *   "combine_max_open"     4      transcript-position classes with a staging buffer of their own
  *   "combine_mapped_out"   1024   chains up to this wide write their results straight into pinned host memory

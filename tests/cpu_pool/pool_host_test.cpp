@@ -509,12 +509,12 @@ int main(int argc, char **argv) {
                 fprintf(stderr, "policy (cohorts): %s\n", what);
             }
         };
-        // ---- regimes (combine_quiet_us 20, combine_wait_us 100, combine_inflight 6, combine_wide_proofs 384, combine_inflight_wide 3, combine_hold_us 400, combine_max_age_us 1500)
+        // ---- regimes (combine_quiet_us 20, combine_wait_us 100, combine_inflight 4, combine_wide_proofs 384, combine_inflight_wide 3, combine_hold_us 400, combine_max_age_us 1500)
         regimes(0, 5, 10, 5, 0, 0, 12, "fresh arrivals keep a buffer open");
         regimes(1, 5, 30, 25, 0, 0, 12, "nothing joined for the quiet period: leave");
         regimes(1, 5, 120, 5, 0, 0, 12, "the first request has waited combine_wait_us: leave although requests still arrive");
-        regimes(0, 5, 120, 25, 6, 600, 5, "six narrow chains run: the buffer keeps filling");
-        regimes(1, 5, 120, 25, 5, 500, 6, "... five: it leaves");
+        regimes(0, 5, 120, 25, 4, 400, 5, "four narrow chains run: the buffer keeps filling");
+        regimes(1, 5, 120, 25, 3, 300, 6, "... three: it leaves");
         regimes(0, 100, 120, 25, 3, 1500, 8, "three WIDE chains run (500 each): at most three");
         regimes(0, 100, 120, 25, 2, 1000, 9, "two wide chains run: a quiet fragment smaller than half of what runs waits for company");
         regimes(1, 250, 120, 25, 2, 1000, 9, "... half as wide as what runs: leaves");
