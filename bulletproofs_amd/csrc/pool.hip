@@ -2475,7 +2475,8 @@ static int flush_dev(bpgpu_pool *p, pool_dev *d, bool one_chain) {
         segs.clear();
         labs.clear();
         carried.clear();
-        const size_t per = fp.per;   // proofs per chain
+        const size_t per = fp.per;   // proofs per chain.  (A small LEADING chain, whose table walk would start while the others are still in their early
+                                     // phases, was measured on the 20-step bursts: worse at every size tried, profiles/r06/burst_small_leading_chain_ab.txt.)
         uint32_t filled = 0;
         bool any_msm = false, any_ticket = false;
         while (i < items.size() && filled < per && items[i].same_shape(head)) {
