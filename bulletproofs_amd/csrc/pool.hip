@@ -1526,7 +1526,7 @@ static void svc_main(bpgpu_pool *p, pool_dev *d) {
                     to_complete.push_back(b);
                 } else {
                     (void)hipGetLastError();
-                    if (b->key.kind == CQ_RP && b->K <= 4 && d->ema_small_ns) {   // a narrow chain's caller is blocked on exactly this: know when it is due
+                    if (b->key.kind == CQ_RP && b->K <= 4 && d->ema_small_ns) {   // a narrow chain's caller is blocked on exactly this: know when it is due (one call -3 us: profiles/r06/due_poll_ab.txt)
                         const uint64_t due = b->ev.t_issue1 + d->ema_small_ns;
                         if (due < soonest_due) soonest_due = due;
                     }
